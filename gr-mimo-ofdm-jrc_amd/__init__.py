@@ -1,0 +1,443 @@
+"""gr-mimo-ofdm-jrc_amd — MI355X (gfx950) implementation of the gr-mimo-ofdm-jrc radar/equalizer hot path.
+
+The product is the C-ABI shared library built from csrc/*.hip (see include/jrc.h).  This module is the
+thin Python host side: a ctypes binding plus classes that mirror the reference's block interface
+(same names, constructor arguments and work() semantics as include/mimo_ofdm_jrc/*.h in the reference)
+so the parity tests read like tests of the reference blocks.
+
+There is NO CPU fallback: importing works anywhere (so the symbol checks can run), but creating a
+Context without a usable HIP device raises JrcError.  Nothing here imports oracle/.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libjrc_hip.so")
+INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
+
+JRC_OK = 0
+JRC_ERR_NO_DEVICE = -1
+JRC_ERR_HIP = -2
+JRC_ERR_INVALID_ARG = -3
+JRC_ERR_UNSUPPORTED = -4
+JRC_ERR_LENGTH_MISMATCH = -5
+JRC_ERR_SHORT_INPUT = -6
+
+_cfp = C.POINTER(C.c_float)
+_vp = C.c_void_p
+
+
+class JrcError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("jrc status %d: %s" % (status, msg))
+        self.status = status
+
+
+class RaResult(C.Structure):
+    """jrc_ra_result (include/jrc.h)"""
+    _fields_ = [("peak_range_idx", C.c_int32), ("peak_angle_idx", C.c_int32),
+                ("angle_null_idx", C.c_int32),
+                ("discard_range_idx", C.c_int32), ("discard_angle_idx", C.c_int32),
+                ("n_noise_samples", C.c_int32),
+                ("peak_power", C.c_float), ("noise_power", C.c_float), ("snr_est", C.c_float),
+                ("range_val", C.c_float), ("angle_val", C.c_float),
+                ("published", C.c_int32)]
+
+
+class ChainCfg(C.Structure):
+    """jrc_chain_cfg (include/jrc.h)"""
+    _fields_ = [("fft_len", C.c_int32), ("N_tx", C.c_int32), ("N_rx", C.c_int32), ("N_sym", C.c_int32),
+                ("N_pre", C.c_int32), ("interp_range", C.c_int32), ("interp_angle", C.c_int32),
+                ("enable_tx_interleave", C.c_int32), ("n_items", C.c_int32),
+                ("noise_discard_range_m", C.c_float), ("noise_discard_angle_deg", C.c_float),
+                ("snr_threshold", C.c_float), ("power_threshold", C.c_float)]
+
+
+_lib = None
+
+
+def load(build_if_missing=False):
+    """dlopen libjrc_hip.so.  Fails loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        if build_if_missing:
+            _build.build()
+        else:
+            raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(the HIP extension is mandatory, there is no CPU fallback)" % LIB_PATH)
+    # torch bundles its own libamdhip64 (SONAME libamdhip64.so.7, NEEDED as "libamdhip64.so"): it must be
+    # loaded first so that this library binds to the same HIP runtime instance instead of a second copy.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = C.CDLL(LIB_PATH)
+    L.jrc_abi_version.restype = C.c_int
+    L.jrc_device_count.restype = C.c_int
+    L.jrc_create.argtypes = [C.c_int, C.POINTER(_vp)]
+    L.jrc_destroy.argtypes = [_vp]
+    L.jrc_strerror.restype = C.c_char_p
+    L.jrc_strerror.argtypes = [C.c_int]
+    L.jrc_last_error.restype = C.c_char_p
+    L.jrc_last_error.argtypes = [_vp]
+    L.jrc_device_name.argtypes = [_vp, C.c_char_p, C.c_size_t]
+    L.jrc_sync.argtypes = [_vp]
+    L.jrc_stream.restype = _vp
+    L.jrc_stream.argtypes = [_vp]
+    L.jrc_dev_malloc.argtypes = [_vp, C.c_size_t, C.POINTER(_vp)]
+    L.jrc_dev_free.argtypes = [_vp, _vp]
+    L.jrc_dev_memset.argtypes = [_vp, _vp, C.c_int, C.c_size_t]
+    L.jrc_memcpy_h2d.argtypes = [_vp, _vp, _vp, C.c_size_t]
+    L.jrc_memcpy_d2h.argtypes = [_vp, _vp, _vp, C.c_size_t]
+    L.jrc_radar_create.argtypes = [_vp] + [C.c_int] * 10 + [C.POINTER(_vp)]
+    L.jrc_radar_destroy.argtypes = [_vp]
+    L.jrc_radar_set_background_record.argtypes = [_vp, C.c_int]
+    L.jrc_radar_ring_size.argtypes = [_vp]
+    L.jrc_radar_work.argtypes = [_vp, C.POINTER(_vp), C.POINTER(_vp), C.c_size_t, C.c_size_t, C.c_size_t, _vp]
+    L.jrc_fft_vcc.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, _vp, _vp]
+    L.jrc_fft_vcc_dev.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, _vp, _vp, _vp]
+    L.jrc_matrix_transpose.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]
+    L.jrc_matrix_transpose_dev.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, _vp, _vp, _vp]
+    L.jrc_ra_estimate.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int,
+                                  C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(RaResult)]
+    L.jrc_cp_remove.argtypes = [_vp, C.c_int, C.c_int, C.c_size_t, _vp, _vp]
+    L.jrc_cp_remove_fft.argtypes = [_vp, C.c_int, C.c_int, C.c_size_t, _vp, _vp]
+    L.jrc_cp_remove_fft_dev.argtypes = [_vp, C.c_int, C.c_int, C.c_size_t, _vp, _vp, _vp]
+    L.jrc_fft_peak_detect.argtypes = [_vp, C.c_int, C.c_float, C.c_float, C.c_int, C.c_size_t, _vp,
+                                      _cfp, _cfp, _cfp, C.POINTER(C.c_int)]
+    L.jrc_chain_create.argtypes = [_vp, C.POINTER(ChainCfg), _vp, _vp, C.c_int, C.POINTER(_vp)]
+    L.jrc_chain_destroy.argtypes = [_vp]
+    for fn in ("jrc_chain_frame_bytes", "jrc_chain_chanest_bytes", "jrc_chain_map_bytes"):
+        getattr(L, fn).restype = C.c_size_t
+        getattr(L, fn).argtypes = [_vp]
+    L.jrc_chain_run_dev.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp]
+    L.jrc_chain_fetch_results.argtypes = [_vp, C.c_int, _vp, C.POINTER(RaResult), _vp]
+    L.jrc_chain_set_timing.argtypes = [_vp, C.c_int]
+    L.jrc_chain_get_timing.argtypes = [_vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    _lib = L
+    return L
+
+
+def _c64(a):
+    return np.ascontiguousarray(a, dtype=np.complex64)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_vp)
+
+
+class Context:
+    """jrc_ctx: one per host thread, bound to one GPU."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = _vp()
+        st = self.lib.jrc_create(device, C.byref(h))
+        if st != JRC_OK:
+            raise JrcError(st, self.lib.jrc_strerror(st).decode())
+        self.h = h
+        self.device = device
+
+    def check(self, st):
+        if st < 0:
+            msg = self.lib.jrc_last_error(self.h).decode() or self.lib.jrc_strerror(st).decode()
+            if st == JRC_ERR_LENGTH_MISMATCH:
+                raise RuntimeError(msg)       # std::runtime_error in the reference
+            if st == JRC_ERR_INVALID_ARG:
+                raise ValueError(msg)         # std::invalid_argument in the reference
+            raise JrcError(st, msg)
+        return st
+
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        self.check(self.lib.jrc_device_name(self.h, buf, 256))
+        return buf.value.decode()
+
+    def sync(self):
+        self.check(self.lib.jrc_sync(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.jrc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(int(os.environ.get("LOCAL_RANK", "0")) if _device_count() > 1 else 0)
+    return _default_ctx
+
+
+def _device_count():
+    return load().jrc_device_count()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Block mirrors.  Names / constructor arguments follow the reference's public headers
+# (include/mimo_ofdm_jrc/*.h); work() takes and returns numpy arrays instead of GNU Radio buffers.
+# ---------------------------------------------------------------------------------------------------------
+class mimo_ofdm_radar:
+    """include/mimo_ofdm_jrc/mimo_ofdm_radar.h:35-64; work = lib/mimo_ofdm_radar_impl.cc:131-340"""
+
+    def __init__(self, fft_len, N_tx, N_rx, N_sym, N_pre, background_removal=False, background_recording=False,
+                 record_len=8, interp_factor=1, enable_tx_interleave=False, radar_chan_file="",
+                 len_tag_key="packet_len", debug=False, ctx=None):
+        self.ctx = ctx or default_context()
+        self.fft_len, self.N_tx, self.N_rx, self.N_sym, self.N_pre = fft_len, N_tx, N_rx, N_sym, N_pre
+        self.interp_factor = interp_factor
+        h = _vp()
+        self.ctx.check(self.ctx.lib.jrc_radar_create(self.ctx.h, fft_len, N_tx, N_rx, N_sym, N_pre,
+                                                     int(background_removal), int(background_recording), record_len,
+                                                     interp_factor, int(enable_tx_interleave), C.byref(h)))
+        self.h = h
+
+    def set_background_record(self, background_record):
+        self.ctx.check(self.ctx.lib.jrc_radar_set_background_record(self.h, int(background_record)))
+
+    def ring_size(self):
+        return self.ctx.lib.jrc_radar_ring_size(self.h)
+
+    def general_work(self, tx, rx, tx_discard=0):
+        """tx: N_tx arrays [n_items, fft_len]; rx: N_rx arrays -> [P, fft_len*interp_factor] complex64.
+        The block emits P items and a packet_len=P tag (lib/mimo_ofdm_radar_impl.cc:303-309)."""
+        ktx = [_c64(a) for a in tx]
+        krx = [_c64(a) for a in rx]
+        assert len(ktx) == self.N_tx and len(krx) == self.N_rx
+        ptx = (_vp * len(ktx))(*[_ptr(a) for a in ktx])
+        prx = (_vp * len(krx))(*[_ptr(a) for a in krx])
+        n_tx = min(a.size // self.fft_len for a in ktx)
+        n_rx = min(a.size // self.fft_len for a in krx)
+        P = self.N_tx * self.N_rx
+        out = np.empty((P, self.fft_len * self.interp_factor), np.complex64)
+        n = self.ctx.check(self.ctx.lib.jrc_radar_work(self.h, ptx, prx, n_tx, n_rx, tx_discard, _ptr(out)))
+        assert n == P
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.jrc_radar_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class fft_vcc:
+    """stock gr::fft::fft_vcc(fft_size, forward, window, shift) as used by the flowgraphs"""
+
+    def __init__(self, fft_size, forward, window=None, shift=False, ctx=None):
+        self.ctx = ctx or default_context()
+        self.fft_size, self.forward, self.shift = fft_size, bool(forward), bool(shift)
+        self.window = None if window is None or len(window) == 0 else np.ascontiguousarray(window, np.float32)
+        if self.window is not None and len(self.window) != fft_size:
+            raise ValueError("window size must equal fft_size")
+
+    def work(self, x):
+        x = _c64(x)
+        batch = x.size // self.fft_size
+        out = np.empty_like(x)
+        self.ctx.check(self.ctx.lib.jrc_fft_vcc(self.ctx.h, self.fft_size, int(self.forward), int(self.shift),
+                                                None if self.window is None else _ptr(self.window), batch,
+                                                _ptr(x), _ptr(out)))
+        return out
+
+
+class matrix_transpose:
+    """include/mimo_ofdm_jrc/matrix_transpose.h; work = lib/matrix_transpose_impl.cc:69-110"""
+
+    def __init__(self, input_len, output_len, interp_factor, debug=False, len_key="packet_len", ctx=None):
+        self.ctx = ctx or default_context()
+        self.input_len, self.output_len, self.interp_factor = input_len, output_len, interp_factor
+
+    def calculate_output_stream_length(self, ninput_items):
+        return self.input_len
+
+    def work(self, x):
+        x = _c64(x).reshape(-1, self.input_len)
+        out = np.empty((self.input_len, self.output_len * self.interp_factor), np.complex64)
+        self.ctx.check(self.ctx.lib.jrc_matrix_transpose(self.ctx.h, self.input_len, self.output_len,
+                                                         self.interp_factor, x.shape[0], _ptr(x), _ptr(out)))
+        return out
+
+
+class range_angle_estimator:
+    """include/mimo_ofdm_jrc/range_angle_estimator.h; work = lib/range_angle_estimator_impl.cc:121-284.
+    work() returns the jrc_ra_result; `published` says whether the reference would have emitted the
+    {range, angle, power, snr} message on port "params"."""
+
+    def __init__(self, vlen, range_bins, angle_bins, noise_discard_range_m, noise_discard_angle_deg,
+                 snr_threshold, power_threshold, stats_path="", stats_record=False, len_key="packet_len",
+                 debug=False, ctx=None):
+        self.ctx = ctx or default_context()
+        self.vlen = vlen
+        self.range_bins = np.ascontiguousarray(range_bins, np.float32)
+        self.angle_bins = np.ascontiguousarray(angle_bins, np.float32)
+        self.ndr, self.nda = float(noise_discard_range_m), float(noise_discard_angle_deg)
+        self.snr_threshold, self.power_threshold = float(snr_threshold), float(power_threshold)
+
+    def set_snr_threshold(self, v):
+        self.snr_threshold = float(v)
+
+    def set_power_threshold(self, v):
+        self.power_threshold = float(v)
+
+    def work(self, m):
+        m = _c64(m).reshape(-1, self.vlen)
+        res = RaResult()
+        self.ctx.check(self.ctx.lib.jrc_ra_estimate(self.ctx.h, self.vlen, m.shape[0], _ptr(m),
+                                                    _ptr(self.range_bins), len(self.range_bins),
+                                                    _ptr(self.angle_bins), len(self.angle_bins),
+                                                    self.ndr, self.nda, self.snr_threshold, self.power_threshold,
+                                                    C.byref(res)))
+        return res
+
+
+class ofdm_cyclic_prefix_remover:
+    """include/mimo_ofdm_jrc/ofdm_cyclic_prefix_remover.h; work = lib/ofdm_cyclic_prefix_remover_impl.cc:69-99"""
+
+    def __init__(self, fft_len, cp_len, len_key="packet_len", ctx=None):
+        self.ctx = ctx or default_context()
+        self.fft_len, self.cp_len = fft_len, cp_len
+
+    def calculate_output_stream_length(self, ninput_items):
+        return ninput_items // (self.fft_len + self.cp_len)
+
+    def work(self, x, fused_fft=False):
+        x = _c64(x).ravel()
+        nout = x.size // (self.fft_len + self.cp_len)
+        out = np.empty((nout, self.fft_len), np.complex64)
+        fn = self.ctx.lib.jrc_cp_remove_fft if fused_fft else self.ctx.lib.jrc_cp_remove
+        n = self.ctx.check(fn(self.ctx.h, self.fft_len, self.cp_len, x.size, _ptr(x), _ptr(out)))
+        assert n == nout
+        return out
+
+
+class fft_peak_detect:
+    """include/mimo_ofdm_jrc/fft_peak_detect.h; work = lib/fft_peak_detect_impl.cc:77-111"""
+
+    def __init__(self, samp_rate, interp_factor, threshold, samp_protect, max_freq=(), cut_max_freq=False,
+                 len_key="packet_len", ctx=None):
+        self.ctx = ctx or default_context()
+        self.samp_rate, self.interp_factor = int(samp_rate), float(interp_factor)
+        self.threshold, self.samp_protect = float(threshold), int(samp_protect)
+
+    def set_threshold(self, t):
+        self.threshold = float(t)
+
+    def set_samp_protect(self, s):
+        self.samp_protect = int(s)
+
+    def work(self, x):
+        """returns (k, freq, phase, mag); k == -1 -> the reference leaves its outputs unset (NaN here)"""
+        x = _c64(x).ravel()
+        f = np.full(1, np.nan, np.float32)
+        p = np.full(1, np.nan, np.float32)
+        m = np.full(1, np.nan, np.float32)
+        k = C.c_int(-2)
+        n = self.ctx.check(self.ctx.lib.jrc_fft_peak_detect(
+            self.ctx.h, self.samp_rate, self.interp_factor, self.threshold, self.samp_protect, x.size, _ptr(x),
+            f.ctypes.data_as(_cfp), p.ctypes.data_as(_cfp), m.ctypes.data_as(_cfp), C.byref(k)))
+        assert n == 1
+        return k.value, float(f[0]), float(p[0]), float(m[0])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Fused, device-resident radar chain (torch tensors are only device memory + stream plumbing)
+# ---------------------------------------------------------------------------------------------------------
+def radar_axes(fft_len, samp_rate, interp_range, n_pairs, interp_angle):
+    """range / angle bin axes exactly as the radar flowgraph hands them to the estimator
+    (examples/simulation/radar/mimo_ofdm_jrc_radar_sim.grc:1390-1400), cast to float32."""
+    nr, na = fft_len * interp_range, n_pairs * interp_angle
+    range_bins = np.linspace(0, 3e8 * fft_len / (2 * samp_rate), nr)
+    angle_bins = np.arcsin(2 / na * (np.arange(0, na) - np.floor(na / 2) + 0.5)) * 180 / np.pi
+    return range_bins.astype(np.float32), angle_bins.astype(np.float32)
+
+
+class RadarChain:
+    """jrc_chain: A1 -> A2 -> A3 -> A4 -> A5 for a batch of frames resident in HBM."""
+
+    def __init__(self, fft_len, N_tx, N_rx, N_sym, N_pre, interp_range, interp_angle, range_bins, angle_bins,
+                 noise_discard_range_m, noise_discard_angle_deg, snr_threshold=0.0, power_threshold=0.0,
+                 n_items=None, enable_tx_interleave=False, max_frames=64, ctx=None):
+        self.ctx = ctx or default_context()
+        self.cfg = ChainCfg(fft_len, N_tx, N_rx, N_sym, N_pre, interp_range, interp_angle, int(enable_tx_interleave),
+                            n_items if n_items is not None else N_pre + N_sym,
+                            noise_discard_range_m, noise_discard_angle_deg, snr_threshold, power_threshold)
+        self.P, self.NR, self.NA = N_tx * N_rx, fft_len * interp_range, N_tx * N_rx * interp_angle
+        self.max_frames = max_frames
+        rb = np.ascontiguousarray(range_bins, np.float32)
+        ab = np.ascontiguousarray(angle_bins, np.float32)
+        assert len(rb) == self.NR and len(ab) == self.NA
+        h = _vp()
+        self.ctx.check(self.ctx.lib.jrc_chain_create(self.ctx.h, C.byref(self.cfg), _ptr(rb), _ptr(ab), max_frames,
+                                                     C.byref(h)))
+        self.h = h
+        L = self.ctx.lib
+        self.frame_bytes = L.jrc_chain_frame_bytes(h)
+        self.chanest_bytes = L.jrc_chain_chanest_bytes(h)
+        self.map_bytes = L.jrc_chain_map_bytes(h)
+
+    def frame_shape(self):
+        c = self.cfg
+        return (c.N_tx + c.N_rx, c.n_items, c.fft_len)
+
+    def alloc(self, n_frames, device):
+        """device buffers as torch tensors (complex64 viewed as float32 pairs)"""
+        import torch
+        c = self.cfg
+        return dict(
+            frames=torch.empty((n_frames, c.N_tx + c.N_rx, c.n_items, c.fft_len, 2), dtype=torch.float32, device=device),
+            chanest=torch.empty((n_frames, self.P, c.fft_len, 2), dtype=torch.float32, device=device),
+            map=torch.empty((n_frames, self.NR, self.NA, 2), dtype=torch.float32, device=device),
+            results=torch.empty((n_frames, C.sizeof(RaResult)), dtype=torch.uint8, device=device),
+        )
+
+    def run(self, bufs, n_frames, stream=None):
+        """asynchronous on `stream` (an int hipStream_t handle, e.g. torch.cuda.current_stream().cuda_stream)"""
+        self.ctx.check(self.ctx.lib.jrc_chain_run_dev(self.h, n_frames, bufs["frames"].data_ptr(),
+                                                      bufs["chanest"].data_ptr(), bufs["map"].data_ptr(),
+                                                      bufs["results"].data_ptr(), stream))
+
+    def results(self, bufs, n_frames, stream=None):
+        arr = (RaResult * n_frames)()
+        self.ctx.check(self.ctx.lib.jrc_chain_fetch_results(self.h, n_frames, bufs["results"].data_ptr(), arr, stream))
+        return list(arr)
+
+    def set_timing(self, on):
+        self.ctx.check(self.ctx.lib.jrc_chain_set_timing(self.h, int(on)))
+
+    def get_timing(self):
+        ms = (C.c_float * 3)()
+        n = C.c_int(0)
+        self.ctx.check(self.ctx.lib.jrc_chain_get_timing(self.h, ms, C.byref(n)))
+        return dict(radar_chanest=ms[0], range_angle_fused=ms[1], ra_finalize=ms[2], launches=n.value)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.jrc_chain_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,74 @@
+"""Builds libjrc_hip.so (hand-written HIP kernels + the C ABI of include/jrc.h) for gfx950 with hipcc.
+
+In-tree build: the .so lands in gr-mimo-ofdm-jrc_amd/lib/ (git-ignored, but it travels to the GPU box).
+hipcc cross-compiles without a GPU, so this runs in the CPU-only container as the "does it build" check.
+"""
+import concurrent.futures
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(HERE, "build")
+LIB = os.path.join(LIBDIR, "libjrc_hip.so")
+ARCH = "gfx950"
+
+SOURCES = ["ctx.hip", "radar.hip", "fft.hip", "estimator.hip", "chain.hip", "comm.hip"]
+HEADERS = ["jrc_internal.h", "radar_kernels.h", os.path.join("..", "..", "include", "jrc.h")]
+
+HIPCC_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+               "-fno-gpu-rdc"]
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the HIP extension is mandatory (no CPU fallback exists)")
+    return exe
+
+
+def _mtime(p):
+    return os.path.getmtime(p) if os.path.exists(p) else 0.0
+
+
+def _compile(src):
+    obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
+    srcp = os.path.join(CSRC, src)
+    deps = [srcp] + [os.path.join(CSRC, h) for h in HEADERS]
+    if _mtime(obj) >= max(_mtime(d) for d in deps):
+        return obj, False
+    cmd = [hipcc()] + HIPCC_FLAGS + ["-c", srcp, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    return obj, True
+
+
+def build(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJDIR):
+            os.remove(os.path.join(OBJDIR, f))
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    with concurrent.futures.ThreadPoolExecutor(max_workers=4) as ex:
+        results = list(ex.map(_compile, srcs))
+    objs = [o for o, _ in results]
+    rebuilt = any(ch for _, ch in results)
+    if rebuilt or not os.path.exists(LIB) or _mtime(LIB) < max(_mtime(o) for o in objs):
+        cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+        if verbose:
+            print("built", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)

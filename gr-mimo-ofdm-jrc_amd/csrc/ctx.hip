@@ -1,0 +1,179 @@
+// ctx.hip — context, error reporting, staging memory and twiddle tables for include/jrc.h
+#include "jrc_internal.h"
+
+#include <cmath>
+
+int jrc_fail(jrc_ctx* ctx, int status, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->last_error = buf;
+    return status;
+}
+
+extern "C" int jrc_abi_version(void) { return JRC_ABI_VERSION; }
+
+extern "C" int jrc_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" const char* jrc_strerror(int status)
+{
+    switch (status) {
+        case JRC_OK: return "ok";
+        case JRC_ERR_NO_DEVICE: return "no usable HIP device (the HIP path is mandatory; there is no CPU fallback)";
+        case JRC_ERR_HIP: return "HIP runtime error";
+        case JRC_ERR_INVALID_ARG: return "invalid argument";
+        case JRC_ERR_UNSUPPORTED: return "size or shape not supported by the HIP kernels";
+        case JRC_ERR_LENGTH_MISMATCH: return "[MATRIX TRANSPOSE] input_len and output_len do not match to packet length";
+        case JRC_ERR_SHORT_INPUT: return "not enough input items for one frame";
+        case JRC_ERR_NOMEM: return "out of memory";
+        case JRC_ERR_SIG_FIELD: return "[MIMO PRECODER] something is wrong!! (OFDM symbol count mismatch)";
+        case JRC_ERR_IO: return "could not open file";
+        default: return "unknown jrc status";
+    }
+}
+
+extern "C" int jrc_create(int device, jrc_ctx** out)
+{
+    if (!out) return JRC_ERR_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return JRC_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return JRC_ERR_INVALID_ARG;
+    if (hipSetDevice(device) != hipSuccess) return JRC_ERR_NO_DEVICE;
+    jrc_ctx* ctx = new jrc_ctx();
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return JRC_ERR_NO_DEVICE;
+    }
+    *out = ctx;
+    return JRC_OK;
+}
+
+extern "C" void jrc_destroy(jrc_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->twiddles) (void)hipFree(kv.second);
+    for (int i = 0; i < 4; i++)
+        if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" const char* jrc_last_error(const jrc_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+extern "C" int jrc_device_name(const jrc_ctx* ctx, char* buf, size_t len)
+{
+    if (!ctx || !buf || len == 0) return JRC_ERR_INVALID_ARG;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return JRC_ERR_HIP;
+    snprintf(buf, len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return JRC_OK;
+}
+
+extern "C" int jrc_sync(jrc_ctx* ctx)
+{
+    if (!ctx) return JRC_ERR_INVALID_ARG;
+    JRC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JRC_OK;
+}
+
+extern "C" void* jrc_stream(jrc_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+extern "C" int jrc_dev_malloc(jrc_ctx* ctx, size_t bytes, void** dptr)
+{
+    if (!ctx || !dptr) return JRC_ERR_INVALID_ARG;
+    JRC_HIP(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
+    if (e == hipErrorOutOfMemory) return jrc_fail(ctx, JRC_ERR_NOMEM, "hipMalloc(%zu) out of memory", bytes);
+    JRC_HIP(ctx, e);
+    return JRC_OK;
+}
+
+extern "C" int jrc_dev_free(jrc_ctx* ctx, void* dptr)
+{
+    if (!ctx) return JRC_ERR_INVALID_ARG;
+    if (dptr) JRC_HIP(ctx, hipFree(dptr));
+    return JRC_OK;
+}
+
+extern "C" int jrc_dev_memset(jrc_ctx* ctx, void* dptr, int value, size_t bytes)
+{
+    if (!ctx) return JRC_ERR_INVALID_ARG;
+    JRC_HIP(ctx, hipMemsetAsync(dptr, value, bytes, ctx->stream));
+    JRC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JRC_OK;
+}
+
+extern "C" int jrc_memcpy_h2d(jrc_ctx* ctx, void* dptr, const void* hptr, size_t bytes)
+{
+    if (!ctx) return JRC_ERR_INVALID_ARG;
+    JRC_HIP(ctx, hipMemcpyAsync(dptr, hptr, bytes, hipMemcpyHostToDevice, ctx->stream));
+    JRC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JRC_OK;
+}
+
+extern "C" int jrc_memcpy_d2h(jrc_ctx* ctx, void* hptr, const void* dptr, size_t bytes)
+{
+    if (!ctx) return JRC_ERR_INVALID_ARG;
+    JRC_HIP(ctx, hipMemcpyAsync(hptr, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    JRC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JRC_OK;
+}
+
+int jrc_ensure_pinned(jrc_ctx* ctx, size_t bytes)
+{
+    if (ctx->pinned_bytes >= bytes) return JRC_OK;
+    if (ctx->pinned) { (void)hipHostFree(ctx->pinned); ctx->pinned = nullptr; ctx->pinned_bytes = 0; }
+    size_t want = bytes + bytes / 4 + 4096;
+    JRC_HIP(ctx, hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault));
+    ctx->pinned_bytes = want;
+    return JRC_OK;
+}
+
+int jrc_ensure_scratch(jrc_ctx* ctx, int slot, size_t bytes)
+{
+    if (ctx->scratch_bytes[slot] >= bytes) return JRC_OK;
+    if (ctx->scratch[slot]) {
+        JRC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->scratch[slot]);
+        ctx->scratch[slot] = nullptr;
+        ctx->scratch_bytes[slot] = 0;
+    }
+    size_t want = bytes + bytes / 4 + 4096;
+    hipError_t e = hipMalloc(&ctx->scratch[slot], want);
+    if (e == hipErrorOutOfMemory) return jrc_fail(ctx, JRC_ERR_NOMEM, "hipMalloc(%zu) out of memory", want);
+    JRC_HIP(ctx, e);
+    ctx->scratch_bytes[slot] = want;
+    return JRC_OK;
+}
+
+int jrc_get_twiddles(jrc_ctx* ctx, int n, int sign, const float2** out)
+{
+    long key = (long)sign * n;
+    auto it = ctx->twiddles.find(key);
+    if (it != ctx->twiddles.end()) { *out = it->second; return JRC_OK; }
+    std::vector<float2> h((size_t)n);
+    for (int k = 0; k < n; k++) {
+        // exact octant symmetry is not needed; double cos/sin rounded once to float
+        double ang = (double)sign * 2.0 * M_PI * (double)k / (double)n;
+        h[k] = make_float2((float)cos(ang), (float)sin(ang));
+    }
+    float2* d = nullptr;
+    JRC_HIP(ctx, hipMalloc((void**)&d, sizeof(float2) * (size_t)n));
+    JRC_HIP(ctx, hipMemcpy(d, h.data(), sizeof(float2) * (size_t)n, hipMemcpyHostToDevice));
+    ctx->twiddles[key] = d;
+    *out = d;
+    return JRC_OK;
+}

@@ -1,0 +1,279 @@
+// fft.hip — stock-block stages between the reference's hot-path blocks, plus the two copy blocks
+//
+//   A2/A4/A7  gr::fft::fft_vcc (FFTW3f inside GNU Radio 3.8; wired in
+//             examples/simulation/radar/mimo_ofdm_jrc_radar_sim.grc:877-1047)
+//   A3        matrix_transpose_impl::work          (reference lib/matrix_transpose_impl.cc:69-110)
+//   A6        ofdm_cyclic_prefix_remover_impl::work (reference lib/ofdm_cyclic_prefix_remover_impl.cc:69-99)
+//
+// The FFT here is the literal per-block drop-in (any power of two up to 16384, LDS resident, one
+// transform per workgroup or several small ones packed into one).  The roofline-critical 2-D
+// range-angle transform does NOT go through this kernel; it is the fused kernel in chain.hip.
+#include "radar_kernels.h"
+
+// ------------------------------------------------------------------------------------------------
+// in-place radix-2 decimation-in-frequency in LDS; input natural order, result bit-reversed in LDS,
+// un-permuted (and fftshift-ed) on the way out.  tw[k] = exp(sign*j*2*pi*k/n), k < n.
+__global__ __launch_bounds__(256) void fft_pow2_kernel(const float2* __restrict__ in, float2* __restrict__ out,
+                                                       const float2* __restrict__ tw,
+                                                       const float* __restrict__ window, int n, int logn,
+                                                       int forward, int shift, size_t batch, long in_stride,
+                                                       int in_offset, int tp /* threads per transform */)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    const int per_block = blockDim.x / tp;
+    const int lt = threadIdx.x % tp;
+    const int lb = threadIdx.x / tp;
+    const size_t b = (size_t)blockIdx.x * per_block + lb;
+    const bool live = b < batch;
+    float2* x = lds + (size_t)lb * n;
+    const int half_n = n >> 1;
+
+    if (live) {
+        const float2* src = in + b * (size_t)in_stride + in_offset;
+        for (int i = lt; i < n; i += tp) {
+            int si = (!forward && shift) ? ((i + half_n) & (n - 1)) : i;   // ifftshift on the way in
+            float2 v = src[si];
+            if (window) { float w = window[si]; v.x *= w; v.y *= w; }
+            x[i] = v;
+        }
+    }
+    for (int half = half_n; half >= 1; half >>= 1) {
+        __syncthreads();
+        if (live) {
+            const int tstep = half_n / half;
+            for (int j = lt; j < half_n; j += tp) {
+                const int k = j & (half - 1);
+                const int i0 = ((j - k) << 1) + k;
+                const int i1 = i0 + half;
+                float2 a = x[i0], c = x[i1];
+                x[i0] = cadd(a, c);
+                float2 d = csub(a, c);
+                x[i1] = (k == 0) ? d : cmul(d, tw[k * tstep]);
+            }
+        }
+    }
+    __syncthreads();
+    if (live) {
+        float2* dst = out + b * (size_t)n;
+        for (int pos = lt; pos < n; pos += tp) {
+            int k = (forward && shift) ? ((pos + half_n) & (n - 1)) : pos;   // fftshift on the way out
+            unsigned r = __brev((unsigned)k) >> (32 - logn);
+            dst[pos] = x[logn ? r : 0];
+        }
+    }
+}
+
+int launch_fft_vcc(jrc_ctx* ctx, int n, int forward, int shift, const float* d_window, size_t batch,
+                   const float2* d_in, float2* d_out, long in_stride, int in_offset, hipStream_t stream)
+{
+    if (!jrc_is_pow2(n) || n < 2 || n > 16384)
+        return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "fft_vcc: fft_size %d is not a power of two in [2, 16384]", n);
+    if (batch == 0) return JRC_OK;
+    const float2* tw = nullptr;
+    JRC_TRY(jrc_get_twiddles(ctx, n, forward ? -1 : +1, &tw));
+    const int logn = jrc_ilog2(n);
+    int tp = n / 2; if (tp > 256) tp = 256; if (tp < 1) tp = 1;
+    const int per_block = 256 / tp;
+    const size_t blocks = (batch + per_block - 1) / per_block;
+    const size_t lds_bytes = sizeof(float2) * (size_t)n * per_block;
+    static bool attr_set = false;
+    if (!attr_set) {
+        JRC_HIP(ctx, hipFuncSetAttribute((const void*)fft_pow2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(fft_pow2_kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, stream, d_in, d_out, tw,
+                       d_window, n, logn, forward, shift, batch, in_stride, in_offset, tp);
+    JRC_HIP(ctx, hipGetLastError());
+    return JRC_OK;
+}
+
+extern "C" int jrc_fft_vcc_dev(jrc_ctx* ctx, int fft_size, int forward, int shift, const float* d_window,
+                               size_t batch, const jrc_cf32* d_in, jrc_cf32* d_out, void* stream)
+{
+    if (!ctx || !d_in || !d_out) return JRC_ERR_INVALID_ARG;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    return launch_fft_vcc(ctx, fft_size, forward, shift, d_window, batch, (const float2*)d_in, (float2*)d_out,
+                          fft_size, 0, s);
+}
+
+extern "C" int jrc_fft_vcc(jrc_ctx* ctx, int fft_size, int forward, int shift, const float* window, size_t batch,
+                           const jrc_cf32* in, jrc_cf32* out)
+{
+    if (!ctx || !in || !out) return JRC_ERR_INVALID_ARG;
+    if (!jrc_is_pow2(fft_size) || fft_size < 2 || fft_size > 16384)
+        return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "fft_vcc: fft_size %d is not a power of two in [2, 16384]", fft_size);
+    JRC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = sizeof(float2) * (size_t)fft_size * batch;
+    const size_t wbytes = window ? sizeof(float) * (size_t)fft_size : 0;
+    JRC_TRY(jrc_ensure_pinned(ctx, bytes + wbytes));
+    JRC_TRY(jrc_ensure_scratch(ctx, 0, bytes));
+    JRC_TRY(jrc_ensure_scratch(ctx, 1, bytes));
+    JRC_TRY(jrc_ensure_scratch(ctx, 2, wbytes ? wbytes : 4));
+    memcpy(ctx->pinned, in, bytes);
+    if (window) memcpy((char*)ctx->pinned + bytes, window, wbytes);
+    if (bytes) JRC_HIP(ctx, hipMemcpyAsync(ctx->scratch[0], ctx->pinned, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (window) JRC_HIP(ctx, hipMemcpyAsync(ctx->scratch[2], (char*)ctx->pinned + bytes, wbytes, hipMemcpyHostToDevice, ctx->stream));
+    JRC_TRY(launch_fft_vcc(ctx, fft_size, forward, shift, window ? (const float*)ctx->scratch[2] : nullptr, batch,
+                           (const float2*)ctx->scratch[0], (float2*)ctx->scratch[1], fft_size, 0, ctx->stream));
+    if (bytes) JRC_HIP(ctx, hipMemcpyAsync(ctx->pinned, ctx->scratch[1], bytes, hipMemcpyDeviceToHost, ctx->stream));
+    JRC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(out, ctx->pinned, bytes);
+    return JRC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// A3 matrix_transpose: out[l][k] = in[k][l] (k < ninput_items), zero for ninput_items <= k < W
+// 64x64 tiles through LDS so both the reads (along l) and the writes (along k) are coalesced.
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const float2* __restrict__ in, float2* __restrict__ out,
+                                                            int input_len, int ninput, int W)
+{
+    __shared__ float2 tile[64][65];
+    const size_t b = blockIdx.z;
+    const float2* src = in + b * (size_t)ninput * input_len;
+    float2* dst = out + b * (size_t)input_len * W;
+    const int l0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
+    const bool any = k0 < ninput;
+    if (any) {
+        for (int kk = ty; kk < 64; kk += 4) {
+            int k = k0 + kk, l = l0 + tx;
+            if (k < ninput && l < input_len) tile[kk][tx] = src[(size_t)k * input_len + l];
+        }
+    }
+    __syncthreads();
+    for (int ll = ty; ll < 64; ll += 4) {
+        int l = l0 + ll, k = k0 + tx;
+        if (l < input_len && k < W) {
+            float2 v = make_float2(0.f, 0.f);
+            if (any && k < ninput) v = tile[tx][ll];
+            dst[(size_t)l * W + k] = v;
+        }
+    }
+}
+
+static int transpose_check(jrc_ctx* ctx, int input_len, int output_len, int interp_factor, int ninput_items)
+{
+    if (input_len <= 0 || output_len <= 0 || interp_factor <= 0 || ninput_items < 0)
+        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "matrix_transpose: non-positive size");
+    // lib/matrix_transpose_impl.cc:82  (float division vs integer division)
+    if (ninput_items * float(input_len) / float(output_len) - ninput_items * input_len / output_len != 0)
+        return jrc_fail(ctx, JRC_ERR_LENGTH_MISMATCH, "%s", jrc_strerror(JRC_ERR_LENGTH_MISMATCH));
+    if (ninput_items > output_len * interp_factor)
+        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "matrix_transpose: %d input items do not fit an output row of %d",
+                        ninput_items, output_len * interp_factor);
+    return JRC_OK;
+}
+
+extern "C" int jrc_matrix_transpose_dev(jrc_ctx* ctx, int input_len, int output_len, int interp_factor,
+                                        int ninput_items, size_t batch, const jrc_cf32* d_in, jrc_cf32* d_out,
+                                        void* stream)
+{
+    if (!ctx || !d_in || !d_out) return JRC_ERR_INVALID_ARG;
+    JRC_TRY(transpose_check(ctx, input_len, output_len, interp_factor, ninput_items));
+    if (batch == 0) return input_len;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    const int W = output_len * interp_factor;
+    dim3 grid((input_len + 63) / 64, (W + 63) / 64, (unsigned)batch);
+    hipLaunchKernelGGL(transpose_pad_kernel, grid, dim3(256), 0, s, (const float2*)d_in, (float2*)d_out, input_len,
+                       ninput_items, W);
+    JRC_HIP(ctx, hipGetLastError());
+    return input_len;
+}
+
+extern "C" int jrc_matrix_transpose(jrc_ctx* ctx, int input_len, int output_len, int interp_factor,
+                                    int ninput_items, const jrc_cf32* in, jrc_cf32* out)
+{
+    if (!ctx || !in || !out) return JRC_ERR_INVALID_ARG;
+    JRC_TRY(transpose_check(ctx, input_len, output_len, interp_factor, ninput_items));
+    JRC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t in_bytes = sizeof(float2) * (size_t)ninput_items * input_len;
+    const size_t out_bytes = sizeof(float2) * (size_t)input_len * output_len * interp_factor;
+    JRC_TRY(jrc_ensure_pinned(ctx, in_bytes > out_bytes ? in_bytes : out_bytes));
+    JRC_TRY(jrc_ensure_scratch(ctx, 0, in_bytes ? in_bytes : 8));
+    JRC_TRY(jrc_ensure_scratch(ctx, 1, out_bytes));
+    memcpy(ctx->pinned, in, in_bytes);
+    if (in_bytes) JRC_HIP(ctx, hipMemcpyAsync(ctx->scratch[0], ctx->pinned, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    int r = jrc_matrix_transpose_dev(ctx, input_len, output_len, interp_factor, ninput_items, 1,
+                                     (const jrc_cf32*)ctx->scratch[0], (jrc_cf32*)ctx->scratch[1], nullptr);
+    if (r < 0) return r;
+    JRC_HIP(ctx, hipMemcpyAsync(ctx->pinned, ctx->scratch[1], out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    JRC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(out, ctx->pinned, out_bytes);
+    return input_len;
+}
+
+// ------------------------------------------------------------------------------------------------
+// A6 cyclic prefix removal: out[k][0..N) = in[k*(N+cp)+cp ...]
+__global__ void cp_remove_kernel(const float2* __restrict__ in, float2* __restrict__ out, int n, int cp,
+                                 size_t total /* nsym*n */)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        size_t k = i / n;
+        int j = (int)(i - k * n);
+        out[i] = in[k * (size_t)(n + cp) + cp + j];
+    }
+}
+
+extern "C" int jrc_cp_remove(jrc_ctx* ctx, int fft_len, int cp_len, size_t ninput_items, const jrc_cf32* in,
+                             jrc_cf32* out)
+{
+    if (!ctx || !in || !out) return JRC_ERR_INVALID_ARG;
+    if (fft_len <= 0 || cp_len < 0) return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "cp_remover: bad fft_len/cp_len");
+    const size_t nsym = ninput_items / (size_t)(fft_len + cp_len);   // :86
+    if (nsym == 0) return 0;
+    JRC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t in_bytes = sizeof(float2) * nsym * (size_t)(fft_len + cp_len);
+    const size_t out_bytes = sizeof(float2) * nsym * (size_t)fft_len;
+    JRC_TRY(jrc_ensure_pinned(ctx, in_bytes));
+    JRC_TRY(jrc_ensure_scratch(ctx, 0, in_bytes));
+    JRC_TRY(jrc_ensure_scratch(ctx, 1, out_bytes));
+    memcpy(ctx->pinned, in, in_bytes);
+    JRC_HIP(ctx, hipMemcpyAsync(ctx->scratch[0], ctx->pinned, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    const size_t total = nsym * (size_t)fft_len;
+    unsigned blocks = (unsigned)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(cp_remove_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const float2*)ctx->scratch[0],
+                       (float2*)ctx->scratch[1], fft_len, cp_len, total);
+    JRC_HIP(ctx, hipGetLastError());
+    JRC_HIP(ctx, hipMemcpyAsync(ctx->pinned, ctx->scratch[1], out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    JRC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(out, ctx->pinned, out_bytes);
+    return (int)nsym;
+}
+
+// A6 + A7 fused: strided load (skipping the prefix) straight into the LDS FFT, fftshift on the way out
+extern "C" int jrc_cp_remove_fft_dev(jrc_ctx* ctx, int fft_len, int cp_len, size_t n_symbols, const jrc_cf32* d_in,
+                                     jrc_cf32* d_out, void* stream)
+{
+    if (!ctx || !d_in || !d_out) return JRC_ERR_INVALID_ARG;
+    if (cp_len < 0) return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "cp_remover: bad cp_len");
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    JRC_TRY(launch_fft_vcc(ctx, fft_len, 1, 1, nullptr, n_symbols, (const float2*)d_in, (float2*)d_out,
+                           (long)fft_len + cp_len, cp_len, s));
+    return (int)n_symbols;
+}
+
+extern "C" int jrc_cp_remove_fft(jrc_ctx* ctx, int fft_len, int cp_len, size_t ninput_items, const jrc_cf32* in,
+                                 jrc_cf32* out)
+{
+    if (!ctx || !in || !out) return JRC_ERR_INVALID_ARG;
+    if (fft_len <= 0 || cp_len < 0) return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "cp_remover: bad fft_len/cp_len");
+    const size_t nsym = ninput_items / (size_t)(fft_len + cp_len);
+    if (nsym == 0) return 0;
+    JRC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t in_bytes = sizeof(float2) * nsym * (size_t)(fft_len + cp_len);
+    const size_t out_bytes = sizeof(float2) * nsym * (size_t)fft_len;
+    JRC_TRY(jrc_ensure_pinned(ctx, in_bytes));
+    JRC_TRY(jrc_ensure_scratch(ctx, 0, in_bytes));
+    JRC_TRY(jrc_ensure_scratch(ctx, 1, out_bytes));
+    memcpy(ctx->pinned, in, in_bytes);
+    JRC_HIP(ctx, hipMemcpyAsync(ctx->scratch[0], ctx->pinned, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    int r = jrc_cp_remove_fft_dev(ctx, fft_len, cp_len, nsym, (const jrc_cf32*)ctx->scratch[0],
+                                  (jrc_cf32*)ctx->scratch[1], nullptr);
+    if (r < 0) return r;
+    JRC_HIP(ctx, hipMemcpyAsync(ctx->pinned, ctx->scratch[1], out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    JRC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(out, ctx->pinned, out_bytes);
+    return (int)nsym;
+}

@@ -1,0 +1,118 @@
+// jrc_internal.h — shared host-side state and device helpers for the gfx950 kernels behind include/jrc.h
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/jrc.h"
+
+struct jrc_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+    // pinned staging for the host-buffer entry points (GNU Radio buffers are pageable ring buffers)
+    void* pinned = nullptr;
+    size_t pinned_bytes = 0;
+    // device scratch for the host-buffer entry points
+    void* scratch[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_bytes[4] = {0, 0, 0, 0};
+    // twiddle tables exp(sign*j*2*pi*k/n), k < n, keyed by sign*n
+    std::map<long, float2*> twiddles;
+};
+
+int  jrc_fail(jrc_ctx* ctx, int status, const char* fmt, ...);
+int  jrc_ensure_pinned(jrc_ctx* ctx, size_t bytes);
+int  jrc_ensure_scratch(jrc_ctx* ctx, int slot, size_t bytes);
+// full-circle table of n entries: tw[k] = exp(sign * j * 2*pi * k / n), computed in double
+int  jrc_get_twiddles(jrc_ctx* ctx, int n, int sign, const float2** out);
+
+#define JRC_HIP(ctx, expr)                                                                      \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess)                                                                   \
+            return jrc_fail((ctx), JRC_ERR_HIP, "%s failed: %s (%s:%d)", #expr,                 \
+                            hipGetErrorString(_e), __FILE__, __LINE__);                         \
+    } while (0)
+
+#define JRC_TRY(expr)                       \
+    do {                                    \
+        int _s = (expr);                    \
+        if (_s < 0) return _s;              \
+    } while (0)
+
+static inline bool jrc_is_pow2(long n) { return n > 0 && (n & (n - 1)) == 0; }
+static inline int  jrc_ilog2(long n) { int l = 0; while ((1L << l) < n) l++; return l; }
+
+// ---- device helpers -----------------------------------------------------------------------
+#ifdef __HIPCC__
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+// |z|^2 exactly as the reference computes it: std::pow(std::abs(z), 2) with abs = glibc hypotf
+// (= (float)sqrt((double)x*x + (double)y*y)) and pow(float,int) evaluated in double
+// (lib/range_angle_estimator_impl.cc:141).  Returns the double before the final float rounding.
+__device__ __forceinline__ double ref_power_f64(float2 z)
+{
+    double d = (double)z.x * (double)z.x + (double)z.y * (double)z.y;
+    float h = (float)sqrt(d);
+    return (double)h * (double)h;
+}
+__device__ __forceinline__ float ref_hypotf(float2 z)
+{
+    double d = (double)z.x * (double)z.x + (double)z.y * (double)z.y;
+    return (float)sqrt(d);
+}
+
+// running first-arg-max with the reference's strict '>' semantics, filtered by a cheap f32 test so
+// that the f64 path above only runs for candidates within 1e-5 of the running maximum.
+struct PeakTracker {
+    float fast_max;   // max of re*re+im*im seen so far (f32)
+    float thr;        // fast_max * (1 - 1e-5)
+    float best;       // exact power of the best candidate
+    unsigned idx;     // its flat index
+    __device__ __forceinline__ void init() { fast_max = -1.0f; thr = -1.0f; best = -1.0f; idx = 0xffffffffu; }
+    __device__ __forceinline__ void visit(float2 z, unsigned flat)
+    {
+        float pf = fmaf(z.x, z.x, z.y * z.y);
+        if (pf >= thr) {
+            float pe = (float)ref_power_f64(z);
+            if (pe > best || (pe == best && flat < idx)) { best = pe; idx = flat; }
+            fast_max = fmaxf(fast_max, pf);
+            thr = fast_max * (1.0f - 1e-5f);
+        }
+    }
+    __device__ __forceinline__ void merge(float obest, unsigned oidx)
+    {
+        if (obest > best || (obest == best && oidx < idx)) { best = obest; idx = oidx; }
+    }
+};
+
+struct PeakPartial { float best; unsigned idx; };
+
+// block-wide (256 threads max 1024) reduction of PeakTracker; result valid in thread 0
+__device__ __forceinline__ void block_reduce_peak(PeakTracker& t, PeakPartial* smem /* >= nwaves */)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        float ob = __shfl_xor(t.best, off);
+        unsigned oi = __shfl_xor(t.idx, off);
+        t.merge(ob, oi);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if (lane == 0) { smem[wave].best = t.best; smem[wave].idx = t.idx; }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int w = 1; w < nw; w++) t.merge(smem[w].best, smem[w].idx);
+}
+
+#endif  // __HIPCC__

@@ -1,0 +1,248 @@
+// radar.hip — A1: MIMO-OFDM radar channel estimate (matched filter over OFDM symbols)
+//
+// Replaces mimo_ofdm_radar_impl::general_work (reference lib/mimo_ofdm_radar_impl.cc:131-340):
+//   H[p][sc] = sum_{sym<S} rx_r[sym][sc] * conj(tx_t[sym][sc]),  p = r*T+t (or t*R+r when interleaved)
+// HBM-bound: (T+R)*S*N*8 bytes read, P*N*8 written per frame; one lane per subcarrier so every load is
+// a coalesced 512-byte wave access, all P accumulators live in registers, symbols are accumulated in
+// order with individually rounded products (no FMA contraction) so the result is bit-identical to
+// the reference's scalar loop.
+#include "radar_kernels.h"
+
+// ------------------------------------------------------------------------------------------------
+template <int T, int R>
+__global__ __launch_bounds__(256) void radar_chanest_kernel(const float2* __restrict__ frames,
+                                                            float2* __restrict__ H, ChanestGeom g)
+{
+#pragma clang fp contract(off)
+    const int sc = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y;
+    if (sc >= g.N) return;
+    const float2* fb = frames + (size_t)f * g.frame_stride;
+    const float2* txp[T];
+    const float2* rxp[R];
+#pragma unroll
+    for (int t = 0; t < T; t++) txp[t] = fb + (size_t)t * g.port_stride + (size_t)g.tx_item0 * g.N + sc;
+#pragma unroll
+    for (int r = 0; r < R; r++) rxp[r] = fb + (size_t)(T + r) * g.port_stride + (size_t)g.rx_item0 * g.N + sc;
+
+    float2 acc[R][T];
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int t = 0; t < T; t++) acc[r][t] = make_float2(0.f, 0.f);
+
+#pragma unroll 4
+    for (int sym = 0; sym < g.S; sym++) {
+        float2 tx[T], rx[R];
+#pragma unroll
+        for (int t = 0; t < T; t++) tx[t] = txp[t][(size_t)sym * g.N];
+#pragma unroll
+        for (int r = 0; r < R; r++) rx[r] = rxp[r][(size_t)sym * g.N];
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int t = 0; t < T; t++) {
+                // rx * conj(tx) = (ac + bd) + j(bc - ad), products rounded individually (:273)
+                float pr = rx[r].x * tx[t].x + rx[r].y * tx[t].y;
+                float pi = rx[r].y * tx[t].x - rx[r].x * tx[t].y;
+                acc[r][t].x = acc[r][t].x + pr;
+                acc[r][t].y = acc[r][t].y + pi;
+            }
+    }
+    float2* Hf = H + (size_t)f * T * R * g.N;
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            const int p = g.interleave ? (t * R + r) : (r * T + t);   // :262-269
+            Hf[(size_t)p * g.N + sc] = acc[r][t];
+        }
+}
+
+// any T, R: one lane per (pair, subcarrier)
+__global__ __launch_bounds__(256) void radar_chanest_generic_kernel(const float2* __restrict__ frames,
+                                                                    float2* __restrict__ H, ChanestGeom g,
+                                                                    int T, int R)
+{
+#pragma clang fp contract(off)
+    const int sc = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y;
+    const int rt = blockIdx.z;
+    if (sc >= g.N) return;
+    const int r = rt / T, t = rt % T;
+    const float2* fb = frames + (size_t)f * g.frame_stride;
+    const float2* txp = fb + (size_t)t * g.port_stride + (size_t)g.tx_item0 * g.N + sc;
+    const float2* rxp = fb + (size_t)(T + r) * g.port_stride + (size_t)g.rx_item0 * g.N + sc;
+    float2 acc = make_float2(0.f, 0.f);
+    for (int sym = 0; sym < g.S; sym++) {
+        float2 tx = txp[(size_t)sym * g.N], rx = rxp[(size_t)sym * g.N];
+        float pr = rx.x * tx.x + rx.y * tx.y;
+        float pi = rx.y * tx.x - rx.x * tx.y;
+        acc.x = acc.x + pr;
+        acc.y = acc.y + pi;
+    }
+    const int p = g.interleave ? (t * R + r) : (r * T + t);
+    H[((size_t)f * T * R + p) * g.N + sc] = acc;
+}
+
+int launch_radar_chanest(jrc_ctx* ctx, int T, int R, const float2* d_frames, float2* d_H,
+                         const ChanestGeom& g, int n_frames, hipStream_t stream)
+{
+    const int threads = g.N >= 256 ? 256 : (g.N <= 64 ? 64 : ((g.N + 63) / 64) * 64);
+    dim3 grid((g.N + threads - 1) / threads, n_frames, 1);
+#define JRC_CASE(TT, RR)                                                                             \
+    if (T == TT && R == RR) {                                                                        \
+        hipLaunchKernelGGL((radar_chanest_kernel<TT, RR>), grid, dim3(threads), 0, stream, d_frames, \
+                           d_H, g);                                                                  \
+        JRC_HIP(ctx, hipGetLastError());                                                             \
+        return JRC_OK;                                                                               \
+    }
+    JRC_CASE(1, 1) JRC_CASE(1, 2) JRC_CASE(1, 4) JRC_CASE(2, 1) JRC_CASE(2, 2) JRC_CASE(2, 4)
+    JRC_CASE(4, 1) JRC_CASE(4, 2) JRC_CASE(4, 4)
+#undef JRC_CASE
+    grid.z = T * R;
+    hipLaunchKernelGGL(radar_chanest_generic_kernel, grid, dim3(threads), 0, stream, d_frames, d_H, g, T, R);
+    JRC_HIP(ctx, hipGetLastError());
+    return JRC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// background recording / removal (lib/mimo_ofdm_radar_impl.cc:276-293)
+__global__ void radar_background_kernel(float2* __restrict__ est, float2* __restrict__ temp,
+                                        const float2* __restrict__ ring, int pn, int ring_size,
+                                        int ring_head, int record_len, int recording, int removal)
+{
+#pragma clang fp contract(off)
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= pn) return;
+    float2 e = est[idx];
+    if (recording) temp[idx] = e;
+    if (removal) {
+        float2 m = make_float2(0.f, 0.f);
+        const float n = (float)ring_size;
+        for (int i = 0; i < ring_size; i++) {
+            const int slot = (ring_head + i) % record_len;
+            float2 v = ring[(size_t)slot * pn + idx];
+            m.x = m.x + v.x / n;      // complex / float divides each component (:289)
+            m.y = m.y + v.y / n;
+        }
+        est[idx] = make_float2(e.x - m.x, e.y - m.y);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct jrc_radar {
+    jrc_ctx* ctx;
+    int N, T, R, S, Npre, Ir, interleave;
+    int bg_removal, bg_recording, record_len;
+    float2* d_in = nullptr;    // [T+R][S][N]
+    float2* d_est = nullptr;   // [P][N]
+    float2* d_temp = nullptr;  // radar_chan_est_temp
+    float2* d_ring = nullptr;  // [record_len][P*N]
+    int ring_size = 0, ring_head = 0;
+};
+
+extern "C" int jrc_radar_create(jrc_ctx* ctx, int fft_len, int N_tx, int N_rx, int N_sym, int N_pre,
+                                int background_removal, int background_recording, int record_len,
+                                int interp_factor, int enable_tx_interleave, jrc_radar** out)
+{
+    if (!ctx || !out) return JRC_ERR_INVALID_ARG;
+    if (fft_len <= 0 || N_tx <= 0 || N_rx <= 0 || N_sym < 0 || N_pre < 0 || interp_factor <= 0 || record_len < 0)
+        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "mimo_ofdm_radar: non-positive size parameter");
+    jrc_radar* r = new jrc_radar();
+    r->ctx = ctx;
+    r->N = fft_len; r->T = N_tx; r->R = N_rx; r->S = N_sym; r->Npre = N_pre; r->Ir = interp_factor;
+    r->interleave = enable_tx_interleave;
+    r->bg_removal = background_removal; r->bg_recording = background_recording; r->record_len = record_len;
+    const size_t pn = (size_t)N_tx * N_rx * fft_len;
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e == hipSuccess) e = hipMalloc((void**)&r->d_in, sizeof(float2) * (size_t)(N_tx + N_rx) * (N_sym ? N_sym : 1) * fft_len);
+    if (e == hipSuccess) e = hipMalloc((void**)&r->d_est, sizeof(float2) * pn);
+    if (e == hipSuccess) e = hipMalloc((void**)&r->d_temp, sizeof(float2) * pn);
+    if (e == hipSuccess) e = hipMalloc((void**)&r->d_ring, sizeof(float2) * pn * (record_len ? record_len : 1));
+    if (e == hipSuccess) e = hipMemset(r->d_temp, 0, sizeof(float2) * pn);   // vector::resize value-initialises (:115)
+    if (e != hipSuccess) {
+        jrc_radar_destroy(r);
+        return jrc_fail(ctx, JRC_ERR_HIP, "jrc_radar_create: %s", hipGetErrorString(e));
+    }
+    *out = r;
+    return JRC_OK;
+}
+
+extern "C" void jrc_radar_destroy(jrc_radar* r)
+{
+    if (!r) return;
+    (void)hipStreamSynchronize(r->ctx->stream);
+    if (r->d_in) (void)hipFree(r->d_in);
+    if (r->d_est) (void)hipFree(r->d_est);
+    if (r->d_temp) (void)hipFree(r->d_temp);
+    if (r->d_ring) (void)hipFree(r->d_ring);
+    delete r;
+}
+
+extern "C" int jrc_radar_set_background_record(jrc_radar* r, int on)
+{
+    if (!r) return JRC_ERR_INVALID_ARG;
+    r->bg_recording = on;
+    return JRC_OK;
+}
+
+extern "C" int jrc_radar_ring_size(const jrc_radar* r) { return r ? r->ring_size : JRC_ERR_INVALID_ARG; }
+
+extern "C" int jrc_radar_work(jrc_radar* r, const jrc_cf32* const* tx, const jrc_cf32* const* rx,
+                              size_t n_items_tx, size_t n_items_rx, size_t tx_discard, jrc_cf32* out)
+{
+    if (!r || !tx || !rx || !out) return JRC_ERR_INVALID_ARG;
+    jrc_ctx* ctx = r->ctx;
+    const int N = r->N, T = r->T, R = r->R, S = r->S, P = T * R;
+    // The reference reads N_pre+N_sym items (+ discard on TX) without checking (:250-274); fail loudly instead.
+    if (n_items_rx < (size_t)(r->Npre + S) || n_items_tx < tx_discard + (size_t)(r->Npre + S))
+        return jrc_fail(ctx, JRC_ERR_SHORT_INPUT, "mimo_ofdm_radar: need %d items (+%zu discard) per port, got tx=%zu rx=%zu",
+                        r->Npre + S, tx_discard, n_items_tx, n_items_rx);
+    JRC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t port_items = (size_t)S * N;
+    const size_t in_bytes = sizeof(float2) * (size_t)(T + R) * port_items;
+    const size_t est_bytes = sizeof(float2) * (size_t)P * N;
+    JRC_TRY(jrc_ensure_pinned(ctx, in_bytes + est_bytes));
+    float2* h_in = (float2*)ctx->pinned;
+    float2* h_est = (float2*)((char*)ctx->pinned + in_bytes);
+    for (int t = 0; t < T; t++)
+        memcpy(h_in + (size_t)t * port_items, (const float2*)tx[t] + ((size_t)r->Npre + tx_discard) * N,
+               sizeof(float2) * port_items);
+    for (int q = 0; q < R; q++)
+        memcpy(h_in + (size_t)(T + q) * port_items, (const float2*)rx[q] + (size_t)r->Npre * N,
+               sizeof(float2) * port_items);
+    if (in_bytes) JRC_HIP(ctx, hipMemcpyAsync(r->d_in, h_in, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+
+    ChanestGeom g;
+    g.N = N; g.S = S; g.frame_stride = (long)(T + R) * (long)port_items; g.port_stride = (long)port_items;
+    g.tx_item0 = 0; g.rx_item0 = 0; g.interleave = r->interleave;
+    JRC_TRY(launch_radar_chanest(ctx, T, R, r->d_in, r->d_est, g, 1, ctx->stream));
+
+    const int pn = P * N;
+    if (r->bg_recording || r->bg_removal) {
+        hipLaunchKernelGGL(radar_background_kernel, dim3((pn + 255) / 256), dim3(256), 0, ctx->stream, r->d_est,
+                           r->d_temp, r->d_ring, pn, r->ring_size, r->ring_head, r->record_len ? r->record_len : 1,
+                           r->bg_recording, r->bg_removal);
+        JRC_HIP(ctx, hipGetLastError());
+    }
+    if (r->bg_removal && r->record_len > 0) {   // :297-300 circular_buffer::push_back
+        int slot;
+        if (r->ring_size < r->record_len) {
+            slot = (r->ring_head + r->ring_size) % r->record_len;
+            r->ring_size++;
+        } else {
+            slot = r->ring_head;
+            r->ring_head = (r->ring_head + 1) % r->record_len;
+        }
+        JRC_HIP(ctx, hipMemcpyAsync(r->d_ring + (size_t)slot * pn, r->d_temp, sizeof(float2) * pn,
+                                    hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    JRC_HIP(ctx, hipMemcpyAsync(h_est, r->d_est, est_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    JRC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // zero-padded rows on the host side of the PCIe link (:243, :312-315): only P*N values cross it
+    memset(out, 0, sizeof(float2) * (size_t)P * N * r->Ir);
+    for (int p = 0; p < P; p++)
+        memcpy((float2*)out + (size_t)p * N * r->Ir, h_est + (size_t)p * N, sizeof(float2) * N);
+    return P;
+}

@@ -1,0 +1,179 @@
+/*
+ * jrc.h — C ABI of the MI355X (gfx950) implementation of the gr-mimo-ofdm-jrc hot path.
+ *
+ * This is the drop-in boundary: the GNU Radio block wrappers call these
+ * entry points from their work()/general_work() bodies.  Plain pointers and sizes only; no C++
+ * or torch types cross this line.  Citations are to the reference tree (/root/reference).
+ *
+ * Conventions
+ *   - jrc_cf32 is gr_complex (std::complex<float>): interleaved re, im.
+ *   - Functions return JRC_OK (0) or a negative jrc_status; jrc_strerror() names it and
+ *     jrc_last_error() gives the detailed message (HIP error string, offending size ...).
+ *     The reference signals the same conditions with C++ exceptions; the wrappers re-throw.
+ *   - "host" entry points take caller-owned host memory (GNU Radio ring buffers), stage through
+ *     pinned memory, run the HIP kernels and are synchronous on return.
+ *   - "_dev" entry points take device pointers (hipMalloc / torch.cuda tensors) and a stream
+ *     (hipStream_t passed as void*; NULL = the context's own stream) and are asynchronous.
+ *   - One jrc_ctx per host thread; a ctx is bound to one GPU.  There is no CPU fallback: without a
+ *     usable HIP device jrc_create() fails with JRC_ERR_NO_DEVICE.
+ */
+#ifndef JRC_H
+#define JRC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JRC_ABI_VERSION 1
+
+typedef struct { float re, im; } jrc_cf32;
+
+typedef enum {
+    JRC_OK = 0,
+    JRC_ERR_NO_DEVICE = -1,        /* no HIP device / HIP runtime failure at init */
+    JRC_ERR_HIP = -2,              /* a HIP call failed; see jrc_last_error() */
+    JRC_ERR_INVALID_ARG = -3,      /* std::invalid_argument in the reference */
+    JRC_ERR_UNSUPPORTED = -4,      /* size/shape outside what the HIP kernels implement */
+    JRC_ERR_LENGTH_MISMATCH = -5,  /* matrix_transpose runtime_error (lib/matrix_transpose_impl.cc:82-83) */
+    JRC_ERR_SHORT_INPUT = -6,      /* fewer items than the block needs for one frame */
+    JRC_ERR_NOMEM = -7,
+    JRC_ERR_SIG_FIELD = -8,        /* precoder: frame_param.n_ofdm_sym mismatch (lib/mimo_precoder_impl.cc:327-333) */
+    JRC_ERR_IO = -9                /* file could not be opened (estimator / equalizer CSV side files) */
+} jrc_status;
+
+typedef struct jrc_ctx jrc_ctx;
+
+/* ---- context ---------------------------------------------------------------------------- */
+int         jrc_abi_version(void);
+int         jrc_device_count(void);                       /* never initialises a device */
+int         jrc_create(int device, jrc_ctx** ctx);
+void        jrc_destroy(jrc_ctx* ctx);
+const char* jrc_strerror(int status);
+const char* jrc_last_error(const jrc_ctx* ctx);
+int         jrc_device_name(const jrc_ctx* ctx, char* buf, size_t len);
+int         jrc_sync(jrc_ctx* ctx);                        /* wait for the ctx stream */
+void*       jrc_stream(jrc_ctx* ctx);                      /* the ctx's hipStream_t */
+
+/* device memory helpers for non-torch hosts (the GNU Radio wrappers, C tests) */
+int jrc_dev_malloc(jrc_ctx* ctx, size_t bytes, void** dptr);
+int jrc_dev_free(jrc_ctx* ctx, void* dptr);
+int jrc_dev_memset(jrc_ctx* ctx, void* dptr, int value, size_t bytes);
+int jrc_memcpy_h2d(jrc_ctx* ctx, void* dptr, const void* hptr, size_t bytes);   /* synchronous */
+int jrc_memcpy_d2h(jrc_ctx* ctx, void* hptr, const void* dptr, size_t bytes);   /* synchronous */
+
+/* ---- A1  mimo_ofdm_radar  (replaces mimo_ofdm_radar_impl::general_work,
+ *          lib/mimo_ofdm_radar_impl.cc:131-340; ctor :66-120; setter :342-346) ------------------- */
+typedef struct jrc_radar jrc_radar;
+int  jrc_radar_create(jrc_ctx* ctx, int fft_len, int N_tx, int N_rx, int N_sym, int N_pre,
+                      int background_removal, int background_recording, int record_len,
+                      int interp_factor, int enable_tx_interleave, jrc_radar** radar);
+void jrc_radar_destroy(jrc_radar* radar);
+int  jrc_radar_set_background_record(jrc_radar* radar, int background_recording);
+int  jrc_radar_ring_size(const jrc_radar* radar);
+/* tx[t] / rx[r]: the T / R GNU Radio input port buffers (item = fft_len cf32) positioned at the
+ * tagged packet start; n_items_* = ninput_items on those ports; tx_discard = items of stale TX
+ * packets skipped (:191-198).  out = output port buffer, P x (fft_len*interp_factor) cf32
+ * (zero-padded rows, :303-315).  Returns the number of items produced (P) or < 0. */
+int  jrc_radar_work(jrc_radar* radar, const jrc_cf32* const* tx, const jrc_cf32* const* rx,
+                    size_t n_items_tx, size_t n_items_rx, size_t tx_discard, jrc_cf32* out);
+
+/* ---- A2/A4/A7  stock gr::fft::fft_vcc (FFTW3f in GNU Radio 3.8; flowgraph wiring
+ *          examples/simulation/radar/mimo_ofdm_jrc_radar_sim.grc:877-1047) -------------------------
+ * forward: out = [fftshift] FFT(in .* window); reverse: out = unnormalised IFFT([ifftshift](in .* window)).
+ * fft_size must be a power of two in [2, 16384].  window may be NULL (rectangular). */
+int jrc_fft_vcc(jrc_ctx* ctx, int fft_size, int forward, int shift, const float* window,
+                size_t batch, const jrc_cf32* in, jrc_cf32* out);
+int jrc_fft_vcc_dev(jrc_ctx* ctx, int fft_size, int forward, int shift, const float* d_window,
+                    size_t batch, const jrc_cf32* d_in, jrc_cf32* d_out, void* stream);
+
+/* ---- A3  matrix_transpose (replaces matrix_transpose_impl::work, lib/matrix_transpose_impl.cc:69-110)
+ * in: ninput_items x input_len; out: input_len x (output_len*interp_factor), zero padded.
+ * Returns items produced (= input_len), or JRC_ERR_LENGTH_MISMATCH (:82-83). */
+int jrc_matrix_transpose(jrc_ctx* ctx, int input_len, int output_len, int interp_factor,
+                         int ninput_items, const jrc_cf32* in, jrc_cf32* out);
+int jrc_matrix_transpose_dev(jrc_ctx* ctx, int input_len, int output_len, int interp_factor,
+                             int ninput_items, size_t batch, const jrc_cf32* d_in, jrc_cf32* d_out,
+                             void* stream);
+
+/* ---- A5  range_angle_estimator (replaces range_angle_estimator_impl::work,
+ *          lib/range_angle_estimator_impl.cc:121-284) ------------------------------------------ */
+typedef struct {
+    int32_t peak_range_idx, peak_angle_idx;   /* first arg-max of |z|^2 in scan order (:137-151) */
+    int32_t angle_null_idx;                   /* (:155-187) */
+    int32_t discard_range_idx, discard_angle_idx;   /* (:189-195) */
+    int32_t n_noise_samples;
+    float   peak_power, noise_power, snr_est; /* (:227-232) */
+    float   range_val, angle_val;             /* range_bins[peak_range_idx], angle_bins[peak_angle_idx] */
+    int32_t published;                        /* snr_est >= snr_threshold && peak_power >= power_threshold (:234) */
+} jrc_ra_result;
+int jrc_ra_estimate(jrc_ctx* ctx, int vlen, int n_inputs, const jrc_cf32* in,
+                    const float* range_bins, int n_range_bins,
+                    const float* angle_bins, int n_angle_bins,
+                    float noise_discard_range_m, float noise_discard_angle_deg,
+                    float snr_threshold, float power_threshold, jrc_ra_result* result);
+
+/* ---- A6  ofdm_cyclic_prefix_remover (replaces ofdm_cyclic_prefix_remover_impl::work,
+ *          lib/ofdm_cyclic_prefix_remover_impl.cc:69-99).  Returns noutput_items. ---------------- */
+int jrc_cp_remove(jrc_ctx* ctx, int fft_len, int cp_len, size_t ninput_items,
+                  const jrc_cf32* in, jrc_cf32* out);
+/* A6+A7 fused: CP removal followed by fft_vxx forward+shift of size fft_len (RX OFDM demod). */
+int jrc_cp_remove_fft(jrc_ctx* ctx, int fft_len, int cp_len, size_t ninput_items,
+                      const jrc_cf32* in, jrc_cf32* out);
+int jrc_cp_remove_fft_dev(jrc_ctx* ctx, int fft_len, int cp_len, size_t n_symbols,
+                          const jrc_cf32* d_in, jrc_cf32* d_out, void* stream);
+
+/* ---- B1  fft_peak_detect (replaces fft_peak_detect_impl::work, lib/fft_peak_detect_impl.cc:77-111)
+ * Returns 1 (items produced, always, :110).  *k_out = winning bin or -1; when -1 the three
+ * outputs are left untouched exactly like the reference. */
+int jrc_fft_peak_detect(jrc_ctx* ctx, int samp_rate, float interp_factor, float threshold,
+                        int samp_protect, size_t ninput_items, const jrc_cf32* in,
+                        float* out_freq, float* out_phase, float* out_mag, int* k_out);
+
+/* ---- fused, device-resident radar chain  A1 -> A2 -> A3 -> A4 -> A5 over a batch of frames ------
+ * One launch sequence replaces mimo_ofdm_radar + fft_vxx(reverse) + matrix_transpose +
+ * fft_vxx(forward,shift) + range_angle_estimator of the radar flowgraph
+ * (examples/simulation/radar/mimo_ofdm_jrc_radar_sim.grc:2189-2197).  Frames are independent. */
+typedef struct {
+    int32_t fft_len, N_tx, N_rx, N_sym, N_pre;
+    int32_t interp_range, interp_angle;       /* Ir (mimo_ofdm_radar), Ia (matrix_transpose) */
+    int32_t enable_tx_interleave;
+    int32_t n_items;                          /* items per port per frame in d_frames (>= N_pre+N_sym) */
+    float   noise_discard_range_m, noise_discard_angle_deg;
+    float   snr_threshold, power_threshold;
+} jrc_chain_cfg;
+
+typedef struct jrc_chain jrc_chain;
+int  jrc_chain_create(jrc_ctx* ctx, const jrc_chain_cfg* cfg,
+                      const float* range_bins /* fft_len*interp_range */,
+                      const float* angle_bins /* N_tx*N_rx*interp_angle */,
+                      int max_frames, jrc_chain** chain);
+void jrc_chain_destroy(jrc_chain* chain);
+/* bytes per frame of each device buffer the caller provides */
+size_t jrc_chain_frame_bytes(const jrc_chain* chain);     /* (T+R) * n_items * fft_len * 8 */
+size_t jrc_chain_chanest_bytes(const jrc_chain* chain);   /* P * fft_len * 8 */
+size_t jrc_chain_map_bytes(const jrc_chain* chain);       /* (fft_len*Ir) * (P*Ia) * 8 */
+/* d_frames : [n_frames][T+R][n_items][fft_len] cf32, ports ordered TX0..TX(T-1), RX0..RX(R-1)
+ * d_chanest: [n_frames][P][fft_len] cf32            (A1 output before zero padding)
+ * d_map    : [n_frames][fft_len*Ir][P*Ia] cf32      (A4 output; the estimator's input)
+ * d_results: [n_frames] jrc_ra_result (snr_est/published are filled by jrc_chain_finish_results)
+ * Asynchronous on `stream`. */
+int  jrc_chain_run_dev(jrc_chain* chain, int n_frames, const jrc_cf32* d_frames,
+                       jrc_cf32* d_chanest, jrc_cf32* d_map, jrc_ra_result* d_results, void* stream);
+/* D2H the results of the last run and complete snr_est / published on the host with libm's log10f
+ * (bit-identical to the reference's std::log10, :227). Synchronises `stream`. */
+int  jrc_chain_fetch_results(jrc_chain* chain, int n_frames, const jrc_ra_result* d_results,
+                             jrc_ra_result* h_results, void* stream);
+/* HIP-event timing of the dominant kernel (range-angle FFT + detect) for bench.py's roofline:
+ * when enabled every jrc_chain_run_dev brackets each kernel with events on `stream`. */
+int  jrc_chain_set_timing(jrc_chain* chain, int enabled);
+/* mean milliseconds per launch since timing was enabled/reset, per kernel:
+ * ms[0]=radar_chanest, ms[1]=range_angle_fused, ms[2]=ra_finalize; *launches = runs measured */
+int  jrc_chain_get_timing(jrc_chain* chain, float ms[3], int* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JRC_H */

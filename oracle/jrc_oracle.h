@@ -1,0 +1,93 @@
+/*
+ * jrc_oracle.h — CPU restatement (TEST INFRASTRUCTURE, not product) of the
+ * MIMO-OFDM radar / equalizer / precoder hot path of gr-mimo-ofdm-jrc.
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures,
+ * and its sources cannot be built in this image (they need GNU Radio 3.8,
+ * Eigen3, Boost, FFTW3f and VOLK headers, none of which exist here; writing
+ * stand-ins for them is not a reference build).  Every function below is a
+ * line-by-line restatement of the cited reference code in plain C with the
+ * same float/double evaluation order, checked against closed forms and the
+ * constant tables minted from the reference's flowgraph-embedded Python
+ * module (tests/golden/ofdm_config_64.npz).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * link or call this library.  The shipped path is gr-mimo-ofdm-jrc_amd/csrc.
+ *
+ * All complex buffers are interleaved float pairs (gr_complex layout).
+ * Reference citations are relative to /root/reference.
+ */
+#ifndef JRC_ORACLE_H
+#define JRC_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- A1: mimo_ofdm_radar_impl::general_work (lib/mimo_ofdm_radar_impl.cc:131-340) ---- */
+typedef struct orc_radar_state orc_radar_state;
+orc_radar_state* orc_radar_create(int fft_len, int N_tx, int N_rx, int N_sym, int N_pre,
+                                  int background_removal, int background_recording,
+                                  int record_len, int interp_factor, int enable_tx_interleave);
+void orc_radar_destroy(orc_radar_state* st);
+void orc_radar_set_background_record(orc_radar_state* st, int on);
+int  orc_radar_ring_size(const orc_radar_state* st);
+/* tx[t], rx[r]: port buffers exactly as GNU Radio hands them (item 0 = first
+ * OFDM symbol of the tagged packet); tx_discard = items skipped on the TX
+ * ports (lib/mimo_ofdm_radar_impl.cc:191-198).  out: P x (N*Ir). */
+void orc_radar_work(orc_radar_state* st, const float* const* tx, const float* const* rx,
+                    long tx_discard, float* out);
+
+/* ---- stock gr::fft::fft_vcc semantics (GNU Radio 3.8 gr-fft, not in tree) ----
+ * forward: out = [fftshift](FFT(in * window)); reverse: out = IFFT_unnorm([ifftshift](in*window)).
+ * window may be NULL.  Computed in double, rounded once to float. */
+void orc_fft_vcc(int n, int forward, int shift, const float* window, long batch,
+                 const float* in, float* out);
+
+/* ---- A3: matrix_transpose_impl::work (lib/matrix_transpose_impl.cc:69-110) ----
+ * returns input_len (items produced) or -1 for the runtime_error at :82-83 */
+int orc_matrix_transpose(int input_len, int output_len, int interp_factor, int ninput_items,
+                         const float* in, float* out);
+
+/* ---- A5: range_angle_estimator_impl::work (lib/range_angle_estimator_impl.cc:121-284) ---- */
+typedef struct {
+    int   peak_range_idx, peak_angle_idx;
+    int   angle_null_idx;
+    int   discard_range_idx, discard_angle_idx;
+    int   n_noise_samples;
+    float peak_power, noise_power, snr_est;
+    float range_val, angle_val;
+    int   published; /* snr_est >= snr_threshold && peak_power >= power_threshold (:234) */
+} orc_ra_result;
+void orc_ra_estimate(int vlen, int n_inputs, const float* in,
+                     const float* range_bins, int n_range_bins,
+                     const float* angle_bins, int n_angle_bins,
+                     float noise_discard_range_m, float noise_discard_angle_deg,
+                     float snr_threshold, float power_threshold, orc_ra_result* res);
+
+/* ---- A6: ofdm_cyclic_prefix_remover_impl::work (lib/ofdm_cyclic_prefix_remover_impl.cc:69-99) ----
+ * returns noutput_items */
+int orc_cp_remove(int fft_len, int cp_len, long ninput_items, const float* in, float* out);
+
+/* ---- B1: fft_peak_detect_impl::work (lib/fft_peak_detect_impl.cc:77-111) ----
+ * returns k (or -1: nothing above threshold, outputs untouched as in the reference) */
+int orc_fft_peak_detect(int samp_rate, float interp_factor, float threshold, int samp_protect,
+                        long ninput_items, const float* in,
+                        float* out_freq, float* out_phase, float* out_mag);
+
+/* ---- composed radar chain A1 -> A2 -> A3 -> A4 (-> A5) for one frame, used as the CPU baseline ----
+ * Hpad/range/tr are caller-provided scratch (P*N*Ir, P*N*Ir, N*Ir*P*Ia floats*2); map = N*Ir x P*Ia */
+void orc_radar_chain(orc_radar_state* st, const float* const* tx, const float* const* rx,
+                     int interp_angle, float* Hpad, float* range, float* tr, float* map);
+
+/* single-precision radix-2 FFT (same semantics as orc_fft_vcc, float arithmetic):
+ * only used to TIME a CPU baseline with the arithmetic type the reference (FFTW3f) uses. */
+void orc_fft_vcc_f32(int n, int forward, int shift, long batch, const float* in, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
