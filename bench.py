@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py — OFDM frames/s of the radar hot path (A1 -> A5) on MI355X, with the roofline of the dominant
+kernel and a CPU baseline beside it.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config B|D|A] [--frames F]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the fused chain (mimo_ofdm_radar -> range IFFT -> transpose/pad -> angle FFT ->
+range_angle_estimator) over one batch of F synthetic frames already resident in HBM.  Frames are
+independent, so N GPUs each process their own batch (weak scaling, no data-path collective); the only
+collectives are the barriers / MAX-reduce of the timing contract.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="B", choices=["A", "B", "D"])
+    ap.add_argument("--frames", type=int, default=0, help="frames per GPU per step (0 = per-config default)")
+    ap.add_argument("--distinct", type=int, default=32, help="distinct synthetic frames generated per GPU (tiled to --frames)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (rank 0, N=1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather-results", action="store_true",
+                    help="also RCCL all-gather the per-frame results every step (optional exchange, off by default)")
+    return ap.parse_args()
+
+
+def scenario(name):
+    from jrc_amd import synth
+    return {"A": synth.config_A, "B": synth.config_B, "D": synth.config_D}[name]()
+
+
+def cpu_baseline(sc, Ir, Ia, frames, axes, budget_s):
+    """the oracle's block-by-block chain (A1..A5, float32, one thread) timed on a bounded sample of the same frames"""
+    import oracle
+    rb, ab, ndr, nda = axes
+    P = sc.T * sc.R
+    rad = oracle.Radar(sc.N, sc.T, sc.R, sc.S, sc.Npre, interp_factor=Ir)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        fr = frames[done % len(frames)]
+        m = rad.chain([fr[t] for t in range(sc.T)], [fr[sc.T + r] for r in range(sc.R)], Ia)
+        oracle.ra_estimate(m, rb, ab, ndr, nda, 15.0, 0.0)
+        done += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or done >= 4096:
+            break
+    return {"value": done / el, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d frames of the same workload, oracle C port (float32 radix-2 FFTs), 1 thread, %.1f s" % (done, el)}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
+        a.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    import jrc_amd
+    from jrc_amd import synth
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the HIP path is mandatory; there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    sc = scenario(a.config)
+    Ir, Ia = 8, 16
+    P, NR, NA = sc.T * sc.R, sc.N * Ir, sc.T * sc.R * Ia
+    F = a.frames or {"A": 4096, "B": 256, "D": 64}[a.config]
+    rb, ab = jrc_amd.radar_axes(sc.N, sc.fs, Ir, P, Ia)
+    ndr = 2 * 3e8 / (2 * sc.fs)
+    nda = 2 * float(np.rad2deg(np.arcsin(2 / P))) if P > 2 else 30.0
+
+    ctx = jrc_amd.Context(local_rank)
+    chain = jrc_amd.RadarChain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb, ab, ndr, nda, 15.0, 0.0,
+                               max_frames=F, ctx=ctx)
+    bufs = chain.alloc(F, dev)
+    n_distinct = min(a.distinct, F)
+    host_frames = synth.make_frames(sc, n_distinct, first_frame=rank * F)
+    hf = torch.from_numpy(host_frames.view(np.float32).reshape((n_distinct,) + tuple(bufs["frames"].shape[1:])))
+    for f0 in range(0, F, n_distinct):
+        n = min(n_distinct, F - f0)
+        bufs["frames"][f0:f0 + n].copy_(hf[:n])
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    gathered = None
+    if a.gather_results and world > 1:
+        gathered = torch.empty((world,) + tuple(bufs["results"].shape), dtype=torch.uint8, device=dev)
+
+    def step():
+        chain.run(bufs, F)
+        if gathered is not None:
+            ctx.sync()
+            dist.all_gather_into_tensor(gathered, bufs["results"])
+
+    for _ in range(a.warmup):
+        step()
+    ctx.sync()
+    torch.cuda.synchronize()
+    chain.set_timing(True)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    ctx.sync()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kt = chain.get_timing()
+    res = chain.results(bufs, F)
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    if rank == 0:
+        total_frames = F * a.steps * world
+        ms_step = 1e3 * elapsed / a.steps
+        # algorithmic bytes of the dominant kernel: unpadded H in, complex map out
+        alg_bytes = F * (P * sc.N * 8 + NR * NA * 8)
+        k_ms = kt["range_angle_fused"]
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        out = {
+            "metric": "ofdm_frames_per_sec", "value": total_frames / elapsed, "unit": "frames/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "config %s: %dTx x %dRx, %d subcarriers, %d symbols, Ir=%d, Ia=%d -> %dx%d range-angle map + "
+                                   "peak/SNR estimate (mimo_ofdm_radar -> range IFFT -> transpose -> angle FFT -> "
+                                   "range_angle_estimator), %d frames/GPU/step resident in HBM"
+                                   % (a.config, sc.T, sc.R, sc.N, sc.S, Ir, Ia, NR, NA, F),
+                       "frames_per_gpu_per_step": F, "parallelism": "frame-sharded x%d, no data-path collective" % world,
+                       "gather_results": bool(gathered is not None)},
+            "roofline": {"bound": "hbm", "kernel": "range_angle_fused_kernel<%d>" % P, "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                         "avg_launch_ms": k_ms, "launches_timed": kt["launches"]},
+            "kernels_ms": {k: kt[k] for k in ("radar_chanest", "range_angle_fused", "ra_finalize")},
+            "check": {"range_m": res[0].range_val, "angle_deg": res[0].angle_val, "snr_db": res[0].snr_est},
+            "device": ctx.device_name(),
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sc, Ir, Ia, host_frames, (rb, ab, ndr, nda), a.cpu_seconds)
+            out["cpu_baseline"]["host_cpus"] = os.cpu_count()
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

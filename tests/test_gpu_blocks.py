@@ -1,0 +1,192 @@
+"""GPU tier: every per-block C-ABI entry point (host buffers in/out, like a GNU Radio work() call) against
+the oracle on the same seeded inputs.  Integer/index results and the scalar-loop arithmetic are bit-exact;
+the FFT stages use the north-star tolerance 1e-4 on ||a-b||_inf/||b||_inf (FFTW's summation order is not
+reproducible by any other FFT), tightened to 2e-6 here because both sides are within float rounding."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import crandn, rel_err
+
+pytestmark = pytest.mark.gpu
+FFT_TOL = 2e-6        # well inside the 1e-4 the north star allows
+
+
+@pytest.mark.parametrize("N,T,R,S,Npre,Ir,interleave,discard", [
+    (64, 4, 2, 4, 5, 8, False, 0),       # the reference's example flowgraph shape
+    (64, 4, 2, 4, 5, 1, True, 0),
+    (64, 1, 1, 16, 5, 8, False, 0),      # BASELINE config A
+    (256, 4, 4, 64, 5, 8, False, 2),     # config B, with stale TX packets discarded
+    (1024, 4, 4, 128, 5, 8, False, 0),   # config D
+    (96, 3, 2, 7, 1, 2, False, 1),       # odd sizes -> generic kernel
+    (16, 2, 4, 1, 0, 1, True, 0),
+])
+def test_mimo_ofdm_radar_bit_exact(jrc, ctx, N, T, R, S, Npre, Ir, interleave, discard):
+    rng = np.random.default_rng(N + T + R)
+    tx = [crandn(rng, Npre + discard + S + 2, N) for _ in range(T)]
+    rx = [crandn(rng, Npre + S + 1, N) for _ in range(R)]
+    ref = oracle.Radar(N, T, R, S, Npre, interp_factor=Ir, enable_tx_interleave=interleave).work(tx, rx, discard)
+    blk = jrc.mimo_ofdm_radar(N, T, R, S, Npre, False, False, 8, Ir, interleave, "", ctx=ctx)
+    out = blk.general_work(tx, rx, discard)
+    assert out.shape == ref.shape and np.array_equal(out, ref)
+
+
+def test_mimo_ofdm_radar_background_ring(jrc, ctx):
+    rng = np.random.default_rng(11)
+    N, T, R, S, Npre, L = 64, 4, 2, 4, 5, 3
+    ref = oracle.Radar(N, T, R, S, Npre, True, True, L, 8)
+    blk = jrc.mimo_ofdm_radar(N, T, R, S, Npre, True, True, L, 8, False, "", ctx=ctx)
+    for rec in [True, True, False, True, True, True, False]:
+        tx = [crandn(rng, Npre + S, N) for _ in range(T)]
+        rx = [crandn(rng, Npre + S, N) for _ in range(R)]
+        ref.set_background_record(rec)
+        blk.set_background_record(rec)
+        assert np.array_equal(blk.general_work(tx, rx), ref.work(tx, rx))
+    assert blk.ring_size() == ref.ring_size() == L
+
+
+def test_mimo_ofdm_radar_short_input_fails_loudly(jrc, ctx):
+    blk = jrc.mimo_ofdm_radar(64, 2, 2, 4, 5, ctx=ctx)
+    z = [np.zeros((6, 64), np.complex64)] * 2
+    with pytest.raises(jrc.JrcError) as e:
+        blk.general_work(z, z)
+    assert e.value.status == jrc.JRC_ERR_SHORT_INPUT
+
+
+@pytest.mark.parametrize("n", [2, 4, 64, 256, 512, 2048, 8192, 16384])
+@pytest.mark.parametrize("forward,shift", [(True, False), (True, True), (False, False), (False, True)])
+def test_fft_vcc(jrc, ctx, n, forward, shift):
+    rng = np.random.default_rng(n + forward + 2 * shift)
+    batch = 5 if n <= 2048 else 2
+    x = crandn(rng, batch, n)
+    got = jrc.fft_vcc(n, forward, None, shift, ctx=ctx).work(x)
+    assert rel_err(got, oracle.fft_vcc(x, forward, shift)) < FFT_TOL
+
+
+def test_fft_vcc_window_and_impulse(jrc, ctx):
+    rng = np.random.default_rng(5)
+    n = 64
+    w = np.full(n, 1 / np.sqrt(64), np.float32)
+    x = crandn(rng, 7, n)
+    got = jrc.fft_vcc(n, False, w, True, ctx=ctx).work(x)
+    assert rel_err(got, oracle.fft_vcc(x, False, True, window=w)) < FFT_TOL
+    imp = np.zeros((1, 256), np.complex64)
+    imp[0, 3] = 1
+    got = jrc.fft_vcc(256, True, None, False, ctx=ctx).work(imp)
+    assert rel_err(got, np.exp(-2j * np.pi * 3 * np.arange(256) / 256)) < FFT_TOL
+    with pytest.raises(jrc.JrcError) as e:
+        jrc.fft_vcc(40, True, ctx=ctx).work(np.zeros(40, np.complex64))
+    assert e.value.status == jrc.JRC_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("P,L,Ia", [(8, 512, 16), (16, 2048, 16), (16, 8192, 16), (3, 50, 2), (64, 64, 1), (1, 7, 4)])
+def test_matrix_transpose(jrc, ctx, P, L, Ia):
+    rng = np.random.default_rng(P * L)
+    x = crandn(rng, P, L)
+    blk = jrc.matrix_transpose(L, P, Ia, ctx=ctx)
+    assert blk.calculate_output_stream_length(P) == L
+    assert np.array_equal(blk.work(x), oracle.matrix_transpose(x, L, P, Ia))
+
+
+def test_matrix_transpose_length_mismatch(jrc, ctx):
+    with pytest.raises(RuntimeError, match="MATRIX TRANSPOSE"):
+        jrc.matrix_transpose(10, 4, 1, ctx=ctx).work(np.zeros((3, 10), np.complex64))
+
+
+@pytest.mark.parametrize("N,cp,k,tail", [(64, 16, 9, 0), (256, 64, 69, 5), (1024, 256, 133, 0), (16, 0, 3, 1), (7, 3, 4, 2)])
+def test_cp_remover(jrc, ctx, N, cp, k, tail):
+    rng = np.random.default_rng(N + cp)
+    x = crandn(rng, k * (N + cp) + tail)
+    blk = jrc.ofdm_cyclic_prefix_remover(N, cp, ctx=ctx)
+    assert blk.calculate_output_stream_length(x.size) == k
+    assert np.array_equal(blk.work(x), oracle.cp_remove(x, N, cp))
+
+
+@pytest.mark.parametrize("N,cp,k", [(64, 16, 9), (256, 64, 69), (1024, 256, 133)])
+def test_cp_remover_fused_with_rx_fft(jrc, ctx, N, cp, k):
+    rng = np.random.default_rng(N)
+    x = crandn(rng, k * (N + cp))
+    got = jrc.ofdm_cyclic_prefix_remover(N, cp, ctx=ctx).work(x, fused_fft=True)
+    ref = oracle.fft_vcc(oracle.cp_remove(x, N, cp), True, True)
+    assert rel_err(got, ref) < FFT_TOL
+
+
+def _axes(jrc, N=64, Ir=8, P=8, Ia=16):
+    return jrc.radar_axes(N, 125e6, Ir, P, Ia)
+
+
+def _same_result(g, o):
+    for k in ("peak_range_idx", "peak_angle_idx", "angle_null_idx", "discard_range_idx", "discard_angle_idx",
+              "n_noise_samples", "published"):
+        assert getattr(g, k) == getattr(o, k), k
+    for k in ("peak_power", "noise_power", "snr_est", "range_val", "angle_val"):
+        a, b = getattr(g, k), getattr(o, k)
+        assert a == b or (np.isnan(a) and np.isnan(b)), (k, a, b)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_range_angle_estimator_random_maps_bit_exact(jrc, ctx, seed):
+    rng = np.random.default_rng(seed)
+    rb, ab = _axes(jrc)
+    m = crandn(rng, 512, 128, scale=0.05)
+    pr, pa = rng.integers(0, 512), rng.integers(0, 128)
+    m[pr, pa] += 3.0
+    est = jrc.range_angle_estimator(128, rb, ab, 2.4, 28.96, 15.0, 0.0, ctx=ctx)
+    _same_result(est.work(m), oracle.ra_estimate(m, rb, ab, 2.4, 28.96, 15.0, 0.0))
+
+
+@pytest.mark.parametrize("bin_", [0, 1, 60, 63, 64, 100, 126, 127])
+def test_range_angle_estimator_null_angle_paths(jrc, ctx, bin_):
+    rb, ab = _axes(jrc)
+    m = np.full((512, 128), 0.1, np.complex64)
+    m[500, bin_] = 5.0                       # also wraps the range window
+    est = jrc.range_angle_estimator(128, rb, ab, 2.4, 28.96, 15.0, 0.0, ctx=ctx)
+    _same_result(est.work(m), oracle.ra_estimate(m, rb, ab, 2.4, 28.96, 15.0, 0.0))
+
+
+def test_range_angle_estimator_ties_zero_map_and_thresholds(jrc, ctx):
+    rb, ab = _axes(jrc)
+    m = np.full((512, 128), 0.1, np.complex64)
+    for cell in [(300, 5), (7, 64), (7, 63)]:
+        m[cell] = 2.0
+    est = jrc.range_angle_estimator(128, rb, ab, 2.4, 28.96, 15.0, 0.0, ctx=ctx)
+    g = est.work(m)
+    assert (g.peak_range_idx, g.peak_angle_idx) == (7, 63)            # first maximum in scan order
+    _same_result(g, oracle.ra_estimate(m, rb, ab, 2.4, 28.96, 15.0, 0.0))
+    z = np.zeros((512, 128), np.complex64)                            # all-zero map: cell (0,0), snr = nan
+    _same_result(est.work(z), oracle.ra_estimate(z, rb, ab, 2.4, 28.96, 15.0, 0.0))
+    est.set_snr_threshold(100.0)
+    assert est.work(m).published == 0
+    est.set_snr_threshold(1.0)
+    est.set_power_threshold(10.0)
+    assert est.work(m).published == 0
+
+
+def test_range_angle_estimator_config_d_map(jrc, ctx):
+    rng = np.random.default_rng(9)
+    rb, ab = jrc.radar_axes(1024, 125e6, 8, 16, 16)
+    m = crandn(rng, 8192, 256, scale=0.01)
+    m[4097, 200] = 1.0
+    est = jrc.range_angle_estimator(256, rb, ab, 2.4, 14.36, 15.0, 0.0, ctx=ctx)
+    _same_result(est.work(m), oracle.ra_estimate(m, rb, ab, 2.4, 14.36, 15.0, 0.0))
+
+
+def test_fft_peak_detect(jrc, ctx):
+    rng = np.random.default_rng(3)
+    n, fs, interp = 40000, 125000000, 8.0            # the USRP alignment flowgraph's size (not a power of two)
+    det = jrc.fft_peak_detect(fs, interp, -20.0, 10, ctx=ctx)
+    for pk in (123, 20000, 20001, 39900):
+        x = crandn(rng, n, scale=0.001)
+        x[pk] = 2 * np.exp(1.1j)
+        g = det.work(x)
+        o = oracle.fft_peak_detect(x, fs, interp, -20.0, 10)
+        assert g == o and g[0] == pk
+    x = crandn(rng, n, scale=0.001)
+    det.set_threshold(30.0)
+    g = det.work(x)
+    assert g[0] == -1 and np.isnan(g[1])                                 # outputs untouched, one item produced
+    det.set_threshold(-20.0)
+    x[5] = 100.0
+    x[700] = 3.0
+    x[900] = 3.0
+    assert det.work(x)[0] == oracle.fft_peak_detect(x, fs, interp, -20.0, 10)[0] == 700

@@ -1,0 +1,118 @@
+"""GPU tier: the fused device-resident radar chain (A1->A5) against the oracle's block-by-block chain."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+MAP_TOL = 1e-4        # north-star tolerance on ||a-b||_inf / ||b||_inf for complex-float tensors
+FFT_TOL = 5e-6        # what we actually hold against the double-precision definition
+
+
+def run_chain(jrc, ctx, sc, Ir, Ia, F, frames=None, interleave=False):
+    import torch
+    from jrc_amd import synth
+    P = sc.T * sc.R
+    if frames is None:
+        frames = synth.make_frames(sc, F)
+    rb, ab = jrc.radar_axes(sc.N, sc.fs, Ir, P, Ia)
+    ndr, nda = 2 * 3e8 / (2 * sc.fs), 2 * float(np.rad2deg(np.arcsin(2 / P))) if P > 2 else 30.0
+    chain = jrc.RadarChain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb, ab, ndr, nda, 15.0, 0.0,
+                           enable_tx_interleave=interleave, max_frames=F, ctx=ctx)
+    bufs = chain.alloc(F, "cuda:0")
+    bufs["frames"].copy_(torch.from_numpy(frames.view(np.float32).reshape(bufs["frames"].shape)))
+    bufs["map"].fill_(float("nan"))          # every cell must be written by the kernel
+    torch.cuda.synchronize()
+    chain.run(bufs, F)
+    res = chain.results(bufs, F)
+    gmap = bufs["map"].cpu().numpy().view(np.complex64)[..., 0]
+    gH = bufs["chanest"].cpu().numpy().view(np.complex64)[..., 0]
+    return frames, gH, gmap, res, (rb, ab, ndr, nda)
+
+
+def oracle_chain(sc, Ir, Ia, frame, interleave=False):
+    P = sc.T * sc.R
+    rad = oracle.Radar(sc.N, sc.T, sc.R, sc.S, sc.Npre, interp_factor=Ir, enable_tx_interleave=interleave)
+    H = rad.work([frame[t] for t in range(sc.T)], [frame[sc.T + r] for r in range(sc.R)])
+    rng = oracle.fft_vcc(H, False, False)                          # fft_vxx reverse, no shift, N*Ir
+    tr = oracle.matrix_transpose(rng, sc.N * Ir, P, Ia)            # matrix_transpose
+    return H, oracle.fft_vcc(tr, True, True)                       # fft_vxx forward, shift, P*Ia
+
+
+def check(jrc, ctx, sc, Ir, Ia, F, n_check=None, interleave=False):
+    frames, gH, gmap, res, (rb, ab, ndr, nda) = run_chain(jrc, ctx, sc, Ir, Ia, F, interleave=interleave)
+    assert not np.isnan(gmap.view(np.float32)).any()
+    for f in range(F if n_check is None else n_check):
+        H, m = oracle_chain(sc, Ir, Ia, frames[f], interleave)
+        assert np.array_equal(gH[f], H[:, :sc.N])                   # A1 is bit-exact
+        assert rel_err(gmap[f], m) < FFT_TOL < MAP_TOL              # A2-A4
+        o = oracle.ra_estimate(gmap[f], rb, ab, ndr, nda, 15.0, 0.0)   # A5 on the same map: exact
+        g = res[f]
+        for k in ("peak_range_idx", "peak_angle_idx", "angle_null_idx", "n_noise_samples", "published"):
+            assert getattr(g, k) == getattr(o, k), k
+        for k in ("peak_power", "noise_power", "snr_est", "range_val", "angle_val"):
+            assert getattr(g, k) == getattr(o, k), k
+        # and against the oracle's own map: same cell unless two cells tie within float rounding
+        o2 = oracle.ra_estimate(m, rb, ab, ndr, nda, 15.0, 0.0)
+        if (o2.peak_range_idx, o2.peak_angle_idx) != (g.peak_range_idx, g.peak_angle_idx):
+            assert abs(o2.peak_power - g.peak_power) <= 1e-5 * o2.peak_power
+        assert abs(o2.snr_est - g.snr_est) < 1e-2
+    return frames, gmap, res
+
+
+def test_chain_config_a_siso(jrc, ctx):
+    from jrc_amd import synth
+    frames, gmap, res = check(jrc, ctx, synth.config_A(), 8, 16, 3)
+    assert abs(res[0].range_val - 10.0) < 0.3
+
+
+def test_chain_reference_example_shape(jrc, ctx):
+    """4 TX x 2 RX, N = 64, S = N_tx LTF symbols, Ir = 8, Ia = 16: the radar_sim flowgraph's operating point"""
+    from jrc_amd import synth
+    sc = synth.Scenario(64, 4, 2, 4, targets=[(25.0, -30.0, 0.0, 100.0)])
+    frames, gmap, res = check(jrc, ctx, sc, 8, 16, 9)
+    assert abs(res[0].range_val - 25.0) < 0.3 and abs(res[0].angle_val + 30.0) < 2.0
+
+
+def test_chain_config_b(jrc, ctx):
+    from jrc_amd import synth
+    frames, gmap, res = check(jrc, ctx, synth.config_B(), 8, 16, 10, n_check=3)
+    for r in res:
+        assert abs(r.range_val - 10.0) < 0.2 and abs(r.angle_val - 20.0) < 1.0 and r.published == 1
+
+
+def test_chain_config_d_eight_targets(jrc, ctx):
+    from jrc_amd import synth
+    check(jrc, ctx, synth.config_D(), 8, 16, 3, n_check=2)
+
+
+@pytest.mark.parametrize("T,R,N,S,Ir,Ia,interleave", [(2, 1, 128, 3, 4, 8, False), (2, 2, 64, 2, 2, 2, True),
+                                                      (4, 4, 512, 8, 1, 4, False), (1, 2, 2048, 2, 2, 32, False)])
+def test_chain_other_shapes(jrc, ctx, T, R, N, S, Ir, Ia, interleave):
+    from jrc_amd import synth
+    sc = synth.Scenario(N, T, R, S, targets=[(8.0, 10.0, 5.0, 50.0)])
+    check(jrc, ctx, sc, Ir, Ia, 2, interleave=interleave)
+
+
+def test_chain_linearity_and_frame_independence(jrc, ctx):
+    """size-independent properties at config-B size: map(a*rx) = a*map(rx); a frame's result does not depend
+    on its neighbours in the batch or on its slot."""
+    from jrc_amd import synth
+    sc = synth.config_B()
+    fr = synth.make_frames(sc, 4)
+    _, _, m1, r1, _ = run_chain(jrc, ctx, sc, 8, 16, 4, frames=fr)
+    fr2 = fr[::-1].copy()
+    fr2[:, sc.T:] *= 2.0                                   # scale RX by 2 (exact in float)
+    _, _, m2, r2, _ = run_chain(jrc, ctx, sc, 8, 16, 4, frames=fr2)
+    assert np.array_equal(m2[::-1], 2.0 * m1)
+    for a, b in zip(r1, r2[::-1]):
+        assert (a.peak_range_idx, a.peak_angle_idx) == (b.peak_range_idx, b.peak_angle_idx)
+        assert b.peak_power == 4.0 * a.peak_power
+
+
+def test_chain_unsupported_shape_fails_loudly(jrc, ctx):
+    rb, ab = jrc.radar_axes(48, 125e6, 8, 8, 16)
+    with pytest.raises(jrc.JrcError) as e:
+        jrc.RadarChain(48, 4, 2, 4, 5, 8, 16, rb, ab, 2.4, 29.0, ctx=ctx)
+    assert e.value.status == jrc.JRC_ERR_UNSUPPORTED
