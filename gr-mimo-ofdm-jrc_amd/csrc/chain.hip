@@ -194,11 +194,11 @@ static int launch_fused(jrc_chain* ch, int n_frames, const float2* d_H, float2* 
 {
     const int groups = (n_frames + 7) / 8;
     dim3 grid((unsigned)(groups * 8 * ch->C));
-    static bool attr_set = false;
-    if (!attr_set) {
+    static size_t attr_bytes = 64 * 1024;   // dynamic LDS above 64 KiB must be opted into per kernel
+    if (ch->lds_bytes > attr_bytes) {
         JRC_HIP(ch->ctx, hipFuncSetAttribute((const void*)range_angle_fused_kernel<P>,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)ch->lds_bytes));
+        attr_bytes = ch->lds_bytes;
     }
     hipLaunchKernelGGL((range_angle_fused_kernel<P>), grid, dim3(256), ch->lds_bytes, s, d_H, d_map, ch->d_partials,
                        ch->twR, ch->twA, ch->cfg.fft_len, ch->NR, ch->cfg.interp_angle, n_frames);

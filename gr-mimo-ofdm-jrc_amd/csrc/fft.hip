@@ -76,10 +76,10 @@ int launch_fft_vcc(jrc_ctx* ctx, int n, int forward, int shift, const float* d_w
     const int per_block = 256 / tp;
     const size_t blocks = (batch + per_block - 1) / per_block;
     const size_t lds_bytes = sizeof(float2) * (size_t)n * per_block;
-    static bool attr_set = false;
-    if (!attr_set) {
-        JRC_HIP(ctx, hipFuncSetAttribute((const void*)fft_pow2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+    static size_t attr_bytes = 64 * 1024;   // dynamic LDS above 64 KiB must be opted into per kernel
+    if (lds_bytes > attr_bytes) {
+        JRC_HIP(ctx, hipFuncSetAttribute((const void*)fft_pow2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr_bytes = lds_bytes;
     }
     hipLaunchKernelGGL(fft_pow2_kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, stream, d_in, d_out, tw,
                        d_window, n, logn, forward, shift, batch, in_stride, in_offset, tp);
