@@ -135,7 +135,9 @@ __global__ __launch_bounds__(256) void range_angle_fused_kernel(
     const int items = RA_L * ipr;
     const int amask = NA - 1, ahalf = NA >> 1;
     float2* mapf = map + (size_t)f * NR * NA;
-    for (int w = tid; w < items; w += 256) {
+    for (int w0 = 0; w0 < items; w0 += 256) {     // items is a multiple of 64: whole waves are in or out
+        const int w = w0 + tid;
+        if (w >= items) break;
         const int i = w % ipr, ql = w / ipr;
         const int k = C * ql + c;            // global range bin
         float2 x[P];
@@ -161,8 +163,19 @@ __global__ __launch_bounds__(256) void range_angle_fused_kernel(
             const int a = (Ia * u + 2 * i + ahalf) & amask;   // fftshift: out'[a'] = out[(a' + NA/2) % NA]
             float4 val = make_float4(o0[u].x, o0[u].y, o1[u].x, o1[u].y);
             *reinterpret_cast<float4*>(row + a) = val;
-            trk.visit(o0[u], flat0 + a);
-            trk.visit(o1[u], flat0 + a + 1);
+        }
+        // estimator arg-max (lib/range_angle_estimator_impl.cc:137-151) on the values still in registers
+        float m = -1.0f;
+#pragma unroll
+        for (int u = 0; u < P; u++) m = fmaxf(m, fmaxf(fast_power(o0[u]), fast_power(o1[u])));
+        const float thr = trk.raise(m);
+        if (m >= thr) {
+#pragma unroll
+            for (int u = 0; u < P; u++) {
+                const int a = (Ia * u + 2 * i + ahalf) & amask;
+                if (fast_power(o0[u]) >= thr) trk.exact(o0[u], flat0 + a);
+                if (fast_power(o1[u]) >= thr) trk.exact(o1[u], flat0 + a + 1);
+            }
         }
     }
     block_reduce_peak(trk, red);

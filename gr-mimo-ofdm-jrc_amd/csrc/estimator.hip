@@ -18,9 +18,33 @@ __global__ __launch_bounds__(256) void ra_partial_kernel(const float2* __restric
     __shared__ PeakPartial red[4];
     PeakTracker t;
     t.init();
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride)
-        t.visit(map[i], (unsigned)i);
+    // 4 cells per lane per trip (two 16-byte loads); trip count is uniform across the block so the wave-wide
+    // running maximum in PeakTracker::raise() is well defined
+    const size_t per_trip = (size_t)gridDim.x * blockDim.x * 4;
+    const size_t trips = (total + per_trip - 1) / per_trip;
+    const bool vec_ok = ((total & 1) == 0) && ((reinterpret_cast<size_t>(map) & 15) == 0);
+    for (size_t trip = 0; trip < trips; trip++) {
+        const size_t i0 = trip * per_trip + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+        float2 z[4];
+        float m = -1.0f;
+        if (vec_ok && i0 + 4 <= total) {
+            const float4 v0 = *reinterpret_cast<const float4*>(map + i0);
+            const float4 v1 = *reinterpret_cast<const float4*>(map + i0 + 2);
+            z[0] = make_float2(v0.x, v0.y); z[1] = make_float2(v0.z, v0.w);
+            z[2] = make_float2(v1.x, v1.y); z[3] = make_float2(v1.z, v1.w);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) z[j] = (i0 + j < total) ? map[i0 + j] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (i0 + j < total) m = fmaxf(m, fast_power(z[j]));
+        const float thr = t.raise(m);
+        if (m >= thr) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (i0 + j < total && fast_power(z[j]) >= thr) t.exact(z[j], (unsigned)(i0 + j));
+        }
+    }
     block_reduce_peak(t, red);
     if (threadIdx.x == 0) { partials[blockIdx.x].best = t.best; partials[blockIdx.x].idx = t.idx; }
 }

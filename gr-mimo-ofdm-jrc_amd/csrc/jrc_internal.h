@@ -74,23 +74,35 @@ __device__ __forceinline__ float ref_hypotf(float2 z)
     return (float)sqrt(d);
 }
 
-// running first-arg-max with the reference's strict '>' semantics, filtered by a cheap f32 test so
-// that the f64 path above only runs for candidates within 1e-5 of the running maximum.
+// Running first-arg-max with the reference's strict '>' semantics (ties -> lowest flat index = first in the
+// reference's scan order).  The exact f64 power above is only evaluated for candidates whose cheap f32 power
+// is within 1e-5 of a WAVE-wide running maximum: f32 and exact powers differ by < 4e-7 relative, so the true
+// arg-max always passes the filter, while after the first few elements almost no lane does, and the
+// divergent f64 path stays off the streaming critical path.
+__device__ __forceinline__ float fast_power(float2 z) { return fmaf(z.x, z.x, z.y * z.y); }
+
+__device__ __forceinline__ float wave_max_f32(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
 struct PeakTracker {
-    float fast_max;   // max of re*re+im*im seen so far (f32)
-    float thr;        // fast_max * (1 - 1e-5)
-    float best;       // exact power of the best candidate
+    float run_max;    // wave-uniform running maximum of the f32 powers
+    float best;       // exact power of the best candidate seen by this lane
     unsigned idx;     // its flat index
-    __device__ __forceinline__ void init() { fast_max = -1.0f; thr = -1.0f; best = -1.0f; idx = 0xffffffffu; }
-    __device__ __forceinline__ void visit(float2 z, unsigned flat)
+    __device__ __forceinline__ void init() { run_max = -1.0f; best = -1.0f; idx = 0xffffffffu; }
+    // all lanes of the wave call this together with their local f32 maximum; returns the filter threshold
+    __device__ __forceinline__ float raise(float lane_max)
     {
-        float pf = fmaf(z.x, z.x, z.y * z.y);
-        if (pf >= thr) {
-            float pe = (float)ref_power_f64(z);
-            if (pe > best || (pe == best && flat < idx)) { best = pe; idx = flat; }
-            fast_max = fmaxf(fast_max, pf);
-            thr = fast_max * (1.0f - 1e-5f);
-        }
+        run_max = fmaxf(run_max, wave_max_f32(lane_max));
+        return run_max * (1.0f - 1e-5f);
+    }
+    __device__ __forceinline__ void exact(float2 z, unsigned flat)
+    {
+        float pe = (float)ref_power_f64(z);
+        if (pe > best || (pe == best && flat < idx)) { best = pe; idx = flat; }
     }
     __device__ __forceinline__ void merge(float obest, unsigned oidx)
     {

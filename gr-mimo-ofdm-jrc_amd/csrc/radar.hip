@@ -9,54 +9,63 @@
 #include "radar_kernels.h"
 
 // ------------------------------------------------------------------------------------------------
-template <int T, int R>
+// One lane per (subcarrier, RX antenna): T accumulators in registers, symbols consumed in batches of U
+// so that U*(T+1) independent 8-byte loads are in flight per lane before the first dependent use.  The R
+// waves of a workgroup walk the same TX rows, so the T re-reads of each TX row hit L1/L2, not HBM.
+template <int T, int U>
 __global__ __launch_bounds__(256) void radar_chanest_kernel(const float2* __restrict__ frames,
-                                                            float2* __restrict__ H, ChanestGeom g)
+                                                            float2* __restrict__ H, ChanestGeom g, int R)
 {
 #pragma clang fp contract(off)
-    const int sc = blockIdx.x * blockDim.x + threadIdx.x;
+    const int sc = blockIdx.x * 64 + threadIdx.x;
+    const int r = threadIdx.y;
     const int f = blockIdx.y;
     if (sc >= g.N) return;
     const float2* fb = frames + (size_t)f * g.frame_stride;
-    const float2* txp[T];
-    const float2* rxp[R];
-#pragma unroll
-    for (int t = 0; t < T; t++) txp[t] = fb + (size_t)t * g.port_stride + (size_t)g.tx_item0 * g.N + sc;
-#pragma unroll
-    for (int r = 0; r < R; r++) rxp[r] = fb + (size_t)(T + r) * g.port_stride + (size_t)g.rx_item0 * g.N + sc;
+    const float2* rxp = fb + (size_t)(T + r) * g.port_stride + (size_t)g.rx_item0 * g.N + sc;
+    const float2* txp = fb + (size_t)g.tx_item0 * g.N + sc;
 
-    float2 acc[R][T];
+    float2 acc[T];
 #pragma unroll
-    for (int r = 0; r < R; r++)
-#pragma unroll
-        for (int t = 0; t < T; t++) acc[r][t] = make_float2(0.f, 0.f);
+    for (int t = 0; t < T; t++) acc[t] = make_float2(0.f, 0.f);
 
-#pragma unroll 4
-    for (int sym = 0; sym < g.S; sym++) {
-        float2 tx[T], rx[R];
+    int sym = 0;
+    for (; sym + U <= g.S; sym += U) {
+        float2 rx[U], tx[U][T];
 #pragma unroll
-        for (int t = 0; t < T; t++) tx[t] = txp[t][(size_t)sym * g.N];
+        for (int u = 0; u < U; u++) {
+            rx[u] = rxp[(size_t)(sym + u) * g.N];
 #pragma unroll
-        for (int r = 0; r < R; r++) rx[r] = rxp[r][(size_t)sym * g.N];
+            for (int t = 0; t < T; t++) tx[u][t] = txp[(size_t)t * g.port_stride + (size_t)(sym + u) * g.N];
+        }
 #pragma unroll
-        for (int r = 0; r < R; r++)
+        for (int u = 0; u < U; u++)
 #pragma unroll
             for (int t = 0; t < T; t++) {
                 // rx * conj(tx) = (ac + bd) + j(bc - ad), products rounded individually (:273)
-                float pr = rx[r].x * tx[t].x + rx[r].y * tx[t].y;
-                float pi = rx[r].y * tx[t].x - rx[r].x * tx[t].y;
-                acc[r][t].x = acc[r][t].x + pr;
-                acc[r][t].y = acc[r][t].y + pi;
+                float pr = rx[u].x * tx[u][t].x + rx[u].y * tx[u][t].y;
+                float pi = rx[u].y * tx[u][t].x - rx[u].x * tx[u][t].y;
+                acc[t].x = acc[t].x + pr;
+                acc[t].y = acc[t].y + pi;
             }
+    }
+    for (; sym < g.S; sym++) {
+        float2 rx = rxp[(size_t)sym * g.N];
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            float2 tx = txp[(size_t)t * g.port_stride + (size_t)sym * g.N];
+            float pr = rx.x * tx.x + rx.y * tx.y;
+            float pi = rx.y * tx.x - rx.x * tx.y;
+            acc[t].x = acc[t].x + pr;
+            acc[t].y = acc[t].y + pi;
+        }
     }
     float2* Hf = H + (size_t)f * T * R * g.N;
 #pragma unroll
-    for (int r = 0; r < R; r++)
-#pragma unroll
-        for (int t = 0; t < T; t++) {
-            const int p = g.interleave ? (t * R + r) : (r * T + t);   // :262-269
-            Hf[(size_t)p * g.N + sc] = acc[r][t];
-        }
+    for (int t = 0; t < T; t++) {
+        const int p = g.interleave ? (t * R + r) : (r * T + t);   // :262-269
+        Hf[(size_t)p * g.N + sc] = acc[t];
+    }
 }
 
 // any T, R: one lane per (pair, subcarrier)
@@ -88,19 +97,17 @@ __global__ __launch_bounds__(256) void radar_chanest_generic_kernel(const float2
 int launch_radar_chanest(jrc_ctx* ctx, int T, int R, const float2* d_frames, float2* d_H,
                          const ChanestGeom& g, int n_frames, hipStream_t stream)
 {
-    const int threads = g.N >= 256 ? 256 : (g.N <= 64 ? 64 : ((g.N + 63) / 64) * 64);
-    dim3 grid((g.N + threads - 1) / threads, n_frames, 1);
-#define JRC_CASE(TT, RR)                                                                             \
-    if (T == TT && R == RR) {                                                                        \
-        hipLaunchKernelGGL((radar_chanest_kernel<TT, RR>), grid, dim3(threads), 0, stream, d_frames, \
-                           d_H, g);                                                                  \
-        JRC_HIP(ctx, hipGetLastError());                                                             \
-        return JRC_OK;                                                                               \
+    if (n_frames <= 0 || g.N <= 0) return JRC_OK;
+    if (R <= 4 && (T == 1 || T == 2 || T == 4)) {
+        dim3 grid((g.N + 63) / 64, n_frames, 1), block(64, R, 1);
+        if (T == 1) hipLaunchKernelGGL((radar_chanest_kernel<1, 8>), grid, block, 0, stream, d_frames, d_H, g, R);
+        else if (T == 2) hipLaunchKernelGGL((radar_chanest_kernel<2, 8>), grid, block, 0, stream, d_frames, d_H, g, R);
+        else hipLaunchKernelGGL((radar_chanest_kernel<4, 8>), grid, block, 0, stream, d_frames, d_H, g, R);
+        JRC_HIP(ctx, hipGetLastError());
+        return JRC_OK;
     }
-    JRC_CASE(1, 1) JRC_CASE(1, 2) JRC_CASE(1, 4) JRC_CASE(2, 1) JRC_CASE(2, 2) JRC_CASE(2, 4)
-    JRC_CASE(4, 1) JRC_CASE(4, 2) JRC_CASE(4, 4)
-#undef JRC_CASE
-    grid.z = T * R;
+    const int threads = g.N >= 256 ? 256 : (g.N <= 64 ? 64 : ((g.N + 63) / 64) * 64);
+    dim3 grid((g.N + threads - 1) / threads, n_frames, T * R);
     hipLaunchKernelGGL(radar_chanest_generic_kernel, grid, dim3(threads), 0, stream, d_frames, d_H, g, T, R);
     JRC_HIP(ctx, hipGetLastError());
     return JRC_OK;
