@@ -21,6 +21,9 @@ HEADERS = ["jrc_internal.h", "radar_kernels.h", os.path.join("..", "..", "includ
 
 HIPCC_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
                "-fno-gpu-rdc"]
+# per-file extras.  chain.hip: the SLP vectorizer packs the complex butterflies into v_pk_*_f32, which on
+# gfx950 run at the scalar f32 rate but cost ~100 extra v_mov and ~50 VGPRs in the fused kernel.
+EXTRA_FLAGS = {"chain.hip": ["-fno-slp-vectorize"]}
 
 
 def hipcc():
@@ -37,10 +40,10 @@ def _mtime(p):
 def _compile(src):
     obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
     srcp = os.path.join(CSRC, src)
-    deps = [srcp] + [os.path.join(CSRC, h) for h in HEADERS]
+    deps = [srcp, os.path.abspath(__file__)] + [os.path.join(CSRC, h) for h in HEADERS]
     if _mtime(obj) >= max(_mtime(d) for d in deps):
         return obj, False
-    cmd = [hipcc()] + HIPCC_FLAGS + ["-c", srcp, "-o", obj]
+    cmd = [hipcc()] + HIPCC_FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", srcp, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))

@@ -25,6 +25,7 @@
 #include "radar_kernels.h"
 
 #include <cmath>
+#include <cstdlib>
 
 #define RA_L 64   // range bins (and fold length) per workgroup
 
@@ -72,121 +73,162 @@ __device__ __forceinline__ void fft_fwd_small(float2 (&x)[P])
 }
 
 // ---- the fused kernel ------------------------------------------------------------------------
-template <int P>
-__global__ __launch_bounds__(256) void range_angle_fused_kernel(
+// Grid: one workgroup per (frame, slice); a slice owns the residue classes c = slice + WPF*i, i < C/WPF.
+// The frame's channel estimate H (P x N) is staged in LDS once per workgroup and reused for every class;
+// the class twiddles of the NEXT class are prefetched into registers while the current class is being
+// stored, so the only exposed global-memory latency is the one H fetch per workgroup.
+// LDS = P*N*8 (H) + P*64*8 (range bins of the current class): 40 KiB for config B -> 4 workgroups per CU;
+// 136 KiB for config D -> one 1024-thread workgroup per CU.
+template <int P, int NT, int MMAX, bool TWC_LDS>
+__global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : 3))) void range_angle_fused_kernel(
     const float2* __restrict__ H,        // [F][P][N]
     float2* __restrict__ map,            // [F][NR][NA]
-    PeakPartial* __restrict__ partials,  // [F][C]
+    PeakPartial* __restrict__ partials,  // [F][WPF]
     const float2* __restrict__ twR,      // [NR]  exp(+j 2 pi i / NR)
     const float2* __restrict__ twA,      // [NA]  exp(-j 2 pi i / NA)
-    int N, int NR, int Ia, int F)
+    int N, int NR, int Ia, int F, int WPF)
 {
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    constexpr int NW = NT / 64;
     const int NA = P * Ia;
     const int C = NR / RA_L;
-    // XCD-aware decode: block b runs on XCD b%8; all residue classes of a frame share that frame's H,
+    // XCD-aware decode: block b runs on XCD b%8; the slices of a frame share that frame's H,
     // so keep a frame's workgroups on one XCD (one L2).
     const int xcd = blockIdx.x & 7;
     const int j = blockIdx.x >> 3;
-    const int f = (j / C) * 8 + xcd;
-    const int c = j % C;
+    const int f = (j / WPF) * 8 + xcd;
+    const int slice = j % WPF;
     if (f >= F) return;
 
-    float2* s_twc = smem;                       // [N]   exp(+j 2 pi n c / NR)
-    float2* s_g = s_twc + N;                    // [P][65]
-    float2* s_twA = s_g + P * (RA_L + 1);       // [NA]
-    float2* s_tw64 = s_twA + NA;                // [32]  exp(+j 2 pi k / 64)
-    __shared__ PeakPartial red[4];
+    float2* s_H = smem;                         // [P][N]
+    float2* s_g = s_H + (size_t)P * N;          // [P][64]; reused as reduction scratch at the end
+    float2* s_twc = s_g + P * RA_L;             // [N] class twiddles (TWC_LDS only)
+    constexpr int NPT = TWC_LDS ? 4 : 1;        // class twiddles prefetched per thread (N <= NT*NPT)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int n = tid; n < N; n += 256) s_twc[n] = twR[(int)(((long)n * c) % NR)];
-    for (int a = tid; a < NA; a += 256) s_twA[a] = twA[a];
-    if (tid < 32) s_tw64[tid] = twR[tid * (NR / 64)];
-    __syncthreads();
+    const int M = N / RA_L;                     // fold length per lane, <= MMAX
 
-    // ---- range axis: fold to 64 points, 64-point inverse FFT across the wavefront -----------------
-    const float2* Hf = H + (size_t)f * P * N;
-    for (int p = wave; p < P; p += 4) {
-        const float2* Hp = Hf + (size_t)p * N;
-        float2 v = make_float2(0.f, 0.f);
-        for (int n = lane; n < N; n += RA_L) {
-            float2 h = Hp[n], w = s_twc[n];
-            v.x = fmaf(h.x, w.x, fmaf(-h.y, w.y, v.x));
-            v.y = fmaf(h.x, w.y, fmaf(h.y, w.x, v.y));
-        }
+    // class twiddles for this lane's fold inputs n = lane + 64 m:  exp(+j 2 pi n c / NR)
+    // (large N: staged through LDS one class ahead instead of living in registers across the store phase)
+    float2 tc[TWC_LDS ? 1 : MMAX];
+    float2 tn[NPT];
+    if constexpr (TWC_LDS) {
 #pragma unroll
-        for (int half = 32; half >= 1; half >>= 1) {     // radix-2 DIF, twiddle exp(+j 2 pi k / (2 half))
-            float2 o = make_float2(__shfl_xor(v.x, half), __shfl_xor(v.y, half));
-            if (lane & half) {
-                float2 d = csub(o, v);
-                v = cmul(d, s_tw64[(lane & (half - 1)) * (32 / half)]);
-            } else {
-                v = cadd(v, o);
-            }
-        }
-        s_g[p * (RA_L + 1) + (__brev((unsigned)lane) >> 26)] = v;   // lane holds X[bitrev6(lane)]
+        for (int q = 0; q < NPT; q++) { const int n = tid + NT * q; if (n < N) tn[q] = twR[(n * slice) & (NR - 1)]; }
+    } else {
+#pragma unroll
+        for (int m = 0; m < MMAX; m++)
+            if (m < M) tc[m] = twR[((lane + RA_L * m) * slice) & (NR - 1)];     // n*c < 2^31
     }
-    __syncthreads();
+    {
+        // stage H: 16-byte loads, fully coalesced
+        const float4* Hf4 = reinterpret_cast<const float4*>(H + (size_t)f * P * N);
+        float4* sH4 = reinterpret_cast<float4*>(s_H);
+        for (int i = tid; i < (P * N) / 2; i += NT) sH4[i] = Hf4[i];
+    }
+    // 64-point inverse FFT twiddles of this lane, one per radix-2 stage: exp(+j 2 pi k / (2 half))
+    float2 t64[6];
+#pragma unroll
+    for (int st = 0; st < 6; st++) {
+        const int half = 32 >> st;
+        t64[st] = twR[((lane & (half - 1)) * (32 / half)) * (NR / 64)];
+    }
+    // angle twiddles of this lane's residue r = tid % Ia:  exp(-j 2 pi p r / NA)
+    const int r = tid % Ia;
+    float2 ta[P];
+#pragma unroll
+    for (int p = 1; p < P; p++) ta[p] = twA[(p * r) & (NA - 1)];
 
-    // ---- angle axis + fftshift + store + arg-max -------------------------------------------------
     PeakTracker trk;
     trk.init();
-    const int ipr = Ia >> 1;                 // residue pairs per range bin
-    const int items = RA_L * ipr;
-    const int amask = NA - 1, ahalf = NA >> 1;
+    const int items = RA_L * Ia;                // (range bin, residue) pairs per class; a multiple of 64
+    const int ahalf = NA >> 1, amask = NA - 1;
     float2* mapf = map + (size_t)f * NR * NA;
-    for (int w0 = 0; w0 < items; w0 += 256) {     // items is a multiple of 64: whole waves are in or out
-        const int w = w0 + tid;
-        if (w >= items) break;
-        const int i = w % ipr, ql = w / ipr;
-        const int k = C * ql + c;            // global range bin
-        float2 x[P];
+
+#pragma unroll 1
+    for (int c = slice; c < C; c += WPF) {
+        if constexpr (TWC_LDS) {
 #pragma unroll
-        for (int p = 0; p < P; p++) x[p] = s_g[p * (RA_L + 1) + ql];
-        float2 o0[P], o1[P];
-        {
-            const int r = 2 * i;
+            for (int q = 0; q < NPT; q++) { const int n = tid + NT * q; if (n < N) s_twc[n] = tn[q]; }
+        }
+        __syncthreads();                        // s_H staged (first trip) / previous class's s_g reads done
+        // ---- range axis: fold to 64 points, 64-point inverse FFT across the wavefront -------------
+#pragma unroll 1
+        for (int p = wave; p < P; p += NW) {
+            const float2* Hp = s_H + (size_t)p * N + lane;
+            float2 v = make_float2(0.f, 0.f);
 #pragma unroll
-            for (int p = 0; p < P; p++) o0[p] = (p == 0) ? x[0] : cmul(x[p], s_twA[(p * r) & amask]);
-            fft_fwd_small<P>(o0);
+            for (int m = 0; m < MMAX; m++)
+                if (m < M) {
+                    float2 w;
+                    if constexpr (TWC_LDS) w = s_twc[lane + RA_L * m]; else w = tc[m];
+                    const float2 h = Hp[RA_L * m];
+                    v.x = fmaf(h.x, w.x, fmaf(-h.y, w.y, v.x));
+                    v.y = fmaf(h.x, w.y, fmaf(h.y, w.x, v.y));
+                }
+#pragma unroll
+            for (int st = 0; st < 6; st++) {   // radix-2 DIF
+                const int half = 32 >> st;
+                const float2 o = make_float2(__shfl_xor(v.x, half), __shfl_xor(v.y, half));
+                v = (lane & half) ? cmul(csub(o, v), t64[st]) : cadd(v, o);
+            }
+            s_g[p * RA_L + (__brev((unsigned)lane) >> 26)] = v;   // lane holds X[bitrev6(lane)]
         }
         {
-            const int r = 2 * i + 1;
+            const int cn = c + WPF;             // prefetch the next class's twiddles; they land during the stores
+            if (cn < C) {
+                if constexpr (TWC_LDS) {
 #pragma unroll
-            for (int p = 0; p < P; p++) o1[p] = (p == 0) ? x[0] : cmul(x[p], s_twA[(p * r) & amask]);
-            fft_fwd_small<P>(o1);
+                    for (int q = 0; q < NPT; q++) { const int n = tid + NT * q; if (n < N) tn[q] = twR[(n * cn) & (NR - 1)]; }
+                } else {
+#pragma unroll
+                    for (int m = 0; m < MMAX; m++)
+                        if (m < M) tc[m] = twR[((lane + RA_L * m) * cn) & (NR - 1)];
+                }
+            }
         }
-        float2* row = mapf + (size_t)k * NA;
-        const unsigned flat0 = (unsigned)k * (unsigned)NA;
+        __syncthreads();
+
+        // ---- angle axis + fftshift + store + arg-max ---------------------------------------------
+#pragma unroll 1
+        for (int w0 = 0; w0 < items; w0 += NT) {     // whole waves are in or out
+            const int w = w0 + tid;
+            if (w >= items) break;
+            const int ql = w / Ia;               // (w % Ia == r because Ia divides NT)
+            const int k = C * ql + c;            // global range bin
+            float2 y[P];
+            y[0] = s_g[ql];
 #pragma unroll
-        for (int u = 0; u < P; u++) {
-            const int a = (Ia * u + 2 * i + ahalf) & amask;   // fftshift: out'[a'] = out[(a' + NA/2) % NA]
-            float4 val = make_float4(o0[u].x, o0[u].y, o1[u].x, o1[u].y);
-            *reinterpret_cast<float4*>(row + a) = val;
-        }
-        // estimator arg-max (lib/range_angle_estimator_impl.cc:137-151) on the values still in registers
-        float m = -1.0f;
-#pragma unroll
-        for (int u = 0; u < P; u++) m = fmaxf(m, fmaxf(fast_power(o0[u]), fast_power(o1[u])));
-        const float thr = trk.raise(m);
-        if (m >= thr) {
+            for (int p = 1; p < P; p++) y[p] = cmul(s_g[p * RA_L + ql], ta[p]);
+            fft_fwd_small<P>(y);
+            float2* row = mapf + (size_t)k * NA;
+            float m = -1.0f;
 #pragma unroll
             for (int u = 0; u < P; u++) {
-                const int a = (Ia * u + 2 * i + ahalf) & amask;
-                if (fast_power(o0[u]) >= thr) trk.exact(o0[u], flat0 + a);
-                if (fast_power(o1[u]) >= thr) trk.exact(o1[u], flat0 + a + 1);
+                const int a = (Ia * u + r + ahalf) & amask;   // fftshift: out'[a'] = out[(a' + NA/2) % NA]
+                row[a] = y[u];
+                m = fmaxf(m, fast_power(y[u]));
+            }
+            // estimator arg-max (lib/range_angle_estimator_impl.cc:137-151) on the values still in registers
+            const float thr = trk.raise(m);
+            if (m >= thr) {
+                const unsigned flat0 = (unsigned)k * (unsigned)NA;
+#pragma unroll
+                for (int u = 0; u < P; u++)
+                    if (fast_power(y[u]) >= thr) trk.exact(y[u], flat0 + ((Ia * u + r + ahalf) & amask));
             }
         }
     }
-    block_reduce_peak(trk, red);
-    if (tid == 0) { partials[(size_t)f * C + c].best = trk.best; partials[(size_t)f * C + c].idx = trk.idx; }
+    __syncthreads();
+    block_reduce_peak(trk, reinterpret_cast<PeakPartial*>(s_g));
+    if (tid == 0) { partials[(size_t)f * WPF + slice].best = trk.best; partials[(size_t)f * WPF + slice].idx = trk.idx; }
 }
 
 // ------------------------------------------------------------------------------------------------
 struct jrc_chain {
     jrc_ctx* ctx;
     jrc_chain_cfg cfg;
-    int P, NR, NA, C, max_frames;
+    int P, NR, NA, C, threads, wg_per_cu, n_cus, wpf_override, max_frames;
     float* d_bins = nullptr;          // range_bins (NR) then angle_bins (NA)
     PeakPartial* d_partials = nullptr;
     const float2* twR = nullptr;
@@ -202,21 +244,42 @@ struct jrc_chain {
     jrc_ra_result* h_pinned = nullptr;
 };
 
-template <int P>
-static int launch_fused(jrc_chain* ch, int n_frames, const float2* d_H, float2* d_map, hipStream_t s)
+// slices per frame: enough workgroups to fill every CU once (they are persistent over their classes), not more
+static int chain_pick_wpf(const jrc_chain* ch, int n_frames)
+{
+    if (ch->wpf_override > 0) return ch->wpf_override < ch->C ? ch->wpf_override : ch->C;
+    const int target = ch->n_cus * ch->wg_per_cu;
+    int wpf = 1;
+    while (wpf * 2 <= ch->C && (long)wpf * 2 * n_frames <= target) wpf *= 2;
+    return wpf;
+}
+
+template <int P, int NT, int MMAX, bool TWC_LDS>
+static int launch_fused_nt(jrc_chain* ch, int n_frames, int wpf, const float2* d_H, float2* d_map, hipStream_t s)
 {
     const int groups = (n_frames + 7) / 8;
-    dim3 grid((unsigned)(groups * 8 * ch->C));
+    dim3 grid((unsigned)(groups * 8 * wpf));
     static size_t attr_bytes = 64 * 1024;   // dynamic LDS above 64 KiB must be opted into per kernel
     if (ch->lds_bytes > attr_bytes) {
-        JRC_HIP(ch->ctx, hipFuncSetAttribute((const void*)range_angle_fused_kernel<P>,
+        JRC_HIP(ch->ctx, hipFuncSetAttribute((const void*)range_angle_fused_kernel<P, NT, MMAX, TWC_LDS>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ch->lds_bytes));
         attr_bytes = ch->lds_bytes;
     }
-    hipLaunchKernelGGL((range_angle_fused_kernel<P>), grid, dim3(256), ch->lds_bytes, s, d_H, d_map, ch->d_partials,
-                       ch->twR, ch->twA, ch->cfg.fft_len, ch->NR, ch->cfg.interp_angle, n_frames);
+    hipLaunchKernelGGL((range_angle_fused_kernel<P, NT, MMAX, TWC_LDS>), grid, dim3(NT), ch->lds_bytes, s, d_H, d_map,
+                       ch->d_partials, ch->twR, ch->twA, ch->cfg.fft_len, ch->NR, ch->cfg.interp_angle, n_frames, wpf);
     JRC_HIP(ch->ctx, hipGetLastError());
     return JRC_OK;
+}
+
+template <int P>
+static int launch_fused(jrc_chain* ch, int n_frames, int wpf, const float2* d_H, float2* d_map, hipStream_t s)
+{
+    // small frames: 256-thread workgroups, up to three per CU; large frames (H fills most of the LDS): one
+    // 512-thread workgroup per CU
+    if (ch->threads == 1024) return launch_fused_nt<P, 1024, 16, true>(ch, n_frames, wpf, d_H, d_map, s);
+    if (ch->threads == 512) return launch_fused_nt<P, 512, 16, true>(ch, n_frames, wpf, d_H, d_map, s);
+    if (ch->cfg.fft_len > 256) return launch_fused_nt<P, 256, 16, true>(ch, n_frames, wpf, d_H, d_map, s);
+    return launch_fused_nt<P, 256, 4, false>(ch, n_frames, wpf, d_H, d_map, s);
 }
 
 extern "C" int jrc_chain_create(jrc_ctx* ctx, const jrc_chain_cfg* cfg, const float* range_bins,
@@ -229,16 +292,35 @@ extern "C" int jrc_chain_create(jrc_ctx* ctx, const jrc_chain_cfg* cfg, const fl
         return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_create: inconsistent sizes");
     const long NR = (long)N * cfg->interp_range, NA = (long)P * cfg->interp_angle;
     if (!jrc_is_pow2(N) || N < RA_L || !jrc_is_pow2(cfg->interp_range) || !jrc_is_pow2(P) || P > 16 ||
-        !jrc_is_pow2(cfg->interp_angle) || cfg->interp_angle < 2 || NA < 4 || NR * NA >= (1L << 32) || N > 8192)
+        !jrc_is_pow2(cfg->interp_angle) || cfg->interp_angle < 2 || NA < 4 || NR * NA >= (1L << 32) || N > 1024 ||
+        cfg->interp_angle > 64 ||
+        (P * N) % 2 != 0)
         return jrc_fail(ctx, JRC_ERR_UNSUPPORTED,
-                        "fused radar chain needs power-of-two fft_len in [64, 8192], power-of-two N_tx*N_rx <= 16, "
-                        "power-of-two interpolation factors (angle >= 2); got N=%d P=%d Ir=%d Ia=%d",
+                        "fused radar chain needs power-of-two fft_len in [64, 1024], power-of-two N_tx*N_rx <= 16, "
+                        "power-of-two interpolation factors (2 <= angle <= 64); got N=%d P=%d Ir=%d Ia=%d",
                         N, P, cfg->interp_range, cfg->interp_angle);
     JRC_HIP(ctx, hipSetDevice(ctx->device));
     jrc_chain* ch = new jrc_chain();
     ch->ctx = ctx; ch->cfg = *cfg; ch->P = P; ch->NR = (int)NR; ch->NA = (int)NA; ch->C = (int)(NR / RA_L);
     ch->max_frames = max_frames;
-    ch->lds_bytes = sizeof(float2) * ((size_t)N + (size_t)P * (RA_L + 1) + (size_t)NA + 32);
+    ch->lds_bytes = sizeof(float2) * ((size_t)P * N + (size_t)P * RA_L + (N > 256 ? (size_t)N : 0));
+    ch->threads = (ch->lds_bytes > 80 * 1024) ? 512 : 256;
+    if (getenv("JRC_THREADS")) { int t = atoi(getenv("JRC_THREADS")); if ((t == 1024 || t == 512) && N > 256) ch->threads = t; else ch->threads = 256; }
+    ch->wpf_override = getenv("JRC_WPF") ? atoi(getenv("JRC_WPF")) : 0;
+    {
+        hipDeviceProp_t prop;
+        JRC_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+        ch->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        int by_lds = (int)((160 * 1024) / (ch->lds_bytes + 64));
+        int by_regs = ch->threads == 256 ? 3 : 1;          // __launch_bounds__ of the kernel variants
+        ch->wg_per_cu = by_lds < by_regs ? by_lds : by_regs;
+        if (ch->wg_per_cu < 1) ch->wg_per_cu = 1;
+        if (ch->wg_per_cu > 2) ch->wg_per_cu = 2;          // measured: 2 long-lived workgroups per CU beat 3-4 short ones
+    }
+    if (ch->lds_bytes + 64 > 160 * 1024) {
+        delete ch;
+        return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "fused radar chain: P*N = %d does not fit the 160 KiB LDS", P * N);
+    }
     hipError_t e = hipMalloc((void**)&ch->d_bins, sizeof(float) * (size_t)(NR + NA));
     if (e == hipSuccess) e = hipMemcpy(ch->d_bins, range_bins, sizeof(float) * NR, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ch->d_bins + NR, angle_bins, sizeof(float) * NA, hipMemcpyHostToDevice);
@@ -336,13 +418,14 @@ extern "C" int jrc_chain_run_dev(jrc_chain* ch, int n_frames, const jrc_cf32* d_
     JRC_TRY(launch_radar_chanest(ctx, c.N_tx, c.N_rx, (const float2*)d_frames, (float2*)d_chanest, g, n_frames, s));
     if (ev) JRC_HIP(ctx, hipEventRecord(ev[1], s));
     // A2 + A3 + A4 + arg-max half of A5
+    const int wpf = chain_pick_wpf(ch, n_frames);
     int st;
     switch (ch->P) {
-        case 1: st = launch_fused<1>(ch, n_frames, (const float2*)d_chanest, (float2*)d_map, s); break;
-        case 2: st = launch_fused<2>(ch, n_frames, (const float2*)d_chanest, (float2*)d_map, s); break;
-        case 4: st = launch_fused<4>(ch, n_frames, (const float2*)d_chanest, (float2*)d_map, s); break;
-        case 8: st = launch_fused<8>(ch, n_frames, (const float2*)d_chanest, (float2*)d_map, s); break;
-        default: st = launch_fused<16>(ch, n_frames, (const float2*)d_chanest, (float2*)d_map, s); break;
+        case 1: st = launch_fused<1>(ch, n_frames, wpf, (const float2*)d_chanest, (float2*)d_map, s); break;
+        case 2: st = launch_fused<2>(ch, n_frames, wpf, (const float2*)d_chanest, (float2*)d_map, s); break;
+        case 4: st = launch_fused<4>(ch, n_frames, wpf, (const float2*)d_chanest, (float2*)d_map, s); break;
+        case 8: st = launch_fused<8>(ch, n_frames, wpf, (const float2*)d_chanest, (float2*)d_map, s); break;
+        default: st = launch_fused<16>(ch, n_frames, wpf, (const float2*)d_chanest, (float2*)d_map, s); break;
     }
     JRC_TRY(st);
     if (ev) JRC_HIP(ctx, hipEventRecord(ev[2], s));
@@ -350,7 +433,7 @@ extern "C" int jrc_chain_run_dev(jrc_chain* ch, int n_frames, const jrc_cf32* d_
     RaParams prm;
     prm.vlen = ch->NA; prm.n_inputs = ch->NR; prm.n_range_bins = ch->NR; prm.n_angle_bins = ch->NA;
     prm.noise_discard_range_m = c.noise_discard_range_m; prm.noise_discard_angle_deg = c.noise_discard_angle_deg;
-    JRC_TRY(launch_ra_finalize(ctx, (const float2*)d_map, (size_t)ch->NR * ch->NA, ch->d_partials, ch->C, prm, ch->d_bins,
+    JRC_TRY(launch_ra_finalize(ctx, (const float2*)d_map, (size_t)ch->NR * ch->NA, ch->d_partials, wpf, prm, ch->d_bins,
                                ch->d_bins + ch->NR, d_results, n_frames, s));
     if (ev) JRC_HIP(ctx, hipEventRecord(ev[3], s));
     return JRC_OK;

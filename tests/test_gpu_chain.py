@@ -88,7 +88,8 @@ def test_chain_config_d_eight_targets(jrc, ctx):
 
 
 @pytest.mark.parametrize("T,R,N,S,Ir,Ia,interleave", [(2, 1, 128, 3, 4, 8, False), (2, 2, 64, 2, 2, 2, True),
-                                                      (4, 4, 512, 8, 1, 4, False), (1, 2, 2048, 2, 2, 32, False)])
+                                                      (4, 4, 512, 8, 1, 4, False), (1, 2, 1024, 2, 2, 32, False),
+                                                      (4, 1, 64, 4, 8, 64, False)])
 def test_chain_other_shapes(jrc, ctx, T, R, N, S, Ir, Ia, interleave):
     from jrc_amd import synth
     sc = synth.Scenario(N, T, R, S, targets=[(8.0, 10.0, 5.0, 50.0)])
@@ -115,4 +116,8 @@ def test_chain_unsupported_shape_fails_loudly(jrc, ctx):
     rb, ab = jrc.radar_axes(48, 125e6, 8, 8, 16)
     with pytest.raises(jrc.JrcError) as e:
         jrc.RadarChain(48, 4, 2, 4, 5, 8, 16, rb, ab, 2.4, 29.0, ctx=ctx)
+    assert e.value.status == jrc.JRC_ERR_UNSUPPORTED
+    rb, ab = jrc.radar_axes(2048, 125e6, 2, 2, 32)        # fft_len above the fused kernel's LDS budget
+    with pytest.raises(jrc.JrcError) as e:
+        jrc.RadarChain(2048, 1, 2, 2, 5, 2, 32, rb, ab, 2.4, 29.0, ctx=ctx)
     assert e.value.status == jrc.JRC_ERR_UNSUPPORTED

@@ -1,0 +1,100 @@
+// store_bw.hip — micro-benchmark of map-store patterns on MI355X (tools only; not part of the product)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ inline void nt_store(float4 v, float4* p) { v4f w = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(w, (v4f*)p); }
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+// (a) linear
+__global__ void k_linear(float4* out, size_t n4) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
+    float4 v = make_float4(i, 1, 2, 3);
+    for (; i < n4; i += st) out[i] = v;
+}
+// (b) fused-kernel pattern: WG (f,c) writes rows k = C*ql + c, 64 rows, NA=256 cf32 per row (=128 float4).
+// thread item w: i = w%8, ql = w/8; for u<16: a' = 16u+2i -> float4 index (k*256 + a')/2
+template <int NT>
+__global__ void k_pattern(float4* out, int C, int F) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, f = (j / C) * 8 + xcd, c = j % C;
+    if (f >= F) return;
+    float4* mapf = out + (size_t)f * C * 64 * 128;
+    for (int w = threadIdx.x; w < 512; w += 256) {
+        int i = w & 7, ql = w >> 3, k = C * ql + c;
+        float4* row = mapf + (size_t)k * 128;
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            float4 v = make_float4(u, w, k, f);
+            if (NT) nt_store(v, row + ((16 * u + 2 * i + 128) & 255) / 2);
+            else row[((16 * u + 2 * i + 128) & 255) / 2] = v;
+        }
+    }
+}
+// (b2) same rows, but 8-byte stores: 16 lanes cover one 128-byte line (one residue per lane)
+__global__ void k_pattern_x2(float2* out, int C, int F) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, f = (j / C) * 8 + xcd, c = j % C;
+    if (f >= F) return;
+    float2* mapf = out + (size_t)f * C * 64 * 256;
+    for (int w = threadIdx.x; w < 1024; w += 256) {
+        int r = w & 15, ql = w >> 4, k = C * ql + c;
+        float2* row = mapf + (size_t)k * 256;
+#pragma unroll
+        for (int u = 0; u < 16; u++) row[(16 * u + r + 128) & 255] = make_float2(u, w);
+    }
+}
+// (d) row-contiguous: each wave writes 1 KB contiguous per instruction; WG writes its 64 rows, 2 instr per row
+template <int NT>
+__global__ void k_rows(float4* out, int C, int F) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, f = (j / C) * 8 + xcd, c = j % C;
+    if (f >= F) return;
+    float4* mapf = out + (size_t)f * C * 64 * 128;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int ql = wave; ql < 64; ql += 4) {
+        float4* row = mapf + (size_t)(C * ql + c) * 128;
+        float4 v = make_float4(ql, lane, c, f);
+        if (NT) { nt_store(v, row + lane); nt_store(v, row + 64 + lane); }
+        else { row[lane] = v; row[64 + lane] = v; }
+    }
+}
+// (e) like (d) but rows of a WG are CONTIGUOUS (k = 64*c + ql): 128 KB contiguous per WG
+__global__ void k_rows_contig(float4* out, int C, int F) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, f = (j / C) * 8 + xcd, c = j % C;
+    if (f >= F) return;
+    float4* mapf = out + (size_t)f * C * 64 * 128;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int ql = wave; ql < 64; ql += 4) {
+        float4* row = mapf + (size_t)(64 * c + ql) * 128;
+        float4 v = make_float4(ql, lane, c, f);
+        row[lane] = v; row[64 + lane] = v;
+    }
+}
+
+int main() {
+    const int F = 256, C = 32;                          // config B: 256 frames x 2048 rows x 2 KB = 1 GiB
+    const size_t bytes = (size_t)F * C * 64 * 2048;
+    float4* d; CK(hipMalloc(&d, bytes));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto run = [&](const char* name, auto launch) {
+        for (int i = 0; i < 3; i++) launch();
+        hipEventRecord(e0);
+        for (int i = 0; i < 10; i++) launch();
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10;
+        printf("%-28s %8.3f ms  %7.1f GB/s\n", name, ms, bytes / ms / 1e6);
+        return 0;
+    };
+    const int grid = F * C;
+    run("linear grid=2048", [&] { hipLaunchKernelGGL(k_linear, dim3(2048), dim3(256), 0, 0, d, bytes / 16); });
+    run("linear grid=8192", [&] { hipLaunchKernelGGL(k_linear, dim3(8192), dim3(256), 0, 0, d, bytes / 16); });
+    run("linear grid=65536", [&] { hipLaunchKernelGGL(k_linear, dim3(65536), dim3(256), 0, 0, d, bytes / 16); });
+    run("pattern 128B segs", [&] { hipLaunchKernelGGL(k_pattern<0>, dim3(grid), dim3(256), 0, 0, d, C, F); });
+    run("pattern 128B segs dwordx2", [&] { hipLaunchKernelGGL(k_pattern_x2, dim3(grid), dim3(256), 0, 0, (float2*)d, C, F); });
+    run("pattern 128B segs nt", [&] { hipLaunchKernelGGL(k_pattern<1>, dim3(grid), dim3(256), 0, 0, d, C, F); });
+    run("rows 1KB/instr strided", [&] { hipLaunchKernelGGL(k_rows<0>, dim3(grid), dim3(256), 0, 0, d, C, F); });
+    run("rows 1KB/instr strided nt", [&] { hipLaunchKernelGGL(k_rows<1>, dim3(grid), dim3(256), 0, 0, d, C, F); });
+    run("rows contiguous per WG", [&] { hipLaunchKernelGGL(k_rows_contig, dim3(grid), dim3(256), 0, 0, d, C, F); });
+    CK(hipMemset(d, 0, bytes));
+    run("memset-like linear again", [&] { hipLaunchKernelGGL(k_linear, dim3(8192), dim3(256), 0, 0, d, bytes / 16); });
+    hipFree(d);
+    return 0;
+}
