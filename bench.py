@@ -148,6 +148,13 @@ def main():
         ms_step = 1e3 * elapsed / a.steps
         # algorithmic bytes of the dominant kernel: unpadded H in, complex map out
         alg_bytes = F * (P * sc.N * 8 + NR * NA * 8)
+        traffic = None
+        try:   # PMC-measured HBM bytes of the same kernel/config, collected in separate rocprofv3 --pmc passes
+            pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(a.config)
+            if pt and pt["frames_per_launch"] == F:
+                traffic = pt["hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         k_ms = kt["range_angle_fused"]
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         out = {
@@ -163,7 +170,7 @@ def main():
                        "gather_results": bool(gathered is not None)},
             "roofline": {"bound": "hbm", "kernel": "range_angle_fused_kernel<%d>" % P, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                         "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": k_ms, "launches_timed": kt["launches"]},
             "kernels_ms": {k: kt[k] for k in ("radar_chanest", "range_angle_fused", "ra_finalize")},
             "check": {"range_m": res[0].range_val, "angle_deg": res[0].angle_val, "snr_db": res[0].snr_est},
