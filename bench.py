@@ -77,7 +77,7 @@ def main():
     import torch
     import torch.distributed as dist
     import jrc_amd
-    from jrc_amd import synth
+    from jrc_amd import shard, synth
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP path is mandatory; there is no CPU fallback)")
@@ -100,7 +100,8 @@ def main():
                                max_frames=F, ctx=ctx)
     bufs = chain.alloc(F, dev)
     n_distinct = min(a.distinct, F)
-    host_frames = synth.make_frames(sc, n_distinct, first_frame=rank * F)
+    first_frame = shard.frame_shard(world * F, rank, world)[0]      # this rank's block of the global frame stream
+    host_frames = synth.make_frames(sc, n_distinct, first_frame=first_frame)
     hf = torch.from_numpy(host_frames.view(np.float32).reshape((n_distinct,) + tuple(bufs["frames"].shape[1:])))
     for f0 in range(0, F, n_distinct):
         n = min(n_distinct, F - f0)
@@ -111,15 +112,14 @@ def main():
         if world > 1:
             dist.barrier()
 
-    gathered = None
-    if a.gather_results and world > 1:
-        gathered = torch.empty((world,) + tuple(bufs["results"].shape), dtype=torch.uint8, device=dev)
+    gathered = [None]
+    do_gather = a.gather_results and world > 1
 
     def step():
         chain.run(bufs, F)
-        if gathered is not None:
+        if do_gather:                         # optional exchange step: per-frame result records over RCCL
             ctx.sync()
-            dist.all_gather_into_tensor(gathered, bufs["results"])
+            gathered[0] = shard.gather_results(bufs["results"], world * F)
 
     for _ in range(a.warmup):
         step()
@@ -138,10 +138,7 @@ def main():
     kt = chain.get_timing()
     res = chain.results(bufs, F)
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
+    elapsed = shard.max_over_ranks(elapsed, dev)
 
     if rank == 0:
         total_frames = F * a.steps * world
@@ -167,7 +164,7 @@ def main():
                                    "range_angle_estimator), %d frames/GPU/step resident in HBM"
                                    % (a.config, sc.T, sc.R, sc.N, sc.S, Ir, Ia, NR, NA, F),
                        "frames_per_gpu_per_step": F, "parallelism": "frame-sharded x%d, no data-path collective" % world,
-                       "gather_results": bool(gathered is not None)},
+                       "gather_results": bool(do_gather)},
             "roofline": {"bound": "hbm", "kernel": "range_angle_fused_kernel<%d>" % P, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,

@@ -1,0 +1,88 @@
+"""N>1 path on CPU: two gloo ranks shard a frame stream, process their blocks independently (the oracle stands
+in for the per-GPU chain here) and all-gather the per-frame result records; the gathered stream must equal
+the single-process result frame for frame."""
+import ctypes
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import jrc_amd
+from jrc_amd import shard, synth
+import oracle
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _process(frames, sc, Ir, Ia):
+    P = sc.T * sc.R
+    rb, ab = jrc_amd.radar_axes(sc.N, sc.fs, Ir, P, Ia)
+    recs = []
+    for fr in frames:
+        rad = oracle.Radar(sc.N, sc.T, sc.R, sc.S, sc.Npre, interp_factor=Ir)
+        m = rad.chain([fr[t] for t in range(sc.T)], [fr[sc.T + r] for r in range(sc.R)], Ia)
+        r = oracle.ra_estimate(m, rb, ab, 2.4, 29.0, 15.0, 0.0)
+        recs.append(np.frombuffer(ctypes.string_at(ctypes.byref(r), ctypes.sizeof(r)), np.uint8).copy())
+    return torch.from_numpy(np.stack(recs)) if recs else torch.zeros((0, ctypes.sizeof(oracle.RaResult)), dtype=torch.uint8)
+
+
+def _worker(rank, world, port, n_frames, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sc = synth.Scenario(64, 2, 2, 4, targets=[(12.0, -25.0, 0.0, 100.0)])
+    lo, hi = shard.frame_shard(n_frames, rank, world)
+    frames = synth.make_frames(sc, hi - lo, first_frame=lo)      # every rank generates only its own block
+    local = _process(frames, sc, 4, 8)
+    allr = shard.gather_results(local, n_frames)
+    t = shard.max_over_ranks(0.1 * (rank + 1))
+    if rank == 0:
+        q.put((allr.numpy().copy(), t))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames", [6, 7])
+def test_two_ranks_equal_one(n_frames):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        gathered, tmax = q.get(timeout=90)
+    finally:
+        for p in procs:
+            p.join(30)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs)
+    sc = synth.Scenario(64, 2, 2, 4, targets=[(12.0, -25.0, 0.0, 100.0)])
+    ref = _process(synth.make_frames(sc, n_frames), sc, 4, 8).numpy()
+    assert gathered.shape == ref.shape and np.array_equal(gathered, ref)
+    assert abs(tmax - 0.2) < 1e-9                         # MAX over ranks of the per-rank elapsed time
+
+
+def test_frame_shard_partitions_exactly():
+    for n in (0, 1, 5, 8, 64, 1000):
+        for w in (1, 2, 3, 4, 8):
+            blocks = [shard.frame_shard(n, r, w) for r in range(w)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(w - 1))
+            sizes = shard.shard_sizes(n, w)
+            assert max(sizes) - min(sizes) <= 1
+            for f in range(n):
+                owner = [r for r, (lo, hi) in enumerate(blocks) if lo <= f < hi]
+                assert owner == [f * w // n] or len(owner) == 1
