@@ -179,3 +179,178 @@ def fft_peak_detect(x, samp_rate, interp_factor, threshold, samp_protect):
     k = lib().orc_fft_peak_detect(samp_rate, interp_factor, threshold, samp_protect, x.size, _fp(x),
                                   _fp(f), _fp(p), _fp(m))
     return k, float(f[0]), float(p[0]), float(m[0])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# comm side: SIG codec, C1 equalizer, C2 precoder, C3 steering  (oracle/jrc_oracle_comm.c)
+# ---------------------------------------------------------------------------------------------------------
+c_int_p = C.POINTER(C.c_int)
+
+
+class EqCfg(C.Structure):
+    _fields_ = [("estimator", C.c_int), ("freq", C.c_double), ("bw", C.c_double),
+                ("fft_len", C.c_int), ("cp_len", C.c_int), ("n_data", C.c_int), ("n_pilot", C.c_int),
+                ("data_carriers", c_int_p), ("pilot_carriers", c_int_p),
+                ("n_pilot_rows", C.c_int), ("pilot_symbols", c_float_p), ("ltf_seq", c_float_p),
+                ("mapped_ltf", c_float_p), ("mapped_cols", C.c_int), ("n_mimo_ltf", C.c_int)]
+
+
+class EqEvent(C.Structure):
+    _fields_ = [("kind", C.c_int), ("offset", C.c_long),
+                ("data_bytes", C.c_uint64), ("mcs", C.c_uint64), ("packet_type", C.c_uint64),
+                ("snr", C.c_double), ("freq_offset", C.c_double), ("snr_data", C.c_double),
+                ("n_chan_mean", C.c_int), ("chan_mean", C.c_float * 32)]
+
+
+class PreCfg(C.Structure):
+    _fields_ = [("fft_len", C.c_int), ("n_tx", C.c_int), ("n_data", C.c_int), ("n_pilot", C.c_int),
+                ("data_carriers", c_int_p), ("pilot_carriers", c_int_p),
+                ("n_pilot_rows", C.c_int), ("pilot_symbols", c_float_p),
+                ("n_sync", C.c_int), ("sync_words", c_float_p), ("mapped_ltf", c_float_p)]
+
+
+def _comm_lib():
+    L = lib()
+    if not getattr(L, "_comm_ready", False):
+        L.orc_n_ofdm_sym.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.orc_sig_encode.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, c_float_p]
+        L.orc_viterbi_k7.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.POINTER(C.c_uint8)]
+        L.orc_sig_parse.argtypes = [C.POINTER(C.c_uint8), C.c_int, c_int_p, c_int_p, c_int_p, c_int_p]
+        L.orc_eq_create.restype = C.c_void_p
+        L.orc_eq_create.argtypes = [C.POINTER(EqCfg)]
+        L.orc_eq_destroy.argtypes = [C.c_void_p]
+        L.orc_eq_set_estimator.argtypes = [C.c_void_p, C.c_int]
+        L.orc_eq_work.argtypes = [C.c_void_p, C.c_int, C.c_int, c_float_p, C.POINTER(C.c_long),
+                                  C.POINTER(C.c_double), C.c_int, c_float_p, c_int_p,
+                                  C.POINTER(EqEvent), C.c_int, c_int_p, c_float_p, c_int_p]
+        L.orc_steering_from_channel.argtypes = [C.c_int, c_float_p, C.c_int, c_float_p]
+        L.orc_dft_matrix.argtypes = [C.c_int, c_float_p]
+        L.orc_precoder_work.argtypes = [C.POINTER(PreCfg), C.c_int, c_float_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        c_float_p, c_float_p, c_float_p, C.POINTER(c_float_p)]
+        L._comm_ready = True
+    return L
+
+
+def n_ofdm_sym(mcs, n_data_carriers, nbytes):
+    return _comm_lib().orc_n_ofdm_sym(mcs, n_data_carriers, nbytes)
+
+
+def sig_encode(n_data_carriers, mcs, packet_type, length):
+    out = np.zeros(n_data_carriers, np.float32)
+    assert _comm_lib().orc_sig_encode(n_data_carriers, mcs, packet_type, length, _fp(out)) == 0
+    return out
+
+
+def viterbi_k7(coded_bits):
+    coded = np.ascontiguousarray(coded_bits, np.uint8)
+    n = coded.size // 2
+    dec = np.zeros(n, np.uint8)
+    _comm_lib().orc_viterbi_k7(coded.ctypes.data_as(C.POINTER(C.c_uint8)), n, dec.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return dec
+
+
+def sig_parse(bits, n_data_carriers):
+    bits = np.ascontiguousarray(bits, np.uint8)
+    mcs, pt, ln, ns = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    ok = _comm_lib().orc_sig_parse(bits.ctypes.data_as(C.POINTER(C.c_uint8)), n_data_carriers,
+                                   C.byref(mcs), C.byref(pt), C.byref(ln), C.byref(ns))
+    return bool(ok), mcs.value, pt.value, ln.value, ns.value
+
+
+def _ip(a):
+    return a.ctypes.data_as(c_int_p)
+
+
+class Equalizer:
+    """mimo_ofdm_equalizer_impl restated (lib/mimo_ofdm_equalizer_impl.cc:66-648)"""
+
+    def __init__(self, estimator_algo, freq, bw, fft_len, cp_len, data_carriers, pilot_carriers, pilot_symbols,
+                 ltf_seq, mapped_ltf_symbols, n_mimo_ltf):
+        self._keep = dict(
+            dc=np.ascontiguousarray(data_carriers, np.int32), pc=np.ascontiguousarray(pilot_carriers, np.int32),
+            ps=_c64(pilot_symbols), ltf=_c64(ltf_seq), ml=_c64(mapped_ltf_symbols))
+        k = self._keep
+        self.fft_len, self.n_data, self.n_tx = fft_len, len(k["dc"]), k["ml"].shape[1] // n_mimo_ltf
+        cfg = EqCfg(int(estimator_algo), freq, bw, fft_len, cp_len, len(k["dc"]), len(k["pc"]), _ip(k["dc"]), _ip(k["pc"]),
+                    k["ps"].shape[0], _fp(k["ps"]), _fp(k["ltf"]), _fp(k["ml"]), k["ml"].shape[1], n_mimo_ltf)
+        self._h = _comm_lib().orc_eq_create(C.byref(cfg))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _comm_lib().orc_eq_destroy(self._h)
+            self._h = None
+
+    def set_estimator(self, algo):
+        _comm_lib().orc_eq_set_estimator(self._h, int(algo))
+
+    def general_work(self, symbols, frame_start_tags=(), noutput_items=None):
+        """symbols [n_in, fft_len]; frame_start_tags: [(item_offset, phase)].  returns dict(out, consumed, events, chan_est)"""
+        x = _c64(symbols).reshape(-1, self.fft_len)
+        nin = x.shape[0]
+        nout = nin if noutput_items is None else noutput_items
+        out = np.zeros((max(nout, 1), self.n_data), np.complex64)
+        offs = (C.c_long * max(1, len(frame_start_tags)))(*[int(t[0]) for t in frame_start_tags])
+        vals = (C.c_double * max(1, len(frame_start_tags)))(*[float(t[1]) for t in frame_start_tags])
+        cons, nev, cw = C.c_int(), C.c_int(), C.c_int()
+        ev = (EqEvent * 8)()
+        ce = np.zeros((self.fft_len, self.n_tx), np.complex64)
+        n = _comm_lib().orc_eq_work(self._h, nout, nin, _fp(x), offs, vals, len(frame_start_tags), _fp(out),
+                                    C.byref(cons), ev, 8, C.byref(nev), _fp(ce), C.byref(cw))
+        events = []
+        for e in ev[:nev.value]:
+            d = dict(kind=e.kind, offset=e.offset)
+            if e.kind == 1:
+                d.update(data_bytes=e.data_bytes, mcs=e.mcs, packet_type=e.packet_type, snr=e.snr, freq_offset=e.freq_offset)
+            else:
+                cm = np.array(e.chan_mean[:2 * e.n_chan_mean], np.float32).view(np.complex64)
+                d.update(snr_data=e.snr_data, chan_mean=cm)
+            events.append(d)
+        return dict(out=out[:n], consumed=cons.value, events=events, chan_est=ce if cw.value else None)
+
+
+def steering_from_channel(h, phased=False):
+    """T x T steering matrix from a channel row h (lib/mimo_precoder_impl.cc:846-861): returns Q[t, j]"""
+    h = _c64(h)
+    T = h.size
+    q = np.zeros(T * T, np.complex64)
+    _comm_lib().orc_steering_from_channel(T, _fp(h), int(phased), _fp(q))
+    return q.reshape(T, T).T.copy()          # stored column-major
+
+
+def dft_matrix(T):
+    q = np.zeros(T * T, np.complex64)
+    _comm_lib().orc_dft_matrix(T, _fp(q))
+    return q.reshape(T, T).T.copy()
+
+
+class Precoder:
+    """mimo_precoder_impl restated (lib/mimo_precoder_impl.cc:78-741); deterministic inputs only"""
+
+    def __init__(self, fft_len, N_tx, N_ss, data_carriers, pilot_carriers, pilot_symbols, sync_words, mapped_ltf_symbols):
+        self._keep = dict(dc=np.ascontiguousarray(data_carriers, np.int32), pc=np.ascontiguousarray(pilot_carriers, np.int32),
+                          ps=_c64(pilot_symbols), sw=_c64(sync_words), ml=_c64(mapped_ltf_symbols))
+        k = self._keep
+        self.N, self.T, self.n_sync, self.n_data = fft_len, N_tx, k["sw"].shape[0], len(k["dc"])
+        self.cfg = PreCfg(fft_len, N_tx, len(k["dc"]), len(k["pc"]), _ip(k["dc"]), _ip(k["pc"]), k["ps"].shape[0],
+                          _fp(k["ps"]), k["sw"].shape[0], _fp(k["sw"]), _fp(k["ml"]))
+
+    def calculate_output_stream_length(self, ninput_items):
+        return self.n_sync + 1 + self.T + ninput_items // self.n_data
+
+    def work(self, symbols, mcs, packet_type, pdu_len, steer_mode=0, Q_mean=None, Q_sc=None, radar_streams=None):
+        """Q_mean [T,T] / Q_sc [N,T,T] indexed [t, j]; radar_streams [(T-1), n_sym, N] or None -> out [T, n_total, N]"""
+        x = _c64(symbols).ravel()
+        n_sym = x.size // self.n_data
+        n_total = n_sym + self.n_sync + self.T + 1
+        out = np.zeros((self.T, n_total, self.N), np.complex64)
+        ptrs = (c_float_p * self.T)(*[_fp(out[t]) for t in range(self.T)])
+        qm = None if Q_mean is None else np.ascontiguousarray(_c64(Q_mean).T)            # -> column-major
+        qs = None if Q_sc is None else np.ascontiguousarray(np.transpose(_c64(Q_sc), (0, 2, 1)))
+        rs = None if radar_streams is None else _c64(radar_streams)
+        r = _comm_lib().orc_precoder_work(C.byref(self.cfg), x.size, _fp(x), mcs, packet_type, pdu_len, steer_mode,
+                                          None if qm is None else _fp(qm), None if qs is None else _fp(qs),
+                                          None if rs is None else _fp(rs), ptrs)
+        if r < 0:
+            raise RuntimeError("[MIMO PRECODER] something is wrong!!")
+        assert r == n_total
+        return out

@@ -87,6 +87,62 @@ void orc_radar_chain(orc_radar_state* st, const float* const* tx, const float* c
  * only used to TIME a CPU baseline with the arithmetic type the reference (FFTW3f) uses. */
 void orc_fft_vcc_f32(int n, int forward, int shift, long batch, const float* in, float* out);
 
+/* ---- SIG field codec shared by C1/C2 (lib/utils.cc:26-111, :207-217; lib/mimo_precoder_impl.cc:985-1060;
+ *      lib/mimo_ofdm_equalizer_impl.cc:650-781) ---- */
+int  orc_mcs_params(int mcs, int n_data_carriers, int* n_bpsc, int* n_cbps, int* n_dbps, int* rate_field);
+int  orc_n_ofdm_sym(int mcs, int n_data_carriers, int data_size_byte);
+int  orc_sig_encode(int n_data_carriers, int mcs, int packet_type, int length, float* out_re);
+void orc_viterbi_k7(const uint8_t* coded, int n_decoded, uint8_t* decoded);
+int  orc_sig_parse(const uint8_t* bits, int n_data_carriers, int* mcs, int* packet_type, int* length, int* n_ofdm_sym);
+
+/* ---- C1: mimo_ofdm_equalizer_impl::general_work (lib/mimo_ofdm_equalizer_impl.cc:191-648) ---- */
+typedef struct {
+    int    estimator;              /* 0 = LS, 1 = STA */
+    double freq, bw;
+    int    fft_len, cp_len;
+    int    n_data, n_pilot;
+    const int* data_carriers;      /* signed, as passed to make() */
+    const int* pilot_carriers;
+    int    n_pilot_rows;
+    const float* pilot_symbols;    /* complex [n_pilot_rows][n_pilot] */
+    const float* ltf_seq;          /* complex [fft_len] */
+    const float* mapped_ltf;       /* complex [fft_len][mapped_cols], mapped_cols = N_tx*n_mimo_ltf */
+    int    mapped_cols;
+    int    n_mimo_ltf;
+} orc_eq_cfg;
+typedef struct {
+    int      kind;                 /* 1 = stream_start (:331-337), 2 = stream_end (:626-629) */
+    long     offset;               /* output item index relative to this call (nitems_written + offset) */
+    uint64_t data_bytes, mcs, packet_type;
+    double   snr, freq_offset;     /* stream_start */
+    double   snr_data;             /* stream_end */
+    int      n_chan_mean;
+    float    chan_mean[32];        /* complex, stream_end */
+} orc_eq_event;
+typedef struct orc_eq_state orc_eq_state;
+orc_eq_state* orc_eq_create(const orc_eq_cfg* cfg);
+void orc_eq_destroy(orc_eq_state* st);
+void orc_eq_set_estimator(orc_eq_state* st, int algo);
+int  orc_eq_work(orc_eq_state* st, int noutput_items, int ninput_items, const float* in,
+                 const long* tag_offsets, const double* tag_values, int n_tags,
+                 float* out, int* n_consumed, orc_eq_event* events, int max_events, int* n_events,
+                 float* chan_est, int* chan_est_written);
+
+/* ---- C3 / C2 (lib/mimo_precoder_impl.cc:275-983) ---- */
+void orc_steering_from_channel(int T, const float* h, int phased, float* Q /* col-major T x T */);
+void orc_dft_matrix(int T, float* F /* col-major T x T */);
+typedef struct {
+    int fft_len, n_tx;
+    int n_data, n_pilot;
+    const int* data_carriers; const int* pilot_carriers;
+    int n_pilot_rows; const float* pilot_symbols;
+    int n_sync; const float* sync_words;        /* complex [n_sync][fft_len] */
+    const float* mapped_ltf;                    /* complex [fft_len][n_tx*n_tx] */
+} orc_pre_cfg;
+int orc_precoder_work(const orc_pre_cfg* c, int ninput_items, const float* in, int mcs, int packet_type,
+                      int pdu_len, int steer_mode, const float* Q_mean, const float* Q_sc,
+                      const float* radar_streams, float* const* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,184 @@
+"""CPU tier: comm-side oracle (SIG codec, equalizer, precoder, steering) against closed forms and round trips,
+parameterised with the constant tables minted from the reference's ofdm_config module."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import crandn, rel_err
+
+NDP, DATA = 1, 2
+LS, STA = 0, 1
+
+
+def conv_encode_np(bits):
+    """independent restatement of the K=7 (0155, 0117) encoder as GF(2) polynomial products"""
+    g0 = [(0o155 >> k) & 1 for k in range(7)]        # tap k applies to the input k steps ago
+    g1 = [(0o117 >> k) & 1 for k in range(7)]
+    b = np.concatenate([np.zeros(6, int), np.asarray(bits, int)])
+    out = np.zeros(2 * len(bits), np.uint8)
+    for i in range(len(bits)):
+        w = b[i:i + 7][::-1]                          # w[k] = input k steps ago
+        out[2 * i] = np.dot(g0, w) % 2
+        out[2 * i + 1] = np.dot(g1, w) % 2
+    return out
+
+
+@pytest.mark.parametrize("mcs", range(6))
+@pytest.mark.parametrize("ptype", [NDP, DATA])
+@pytest.mark.parametrize("length", [0, 1, 100, 1500, 4095])
+def test_sig_field_round_trip(mcs, ptype, length):
+    nd = 48
+    sym = oracle.sig_encode(nd, mcs, ptype, length)
+    assert set(np.unique(sym)) <= {-1.0, 1.0}
+    bits = (sym > 0).astype(np.uint8)
+    dec = oracle.viterbi_k7(bits)
+    ok, m, p, ln, ns = oracle.sig_parse(dec, nd)
+    assert ok and (m, p, ln) == (mcs, ptype, length)
+    assert ns == oracle.n_ofdm_sym(mcs, nd, length)
+    hdr = dec[:24]                                            # header layout (lib/mimo_precoder_impl.cc:1003-1033)
+    assert hdr[17] == hdr[:17].sum() % 2 and not hdr[18:].any()
+    assert np.array_equal(conv_encode_np(hdr), bits)          # encoder is the (0155, 0117) code, not interleaved
+
+
+def test_sig_field_survives_channel_errors_and_detects_parity():
+    sym = oracle.sig_encode(48, 2, DATA, 777)
+    bits = (sym > 0).astype(np.uint8)
+    bad = bits.copy()
+    bad[[5, 30]] ^= 1                                          # two isolated errors: free distance 10 corrects them
+    ok, m, p, ln, _ = oracle.sig_parse(oracle.viterbi_k7(bad), 48)
+    assert ok and (m, p, ln) == (2, DATA, 777)
+    # the reference's check only fires when bits 17..22 are ALL zero, i.e. it also requires the parity bit
+    # itself to be 0 (lib/mimo_ofdm_equalizer_impl.cc:695-702): a corrupted header whose parity bit is 1 passes
+    seen = set()
+    for length in range(700, 740):
+        hdr = oracle.viterbi_k7((oracle.sig_encode(48, 2, DATA, length) > 0).astype(np.uint8))
+        p17 = int(hdr[17])
+        hdr[6] ^= 1                                            # wrong length bit -> parity mismatch
+        assert oracle.sig_parse(hdr, 48)[0] == bool(p17)
+        seen.add(p17)
+    assert seen == {0, 1}
+
+
+def test_n_ofdm_sym_formula():
+    for mcs, dbps in [(0, 24), (1, 36), (2, 48), (3, 72), (4, 96), (5, 144)]:
+        for nbytes in (0, 1, 50, 999):
+            assert oracle.n_ofdm_sym(mcs, 48, nbytes) == int(np.ceil((16 + 8 * nbytes + 6) / dbps))
+
+
+def test_steering_matrix_properties():
+    rng = np.random.default_rng(0)
+    for T in (2, 4):
+        h = crandn(rng, T)
+        Q = oracle.steering_from_channel(h)
+        V = Q * np.linalg.norm(Q) / np.sqrt(T)
+        assert np.allclose(Q.conj().T @ Q, np.eye(T), atol=2e-6)            # unitary (||V||_F = sqrt(T))
+        row = h @ Q                                                           # h^T V = [beta, 0, ..., 0]
+        assert abs(abs(row[0]) - np.linalg.norm(h)) < 1e-5 and np.abs(row[1:]).max() < 1e-5
+        assert abs(abs(np.vdot(np.conj(h), Q[:, 0])) / np.linalg.norm(h) - 1) < 1e-5
+        Qp = oracle.steering_from_channel(h, phased=True)
+        assert np.allclose(Qp[:, 0], np.conj(h) * np.sqrt(T) / np.linalg.norm(h), atol=1e-6) and not Qp[:, 1:].any()
+    F = oracle.dft_matrix(4)
+    k = np.arange(4)
+    assert np.allclose(F, np.exp(-2j * np.pi * np.outer(k, k) / 4) / 2, atol=1e-6)
+
+
+def make_blocks(o, est=LS, T=4):
+    dc, pc = o["data_subcarriers"], o["pilot_subcarriers"]
+    ps, sw, ml, ltf = o["pilot_symbols"], o["l_stf_ltf_64"], o["ltf_mapped_sc__ss_sym"], o["ltf_64"]
+    pre = oracle.Precoder(64, T, 1, dc, pc, ps, sw, ml)
+    eq = oracle.Equalizer(est, 24e9, 125e6, 64, 16, dc, pc, ps, ltf, ml, T)
+    return pre, eq
+
+
+def through_channel(tx, h, noise=0.0, rng=None):
+    """flat MISO channel per subcarrier; equalizer input = [LTF, LTF, SIG, MIMO-LTFs, data] (frame_sync drops the STFs)"""
+    y = np.tensordot(h, tx, axes=(0, 0))                      # [n_total, N]
+    y = np.concatenate([y[3:4], y[3:]], axis=0)
+    if noise:
+        y = y + noise * (rng.standard_normal(y.shape) + 1j * rng.standard_normal(y.shape))
+    return y.astype(np.complex64)
+
+
+def qpsk(rng, n):
+    pts = np.array([-1 - 1j, 1 - 1j, -1 + 1j, 1 + 1j]) * (0.707107 / 2)
+    return pts[rng.integers(0, 4, n)].astype(np.complex64)
+
+
+@pytest.mark.parametrize("est", [LS, STA])
+def test_ndp_frame_round_trip_and_channel_estimate(ofdm64, est):
+    rng = np.random.default_rng(1)
+    pre, eq = make_blocks(ofdm64, est)
+    nbytes, mcs = 30, 2
+    ns = oracle.n_ofdm_sym(mcs, 48, nbytes)
+    s = qpsk(rng, ns * 48)
+    tx = pre.work(s, mcs, NDP, nbytes)
+    assert tx.shape == (4, 4 + 1 + 4 + ns, 64) and not tx[2:, :5].any()        # legacy preamble only on outputs 0, 1
+    h = crandn(rng, 4)
+    r = eq.general_work(through_channel(tx, h), [(0, 0.0)])
+    assert r["consumed"] == ns + 7 and r["out"].shape == (ns, 48)
+    assert rel_err(r["out"], s.reshape(ns, 48)) < 1e-5
+    ev = r["events"]
+    assert [e["kind"] for e in ev] == [1, 2] and ev[0]["offset"] == 0 and ev[1]["offset"] == ns - 1
+    assert (ev[0]["data_bytes"], ev[0]["mcs"], ev[0]["packet_type"]) == (nbytes, mcs, NDP)
+    ltf = ofdm64["ltf_64"].real
+    exp = (4 * np.outer(ltf * ltf, h)).astype(np.complex64)                    # H = N_ltf * |ltf|^2 * h (no 1/N_ltf, :398)
+    assert rel_err(r["chan_est"], exp) < 1e-5
+    assert np.allclose(ev[1]["chan_mean"], 4 * h, atol=1e-4)
+
+
+@pytest.mark.parametrize("steer", ["dft", "svd_mean", "svd_sc", "phased"])
+def test_data_frame_precoded_round_trip(ofdm64, steer):
+    rng = np.random.default_rng(2)
+    pre, eq = make_blocks(ofdm64)
+    nbytes, mcs = 61, 2
+    ns = oracle.n_ofdm_sym(mcs, 48, nbytes)
+    s = qpsk(rng, ns * 48)
+    h = crandn(rng, 4)
+    kw = {}
+    if steer == "svd_mean":
+        kw = dict(steer_mode=1, Q_mean=oracle.steering_from_channel(h))
+    elif steer == "phased":
+        kw = dict(steer_mode=1, Q_mean=oracle.steering_from_channel(h, phased=True))
+    elif steer == "svd_sc":
+        kw = dict(steer_mode=2, Q_sc=np.stack([oracle.steering_from_channel(h)] * 64))
+    tx = pre.work(s, mcs, DATA, nbytes, **kw)
+    if steer == "dft":
+        assert np.allclose(tx[:, 9:, ofdm64["data_subcarriers"][0] + 32], np.outer(np.full(4, 0.5), s.reshape(ns, 48)[:, 0]), atol=1e-6)
+    r = eq.general_work(through_channel(tx, h, 1e-4, rng), [(0, 0.0)])
+    assert r["out"].shape == (ns, 48) and rel_err(r["out"], s.reshape(ns, 48)) < 5e-3
+    assert r["events"][0]["packet_type"] == DATA and r["events"][1]["snr_data"] > 30
+    if steer in ("svd_mean", "svd_sc"):                                         # beamforming gain: |h^T q0| = ||h||
+        assert abs(abs(r["events"][1]["chan_mean"][0]) - np.linalg.norm(h)) < 2e-2
+
+
+def test_radar_streams_are_orthogonal_to_the_user(ofdm64):
+    rng = np.random.default_rng(3)
+    pre, eq = make_blocks(ofdm64)
+    nbytes, mcs = 20, 2
+    ns = oracle.n_ofdm_sym(mcs, 48, nbytes)
+    s = qpsk(rng, ns * 48)
+    h = crandn(rng, 4)
+    rs = qpsk(rng, 3 * ns * 64).reshape(3, ns, 64)
+    tx = pre.work(s, mcs, DATA, nbytes, steer_mode=1, Q_mean=oracle.steering_from_channel(h), radar_streams=rs)
+    r = eq.general_work(through_channel(tx, h), [(0, 0.0)])
+    assert rel_err(r["out"], s.reshape(ns, 48)) < 1e-4       # null-space streams do not reach the user
+
+
+def test_precoder_rejects_inconsistent_length(ofdm64):
+    pre, _ = make_blocks(ofdm64)
+    with pytest.raises(RuntimeError):
+        pre.work(np.zeros(48 * 3, np.complex64), 2, DATA, 500)
+
+
+def test_equalizer_skips_without_frame_start_and_after_frame_end(ofdm64):
+    rng = np.random.default_rng(4)
+    pre, eq = make_blocks(ofdm64)
+    ns = oracle.n_ofdm_sym(2, 48, 10)
+    s = qpsk(rng, ns * 48)
+    y = through_channel(pre.work(s, 2, NDP, 10), crandn(rng, 4))
+    r = eq.general_work(y)                                   # no tag yet: everything is consumed, nothing produced
+    assert r["consumed"] == len(y) and len(r["out"]) == 0
+    y2 = np.concatenate([y, crandn(rng, 5, 64)])             # trailing garbage after the frame is skipped (:250-255)
+    r = eq.general_work(y2, [(0, 0.0)])
+    assert r["consumed"] == len(y2) and r["out"].shape == (ns, 48)
+    assert rel_err(r["out"], s.reshape(ns, 48)) < 1e-5
