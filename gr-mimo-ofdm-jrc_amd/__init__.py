@@ -441,3 +441,213 @@ class RadarChain:
             self.close()
         except Exception:
             pass
+
+
+# ---------------------------------------------------------------------------------------------------------
+# comm side: C1 mimo_ofdm_equalizer, C2 mimo_precoder, C3 steering
+# ---------------------------------------------------------------------------------------------------------
+LS, STA = 0, 1                      # ChannelEstimator (include/mimo_ofdm_jrc/mimo_ofdm_equalizer.h:27-30)
+NDP, DATA = 1, 2                    # PACKET_TYPE (include/mimo_ofdm_jrc/stream_encoder.h)
+_i32p = C.POINTER(C.c_int32)
+
+
+class EqCfg(C.Structure):
+    """jrc_eq_cfg"""
+    _fields_ = [("estimator", C.c_int32), ("freq", C.c_double), ("bw", C.c_double),
+                ("fft_len", C.c_int32), ("cp_len", C.c_int32), ("n_data", C.c_int32), ("n_pilot", C.c_int32),
+                ("data_carriers", _i32p), ("pilot_carriers", _i32p), ("n_pilot_rows", C.c_int32),
+                ("pilot_symbols", _vp), ("ltf_seq", _vp), ("mapped_ltf", _vp),
+                ("mapped_cols", C.c_int32), ("n_mimo_ltf", C.c_int32)]
+
+
+class EqEvent(C.Structure):
+    """jrc_eq_event"""
+    _fields_ = [("kind", C.c_int32), ("n_chan_mean", C.c_int32), ("offset", C.c_int64),
+                ("data_bytes", C.c_uint64), ("mcs", C.c_uint64), ("packet_type", C.c_uint64),
+                ("snr", C.c_double), ("freq_offset", C.c_double), ("snr_data", C.c_double),
+                ("chan_mean", C.c_float * 32)]
+
+
+class PreCfg(C.Structure):
+    """jrc_pre_cfg"""
+    _fields_ = [("fft_len", C.c_int32), ("N_tx", C.c_int32), ("n_data", C.c_int32), ("n_pilot", C.c_int32),
+                ("data_carriers", _i32p), ("pilot_carriers", _i32p), ("n_pilot_rows", C.c_int32),
+                ("pilot_symbols", _vp), ("n_sync", C.c_int32), ("sync_words", _vp), ("mapped_ltf", _vp)]
+
+
+def _load_comm():
+    L = load()
+    if not getattr(L, "_comm_ready", False):
+        L.jrc_equalizer_create.argtypes = [_vp, C.POINTER(EqCfg), C.c_int, C.POINTER(_vp)]
+        L.jrc_equalizer_destroy.argtypes = [_vp]
+        L.jrc_equalizer_set_estimator.argtypes = [_vp, C.c_int]
+        L.jrc_equalizer_set_bandwidth.argtypes = [_vp, C.c_double]
+        L.jrc_equalizer_set_frequency.argtypes = [_vp, C.c_double]
+        L.jrc_equalizer_work.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                                         C.c_int, _vp, C.POINTER(C.c_int), C.POINTER(EqEvent), C.c_int,
+                                         C.POINTER(C.c_int), _vp, C.POINTER(C.c_int)]
+        L.jrc_equalizer_frames_dev.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]
+        L.jrc_steering_from_channel.argtypes = [_vp, C.c_int, C.c_int, _vp, C.c_int, _vp]
+        L.jrc_dft_matrix.argtypes = [_vp, C.c_int, _vp]
+        L.jrc_precoder_create.argtypes = [_vp, C.POINTER(PreCfg), C.POINTER(_vp)]
+        L.jrc_precoder_destroy.argtypes = [_vp]
+        L.jrc_precoder_output_length.argtypes = [_vp, C.c_int]
+        L.jrc_precoder_work.argtypes = [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.POINTER(_vp)]
+        L.jrc_n_ofdm_sym.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.jrc_sig_encode.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _cfp]
+        L._comm_ready = True
+    return L
+
+
+def n_ofdm_sym(mcs, n_data_carriers, nbytes):
+    return _load_comm().jrc_n_ofdm_sym(mcs, n_data_carriers, nbytes)
+
+
+def _event_dict(e):
+    d = dict(kind=e.kind, offset=e.offset)
+    if e.kind == 1:
+        d.update(data_bytes=e.data_bytes, mcs=e.mcs, packet_type=e.packet_type, snr=e.snr, freq_offset=e.freq_offset)
+    else:
+        d.update(snr_data=e.snr_data, chan_mean=np.array(e.chan_mean[:2 * e.n_chan_mean], np.float32).view(np.complex64))
+    return d
+
+
+class mimo_ofdm_equalizer:
+    """include/mimo_ofdm_jrc/mimo_ofdm_equalizer.h:64-78; general_work = lib/mimo_ofdm_equalizer_impl.cc:191-648.
+    Tags come back as event dicts (stream_start / stream_end); chan_est is what the reference writes to
+    chan_est_file for an NDP frame."""
+
+    def __init__(self, estimator_algo, freq, bw, fft_len, cp_len, data_carriers, pilot_carriers, pilot_symbols,
+                 long_seq, mapped_ltf_symbols, n_mimo_ltf, chan_est_file="", comm_log_file="", stats_record=False,
+                 debug=False, n_streams=1, ctx=None):
+        self.ctx = ctx or default_context()
+        L = _load_comm()
+        self._keep = dict(dc=np.ascontiguousarray(data_carriers, np.int32), pc=np.ascontiguousarray(pilot_carriers, np.int32),
+                          ps=_c64(pilot_symbols), ltf=_c64(long_seq), ml=_c64(mapped_ltf_symbols))
+        k = self._keep
+        self.fft_len, self.n_data, self.n_streams = fft_len, len(k["dc"]), n_streams
+        self.n_tx = k["ml"].shape[1] // n_mimo_ltf
+        cfg = EqCfg(int(estimator_algo), freq, bw, fft_len, cp_len, len(k["dc"]), len(k["pc"]),
+                    k["dc"].ctypes.data_as(_i32p), k["pc"].ctypes.data_as(_i32p), k["ps"].shape[0],
+                    _ptr(k["ps"]), _ptr(k["ltf"]), _ptr(k["ml"]), k["ml"].shape[1], n_mimo_ltf)
+        h = _vp()
+        self.ctx.check(L.jrc_equalizer_create(self.ctx.h, C.byref(cfg), n_streams, C.byref(h)))
+        self.h = h
+
+    def set_estimator(self, algo):
+        self.ctx.check(self.ctx.lib.jrc_equalizer_set_estimator(self.h, int(algo)))
+
+    def set_bandwidth(self, bw):
+        self.ctx.check(self.ctx.lib.jrc_equalizer_set_bandwidth(self.h, float(bw)))
+
+    def set_frequency(self, freq):
+        self.ctx.check(self.ctx.lib.jrc_equalizer_set_frequency(self.h, float(freq)))
+
+    def general_work(self, symbols, frame_start_tags=(), noutput_items=None, stream=0):
+        x = _c64(symbols).reshape(-1, self.fft_len)
+        nin = x.shape[0]
+        nout = nin if noutput_items is None else noutput_items
+        out = np.zeros((max(nout, 1), self.n_data), np.complex64)
+        nt = len(frame_start_tags)
+        offs = (C.c_int64 * max(1, nt))(*[int(t[0]) for t in frame_start_tags])
+        vals = (C.c_double * max(1, nt))(*[float(t[1]) for t in frame_start_tags])
+        cons, nev, cw = C.c_int(), C.c_int(), C.c_int()
+        ev = (EqEvent * 8)()
+        ce = np.zeros((self.fft_len, self.n_tx), np.complex64)
+        n = self.ctx.check(self.ctx.lib.jrc_equalizer_work(self.h, stream, nout, nin, _ptr(x), offs, vals, nt, _ptr(out),
+                                                           C.byref(cons), ev, 8, C.byref(nev), _ptr(ce), C.byref(cw)))
+        return dict(out=out[:n], consumed=cons.value, events=[_event_dict(e) for e in ev[:nev.value]],
+                    chan_est=ce if cw.value else None)
+
+    def frames_dev(self, d_in, d_phase, n_symbols, max_out, stream=None):
+        """batched device-resident frames (torch tensors): d_in [n_streams, n_symbols, fft_len, 2] f32, d_phase [n_streams] f64"""
+        import torch
+        ns = d_in.shape[0]
+        out = torch.empty((ns, max_out, self.n_data, 2), dtype=torch.float32, device=d_in.device)
+        n_out = torch.empty((ns,), dtype=torch.int32, device=d_in.device)
+        ev = torch.zeros((ns, 2, C.sizeof(EqEvent)), dtype=torch.uint8, device=d_in.device)
+        self.ctx.check(self.ctx.lib.jrc_equalizer_frames_dev(self.h, ns, n_symbols, d_in.data_ptr(), d_phase.data_ptr(), max_out,
+                                                             out.data_ptr(), n_out.data_ptr(), ev.data_ptr(), stream))
+        return out, n_out, ev
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.jrc_equalizer_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def steering_from_channel(h, phased=False, ctx=None):
+    """h: [n, T] (or [T]) channel rows -> Q[n, t, j] (lib/mimo_precoder_impl.cc:846-861)"""
+    ctx = ctx or default_context()
+    h = _c64(h)
+    single = h.ndim == 1
+    h2 = h.reshape(-1, h.shape[-1])
+    n, T = h2.shape
+    q = np.zeros((n, T * T), np.complex64)
+    ctx.check(_load_comm().jrc_steering_from_channel(ctx.h, T, n, _ptr(h2), int(phased), _ptr(q)))
+    Q = np.transpose(q.reshape(n, T, T), (0, 2, 1)).copy()        # stored column-major
+    return Q[0] if single else Q
+
+
+class mimo_precoder:
+    """include/mimo_ofdm_jrc/mimo_precoder.h; work = lib/mimo_precoder_impl.cc:275-741.  The steering-matrix source
+    (CSV / radar log parsing, file mtime cache) stays in the host wrapper; work() takes the matrices explicitly."""
+
+    def __init__(self, fft_len, N_tx, N_ss, data_carriers, pilot_carriers, pilot_symbols, sync_words, mapped_ltf_symbols,
+                 chan_est_file="", chan_est_smoothing=False, radar_log_file="", radar_aided=False, phased_steering=False,
+                 use_radar_streams=False, len_tag_key="packet_len", debug=False, ctx=None):
+        self.ctx = ctx or default_context()
+        L = _load_comm()
+        self._keep = dict(dc=np.ascontiguousarray(data_carriers, np.int32), pc=np.ascontiguousarray(pilot_carriers, np.int32),
+                          ps=_c64(pilot_symbols), sw=_c64(sync_words), ml=_c64(mapped_ltf_symbols))
+        k = self._keep
+        if any(len(w) != fft_len for w in k["sw"]):
+            raise ValueError("[MIMO PRECODER] sync words must be fft length")
+        if k["ml"].shape != (fft_len, N_tx * N_tx):
+            raise ValueError("[MIMO PRECODER] MIMO LTF symbols should have (fft length x Ntx) rows!!")
+        if k["ps"].shape[1] != len(k["pc"]):
+            raise ValueError("pilot_carriers do not match pilot_symbols")
+        self.N, self.T, self.n_sync, self.n_data = fft_len, N_tx, k["sw"].shape[0], len(k["dc"])
+        cfg = PreCfg(fft_len, N_tx, len(k["dc"]), len(k["pc"]), k["dc"].ctypes.data_as(_i32p), k["pc"].ctypes.data_as(_i32p),
+                     k["ps"].shape[0], _ptr(k["ps"]), k["sw"].shape[0], _ptr(k["sw"]), _ptr(k["ml"]))
+        h = _vp()
+        self.ctx.check(L.jrc_precoder_create(self.ctx.h, C.byref(cfg), C.byref(h)))
+        self.h = h
+
+    def calculate_output_stream_length(self, ninput_items):
+        return self.ctx.lib.jrc_precoder_output_length(self.h, ninput_items)
+
+    def work(self, symbols, mcs, packet_type, pdu_len, steer_mode=0, Q_mean=None, Q_sc=None, radar_streams=None):
+        x = _c64(symbols).ravel()
+        n_sym = x.size // self.n_data
+        n_total = n_sym + self.n_sync + self.T + 1
+        out = np.zeros((self.T, n_total, self.N), np.complex64)
+        ptrs = (_vp * self.T)(*[_ptr(out[t]) for t in range(self.T)])
+        qm = None if Q_mean is None else np.ascontiguousarray(_c64(Q_mean).T)
+        qs = None if Q_sc is None else np.ascontiguousarray(np.transpose(_c64(Q_sc), (0, 2, 1)))
+        rs = None if radar_streams is None else _c64(radar_streams)
+        st = self.ctx.lib.jrc_precoder_work(self.h, x.size, _ptr(x), mcs, packet_type, pdu_len, steer_mode,
+                                            None if qm is None else _ptr(qm), None if qs is None else _ptr(qs),
+                                            None if rs is None else _ptr(rs), ptrs)
+        if st == -8:
+            raise RuntimeError(self.ctx.lib.jrc_last_error(self.ctx.h).decode())   # std::runtime_error (:327-333)
+        self.ctx.check(st)
+        assert st == n_total
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.jrc_precoder_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,895 @@
+// comm.hip — comm-side rows of the hot path: C1 mimo_ofdm_equalizer, C2 mimo_precoder, C3 steering
+//
+//   C1 replaces mimo_ofdm_equalizer_impl::general_work + helpers (reference lib/mimo_ofdm_equalizer_impl.cc:191-922)
+//   C2 replaces mimo_precoder_impl::work + generate_signal_field   (reference lib/mimo_precoder_impl.cc:275-741, :985-1060)
+//   C3 replaces the Eigen JacobiSVD / phased-steering bodies       (reference lib/mimo_precoder_impl.cc:846-861, :880-893, :961-974)
+//
+// All three are small per-subcarrier problems (K = N_tx <= 8): no GEMM shape, no MFMA.  The equalizer is a
+// per-frame sequential state machine over OFDM symbols, so the parallel axes are subcarriers (lanes) and
+// independent RX streams / frames (workgroups); its state lives in LDS for the duration of a launch.
+#include "jrc_internal.h"
+
+#include <algorithm>
+#include <cmath>
+
+// ------------------------------------------------------------------------------------------------
+// scalar helpers restating libstdc++ / libgcc complex arithmetic (the reference's std::complex<float> ops)
+__device__ __forceinline__ float2 c_mul(float2 a, float2 b)
+{
+#pragma clang fp contract(off)
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 c_conj(float2 a) { return make_float2(a.x, -a.y); }
+__device__ __forceinline__ float2 c_div(float2 n, float2 dn)   // libgcc __divsc3 (Smith), finite inputs
+{
+#pragma clang fp contract(off)
+    const float a = n.x, b = n.y, c = dn.x, d = dn.y;
+    float x, y;
+    if (fabsf(c) < fabsf(d)) {
+        const float ratio = c / d, denom = (c * ratio) + d;
+        x = ((a * ratio) + b) / denom;
+        y = ((b * ratio) - a) / denom;
+    } else {
+        const float ratio = d / c, denom = (d * ratio) + c;
+        x = ((b * ratio) + a) / denom;
+        y = (b - (a * ratio)) / denom;
+    }
+    return make_float2(x, y);
+}
+__device__ __forceinline__ float2 c_expj(double x)   // std::exp(gr_complex(0, x)): the double is narrowed first
+{
+    const float xf = (float)x;
+    return make_float2(cosf(xf), sinf(xf));
+}
+
+__host__ __device__ inline int popc8(int n) { int s = 0; for (int i = 0; i < 8; i++) s += (n >> i) & 1; return s; }
+
+// ------------------------------------------------------------------------------------------------
+// host-side SIG helpers (lib/utils.cc:26-111)
+static int mcs_params(int mcs, int n_data, int* n_dbps, int* rate_field)
+{
+    int bpsc, num, den, rf;
+    switch (mcs) {
+        case 0: bpsc = 1; num = 1; den = 2; rf = 0x0D; break;
+        case 1: bpsc = 1; num = 3; den = 4; rf = 0x0F; break;
+        case 2: bpsc = 2; num = 1; den = 2; rf = 0x05; break;
+        case 3: bpsc = 2; num = 3; den = 4; rf = 0x07; break;
+        case 4: bpsc = 4; num = 1; den = 2; rf = 0x09; break;
+        case 5: bpsc = 4; num = 3; den = 4; rf = 0x0B; break;
+        default: return -1;
+    }
+    if (n_dbps) *n_dbps = n_data * bpsc * num / den;
+    if (rate_field) *rate_field = rf;
+    return 0;
+}
+
+__host__ __device__ inline int n_ofdm_sym_dev(int mcs, int n_data, int nbytes)
+{
+    int bpsc = mcs <= 1 ? 1 : (mcs <= 3 ? 2 : 4);
+    int cbps = n_data * bpsc;
+    int dbps = (mcs & 1) ? cbps * 3 / 4 : cbps / 2;
+    return (int)ceil((16 + 8 * nbytes + 6) / (double)dbps);     // lib/utils.cc:31
+}
+
+extern "C" int jrc_n_ofdm_sym(int mcs, int n_data_carriers, int data_size_byte)
+{
+    if (mcs < 0 || mcs > 5 || n_data_carriers <= 0) return JRC_ERR_INVALID_ARG;
+    return n_ofdm_sym_dev(mcs, n_data_carriers, data_size_byte);
+}
+
+extern "C" int jrc_sig_encode(int n_data, int mcs, int packet_type, int length, float* out_re)
+{
+    int rate_field;
+    if (!out_re || n_data < 48 || mcs_params(mcs, n_data, nullptr, &rate_field) < 0) return JRC_ERR_INVALID_ARG;
+    char hdr[24] = {0};                                                  // lib/mimo_precoder_impl.cc:1003-1038
+    hdr[0] = (rate_field >> 3) & 1; hdr[1] = (rate_field >> 2) & 1; hdr[2] = (rate_field >> 1) & 1; hdr[3] = rate_field & 1;
+    hdr[4] = (packet_type == 2) ? 1 : 0;
+    for (int i = 0; i < 12; i++) hdr[5 + i] = (length >> i) & 1;
+    int sum = 0;
+    for (int i = 0; i < 17; i++) sum += hdr[i];
+    hdr[17] = sum % 2;
+    int state = 0;
+    for (int i = 0; 2 * i + 1 < n_data; i++) {                           // convolutional_encoding, lib/utils.cc:207-217
+        state = ((state << 1) & 0x7e) | (i < 24 ? hdr[i] : 0);
+        out_re[2 * i] = (popc8(state & 0155) & 1) ? 1.0f : -1.0f;        // BPSK map: 0 -> -1, 1 -> +1
+        out_re[2 * i + 1] = (popc8(state & 0117) & 1) ? 1.0f : -1.0f;
+    }
+    return JRC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C1 equalizer
+struct EqDev {
+    int N, cp, ND, NP, NAct, NL, T, mapped_cols, n_pilot_rows, estimator;
+    double freq, bw;
+    const int* data_c; const int* pilot_c; const int* active_c;
+    const float2* pilot_sym; const float2* ltf; const float2* mapped;
+};
+
+struct EqState {
+    int symbol_ind, total_out, n_ofdm_symbols_SIG, sig_ok, equalize_done;
+    int mcs, packet_type, data_length, snr_est_count, n_chan_mean;
+    double freq_offset, er, epsilon0, snr_est, precoded_snr_est, signal_power_sum, noise_power_sum;
+    float2 chan_mean[16];
+};
+
+struct EqIo {
+    const float2* in; long in_stride; int ninput;
+    const long long* tag_offsets; const double* tag_values; int n_tags;   // tag_offsets == nullptr: one tag at item 0 per stream
+    float2* out; long out_stride; int noutput;
+    int* n_out; int* n_consumed; jrc_eq_event* events; int max_events; int* n_events;
+    float2* chan_est; int* chan_est_written;
+    int stream0;
+};
+
+__device__ __forceinline__ float2 demod_point(int bps, float2 z)
+{
+    if (bps == 1) return make_float2(z.x > 0 ? 1.0f : -1.0f, 0.f);       // constellation_bpsk
+    const float a = 0.707107f;                                             // constellation_qpsk, then /2 (:511-514)
+    return make_float2((z.x > 0 ? a : -a) / 2.0f, (z.y > 0 ? a : -a) / 2.0f);
+}
+
+__global__ __launch_bounds__(1024) void equalizer_kernel(EqDev d, EqState* states, float2* H_all, float2* Hm_all,
+                                                         float2* pre_all, EqIo io)
+{
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) unsigned char eq_smem[];
+    const int N = d.N, ND = d.ND, NP = d.NP, NL = d.NL, T = d.T;
+    float2* Y = reinterpret_cast<float2*>(eq_smem);
+    float2* H = Y + N;
+    float2* Hm = H + N;
+    float2* Z = Hm + N;                       // [ND]
+    float2* est = Z + ND;                     // [NP]
+    unsigned long long* surv = reinterpret_cast<unsigned long long*>(est + NP);   // [ND/2]
+    unsigned char* bits = reinterpret_cast<unsigned char*>(surv + ND / 2);        // [ND]
+    unsigned char* dec = bits + ND;                                               // [ND/2]
+    __shared__ EqState S;
+    __shared__ float2 s_rot;
+    __shared__ int s_flag;
+
+    const int tid = threadIdx.x, NT = blockDim.x;
+    const int b = blockIdx.x;
+    const int stream = io.stream0 + b;
+    EqState* gst = states + stream;
+    float2* gH = H_all + (size_t)stream * N;
+    float2* gHm = Hm_all + (size_t)stream * N;
+    float2* pre = pre_all + (size_t)stream * N * NL;
+    const float2* in = io.in + (size_t)b * io.in_stride;
+    float2* out = io.out + (size_t)b * io.out_stride;
+    float2* chan_est = io.chan_est ? io.chan_est + (size_t)b * N * T : nullptr;
+    jrc_eq_event* events = io.events + (size_t)b * io.max_events;
+
+    if (tid == 0) S = *gst;
+    for (int i = tid; i < N; i += NT) { H[i] = gH[i]; Hm[i] = gHm[i]; }
+    __syncthreads();
+
+    int n_in = 0, n_out = 0, nev = 0, ce_written = 0;
+    while (n_in < io.ninput && n_out < io.noutput) {                                   // :219
+        if (tid == 0) {
+            int hit = -1;
+            if (io.tag_offsets == nullptr) { if (n_in == 0) hit = stream; }
+            else for (int t = 0; t < io.n_tags; t++) if (io.tag_offsets[t] == n_in) { hit = t; break; }
+            if (hit >= 0) {                                                             // frame_start :221-245
+                const double v = io.tag_values[io.tag_offsets == nullptr ? b : hit];
+                S.symbol_ind = 0; S.total_out = 0; S.n_ofdm_symbols_SIG = 0;
+                S.freq_offset = v * d.bw / (2 * M_PI);
+                S.epsilon0 = v * d.bw / (2 * M_PI * d.freq);
+                S.er = 0; S.sig_ok = 1; S.equalize_done = 0;
+                S.signal_power_sum = 0; S.noise_power_sum = 0; S.snr_est_count = 0;
+            }
+        }
+        __syncthreads();
+        const int sym = S.symbol_ind;
+        if (sym > S.n_ofdm_symbols_SIG + 2 + NL || !S.sig_ok) { n_in++; __syncthreads(); continue; }   // :250-255
+
+        {   // sampling-offset de-rotation :261-264
+            const double k0 = 2 * M_PI * sym * ((N + d.cp) * 1.0 / N) * (S.epsilon0 + S.er);
+            for (int i = tid; i < N; i += NT) Y[i] = c_mul(in[(size_t)n_in * N + i], c_expj(k0 * (i - N / 2)));
+        }
+        __syncthreads();
+
+        if (sym == 0) {                                                                 // :272-275
+            for (int i = tid; i < N; i += NT) H[i] = Y[i];
+        } else if (sym == 1) {                                                          // :277-306
+            if (tid == 0) {
+                double signal = 0, noise = 0;
+                for (int k = 0; k < d.NAct; k++) {
+                    const int c = d.active_c[k];
+                    const double hn = (double)ref_hypotf(make_float2(H[c].x - Y[c].x, H[c].y - Y[c].y));
+                    const double hs = (double)ref_hypotf(make_float2(H[c].x + Y[c].x, H[c].y + Y[c].y));
+                    noise += hn * hn; signal += hs * hs;
+                }
+                S.snr_est = 10 * log10(signal / noise / 2);
+            }
+            __syncthreads();
+            for (int k = tid; k < d.NAct; k += NT) {
+                const int c = d.active_c[k];
+                const float2 l = d.ltf[c];
+                H[c] = c_div(make_float2(H[c].x + Y[c].x, H[c].y + Y[c].y), c_mul(l, make_float2(2.f, 0.f)));
+            }
+        } else if (sym == 2) {                                                          // SIG :308-344
+            if (tid == 0) {
+                float2 sum = make_float2(0.f, 0.f);
+                for (int k = 0; k < NP; k++) {                                          // estimate_residual_cfo :908-922
+                    est[k] = c_mul(H[d.pilot_c[k]], d.pilot_sym[k]);
+                    const float2 p = c_mul(Y[d.pilot_c[k]], c_conj(est[k]));
+                    sum.x = sum.x + p.x; sum.y = sum.y + p.y;
+                }
+                s_rot = c_expj(-(double)atan2f(sum.y, sum.x));
+            }
+            __syncthreads();
+            for (int i = tid; i < N; i += NT) Y[i] = c_mul(Y[i], s_rot);
+            __syncthreads();
+            for (int i = tid; i < ND; i += NT) {
+                Z[i] = c_div(Y[d.data_c[i]], H[d.data_c[i]]);                           // symbol_equalize :900-906
+                bits[i] = Z[i].x > 0;                                                   // BPSK decision
+            }
+            __syncthreads();
+            if (tid < 64) {   // K=7 (0155,0117) hard-decision Viterbi: one lane per trellis state
+                const int s6 = tid, nd = ND / 2;
+                int metric = s6 ? (1 << 28) : 0;
+                const int e0a = popc8(s6 & 0155) & 1, e1a = popc8(s6 & 0117) & 1;                 // predecessor bit h = 0
+                const int e0b = popc8((s6 | 64) & 0155) & 1, e1b = popc8((s6 | 64) & 0117) & 1;   // h = 1
+                for (int i = 0; i < nd; i++) {
+                    const int r0 = bits[2 * i], r1 = bits[2 * i + 1];
+                    const int m0 = __shfl(metric, s6 >> 1) + (e0a != r0) + (e1a != r1);
+                    const int m1 = __shfl(metric, (s6 >> 1) | 32) + (e0b != r0) + (e1b != r1);
+                    const int pick = m1 < m0;
+                    metric = pick ? m1 : m0;
+                    const unsigned long long mask = __ballot(pick);
+                    if (tid == 0) surv[i] = mask;
+                }
+                int best = metric, bs = s6;                                             // lowest state among minima
+                for (int off = 32; off > 0; off >>= 1) {
+                    const int om = __shfl_xor(best, off), os = __shfl_xor(bs, off);
+                    if (om < best || (om == best && os < bs)) { best = om; bs = os; }
+                }
+                if (tid == 0) {
+                    int s = bs;
+                    for (int i = nd - 1; i >= 0; i--) {
+                        dec[i] = (unsigned char)(s & 1);
+                        s = (s >> 1) | ((int)((surv[i] >> s) & 1ull) << 5);
+                    }
+                    // parse :669-781
+                    int rate = 0, pt = 0, len = 0, parity = 0;
+                    for (int i = 0; i < 17; i++) {
+                        parity ^= dec[i];
+                        if (i < 4 && dec[i]) rate |= 1 << i;
+                        if (i == 4 && dec[i]) pt |= 1;
+                        if (dec[i] && i > 4) len |= 1 << (i - 5);
+                    }
+                    int trailing_ok = 1;
+                    for (int i = 17; i < 23; i++) if (dec[i]) trailing_ok = 0;
+                    int ok = 1, mcs = 0;
+                    S.data_length = len;
+                    if (parity != dec[17] && trailing_ok) { ok = 0; S.data_length = 0; S.n_ofdm_symbols_SIG = 0; }
+                    else {
+                        switch (rate) {
+                            case 11: mcs = 0; break; case 15: mcs = 1; break; case 10: mcs = 2; break;
+                            case 14: mcs = 3; break; case 9: mcs = 4; break; case 13: mcs = 5; break;
+                            default: ok = 0;
+                        }
+                        S.packet_type = pt == 0 ? 1 : 2;
+                        if (ok) { S.mcs = mcs; S.n_ofdm_symbols_SIG = n_ofdm_sym_dev(mcs, ND, len); }
+                    }
+                    S.sig_ok = ok;
+                    if (ok && nev < io.max_events) {                                    // stream_start tag :331-337
+                        jrc_eq_event e;
+                        e.kind = 1; e.n_chan_mean = 0; e.offset = n_out; e.data_bytes = (unsigned long long)len;
+                        e.mcs = (unsigned long long)mcs; e.packet_type = (unsigned long long)S.packet_type;
+                        e.snr = S.snr_est; e.freq_offset = S.freq_offset; e.snr_data = 0;
+                        for (int t = 0; t < 16; t++) { e.chan_mean[t].re = 0; e.chan_mean[t].im = 0; }
+                        events[nev] = e;
+                    }
+                    s_flag = ok;
+                }
+            }
+            __syncthreads();
+            if (s_flag && nev < io.max_events) nev++;
+        } else if (sym <= 2 + NL) {                                                     // MIMO-LTFs :346-463
+            const int l = sym - 3;
+            for (int i = tid; i < N; i += NT) pre[(size_t)i * NL + l] = Y[i];
+            __syncthreads();
+            if (l == NL - 1) {
+                if (S.packet_type == 1) {                                               // NDP :375-422
+                    for (int sc = tid; sc < N; sc += NT)
+                        for (int t = 0; t < T; t++) {
+                            float2 h = make_float2(0.f, 0.f);
+                            for (int q = 0; q < NL; q++) {
+                                const float2 p = c_mul(c_conj(d.mapped[(size_t)sc * d.mapped_cols + t * NL + q]), pre[(size_t)sc * NL + q]);
+                                h.x = h.x + p.x; h.y = h.y + p.y;
+                            }
+                            if (chan_est) chan_est[(size_t)sc * T + t] = h;     // content of chan_est_file (:392-416)
+                        }
+                    __syncthreads();
+                    if (tid == 0) {
+                        for (int t = 0; t < T; t++) {
+                            float2 m = make_float2(0.f, 0.f);
+                            for (int k = 0; k < d.NAct; k++) {
+                                const int sc = d.active_c[k];
+                                float2 h;
+                                if (chan_est) h = chan_est[(size_t)sc * T + t];
+                                else {
+                                    h = make_float2(0.f, 0.f);
+                                    for (int q = 0; q < NL; q++) {
+                                        const float2 p = c_mul(c_conj(d.mapped[(size_t)sc * d.mapped_cols + t * NL + q]), pre[(size_t)sc * NL + q]);
+                                        h.x = h.x + p.x; h.y = h.y + p.y;
+                                    }
+                                }
+                                m.x = m.x + h.x; m.y = m.y + h.y;
+                            }
+                            S.chan_mean[t] = make_float2(m.x / (float)d.NAct, m.y / (float)d.NAct);
+                        }
+                        S.n_chan_mean = T;
+                    }
+                    ce_written = 1;
+                } else if (S.packet_type == 2) {                                        // DATA :423-456
+                    for (int k = tid; k < d.NAct; k += NT) {
+                        const int sc = k < ND ? d.data_c[k] : d.pilot_c[k - ND];
+                        float2 acc = make_float2(0.f, 0.f);
+                        for (int q = 0; q < NL; q++) {                                  // row(0).dot(y): conjugates the row
+                            const float2 p = c_mul(c_conj(d.mapped[(size_t)sc * d.mapped_cols + q]), pre[(size_t)sc * NL + q]);
+                            acc.x = acc.x + p.x; acc.y = acc.y + p.y;
+                        }
+                        Hm[sc] = make_float2(acc.x / (float)NL, acc.y / (float)NL);
+                    }
+                    __syncthreads();
+                    if (tid == 0) {
+                        float2 m = make_float2(0.f, 0.f);
+                        for (int k = 0; k < ND; k++) { m.x = m.x + Hm[d.data_c[k]].x; m.y = m.y + Hm[d.data_c[k]].y; }
+                        for (int k = 0; k < NP; k++) { m.x = m.x + Hm[d.pilot_c[k]].x; m.y = m.y + Hm[d.pilot_c[k]].y; }
+                        S.chan_mean[0] = make_float2(m.x / (float)d.NAct, m.y / (float)d.NAct);
+                        S.n_chan_mean = 1;
+                    }
+                }
+            }
+        } else {                                                                        // data symbols :465-605
+            const int row = (sym - 3 - NL) % d.n_pilot_rows;
+            const float2* ref = d.pilot_sym + (size_t)row * NP;
+            float2* Hsel = S.packet_type == 1 ? H : Hm;
+            if (tid == 0) {
+                float2 sum = make_float2(0.f, 0.f);
+                for (int k = 0; k < NP; k++) {
+                    est[k] = c_mul(Hsel[d.pilot_c[k]], ref[k]);
+                    const float2 p = c_mul(Y[d.pilot_c[k]], c_conj(est[k]));
+                    sum.x = sum.x + p.x; sum.y = sum.y + p.y;
+                }
+                s_rot = c_expj(-(double)atan2f(sum.y, sum.x));
+            }
+            __syncthreads();
+            for (int i = tid; i < N; i += NT) Y[i] = c_mul(Y[i], s_rot);
+            __syncthreads();
+            if (tid == 0) {                                                             // :484-493
+                for (int k = 0; k < NP; k++) {
+                    S.signal_power_sum += (double)c_mul(est[k], c_conj(est[k])).x;
+                    const float2 e = make_float2(est[k].x - Y[d.pilot_c[k]].x, est[k].y - Y[d.pilot_c[k]].y);
+                    S.noise_power_sum += (double)c_mul(e, c_conj(e)).x;
+                    S.snr_est_count++;
+                }
+            }
+            __syncthreads();
+            const int bps = (S.mcs <= 1) ? 1 : (S.mcs <= 3 ? 2 : 4);
+            if (S.packet_type == 1) {
+                for (int i = tid; i < ND; i += NT) Z[i] = c_div(Y[d.data_c[i]], H[d.data_c[i]]);
+                if (d.estimator == 1 && bps <= 2) {                                     // STA :498-535
+                    __syncthreads();
+                    const float alpha = 0.5f;
+                    for (int i = tid; i < ND; i += NT) {
+                        const int sc = d.data_c[i];
+                        const float2 upd = c_div(Y[sc], demod_point(bps, Z[i]));
+                        const float2 a = c_mul(make_float2(1 - alpha, 0.f), H[sc]), bb = c_mul(make_float2(alpha, 0.f), upd);
+                        H[sc] = make_float2(a.x + bb.x, a.y + bb.y);
+                    }
+                    for (int k = tid; k < NP; k += NT) {
+                        const int sc = d.pilot_c[k];
+                        const float2 a = c_mul(make_float2(1 - alpha, 0.f), H[sc]);
+                        const float2 bb = c_div(c_mul(make_float2(alpha, 0.f), Y[sc]), ref[k]);
+                        H[sc] = make_float2(a.x + bb.x, a.y + bb.y);
+                    }
+                }
+            } else if (S.packet_type == 2) {
+                const double nvar = S.noise_power_sum / S.snr_est_count;
+                for (int i = tid; i < ND; i += NT) {                                    // :540-550
+                    const int sc = d.data_c[i];
+                    const float csi = (float)((double)c_mul(Hm[sc], c_conj(Hm[sc])).x + nvar);
+                    const float2 num = c_mul(Y[sc], c_conj(Hm[sc]));
+                    Z[i] = make_float2(num.x / csi, num.y / csi);
+                }
+                if (d.estimator == 1 && bps <= 2) {                                     // STA :552-592
+                    __syncthreads();
+                    const float alpha = 0.4f;
+                    for (int i = tid; i < ND; i += NT) {
+                        const int sc = d.data_c[i];
+                        const float2 a = c_mul(make_float2(1 - alpha, 0.f), Hm[sc]);
+                        const float2 bb = c_div(c_mul(make_float2(alpha, 0.f), Y[sc]), demod_point(bps, Z[i]));
+                        Hm[sc] = make_float2(a.x + bb.x, a.y + bb.y);
+                    }
+                    for (int k = tid; k < NP; k += NT) {
+                        const int sc = d.pilot_c[k];
+                        const float2 a = c_mul(make_float2(1 - alpha, 0.f), Hm[sc]);
+                        const float2 bb = c_div(c_mul(make_float2(alpha, 0.f), Y[sc]), ref[k]);
+                        Hm[sc] = make_float2(a.x + bb.x, a.y + bb.y);
+                    }
+                }
+            }
+            __syncthreads();
+            for (int i = tid; i < ND; i += NT) out[(size_t)n_out * ND + i] = Z[i];      // :602
+            n_out++;
+        }
+        __syncthreads();
+        if (tid == 0) S.symbol_ind = sym + 1;
+        n_in++;
+        __syncthreads();
+    }
+
+    if (tid == 0) {
+        S.total_out += n_out;
+        if (S.total_out == S.n_ofdm_symbols_SIG && S.sig_ok && !S.equalize_done) {      // stream_end tag :611-632
+            if (S.snr_est_count != 0)
+                S.precoded_snr_est = 10 * log10((S.signal_power_sum / S.snr_est_count) / (S.noise_power_sum / S.snr_est_count));
+            if (nev < io.max_events) {
+                jrc_eq_event e;
+                e.kind = 2; e.n_chan_mean = S.n_chan_mean; e.offset = (long long)n_out - 1;
+                e.data_bytes = 0; e.mcs = 0; e.packet_type = 0; e.snr = 0; e.freq_offset = 0;
+                e.snr_data = S.precoded_snr_est;
+                for (int t = 0; t < 16; t++) { e.chan_mean[t].re = t < S.n_chan_mean ? S.chan_mean[t].x : 0.f; e.chan_mean[t].im = t < S.n_chan_mean ? S.chan_mean[t].y : 0.f; }
+                events[nev++] = e;
+            }
+            S.equalize_done = 1;
+        }
+        *gst = S;
+        io.n_out[b] = n_out;
+        io.n_consumed[b] = n_in;
+        io.n_events[b] = nev;
+        if (io.chan_est_written) io.chan_est_written[b] = ce_written;
+    }
+    for (int i = tid; i < N; i += NT) { gH[i] = H[i]; gHm[i] = Hm[i]; }
+}
+
+struct jrc_equalizer {
+    jrc_ctx* ctx;
+    EqDev d;
+    int n_streams;
+    void* tables = nullptr;      // one allocation for all constant tables
+    EqState* states = nullptr;
+    float2 *H = nullptr, *Hm = nullptr, *pre = nullptr;
+    int* counters = nullptr;     // [n_streams][4]: n_out, n_consumed, n_events, chan_est_written
+    size_t lds_bytes;
+    int threads;
+};
+
+extern "C" int jrc_equalizer_create(jrc_ctx* ctx, const jrc_eq_cfg* c, int n_streams, jrc_equalizer** out)
+{
+    if (!ctx || !c || !out || n_streams <= 0) return JRC_ERR_INVALID_ARG;
+    if (c->fft_len <= 0 || c->n_data < 48 || c->n_pilot <= 0 || c->n_mimo_ltf <= 0 || c->mapped_cols % c->n_mimo_ltf ||
+        c->n_pilot_rows <= 0 || !c->data_carriers || !c->pilot_carriers || !c->pilot_symbols || !c->ltf_seq || !c->mapped_ltf)
+        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "mimo_ofdm_equalizer: bad configuration");
+    if (c->estimator != 0 && c->estimator != 1)
+        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "[OFDM Equalizer] Estimator not implemented");      // :941-943
+    const int N = c->fft_len, ND = c->n_data, NP = c->n_pilot, T = c->mapped_cols / c->n_mimo_ltf;
+    if (T > 16 || N > 4096) return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "mimo_ofdm_equalizer: N_tx <= 16, fft_len <= 4096");
+    JRC_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<int> dc(ND), pc(NP), ac;
+    for (int i = 0; i < NP; i++) pc[i] = c->pilot_carriers[i] + N / 2;                 // :134-137
+    for (int i = 0; i < ND; i++) dc[i] = c->data_carriers[i] + N / 2;                  // :139-142
+    for (int v : dc) if (v < 0 || v >= N) return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "data carrier index out of bounds");
+    for (int v : pc) if (v < 0 || v >= N) return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "pilot carrier index out of bounds");
+    ac = dc; ac.insert(ac.end(), pc.begin(), pc.end());
+    std::sort(ac.begin(), ac.end());                                                    // :159
+    jrc_equalizer* eq = new jrc_equalizer();
+    eq->ctx = ctx; eq->n_streams = n_streams;
+    const size_t b_int = sizeof(int) * (size_t)(ND + NP + ac.size());
+    const size_t b_ps = sizeof(float2) * (size_t)c->n_pilot_rows * NP, b_ltf = sizeof(float2) * N;
+    const size_t b_map = sizeof(float2) * (size_t)N * c->mapped_cols;
+    const size_t off_ps = (b_int + 15) & ~size_t(15);
+    const size_t total = off_ps + b_ps + b_ltf + b_map;
+    std::vector<unsigned char> host(total);
+    memcpy(host.data(), dc.data(), sizeof(int) * ND);
+    memcpy(host.data() + sizeof(int) * ND, pc.data(), sizeof(int) * NP);
+    memcpy(host.data() + sizeof(int) * (ND + NP), ac.data(), sizeof(int) * ac.size());
+    memcpy(host.data() + off_ps, c->pilot_symbols, b_ps);
+    memcpy(host.data() + off_ps + b_ps, c->ltf_seq, b_ltf);
+    memcpy(host.data() + off_ps + b_ps + b_ltf, c->mapped_ltf, b_map);
+    hipError_t e = hipMalloc(&eq->tables, total);
+    if (e == hipSuccess) e = hipMemcpy(eq->tables, host.data(), total, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void**)&eq->states, sizeof(EqState) * n_streams);
+    if (e == hipSuccess) e = hipMemset(eq->states, 0, sizeof(EqState) * n_streams);    // sig_ok = 0: skip until a frame_start
+    if (e == hipSuccess) e = hipMalloc((void**)&eq->H, sizeof(float2) * (size_t)N * n_streams);
+    if (e == hipSuccess) e = hipMalloc((void**)&eq->Hm, sizeof(float2) * (size_t)N * n_streams);
+    if (e == hipSuccess) e = hipMalloc((void**)&eq->pre, sizeof(float2) * (size_t)N * c->n_mimo_ltf * n_streams);
+    if (e == hipSuccess) e = hipMalloc((void**)&eq->counters, sizeof(int) * 4 * (size_t)n_streams);
+    if (e == hipSuccess) e = hipMemset(eq->H, 0, sizeof(float2) * (size_t)N * n_streams);
+    if (e == hipSuccess) e = hipMemset(eq->Hm, 0, sizeof(float2) * (size_t)N * n_streams);
+    if (e == hipSuccess) e = hipMemset(eq->pre, 0, sizeof(float2) * (size_t)N * c->n_mimo_ltf * n_streams);
+    if (e != hipSuccess) { jrc_equalizer_destroy(eq); return jrc_fail(ctx, JRC_ERR_HIP, "jrc_equalizer_create: %s", hipGetErrorString(e)); }
+    unsigned char* tb = (unsigned char*)eq->tables;
+    EqDev& d = eq->d;
+    d.N = N; d.cp = c->cp_len; d.ND = ND; d.NP = NP; d.NAct = (int)ac.size(); d.NL = c->n_mimo_ltf; d.T = T;
+    d.mapped_cols = c->mapped_cols; d.n_pilot_rows = c->n_pilot_rows; d.estimator = c->estimator;
+    d.freq = c->freq; d.bw = c->bw;
+    d.data_c = (const int*)tb; d.pilot_c = d.data_c + ND; d.active_c = d.pilot_c + NP;
+    d.pilot_sym = (const float2*)(tb + off_ps); d.ltf = (const float2*)(tb + off_ps + b_ps);
+    d.mapped = (const float2*)(tb + off_ps + b_ps + b_ltf);
+    eq->threads = N >= 1024 ? 1024 : ((N + 63) / 64) * 64;
+    eq->lds_bytes = sizeof(float2) * (size_t)(3 * N + ND + NP) + sizeof(unsigned long long) * (ND / 2 + 1) + ND + ND / 2 + 16;
+    if (eq->lds_bytes > 64 * 1024)
+        JRC_HIP(ctx, hipFuncSetAttribute((const void*)equalizer_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eq->lds_bytes));
+    *out = eq;
+    return JRC_OK;
+}
+
+extern "C" void jrc_equalizer_destroy(jrc_equalizer* eq)
+{
+    if (!eq) return;
+    (void)hipStreamSynchronize(eq->ctx->stream);
+    if (eq->tables) (void)hipFree(eq->tables);
+    if (eq->states) (void)hipFree(eq->states);
+    if (eq->H) (void)hipFree(eq->H);
+    if (eq->Hm) (void)hipFree(eq->Hm);
+    if (eq->pre) (void)hipFree(eq->pre);
+    if (eq->counters) (void)hipFree(eq->counters);
+    delete eq;
+}
+
+extern "C" int jrc_equalizer_set_estimator(jrc_equalizer* eq, int algo)
+{
+    if (!eq) return JRC_ERR_INVALID_ARG;
+    if (algo != 0 && algo != 1) return jrc_fail(eq->ctx, JRC_ERR_INVALID_ARG, "[OFDM Equalizer] Estimator not implemented");
+    eq->d.estimator = algo;
+    return JRC_OK;
+}
+extern "C" int jrc_equalizer_set_bandwidth(jrc_equalizer* eq, double bw) { if (!eq) return JRC_ERR_INVALID_ARG; eq->d.bw = bw; return JRC_OK; }
+extern "C" int jrc_equalizer_set_frequency(jrc_equalizer* eq, double f) { if (!eq) return JRC_ERR_INVALID_ARG; eq->d.freq = f; return JRC_OK; }
+
+extern "C" int jrc_equalizer_work(jrc_equalizer* eq, int stream, int noutput_items, int ninput_items, const jrc_cf32* in,
+                                  const int64_t* tag_offsets, const double* tag_values, int n_tags, jrc_cf32* out,
+                                  int* n_consumed, jrc_eq_event* events, int max_events, int* n_events,
+                                  jrc_cf32* chan_est, int* chan_est_written)
+{
+    if (!eq || !in || !out || !n_consumed || !n_events || (max_events > 0 && !events)) return JRC_ERR_INVALID_ARG;
+    jrc_ctx* ctx = eq->ctx;
+    if (stream < 0 || stream >= eq->n_streams || noutput_items < 0 || ninput_items < 0 || n_tags < 0 || max_events < 0)
+        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_equalizer_work: bad stream/sizes");
+    *n_consumed = 0; *n_events = 0;
+    if (chan_est_written) *chan_est_written = 0;
+    if (ninput_items == 0 || noutput_items == 0) return 0;
+    JRC_HIP(ctx, hipSetDevice(ctx->device));
+    const EqDev& d = eq->d;
+    const size_t b_in = sizeof(float2) * (size_t)ninput_items * d.N, b_out = sizeof(float2) * (size_t)noutput_items * d.ND;
+    const size_t b_tag = (sizeof(long long) + sizeof(double)) * (size_t)(n_tags ? n_tags : 1);
+    const size_t b_ev = sizeof(jrc_eq_event) * (size_t)(max_events ? max_events : 1), b_ce = sizeof(float2) * (size_t)d.N * d.T;
+    JRC_TRY(jrc_ensure_pinned(ctx, b_in + b_tag + b_out + b_ev + b_ce + 64));
+    JRC_TRY(jrc_ensure_scratch(ctx, 0, b_in + b_tag));
+    JRC_TRY(jrc_ensure_scratch(ctx, 1, b_out));
+    JRC_TRY(jrc_ensure_scratch(ctx, 2, b_ev + b_ce));
+    unsigned char* hp = (unsigned char*)ctx->pinned;
+    memcpy(hp, in, b_in);
+    long long* h_off = (long long*)(hp + b_in);
+    double* h_val = (double*)(h_off + (n_tags ? n_tags : 1));
+    for (int t = 0; t < n_tags; t++) { h_off[t] = tag_offsets[t]; h_val[t] = tag_values[t]; }
+    if (!n_tags) { h_off[0] = -1; h_val[0] = 0; }
+    JRC_HIP(ctx, hipMemcpyAsync(ctx->scratch[0], hp, b_in + b_tag, hipMemcpyHostToDevice, ctx->stream));
+    EqIo io;
+    io.in = (const float2*)ctx->scratch[0]; io.in_stride = 0; io.ninput = ninput_items;
+    io.tag_offsets = (const long long*)((unsigned char*)ctx->scratch[0] + b_in);
+    io.tag_values = (const double*)(io.tag_offsets + (n_tags ? n_tags : 1)); io.n_tags = n_tags ? n_tags : 1;
+    io.out = (float2*)ctx->scratch[1]; io.out_stride = 0; io.noutput = noutput_items;
+    int* cnt = eq->counters + 4 * (size_t)stream;
+    io.n_out = cnt; io.n_consumed = cnt + 1; io.n_events = cnt + 2; io.chan_est_written = cnt + 3;
+    io.events = (jrc_eq_event*)ctx->scratch[2]; io.max_events = max_events;
+    io.chan_est = (float2*)((unsigned char*)ctx->scratch[2] + b_ev);
+    io.stream0 = stream;
+    hipLaunchKernelGGL(equalizer_kernel, dim3(1), dim3(eq->threads), eq->lds_bytes, ctx->stream, eq->d, eq->states, eq->H,
+                       eq->Hm, eq->pre, io);
+    JRC_HIP(ctx, hipGetLastError());
+    unsigned char* h_out = hp + b_in + b_tag;
+    int* h_cnt = (int*)(h_out + b_out + b_ev + b_ce);
+    JRC_HIP(ctx, hipMemcpyAsync(h_cnt, cnt, sizeof(int) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    JRC_HIP(ctx, hipMemcpyAsync(h_out, ctx->scratch[1], b_out, hipMemcpyDeviceToHost, ctx->stream));
+    JRC_HIP(ctx, hipMemcpyAsync(h_out + b_out, ctx->scratch[2], b_ev + b_ce, hipMemcpyDeviceToHost, ctx->stream));
+    JRC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int n_out = h_cnt[0];
+    memcpy(out, h_out, sizeof(float2) * (size_t)n_out * d.ND);
+    *n_consumed = h_cnt[1];
+    *n_events = h_cnt[2];
+    for (int i = 0; i < h_cnt[2]; i++) events[i] = ((jrc_eq_event*)(h_out + b_out))[i];
+    if (h_cnt[3]) {
+        if (chan_est) memcpy(chan_est, h_out + b_out + b_ev, b_ce);
+        if (chan_est_written) *chan_est_written = 1;
+    }
+    return n_out;
+}
+
+extern "C" int jrc_equalizer_frames_dev(jrc_equalizer* eq, int n_streams, int n_symbols, const jrc_cf32* d_in,
+                                        const double* d_phase, int max_out, jrc_cf32* d_out, int32_t* d_n_out,
+                                        jrc_eq_event* d_events, void* stream)
+{
+    if (!eq || !d_in || !d_phase || !d_out || !d_n_out || !d_events) return JRC_ERR_INVALID_ARG;
+    jrc_ctx* ctx = eq->ctx;
+    if (n_streams <= 0 || n_streams > eq->n_streams || n_symbols <= 0 || max_out <= 0)
+        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_equalizer_frames_dev: bad sizes");
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    EqIo io;
+    io.in = (const float2*)d_in; io.in_stride = (long)n_symbols * eq->d.N; io.ninput = n_symbols;
+    io.tag_offsets = nullptr; io.tag_values = d_phase; io.n_tags = 1;
+    io.out = (float2*)d_out; io.out_stride = (long)max_out * eq->d.ND; io.noutput = max_out;
+    io.n_out = d_n_out; io.n_consumed = eq->counters; io.n_events = eq->counters + eq->n_streams;
+    io.chan_est_written = nullptr; io.events = d_events; io.max_events = 2; io.chan_est = nullptr; io.stream0 = 0;
+    hipLaunchKernelGGL(equalizer_kernel, dim3(n_streams), dim3(eq->threads), eq->lds_bytes, s, eq->d, eq->states, eq->H,
+                       eq->Hm, eq->pre, io);
+    JRC_HIP(ctx, hipGetLastError());
+    return JRC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C3 steering
+__global__ void steering_kernel(const float2* __restrict__ h, float2* __restrict__ Q, int T, int n, int phased)
+{
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float2* hv = h + (size_t)i * T;
+    float2* q = Q + (size_t)i * T * T;
+    const float sqT = sqrtf((float)T);
+    if (phased) {                                                                        // :848-853
+        float nrm = 0.f;
+        for (int t = 0; t < T; t++) nrm = nrm + (hv[t].x * hv[t].x + hv[t].y * hv[t].y);
+        nrm = sqrtf(nrm);
+        for (int k = 0; k < T * T; k++) q[k] = make_float2(0.f, 0.f);
+        for (int t = 0; t < T; t++) q[t] = make_float2(hv[t].x * sqT / nrm, -hv[t].y * sqT / nrm);
+        return;
+    }
+    float2 x[8], v[8];
+    for (int t = 0; t < T; t++) x[t] = c_conj(hv[t]);
+    float tail = 0.f;
+    for (int t = 1; t < T; t++) tail = tail + (x[t].x * x[t].x + x[t].y * x[t].y);
+    const float2 c0 = x[0];
+    float2 tau;
+    v[0] = make_float2(1.f, 0.f);
+    if (tail <= 1.17549435e-38f && c0.y * c0.y <= 1.17549435e-38f) {                      // Eigen makeHouseholder degenerate case
+        tau = make_float2(0.f, 0.f);
+        for (int t = 1; t < T; t++) v[t] = make_float2(0.f, 0.f);
+    } else {
+        float beta = sqrtf((c0.x * c0.x + c0.y * c0.y) + tail);
+        if (c0.x >= 0) beta = -beta;
+        const float2 den = make_float2(c0.x - beta, c0.y);
+        for (int t = 1; t < T; t++) v[t] = c_div(x[t], den);
+        const float2 tt = make_float2((beta - c0.x) / beta, (-c0.y) / beta);
+        tau = c_conj(tt);
+    }
+    float fro = 0.f;
+    const float2 ctau = c_conj(tau);
+    for (int col = 0; col < T; col++)
+        for (int rw = 0; rw < T; rw++) {                                                  // V = H^H = I - conj(tau) v v^H
+            const float2 vv = c_mul(c_mul(ctau, v[rw]), c_conj(v[col]));
+            const float2 e = make_float2((rw == col ? 1.f : 0.f) - vv.x, -vv.y);
+            q[(size_t)col * T + rw] = e;
+            fro = fro + (e.x * e.x + e.y * e.y);
+        }
+    fro = sqrtf(fro);
+    for (int k = 0; k < T * T; k++) q[k] = make_float2(q[k].x * sqT / fro, q[k].y * sqT / fro);   // :858
+}
+
+extern "C" int jrc_steering_from_channel(jrc_ctx* ctx, int T, int n, const jrc_cf32* h, int phased, jrc_cf32* Q)
+{
+    if (!ctx || !h || !Q || n < 0) return JRC_ERR_INVALID_ARG;
+    if (T < 1 || T > 8) return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "steering: N_tx must be in [1, 8]");
+    if (n == 0) return JRC_OK;
+    JRC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t b_h = sizeof(float2) * (size_t)n * T, b_q = sizeof(float2) * (size_t)n * T * T;
+    JRC_TRY(jrc_ensure_pinned(ctx, b_h + b_q));
+    JRC_TRY(jrc_ensure_scratch(ctx, 0, b_h));
+    JRC_TRY(jrc_ensure_scratch(ctx, 1, b_q));
+    memcpy(ctx->pinned, h, b_h);
+    JRC_HIP(ctx, hipMemcpyAsync(ctx->scratch[0], ctx->pinned, b_h, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(steering_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, (const float2*)ctx->scratch[0],
+                       (float2*)ctx->scratch[1], T, n, phased);
+    JRC_HIP(ctx, hipGetLastError());
+    JRC_HIP(ctx, hipMemcpyAsync((char*)ctx->pinned + b_h, ctx->scratch[1], b_q, hipMemcpyDeviceToHost, ctx->stream));
+    JRC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(Q, (char*)ctx->pinned + b_h, b_q);
+    return JRC_OK;
+}
+
+static void dft_matrix_host(int T, float2* F)   // get_dft_matrix_eigen :761-772, column-major
+{
+    for (int r = 0; r < T; r++)
+        for (int c = 0; c < T; c++) {
+            const float ang = (float)(-2 * M_PI * float(r * c) / float(T));
+            const float s = (float)std::sqrt((double)T);
+            F[(size_t)c * T + r] = make_float2(cosf(ang) / s, sinf(ang) / s);
+        }
+}
+
+extern "C" int jrc_dft_matrix(jrc_ctx* ctx, int T, jrc_cf32* F)
+{
+    if (!ctx || !F || T < 1 || T > 16) return JRC_ERR_INVALID_ARG;
+    dft_matrix_host(T, (float2*)F);
+    return JRC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C2 precoder: one lane per (OFDM symbol k, subcarrier sc), writing all T output ports
+struct PreDev {
+    int N, T, ND, NP, NS, n_pilot_rows;
+    const int* data_c; const int* pilot_c; const short* role;   // role[sc]: -1 unused, 0..ND-1 data index, 0x4000|k pilot index
+    const float2* pilot_sym; const float2* sync; const float2* mapped;
+};
+
+__global__ __launch_bounds__(256) void precoder_kernel(PreDev d, const float2* __restrict__ in, const float* __restrict__ sig,
+                                                       int n_sym, int packet_type, int steer_mode,
+                                                       const float2* __restrict__ Qm, const float2* __restrict__ Qsc,
+                                                       const float2* __restrict__ rs, float2* __restrict__ out /* [T][n_total][N] */)
+{
+    const int N = d.N, T = d.T, NL = d.T;
+    const int n_total = n_sym + d.NS + T + 1;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)n_total * N) return;
+    const int k = (int)(idx / N), sc = (int)(idx % N);
+    const short role = d.role[sc];
+    float2 o[8];
+    for (int t = 0; t < T; t++) o[t] = make_float2(0.f, 0.f);                             // memset :337
+    if (k < d.NS) {                                                                       // sync words, ports 0,1 only :340-347
+        for (int t = 0; t < T && t < 2; t++) o[t] = d.sync[(size_t)k * N + sc];
+    } else if (k == d.NS) {                                                               // SIG :353-371
+        float2 v = make_float2(0.f, 0.f);
+        if (role >= 0 && !(role & 0x4000)) v = make_float2(sig[role], 0.f);
+        else if (role >= 0) v = d.pilot_sym[role & 0x3fff];
+        for (int t = 0; t < T && t < 2; t++) o[t] = v;
+    } else if (k < d.NS + 1 + T) {                                                        // MIMO-LTFs
+        const int l = k - d.NS - 1;
+        const float2* X = d.mapped + (size_t)sc * T * NL;                                 // row-major T x NL
+        if (packet_type == 1) {                                                           // NDP :379-388
+            for (int t = 0; t < T; t++) o[t] = X[t * NL + l];
+        } else {                                                                          // DATA :536-581
+            bool zero = true;
+            for (int i = 0; i < T * NL; i++) if (X[i].x != 0.f || X[i].y != 0.f) zero = false;
+            if (!zero) {
+                const float2* Q = steer_mode == 2 ? Qsc + (size_t)sc * T * T : Qm;
+                for (int t = 0; t < T; t++) {
+                    float2 acc = make_float2(0.f, 0.f);
+                    for (int j = 0; j < T; j++) acc = cadd(acc, cmul(Q[(size_t)j * T + t], X[j * NL + l]));
+                    o[t] = acc;
+                }
+            }
+        }
+    } else if (role >= 0) {                                                               // data / pilot carriers
+        const int m = k - d.NS - 1 - T;
+        float2 s0;
+        if (role & 0x4000) s0 = d.pilot_sym[(size_t)(m % d.n_pilot_rows) * d.NP + (role & 0x3fff)];
+        else s0 = in[(size_t)m * d.ND + role];
+        if (packet_type == 1) {                                                           // NDP :394-428
+            for (int t = 0; t < T && t < 2; t++) o[t] = s0;
+        } else {                                                                          // DATA :589-712
+            const float2* Q = steer_mode == 2 ? Qsc + (size_t)sc * T * T : Qm;
+            for (int t = 0; t < T; t++) {
+                float2 acc = cmul(Q[t], s0);                                              // column 0 = the data stream
+                if (rs)
+                    for (int j = 1; j < T; j++) acc = cadd(acc, cmul(Q[(size_t)j * T + t], rs[((size_t)(j - 1) * n_sym + m) * N + sc]));
+                o[t] = acc;
+            }
+        }
+    }
+    for (int t = 0; t < T; t++) out[((size_t)t * n_total + k) * N + sc] = o[t];
+}
+
+struct jrc_precoder {
+    jrc_ctx* ctx;
+    PreDev d;
+    void* tables = nullptr;
+    float2 dft[64];
+    std::vector<int> dc, pc;
+};
+
+extern "C" int jrc_precoder_create(jrc_ctx* ctx, const jrc_pre_cfg* c, jrc_precoder** out)
+{
+    if (!ctx || !c || !out) return JRC_ERR_INVALID_ARG;
+    const int N = c->fft_len, T = c->N_tx, ND = c->n_data, NP = c->n_pilot;
+    if (N <= 0 || T <= 0 || !c->data_carriers || ND <= 0)
+        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "Data carriers must be of type vector of vector i.e. ().");           // :119-122
+    if (!c->pilot_carriers || NP <= 0)
+        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "Pilot carriers must be of type vector of vector i.e. ((),).");        // :139-141
+    if (!c->pilot_symbols || c->n_pilot_rows <= 0)
+        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "Pilot symbols must be of type vector of vector i.e. ((),).");         // :155-157
+    if (!c->sync_words || !c->mapped_ltf || c->n_sync < 0) return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "mimo_precoder: missing tables");
+    if (T > 8 || ND < 48 || ND >= 0x4000) return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "mimo_precoder: N_tx <= 8, 48 <= data carriers < 16384");
+    jrc_precoder* p = new jrc_precoder();
+    p->ctx = ctx;
+    p->dc.resize(ND); p->pc.resize(NP);
+    std::vector<short> role(N, -1);
+    for (int i = 0; i < ND; i++) {                                                        // :124-137
+        int v = c->data_carriers[i];
+        if (v < 0) v += N;
+        if (v > N || v < 0) { delete p; return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "data carrier index out of bounds"); }
+        p->dc[i] = (v + N / 2) % N;
+        role[p->dc[i]] = (short)i;
+    }
+    for (int i = 0; i < NP; i++) {                                                        // :143-153
+        int v = c->pilot_carriers[i];
+        if (v < 0) v += N;
+        if (v > N || v < 0) { delete p; return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "pilot carrier index out of bounds"); }
+        p->pc[i] = (v + N / 2) % N;
+        role[p->pc[i]] = (short)(0x4000 | i);
+    }
+    JRC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t b_role = (sizeof(short) * N + 15) & ~size_t(15);
+    const size_t b_ps = sizeof(float2) * (size_t)c->n_pilot_rows * NP, b_sync = sizeof(float2) * (size_t)c->n_sync * N;
+    const size_t b_map = sizeof(float2) * (size_t)N * T * T;
+    std::vector<unsigned char> host(b_role + b_ps + b_sync + b_map);
+    memcpy(host.data(), role.data(), sizeof(short) * N);
+    memcpy(host.data() + b_role, c->pilot_symbols, b_ps);
+    memcpy(host.data() + b_role + b_ps, c->sync_words, b_sync);
+    memcpy(host.data() + b_role + b_ps + b_sync, c->mapped_ltf, b_map);
+    hipError_t e = hipMalloc(&p->tables, host.size());
+    if (e == hipSuccess) e = hipMemcpy(p->tables, host.data(), host.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { jrc_precoder_destroy(p); return jrc_fail(ctx, JRC_ERR_HIP, "jrc_precoder_create: %s", hipGetErrorString(e)); }
+    unsigned char* tb = (unsigned char*)p->tables;
+    PreDev& d = p->d;
+    d.N = N; d.T = T; d.ND = ND; d.NP = NP; d.NS = c->n_sync; d.n_pilot_rows = c->n_pilot_rows;
+    d.data_c = nullptr; d.pilot_c = nullptr; d.role = (const short*)tb;
+    d.pilot_sym = (const float2*)(tb + b_role); d.sync = (const float2*)(tb + b_role + b_ps);
+    d.mapped = (const float2*)(tb + b_role + b_ps + b_sync);
+    dft_matrix_host(T, p->dft);
+    *out = p;
+    return JRC_OK;
+}
+
+extern "C" void jrc_precoder_destroy(jrc_precoder* p)
+{
+    if (!p) return;
+    (void)hipStreamSynchronize(p->ctx->stream);
+    if (p->tables) (void)hipFree(p->tables);
+    delete p;
+}
+
+extern "C" int jrc_precoder_output_length(const jrc_precoder* p, int ninput_items)
+{
+    if (!p) return JRC_ERR_INVALID_ARG;
+    return p->d.NS + 1 + p->d.T + ninput_items / p->d.ND;                                 // :265-272
+}
+
+extern "C" int jrc_precoder_work(jrc_precoder* p, int ninput_items, const jrc_cf32* in, int mcs, int packet_type,
+                                 int pdu_len, int steer_mode, const jrc_cf32* Q_mean, const jrc_cf32* Q_sc,
+                                 const jrc_cf32* radar_streams, jrc_cf32* const* out)
+{
+    if (!p || !in || !out) return JRC_ERR_INVALID_ARG;
+    jrc_ctx* ctx = p->ctx;
+    const PreDev& d = p->d;
+    const int N = d.N, T = d.T;
+    if (packet_type != 1 && packet_type != 2)
+        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "[MIMO PRECODER] packet type is not defined!");              // :716-719
+    if (mcs < 0 || mcs > 5) return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "[MIMO PRECODER] unknown mcs");
+    const int n_sym = ninput_items / d.ND;
+    if (n_ofdm_sym_dev(mcs, d.ND, pdu_len) != n_sym)
+        return jrc_fail(ctx, JRC_ERR_SIG_FIELD, "%s", jrc_strerror(JRC_ERR_SIG_FIELD));                         // :327-333
+    if (steer_mode < 0 || steer_mode > 2 || (steer_mode == 1 && !Q_mean) || (steer_mode == 2 && !Q_sc))
+        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "mimo_precoder: steering matrices missing for steer_mode %d", steer_mode);
+    JRC_HIP(ctx, hipSetDevice(ctx->device));
+    const int n_total = n_sym + d.NS + T + 1;
+    const size_t b_in = sizeof(float2) * (size_t)n_sym * d.ND, b_sig = sizeof(float) * (size_t)d.ND;
+    const size_t b_qm = sizeof(float2) * (size_t)T * T, b_qsc = steer_mode == 2 ? sizeof(float2) * (size_t)N * T * T : 0;
+    const size_t b_rs = radar_streams ? sizeof(float2) * (size_t)(T - 1) * n_sym * N : 0;
+    const size_t b_out = sizeof(float2) * (size_t)T * n_total * N;
+    const size_t b_up = b_in + b_sig + b_qm + b_qsc + b_rs;
+    JRC_TRY(jrc_ensure_pinned(ctx, b_up > b_out ? b_up : b_out));
+    JRC_TRY(jrc_ensure_scratch(ctx, 0, b_up));
+    JRC_TRY(jrc_ensure_scratch(ctx, 1, b_out));
+    unsigned char* hp = (unsigned char*)ctx->pinned;
+    memcpy(hp, in, b_in);
+    JRC_TRY(jrc_sig_encode(d.ND, mcs, packet_type, pdu_len, (float*)(hp + b_in)));                              // generate_signal_field
+    memcpy(hp + b_in + b_sig, steer_mode == 1 ? (const void*)Q_mean : (const void*)p->dft, b_qm);
+    if (b_qsc) memcpy(hp + b_in + b_sig + b_qm, Q_sc, b_qsc);
+    if (b_rs) memcpy(hp + b_in + b_sig + b_qm + b_qsc, radar_streams, b_rs);
+    JRC_HIP(ctx, hipMemcpyAsync(ctx->scratch[0], hp, b_up, hipMemcpyHostToDevice, ctx->stream));
+    unsigned char* dp = (unsigned char*)ctx->scratch[0];
+    const size_t total = (size_t)n_total * N;
+    hipLaunchKernelGGL(precoder_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, p->d,
+                       (const float2*)dp, (const float*)(dp + b_in), n_sym, packet_type, steer_mode,
+                       (const float2*)(dp + b_in + b_sig), b_qsc ? (const float2*)(dp + b_in + b_sig + b_qm) : nullptr,
+                       b_rs ? (const float2*)(dp + b_in + b_sig + b_qm + b_qsc) : nullptr, (float2*)ctx->scratch[1]);
+    JRC_HIP(ctx, hipGetLastError());
+    JRC_HIP(ctx, hipMemcpyAsync(hp, ctx->scratch[1], b_out, hipMemcpyDeviceToHost, ctx->stream));
+    JRC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int t = 0; t < T; t++) memcpy(out[t], hp + sizeof(float2) * (size_t)t * n_total * N, sizeof(float2) * (size_t)n_total * N);
+    return n_total;
+}

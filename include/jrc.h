@@ -173,6 +173,96 @@ int  jrc_chain_set_timing(jrc_chain* chain, int enabled);
  * ms[0]=radar_chanest, ms[1]=range_angle_fused, ms[2]=ra_finalize; *launches = runs measured */
 int  jrc_chain_get_timing(jrc_chain* chain, float ms[3], int* launches);
 
+/* ---- C1  mimo_ofdm_equalizer (replaces mimo_ofdm_equalizer_impl::general_work and helpers,
+ *          lib/mimo_ofdm_equalizer_impl.cc:191-922; ctor :66-180; setters :924-960) -------------------------
+ * One jrc_equalizer holds `n_streams` independent per-RX-stream states (the reference block has one input
+ * port; "4 RX" = 4 instances).  The per-symbol state machine (L-LTF LS estimate, SIG decode incl. the K=7
+ * Viterbi, MIMO-LTF estimate, pilot CPE tracking, ZF / MMSE-like equalisation, optional STA update) runs in
+ * one kernel, one workgroup per stream, one lane per subcarrier. */
+typedef struct {
+    int32_t estimator;                 /* ChannelEstimator: 0 = LS, 1 = STA (include/mimo_ofdm_jrc/mimo_ofdm_equalizer.h:27-30) */
+    double  freq, bw;
+    int32_t fft_len, cp_len;
+    int32_t n_data, n_pilot;
+    const int32_t* data_carriers;      /* signed subcarrier indices exactly as passed to make() */
+    const int32_t* pilot_carriers;
+    int32_t n_pilot_rows;
+    const jrc_cf32* pilot_symbols;     /* [n_pilot_rows][n_pilot] */
+    const jrc_cf32* ltf_seq;           /* [fft_len] */
+    const jrc_cf32* mapped_ltf;        /* [fft_len][mapped_cols], mapped_cols = N_tx * n_mimo_ltf */
+    int32_t mapped_cols, n_mimo_ltf;
+} jrc_eq_cfg;
+
+typedef struct {
+    int32_t  kind;                     /* 1 = "stream_start" tag (:331-337), 2 = "stream_end" tag (:626-629) */
+    int32_t  n_chan_mean;
+    int64_t  offset;                   /* output item the tag sits on, relative to this call (may be -1) */
+    uint64_t data_bytes, mcs, packet_type;
+    double   snr, freq_offset;         /* stream_start dict */
+    double   snr_data;                 /* stream_end dict */
+    jrc_cf32 chan_mean[16];            /* stream_end dict "chan_mean" */
+} jrc_eq_event;
+
+typedef struct jrc_equalizer jrc_equalizer;
+int  jrc_equalizer_create(jrc_ctx* ctx, const jrc_eq_cfg* cfg, int n_streams, jrc_equalizer** eq);
+void jrc_equalizer_destroy(jrc_equalizer* eq);
+int  jrc_equalizer_set_estimator(jrc_equalizer* eq, int algo);
+int  jrc_equalizer_set_bandwidth(jrc_equalizer* eq, double bw);
+int  jrc_equalizer_set_frequency(jrc_equalizer* eq, double freq);
+/* general_work() of stream `stream`: in = ninput_items vectors of fft_len; frame_start tags given as item
+ * offsets relative to `in` plus their double value; out = up to noutput_items vectors of n_data.
+ * chan_est (may be NULL): [fft_len][N_tx], written when an NDP frame's MIMO-LTFs complete (the content of the
+ * reference's chan_est_file, :378-416); *chan_est_written says so.  Returns items produced or < 0. */
+int  jrc_equalizer_work(jrc_equalizer* eq, int stream, int noutput_items, int ninput_items, const jrc_cf32* in,
+                        const int64_t* tag_offsets, const double* tag_values, int n_tags, jrc_cf32* out,
+                        int* n_consumed, jrc_eq_event* events, int max_events, int* n_events,
+                        jrc_cf32* chan_est, int* chan_est_written);
+/* Batched, device-resident: every stream s gets one frame of n_symbols vectors starting at
+ * d_in + s*n_symbols*fft_len with a frame_start tag of value d_phase[s] on its first item.
+ * d_out: [n_streams][max_out][n_data]; d_n_out: [n_streams] items produced; d_events: [n_streams][2]. */
+int  jrc_equalizer_frames_dev(jrc_equalizer* eq, int n_streams, int n_symbols, const jrc_cf32* d_in,
+                              const double* d_phase, int max_out, jrc_cf32* d_out, int32_t* d_n_out,
+                              jrc_eq_event* d_events, void* stream);
+
+/* ---- C3  steering matrices (replaces the per-subcarrier body of compute_steering_matrix /
+ *          compute_radar_aided_steering, lib/mimo_precoder_impl.cc:846-861, :880-893, :961-974) -----------
+ * h: [n][T] channel rows; Q: [n][T*T] column-major (Eigen layout of steering_matrix[sc]).
+ * phased: Q[:,0] = sqrt(T) conj(h)/||h||, rest 0.  Otherwise Q = V sqrt(T)/||V||_F with V the full
+ * right-singular basis Eigen's JacobiSVD returns for a 1 x T row (Householder construction). T <= 8. */
+int jrc_steering_from_channel(jrc_ctx* ctx, int T, int n, const jrc_cf32* h, int phased, jrc_cf32* Q);
+/* get_dft_matrix_eigen (lib/mimo_precoder_impl.cc:761-772), column-major T x T */
+int jrc_dft_matrix(jrc_ctx* ctx, int T, jrc_cf32* F);
+
+/* ---- C2  mimo_precoder (replaces mimo_precoder_impl::work, lib/mimo_precoder_impl.cc:275-741;
+ *          generate_signal_field :985-1060; calculate_output_stream_length :265-272) -------------------- */
+typedef struct {
+    int32_t fft_len, N_tx;
+    int32_t n_data, n_pilot;
+    const int32_t* data_carriers;
+    const int32_t* pilot_carriers;
+    int32_t n_pilot_rows;
+    const jrc_cf32* pilot_symbols;     /* [n_pilot_rows][n_pilot] */
+    int32_t n_sync;
+    const jrc_cf32* sync_words;        /* [n_sync][fft_len] */
+    const jrc_cf32* mapped_ltf;        /* [fft_len][N_tx*N_tx] */
+} jrc_pre_cfg;
+typedef struct jrc_precoder jrc_precoder;
+int  jrc_precoder_create(jrc_ctx* ctx, const jrc_pre_cfg* cfg, jrc_precoder** pre);
+void jrc_precoder_destroy(jrc_precoder* pre);
+int  jrc_precoder_output_length(const jrc_precoder* pre, int ninput_items);
+/* steer_mode: 0 = DFT ("fourier") precoding, 1 = one steering matrix Q_mean for every subcarrier (channel
+ * smoothing / radar-aided), 2 = per-subcarrier Q_sc[fft_len][T*T].  Matrices column-major.
+ * radar_streams: NULL (use_radar_streams = false) or [(T-1)][n_sym][fft_len] symbols for streams 1..T-1 (the
+ * reference draws them from std::random_device, :435-437; here the caller supplies them).
+ * out[t]: [n_sync + 1 + N_tx + n_sym][fft_len].  Returns items produced per port, or JRC_ERR_SIG_FIELD. */
+int  jrc_precoder_work(jrc_precoder* pre, int ninput_items, const jrc_cf32* in, int mcs, int packet_type,
+                       int pdu_len, int steer_mode, const jrc_cf32* Q_mean, const jrc_cf32* Q_sc,
+                       const jrc_cf32* radar_streams, jrc_cf32* const* out);
+
+/* SIG-field helpers shared by C1/C2 (host side; lib/utils.cc:26-111, lib/mimo_precoder_impl.cc:985-1060) */
+int  jrc_n_ofdm_sym(int mcs, int n_data_carriers, int data_size_byte);
+int  jrc_sig_encode(int n_data_carriers, int mcs, int packet_type, int length, float* out_re);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,181 @@
+"""GPU tier: equalizer (C1), precoder (C2) and steering (C3) entry points against the oracle on the same inputs.
+Tolerance: the north star's 1e-4 on ||a-b||_inf/||b||_inf; the kernels restate the reference's scalar complex
+arithmetic (libgcc division, unfused products), so what remains is libm-vs-ocml sin/cos/atan2 rounding (1e-6)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import crandn, rel_err
+from test_oracle_comm import qpsk, through_channel
+
+pytestmark = pytest.mark.gpu
+NDP, DATA, LS, STA = 1, 2, 0, 1
+TOL = 2e-5
+
+
+def blocks(jrc, ctx, o, est=LS, T=4):
+    dc, pc = o["data_subcarriers"], o["pilot_subcarriers"]
+    ps, sw, ml, ltf = o["pilot_symbols"], o["l_stf_ltf_64"], o["ltf_mapped_sc__ss_sym"], o["ltf_64"]
+    gp = jrc.mimo_precoder(64, T, 1, dc, pc, ps, sw, ml, ctx=ctx)
+    ge = jrc.mimo_ofdm_equalizer(est, 24e9, 125e6, 64, 16, dc, pc, ps, ltf, ml, T, ctx=ctx)
+    op = oracle.Precoder(64, T, 1, dc, pc, ps, sw, ml)
+    oe = oracle.Equalizer(est, 24e9, 125e6, 64, 16, dc, pc, ps, ltf, ml, T)
+    return gp, ge, op, oe
+
+
+def close(a, b, rel=1e-3):
+    return a == b or abs(a - b) < rel * max(1.0, abs(b))        # a == b also covers +-inf (noise-free channels)
+
+
+def same_events(ge, oe):
+    assert len(ge) == len(oe)
+    for a, b in zip(ge, oe):
+        assert a["kind"] == b["kind"] and a["offset"] == b["offset"]
+        if a["kind"] == 1:
+            assert (a["data_bytes"], a["mcs"], a["packet_type"]) == (b["data_bytes"], b["mcs"], b["packet_type"])
+            assert close(a["snr"], b["snr"]) and a["freq_offset"] == b["freq_offset"]
+        else:
+            assert close(a["snr_data"], b["snr_data"])
+            assert rel_err(a["chan_mean"], b["chan_mean"]) < TOL
+
+
+@pytest.mark.parametrize("T", [2, 4, 8])
+def test_steering_matrices(jrc, ctx, T):
+    rng = np.random.default_rng(T)
+    h = crandn(rng, 64, T)
+    h[3, 1:] = 0                                   # degenerate Householder case
+    h[5, 0] = -abs(h[5, 0])                        # both signs of Re x0
+    for phased in (False, True):
+        Q = jrc.steering_from_channel(h, phased, ctx=ctx)
+        ref = np.stack([oracle.steering_from_channel(h[i], phased) for i in range(64)])
+        assert rel_err(Q, ref) < 1e-6
+    Q = jrc.steering_from_channel(h, False, ctx=ctx)
+    for i in range(64):
+        assert np.allclose(Q[i].conj().T @ Q[i], np.eye(T), atol=5e-6)
+
+
+@pytest.mark.parametrize("ptype,steer", [(NDP, "dft"), (DATA, "dft"), (DATA, "mean"), (DATA, "sc"), (DATA, "radar")])
+def test_precoder_work(jrc, ctx, ofdm64, ptype, steer):
+    rng = np.random.default_rng(7)
+    gp, _, op, _ = blocks(jrc, ctx, ofdm64)
+    nbytes, mcs = 77, 2
+    ns = oracle.n_ofdm_sym(mcs, 48, nbytes)
+    assert jrc.n_ofdm_sym(mcs, 48, nbytes) == ns and gp.calculate_output_stream_length(ns * 48) == ns + 9
+    s = qpsk(rng, ns * 48)
+    kw = {}
+    if steer in ("mean", "radar"):
+        kw = dict(steer_mode=1, Q_mean=oracle.steering_from_channel(crandn(rng, 4)))
+    if steer == "sc":
+        kw = dict(steer_mode=2, Q_sc=np.stack([oracle.steering_from_channel(crandn(rng, 4)) for _ in range(64)]))
+    if steer == "radar":
+        kw["radar_streams"] = qpsk(rng, 3 * ns * 64).reshape(3, ns, 64)
+    got = gp.work(s, mcs, ptype, nbytes, **kw)
+    ref = op.work(s, mcs, ptype, nbytes, **kw)
+    assert got.shape == ref.shape and rel_err(got, ref) < 1e-6
+    assert np.array_equal(got[:, :5], ref[:, :5])          # sync words + SIG field are exact
+    with pytest.raises(RuntimeError, match="MIMO PRECODER"):
+        gp.work(s, mcs, ptype, nbytes + 200, **kw)
+
+
+@pytest.mark.parametrize("est", [LS, STA])
+@pytest.mark.parametrize("ptype", [NDP, DATA])
+@pytest.mark.parametrize("mcs", [0, 2, 3])
+def test_equalizer_whole_frame(jrc, ctx, ofdm64, est, ptype, mcs):
+    rng = np.random.default_rng(est * 10 + ptype + mcs)
+    gp, ge, op, oe = blocks(jrc, ctx, ofdm64, est)
+    nbytes = 45
+    ns = oracle.n_ofdm_sym(mcs, 48, nbytes)
+    s = qpsk(rng, ns * 48) if mcs >= 2 else (rng.integers(0, 2, ns * 48) * 2 - 1).astype(np.complex64)
+    y = through_channel(op.work(s, mcs, ptype, nbytes), crandn(rng, 4), 2e-3, rng)
+    y = np.concatenate([crandn(rng, 2, 64), y, crandn(rng, 3, 64)])        # junk before the tag and after the frame
+    g = ge.general_work(y, [(2, 0.013)])
+    o = oe.general_work(y, [(2, 0.013)])
+    assert g["consumed"] == o["consumed"] == len(y) and g["out"].shape == o["out"].shape == (ns, 48)
+    assert rel_err(g["out"], o["out"]) < TOL
+    same_events(g["events"], o["events"])
+    if ptype == NDP:
+        assert rel_err(g["chan_est"], o["chan_est"]) < TOL
+    else:
+        assert g["chan_est"] is None and o["chan_est"] is None
+
+
+def test_equalizer_split_calls_keep_state(jrc, ctx, ofdm64):
+    """work() may see a frame in pieces; state (incl. the MIMO-LTF store the reference loses) persists"""
+    rng = np.random.default_rng(5)
+    gp, ge, op, oe = blocks(jrc, ctx, ofdm64, STA)
+    nbytes, mcs = 120, 2
+    ns = oracle.n_ofdm_sym(mcs, 48, nbytes)
+    s = qpsk(rng, ns * 48)
+    y = through_channel(op.work(s, mcs, DATA, nbytes), crandn(rng, 4), 1e-3, rng)
+    whole = oe.general_work(y, [(0, -0.02)])
+    outs, pos = [], 0
+    for chunk in (1, 4, 3, 2, 100):
+        part = y[pos:pos + chunk]
+        if len(part) == 0:
+            break
+        r = ge.general_work(part, [(0, -0.02)] if pos == 0 else [])
+        assert r["consumed"] == len(part)
+        outs.append(r["out"])
+        pos += chunk
+    got = np.concatenate(outs)
+    assert got.shape == whole["out"].shape and rel_err(got, whole["out"]) < TOL
+
+
+def test_equalizer_limited_output_space_and_sig_failure(jrc, ctx, ofdm64):
+    rng = np.random.default_rng(6)
+    gp, ge, op, oe = blocks(jrc, ctx, ofdm64)
+    ns = oracle.n_ofdm_sym(2, 48, 60)
+    s = qpsk(rng, ns * 48)
+    y = through_channel(op.work(s, 2, NDP, 60), crandn(rng, 4))
+    g = ge.general_work(y, [(0, 0.0)], noutput_items=3)
+    o = oe.general_work(y, [(0, 0.0)], noutput_items=3)
+    assert g["consumed"] == o["consumed"] and g["out"].shape == o["out"].shape == (3, 48)
+    g2 = ge.general_work(y[g["consumed"]:])
+    o2 = oe.general_work(y[o["consumed"]:])
+    assert rel_err(np.concatenate([g["out"], g2["out"]]), np.concatenate([o["out"], o2["out"]])) < TOL
+    bad = y.copy()
+    bad[2] = crandn(rng, 64)                                   # destroy the SIG symbol
+    g = ge.general_work(bad, [(0, 0.0)])
+    o = oe.general_work(bad, [(0, 0.0)])
+    assert g["consumed"] == o["consumed"] and len(g["out"]) == len(o["out"])
+    same_events(g["events"], o["events"])
+
+
+def test_equalizer_batched_frames_on_device(jrc, ctx, ofdm64):
+    """config-C style: several RX lanes x frames, one workgroup each, device resident"""
+    import torch
+    rng = np.random.default_rng(8)
+    o = ofdm64
+    S = 6
+    gp, _, op, _ = blocks(jrc, ctx, o)
+    ge = jrc.mimo_ofdm_equalizer(LS, 24e9, 125e6, 64, 16, o["data_subcarriers"], o["pilot_subcarriers"], o["pilot_symbols"],
+                                 o["ltf_64"], o["ltf_mapped_sc__ss_sym"], 4, n_streams=S, ctx=ctx)
+    nbytes, mcs = 50, 2
+    ns = oracle.n_ofdm_sym(mcs, 48, nbytes)
+    frames, refs, phases = [], [], []
+    for i in range(S):
+        s = qpsk(rng, ns * 48)
+        y = through_channel(op.work(s, mcs, DATA if i % 2 else NDP, nbytes), crandn(rng, 4), 1e-3, rng)
+        ph = 0.01 * i
+        oe = oracle.Equalizer(LS, 24e9, 125e6, 64, 16, o["data_subcarriers"], o["pilot_subcarriers"], o["pilot_symbols"],
+                              o["ltf_64"], o["ltf_mapped_sc__ss_sym"], 4)
+        refs.append(oe.general_work(y, [(0, ph)]))
+        frames.append(y)
+        phases.append(ph)
+    x = np.stack(frames)
+    d_in = torch.from_numpy(x.view(np.float32).reshape(S, x.shape[1], 64, 2)).to("cuda:0")
+    d_ph = torch.tensor(phases, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    out, n_out, ev = ge.frames_dev(d_in, d_ph, x.shape[1], ns)
+    ctx.sync()
+    out = out.cpu().numpy().view(np.complex64)[..., 0]
+    assert n_out.cpu().tolist() == [ns] * S
+    evb = ev.cpu().numpy()
+    for i in range(S):
+        assert rel_err(out[i], refs[i]["out"]) < TOL
+        e0 = jrc.EqEvent.from_buffer_copy(evb[i, 0].tobytes())
+        e1 = jrc.EqEvent.from_buffer_copy(evb[i, 1].tobytes())
+        assert (e0.kind, e1.kind) == (1, 2) and e0.packet_type == refs[i]["events"][0]["packet_type"]
+        assert abs(e1.snr_data - refs[i]["events"][1]["snr_data"]) < 1e-3 * abs(refs[i]["events"][1]["snr_data"])
