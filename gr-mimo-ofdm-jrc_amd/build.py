@@ -73,5 +73,32 @@ def build(force=False, verbose=False):
     return LIB
 
 
+HOST_DIR = os.path.join(HERE, "host")
+HOST_LIB = os.path.join(LIBDIR, "libjrc_blocks.so")
+HOST_SOURCES = ["jrc_blocks.cc", "jrc_blocks_capi.cc"]
+
+
+def build_host(force=False, verbose=False):
+    """host-side C++ blocks (reference block interface over the C ABI) + their C test harness, with g++ against the
+    stand-alone runtime (no GNU Radio in this image); links libjrc_hip.so"""
+    build()
+    srcs = [os.path.join(HOST_DIR, s) for s in HOST_SOURCES]
+    deps = srcs + [os.path.join(HOST_DIR, h) for h in ("jrc_blocks.h", "jrc_block_runtime.h")] + [os.path.join(HERE, "..", "include", "jrc.h")]
+    if not force and os.path.exists(HOST_LIB) and _mtime(HOST_LIB) >= max(_mtime(d) for d in deps):
+        return HOST_LIB
+    cxx = shutil.which("g++") or "g++"
+    cmd = [cxx, "-O2", "-std=c++14", "-fPIC", "-shared", "-Wall", "-o", HOST_LIB] + srcs + \
+          ["-L" + LIBDIR, "-ljrc_hip", "-Wl,-rpath,$ORIGIN", "-lpthread"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("host block build failed:\n%s\n%s" % (r.stdout, r.stderr))
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    if verbose:
+        print("built", HOST_LIB)
+    return HOST_LIB
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
+    build_host(force="--force" in sys.argv, verbose=True)

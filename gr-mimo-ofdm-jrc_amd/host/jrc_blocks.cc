@@ -1,0 +1,619 @@
+// jrc_blocks.cc — work()/general_work() bodies of the seven hot-path blocks over the C ABI (include/jrc.h).
+// Tag, message and file handling is host code that follows the reference line by line (citations are to
+// /root/reference/lib); all sample arithmetic happens in the HIP kernels behind the jrc_* calls.
+#include "jrc_blocks.h"
+
+#include <sys/stat.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <ctime>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <random>
+
+#include "../../include/jrc.h"
+
+namespace gr {
+namespace mimo_ofdm_jrc {
+
+namespace {
+
+int device_from_env()
+{
+    const char* d = getenv("JRC_DEVICE");
+    return d ? atoi(d) : 0;
+}
+
+// one context per block = per scheduler thread
+struct ctx_holder {
+    jrc_ctx* ctx = nullptr;
+    ctx_holder()
+    {
+        int st = jrc_create(device_from_env(), &ctx);
+        if (st != JRC_OK) throw std::runtime_error(std::string("jrc_create: ") + jrc_strerror(st));
+    }
+    ~ctx_holder() { jrc_destroy(ctx); }
+    void check(int st) const
+    {
+        if (st >= 0) return;
+        std::string msg = jrc_last_error(ctx);
+        if (msg.empty()) msg = jrc_strerror(st);
+        if (st == JRC_ERR_INVALID_ARG) throw std::invalid_argument(msg);
+        throw std::runtime_error(msg);
+    }
+};
+
+std::string current_date_time()   // lib/utils.cc:295-305
+{
+    time_t now = time(0);
+    struct tm tstruct = *localtime(&now);
+    char buf[80];
+    strftime(buf, sizeof(buf), "%m-%d-%Y %H:%M:%S", &tstruct);
+    return buf;
+}
+
+std::string current_date_time2()   // lib/utils.cc:307-319
+{
+    auto now = std::chrono::system_clock::now();
+    auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(now.time_since_epoch()) % 1000;
+    auto timer = std::chrono::system_clock::to_time_t(now);
+    std::tm bt = *std::localtime(&timer);
+    std::ostringstream oss;
+    oss << std::put_time(&bt, "%H:%M:%S");
+    oss << '.' << std::setfill('0') << std::setw(3) << ms.count();
+    return oss.str();
+}
+
+}  // namespace
+
+// =================================================================================================
+// mimo_ofdm_radar  (lib/mimo_ofdm_radar_impl.cc)
+// =================================================================================================
+class mimo_ofdm_radar_impl : public mimo_ofdm_radar {
+    ctx_holder d_c;
+    jrc_radar* d_radar = nullptr;
+    int d_fft_len, d_N_tx, d_N_rx, d_N_sym, d_N_pre, d_interp_factor;
+    bool new_radar_frame = false;   // uninitialised in the reference (lib/mimo_ofdm_radar_impl.h:59)
+
+public:
+    mimo_ofdm_radar_impl(int fft_len, int N_tx, int N_rx, int N_sym, int N_pre, bool background_removal,
+                         bool background_recording, int record_len, int interp_factor, bool enable_tx_interleave,
+                         const std::string&, const std::string&, bool)
+        : jrc_rt::block("mimo_ofdm_radar", jrc_rt::io_signature::make(N_tx + N_rx, N_tx + N_rx, sizeof(gr_complex) * fft_len),
+                        jrc_rt::io_signature::make(1, 1, sizeof(gr_complex) * fft_len * interp_factor)),   // :81-83
+          d_fft_len(fft_len), d_N_tx(N_tx), d_N_rx(N_rx), d_N_sym(N_sym), d_N_pre(N_pre), d_interp_factor(interp_factor)
+    {
+        d_c.check(jrc_radar_create(d_c.ctx, fft_len, N_tx, N_rx, N_sym, N_pre, background_removal, background_recording,
+                                   record_len, interp_factor, enable_tx_interleave, &d_radar));
+        set_tag_propagation_policy(TPP_DONT);
+    }
+    ~mimo_ofdm_radar_impl() override { jrc_radar_destroy(d_radar); }
+
+    int general_work(int noutput_items, gr_vector_int& ninput_items, gr_vector_const_void_star& input_items,
+                     gr_vector_void_star& output_items) override
+    {
+        std::vector<jrc_rt::tag_t> rx_tags, tx_tags;
+        uint64_t rx_packet_len = 0, tx_packet_len = 0, n_tx_samples_discard = 0;
+        get_tags_in_range(rx_tags, d_N_tx, nitems_read(d_N_tx), nitems_read(d_N_tx) + ninput_items[d_N_tx],
+                          pmt::mp("packet_len"));                                                    // :167
+        if (!rx_tags.empty()) {
+            get_tags_in_range(tx_tags, 0, nitems_read(0), nitems_read(0) + ninput_items[0], pmt::mp("packet_len"));
+            new_radar_frame = true;
+            size_t tx_frame_offset = 0;
+            if (tx_tags.size() > rx_tags.size()) {                                                    // :191-198
+                tx_frame_offset = tx_tags.size() - rx_tags.size();
+                for (size_t i = 0; i < tx_frame_offset; i++) n_tx_samples_discard += pmt::to_uint64(tx_tags[i].value);
+            }
+            if (tx_tags.size() <= tx_frame_offset) throw std::runtime_error("[MIMO OFDM RADAR] no packet_len tag on TX input");
+            rx_packet_len = pmt::to_uint64(rx_tags[0].value);
+            tx_packet_len = pmt::to_uint64(tx_tags[tx_frame_offset].value);
+        }
+        if (!new_radar_frame) {                                                                       // :219-234
+            for (int i = 0; i < d_N_tx + d_N_rx; i++) consume(i, ninput_items[i]);
+            return 0;
+        }
+        std::vector<const jrc_cf32*> tx(d_N_tx), rx(d_N_rx);
+        for (int t = 0; t < d_N_tx; t++) tx[t] = (const jrc_cf32*)input_items[t];
+        for (int r = 0; r < d_N_rx; r++) rx[r] = (const jrc_cf32*)input_items[d_N_tx + r];
+        int n = jrc_radar_work(d_radar, tx.data(), rx.data(), ninput_items[0], ninput_items[d_N_tx], n_tx_samples_discard,
+                               (jrc_cf32*)output_items[0]);
+        d_c.check(n);
+        (void)noutput_items;
+        add_item_tag(0, nitems_written(0), pmt::string_to_symbol("packet_len"), pmt::from_long(n),
+                     pmt::string_to_symbol(alias()));                                                 // :303-309
+        for (int r = 0; r < d_N_rx; r++) consume(r + d_N_tx, (int)rx_packet_len);                    // :326-334
+        for (int t = 0; t < d_N_tx; t++) consume(t, (int)(n_tx_samples_discard + tx_packet_len));
+        new_radar_frame = false;
+        return n;
+    }
+    void set_background_record(bool b) override { jrc_radar_set_background_record(d_radar, b); }      // :342-346
+    void capture_radar_data(bool) override {}   // CSV dump of the estimate (:348-387) is a debug side channel, not rebuilt
+};
+
+mimo_ofdm_radar::sptr mimo_ofdm_radar::make(int fft_len, int N_tx, int N_rx, int N_sym, int N_pre, bool background_removal,
+                                            bool background_recording, int record_len, int interp_factor,
+                                            bool enable_tx_interleave, const std::string& radar_chan_file,
+                                            const std::string& len_tag_key, bool debug)
+{
+    return JRC_GET_INITIAL_SPTR(new mimo_ofdm_radar_impl(fft_len, N_tx, N_rx, N_sym, N_pre, background_removal,
+                                                         background_recording, record_len, interp_factor,
+                                                         enable_tx_interleave, radar_chan_file, len_tag_key, debug));
+}
+
+// =================================================================================================
+// matrix_transpose  (lib/matrix_transpose_impl.cc)
+// =================================================================================================
+class matrix_transpose_impl : public matrix_transpose {
+    ctx_holder d_c;
+    int d_input_len, d_output_len, d_interp_factor;
+
+public:
+    matrix_transpose_impl(int input_len, int output_len, int interp_factor, bool, const std::string& len_key)
+        : jrc_rt::tagged_stream_block("matrix_transpose", jrc_rt::io_signature::make(1, 1, sizeof(gr_complex) * input_len),
+                                      jrc_rt::io_signature::make(1, 1, sizeof(gr_complex) * output_len * interp_factor), len_key),
+          d_input_len(input_len), d_output_len(output_len), d_interp_factor(interp_factor)
+    {
+        set_relative_rate((double)input_len / (double)output_len);
+        set_tag_propagation_policy(TPP_DONT);
+    }
+    int calculate_output_stream_length(const gr_vector_int&) override { return d_input_len; }          // :62-67
+    int work(int, gr_vector_int& ninput_items, gr_vector_const_void_star& in, gr_vector_void_star& out) override
+    {
+        int n = jrc_matrix_transpose(d_c.ctx, d_input_len, d_output_len, d_interp_factor, ninput_items[0],
+                                     (const jrc_cf32*)in[0], (jrc_cf32*)out[0]);
+        if (n == JRC_ERR_LENGTH_MISMATCH) throw std::runtime_error(jrc_strerror(n));                 // :82-83
+        d_c.check(n);
+        return n;
+    }
+};
+matrix_transpose::sptr matrix_transpose::make(int input_len, int output_len, int interp_factor, bool debug, std::string len_key)
+{
+    return JRC_GET_INITIAL_SPTR(new matrix_transpose_impl(input_len, output_len, interp_factor, debug, len_key));
+}
+
+// =================================================================================================
+// range_angle_estimator  (lib/range_angle_estimator_impl.cc)
+// =================================================================================================
+class range_angle_estimator_impl : public range_angle_estimator {
+    ctx_holder d_c;
+    int d_vlen;
+    std::vector<float> d_range_bins, d_angle_bins;
+    float d_ndr, d_nda, d_snr_threshold, d_power_threshold;
+    std::string d_stats_path;
+    bool d_stats_record, d_new_stat_started = false;
+
+    static pmt::pmt_t pack(const char* key, float v) { return pmt::list2(pmt::string_to_symbol(key), pmt::init_f32vector(1, &v)); }
+
+public:
+    range_angle_estimator_impl(int vlen, std::vector<float> range_bins, std::vector<float> angle_bins, float ndr, float nda,
+                               float snr_threshold, float power_threshold, const std::string& stats_path, bool stats_record,
+                               const std::string& len_key, bool)
+        : jrc_rt::tagged_stream_block("range_angle_estimator", jrc_rt::io_signature::make(1, 1, sizeof(gr_complex) * vlen),
+                                      jrc_rt::io_signature::make(0, 0, 0), len_key),
+          d_vlen(vlen), d_range_bins(range_bins), d_angle_bins(angle_bins), d_ndr(ndr), d_nda(nda),
+          d_snr_threshold(snr_threshold), d_power_threshold(power_threshold), d_stats_path(stats_path), d_stats_record(stats_record)
+    {
+        message_port_register_out(pmt::mp("params"));                                                 // :89
+        std::ofstream f(d_stats_path, std::ofstream::app);                                            // :93-97
+        if (!f.is_open()) std::cerr << "[RANGE-ANGLE ESTIMATOR] Could not open log file at " << d_stats_path << std::endl;
+    }
+    int calculate_output_stream_length(const gr_vector_int&) override { return 0; }                   // :114-119
+    int work(int, gr_vector_int& ninput_items, gr_vector_const_void_star& in, gr_vector_void_star&) override
+    {
+        jrc_ra_result r;
+        d_c.check(jrc_ra_estimate(d_c.ctx, d_vlen, ninput_items[0], (const jrc_cf32*)in[0], d_range_bins.data(),
+                                  (int)d_range_bins.size(), d_angle_bins.data(), (int)d_angle_bins.size(), d_ndr, d_nda,
+                                  d_snr_threshold, d_power_threshold, &r));
+        if (r.published) {                                                                            // :234-253
+            message_port_pub(pmt::mp("params"), pmt::list4(pack("range", r.range_val), pack("angle", r.angle_val),
+                                                           pack("power", r.peak_power), pack("snr", r.snr_est)));
+            if (d_stats_record) {                                                                     // :255-279
+                std::ofstream f(d_stats_path, std::ofstream::app);
+                if (!f.is_open()) throw std::runtime_error("[STREAM DECODER] Could not open file!!");
+                if (!d_new_stat_started) { f << "\n NEW RECORD - " << current_date_time() << "\n"; d_new_stat_started = true; }
+                f << current_date_time2() << ", \t" << r.peak_power << ", \t" << r.snr_est << ", \t" << r.range_val << ", \t"
+                  << r.angle_val << "\n";
+            }
+        }
+        return 0;
+    }
+    void set_snr_threshold(float v) override { d_snr_threshold = v; }
+    void set_power_threshold(float v) override { d_power_threshold = v; }
+    void set_stats_record(bool v) override { d_stats_record = v; d_new_stat_started = false; }        // :289-302
+};
+range_angle_estimator::sptr range_angle_estimator::make(int vlen, std::vector<float> range_bins, std::vector<float> angle_bins,
+                                                        float ndr, float nda, float snr_threshold, float power_threshold,
+                                                        const std::string& stats_path, bool stats_record,
+                                                        const std::string& len_key, bool debug)
+{
+    return JRC_GET_INITIAL_SPTR(new range_angle_estimator_impl(vlen, range_bins, angle_bins, ndr, nda, snr_threshold,
+                                                               power_threshold, stats_path, stats_record, len_key, debug));
+}
+
+// =================================================================================================
+// ofdm_cyclic_prefix_remover  (lib/ofdm_cyclic_prefix_remover_impl.cc)
+// =================================================================================================
+class ofdm_cyclic_prefix_remover_impl : public ofdm_cyclic_prefix_remover {
+    ctx_holder d_c;
+    int d_fft_len, d_cp_len;
+    std::vector<jrc_rt::tag_t> d_tags;
+
+public:
+    ofdm_cyclic_prefix_remover_impl(int fft_len, int cp_len, const std::string& len_key)
+        : jrc_rt::tagged_stream_block("ofdm_cyclic_prefix_remover", jrc_rt::io_signature::make(1, 1, sizeof(gr_complex)),
+                                      jrc_rt::io_signature::make(1, 1, sizeof(gr_complex) * fft_len), len_key),
+          d_fft_len(fft_len), d_cp_len(cp_len)
+    {
+        set_tag_propagation_policy(TPP_DONT);
+    }
+    int calculate_output_stream_length(const gr_vector_int& n) override { return n[0] / (d_fft_len + d_cp_len); }   // :62-67
+    int work(int, gr_vector_int& ninput_items, gr_vector_const_void_star& in, gr_vector_void_star& out) override
+    {
+        get_tags_in_range(d_tags, 0, nitems_read(0), nitems_read(0) + 1);                             // :79-83
+        for (auto& t : d_tags) add_item_tag(0, nitems_written(0), t.key, t.value, t.srcid);
+        int n = jrc_cp_remove(d_c.ctx, d_fft_len, d_cp_len, ninput_items[0], (const jrc_cf32*)in[0], (jrc_cf32*)out[0]);
+        d_c.check(n);
+        return n;
+    }
+};
+ofdm_cyclic_prefix_remover::sptr ofdm_cyclic_prefix_remover::make(int fft_len, int cp_len, std::string len_key)
+{
+    return JRC_GET_INITIAL_SPTR(new ofdm_cyclic_prefix_remover_impl(fft_len, cp_len, len_key));
+}
+
+// =================================================================================================
+// fft_peak_detect  (lib/fft_peak_detect_impl.cc)
+// =================================================================================================
+class fft_peak_detect_impl : public fft_peak_detect {
+    ctx_holder d_c;
+    int d_samp_rate, d_samp_protect;
+    float d_interp_factor, d_threshold;
+    std::vector<float> d_max_freq;
+
+public:
+    fft_peak_detect_impl(int samp_rate, float interp_factor, float threshold, int samp_protect, std::vector<float> max_freq,
+                         bool, const std::string& len_key)
+        : jrc_rt::tagged_stream_block("fft_peak_detect", jrc_rt::io_signature::make(1, 1, sizeof(gr_complex)),
+                                      jrc_rt::io_signature::make3(3, 3, sizeof(float), sizeof(float), sizeof(float)), len_key),
+          d_samp_rate(samp_rate), d_samp_protect(samp_protect), d_interp_factor(interp_factor), d_threshold(threshold),
+          d_max_freq(max_freq)
+    {
+        set_tag_propagation_policy(TPP_DONT);
+    }
+    int calculate_output_stream_length(const gr_vector_int&) override { return 1; }
+    int work(int, gr_vector_int& ninput_items, gr_vector_const_void_star& in, gr_vector_void_star& out) override
+    {
+        int k;
+        int n = jrc_fft_peak_detect(d_c.ctx, d_samp_rate, d_interp_factor, d_threshold, d_samp_protect, ninput_items[0],
+                                    (const jrc_cf32*)in[0], (float*)out[0], (float*)out[1], (float*)out[2], &k);
+        d_c.check(n);
+        return n;                                                                                     // always 1 (:110)
+    }
+    void set_threshold(float t) override { d_threshold = t; }
+    void set_samp_protect(int s) override { d_samp_protect = s; }
+    void set_max_freq(std::vector<float> f) override { d_max_freq = f; }
+};
+fft_peak_detect::sptr fft_peak_detect::make(int samp_rate, float interp_factor, float threshold, int samp_protect,
+                                            std::vector<float> max_freq, bool cut_max_freq, const std::string& len_key)
+{
+    return JRC_GET_INITIAL_SPTR(new fft_peak_detect_impl(samp_rate, interp_factor, threshold, samp_protect, max_freq, cut_max_freq, len_key));
+}
+
+// =================================================================================================
+// mimo_ofdm_equalizer  (lib/mimo_ofdm_equalizer_impl.cc)
+// =================================================================================================
+static std::vector<gr_complex> flatten(const std::vector<std::vector<gr_complex>>& v)
+{
+    std::vector<gr_complex> o;
+    for (auto& r : v) o.insert(o.end(), r.begin(), r.end());
+    return o;
+}
+
+class mimo_ofdm_equalizer_impl : public mimo_ofdm_equalizer {
+    ctx_holder d_c;
+    jrc_equalizer* d_eq = nullptr;
+    int d_fft_len, d_N_data, d_N_tx;
+    std::string d_chan_est_file;
+    bool d_stats_record;
+    std::vector<gr_complex> d_chan_est;
+    std::vector<jrc_rt::tag_t> tags;
+
+public:
+    mimo_ofdm_equalizer_impl(ChannelEstimator algo, double freq, double bw, int fft_len, int cp_len, std::vector<int> data_carriers,
+                             std::vector<int> pilot_carriers, const std::vector<std::vector<gr_complex>>& pilot_symbols,
+                             std::vector<gr_complex> ltf_seq, const std::vector<std::vector<gr_complex>>& mapped_ltf_symbols,
+                             int n_mimo_ltf, const std::string& chan_est_file, const std::string&, bool stats_record, bool)
+        : jrc_rt::block("mimo_ofdm_equalizer", jrc_rt::io_signature::make(1, 1, fft_len * sizeof(gr_complex)),
+                        jrc_rt::io_signature::make(1, 1, data_carriers.size() * sizeof(gr_complex))),              // :89-91
+          d_fft_len(fft_len), d_N_data((int)data_carriers.size()), d_chan_est_file(chan_est_file), d_stats_record(stats_record)
+    {
+        if (algo != LS && algo != STA) throw std::runtime_error("[OFDM Equalizer] Estimator not implemented");    // :941-943
+        std::vector<gr_complex> ps = flatten(pilot_symbols), ml = flatten(mapped_ltf_symbols);
+        jrc_eq_cfg c;
+        c.estimator = algo; c.freq = freq; c.bw = bw; c.fft_len = fft_len; c.cp_len = cp_len;
+        c.n_data = (int)data_carriers.size(); c.n_pilot = (int)pilot_carriers.size();
+        c.data_carriers = data_carriers.data(); c.pilot_carriers = pilot_carriers.data();
+        c.n_pilot_rows = (int)pilot_symbols.size(); c.pilot_symbols = (const jrc_cf32*)ps.data();
+        c.ltf_seq = (const jrc_cf32*)ltf_seq.data(); c.mapped_ltf = (const jrc_cf32*)ml.data();
+        c.mapped_cols = (int)mapped_ltf_symbols[0].size(); c.n_mimo_ltf = n_mimo_ltf;
+        d_N_tx = c.mapped_cols / n_mimo_ltf;                                                                       // :168
+        d_c.check(jrc_equalizer_create(d_c.ctx, &c, 1, &d_eq));
+        d_chan_est.resize((size_t)fft_len * d_N_tx);
+        set_tag_propagation_policy(TPP_DONT);
+    }
+    ~mimo_ofdm_equalizer_impl() override { jrc_equalizer_destroy(d_eq); }
+    void forecast(int noutput_items, gr_vector_int& req) override { req[0] = noutput_items; }                    // :182-186
+
+    int general_work(int noutput_items, gr_vector_int& ninput_items, gr_vector_const_void_star& in, gr_vector_void_star& out) override
+    {
+        jrc_rt::block::set_thread_priority(50);
+        jrc_rt::thread::scoped_lock lock(d_setlock);
+        get_tags_in_window(tags, 0, 0, ninput_items[0], pmt::string_to_symbol("frame_start"));                   // :221
+        std::vector<int64_t> offs; std::vector<double> vals;
+        for (auto& t : tags) { offs.push_back((int64_t)(t.offset - nitems_read(0))); vals.push_back(pmt::to_double(t.value)); }
+        int consumed = 0, n_ev = 0, ce_written = 0;
+        jrc_eq_event ev[4];
+        int n = jrc_equalizer_work(d_eq, 0, noutput_items, ninput_items[0], (const jrc_cf32*)in[0], offs.data(), vals.data(),
+                                   (int)offs.size(), (jrc_cf32*)out[0], &consumed, ev, 4, &n_ev, (jrc_cf32*)d_chan_est.data(), &ce_written);
+        d_c.check(n);
+        for (int i = 0; i < n_ev; i++) {
+            pmt::pmt_t dict = pmt::make_dict();
+            if (ev[i].kind == 1) {                                                                                // :331-337
+                dict = pmt::dict_add(dict, pmt::mp("data_bytes"), pmt::from_uint64(ev[i].data_bytes));
+                dict = pmt::dict_add(dict, pmt::mp("mcs"), pmt::from_uint64(ev[i].mcs));
+                dict = pmt::dict_add(dict, pmt::mp("packet_type"), pmt::from_uint64(ev[i].packet_type));
+                dict = pmt::dict_add(dict, pmt::mp("snr"), pmt::from_double(ev[i].snr));
+                dict = pmt::dict_add(dict, pmt::mp("freq_offset"), pmt::from_double(ev[i].freq_offset));
+                add_item_tag(0, nitems_written(0) + ev[i].offset, pmt::string_to_symbol("stream_start"), dict, pmt::string_to_symbol(alias()));
+            } else {                                                                                              // :626-629
+                dict = pmt::dict_add(dict, pmt::mp("snr_data"), pmt::from_double(ev[i].snr_data));
+                dict = pmt::dict_add(dict, pmt::mp("chan_mean"), pmt::init_c32vector(ev[i].n_chan_mean, (const gr_complex*)ev[i].chan_mean));
+                add_item_tag(0, nitems_written(0) + ev[i].offset, pmt::string_to_symbol("stream_end"), dict, pmt::string_to_symbol(alias()));
+            }
+        }
+        if (ce_written) write_chan_est();
+        consume(0, consumed);
+        return n;
+    }
+    // chan_est_file wire format "sc:(re,im);(re,im);...\n" (:378-416), read back by mimo_precoder (:806-833).
+    // Eigen's FullPrecision prints 6-7 significant digits depending on its version; 9 are written here (float round trip).
+    void write_chan_est()
+    {
+        std::ofstream f(d_chan_est_file, std::ofstream::trunc);
+        if (!f.is_open()) throw std::runtime_error("[OFDM Equalizer] Could not open file!!");
+        char buf[96];
+        for (int sc = 0; sc < d_fft_len; sc++) {
+            f << sc << ":";
+            for (int t = 0; t < d_N_tx; t++) {
+                const gr_complex h = d_chan_est[(size_t)sc * d_N_tx + t];
+                snprintf(buf, sizeof(buf), "%s(%.9g,%.9g)", t ? ";" : "", h.real(), h.imag());
+                f << buf;
+            }
+            f << "\n";
+        }
+    }
+    void set_estimator(ChannelEstimator algo) override
+    {
+        jrc_rt::thread::scoped_lock lock(d_setlock);
+        if (algo != LS && algo != STA) throw std::runtime_error("[OFDM Equalizer] Estimator not implemented");
+        jrc_equalizer_set_estimator(d_eq, algo);
+    }
+    void set_bandwidth(double bw) override { jrc_rt::thread::scoped_lock lock(d_setlock); jrc_equalizer_set_bandwidth(d_eq, bw); }
+    void set_frequency(double f) override { jrc_rt::thread::scoped_lock lock(d_setlock); jrc_equalizer_set_frequency(d_eq, f); }
+    void set_stats_record(bool s) override { jrc_rt::thread::scoped_lock lock(d_setlock); d_stats_record = s; }
+};
+mimo_ofdm_equalizer::sptr mimo_ofdm_equalizer::make(ChannelEstimator estimator_algo, double freq, double bw, int fft_len, int cp_len,
+                                                    std::vector<int> data_carriers, std::vector<int> pilot_carriers,
+                                                    const std::vector<std::vector<gr_complex>>& pilot_symbols,
+                                                    std::vector<gr_complex> long_seq,
+                                                    const std::vector<std::vector<gr_complex>>& mapped_ltf_symbols, int n_mimo_ltf,
+                                                    const std::string& chan_est_file, const std::string& comm_log_file,
+                                                    bool stats_record, bool debug)
+{
+    return JRC_GET_INITIAL_SPTR(new mimo_ofdm_equalizer_impl(estimator_algo, freq, bw, fft_len, cp_len, data_carriers, pilot_carriers,
+                                                             pilot_symbols, long_seq, mapped_ltf_symbols, n_mimo_ltf, chan_est_file,
+                                                             comm_log_file, stats_record, debug));
+}
+
+// =================================================================================================
+// mimo_precoder  (lib/mimo_precoder_impl.cc)
+// =================================================================================================
+class mimo_precoder_impl : public mimo_precoder {
+    ctx_holder d_c;
+    jrc_precoder* d_pre = nullptr;
+    int d_fft_len, d_N_tx, d_N_data;
+    std::vector<int> d_active;   // data then pilot carriers, shifted indices (:197-200)
+    std::string d_chan_est_file, d_radar_log_file;
+    bool d_chan_est_smoothing, d_radar_aided, d_phased_steering, d_use_radar_streams;
+    std::vector<gr_complex> steering_matrix;        // [fft_len][T*T] column-major
+    std::vector<gr_complex> steering_matrix_mean;   // [T*T]
+    std::vector<gr_complex> chan_est_vector_mean;   // [T]
+    bool mean_chan_est_changed = true;
+    std::time_t last_chanEst_update_time = 0;
+    std::vector<gr_complex> d_radar_streams;
+
+public:
+    mimo_precoder_impl(int fft_len, int N_tx, int N_ss, const std::vector<int>& data_carriers, const std::vector<int>& pilot_carriers,
+                       const std::vector<std::vector<gr_complex>>& pilot_symbols, const std::vector<std::vector<gr_complex>>& sync_words,
+                       const std::vector<std::vector<gr_complex>>& mapped_ltf_symbols, const std::string& chan_est_file,
+                       bool chan_est_smoothing, const std::string& radar_log_file, bool radar_aided, bool phased_steering,
+                       bool use_radar_streams, const std::string& len_tag_key, bool)
+        : jrc_rt::tagged_stream_block("mimo_precoder", jrc_rt::io_signature::make(N_ss, N_ss, sizeof(gr_complex)),
+                                      jrc_rt::io_signature::make(N_tx, N_tx, fft_len * sizeof(gr_complex)), len_tag_key),   // :94-96
+          d_fft_len(fft_len), d_N_tx(N_tx), d_N_data((int)data_carriers.size()), d_chan_est_file(chan_est_file),
+          d_radar_log_file(radar_log_file), d_chan_est_smoothing(chan_est_smoothing), d_radar_aided(radar_aided),
+          d_phased_steering(phased_steering), d_use_radar_streams(use_radar_streams)
+    {
+        if (data_carriers.empty()) throw std::invalid_argument("Data carriers must be of type vector of vector i.e. ().");
+        if (pilot_carriers.empty()) throw std::invalid_argument("Pilot carriers must be of type vector of vector i.e. ((),).");
+        if (pilot_symbols.empty()) throw std::invalid_argument("Pilot symbols must be of type vector of vector i.e. ((),).");
+        for (auto& p : pilot_symbols)
+            if (p.size() != pilot_carriers.size()) throw std::invalid_argument("pilot_carriers do not match pilot_symbols");   // :158-164
+        for (auto& w : sync_words)
+            if (w.size() != (unsigned)fft_len) throw std::invalid_argument("[MIMO PRECODER] sync words must be fft length");   // :170-176
+        if (mapped_ltf_symbols.size() != (size_t)fft_len)
+            throw std::invalid_argument("[MIMO PRECODER] MIMO LTF symbols should have (fft length x Ntx) rows!!");             // :179-182
+        for (auto& r : mapped_ltf_symbols)
+            if (r.size() != (size_t)N_tx * N_tx) throw std::invalid_argument("[MIMO PRECODER] MIMO LTF symbols should have (Ntx) columns!!");
+        std::vector<gr_complex> ps = flatten(pilot_symbols), sw = flatten(sync_words), ml = flatten(mapped_ltf_symbols);
+        jrc_pre_cfg c;
+        c.fft_len = fft_len; c.N_tx = N_tx; c.n_data = (int)data_carriers.size(); c.n_pilot = (int)pilot_carriers.size();
+        c.data_carriers = data_carriers.data(); c.pilot_carriers = pilot_carriers.data();
+        c.n_pilot_rows = (int)pilot_symbols.size(); c.pilot_symbols = (const jrc_cf32*)ps.data();
+        c.n_sync = (int)sync_words.size(); c.sync_words = (const jrc_cf32*)sw.data(); c.mapped_ltf = (const jrc_cf32*)ml.data();
+        d_c.check(jrc_precoder_create(d_c.ctx, &c, &d_pre));
+        auto shift = [&](int v) { if (v < 0) v += fft_len; return (v + fft_len / 2) % fft_len; };
+        for (int v : data_carriers) d_active.push_back(shift(v));
+        for (int v : pilot_carriers) d_active.push_back(shift(v));
+        steering_matrix.assign((size_t)fft_len * N_tx * N_tx, gr_complex(0, 0));
+        steering_matrix_mean.assign((size_t)N_tx * N_tx, gr_complex(0, 0));
+        chan_est_vector_mean.assign(N_tx, gr_complex(0, 0));
+        set_tag_propagation_policy(TPP_DONT);
+        set_relative_rate(1, (uint64_t)data_carriers.size());
+    }
+    ~mimo_precoder_impl() override { jrc_precoder_destroy(d_pre); }
+    int calculate_output_stream_length(const gr_vector_int& n) override { return jrc_precoder_output_length(d_pre, n[0]); }   // :265-272
+
+    bool is_active(int line) const { for (int a : d_active) if (a == line) return true; return false; }
+
+    // lib/mimo_precoder_impl.cc:775-898: parse "sc:(re,im);...", per-subcarrier and mean steering matrices
+    bool compute_steering_matrix()
+    {
+        std::ifstream f(d_chan_est_file);
+        if (!f.is_open()) {
+            if (!d_chan_est_file.empty()) std::cerr << "[MIMO PRECODER] Could not open channel estimate file at " << d_chan_est_file << std::endl;
+            return false;
+        }
+        struct stat sb;
+        std::time_t curr = (stat(d_chan_est_file.c_str(), &sb) == 0) ? sb.st_mtime : 0;                             // boost last_write_time :791
+        if (curr <= last_chanEst_update_time && !mean_chan_est_changed) return true;                                  // :794-798
+        std::fill(chan_est_vector_mean.begin(), chan_est_vector_mean.end(), gr_complex(0, 0));
+        const int T = d_N_tx;
+        std::vector<gr_complex> rows;   // [n_lines][T]
+        std::vector<int> sc_of_line;
+        std::string line;
+        int n_line_read = 0;
+        while (std::getline(f, line)) {
+            std::stringstream ls(line);
+            std::string entry;
+            getline(ls, entry, ':');
+            int sc_idx = std::stoi(entry);
+            std::vector<gr_complex> v(T);
+            int n_col = 0;
+            while (getline(ls, entry, ';')) {
+                float re = 0, im = 0;
+                sscanf(entry.c_str(), "(%f,%f)", &re, &im);
+                if (n_col < T) {
+                    if (is_active(n_line_read)) chan_est_vector_mean[n_col] += gr_complex(re, im);                   // :814-817
+                    v[n_col] = gr_complex(re, im);
+                }
+                n_col++;
+            }
+            n_line_read++;
+            if (n_col != T) { std::cerr << "[MIMO PRECODER] Steering matrix computation FAILED! --> Line is not correct: " << n_line_read << std::endl; return false; }
+            if (sc_idx < 0 || sc_idx >= d_fft_len) return false;
+            rows.insert(rows.end(), v.begin(), v.end());
+            sc_of_line.push_back(sc_idx);
+        }
+        if (n_line_read < d_fft_len) { std::cerr << "[MIMO PRECODER] Steering matrix computation FAILED! --> Number of parsed lines not correct: " << n_line_read << std::endl; return false; }
+        std::vector<gr_complex> Q((size_t)n_line_read * T * T);
+        d_c.check(jrc_steering_from_channel(d_c.ctx, T, n_line_read, (const jrc_cf32*)rows.data(), d_phased_steering, (jrc_cf32*)Q.data()));   // :846-861
+        for (int l = 0; l < n_line_read; l++)
+            std::copy(Q.begin() + (size_t)l * T * T, Q.begin() + (size_t)(l + 1) * T * T, steering_matrix.begin() + (size_t)sc_of_line[l] * T * T);
+        for (int t = 0; t < T; t++) chan_est_vector_mean[t] = chan_est_vector_mean[t] / (gr_complex)(float)d_active.size();   // :872-875
+        d_c.check(jrc_steering_from_channel(d_c.ctx, T, 1, (const jrc_cf32*)chan_est_vector_mean.data(), d_phased_steering,
+                                            (jrc_cf32*)steering_matrix_mean.data()));                                 // :880-893
+        mean_chan_est_changed = false;
+        last_chanEst_update_time = curr;
+        return true;
+    }
+
+    // lib/mimo_precoder_impl.cc:903-983: last line of the radar log, 5th field = angle estimate
+    bool compute_radar_aided_steering()
+    {
+        std::ifstream f(d_radar_log_file);
+        if (!f.is_open()) { std::cerr << "[MIMO PRECODER] Could not open radar log file at " << d_radar_log_file << std::endl; return false; }
+        std::string line, lastline;
+        while (std::getline(f, line)) if (!line.empty()) lastline = line;
+        if (lastline.empty()) {
+            std::cerr << "[MIMO PRECODER] Radar log file is empty at " << d_radar_log_file << std::endl;
+            compute_steering_matrix();                                                                               // :939-941
+            return false;
+        }
+        std::stringstream ls(lastline);
+        std::string entry;
+        for (int i = 0; i < 4; i++) getline(ls, entry, ',');
+        getline(ls, entry, '\n');
+        float angle_estimate = std::stof(entry);
+        for (int t = 0; t < d_N_tx; t++)
+            chan_est_vector_mean[t] = std::exp(gr_complex(0, M_PI * sin(angle_estimate / 180.0 * M_PI) * t));     // :956-959
+        d_c.check(jrc_steering_from_channel(d_c.ctx, d_N_tx, 1, (const jrc_cf32*)chan_est_vector_mean.data(), d_phased_steering,
+                                            (jrc_cf32*)steering_matrix_mean.data()));                                 // :961-974
+        mean_chan_est_changed = true;
+        return true;
+    }
+
+    int work(int, gr_vector_int& ninput_items, gr_vector_const_void_star& input_items, gr_vector_void_star& output_items) override
+    {
+        jrc_rt::block::set_thread_priority(30);
+        jrc_rt::thread::scoped_lock lock(d_setlock);
+        if (output_items.size() != (size_t)d_N_tx) throw std::runtime_error("[MIMO PRECODER] output_items should contain {N_tx} buffers!!");
+        std::vector<jrc_rt::tag_t> tags;
+        get_tags_in_range(tags, 0, nitems_read(0), nitems_read(0) + ninput_items[0], pmt::mp("mcs"));               // :305-325
+        if (tags.size() != 1) throw std::runtime_error("no mcs tag in input stream!");
+        int mcs = (int)pmt::to_long(tags[0].value);
+        get_tags_in_range(tags, 0, nitems_read(0), nitems_read(0) + ninput_items[0], pmt::mp("packet_type"));
+        if (tags.size() != 1) throw std::runtime_error("no packet_type tag in input stream!");
+        int packet_type = (int)pmt::to_uint64(tags[0].value);
+        get_tags_in_range(tags, 0, nitems_read(0), nitems_read(0) + ninput_items[0], pmt::mp("pdu_len"));
+        if (tags.size() != 1) throw std::runtime_error("no pdu_len tag in input stream!");
+        int data_size_crc = (int)pmt::to_long(tags[0].value);
+
+        int steer_mode = 0;
+        const gr_complex* rs = nullptr;
+        if (packet_type == DATA) {
+            bool custom = d_radar_aided ? compute_radar_aided_steering() : compute_steering_matrix();               // :500-532
+            if (custom) steer_mode = (!d_chan_est_smoothing && !d_radar_aided) ? 2 : 1;                               // :600
+            if (d_use_radar_streams) {                                                                               // :435-493
+                const int n_sym = ninput_items[0] / d_N_data;
+                d_radar_streams.assign((size_t)(d_N_tx - 1) * n_sym * d_fft_len, gr_complex(0, 0));
+                std::random_device rd;
+                std::default_random_engine e1(rd());
+                std::uniform_int_distribution<unsigned int> uniform_dist(0, 3);
+                const float a = 0.707107f / 2.0f;
+                for (auto& s : d_radar_streams) { unsigned q = uniform_dist(e1); s = gr_complex((q & 1) ? a : -a, (q & 2) ? a : -a); }
+                rs = d_radar_streams.data();
+            }
+        }
+        std::vector<jrc_cf32*> outs(d_N_tx);
+        for (int t = 0; t < d_N_tx; t++) outs[t] = (jrc_cf32*)output_items[t];
+        int n = jrc_precoder_work(d_pre, ninput_items[0], (const jrc_cf32*)input_items[0], mcs, packet_type, data_size_crc, steer_mode,
+                                  (const jrc_cf32*)steering_matrix_mean.data(), (const jrc_cf32*)steering_matrix.data(),
+                                  (const jrc_cf32*)rs, outs.data());
+        if (n == JRC_ERR_SIG_FIELD) throw std::runtime_error("[MIMO PRECODER] something is wrong!!");               // :327-333
+        d_c.check(n);
+        return n;                                                                                                    // :740
+    }
+    void set_chan_est_smoothing(bool v) override { jrc_rt::thread::scoped_lock lock(d_setlock); d_chan_est_smoothing = v; }
+    void set_radar_aided(bool v) override { jrc_rt::thread::scoped_lock lock(d_setlock); d_radar_aided = v; }
+    void set_use_radar_streams(bool v) override { jrc_rt::thread::scoped_lock lock(d_setlock); d_use_radar_streams = v; }
+    void set_phased_steering(bool v) override { jrc_rt::thread::scoped_lock lock(d_setlock); mean_chan_est_changed = true; d_phased_steering = v; }
+};
+mimo_precoder::sptr mimo_precoder::make(int fft_len, int N_tx, int N_ss, const std::vector<int>& data_carriers,
+                                        const std::vector<int>& pilot_carriers, const std::vector<std::vector<gr_complex>>& pilot_symbols,
+                                        const std::vector<std::vector<gr_complex>>& sync_words,
+                                        const std::vector<std::vector<gr_complex>>& mapped_ltf_symbols, const std::string& chan_est_file,
+                                        bool chan_est_smoothing, const std::string& radar_log_file, bool radar_aided, bool phased_steering,
+                                        bool use_radar_streams, const std::string& len_tag_key, bool debug)
+{
+    return JRC_GET_INITIAL_SPTR(new mimo_precoder_impl(fft_len, N_tx, N_ss, data_carriers, pilot_carriers, pilot_symbols, sync_words,
+                                                       mapped_ltf_symbols, chan_est_file, chan_est_smoothing, radar_log_file, radar_aided,
+                                                       phased_steering, use_radar_streams, len_tag_key, debug));
+}
+
+}  // namespace mimo_ofdm_jrc
+}  // namespace gr

@@ -1,0 +1,102 @@
+// jrc_blocks.h — host-side blocks with the reference's public interface (namespace, class names, make() signatures
+// and setters of /root/reference/include/mimo_ofdm_jrc/*.h), implemented over the C ABI of include/jrc.h.
+//
+//   reference header                                   class here
+//   include/mimo_ofdm_jrc/mimo_ofdm_radar.h:35-64      gr::mimo_ofdm_jrc::mimo_ofdm_radar
+//   include/mimo_ofdm_jrc/matrix_transpose.h           gr::mimo_ofdm_jrc::matrix_transpose
+//   include/mimo_ofdm_jrc/range_angle_estimator.h      gr::mimo_ofdm_jrc::range_angle_estimator
+//   include/mimo_ofdm_jrc/ofdm_cyclic_prefix_remover.h gr::mimo_ofdm_jrc::ofdm_cyclic_prefix_remover
+//   include/mimo_ofdm_jrc/fft_peak_detect.h            gr::mimo_ofdm_jrc::fft_peak_detect
+//   include/mimo_ofdm_jrc/mimo_ofdm_equalizer.h:64-78  gr::mimo_ofdm_jrc::mimo_ofdm_equalizer
+//   include/mimo_ofdm_jrc/mimo_precoder.h              gr::mimo_ofdm_jrc::mimo_precoder
+//
+// Built against GNU Radio 3.8 with -DJRC_WITH_GNURADIO; otherwise against the stand-alone test runtime.
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "jrc_block_runtime.h"
+
+enum ChannelEstimator { LS = 0, STA = 1 };
+enum MCS : uint8_t { BPSK_1_2 = 0, BPSK_3_4 = 1, QPSK_1_2 = 2, QPSK_3_4 = 3, QAM16_1_2 = 4, QAM16_3_4 = 5 };
+enum PACKET_TYPE : uint8_t { NDP = 1, DATA = 2 };
+
+namespace gr {
+namespace mimo_ofdm_jrc {
+
+class mimo_ofdm_radar : virtual public jrc_rt::block {
+public:
+    typedef JRC_SPTR<mimo_ofdm_radar> sptr;
+    static sptr make(int fft_len, int N_tx, int N_rx, int N_sym, int N_pre, bool background_removal,
+                     bool background_recording, int record_len, int interp_factor, bool enable_tx_interleave,
+                     const std::string& radar_chan_file, const std::string& len_tag_key = "packet_len", bool debug = false);
+    virtual void set_background_record(bool background_record) = 0;
+    virtual void capture_radar_data(bool capture_sig) = 0;
+};
+
+class matrix_transpose : virtual public jrc_rt::tagged_stream_block {
+public:
+    typedef JRC_SPTR<matrix_transpose> sptr;
+    static sptr make(int input_len, int output_len, int interp_factor, bool debug, std::string len_key = "packet_len");
+};
+
+class range_angle_estimator : virtual public jrc_rt::tagged_stream_block {
+public:
+    typedef JRC_SPTR<range_angle_estimator> sptr;
+    static sptr make(int vlen, std::vector<float> range_bins, std::vector<float> angle_bins, float noise_discard_range_m,
+                     float noise_discard_angle_deg, float snr_threshold, float power_threshold,
+                     const std::string& stats_path, bool stats_record, const std::string& len_key = "packet_len",
+                     bool debug = false);
+    virtual void set_snr_threshold(float snr_threshold) = 0;
+    virtual void set_power_threshold(float power_threshold) = 0;
+    virtual void set_stats_record(bool stats_record) = 0;
+};
+
+class ofdm_cyclic_prefix_remover : virtual public jrc_rt::tagged_stream_block {
+public:
+    typedef JRC_SPTR<ofdm_cyclic_prefix_remover> sptr;
+    static sptr make(int fft_len, int cp_len, std::string len_key = "packet_len");
+};
+
+class fft_peak_detect : virtual public jrc_rt::tagged_stream_block {
+public:
+    typedef JRC_SPTR<fft_peak_detect> sptr;
+    static sptr make(int samp_rate, float interp_factor, float threshold, int samp_protect, std::vector<float> max_freq,
+                     bool cut_max_freq, const std::string& len_key);
+    virtual void set_threshold(float threshold) = 0;
+    virtual void set_samp_protect(int samp) = 0;
+    virtual void set_max_freq(std::vector<float> freq) = 0;
+};
+
+class mimo_ofdm_equalizer : virtual public jrc_rt::block {
+public:
+    typedef JRC_SPTR<mimo_ofdm_equalizer> sptr;
+    virtual void set_estimator(ChannelEstimator algo) = 0;
+    virtual void set_bandwidth(double bw) = 0;
+    virtual void set_frequency(double freq) = 0;
+    virtual void set_stats_record(bool stats_record) = 0;
+    static sptr make(ChannelEstimator estimator_algo, double freq, double bw, int fft_len, int cp_len,
+                     std::vector<int> data_carriers, std::vector<int> pilot_carriers,
+                     const std::vector<std::vector<gr_complex>>& pilot_symbols, std::vector<gr_complex> long_seq,
+                     const std::vector<std::vector<gr_complex>>& mapped_ltf_symbols, int n_mimo_ltf,
+                     const std::string& chan_est_file, const std::string& comm_log_file, bool stats_record, bool debug);
+};
+
+class mimo_precoder : virtual public jrc_rt::tagged_stream_block {
+public:
+    typedef JRC_SPTR<mimo_precoder> sptr;
+    static sptr make(int fft_len, int N_tx, int N_ss, const std::vector<int>& data_carriers,
+                     const std::vector<int>& pilot_carriers, const std::vector<std::vector<gr_complex>>& pilot_symbols,
+                     const std::vector<std::vector<gr_complex>>& sync_words,
+                     const std::vector<std::vector<gr_complex>>& mapped_ltf_symbols, const std::string& chan_est_file,
+                     bool chan_est_smoothing, const std::string& radar_log_file, bool radar_aided, bool phased_steering,
+                     bool use_radar_streams, const std::string& len_tag_key = "packet_len", bool debug = false);
+    virtual void set_chan_est_smoothing(bool chan_est_smoothing) = 0;
+    virtual void set_radar_aided(bool radar_aided) = 0;
+    virtual void set_use_radar_streams(bool use_radar_streams) = 0;
+    virtual void set_phased_steering(bool phased_steering) = 0;
+};
+
+}  // namespace mimo_ofdm_jrc
+}  // namespace gr
