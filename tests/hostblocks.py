@@ -1,0 +1,138 @@
+"""ctypes driver for gr-mimo-ofdm-jrc_amd/lib/libjrc_blocks.so (the C++ host-side blocks + their C test harness)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "gr-mimo-ofdm-jrc_amd", "lib", "libjrc_blocks.so")
+_vp, _fp, _ip = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        import jrc_amd
+        jrc_amd.load(build_if_missing=True)           # torch first, then libjrc_hip.so (one HIP runtime)
+        if not os.path.exists(LIB):
+            jrc_amd._build.build_host()
+        L = C.CDLL(LIB)
+        L.jrcb_last_error.restype = C.c_char_p
+        for name in ("jrcb_make_radar", "jrcb_make_transpose", "jrcb_make_estimator", "jrcb_make_cp_remover",
+                     "jrcb_make_peak_detect", "jrcb_make_equalizer", "jrcb_make_precoder"):
+            getattr(L, name).restype = _vp
+        L.jrcb_make_radar.argtypes = [C.c_int] * 10
+        L.jrcb_make_transpose.argtypes = [C.c_int] * 3
+        L.jrcb_make_estimator.argtypes = [C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_char_p, C.c_int]
+        L.jrcb_make_cp_remover.argtypes = [C.c_int, C.c_int]
+        L.jrcb_make_peak_detect.argtypes = [C.c_int, C.c_float, C.c_float, C.c_int]
+        L.jrcb_make_equalizer.argtypes = [C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, _ip, C.c_int, _ip, C.c_int, _fp, C.c_int,
+                                          _fp, _fp, C.c_int, C.c_int, C.c_char_p]
+        L.jrcb_make_precoder.argtypes = [C.c_int, C.c_int, _ip, C.c_int, _ip, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_char_p,
+                                         C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int]
+        L.jrcb_destroy.argtypes = [_vp]
+        L.jrcb_add_in_tag.argtypes = [_vp, C.c_int, C.c_uint64, C.c_char_p, C.c_int, C.c_long, C.c_double]
+        L.jrcb_run.argtypes = [_vp, C.c_int, _ip, C.c_int, C.POINTER(_vp), C.c_int, C.POINTER(_vp)]
+        L.jrcb_consumed.argtypes = [_vp, C.c_int]
+        L.jrcb_state_json.argtypes = [_vp, C.c_char_p, C.c_int]
+        L.jrcb_call_setter.argtypes = [_vp, C.c_char_p, C.c_double]
+        _lib = L
+    return _lib
+
+
+def _c(a):
+    return np.ascontiguousarray(a, np.complex64)
+
+
+def _f(a):
+    return a.ctypes.data_as(_fp)
+
+
+class Block:
+    def __init__(self, handle):
+        if not handle:
+            msg = lib().jrcb_last_error().decode()
+            raise (ValueError if "invalid_argument" in msg else RuntimeError)(msg)    # the exception type make() threw
+        self.h = handle
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().jrcb_destroy(self.h)
+            self.h = None
+
+    def tag(self, port, offset, key, value):
+        if isinstance(value, float):
+            lib().jrcb_add_in_tag(self.h, port, offset, key.encode(), 2, 0, value)
+        else:
+            lib().jrcb_add_in_tag(self.h, port, offset, key.encode(), 0, int(value), 0.0)
+
+    def run(self, noutput_items, ins, outs):
+        """ins / outs: lists of numpy arrays (already sized); returns items produced.  Raises like the block would."""
+        nin = (C.c_int * max(1, len(ins)))(*[getattr(a, "_nitems", len(a)) for a in ins])
+        pin = (_vp * max(1, len(ins)))(*[a.ctypes.data for a in ins])
+        pout = (_vp * max(1, len(outs)))(*[a.ctypes.data for a in outs])
+        n = lib().jrcb_run(self.h, noutput_items, nin, len(ins), pin, len(outs), pout)
+        if n == -1001:
+            raise ValueError(lib().jrcb_last_error().decode())
+        if n == -1000:
+            raise RuntimeError(lib().jrcb_last_error().decode())
+        return n
+
+    def consumed(self, port):
+        return lib().jrcb_consumed(self.h, port)
+
+    def state(self):
+        buf = C.create_string_buffer(1 << 20)
+        n = lib().jrcb_state_json(self.h, buf, len(buf))
+        assert n > 0
+        return json.loads(buf.value.decode())
+
+    def set(self, name, v):
+        r = lib().jrcb_call_setter(self.h, name.encode(), float(v))
+        if r == -1000:
+            raise RuntimeError(lib().jrcb_last_error().decode())
+        assert r == 0, name
+
+
+def radar(fft_len, N_tx, N_rx, N_sym, N_pre, bg_removal=False, bg_recording=False, record_len=8, interp=1, interleave=False):
+    return Block(lib().jrcb_make_radar(fft_len, N_tx, N_rx, N_sym, N_pre, int(bg_removal), int(bg_recording), record_len, interp, int(interleave)))
+
+
+def transpose(input_len, output_len, interp):
+    return Block(lib().jrcb_make_transpose(input_len, output_len, interp))
+
+
+def estimator(vlen, rb, ab, ndr, nda, snr_thr, pow_thr, stats_path="", stats_record=False):
+    rb = np.ascontiguousarray(rb, np.float32)
+    ab = np.ascontiguousarray(ab, np.float32)
+    return Block(lib().jrcb_make_estimator(vlen, _f(rb), len(rb), _f(ab), len(ab), ndr, nda, snr_thr, pow_thr, stats_path.encode(), int(stats_record)))
+
+
+def cp_remover(fft_len, cp_len):
+    return Block(lib().jrcb_make_cp_remover(fft_len, cp_len))
+
+
+def peak_detect(samp_rate, interp, threshold, samp_protect):
+    return Block(lib().jrcb_make_peak_detect(samp_rate, interp, threshold, samp_protect))
+
+
+def equalizer(o, algo=0, freq=24e9, bw=125e6, n_ltf=4, chan_est_file=""):
+    dc = np.ascontiguousarray(o["data_subcarriers"], np.int32)
+    pc = np.ascontiguousarray(o["pilot_subcarriers"], np.int32)
+    ps, ltf, ml = _c(o["pilot_symbols"]), _c(o["ltf_64"]), _c(o["ltf_mapped_sc__ss_sym"])
+    return Block(lib().jrcb_make_equalizer(algo, freq, bw, 64, 16, dc.ctypes.data_as(_ip), len(dc), pc.ctypes.data_as(_ip), len(pc),
+                                           _f(ps.view(np.float32)), ps.shape[0], _f(ltf.view(np.float32)), _f(ml.view(np.float32)),
+                                           ml.shape[1], n_ltf, chan_est_file.encode()))
+
+
+def precoder(o, T=4, chan_est_file="", smoothing=False, radar_log_file="", radar_aided=False, phased=False, radar_streams=False,
+             dc=None, pc=None):
+    dc = np.ascontiguousarray(o["data_subcarriers"] if dc is None else dc, np.int32)
+    pc = np.ascontiguousarray(o["pilot_subcarriers"] if pc is None else pc, np.int32)
+    ps, sw, ml = _c(o["pilot_symbols"]), _c(o["l_stf_ltf_64"]), _c(o["ltf_mapped_sc__ss_sym"])
+    return Block(lib().jrcb_make_precoder(64, T, dc.ctypes.data_as(_ip), len(dc), pc.ctypes.data_as(_ip), len(pc),
+                                          _f(ps.view(np.float32)), ps.shape[0], _f(sw.view(np.float32)), sw.shape[0],
+                                          _f(ml.view(np.float32)), chan_est_file.encode(), int(smoothing), radar_log_file.encode(),
+                                          int(radar_aided), int(phased), int(radar_streams)))
