@@ -80,7 +80,10 @@ __device__ __forceinline__ void fft_fwd_small(float2 (&x)[P])
 // LDS = P*N*8 (H) + P*64*8 (range bins of the current class): 40 KiB for config B -> 4 workgroups per CU;
 // 136 KiB for config D -> one 1024-thread workgroup per CU.
 template <int P, int NT, int MMAX, bool TWC_LDS>
-__global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : 3))) void range_angle_fused_kernel(
+#ifndef JRC_WPS256
+#define JRC_WPS256 3
+#endif
+__global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))) void range_angle_fused_kernel(
     const float2* __restrict__ H,        // [F][P][N]
     float2* __restrict__ map,            // [F][NR][NA]
     PeakPartial* __restrict__ partials,  // [F][WPF]
@@ -277,6 +280,7 @@ static int launch_fused(jrc_chain* ch, int n_frames, int wpf, const float2* d_H,
     // small frames: 256-thread workgroups, up to three per CU; large frames (H fills most of the LDS): one
     // 512-thread workgroup per CU
     if (ch->threads == 1024) return launch_fused_nt<P, 1024, 16, true>(ch, n_frames, wpf, d_H, d_map, s);
+    if (ch->threads == 512 && ch->cfg.fft_len <= 256) return launch_fused_nt<P, 512, 4, false>(ch, n_frames, wpf, d_H, d_map, s);
     if (ch->threads == 512) return launch_fused_nt<P, 512, 16, true>(ch, n_frames, wpf, d_H, d_map, s);
     if (ch->cfg.fft_len > 256) return launch_fused_nt<P, 256, 16, true>(ch, n_frames, wpf, d_H, d_map, s);
     return launch_fused_nt<P, 256, 4, false>(ch, n_frames, wpf, d_H, d_map, s);
@@ -305,7 +309,7 @@ extern "C" int jrc_chain_create(jrc_ctx* ctx, const jrc_chain_cfg* cfg, const fl
     ch->max_frames = max_frames;
     ch->lds_bytes = sizeof(float2) * ((size_t)P * N + (size_t)P * RA_L + (N > 256 ? (size_t)N : 0));
     ch->threads = (ch->lds_bytes > 80 * 1024) ? 512 : 256;
-    if (getenv("JRC_THREADS")) { int t = atoi(getenv("JRC_THREADS")); if ((t == 1024 || t == 512) && N > 256) ch->threads = t; else ch->threads = 256; }
+    if (getenv("JRC_THREADS")) { int t = atoi(getenv("JRC_THREADS")); if (t == 512 || (t == 1024 && N > 256)) ch->threads = t; else ch->threads = 256; }
     ch->wpf_override = getenv("JRC_WPF") ? atoi(getenv("JRC_WPF")) : 0;
     {
         hipDeviceProp_t prop;

@@ -193,27 +193,47 @@ void orc_fft_vcc(int n, int forward, int shift, const float* window, long batch,
     free(re);
 }
 
-/* float radix-2 FFT, for CPU-baseline timing only (FFTW3f stand-in arithmetic type) */
-void orc_fft_vcc_f32(int n, int forward, int shift, long batch, const float* in, float* out)
+/* float radix-2 FFT, for CPU-baseline timing only (FFTW3f stand-in arithmetic type).  Twiddle and bit-reversal
+ * tables are cached per (size, direction) so the timed loop does only butterflies, like a planned FFT. */
+typedef struct { int n, sign; float* tw; int* rev; } f32_plan;
+static _Thread_local f32_plan g_plans[8];
+
+static const f32_plan* get_plan(int n, int sign)
 {
-    float* tw = (float*)malloc(sizeof(float) * (size_t)n);  /* n/2 complex twiddles */
-    const int sign = forward ? -1 : +1;
+    for (int i = 0; i < 8; i++) if (g_plans[i].n == n && g_plans[i].sign == sign) return &g_plans[i];
+    int slot = 0;
+    for (int i = 0; i < 8; i++) if (g_plans[i].n == 0) { slot = i; break; }
+    f32_plan* p = &g_plans[slot];
+    free(p->tw); free(p->rev);
+    p->n = n; p->sign = sign;
+    p->tw = (float*)malloc(sizeof(float) * (size_t)n);
+    p->rev = (int*)malloc(sizeof(int) * (size_t)n);
     for (int k = 0; k < n / 2; k++) {
         double ang = sign * 2.0 * M_PI * (double)k / (double)n;
-        tw[2 * k] = (float)cos(ang); tw[2 * k + 1] = (float)sin(ang);
+        p->tw[2 * k] = (float)cos(ang); p->tw[2 * k + 1] = (float)sin(ang);
     }
+    int bits = 0; while ((1 << bits) < n) bits++;
+    for (int i = 0; i < n; i++) {
+        unsigned j = 0;
+        for (int q = 0; q < bits; q++) if (i & (1 << q)) j |= 1u << (bits - 1 - q);
+        p->rev[i] = (int)j;
+    }
+    return p;
+}
+
+void orc_fft_vcc_f32(int n, int forward, int shift, long batch, const float* in, float* out)
+{
+    const f32_plan* pl = get_plan(n, forward ? -1 : +1);
+    const float* tw = pl->tw; const int* rev = pl->rev;
     float* buf = (float*)malloc(sizeof(float) * 2 * (size_t)n);
     const int half = n / 2;
     for (long b = 0; b < batch; b++) {
         const float* x = in + (size_t)b * n * 2;
         float* y = out + (size_t)b * n * 2;
-        /* load with optional ifftshift, bit-reversed placement */
-        int bits = 0; while ((1 << bits) < n) bits++;
-        for (int i = 0; i < n; i++) {
-            int src = (!forward && shift) ? (i + half) % n : i;
-            unsigned j = 0; for (int q = 0; q < bits; q++) if (i & (1 << q)) j |= 1u << (bits - 1 - q);
-            buf[2 * j] = x[2 * src]; buf[2 * j + 1] = x[2 * src + 1];
-        }
+        if (!forward && shift)
+            for (int i = 0; i < n; i++) { int src = (i + half) % n, j = rev[i]; buf[2 * j] = x[2 * src]; buf[2 * j + 1] = x[2 * src + 1]; }
+        else
+            for (int i = 0; i < n; i++) { int j = rev[i]; buf[2 * j] = x[2 * i]; buf[2 * j + 1] = x[2 * i + 1]; }
         for (int len = 2; len <= n; len <<= 1) {
             int h = len >> 1, step = n / len;
             for (int i0 = 0; i0 < n; i0 += len)
@@ -226,12 +246,14 @@ void orc_fft_vcc_f32(int n, int forward, int shift, long batch, const float* in,
                     buf[2 * i] += xr; buf[2 * i + 1] += xi;
                 }
         }
-        for (int i = 0; i < n; i++) {
-            int src = (forward && shift) ? (i + half) % n : i;
-            y[2 * i] = buf[2 * src]; y[2 * i + 1] = buf[2 * src + 1];
+        if (forward && shift) {
+            memcpy(y, buf + 2 * half, sizeof(float) * 2 * (size_t)(n - half));
+            memcpy(y + 2 * (n - half), buf, sizeof(float) * 2 * (size_t)half);
+        } else {
+            memcpy(y, buf, sizeof(float) * 2 * (size_t)n);
         }
     }
-    free(buf); free(tw);
+    free(buf);
 }
 
 /* ------------------------------------------------------------------------------------------

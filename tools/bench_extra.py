@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""Secondary figures SURVEY.md §8(d) asks for next to bench.py's headline line (tools only; prints JSON lines):
+  * radar chain WITH the RX OFDM demod in front (A6 cyclic-prefix removal + A7 fft fwd/shift fused, then A1..A5)
+  * equalizer path, config C: 4 RX lanes x frames of [2 L-LTF, SIG, 4 MIMO-LTF, 64 data symbols] x 256 subcarriers, LS, DATA
+"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import jrc_amd
+from jrc_amd import synth
+
+
+def timed(fn, steps=30, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def radar_with_demod(cfg="B", F=256):
+    sc = {"B": synth.config_B, "D": synth.config_D}[cfg]()
+    Ir, Ia, P = 8, 16, sc.T * sc.R
+    rb, ab = jrc_amd.radar_axes(sc.N, sc.fs, Ir, P, Ia)
+    ctx = jrc_amd.Context(0)
+    chain = jrc_amd.RadarChain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb, ab, 2.4, 14.36, 15.0, 0.0, max_frames=F, ctx=ctx)
+    bufs = chain.alloc(F, "cuda:0")
+    fr = synth.make_frames(sc, 16)
+    hf = torch.from_numpy(fr.view(np.float32).reshape((16,) + tuple(bufs["frames"].shape[1:])))
+    for f0 in range(0, F, 16):
+        bufs["frames"][f0:f0 + 16].copy_(hf[:min(16, F - f0)])
+    n_items = sc.Npre + sc.S
+    # time-domain RX streams with cyclic prefix: [F][R][n_items*(N+cp)] (content irrelevant for timing: random)
+    td = torch.randn((F, sc.R, n_items * (sc.N + sc.cp), 2), dtype=torch.float32, device="cuda:0") * 1e-3
+    rx_view = bufs["frames"][:, sc.T:]                      # the RX ports of the frame buffer, [F][R][n_items][N][2]
+    assert rx_view.is_contiguous() is False
+    rx_tmp = torch.empty((F, sc.R, n_items, sc.N, 2), dtype=torch.float32, device="cuda:0")
+    L = ctx.lib
+    torch.cuda.synchronize()
+
+    def step():
+        # A6+A7 for all F*R streams in one launch (n_symbols = F*R*n_items, symbols are contiguous per stream)
+        ctx.check(L.jrc_cp_remove_fft_dev(ctx.h, sc.N, sc.cp, F * sc.R * n_items, td.data_ptr(), rx_tmp.data_ptr(), None))
+        chain.run(bufs, F)
+    t = timed(step)
+    t_chain = timed(lambda: chain.run(bufs, F))
+    return dict(what="radar chain incl. RX OFDM demod (A6+A7 fused) config %s" % cfg, frames_per_step=F,
+                ms_per_step=t * 1e3, frames_per_s=F / t, ms_chain_only=t_chain * 1e3, frames_per_s_chain_only=F / t_chain)
+
+
+def equalizer_config_c(n_frames=2048, lanes=4):
+    N, cp, T, S = 256, 64, 4, 64
+    rng = np.random.default_rng(0)
+    guard = 16
+    act = [c for c in range(-N // 2 + guard, N // 2 - guard + 1) if c != 0]
+    pilots = [c for c in act if c % 32 == 16][:8]
+    data = [c for c in act if c not in pilots]
+    ltf = np.zeros(N, np.complex64)
+    ltf[np.array(act) + N // 2] = rng.choice([-1.0, 1.0], len(act))
+    Pm = synth.hadamard(T)
+    mapped = np.stack([(Pm * ltf[sc]).reshape(-1) for sc in range(N)]).astype(np.complex64)
+    pil = np.tile(np.array([1, 1, 1, -1, 1, 1, 1, -1], np.complex64)[:len(pilots)], (8, 1))
+    sw = np.stack([ltf, ltf, ltf, ltf])
+    ctx = jrc_amd.Context(0)
+    pre = jrc_amd.mimo_precoder(N, T, 1, data, pilots, pil, sw, mapped, ctx=ctx)
+    nd = len(data)
+    mcs = 2
+    nbytes = (S * nd - 22) // 8
+    ns = jrc_amd.n_ofdm_sym(mcs, nd, nbytes)
+    assert ns == S, (ns, S)
+    pts = np.array([-1 - 1j, 1 - 1j, -1 + 1j, 1 + 1j]) * (0.707107 / 2)
+    s = pts[rng.integers(0, 4, ns * nd)].astype(np.complex64)
+    tx = pre.work(s, mcs, jrc_amd.DATA, nbytes)
+    streams = n_frames * lanes
+    base = []
+    for i in range(8):
+        h = (rng.standard_normal(T) + 1j * rng.standard_normal(T)).astype(np.complex64)
+        y = np.tensordot(h, tx, axes=(0, 0))
+        y = np.concatenate([y[3:4], y[3:]], axis=0)
+        y = y + 1e-3 * (rng.standard_normal(y.shape) + 1j * rng.standard_normal(y.shape))
+        base.append(y.astype(np.complex64))
+    n_sym = base[0].shape[0]
+    x = np.stack([base[i % 8] for i in range(streams)])
+    eq = jrc_amd.mimo_ofdm_equalizer(jrc_amd.LS, 24e9, 125e6, N, cp, data, pilots, pil, ltf, mapped, T, n_streams=streams, ctx=ctx)
+    d_in = torch.from_numpy(x.view(np.float32).reshape(streams, n_sym, N, 2)).to("cuda:0")
+    d_ph = torch.zeros(streams, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    out, n_out, ev = eq.frames_dev(d_in, d_ph, n_sym, ns)
+    ctx.sync()
+    assert n_out.min().item() == ns and n_out.max().item() == ns
+    got = out[0].cpu().numpy().view(np.complex64)[..., 0]
+    err = np.abs(got - s.reshape(ns, nd)).max() / np.abs(s).max()
+    t = timed(lambda: eq.frames_dev(d_in, d_ph, n_sym, ns))
+    byts = streams * (n_sym * N * 8 + ns * nd * 8)
+    return dict(what="equalizer config C: %d frames x %d RX lanes, %d symbols x %d sc, LS, DATA" % (n_frames, lanes, n_sym, N),
+                ms_per_step=t * 1e3, frames_per_s=n_frames / t, lane_frames_per_s=streams / t, GBps=byts / t / 1e9,
+                symbol_error_vs_tx=float(err))
+
+
+if __name__ == "__main__":
+    for fn in (lambda: radar_with_demod("B", 256), lambda: radar_with_demod("D", 64), equalizer_config_c):
+        print(json.dumps(fn()))
