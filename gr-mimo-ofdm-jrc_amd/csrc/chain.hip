@@ -232,6 +232,9 @@ struct jrc_chain {
     jrc_ctx* ctx;
     jrc_chain_cfg cfg;
     int P, NR, NA, C, threads, wg_per_cu, n_cus, wpf_override, max_frames;
+    bool generic = false;             // shapes the fused kernel does not cover: block-by-block kernels on the device
+    float2* d_pad = nullptr;          // generic mode: [max_frames][P][NR] zero-padded rows / range profiles
+    int gen_blocks = 0;               // generic mode: partial-maximum blocks per frame
     float* d_bins = nullptr;          // range_bins (NR) then angle_bins (NA)
     PeakPartial* d_partials = nullptr;
     const float2* twR = nullptr;
@@ -246,6 +249,17 @@ struct jrc_chain {
     int launches = 0;
     jrc_ra_result* h_pinned = nullptr;
 };
+
+// generic mode helper: rows of H -> zero-padded rows of length NR (the padding mimo_ofdm_radar emits, :243, :312-315)
+__global__ void pad_rows_kernel(const float2* __restrict__ H, float2* __restrict__ out, int N, int NR, size_t rows)
+{
+    const size_t total = rows * (size_t)NR;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / NR;
+        const int k = (int)(i - row * NR);
+        out[i] = k < N ? H[row * N + k] : make_float2(0.f, 0.f);
+    }
+}
 
 // slices per frame: enough workgroups to fill every CU once (they are persistent over their classes), not more
 static int chain_pick_wpf(const jrc_chain* ch, int n_frames)
@@ -295,18 +309,22 @@ extern "C" int jrc_chain_create(jrc_ctx* ctx, const jrc_chain_cfg* cfg, const fl
         cfg->interp_angle <= 0 || cfg->n_items < cfg->N_pre + cfg->N_sym)
         return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_create: inconsistent sizes");
     const long NR = (long)N * cfg->interp_range, NA = (long)P * cfg->interp_angle;
-    if (!jrc_is_pow2(N) || N < RA_L || !jrc_is_pow2(cfg->interp_range) || !jrc_is_pow2(P) || P > 16 ||
-        !jrc_is_pow2(cfg->interp_angle) || cfg->interp_angle < 2 || NA < 4 || NR * NA >= (1L << 32) || N > 1024 ||
-        cfg->interp_angle > 64 ||
-        (P * N) % 2 != 0)
+    const bool fused_ok = jrc_is_pow2(N) && N >= RA_L && N <= 1024 && jrc_is_pow2(cfg->interp_range) && jrc_is_pow2(P) &&
+                          P <= 16 && jrc_is_pow2(cfg->interp_angle) && cfg->interp_angle >= 2 && cfg->interp_angle <= 64 &&
+                          NA >= 4 && (P * N) % 2 == 0 &&
+                          sizeof(float2) * ((size_t)P * N + (size_t)P * RA_L + (N > 256 ? (size_t)N : 0)) + 64 <= 160 * 1024;
+    // everything else with power-of-two transform sizes runs block by block (A1, pad, A2, A3, A4, A5 kernels)
+    const bool generic_ok = jrc_is_pow2(NR) && jrc_is_pow2(NA) && NR >= 2 && NA >= 2 && NR <= 16384 && NA <= 16384;
+    if (NR * NA >= (1L << 32) || (!fused_ok && !generic_ok))
         return jrc_fail(ctx, JRC_ERR_UNSUPPORTED,
-                        "fused radar chain needs power-of-two fft_len in [64, 1024], power-of-two N_tx*N_rx <= 16, "
-                        "power-of-two interpolation factors (2 <= angle <= 64); got N=%d P=%d Ir=%d Ia=%d",
+                        "radar chain needs power-of-two transform sizes fft_len*interp_range and N_tx*N_rx*interp_angle "
+                        "(each <= 16384); got N=%d P=%d Ir=%d Ia=%d",
                         N, P, cfg->interp_range, cfg->interp_angle);
     JRC_HIP(ctx, hipSetDevice(ctx->device));
     jrc_chain* ch = new jrc_chain();
     ch->ctx = ctx; ch->cfg = *cfg; ch->P = P; ch->NR = (int)NR; ch->NA = (int)NA; ch->C = (int)(NR / RA_L);
     ch->max_frames = max_frames;
+    ch->generic = !fused_ok || getenv("JRC_CHAIN_GENERIC") != nullptr;
     ch->lds_bytes = sizeof(float2) * ((size_t)P * N + (size_t)P * RA_L + (N > 256 ? (size_t)N : 0));
     ch->threads = (ch->lds_bytes > 80 * 1024) ? 512 : 256;
     if (getenv("JRC_THREADS")) { int t = atoi(getenv("JRC_THREADS")); if (t == 512 || (t == 1024 && N > 256)) ch->threads = t; else ch->threads = 256; }
@@ -321,19 +339,22 @@ extern "C" int jrc_chain_create(jrc_ctx* ctx, const jrc_chain_cfg* cfg, const fl
         if (ch->wg_per_cu < 1) ch->wg_per_cu = 1;
         if (ch->wg_per_cu > 2) ch->wg_per_cu = 2;          // measured: 2 long-lived workgroups per CU beat 3-4 short ones
     }
-    if (ch->lds_bytes + 64 > 160 * 1024) {
-        delete ch;
-        return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "fused radar chain: P*N = %d does not fit the 160 KiB LDS", P * N);
+    if (ch->generic) {
+        if (!generic_ok) { delete ch; return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "JRC_CHAIN_GENERIC: transform sizes must be powers of two"); }
+        ch->C = 1;
+        long nb = ((long)NR * NA + 2047) / 2048;
+        ch->gen_blocks = (int)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb));
     }
     hipError_t e = hipMalloc((void**)&ch->d_bins, sizeof(float) * (size_t)(NR + NA));
     if (e == hipSuccess) e = hipMemcpy(ch->d_bins, range_bins, sizeof(float) * NR, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ch->d_bins + NR, angle_bins, sizeof(float) * NA, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc((void**)&ch->d_partials, sizeof(PeakPartial) * (size_t)max_frames * ch->C);
+    if (e == hipSuccess) e = hipMalloc((void**)&ch->d_partials, sizeof(PeakPartial) * (size_t)max_frames * (ch->generic ? ch->gen_blocks : ch->C));
+    if (e == hipSuccess && ch->generic) e = hipMalloc((void**)&ch->d_pad, sizeof(float2) * (size_t)max_frames * P * NR);
     if (e == hipSuccess) e = hipHostMalloc((void**)&ch->h_pinned, sizeof(jrc_ra_result) * (size_t)max_frames, hipHostMallocDefault);
     int st = JRC_OK;
     if (e != hipSuccess) st = jrc_fail(ctx, JRC_ERR_HIP, "jrc_chain_create: %s", hipGetErrorString(e));
-    if (st == JRC_OK) st = jrc_get_twiddles(ctx, (int)NR, +1, &ch->twR);
-    if (st == JRC_OK) st = jrc_get_twiddles(ctx, (int)NA, -1, &ch->twA);
+    if (st == JRC_OK && !ch->generic) st = jrc_get_twiddles(ctx, (int)NR, +1, &ch->twR);
+    if (st == JRC_OK && !ch->generic) st = jrc_get_twiddles(ctx, (int)NA, -1, &ch->twA);
     if (st != JRC_OK) { jrc_chain_destroy(ch); return st; }
     *out = ch;
     return JRC_OK;
@@ -346,6 +367,7 @@ extern "C" void jrc_chain_destroy(jrc_chain* ch)
     for (auto& e : ch->ev) (void)hipEventDestroy(e);
     if (ch->d_bins) (void)hipFree(ch->d_bins);
     if (ch->d_partials) (void)hipFree(ch->d_partials);
+    if (ch->d_pad) (void)hipFree(ch->d_pad);
     if (ch->h_pinned) (void)hipHostFree(ch->h_pinned);
     delete ch;
 }
@@ -422,22 +444,41 @@ extern "C" int jrc_chain_run_dev(jrc_chain* ch, int n_frames, const jrc_cf32* d_
     JRC_TRY(launch_radar_chanest(ctx, c.N_tx, c.N_rx, (const float2*)d_frames, (float2*)d_chanest, g, n_frames, s));
     if (ev) JRC_HIP(ctx, hipEventRecord(ev[1], s));
     // A2 + A3 + A4 + arg-max half of A5
-    const int wpf = chain_pick_wpf(ch, n_frames);
-    int st;
-    switch (ch->P) {
-        case 1: st = launch_fused<1>(ch, n_frames, wpf, (const float2*)d_chanest, (float2*)d_map, s); break;
-        case 2: st = launch_fused<2>(ch, n_frames, wpf, (const float2*)d_chanest, (float2*)d_map, s); break;
-        case 4: st = launch_fused<4>(ch, n_frames, wpf, (const float2*)d_chanest, (float2*)d_map, s); break;
-        case 8: st = launch_fused<8>(ch, n_frames, wpf, (const float2*)d_chanest, (float2*)d_map, s); break;
-        default: st = launch_fused<16>(ch, n_frames, wpf, (const float2*)d_chanest, (float2*)d_map, s); break;
+    int partials_per_frame;
+    if (ch->generic) {
+        // A1 output -> zero pad -> A2 fft_vxx reverse (NR) -> A3 matrix_transpose -> A4 fft_vxx forward+shift (NA), in place
+        const size_t rows = (size_t)n_frames * ch->P;
+        unsigned pb = (unsigned)((rows * ch->NR + 255) / 256); if (pb > 8192) pb = 8192;
+        hipLaunchKernelGGL(pad_rows_kernel, dim3(pb), dim3(256), 0, s, (const float2*)d_chanest, ch->d_pad, c.fft_len, ch->NR, rows);
+        JRC_HIP(ctx, hipGetLastError());
+        JRC_TRY(launch_fft_vcc(ctx, ch->NR, 0, 0, nullptr, rows, ch->d_pad, ch->d_pad, ch->NR, 0, s));
+        int tr = jrc_matrix_transpose_dev(ctx, ch->NR, ch->P, c.interp_angle, ch->P, (size_t)n_frames, (const jrc_cf32*)ch->d_pad, d_map, (void*)s);
+        if (tr < 0) return tr;
+        JRC_TRY(launch_fft_vcc(ctx, ch->NA, 1, 1, nullptr, (size_t)n_frames * ch->NR, (const float2*)d_map, (float2*)d_map, ch->NA, 0, s));
+        if (ev) JRC_HIP(ctx, hipEventRecord(ev[2], s));
+        for (int f = 0; f < n_frames; f++)
+            JRC_TRY(launch_ra_partial(ctx, (const float2*)d_map + (size_t)f * ch->NR * ch->NA, (size_t)ch->NR * ch->NA,
+                                      ch->d_partials + (size_t)f * ch->gen_blocks, ch->gen_blocks, s));
+        partials_per_frame = ch->gen_blocks;
+    } else {
+        const int wpf = chain_pick_wpf(ch, n_frames);
+        int st;
+        switch (ch->P) {
+            case 1: st = launch_fused<1>(ch, n_frames, wpf, (const float2*)d_chanest, (float2*)d_map, s); break;
+            case 2: st = launch_fused<2>(ch, n_frames, wpf, (const float2*)d_chanest, (float2*)d_map, s); break;
+            case 4: st = launch_fused<4>(ch, n_frames, wpf, (const float2*)d_chanest, (float2*)d_map, s); break;
+            case 8: st = launch_fused<8>(ch, n_frames, wpf, (const float2*)d_chanest, (float2*)d_map, s); break;
+            default: st = launch_fused<16>(ch, n_frames, wpf, (const float2*)d_chanest, (float2*)d_map, s); break;
+        }
+        JRC_TRY(st);
+        if (ev) JRC_HIP(ctx, hipEventRecord(ev[2], s));
+        partials_per_frame = wpf;
     }
-    JRC_TRY(st);
-    if (ev) JRC_HIP(ctx, hipEventRecord(ev[2], s));
     // rest of A5
     RaParams prm;
     prm.vlen = ch->NA; prm.n_inputs = ch->NR; prm.n_range_bins = ch->NR; prm.n_angle_bins = ch->NA;
     prm.noise_discard_range_m = c.noise_discard_range_m; prm.noise_discard_angle_deg = c.noise_discard_angle_deg;
-    JRC_TRY(launch_ra_finalize(ctx, (const float2*)d_map, (size_t)ch->NR * ch->NA, ch->d_partials, wpf, prm, ch->d_bins,
+    JRC_TRY(launch_ra_finalize(ctx, (const float2*)d_map, (size_t)ch->NR * ch->NA, ch->d_partials, partials_per_frame, prm, ch->d_bins,
                                ch->d_bins + ch->NR, d_results, n_frames, s));
     if (ev) JRC_HIP(ctx, hipEventRecord(ev[3], s));
     return JRC_OK;

@@ -117,7 +117,31 @@ def test_chain_unsupported_shape_fails_loudly(jrc, ctx):
     with pytest.raises(jrc.JrcError) as e:
         jrc.RadarChain(48, 4, 2, 4, 5, 8, 16, rb, ab, 2.4, 29.0, ctx=ctx)
     assert e.value.status == jrc.JRC_ERR_UNSUPPORTED
-    rb, ab = jrc.radar_axes(2048, 125e6, 2, 2, 32)        # fft_len above the fused kernel's LDS budget
+    rb, ab = jrc.radar_axes(64, 125e6, 8, 6, 16)          # P = 6: angle transform size 96 is not a power of two
     with pytest.raises(jrc.JrcError) as e:
-        jrc.RadarChain(2048, 1, 2, 2, 5, 2, 32, rb, ab, 2.4, 29.0, ctx=ctx)
+        jrc.RadarChain(64, 3, 2, 4, 5, 8, 16, rb, ab, 2.4, 29.0, ctx=ctx)
     assert e.value.status == jrc.JRC_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("T,R,N,S,Ir,Ia", [(1, 2, 2048, 2, 2, 32),     # fft_len above the fused kernel's LDS budget
+                                           (2, 2, 32, 3, 4, 4),         # fft_len below the fused kernel's 64-point fold
+                                           (4, 2, 64, 4, 8, 1),         # no angle interpolation
+                                           (8, 4, 64, 2, 2, 2)])        # 32 virtual pairs
+def test_chain_generic_mode_for_shapes_outside_the_fused_kernel(jrc, ctx, T, R, N, S, Ir, Ia):
+    """shapes the fused kernel does not cover run block by block on the device (A1, pad, A2, A3, A4, A5 kernels)"""
+    from jrc_amd import synth
+    sc = synth.Scenario(N, T, R, S, targets=[(6.0, -15.0, 0.0, 80.0)])
+    check(jrc, ctx, sc, Ir, Ia, 3)
+
+
+def test_chain_generic_and_fused_modes_agree(jrc, ctx, monkeypatch):
+    from jrc_amd import synth
+    sc = synth.Scenario(256, 4, 4, 8, targets=[(10.0, 20.0, 0.0, 100.0)])
+    fr = synth.make_frames(sc, 3)
+    _, H1, m1, r1, _ = run_chain(jrc, ctx, sc, 8, 16, 3, frames=fr)
+    monkeypatch.setenv("JRC_CHAIN_GENERIC", "1")
+    _, H2, m2, r2, _ = run_chain(jrc, ctx, sc, 8, 16, 3, frames=fr)
+    assert np.array_equal(H1, H2) and rel_err(m1, m2) < FFT_TOL
+    for a, b in zip(r1, r2):
+        assert (a.peak_range_idx, a.peak_angle_idx) == (b.peak_range_idx, b.peak_angle_idx)
+        assert abs(a.snr_est - b.snr_est) < 1e-2
