@@ -109,6 +109,8 @@ def load(build_if_missing=False):
     L.jrc_cp_remove.argtypes = [_vp, C.c_int, C.c_int, C.c_size_t, _vp, _vp]
     L.jrc_cp_remove_fft.argtypes = [_vp, C.c_int, C.c_int, C.c_size_t, _vp, _vp]
     L.jrc_cp_remove_fft_dev.argtypes = [_vp, C.c_int, C.c_int, C.c_size_t, _vp, _vp, _vp]
+    L.jrc_ofdm_mod.argtypes = [_vp, C.c_int, C.c_int, _vp, C.c_size_t, _vp, _vp]
+    L.jrc_ofdm_mod_dev.argtypes = [_vp, C.c_int, C.c_int, _vp, C.c_size_t, _vp, _vp, _vp]
     L.jrc_fft_peak_detect.argtypes = [_vp, C.c_int, C.c_float, C.c_float, C.c_int, C.c_size_t, _vp,
                                       _cfp, _cfp, _cfp, C.POINTER(C.c_int)]
     L.jrc_chain_create.argtypes = [_vp, C.POINTER(ChainCfg), _vp, _vp, C.c_int, C.POINTER(_vp)]
@@ -329,6 +331,17 @@ class ofdm_cyclic_prefix_remover:
         n = self.ctx.check(fn(self.ctx.h, self.fft_len, self.cp_len, x.size, _ptr(x), _ptr(out)))
         assert n == nout
         return out
+
+
+def ofdm_mod(x, fft_len, cp_len, window=None, ctx=None):
+    """TX OFDM modulator: fft_vxx reverse+shift(+window) then cyclic prefixer; x [n_sym, fft_len] -> [n_sym, cp+fft_len]"""
+    ctx = ctx or default_context()
+    x = _c64(x).reshape(-1, fft_len)
+    w = None if window is None else np.ascontiguousarray(window, np.float32)
+    out = np.empty((x.shape[0], cp_len + fft_len), np.complex64)
+    n = ctx.check(ctx.lib.jrc_ofdm_mod(ctx.h, fft_len, cp_len, None if w is None else _ptr(w), x.shape[0], _ptr(x), _ptr(out)))
+    assert n == x.shape[0]
+    return out
 
 
 class fft_peak_detect:

@@ -17,7 +17,8 @@ __global__ __launch_bounds__(256) void fft_pow2_kernel(const float2* __restrict_
                                                        const float2* __restrict__ tw,
                                                        const float* __restrict__ window, int n, int logn,
                                                        int forward, int shift, size_t batch, long in_stride,
-                                                       int in_offset, int tp /* threads per transform */)
+                                                       int in_offset, int tp /* threads per transform */,
+                                                       long out_stride, int cp_out /* cyclic prefix to prepend */)
 {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int per_block = blockDim.x / tp;
@@ -54,17 +55,32 @@ __global__ __launch_bounds__(256) void fft_pow2_kernel(const float2* __restrict_
     }
     __syncthreads();
     if (live) {
-        float2* dst = out + b * (size_t)n;
+        float2* dst = out + b * (size_t)out_stride + cp_out;
         for (int pos = lt; pos < n; pos += tp) {
             int k = (forward && shift) ? ((pos + half_n) & (n - 1)) : pos;   // fftshift on the way out
             unsigned r = __brev((unsigned)k) >> (32 - logn);
             dst[pos] = x[logn ? r : 0];
         }
+        for (int j = lt; j < cp_out; j += tp) {                              // cyclic prefix = last cp_out samples
+            unsigned r = __brev((unsigned)(n - cp_out + j)) >> (32 - logn);
+            dst[j - cp_out] = x[r];
+        }
     }
 }
 
+static int launch_fft_vcc_ex(jrc_ctx* ctx, int n, int forward, int shift, const float* d_window, size_t batch,
+                             const float2* d_in, float2* d_out, long in_stride, int in_offset, long out_stride, int cp_out,
+                             hipStream_t stream);
+
 int launch_fft_vcc(jrc_ctx* ctx, int n, int forward, int shift, const float* d_window, size_t batch,
                    const float2* d_in, float2* d_out, long in_stride, int in_offset, hipStream_t stream)
+{
+    return launch_fft_vcc_ex(ctx, n, forward, shift, d_window, batch, d_in, d_out, in_stride, in_offset, n, 0, stream);
+}
+
+static int launch_fft_vcc_ex(jrc_ctx* ctx, int n, int forward, int shift, const float* d_window, size_t batch,
+                             const float2* d_in, float2* d_out, long in_stride, int in_offset, long out_stride, int cp_out,
+                             hipStream_t stream)
 {
     if (!jrc_is_pow2(n) || n < 2 || n > 16384)
         return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "fft_vcc: fft_size %d is not a power of two in [2, 16384]", n);
@@ -82,7 +98,7 @@ int launch_fft_vcc(jrc_ctx* ctx, int n, int forward, int shift, const float* d_w
         attr_bytes = lds_bytes;
     }
     hipLaunchKernelGGL(fft_pow2_kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, stream, d_in, d_out, tw,
-                       d_window, n, logn, forward, shift, batch, in_stride, in_offset, tp);
+                       d_window, n, logn, forward, shift, batch, in_stride, in_offset, tp, out_stride, cp_out);
     JRC_HIP(ctx, hipGetLastError());
     return JRC_OK;
 }
@@ -276,4 +292,45 @@ extern "C" int jrc_cp_remove_fft(jrc_ctx* ctx, int fft_len, int cp_len, size_t n
     JRC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(out, ctx->pinned, out_bytes);
     return (int)nsym;
+}
+
+// ------------------------------------------------------------------------------------------------
+// TX OFDM modulator: the stock chain after mimo_precoder in the flowgraphs,
+//   fft_vxx reverse + shift + window  ->  digital_ofdm_cyclic_prefixer(cp_len, rolloff 0)
+// (examples/simulation/radar/mimo_ofdm_jrc_radar_sim.grc:801-897), fused: x = N*ifft(ifftshift(X .* w)), out = [x[N-cp:], x]
+extern "C" int jrc_ofdm_mod_dev(jrc_ctx* ctx, int fft_len, int cp_len, const float* d_window, size_t n_symbols,
+                                const jrc_cf32* d_in, jrc_cf32* d_out, void* stream)
+{
+    if (!ctx || !d_in || !d_out) return JRC_ERR_INVALID_ARG;
+    if (cp_len < 0 || cp_len > fft_len) return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "ofdm_mod: bad cp_len");
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    JRC_TRY(launch_fft_vcc_ex(ctx, fft_len, 0, 1, d_window, n_symbols, (const float2*)d_in, (float2*)d_out, fft_len, 0,
+                              (long)fft_len + cp_len, cp_len, s));
+    return (int)n_symbols;
+}
+
+extern "C" int jrc_ofdm_mod(jrc_ctx* ctx, int fft_len, int cp_len, const float* window, size_t n_symbols,
+                            const jrc_cf32* in, jrc_cf32* out)
+{
+    if (!ctx || !in || !out) return JRC_ERR_INVALID_ARG;
+    if (fft_len <= 0 || cp_len < 0 || cp_len > fft_len) return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "ofdm_mod: bad fft_len/cp_len");
+    if (n_symbols == 0) return 0;
+    JRC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t in_bytes = sizeof(float2) * n_symbols * (size_t)fft_len, out_bytes = sizeof(float2) * n_symbols * (size_t)(fft_len + cp_len);
+    const size_t wbytes = window ? sizeof(float) * (size_t)fft_len : 0;
+    JRC_TRY(jrc_ensure_pinned(ctx, (in_bytes + wbytes > out_bytes) ? in_bytes + wbytes : out_bytes));
+    JRC_TRY(jrc_ensure_scratch(ctx, 0, in_bytes));
+    JRC_TRY(jrc_ensure_scratch(ctx, 1, out_bytes));
+    JRC_TRY(jrc_ensure_scratch(ctx, 2, wbytes ? wbytes : 4));
+    memcpy(ctx->pinned, in, in_bytes);
+    if (window) memcpy((char*)ctx->pinned + in_bytes, window, wbytes);
+    JRC_HIP(ctx, hipMemcpyAsync(ctx->scratch[0], ctx->pinned, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (window) JRC_HIP(ctx, hipMemcpyAsync(ctx->scratch[2], (char*)ctx->pinned + in_bytes, wbytes, hipMemcpyHostToDevice, ctx->stream));
+    int r = jrc_ofdm_mod_dev(ctx, fft_len, cp_len, window ? (const float*)ctx->scratch[2] : nullptr, n_symbols,
+                             (const jrc_cf32*)ctx->scratch[0], (jrc_cf32*)ctx->scratch[1], nullptr);
+    if (r < 0) return r;
+    JRC_HIP(ctx, hipMemcpyAsync(ctx->pinned, ctx->scratch[1], out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    JRC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(out, ctx->pinned, out_bytes);
+    return (int)n_symbols;
 }

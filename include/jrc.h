@@ -125,6 +125,14 @@ int jrc_cp_remove_fft(jrc_ctx* ctx, int fft_len, int cp_len, size_t ninput_items
 int jrc_cp_remove_fft_dev(jrc_ctx* ctx, int fft_len, int cp_len, size_t n_symbols,
                           const jrc_cf32* d_in, jrc_cf32* d_out, void* stream);
 
+/* TX OFDM modulator, SURVEY.md §8(f) rank 1: fft_vxx reverse+shift+window followed by digital_ofdm_cyclic_prefixer
+ * (rolloff 0) as wired after mimo_precoder (examples/simulation/radar/mimo_ofdm_jrc_radar_sim.grc:801-897).
+ * in: n_symbols x fft_len (DC at fft_len/2); out: n_symbols x (cp_len + fft_len) time samples.  Returns n_symbols. */
+int jrc_ofdm_mod(jrc_ctx* ctx, int fft_len, int cp_len, const float* window, size_t n_symbols,
+                 const jrc_cf32* in, jrc_cf32* out);
+int jrc_ofdm_mod_dev(jrc_ctx* ctx, int fft_len, int cp_len, const float* d_window, size_t n_symbols,
+                     const jrc_cf32* d_in, jrc_cf32* d_out, void* stream);
+
 /* ---- B1  fft_peak_detect (replaces fft_peak_detect_impl::work, lib/fft_peak_detect_impl.cc:77-111)
  * Returns 1 (items produced, always, :110).  *k_out = winning bin or -1; when -1 the three
  * outputs are left untouched exactly like the reference. */
@@ -135,7 +143,10 @@ int jrc_fft_peak_detect(jrc_ctx* ctx, int samp_rate, float interp_factor, float 
 /* ---- fused, device-resident radar chain  A1 -> A2 -> A3 -> A4 -> A5 over a batch of frames ------
  * One launch sequence replaces mimo_ofdm_radar + fft_vxx(reverse) + matrix_transpose +
  * fft_vxx(forward,shift) + range_angle_estimator of the radar flowgraph
- * (examples/simulation/radar/mimo_ofdm_jrc_radar_sim.grc:2189-2197).  Frames are independent. */
+ * (examples/simulation/radar/mimo_ofdm_jrc_radar_sim.grc:2189-2197).  Frames are independent.
+ * Shapes: both transform sizes fft_len*interp_range and N_tx*N_rx*interp_angle must be powers of two (<= 16384).
+ * Power-of-two fft_len in [64, 1024], N_tx*N_rx <= 16 and 2 <= interp_angle <= 64 take the fused kernel (A2-A4 and
+ * the arg-max never leave the chip); other shapes run block by block on the device with the same results. */
 typedef struct {
     int32_t fft_len, N_tx, N_rx, N_sym, N_pre;
     int32_t interp_range, interp_angle;       /* Ir (mimo_ofdm_radar), Ia (matrix_transpose) */

@@ -111,6 +111,21 @@ def test_cp_remover_fused_with_rx_fft(jrc, ctx, N, cp, k):
     assert rel_err(got, ref) < FFT_TOL
 
 
+@pytest.mark.parametrize("N,cp,k,win", [(64, 16, 9, True), (256, 64, 73, False), (1024, 256, 5, True), (64, 0, 3, False)])
+def test_tx_ofdm_modulator_and_rx_demod_round_trip(jrc, ctx, N, cp, k, win):
+    """fft_vxx reverse/shift/window + cyclic prefixer (TX side of the flowgraph), then A6+A7 brings the symbols back"""
+    rng = np.random.default_rng(N + cp)
+    X = crandn(rng, k, N)
+    w = np.full(N, 1 / np.sqrt(64), np.float32) if win else None
+    got = jrc.ofdm_mod(X, N, cp, w, ctx=ctx)
+    x = oracle.fft_vcc(X, False, True, window=w)
+    ref = np.concatenate([x[:, N - cp:], x], axis=1) if cp else x
+    assert got.shape == (k, N + cp) and rel_err(got, ref) < FFT_TOL
+    back = jrc.ofdm_cyclic_prefix_remover(N, cp, ctx=ctx).work(got.ravel(), fused_fft=True)
+    scale = N * (1 / np.sqrt(64) if win else 1.0)
+    assert rel_err(back, X * scale) < 5e-6
+
+
 def _axes(jrc, N=64, Ir=8, P=8, Ia=16):
     return jrc.radar_axes(N, 125e6, Ir, P, Ia)
 
