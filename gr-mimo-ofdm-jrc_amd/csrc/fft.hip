@@ -68,6 +68,93 @@ __global__ __launch_bounds__(256) void fft_pow2_kernel(const float2* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Stockham autosort FFT, radix 4 (one leading radix-2 pass when log2 n is odd): natural order in and out, so no
+// bit-reversal gather; the first pass reads global memory directly and the last pass writes it directly, with
+// coalesced 512-byte wave accesses on both sides.  n <= 8192 (two LDS buffers of n points).
+template <int R>
+__device__ __forceinline__ void stockham_pass(const float2* __restrict__ src_g, long src_wrap /* n if ifftshift else 0 */,
+                                              const float* __restrict__ window, const float2* src_l, float2* dst_l,
+                                              float2* __restrict__ dst_g, int dst_rot /* n/2 if fftshift else 0 */,
+                                              const float2* __restrict__ tw, int n, int Ns, int sign, int lt, int tp)
+{
+    const int nb = n / R;
+    for (int j = lt; j < nb; j += tp) {
+        const int k = j & (Ns - 1);
+        float2 v[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int idx = j + r * nb;
+            if (src_g) {
+                const int si = src_wrap ? ((idx + (n >> 1)) & (n - 1)) : idx;          // ifftshift on the way in
+                v[r] = src_g[si];
+                if (window) { const float w = window[si]; v[r].x *= w; v[r].y *= w; }
+            } else {
+                v[r] = src_l[idx];
+            }
+            if (r && k) v[r] = cmul(v[r], tw[(k * r * (n / (Ns * R))) & (n - 1)]);
+        }
+        if (R == 2) {
+            const float2 a = v[0], b = v[1];
+            v[0] = cadd(a, b); v[1] = csub(a, b);
+        } else {
+            const float2 a = cadd(v[0], v[2]), b = csub(v[0], v[2]), c = cadd(v[1], v[3]), d = csub(v[1], v[3]);
+            // forward: X1 = b - j d, X3 = b + j d ; inverse: X1 = b + j d, X3 = b - j d
+            const float2 jd = sign < 0 ? make_float2(d.y, -d.x) : make_float2(-d.y, d.x);
+            v[0] = cadd(a, c); v[2] = csub(a, c); v[1] = cadd(b, jd); v[3] = csub(b, jd);
+        }
+        const int j0 = ((j - k) * R) + k;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int o = j0 + r * Ns;
+            if (dst_g) dst_g[dst_rot ? ((o + dst_rot) & (n - 1)) : o] = v[r];          // fftshift on the way out
+            else dst_l[o] = v[r];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void fft_stockham_kernel(const float2* __restrict__ in, float2* __restrict__ out,
+                                                           const float2* __restrict__ tw, const float* __restrict__ window,
+                                                           int n, int logn, int forward, int shift, size_t batch,
+                                                           long in_stride, int in_offset, int tp, long out_stride, int cp_out)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    const int per_block = blockDim.x / tp;
+    const int lt = threadIdx.x % tp, lb = threadIdx.x / tp;
+    const size_t b = (size_t)blockIdx.x * per_block + lb;
+    const bool live = b < batch;
+    float2* buf0 = lds + (size_t)lb * 2 * n;
+    float2* buf1 = buf0 + n;
+    const int sign = forward ? -1 : 1;
+    const float2* src_g = in + b * (size_t)in_stride + in_offset;
+    float2* dst_g = out + b * (size_t)out_stride + cp_out;
+    const long wrap = (!forward && shift) ? n : 0;
+    const int rot = (forward && shift) ? (n >> 1) : 0;
+    const bool need_copy = cp_out > 0;            // the cyclic prefix needs the finished symbol: last pass goes through LDS
+
+    int Ns = 1;
+    const float2* cur = nullptr;                  // nullptr = still in global memory
+    float2* nxt = buf0;
+    bool first = true;
+    while (Ns < n) {
+        const int R = ((logn & 1) && first) ? 2 : 4;
+        const bool last = Ns * R == n;
+        float2* dl = (last && !need_copy) ? nullptr : nxt;
+        float2* dg = (last && !need_copy) ? dst_g : nullptr;
+        if (live) {
+            if (R == 2) stockham_pass<2>(first ? src_g : nullptr, wrap, first ? window : nullptr, cur, dl, dg, rot, tw, n, Ns, sign, lt, tp);
+            else stockham_pass<4>(first ? src_g : nullptr, wrap, first ? window : nullptr, cur, dl, dg, rot, tw, n, Ns, sign, lt, tp);
+        }
+        __syncthreads();
+        cur = nxt; nxt = (nxt == buf0) ? buf1 : buf0;
+        Ns *= R; first = false;
+    }
+    if (need_copy && live) {
+        for (int pos = lt; pos < n; pos += tp) dst_g[pos] = cur[rot ? ((pos + rot) & (n - 1)) : pos];
+        for (int jj = lt; jj < cp_out; jj += tp) { const int pos = n - cp_out + jj; dst_g[jj - cp_out] = cur[rot ? ((pos + rot) & (n - 1)) : pos]; }
+    }
+}
+
 static int launch_fft_vcc_ex(jrc_ctx* ctx, int n, int forward, int shift, const float* d_window, size_t batch,
                              const float2* d_in, float2* d_out, long in_stride, int in_offset, long out_stride, int cp_out,
                              hipStream_t stream);
@@ -88,6 +175,21 @@ static int launch_fft_vcc_ex(jrc_ctx* ctx, int n, int forward, int shift, const 
     const float2* tw = nullptr;
     JRC_TRY(jrc_get_twiddles(ctx, n, forward ? -1 : +1, &tw));
     const int logn = jrc_ilog2(n);
+    if (n >= 4 && n <= 8192) {            // Stockham radix-4, natural order (the default)
+        int tp = n / 4; if (tp > 256) tp = 256; if (tp < 1) tp = 1;
+        const int per_block = 256 / tp;
+        const size_t blocks = (batch + per_block - 1) / per_block;
+        const size_t lds_bytes = sizeof(float2) * 2 * (size_t)n * per_block;
+        static size_t attr_bytes2 = 64 * 1024;
+        if (lds_bytes > attr_bytes2) {
+            JRC_HIP(ctx, hipFuncSetAttribute((const void*)fft_stockham_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            attr_bytes2 = lds_bytes;
+        }
+        hipLaunchKernelGGL(fft_stockham_kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, stream, d_in, d_out, tw,
+                           d_window, n, logn, forward, shift, batch, in_stride, in_offset, tp, out_stride, cp_out);
+        JRC_HIP(ctx, hipGetLastError());
+        return JRC_OK;
+    }
     int tp = n / 2; if (tp > 256) tp = 256; if (tp < 1) tp = 1;
     const int per_block = 256 / tp;
     const size_t blocks = (batch + per_block - 1) / per_block;
