@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--distinct", type=int, default=32, help="distinct synthetic frames generated per GPU (tiled to --frames)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests of the N>1 path)")
+    ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses GPU 0")
     ap.add_argument("--gather-results", action="store_true",
                     help="also RCCL all-gather the per-frame results every step (optional exchange, off by default)")
     return ap.parse_args()
@@ -119,11 +121,16 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP path is mandatory; there is no CPU fallback)")
+    if a.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(dev))
+        else:
+            dist.init_process_group(a.backend)
 
     ctx = jrc_amd.Context(local_rank)
     chain = jrc_amd.RadarChain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb, ab, ndr, nda, 15.0, 0.0,
@@ -165,7 +172,7 @@ def main():
     kt = chain.get_timing()
     res = chain.results(bufs, F)
 
-    elapsed = shard.max_over_ranks(elapsed, dev)
+    elapsed = shard.max_over_ranks(elapsed, dev if a.backend == "nccl" else "cpu")
 
     if rank == 0:
         total_frames = F * a.steps * world
