@@ -179,3 +179,62 @@ def test_equalizer_batched_frames_on_device(jrc, ctx, ofdm64):
         e1 = jrc.EqEvent.from_buffer_copy(evb[i, 1].tobytes())
         assert (e0.kind, e1.kind) == (1, 2) and e0.packet_type == refs[i]["events"][0]["packet_type"]
         assert abs(e1.snr_data - refs[i]["events"][1]["snr_data"]) < 1e-3 * abs(refs[i]["events"][1]["snr_data"])
+
+
+def config_c_tables(N=256, T=4, seed=0):
+    """documented generalisation of the 64-carrier tables to N = 256 (the reference has none): +-1 LTF with
+    guard bands and DC nulled, the reference's P_ltf Hadamard mapping, pilots every 32 carriers with the 802.11 polarity row"""
+    from jrc_amd import synth
+    rng = np.random.default_rng(seed)
+    guard = N // 16
+    act = [c for c in range(-N // 2 + guard, N // 2 - guard + 1) if c != 0]
+    pilots = [c for c in act if c % 32 == 16][:8]
+    data = [c for c in act if c not in pilots]
+    ltf = np.zeros(N, np.complex64)
+    ltf[np.array(act) + N // 2] = rng.choice([-1.0, 1.0], len(act))
+    mapped = np.stack([(synth.hadamard(T) * ltf[sc]).reshape(-1) for sc in range(N)]).astype(np.complex64)
+    pil = np.array([[1, 1, 1, -1, 1, 1, 1, -1], [-1, -1, -1, 1, -1, -1, -1, 1], [1, 1, 1, -1, 1, 1, 1, -1]], np.complex64)[:, :len(pilots)]
+    sync = np.stack([ltf, ltf, ltf, ltf])
+    return data, pilots, pil, ltf, mapped, sync
+
+
+@pytest.mark.parametrize("est,ptype,steer", [(LS, DATA, "dft"), (LS, DATA, "sc"), (LS, NDP, "dft"), (STA, DATA, "mean")])
+def test_config_c_equalizer_and_precoder_256_subcarriers_64_symbols(jrc, ctx, est, ptype, steer):
+    """BASELINE config C: 4 TX, 256 subcarriers, 64 data symbols, LS channel estimate + per-subcarrier solve; the north
+    star's tolerance 1e-4 on ||a-b||_inf/||b||_inf against the oracle (the restated Eigen/libstdc++ arithmetic)"""
+    N, cp, T, S = 256, 64, 4, 64
+    rng = np.random.default_rng(11)
+    data, pilots, pil, ltf, mapped, sync = config_c_tables(N, T)
+    nd = len(data)
+    mcs = 2
+    nbytes = (S * nd - 22) // 8
+    assert oracle.n_ofdm_sym(mcs, nd, nbytes) == S
+    s = qpsk(rng, S * nd)
+    h = crandn(rng, T)
+    gp = jrc.mimo_precoder(N, T, 1, data, pilots, pil, sync, mapped, ctx=ctx)
+    op = oracle.Precoder(N, T, 1, data, pilots, pil, sync, mapped)
+    kw = {}
+    if steer == "sc":
+        hs = crandn(rng, N, T)
+        kw = dict(steer_mode=2, Q_sc=jrc.steering_from_channel(hs, ctx=ctx))
+        assert rel_err(kw["Q_sc"], np.stack([oracle.steering_from_channel(hs[i]) for i in range(N)])) < 1e-6
+    elif steer == "mean":
+        kw = dict(steer_mode=1, Q_mean=oracle.steering_from_channel(h))
+    tx_g = gp.work(s, mcs, ptype, nbytes, **kw)
+    tx_o = op.work(s, mcs, ptype, nbytes, **kw)
+    assert tx_g.shape == (T, S + 9, N) and rel_err(tx_g, tx_o) < 1e-6
+    y = np.tensordot(h, tx_o, axes=(0, 0))
+    y = np.concatenate([y[3:4], y[3:]], axis=0)
+    y = (y + 2e-3 * (rng.standard_normal(y.shape) + 1j * rng.standard_normal(y.shape))).astype(np.complex64)
+    ge = jrc.mimo_ofdm_equalizer(est, 24e9, 125e6, N, cp, data, pilots, pil, ltf, mapped, T, ctx=ctx)
+    oe = oracle.Equalizer(est, 24e9, 125e6, N, cp, data, pilots, pil, ltf, mapped, T)
+    g = ge.general_work(y, [(0, 0.004)])
+    o = oe.general_work(y, [(0, 0.004)])
+    assert g["out"].shape == o["out"].shape == (S, nd) and g["consumed"] == o["consumed"] == len(y)
+    assert rel_err(g["out"], o["out"]) < 1e-4
+    same_events(g["events"], o["events"])
+    if ptype == NDP:
+        assert rel_err(g["chan_est"], o["chan_est"]) < 1e-4
+    if steer != "sc" and est == LS:
+        ref = s.reshape(S, nd)                                      # and the frame really decodes: QPSK decisions match
+        assert np.mean((np.sign(g["out"].real) == np.sign(ref.real)) & (np.sign(g["out"].imag) == np.sign(ref.imag))) > 0.999
