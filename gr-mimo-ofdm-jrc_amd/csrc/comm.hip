@@ -100,7 +100,7 @@ extern "C" int jrc_sig_encode(int n_data, int mcs, int packet_type, int length, 
 // ------------------------------------------------------------------------------------------------
 // C1 equalizer
 struct EqDev {
-    int N, cp, ND, NP, NAct, NL, T, mapped_cols, n_pilot_rows, estimator;
+    int N, cp, ND, NP, NAct, NL, T, mapped_cols, n_pilot_rows, estimator, lds_tables;
     double freq, bw;
     const int* data_c; const int* pilot_c; const int* active_c;
     const float2* pilot_sym; const float2* ltf; const float2* mapped;
@@ -143,9 +143,17 @@ __global__ __launch_bounds__(1024) void equalizer_kernel(EqDev d, EqState* state
     unsigned long long* surv = reinterpret_cast<unsigned long long*>(est + NP);   // [ND/2]
     unsigned char* bits = reinterpret_cast<unsigned char*>(surv + ND / 2);        // [ND]
     unsigned char* dec = bits + ND;                                               // [ND/2]
+    // constant tables staged in LDS: the serial (one-lane) sections below walk them with dependent loads, which from
+    // global memory cost microseconds each once every CU is busy
+    int* dc = reinterpret_cast<int*>(eq_smem + d.lds_tables);                     // [ND] data carriers
+    int* pc = dc + ND;                                                            // [NP] pilot carriers
+    int* ac = pc + NP;                                                            // [NAct] sorted active carriers
+    float2* s_ltf = reinterpret_cast<float2*>(ac + d.NAct + ((ND + NP + d.NAct) & 1));   // [N]
+    float2* s_ref = s_ltf + N;                                                    // [NP] pilot row of the current symbol
     __shared__ EqState S;
     __shared__ float2 s_rot;
     __shared__ int s_flag;
+    __shared__ double s_dred[32];
 
     const int tid = threadIdx.x, NT = blockDim.x;
     const int b = blockIdx.x;
@@ -160,12 +168,29 @@ __global__ __launch_bounds__(1024) void equalizer_kernel(EqDev d, EqState* state
     jrc_eq_event* events = io.events + (size_t)b * io.max_events;
 
     if (tid == 0) S = *gst;
-    for (int i = tid; i < N; i += NT) { H[i] = gH[i]; Hm[i] = gHm[i]; }
+    for (int i = tid; i < N; i += NT) { H[i] = gH[i]; Hm[i] = gHm[i]; s_ltf[i] = d.ltf[i]; }
+    for (int i = tid; i < ND; i += NT) dc[i] = d.data_c[i];
+    for (int i = tid; i < NP; i += NT) pc[i] = d.pilot_c[i];
+    for (int i = tid; i < d.NAct; i += NT) ac[i] = d.active_c[i];
     __syncthreads();
 
-    int n_in = 0, n_out = 0, nev = 0, ce_written = 0;
+    int n_in = 0, n_out = 0, nev = 0, ce_written = 0, advance = 0;
+    // input symbols are prefetched one symbol ahead into registers: a symbol is only a few microseconds of work, so
+    // an HBM round trip per symbol would otherwise dominate the per-frame latency
+    constexpr int EPT = 4;                                                              // fft_len <= 4 * blockDim
+    float2 xin[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; e++) { const int i = tid + e * NT; if (i < N && io.ninput > 0) xin[e] = in[i]; }
     while (n_in < io.ninput && n_out < io.noutput) {                                   // :219
+        float2 cur[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+            cur[e] = xin[e];
+            const int i = tid + e * NT;
+            if (i < N && n_in + 1 < io.ninput) xin[e] = in[(size_t)(n_in + 1) * N + i];
+        }
         if (tid == 0) {
+            if (advance) S.symbol_ind++;                                                // d_symbol_ind++ of the previous turn (:607)
             int hit = -1;
             if (io.tag_offsets == nullptr) { if (n_in == 0) hit = stream; }
             else for (int t = 0; t < io.n_tags; t++) if (io.tag_offsets[t] == n_in) { hit = t; break; }
@@ -180,39 +205,50 @@ __global__ __launch_bounds__(1024) void equalizer_kernel(EqDev d, EqState* state
         }
         __syncthreads();
         const int sym = S.symbol_ind;
-        if (sym > S.n_ofdm_symbols_SIG + 2 + NL || !S.sig_ok) { n_in++; __syncthreads(); continue; }   // :250-255
+        if (sym > S.n_ofdm_symbols_SIG + 2 + NL || !S.sig_ok) { n_in++; advance = 0; __syncthreads(); continue; }   // :250-255
 
+        if (sym >= 2 && tid < NP) {   // pilot row of this symbol (SIG: row 0; data symbol m: row m mod n_rows), read by lane 0 below
+            const int row = sym == 2 ? 0 : (sym > 2 + NL ? (sym - 3 - NL) % d.n_pilot_rows : 0);
+            s_ref[tid] = d.pilot_sym[(size_t)row * NP + tid];
+        }
         {   // sampling-offset de-rotation :261-264
             const double k0 = 2 * M_PI * sym * ((N + d.cp) * 1.0 / N) * (S.epsilon0 + S.er);
-            for (int i = tid; i < N; i += NT) Y[i] = c_mul(in[(size_t)n_in * N + i], c_expj(k0 * (i - N / 2)));
+#pragma unroll
+            for (int e = 0; e < EPT; e++) { const int i = tid + e * NT; if (i < N) Y[i] = c_mul(cur[e], c_expj(k0 * (i - N / 2))); }
         }
         __syncthreads();
 
         if (sym == 0) {                                                                 // :272-275
             for (int i = tid; i < N; i += NT) H[i] = Y[i];
         } else if (sym == 1) {                                                          // :277-306
-            if (tid == 0) {
+            {   // SNR from the two L-LTF periods (:279-305); double sums reduced across the workgroup
                 double signal = 0, noise = 0;
-                for (int k = 0; k < d.NAct; k++) {
-                    const int c = d.active_c[k];
+                for (int k = tid; k < d.NAct; k += NT) {
+                    const int c = ac[k];
                     const double hn = (double)ref_hypotf(make_float2(H[c].x - Y[c].x, H[c].y - Y[c].y));
                     const double hs = (double)ref_hypotf(make_float2(H[c].x + Y[c].x, H[c].y + Y[c].y));
                     noise += hn * hn; signal += hs * hs;
                 }
-                S.snr_est = 10 * log10(signal / noise / 2);
+                for (int off = 32; off > 0; off >>= 1) { noise += __shfl_down(noise, off); signal += __shfl_down(signal, off); }
+                if ((tid & 63) == 0) { s_dred[tid >> 6] = noise; s_dred[16 + (tid >> 6)] = signal; }
+                __syncthreads();
+                if (tid == 0) {
+                    double n2 = 0, s2 = 0;
+                    for (int w = 0; w < (NT + 63) / 64; w++) { n2 += s_dred[w]; s2 += s_dred[16 + w]; }
+                    S.snr_est = 10 * log10(s2 / n2 / 2);
+                }
             }
-            __syncthreads();
             for (int k = tid; k < d.NAct; k += NT) {
-                const int c = d.active_c[k];
-                const float2 l = d.ltf[c];
+                const int c = ac[k];
+                const float2 l = s_ltf[c];
                 H[c] = c_div(make_float2(H[c].x + Y[c].x, H[c].y + Y[c].y), c_mul(l, make_float2(2.f, 0.f)));
             }
         } else if (sym == 2) {                                                          // SIG :308-344
             if (tid == 0) {
                 float2 sum = make_float2(0.f, 0.f);
                 for (int k = 0; k < NP; k++) {                                          // estimate_residual_cfo :908-922
-                    est[k] = c_mul(H[d.pilot_c[k]], d.pilot_sym[k]);
-                    const float2 p = c_mul(Y[d.pilot_c[k]], c_conj(est[k]));
+                    est[k] = c_mul(H[pc[k]], s_ref[k]);
+                    const float2 p = c_mul(Y[pc[k]], c_conj(est[k]));
                     sum.x = sum.x + p.x; sum.y = sum.y + p.y;
                 }
                 s_rot = c_expj(-(double)atan2f(sum.y, sum.x));
@@ -221,7 +257,7 @@ __global__ __launch_bounds__(1024) void equalizer_kernel(EqDev d, EqState* state
             for (int i = tid; i < N; i += NT) Y[i] = c_mul(Y[i], s_rot);
             __syncthreads();
             for (int i = tid; i < ND; i += NT) {
-                Z[i] = c_div(Y[d.data_c[i]], H[d.data_c[i]]);                           // symbol_equalize :900-906
+                Z[i] = c_div(Y[dc[i]], H[dc[i]]);                           // symbol_equalize :900-906
                 bits[i] = Z[i].x > 0;                                                   // BPSK decision
             }
             __syncthreads();
@@ -306,7 +342,7 @@ __global__ __launch_bounds__(1024) void equalizer_kernel(EqDev d, EqState* state
                         for (int t = 0; t < T; t++) {
                             float2 m = make_float2(0.f, 0.f);
                             for (int k = 0; k < d.NAct; k++) {
-                                const int sc = d.active_c[k];
+                                const int sc = ac[k];
                                 float2 h;
                                 if (chan_est) h = chan_est[(size_t)sc * T + t];
                                 else {
@@ -325,7 +361,7 @@ __global__ __launch_bounds__(1024) void equalizer_kernel(EqDev d, EqState* state
                     ce_written = 1;
                 } else if (S.packet_type == 2) {                                        // DATA :423-456
                     for (int k = tid; k < d.NAct; k += NT) {
-                        const int sc = k < ND ? d.data_c[k] : d.pilot_c[k - ND];
+                        const int sc = k < ND ? dc[k] : pc[k - ND];
                         float2 acc = make_float2(0.f, 0.f);
                         for (int q = 0; q < NL; q++) {                                  // row(0).dot(y): conjugates the row
                             const float2 p = c_mul(c_conj(d.mapped[(size_t)sc * d.mapped_cols + q]), pre[(size_t)sc * NL + q]);
@@ -336,91 +372,97 @@ __global__ __launch_bounds__(1024) void equalizer_kernel(EqDev d, EqState* state
                     __syncthreads();
                     if (tid == 0) {
                         float2 m = make_float2(0.f, 0.f);
-                        for (int k = 0; k < ND; k++) { m.x = m.x + Hm[d.data_c[k]].x; m.y = m.y + Hm[d.data_c[k]].y; }
-                        for (int k = 0; k < NP; k++) { m.x = m.x + Hm[d.pilot_c[k]].x; m.y = m.y + Hm[d.pilot_c[k]].y; }
+                        for (int k = 0; k < ND; k++) { m.x = m.x + Hm[dc[k]].x; m.y = m.y + Hm[dc[k]].y; }
+                        for (int k = 0; k < NP; k++) { m.x = m.x + Hm[pc[k]].x; m.y = m.y + Hm[pc[k]].y; }
                         S.chan_mean[0] = make_float2(m.x / (float)d.NAct, m.y / (float)d.NAct);
                         S.n_chan_mean = 1;
                     }
                 }
             }
         } else {                                                                        // data symbols :465-605
-            const int row = (sym - 3 - NL) % d.n_pilot_rows;
-            const float2* ref = d.pilot_sym + (size_t)row * NP;
+            const float2* ref = s_ref;          // d_pilot_symbols[(sym - 3 - N_ltf) % size], staged above (:467)
             float2* Hsel = S.packet_type == 1 ? H : Hm;
-            if (tid == 0) {
-                float2 sum = make_float2(0.f, 0.f);
-                for (int k = 0; k < NP; k++) {
-                    est[k] = c_mul(Hsel[d.pilot_c[k]], ref[k]);
-                    const float2 p = c_mul(Y[d.pilot_c[k]], c_conj(est[k]));
+            if (tid < 64) {   // one wavefront: lane k owns pilot k (strided when there are more than 64 pilots)
+                float2 sum = make_float2(0.f, 0.f);                                     // estimate_residual_cfo :908-922
+                for (int k = tid; k < NP; k += 64) {
+                    est[k] = c_mul(Hsel[pc[k]], ref[k]);
+                    const float2 p = c_mul(Y[pc[k]], c_conj(est[k]));
                     sum.x = sum.x + p.x; sum.y = sum.y + p.y;
                 }
-                s_rot = c_expj(-(double)atan2f(sum.y, sum.x));
-            }
-            __syncthreads();
-            for (int i = tid; i < N; i += NT) Y[i] = c_mul(Y[i], s_rot);
-            __syncthreads();
-            if (tid == 0) {                                                             // :484-493
-                for (int k = 0; k < NP; k++) {
-                    S.signal_power_sum += (double)c_mul(est[k], c_conj(est[k])).x;
-                    const float2 e = make_float2(est[k].x - Y[d.pilot_c[k]].x, est[k].y - Y[d.pilot_c[k]].y);
-                    S.noise_power_sum += (double)c_mul(e, c_conj(e)).x;
-                    S.snr_est_count++;
+                for (int off = 32; off > 0; off >>= 1) { sum.x += __shfl_xor(sum.x, off); sum.y += __shfl_xor(sum.y, off); }
+                const float2 r0 = c_expj(-(double)atan2f(sum.y, sum.x));
+                double sig = 0, noi = 0;
+                for (int k = tid; k < NP; k += 64) {                                    // :484-493, on the de-rotated pilots
+                    sig += (double)c_mul(est[k], c_conj(est[k])).x;
+                    const float2 yr = c_mul(Y[pc[k]], r0);
+                    const float2 e = make_float2(est[k].x - yr.x, est[k].y - yr.y);
+                    noi += (double)c_mul(e, c_conj(e)).x;
+                }
+                for (int off = 32; off > 0; off >>= 1) { sig += __shfl_xor(sig, off); noi += __shfl_xor(noi, off); }
+                if (tid == 0) {
+                    s_rot = r0;
+                    S.signal_power_sum += sig; S.noise_power_sum += noi; S.snr_est_count += NP;
                 }
             }
             __syncthreads();
+            const float2 rot = s_rot;           // Y is de-rotated on the fly (:480-482): it is not needed after this symbol
             const int bps = (S.mcs <= 1) ? 1 : (S.mcs <= 3 ? 2 : 4);
+            const bool sta = d.estimator == 1 && bps <= 2;
+            float2* o = out + (size_t)n_out * ND;
             if (S.packet_type == 1) {
-                for (int i = tid; i < ND; i += NT) Z[i] = c_div(Y[d.data_c[i]], H[d.data_c[i]]);
-                if (d.estimator == 1 && bps <= 2) {                                     // STA :498-535
-                    __syncthreads();
-                    const float alpha = 0.5f;
-                    for (int i = tid; i < ND; i += NT) {
-                        const int sc = d.data_c[i];
-                        const float2 upd = c_div(Y[sc], demod_point(bps, Z[i]));
+                const float alpha = 0.5f;                                               // STA :498-535
+                for (int i = tid; i < ND; i += NT) {
+                    const int sc = dc[i];
+                    const float2 yr = c_mul(Y[sc], rot);
+                    const float2 z = c_div(yr, H[sc]);                                  // symbol_equalize :900-906
+                    o[i] = z;                                                           // :602
+                    if (sta) {
+                        const float2 upd = c_div(yr, demod_point(bps, z));
                         const float2 a = c_mul(make_float2(1 - alpha, 0.f), H[sc]), bb = c_mul(make_float2(alpha, 0.f), upd);
                         H[sc] = make_float2(a.x + bb.x, a.y + bb.y);
                     }
+                }
+                if (sta)
                     for (int k = tid; k < NP; k += NT) {
-                        const int sc = d.pilot_c[k];
+                        const int sc = pc[k];
                         const float2 a = c_mul(make_float2(1 - alpha, 0.f), H[sc]);
-                        const float2 bb = c_div(c_mul(make_float2(alpha, 0.f), Y[sc]), ref[k]);
+                        const float2 bb = c_div(c_mul(make_float2(alpha, 0.f), c_mul(Y[sc], rot)), ref[k]);
                         H[sc] = make_float2(a.x + bb.x, a.y + bb.y);
                     }
-                }
             } else if (S.packet_type == 2) {
                 const double nvar = S.noise_power_sum / S.snr_est_count;
+                const float alpha = 0.4f;                                               // STA :552-592
                 for (int i = tid; i < ND; i += NT) {                                    // :540-550
-                    const int sc = d.data_c[i];
+                    const int sc = dc[i];
+                    const float2 yr = c_mul(Y[sc], rot);
                     const float csi = (float)((double)c_mul(Hm[sc], c_conj(Hm[sc])).x + nvar);
-                    const float2 num = c_mul(Y[sc], c_conj(Hm[sc]));
-                    Z[i] = make_float2(num.x / csi, num.y / csi);
-                }
-                if (d.estimator == 1 && bps <= 2) {                                     // STA :552-592
-                    __syncthreads();
-                    const float alpha = 0.4f;
-                    for (int i = tid; i < ND; i += NT) {
-                        const int sc = d.data_c[i];
+                    const float2 num = c_mul(yr, c_conj(Hm[sc]));
+                    const float2 z = make_float2(num.x / csi, num.y / csi);
+                    o[i] = z;
+                    if (sta) {
                         const float2 a = c_mul(make_float2(1 - alpha, 0.f), Hm[sc]);
-                        const float2 bb = c_div(c_mul(make_float2(alpha, 0.f), Y[sc]), demod_point(bps, Z[i]));
+                        const float2 bb = c_div(c_mul(make_float2(alpha, 0.f), yr), demod_point(bps, z));
                         Hm[sc] = make_float2(a.x + bb.x, a.y + bb.y);
                     }
+                }
+                if (sta)
                     for (int k = tid; k < NP; k += NT) {
-                        const int sc = d.pilot_c[k];
+                        const int sc = pc[k];
                         const float2 a = c_mul(make_float2(1 - alpha, 0.f), Hm[sc]);
-                        const float2 bb = c_div(c_mul(make_float2(alpha, 0.f), Y[sc]), ref[k]);
+                        const float2 bb = c_div(c_mul(make_float2(alpha, 0.f), c_mul(Y[sc], rot)), ref[k]);
                         Hm[sc] = make_float2(a.x + bb.x, a.y + bb.y);
                     }
-                }
+            } else {
+                for (int i = tid; i < ND; i += NT) o[i] = Z[i];                         // unknown packet type: the reference emits stale Z
             }
-            __syncthreads();
-            for (int i = tid; i < ND; i += NT) out[(size_t)n_out * ND + i] = Z[i];      // :602
             n_out++;
         }
-        __syncthreads();
-        if (tid == 0) S.symbol_ind = sym + 1;
+        advance = 1;
         n_in++;
         __syncthreads();
     }
+    if (tid == 0 && advance) S.symbol_ind++;
+
 
     if (tid == 0) {
         S.total_out += n_out;
@@ -511,7 +553,12 @@ extern "C" int jrc_equalizer_create(jrc_ctx* ctx, const jrc_eq_cfg* c, int n_str
     d.pilot_sym = (const float2*)(tb + off_ps); d.ltf = (const float2*)(tb + off_ps + b_ps);
     d.mapped = (const float2*)(tb + off_ps + b_ps + b_ltf);
     eq->threads = N >= 1024 ? 1024 : ((N + 63) / 64) * 64;
-    eq->lds_bytes = sizeof(float2) * (size_t)(3 * N + ND + NP) + sizeof(unsigned long long) * (ND / 2 + 1) + ND + ND / 2 + 16;
+    {
+        size_t off = sizeof(float2) * (size_t)(3 * N + ND + NP) + sizeof(unsigned long long) * (ND / 2) + ND + ND / 2;
+        off = (off + 15) & ~size_t(15);
+        d.lds_tables = (int)off;
+        eq->lds_bytes = off + sizeof(int) * (size_t)(ND + NP + ac.size() + 1) + sizeof(float2) * (size_t)(N + NP) + 16;
+    }
     if (eq->lds_bytes > 64 * 1024)
         JRC_HIP(ctx, hipFuncSetAttribute((const void*)equalizer_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eq->lds_bytes));
     *out = eq;
