@@ -120,6 +120,7 @@ def load(build_if_missing=False):
         getattr(L, fn).argtypes = [_vp]
     L.jrc_chain_run_dev.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp]
     L.jrc_chain_fetch_results.argtypes = [_vp, C.c_int, _vp, C.POINTER(RaResult), _vp]
+    L.jrc_range_doppler_dev.argtypes = [_vp, C.POINTER(ChainCfg), C.c_int, C.c_int, _vp, _vp, _vp, _vp]
     L.jrc_chain_set_timing.argtypes = [_vp, C.c_int]
     L.jrc_chain_get_timing.argtypes = [_vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     _lib = L
@@ -434,6 +435,17 @@ class RadarChain:
         arr = (RaResult * n_frames)()
         self.ctx.check(self.ctx.lib.jrc_chain_fetch_results(self.h, n_frames, bufs["results"].data_ptr(), arr, stream))
         return list(arr)
+
+    def range_doppler(self, bufs, n_frames, interp_doppler=1, stream=None):
+        """row D: [n_frames, P, N*Ir, S*Id] complex range-Doppler map of the frames in bufs["frames"] (torch, on device)"""
+        import torch
+        c = self.cfg
+        dev = bufs["frames"].device
+        work = torch.empty((n_frames, self.P, c.N_sym, self.NR, 2), dtype=torch.float32, device=dev)
+        out = torch.empty((n_frames, self.P, self.NR, c.N_sym * interp_doppler, 2), dtype=torch.float32, device=dev)
+        self.ctx.check(self.ctx.lib.jrc_range_doppler_dev(self.ctx.h, C.byref(self.cfg), interp_doppler, n_frames,
+                                                         bufs["frames"].data_ptr(), work.data_ptr(), out.data_ptr(), stream))
+        return out
 
     def set_timing(self, on):
         self.ctx.check(self.ctx.lib.jrc_chain_set_timing(self.h, int(on)))

@@ -499,3 +499,55 @@ extern "C" int jrc_chain_fetch_results(jrc_chain* ch, int n_frames, const jrc_ra
     }
     return JRC_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Row D: range-Doppler map.  NO REFERENCE COUNTERPART — the reference collapses the symbol axis
+// (lib/mimo_ofdm_radar_impl.cc:271-274) and has no FFT over symbols; BASELINE.json lists the configuration, so this is
+// the build's own definition (oracle: numpy, tests/test_gpu_chain.py), parity unpinned by construction:
+//   D[p][sym][sc] = rx_r[sym][sc] * conj(tx_t[sym][sc])                      (the summand of A1, p = r*T+t)
+//   RD[p][k][d]   = fftshift_d FFT_{S*Id}( IFFT_{N*Ir}( D[p][.][.] zero-padded )[.][k] )   (unnormalised, like fft_vxx)
+// Built from the same kernels as the generic chain: product+pad, Stockham FFT over range, tiled transpose+pad,
+// Stockham FFT (+shift) over Doppler.
+__global__ void rd_product_pad_kernel(const float2* __restrict__ frames, float2* __restrict__ out, ChanestGeom g, int T, int R,
+                                      int NR, size_t total)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % NR);
+        size_t q = i / NR;
+        const int sym = (int)(q % g.S); q /= g.S;
+        const int p = (int)(q % (T * R));
+        const size_t f = q / (T * R);
+        float2 v = make_float2(0.f, 0.f);
+        if (k < g.N) {
+            const int r = g.interleave ? p % R : p / T, t = g.interleave ? p / R : p % T;
+            const float2* fb = frames + f * g.frame_stride;
+            const float2 a = fb[(size_t)(T + r) * g.port_stride + (size_t)(g.rx_item0 + sym) * g.N + k];
+            const float2 b = fb[(size_t)t * g.port_stride + (size_t)(g.tx_item0 + sym) * g.N + k];
+            v = make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+        }
+        out[i] = v;
+    }
+}
+
+extern "C" int jrc_range_doppler_dev(jrc_ctx* ctx, const jrc_chain_cfg* c, int interp_doppler, int n_frames,
+                                     const jrc_cf32* d_frames, jrc_cf32* d_work, jrc_cf32* d_out, void* stream)
+{
+    if (!ctx || !c || !d_frames || !d_work || !d_out || n_frames <= 0 || interp_doppler <= 0) return JRC_ERR_INVALID_ARG;
+    const int N = c->fft_len, T = c->N_tx, R = c->N_rx, P = T * R, S = c->N_sym;
+    const long NR = (long)N * c->interp_range, ND = (long)S * interp_doppler;
+    if (!jrc_is_pow2(NR) || !jrc_is_pow2(ND) || NR < 2 || ND < 2 || NR > 16384 || ND > 16384 || c->n_items < c->N_pre + S)
+        return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "range-Doppler needs power-of-two fft_len*interp_range and N_sym*interp_doppler (<= 16384)");
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    ChanestGeom g;
+    g.N = N; g.S = S; g.port_stride = (long)c->n_items * N; g.frame_stride = g.port_stride * (T + R);
+    g.tx_item0 = c->N_pre; g.rx_item0 = c->N_pre; g.interleave = c->enable_tx_interleave;
+    const size_t rows = (size_t)n_frames * P * S, total = rows * NR;
+    unsigned pb = (unsigned)((total + 255) / 256); if (pb > 16384) pb = 16384;
+    hipLaunchKernelGGL(rd_product_pad_kernel, dim3(pb), dim3(256), 0, s, (const float2*)d_frames, (float2*)d_work, g, T, R, (int)NR, total);
+    JRC_HIP(ctx, hipGetLastError());
+    JRC_TRY(launch_fft_vcc(ctx, (int)NR, 0, 0, nullptr, rows, (const float2*)d_work, (float2*)d_work, NR, 0, s));     // range
+    int tr = jrc_matrix_transpose_dev(ctx, (int)NR, S, interp_doppler, S, (size_t)n_frames * P, d_work, d_out, (void*)s);
+    if (tr < 0) return tr;
+    JRC_TRY(launch_fft_vcc(ctx, (int)ND, 1, 1, nullptr, (size_t)n_frames * P * NR, (const float2*)d_out, (float2*)d_out, ND, 0, s));   // Doppler
+    return JRC_OK;
+}

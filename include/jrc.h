@@ -184,6 +184,13 @@ int  jrc_chain_set_timing(jrc_chain* chain, int enabled);
  * ms[0]=radar_chanest, ms[1]=range_angle_fused, ms[2]=ra_finalize; *launches = runs measured */
 int  jrc_chain_get_timing(jrc_chain* chain, float ms[3], int* launches);
 
+/* ---- D  range-Doppler map — NO reference counterpart (the reference sums over symbols,
+ *          lib/mimo_ofdm_radar_impl.cc:271-274); defined by this build, parity unpinned by construction:
+ *   D[p][sym][sc] = rx_r[sym][sc]*conj(tx_t[sym][sc]);  out[f][p][k][d] = fftshift_d FFT_{S*Id}(IFFT_{N*Ir}(D zero-padded))
+ * d_work: n_frames*P*S*(N*Ir) cf32 scratch; d_out: [n_frames][P][N*Ir][S*Id] cf32.  cfg: the chain's (interp_angle unused). */
+int jrc_range_doppler_dev(jrc_ctx* ctx, const jrc_chain_cfg* cfg, int interp_doppler, int n_frames,
+                          const jrc_cf32* d_frames, jrc_cf32* d_work, jrc_cf32* d_out, void* stream);
+
 /* ---- C1  mimo_ofdm_equalizer (replaces mimo_ofdm_equalizer_impl::general_work and helpers,
  *          lib/mimo_ofdm_equalizer_impl.cc:191-922; ctor :66-180; setters :924-960) -------------------------
  * One jrc_equalizer holds `n_streams` independent per-RX-stream states (the reference block has one input

@@ -145,3 +145,33 @@ def test_chain_generic_and_fused_modes_agree(jrc, ctx, monkeypatch):
     for a, b in zip(r1, r2):
         assert (a.peak_range_idx, a.peak_angle_idx) == (b.peak_range_idx, b.peak_angle_idx)
         assert abs(a.snr_est - b.snr_est) < 1e-2
+
+
+@pytest.mark.parametrize("T,R,N,S,Ir,Id,vel", [(2, 2, 64, 16, 4, 4, 30.0), (4, 4, 256, 64, 2, 1, -20.0), (1, 1, 64, 64, 2, 2, 600.0)])
+def test_range_doppler_map_row_d(jrc, ctx, T, R, N, S, Ir, Id, vel):
+    """row D has no reference counterpart (the reference sums over symbols): checked against the numpy definition
+    fftshift(FFT_sym(IFFT_sc(rx*conj(tx), zero-padded))) and, for one TX, against the Doppler of the synthetic target"""
+    import torch
+    from jrc_amd import synth
+    sc = synth.Scenario(N, T, R, S, targets=[(10.0, 0.0, vel, 100.0)])
+    F, P = 2, T * R
+    frames = synth.make_frames(sc, F)
+    rb, ab = jrc.radar_axes(N, sc.fs, Ir, P, 2)
+    chain = jrc.RadarChain(N, T, R, S, sc.Npre, Ir, 2, rb, ab, 2.4, 30.0, max_frames=F, ctx=ctx)
+    bufs = chain.alloc(F, "cuda:0")
+    bufs["frames"].copy_(torch.from_numpy(frames.view(np.float32).reshape(bufs["frames"].shape)))
+    torch.cuda.synchronize()
+    rd = chain.range_doppler(bufs, F, Id)
+    ctx.sync()
+    got = rd.cpu().numpy().view(np.complex64)[..., 0]
+    tx = frames[:, :T, sc.Npre:].astype(np.complex128)
+    rx = frames[:, T:, sc.Npre:].astype(np.complex128)
+    D = np.einsum("frsn,ftsn->frtsn", rx, np.conj(tx)).reshape(F, P, S, N)
+    rng = np.fft.ifft(D, n=N * Ir, axis=-1) * (N * Ir)                                   # [F][P][S][NR]
+    ref = np.fft.fftshift(np.fft.fft(np.swapaxes(rng, -1, -2), n=S * Id, axis=-1), axes=-1)   # [F][P][NR][S*Id]
+    assert got.shape == ref.shape and rel_err(got, ref) < FFT_TOL
+    if T == 1:                                                          # one TX: rx*conj(tx) is a clean channel probe
+        k, d = np.unravel_index(np.argmax(np.abs(got[0, 0])), got[0, 0].shape)
+        bin_d = 2 * vel * sc.fc / 3e8 * (N + sc.cp) / sc.fs * S * Id    # Doppler shift in (interpolated) Doppler bins
+        assert abs((d - S * Id // 2) - bin_d) <= 1.5 and abs(bin_d) > 4
+        assert abs(rb[k] - 10.0) < 0.7
