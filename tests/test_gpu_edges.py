@@ -1,0 +1,85 @@
+"""GPU tier: empty, ragged and boundary inputs of the per-block entry points, checked against the oracle's behaviour."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import crandn, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def test_empty_and_sub_symbol_inputs(jrc, ctx):
+    rng = np.random.default_rng(0)
+    assert jrc.ofdm_cyclic_prefix_remover(64, 16, ctx=ctx).work(crandn(rng, 79)).shape == (0, 64)      # < one symbol
+    assert jrc.ofdm_cyclic_prefix_remover(64, 16, ctx=ctx).work(np.zeros(0, np.complex64)).shape == (0, 64)
+    assert jrc.fft_vcc(64, True, ctx=ctx).work(np.zeros((0, 64), np.complex64)).shape == (0, 64)          # batch 0
+    assert jrc.ofdm_mod(np.zeros((0, 64), np.complex64), 64, 16, ctx=ctx).shape == (0, 80)
+    t = jrc.matrix_transpose(8, 4, 2, ctx=ctx).work(np.zeros((0, 8), np.complex64))                        # empty packet
+    assert t.shape == (8, 8) and not t.any()
+    k, f, p, m = jrc.fft_peak_detect(1000, 1.0, -50.0, 10, ctx=ctx).work(crandn(rng, 20))                  # all samples protected
+    assert k == -1 and np.isnan(f)
+    k, f, p, m = jrc.fft_peak_detect(1000, 1.0, -50.0, 0, ctx=ctx).work(np.zeros(0, np.complex64))
+    assert k == -1
+
+
+def test_radar_zero_symbols_and_single_subcarrier(jrc, ctx):
+    rng = np.random.default_rng(1)
+    tx = [crandn(rng, 3, 8) for _ in range(2)]
+    rx = [crandn(rng, 3, 8) for _ in range(1)]
+    out = jrc.mimo_ofdm_radar(8, 2, 1, 0, 3, interp_factor=2, ctx=ctx).general_work(tx, rx)               # N_sym = 0: all zero rows
+    assert out.shape == (2, 16) and not out.any()
+    tx = [crandn(rng, 4, 1)]
+    rx = [crandn(rng, 4, 1)]
+    got = jrc.mimo_ofdm_radar(1, 1, 1, 3, 1, ctx=ctx).general_work(tx, rx)
+    assert np.array_equal(got, oracle.Radar(1, 1, 1, 3, 1).work(tx, rx))
+
+
+def test_estimator_partial_packet_and_tiny_maps(jrc, ctx):
+    """ninput_items may be smaller than the bin axis (short packet): n_inputs, not len(range_bins), wraps the noise window"""
+    rng = np.random.default_rng(2)
+    rb, ab = jrc.radar_axes(64, 125e6, 8, 8, 16)
+    m = crandn(rng, 300, 128, scale=0.05)
+    m[250, 31] = 4.0
+    est = jrc.range_angle_estimator(128, rb, ab, 2.4, 28.96, 15.0, 0.0, ctx=ctx)
+    g, o = est.work(m), oracle.ra_estimate(m, rb, ab, 2.4, 28.96, 15.0, 0.0)
+    for k in ("peak_range_idx", "peak_angle_idx", "angle_null_idx", "n_noise_samples", "published"):
+        assert getattr(g, k) == getattr(o, k)
+    assert g.noise_power == o.noise_power and g.snr_est == o.snr_est
+    rb2, ab2 = np.linspace(0, 10, 4).astype(np.float32), np.linspace(-60, 60, 4).astype(np.float32)
+    m2 = crandn(rng, 4, 4)
+    g = jrc.range_angle_estimator(4, rb2, ab2, 5.0, 50.0, 0.0, 0.0, ctx=ctx).work(m2)
+    o = oracle.ra_estimate(m2, rb2, ab2, 5.0, 50.0, 0.0, 0.0)
+    assert (g.peak_range_idx, g.peak_angle_idx, g.n_noise_samples) == (o.peak_range_idx, o.peak_angle_idx, o.n_noise_samples)
+    assert g.noise_power == o.noise_power
+    with pytest.raises(ValueError):
+        jrc.range_angle_estimator(128, rb[:100], ab, 2.4, 28.96, 15.0, 0.0, ctx=ctx).work(m)                  # more rows than range bins
+
+
+def test_equalizer_and_precoder_degenerate_calls(jrc, ctx, ofdm64):
+    o = ofdm64
+    eq = jrc.mimo_ofdm_equalizer(0, 24e9, 125e6, 64, 16, o["data_subcarriers"], o["pilot_subcarriers"], o["pilot_symbols"],
+                                 o["ltf_64"], o["ltf_mapped_sc__ss_sym"], 4, ctx=ctx)
+    r = eq.general_work(np.zeros((0, 64), np.complex64))
+    assert r["consumed"] == 0 and len(r["out"]) == 0 and r["events"] == []
+    r = eq.general_work(np.ones((3, 64), np.complex64), [(0, 0.0)], noutput_items=0)
+    assert r["consumed"] == 0 and len(r["out"]) == 0
+    pre = jrc.mimo_precoder(64, 4, 1, o["data_subcarriers"], o["pilot_subcarriers"], o["pilot_symbols"], o["l_stf_ltf_64"],
+                            o["ltf_mapped_sc__ss_sym"], ctx=ctx)
+    with pytest.raises(ValueError, match="packet type"):
+        pre.work(np.zeros(48, np.complex64), 0, 7, 0)
+    with pytest.raises(ValueError):
+        jrc.mimo_precoder(64, 4, 1, [], o["pilot_subcarriers"], o["pilot_symbols"], o["l_stf_ltf_64"], o["ltf_mapped_sc__ss_sym"], ctx=ctx)
+    with pytest.raises(ValueError, match="Estimator"):
+        jrc.mimo_ofdm_equalizer(5, 24e9, 125e6, 64, 16, o["data_subcarriers"], o["pilot_subcarriers"], o["pilot_symbols"],
+                                o["ltf_64"], o["ltf_mapped_sc__ss_sym"], 4, ctx=ctx)
+
+
+def test_largest_supported_transform_and_map(jrc, ctx):
+    rng = np.random.default_rng(3)
+    x = crandn(rng, 1, 16384)
+    assert rel_err(jrc.fft_vcc(16384, False, None, True, ctx=ctx).work(x), oracle.fft_vcc(x, False, True)) < 2e-6
+    m = crandn(rng, 8192, 256, scale=0.01)                                   # config-D sized map, peak in the last cell
+    m[8191, 255] = 1.0
+    rb, ab = jrc.radar_axes(1024, 125e6, 8, 16, 16)
+    g = jrc.range_angle_estimator(256, rb, ab, 2.4, 14.36, 15.0, 0.0, ctx=ctx).work(m)
+    assert (g.peak_range_idx, g.peak_angle_idx) == (8191, 255)
