@@ -100,6 +100,7 @@ def load(build_if_missing=False):
     L.jrc_radar_set_background_record.argtypes = [_vp, C.c_int]
     L.jrc_radar_ring_size.argtypes = [_vp]
     L.jrc_radar_work.argtypes = [_vp, C.POINTER(_vp), C.POINTER(_vp), C.c_size_t, C.c_size_t, C.c_size_t, _vp]
+    L.jrc_radar_chanest_dev.argtypes = [_vp] + [C.c_int] * 8 + [_vp, _vp, _vp]
     L.jrc_fft_vcc.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, _vp, _vp]
     L.jrc_fft_vcc_dev.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, _vp, _vp, _vp]
     L.jrc_matrix_transpose.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]

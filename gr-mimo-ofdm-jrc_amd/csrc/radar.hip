@@ -8,6 +8,8 @@
 // the reference's scalar loop.
 #include "radar_kernels.h"
 
+#include <cstdlib>
+
 // ------------------------------------------------------------------------------------------------
 // One lane per (subcarrier, RX antenna): T accumulators in registers, symbols consumed in batches of U
 // so that U*(T+1) independent 8-byte loads are in flight per lane before the first dependent use.  The R
@@ -68,6 +70,60 @@ __global__ __launch_bounds__(256) void radar_chanest_kernel(const float2* __rest
     }
 }
 
+// Same arithmetic, two adjacent subcarriers per lane (16-byte loads): half the load instructions per byte.
+template <int T, int U>
+__global__ __launch_bounds__(256) void radar_chanest_x2_kernel(const float2* __restrict__ frames,
+                                                               float2* __restrict__ H, ChanestGeom g, int R)
+{
+#pragma clang fp contract(off)
+    const int sc = (blockIdx.x * 64 + threadIdx.x) * 2;
+    const int r = threadIdx.y;
+    const int f = blockIdx.y;
+    if (sc >= g.N) return;
+    const float2* fb = frames + (size_t)f * g.frame_stride;
+    const float4* rxp = reinterpret_cast<const float4*>(fb + (size_t)(T + r) * g.port_stride + (size_t)g.rx_item0 * g.N + sc);
+    const float2* txb = fb + (size_t)g.tx_item0 * g.N + sc;
+    const size_t row4 = (size_t)g.N / 2;      // float4 per symbol row
+
+    float4 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; t++) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    auto mac = [&](float4& a, const float4 rx, const float4 tx) {
+        // rx * conj(tx) = (ac + bd) + j(bc - ad) for both subcarriers, products rounded individually (:273)
+        const float pr0 = rx.x * tx.x + rx.y * tx.y, pi0 = rx.y * tx.x - rx.x * tx.y;
+        const float pr1 = rx.z * tx.z + rx.w * tx.w, pi1 = rx.w * tx.z - rx.z * tx.w;
+        a.x = a.x + pr0; a.y = a.y + pi0; a.z = a.z + pr1; a.w = a.w + pi1;
+    };
+    int sym = 0;
+    for (; sym + U <= g.S; sym += U) {
+        float4 rx[U], tx[U][T];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            rx[u] = rxp[(size_t)(sym + u) * row4];
+#pragma unroll
+            for (int t = 0; t < T; t++)
+                tx[u][t] = *reinterpret_cast<const float4*>(txb + (size_t)t * g.port_stride + (size_t)(sym + u) * g.N);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int t = 0; t < T; t++) mac(acc[t], rx[u], tx[u][t]);
+    }
+    for (; sym < g.S; sym++) {
+        const float4 rx = rxp[(size_t)sym * row4];
+#pragma unroll
+        for (int t = 0; t < T; t++)
+            mac(acc[t], rx, *reinterpret_cast<const float4*>(txb + (size_t)t * g.port_stride + (size_t)sym * g.N));
+    }
+    float2* Hf = H + (size_t)f * T * R * g.N;
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+        const int p = g.interleave ? (t * R + r) : (r * T + t);   // :262-269
+        *reinterpret_cast<float4*>(Hf + (size_t)p * g.N + sc) = acc[t];
+    }
+}
+
 // any T, R: one lane per (pair, subcarrier)
 __global__ __launch_bounds__(256) void radar_chanest_generic_kernel(const float2* __restrict__ frames,
                                                                     float2* __restrict__ H, ChanestGeom g,
@@ -98,6 +154,16 @@ int launch_radar_chanest(jrc_ctx* ctx, int T, int R, const float2* d_frames, flo
                          const ChanestGeom& g, int n_frames, hipStream_t stream)
 {
     if (n_frames <= 0 || g.N <= 0) return JRC_OK;
+    const bool aligned16 = (g.N % 2 == 0) && (g.port_stride % 2 == 0) && (g.frame_stride % 2 == 0) &&
+                           ((reinterpret_cast<size_t>(d_frames) | reinterpret_cast<size_t>(d_H)) & 15) == 0;
+    if (R <= 4 && (T == 1 || T == 2 || T == 4) && aligned16 && g.N >= 128 && !getenv("JRC_CHANEST_X1")) {
+        dim3 grid((g.N / 2 + 63) / 64, n_frames, 1), block(64, R, 1);
+        if (T == 1) hipLaunchKernelGGL((radar_chanest_x2_kernel<1, 8>), grid, block, 0, stream, d_frames, d_H, g, R);
+        else if (T == 2) hipLaunchKernelGGL((radar_chanest_x2_kernel<2, 4>), grid, block, 0, stream, d_frames, d_H, g, R);
+        else hipLaunchKernelGGL((radar_chanest_x2_kernel<4, 4>), grid, block, 0, stream, d_frames, d_H, g, R);
+        JRC_HIP(ctx, hipGetLastError());
+        return JRC_OK;
+    }
     if (R <= 4 && (T == 1 || T == 2 || T == 4)) {
         dim3 grid((g.N + 63) / 64, n_frames, 1), block(64, R, 1);
         if (T == 1) hipLaunchKernelGGL((radar_chanest_kernel<1, 8>), grid, block, 0, stream, d_frames, d_H, g, R);
@@ -252,4 +318,19 @@ extern "C" int jrc_radar_work(jrc_radar* r, const jrc_cf32* const* tx, const jrc
     for (int p = 0; p < P; p++)
         memcpy((float2*)out + (size_t)p * N * r->Ir, h_est + (size_t)p * N, sizeof(float2) * N);
     return P;
+}
+
+// batched, device-resident A1 alone (the first stage of jrc_chain_run_dev), for callers that keep their own pipeline
+extern "C" int jrc_radar_chanest_dev(jrc_ctx* ctx, int fft_len, int N_tx, int N_rx, int N_sym, int N_pre, int n_items,
+                                     int enable_tx_interleave, int n_frames, const jrc_cf32* d_frames, jrc_cf32* d_chanest,
+                                     void* stream)
+{
+    if (!ctx || !d_frames || !d_chanest) return JRC_ERR_INVALID_ARG;
+    if (fft_len <= 0 || N_tx <= 0 || N_rx <= 0 || N_sym < 0 || N_pre < 0 || n_items < N_pre + N_sym || n_frames < 0)
+        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_radar_chanest_dev: inconsistent sizes");
+    ChanestGeom g;
+    g.N = fft_len; g.S = N_sym; g.port_stride = (long)n_items * fft_len; g.frame_stride = g.port_stride * (N_tx + N_rx);
+    g.tx_item0 = N_pre; g.rx_item0 = N_pre; g.interleave = enable_tx_interleave;
+    return launch_radar_chanest(ctx, N_tx, N_rx, (const float2*)d_frames, (float2*)d_chanest, g, n_frames,
+                                stream ? (hipStream_t)stream : ctx->stream);
 }

@@ -80,6 +80,11 @@ int  jrc_radar_ring_size(const jrc_radar* radar);
 int  jrc_radar_work(jrc_radar* radar, const jrc_cf32* const* tx, const jrc_cf32* const* rx,
                     size_t n_items_tx, size_t n_items_rx, size_t tx_discard, jrc_cf32* out);
 
+/* batched, device-resident A1: d_frames [n_frames][T+R][n_items][fft_len] -> d_chanest [n_frames][P][fft_len] (no padding) */
+int  jrc_radar_chanest_dev(jrc_ctx* ctx, int fft_len, int N_tx, int N_rx, int N_sym, int N_pre, int n_items,
+                           int enable_tx_interleave, int n_frames, const jrc_cf32* d_frames, jrc_cf32* d_chanest,
+                           void* stream);
+
 /* ---- A2/A4/A7  stock gr::fft::fft_vcc (FFTW3f in GNU Radio 3.8; flowgraph wiring
  *          examples/simulation/radar/mimo_ofdm_jrc_radar_sim.grc:877-1047) -------------------------
  * forward: out = [fftshift] FFT(in .* window); reverse: out = unnormalised IFFT([ifftshift](in .* window)).
