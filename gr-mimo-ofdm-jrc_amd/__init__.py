@@ -677,3 +677,111 @@ class mimo_precoder:
             self.close()
         except Exception:
             pass
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# target_simulator on the device
+class TsimCfg(C.Structure):
+    _fields_ = [("n_targets", C.c_int), ("range", _cfp), ("velocity", _cfp), ("rcs", _cfp), ("azimuth", _cfp),
+                ("n_rx", C.c_int), ("position_rx", _cfp), ("samp_rate", C.c_int), ("center_freq", C.c_float),
+                ("self_coupling_db", C.c_float), ("rndm_phaseshift", C.c_int), ("self_coupling", C.c_int),
+                ("sum_targets", C.c_int), ("max_bursts", C.c_int)]
+
+
+def _load_tsim():
+    L = load()
+    if not getattr(L, "_tsim_ready", False):
+        L.jrc_tsim_create.restype = _vp
+        L.jrc_tsim_create.argtypes = [_vp, C.POINTER(TsimCfg)]
+        L.jrc_tsim_destroy.argtypes = [_vp]
+        L.jrc_tsim_destroy.restype = None
+        L.jrc_tsim_set_targets.argtypes = [_vp, C.c_int, _cfp, _cfp, _cfp, _cfp]
+        L.jrc_tsim_work.argtypes = [_vp, _vp, C.c_int, C.POINTER(_vp), _vp]
+        L.jrc_tsim_run_dev.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _vp]
+        L.jrc_tsim_burst_capacity.argtypes = [_vp]
+        L._tsim_ready = True
+    return L
+
+
+def _f32(v):
+    return np.ascontiguousarray(np.atleast_1d(v), dtype=np.float32)
+
+
+class target_simulator:
+    """include/mimo_ofdm_jrc/target_simulator.h make(range, velocity, rcs, azimuth, position_rx, samp_rate, center_freq,
+    self_coupling_db, rndm_phaseshift, self_coupling, len_key, debug); work = lib/target_simulator_impl.cc:202-385.
+    One input stream, len(position_rx) output streams.  `sum_targets` (not in the reference) accumulates the targets
+    instead of letting the last one overwrite the others; `max_bursts` sizes the batched device form run_dev()."""
+
+    def __init__(self, range, velocity, rcs, azimuth, position_rx, samp_rate, center_freq, self_coupling_db=-40.0,
+                 rndm_phaseshift=False, self_coupling=False, len_key="packet_len", debug=False, sum_targets=False,
+                 max_bursts=1, seed=None, ctx=None):
+        self.ctx = ctx or default_context()
+        L = _load_tsim()
+        self._keep = [_f32(v) for v in (range, velocity, rcs, azimuth, position_rx)]
+        r, v, s, a, p = self._keep
+        if not (r.size == v.size == s.size == a.size):
+            raise ValueError("[TARGET SIM] range, velocity, rcs and azimuth must have the same length")
+        self.K, self.R = int(r.size), int(p.size)
+        self.samp_rate = int(samp_rate)
+        self.rndm_phaseshift = bool(rndm_phaseshift)
+        cfg = TsimCfg(self.K, r.ctypes.data_as(_cfp), v.ctypes.data_as(_cfp), s.ctypes.data_as(_cfp), a.ctypes.data_as(_cfp),
+                      self.R, p.ctypes.data_as(_cfp), self.samp_rate, float(center_freq), float(self_coupling_db),
+                      int(self.rndm_phaseshift), int(bool(self_coupling)), int(bool(sum_targets)), int(max_bursts))
+        self.h = L.jrc_tsim_create(self.ctx.h, C.byref(cfg))
+        if not self.h:
+            raise ValueError(self.ctx.lib.jrc_last_error(self.ctx.h).decode())
+        self._rng = np.random.default_rng(seed)        # the reference seeds std::rand with time(NULL) (:196)
+        self.nitems_written = 0
+
+    def setup_targets(self, range, velocity, rcs, azimuth):
+        k = [_f32(v) for v in (range, velocity, rcs, azimuth)]
+        self.ctx.check(self.ctx.lib.jrc_tsim_set_targets(self.h, int(k[0].size), *[x.ctypes.data_as(_cfp) for x in k]))
+        self._keep[:4] = k
+        self.K = int(k[0].size)
+
+    def calculate_output_stream_length(self, ninput_items):
+        return ninput_items
+
+    def draw_phases(self):
+        """:316-321 — exp(j 2 pi ((rand() % 1000 + 1) / 1000)) per target"""
+        u = (self._rng.integers(0, 1000, self.K) + 1) / 1000.0
+        ang = (2 * np.pi * u.astype(np.float32)).astype(np.float32)
+        return (np.cos(ang) + 1j * np.sin(ang)).astype(np.complex64)
+
+    def rx_time_tag(self):
+        """(:331-335) value of the rx_time tag of the burst about to be produced: (uint64 secs, double frac)"""
+        secs = self.nitems_written // self.samp_rate
+        frac = float(np.float32(self.nitems_written) / np.float32(self.samp_rate)) - secs
+        return int(secs), frac
+
+    def work(self, x, target_phase=None):
+        x = _c64(x).ravel()
+        n = x.size
+        out = np.zeros((self.R, n), np.complex64)
+        if n == 0:
+            return out
+        if self.rndm_phaseshift and target_phase is None:
+            target_phase = self.draw_phases()
+        tp = None if target_phase is None else _c64(target_phase)
+        ptrs = (_vp * self.R)(*[_ptr(out[l]) for l in range(self.R)])
+        st = self.ctx.check(self.ctx.lib.jrc_tsim_work(self.h, _ptr(x), n, ptrs, None if tp is None else _ptr(tp)))
+        self.nitems_written += n
+        return out
+
+    def run_dev(self, d_in, d_out, n_bursts, n_input, target_phase=None, accumulate_out=False, stream=None):
+        """d_in: torch complex64 [n_bursts][n_input]; d_out: [n_bursts][n_rx][n_input] (device tensors)"""
+        tp = None if target_phase is None else _c64(target_phase)
+        self.ctx.check(self.ctx.lib.jrc_tsim_run_dev(self.h, n_bursts, n_input, _vp(d_in.data_ptr()), _vp(d_out.data_ptr()),
+                                                     None if tp is None else _ptr(tp), int(accumulate_out), stream))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.jrc_tsim_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -23,54 +23,12 @@
 //   fftshift is a rotation of u.  The transpose + zero padding of matrix_transpose never touches
 //   memory.
 #include "radar_kernels.h"
+#include "fft_device.h"
 
 #include <cmath>
 #include <cstdlib>
 
 #define RA_L 64   // range bins (and fold length) per workgroup
-
-// ---- tiny in-register forward FFT, P in {1,2,4,8,16}, natural order in / out --------------------
-template <int P, int K>
-struct TwMul {   // multiply by w_P^K = exp(-j 2 pi K / P)
-    static __device__ __forceinline__ float2 mul(float2 v)
-    {
-        constexpr int idx = K * (16 / P);   // sixteenths of a turn, 0..7
-        constexpr float R2 = 0.70710678118654752440f;
-        constexpr float C1 = 0.92387953251128675613f, S1 = 0.38268343236508977173f;
-        if constexpr (idx == 0) return v;
-        else if constexpr (idx == 4) return make_float2(v.y, -v.x);
-        else if constexpr (idx == 2) return make_float2((v.x + v.y) * R2, (v.y - v.x) * R2);
-        else if constexpr (idx == 6) return make_float2((v.y - v.x) * R2, -(v.x + v.y) * R2);
-        else if constexpr (idx == 1) return make_float2(v.x * C1 + v.y * S1, v.y * C1 - v.x * S1);
-        else if constexpr (idx == 3) return make_float2(v.x * S1 + v.y * C1, v.y * S1 - v.x * C1);
-        else if constexpr (idx == 5) return make_float2(v.y * C1 - v.x * S1, -(v.x * C1 + v.y * S1));
-        else return make_float2(v.y * S1 - v.x * C1, -(v.x * S1 + v.y * C1));   // idx == 7
-    }
-};
-
-template <int P, int K>
-struct Bfly {
-    static __device__ __forceinline__ void run(float2* x, const float2* e, const float2* o)
-    {
-        float2 t = TwMul<P, K>::mul(o[K]);
-        x[K] = cadd(e[K], t);
-        x[K + P / 2] = csub(e[K], t);
-        if constexpr (K + 1 < P / 2) Bfly<P, K + 1>::run(x, e, o);
-    }
-};
-
-template <int P>
-__device__ __forceinline__ void fft_fwd_small(float2 (&x)[P])
-{
-    if constexpr (P > 1) {
-        float2 e[P / 2], o[P / 2];
-#pragma unroll
-        for (int k = 0; k < P / 2; k++) { e[k] = x[2 * k]; o[k] = x[2 * k + 1]; }
-        fft_fwd_small<P / 2>(e);
-        fft_fwd_small<P / 2>(o);
-        Bfly<P, 0>::run(x, e, o);
-    }
-}
 
 // ---- the fused kernel ------------------------------------------------------------------------
 // Grid: one workgroup per (frame, slice); a slice owns the residue classes c = slice + WPF*i, i < C/WPF.

@@ -9,6 +9,7 @@
 // transform per workgroup or several small ones packed into one).  The roofline-critical 2-D
 // range-angle transform does NOT go through this kernel; it is the fused kernel in chain.hip.
 #include "radar_kernels.h"
+#include "fft_device.h"
 
 // ------------------------------------------------------------------------------------------------
 // in-place radix-2 decimation-in-frequency in LDS; input natural order, result bit-reversed in LDS,
@@ -72,47 +73,6 @@ __global__ __launch_bounds__(256) void fft_pow2_kernel(const float2* __restrict_
 // Stockham autosort FFT, radix 4 (one leading radix-2 pass when log2 n is odd): natural order in and out, so no
 // bit-reversal gather; the first pass reads global memory directly and the last pass writes it directly, with
 // coalesced 512-byte wave accesses on both sides.  n <= 8192 (two LDS buffers of n points).
-template <int R>
-__device__ __forceinline__ void stockham_pass(const float2* __restrict__ src_g, long src_wrap /* n if ifftshift else 0 */,
-                                              const float* __restrict__ window, const float2* src_l, float2* dst_l,
-                                              float2* __restrict__ dst_g, int dst_rot /* n/2 if fftshift else 0 */,
-                                              const float2* __restrict__ tw, int n, int Ns, int sign, int lt, int tp)
-{
-    const int nb = n / R;
-    for (int j = lt; j < nb; j += tp) {
-        const int k = j & (Ns - 1);
-        float2 v[R];
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            const int idx = j + r * nb;
-            if (src_g) {
-                const int si = src_wrap ? ((idx + (n >> 1)) & (n - 1)) : idx;          // ifftshift on the way in
-                v[r] = src_g[si];
-                if (window) { const float w = window[si]; v[r].x *= w; v[r].y *= w; }
-            } else {
-                v[r] = src_l[idx];
-            }
-            if (r && k) v[r] = cmul(v[r], tw[(k * r * (n / (Ns * R))) & (n - 1)]);
-        }
-        if (R == 2) {
-            const float2 a = v[0], b = v[1];
-            v[0] = cadd(a, b); v[1] = csub(a, b);
-        } else {
-            const float2 a = cadd(v[0], v[2]), b = csub(v[0], v[2]), c = cadd(v[1], v[3]), d = csub(v[1], v[3]);
-            // forward: X1 = b - j d, X3 = b + j d ; inverse: X1 = b + j d, X3 = b - j d
-            const float2 jd = sign < 0 ? make_float2(d.y, -d.x) : make_float2(-d.y, d.x);
-            v[0] = cadd(a, c); v[2] = csub(a, c); v[1] = cadd(b, jd); v[3] = csub(b, jd);
-        }
-        const int j0 = ((j - k) * R) + k;
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            const int o = j0 + r * Ns;
-            if (dst_g) dst_g[dst_rot ? ((o + dst_rot) & (n - 1)) : o] = v[r];          // fftshift on the way out
-            else dst_l[o] = v[r];
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void fft_stockham_kernel(const float2* __restrict__ in, float2* __restrict__ out,
                                                            const float2* __restrict__ tw, const float* __restrict__ window,
                                                            int n, int logn, int forward, int shift, size_t batch,

@@ -1,0 +1,91 @@
+// fft_device.h — device-side FFT building blocks shared by fft.hip (fft_vcc), chain.hip (fused range-angle kernel)
+// and tsim.hip (target simulator): an in-register power-of-two FFT up to 16 points and one Stockham radix-2/4 pass.
+#pragma once
+
+#include "jrc_internal.h"
+
+// ---- tiny in-register forward FFT, P in {1,2,4,8,16}, natural order in / out --------------------
+template <int P, int K>
+struct TwMul {   // multiply by w_P^K = exp(-j 2 pi K / P)
+    static __device__ __forceinline__ float2 mul(float2 v)
+    {
+        constexpr int idx = K * (16 / P);   // sixteenths of a turn, 0..7
+        constexpr float R2 = 0.70710678118654752440f;
+        constexpr float C1 = 0.92387953251128675613f, S1 = 0.38268343236508977173f;
+        if constexpr (idx == 0) return v;
+        else if constexpr (idx == 4) return make_float2(v.y, -v.x);
+        else if constexpr (idx == 2) return make_float2((v.x + v.y) * R2, (v.y - v.x) * R2);
+        else if constexpr (idx == 6) return make_float2((v.y - v.x) * R2, -(v.x + v.y) * R2);
+        else if constexpr (idx == 1) return make_float2(v.x * C1 + v.y * S1, v.y * C1 - v.x * S1);
+        else if constexpr (idx == 3) return make_float2(v.x * S1 + v.y * C1, v.y * S1 - v.x * C1);
+        else if constexpr (idx == 5) return make_float2(v.y * C1 - v.x * S1, -(v.x * C1 + v.y * S1));
+        else return make_float2(v.y * S1 - v.x * C1, -(v.x * S1 + v.y * C1));   // idx == 7
+    }
+};
+
+template <int P, int K>
+struct Bfly {
+    static __device__ __forceinline__ void run(float2* x, const float2* e, const float2* o)
+    {
+        float2 t = TwMul<P, K>::mul(o[K]);
+        x[K] = cadd(e[K], t);
+        x[K + P / 2] = csub(e[K], t);
+        if constexpr (K + 1 < P / 2) Bfly<P, K + 1>::run(x, e, o);
+    }
+};
+
+template <int P>
+__device__ __forceinline__ void fft_fwd_small(float2 (&x)[P])
+{
+    if constexpr (P > 1) {
+        float2 e[P / 2], o[P / 2];
+#pragma unroll
+        for (int k = 0; k < P / 2; k++) { e[k] = x[2 * k]; o[k] = x[2 * k + 1]; }
+        fft_fwd_small<P / 2>(e);
+        fft_fwd_small<P / 2>(o);
+        Bfly<P, 0>::run(x, e, o);
+    }
+}
+
+// ---- one Stockham autosort pass (radix R in {2,4}) over n points; sources / destinations may be global or LDS ----
+template <int R>
+__device__ __forceinline__ void stockham_pass(const float2* __restrict__ src_g, long src_wrap /* n if ifftshift else 0 */,
+                                              const float* __restrict__ window, const float2* src_l, float2* dst_l,
+                                              float2* __restrict__ dst_g, int dst_rot /* n/2 if fftshift else 0 */,
+                                              const float2* __restrict__ tw, int n, int Ns, int sign, int lt, int tp)
+{
+    const int nb = n / R;
+    for (int j = lt; j < nb; j += tp) {
+        const int k = j & (Ns - 1);
+        float2 v[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int idx = j + r * nb;
+            if (src_g) {
+                const int si = src_wrap ? ((idx + (n >> 1)) & (n - 1)) : idx;          // ifftshift on the way in
+                v[r] = src_g[si];
+                if (window) { const float w = window[si]; v[r].x *= w; v[r].y *= w; }
+            } else {
+                v[r] = src_l[idx];
+            }
+            if (r && k) v[r] = cmul(v[r], tw[(k * r * (n / (Ns * R))) & (n - 1)]);
+        }
+        if (R == 2) {
+            const float2 a = v[0], b = v[1];
+            v[0] = cadd(a, b); v[1] = csub(a, b);
+        } else {
+            const float2 a = cadd(v[0], v[2]), b = csub(v[0], v[2]), c = cadd(v[1], v[3]), d = csub(v[1], v[3]);
+            // forward: X1 = b - j d, X3 = b + j d ; inverse: X1 = b + j d, X3 = b - j d
+            const float2 jd = sign < 0 ? make_float2(d.y, -d.x) : make_float2(-d.y, d.x);
+            v[0] = cadd(a, c); v[2] = csub(a, c); v[1] = cadd(b, jd); v[3] = csub(b, jd);
+        }
+        const int j0 = ((j - k) * R) + k;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int o = j0 + r * Ns;
+            if (dst_g) dst_g[dst_rot ? ((o + dst_rot) & (n - 1)) : o] = v[r];          // fftshift on the way out
+            else dst_l[o] = v[r];
+        }
+    }
+}
+

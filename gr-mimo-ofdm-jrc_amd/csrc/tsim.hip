@@ -1,0 +1,554 @@
+// tsim.hip — target_simulator on the device (reference lib/target_simulator_impl.cc:132-385).
+//
+// Per burst of n samples (n is arbitrary: (preamble + symbols + 3 pad symbols) x (fft_len + cp), e.g. 22080) and per
+// target k the reference computes, for every RX antenna l,
+//      out_l = IFFT_n( FFT_n( in . doppler_k ) . timeshift_{l,k} ) [. phase_k]   (+ self coupling)
+// with two FFTW3f transforms of length n per (l, k).  Here:
+//   * FFT_n( in . doppler_k ) does not depend on l and is computed once per target;
+//   * the length-n DFTs are chirp-z (Bluestein) transforms over a power-of-two M >= 2n-1:
+//         X[k] = c[k] . sum_i (x[i] c[i]) conj(c)[k-i],   c[i] = exp(-j pi i^2 / n)
+//     and because the inverse DFT uses conj(c), the chirp factors between the two transforms cancel
+//     (X[i] ts[i] conj(c)[i] = conv[i] ts[i]):  the whole block is two circular convolutions of length M;
+//   * every length-M FFT is a four-step transform M = 256 x n2: a column pass (256-point FFT over a stride-n2 column,
+//     16 columns per workgroup so each row access is a 128-byte segment, FFT in registers as 16 x 16 with one LDS
+//     exchange) and a row pass (n2-point Stockham FFT in LDS).  The forward transform leaves its output in
+//     [k1][k2] (digit-swapped) order; the pointwise product with the chirp spectrum and the inverse row FFT happen
+//     on the same row in the same workgroup, and the inverse column pass restores natural order — no transposes;
+//   * the inverse column pass of the first convolution, the product with timeshift_{l,k} and the forward column pass
+//     of the second convolution for all R antennas are one kernel (the data is already distributed as the next
+//     transform needs it).
+// The channel filters themselves (doppler_k, timeshift_{l,k}) are the reference's float/double recurrences,
+// evaluated on the host once per burst length like the reference does (:249-300) and kept in HBM.
+#include "fft_device.h"
+
+#include <cmath>
+#include <complex>
+#include <vector>
+
+#define TS_N1 256      // column-pass FFT length
+#define TS_CW 16       // columns per workgroup (16 x 8 B = 128-byte row segments)
+#define TS_XPAD 272    // LDS stride between q planes of the 16x16 exchange (256 + 16: see fft256_cols)
+
+struct jrc_tsim {
+    jrc_ctx* ctx = nullptr;
+    int K = 0, R = 0;
+    std::vector<float> range, velocity, rcs, azimuth, position_rx;
+    int samp_rate = 0;
+    float center_freq = 0.f, self_coupling_db = 0.f;
+    int rndm_phaseshift = 0, self_coupling = 0, sum_targets = 0;
+    int max_bursts = 1;
+    std::vector<float> doppler, scale_ampl, timeshift;     // [K], [K], [R][K]
+    // per burst length
+    int n = 0, M = 0, n2 = 0;
+    float2* d_dop = nullptr;      // [K][n]
+    float2* d_ts = nullptr;       // [R][K][n]
+    float2* d_chirp = nullptr;    // [n]   c[i] = exp(-j pi i^2 / n)
+    float2* d_bhat = nullptr;     // [256][n2] FFT_M(conj(c) wrapped) / M in [k1][k2] order
+    float2* d_u = nullptr;        // [max_bursts][M]
+    float2* d_g = nullptr;        // [max_bursts][R][M]
+    float2* d_phase = nullptr;    // [K]
+    size_t u_cap = 0, g_cap = 0;
+};
+
+// ---- 256-point forward FFT over 16 columns, in registers ---------------------------------------
+// thread (c = tid & 15, s = tid >> 4) enters with x[j] = element (s + 16 j) of column c and leaves with
+// x[r] = element (q + 16 r), q = s:  X[q + 16 r] = sum_s w16^{s r} [ w256^{s q} sum_j x[s + 16 j] w16^{j q} ].
+// xch: 16 * TS_XPAD float2 of LDS; plane q at q*TS_XPAD, then [s][c] with c fastest, so the 64 lanes of a wave write
+// 512 contiguous bytes and read four 128-byte runs whose banks pair up without conflict.
+__device__ __forceinline__ void fft256_cols(float2 (&x)[16], float2* xch, const float2* tw256 /* LDS, exp(-j2pi k/256) */)
+{
+    const int c = threadIdx.x & 15, s = threadIdx.x >> 4;
+    fft_fwd_small<16>(x);
+#pragma unroll
+    for (int q = 1; q < 16; q++) x[q] = cmul(x[q], tw256[s * q]);
+    __syncthreads();                                   // previous user of xch is done
+#pragma unroll
+    for (int q = 0; q < 16; q++) xch[q * TS_XPAD + s * 16 + c] = x[q];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = xch[s * TS_XPAD + j * 16 + c];   // my q = s: A[s' = j][q]
+    fft_fwd_small<16>(x);
+}
+__device__ __forceinline__ void swap_reim(float2 (&x)[16])
+{
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = make_float2(x[j].y, x[j].x);
+}
+// inverse (unnormalised) via IFFT(x) = swap(FFT(swap(x)))
+__device__ __forceinline__ void ifft256_cols(float2 (&x)[16], float2* xch, const float2* tw256)
+{
+    swap_reim(x); fft256_cols(x, xch, tw256); swap_reim(x);
+}
+
+// outer four-step twiddles w_M^{i2 * k1}, k1 = s + 16 j:  w^{i2 s} . (w^{16 i2})^j, the second factor shared by the
+// 16 threads of a column through LDS (one sincospi per thread for each factor; arguments are exact dyadic fractions)
+__device__ __forceinline__ float2 unit_pow(long num, int M /* pow2 */)
+{
+    const int m = (int)(num & (long)(M - 1));
+    float sn, cs;
+    sincospif(-2.0f * (float)m / (float)M, &sn, &cs);
+    return make_float2(cs, sn);                         // exp(-j 2 pi m / M)
+}
+__device__ __forceinline__ void outer_twiddle_setup(float2* twc /* LDS [16][16] */, float2& t1, int col0, int M)
+{
+    const int c = threadIdx.x & 15, s = threadIdx.x >> 4;
+    const long i2 = col0 + c;
+    twc[s * 16 + c] = unit_pow(16L * i2 * s, M);        // (w^{16 i2})^s, [power][column]
+    t1 = unit_pow(i2 * s, M);
+}
+__device__ __forceinline__ float2 conjf2(float2 a) { return make_float2(a.x, -a.y); }
+
+__device__ __forceinline__ void load_tw256(float2* tw256, const float2* __restrict__ tw256_g)
+{
+    tw256[threadIdx.x] = tw256_g[threadIdx.x];
+}
+
+// ---- kernel A: x = in . doppler_k . c  (zero padded to M)  ->  column FFT  ->  outer twiddle  ->  U[k1][i2] ---------
+// PLAIN (table setup): x = in (already padded, length M)
+template <bool PLAIN>
+__global__ __launch_bounds__(256) void tsim_col_first_kernel(const float2* __restrict__ in, long in_stride,
+                                                             const float2* __restrict__ dop, const float2* __restrict__ chirp,
+                                                             float2* __restrict__ U, const float2* __restrict__ tw256_g,
+                                                             int n, int n2, int M)
+{
+    __shared__ float2 xch[16 * TS_XPAD];
+    __shared__ float2 tw256[256];
+    __shared__ float2 twc[256];
+    const int c = threadIdx.x & 15, s = threadIdx.x >> 4;
+    const int col0 = blockIdx.x * TS_CW;
+    const size_t b = blockIdx.y;
+    const float2* src = in + b * (size_t)in_stride;
+    float2 t1;
+    load_tw256(tw256, tw256_g);
+    outer_twiddle_setup(twc, t1, col0, M);
+    float2 x[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const long i = (long)(s + 16 * j) * n2 + col0 + c;
+        if (PLAIN) {
+            x[j] = src[i];
+        } else if (i < n) {
+            const float2 v = cmul(src[i], dop[i]);       // volk_32fc_x2_multiply_32fc (:345)
+            x[j] = cmul(v, chirp[i]);
+        } else {
+            x[j] = make_float2(0.f, 0.f);
+        }
+    }
+    __syncthreads();                                      // tw256 / twc visible
+    fft256_cols(x, xch, tw256);
+    float2* dst = U + b * (size_t)M;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const float2 w = cmul(t1, twc[r * 16 + c]);       // w_M^{i2 (s + 16 r)}
+        dst[(size_t)(s + 16 * r) * n2 + col0 + c] = cmul(x[r], w);
+    }
+}
+
+// ---- row kernel: row FFT (n2) -> . Bhat[k1][.] (or conj) -> inverse row FFT, in place -------------------------------
+// FWD_ONLY (table setup): row FFT only.
+template <bool FWD_ONLY>
+__global__ __launch_bounds__(256) void tsim_rowconv_kernel(float2* __restrict__ X, const float2* __restrict__ bhat, int conj_b,
+                                                           const float2* __restrict__ tw_f, const float2* __restrict__ tw_i,
+                                                           int n2, int logn2, size_t rows, int tp)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    const int per_block = blockDim.x / tp;
+    const int lt = threadIdx.x % tp, lb = threadIdx.x / tp;
+    const size_t row = (size_t)blockIdx.x * per_block + lb;
+    const bool live = row < rows;
+    float2* buf0 = lds + (size_t)lb * 2 * n2;
+    float2* buf1 = buf0 + n2;
+    float2* g = X + row * (size_t)n2;
+    const int k1 = (int)(row & (TS_N1 - 1));
+    const float2* brow = bhat ? bhat + (size_t)k1 * n2 : nullptr;
+
+    const float2* cur = nullptr;
+    float2* nxt = buf0;
+    for (int dir = 0; dir < (FWD_ONLY ? 1 : 2); dir++) {
+        const float2* tw = dir ? tw_i : tw_f;
+        const int sign = dir ? 1 : -1;
+        int Ns = 1;
+        bool first = true;
+        while (Ns < n2) {
+            const int Rx = ((logn2 & 1) && first) ? 2 : 4;
+            const bool last = Ns * Rx == n2;
+            const bool from_g = (dir == 0 && first);
+            const bool to_g = last && (FWD_ONLY || dir == 1);
+            if (live) {
+                if (Rx == 2) stockham_pass<2>(from_g ? g : nullptr, 0, nullptr, cur, to_g ? nullptr : nxt, to_g ? g : nullptr, 0, tw, n2, Ns, sign, lt, tp);
+                else stockham_pass<4>(from_g ? g : nullptr, 0, nullptr, cur, to_g ? nullptr : nxt, to_g ? g : nullptr, 0, tw, n2, Ns, sign, lt, tp);
+            }
+            __syncthreads();
+            cur = nxt; nxt = (nxt == buf0) ? buf1 : buf0;
+            Ns *= Rx; first = false;
+        }
+        if (!FWD_ONLY && dir == 0) {
+            if (live) {
+                float2* w = const_cast<float2*>(cur);
+                for (int k2 = lt; k2 < n2; k2 += tp) {
+                    float2 bv = brow[k2];
+                    if (conj_b) bv.y = -bv.y;
+                    w[k2] = cmul(w[k2], bv);
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---- kernel MID: Z -> conj outer twiddle -> inverse column FFT = conv (natural order) -> for each antenna l:
+//      g = conv . timeshift_{l,k} (zero beyond n) -> column FFT -> outer twiddle -> G[l][k1][i2] ---------------------
+__global__ __launch_bounds__(256) void tsim_col_mid_kernel(const float2* __restrict__ Z, float2* __restrict__ G,
+                                                           const float2* __restrict__ ts /* [R][K][n] + k*n */, long ts_l_stride,
+                                                           const float2* __restrict__ tw256_g, int R, int n, int n2, int M)
+{
+    __shared__ float2 xch[16 * TS_XPAD];
+    __shared__ float2 tw256[256];
+    __shared__ float2 twc[256];
+    const int c = threadIdx.x & 15, s = threadIdx.x >> 4;
+    const int col0 = blockIdx.x * TS_CW;
+    const size_t b = blockIdx.y;
+    const float2* src = Z + b * (size_t)M;
+    float2 t1;
+    load_tw256(tw256, tw256_g);
+    outer_twiddle_setup(twc, t1, col0, M);
+    float2 x[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = src[(size_t)(s + 16 * j) * n2 + col0 + c];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = cmul(x[j], conjf2(cmul(t1, twc[j * 16 + c])));
+    ifft256_cols(x, xch, tw256);                          // x[r] = conv[(s + 16 r) n2 + i2]
+    for (int l = 0; l < R; l++) {
+        const float2* tsl = ts + (size_t)l * ts_l_stride;
+        float2 y[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const long i = (long)(s + 16 * r) * n2 + col0 + c;
+            y[r] = (i < n) ? cmul(x[r], tsl[i]) : make_float2(0.f, 0.f);     // :352
+        }
+        fft256_cols(y, xch, tw256);
+        float2* dst = G + (b * R + l) * (size_t)M;
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            dst[(size_t)(s + 16 * r) * n2 + col0 + c] = cmul(y[r], cmul(t1, twc[r * 16 + c]));
+    }
+}
+
+// ---- kernel OUT: Y_l -> conj outer twiddle -> inverse column FFT -> . conj(c)[m] [. phase_k] -> out_l[m]
+//      (= or +=), plus the self-coupling term sc . in[m] (:372-378) when asked ---------------------------------------
+__global__ __launch_bounds__(256) void tsim_col_out_kernel(const float2* __restrict__ Y, float2* __restrict__ out,
+                                                           long out_burst_stride, long out_rx_stride,
+                                                           const float2* __restrict__ chirp, const float2* __restrict__ phase_k,
+                                                           const float2* __restrict__ in, long in_stride, float self_coupling,
+                                                           int add_self, int accumulate,
+                                                           const float2* __restrict__ tw256_g, int R, int n, int n2, int M)
+{
+    __shared__ float2 xch[16 * TS_XPAD];
+    __shared__ float2 tw256[256];
+    __shared__ float2 twc[256];
+    const int c = threadIdx.x & 15, s = threadIdx.x >> 4;
+    const int col0 = blockIdx.x * TS_CW;
+    const size_t bl = blockIdx.y;                         // burst * R + l
+    const size_t b = bl / R, l = bl % R;
+    const float2* src = Y + bl * (size_t)M;
+    float2 t1;
+    load_tw256(tw256, tw256_g);
+    outer_twiddle_setup(twc, t1, col0, M);
+    float2 x[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = src[(size_t)(s + 16 * j) * n2 + col0 + c];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = cmul(x[j], conjf2(cmul(t1, twc[j * 16 + c])));
+    ifft256_cols(x, xch, tw256);
+    float2* o = out + b * (size_t)out_burst_stride + l * (size_t)out_rx_stride;
+    const float2* inb = in + b * (size_t)in_stride;
+    const bool has_phase = phase_k != nullptr;
+    const float2 ph = has_phase ? *phase_k : make_float2(1.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const long m = (long)(s + 16 * r) * n2 + col0 + c;
+        if (m < n) {
+            float2 v = cmul(x[r], conjf2(chirp[m]));
+            if (has_phase) v = cmul(v, ph);               // :358-362
+            if (accumulate) v = cadd(o[m], v);
+            if (add_self) {                               // out += (gr_complex)pow(10, db/20) * in  (:376)
+                const float2 xi = inb[m];
+                v = cadd(v, make_float2(self_coupling * xi.x - 0.0f * xi.y, self_coupling * xi.y + 0.0f * xi.x));
+            }
+            o[m] = v;
+        }
+    }
+}
+
+// no targets at all: out = [out +] sc . in
+__global__ void tsim_passthrough_kernel(float2* __restrict__ out, long out_burst_stride, long out_rx_stride,
+                                        const float2* __restrict__ in, long in_stride, float self_coupling, int add_self,
+                                        int accumulate, int R, int n)
+{
+    const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n) return;
+    const size_t b = blockIdx.y / R, l = blockIdx.y % R;
+    float2* o = out + b * (size_t)out_burst_stride + l * (size_t)out_rx_stride;
+    float2 v = accumulate ? o[m] : make_float2(0.f, 0.f);
+    if (add_self) { const float2 xi = in[b * (size_t)in_stride + m]; v = cadd(v, make_float2(self_coupling * xi.x, self_coupling * xi.y)); }
+    o[m] = v;
+}
+
+// ---- host side -------------------------------------------------------------------------------
+static const double TS_FOUR_PI_CUBED_SQRT = 44.54662397465366;   // :33
+static const float TS_C_LIGHT = 3e8f;                           // target_simulator_impl.h c_light
+
+static void tsim_setup_targets(jrc_tsim* h)                     // :132-198
+{
+    const int K = h->K, R = h->R;
+    h->doppler.resize(K); h->scale_ampl.resize(K); h->timeshift.resize((size_t)K * R);
+    for (int k = 0; k < K; k++) h->doppler[k] = 2 * h->velocity[k] * h->center_freq / TS_C_LIGHT;
+    for (int l = 0; l < R; l++)
+        for (int k = 0; k < K; k++)
+            h->timeshift[(size_t)l * K + k] = (2.0 * h->range[k] - h->position_rx[l] * std::sin(h->azimuth[k] * M_PI / 180.0)) / TS_C_LIGHT;
+    for (int k = 0; k < K; k++)
+        h->scale_ampl[k] = TS_C_LIGHT * std::sqrt(h->rcs[k]) / TS_FOUR_PI_CUBED_SQRT / (h->range[k] * h->range[k]) / h->center_freq;
+}
+
+static int tsim_rows_launch(jrc_tsim* h, bool fwd_only, float2* X, int conj_b, size_t rows, hipStream_t stream)
+{
+    jrc_ctx* ctx = h->ctx;
+    const int n2 = h->n2;
+    const float2 *twf = nullptr, *twi = nullptr;
+    JRC_TRY(jrc_get_twiddles(ctx, n2, -1, &twf));
+    JRC_TRY(jrc_get_twiddles(ctx, n2, +1, &twi));
+    int tp = n2 / 4; if (tp > 256) tp = 256;
+    const int per_block = 256 / tp;
+    const size_t blocks = (rows + per_block - 1) / per_block;
+    const size_t lds_bytes = sizeof(float2) * 2 * (size_t)n2 * per_block;
+    static size_t attr_a = 64 * 1024, attr_b = 64 * 1024;
+    if (fwd_only) {
+        if (lds_bytes > attr_a) {
+            JRC_HIP(ctx, hipFuncSetAttribute((const void*)tsim_rowconv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            attr_a = lds_bytes;
+        }
+        hipLaunchKernelGGL(tsim_rowconv_kernel<true>, dim3((unsigned)blocks), dim3(256), lds_bytes, stream, X,
+                           (const float2*)nullptr, 0, twf, twi, n2, jrc_ilog2(n2), rows, tp);
+    } else {
+        if (lds_bytes > attr_b) {
+            JRC_HIP(ctx, hipFuncSetAttribute((const void*)tsim_rowconv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            attr_b = lds_bytes;
+        }
+        hipLaunchKernelGGL(tsim_rowconv_kernel<false>, dim3((unsigned)blocks), dim3(256), lds_bytes, stream, X,
+                           (const float2*)h->d_bhat, conj_b, twf, twi, n2, jrc_ilog2(n2), rows, tp);
+    }
+    JRC_HIP(ctx, hipGetLastError());
+    return JRC_OK;
+}
+
+static void tsim_free_tables(jrc_tsim* h)
+{
+    (void)hipFree(h->d_dop); (void)hipFree(h->d_ts); (void)hipFree(h->d_chirp); (void)hipFree(h->d_bhat);
+    h->d_dop = h->d_ts = h->d_chirp = h->d_bhat = nullptr;
+    h->n = 0;
+}
+
+// channel filters and chirp tables for bursts of n samples (:249-300 + the Bluestein tables)
+static int tsim_prepare(jrc_tsim* h, int n, hipStream_t stream)
+{
+    jrc_ctx* ctx = h->ctx;
+    if (h->n == n) return JRC_OK;
+    if (n > (1 << 20))
+        return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "target_simulator: burst of %d samples exceeds 2^20", n);
+    JRC_HIP(ctx, hipStreamSynchronize(stream));
+    tsim_free_tables(h);
+    const int K = h->K, R = h->R;
+    long M = 32768;
+    while (M < 2L * n - 1) M <<= 1;
+    const int n2 = (int)(M / TS_N1);
+    // work buffers
+    const size_t need_u = sizeof(float2) * (size_t)h->max_bursts * M, need_g = need_u * (size_t)(R > 0 ? R : 1);
+    if (need_u > h->u_cap) { (void)hipFree(h->d_u); h->d_u = nullptr; h->u_cap = 0; JRC_HIP(ctx, hipMalloc((void**)&h->d_u, need_u)); h->u_cap = need_u; }
+    if (need_g > h->g_cap) { (void)hipFree(h->d_g); h->d_g = nullptr; h->g_cap = 0; JRC_HIP(ctx, hipMalloc((void**)&h->d_g, need_g)); h->g_cap = need_g; }
+
+    std::vector<float> freq((size_t)n);
+    for (int i = 0; i < n; i++) {                      // :262-268, float arithmetic
+        if (i < n / 2) freq[i] = i * (float)h->samp_rate / (float)n;
+        else freq[i] = i * (float)h->samp_rate / (float)n - (float)h->samp_rate;
+    }
+    std::vector<std::complex<float>> dop((size_t)K * n), ts((size_t)R * K * n);
+    for (int k = 0; k < K; k++) {
+        std::complex<float> phase_doppler = 0;         // :281
+        for (int i = 0; i < n; i++) {                  // :282-287
+            dop[(size_t)k * n + i] = std::exp(phase_doppler) * h->scale_ampl[k];
+            phase_doppler = std::complex<float>(0, std::fmod(std::imag(phase_doppler) + 2 * M_PI * h->doppler[k] / (float)h->samp_rate, 2 * M_PI));
+        }
+        for (int l = 0; l < R; l++) {                  // :291-305
+            std::complex<float>* t = &ts[((size_t)l * K + k) * n];
+            for (int i = 0; i < n; i++) {
+                std::complex<float> phase_time(0, std::fmod(2 * M_PI * (h->timeshift[(size_t)l * K + k]) * (freq[i] + h->center_freq), 2 * M_PI));
+                t[i] = std::exp(-phase_time) / (float)n;
+            }
+        }
+    }
+    // chirp c[i] = exp(-j pi i^2 / n) with i^2 reduced mod 2n in integers; b = conj(c) wrapped to length M, / M
+    std::vector<float2> chirp((size_t)n), bpad((size_t)M, make_float2(0.f, 0.f));
+    for (long i = 0; i < n; i++) {
+        const long q = (i * i) % (2L * n);
+        const double a = M_PI * (double)q / (double)n;
+        chirp[i] = make_float2((float)std::cos(a), (float)(-std::sin(a)));
+        const float2 bv = make_float2((float)(std::cos(a) / (double)M), (float)(std::sin(a) / (double)M));
+        bpad[i] = bv;
+        if (i) bpad[M - i] = bv;
+    }
+    if (K > 0) {
+        JRC_HIP(ctx, hipMalloc((void**)&h->d_dop, sizeof(float2) * (size_t)K * n));
+        JRC_HIP(ctx, hipMalloc((void**)&h->d_ts, sizeof(float2) * (size_t)R * K * n));
+        JRC_HIP(ctx, hipMemcpy(h->d_dop, dop.data(), sizeof(float2) * (size_t)K * n, hipMemcpyHostToDevice));
+        JRC_HIP(ctx, hipMemcpy(h->d_ts, ts.data(), sizeof(float2) * (size_t)R * K * n, hipMemcpyHostToDevice));
+    }
+    JRC_HIP(ctx, hipMalloc((void**)&h->d_chirp, sizeof(float2) * (size_t)n));
+    JRC_HIP(ctx, hipMemcpy(h->d_chirp, chirp.data(), sizeof(float2) * (size_t)n, hipMemcpyHostToDevice));
+    JRC_HIP(ctx, hipMalloc((void**)&h->d_bhat, sizeof(float2) * (size_t)M));
+    float2* d_tmp = nullptr;
+    JRC_HIP(ctx, hipMalloc((void**)&d_tmp, sizeof(float2) * (size_t)M));
+    JRC_HIP(ctx, hipMemcpy(d_tmp, bpad.data(), sizeof(float2) * (size_t)M, hipMemcpyHostToDevice));
+    h->n = n; h->M = (int)M; h->n2 = n2;
+    const float2* tw256 = nullptr;
+    int st = jrc_get_twiddles(ctx, TS_N1, -1, &tw256);
+    if (st == JRC_OK) {
+        hipLaunchKernelGGL(tsim_col_first_kernel<true>, dim3(n2 / TS_CW, 1), dim3(256), 0, stream, (const float2*)d_tmp, (long)M,
+                           (const float2*)nullptr, (const float2*)nullptr, h->d_bhat, tw256, n, n2, (int)M);
+        st = tsim_rows_launch(h, true, h->d_bhat, 0, TS_N1, stream);
+    }
+    hipError_t e = hipStreamSynchronize(stream);
+    (void)hipFree(d_tmp);
+    if (st != JRC_OK) { h->n = 0; return st; }
+    if (e != hipSuccess) { h->n = 0; return jrc_fail(ctx, JRC_ERR_HIP, "target_simulator table setup: %s", hipGetErrorString(e)); }
+    return JRC_OK;
+}
+
+extern "C" jrc_tsim* jrc_tsim_create(jrc_ctx* ctx, const jrc_tsim_cfg* cfg)
+{
+    if (!ctx) return nullptr;
+    if (!cfg || cfg->n_targets < 0 || cfg->n_rx < 1 || cfg->samp_rate <= 0 || cfg->max_bursts < 1 ||
+        (cfg->n_targets > 0 && (!cfg->range || !cfg->velocity || !cfg->rcs || !cfg->azimuth)) || !cfg->position_rx) {
+        jrc_fail(ctx, JRC_ERR_INVALID_ARG, "target_simulator: invalid configuration");
+        return nullptr;
+    }
+    if (hipSetDevice(ctx->device) != hipSuccess) { jrc_fail(ctx, JRC_ERR_HIP, "hipSetDevice failed"); return nullptr; }
+    jrc_tsim* h = new jrc_tsim();
+    h->ctx = ctx;
+    h->K = cfg->n_targets; h->R = cfg->n_rx;
+    h->range.assign(cfg->range, cfg->range + h->K); h->velocity.assign(cfg->velocity, cfg->velocity + h->K);
+    h->rcs.assign(cfg->rcs, cfg->rcs + h->K); h->azimuth.assign(cfg->azimuth, cfg->azimuth + h->K);
+    h->position_rx.assign(cfg->position_rx, cfg->position_rx + h->R);
+    h->samp_rate = cfg->samp_rate; h->center_freq = cfg->center_freq; h->self_coupling_db = cfg->self_coupling_db;
+    h->rndm_phaseshift = cfg->rndm_phaseshift; h->self_coupling = cfg->self_coupling; h->sum_targets = cfg->sum_targets;
+    h->max_bursts = cfg->max_bursts;
+    tsim_setup_targets(h);
+    if (hipMalloc((void**)&h->d_phase, sizeof(float2) * (size_t)(h->K > 0 ? h->K : 1)) != hipSuccess) {
+        jrc_fail(ctx, JRC_ERR_NOMEM, "target_simulator: hipMalloc failed");
+        delete h;
+        return nullptr;
+    }
+    return h;
+}
+
+extern "C" void jrc_tsim_destroy(jrc_tsim* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->ctx->device);
+    (void)hipStreamSynchronize(h->ctx->stream);
+    tsim_free_tables(h);
+    (void)hipFree(h->d_u); (void)hipFree(h->d_g); (void)hipFree(h->d_phase);
+    delete h;
+}
+
+extern "C" int jrc_tsim_run_dev(jrc_tsim* h, int n_bursts, int n_input, const jrc_cf32* d_in, jrc_cf32* d_out,
+                                const jrc_cf32* target_phase, int accumulate_out, void* stream)
+{
+    if (!h) return JRC_ERR_INVALID_ARG;
+    jrc_ctx* ctx = h->ctx;
+    if (n_bursts < 0 || n_input < 0 || (n_bursts > 0 && n_input > 0 && (!d_in || !d_out)))
+        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "target_simulator: invalid arguments");
+    if (n_bursts > h->max_bursts)
+        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "target_simulator: %d bursts exceed max_bursts %d", n_bursts, h->max_bursts);
+    if (n_bursts == 0 || n_input == 0) return JRC_OK;
+    JRC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    const int n = n_input, K = h->K, R = h->R;
+    const float2* in = (const float2*)d_in;
+    float2* out = (float2*)d_out;
+    const float sc = (float)std::pow(10, h->self_coupling_db / 20.0);         // :376
+    if (K == 0) {
+        hipLaunchKernelGGL(tsim_passthrough_kernel, dim3((n + 255) / 256, n_bursts * R), dim3(256), 0, s, out, (long)R * n, (long)n,
+                           in, (long)n, sc, h->self_coupling, accumulate_out, R, n);
+        JRC_HIP(ctx, hipGetLastError());
+        return JRC_OK;
+    }
+    JRC_TRY(tsim_prepare(h, n, s));
+    const bool use_phase = h->rndm_phaseshift && target_phase;
+    if (use_phase) JRC_HIP(ctx, hipMemcpyAsync(h->d_phase, target_phase, sizeof(float2) * (size_t)K, hipMemcpyHostToDevice, s));
+    const float2* tw256 = nullptr;
+    JRC_TRY(jrc_get_twiddles(ctx, TS_N1, -1, &tw256));
+    const int M = h->M, n2 = h->n2;
+    const dim3 colgrid(n2 / TS_CW, n_bursts), colgrid_out(n2 / TS_CW, n_bursts * R);
+    // as written in the reference every target overwrites the output buffer (:354-366), so only the last one is
+    // observable; sum_targets accumulates them instead
+    const int k_first = h->sum_targets ? 0 : K - 1;
+    for (int k = k_first; k < K; k++) {
+        hipLaunchKernelGGL(tsim_col_first_kernel<false>, colgrid, dim3(256), 0, s, in, (long)n, (const float2*)h->d_dop + (size_t)k * n,
+                           (const float2*)h->d_chirp, h->d_u, tw256, n, n2, M);
+        JRC_HIP(ctx, hipGetLastError());
+        JRC_TRY(tsim_rows_launch(h, false, h->d_u, 0, (size_t)n_bursts * TS_N1, s));
+        hipLaunchKernelGGL(tsim_col_mid_kernel, colgrid, dim3(256), 0, s, (const float2*)h->d_u, h->d_g,
+                           (const float2*)h->d_ts + (size_t)k * n, (long)K * n, tw256, R, n, n2, M);
+        JRC_HIP(ctx, hipGetLastError());
+        JRC_TRY(tsim_rows_launch(h, false, h->d_g, 1, (size_t)n_bursts * R * TS_N1, s));
+        const int last = k == K - 1;
+        hipLaunchKernelGGL(tsim_col_out_kernel, colgrid_out, dim3(256), 0, s, (const float2*)h->d_g, out, (long)R * n, (long)n,
+                           (const float2*)h->d_chirp, use_phase ? (const float2*)h->d_phase + k : (const float2*)nullptr,
+                           in, (long)n, sc, (last && h->self_coupling) ? 1 : 0, (accumulate_out || k > k_first) ? 1 : 0,
+                           tw256, R, n, n2, M);
+        JRC_HIP(ctx, hipGetLastError());
+    }
+    return JRC_OK;
+}
+
+extern "C" int jrc_tsim_work(jrc_tsim* h, const jrc_cf32* in, int n_input, jrc_cf32* const* out, const jrc_cf32* target_phase)
+{
+    if (!h) return JRC_ERR_INVALID_ARG;
+    jrc_ctx* ctx = h->ctx;
+    if (n_input < 0 || (n_input > 0 && (!in || !out))) return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "target_simulator: null buffers");
+    if (n_input == 0) return 0;
+    JRC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = sizeof(float2) * (size_t)n_input, obytes = bytes * (size_t)h->R;
+    JRC_TRY(jrc_ensure_pinned(ctx, bytes + obytes));
+    JRC_TRY(jrc_ensure_scratch(ctx, 0, bytes));
+    JRC_TRY(jrc_ensure_scratch(ctx, 1, obytes));
+    memcpy(ctx->pinned, in, bytes);
+    JRC_HIP(ctx, hipMemcpyAsync(ctx->scratch[0], ctx->pinned, bytes, hipMemcpyHostToDevice, ctx->stream));
+    JRC_TRY(jrc_tsim_run_dev(h, 1, n_input, (const jrc_cf32*)ctx->scratch[0], (jrc_cf32*)ctx->scratch[1], target_phase, 0, ctx->stream));
+    JRC_HIP(ctx, hipMemcpyAsync((char*)ctx->pinned + bytes, ctx->scratch[1], obytes, hipMemcpyDeviceToHost, ctx->stream));
+    JRC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int l = 0; l < h->R; l++) memcpy(out[l], (char*)ctx->pinned + bytes + (size_t)l * bytes, bytes);
+    return n_input;
+}
+
+extern "C" int jrc_tsim_set_targets(jrc_tsim* h, int n_targets, const float* range, const float* velocity, const float* rcs,
+                                    const float* azimuth)
+{
+    if (!h) return JRC_ERR_INVALID_ARG;
+    if (n_targets < 0 || (n_targets > 0 && (!range || !velocity || !rcs || !azimuth)))
+        return jrc_fail(h->ctx, JRC_ERR_INVALID_ARG, "target_simulator: invalid targets");
+    JRC_HIP(h->ctx, hipSetDevice(h->ctx->device));
+    JRC_HIP(h->ctx, hipStreamSynchronize(h->ctx->stream));
+    h->K = n_targets;
+    h->range.assign(range, range + n_targets); h->velocity.assign(velocity, velocity + n_targets);
+    h->rcs.assign(rcs, rcs + n_targets); h->azimuth.assign(azimuth, azimuth + n_targets);
+    tsim_setup_targets(h);
+    tsim_free_tables(h);                                  // d_new_channel = true (:150)
+    (void)hipFree(h->d_phase); h->d_phase = nullptr;
+    JRC_HIP(h->ctx, hipMalloc((void**)&h->d_phase, sizeof(float2) * (size_t)(n_targets > 0 ? n_targets : 1)));
+    return JRC_OK;
+}
+
+extern "C" int jrc_tsim_burst_capacity(const jrc_tsim* h) { return h ? h->max_bursts : 0; }

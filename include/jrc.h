@@ -286,6 +286,45 @@ int  jrc_precoder_work(jrc_precoder* pre, int ninput_items, const jrc_cf32* in, 
 int  jrc_n_ofdm_sym(int mcs, int n_data_carriers, int data_size_byte);
 int  jrc_sig_encode(int n_data_carriers, int mcs, int packet_type, int length, float* out_re);
 
+/* ---- target_simulator (lib/target_simulator_impl.cc:66-385; make() in
+ * include/mimo_ofdm_jrc/target_simulator.h) — one input stream (a TX burst), n_rx output streams.  Per target k and
+ * antenna l: out_l = IFFT_n(FFT_n(in . doppler_k) . timeshift_{l,k}) [. phase_k], + 10^(self_coupling_db/20) . in
+ * when self_coupling.  n = burst length, any value up to 2^20 (chirp-z transforms on the device). ---- */
+typedef struct jrc_tsim jrc_tsim;
+typedef struct {
+    int n_targets;                 /* range.size() (:160) */
+    const float* range;            /* [n_targets] m */
+    const float* velocity;         /* [n_targets] m/s */
+    const float* rcs;              /* [n_targets] m^2 */
+    const float* azimuth;          /* [n_targets] deg */
+    int n_rx;                      /* position_rx.size() = number of output streams */
+    const float* position_rx;      /* [n_rx] m */
+    int samp_rate;                 /* Hz */
+    float center_freq;             /* Hz */
+    float self_coupling_db;
+    int rndm_phaseshift;           /* when set, jrc_tsim_work/run_dev apply the caller-drawn target_phase[k] (:316-321) */
+    int self_coupling;
+    int sum_targets;               /* 0 = as written in the reference: every target overwrites the output (:354-366), the
+                                      last one is what leaves the block; 1 = targets are accumulated */
+    int max_bursts;                /* capacity of jrc_tsim_run_dev (device work buffers are sized for it) */
+} jrc_tsim_cfg;
+/* returns NULL on error (jrc_last_error(ctx)) — the reference constructor throws */
+jrc_tsim* jrc_tsim_create(jrc_ctx* ctx, const jrc_tsim_cfg* cfg);
+void jrc_tsim_destroy(jrc_tsim* h);
+/* setup_targets() (:121-198): new target list, channel filters are rebuilt on the next burst */
+int jrc_tsim_set_targets(jrc_tsim* h, int n_targets, const float* range, const float* velocity, const float* rcs,
+                         const float* azimuth);
+/* target_simulator_impl::work (:202-385) on host buffers: one tagged burst in[n_input] -> out[l][n_input], l < n_rx.
+ * target_phase: n_targets complex multipliers exp(j 2 pi rand) drawn by the caller (used only when rndm_phaseshift;
+ * may be NULL).  Returns n_input (items produced per output) or a negative status. */
+int jrc_tsim_work(jrc_tsim* h, const jrc_cf32* in, int n_input, jrc_cf32* const* out, const jrc_cf32* target_phase);
+/* batched device form: d_in [n_bursts][n_input], d_out [n_bursts][n_rx][n_input]; accumulate_out != 0 adds to d_out
+ * instead of overwriting it (absorbs the blocks_add_xx that sums the per-TX simulators,
+ * examples/simulation/radar/mimo_ofdm_jrc_radar_sim.grc:2213-2220).  Asynchronous on `stream` (NULL = ctx stream). */
+int jrc_tsim_run_dev(jrc_tsim* h, int n_bursts, int n_input, const jrc_cf32* d_in, jrc_cf32* d_out,
+                     const jrc_cf32* target_phase, int accumulate_out, void* stream);
+int jrc_tsim_burst_capacity(const jrc_tsim* h);
+
 #ifdef __cplusplus
 }
 #endif

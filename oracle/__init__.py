@@ -33,7 +33,7 @@ class RaResult(C.Structure):
 
 def build(force=False):
     """Compile oracle/jrc_oracle*.c with gcc (the checker, not the product)."""
-    srcs = [os.path.join(_HERE, f) for f in ("jrc_oracle.c", "jrc_oracle_comm.c", "jrc_oracle.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("jrc_oracle.c", "jrc_oracle_comm.c", "jrc_oracle_tsim.c", "jrc_oracle.h", "Makefile")]
     if (not force and os.path.exists(_LIB_PATH)
             and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
         return _LIB_PATH
@@ -354,3 +354,66 @@ class Precoder:
             raise RuntimeError("[MIMO PRECODER] something is wrong!!")
         assert r == n_total
         return out
+
+
+def _farr(v):
+    return np.ascontiguousarray(np.atleast_1d(v), dtype=np.float32)
+
+
+def dft_any(x, forward=True):
+    """gr::fft::fft_complex of any length restated (unnormalised; double inside, rounded once to float)"""
+    L = lib()
+    L.orc_dft_any.argtypes = [C.c_int, C.c_int, c_float_p, c_float_p]
+    x = _c64(x)
+    out = np.empty_like(x)
+    L.orc_dft_any(x.size, 1 if forward else 0, _fp(x), _fp(out))
+    return out
+
+
+class TargetSimulator:
+    """target_simulator_impl (lib/target_simulator_impl.cc:66-385) restated: 1 input stream, len(position_rx) outputs."""
+
+    def __init__(self, range_m, velocity, rcs, azimuth, position_rx, samp_rate, center_freq, self_coupling_db=-40.0,
+                 rndm_phaseshift=False, self_coupling=False):
+        L = lib()
+        L.orc_tsim_create.restype = C.c_void_p
+        L.orc_tsim_create.argtypes = [C.c_int, c_float_p, c_float_p, c_float_p, c_float_p, C.c_int, c_float_p, C.c_int,
+                                      C.c_float, C.c_float, C.c_int, C.c_int]
+        L.orc_tsim_destroy.argtypes = [C.c_void_p]
+        L.orc_tsim_work.argtypes = [C.c_void_p, c_float_p, C.c_int, C.POINTER(c_float_p), c_float_p, C.c_int]
+        for f in (L.orc_tsim_filt_doppler, L.orc_tsim_filt_time):
+            f.restype = c_float_p
+        L.orc_tsim_filt_doppler.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_tsim_filt_time.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        self._L = L
+        r, v, s, a, p = (_farr(x) for x in (range_m, velocity, rcs, azimuth, position_rx))
+        assert r.size == v.size == s.size == a.size
+        self.K, self.R = r.size, p.size
+        self._h = L.orc_tsim_create(self.K, _fp(r), _fp(v), _fp(s), _fp(a), self.R, _fp(p), int(samp_rate),
+                                    float(center_freq), float(self_coupling_db), int(rndm_phaseshift), int(self_coupling))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.orc_tsim_destroy(self._h)
+            self._h = None
+
+    def work(self, x, target_phase=None, sum_targets=False):
+        x = _c64(x)
+        n = x.size
+        out = np.zeros((self.R, n), np.complex64)
+        ptrs = (c_float_p * self.R)(*[_fp(out[l]) for l in range(self.R)])
+        tp = None
+        if target_phase is not None:
+            tpa = _c64(target_phase)
+            assert tpa.size == self.K
+            tp = _fp(tpa)
+        self._L.orc_tsim_work(self._h, _fp(x), n, ptrs, tp, int(sum_targets))
+        return out
+
+    def filt_doppler(self, n, k):
+        p = self._L.orc_tsim_filt_doppler(self._h, n, k)
+        return np.ctypeslib.as_array(p, shape=(2 * n,)).copy().view(np.complex64)
+
+    def filt_time(self, n, l, k):
+        p = self._L.orc_tsim_filt_time(self._h, n, l, k)
+        return np.ctypeslib.as_array(p, shape=(2 * n,)).copy().view(np.complex64)

@@ -143,6 +143,23 @@ int orc_precoder_work(const orc_pre_cfg* c, int ninput_items, const float* in, i
                       int pdu_len, int steer_mode, const float* Q_mean, const float* Q_sc,
                       const float* radar_streams, float* const* out);
 
+/* ---- §8(f) rank 2: target_simulator_impl (lib/target_simulator_impl.cc:132-385) ---- */
+typedef struct orc_tsim_state orc_tsim_state;
+orc_tsim_state* orc_tsim_create(int K, const float* range, const float* velocity, const float* rcs,
+                                const float* azimuth, int R, const float* position_rx, int samp_rate,
+                                float center_freq, float self_coupling_db, int rndm_phaseshift, int self_coupling);
+void orc_tsim_destroy(orc_tsim_state* st);
+/* channel filters of a burst of n samples (:249-300): n complex floats each */
+const float* orc_tsim_filt_doppler(orc_tsim_state* st, int n, int k);
+const float* orc_tsim_filt_time(orc_tsim_state* st, int n, int l, int k);
+/* one tagged burst: in[n_input] -> out[l][n_input], l < R.  target_phase: K complex multipliers (caller-drawn random
+ * phases, used when rndm_phaseshift), may be NULL.  sum_targets 0 = as written in the reference (last target wins),
+ * 1 = targets accumulated.  Returns n_input. */
+int orc_tsim_work(orc_tsim_state* st, const float* in, int n_input, float* const* out, const float* target_phase,
+                  int sum_targets);
+/* unnormalised DFT of any length (gr::fft::fft_complex forward/reverse restated), double inside */
+void orc_dft_any(int n, int forward, const float* in, float* out);
+
 #ifdef __cplusplus
 }
 #endif
