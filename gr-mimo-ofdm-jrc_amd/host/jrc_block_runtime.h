@@ -59,6 +59,7 @@ inline pmt_t init_f32vector(size_t n, const float* v) { auto p = mk(node::F32VEC
 inline pmt_t init_c32vector(size_t n, const gr_complex* v) { auto p = mk(node::C32VEC); p->c.assign(v, v + n); return p; }
 inline pmt_t list2(pmt_t a, pmt_t b) { auto p = mk(node::LIST); p->list = {a, b}; return p; }
 inline pmt_t list4(pmt_t a, pmt_t b, pmt_t c, pmt_t d) { auto p = mk(node::LIST); p->list = {a, b, c, d}; return p; }
+inline pmt_t make_tuple(pmt_t a, pmt_t b) { return list2(a, b); }
 inline pmt_t make_dict() { return mk(node::DICT); }
 inline pmt_t dict_add(const pmt_t& dct, const pmt_t& key, const pmt_t& val)
 {

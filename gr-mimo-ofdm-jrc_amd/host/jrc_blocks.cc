@@ -615,5 +615,92 @@ mimo_precoder::sptr mimo_precoder::make(int fft_len, int N_tx, int N_ss, const s
                                                        phased_steering, use_radar_streams, len_tag_key, debug));
 }
 
+// =================================================================================================
+// target_simulator  (lib/target_simulator_impl.cc)
+// =================================================================================================
+class target_simulator_impl : public target_simulator {
+    ctx_holder d_c;
+    jrc_tsim* d_sim = nullptr;
+    int d_samp_rate = 0, d_num_targets = 0;
+    size_t d_n_rx;
+    bool d_rndm_phaseshift = false;
+    pmt::pmt_t d_key, d_srcid;
+    std::vector<gr_complex> d_phase;
+
+public:
+    target_simulator_impl(std::vector<float> range, std::vector<float> velocity, std::vector<float> rcs, std::vector<float> azimuth,
+                          std::vector<float> position_rx, int samp_rate, float center_freq, float self_coupling_db,
+                          bool rndm_phaseshift, bool self_coupling, const std::string& len_key, bool)
+        : jrc_rt::tagged_stream_block("target_simulator", jrc_rt::io_signature::make(1, 1, sizeof(gr_complex)),
+                                      jrc_rt::io_signature::make((int)position_rx.size(), (int)position_rx.size(), sizeof(gr_complex)),
+                                      len_key),                                                                 // :80-83
+          d_n_rx(position_rx.size())
+    {
+        setup_targets(range, velocity, rcs, azimuth, position_rx, samp_rate, center_freq, self_coupling_db, rndm_phaseshift,
+                      self_coupling);
+    }
+    ~target_simulator_impl() override { jrc_tsim_destroy(d_sim); }
+
+    void setup_targets(std::vector<float> range, std::vector<float> velocity, std::vector<float> rcs, std::vector<float> azimuth,
+                       std::vector<float> position_rx, int samp_rate, float center_freq, float self_coupling_db,
+                       bool rndm_phaseshift, bool self_coupling) override                                      // :121-198
+    {
+        jrc_rt::thread::scoped_lock lock(d_setlock);
+        if (velocity.size() != range.size() || rcs.size() != range.size() || azimuth.size() != range.size())
+            throw std::invalid_argument("[TARGET SIM] range, velocity, rcs and azimuth must have the same length");   // FIXME at :160
+        if (position_rx.size() != d_n_rx)
+            throw std::invalid_argument("[TARGET SIM] position_rx must keep the number of output streams");
+        jrc_tsim_cfg c;
+        c.n_targets = (int)range.size();
+        c.range = range.data(); c.velocity = velocity.data(); c.rcs = rcs.data(); c.azimuth = azimuth.data();
+        c.n_rx = (int)position_rx.size(); c.position_rx = position_rx.data();
+        c.samp_rate = samp_rate; c.center_freq = center_freq; c.self_coupling_db = self_coupling_db;
+        c.rndm_phaseshift = rndm_phaseshift; c.self_coupling = self_coupling;
+        c.sum_targets = 0;                  // as written in the reference (:354-366)
+        c.max_bursts = 1;
+        jrc_tsim* fresh = jrc_tsim_create(d_c.ctx, &c);
+        if (!fresh) throw std::invalid_argument(jrc_last_error(d_c.ctx));
+        jrc_tsim_destroy(d_sim);
+        d_sim = fresh;
+        d_samp_rate = samp_rate; d_num_targets = c.n_targets; d_rndm_phaseshift = rndm_phaseshift;
+        d_key = pmt::string_to_symbol("rx_time");                                                             // :153-154
+        d_srcid = pmt::string_to_symbol("stat_targ_sim");
+        if (d_rndm_phaseshift) std::srand(std::time(NULL));                                                   // :196
+    }
+
+    int calculate_output_stream_length(const gr_vector_int& ninput_items) override { return ninput_items[0]; }   // :113-118
+
+    int work(int, gr_vector_int& ninput_items, gr_vector_const_void_star& in, gr_vector_void_star& out) override
+    {
+        jrc_rt::thread::scoped_lock lock(d_setlock);
+        const int n_input = ninput_items[0];
+        const gr_complex* phases = nullptr;
+        if (d_rndm_phaseshift) {                                                                              // :313-322
+            d_phase.resize(d_num_targets);
+            for (int k = 0; k < d_num_targets; k++)
+                d_phase[k] = std::exp(gr_complex(0, 2 * M_PI * float((std::rand() % 1000 + 1) / 1000.0)));
+            phases = d_phase.data();
+        }
+        for (size_t l = 0; l < d_n_rx; l++) {                                                                 // :331-335
+            const uint64_t time_sec = nitems_written(l) / d_samp_rate;
+            const double time_frac_sec = nitems_written(l) / (float)d_samp_rate - time_sec;
+            add_item_tag(l, nitems_written(l), d_key, pmt::make_tuple(pmt::from_uint64(time_sec), pmt::from_double(time_frac_sec)), d_srcid);
+        }
+        std::vector<jrc_cf32*> o(d_n_rx);
+        for (size_t l = 0; l < d_n_rx; l++) o[l] = (jrc_cf32*)out[l];
+        int n = jrc_tsim_work(d_sim, (const jrc_cf32*)in[0], n_input, o.data(), (const jrc_cf32*)phases);
+        d_c.check(n);
+        return n_input;                                                                                       // :384
+    }
+};
+target_simulator::sptr target_simulator::make(std::vector<float> range, std::vector<float> velocity, std::vector<float> rcs,
+                                              std::vector<float> azimuth, std::vector<float> position_rx, int samp_rate,
+                                              float center_freq, float self_coupling_db, bool rndm_phaseshift, bool self_coupling,
+                                              const std::string& len_key, bool debug)
+{
+    return JRC_GET_INITIAL_SPTR(new target_simulator_impl(range, velocity, rcs, azimuth, position_rx, samp_rate, center_freq,
+                                                          self_coupling_db, rndm_phaseshift, self_coupling, len_key, debug));
+}
+
 }  // namespace mimo_ofdm_jrc
 }  // namespace gr

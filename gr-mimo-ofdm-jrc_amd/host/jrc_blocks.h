@@ -9,6 +9,7 @@
 //   include/mimo_ofdm_jrc/fft_peak_detect.h            gr::mimo_ofdm_jrc::fft_peak_detect
 //   include/mimo_ofdm_jrc/mimo_ofdm_equalizer.h:64-78  gr::mimo_ofdm_jrc::mimo_ofdm_equalizer
 //   include/mimo_ofdm_jrc/mimo_precoder.h              gr::mimo_ofdm_jrc::mimo_precoder
+//   include/mimo_ofdm_jrc/target_simulator.h:30-60     gr::mimo_ofdm_jrc::target_simulator
 //
 // Built against GNU Radio 3.8 with -DJRC_WITH_GNURADIO; otherwise against the stand-alone test runtime.
 #pragma once
@@ -96,6 +97,18 @@ public:
     virtual void set_radar_aided(bool radar_aided) = 0;
     virtual void set_use_radar_streams(bool use_radar_streams) = 0;
     virtual void set_phased_steering(bool phased_steering) = 0;
+};
+
+class target_simulator : virtual public jrc_rt::tagged_stream_block {
+public:
+    typedef JRC_SPTR<target_simulator> sptr;
+    static sptr make(std::vector<float> range, std::vector<float> velocity, std::vector<float> rcs, std::vector<float> azimuth,
+                     std::vector<float> position_rx, int samp_rate, float center_freq, float self_coupling_db,
+                     bool rndm_phaseshift = false, bool self_coupling = false, const std::string& len_key = "packet_len",
+                     bool debug = false);
+    virtual void setup_targets(std::vector<float> range, std::vector<float> velocity, std::vector<float> rcs,
+                               std::vector<float> azimuth, std::vector<float> position_rx, int samp_rate, float center_freq,
+                               float self_coupling_db, bool rndm_phaseshift, bool self_coupling) = 0;
 };
 
 }  // namespace mimo_ofdm_jrc

@@ -81,6 +81,17 @@ void* jrcb_make_precoder(int fft_len, int N_tx, const int* dc, int n_dc, const i
 }
 
 // kind: 0 long, 1 uint64, 2 double
+void* jrcb_make_target_simulator(const float* range, const float* velocity, const float* rcs, const float* azimuth, int n_targets,
+                                 const float* position_rx, int n_rx, int samp_rate, float center_freq, float self_coupling_db,
+                                 int rndm_phaseshift, int self_coupling)
+{
+    return guard_make([&] { return std::static_pointer_cast<jrc_host::block>(std::shared_ptr<target_simulator>(
+        target_simulator::make(std::vector<float>(range, range + n_targets), std::vector<float>(velocity, velocity + n_targets),
+                               std::vector<float>(rcs, rcs + n_targets), std::vector<float>(azimuth, azimuth + n_targets),
+                               std::vector<float>(position_rx, position_rx + n_rx), samp_rate, center_freq, self_coupling_db,
+                               rndm_phaseshift != 0, self_coupling != 0))); });
+}
+
 int jrcb_add_in_tag(void* h, int port, uint64_t offset, const char* key, int kind, long lv, double dv)
 {
     auto& b = ((handle*)h)->b;

@@ -21,7 +21,7 @@ def lib():
         L = C.CDLL(LIB)
         L.jrcb_last_error.restype = C.c_char_p
         for name in ("jrcb_make_radar", "jrcb_make_transpose", "jrcb_make_estimator", "jrcb_make_cp_remover",
-                     "jrcb_make_peak_detect", "jrcb_make_equalizer", "jrcb_make_precoder"):
+                     "jrcb_make_peak_detect", "jrcb_make_equalizer", "jrcb_make_precoder", "jrcb_make_target_simulator"):
             getattr(L, name).restype = _vp
         L.jrcb_make_radar.argtypes = [C.c_int] * 10
         L.jrcb_make_transpose.argtypes = [C.c_int] * 3
@@ -32,6 +32,7 @@ def lib():
                                           _fp, _fp, C.c_int, C.c_int, C.c_char_p]
         L.jrcb_make_precoder.argtypes = [C.c_int, C.c_int, _ip, C.c_int, _ip, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_char_p,
                                          C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int]
+        L.jrcb_make_target_simulator.argtypes = [_fp, _fp, _fp, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int]
         L.jrcb_destroy.argtypes = [_vp]
         L.jrcb_add_in_tag.argtypes = [_vp, C.c_int, C.c_uint64, C.c_char_p, C.c_int, C.c_long, C.c_double]
         L.jrcb_run.argtypes = [_vp, C.c_int, _ip, C.c_int, C.POINTER(_vp), C.c_int, C.POINTER(_vp)]
@@ -112,6 +113,15 @@ def estimator(vlen, rb, ab, ndr, nda, snr_thr, pow_thr, stats_path="", stats_rec
 
 def cp_remover(fft_len, cp_len):
     return Block(lib().jrcb_make_cp_remover(fft_len, cp_len))
+
+
+def target_simulator(range_m, velocity, rcs, azimuth, position_rx, samp_rate, center_freq, self_coupling_db=-40.0,
+                     rndm_phaseshift=False, self_coupling=False):
+    r, v, s, a, p = (np.ascontiguousarray(np.atleast_1d(x), np.float32) for x in (range_m, velocity, rcs, azimuth, position_rx))
+    if not (v.size == s.size == a.size == r.size):       # the C harness takes one count; mismatches are tested in Python
+        raise ValueError("length mismatch")
+    return Block(lib().jrcb_make_target_simulator(_f(r), _f(v), _f(s), _f(a), r.size, _f(p), p.size, int(samp_rate),
+                                                  float(center_freq), float(self_coupling_db), int(rndm_phaseshift), int(self_coupling)))
 
 
 def peak_detect(samp_rate, interp, threshold, samp_protect):

@@ -21,7 +21,7 @@ def test_host_library_exports_harness_and_links_the_abi(jrc):
         assert hasattr(L, sym)
     src = open(os.path.join(ROOT, "gr-mimo-ofdm-jrc_amd", "host", "jrc_blocks.cc")).read()
     for cls in ("mimo_ofdm_radar", "matrix_transpose", "range_angle_estimator", "ofdm_cyclic_prefix_remover",
-                "fft_peak_detect", "mimo_ofdm_equalizer", "mimo_precoder"):
+                "fft_peak_detect", "mimo_ofdm_equalizer", "mimo_precoder", "target_simulator"):
         assert re.search(r"%s::sptr\s+%s::make\(" % (cls, cls), src), cls
 
 
@@ -219,3 +219,47 @@ def test_precoder_block_errors_and_radar_aided_steering(jrc, ofdm64, tmp_path):
     op = oracle.Precoder(64, 4, 1, o["data_subcarriers"], o["pilot_subcarriers"], o["pilot_symbols"], o["l_stf_ltf_64"], o["ltf_mapped_sc__ss_sym"])
     ref = op.work(s, 2, 2, 10, steer_mode=1, Q_mean=oracle.steering_from_channel(hvec))
     assert rel_err(np.stack(outs), ref) < 1e-5
+
+
+@gpu
+def test_target_simulator_block_tags_and_outputs(jrc):
+    """lib/target_simulator_impl.cc:202-385 through the C++ block: R output streams, rx_time tuple tag per stream,
+    length tag rewritten by the TSB base, whole burst consumed; the reference's last-target-wins behaviour"""
+    import hostblocks as hb
+    rng = np.random.default_rng(5)
+    fs, fc, n = 125_000_000, 24e9, 1600
+    tg = ([10.0, 31.0], [0.0, 9.0], [100.0, 25.0], [20.0, -15.0])
+    pos = [0.0, 0.00625, 0.0125]
+    b = hb.target_simulator(*tg, pos, fs, fc)
+    want = oracle.TargetSimulator(*tg, pos, fs, fc)
+    total = 0
+    for turn in range(2):
+        x = crandn(rng, n)
+        outs = [np.zeros(n, np.complex64) for _ in pos]
+        if turn == 0:
+            assert b.run(n, [x], outs) == 0                     # no length tag yet
+        b.tag(0, total, "packet_len", n)
+        assert b.run(n, [x], outs) == n and b.consumed(0) == n
+        ref = want.work(x)
+        for l in range(len(pos)):
+            assert rel_err(outs[l], ref[l]) < 1e-4
+        total += n
+    st = b.state()
+    assert st["nitems_written"] == [2 * n] * 3
+    for l in range(3):
+        tags = st["out_tags"][l]
+        rx = [t for t in tags if t["key"] == "rx_time"]
+        assert [t["offset"] for t in rx] == [0, n]
+        secs, frac = rx[1]["value"]
+        assert secs == 0 and abs(frac - n / fs) < 1e-9           # (:331-335)
+        assert [t["value"] for t in tags if t["key"] == "packet_len"] == [n, n]
+    # random phases: |out| is unchanged, the phase is one of the 1000 values of (:319)
+    r = hb.target_simulator([10.0], [0.0], [100.0], [0.0], [0.0], fs, fc, rndm_phaseshift=True)
+    r.tag(0, 0, "packet_len", n)
+    o = [np.zeros(n, np.complex64)]
+    assert r.run(n, [x], o) == n
+    base = oracle.TargetSimulator([10.0], [0.0], [100.0], [0.0], [0.0], fs, fc).work(x)[0]
+    ratio = o[0][np.abs(base) > 1e-9] / base[np.abs(base) > 1e-9]
+    assert np.allclose(np.abs(ratio), 1.0, atol=1e-3)
+    k = np.angle(np.mean(ratio)) / (2 * np.pi) * 1000
+    assert abs(k - round(k)) < 0.05
