@@ -80,6 +80,54 @@ __device__ __forceinline__ void ifft256_cols(float2 (&x)[16], float2* xch, const
     swap_reim(x); fft256_cols(x, xch, tw256); swap_reim(x);
 }
 
+// ---- the same 256-point FFT over 16 contiguous rows of 256 points (row pass when n2 == 256) --------------------
+// thread (rl = tid >> 4, s = tid & 15) holds x[j] = element (s + 16 j) of row rl on entry and element (s + 16 r) of the
+// transform on exit, so a forward transform, a pointwise product and an inverse transform chain without any
+// redistribution.  Exchange layout: row rl at rl*TS_XPAD, plane q at q*17, then s — writes are 16-lane contiguous
+// runs, reads have stride 17 (odd) inside a row and the four rows of a wave pair up on disjoint banks.
+__device__ __forceinline__ void fft256_rows(float2 (&x)[16], float2* xch, const float2* tw256)
+{
+    const int s = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    fft_fwd_small<16>(x);
+#pragma unroll
+    for (int q = 1; q < 16; q++) x[q] = cmul(x[q], tw256[s * q]);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; q++) xch[rl * TS_XPAD + q * 17 + s] = x[q];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = xch[rl * TS_XPAD + s * 17 + j];
+    fft_fwd_small<16>(x);
+}
+
+// row pass for n2 == 256: 16 rows per workgroup, forward FFT -> . Bhat (or conj) -> inverse FFT, all in registers
+__global__ __launch_bounds__(256) void tsim_rowconv256_kernel(float2* __restrict__ X, const float2* __restrict__ bhat, int conj_b,
+                                                              const float2* __restrict__ tw256_g, size_t rows)
+{
+    __shared__ float2 xch[16 * TS_XPAD];
+    __shared__ float2 tw256[256];
+    const int s = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const size_t row = (size_t)blockIdx.x * 16 + rl;            // rows is a multiple of 256
+    tw256[threadIdx.x] = tw256_g[threadIdx.x];
+    float2* g = X + row * 256;
+    const float2* brow = bhat + (size_t)(row & (TS_N1 - 1)) * 256;
+    float2 x[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = g[s + 16 * j];
+    __syncthreads();
+    fft256_rows(x, xch, tw256);
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        float2 bv = brow[s + 16 * r];
+        if (conj_b) bv.y = -bv.y;
+        x[r] = cmul(x[r], bv);
+    }
+    swap_reim(x); fft256_rows(x, xch, tw256); swap_reim(x);
+#pragma unroll
+    for (int r = 0; r < 16; r++) g[s + 16 * r] = x[r];
+    (void)rows;
+}
+
 // outer four-step twiddles w_M^{i2 * k1}, k1 = s + 16 j:  w^{i2 s} . (w^{16 i2})^j, the second factor shared by the
 // 16 threads of a column through LDS (one sincospi per thread for each factor; arguments are exact dyadic fractions)
 __device__ __forceinline__ float2 unit_pow(long num, int M /* pow2 */)
@@ -319,6 +367,14 @@ static int tsim_rows_launch(jrc_tsim* h, bool fwd_only, float2* X, int conj_b, s
     const float2 *twf = nullptr, *twi = nullptr;
     JRC_TRY(jrc_get_twiddles(ctx, n2, -1, &twf));
     JRC_TRY(jrc_get_twiddles(ctx, n2, +1, &twi));
+    if (!fwd_only && n2 == 256) {
+        const float2* tw256 = nullptr;
+        JRC_TRY(jrc_get_twiddles(ctx, TS_N1, -1, &tw256));
+        hipLaunchKernelGGL(tsim_rowconv256_kernel, dim3((unsigned)(rows / 16)), dim3(256), 0, stream, X, (const float2*)h->d_bhat,
+                           conj_b, tw256, rows);
+        JRC_HIP(ctx, hipGetLastError());
+        return JRC_OK;
+    }
     int tp = n2 / 4; if (tp > 256) tp = 256;
     const int per_block = 256 / tp;
     const size_t blocks = (rows + per_block - 1) / per_block;
