@@ -50,6 +50,8 @@ struct jrc_tsim {
     size_t u_cap = 0, g_cap = 0;
 };
 
+__device__ __forceinline__ float2 conjf2(float2 a) { return make_float2(a.x, -a.y); }
+
 // ---- 256-point forward FFT over 16 columns, in registers ---------------------------------------
 // thread (c = tid & 15, s = tid >> 4) enters with x[j] = element (s + 16 j) of column c and leaves with
 // x[r] = element (q + 16 r), q = s:  X[q + 16 r] = sum_s w16^{s r} [ w256^{s q} sum_j x[s + 16 j] w16^{j q} ].
@@ -128,6 +130,79 @@ __global__ __launch_bounds__(256) void tsim_rowconv256_kernel(float2* __restrict
     (void)rows;
 }
 
+// row pass for n2 = m * 256, m in {2, 4, 8, 16}: the row is itself a two-step transform  i = i_a*256 + i_b  ->
+// k = k_a + m*k_b  (m-point FFTs over i_a in registers, twiddle w_n2^{i_b k_a}, then 256-point FFTs over i_b as above).
+// The transform is left in [k_a][k_b] order: the chirp spectrum is produced by the same kernel (FWD_ONLY), and the
+// inverse runs the steps backwards, so no reordering pass exists.  16*m threads per row, 16/m rows per workgroup.
+template <int M_, bool FWD_ONLY>
+__global__ __launch_bounds__(256) void tsim_rowconv_m_kernel(float2* __restrict__ X, const float2* __restrict__ bhat, int conj_b,
+                                                             const float2* __restrict__ tw256_g, const float2* __restrict__ twn2_g)
+{
+    constexpr int TPR = 16 * M_;             // threads per row
+    constexpr int U = 16 / M_;               // i_b values per thread in the m-point step
+    constexpr int N2 = 256 * M_;
+    __shared__ float2 xch[16 * TS_XPAD];
+    __shared__ float2 tw256[256];
+    const int rowl = threadIdx.x / TPR, t = threadIdx.x % TPR;
+    const int s = threadIdx.x & 15, plane = threadIdx.x >> 4;          // plane = rowl * M_ + k_a
+    const size_t row = (size_t)blockIdx.x * (256 / TPR) + rowl;
+    tw256[threadIdx.x] = tw256_g[threadIdx.x];
+    float2* g = X + row * N2;
+    float2 y[16];                             // [u][i_a]
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int a = 0; a < M_; a++) y[u * M_ + a] = g[a * 256 + t + TPR * u];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        fft_fwd_small<M_>(*reinterpret_cast<float2(*)[M_]>(&y[u * M_]));
+        const int ib = t + TPR * u;
+#pragma unroll
+        for (int a = 1; a < M_; a++) y[u * M_ + a] = cmul(y[u * M_ + a], twn2_g[ib * a]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int a = 0; a < M_; a++) xch[(rowl * M_ + a) * TS_XPAD + t + TPR * u] = y[u * M_ + a];
+    __syncthreads();
+    float2 x[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = xch[plane * TS_XPAD + s + 16 * j];
+    fft256_rows(x, xch, tw256);               // x[r] = transform element k_b = s + 16 r of plane k_a
+    const int ka = plane % M_;
+    if (FWD_ONLY) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) g[ka * 256 + s + 16 * r] = x[r];
+        return;
+    }
+    const float2* brow = bhat + (row & (TS_N1 - 1)) * (size_t)N2 + ka * 256;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        float2 bv = brow[s + 16 * r];
+        if (conj_b) bv.y = -bv.y;
+        x[r] = cmul(x[r], bv);
+    }
+    swap_reim(x); fft256_rows(x, xch, tw256); swap_reim(x);            // x[r] = element i_b = s + 16 r of plane k_a
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; r++) xch[plane * TS_XPAD + s + 16 * r] = x[r];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int ib = t + TPR * u;
+#pragma unroll
+        for (int a = 0; a < M_; a++) {
+            float2 v = xch[(rowl * M_ + a) * TS_XPAD + ib];
+            if (a) v = cmul(v, conjf2(twn2_g[ib * a]));
+            y[u * M_ + a] = make_float2(v.y, v.x);                      // swapped: inverse m-point FFT via the forward one
+        }
+        fft_fwd_small<M_>(*reinterpret_cast<float2(*)[M_]>(&y[u * M_]));
+#pragma unroll
+        for (int a = 0; a < M_; a++) g[a * 256 + ib] = make_float2(y[u * M_ + a].y, y[u * M_ + a].x);
+    }
+}
+
 // outer four-step twiddles w_M^{i2 * k1}, k1 = s + 16 j:  w^{i2 s} . (w^{16 i2})^j, the second factor shared by the
 // 16 threads of a column through LDS (one sincospi per thread for each factor; arguments are exact dyadic fractions)
 __device__ __forceinline__ float2 unit_pow(long num, int M /* pow2 */)
@@ -144,7 +219,6 @@ __device__ __forceinline__ void outer_twiddle_setup(float2* twc /* LDS [16][16] 
     twc[s * 16 + c] = unit_pow(16L * i2 * s, M);        // (w^{16 i2})^s, [power][column]
     t1 = unit_pow(i2 * s, M);
 }
-__device__ __forceinline__ float2 conjf2(float2 a) { return make_float2(a.x, -a.y); }
 
 __device__ __forceinline__ void load_tw256(float2* tw256, const float2* __restrict__ tw256_g)
 {
@@ -367,6 +441,22 @@ static int tsim_rows_launch(jrc_tsim* h, bool fwd_only, float2* X, int conj_b, s
     const float2 *twf = nullptr, *twi = nullptr;
     JRC_TRY(jrc_get_twiddles(ctx, n2, -1, &twf));
     JRC_TRY(jrc_get_twiddles(ctx, n2, +1, &twi));
+    if (n2 >= 512 && n2 <= 4096) {
+        const float2* tw256 = nullptr;
+        JRC_TRY(jrc_get_twiddles(ctx, TS_N1, -1, &tw256));
+        const int m = n2 / 256;
+        const dim3 grid((unsigned)(rows / (16 / m)));
+        const float2* bh = fwd_only ? nullptr : (const float2*)h->d_bhat;
+#define TS_LAUNCH_M(MM)                                                                                                   \
+        do {                                                                                                              \
+            if (fwd_only) hipLaunchKernelGGL((tsim_rowconv_m_kernel<MM, true>), grid, dim3(256), 0, stream, X, bh, conj_b, tw256, twf); \
+            else hipLaunchKernelGGL((tsim_rowconv_m_kernel<MM, false>), grid, dim3(256), 0, stream, X, bh, conj_b, tw256, twf);        \
+        } while (0)
+        if (m == 2) TS_LAUNCH_M(2); else if (m == 4) TS_LAUNCH_M(4); else if (m == 8) TS_LAUNCH_M(8); else TS_LAUNCH_M(16);
+#undef TS_LAUNCH_M
+        JRC_HIP(ctx, hipGetLastError());
+        return JRC_OK;
+    }
     if (!fwd_only && n2 == 256) {
         const float2* tw256 = nullptr;
         JRC_TRY(jrc_get_twiddles(ctx, TS_N1, -1, &tw256));

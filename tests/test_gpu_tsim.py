@@ -28,6 +28,22 @@ def test_single_target_any_length(jrc, ctx, n):
     assert rel_err(got, want) < TOL
 
 
+@pytest.mark.parametrize("n", [40000, 70000, 174080, 300000, 600000])
+def test_long_bursts(jrc, ctx, n):
+    """chirp-z lengths M = 2^17 .. 2^21: row pass as m x 256 two-step transforms (m = 2..16) and the generic Stockham rows"""
+    args = ([35.0], [-12.0], [40.0], [-25.0], POS4[:2], FS, FC)
+    x = burst(n, n)
+    got = jrc.target_simulator(*args, ctx=ctx).work(x)
+    want = oracle.TargetSimulator(*args).work(x)
+    assert rel_err(got, want) < TOL
+
+
+def test_burst_too_long_is_refused(jrc, ctx):
+    g = jrc.target_simulator([10.0], [0.0], [1.0], [0.0], [0.0], FS, FC, ctx=ctx)
+    with pytest.raises(jrc.JrcError):
+        g.work(np.zeros((1 << 20) + 1, np.complex64))
+
+
 @pytest.mark.parametrize("sum_targets", [False, True])
 def test_three_targets(jrc, ctx, sum_targets):
     n = 24 * 80

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Secondary figures SURVEY.md §8(d) asks for next to bench.py's headline line (tools only; prints JSON lines):
   * radar chain WITH the RX OFDM demod in front (A6 cyclic-prefix removal + A7 fft fwd/shift fused, then A1..A5)
+  * the device-resident simulation flowgraph: 4 target simulators (one per TX, summed into the RX streams) -> RX OFDM demod
+    -> A1..A5, per simulated frame
   * equalizer path, config C: 4 RX lanes x frames of [2 L-LTF, SIG, 4 MIMO-LTF, 64 data symbols] x 256 subcarriers, LS, DATA
 """
 import json
@@ -57,6 +59,41 @@ def radar_with_demod(cfg="B", F=256):
                 ms_per_step=t * 1e3, frames_per_s=F / t, ms_chain_only=t_chain * 1e3, frames_per_s_chain_only=F / t_chain)
 
 
+def simulated_chain(cfg="B", F=64):
+    """T target simulators (accumulating into the RX bursts) + RX demod + radar chain per frame, everything in HBM"""
+    sc = {"B": synth.config_B, "D": synth.config_D}[cfg]()
+    Ir, Ia, P = 8, 16, sc.T * sc.R
+    rb, ab = jrc_amd.radar_axes(sc.N, sc.fs, Ir, P, Ia)
+    ctx = jrc_amd.Context(0)
+    chain = jrc_amd.RadarChain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb, ab, 2.4, 14.36, 15.0, 0.0, max_frames=F, ctx=ctx)
+    bufs = chain.alloc(F, "cuda:0")
+    n_items = sc.Npre + sc.S
+    n = (n_items + 3) * (sc.N + sc.cp)                     # burst incl. the 3 zero-pad symbols of the flowgraph
+    lam = 3e8 / sc.fc
+    tg = sc.targets or [(10.0 + 7 * k, -50.0 + 14 * k, 5.0 * k, 50.0) for k in range(8)]
+    rng_m, az, vel, rcs = (np.array(v, np.float32) for v in zip(*tg))
+    sims = [jrc_amd.target_simulator(rng_m, vel, rcs, az, [(r * sc.T + t + 2) * lam / 2 for r in range(sc.R)], int(sc.fs), sc.fc,
+                                     sum_targets=True, max_bursts=F, ctx=ctx) for t in range(sc.T)]
+    tx_td = [torch.randn((F, n, 2), dtype=torch.float32, device="cuda:0") * 0.1 for _ in range(sc.T)]
+    rx_td = torch.zeros((F, sc.R, n, 2), dtype=torch.float32, device="cuda:0")
+    rx_f = torch.empty((F, sc.R, n_items + 3, sc.N, 2), dtype=torch.float32, device="cuda:0")
+    L = ctx.lib
+
+    def sim_only():
+        for t in range(sc.T):
+            sims[t].run_dev(tx_td[t], rx_td, F, n, accumulate_out=(t > 0))
+
+    def step():
+        sim_only()
+        ctx.check(L.jrc_cp_remove_fft_dev(ctx.h, sc.N, sc.cp, F * sc.R * (n_items + 3), rx_td.data_ptr(), rx_f.data_ptr(), None))
+        chain.run(bufs, F)
+    t = timed(step, steps=10, warm=2)
+    ts = timed(sim_only, steps=10, warm=2)
+    return dict(what="simulated frame: %d target simulators (%d targets, %d-sample bursts, chirp-z M=%d) + RX demod + radar chain, config %s"
+                % (sc.T, len(tg), n, 1 << int(np.ceil(np.log2(max(2 * n - 1, 32768)))), cfg), frames_per_step=F, ms_per_step=t * 1e3,
+                frames_per_s=F / t, ms_simulators_only=ts * 1e3, bursts_per_s_simulators=F * sc.T / ts)
+
+
 def equalizer_config_c(n_frames=2048, lanes=4):
     N, cp, T, S = 256, 64, 4, 64
     rng = np.random.default_rng(0)
@@ -107,5 +144,6 @@ def equalizer_config_c(n_frames=2048, lanes=4):
 
 
 if __name__ == "__main__":
-    for fn in (lambda: radar_with_demod("B", 256), lambda: radar_with_demod("D", 64), equalizer_config_c):
+    for fn in (lambda: radar_with_demod("B", 256), lambda: radar_with_demod("D", 64), lambda: simulated_chain("B", 64),
+               lambda: simulated_chain("D", 8), equalizer_config_c):
         print(json.dumps(fn()))
