@@ -44,7 +44,7 @@ struct jrc_tsim {
     float2* d_ts = nullptr;       // [R][K][n]
     float2* d_chirp = nullptr;    // [n]   c[i] = exp(-j pi i^2 / n)
     float2* d_bhat = nullptr;     // [256][n2] FFT_M(conj(c) wrapped) / M in [k1][k2] order
-    float2* d_u = nullptr;        // [max_bursts][M]
+    float2* d_u = nullptr;        // [max_bursts][Kz][M], Kz = K when sum_targets else 1
     float2* d_g = nullptr;        // [max_bursts][R][M]
     float2* d_phase = nullptr;    // [K]
     size_t u_cap = 0, g_cap = 0;
@@ -238,8 +238,9 @@ __global__ __launch_bounds__(256) void tsim_col_first_kernel(const float2* __res
     __shared__ float2 twc[256];
     const int c = threadIdx.x & 15, s = threadIdx.x >> 4;
     const int col0 = blockIdx.x * TS_CW;
-    const size_t b = blockIdx.y;
+    const size_t b = blockIdx.y, z = blockIdx.z;          // z = target within this launch (dop advances n per target)
     const float2* src = in + b * (size_t)in_stride;
+    if (!PLAIN) dop += z * (size_t)n;
     float2 t1;
     load_tw256(tw256, tw256_g);
     outer_twiddle_setup(twc, t1, col0, M);
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(256) void tsim_col_first_kernel(const float2* __res
     }
     __syncthreads();                                      // tw256 / twc visible
     fft256_cols(x, xch, tw256);
-    float2* dst = U + b * (size_t)M;
+    float2* dst = U + (b * gridDim.z + z) * (size_t)M;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const float2 w = cmul(t1, twc[r * 16 + c]);       // w_M^{i2 (s + 16 r)}
@@ -318,11 +319,71 @@ __global__ __launch_bounds__(256) void tsim_rowconv_kernel(float2* __restrict__ 
     }
 }
 
-// ---- kernel MID: Z -> conj outer twiddle -> inverse column FFT = conv (natural order) -> for each antenna l:
-//      g = conv . timeshift_{l,k} (zero beyond n) -> column FFT -> outer twiddle -> G[l][k1][i2] ---------------------
+// ---- kernel MID: for every target z of the launch: Z_z -> conj outer twiddle -> inverse column FFT = conv_z (natural
+//      order); acc_l += conv_z . timeshift_{l,z} [. phase_z]  (zero beyond n);  then per antenna l: column FFT -> outer
+//      twiddle -> G[l][k1][i2].  The sum over targets is taken here, in the middle of the two convolutions (both are
+//      linear), so K targets cost K + R convolutions instead of K (1 + R).  RC antennas per launch (accumulators in
+//      registers). -----------------------------------------------------------------------------------------------------
+template <int RC>
 __global__ __launch_bounds__(256) void tsim_col_mid_kernel(const float2* __restrict__ Z, float2* __restrict__ G,
-                                                           const float2* __restrict__ ts /* [R][K][n] + k*n */, long ts_l_stride,
-                                                           const float2* __restrict__ tw256_g, int R, int n, int n2, int M)
+                                                           const float2* __restrict__ ts /* [R][K][n] + (l0*K + k0)*n */, long ts_l_stride,
+                                                           const float2* __restrict__ phase /* + k0, or null */,
+                                                           const float2* __restrict__ tw256_g, int Kz, int R, int l0, int n, int n2, int M)
+{
+    __shared__ float2 xch[16 * TS_XPAD];
+    __shared__ float2 tw256[256];
+    __shared__ float2 twc[256];
+    const int c = threadIdx.x & 15, s = threadIdx.x >> 4;
+    const int col0 = blockIdx.x * TS_CW;
+    const size_t b = blockIdx.y;
+    float2 t1;
+    load_tw256(tw256, tw256_g);
+    outer_twiddle_setup(twc, t1, col0, M);
+    float2 acc[RC][16];
+#pragma unroll
+    for (int l = 0; l < RC; l++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[l][r] = make_float2(0.f, 0.f);
+    __syncthreads();
+    for (int z = 0; z < Kz; z++) {
+        const float2* src = Z + (b * Kz + z) * (size_t)M;
+        float2 x[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) x[j] = src[(size_t)(s + 16 * j) * n2 + col0 + c];
+#pragma unroll
+        for (int j = 0; j < 16; j++) x[j] = cmul(x[j], conjf2(cmul(t1, twc[j * 16 + c])));
+        ifft256_cols(x, xch, tw256);                      // x[r] = conv_z[(s + 16 r) n2 + i2]
+        if (phase) {
+            const float2 ph = phase[z];                   // :358-362, folded in before the (linear) second transform
+#pragma unroll
+            for (int r = 0; r < 16; r++) x[r] = cmul(x[r], ph);
+        }
+#pragma unroll
+        for (int l = 0; l < RC; l++) {
+            const float2* tsl = ts + (size_t)l * ts_l_stride + (size_t)z * n;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const long i = (long)(s + 16 * r) * n2 + col0 + c;
+                if (i < n) acc[l][r] = cadd(acc[l][r], cmul(x[r], tsl[i]));      // :352
+            }
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < RC; l++) {
+        fft256_cols(acc[l], xch, tw256);
+        float2* dst = G + (b * R + l0 + l) * (size_t)M;
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            dst[(size_t)(s + 16 * r) * n2 + col0 + c] = cmul(acc[l][r], cmul(t1, twc[r * 16 + c]));
+    }
+}
+
+// single target per launch (the reference's own behaviour, and K = 1): no accumulators — one inverse column FFT, then the
+// antennas one after the other out of the same registers
+__global__ __launch_bounds__(256) void tsim_col_mid1_kernel(const float2* __restrict__ Z, float2* __restrict__ G,
+                                                            const float2* __restrict__ ts /* [R][K][n] + k*n */, long ts_l_stride,
+                                                            const float2* __restrict__ phase /* + k, or null */,
+                                                            const float2* __restrict__ tw256_g, int R, int n, int n2, int M)
 {
     __shared__ float2 xch[16 * TS_XPAD];
     __shared__ float2 tw256[256];
@@ -341,6 +402,11 @@ __global__ __launch_bounds__(256) void tsim_col_mid_kernel(const float2* __restr
 #pragma unroll
     for (int j = 0; j < 16; j++) x[j] = cmul(x[j], conjf2(cmul(t1, twc[j * 16 + c])));
     ifft256_cols(x, xch, tw256);                          // x[r] = conv[(s + 16 r) n2 + i2]
+    if (phase) {
+        const float2 ph = phase[0];
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[r] = cmul(x[r], ph);
+    }
     for (int l = 0; l < R; l++) {
         const float2* tsl = ts + (size_t)l * ts_l_stride;
         float2 y[16];
@@ -357,11 +423,11 @@ __global__ __launch_bounds__(256) void tsim_col_mid_kernel(const float2* __restr
     }
 }
 
-// ---- kernel OUT: Y_l -> conj outer twiddle -> inverse column FFT -> . conj(c)[m] [. phase_k] -> out_l[m]
+// ---- kernel OUT: Y_l -> conj outer twiddle -> inverse column FFT -> . conj(c)[m] -> out_l[m]
 //      (= or +=), plus the self-coupling term sc . in[m] (:372-378) when asked ---------------------------------------
 __global__ __launch_bounds__(256) void tsim_col_out_kernel(const float2* __restrict__ Y, float2* __restrict__ out,
                                                            long out_burst_stride, long out_rx_stride,
-                                                           const float2* __restrict__ chirp, const float2* __restrict__ phase_k,
+                                                           const float2* __restrict__ chirp,
                                                            const float2* __restrict__ in, long in_stride, float self_coupling,
                                                            int add_self, int accumulate,
                                                            const float2* __restrict__ tw256_g, int R, int n, int n2, int M)
@@ -386,14 +452,11 @@ __global__ __launch_bounds__(256) void tsim_col_out_kernel(const float2* __restr
     ifft256_cols(x, xch, tw256);
     float2* o = out + b * (size_t)out_burst_stride + l * (size_t)out_rx_stride;
     const float2* inb = in + b * (size_t)in_stride;
-    const bool has_phase = phase_k != nullptr;
-    const float2 ph = has_phase ? *phase_k : make_float2(1.f, 0.f);
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const long m = (long)(s + 16 * r) * n2 + col0 + c;
         if (m < n) {
             float2 v = cmul(x[r], conjf2(chirp[m]));
-            if (has_phase) v = cmul(v, ph);               // :358-362
             if (accumulate) v = cadd(o[m], v);
             if (add_self) {                               // out += (gr_complex)pow(10, db/20) * in  (:376)
                 const float2 xi = inb[m];
@@ -510,7 +573,8 @@ static int tsim_prepare(jrc_tsim* h, int n, hipStream_t stream)
     while (M < 2L * n - 1) M <<= 1;
     const int n2 = (int)(M / TS_N1);
     // work buffers
-    const size_t need_u = sizeof(float2) * (size_t)h->max_bursts * M, need_g = need_u * (size_t)(R > 0 ? R : 1);
+    const size_t per = sizeof(float2) * (size_t)h->max_bursts * M;
+    const size_t need_u = per * (size_t)(h->sum_targets && K > 1 ? K : 1), need_g = per * (size_t)(R > 0 ? R : 1);
     if (need_u > h->u_cap) { (void)hipFree(h->d_u); h->d_u = nullptr; h->u_cap = 0; JRC_HIP(ctx, hipMalloc((void**)&h->d_u, need_u)); h->u_cap = need_u; }
     if (need_g > h->g_cap) { (void)hipFree(h->d_g); h->d_g = nullptr; h->g_cap = 0; JRC_HIP(ctx, hipMalloc((void**)&h->d_g, need_g)); h->g_cap = need_g; }
 
@@ -636,26 +700,33 @@ extern "C" int jrc_tsim_run_dev(jrc_tsim* h, int n_bursts, int n_input, const jr
     const float2* tw256 = nullptr;
     JRC_TRY(jrc_get_twiddles(ctx, TS_N1, -1, &tw256));
     const int M = h->M, n2 = h->n2;
-    const dim3 colgrid(n2 / TS_CW, n_bursts), colgrid_out(n2 / TS_CW, n_bursts * R);
     // as written in the reference every target overwrites the output buffer (:354-366), so only the last one is
-    // observable; sum_targets accumulates them instead
-    const int k_first = h->sum_targets ? 0 : K - 1;
-    for (int k = k_first; k < K; k++) {
-        hipLaunchKernelGGL(tsim_col_first_kernel<false>, colgrid, dim3(256), 0, s, in, (long)n, (const float2*)h->d_dop + (size_t)k * n,
-                           (const float2*)h->d_chirp, h->d_u, tw256, n, n2, M);
-        JRC_HIP(ctx, hipGetLastError());
-        JRC_TRY(tsim_rows_launch(h, false, h->d_u, 0, (size_t)n_bursts * TS_N1, s));
-        hipLaunchKernelGGL(tsim_col_mid_kernel, colgrid, dim3(256), 0, s, (const float2*)h->d_u, h->d_g,
-                           (const float2*)h->d_ts + (size_t)k * n, (long)K * n, tw256, R, n, n2, M);
-        JRC_HIP(ctx, hipGetLastError());
-        JRC_TRY(tsim_rows_launch(h, false, h->d_g, 1, (size_t)n_bursts * R * TS_N1, s));
-        const int last = k == K - 1;
-        hipLaunchKernelGGL(tsim_col_out_kernel, colgrid_out, dim3(256), 0, s, (const float2*)h->d_g, out, (long)R * n, (long)n,
-                           (const float2*)h->d_chirp, use_phase ? (const float2*)h->d_phase + k : (const float2*)nullptr,
-                           in, (long)n, sc, (last && h->self_coupling) ? 1 : 0, (accumulate_out || k > k_first) ? 1 : 0,
-                           tw256, R, n, n2, M);
+    // observable; sum_targets accumulates them instead (in the middle kernel, between the two convolutions)
+    const int k0 = h->sum_targets ? 0 : K - 1, Kz = K - k0;
+    const dim3 grid_first(n2 / TS_CW, n_bursts, Kz), grid_mid(n2 / TS_CW, n_bursts), grid_out(n2 / TS_CW, n_bursts * R);
+    hipLaunchKernelGGL(tsim_col_first_kernel<false>, grid_first, dim3(256), 0, s, in, (long)n, (const float2*)h->d_dop + (size_t)k0 * n,
+                       (const float2*)h->d_chirp, h->d_u, tw256, n, n2, M);
+    JRC_HIP(ctx, hipGetLastError());
+    JRC_TRY(tsim_rows_launch(h, false, h->d_u, 0, (size_t)n_bursts * Kz * TS_N1, s));
+    const float2* ph = use_phase ? (const float2*)h->d_phase + k0 : (const float2*)nullptr;
+    if (Kz == 1) {
+        hipLaunchKernelGGL(tsim_col_mid1_kernel, grid_mid, dim3(256), 0, s, (const float2*)h->d_u, h->d_g,
+                           (const float2*)h->d_ts + (size_t)k0 * n, (long)K * n, ph, tw256, R, n, n2, M);
         JRC_HIP(ctx, hipGetLastError());
     }
+    for (int l0 = (Kz == 1) ? R : 0; l0 < R;) {
+        const int rc = (R - l0 >= 4) ? 4 : ((R - l0 >= 2) ? 2 : 1);
+        const float2* tsp = (const float2*)h->d_ts + ((size_t)l0 * K + k0) * n;
+        if (rc == 4) hipLaunchKernelGGL(tsim_col_mid_kernel<4>, grid_mid, dim3(256), 0, s, (const float2*)h->d_u, h->d_g, tsp, (long)K * n, ph, tw256, Kz, R, l0, n, n2, M);
+        else if (rc == 2) hipLaunchKernelGGL(tsim_col_mid_kernel<2>, grid_mid, dim3(256), 0, s, (const float2*)h->d_u, h->d_g, tsp, (long)K * n, ph, tw256, Kz, R, l0, n, n2, M);
+        else hipLaunchKernelGGL(tsim_col_mid_kernel<1>, grid_mid, dim3(256), 0, s, (const float2*)h->d_u, h->d_g, tsp, (long)K * n, ph, tw256, Kz, R, l0, n, n2, M);
+        JRC_HIP(ctx, hipGetLastError());
+        l0 += rc;
+    }
+    JRC_TRY(tsim_rows_launch(h, false, h->d_g, 1, (size_t)n_bursts * R * TS_N1, s));
+    hipLaunchKernelGGL(tsim_col_out_kernel, grid_out, dim3(256), 0, s, (const float2*)h->d_g, out, (long)R * n, (long)n,
+                       (const float2*)h->d_chirp, in, (long)n, sc, h->self_coupling ? 1 : 0, accumulate_out ? 1 : 0, tw256, R, n, n2, M);
+    JRC_HIP(ctx, hipGetLastError());
     return JRC_OK;
 }
 
