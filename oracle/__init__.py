@@ -33,7 +33,7 @@ class RaResult(C.Structure):
 
 def build(force=False):
     """Compile oracle/jrc_oracle*.c with gcc (the checker, not the product)."""
-    srcs = [os.path.join(_HERE, f) for f in ("jrc_oracle.c", "jrc_oracle_comm.c", "jrc_oracle_tsim.c", "jrc_oracle.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("jrc_oracle.c", "jrc_oracle_comm.c", "jrc_oracle_tsim.c", "jrc_oracle_codec.c", "jrc_oracle.h", "Makefile")]
     if (not force and os.path.exists(_LIB_PATH)
             and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
         return _LIB_PATH
@@ -417,3 +417,86 @@ class TargetSimulator:
     def filt_time(self, n, l, k):
         p = self._L.orc_tsim_filt_time(self._h, n, l, k)
         return np.ctypeslib.as_array(p, shape=(2 * n,)).copy().view(np.complex64)
+
+
+# ---- bit codec (oracle/jrc_oracle_codec.c) -----------------------------------------------------------------------
+_u8p = C.POINTER(C.c_uint8)
+
+
+def _codec_lib():
+    L = lib()
+    if not getattr(L, "_codec_ready", False):
+        L.orc_crc32.restype = C.c_uint32
+        L.orc_crc32.argtypes = [_u8p, C.c_size_t]
+        L.orc_stream_encode.argtypes = [C.c_int, C.c_int, _u8p, C.c_int, C.c_int, c_float_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_viterbi_windowed.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _u8p, _u8p]
+        L.orc_stream_decode.argtypes = [C.c_int, C.c_int, C.c_int, c_float_p, _u8p]
+        L.orc_constellation_point.argtypes = [C.c_int, C.c_int, c_float_p, c_float_p]
+        L.orc_constellation_decide.argtypes = [C.c_int, C.c_float, C.c_float]
+        L._codec_ready = True
+    return L
+
+
+def _u8(a):
+    return np.ascontiguousarray(np.frombuffer(bytes(a), np.uint8) if isinstance(a, (bytes, bytearray)) else a, dtype=np.uint8)
+
+
+def crc32(data):
+    d = _u8(data)
+    return int(_codec_lib().orc_crc32(d.ctypes.data_as(_u8p), d.size))
+
+
+def packet_params(mcs, n_dc, data_size_byte):
+    """ofdm_mcs + packet_param (lib/utils.cc:26-111): dict of n_bpsc, n_cbps, n_dbps, n_ofdm_sym, n_data_bits, n_pad_bits"""
+    bpsc = [1, 1, 2, 2, 4, 4][mcs]
+    cbps = n_dc * bpsc
+    dbps = cbps // 2 if mcs % 2 == 0 else cbps * 3 // 4
+    ns = int(np.ceil((16 + 8 * data_size_byte + 6) / float(dbps)))
+    return dict(n_bpsc=bpsc, n_cbps=cbps, n_dbps=dbps, n_ofdm_sym=ns, n_data_bits=ns * dbps,
+                n_pad_bits=ns * dbps - (16 + 8 * data_size_byte + 6), n_encoded_bits=ns * cbps)
+
+
+def stream_encode(mcs, n_dc, psdu, scrambler_init=1):
+    """stream_encoder_impl::general_work (lib/stream_encoder_impl.cc:76-270): returns (symbols [n_sym*n_dc], tags dict)"""
+    L = _codec_lib()
+    p = _u8(psdu)
+    pp = packet_params(mcs, n_dc, p.size + 4)
+    out = np.zeros(pp["n_ofdm_sym"] * n_dc, np.complex64)
+    ns, pl = C.c_int(), C.c_int()
+    n = L.orc_stream_encode(mcs, n_dc, p.ctypes.data_as(_u8p), p.size, scrambler_init, _fp(out), C.byref(ns), C.byref(pl))
+    if n < 0:
+        return None, None
+    assert n == out.size
+    return out, dict(packet_len=n, packet_type=int(p[0]) if p.size else 0, mcs=mcs, pdu_len=pl.value)
+
+
+def viterbi_windowed(mcs, n_sym, n_cbps, n_data_bits, bits):
+    L = _codec_lib()
+    b = _u8(bits)
+    assert b.size == n_sym * n_cbps
+    dec = np.zeros(n_data_bits + 64, np.uint8)
+    n = L.orc_viterbi_windowed(mcs, n_sym, n_cbps, n_data_bits, b.ctypes.data_as(_u8p), dec.ctypes.data_as(_u8p))
+    return dec[:n]
+
+
+def stream_decode(mcs, n_dc, data_size_byte, symbols):
+    """stream_decoder_impl decode()+descramble(): returns (crc_ok, payload bytes without the CRC), or (None, None) if refused"""
+    L = _codec_lib()
+    s = _c64(symbols).ravel()
+    pp = packet_params(mcs, n_dc, data_size_byte)
+    assert s.size >= pp["n_ofdm_sym"] * n_dc
+    out = np.zeros(max(data_size_byte, 8), np.uint8)
+    ok = L.orc_stream_decode(mcs, n_dc, data_size_byte, _fp(s), out.ctypes.data_as(_u8p))
+    if ok < 0:
+        return None, None
+    return bool(ok), out[:max(data_size_byte - 4, 0)].tobytes()
+
+
+def constellation_point(bpsc, value):
+    re, im = C.c_float(), C.c_float()
+    _codec_lib().orc_constellation_point(bpsc, value, C.byref(re), C.byref(im))
+    return complex(re.value, im.value)
+
+
+def constellation_decide(bpsc, z):
+    return _codec_lib().orc_constellation_decide(bpsc, float(np.real(z)), float(np.imag(z)))

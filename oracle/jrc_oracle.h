@@ -160,6 +160,15 @@ int orc_tsim_work(orc_tsim_state* st, const float* in, int n_input, float* const
 /* unnormalised DFT of any length (gr::fft::fft_complex forward/reverse restated), double inside */
 void orc_dft_any(int n, int forward, const float* in, float* out);
 
+/* ---- §8(f) rank 4: bit codec (lib/stream_encoder_impl.cc, lib/stream_decoder_impl.cc, lib/utils.cc, lib/viterbi_decoder.cc) ---- */
+uint32_t orc_crc32(const uint8_t* p, size_t n);
+void orc_constellation_point(int bpsc, int value, float* re, float* im);
+int  orc_constellation_decide(int bpsc, float re, float im);
+int  orc_stream_encode(int mcs, int n_dc, const uint8_t* psdu, int len, int scrambler_init, float* out_sym, int* n_ofdm_sym,
+                       int* pdu_len_tag);
+int  orc_viterbi_windowed(int mcs, int n_sym, int n_cbps, int n_data_bits, const uint8_t* in, uint8_t* decoded);
+int  orc_stream_decode(int mcs, int n_dc, int data_size_byte, const float* sym, uint8_t* out_payload);
+
 #ifdef __cplusplus
 }
 #endif
