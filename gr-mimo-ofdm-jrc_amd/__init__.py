@@ -785,3 +785,95 @@ class target_simulator:
             self.close()
         except Exception:
             pass
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# bit codec (stream_encoder / stream_decoder) on the device
+_u8p = C.POINTER(C.c_uint8)
+MAX_PAYLOAD_SIZE = 3100                     # lib/utils.h
+
+
+def _load_codec():
+    L = load()
+    if not getattr(L, "_codec_ready", False):
+        L.jrc_stream_n_ofdm_sym.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.jrc_stream_encode.argtypes = [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int]
+        L.jrc_stream_encode_dev.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_long, _vp, _vp, _vp, C.c_long, _vp, _vp]
+        L.jrc_stream_decode.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, C.POINTER(C.c_int)]
+        L.jrc_stream_decode_dev.argtypes = [_vp, C.c_int, C.c_int, _vp, C.c_long, _vp, _vp, _vp, C.c_long, _vp, _vp]
+        L._codec_ready = True
+    return L
+
+
+class stream_encoder:
+    """include/mimo_ofdm_jrc/stream_encoder.h:62 make(mod_encode, data_len, N_ss_radar, debug); general_work =
+    lib/stream_encoder_impl.cc:76-270.  PDUs arrive on the `pdu_in` message port in the reference; here work(pdu) takes the
+    bytes and returns the symbols plus the four tags the block attaches (packet_len, packet_type, mcs, pdu_len)."""
+
+    def __init__(self, mod_encode, data_len, N_ss_radar=0, debug=False, ctx=None):
+        self.ctx = ctx or default_context()
+        self.L = _load_codec()
+        if not 0 <= int(mod_encode) <= 5:
+            raise ValueError("wrong encoding")
+        self.mcs, self.data_len = int(mod_encode), int(data_len)
+        self.d_scrambler = 1                                   # :53
+
+    def set_mcs(self, mod_encode):
+        if not 0 <= int(mod_encode) <= 5:
+            raise ValueError("wrong encoding")
+        self.mcs = int(mod_encode)
+
+    def work(self, pdu):
+        p = np.frombuffer(bytes(pdu), np.uint8).copy() if not isinstance(pdu, np.ndarray) else np.ascontiguousarray(pdu, np.uint8)
+        if p.size + 4 > MAX_PAYLOAD_SIZE:                      # printed and dropped (:139-143); the scrambler seed is not advanced
+            return None, None
+        ns = self.L.jrc_stream_n_ofdm_sym(self.mcs, self.data_len, p.size + 4)
+        out = np.zeros(ns * self.data_len, np.complex64)
+        n = self.ctx.check(self.L.jrc_stream_encode(self.ctx.h, self.mcs, self.data_len, _ptr(p) if p.size else None, p.size,
+                                                    self.d_scrambler, _ptr(out), out.size))
+        assert n == out.size
+        self.d_scrambler += 1                                  # scramble(..., d_scrambler++) (:171-175)
+        if self.d_scrambler > 127:
+            self.d_scrambler = 1
+        tags = dict(packet_len=n, packet_type=int(p[0]) if p.size else 0, mcs=self.mcs, pdu_len=p.size + 4)
+        return out, tags
+
+    def encode_dev(self, d_psdu, psdu_stride, d_len, d_scrambler, d_out, sym_stride, d_n_sym, n_frames, stream=None):
+        self.ctx.check(self.L.jrc_stream_encode_dev(self.ctx.h, self.mcs, self.data_len, n_frames, _vp(d_psdu.data_ptr()), psdu_stride,
+                                                    _vp(d_len.data_ptr()), _vp(d_scrambler.data_ptr()), _vp(d_out.data_ptr()),
+                                                    sym_stride, _vp(d_n_sym.data_ptr()), stream))
+
+
+class stream_decoder:
+    """include/mimo_ofdm_jrc/stream_decoder.h:49 make(n_data_carriers, comm_log_file, stats_record, debug); decode() =
+    lib/stream_decoder_impl.cc:205-405.  work(symbols, stream_start) decodes one frame described by the equalizer's
+    stream_start dictionary (data_bytes, mcs, packet_type, snr) and returns what the block publishes on `sym`:
+    (crc_ok, payload bytes); the rolling packet-error rate over 25 frames (:64, :186) is kept in .per."""
+
+    def __init__(self, n_data_carriers, comm_log_file="", stats_record=False, debug=False, ctx=None):
+        self.ctx = ctx or default_context()
+        self.L = _load_codec()
+        self.n_data_carriers = int(n_data_carriers)
+        self._per = []
+
+    @property
+    def per(self):
+        w = self._per[-25:]
+        return 100.0 * (sum(w) / len(w)) if w else 0.0
+
+    def work(self, symbols, stream_start):
+        mcs, nbytes = int(stream_start["mcs"]), int(stream_start["data_bytes"])
+        s = _c64(symbols).ravel()
+        out = np.zeros(max(nbytes, 8), np.uint8)
+        ok = C.c_int(0)
+        n = self.L.jrc_stream_decode(self.ctx.h, mcs, self.n_data_carriers, nbytes, _ptr(s), s.size, _ptr(out), C.byref(ok))
+        if n == JRC_ERR_UNSUPPORTED:
+            return None, None                                  # frame refused, nothing is decoded (:133-146)
+        self.ctx.check(n)
+        self._per.append(0 if ok.value else 1)                 # per_stats(0|1) (:283, :322)
+        return bool(ok.value), out[:n].tobytes()
+
+    def decode_dev(self, d_sym, sym_stride, d_mcs, d_data_bytes, d_payload, payload_stride, d_status, n_frames, stream=None):
+        self.ctx.check(self.L.jrc_stream_decode_dev(self.ctx.h, self.n_data_carriers, n_frames, _vp(d_sym.data_ptr()), sym_stride,
+                                                    _vp(d_mcs.data_ptr()), _vp(d_data_bytes.data_ptr()), _vp(d_payload.data_ptr()),
+                                                    payload_stride, _vp(d_status.data_ptr()), stream))

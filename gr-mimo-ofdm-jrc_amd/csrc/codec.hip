@@ -1,0 +1,386 @@
+// codec.hip — the bit codec around the comm chain on the device, frame-batched:
+//   stream_encoder  lib/stream_encoder_impl.cc:76-270 + lib/utils.cc:26-290 : PDU bytes -> CRC-32 -> bits -> scrambler ->
+//                   K=7 (0155, 0117) convolutional code -> puncturing -> constellation points
+//   stream_decoder  lib/stream_decoder_impl.cc:205-435 + lib/viterbi_decoder.cc:62-330 : hard decisions -> depuncture ->
+//                   windowed Viterbi (byte metrics, 8-bit path chunks, traceback over 5 / 10 chunks) -> descrambler -> CRC
+// Integer work, bit-exact with the reference arithmetic (the __m128i byte lanes of the SSE2 decoder are one trellis state
+// each, here one lane of a wave64 each).  One workgroup (encoder) / one wave (decoder) per frame: frames are the
+// parallel axis, the trellis recursion inside a frame is sequential by nature.
+#include "jrc_internal.h"
+
+#define CODEC_MAX_PAYLOAD 3100                                              // lib/utils.h MAX_PAYLOAD_SIZE
+#define CODEC_MAX_SYM (((16 + 8 * CODEC_MAX_PAYLOAD + 6) / 24) + 1)         // lib/utils.h MAX_SYM
+#define CODEC_MAX_DBPS 4096                                                  // data bits per OFDM symbol this build sizes its LDS for
+#define CODEC_MAX_DATA_BITS (16 + 8 * CODEC_MAX_PAYLOAD + 6 + CODEC_MAX_DBPS) // n_data_bits < payload bits + one symbol
+
+struct McsParams { int n_bpsc, n_cbps, n_dbps, half_rate; };
+
+__host__ __device__ static inline bool mcs_params(int mcs, int n_dc, McsParams& p)   // ofdm_mcs (lib/utils.cc:55-111)
+{
+    if (mcs < 0 || mcs > 5) return false;
+    p.n_bpsc = (mcs < 2) ? 1 : ((mcs < 4) ? 2 : 4);
+    p.n_cbps = n_dc * p.n_bpsc;
+    p.half_rate = (mcs & 1) == 0;
+    p.n_dbps = p.half_rate ? p.n_cbps / 2 : p.n_cbps * 3 / 4;
+    return p.n_dbps >= 1 && p.n_dbps <= CODEC_MAX_DBPS;
+}
+__host__ __device__ static inline int n_sym_for(int data_size_byte, int n_dbps)      // packet_param (:30)
+{
+    const int bits = 16 + 8 * data_size_byte + 6;
+    return (bits + n_dbps - 1) / n_dbps;               // == (int)ceil(bits / (double)n_dbps) for these magnitudes
+}
+
+__device__ __forceinline__ unsigned crc_table_entry(unsigned i)
+{
+    unsigned c = i;
+#pragma unroll
+    for (int b = 0; b < 8; b++) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
+    return c;
+}
+
+__device__ __forceinline__ float2 constellation_point(int bpsc, int v)     // gr::digital bpsk / qpsk (/2, :218-221) / 16qam
+{
+    if (bpsc == 1) return make_float2(v ? 1.0f : -1.0f, 0.0f);
+    if (bpsc == 2) {
+        const float s = 0.707107f;
+        return make_float2(((v & 1) ? s : -s) / 2.0f, ((v & 2) ? s : -s) / 2.0f);
+    }
+    const float level = 0.316227766016837933f;                             // sqrt(float(0.1)) rounded to float
+    const float a = (v & 2) ? 1.0f : 3.0f, b = (v & 8) ? 1.0f : 3.0f;
+    return make_float2(((v & 1) ? a : -a) * level, ((v & 4) ? b : -b) * level);
+}
+__device__ __forceinline__ int constellation_decide(int bpsc, float2 z)
+{
+    if (bpsc == 1) return z.x > 0;
+    if (bpsc == 2) return 2 * (z.y > 0) + (z.x > 0);
+    const float level = 0.316227766016837933f;
+    return (z.x > 0) | ((fabsf(z.x) < 2 * level) << 1) | ((z.y > 0) << 2) | ((fabsf(z.y) < 2 * level) << 3);
+}
+
+// ---- encoder: one workgroup per PDU ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void stream_encode_kernel(int mcs, int n_dc, const unsigned char* __restrict__ psdu, long psdu_stride,
+                                                            const int* __restrict__ lens, const unsigned char* __restrict__ scr_init,
+                                                            float2* __restrict__ out, long sym_stride, int* __restrict__ n_sym_out)
+{
+    __shared__ unsigned crc_tab[256];
+    __shared__ unsigned char seq[128];
+    __shared__ unsigned fcs_s;
+    extern __shared__ unsigned char sbits[];                               // scrambled data bits, one per byte
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int len = lens[f];
+    McsParams p;
+    mcs_params(mcs, n_dc, p);
+    if (len < 0 || len + 4 > CODEC_MAX_PAYLOAD) {                          // :139-143: "Data Packet too Large" -> nothing is produced
+        if (tid == 0) n_sym_out[f] = 0;
+        return;
+    }
+    const unsigned char* pk = psdu + (size_t)f * psdu_stride;
+    const int dsb = len + 4;
+    const int n_sym = n_sym_for(dsb, p.n_dbps);
+    const int ndb = n_sym * p.n_dbps, npad = ndb - (16 + 8 * dsb + 6);
+    crc_tab[tid] = crc_table_entry(tid);
+    __syncthreads();
+    if (tid == 0) {                                                        // boost::crc_32_type over the PDU (:150-153)
+        unsigned c = 0xFFFFFFFFu;
+        for (int i = 0; i < len; i++) c = crc_tab[(c ^ pk[i]) & 0xff] ^ (c >> 8);
+        fcs_s = c ^ 0xFFFFFFFFu;
+    }
+    if (tid == 64) {                                                       // scrambler sequence (period 127) for this PDU's state (:151-162)
+        int state = (signed char)scr_init[f];
+        for (int i = 0; i < 127; i++) {
+            const int fb = (!!(state & 64)) ^ (!!(state & 8));
+            seq[i] = (unsigned char)fb;
+            state = ((state << 1) & 0x7e) | fb;
+        }
+    }
+    __syncthreads();
+    const unsigned fcs = fcs_s;
+    for (int i = tid; i < ndb; i += 256) {                                 // generate_bits + scramble + reset_tail_bits
+        int bit = 0;
+        if (i >= 16 && i < 16 + 8 * dsb) {
+            const int by = (i - 16) >> 3, b = (i - 16) & 7;
+            const unsigned v = by < len ? pk[by] : (fcs >> (8 * (by - len))) & 0xff;
+            bit = (v >> b) & 1;
+        }
+        bit ^= seq[i % 127];
+        const int tail = ndb - npad - 6;
+        if (i >= tail && i < tail + 6) bit = 0;
+        sbits[i] = (unsigned char)bit;
+    }
+    __syncthreads();
+    float2* o = out + (size_t)f * sym_stride;
+    const int nsymb = n_sym * n_dc;
+    for (int j = tid; j < nsymb; j += 256) {                               // convolutional code + puncturing + split + mapping
+        int v = 0;
+        for (int k = 0; k < p.n_bpsc; k++) {
+            const int c = j * p.n_bpsc + k;                                // index in the punctured stream
+            int e = c;
+            if (!p.half_rate) { const int q = c >> 2, r = c & 3; e = 6 * q + (r == 3 ? 5 : r); }   // kept positions 0,1,2,5 of every 6 (:211-216)
+            const int i = e >> 1;
+            int reg = 0;                                                   // encoder register after bit i: bit d = in[i - d]
+#pragma unroll
+            for (int d = 0; d < 7; d++) if (i - d >= 0) reg |= sbits[i - d] << d;
+            const int taps = (e & 1) ? 0117 : 0155;
+            v |= (__popc(reg & taps) & 1) << k;
+        }
+        o[j] = constellation_point(p.n_bpsc, v);
+    }
+    if (tid == 0) n_sym_out[f] = nsymb;
+}
+
+// ---- decoder: one wave per frame, lane = trellis state -----------------------------------------------
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ int wave_min_i32(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off));
+    return v;
+}
+
+#define DEC_WAVES 4      // frames per workgroup
+
+__global__ __launch_bounds__(64 * DEC_WAVES) void stream_decode_kernel(int n_dc, int n_frames, const float2* __restrict__ sym, long sym_stride,
+                                                                       const int* __restrict__ mcs_arr, const int* __restrict__ bytes_arr,
+                                                                       unsigned char* __restrict__ payload, long payload_stride,
+                                                                       int* __restrict__ status)
+{
+    // per wave: coded hard bits (packed), decoded bytes, path ring
+    __shared__ unsigned coded[DEC_WAVES][(2 * CODEC_MAX_DATA_BITS + 31) / 32 + 1];
+    __shared__ unsigned char decoded[DEC_WAVES][CODEC_MAX_DATA_BITS / 8 + 16];
+    __shared__ unsigned char ring[DEC_WAVES][10][64];
+    __shared__ unsigned char seq[DEC_WAVES][128];
+    __shared__ unsigned crc_tab[256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int f = blockIdx.x * DEC_WAVES + w;
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) crc_tab[i] = crc_table_entry(i);
+    __syncthreads();
+    if (f >= n_frames) return;
+    const int mcs = mcs_arr[f], dsb = bytes_arr[f];
+    McsParams p;
+    if (!mcs_params(mcs, n_dc, p) || dsb < 0 || dsb > CODEC_MAX_PAYLOAD || n_sym_for(dsb, p.n_dbps) > CODEC_MAX_SYM) {   // :133-146
+        if (lane == 0) status[f] = -1;
+        return;
+    }
+    const int n_sym = n_sym_for(dsb, p.n_dbps);
+    const int ndb = n_sym * p.n_dbps, n_coded = n_sym * p.n_cbps;
+    const float2* s = sym + (size_t)f * sym_stride;
+    unsigned* cb = coded[w];
+    // hard decisions (decision_maker, :166-169) -> packed bit array of the punctured stream
+    const int words = (n_coded + 31) / 32;
+    for (int wi = lane; wi < words; wi += 64) {
+        unsigned acc = 0;
+        for (int b = 0; b < 32; b++) {
+            const int c = wi * 32 + b;
+            if (c < n_coded) {
+                const int j = c / p.n_bpsc, k = c % p.n_bpsc;
+                acc |= (unsigned)((constellation_decide(p.n_bpsc, s[j]) >> k) & 1) << b;
+            }
+        }
+        cb[wi] = acc;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0);
+    // trellis: lane = new state s; butterfly k = s >> 1 reads old states k and k + 32 (viterbi_butterfly2_sse2, :87-180)
+    const int k = lane >> 1, odd = lane & 1;
+    const int bt0 = __popc((2 * k) & 0x6d) & 1, bt1 = __popc((2 * k) & 0x4f) & 1;       // d_branchtab27_sse2 (:323-326)
+    const int nt = p.half_rate ? 5 : 10;                                                // reset() (:293-315)
+    unsigned st = 0;                                                                    // metric | path << 8
+    const int n_calls = nt + (ndb + 7) / 8;                                             // get_output calls until n_decoded >= n_data_bits
+    const int n_steps = 6 + 8 * (n_calls - 1);
+    int store_pos = 0, out_count = 0;
+    for (int i = lane; i < 10 * 64; i += 64) (&ring[w][0][0])[i] = 0;
+    __builtin_amdgcn_wave_barrier();
+    for (int t = 0; t < n_steps; t++) {
+        // the two symbols of this step in the depunctured stream (2 = erasure; past the end of the frame = 0)
+        int s0, s1;
+        {
+            const int e0 = 2 * t, e1 = 2 * t + 1;
+            auto fetch = [&](int e) -> int {
+                int c;
+                if (p.half_rate) c = e;
+                else { const int q = e / 6, r = e % 6; if (r == 3 || r == 4) return (e < 2 * ndb) ? 2 : 0; c = 4 * q + (r == 5 ? 3 : r); }
+                if (c >= n_coded) return 0;
+                return (cb[c >> 5] >> (c & 31)) & 1;
+            };
+            s0 = fetch(e0); s1 = fetch(e1);
+        }
+        int metsvm, metsv;
+        if (s0 == 2) { metsvm = bt1 ^ s1; metsv = 1 - metsvm; }
+        else if (s1 == 2) { metsvm = bt0 ^ s0; metsv = 1 - metsvm; }
+        else { metsvm = (bt0 ^ s0) + (bt1 ^ s1); metsv = 2 - metsvm; }
+        const unsigned a = __shfl(st, k), b = __shfl(st, k + 32);
+        const int ma = a & 0xff, mb = b & 0xff;
+        // even new state: m0 = ma + metsv vs m1 = mb + metsvm ; odd: m2 = ma + metsvm vs m3 = mb + metsv
+        const int x = (ma + (odd ? metsvm : metsv)) & 0xff, y = (mb + (odd ? metsv : metsvm)) & 0xff;
+        const int dec = (signed char)((x - y) & 0xff) > 0;                              // _mm_cmpgt_epi8(_mm_sub_epi8(m0, m1), 0)
+        const unsigned pa = ((a >> 8) << 1) & 0xff, pb = ((((b >> 8) << 1) & 0xff) + 1) & 0xff;
+        st = (unsigned)(dec ? x : y) | ((dec ? pa : pb) << 8);
+        if (t >= 5 && ((t - 5) & 7) == 0) {                                             // viterbi_get_output_sse2 (:183-225) after steps 6, 14, 22, ...
+            store_pos = (store_pos + 1) % nt;
+            const int metric = st & 0xff;
+            ring[w][store_pos][lane] = (unsigned char)(st >> 8);
+            const int best = wave_max_i32(metric), mn = wave_min_i32(metric);
+            int beststate = __ffsll((unsigned long long)__ballot(metric == best)) - 1;  // first maximum (strict > in the scan)
+            __builtin_amdgcn_wave_barrier();
+            int pos = store_pos;
+            for (int i = 0; i < nt - 1; i++) {
+                beststate = ring[w][pos][beststate] >> 2;
+                pos = (pos - 1 + nt) % nt;
+            }
+            const unsigned char c = ring[w][pos][beststate];
+            if (out_count >= nt && lane == 0) decoded[w][out_count - nt] = c;           // bits MSB first (:277-281)
+            out_count++;
+            st = (unsigned)((metric - mn) & 0xff);                                      // paths zeroed, metrics renormalised
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // descramble (:406-433): state from the first 7 decoded bits, then the same x^7 + x^4 + 1 sequence
+    const unsigned char* db = decoded[w];
+    auto dbit = [&](int i) -> int { return (db[i >> 3] >> (7 - (i & 7))) & 1; };
+    int state = 0;
+    for (int i = 0; i < 7; i++) if (dbit(i)) state |= 1 << (6 - i);
+    if (lane == 0) {
+        int stt = state;
+        for (int i = 0; i < 127; i++) {
+            const int fb = (!!(stt & 64)) ^ (!!(stt & 8));
+            seq[w][i] = (unsigned char)fb;
+            stt = ((stt << 1) & 0x7e) | fb;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // out_bytes[2 ...] (the PSDU incl. CRC): bit i of the stream, i >= 16, is decoded[i] ^ seq[(i - 7) % 127]
+    unsigned char* pl = payload + (size_t)f * payload_stride;
+    // bytes are produced in place over the front of a scratch region: reuse `coded` (no longer needed) as the byte buffer
+    unsigned char* bytes = reinterpret_cast<unsigned char*>(cb);
+    for (int by = lane; by < dsb; by += 64) {
+        int v = 0;
+        for (int b = 0; b < 8; b++) {
+            const int i = 16 + by * 8 + b;
+            v |= (dbit(i) ^ seq[w][(i - 7) % 127]) << b;
+        }
+        bytes[by] = (unsigned char)v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        unsigned c = 0xFFFFFFFFu;
+        for (int i = 0; i < dsb; i++) c = crc_tab[(c ^ bytes[i]) & 0xff] ^ (c >> 8);
+        status[f] = ((c ^ 0xFFFFFFFFu) == 558161692u) ? 1 : 0;                          // :245-246
+    }
+    for (int by = lane; by < dsb - 4; by += 64) pl[by] = bytes[by];
+}
+
+// ---- C ABI ------------------------------------------------------------------------------------------
+extern "C" int jrc_stream_n_ofdm_sym(int mcs, int n_data_carriers, int data_size_byte)
+{
+    McsParams p;
+    if (!mcs_params(mcs, n_data_carriers, p) || data_size_byte < 0) return JRC_ERR_INVALID_ARG;
+    return n_sym_for(data_size_byte, p.n_dbps);
+}
+
+extern "C" int jrc_stream_encode_dev(jrc_ctx* ctx, int mcs, int n_data_carriers, int n_frames, const uint8_t* d_psdu, long psdu_stride,
+                                     const int* d_len, const uint8_t* d_scrambler, jrc_cf32* d_out, long sym_stride, int* d_n_sym,
+                                     void* stream)
+{
+    if (!ctx) return JRC_ERR_INVALID_ARG;
+    McsParams p;
+    if (!mcs_params(mcs, n_data_carriers, p) || n_data_carriers < 1)
+        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "stream_encoder: wrong encoding %d", mcs);       // std::invalid_argument("wrong encoding")
+    if (n_frames < 0 || (n_frames > 0 && (!d_psdu || !d_len || !d_scrambler || !d_out || !d_n_sym)))
+        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "stream_encoder: invalid arguments");
+    if (n_frames == 0) return JRC_OK;
+    JRC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    const size_t lds = (size_t)CODEC_MAX_DATA_BITS;
+    hipLaunchKernelGGL(stream_encode_kernel, dim3(n_frames), dim3(256), lds, s, mcs, n_data_carriers, d_psdu, psdu_stride, d_len,
+                       d_scrambler, (float2*)d_out, sym_stride, d_n_sym);
+    JRC_HIP(ctx, hipGetLastError());
+    return JRC_OK;
+}
+
+extern "C" int jrc_stream_decode_dev(jrc_ctx* ctx, int n_data_carriers, int n_frames, const jrc_cf32* d_sym, long sym_stride,
+                                     const int* d_mcs, const int* d_data_bytes, uint8_t* d_payload, long payload_stride, int* d_status,
+                                     void* stream)
+{
+    if (!ctx) return JRC_ERR_INVALID_ARG;
+    if (n_data_carriers < 1 || n_frames < 0 || (n_frames > 0 && (!d_sym || !d_mcs || !d_data_bytes || !d_payload || !d_status)))
+        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "stream_decoder: invalid arguments");
+    if (n_frames == 0) return JRC_OK;
+    JRC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    hipLaunchKernelGGL(stream_decode_kernel, dim3((n_frames + DEC_WAVES - 1) / DEC_WAVES), dim3(64 * DEC_WAVES), 0, s, n_data_carriers,
+                       n_frames, (const float2*)d_sym, sym_stride, d_mcs, d_data_bytes, d_payload, payload_stride, d_status);
+    JRC_HIP(ctx, hipGetLastError());
+    return JRC_OK;
+}
+
+// host-buffer forms (one PDU / one frame), as the blocks' general_work would call them
+extern "C" int jrc_stream_encode(jrc_ctx* ctx, int mcs, int n_data_carriers, const uint8_t* psdu, int len, int scrambler_init,
+                                 jrc_cf32* out_symbols, int out_capacity)
+{
+    if (!ctx || len < 0 || (len > 0 && !psdu)) return JRC_ERR_INVALID_ARG;
+    McsParams p;
+    if (!mcs_params(mcs, n_data_carriers, p)) return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "stream_encoder: wrong encoding %d", mcs);
+    if (len + 4 > CODEC_MAX_PAYLOAD) return 0;                                              // :139-143
+    const int nsymb = n_sym_for(len + 4, p.n_dbps) * n_data_carriers;
+    if (!out_symbols || out_capacity < nsymb) return jrc_fail(ctx, JRC_ERR_SHORT_INPUT, "stream_encoder: output holds %d symbols, %d needed", out_capacity, nsymb);
+    JRC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t in_bytes = ((size_t)len + 15) & ~(size_t)15, meta = 16, out_bytes = sizeof(float2) * (size_t)nsymb;
+    JRC_TRY(jrc_ensure_pinned(ctx, in_bytes + meta + out_bytes + 16));
+    JRC_TRY(jrc_ensure_scratch(ctx, 0, in_bytes + meta));
+    JRC_TRY(jrc_ensure_scratch(ctx, 1, out_bytes + 16));
+    char* pin = (char*)ctx->pinned;
+    if (len) memcpy(pin, psdu, (size_t)len);
+    int* meta_h = (int*)(pin + in_bytes);
+    meta_h[0] = len; ((unsigned char*)&meta_h[1])[0] = (unsigned char)scrambler_init;
+    JRC_HIP(ctx, hipMemcpyAsync(ctx->scratch[0], pin, in_bytes + meta, hipMemcpyHostToDevice, ctx->stream));
+    char* d0 = (char*)ctx->scratch[0];
+    char* d1 = (char*)ctx->scratch[1];
+    JRC_TRY(jrc_stream_encode_dev(ctx, mcs, n_data_carriers, 1, (const uint8_t*)d0, (long)in_bytes, (const int*)(d0 + in_bytes),
+                                  (const uint8_t*)(d0 + in_bytes + 4), (jrc_cf32*)(d1 + 16), nsymb, (int*)d1, ctx->stream));
+    JRC_HIP(ctx, hipMemcpyAsync(pin + in_bytes + meta, d1, out_bytes + 16, hipMemcpyDeviceToHost, ctx->stream));
+    JRC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int produced = *(int*)(pin + in_bytes + meta);
+    memcpy(out_symbols, pin + in_bytes + meta + 16, out_bytes);
+    return produced;
+}
+
+extern "C" int jrc_stream_decode(jrc_ctx* ctx, int mcs, int n_data_carriers, int data_size_byte, const jrc_cf32* symbols, int n_symbols,
+                                 uint8_t* out_payload, int* crc_ok)
+{
+    if (!ctx || !crc_ok) return JRC_ERR_INVALID_ARG;
+    McsParams p;
+    *crc_ok = 0;
+    if (!mcs_params(mcs, n_data_carriers, p) || data_size_byte < 0 || data_size_byte > CODEC_MAX_PAYLOAD ||
+        n_sym_for(data_size_byte, p.n_dbps) > CODEC_MAX_SYM)
+        return JRC_ERR_UNSUPPORTED;                                                         // frame refused (:133-146)
+    const int need = n_sym_for(data_size_byte, p.n_dbps) * n_data_carriers;
+    if (!symbols || n_symbols < need) return jrc_fail(ctx, JRC_ERR_SHORT_INPUT, "stream_decoder: %d symbols given, %d needed", n_symbols, need);
+    if (data_size_byte > 4 && !out_payload) return JRC_ERR_INVALID_ARG;
+    JRC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t sb = sizeof(float2) * (size_t)need, pb = ((size_t)data_size_byte + 15) & ~(size_t)15;
+    JRC_TRY(jrc_ensure_pinned(ctx, sb + 16 + pb + 16));
+    JRC_TRY(jrc_ensure_scratch(ctx, 0, sb + 16));
+    JRC_TRY(jrc_ensure_scratch(ctx, 1, pb + 16));
+    char* pin = (char*)ctx->pinned;
+    int* meta = (int*)pin;
+    meta[0] = mcs; meta[1] = data_size_byte;
+    memcpy(pin + 16, symbols, sb);
+    JRC_HIP(ctx, hipMemcpyAsync(ctx->scratch[0], pin, sb + 16, hipMemcpyHostToDevice, ctx->stream));
+    char* d0 = (char*)ctx->scratch[0];
+    char* d1 = (char*)ctx->scratch[1];
+    JRC_TRY(jrc_stream_decode_dev(ctx, n_data_carriers, 1, (const jrc_cf32*)(d0 + 16), need, (const int*)d0, (const int*)(d0 + 4),
+                                  (uint8_t*)(d1 + 16), (long)pb, (int*)d1, ctx->stream));
+    JRC_HIP(ctx, hipMemcpyAsync(pin + sb + 16, d1, pb + 16, hipMemcpyDeviceToHost, ctx->stream));
+    JRC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int st = *(int*)(pin + sb + 16);
+    if (st < 0) return JRC_ERR_UNSUPPORTED;
+    *crc_ok = st;
+    if (data_size_byte > 4) memcpy(out_payload, pin + sb + 16 + 16, (size_t)data_size_byte - 4);
+    return data_size_byte > 4 ? data_size_byte - 4 : 0;
+}

@@ -325,6 +325,33 @@ int jrc_tsim_run_dev(jrc_tsim* h, int n_bursts, int n_input, const jrc_cf32* d_i
                      const jrc_cf32* target_phase, int accumulate_out, void* stream);
 int jrc_tsim_burst_capacity(const jrc_tsim* h);
 
+/* ---- bit codec.  stream_encoder (lib/stream_encoder_impl.cc:76-270, make(mod_encode, data_len,
+ * N_ss_radar, debug) in include/mimo_ofdm_jrc/stream_encoder.h:62) and stream_decoder (lib/stream_decoder_impl.cc:100-435,
+ * make(n_data_carriers, comm_log_file, stats_record, debug)); mcs = the reference's MCS enum 0..5
+ * (BPSK 1/2, 3/4, QPSK 1/2, 3/4, 16QAM 1/2, 3/4), payloads up to 3100 bytes incl. CRC (lib/utils.h MAX_PAYLOAD_SIZE). ---- */
+/* packet_param::n_ofdm_sym for data_size_byte bytes (PDU + 4 CRC bytes) */
+int jrc_stream_n_ofdm_sym(int mcs, int n_data_carriers, int data_size_byte);
+/* one PDU -> n_ofdm_sym * n_data_carriers constellation points.  psdu[0] is the packet type byte exactly as the block
+ * receives it; scrambler_init = the block's d_scrambler (1..127).  Returns the number of symbols written, 0 if the PDU is
+ * too large (the reference prints and drops it, :139-143), negative on error. */
+int jrc_stream_encode(jrc_ctx* ctx, int mcs, int n_data_carriers, const uint8_t* psdu, int len, int scrambler_init,
+                      jrc_cf32* out_symbols, int out_capacity);
+/* batched: d_psdu [n_frames][psdu_stride] bytes, d_len[n_frames], d_scrambler[n_frames] -> d_out [n_frames][sym_stride],
+ * d_n_sym[n_frames] = symbols produced per PDU (0 = dropped).  Asynchronous on `stream`. */
+int jrc_stream_encode_dev(jrc_ctx* ctx, int mcs, int n_data_carriers, int n_frames, const uint8_t* d_psdu, long psdu_stride,
+                          const int* d_len, const uint8_t* d_scrambler, jrc_cf32* d_out, long sym_stride, int* d_n_sym,
+                          void* stream);
+/* one equalised frame (n_ofdm_sym * n_data_carriers symbols; mcs / data_size_byte from the stream_start tag, :118-131) ->
+ * payload bytes (PSDU without CRC, data_size_byte - 4 of them).  *crc_ok = 1 when the CRC-32 residue matches (:246).
+ * Returns the payload length, JRC_ERR_UNSUPPORTED when the reference would refuse the frame (:133-146). */
+int jrc_stream_decode(jrc_ctx* ctx, int mcs, int n_data_carriers, int data_size_byte, const jrc_cf32* symbols, int n_symbols,
+                      uint8_t* out_payload, int* crc_ok);
+/* batched: d_sym [n_frames][sym_stride], d_mcs / d_data_bytes [n_frames] -> d_payload [n_frames][payload_stride],
+ * d_status[n_frames] = 1 (CRC ok), 0 (CRC wrong), -1 (refused).  Asynchronous on `stream`. */
+int jrc_stream_decode_dev(jrc_ctx* ctx, int n_data_carriers, int n_frames, const jrc_cf32* d_sym, long sym_stride,
+                          const int* d_mcs, const int* d_data_bytes, uint8_t* d_payload, long payload_stride, int* d_status,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif
