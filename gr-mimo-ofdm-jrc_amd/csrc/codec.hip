@@ -144,23 +144,25 @@ __device__ __forceinline__ int wave_min_i32(int v)
 
 #define DEC_WAVES 4      // frames per workgroup
 
+// Hard decisions never touch memory: every 64 coded bits, lane i loads the symbol that carries coded bit c0 + i (issued one
+// block ahead), decides it (decision_maker, :166-169) and a wave ballot turns the 64 decisions into one scalar bit word.
+// Decoded bytes are descrambled and fed to the CRC as they leave the traceback, so the only LDS is the path ring.
 __global__ __launch_bounds__(64 * DEC_WAVES) void stream_decode_kernel(int n_dc, int n_frames, const float2* __restrict__ sym, long sym_stride,
                                                                        const int* __restrict__ mcs_arr, const int* __restrict__ bytes_arr,
                                                                        unsigned char* __restrict__ payload, long payload_stride,
                                                                        int* __restrict__ status)
 {
-    // per wave: coded hard bits (packed), decoded bytes, path ring
-    __shared__ unsigned coded[DEC_WAVES][(2 * CODEC_MAX_DATA_BITS + 31) / 32 + 1];
-    __shared__ unsigned char decoded[DEC_WAVES][CODEC_MAX_DATA_BITS / 8 + 16];
     __shared__ unsigned char ring[DEC_WAVES][10][64];
-    __shared__ unsigned char seq[DEC_WAVES][128];
     __shared__ unsigned crc_tab[256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int f = blockIdx.x * DEC_WAVES + w;
     for (int i = threadIdx.x; i < 256; i += blockDim.x) crc_tab[i] = crc_table_entry(i);
+    for (int i = lane; i < 10 * 64; i += 64) (&ring[w][0][0])[i] = 0;                   // d_ppresult zeroed (:333-337)
     __syncthreads();
     if (f >= n_frames) return;
-    const int mcs = mcs_arr[f], dsb = bytes_arr[f];
+    // everything that depends only on the frame is wave-uniform: keep it in scalar registers so the control flow below is
+    // scalar branches, not exec-masked vector code
+    const int mcs = __builtin_amdgcn_readfirstlane(mcs_arr[f]), dsb = __builtin_amdgcn_readfirstlane(bytes_arr[f]);
     McsParams p;
     if (!mcs_params(mcs, n_dc, p) || dsb < 0 || dsb > CODEC_MAX_PAYLOAD || n_sym_for(dsb, p.n_dbps) > CODEC_MAX_SYM) {   // :133-146
         if (lane == 0) status[f] = -1;
@@ -169,45 +171,55 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void stream_decode_kernel(int n_dc,
     const int n_sym = n_sym_for(dsb, p.n_dbps);
     const int ndb = n_sym * p.n_dbps, n_coded = n_sym * p.n_cbps;
     const float2* s = sym + (size_t)f * sym_stride;
-    unsigned* cb = coded[w];
-    // hard decisions (decision_maker, :166-169) -> packed bit array of the punctured stream
-    const int words = (n_coded + 31) / 32;
-    for (int wi = lane; wi < words; wi += 64) {
-        unsigned acc = 0;
-        for (int b = 0; b < 32; b++) {
-            const int c = wi * 32 + b;
-            if (c < n_coded) {
-                const int j = c / p.n_bpsc, k = c % p.n_bpsc;
-                acc |= (unsigned)((constellation_decide(p.n_bpsc, s[j]) >> k) & 1) << b;
-            }
-        }
-        cb[wi] = acc;
-    }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0);
-    // trellis: lane = new state s; butterfly k = s >> 1 reads old states k and k + 32 (viterbi_butterfly2_sse2, :87-180)
+    unsigned char* pl = payload + (size_t)f * payload_stride;
+    const int bpsc = p.n_bpsc, half_rate = p.half_rate;
+
+    // coded-bit source
+    auto load_sym = [&](int c0) -> float2 {
+        const int c = c0 + lane;
+        return (c < n_coded) ? s[c / bpsc] : make_float2(-1.f, -1.f);                  // past the frame: decides to 0
+    };
+    auto decide_word = [&](float2 z, int c0) -> unsigned long long {
+        const int c = c0 + lane;
+        const int bit = (c < n_coded) ? ((constellation_decide(bpsc, z) >> (c % bpsc)) & 1) : 0;
+        return __ballot(bit);
+    };
+    float2 z_pending = load_sym(0);
+    unsigned long long word = decide_word(z_pending, 0);
+    z_pending = load_sym(64);
+    int wbase = 0, wpos = 0;                  // wpos = bits of `word` already consumed
+    auto next_bit = [&]() -> int {
+        const int b = (int)((word >> wpos) & 1ull);
+        wpos++;
+        return b;
+    };
+
+    // trellis: lane = new state; butterfly k = lane >> 1 reads old states k and k + 32 (viterbi_butterfly2_sse2, :87-180)
     const int k = lane >> 1, odd = lane & 1;
     const int bt0 = __popc((2 * k) & 0x6d) & 1, bt1 = __popc((2 * k) & 0x4f) & 1;       // d_branchtab27_sse2 (:323-326)
-    const int nt = p.half_rate ? 5 : 10;                                                // reset() (:293-315)
+    const int nt = half_rate ? 5 : 10;                                                  // reset() (:293-315)
     unsigned st = 0;                                                                    // metric | path << 8
     const int n_calls = nt + (ndb + 7) / 8;                                             // get_output calls until n_decoded >= n_data_bits
     const int n_steps = 6 + 8 * (n_calls - 1);
-    int store_pos = 0, out_count = 0;
-    for (int i = lane; i < 10 * 64; i += 64) (&ring[w][0][0])[i] = 0;
-    __builtin_amdgcn_wave_barrier();
+    int store_pos = 0, out_count = 0, phase3 = 0;
+    int lfsr = 0;
+    unsigned crc = 0xFFFFFFFFu;
     for (int t = 0; t < n_steps; t++) {
-        // the two symbols of this step in the depunctured stream (2 = erasure; past the end of the frame = 0)
-        int s0, s1;
-        {
-            const int e0 = 2 * t, e1 = 2 * t + 1;
-            auto fetch = [&](int e) -> int {
-                int c;
-                if (p.half_rate) c = e;
-                else { const int q = e / 6, r = e % 6; if (r == 3 || r == 4) return (e < 2 * ndb) ? 2 : 0; c = 4 * q + (r == 5 ? 3 : r); }
-                if (c >= n_coded) return 0;
-                return (cb[c >> 5] >> (c & 31)) & 1;
-            };
-            s0 = fetch(e0); s1 = fetch(e1);
+        int s0 = 0, s1 = 0;                                                             // past the end of the frame: 0 (fresh buffers)
+        if (t < ndb) {
+            // a word runs out only on a step boundary: 64 bits = 32 steps at rate 1/2, 48 steps (phase 0) at rate 3/4
+            if (wpos == 64) {
+                wbase += 64; wpos = 0;
+                word = decide_word(z_pending, wbase);
+                z_pending = load_sym(wbase + 64);
+            }
+            if (half_rate) { s0 = next_bit(); s1 = next_bit(); }
+            else {                                                                      // depuncture (:236-252): pattern 1,1,1,0,0,1
+                if (phase3 == 0) { s0 = next_bit(); s1 = next_bit(); }
+                else if (phase3 == 1) { s0 = next_bit(); s1 = 2; }
+                else { s0 = 2; s1 = next_bit(); }
+                phase3 = (phase3 == 2) ? 0 : phase3 + 1;
+            }
         }
         int metsvm, metsv;
         if (s0 == 2) { metsvm = bt1 ^ s1; metsv = 1 - metsvm; }
@@ -221,7 +233,7 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void stream_decode_kernel(int n_dc,
         const unsigned pa = ((a >> 8) << 1) & 0xff, pb = ((((b >> 8) << 1) & 0xff) + 1) & 0xff;
         st = (unsigned)(dec ? x : y) | ((dec ? pa : pb) << 8);
         if (t >= 5 && ((t - 5) & 7) == 0) {                                             // viterbi_get_output_sse2 (:183-225) after steps 6, 14, 22, ...
-            store_pos = (store_pos + 1) % nt;
+            store_pos = (store_pos + 1 == nt) ? 0 : store_pos + 1;
             const int metric = st & 0xff;
             ring[w][store_pos][lane] = (unsigned char)(st >> 8);
             const int best = wave_max_i32(metric), mn = wave_min_i32(metric);
@@ -230,49 +242,36 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void stream_decode_kernel(int n_dc,
             int pos = store_pos;
             for (int i = 0; i < nt - 1; i++) {
                 beststate = ring[w][pos][beststate] >> 2;
-                pos = (pos - 1 + nt) % nt;
+                pos = (pos == 0) ? nt - 1 : pos - 1;
             }
-            const unsigned char c = ring[w][pos][beststate];
-            if (out_count >= nt && lane == 0) decoded[w][out_count - nt] = c;           // bits MSB first (:277-281)
-            out_count++;
+            const int c = __builtin_amdgcn_readfirstlane((int)ring[w][pos][beststate]);
             st = (unsigned)((metric - mn) & 0xff);                                      // paths zeroed, metrics renormalised
+            if (out_count >= nt) {                                                      // decoded bits, MSB first (:277-281)
+                const int j = out_count - nt;                                           // byte j = stream bits 8j .. 8j+7
+                int ob = 0;
+                if (j == 0) {                                                           // descramble (:406-433): state from bits 0..6
+                    lfsr = (c >> 1) & 0x7f;
+                    const int fb = (!!(lfsr & 64)) ^ (!!(lfsr & 8));                    // bit 7 belongs to out_bytes[0] (unused)
+                    lfsr = ((lfsr << 1) & 0x7e) | fb;
+                } else {
+#pragma unroll
+                    for (int bb = 0; bb < 8; bb++) {
+                        const int fb = (!!(lfsr & 64)) ^ (!!(lfsr & 8));
+                        ob |= (fb ^ ((c >> (7 - bb)) & 1)) << bb;
+                        lfsr = ((lfsr << 1) & 0x7e) | fb;
+                    }
+                }
+                const int by = j - 2;                                                   // out_bytes + 2 = PSDU incl. CRC
+                if (by >= 0 && by < dsb) {
+                    crc = crc_tab[(crc ^ (unsigned)ob) & 0xff] ^ (crc >> 8);
+                    if (by < dsb - 4 && lane == 0) pl[by] = (unsigned char)ob;
+                }
+            }
+            out_count++;
             __builtin_amdgcn_wave_barrier();
         }
     }
-    __builtin_amdgcn_wave_barrier();
-    // descramble (:406-433): state from the first 7 decoded bits, then the same x^7 + x^4 + 1 sequence
-    const unsigned char* db = decoded[w];
-    auto dbit = [&](int i) -> int { return (db[i >> 3] >> (7 - (i & 7))) & 1; };
-    int state = 0;
-    for (int i = 0; i < 7; i++) if (dbit(i)) state |= 1 << (6 - i);
-    if (lane == 0) {
-        int stt = state;
-        for (int i = 0; i < 127; i++) {
-            const int fb = (!!(stt & 64)) ^ (!!(stt & 8));
-            seq[w][i] = (unsigned char)fb;
-            stt = ((stt << 1) & 0x7e) | fb;
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    // out_bytes[2 ...] (the PSDU incl. CRC): bit i of the stream, i >= 16, is decoded[i] ^ seq[(i - 7) % 127]
-    unsigned char* pl = payload + (size_t)f * payload_stride;
-    // bytes are produced in place over the front of a scratch region: reuse `coded` (no longer needed) as the byte buffer
-    unsigned char* bytes = reinterpret_cast<unsigned char*>(cb);
-    for (int by = lane; by < dsb; by += 64) {
-        int v = 0;
-        for (int b = 0; b < 8; b++) {
-            const int i = 16 + by * 8 + b;
-            v |= (dbit(i) ^ seq[w][(i - 7) % 127]) << b;
-        }
-        bytes[by] = (unsigned char)v;
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) {
-        unsigned c = 0xFFFFFFFFu;
-        for (int i = 0; i < dsb; i++) c = crc_tab[(c ^ bytes[i]) & 0xff] ^ (c >> 8);
-        status[f] = ((c ^ 0xFFFFFFFFu) == 558161692u) ? 1 : 0;                          // :245-246
-    }
-    for (int by = lane; by < dsb - 4; by += 64) pl[by] = bytes[by];
+    if (lane == 0) status[f] = ((crc ^ 0xFFFFFFFFu) == 558161692u) ? 1 : 0;              // :245-246
 }
 
 // ---- C ABI ------------------------------------------------------------------------------------------
