@@ -27,6 +27,8 @@ namespace jrc_rt = gr;
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <deque>
+#include <map>
 #include <utility>
 #include <vector>
 
@@ -39,9 +41,9 @@ namespace pmt {
 struct node;
 typedef std::shared_ptr<node> pmt_t;
 struct node {
-    enum kind_t { NIL, SYMBOL, LONG, U64, DOUBLE, F32VEC, C32VEC, LIST, DICT } kind = NIL;
+    enum kind_t { NIL, SYMBOL, LONG, U64, DOUBLE, F32VEC, C32VEC, LIST, DICT, BLOB, PAIR } kind = NIL;
     std::string s; long l = 0; uint64_t u = 0; double d = 0;
-    std::vector<float> f; std::vector<gr_complex> c;
+    std::vector<float> f; std::vector<gr_complex> c; std::vector<uint8_t> blob;
     std::vector<pmt_t> list; std::vector<std::pair<std::string, pmt_t>> dict;
 };
 inline pmt_t mk(node::kind_t k) { auto p = std::make_shared<node>(); p->kind = k; return p; }
@@ -55,12 +57,29 @@ inline pmt_t from_double(double v) { auto p = mk(node::DOUBLE); p->d = v; return
 inline long to_long(const pmt_t& p) { return p->kind == node::U64 ? (long)p->u : (p->kind == node::DOUBLE ? (long)p->d : p->l); }
 inline uint64_t to_uint64(const pmt_t& p) { return p->kind == node::LONG ? (uint64_t)p->l : p->u; }
 inline double to_double(const pmt_t& p) { return p->kind == node::LONG ? (double)p->l : (p->kind == node::U64 ? (double)p->u : p->d); }
+inline float to_float(const pmt_t& p) { return (float)to_double(p); }
 inline pmt_t init_f32vector(size_t n, const float* v) { auto p = mk(node::F32VEC); p->f.assign(v, v + n); return p; }
 inline pmt_t init_c32vector(size_t n, const gr_complex* v) { auto p = mk(node::C32VEC); p->c.assign(v, v + n); return p; }
 inline pmt_t list2(pmt_t a, pmt_t b) { auto p = mk(node::LIST); p->list = {a, b}; return p; }
 inline pmt_t list4(pmt_t a, pmt_t b, pmt_t c, pmt_t d) { auto p = mk(node::LIST); p->list = {a, b, c, d}; return p; }
 inline pmt_t make_tuple(pmt_t a, pmt_t b) { return list2(a, b); }
 inline pmt_t make_dict() { return mk(node::DICT); }
+inline pmt_t make_blob(const void* p, size_t n) { auto b = mk(node::BLOB); b->blob.assign((const uint8_t*)p, (const uint8_t*)p + n); return b; }
+inline pmt_t cons(pmt_t a, pmt_t b) { auto p = mk(node::PAIR); p->list = {a, b}; return p; }
+inline pmt_t car(const pmt_t& p) { return p->list[0]; }
+inline pmt_t cdr(const pmt_t& p) { return p->list[1]; }
+inline bool is_symbol(const pmt_t& p) { return p && p->kind == node::SYMBOL; }
+inline bool is_pair(const pmt_t& p) { return p && p->kind == node::PAIR; }
+inline size_t blob_length(const pmt_t& p) { return p->blob.size(); }
+inline const void* blob_data(const pmt_t& p) { return p->blob.data(); }
+inline float to_float(const pmt_t& p);
+inline std::vector<gr_complex> c32vector_elements(const pmt_t& p) { return p && p->kind == node::C32VEC ? p->c : std::vector<gr_complex>(); }
+inline pmt_t dict_ref(const pmt_t& dct, const pmt_t& key, const pmt_t& not_found)
+{
+    if (dct && dct->kind == node::DICT)
+        for (auto& kv : dct->dict) if (kv.first == key->s) return kv.second;
+    return not_found;
+}
 inline pmt_t dict_add(const pmt_t& dct, const pmt_t& key, const pmt_t& val)
 {
     auto p = std::make_shared<node>(*dct);
@@ -82,6 +101,8 @@ inline void to_json(const pmt_t& p, std::ostringstream& o)
         case node::F32VEC: o << '['; for (size_t i = 0; i < p->f.size(); i++) { if (i) o << ','; o << (double)p->f[i]; } o << ']'; break;
         case node::C32VEC: o << '['; for (size_t i = 0; i < p->c.size(); i++) { if (i) o << ','; o << '[' << (double)p->c[i].real() << ',' << (double)p->c[i].imag() << ']'; } o << ']'; break;
         case node::LIST: o << '['; for (size_t i = 0; i < p->list.size(); i++) { if (i) o << ','; to_json(p->list[i], o); } o << ']'; break;
+        case node::BLOB: o << "{\"blob\":["; for (size_t i = 0; i < p->blob.size(); i++) { if (i) o << ','; o << (int)p->blob[i]; } o << "]}"; break;
+        case node::PAIR: o << "{\"car\":"; to_json(p->list[0], o); o << ",\"cdr\":"; to_json(p->list[1], o); o << '}'; break;
         case node::DICT: o << '{'; for (size_t i = 0; i < p->dict.size(); i++) { if (i) o << ','; o << '"' << p->dict[i].first << "\":"; to_json(p->dict[i].second, o); } o << '}'; break;
     }
 }
@@ -125,6 +146,7 @@ public:
     std::vector<uint64_t> t_read, t_written;
     std::vector<int> t_consumed;
     std::vector<std::pair<std::string, pmt::pmt_t>> t_published;
+    std::map<std::string, std::deque<pmt::pmt_t>> t_msg_in;     // message input queues (what the scheduler delivers)
     // one scheduler turn: call general_work, then advance the item counters like the scheduler does
     virtual int t_run(int noutput_items, gr_vector_int& nin, gr_vector_const_void_star& in, gr_vector_void_star& out)
     {
@@ -165,6 +187,14 @@ protected:
     void consume(int port, int n) { t_consumed[port] += n; }
     void consume_each(int n) { for (auto& c : t_consumed) c += n; }
     void message_port_register_out(const pmt::pmt_t&) {}
+    void message_port_register_in(const pmt::pmt_t&) {}
+    pmt::pmt_t delete_head_nowait(const pmt::pmt_t& port)
+    {
+        auto& q = t_msg_in[port->s];
+        if (q.empty()) return pmt::pmt_t();
+        auto m = q.front(); q.pop_front();
+        return m;
+    }
     void message_port_pub(const pmt::pmt_t& port, const pmt::pmt_t& msg) { t_published.emplace_back(port->s, msg); }
     double pc_output_buffers_full(int) { return 0; }
     thread::mutex d_setlock;

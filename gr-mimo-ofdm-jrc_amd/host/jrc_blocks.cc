@@ -10,6 +10,8 @@
 #include <cstdio>
 #include <cstring>
 #include <ctime>
+#include <deque>
+#include <mutex>
 #include <fstream>
 #include <iomanip>
 #include <iostream>
@@ -700,6 +702,248 @@ target_simulator::sptr target_simulator::make(std::vector<float> range, std::vec
 {
     return JRC_GET_INITIAL_SPTR(new target_simulator_impl(range, velocity, rcs, azimuth, position_rx, samp_rate, center_freq,
                                                           self_coupling_db, rndm_phaseshift, self_coupling, len_key, debug));
+}
+
+// =================================================================================================
+// stream_encoder  (lib/stream_encoder_impl.cc)
+// =================================================================================================
+class stream_encoder_impl : public stream_encoder {
+    ctx_holder d_c;
+    int d_data_len, d_symbol_len = 0, d_offset = 0;
+    MCS d_mod_encode;
+    uint8_t d_scrambler = 1;                                                                         // :53
+    std::vector<gr_complex> d_complex_symbols;
+    std::mutex d_mutex;
+    static const int MAX_PAYLOAD_SIZE = 3100;                                                        // lib/utils.h
+
+public:
+    stream_encoder_impl(MCS mod_encode, int data_len, int, bool)
+        : jrc_rt::block("stream_encoder", jrc_rt::io_signature::make(0, 0, 0), jrc_rt::io_signature::make(1, 1, sizeof(gr_complex))),
+          d_data_len(data_len), d_mod_encode(mod_encode)
+    {
+        message_port_register_in(pmt::mp("pdu_in"));                                                 // :51
+        if (jrc_stream_n_ofdm_sym(mod_encode, data_len, 4) < 0) throw std::invalid_argument("wrong encoding");
+    }
+    void set_mcs(MCS mod_encode) override                                                            // :272-278
+    {
+        std::unique_lock<std::mutex> lock(d_mutex);
+        d_mod_encode = mod_encode;
+    }
+    int general_work(int noutput_items, gr_vector_int&, gr_vector_const_void_star&, gr_vector_void_star& output_items) override
+    {
+        gr_complex* out = (gr_complex*)output_items[0];
+        while (!d_offset) {                                                                          // :88
+            pmt::pmt_t msg(delete_head_nowait(pmt::intern("pdu_in")));
+            if (!msg.get()) return 0;
+            std::unique_lock<std::mutex> lock(d_mutex);
+            std::string str;
+            const char* data_packet;
+            int packet_size_byte;
+            if (pmt::is_symbol(msg)) {                                                               // :103-112
+                str = pmt::symbol_to_string(msg);
+                packet_size_byte = (int)str.length();
+                data_packet = str.data();
+            } else if (pmt::is_pair(msg)) {                                                          // :113-120
+                packet_size_byte = (int)pmt::blob_length(pmt::cdr(msg));
+                data_packet = reinterpret_cast<const char*>(pmt::blob_data(pmt::cdr(msg)));
+            } else {
+                throw std::invalid_argument("[STREAM ENCODER] Encoder expects PDUs or strings");   // :123
+            }
+            const int packet_type = packet_size_byte ? (unsigned char)data_packet[0] : 0;            // (PACKET_TYPE) first byte
+            if (packet_size_byte + 4 > MAX_PAYLOAD_SIZE) {                                           // :139-143
+                std::cout << "[STREAM ENCODER] Data Packet too Large -> Maximun Packet Size (byte): " << MAX_PAYLOAD_SIZE << std::endl;
+                return 0;
+            }
+            const int n_sym = jrc_stream_n_ofdm_sym(d_mod_encode, d_data_len, packet_size_byte + 4);
+            if (n_sym < 0) throw std::invalid_argument("wrong encoding");                            // :206-208
+            d_symbol_len = n_sym * d_data_len;                                                       // :186
+            d_complex_symbols.assign((size_t)d_symbol_len, gr_complex(0, 0));
+            int n = jrc_stream_encode(d_c.ctx, d_mod_encode, d_data_len, (const uint8_t*)data_packet, packet_size_byte, d_scrambler++,
+                                      (jrc_cf32*)d_complex_symbols.data(), d_symbol_len);
+            if (d_scrambler > 127) d_scrambler = 1;                                                  // :171-175
+            d_c.check(n);
+            const pmt::pmt_t srcid = pmt::string_to_symbol(alias());                                 // tags (:224-241)
+            add_item_tag(0, nitems_written(0), pmt::string_to_symbol("packet_len"), pmt::from_long(d_symbol_len), srcid);
+            add_item_tag(0, nitems_written(0), pmt::mp("packet_type"), pmt::from_long(packet_type), srcid);
+            add_item_tag(0, nitems_written(0), pmt::mp("mcs"), pmt::from_long(d_mod_encode), srcid);
+            add_item_tag(0, nitems_written(0), pmt::mp("pdu_len"), pmt::from_long(packet_size_byte + 4), srcid);
+            break;
+        }
+        const int n_out = std::min(noutput_items, d_symbol_len - d_offset);                          // :253-266
+        std::memcpy(out, d_complex_symbols.data() + d_offset, n_out * sizeof(gr_complex));
+        d_offset += n_out;
+        if (d_offset == d_symbol_len) { d_offset = 0; d_complex_symbols.clear(); }
+        return n_out;
+    }
+};
+stream_encoder::sptr stream_encoder::make(MCS mod_encode, int data_len, int N_ss_radar, bool debug)
+{
+    return JRC_GET_INITIAL_SPTR(new stream_encoder_impl(mod_encode, data_len, N_ss_radar, debug));
+}
+
+// =================================================================================================
+// stream_decoder  (lib/stream_decoder_impl.cc)
+// =================================================================================================
+class stream_decoder_impl : public stream_decoder {
+    ctx_holder d_c;
+    int d_n_data_carriers;
+    std::string d_comm_log_file;
+    bool d_stats_record, d_frame_rx_complete = true, d_start_decoding = false, d_new_stat_started = false;
+    std::deque<float> per_stats, snr_data_stats;                     // rolling windows of 25 and 1 (:64-65)
+    float d_snr_est = 0, d_snr_data_est = 0;                         // dB (impl.h:83-84)
+    int d_data_length = 0, d_mcs = 0, d_packet_type = 0, d_n_ofdm_sym = 0, n_copied = 0;
+    std::vector<gr_complex> d_rx_symbols, chan_est_mean;
+    std::vector<uint8_t> d_payload;
+    std::mutex d_mutex;
+    static const int MAX_PAYLOAD_SIZE = 3100, info_bytes = 2 + 2 * sizeof(float);                     // lib/utils.h, impl.h:88
+    static const int MAX_SYM = ((16 + 8 * MAX_PAYLOAD_SIZE + 6) / 24) + 1;
+
+    static float rolling_mean(const std::deque<float>& w)
+    {
+        if (w.empty()) return 0.f;
+        double s = 0; for (float v : w) s += v;
+        return (float)(s / w.size());
+    }
+    static void push(std::deque<float>& w, float v, size_t size) { w.push_back(v); if (w.size() > size) w.pop_front(); }
+
+    void publish_stats()                                                                             // :262-274, :311-323
+    {
+        float per_val = 100.0 * rolling_mean(per_stats);
+        pmt::pmt_t per_pack = pmt::list2(pmt::string_to_symbol("per"), pmt::init_f32vector(1, &per_val));
+        float snr_val = rolling_mean(snr_data_stats);
+        pmt::pmt_t snr_pack = pmt::list2(pmt::string_to_symbol("snr"), pmt::init_f32vector(1, &snr_val));
+        message_port_pub(pmt::mp("stats"), pmt::list2(per_pack, snr_pack));
+    }
+    void publish_sym(bool ok)                                                                        // :249-257, :296-304
+    {
+        std::vector<uint8_t> sob((size_t)info_bytes + (d_data_length > 4 ? d_data_length - 4 : 0));
+        sob[0] = ok ? 1 : 0;
+        sob[1] = (uint8_t)d_packet_type;
+        std::memcpy(&sob[2], &d_snr_est, sizeof(float));
+        std::memcpy(&sob[2 + sizeof(float)], &d_snr_data_est, sizeof(float));
+        if (d_data_length > 4) std::memcpy(&sob[info_bytes], d_payload.data(), (size_t)d_data_length - 4);
+        pmt::pmt_t dict = pmt::dict_add(pmt::make_dict(), pmt::mp("SNR"), pmt::from_double(d_snr_est));
+        message_port_pub(pmt::mp("sym"), pmt::cons(dict, pmt::make_blob(sob.data(), sob.size())));
+    }
+    void log_line(std::ofstream& f, int ok)                                                          // :282-294, :331-343
+    {
+        f << current_date_time2() << ", \t" << ok << ", \t" << d_packet_type << ", \t" << d_mcs << ", \t" << d_snr_est << ", \t"
+          << d_snr_data_est << ", \t" << d_data_length << ", \t";
+        for (size_t i = 0; i < chan_est_mean.size(); i++) f << chan_est_mean[i] << ";";
+        f << "\n";
+        f.flush();
+    }
+    void decode()                                                                                     // :205-405
+    {
+        std::ofstream file_stream(d_comm_log_file, std::ofstream::app);
+        if (d_stats_record) {
+            if (!file_stream.is_open()) throw std::runtime_error("[STREAM DECODER] Could not open file!!");
+            if (!d_new_stat_started) {
+                file_stream << "\n NEW RECORD - " << current_date_time() << "\n";
+                file_stream.flush();
+                d_new_stat_started = true;
+            }
+        }
+        d_payload.assign((size_t)std::max(d_data_length, 8), 0);
+        int crc_ok = 0;
+        int n = jrc_stream_decode(d_c.ctx, d_mcs, d_n_data_carriers, d_data_length, (const jrc_cf32*)d_rx_symbols.data(),
+                                  d_n_ofdm_sym * d_n_data_carriers, d_payload.data(), &crc_ok);
+        d_c.check(n);
+        if (!crc_ok) {                                                                                // :246-296
+            std::cerr << "[STREAM DECODER] Data Checksum is WRONG!!! --> Dropping Packet, bytes:" << d_data_length << std::endl;
+            publish_sym(false);
+            publish_stats();                                             // statistics before this failure is counted
+            push(per_stats, 1, 25);
+            push(snr_data_stats, d_snr_data_est, 1);
+            if (d_stats_record) log_line(file_stream, 0);
+            return;
+        }
+        push(per_stats, 0, 25);                                                                       // :299-301
+        push(snr_data_stats, d_snr_data_est, 1);
+        publish_sym(true);
+        publish_stats();
+        if (d_stats_record) log_line(file_stream, 1);
+    }
+
+public:
+    stream_decoder_impl(int n_data_carriers, const std::string& comm_log_file, bool stats_record, bool)
+        : jrc_rt::block("stream_decoder", jrc_rt::io_signature::make(1, 1, n_data_carriers * sizeof(gr_complex)),
+                        jrc_rt::io_signature::make(1, 1, sizeof(float))),                             // :52-55
+          d_n_data_carriers(n_data_carriers), d_comm_log_file(comm_log_file), d_stats_record(stats_record)
+    {
+        message_port_register_out(pmt::mp("sym"));
+        message_port_register_out(pmt::mp("stats"));
+        set_tag_propagation_policy(TPP_DONT);
+        std::ifstream file_stream(d_comm_log_file);
+        if (!file_stream.is_open()) std::cerr << "[MIMO PRECODER] Could not open log file!" << std::endl;   // sic (:84-88)
+    }
+    void set_stats_record(bool stats_record) override                                                 // :469-483
+    {
+        std::unique_lock<std::mutex> lock(d_mutex);
+        d_stats_record = stats_record;
+        d_new_stat_started = false;
+    }
+    int general_work(int, gr_vector_int& ninput_items, gr_vector_const_void_star& input_items, gr_vector_void_star& output_items) override
+    {
+        const int n_input_items = ninput_items[0];
+        const gr_complex* in = (const gr_complex*)input_items[0];
+        float* per_out = (float*)output_items[0];
+        std::vector<float> per_vector;
+        std::vector<jrc_rt::tag_t> tags;
+        const uint64_t nread = nitems_read(0);
+        jrc_rt::thread::scoped_lock lock(d_setlock);
+        int n_in = 0, n_out = 0;
+        while (n_in < n_input_items) {
+            get_tags_in_range(tags, 0, nread + n_in, nread + n_in + 1, pmt::string_to_symbol("stream_start"));
+            if (tags.size()) {                                                                        // :115-147
+                d_frame_rx_complete = false;
+                pmt::pmt_t dict = tags[0].value;
+                d_snr_est = (float)pmt::to_double(pmt::dict_ref(dict, pmt::mp("snr"), pmt::from_double(0)));
+                d_data_length = (int)pmt::to_uint64(pmt::dict_ref(dict, pmt::mp("data_bytes"), pmt::from_double(0)));
+                d_mcs = (int)pmt::to_uint64(pmt::dict_ref(dict, pmt::mp("mcs"), pmt::from_double(0)));
+                d_packet_type = (int)pmt::to_uint64(pmt::dict_ref(dict, pmt::mp("packet_type"), pmt::from_double(0)));
+                const int n_sym = jrc_stream_n_ofdm_sym(d_mcs, d_n_data_carriers, d_data_length);
+                if (n_sym >= 0 && n_sym <= MAX_SYM && d_data_length <= MAX_PAYLOAD_SIZE) {
+                    d_n_ofdm_sym = n_sym;
+                    n_copied = 0;
+                    d_start_decoding = true;
+                    d_rx_symbols.assign((size_t)n_sym * d_n_data_carriers, gr_complex(0, 0));
+                } else {
+                    d_start_decoding = false;
+                }
+            }
+            get_tags_in_range(tags, 0, nread + n_in, nread + n_in + 1, pmt::mp("stream_end"));
+            if (tags.size()) {                                                                        // :149-157
+                pmt::pmt_t dict = tags[0].value;
+                d_snr_data_est = pmt::to_float(pmt::dict_ref(dict, pmt::mp("snr_data"), pmt::from_double(0)));
+                chan_est_mean = pmt::c32vector_elements(pmt::dict_ref(dict, pmt::mp("chan_mean"), pmt::from_double(0)));
+            }
+            if (n_copied < d_n_ofdm_sym && d_start_decoding) {                                        // :159-185
+                // the hard decisions of :166-169 are taken on the device; the symbols are kept until the frame is complete
+                std::memcpy(&d_rx_symbols[(size_t)n_copied * d_n_data_carriers], in, d_n_data_carriers * sizeof(gr_complex));
+                n_copied++;
+                if (n_copied == d_n_ofdm_sym) {
+                    decode();
+                    in += d_n_data_carriers;
+                    n_in++;
+                    d_frame_rx_complete = true;
+                    n_out++;
+                    per_vector.push_back(100.0 * rolling_mean(per_stats));
+                    n_copied = 0;
+                    break;
+                }
+            }
+            in += d_n_data_carriers;
+            n_in++;
+        }
+        if (n_out) std::memcpy(per_out, per_vector.data(), n_out * sizeof(float));
+        consume(0, n_in);
+        return n_out;
+    }
+};
+stream_decoder::sptr stream_decoder::make(int n_data_carriers, const std::string& comm_log_file, bool stats_record, bool debug)
+{
+    return JRC_GET_INITIAL_SPTR(new stream_decoder_impl(n_data_carriers, comm_log_file, stats_record, debug));
 }
 
 }  // namespace mimo_ofdm_jrc

@@ -10,6 +10,8 @@
 //   include/mimo_ofdm_jrc/mimo_ofdm_equalizer.h:64-78  gr::mimo_ofdm_jrc::mimo_ofdm_equalizer
 //   include/mimo_ofdm_jrc/mimo_precoder.h              gr::mimo_ofdm_jrc::mimo_precoder
 //   include/mimo_ofdm_jrc/target_simulator.h:30-60     gr::mimo_ofdm_jrc::target_simulator
+//   include/mimo_ofdm_jrc/stream_encoder.h:56-64       gr::mimo_ofdm_jrc::stream_encoder
+//   include/mimo_ofdm_jrc/stream_decoder.h:43-56       gr::mimo_ofdm_jrc::stream_decoder
 //
 // Built against GNU Radio 3.8 with -DJRC_WITH_GNURADIO; otherwise against the stand-alone test runtime.
 #pragma once
@@ -109,6 +111,20 @@ public:
     virtual void setup_targets(std::vector<float> range, std::vector<float> velocity, std::vector<float> rcs,
                                std::vector<float> azimuth, std::vector<float> position_rx, int samp_rate, float center_freq,
                                float self_coupling_db, bool rndm_phaseshift, bool self_coupling) = 0;
+};
+
+class stream_encoder : virtual public jrc_rt::block {
+public:
+    typedef JRC_SPTR<stream_encoder> sptr;
+    static sptr make(MCS mod_encode, int data_len, int N_ss_radar, bool debug);
+    virtual void set_mcs(MCS mod_encode) = 0;
+};
+
+class stream_decoder : virtual public jrc_rt::block {
+public:
+    typedef JRC_SPTR<stream_decoder> sptr;
+    static sptr make(int n_data_carriers, const std::string& comm_log_file, bool stats_record, bool debug);
+    virtual void set_stats_record(bool stats_record) = 0;
 };
 
 }  // namespace mimo_ofdm_jrc

@@ -92,6 +92,49 @@ void* jrcb_make_target_simulator(const float* range, const float* velocity, cons
                                rndm_phaseshift != 0, self_coupling != 0))); });
 }
 
+void* jrcb_make_stream_encoder(int mcs, int data_len)
+{
+    return guard_make([&] { return std::static_pointer_cast<jrc_host::block>(std::shared_ptr<stream_encoder>(
+        stream_encoder::make((MCS)mcs, data_len, 0, false))); });
+}
+void* jrcb_make_stream_decoder(int n_data_carriers, const char* comm_log_file, int stats_record)
+{
+    return guard_make([&] { return std::static_pointer_cast<jrc_host::block>(std::shared_ptr<stream_decoder>(
+        stream_decoder::make(n_data_carriers, comm_log_file, stats_record != 0, false))); });
+}
+// message delivery: kind 0 = pmt symbol (string), 1 = PDU pair (dict . blob), 2 = something else (a pmt long)
+int jrcb_post_msg(void* h, const char* port, int kind, const uint8_t* data, int len)
+{
+    auto& b = ((handle*)h)->b;
+    pmt::pmt_t m = kind == 0 ? pmt::string_to_symbol(std::string((const char*)data, (size_t)len))
+                 : kind == 1 ? pmt::cons(pmt::make_dict(), pmt::make_blob(data, (size_t)len)) : pmt::from_long(len);
+    b->t_msg_in[port].push_back(m);
+    return 0;
+}
+// the equalizer's dictionary tags (lib/mimo_ofdm_equalizer_impl.cc:331-337, :626-629) on an input stream
+int jrcb_add_stream_start(void* h, int port, uint64_t offset, long data_bytes, long mcs, long packet_type, double snr)
+{
+    auto& b = ((handle*)h)->b;
+    pmt::pmt_t d = pmt::make_dict();
+    d = pmt::dict_add(d, pmt::mp("data_bytes"), pmt::from_uint64((uint64_t)data_bytes));
+    d = pmt::dict_add(d, pmt::mp("mcs"), pmt::from_uint64((uint64_t)mcs));
+    d = pmt::dict_add(d, pmt::mp("packet_type"), pmt::from_uint64((uint64_t)packet_type));
+    d = pmt::dict_add(d, pmt::mp("snr"), pmt::from_double(snr));
+    jrc_host::tag_t t; t.offset = offset; t.key = pmt::mp("stream_start"); t.value = d;
+    b->t_in_tags[port].push_back(t);
+    return 0;
+}
+int jrcb_add_stream_end(void* h, int port, uint64_t offset, double snr_data, const float* chan_mean, int n_chan)
+{
+    auto& b = ((handle*)h)->b;
+    pmt::pmt_t d = pmt::make_dict();
+    d = pmt::dict_add(d, pmt::mp("snr_data"), pmt::from_double(snr_data));
+    d = pmt::dict_add(d, pmt::mp("chan_mean"), pmt::init_c32vector((size_t)n_chan, (const gr_complex*)chan_mean));
+    jrc_host::tag_t t; t.offset = offset; t.key = pmt::mp("stream_end"); t.value = d;
+    b->t_in_tags[port].push_back(t);
+    return 0;
+}
+
 int jrcb_add_in_tag(void* h, int port, uint64_t offset, const char* key, int kind, long lv, double dv)
 {
     auto& b = ((handle*)h)->b;
@@ -174,6 +217,8 @@ int jrcb_call_setter(void* h, const char* name, double v)
             if (n == "set_use_radar_streams") { p->set_use_radar_streams(v != 0); return 0; }
             if (n == "set_phased_steering") { p->set_phased_steering(v != 0); return 0; }
         }
+        if (auto* se = dynamic_cast<stream_encoder*>(b.get())) { if (n == "set_mcs") { se->set_mcs((MCS)(int)v); return 0; } }
+        if (auto* sd = dynamic_cast<stream_decoder*>(b.get())) { if (n == "set_stats_record") { sd->set_stats_record(v != 0); return 0; } }
         if (auto* d = dynamic_cast<fft_peak_detect*>(b.get())) {
             if (n == "set_threshold") { d->set_threshold((float)v); return 0; }
             if (n == "set_samp_protect") { d->set_samp_protect((int)v); return 0; }

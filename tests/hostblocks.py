@@ -21,7 +21,7 @@ def lib():
         L = C.CDLL(LIB)
         L.jrcb_last_error.restype = C.c_char_p
         for name in ("jrcb_make_radar", "jrcb_make_transpose", "jrcb_make_estimator", "jrcb_make_cp_remover",
-                     "jrcb_make_peak_detect", "jrcb_make_equalizer", "jrcb_make_precoder", "jrcb_make_target_simulator"):
+                     "jrcb_make_peak_detect", "jrcb_make_equalizer", "jrcb_make_precoder", "jrcb_make_target_simulator", "jrcb_make_stream_encoder", "jrcb_make_stream_decoder"):
             getattr(L, name).restype = _vp
         L.jrcb_make_radar.argtypes = [C.c_int] * 10
         L.jrcb_make_transpose.argtypes = [C.c_int] * 3
@@ -33,6 +33,11 @@ def lib():
         L.jrcb_make_precoder.argtypes = [C.c_int, C.c_int, _ip, C.c_int, _ip, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_char_p,
                                          C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int]
         L.jrcb_make_target_simulator.argtypes = [_fp, _fp, _fp, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int]
+        L.jrcb_make_stream_encoder.argtypes = [C.c_int, C.c_int]
+        L.jrcb_make_stream_decoder.argtypes = [C.c_int, C.c_char_p, C.c_int]
+        L.jrcb_post_msg.argtypes = [_vp, C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+        L.jrcb_add_stream_start.argtypes = [_vp, C.c_int, C.c_uint64, C.c_long, C.c_long, C.c_long, C.c_double]
+        L.jrcb_add_stream_end.argtypes = [_vp, C.c_int, C.c_uint64, C.c_double, _fp, C.c_int]
         L.jrcb_destroy.argtypes = [_vp]
         L.jrcb_add_in_tag.argtypes = [_vp, C.c_int, C.c_uint64, C.c_char_p, C.c_int, C.c_long, C.c_double]
         L.jrcb_run.argtypes = [_vp, C.c_int, _ip, C.c_int, C.POINTER(_vp), C.c_int, C.POINTER(_vp)]
@@ -81,6 +86,18 @@ class Block:
             raise RuntimeError(lib().jrcb_last_error().decode())
         return n
 
+    def post(self, port, data, kind=1):
+        """deliver a message: kind 0 = pmt symbol, 1 = PDU pair (dict . blob), 2 = some other pmt"""
+        data = bytes(data)
+        lib().jrcb_post_msg(self.h, port.encode(), kind, data, len(data))
+
+    def stream_start(self, offset, data_bytes, mcs, packet_type, snr, port=0):
+        lib().jrcb_add_stream_start(self.h, port, offset, data_bytes, mcs, packet_type, snr)
+
+    def stream_end(self, offset, snr_data, chan_mean=(), port=0):
+        cm = np.ascontiguousarray(chan_mean, np.complex64)
+        lib().jrcb_add_stream_end(self.h, port, offset, snr_data, cm.view(np.float32).ctypes.data_as(_fp) if cm.size else None, cm.size)
+
     def consumed(self, port):
         return lib().jrcb_consumed(self.h, port)
 
@@ -122,6 +139,14 @@ def target_simulator(range_m, velocity, rcs, azimuth, position_rx, samp_rate, ce
         raise ValueError("length mismatch")
     return Block(lib().jrcb_make_target_simulator(_f(r), _f(v), _f(s), _f(a), r.size, _f(p), p.size, int(samp_rate),
                                                   float(center_freq), float(self_coupling_db), int(rndm_phaseshift), int(self_coupling)))
+
+
+def stream_encoder(mcs, data_len):
+    return Block(lib().jrcb_make_stream_encoder(mcs, data_len))
+
+
+def stream_decoder(n_data_carriers, comm_log_file="", stats_record=False):
+    return Block(lib().jrcb_make_stream_decoder(n_data_carriers, comm_log_file.encode(), int(stats_record)))
 
 
 def peak_detect(samp_rate, interp, threshold, samp_protect):

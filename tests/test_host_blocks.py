@@ -21,7 +21,8 @@ def test_host_library_exports_harness_and_links_the_abi(jrc):
         assert hasattr(L, sym)
     src = open(os.path.join(ROOT, "gr-mimo-ofdm-jrc_amd", "host", "jrc_blocks.cc")).read()
     for cls in ("mimo_ofdm_radar", "matrix_transpose", "range_angle_estimator", "ofdm_cyclic_prefix_remover",
-                "fft_peak_detect", "mimo_ofdm_equalizer", "mimo_precoder", "target_simulator"):
+                "fft_peak_detect", "mimo_ofdm_equalizer", "mimo_precoder", "target_simulator", "stream_encoder",
+                "stream_decoder"):
         assert re.search(r"%s::sptr\s+%s::make\(" % (cls, cls), src), cls
 
 
@@ -263,3 +264,70 @@ def test_target_simulator_block_tags_and_outputs(jrc):
     assert np.allclose(np.abs(ratio), 1.0, atol=1e-3)
     k = np.angle(np.mean(ratio)) / (2 * np.pi) * 1000
     assert abs(k - round(k)) < 0.05
+
+
+@gpu
+def test_stream_encoder_and_decoder_blocks(jrc, tmp_path):
+    """lib/stream_encoder_impl.cc:76-270 and lib/stream_decoder_impl.cc:100-405 as blocks: PDUs in on the message port,
+    symbols out in scheduler-sized pieces with the four tags; the decoder follows stream_start / stream_end tags, publishes
+    the blob + stats messages, the rolling PER and the log file"""
+    import hostblocks as hb
+    rng = np.random.default_rng(8)
+    mcs, ndc = 3, 48
+    enc = hb.stream_encoder(mcs, ndc)
+    out = np.zeros(4096, np.complex64)
+    assert enc.run(4096, [], [out]) == 0                               # no PDU queued
+    pdus = [bytes([2]) + rng.integers(0, 256, 120, dtype=np.uint8).tobytes(), bytes([1]) + b"second pdu as a string"]
+    enc.post("pdu_in", pdus[0], kind=1)
+    enc.post("pdu_in", pdus[1], kind=0)
+    enc.post("pdu_in", bytes(3100), kind=1)                            # too large: printed and dropped (:139-143)
+    frames = []
+    for i, p in enumerate(pdus):
+        want, tags = oracle.stream_encode(mcs, ndc, p, 1 + i)
+        first = np.zeros(100, np.complex64)
+        assert enc.run(100, [], [first]) == 100                        # the scheduler offers 100 items: a partial copy (:253-257)
+        rest = np.zeros(want.size, np.complex64)
+        n = enc.run(rest.size, [], [rest])
+        assert n == want.size - 100
+        got = np.concatenate([first, rest[:n]])
+        np.testing.assert_array_equal(got, want)
+        frames.append((got, tags))
+    assert enc.run(4096, [], [out]) == 0                               # the oversized PDU produced nothing
+    st = enc.state()["out_tags"][0]
+    assert [(t["key"], t["value"]) for t in st[:4]] == [("packet_len", frames[0][1]["packet_len"]), ("packet_type", 2), ("mcs", mcs),
+                                                         ("pdu_len", 125)]
+    assert st[4]["offset"] == frames[0][0].size and st[5]["value"] == 1
+    bad = hb.stream_encoder(mcs, ndc)
+    bad.post("pdu_in", b"", kind=2)
+    with pytest.raises(ValueError, match="Encoder expects PDUs"):
+        bad.run(10, [], [out])
+
+    log = tmp_path / "comm_log.csv"
+    log.write_text("")
+    dec = hb.stream_decoder(ndc, str(log), True)
+    per = np.zeros(4, np.float32)
+    off = 0
+    verdicts = []
+    for i, (sym, tags) in enumerate(frames + [frames[0]]):
+        x = sym.reshape(-1, ndc).copy()
+        if i == 2:
+            x[1:4] = -x[1:4]                                           # three inverted OFDM symbols: CRC fails
+        dec.stream_start(off, tags["pdu_len"], mcs, tags["packet_type"], 21.5)
+        dec.stream_end(off + x.shape[0] - 1, 18.25, [1 + 2j, 3 - 4j])
+        assert dec.run(4, [x], [per]) == 1 and dec.consumed(0) == x.shape[0]
+        off += x.shape[0]
+        verdicts.append(float(per[0]))
+    assert verdicts == [0.0, 0.0, pytest.approx(100.0 / 3)]
+    pub = dec.state()["published"]
+    syms = [m["msg"] for m in pub if m["port"] == "sym"]
+    assert len(syms) == 3 and [m["cdr"]["blob"][0] for m in syms] == [1, 1, 0]
+    blob = bytes(syms[0]["cdr"]["blob"])
+    assert blob[1] == 2 and np.frombuffer(blob[2:10], np.float32).tolist() == [21.5, 18.25] and blob[10:] == pdus[0]
+    assert bytes(syms[1]["cdr"]["blob"])[10:] == pdus[1] and syms[0]["car"] == {"SNR": 21.5}
+    stats = [m["msg"] for m in pub if m["port"] == "stats"]
+    assert stats[2][0][0] == "per" and stats[2][0][1] == [0.0]         # published before the failure is counted (:262-281)
+    lines = [l for l in log.read_text().splitlines() if l.strip()]
+    assert lines[0].startswith(" NEW RECORD - ") and len(lines) == 4
+    f = [c.strip() for c in lines[1].split(", \t")]
+    assert f[1:7] == ["1", "2", str(mcs), "21.5", "18.25", "125"] and f[7] == "(1,2);(3,-4);"
+    assert [c.strip() for c in lines[3].split(", \t")][1] == "0"
