@@ -47,3 +47,31 @@ def test_rx_symbols_match_the_point_target_model(jrc, ctx, ofdm64):
     # the simulator evaluates f + fc in float32 (2048 Hz steps at 24 GHz) on the burst-length frequency grid, so its
     # delay filter is a pure delay only to ~1e-3 of phase per TX
     assert rel_err(e["rx_f"], want) < 1e-2
+
+
+@pytest.mark.parametrize("mcs", [0, 2, 3])
+def test_comm_flowgraph_pdu_round_trip(jrc, ctx, ofdm64, mcs):
+    """examples/comm_sim_flowgraph.py: PDU -> stream_encoder -> precoder -> OFDM mod -> 4x1 channel + noise -> CP removal + FFT
+    -> equalizer -> stream_decoder -> the same PDU; then the NDP channel estimate steers the precoder (beam-forming gain)"""
+    import comm_sim_flowgraph as cfm
+    fg = cfm.CommSimFlowgraph(ofdm64, mcs=mcs, ctx=ctx)
+    rng = np.random.default_rng(mcs)
+    ok, payload, info = fg.send(bytes([1]) + b"sounding packet", snr_db=30.0)
+    assert info["start"]["packet_type"] == 1 and info["start"]["data_bytes"] == 20     # NDP payload rides on TX 0/1 only: its CRC
+    if ok:                                                                             # depends on |h0 + h1|, the sounding does not
+        assert payload == bytes([1]) + b"sounding packet"
+    assert fg.chan_est is not None and fg.chan_est.shape == (64, 4)
+    used = np.abs(fg.chan_est).sum(axis=1) > 0
+    est = fg.chan_est[used].mean(axis=0)
+    assert np.abs(est / est[0] - fg.h / fg.h[0]).max() < 0.1                     # LS estimate of the flat channel (up to a common factor)
+    snrs = {}
+    for steer in (False, True):
+        for i in range(3):
+            pdu = bytes([2]) + rng.integers(0, 256, 150 + 40 * i, dtype=np.uint8).tobytes()
+            ok, payload, info = fg.send(pdu, snr_db=28.0, steer=steer)
+            assert ok and payload == pdu
+            assert info["start"]["mcs"] == mcs and info["start"]["data_bytes"] == len(pdu) + 4
+            snrs[steer] = info["start"]["snr"]
+    assert fg.decoder.per <= 100.0 / 7 + 1e-6                               # at most the NDP payload counted as lost
+    ok, payload, _ = fg.send(bytes([2]) + bytes(300), snr_db=-3.0)                # hopeless SNR: no false "ok"
+    assert not ok
