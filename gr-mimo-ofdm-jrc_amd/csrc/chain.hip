@@ -271,12 +271,14 @@ extern "C" int jrc_chain_create(jrc_ctx* ctx, const jrc_chain_cfg* cfg, const fl
                           P <= 16 && jrc_is_pow2(cfg->interp_angle) && cfg->interp_angle >= 2 && cfg->interp_angle <= 64 &&
                           NA >= 4 && (P * N) % 2 == 0 &&
                           sizeof(float2) * ((size_t)P * N + (size_t)P * RA_L + (N > 256 ? (size_t)N : 0)) + 64 <= 160 * 1024;
-    // everything else with power-of-two transform sizes runs block by block (A1, pad, A2, A3, A4, A5 kernels)
-    const bool generic_ok = jrc_is_pow2(NR) && jrc_is_pow2(NA) && NR >= 2 && NA >= 2 && NR <= 16384 && NA <= 16384;
+    // everything else runs block by block (A1, pad, A2, A3, A4, A5 kernels): powers of two up to 16384, any other size up
+    // to 4096 (chirp-z fft_vcc), e.g. 3 TX x 2 RX -> 96 angle bins
+    auto size_ok = [](long n) { return n >= 1 && (jrc_is_pow2(n) ? n <= 16384 : n <= 4096); };
+    const bool generic_ok = size_ok(NR) && size_ok(NA);
     if (NR * NA >= (1L << 32) || (!fused_ok && !generic_ok))
         return jrc_fail(ctx, JRC_ERR_UNSUPPORTED,
-                        "radar chain needs power-of-two transform sizes fft_len*interp_range and N_tx*N_rx*interp_angle "
-                        "(each <= 16384); got N=%d P=%d Ir=%d Ia=%d",
+                        "radar chain: transform sizes fft_len*interp_range and N_tx*N_rx*interp_angle must be <= 16384 (powers of "
+                        "two) or <= 4096 (other sizes); got N=%d P=%d Ir=%d Ia=%d",
                         N, P, cfg->interp_range, cfg->interp_angle);
     JRC_HIP(ctx, hipSetDevice(ctx->device));
     jrc_chain* ch = new jrc_chain();
@@ -298,7 +300,7 @@ extern "C" int jrc_chain_create(jrc_ctx* ctx, const jrc_chain_cfg* cfg, const fl
         if (ch->wg_per_cu > 2) ch->wg_per_cu = 2;          // measured: 2 long-lived workgroups per CU beat 3-4 short ones
     }
     if (ch->generic) {
-        if (!generic_ok) { delete ch; return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "JRC_CHAIN_GENERIC: transform sizes must be powers of two"); }
+        if (!generic_ok) { delete ch; return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "JRC_CHAIN_GENERIC: transform sizes out of range"); }
         ch->C = 1;
         long nb = ((long)NR * NA + 2047) / 2048;
         ch->gen_blocks = (int)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb));
@@ -493,8 +495,9 @@ extern "C" int jrc_range_doppler_dev(jrc_ctx* ctx, const jrc_chain_cfg* c, int i
     if (!ctx || !c || !d_frames || !d_work || !d_out || n_frames <= 0 || interp_doppler <= 0) return JRC_ERR_INVALID_ARG;
     const int N = c->fft_len, T = c->N_tx, R = c->N_rx, P = T * R, S = c->N_sym;
     const long NR = (long)N * c->interp_range, ND = (long)S * interp_doppler;
-    if (!jrc_is_pow2(NR) || !jrc_is_pow2(ND) || NR < 2 || ND < 2 || NR > 16384 || ND > 16384 || c->n_items < c->N_pre + S)
-        return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "range-Doppler needs power-of-two fft_len*interp_range and N_sym*interp_doppler (<= 16384)");
+    auto size_ok = [](long n) { return n >= 1 && (jrc_is_pow2(n) ? n <= 16384 : n <= 4096); };
+    if (!size_ok(NR) || !size_ok(ND) || c->n_items < c->N_pre + S)
+        return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "range-Doppler: fft_len*interp_range and N_sym*interp_doppler must be <= 16384 (powers of two) or <= 4096");
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     ChanestGeom g;
     g.N = N; g.S = S; g.port_stride = (long)c->n_items * N; g.frame_stride = g.port_stride * (T + R);

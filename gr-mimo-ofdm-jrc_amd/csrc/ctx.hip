@@ -64,6 +64,7 @@ extern "C" void jrc_destroy(jrc_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->twiddles) (void)hipFree(kv.second);
+    for (auto& kv : ctx->bluestein) { (void)hipFree(kv.second.chirp); (void)hipFree(kv.second.bhat); }
     for (int i = 0; i < 4; i++)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -175,5 +176,51 @@ int jrc_get_twiddles(jrc_ctx* ctx, int n, int sign, const float2** out)
     JRC_HIP(ctx, hipMemcpy(d, h.data(), sizeof(float2) * (size_t)n, hipMemcpyHostToDevice));
     ctx->twiddles[key] = d;
     *out = d;
+    return JRC_OK;
+}
+
+int jrc_get_bluestein(jrc_ctx* ctx, int n, int sign, jrc_ctx::bluestein_tab* out)
+{
+    const long key = (long)sign * n;
+    auto it = ctx->bluestein.find(key);
+    if (it != ctx->bluestein.end()) { *out = it->second; return JRC_OK; }
+    int M = 1;
+    while (M < 2 * n - 1) M <<= 1;
+    std::vector<double> cr((size_t)n), ci((size_t)n), br((size_t)M, 0.0), bi((size_t)M, 0.0);
+    for (long k = 0; k < n; k++) {
+        const long q = (k * k) % (2L * n);                       // k^2 mod 2n keeps the angle exact
+        const double a = M_PI * (double)q / (double)n;
+        cr[k] = cos(a); ci[k] = (double)sign * sin(a);
+        br[k] = cr[k]; bi[k] = -ci[k];                           // conj(c), wrapped
+        if (k) { br[M - k] = cr[k]; bi[M - k] = -ci[k]; }
+    }
+    // forward FFT of length M in double (iterative radix 2)
+    for (int i = 1, j = 0; i < M; i++) {
+        int bit = M >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { std::swap(br[i], br[j]); std::swap(bi[i], bi[j]); }
+    }
+    for (int len = 2; len <= M; len <<= 1) {
+        const double ang = -2.0 * M_PI / len;
+        for (int i0 = 0; i0 < M; i0 += len)
+            for (int k = 0; k < len / 2; k++) {
+                const double wr = cos(ang * k), wi = sin(ang * k);
+                const int a = i0 + k, b = a + len / 2;
+                const double xr = br[b] * wr - bi[b] * wi, xi = br[b] * wi + bi[b] * wr;
+                br[b] = br[a] - xr; bi[b] = bi[a] - xi;
+                br[a] += xr; bi[a] += xi;
+            }
+    }
+    std::vector<float2> hc((size_t)n), hb((size_t)M);
+    for (int k = 0; k < n; k++) hc[k] = make_float2((float)cr[k], (float)ci[k]);
+    for (int k = 0; k < M; k++) hb[k] = make_float2((float)(br[k] / M), (float)(bi[k] / M));
+    jrc_ctx::bluestein_tab t{nullptr, nullptr, M};
+    JRC_HIP(ctx, hipMalloc((void**)&t.chirp, sizeof(float2) * (size_t)n));
+    JRC_HIP(ctx, hipMalloc((void**)&t.bhat, sizeof(float2) * (size_t)M));
+    JRC_HIP(ctx, hipMemcpy(t.chirp, hc.data(), sizeof(float2) * (size_t)n, hipMemcpyHostToDevice));
+    JRC_HIP(ctx, hipMemcpy(t.bhat, hb.data(), sizeof(float2) * (size_t)M, hipMemcpyHostToDevice));
+    ctx->bluestein[key] = t;
+    *out = t;
     return JRC_OK;
 }

@@ -115,6 +115,95 @@ __global__ __launch_bounds__(256) void fft_stockham_kernel(const float2* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+#define JRC_FFT_MAX_ANY 4096     // largest non-power-of-two fft_size (chirp-z over M <= 8192 points in LDS)
+
+__global__ void fft_copy1_kernel(const float2* __restrict__ in, float2* __restrict__ out, const float* __restrict__ window, size_t batch,
+                                 long in_stride, int in_offset, long out_stride, int cp_out)
+{
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    float2 v = in[b * (size_t)in_stride + in_offset];
+    if (window) { v.x *= window[0]; v.y *= window[0]; }
+    float2* d = out + b * (size_t)out_stride + cp_out;
+    d[0] = v;
+    for (int j = 0; j < cp_out; j++) d[j - cp_out] = v;
+}
+
+// fft sizes that are not powers of two (3 TX x 2 RX -> 96 angle bins, fft_len 48, ...): chirp-z transform in LDS.
+//   X[k] = c[k] sum_i (x[i] c[i]) conj(c)[k - i],  c[i] = exp(sign j pi i^2 / n)
+// as one circular convolution of length M = 2^m >= 2n-1: load x.c zero-padded, Stockham FFT_M, multiply by the
+// precomputed spectrum of the wrapped conj chirp (/M folded in), inverse Stockham FFT_M, multiply by c.  Same window /
+// shift / stride / cyclic-prefix semantics as the power-of-two kernels (gr-fft 3.8 fft_vcc: forward shift rotates the
+// output by ceil(n/2), reverse shift rotates the input by floor(n/2)).
+__global__ __launch_bounds__(256) void fft_bluestein_kernel(const float2* __restrict__ in, float2* __restrict__ out,
+                                                            const float2* __restrict__ chirp, const float2* __restrict__ bhat,
+                                                            const float2* __restrict__ tw_f, const float2* __restrict__ tw_i,
+                                                            const float* __restrict__ window, int n, int M, int logM, int forward,
+                                                            int shift, size_t batch, long in_stride, int in_offset, int tp,
+                                                            long out_stride, int cp_out)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    const int per_block = blockDim.x / tp;
+    const int lt = threadIdx.x % tp, lb = threadIdx.x / tp;
+    const size_t b = (size_t)blockIdx.x * per_block + lb;
+    const bool live = b < batch;
+    float2* buf0 = lds + (size_t)lb * 2 * M;
+    float2* buf1 = buf0 + M;
+    const float2* src_g = in + b * (size_t)in_stride + in_offset;
+    float2* dst_g = out + b * (size_t)out_stride + cp_out;
+    const int rot_in = (!forward && shift) ? n / 2 : 0;
+    const int rot_out = (forward && shift) ? n / 2 : 0;           // X[k] lands at (k + floor(n/2)) % n  <=>  out[j] = X[(j + ceil(n/2)) % n]
+    if (live)
+        for (int i = lt; i < M; i += tp) {
+            float2 v = make_float2(0.f, 0.f);
+            if (i < n) {
+                int si = i + rot_in; if (si >= n) si -= n;
+                v = src_g[si];
+                if (window) { const float w = window[si]; v.x *= w; v.y *= w; }
+                v = cmul(v, chirp[i]);
+            }
+            buf0[i] = v;
+        }
+    __syncthreads();
+    const float2* cur = buf0;
+    float2* nxt = buf1;
+    for (int dir = 0; dir < 2; dir++) {
+        const float2* tw = dir ? tw_i : tw_f;
+        const int sign = dir ? 1 : -1;
+        int Ns = 1;
+        bool first = true;
+        while (Ns < M) {
+            const int R = ((logM & 1) && first) ? 2 : 4;
+            if (live) {
+                if (R == 2) stockham_pass<2>(nullptr, 0, nullptr, cur, nxt, nullptr, 0, tw, M, Ns, sign, lt, tp);
+                else stockham_pass<4>(nullptr, 0, nullptr, cur, nxt, nullptr, 0, tw, M, Ns, sign, lt, tp);
+            }
+            __syncthreads();
+            const float2* t = cur; cur = nxt; nxt = const_cast<float2*>(t);
+            Ns *= R; first = false;
+        }
+        if (dir == 0) {
+            if (live) {
+                float2* w = const_cast<float2*>(cur);
+                for (int k = lt; k < M; k += tp) w[k] = cmul(w[k], bhat[k]);
+            }
+            __syncthreads();
+        }
+    }
+    if (live) {
+        for (int k = lt; k < n; k += tp) {                        // results to the other buffer in output order
+            int j = k + rot_out; if (j >= n) j -= n;
+            nxt[j] = cmul(cur[k], chirp[k]);
+        }
+    }
+    __syncthreads();
+    if (live) {
+        for (int j = lt; j < n; j += tp) dst_g[j] = nxt[j];
+        for (int jj = lt; jj < cp_out; jj += tp) dst_g[jj - cp_out] = nxt[n - cp_out + jj];
+    }
+}
+
 static int launch_fft_vcc_ex(jrc_ctx* ctx, int n, int forward, int shift, const float* d_window, size_t batch,
                              const float2* d_in, float2* d_out, long in_stride, int in_offset, long out_stride, int cp_out,
                              hipStream_t stream);
@@ -129,9 +218,36 @@ static int launch_fft_vcc_ex(jrc_ctx* ctx, int n, int forward, int shift, const 
                              const float2* d_in, float2* d_out, long in_stride, int in_offset, long out_stride, int cp_out,
                              hipStream_t stream)
 {
-    if (!jrc_is_pow2(n) || n < 2 || n > 16384)
-        return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "fft_vcc: fft_size %d is not a power of two in [2, 16384]", n);
+    if (n < 1 || (jrc_is_pow2(n) ? n > 16384 : n > JRC_FFT_MAX_ANY))
+        return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "fft_vcc: fft_size %d is outside [1, 16384] (powers of two) / [1, %d] (any size)", n, JRC_FFT_MAX_ANY);
     if (batch == 0) return JRC_OK;
+    if (n == 1) {                        // the 1-point transform is a copy (window applied)
+        hipLaunchKernelGGL(fft_copy1_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, stream, d_in, d_out, d_window, batch,
+                           in_stride, in_offset, out_stride, cp_out);
+        JRC_HIP(ctx, hipGetLastError());
+        return JRC_OK;
+    }
+    if (!jrc_is_pow2(n)) {
+        jrc_ctx::bluestein_tab bt;
+        JRC_TRY(jrc_get_bluestein(ctx, n, forward ? -1 : +1, &bt));
+        const float2 *twf = nullptr, *twi = nullptr;
+        JRC_TRY(jrc_get_twiddles(ctx, bt.M, -1, &twf));
+        JRC_TRY(jrc_get_twiddles(ctx, bt.M, +1, &twi));
+        int tp = bt.M / 4; if (tp > 256) tp = 256; if (tp < 1) tp = 1;
+        const int per_block = 256 / tp;
+        const size_t blocks = (batch + per_block - 1) / per_block;
+        const size_t lds_bytes = sizeof(float2) * 2 * (size_t)bt.M * per_block;
+        static size_t attr_bytes3 = 64 * 1024;
+        if (lds_bytes > attr_bytes3) {
+            JRC_HIP(ctx, hipFuncSetAttribute((const void*)fft_bluestein_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            attr_bytes3 = lds_bytes;
+        }
+        hipLaunchKernelGGL(fft_bluestein_kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, stream, d_in, d_out, (const float2*)bt.chirp,
+                           (const float2*)bt.bhat, twf, twi, d_window, n, bt.M, jrc_ilog2(bt.M), forward, shift, batch, in_stride,
+                           in_offset, tp, out_stride, cp_out);
+        JRC_HIP(ctx, hipGetLastError());
+        return JRC_OK;
+    }
     const float2* tw = nullptr;
     JRC_TRY(jrc_get_twiddles(ctx, n, forward ? -1 : +1, &tw));
     const int logn = jrc_ilog2(n);
@@ -178,8 +294,8 @@ extern "C" int jrc_fft_vcc(jrc_ctx* ctx, int fft_size, int forward, int shift, c
                            const jrc_cf32* in, jrc_cf32* out)
 {
     if (!ctx || !in || !out) return JRC_ERR_INVALID_ARG;
-    if (!jrc_is_pow2(fft_size) || fft_size < 2 || fft_size > 16384)
-        return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "fft_vcc: fft_size %d is not a power of two in [2, 16384]", fft_size);
+    if (fft_size < 1 || (jrc_is_pow2(fft_size) ? fft_size > 16384 : fft_size > JRC_FFT_MAX_ANY))
+        return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "fft_vcc: fft_size %d is outside [1, 16384] (powers of two) / [1, %d] (any size)", fft_size, JRC_FFT_MAX_ANY);
     JRC_HIP(ctx, hipSetDevice(ctx->device));
     const size_t bytes = sizeof(float2) * (size_t)fft_size * batch;
     const size_t wbytes = window ? sizeof(float) * (size_t)fft_size : 0;

@@ -24,6 +24,9 @@ struct jrc_ctx {
     size_t scratch_bytes[4] = {0, 0, 0, 0};
     // twiddle tables exp(sign*j*2*pi*k/n), k < n, keyed by sign*n
     std::map<long, float2*> twiddles;
+    // chirp-z tables for fft sizes that are not powers of two, keyed by sign*n
+    struct bluestein_tab { float2* chirp; float2* bhat; int M; };
+    std::map<long, bluestein_tab> bluestein;
 };
 
 int  jrc_fail(jrc_ctx* ctx, int status, const char* fmt, ...);
@@ -31,6 +34,8 @@ int  jrc_ensure_pinned(jrc_ctx* ctx, size_t bytes);
 int  jrc_ensure_scratch(jrc_ctx* ctx, int slot, size_t bytes);
 // full-circle table of n entries: tw[k] = exp(sign * j * 2*pi * k / n), computed in double
 int  jrc_get_twiddles(jrc_ctx* ctx, int n, int sign, const float2** out);
+// chirp c[k] = exp(sign*j*pi*k^2/n) (k < n) and bhat = FFT_M(conj(c) wrapped to M)/M, M = 2^k >= 2n-1, computed in double
+int  jrc_get_bluestein(jrc_ctx* ctx, int n, int sign, jrc_ctx::bluestein_tab* out);
 
 #define JRC_HIP(ctx, expr)                                                                      \
     do {                                                                                        \

@@ -9,6 +9,8 @@
  */
 #include "jrc_oracle.h"
 
+void orc_dft_any_f64(int n, int sign, double* re, double* im);   /* jrc_oracle_tsim.c */
+
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -183,7 +185,8 @@ void orc_fft_vcc(int n, int forward, int shift, const float* window, long batch,
             float xi = window ? x[2 * src + 1] * window[src] : x[2 * src + 1];
             re[i] = xr; im[i] = xi;
         }
-        fft_core_f64(n, forward ? -1 : +1, re, im);
+        if ((n & (n - 1)) == 0) fft_core_f64(n, forward ? -1 : +1, re, im);
+        else orc_dft_any_f64(n, forward ? -1 : +1, re, im);        /* FFTW handles any size: mixed radix in double */
         for (int i = 0; i < n; i++) {
             int src = i;
             if (forward && shift) src = (i + half_out) % n;

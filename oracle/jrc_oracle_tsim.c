@@ -142,6 +142,22 @@ static void dft_rec(int n, int stride, const double complex* in, double complex*
 }
 /* note: the in-place combine above is safe because column q only reads and writes the p entries {r*m+q} */
 
+/* in-place double-precision form for orc_fft_vcc's non-power-of-two sizes */
+void orc_dft_any_f64(int n, int sign, double* re, double* im)
+{
+    double complex* a = (double complex*)malloc(sizeof(double complex) * (size_t)n);
+    double complex* b = (double complex*)malloc(sizeof(double complex) * (size_t)n);
+    double complex* w = (double complex*)malloc(sizeof(double complex) * (size_t)n);
+    double complex* tmp = (double complex*)malloc(sizeof(double complex) * (size_t)n);
+    for (int i = 0; i < n; i++) {
+        a[i] = re[i] + I * im[i];
+        w[i] = cos(2.0 * TS_PI * i / n) + I * (double)sign * sin(2.0 * TS_PI * i / n);
+    }
+    dft_rec(n, 1, a, b, w, 1, tmp);
+    for (int i = 0; i < n; i++) { re[i] = creal(b[i]); im[i] = cimag(b[i]); }
+    free(a); free(b); free(w); free(tmp);
+}
+
 void orc_dft_any(int n, int forward, const float* in, float* out)
 {
     double complex* a = (double complex*)malloc(sizeof(double complex) * (size_t)n);

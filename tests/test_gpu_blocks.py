@@ -53,7 +53,7 @@ def test_mimo_ofdm_radar_short_input_fails_loudly(jrc, ctx):
     assert e.value.status == jrc.JRC_ERR_SHORT_INPUT
 
 
-@pytest.mark.parametrize("n", [2, 4, 64, 256, 512, 2048, 8192, 16384])
+@pytest.mark.parametrize("n", [1, 2, 4, 64, 256, 512, 2048, 8192, 16384, 3, 6, 12, 45, 96, 100, 255, 1000, 3000, 4095])
 @pytest.mark.parametrize("forward,shift", [(True, False), (True, True), (False, False), (False, True)])
 def test_fft_vcc(jrc, ctx, n, forward, shift):
     rng = np.random.default_rng(n + forward + 2 * shift)
@@ -74,9 +74,15 @@ def test_fft_vcc_window_and_impulse(jrc, ctx):
     imp[0, 3] = 1
     got = jrc.fft_vcc(256, True, None, False, ctx=ctx).work(imp)
     assert rel_err(got, np.exp(-2j * np.pi * 3 * np.arange(256) / 256)) < FFT_TOL
-    with pytest.raises(jrc.JrcError) as e:
-        jrc.fft_vcc(40, True, ctx=ctx).work(np.zeros(40, np.complex64))
-    assert e.value.status == jrc.JRC_ERR_UNSUPPORTED
+    x40 = crandn(rng, 3, 40)                           # not a power of two: chirp-z path, windowed, both directions
+    w40 = rng.uniform(0.5, 1.5, 40).astype(np.float32)
+    for fwd in (True, False):
+        got = jrc.fft_vcc(40, fwd, w40, True, ctx=ctx).work(x40)
+        assert rel_err(got, oracle.fft_vcc(x40, fwd, True, window=w40)) < FFT_TOL
+    for n_bad in (5000, 32768):                        # beyond the chirp-z / power-of-two limits: refused, not approximated
+        with pytest.raises(jrc.JrcError) as e:
+            jrc.fft_vcc(n_bad, True, ctx=ctx).work(np.zeros(n_bad, np.complex64))
+        assert e.value.status == jrc.JRC_ERR_UNSUPPORTED
 
 
 @pytest.mark.parametrize("P,L,Ia", [(8, 512, 16), (16, 2048, 16), (16, 8192, 16), (3, 50, 2), (64, 64, 1), (1, 7, 4)])
@@ -102,7 +108,7 @@ def test_cp_remover(jrc, ctx, N, cp, k, tail):
     assert np.array_equal(blk.work(x), oracle.cp_remove(x, N, cp))
 
 
-@pytest.mark.parametrize("N,cp,k", [(64, 16, 9), (256, 64, 69), (1024, 256, 133)])
+@pytest.mark.parametrize("N,cp,k", [(64, 16, 9), (256, 64, 69), (1024, 256, 133), (48, 12, 7), (80, 20, 11), (600, 75, 3)])
 def test_cp_remover_fused_with_rx_fft(jrc, ctx, N, cp, k):
     rng = np.random.default_rng(N)
     x = crandn(rng, k * (N + cp))
@@ -111,7 +117,8 @@ def test_cp_remover_fused_with_rx_fft(jrc, ctx, N, cp, k):
     assert rel_err(got, ref) < FFT_TOL
 
 
-@pytest.mark.parametrize("N,cp,k,win", [(64, 16, 9, True), (256, 64, 73, False), (1024, 256, 5, True), (64, 0, 3, False)])
+@pytest.mark.parametrize("N,cp,k,win", [(64, 16, 9, True), (256, 64, 73, False), (1024, 256, 5, True), (64, 0, 3, False),
+                                        (48, 12, 6, True), (80, 20, 5, False), (75, 7, 4, True)])
 def test_tx_ofdm_modulator_and_rx_demod_round_trip(jrc, ctx, N, cp, k, win):
     """fft_vxx reverse/shift/window + cyclic prefixer (TX side of the flowgraph), then A6+A7 brings the symbols back"""
     rng = np.random.default_rng(N + cp)

@@ -89,7 +89,9 @@ def test_chain_config_d_eight_targets(jrc, ctx):
 
 @pytest.mark.parametrize("T,R,N,S,Ir,Ia,interleave", [(2, 1, 128, 3, 4, 8, False), (2, 2, 64, 2, 2, 2, True),
                                                       (4, 4, 512, 8, 1, 4, False), (1, 2, 1024, 2, 2, 32, False),
-                                                      (4, 1, 64, 4, 8, 64, False)])
+                                                      (4, 1, 64, 4, 8, 64, False),
+                                                      # transform sizes that are not powers of two (chirp-z fft_vcc):
+                                                      (3, 2, 64, 3, 8, 16, False), (3, 1, 48, 3, 4, 8, True), (2, 3, 80, 2, 5, 3, False)])
 def test_chain_other_shapes(jrc, ctx, T, R, N, S, Ir, Ia, interleave):
     from jrc_amd import synth
     sc = synth.Scenario(N, T, R, S, targets=[(8.0, 10.0, 5.0, 50.0)])
@@ -113,13 +115,13 @@ def test_chain_linearity_and_frame_independence(jrc, ctx):
 
 
 def test_chain_unsupported_shape_fails_loudly(jrc, ctx):
-    rb, ab = jrc.radar_axes(48, 125e6, 8, 8, 16)
+    rb, ab = jrc.radar_axes(1000, 125e6, 8, 8, 16)        # range transform 8000: not a power of two and > 4096
     with pytest.raises(jrc.JrcError) as e:
-        jrc.RadarChain(48, 4, 2, 4, 5, 8, 16, rb, ab, 2.4, 29.0, ctx=ctx)
+        jrc.RadarChain(1000, 4, 2, 4, 5, 8, 16, rb, ab, 2.4, 29.0, ctx=ctx)
     assert e.value.status == jrc.JRC_ERR_UNSUPPORTED
-    rb, ab = jrc.radar_axes(64, 125e6, 8, 6, 16)          # P = 6: angle transform size 96 is not a power of two
+    rb, ab = jrc.radar_axes(64, 125e6, 8, 6, 1024)        # angle transform 6144: same
     with pytest.raises(jrc.JrcError) as e:
-        jrc.RadarChain(64, 3, 2, 4, 5, 8, 16, rb, ab, 2.4, 29.0, ctx=ctx)
+        jrc.RadarChain(64, 3, 2, 4, 5, 8, 1024, rb, ab, 2.4, 29.0, ctx=ctx)
     assert e.value.status == jrc.JRC_ERR_UNSUPPORTED
 
 
