@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses GPU 0")
     ap.add_argument("--gather-results", action="store_true",
                     help="also RCCL all-gather the per-frame results every step (optional exchange, off by default)")
+    ap.add_argument("--gather-maps", type=int, default=0, metavar="K",
+                    help="also RCCL all-gather the range-angle maps of the first K frames of every rank each step (optional exchange, off by default)")
     return ap.parse_args()
 
 
@@ -148,12 +150,16 @@ def main():
 
     gathered = [None]
     do_gather = a.gather_results and world > 1
+    k_maps = min(a.gather_maps, F) if world > 1 else 0
 
     def step():
         chain.run(bufs, F)
         if do_gather:                         # optional exchange step: per-frame result records over RCCL
             ctx.sync()
             gathered[0] = shard.gather_results(bufs["results"], world * F)
+        if k_maps:                            # optional exchange step: K maps per rank over RCCL / xGMI
+            ctx.sync()
+            gathered[0] = shard.gather_maps(bufs["map"][:k_maps], world * k_maps)
 
     for _ in range(a.warmup):
         step()
@@ -198,7 +204,7 @@ def main():
                                    "range_angle_estimator), %d frames/GPU/step resident in HBM"
                                    % (a.config, sc.T, sc.R, sc.N, sc.S, Ir, Ia, NR, NA, F),
                        "frames_per_gpu_per_step": F, "parallelism": "frame-sharded x%d, no data-path collective" % world,
-                       "gather_results": bool(do_gather)},
+                       "gather_results": bool(do_gather), "gather_maps_per_gpu": int(k_maps)},
             "roofline": {"bound": "hbm", "kernel": "range_angle_fused_kernel<%d>" % P, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,

@@ -34,6 +34,15 @@ def gather_results(local, n_frames, group=None):
     return torch.cat([out[r][:sizes[r]] for r in range(world)], dim=0)
 
 
+def gather_maps(local_maps, n_frames, group=None):
+    """optional exchange named by the north star: all-gather range-angle maps (float32 tensor [n_local, NR, NA, 2]) into
+    frame order on every rank.  A config-B map is 4 MiB, a config-D map 16 MiB: per step and per GPU this moves
+    (world - 1) x n_local maps over xGMI, so it is meant for a few selected frames (detections), not for whole batches.
+    RCCL picks the algorithm; on the fully connected 8-GPU xGMI mesh every peer pair has its own link, so the cost is
+    one map per link per peer rather than a 7-step ring."""
+    return gather_results(local_maps, n_frames, group=group)
+
+
 def max_over_ranks(seconds, device="cpu", group=None):
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     if dist.is_initialized() and dist.get_world_size(group) > 1:

@@ -45,6 +45,11 @@ def _worker(rank, world, port, n_frames, q):
     frames = synth.make_frames(sc, hi - lo, first_frame=lo)      # every rank generates only its own block
     local = _process(frames, sc, 4, 8)
     allr = shard.gather_results(local, n_frames)
+    maps = torch.arange((hi - lo) * 6, dtype=torch.float32).reshape(hi - lo, 3, 1, 2) + 1000.0 * rank   # stand-in range-angle maps
+    allm = shard.gather_maps(maps, n_frames)
+    want = torch.cat([torch.arange(n * 6, dtype=torch.float32).reshape(n, 3, 1, 2) + 1000.0 * r
+                      for r, n in enumerate(shard.shard_sizes(n_frames, world))])
+    assert torch.equal(allm, want)
     t = shard.max_over_ranks(0.1 * (rank + 1))
     if rank == 0:
         q.put((allr.numpy().copy(), t))
