@@ -33,7 +33,7 @@ class RaResult(C.Structure):
 
 def build(force=False):
     """Compile oracle/jrc_oracle*.c with gcc (the checker, not the product)."""
-    srcs = [os.path.join(_HERE, f) for f in ("jrc_oracle.c", "jrc_oracle_comm.c", "jrc_oracle_tsim.c", "jrc_oracle_codec.c", "jrc_oracle.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("jrc_oracle.c", "jrc_oracle_comm.c", "jrc_oracle_tsim.c", "jrc_oracle_codec.c", "jrc_oracle_sync.c", "jrc_oracle.h", "Makefile")]
     if (not force and os.path.exists(_LIB_PATH)
             and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
         return _LIB_PATH
@@ -500,3 +500,133 @@ def constellation_point(bpsc, value):
 
 def constellation_decide(bpsc, z):
     return _codec_lib().orc_constellation_decide(bpsc, float(np.real(z)), float(np.imag(z)))
+
+
+# ---- sync front-end (oracle/jrc_oracle_sync.c) -----------------------------------------------------------------
+_u64p = C.POINTER(C.c_uint64)
+_dblp = C.POINTER(C.c_double)
+
+
+def _sync_lib():
+    L = lib()
+    if not getattr(L, "_sync_ready", False):
+        L.orc_moving_avg_work.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, c_float_p, c_float_p]
+        L.orc_sync_metrics.argtypes = [c_float_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_float_p, c_float_p, c_float_p]
+        L.orc_fd_create.restype = C.c_void_p
+        L.orc_fd_create.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, C.c_int]
+        L.orc_fd_destroy.argtypes = [C.c_void_p]
+        L.orc_fd_work.argtypes = [C.c_void_p, C.c_int, C.c_int, c_float_p, c_float_p, c_float_p, c_float_p, C.POINTER(C.c_int),
+                                  _u64p, _dblp, C.c_int, C.POINTER(C.c_int)]
+        L.orc_fs_create.restype = C.c_void_p
+        L.orc_fs_create.argtypes = [C.c_int, C.c_int, C.c_int, c_float_p, C.c_int]
+        L.orc_fs_destroy.argtypes = [C.c_void_p]
+        L.orc_fs_frame_start.argtypes = [C.c_void_p]
+        L.orc_fs_freq_offset.restype = C.c_double
+        L.orc_fs_freq_offset.argtypes = [C.c_void_p]
+        L.orc_fs_work.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, _u64p, _dblp, C.c_int, c_float_p,
+                                  C.POINTER(C.c_int), _u64p, _dblp, C.POINTER(C.c_int)]
+        L._sync_ready = True
+    return L
+
+
+def moving_avg(x, length, scale=1.0, max_iter=16000, history=None):
+    """moving_avg_impl::work for one call: x = the new items; history = the length-1 items before them (zeros at stream start)"""
+    L = _sync_lib()
+    x = _c64(x).ravel()
+    h = np.zeros(length - 1, np.complex64) if history is None else _c64(history)
+    buf = np.concatenate([h, x]).astype(np.complex64)
+    out = np.zeros(x.size, np.complex64)
+    n = L.orc_moving_avg_work(length, float(scale), max_iter, x.size, _fp(buf), _fp(out))
+    return out[:n]
+
+
+def sync_metrics(x, delay, window, pwindow, pscale):
+    L = _sync_lib()
+    x = _c64(x).ravel()
+    xd, ia, ic = np.zeros_like(x), np.zeros_like(x), np.zeros(x.size, np.float32)
+    L.orc_sync_metrics(_fp(x), x.size, delay, window, pwindow, float(pscale), _fp(xd), _fp(ia), _fp(ic))
+    return xd, ia, ic
+
+
+class FrameDetector:
+    """frame_detector_impl (lib/frame_detector_impl.cc:40-205) restated; work() = one general_work call"""
+
+    def __init__(self, fft_len, cp_len, threshold, min_n_peaks, ignore_gap):
+        self._L = _sync_lib()
+        self._h = self._L.orc_fd_create(fft_len, cp_len, float(threshold), int(min_n_peaks), int(ignore_gap))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.orc_fd_destroy(self._h)
+            self._h = None
+
+    def work(self, x, in_abs, in_cor, noutput):
+        x, in_abs = _c64(x), _c64(in_abs)
+        in_cor = np.ascontiguousarray(in_cor, np.float32)
+        n = min(x.size, in_abs.size, in_cor.size)
+        out = np.zeros(max(noutput, 1), np.complex64)
+        cons, nt = C.c_int(), C.c_int()
+        to, tc = (C.c_uint64 * 4)(), (C.c_double * 4)()
+        no = self._L.orc_fd_work(self._h, noutput, n, _fp(x), _fp(in_abs), _fp(in_cor), _fp(out), C.byref(cons), to, tc, 4, C.byref(nt))
+        return out[:no], cons.value, [(int(to[i]), float(tc[i])) for i in range(nt.value)]
+
+    def run(self, x, in_abs, in_cor, chunk=1 << 30):
+        """drive work() until the inputs are used up, like a scheduler that always offers everything it has"""
+        pos, outs, tags = 0, [], []
+        while pos < len(x):
+            n = min(chunk, len(x) - pos)
+            o, c, t = self.work(x[pos:pos + n], in_abs[pos:pos + n], in_cor[pos:pos + n], n)
+            outs.append(o)
+            tags += t
+            if c == 0 and o.size == 0:
+                break
+            pos += c
+        return np.concatenate(outs) if outs else np.zeros(0, np.complex64), tags
+
+
+class FrameSync:
+    """frame_sync_impl (lib/frame_sync_impl.cc:45-289) restated; work() = one general_work call"""
+
+    def __init__(self, fft_len, cp_len, sync_length, ltf_seq_time):
+        self._L = _sync_lib()
+        t = _c64(ltf_seq_time)
+        self._h = self._L.orc_fs_create(fft_len, cp_len, int(sync_length), _fp(t), t.size)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.orc_fs_destroy(self._h)
+            self._h = None
+
+    @property
+    def frame_start(self):
+        return self._L.orc_fs_frame_start(self._h)
+
+    @property
+    def freq_offset(self):
+        return self._L.orc_fs_freq_offset(self._h)
+
+    def work(self, x, x_delayed, tags, noutput):
+        """tags: [(absolute offset on input 0, value)]"""
+        x, xd = _c64(x), _c64(x_delayed)
+        out = np.zeros(max(noutput, 1), np.complex64)
+        nt = len(tags)
+        to = (C.c_uint64 * max(nt, 1))(*[int(t[0]) for t in tags])
+        tv = (C.c_double * max(nt, 1))(*[float(t[1]) for t in tags])
+        cons, nto = C.c_int(), C.c_int()
+        oo, ov = (C.c_uint64 * 1)(), (C.c_double * 1)()
+        no = self._L.orc_fs_work(self._h, noutput, x.size, xd.size, _fp(x), _fp(xd), to, tv, nt, _fp(out), C.byref(cons), oo, ov, C.byref(nto))
+        if no < 0:
+            raise RuntimeError("[FRAME SYNC] Something is wrong!")
+        return out[:no], cons.value, [(int(oo[0]), float(ov[0]))] if nto.value else []
+
+    def run(self, x, x_delayed, tags, chunk=8192):
+        pos, outs, otags, idle = 0, [], [], 0
+        n = min(len(x), len(x_delayed))
+        while pos < n and idle < 3:
+            m = min(chunk, n - pos)
+            o, c, t = self.work(x[pos:pos + m], x_delayed[pos:pos + m], tags, m)
+            outs.append(o)
+            otags += t
+            idle = idle + 1 if (c == 0 and o.size == 0) else 0
+            pos += c
+        return np.concatenate(outs) if outs else np.zeros(0, np.complex64), otags

@@ -169,6 +169,25 @@ int  orc_stream_encode(int mcs, int n_dc, const uint8_t* psdu, int len, int scra
 int  orc_viterbi_windowed(int mcs, int n_sym, int n_cbps, int n_data_bits, const uint8_t* in, uint8_t* decoded);
 int  orc_stream_decode(int mcs, int n_dc, int data_size_byte, const float* sym, uint8_t* out_payload);
 
+/* ---- §8(f) rank 4: sync front-end (lib/moving_avg_impl.cc, lib/frame_detector_impl.cc, lib/frame_sync_impl.cc) ---- */
+int  orc_moving_avg_work(int length, float scale, int max_iter, int noutput_items, const float* in, float* out);
+void orc_sync_metrics(const float* x, int n, int delay, int window, int pwindow, float pscale, float* xd, float* in_abs,
+                      float* in_cor);
+typedef struct orc_fd_state orc_fd_state;
+orc_fd_state* orc_fd_create(int fft_len, int cp_len, double threshold, int min_n_peaks, int ignore_gap);
+void orc_fd_destroy(orc_fd_state* s);
+int  orc_fd_work(orc_fd_state* s, int noutput, int ninput, const float* in, const float* in_abs, const float* in_cor, float* out,
+                 int* consumed, uint64_t* tag_off, double* tag_cfo, int max_tags, int* n_tags);
+typedef struct orc_fs_state orc_fs_state;
+orc_fs_state* orc_fs_create(int fft_len, int cp_len, int sync_length, const float* ltf_seq_time, int ntaps);
+void orc_fs_destroy(orc_fs_state* s);
+int  orc_fs_frame_start(const orc_fs_state* s);
+double orc_fs_freq_offset(const orc_fs_state* s);
+/* returns items produced, -1 for the runtime_error of :135 */
+int  orc_fs_work(orc_fs_state* s, int noutput, int ninput0, int ninput1, const float* in, const float* in_delayed,
+                 const uint64_t* tin_off, const double* tin_val, int n_tin, float* out, int* consumed, uint64_t* tag_out_off,
+                 double* tag_out_val, int* n_tag_out);
+
 #ifdef __cplusplus
 }
 #endif
