@@ -877,3 +877,175 @@ class stream_decoder:
         self.ctx.check(self.L.jrc_stream_decode_dev(self.ctx.h, self.n_data_carriers, n_frames, _vp(d_sym.data_ptr()), sym_stride,
                                                     _vp(d_mcs.data_ptr()), _vp(d_data_bytes.data_ptr()), _vp(d_payload.data_ptr()),
                                                     payload_stride, _vp(d_status.data_ptr()), stream))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# sync front-end (moving_avg, frame_detector, frame_sync) on the device
+_u64p = C.POINTER(C.c_uint64)
+_dblp = C.POINTER(C.c_double)
+
+
+def _load_sync():
+    L = load()
+    if not getattr(L, "_sync_ready", False):
+        L.jrc_moving_avg.argtypes = [_vp, C.c_int, C.c_float, C.c_int, C.c_int, _vp, _vp]
+        L.jrc_moving_avg_dev.argtypes = [_vp, C.c_int, C.c_float, C.c_int, _vp, _vp, _vp]
+        L.jrc_sync_metrics_dev.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp, _vp, _vp, _vp, _vp]
+        L.jrc_frame_detector_create.restype = _vp
+        L.jrc_frame_detector_create.argtypes = [_vp, C.c_int, C.c_int, C.c_double, C.c_uint, C.c_uint]
+        L.jrc_frame_detector_destroy.argtypes = [_vp]
+        L.jrc_frame_detector_destroy.restype = None
+        L.jrc_frame_detector_work.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.POINTER(C.c_int), _u64p, _dblp, C.c_int,
+                                              C.POINTER(C.c_int)]
+        L.jrc_frame_sync_create.restype = _vp
+        L.jrc_frame_sync_create.argtypes = [_vp, C.c_int, C.c_int, C.c_uint, _vp, C.c_int]
+        L.jrc_frame_sync_destroy.argtypes = [_vp]
+        L.jrc_frame_sync_destroy.restype = None
+        L.jrc_frame_sync_work.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _u64p, _dblp, C.c_int, _vp, C.POINTER(C.c_int),
+                                          _u64p, _dblp, C.POINTER(C.c_int)]
+        L.jrc_frame_sync_state.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float)]
+        L._sync_ready = True
+    return L
+
+
+class moving_avg:
+    """include/mimo_ofdm_jrc/moving_avg.h make(length, scale, max_iter, debug); work = lib/moving_avg_impl.cc:62-98.  A sync block
+    with history length-1: work(x) takes the new items and keeps the history between calls."""
+
+    def __init__(self, length, scale=1.0, max_iter=4096, debug=False, ctx=None):
+        self.ctx = ctx or default_context()
+        self.L = _load_sync()
+        self.length, self.scale, self.max_iter = int(length), float(scale), int(max_iter)
+        self._hist = np.zeros(self.length - 1, np.complex64)
+
+    def set_length_and_scale(self, length, scale):
+        self.length, self.scale = int(length), float(scale)
+        self._hist = np.zeros(self.length - 1, np.complex64)
+
+    def work(self, x):
+        x = _c64(x).ravel()
+        buf = np.concatenate([self._hist, x]).astype(np.complex64)
+        out = np.zeros(x.size, np.complex64)
+        n = self.ctx.check(self.L.jrc_moving_avg(self.ctx.h, self.length, self.scale, self.max_iter, x.size, _ptr(buf), _ptr(out)))
+        if n and self.length > 1:
+            self._hist = buf[n:n + self.length - 1].copy()     # the scheduler keeps the last length-1 consumed items as history
+        return out[:n]
+
+
+def sync_metrics(x, delay, window, pwindow, pscale, ctx=None):
+    """the detector's three input streams for a capture (stock blocks of the comm flowgraph): (x delayed, in_abs, in_cor)"""
+    import torch
+    ctx = ctx or default_context()
+    L = _load_sync()
+    x = _c64(x).ravel()
+    d_x = torch.from_numpy(x.view(np.float32).copy()).cuda()
+    d_xd, d_ia = torch.empty_like(d_x), torch.empty_like(d_x)
+    d_ic = torch.empty(x.size, dtype=torch.float32, device="cuda")
+    ctx.check(L.jrc_sync_metrics_dev(ctx.h, x.size, delay, window, pwindow, float(pscale), _vp(d_x.data_ptr()), _vp(d_xd.data_ptr()),
+                                     _vp(d_ia.data_ptr()), _vp(d_ic.data_ptr()), None))
+    ctx.sync()
+    return d_xd.cpu().numpy().view(np.complex64), d_ia.cpu().numpy().view(np.complex64), d_ic.cpu().numpy()
+
+
+class frame_detector:
+    """include/mimo_ofdm_jrc/frame_detector.h make(fft_len, cp_len, threshold, min_n_peaks, ignore_gap, debug); general_work =
+    lib/frame_detector_impl.cc:70-205.  work() is one general_work call; run() offers everything until nothing moves."""
+
+    def __init__(self, fft_len, cp_len, threshold, min_n_peaks, ignore_gap, debug=False, ctx=None):
+        self.ctx = ctx or default_context()
+        self.L = _load_sync()
+        self.h = self.L.jrc_frame_detector_create(self.ctx.h, fft_len, cp_len, float(threshold), int(min_n_peaks), int(ignore_gap))
+        if not self.h:
+            raise ValueError(self.ctx.lib.jrc_last_error(self.ctx.h).decode())
+
+    def work(self, x, in_abs, in_cor, noutput):
+        x, in_abs = _c64(x).ravel(), _c64(in_abs).ravel()
+        in_cor = np.ascontiguousarray(in_cor, np.float32)
+        n = min(x.size, in_abs.size, in_cor.size)
+        out = np.zeros(max(noutput, 1), np.complex64)
+        cons, nt = C.c_int(), C.c_int()
+        to, tc = (C.c_uint64 * 8)(), (C.c_double * 8)()
+        no = self.ctx.check(self.L.jrc_frame_detector_work(self.h, noutput, n, _ptr(x), _ptr(in_abs), _ptr(in_cor), _ptr(out),
+                                                           C.byref(cons), to, tc, 8, C.byref(nt)))
+        return out[:no], cons.value, [(int(to[i]), float(tc[i])) for i in range(nt.value)]
+
+    def run(self, x, in_abs, in_cor, chunk=1 << 30):
+        pos, outs, tags = 0, [], []
+        while pos < len(x):
+            n = min(chunk, len(x) - pos)
+            o, c, t = self.work(x[pos:pos + n], in_abs[pos:pos + n], in_cor[pos:pos + n], n)
+            outs.append(o)
+            tags += t
+            if c == 0 and o.size == 0:
+                break
+            pos += c
+        return (np.concatenate(outs) if outs else np.zeros(0, np.complex64)), tags
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.jrc_frame_detector_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class frame_sync:
+    """include/mimo_ofdm_jrc/frame_sync.h make(fft_len, cp_len, sync_length, ltf_seq_time, debug); general_work =
+    lib/frame_sync_impl.cc:89-229.  work() is one general_work call (at most 8192 items, :111)."""
+
+    def __init__(self, fft_len, cp_len, sync_length, ltf_seq_time, debug=False, ctx=None):
+        self.ctx = ctx or default_context()
+        self.L = _load_sync()
+        t = _c64(ltf_seq_time).ravel()
+        self.h = self.L.jrc_frame_sync_create(self.ctx.h, fft_len, cp_len, int(sync_length), _ptr(t), t.size)
+        if not self.h:
+            raise ValueError(self.ctx.lib.jrc_last_error(self.ctx.h).decode())
+
+    def _state(self):
+        st, fs, fo = C.c_int(), C.c_int(), C.c_float()
+        self.L.jrc_frame_sync_state(self.h, C.byref(st), C.byref(fs), C.byref(fo))
+        return st.value, fs.value, fo.value
+
+    state = property(lambda self: self._state()[0])
+    frame_start = property(lambda self: self._state()[1])
+    freq_offset = property(lambda self: self._state()[2])
+
+    def work(self, x, x_delayed, tags, noutput):
+        x, xd = _c64(x).ravel(), _c64(x_delayed).ravel()
+        out = np.zeros(max(noutput, 1), np.complex64)
+        nt = len(tags)
+        to = (C.c_uint64 * max(nt, 1))(*[int(t[0]) for t in tags])
+        tv = (C.c_double * max(nt, 1))(*[float(t[1]) for t in tags])
+        cons, nto = C.c_int(), C.c_int()
+        oo, ov = (C.c_uint64 * 1)(), (C.c_double * 1)()
+        no = self.ctx.check(self.L.jrc_frame_sync_work(self.h, noutput, x.size, xd.size, _ptr(x) if x.size else None,
+                                                       _ptr(xd) if xd.size else None, to, tv, nt, _ptr(out), C.byref(cons), oo, ov,
+                                                       C.byref(nto)))
+        return out[:no], cons.value, ([(int(oo[0]), float(ov[0]))] if nto.value else [])
+
+    def run(self, x, x_delayed, tags, chunk=8192):
+        pos, outs, otags, idle = 0, [], [], 0
+        n = min(len(x), len(x_delayed))
+        while pos < n and idle < 3:
+            m = min(chunk, n - pos)
+            o, c, t = self.work(x[pos:pos + m], x_delayed[pos:pos + m], tags, m)
+            outs.append(o)
+            otags += t
+            idle = idle + 1 if (c == 0 and o.size == 0) else 0
+            pos += c
+        return (np.concatenate(outs) if outs else np.zeros(0, np.complex64)), otags
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.jrc_frame_sync_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

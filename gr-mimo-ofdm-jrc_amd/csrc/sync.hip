@@ -1,0 +1,585 @@
+// sync.hip — the sync front-end of the comm receive chain on the device:
+//   moving_avg      lib/moving_avg_impl.cc:62-98
+//   frame_detector  lib/frame_detector_impl.cc:70-205
+//   frame_sync      lib/frame_sync_impl.cc:89-289
+// These are sample-serial state machines in the reference.  Here the per-sample arithmetic is data-parallel and the
+// state machines only walk what is sparse:
+//   * moving averages are window sums, one output per lane (no running sum, hence none of its float drift);
+//   * the detector's per-sample test (threshold < cor < 2) becomes a bit mask built by every lane at once; one wave then
+//     steps through the mask 64 samples per word — words without a peak bit are skipped whole unless a peak run is open —
+//     and emits copy segments; the carrier de-rotation of the copied samples is a separate parallel kernel;
+//   * frame_sync's LTF matched filter is one lane per lag, the top-4 search a few wave reductions, and its COPY state
+//     (drop the cyclic prefixes, de-rotate) is a closed-form index map evaluated per lane.
+// Scheduler-visible behaviour (items consumed / produced per call, tags, state carried across calls) follows the
+// reference call for call.
+#include "jrc_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+// ---- moving_avg ---------------------------------------------------------------------------------------------------
+__global__ void moving_avg_kernel(const float2* __restrict__ in, float2* __restrict__ out, int length, float scale, int n)
+{
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float2 sum = in[i];
+    for (int k = 1; k < length; k++) { sum.x = sum.x + in[i + k].x; sum.y = sum.y + in[i + k].y; }
+    if (length == 1) { sum.x = in[0].x + in[i].x; sum.y = in[0].y + in[i].y; }   // the reference seeds its running sum with in[0] (:79): length 1 counts it twice
+    out[i] = make_float2(sum.x * scale, sum.y * scale);
+}
+
+extern "C" int jrc_moving_avg_dev(jrc_ctx* ctx, int length, float scale, int n_out, const jrc_cf32* d_in, jrc_cf32* d_out, void* stream)
+{
+    if (!ctx || length < 1 || n_out < 0 || (n_out > 0 && (!d_in || !d_out))) return JRC_ERR_INVALID_ARG;
+    if (n_out == 0) return 0;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    hipLaunchKernelGGL(moving_avg_kernel, dim3((n_out + 255) / 256), dim3(256), 0, s, (const float2*)d_in, (float2*)d_out, length, scale, n_out);
+    JRC_HIP(ctx, hipGetLastError());
+    return n_out;
+}
+
+extern "C" int jrc_moving_avg(jrc_ctx* ctx, int length, float scale, int max_iter, int noutput_items, const jrc_cf32* in, jrc_cf32* out)
+{
+    if (!ctx || length < 1 || noutput_items < 0 || (noutput_items > 0 && (!in || !out))) return JRC_ERR_INVALID_ARG;
+    const int n = noutput_items > max_iter ? max_iter : noutput_items;                           // :78
+    if (n <= 0) return 0;
+    JRC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t ib = sizeof(float2) * ((size_t)n + length - 1), ob = sizeof(float2) * (size_t)n;
+    JRC_TRY(jrc_ensure_pinned(ctx, ib + ob));
+    JRC_TRY(jrc_ensure_scratch(ctx, 0, ib));
+    JRC_TRY(jrc_ensure_scratch(ctx, 1, ob));
+    memcpy(ctx->pinned, in, ib);
+    JRC_HIP(ctx, hipMemcpyAsync(ctx->scratch[0], ctx->pinned, ib, hipMemcpyHostToDevice, ctx->stream));
+    JRC_TRY(jrc_moving_avg_dev(ctx, length, scale, n, (const jrc_cf32*)ctx->scratch[0], (jrc_cf32*)ctx->scratch[1], ctx->stream));
+    JRC_HIP(ctx, hipMemcpyAsync((char*)ctx->pinned + ib, ctx->scratch[1], ob, hipMemcpyDeviceToHost, ctx->stream));
+    JRC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(out, (char*)ctx->pinned + ib, ob);
+    return n;
+}
+
+// ---- detection metrics of the flowgraph's stock blocks (delay, conj, multiply, moving averages, mag, abs, divide) -----
+// xd[i] = x[i - delay];  in_abs[i] = sum_{j = i-window+1..i} x[j] conj(x[j - delay]);  in_cor[i] = |in_abs[i]| / |pscale sum_{pwindow} |x|^2|
+__global__ void sync_metrics_kernel(const float2* __restrict__ x, int n, int delay, int window, int pwindow, float pscale,
+                                    float2* __restrict__ xd, float2* __restrict__ in_abs, float* __restrict__ in_cor)
+{
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    xd[i] = i >= delay ? x[i - delay] : make_float2(0.f, 0.f);
+    float2 a = make_float2(0.f, 0.f);
+    for (int j = i - window + 1; j <= i; j++) {
+        if (j < delay) continue;                                          // the delayed stream starts with zeros
+        const float2 u = x[j], v = x[j - delay];                          // conj(v) * u
+        a.x = a.x + (v.x * u.x + v.y * u.y);
+        a.y = a.y + (v.x * u.y - v.y * u.x);
+    }
+    float p = 0.f;
+    for (int j = i - pwindow + 1; j <= i; j++) {
+        if (j < 0) continue;
+        const float2 u = x[j];
+        p = p + (u.x * u.x + u.y * u.y);
+    }
+    in_abs[i] = a;
+    in_cor[i] = ref_hypotf(a) / fabsf(p * pscale);
+}
+
+extern "C" int jrc_sync_metrics_dev(jrc_ctx* ctx, int n, int delay, int window, int pwindow, float pscale, const jrc_cf32* d_x,
+                                    jrc_cf32* d_xd, jrc_cf32* d_in_abs, float* d_in_cor, void* stream)
+{
+    if (!ctx || n < 0 || delay < 0 || window < 1 || pwindow < 1 || (n > 0 && (!d_x || !d_xd || !d_in_abs || !d_in_cor))) return JRC_ERR_INVALID_ARG;
+    if (n == 0) return JRC_OK;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    hipLaunchKernelGGL(sync_metrics_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const float2*)d_x, n, delay, window, pwindow, pscale,
+                       (float2*)d_xd, (float2*)d_in_abs, d_in_cor);
+    JRC_HIP(ctx, hipGetLastError());
+    return JRC_OK;
+}
+
+// ---- frame_detector ---------------------------------------------------------------------------------------------
+struct FdState {
+    int state;                       // 0 SEARCH, 1 COPY
+    unsigned n_peaks;
+    unsigned long long first_peak_ind;
+    int copied_samples;
+    float coarse_cfo_est;
+    unsigned long long nread, nwritten;
+};
+struct FdSeg { int off, len, copied0; float cfo; };     // out[off + k] = in[off + k] * exp(-j cfo (copied0 + k))
+#define FD_MAX_TAGS 8
+#define FD_MAX_SEGS 16
+struct FdResult {
+    int consumed, produced, n_tags, n_segs;
+    unsigned long long tag_off[FD_MAX_TAGS];
+    double tag_cfo[FD_MAX_TAGS];
+    FdSeg seg[FD_MAX_SEGS];
+};
+struct FdParams { int fft_len, min_n_peaks, ignore_gap, max_peak_distance, max_samples; double threshold, max_peak_value; };
+
+__global__ void fd_marks_kernel(const float* __restrict__ cor, unsigned long long* __restrict__ marks, int n, double thr, double maxv)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int pk = (i < n) && ((double)cor[i] > thr) && ((double)cor[i] < maxv);       // :95 (float promoted to double)
+    const unsigned long long m = __ballot(pk);
+    if ((threadIdx.x & 63) == 0 && i < n + 63) marks[i >> 6] = m;
+}
+
+// one general_work call (:76-195) walked by a single lane over the peak-mask words; `calls` > 1 repeats the call on what is
+// left (the batched pipeline: a scheduler that always offers everything)
+__global__ void fd_scan_kernel(FdParams p, FdState* __restrict__ st_g, const unsigned long long* __restrict__ marks,
+                               const float2* __restrict__ in_abs, int ninput, int noutput, FdResult* __restrict__ res)
+{
+    if (threadIdx.x != 0) return;
+    FdState s = *st_g;
+    FdResult r;
+    r.consumed = 0; r.produced = 0; r.n_tags = 0; r.n_segs = 0;
+    auto is_mark = [&](int i) -> bool { return (marks[i >> 6] >> (i & 63)) & 1ull; };
+    auto cfo_at = [&](int i) -> float { const float2 a = in_abs[i]; return (float)((double)atan2f(a.y, a.x) / (p.fft_len / 4.0)); };   // :112
+    if (s.state == 0) {                                                                  // SEARCH (:89-134)
+        int n_in = 0;
+        while (n_in < ninput) {
+            if (s.n_peaks == 0 && (n_in & 63) == 0 && n_in + 64 <= ninput && marks[n_in >> 6] == 0ull) { n_in += 64; continue; }
+            const unsigned long long pos = s.nread + (unsigned long long)n_in;
+            if (is_mark(n_in)) {
+                if (s.n_peaks < (unsigned)p.min_n_peaks) {
+                    s.n_peaks++;
+                    if (s.n_peaks == 1) s.first_peak_ind = pos;
+                } else if ((pos - s.first_peak_ind) < (unsigned long long)p.max_peak_distance) {
+                    s.state = 1;
+                    s.copied_samples = 0;
+                    s.coarse_cfo_est = cfo_at(n_in);
+                    s.n_peaks = 0;
+                    s.first_peak_ind = 0;
+                    if (r.n_tags < FD_MAX_TAGS) { r.tag_off[r.n_tags] = s.nwritten; r.tag_cfo[r.n_tags] = s.coarse_cfo_est; r.n_tags++; }
+                    break;
+                } else {
+                    s.n_peaks = 0;
+                    s.first_peak_ind = 0;
+                }
+            } else if ((pos - s.first_peak_ind) > (unsigned long long)p.max_peak_distance) {
+                s.n_peaks = 0;
+                s.first_peak_ind = 0;
+            }
+            n_in++;
+        }
+        r.consumed = n_in;
+        s.nread += (unsigned long long)n_in;
+    } else {                                                                             // COPY (:136-191)
+        int n_out = 0;
+        FdSeg seg; seg.off = 0; seg.len = 0; seg.copied0 = s.copied_samples; seg.cfo = s.coarse_cfo_est;
+        while (n_out < ninput && n_out < noutput && s.copied_samples < p.max_samples) {
+            if (s.n_peaks == 0 && (n_out & 63) == 0 && marks[n_out >> 6] == 0ull) {     // no peak in this word: copy it whole
+                int run = 64;
+                if (run > ninput - n_out) run = ninput - n_out;
+                if (run > noutput - n_out) run = noutput - n_out;
+                if (run > p.max_samples - s.copied_samples) run = p.max_samples - s.copied_samples;
+                if (run == 64) { n_out += 64; s.copied_samples += 64; seg.len += 64; continue; }
+            }
+            const unsigned long long pos = s.nread + (unsigned long long)n_out;
+            if (is_mark(n_out)) {
+                if (s.n_peaks < (unsigned)p.min_n_peaks) {
+                    s.n_peaks++;
+                    if (s.n_peaks == 1) s.first_peak_ind = pos;
+                } else if ((pos - s.first_peak_ind) < (unsigned long long)p.max_peak_distance) {
+                    if (s.copied_samples > p.ignore_gap) {                               // a new frame before MAX_SAMPLES (:153-165)
+                        s.copied_samples = 0;
+                        s.n_peaks = 0;
+                        s.first_peak_ind = 0;
+                        s.coarse_cfo_est = cfo_at(n_out);
+                        if (r.n_tags < FD_MAX_TAGS) { r.tag_off[r.n_tags] = s.nwritten + (unsigned long long)n_out; r.tag_cfo[r.n_tags] = s.coarse_cfo_est; r.n_tags++; }
+                        break;
+                    }
+                } else {
+                    s.n_peaks = 0;
+                    s.first_peak_ind = 0;
+                }
+            } else if ((pos - s.first_peak_ind) > (unsigned long long)p.max_peak_distance) {
+                s.n_peaks = 0;
+                s.first_peak_ind = 0;
+            }
+            n_out++; s.copied_samples++; seg.len++;                                      // out[n_out] = in[n_out] * exp(...) (:178)
+        }
+        if (seg.len) r.seg[r.n_segs++] = seg;
+        if (s.copied_samples == p.max_samples) s.state = 0;
+        r.consumed = n_out; r.produced = n_out;
+        s.nread += (unsigned long long)n_out;
+        s.nwritten += (unsigned long long)n_out;
+    }
+    *st_g = s;
+    *res = r;
+}
+
+__global__ void fd_copy_kernel(const float2* __restrict__ in, float2* __restrict__ out, int off, int len, int copied0, float cfo)
+{
+#pragma clang fp contract(off)
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= len) return;
+    const float ang = -cfo * (float)(copied0 + k);                                       // -coarse_cfo_est * copied_samples: float * int
+    float sn, cs;
+    sincosf(ang, &sn, &cs);
+    out[off + k] = cmul(in[off + k], make_float2(cs, sn));
+}
+
+struct jrc_frame_detector {
+    jrc_ctx* ctx;
+    FdParams p;
+    FdState* d_state = nullptr;
+    FdResult* d_res = nullptr;
+    FdResult* h_res = nullptr;        // pinned
+};
+
+extern "C" jrc_frame_detector* jrc_frame_detector_create(jrc_ctx* ctx, int fft_len, int cp_len, double threshold, unsigned min_n_peaks,
+                                                         unsigned ignore_gap)
+{
+    if (!ctx) return nullptr;
+    if (fft_len < 4 || cp_len < 0) { jrc_fail(ctx, JRC_ERR_INVALID_ARG, "frame_detector: invalid sizes"); return nullptr; }
+    if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+    jrc_frame_detector* d = new jrc_frame_detector();
+    d->ctx = ctx;
+    d->p.fft_len = fft_len; d->p.min_n_peaks = (int)min_n_peaks; d->p.ignore_gap = (int)ignore_gap;
+    d->p.threshold = threshold; d->p.max_peak_value = 2.0;                               // :56
+    d->p.max_peak_distance = 2 * (fft_len + cp_len); d->p.max_samples = 540 * (fft_len + cp_len);   // :57-58
+    FdState z; memset(&z, 0, sizeof(z));
+    if (hipMalloc((void**)&d->d_state, sizeof(FdState)) != hipSuccess || hipMalloc((void**)&d->d_res, sizeof(FdResult)) != hipSuccess ||
+        hipHostMalloc((void**)&d->h_res, sizeof(FdResult), hipHostMallocDefault) != hipSuccess ||
+        hipMemcpy(d->d_state, &z, sizeof(z), hipMemcpyHostToDevice) != hipSuccess) {
+        jrc_fail(ctx, JRC_ERR_NOMEM, "frame_detector: allocation failed");
+        delete d;
+        return nullptr;
+    }
+    return d;
+}
+
+extern "C" void jrc_frame_detector_destroy(jrc_frame_detector* d)
+{
+    if (!d) return;
+    (void)hipStreamSynchronize(d->ctx->stream);
+    (void)hipFree(d->d_state); (void)hipFree(d->d_res); (void)hipHostFree(d->h_res);
+    delete d;
+}
+
+// one general_work call on device buffers; result (consumed / produced / tags) lands in the detector's pinned record
+static int fd_work_dev(jrc_frame_detector* d, int noutput, int ninput, const float2* d_in, const float2* d_in_abs, const float* d_in_cor,
+                       float2* d_out, unsigned long long* d_marks, hipStream_t s)
+{
+    jrc_ctx* ctx = d->ctx;
+    const int nblk = (ninput + 63 + 255) / 256;
+    hipLaunchKernelGGL(fd_marks_kernel, dim3(nblk > 0 ? nblk : 1), dim3(256), 0, s, d_in_cor, d_marks, ninput, d->p.threshold, d->p.max_peak_value);
+    hipLaunchKernelGGL(fd_scan_kernel, dim3(1), dim3(64), 0, s, d->p, d->d_state, (const unsigned long long*)d_marks, d_in_abs, ninput, noutput, d->d_res);
+    JRC_HIP(ctx, hipGetLastError());
+    JRC_HIP(ctx, hipMemcpyAsync(d->h_res, d->d_res, sizeof(FdResult), hipMemcpyDeviceToHost, s));
+    JRC_HIP(ctx, hipStreamSynchronize(s));
+    for (int i = 0; i < d->h_res->n_segs; i++) {
+        const FdSeg& g = d->h_res->seg[i];
+        hipLaunchKernelGGL(fd_copy_kernel, dim3((g.len + 255) / 256), dim3(256), 0, s, d_in, d_out, g.off, g.len, g.copied0, g.cfo);
+    }
+    JRC_HIP(ctx, hipGetLastError());
+    return d->h_res->produced;
+}
+
+extern "C" int jrc_frame_detector_work(jrc_frame_detector* d, int noutput_items, int ninput_items, const jrc_cf32* in, const jrc_cf32* in_abs,
+                                       const float* in_cor, jrc_cf32* out, int* n_consumed, uint64_t* tag_offsets, double* tag_cfo,
+                                       int max_tags, int* n_tags)
+{
+    if (!d || !n_consumed || !n_tags) return JRC_ERR_INVALID_ARG;
+    jrc_ctx* ctx = d->ctx;
+    *n_consumed = 0; *n_tags = 0;
+    if (ninput_items < 0 || noutput_items < 0 || (ninput_items > 0 && (!in || !in_abs || !in_cor)) || (noutput_items > 0 && !out))
+        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "frame_detector: invalid buffers");
+    if (ninput_items == 0) return 0;
+    JRC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t cb = sizeof(float2) * (size_t)ninput_items, fb = sizeof(float) * (size_t)ninput_items;
+    const size_t mb = sizeof(unsigned long long) * ((size_t)ninput_items / 64 + 2);
+    JRC_TRY(jrc_ensure_pinned(ctx, 3 * cb + fb));
+    JRC_TRY(jrc_ensure_scratch(ctx, 0, 2 * cb + fb));
+    JRC_TRY(jrc_ensure_scratch(ctx, 1, cb));
+    JRC_TRY(jrc_ensure_scratch(ctx, 2, mb));
+    char* hp = (char*)ctx->pinned;
+    memcpy(hp, in, cb); memcpy(hp + cb, in_abs, cb); memcpy(hp + 2 * cb, in_cor, fb);
+    JRC_HIP(ctx, hipMemcpyAsync(ctx->scratch[0], hp, 2 * cb + fb, hipMemcpyHostToDevice, ctx->stream));
+    char* d0 = (char*)ctx->scratch[0];
+    const int produced = fd_work_dev(d, noutput_items, ninput_items, (const float2*)d0, (const float2*)(d0 + cb), (const float*)(d0 + 2 * cb),
+                                     (float2*)ctx->scratch[1], (unsigned long long*)ctx->scratch[2], ctx->stream);
+    if (produced < 0) return produced;
+    if (produced > 0) {
+        JRC_HIP(ctx, hipMemcpyAsync(hp + 2 * cb + fb, ctx->scratch[1], sizeof(float2) * (size_t)produced, hipMemcpyDeviceToHost, ctx->stream));
+        JRC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        memcpy(out, hp + 2 * cb + fb, sizeof(float2) * (size_t)produced);
+    }
+    *n_consumed = d->h_res->consumed;
+    const int nt = d->h_res->n_tags < max_tags ? d->h_res->n_tags : max_tags;
+    for (int i = 0; i < nt; i++) { tag_offsets[i] = d->h_res->tag_off[i]; tag_cfo[i] = d->h_res->tag_cfo[i]; }
+    *n_tags = nt;
+    return produced;
+}
+
+// ---- frame_sync -------------------------------------------------------------------------------------------------
+struct FsSearch { int frame_start; float freq_offset; int top_idx[4]; };
+
+// LTF matched filter (gr::filter::kernel::fir_filter_ccc::filterN: y[i] = sum_k taps[k] x[i + ntaps-1-k]) over n_cor lags
+// with sample offsets off0 + i, then search_frame_start() (:232-287) on the SYNC_LENGTH collected values
+__global__ __launch_bounds__(1024) void fs_search_kernel(const float2* __restrict__ in, const float2* __restrict__ taps, int ntaps,
+                                                         int sync_length, int fft_len, FsSearch* __restrict__ res)
+{
+#pragma clang fp contract(off)
+    extern __shared__ float2 s_corr[];                 // [sync_length]
+    __shared__ float s_best[16];
+    __shared__ int s_bidx[16];
+    __shared__ int top[4];
+    for (int i = threadIdx.x; i < sync_length; i += blockDim.x) {
+        float2 acc = make_float2(0.f, 0.f);
+        for (int k = 0; k < ntaps; k++) {
+            const float2 p = cmul(taps[k], in[i + ntaps - 1 - k]);
+            acc.x = acc.x + p.x; acc.y = acc.y + p.y;
+        }
+        s_corr[i] = acc;
+    }
+    __syncthreads();
+    // d_cor.sort(compare_abs2) is stable and descending in |value|: the first four are four rounds of "largest, lowest index"
+    for (int round = 0; round < 4; round++) {
+        float best = -1.f; int bidx = 0x7fffffff;
+        for (int i = threadIdx.x; i < sync_length; i += blockDim.x) {
+            bool taken = false;
+            for (int q = 0; q < round; q++) taken |= (top[q] == i);
+            if (taken) continue;
+            const float m = ref_hypotf(s_corr[i]);     // std::abs(gr_complex)
+            if (m > best || (m == best && i < bidx)) { best = m; bidx = i; }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ob = __shfl_xor(best, off); const int oi = __shfl_xor(bidx, off);
+            if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+        }
+        if ((threadIdx.x & 63) == 0) { s_best[threadIdx.x >> 6] = best; s_bidx[threadIdx.x >> 6] = bidx; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int nw = (blockDim.x + 63) >> 6;
+            for (int w = 1; w < nw; w++)
+                if (s_best[w] > best || (s_best[w] == best && s_bidx[w] < bidx)) { best = s_best[w]; bidx = s_bidx[w]; }
+            top[round] = bidx;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        FsSearch r;
+        r.frame_start = sync_length;                                                     // :242
+        r.freq_offset = 0.f;
+        bool have_freq = false;
+        float2 v[4]; int ix[4];
+        for (int q = 0; q < 4; q++) { ix[q] = top[q]; v[q] = s_corr[top[q]]; r.top_idx[q] = top[q]; }
+        bool done = false;
+        for (int i = 0; i < 3 && !done; i++)
+            for (int k = i + 1; k < 4 && !done; k++) {
+                float2 first, second;
+                if (ix[i] > ix[k]) { first = v[k]; second = v[i]; } else { first = v[i]; second = v[k]; }
+                const int diff = abs(ix[i] - ix[k]);
+                const int mn = min(ix[i], ix[k]);
+                const float2 pr = cmul(first, make_float2(second.x, -second.y));
+                const float ang = atan2f(pr.y, pr.x);
+                if (diff == fft_len) { r.frame_start = mn; r.freq_offset = ang / fft_len; have_freq = true; done = true; }
+                else if (diff == fft_len - 1) { r.frame_start = mn; r.freq_offset = ang / (fft_len - 1); have_freq = true; }
+                else if (diff == fft_len + 1) { r.frame_start = mn; r.freq_offset = ang / (fft_len + 1); have_freq = true; }
+            }
+        if (!have_freq) r.freq_offset = __int_as_float(0x7fc00000);                       // "keep the previous d_freq_offset": resolved on the host
+        *res = r;
+    }
+}
+
+// COPY (:175-202) as an index map: input sample n (sample offset so0 + n) is kept when rel >= 0 and it is not a cyclic
+// prefix; kept samples are packed in order.  kept_before(rel) is the closed form of the loop's n_out.
+__host__ __device__ static inline long fs_kept_before(long rel, int N, int cp)
+{
+    if (rel <= 0) return 0;
+    if (rel <= 2L * N) return rel;
+    const long q = (rel - 2L * N) / (N + cp), rem = (rel - 2L * N) % (N + cp);
+    return 2L * N + q * N + (rem > cp ? rem - cp : 0);
+}
+__global__ void fs_copy_kernel(const float2* __restrict__ in_delayed, float2* __restrict__ out, int n_in, int so0, int frame_start, float freq_offset,
+                               int N, int cp, long kept0, int noutput)
+{
+#pragma clang fp contract(off)
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_in) return;
+    const int so = so0 + n;
+    const long rel = (long)so - frame_start;
+    if (rel < 0) return;
+    const bool keep = rel < 2L * N || ((rel - 2L * N) % (N + cp)) > cp - 1;
+    if (!keep) return;
+    const long o = fs_kept_before(rel, N, cp) - kept0;
+    if (o < 0 || o >= noutput) return;
+    float sn, cs;
+    sincosf((float)so * freq_offset, &sn, &cs);                                          // sample_offset * d_freq_offset: int * float (:193)
+    out[o] = cmul(in_delayed[n], make_float2(cs, sn));
+}
+
+struct jrc_frame_sync {
+    jrc_ctx* ctx;
+    int fft_len, cp_len, sync_length, ntaps;
+    float2* d_taps = nullptr;
+    FsSearch* d_res = nullptr;
+    FsSearch* h_res = nullptr;
+    // block state (:37-56)
+    int state = 0;                    // 0 SYNC, 1 COPY, 2 RESET
+    int sample_offset = 0, frame_start = 0, total_out_count = 0;
+    float freq_offset = 0.f;
+    double cfo_coarse_est = 0.0;
+    uint64_t nread = 0, nwritten = 0;
+    std::vector<float2> sync_buf;     // samples collected while in SYNC across calls
+};
+
+extern "C" jrc_frame_sync* jrc_frame_sync_create(jrc_ctx* ctx, int fft_len, int cp_len, unsigned sync_length, const jrc_cf32* ltf_seq_time, int ntaps)
+{
+    if (!ctx) return nullptr;
+    if (fft_len < 4 || cp_len < 0 || sync_length < 4 || sync_length > 8192 || !ltf_seq_time || ntaps < 1) {
+        jrc_fail(ctx, JRC_ERR_INVALID_ARG, "frame_sync: invalid configuration");
+        return nullptr;
+    }
+    if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+    jrc_frame_sync* f = new jrc_frame_sync();
+    f->ctx = ctx; f->fft_len = fft_len; f->cp_len = cp_len; f->sync_length = (int)sync_length; f->ntaps = ntaps;
+    if (hipMalloc((void**)&f->d_taps, sizeof(float2) * (size_t)ntaps) != hipSuccess || hipMalloc((void**)&f->d_res, sizeof(FsSearch)) != hipSuccess ||
+        hipHostMalloc((void**)&f->h_res, sizeof(FsSearch), hipHostMallocDefault) != hipSuccess ||
+        hipMemcpy(f->d_taps, ltf_seq_time, sizeof(float2) * (size_t)ntaps, hipMemcpyHostToDevice) != hipSuccess) {
+        jrc_fail(ctx, JRC_ERR_NOMEM, "frame_sync: allocation failed");
+        delete f;
+        return nullptr;
+    }
+    return f;
+}
+
+extern "C" void jrc_frame_sync_destroy(jrc_frame_sync* f)
+{
+    if (!f) return;
+    (void)hipStreamSynchronize(f->ctx->stream);
+    (void)hipFree(f->d_taps); (void)hipFree(f->d_res); (void)hipHostFree(f->h_res);
+    delete f;
+}
+
+extern "C" int jrc_frame_sync_state(const jrc_frame_sync* f, int* state, int* frame_start, float* freq_offset)
+{
+    if (!f) return JRC_ERR_INVALID_ARG;
+    if (state) *state = f->state;
+    if (frame_start) *frame_start = f->frame_start;
+    if (freq_offset) *freq_offset = f->freq_offset;
+    return JRC_OK;
+}
+
+// search on device samples: d_in must hold sync_length + ntaps - 1 samples
+static int fs_search_dev(jrc_frame_sync* f, const float2* d_in, hipStream_t s)
+{
+    jrc_ctx* ctx = f->ctx;
+    hipLaunchKernelGGL(fs_search_kernel, dim3(1), dim3(256), sizeof(float2) * (size_t)f->sync_length, s, d_in, (const float2*)f->d_taps, f->ntaps,
+                       f->sync_length, f->fft_len, f->d_res);
+    JRC_HIP(ctx, hipGetLastError());
+    JRC_HIP(ctx, hipMemcpyAsync(f->h_res, f->d_res, sizeof(FsSearch), hipMemcpyDeviceToHost, s));
+    JRC_HIP(ctx, hipStreamSynchronize(s));
+    f->frame_start = f->h_res->frame_start;
+    if (f->h_res->freq_offset == f->h_res->freq_offset) f->freq_offset = f->h_res->freq_offset;      // NaN = no pair matched: keep the old value
+    return JRC_OK;
+}
+
+extern "C" int jrc_frame_sync_work(jrc_frame_sync* f, int noutput_items, int ninput0, int ninput1, const jrc_cf32* in, const jrc_cf32* in_delayed,
+                                   const uint64_t* tag_offsets, const double* tag_values, int n_tags, jrc_cf32* out, int* n_consumed,
+                                   uint64_t* tag_out_offset, double* tag_out_value, int* n_tag_out)
+{
+    if (!f || !n_consumed || !n_tag_out) return JRC_ERR_INVALID_ARG;
+    jrc_ctx* ctx = f->ctx;
+    *n_consumed = 0; *n_tag_out = 0;
+    if (noutput_items < 0 || ninput0 < 0 || ninput1 < 0 || n_tags < 0) return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "frame_sync: invalid sizes");
+    int ninput = std::min(std::min(ninput0, ninput1), 8192);                             // :111
+    if (ninput > 0 && (!in || !in_delayed)) return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "frame_sync: null input");
+    if (noutput_items > 0 && !out) return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "frame_sync: null output");
+    JRC_HIP(ctx, hipSetDevice(ctx->device));
+    // the first frame_start tag in [nread, nread + ninput) (:120-146)
+    bool have = false; uint64_t first_off = 0; double first_val = 0;
+    for (int i = 0; i < n_tags; i++)
+        if (tag_offsets[i] >= f->nread && tag_offsets[i] < f->nread + (uint64_t)ninput && (!have || tag_offsets[i] < first_off)) {
+            have = true; first_off = tag_offsets[i]; first_val = tag_values[i];
+        }
+    if (have) {
+        if (first_off > f->nread) {
+            ninput = (int)(first_off - f->nread);
+        } else {
+            if (f->sample_offset && f->state == 0) return jrc_fail(ctx, JRC_ERR_LENGTH_MISMATCH, "[FRAME SYNC] Something is wrong!");   // :135
+            if (f->state == 1) f->state = 2;
+            f->cfo_coarse_est = first_val;
+        }
+    }
+    int n_in = 0, n_out = 0;
+    if (f->state == 0) {                                                                 // SYNC (:153-173)
+        // the reference correlates min(SYNC_LENGTH, ninput - fft_len - 1) lags per call and collects one per consumed sample;
+        // here the samples of the SYNC window are gathered across calls and correlated once it is complete
+        const int usable = ninput - (f->fft_len - 1);                                    // while (n_in + fft_len - 1 < ninput)
+        int take = usable > 0 ? usable : 0;
+        if (take > f->sync_length - f->sample_offset) take = f->sync_length - f->sample_offset;
+        if (take > 0) {
+            const int need_tail = (f->sample_offset + take == f->sync_length) ? f->ntaps - 1 : 0;
+            const int avail_tail = std::min(need_tail, ninput - take);
+            const float2* src = (const float2*)in;
+            f->sync_buf.insert(f->sync_buf.end(), src, src + take + avail_tail);
+            n_in = take;
+            f->sample_offset += take;
+            if (f->sample_offset == f->sync_length) {
+                f->sync_buf.resize((size_t)f->sync_length + f->ntaps - 1, make_float2(0.f, 0.f));
+                const size_t b = sizeof(float2) * f->sync_buf.size();
+                JRC_TRY(jrc_ensure_pinned(ctx, b));
+                JRC_TRY(jrc_ensure_scratch(ctx, 0, b));
+                memcpy(ctx->pinned, f->sync_buf.data(), b);
+                JRC_HIP(ctx, hipMemcpyAsync(ctx->scratch[0], ctx->pinned, b, hipMemcpyHostToDevice, ctx->stream));
+                JRC_TRY(fs_search_dev(f, (const float2*)ctx->scratch[0], ctx->stream));
+                f->sync_buf.clear();
+                f->sample_offset = 0;
+                f->total_out_count = 0;
+                f->state = 1;
+            }
+        }
+    } else if (f->state == 1) {                                                          // COPY (:175-202)
+        const long kept0 = fs_kept_before((long)f->sample_offset - f->frame_start, f->fft_len, f->cp_len);
+        // how far the loop gets: stops at n_in == ninput or as soon as n_out == noutput
+        int lo = 0, hi = ninput;                                                          // largest n with kept(n) - kept0 <= noutput ... then exact stop rule
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) / 2;
+            if (fs_kept_before((long)f->sample_offset + mid - f->frame_start, f->fft_len, f->cp_len) - kept0 < noutput_items) lo = mid; else hi = mid - 1;
+        }
+        // lo = number of samples consumed while n_out < noutput held before each of them; one more is consumed if it exists
+        n_in = lo < ninput ? lo + 1 : lo;
+        if (noutput_items == 0) n_in = 0;
+        n_out = (int)(fs_kept_before((long)f->sample_offset + n_in - f->frame_start, f->fft_len, f->cp_len) - kept0);
+        if (n_in > 0) {
+            const long rel0 = (long)f->sample_offset - f->frame_start;
+            if (rel0 <= 0 && rel0 + n_in > 0) {                                          // the sample with rel == 0 is in this call: tag (:180-186)
+                tag_out_offset[0] = f->nwritten;                                         // nitems_written(0): nothing is produced before rel == 0
+                tag_out_value[0] = f->cfo_coarse_est - f->freq_offset;
+                *n_tag_out = 1;
+            }
+            const size_t ib = sizeof(float2) * (size_t)n_in, ob = sizeof(float2) * (size_t)(n_out > 0 ? n_out : 1);
+            JRC_TRY(jrc_ensure_pinned(ctx, ib + ob));
+            JRC_TRY(jrc_ensure_scratch(ctx, 0, ib));
+            JRC_TRY(jrc_ensure_scratch(ctx, 1, ob));
+            memcpy(ctx->pinned, in_delayed, ib);
+            JRC_HIP(ctx, hipMemcpyAsync(ctx->scratch[0], ctx->pinned, ib, hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(fs_copy_kernel, dim3((n_in + 255) / 256), dim3(256), 0, ctx->stream, (const float2*)ctx->scratch[0], (float2*)ctx->scratch[1],
+                               n_in, f->sample_offset, f->frame_start, f->freq_offset, f->fft_len, f->cp_len, kept0, n_out);
+            JRC_HIP(ctx, hipGetLastError());
+            if (n_out > 0) {
+                JRC_HIP(ctx, hipMemcpyAsync((char*)ctx->pinned + ib, ctx->scratch[1], sizeof(float2) * (size_t)n_out, hipMemcpyDeviceToHost, ctx->stream));
+                JRC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                memcpy(out, (char*)ctx->pinned + ib, sizeof(float2) * (size_t)n_out);
+            } else {
+                JRC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            }
+            f->sample_offset += n_in;
+        }
+    } else {                                                                             // RESET (:204-223)
+        while (n_out < noutput_items) {
+            if (((f->total_out_count + n_out) % f->fft_len) == 0) { f->sample_offset = 0; f->state = 0; break; }
+            ((float2*)out)[n_out] = make_float2(0.f, 0.f);
+            n_out++;
+        }
+    }
+    f->total_out_count += n_out;
+    *n_consumed = n_in;
+    f->nread += (uint64_t)n_in;
+    f->nwritten += (uint64_t)n_out;
+    return n_out;
+}

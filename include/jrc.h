@@ -352,6 +352,41 @@ int jrc_stream_decode_dev(jrc_ctx* ctx, int n_data_carriers, int n_frames, const
                           const int* d_mcs, const int* d_data_bytes, uint8_t* d_payload, long payload_stride, int* d_status,
                           void* stream);
 
+/* ---- sync front-end of the comm receive chain.  moving_avg (lib/moving_avg_impl.cc:62-98;
+ * make(length, scale, max_iter, debug)), frame_detector (lib/frame_detector_impl.cc:70-205; make(fft_len, cp_len,
+ * threshold, min_n_peaks, ignore_gap, debug)), frame_sync (lib/frame_sync_impl.cc:89-289; make(fft_len, cp_len,
+ * sync_length, ltf_seq_time, debug)).  Each *_work call is one general_work()/work() call of the block. ---- */
+/* moving_avg::work: `in` holds length-1 items of history followed by the new items; returns items produced
+ * (min(noutput_items, max_iter)).  Window sums, scaled. */
+int jrc_moving_avg(jrc_ctx* ctx, int length, float scale, int max_iter, int noutput_items, const jrc_cf32* in, jrc_cf32* out);
+int jrc_moving_avg_dev(jrc_ctx* ctx, int length, float scale, int n_out, const jrc_cf32* d_in, jrc_cf32* d_out, void* stream);
+/* the stock blocks wired in front of the detector (blocks_delay, conjugate, multiply, moving averages, complex_to_mag[_squared],
+ * abs, divide; examples/simulation/communication/mimo_ofdm_jrc_comm_sim.grc) for a capture resident on the device:
+ * d_xd[i] = x[i - delay], d_in_abs[i] = sum over `window` of x conj(x delayed), d_in_cor[i] = |in_abs| / |pscale * sum over
+ * `pwindow` of |x|^2| */
+int jrc_sync_metrics_dev(jrc_ctx* ctx, int n, int delay, int window, int pwindow, float pscale, const jrc_cf32* d_x,
+                         jrc_cf32* d_xd, jrc_cf32* d_in_abs, float* d_in_cor, void* stream);
+typedef struct jrc_frame_detector jrc_frame_detector;
+jrc_frame_detector* jrc_frame_detector_create(jrc_ctx* ctx, int fft_len, int cp_len, double threshold, unsigned min_n_peaks,
+                                              unsigned ignore_gap);
+void jrc_frame_detector_destroy(jrc_frame_detector* d);
+/* frame_detector::general_work: inputs in / in_abs / in_cor (ninput_items each), output out.  Returns items produced;
+ * *n_consumed = consume_each(); frame_start tags added in this call come back as (absolute output offset, coarse CFO). */
+int jrc_frame_detector_work(jrc_frame_detector* d, int noutput_items, int ninput_items, const jrc_cf32* in, const jrc_cf32* in_abs,
+                            const float* in_cor, jrc_cf32* out, int* n_consumed, uint64_t* tag_offsets, double* tag_cfo,
+                            int max_tags, int* n_tags);
+typedef struct jrc_frame_sync jrc_frame_sync;
+jrc_frame_sync* jrc_frame_sync_create(jrc_ctx* ctx, int fft_len, int cp_len, unsigned sync_length, const jrc_cf32* ltf_seq_time, int ntaps);
+void jrc_frame_sync_destroy(jrc_frame_sync* f);
+/* frame_sync::general_work: in (port 0) and in_delayed (port 1); tag_offsets/values = the frame_start tags on port 0
+ * (absolute offsets).  Returns items produced (JRC_ERR_LENGTH_MISMATCH for the runtime_error of :135); *n_consumed items
+ * are consumed on both ports; the frame_start tag the call adds, if any, comes back in tag_out_*. */
+int jrc_frame_sync_work(jrc_frame_sync* f, int noutput_items, int ninput0, int ninput1, const jrc_cf32* in, const jrc_cf32* in_delayed,
+                        const uint64_t* tag_offsets, const double* tag_values, int n_tags, jrc_cf32* out, int* n_consumed,
+                        uint64_t* tag_out_offset, double* tag_out_value, int* n_tag_out);
+/* d_state (0 SYNC, 1 COPY, 2 RESET), d_frame_start and d_freq_offset after the last call */
+int jrc_frame_sync_state(const jrc_frame_sync* f, int* state, int* frame_start, float* freq_offset);
+
 #ifdef __cplusplus
 }
 #endif

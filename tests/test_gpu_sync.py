@@ -1,0 +1,126 @@
+"""GPU tier: the sync front-end on the device (moving_avg, frame_detector, frame_sync and the stock
+metric blocks in front of them) through the C ABI against the oracle restatement, call for call: items consumed /
+produced, tags and decisions exact, samples within the north star's 1e-4."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import rel_err
+from test_oracle_sync import CP, N, make_stream
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+SYNC_LEN = 4 * (N + CP)
+
+
+def capture(ofdm64, seed, cfo=0.01, n_frames=1, gap=2500):
+    rng = np.random.default_rng(seed)
+    parts, meta = [], []
+    for k in range(n_frames):
+        payload = bytes([2]) + rng.integers(0, 256, 60 + 30 * k, dtype=np.uint8).tobytes()
+        x, tags, flen = make_stream(ofdm64, payload, 2, rng, lead=600 + 37 * k, tail=gap, cfo=cfo)
+        parts.append(x)
+        meta.append((payload, tags))
+    return np.concatenate(parts), meta
+
+
+@pytest.mark.parametrize("length,scale,n,max_iter", [(32, 1.0, 3000, 16000), (48, 1 / 1.5, 500, 16000), (1, 2.0, 10, 4), (5, 1.0, 100, 60)])
+def test_moving_avg(jrc, ctx, length, scale, n, max_iter):
+    rng = np.random.default_rng(length)
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    blk = jrc.moving_avg(length, scale, max_iter, ctx=ctx)
+    got = blk.work(x)
+    want = oracle.moving_avg(x, length, scale, max_iter)
+    assert got.shape == want.shape and rel_err(got, want) < TOL
+    got2 = blk.work(x[len(got):])                                   # the next call continues with the history of the first
+    want2 = oracle.moving_avg(x[len(got):], length, scale, max_iter, history=np.concatenate([np.zeros(length - 1), x])[len(got):len(got) + length - 1])
+    assert got2.shape == want2.shape and (got2.size == 0 or rel_err(got2, want2) < TOL)
+
+
+def test_metrics_match_the_stock_blocks(jrc, ctx, ofdm64):
+    x, _ = capture(ofdm64, 1)
+    gxd, gia, gic = jrc.sync_metrics(x, 16, 32, 48, 1 / 1.5, ctx=ctx)
+    oxd, oia, oic = oracle.sync_metrics(x, 16, 32, 48, 1 / 1.5)
+    assert np.array_equal(gxd, oxd)
+    assert rel_err(gia, oia) < TOL
+    live = slice(48, None)                                           # the first samples divide by a near-empty power window
+    assert np.abs(gic[live] - oic[live]).max() < 1e-3 * max(1.0, oic[live].max())
+
+
+@pytest.mark.parametrize("chunk", [1 << 30, 4096, 1000, 333])
+def test_detector_call_for_call(jrc, ctx, ofdm64, chunk):
+    x, meta = capture(ofdm64, 2, cfo=-0.015, n_frames=3)
+    xd, ia, ic = oracle.sync_metrics(x, 16, 32, 48, 1 / 1.5)
+    ignore_gap = (4 + 4) * (N + CP)
+    g = jrc.frame_detector(N, CP, 0.6, 10, ignore_gap, ctx=ctx)
+    o = oracle.FrameDetector(N, CP, 0.6, 10, ignore_gap)
+    pos = 0
+    n_tags = 0
+    while pos < x.size:
+        n = min(chunk, x.size - pos)
+        nout = n if chunk > 1000 else max(1, n - 7)                  # a smaller output buffer than input now and then
+        go, gc, gt = g.work(xd[pos:pos + n], ia[pos:pos + n], ic[pos:pos + n], nout)
+        oo, oc, ot = o.work(xd[pos:pos + n], ia[pos:pos + n], ic[pos:pos + n], nout)
+        assert (gc, go.size, len(gt)) == (oc, oo.size, len(ot))
+        for a, b in zip(gt, ot):
+            assert a[0] == b[0] and abs(a[1] - b[1]) < 1e-6
+        if go.size:
+            assert rel_err(go, oo) < TOL
+        n_tags += len(gt)
+        if gc == 0 and go.size == 0:
+            break
+        pos += gc
+    assert n_tags == 3                                               # SEARCH -> COPY, then two re-detections inside COPY (:153-165)
+
+
+@pytest.mark.parametrize("chunk", [8192, 1500, 200])
+def test_frame_sync_call_for_call(jrc, ctx, ofdm64, chunk):
+    x, meta = capture(ofdm64, 3, cfo=0.02, n_frames=2)
+    xd, ia, ic = oracle.sync_metrics(x, 16, 32, 48, 1 / 1.5)
+    seg, dtags = oracle.FrameDetector(N, CP, 0.6, 10, 8 * (N + CP)).run(xd, ia, ic)
+    assert len(dtags) == 2
+    delayed = np.concatenate([np.zeros(SYNC_LEN, np.complex64), seg])[:seg.size]
+    g = jrc.frame_sync(N, CP, SYNC_LEN, ofdm64["l_ltf_fir"], ctx=ctx)
+    o = oracle.FrameSync(N, CP, SYNC_LEN, ofdm64["l_ltf_fir"])
+    pos, idle, tags_seen = 0, 0, []
+    while pos < seg.size and idle < 3:
+        m = min(chunk, seg.size - pos)
+        nout = m if chunk != 1500 else m // 2 + 1
+        go, gc, gt = g.work(seg[pos:pos + m], delayed[pos:pos + m], dtags, nout)
+        oo, oc, ot = o.work(seg[pos:pos + m], delayed[pos:pos + m], dtags, nout)
+        assert (gc, go.size, len(gt)) == (oc, oo.size, len(ot)), (pos, g.state)
+        for a, b in zip(gt, ot):
+            assert a[0] == b[0] and abs(a[1] - b[1]) < 1e-5
+        if go.size:
+            assert rel_err(go, oo) < TOL
+        assert g.frame_start == o.frame_start and abs(g.freq_offset - o.freq_offset) < 1e-6
+        tags_seen += gt
+        idle = idle + 1 if (gc == 0 and go.size == 0) else 0
+        pos += gc
+    assert len(tags_seen) == 2
+
+
+def test_front_end_delivers_decodable_frames(jrc, ctx, ofdm64):
+    """capture -> metrics -> frame_detector -> frame_sync -> fft_vcc -> mimo_ofdm_equalizer -> stream_decoder, all on the device blocks"""
+    x, meta = capture(ofdm64, 4, cfo=0.01, n_frames=2)
+    xd, ia, ic = jrc.sync_metrics(x, 16, 32, 48, 1 / 1.5, ctx=ctx)
+    seg, dtags = jrc.frame_detector(N, CP, 0.6, 10, 8 * (N + CP), ctx=ctx).run(xd, ia, ic)
+    assert len(dtags) == 2
+    delayed = np.concatenate([np.zeros(SYNC_LEN, np.complex64), seg])[:seg.size]
+    out, otags = jrc.frame_sync(N, CP, SYNC_LEN, ofdm64["l_ltf_fir"], ctx=ctx).run(seg, delayed, dtags)
+    assert len(otags) == 2
+    sym_t = out[:(out.size // N) * N].reshape(-1, N)
+    sym_f = jrc.fft_vcc(N, True, None, True, ctx=ctx).work(sym_t) / np.float32(np.sqrt(N))
+    o = ofdm64
+    eq = jrc.mimo_ofdm_equalizer(0, 24e9, 125e6, N, CP, o["data_subcarriers"], o["pilot_subcarriers"], o["pilot_symbols"], o["ltf_64"],
+                                 o["ltf_mapped_sc__ss_sym"], 4, ctx=ctx)
+    dec = jrc.stream_decoder(48, ctx=ctx)
+    got = []
+    tag_sym = [(t[0] // N, t[1]) for t in otags] + [(len(sym_f), 0.0)]
+    for k in range(len(otags)):                                      # one equalizer call per tagged frame
+        frame = sym_f[tag_sym[k][0]:tag_sym[k + 1][0]]
+        r = eq.general_work(frame, [(0, tag_sym[k][1])])
+        starts = [e for e in r["events"] if e["kind"] == 1]
+        assert starts
+        got.append(dec.work(r["out"], starts[0]))
+    assert [g for g in got if g[0]] == [(True, m[0]) for m in meta]
