@@ -27,6 +27,7 @@ namespace jrc_rt = gr;
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <algorithm>
 #include <deque>
 #include <map>
 #include <utility>
@@ -238,6 +239,32 @@ public:
 protected:
     void update_length_tags(int, int) {}                      // no-op inside work()
     std::string d_length_tag_key_str;
+};
+
+// GNU Radio sync_block contract: one output item per input item; with set_history(h) the input pointer starts h-1 items
+// before the first new item and the scheduler only calls work() when noutput_items + h - 1 input items are there.
+class sync_block : public block {
+public:
+    sync_block(const std::string& name, io_signature::sptr in, io_signature::sptr out) : block(name, in, out) {}
+    sync_block() {}
+    virtual int work(int noutput_items, gr_vector_const_void_star& input_items, gr_vector_void_star& output_items) = 0;
+    int general_work(int noutput_items, gr_vector_int& ninput_items, gr_vector_const_void_star& input_items,
+                     gr_vector_void_star& output_items) override
+    {
+        int n = noutput_items;
+        for (int ni : ninput_items) n = std::min(n, ni - (int)(d_history - 1));
+        if (n <= 0) return 0;
+        int r = work(n, input_items, output_items);
+        if (r > 0) consume_each(r);
+        return r;
+    }
+    unsigned history() const { return d_history; }
+
+protected:
+    void set_history(unsigned h) { d_history = h ? h : 1; }
+
+private:
+    unsigned d_history = 1;
 };
 
 }  // namespace jrc_host

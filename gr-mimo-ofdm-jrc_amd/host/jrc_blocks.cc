@@ -946,5 +946,136 @@ stream_decoder::sptr stream_decoder::make(int n_data_carriers, const std::string
     return JRC_GET_INITIAL_SPTR(new stream_decoder_impl(n_data_carriers, comm_log_file, stats_record, debug));
 }
 
+// =================================================================================================
+// moving_avg  (lib/moving_avg_impl.cc)
+// =================================================================================================
+class moving_avg_impl : public moving_avg {
+    ctx_holder d_c;
+    int d_length, d_max_iter, d_new_length;
+    float d_scale, d_new_scale;
+    bool d_updated = false;
+
+public:
+    moving_avg_impl(int length, float scale, int max_iter, bool)
+        : jrc_rt::sync_block("moving_avg", jrc_rt::io_signature::make(1, 1, sizeof(gr_complex)), jrc_rt::io_signature::make(1, 1, sizeof(gr_complex))),
+          d_length(length), d_max_iter(max_iter), d_new_length(length), d_scale(scale), d_new_scale(scale)
+    {
+        set_history(length);                                                                          // :51
+    }
+    int length() const override { return d_new_length; }
+    float scale() const override { return d_new_scale; }
+    void set_length_and_scale(int length, float scale) override { d_new_length = length; d_new_scale = scale; d_updated = true; }   // :100-105
+    void set_length(int length) override { d_new_length = length; d_updated = true; }
+    void set_scale(float scale) override { d_new_scale = scale; d_updated = true; }
+    int work(int noutput_items, gr_vector_const_void_star& input_items, gr_vector_void_star& output_items) override
+    {
+        if (d_updated) {                                                                              // :67-74
+            d_length = d_new_length;
+            d_scale = d_new_scale;
+            set_history(d_length);
+            d_updated = false;
+            return 0;
+        }
+        int n = jrc_moving_avg(d_c.ctx, d_length, d_scale, d_max_iter, noutput_items, (const jrc_cf32*)input_items[0], (jrc_cf32*)output_items[0]);
+        d_c.check(n);
+        return n;                                                                                     // num_iter (:92)
+    }
+};
+moving_avg::sptr moving_avg::make(int length, float scale, int max_iter, bool debug)
+{
+    return JRC_GET_INITIAL_SPTR(new moving_avg_impl(length, scale, max_iter, debug));
+}
+
+// =================================================================================================
+// frame_detector  (lib/frame_detector_impl.cc)
+// =================================================================================================
+class frame_detector_impl : public frame_detector {
+    ctx_holder d_c;
+    jrc_frame_detector* d_det = nullptr;
+    std::mutex d_mutex;
+
+public:
+    frame_detector_impl(int fft_len, int cp_len, double threshold, unsigned int min_n_peaks, unsigned int ignore_gap, bool)
+        : jrc_rt::block("frame_detector", jrc_rt::io_signature::make3(3, 3, sizeof(gr_complex), sizeof(gr_complex), sizeof(float)),
+                        jrc_rt::io_signature::make(1, 1, sizeof(gr_complex)))                         // :42-44
+    {
+        d_det = jrc_frame_detector_create(d_c.ctx, fft_len, cp_len, threshold, min_n_peaks, ignore_gap);
+        if (!d_det) throw std::invalid_argument(jrc_last_error(d_c.ctx));
+        set_tag_propagation_policy(TPP_DONT);
+    }
+    ~frame_detector_impl() override { jrc_frame_detector_destroy(d_det); }
+    int general_work(int noutput_items, gr_vector_int& ninput_items, gr_vector_const_void_star& input_items, gr_vector_void_star& output_items) override
+    {
+        std::unique_lock<std::mutex> lock(d_mutex);
+        const int ninput = std::min(std::min(ninput_items[0], ninput_items[1]), ninput_items[2]);     // :85
+        int consumed = 0, n_tags = 0;
+        uint64_t off[8]; double cfo[8];
+        int n = jrc_frame_detector_work(d_det, noutput_items, ninput, (const jrc_cf32*)input_items[0], (const jrc_cf32*)input_items[1],
+                                        (const float*)input_items[2], (jrc_cf32*)output_items[0], &consumed, off, cfo, 8, &n_tags);
+        d_c.check(n);
+        for (int i = 0; i < n_tags; i++)                                                              // insert_tag (:197-203)
+            add_item_tag(0, off[i], pmt::string_to_symbol("frame_start"), pmt::from_double(cfo[i]), pmt::string_to_symbol(name()));
+        consume_each(consumed);
+        return n;
+    }
+};
+frame_detector::sptr frame_detector::make(int fft_len, int cp_len, double threshold, unsigned int min_n_peaks, unsigned int ignore_gap, bool debug)
+{
+    return JRC_GET_INITIAL_SPTR(new frame_detector_impl(fft_len, cp_len, threshold, min_n_peaks, ignore_gap, debug));
+}
+
+// =================================================================================================
+// frame_sync  (lib/frame_sync_impl.cc)
+// =================================================================================================
+class frame_sync_impl : public frame_sync {
+    ctx_holder d_c;
+    jrc_frame_sync* d_sync = nullptr;
+    int d_fft_len, d_cp_len;
+    std::vector<jrc_rt::tag_t> d_tags;
+    std::mutex d_mutex;
+
+public:
+    frame_sync_impl(int fft_len, int cp_len, unsigned int sync_length, std::vector<gr_complex> ltf_seq_time, bool)
+        : jrc_rt::block("frame_sync", jrc_rt::io_signature::make(2, 2, sizeof(gr_complex)), jrc_rt::io_signature::make(1, 1, sizeof(gr_complex))),
+          d_fft_len(fft_len), d_cp_len(cp_len)
+    {
+        d_sync = jrc_frame_sync_create(d_c.ctx, fft_len, cp_len, sync_length, (const jrc_cf32*)ltf_seq_time.data(), (int)ltf_seq_time.size());
+        if (!d_sync) throw std::invalid_argument(jrc_last_error(d_c.ctx));
+        set_tag_propagation_policy(TPP_DONT);
+    }
+    ~frame_sync_impl() override { jrc_frame_sync_destroy(d_sync); }
+    void forecast(int noutput_items, gr_vector_int& ninput_items_required) override                  // :74-86
+    {
+        int st = 0;
+        jrc_frame_sync_state(d_sync, &st, nullptr, nullptr);
+        const int need = st == 0 ? d_fft_len + d_cp_len : noutput_items;
+        ninput_items_required[0] = need;
+        ninput_items_required[1] = need;
+    }
+    int general_work(int noutput_items, gr_vector_int& ninput_items, gr_vector_const_void_star& input_items, gr_vector_void_star& output_items) override
+    {
+        std::unique_lock<std::mutex> lock(d_mutex);
+        const int ninput = std::min(std::min(ninput_items[0], ninput_items[1]), 8192);               // :111
+        const uint64_t nread = nitems_read(0);
+        get_tags_in_range(d_tags, 0, nread, nread + ninput);                                         // :120
+        std::vector<uint64_t> off; std::vector<double> val;
+        for (auto& t : d_tags) { off.push_back(t.offset); val.push_back(pmt::to_double(t.value)); }
+        int consumed = 0, n_tag_out = 0;
+        uint64_t to = 0; double tv = 0;
+        int n = jrc_frame_sync_work(d_sync, noutput_items, ninput_items[0], ninput_items[1], (const jrc_cf32*)input_items[0],
+                                    (const jrc_cf32*)input_items[1], off.data(), val.data(), (int)off.size(), (jrc_cf32*)output_items[0],
+                                    &consumed, &to, &tv, &n_tag_out);
+        d_c.check(n);                                                                                // JRC_ERR_LENGTH_MISMATCH -> std::runtime_error (:135)
+        if (n_tag_out) add_item_tag(0, to, pmt::string_to_symbol("frame_start"), pmt::from_double(tv), pmt::string_to_symbol(name()));   // :182-186
+        consume(0, consumed);
+        consume(1, consumed);
+        return n;
+    }
+};
+frame_sync::sptr frame_sync::make(int fft_len, int cp_len, unsigned int sync_length, std::vector<gr_complex> ltf_seq_time, bool debug)
+{
+    return JRC_GET_INITIAL_SPTR(new frame_sync_impl(fft_len, cp_len, sync_length, ltf_seq_time, debug));
+}
+
 }  // namespace mimo_ofdm_jrc
 }  // namespace gr

@@ -12,6 +12,9 @@
 //   include/mimo_ofdm_jrc/target_simulator.h:30-60     gr::mimo_ofdm_jrc::target_simulator
 //   include/mimo_ofdm_jrc/stream_encoder.h:56-64       gr::mimo_ofdm_jrc::stream_encoder
 //   include/mimo_ofdm_jrc/stream_decoder.h:43-56       gr::mimo_ofdm_jrc::stream_decoder
+//   include/mimo_ofdm_jrc/moving_avg.h:44-55           gr::mimo_ofdm_jrc::moving_avg
+//   include/mimo_ofdm_jrc/frame_detector.h:44-49       gr::mimo_ofdm_jrc::frame_detector
+//   include/mimo_ofdm_jrc/frame_sync.h:44-49           gr::mimo_ofdm_jrc::frame_sync
 //
 // Built against GNU Radio 3.8 with -DJRC_WITH_GNURADIO; otherwise against the stand-alone test runtime.
 #pragma once
@@ -125,6 +128,29 @@ public:
     typedef JRC_SPTR<stream_decoder> sptr;
     static sptr make(int n_data_carriers, const std::string& comm_log_file, bool stats_record, bool debug);
     virtual void set_stats_record(bool stats_record) = 0;
+};
+
+class moving_avg : virtual public jrc_rt::sync_block {
+public:
+    typedef JRC_SPTR<moving_avg> sptr;
+    static sptr make(int length, float scale, int max_iter, bool debug);
+    virtual int length() const = 0;
+    virtual float scale() const = 0;
+    virtual void set_length_and_scale(int length, float scale) = 0;
+    virtual void set_length(int length) = 0;
+    virtual void set_scale(float scale) = 0;
+};
+
+class frame_detector : virtual public jrc_rt::block {
+public:
+    typedef JRC_SPTR<frame_detector> sptr;
+    static sptr make(int fft_len, int cp_len, double threshold, unsigned int min_n_peaks, unsigned int ignore_gap, bool debug);
+};
+
+class frame_sync : virtual public jrc_rt::block {
+public:
+    typedef JRC_SPTR<frame_sync> sptr;
+    static sptr make(int fft_len, int cp_len, unsigned int sync_length, std::vector<gr_complex> ltf_seq_time, bool debug);
 };
 
 }  // namespace mimo_ofdm_jrc

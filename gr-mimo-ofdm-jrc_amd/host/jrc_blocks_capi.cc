@@ -92,6 +92,20 @@ void* jrcb_make_target_simulator(const float* range, const float* velocity, cons
                                rndm_phaseshift != 0, self_coupling != 0))); });
 }
 
+void* jrcb_make_moving_avg(int length, float scale, int max_iter)
+{
+    return guard_make([&] { return std::static_pointer_cast<jrc_host::block>(std::shared_ptr<moving_avg>(moving_avg::make(length, scale, max_iter, false))); });
+}
+void* jrcb_make_frame_detector(int fft_len, int cp_len, double threshold, unsigned min_n_peaks, unsigned ignore_gap)
+{
+    return guard_make([&] { return std::static_pointer_cast<jrc_host::block>(std::shared_ptr<frame_detector>(
+        frame_detector::make(fft_len, cp_len, threshold, min_n_peaks, ignore_gap, false))); });
+}
+void* jrcb_make_frame_sync(int fft_len, int cp_len, unsigned sync_length, const float* ltf_seq_time, int ntaps)
+{
+    return guard_make([&] { return std::static_pointer_cast<jrc_host::block>(std::shared_ptr<frame_sync>(
+        frame_sync::make(fft_len, cp_len, sync_length, std::vector<gr_complex>((const gr_complex*)ltf_seq_time, (const gr_complex*)ltf_seq_time + ntaps), false))); });
+}
 void* jrcb_make_stream_encoder(int mcs, int data_len)
 {
     return guard_make([&] { return std::static_pointer_cast<jrc_host::block>(std::shared_ptr<stream_encoder>(
@@ -216,6 +230,10 @@ int jrcb_call_setter(void* h, const char* name, double v)
             if (n == "set_radar_aided") { p->set_radar_aided(v != 0); return 0; }
             if (n == "set_use_radar_streams") { p->set_use_radar_streams(v != 0); return 0; }
             if (n == "set_phased_steering") { p->set_phased_steering(v != 0); return 0; }
+        }
+        if (auto* ma = dynamic_cast<moving_avg*>(b.get())) {
+            if (n == "set_length") { ma->set_length((int)v); return 0; }
+            if (n == "set_scale") { ma->set_scale((float)v); return 0; }
         }
         if (auto* se = dynamic_cast<stream_encoder*>(b.get())) { if (n == "set_mcs") { se->set_mcs((MCS)(int)v); return 0; } }
         if (auto* sd = dynamic_cast<stream_decoder*>(b.get())) { if (n == "set_stats_record") { sd->set_stats_record(v != 0); return 0; } }

@@ -22,7 +22,7 @@ def test_host_library_exports_harness_and_links_the_abi(jrc):
     src = open(os.path.join(ROOT, "gr-mimo-ofdm-jrc_amd", "host", "jrc_blocks.cc")).read()
     for cls in ("mimo_ofdm_radar", "matrix_transpose", "range_angle_estimator", "ofdm_cyclic_prefix_remover",
                 "fft_peak_detect", "mimo_ofdm_equalizer", "mimo_precoder", "target_simulator", "stream_encoder",
-                "stream_decoder"):
+                "stream_decoder", "moving_avg", "frame_detector", "frame_sync"):
         assert re.search(r"%s::sptr\s+%s::make\(" % (cls, cls), src), cls
 
 
@@ -331,3 +331,65 @@ def test_stream_encoder_and_decoder_blocks(jrc, tmp_path):
     f = [c.strip() for c in lines[1].split(", \t")]
     assert f[1:7] == ["1", "2", str(mcs), "21.5", "18.25", "125"] and f[7] == "(1,2);(3,-4);"
     assert [c.strip() for c in lines[3].split(", \t")][1] == "0"
+
+
+@gpu
+def test_sync_front_end_blocks(jrc, ofdm64):
+    """moving_avg (sync_block with history), frame_detector and frame_sync as blocks: consume / produce counts, frame_start tags
+    on the way in and out, the setter turn of moving_avg (:67-74), against the oracle restatement"""
+    import hostblocks as hb
+    from test_oracle_sync import CP, N, make_stream
+    rng = np.random.default_rng(12)
+    x, tags, _ = make_stream(ofdm64, bytes([2]) + bytes(80), 2, rng, cfo=0.012)
+    # moving_avg: history 31, two scheduler turns
+    ma = hb.moving_avg(32, 1.0, 16000)
+    prod = (np.conj(np.concatenate([np.zeros(16, np.complex64), x[:-16]])) * x).astype(np.complex64)
+    buf = np.concatenate([np.zeros(31, np.complex64), prod])
+    out = np.zeros(2000, np.complex64)
+    assert ma.run(2000, [buf[:2031]], [out]) == 2000 and ma.consumed(0) == 2000
+    assert rel_err(out, oracle.moving_avg(prod[:2000], 32)) < 1e-4
+    ma.set("set_length", 16)
+    assert ma.run(100, [buf[2000:2131]], [out]) == 0                           # the turn after a setter only re-arms the history
+    assert ma.run(100, [buf[2016:2131]], [out]) == 100
+    assert rel_err(out[:100], oracle.moving_avg(prod[2000:2100], 16, history=prod[1985:2000])) < 1e-4
+
+    xd, ia, ic = oracle.sync_metrics(x, 16, 32, 48, 1 / 1.5)
+    det = hb.frame_detector(N, CP, 0.6, 10, 8 * (N + CP))
+    odet = oracle.FrameDetector(N, CP, 0.6, 10, 8 * (N + CP))
+    seg_parts, pos = [], 0
+    while pos < x.size:
+        o = np.zeros(x.size - pos, np.complex64)
+        n = det.run(o.size, [xd[pos:], ia[pos:], ic[pos:]], [o])
+        oo, oc, ot = odet.work(xd[pos:], ia[pos:], ic[pos:], o.size)
+        assert n == oo.size and det.consumed(0) == det.consumed(1) == det.consumed(2) == oc
+        if n:
+            assert rel_err(o[:n], oo) < 1e-4
+            seg_parts.append(o[:n])
+        if oc == 0 and n == 0:
+            break
+        pos += oc
+    dtags = [t for t in det.state()["out_tags"][0] if t["key"] == "frame_start"]
+    assert len(dtags) == 1 and dtags[0]["offset"] == 0 and abs(dtags[0]["value"] - 0.012) < 2e-3
+    seg = np.concatenate(seg_parts)
+
+    sync_len = 4 * (N + CP)
+    fs = hb.frame_sync(N, CP, sync_len, ofdm64["l_ltf_fir"])
+    ofs = oracle.FrameSync(N, CP, sync_len, ofdm64["l_ltf_fir"])
+    fs.tag(0, 0, "frame_start", float(dtags[0]["value"]))
+    delayed = np.concatenate([np.zeros(sync_len, np.complex64), seg])[:seg.size]
+    pos, total = 0, 0
+    for turn in range(12):
+        m = min(2000, seg.size - pos)
+        if m <= 0:
+            break
+        o = np.zeros(m, np.complex64)
+        n = fs.run(m, [seg[pos:pos + m], delayed[pos:pos + m]], [o])
+        oo, oc, ot = ofs.work(seg[pos:pos + m], delayed[pos:pos + m], [(0, float(dtags[0]["value"]))], m)
+        assert n == oo.size and fs.consumed(0) == fs.consumed(1) == oc
+        if n:
+            assert rel_err(o[:n], oo) < 1e-4
+        pos += oc
+        total += n
+    otags = [t for t in fs.state()["out_tags"][0] if t["key"] == "frame_start"]
+    assert len(otags) == 1 and otags[0]["offset"] == 0 and abs(otags[0]["value"] - 0.012) < 3e-3
+    assert total > 20 * N
