@@ -50,6 +50,7 @@ class RadarSimFlowgraph:
         self.target_sims = [jrc.target_simulator(trgt_range, trgt_velocity, rcs, trgt_angle, self.TX_RXs[t], samp_rate,
                                                  self.rf_freq, -40.0, False, False, sum_targets=sum_targets, ctx=self.ctx)
                             for t in range(T)]
+        self.zero_pads = [jrc.zero_pad(False, 0, 3 * (N + self.cp_len), seed=seed + 100 * t, ctx=self.ctx) for t in range(T)]
         self.cp_remover = jrc.ofdm_cyclic_prefix_remover(N, self.cp_len, ctx=self.ctx)
         self.radar = jrc.mimo_ofdm_radar(N, T, R, T, self.n_sync + 1, False, False, 8, self.Ir, False, "", ctx=self.ctx)
         self.range_ifft = jrc.fft_vcc(N * self.Ir, False, None, False, ctx=self.ctx)
@@ -73,7 +74,7 @@ class RadarSimFlowgraph:
         rx_t = np.zeros((R, (n_total + 3) * (N + cp)), np.complex64)
         for t in range(T):
             td = jrc.ofdm_mod(tx_f[t], N, cp, window=window, ctx=self.ctx).ravel() * np.float32(self.tx_multiplier)
-            burst = np.concatenate([td, np.zeros(3 * (N + cp), np.complex64)])      # zero_pad(0, 3 symbols)
+            burst = self.zero_pads[t].work(td) if noise else np.concatenate([td, np.zeros(3 * (N + cp), np.complex64)])   # zero_pad(0, 3 symbols)
             rx_t += self.target_sims[t].work(burst)                                   # blocks_add_xx
         if noise:
             s = np.sqrt(self.noise_var / 2)

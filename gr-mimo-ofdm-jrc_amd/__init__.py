@@ -1049,3 +1049,26 @@ class frame_sync:
             self.close()
         except Exception:
             pass
+
+
+class zero_pad:
+    """include/mimo_ofdm_jrc/zero_pad.h make(debug, pad_front, pad_tail); work = lib/zero_pad_impl.cc:62-94 (tagged stream block):
+    the burst framed by pad_front / pad_tail samples of N(0, 1e-2) complex noise."""
+
+    def __init__(self, debug=False, pad_front=0, pad_tail=0, seed=0, ctx=None):
+        self.ctx = ctx or default_context()
+        L = load()
+        L.jrc_zero_pad.argtypes = [_vp, C.c_int, C.c_uint, C.c_uint, C.c_uint64, _vp, _vp]
+        self.pad_front, self.pad_tail, self._seed = int(pad_front), int(pad_tail), int(seed)
+
+    def calculate_output_stream_length(self, ninput_items):
+        return ninput_items + self.pad_front + self.pad_tail
+
+    def work(self, x):
+        x = _c64(x).ravel()
+        out = np.zeros(self.calculate_output_stream_length(x.size), np.complex64)
+        n = self.ctx.check(self.ctx.lib.jrc_zero_pad(self.ctx.h, x.size, self.pad_front, self.pad_tail, self._seed,
+                                                     _ptr(x) if x.size else None, _ptr(out)))
+        self._seed += 1                                  # a new draw per packet, like the reference's per-call random_device
+        assert n == out.size
+        return out

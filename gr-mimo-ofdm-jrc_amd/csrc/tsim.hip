@@ -769,3 +769,68 @@ extern "C" int jrc_tsim_set_targets(jrc_tsim* h, int n_targets, const float* ran
 }
 
 extern "C" int jrc_tsim_burst_capacity(const jrc_tsim* h) { return h ? h->max_bursts : 0; }
+
+// ---- zero_pad (lib/zero_pad_impl.cc:62-94): out = [pad_front noise | in | pad_tail noise], noise ~ N(0, 1e-2) per component.
+// The reference draws from std::random_device every call; here a counter-based generator (splitmix64 -> Box-Muller) keyed by
+// (seed, burst, sample) makes the padding reproducible. ------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__global__ void zero_pad_kernel(const float2* __restrict__ in, float2* __restrict__ out, int n_in, int pad_front, int pad_tail,
+                                unsigned long long seed, float sigma, long in_stride, long out_stride)
+{
+    const int n_out = n_in + pad_front + pad_tail;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t b = blockIdx.y;
+    if (i >= n_out) return;
+    float2 v;
+    if (i >= pad_front && i < pad_front + n_in) {
+        v = in[b * (size_t)in_stride + (i - pad_front)];
+    } else {
+        const unsigned long long r = splitmix64(seed ^ splitmix64((b << 32) | (unsigned)i));
+        const float u1 = ((float)(unsigned)(r >> 40) + 1.0f) * (1.0f / 16777216.0f);          // (0, 1]
+        const float u2 = (float)(unsigned)((r >> 8) & 0xffffffu) * (1.0f / 16777216.0f);     // [0, 1)
+        const float rad = sigma * sqrtf(-2.0f * logf(u1));
+        float sn, cs;
+        sincospif(2.0f * u2, &sn, &cs);
+        v = make_float2(rad * cs, rad * sn);
+    }
+    out[b * (size_t)out_stride + i] = v;
+}
+
+extern "C" int jrc_zero_pad_dev(jrc_ctx* ctx, int n_bursts, int n_input, unsigned pad_front, unsigned pad_tail, uint64_t seed,
+                                const jrc_cf32* d_in, jrc_cf32* d_out, void* stream)
+{
+    if (!ctx || n_bursts < 0 || n_input < 0) return JRC_ERR_INVALID_ARG;
+    const long n_out = (long)n_input + pad_front + pad_tail;
+    if (n_bursts == 0 || n_out == 0) return (int)n_out;
+    if ((n_input > 0 && !d_in) || !d_out) return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "zero_pad: null buffers");
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    hipLaunchKernelGGL(zero_pad_kernel, dim3((unsigned)((n_out + 255) / 256), n_bursts), dim3(256), 0, s, (const float2*)d_in, (float2*)d_out,
+                       n_input, (int)pad_front, (int)pad_tail, (unsigned long long)seed, 1e-2f, (long)n_input, n_out);
+    JRC_HIP(ctx, hipGetLastError());
+    return (int)n_out;
+}
+
+extern "C" int jrc_zero_pad(jrc_ctx* ctx, int n_input, unsigned pad_front, unsigned pad_tail, uint64_t seed, const jrc_cf32* in, jrc_cf32* out)
+{
+    if (!ctx || n_input < 0 || (n_input > 0 && !in) || !out) return JRC_ERR_INVALID_ARG;
+    const size_t n_out = (size_t)n_input + pad_front + pad_tail;
+    if (n_out == 0) return 0;
+    JRC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t ib = sizeof(float2) * (size_t)(n_input > 0 ? n_input : 1), ob = sizeof(float2) * n_out;
+    JRC_TRY(jrc_ensure_pinned(ctx, ib + ob));
+    JRC_TRY(jrc_ensure_scratch(ctx, 0, ib));
+    JRC_TRY(jrc_ensure_scratch(ctx, 1, ob));
+    if (n_input) memcpy(ctx->pinned, in, sizeof(float2) * (size_t)n_input);
+    JRC_HIP(ctx, hipMemcpyAsync(ctx->scratch[0], ctx->pinned, ib, hipMemcpyHostToDevice, ctx->stream));
+    JRC_TRY(jrc_zero_pad_dev(ctx, 1, n_input, pad_front, pad_tail, seed, (const jrc_cf32*)ctx->scratch[0], (jrc_cf32*)ctx->scratch[1], ctx->stream));
+    JRC_HIP(ctx, hipMemcpyAsync((char*)ctx->pinned + ib, ctx->scratch[1], ob, hipMemcpyDeviceToHost, ctx->stream));
+    JRC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(out, (char*)ctx->pinned + ib, ob);
+    return (int)n_out;
+}

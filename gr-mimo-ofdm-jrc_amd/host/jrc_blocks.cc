@@ -1077,5 +1077,34 @@ frame_sync::sptr frame_sync::make(int fft_len, int cp_len, unsigned int sync_len
     return JRC_GET_INITIAL_SPTR(new frame_sync_impl(fft_len, cp_len, sync_length, ltf_seq_time, debug));
 }
 
+// =================================================================================================
+// zero_pad  (lib/zero_pad_impl.cc)
+// =================================================================================================
+class zero_pad_impl : public zero_pad {
+    ctx_holder d_c;
+    unsigned d_pad_front, d_pad_tail;
+    uint64_t d_seed;
+
+public:
+    zero_pad_impl(bool, unsigned int pad_front, unsigned int pad_tail)
+        : jrc_rt::tagged_stream_block("zero_pad", jrc_rt::io_signature::make(1, 1, sizeof(gr_complex)),
+                                      jrc_rt::io_signature::make(1, 1, sizeof(gr_complex)), "packet_len"),
+          d_pad_front(pad_front), d_pad_tail(pad_tail), d_seed(std::random_device{}())           // std::random_device per call (:70-71)
+    {
+        set_tag_propagation_policy(TPP_DONT);
+    }
+    int calculate_output_stream_length(const gr_vector_int& ninput_items) override { return ninput_items[0] + d_pad_front + d_pad_tail; }
+    int work(int, gr_vector_int& ninput_items, gr_vector_const_void_star& in, gr_vector_void_star& out) override
+    {
+        int n = jrc_zero_pad(d_c.ctx, ninput_items[0], d_pad_front, d_pad_tail, d_seed++, (const jrc_cf32*)in[0], (jrc_cf32*)out[0]);
+        d_c.check(n);
+        return n;                                                                               // :91-93
+    }
+};
+zero_pad::sptr zero_pad::make(bool debug, unsigned int pad_front, unsigned int pad_tail)
+{
+    return JRC_GET_INITIAL_SPTR(new zero_pad_impl(debug, pad_front, pad_tail));
+}
+
 }  // namespace mimo_ofdm_jrc
 }  // namespace gr

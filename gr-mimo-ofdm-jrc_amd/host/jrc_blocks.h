@@ -15,6 +15,7 @@
 //   include/mimo_ofdm_jrc/moving_avg.h:44-55           gr::mimo_ofdm_jrc::moving_avg
 //   include/mimo_ofdm_jrc/frame_detector.h:44-49       gr::mimo_ofdm_jrc::frame_detector
 //   include/mimo_ofdm_jrc/frame_sync.h:44-49           gr::mimo_ofdm_jrc::frame_sync
+//   include/mimo_ofdm_jrc/zero_pad.h                   gr::mimo_ofdm_jrc::zero_pad
 //
 // Built against GNU Radio 3.8 with -DJRC_WITH_GNURADIO; otherwise against the stand-alone test runtime.
 #pragma once
@@ -139,6 +140,12 @@ public:
     virtual void set_length_and_scale(int length, float scale) = 0;
     virtual void set_length(int length) = 0;
     virtual void set_scale(float scale) = 0;
+};
+
+class zero_pad : virtual public jrc_rt::tagged_stream_block {
+public:
+    typedef JRC_SPTR<zero_pad> sptr;
+    static sptr make(bool debug, unsigned int pad_front, unsigned int pad_tail);
 };
 
 class frame_detector : virtual public jrc_rt::block {

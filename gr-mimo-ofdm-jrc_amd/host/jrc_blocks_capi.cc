@@ -92,6 +92,10 @@ void* jrcb_make_target_simulator(const float* range, const float* velocity, cons
                                rndm_phaseshift != 0, self_coupling != 0))); });
 }
 
+void* jrcb_make_zero_pad(unsigned pad_front, unsigned pad_tail)
+{
+    return guard_make([&] { return std::static_pointer_cast<jrc_host::block>(std::shared_ptr<zero_pad>(zero_pad::make(false, pad_front, pad_tail))); });
+}
 void* jrcb_make_moving_avg(int length, float scale, int max_iter)
 {
     return guard_make([&] { return std::static_pointer_cast<jrc_host::block>(std::shared_ptr<moving_avg>(moving_avg::make(length, scale, max_iter, false))); });

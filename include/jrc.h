@@ -387,6 +387,13 @@ int jrc_frame_sync_work(jrc_frame_sync* f, int noutput_items, int ninput0, int n
 /* d_state (0 SYNC, 1 COPY, 2 RESET), d_frame_start and d_freq_offset after the last call */
 int jrc_frame_sync_state(const jrc_frame_sync* f, int* state, int* frame_start, float* freq_offset);
 
+/* zero_pad (lib/zero_pad_impl.cc:62-94; make(debug, pad_front, pad_tail)): out = [pad_front | in | pad_tail] where the padding is
+ * complex Gaussian noise, N(0, 1e-2) per component (the reference seeds a fresh std::random_device per call; `seed` makes it
+ * reproducible here).  Returns n_input + pad_front + pad_tail.  _dev: n_bursts rows [n_input] -> rows [n_out]. */
+int jrc_zero_pad(jrc_ctx* ctx, int n_input, unsigned pad_front, unsigned pad_tail, uint64_t seed, const jrc_cf32* in, jrc_cf32* out);
+int jrc_zero_pad_dev(jrc_ctx* ctx, int n_bursts, int n_input, unsigned pad_front, unsigned pad_tail, uint64_t seed,
+                     const jrc_cf32* d_in, jrc_cf32* d_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
