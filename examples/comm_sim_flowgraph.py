@@ -3,9 +3,9 @@
 wired over this package's MI355X blocks, PDU bytes in -> PDU bytes out:
 
   PDU -> stream_encoder -> mimo_precoder -> per TX: fft_vxx(reverse, shift, window 1/sqrt(N)) + cyclic prefixer
-      -> flat 4x1 MISO channel + noise (time domain) -> [frame timing taken as known: the sample-serial sync front-end
-         (frame_detector / frame_sync) is not part of this package]
-      -> ofdm_cyclic_prefix_remover -> fft_vxx(forward, shift) -> mimo_ofdm_equalizer -> stream_decoder -> PDU
+      -> flat 4x1 MISO channel, carrier offset, noise (time domain, the burst somewhere inside a longer capture)
+      -> delay / conjugate-multiply / moving averages / divide (detection metrics) -> frame_detector -> frame_sync
+      -> fft_vxx(forward, shift) -> mimo_ofdm_equalizer -> stream_decoder -> PDU
 
 An NDP packet first makes the equalizer write the channel estimate; with --steer the precoder then beam-forms the DATA
 packets with the steering matrix derived from it (the chan_est.csv loop of the reference, here passed in memory).
@@ -34,7 +34,9 @@ class CommSimFlowgraph:
         self.encoder = jrc.stream_encoder(mcs, self.n_dc, ctx=self.ctx)
         self.precoder = jrc.mimo_precoder(self.N, self.T, 1, o["data_subcarriers"], o["pilot_subcarriers"], o["pilot_symbols"],
                                           o["l_stf_ltf_64"], o["ltf_mapped_sc__ss_sym"], ctx=self.ctx)
-        self.cp_remover = jrc.ofdm_cyclic_prefix_remover(self.N, self.cp, ctx=self.ctx)
+        self.rx_fft = jrc.fft_vcc(self.N, True, None, True, ctx=self.ctx)
+        self.ltf_fir = o["l_ltf_fir"]
+        self.sync_length = 4 * (self.N + self.cp)
         self.equalizer = jrc.mimo_ofdm_equalizer(estimator, 24e9, 125e6, self.N, self.cp, o["data_subcarriers"],
                                                  o["pilot_subcarriers"], o["pilot_symbols"], o["ltf_64"],
                                                  o["ltf_mapped_sc__ss_sym"], self.T, ctx=self.ctx)
@@ -43,7 +45,7 @@ class CommSimFlowgraph:
         self.h = (self.rng.standard_normal(self.T) + 1j * self.rng.standard_normal(self.T)).astype(np.complex64) / np.sqrt(2)
         self.chan_est = None
 
-    def send(self, pdu, snr_db=30.0, steer=False):
+    def send(self, pdu, snr_db=30.0, steer=False, cfo=0.01, lead=640):
         """one PDU through the graph; returns (crc_ok, payload, info)"""
         jrc, N, cp, T = self.jrc, self.N, self.cp, self.T
         sym, tags = self.encoder.work(pdu)
@@ -58,10 +60,22 @@ class CommSimFlowgraph:
         rx_t = np.tensordot(self.h, tx_t, axes=(0, 0))
         p_sig = float(np.mean(np.abs(rx_t) ** 2))
         sigma = np.sqrt(p_sig / 10 ** (snr_db / 10.0) / 2)
-        rx_t = (rx_t + sigma * (self.rng.standard_normal(rx_t.shape) + 1j * self.rng.standard_normal(rx_t.shape))).astype(np.complex64)
-        rx_f = self.cp_remover.work(rx_t, fused_fft=True) / np.float32(N ** 0.5)
-        y = np.concatenate([rx_f[3:4], rx_f[3:]], axis=0)                         # frame_sync hands over [LTF, LTF, SIG, MIMO-LTFs, data]
-        eq = self.equalizer.general_work(y, [(0, 0.0)])
+        x = np.concatenate([np.zeros(lead, np.complex64), rx_t, np.zeros(2 * lead, np.complex64)])
+        x = x * np.exp(1j * cfo * np.arange(x.size))                               # carrier frequency offset, rad/sample
+        x = (x + sigma * (self.rng.standard_normal(x.size) + 1j * self.rng.standard_normal(x.size))).astype(np.complex64)
+        # sync front-end: the stock metric blocks, then frame_detector and frame_sync (fresh per capture here)
+        xd, in_abs, in_cor = jrc.sync_metrics(x, N // 4, N // 2, int(1.5 * (N // 2)), 1 / 1.5, ctx=self.ctx)
+        ignore_gap = (4 + T) * (N + cp)
+        seg, dtags = jrc.frame_detector(N, cp, 0.6, 10, ignore_gap, ctx=self.ctx).run(xd, in_abs, in_cor)
+        if not dtags:
+            return False, b"", dict(detected=False)
+        delayed = np.concatenate([np.zeros(self.sync_length, np.complex64), seg])[:seg.size]     # blocks_delay(sync_length)
+        sym_t, stags = jrc.frame_sync(N, cp, self.sync_length, self.ltf_fir, ctx=self.ctx).run(seg, delayed, dtags)
+        if not stags:
+            return False, b"", dict(detected=True, synced=False)
+        sym_t = sym_t[:(sym_t.size // N) * N].reshape(-1, N)
+        y = self.rx_fft.work(sym_t) / np.float32(N ** 0.5)                         # frame_sync hands over [LTF, LTF, SIG, MIMO-LTFs, data]
+        eq = self.equalizer.general_work(y, [(stags[0][0] // N, stags[0][1])])
         if eq["chan_est"] is not None:
             self.chan_est = eq["chan_est"]                                        # what an NDP writes to chan_est.csv
         starts = [e for e in eq["events"] if e["kind"] == 1]
@@ -71,7 +85,8 @@ class CommSimFlowgraph:
         if need < 0 or len(eq["out"]) < need:                                     # a mis-decoded SIG announces more symbols than the frame
             return False, b"", dict(start=starts[0], events=eq["events"])        # has: the block would wait for them forever
         ok, payload = self.decoder.work(eq["out"], starts[0])
-        return ok, payload, dict(start=starts[0], events=eq["events"], n_symbols=len(eq["out"]), per=self.decoder.per)
+        return ok, payload, dict(start=starts[0], events=eq["events"], n_symbols=len(eq["out"]), per=self.decoder.per,
+                                 coarse_cfo=dtags[0][1], cfo_tag=stags[0][1])
 
 
 def load_ofdm_config():
@@ -92,8 +107,9 @@ def main():
     for i in range(a.packets):
         pdu = bytes([DATA]) + rng.integers(0, 256, 200, dtype=np.uint8).tobytes()
         ok, payload, info = fg.send(pdu, a.snr_db, steer=a.steer)
-        print("packet %d: crc ok %s, payload intact %s, SIG snr %.1f dB, PER %.0f %%"
-              % (i, ok, payload == pdu, info["start"]["snr"] if "start" in info else float("nan"), info.get("per", 0.0)))
+        print("packet %d: crc ok %s, payload intact %s, SIG snr %.1f dB, CFO estimate %.4f rad/sample, PER %.0f %%"
+              % (i, ok, payload == pdu, info["start"]["snr"] if "start" in info else float("nan"), info.get("cfo_tag", float("nan")),
+                 info.get("per", 0.0)))
 
 
 if __name__ == "__main__":
