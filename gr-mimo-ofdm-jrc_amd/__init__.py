@@ -1072,3 +1072,55 @@ class zero_pad:
         self._seed += 1                                  # a new draw per packet, like the reference's per-call random_device
         assert n == out.size
         return out
+
+
+class SyncCfg(C.Structure):
+    _fields_ = [("fft_len", C.c_int), ("cp_len", C.c_int), ("threshold", C.c_double), ("min_n_peaks", C.c_uint), ("ignore_gap", C.c_uint),
+                ("sync_length", C.c_int), ("n_taps", C.c_int), ("d_ltf_taps", _vp), ("delay", C.c_int), ("window", C.c_int),
+                ("power_window", C.c_int), ("power_scale", C.c_float)]
+
+
+class SyncFrame(C.Structure):
+    _fields_ = [("start", C.c_int), ("len", C.c_int), ("coarse_cfo", C.c_float), ("frame_start", C.c_int), ("fine_cfo", C.c_float),
+                ("tag_value", C.c_double), ("n_out", C.c_int), ("pad_", C.c_int)]
+
+
+class SyncFrontEnd:
+    """Device-resident sync front end (jrc_sync_frontend_dev): detection metrics -> frame_detector -> frame_sync run to completion
+    on a capture in HBM; frame k lands in row k of `frames` ([max_frames, max_symbols, fft_len] complex, torch tensor)."""
+
+    def __init__(self, fft_len, cp_len, threshold, min_n_peaks, ignore_gap, sync_length, ltf_seq_time, max_frames=64, max_symbols=64,
+                 ctx=None):
+        import torch
+        self.ctx = ctx or default_context()
+        L = _load_sync()
+        L.jrc_sync_frontend_work_bytes.restype = C.c_size_t
+        L.jrc_sync_frontend_work_bytes.argtypes = [C.c_int]
+        L.jrc_sync_frontend_dev.argtypes = [_vp, C.POINTER(SyncCfg), C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]
+        self.L = L
+        t = _c64(ltf_seq_time).ravel()
+        self.d_taps = torch.from_numpy(t.view(np.float32).copy()).cuda()
+        self.cfg = SyncCfg(fft_len, cp_len, float(threshold), int(min_n_peaks), int(ignore_gap), int(sync_length), t.size,
+                           _vp(self.d_taps.data_ptr()), fft_len // 4, fft_len // 2, int(1.5 * (fft_len // 2)), 1 / 1.5)
+        self.max_frames, self.max_symbols, self.fft_len = max_frames, max_symbols, fft_len
+        self.frames = torch.zeros((max_frames, max_symbols, fft_len, 2), dtype=torch.float32, device="cuda")
+        self.d_info = torch.zeros((max_frames, C.sizeof(SyncFrame)), dtype=torch.uint8, device="cuda")
+        self.d_n = torch.zeros(1, dtype=torch.int32, device="cuda")
+        self._work = None
+
+    def run(self, d_x, n_samples, stream=None):
+        """d_x: torch float32 [n_samples, 2] on the device; asynchronous"""
+        import torch
+        need = self.L.jrc_sync_frontend_work_bytes(n_samples)
+        if self._work is None or self._work.numel() < need:
+            self._work = torch.empty(need, dtype=torch.uint8, device="cuda")
+        self.ctx.check(self.L.jrc_sync_frontend_dev(self.ctx.h, C.byref(self.cfg), n_samples, _vp(d_x.data_ptr()), _vp(self._work.data_ptr()),
+                                                    self.max_frames, self.max_symbols, _vp(self.frames.data_ptr()), _vp(self.d_info.data_ptr()),
+                                                    _vp(self.d_n.data_ptr()), stream))
+
+    def results(self):
+        self.ctx.sync()
+        n = int(self.d_n.cpu().item())
+        raw = self.d_info[:n].cpu().numpy().tobytes()
+        info = [SyncFrame.from_buffer_copy(raw[i * C.sizeof(SyncFrame):(i + 1) * C.sizeof(SyncFrame)]) for i in range(n)]
+        return n, info

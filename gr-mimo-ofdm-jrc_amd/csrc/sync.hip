@@ -319,23 +319,11 @@ struct FsSearch { int frame_start; float freq_offset; int top_idx[4]; };
 
 // LTF matched filter (gr::filter::kernel::fir_filter_ccc::filterN: y[i] = sum_k taps[k] x[i + ntaps-1-k]) over n_cor lags
 // with sample offsets off0 + i, then search_frame_start() (:232-287) on the SYNC_LENGTH collected values
-__global__ __launch_bounds__(1024) void fs_search_kernel(const float2* __restrict__ in, const float2* __restrict__ taps, int ntaps,
-                                                         int sync_length, int fft_len, FsSearch* __restrict__ res)
+// body shared by the per-call kernel and the batched pipeline: s_corr[sync_length] holds the matched-filter output
+__device__ __forceinline__ void fs_search_block(const float2* s_corr, int sync_length, int fft_len, FsSearch* res_out,
+                                                float* s_best, int* s_bidx, int* top)
 {
 #pragma clang fp contract(off)
-    extern __shared__ float2 s_corr[];                 // [sync_length]
-    __shared__ float s_best[16];
-    __shared__ int s_bidx[16];
-    __shared__ int top[4];
-    for (int i = threadIdx.x; i < sync_length; i += blockDim.x) {
-        float2 acc = make_float2(0.f, 0.f);
-        for (int k = 0; k < ntaps; k++) {
-            const float2 p = cmul(taps[k], in[i + ntaps - 1 - k]);
-            acc.x = acc.x + p.x; acc.y = acc.y + p.y;
-        }
-        s_corr[i] = acc;
-    }
-    __syncthreads();
     // d_cor.sort(compare_abs2) is stable and descending in |value|: the first four are four rounds of "largest, lowest index"
     for (int round = 0; round < 4; round++) {
         float best = -1.f; int bidx = 0x7fffffff;
@@ -380,9 +368,29 @@ __global__ __launch_bounds__(1024) void fs_search_kernel(const float2* __restric
                 else if (diff == fft_len - 1) { r.frame_start = mn; r.freq_offset = ang / (fft_len - 1); have_freq = true; }
                 else if (diff == fft_len + 1) { r.frame_start = mn; r.freq_offset = ang / (fft_len + 1); have_freq = true; }
             }
-        if (!have_freq) r.freq_offset = __int_as_float(0x7fc00000);                       // "keep the previous d_freq_offset": resolved on the host
-        *res = r;
+        if (!have_freq) r.freq_offset = __int_as_float(0x7fc00000);                       // "keep the previous d_freq_offset": resolved by the caller
+        *res_out = r;
     }
+}
+
+__global__ __launch_bounds__(1024) void fs_search_kernel(const float2* __restrict__ in, const float2* __restrict__ taps, int ntaps,
+                                                         int sync_length, int fft_len, FsSearch* __restrict__ res)
+{
+#pragma clang fp contract(off)
+    extern __shared__ float2 s_corr[];                 // [sync_length]
+    __shared__ float s_best[16];
+    __shared__ int s_bidx[16];
+    __shared__ int top[4];
+    for (int i = threadIdx.x; i < sync_length; i += blockDim.x) {
+        float2 acc = make_float2(0.f, 0.f);
+        for (int k = 0; k < ntaps; k++) {
+            const float2 p = cmul(taps[k], in[i + ntaps - 1 - k]);
+            acc.x = acc.x + p.x; acc.y = acc.y + p.y;
+        }
+        s_corr[i] = acc;
+    }
+    __syncthreads();
+    fs_search_block(s_corr, sync_length, fft_len, res, s_best, s_bidx, top);
 }
 
 // COPY (:175-202) as an index map: input sample n (sample offset so0 + n) is kept when rel >= 0 and it is not a cyclic
@@ -582,4 +590,144 @@ extern "C" int jrc_frame_sync_work(jrc_frame_sync* f, int noutput_items, int nin
     f->nread += (uint64_t)n_in;
     f->nwritten += (uint64_t)n_out;
     return n_out;
+}
+
+// ---- batched, device-resident front end: capture in HBM -> per-frame symbol streams in HBM -------------------------------
+// The three blocks run to completion on a whole capture (a scheduler that always offers everything): the detector scan
+// lists the frames (start sample, coarse CFO, samples copied until the next detection / MAX_SAMPLES / end of capture);
+// one workgroup per frame then does frame_sync's work on the de-rotated samples it would have received: matched filter +
+// search on the first sync_length samples, then the CP-dropping copy with the fine de-rotation, zero-filled to a whole
+// symbol like the RESET state does.  frame k of the capture lands in row k of d_frames.
+struct SfFrame { int start, len; float coarse_cfo; int frame_start; float fine_cfo; double tag_value; int n_out; int pad_; };
+
+__global__ void fd_scan_all_kernel(FdParams p, const unsigned long long* __restrict__ marks, const float2* __restrict__ in_abs, int n,
+                                   SfFrame* __restrict__ frames, int max_frames, int* __restrict__ n_frames)
+{
+    if (threadIdx.x != 0) return;
+    int state = 0, copied = 0, nf = 0;
+    unsigned n_peaks = 0;
+    long first = 0;
+    auto is_mark = [&](int i) -> bool { return (marks[i >> 6] >> (i & 63)) & 1ull; };
+    auto cfo_at = [&](int i) -> float { const float2 a = in_abs[i]; return (float)((double)atan2f(a.y, a.x) / (p.fft_len / 4.0)); };
+    int i = 0;
+    while (i < n) {
+        if (n_peaks == 0 && (i & 63) == 0 && i + 64 <= n && marks[i >> 6] == 0ull && (state == 0 || copied + 64 <= p.max_samples)) {
+            if (state == 1) { copied += 64; frames[nf - 1].len += 64; if (copied == p.max_samples) state = 0; }
+            i += 64;
+            continue;
+        }
+        bool detect = false;
+        if (is_mark(i)) {
+            if (n_peaks < (unsigned)p.min_n_peaks) { n_peaks++; if (n_peaks == 1) first = i; }
+            else if ((i - first) < p.max_peak_distance) { if (state == 0 || copied > p.ignore_gap) detect = true; }
+            else { n_peaks = 0; first = 0; }
+        } else if ((i - first) > p.max_peak_distance) { n_peaks = 0; first = 0; }
+        if (detect) {                                            // SEARCH -> COPY (:108-118) or a new frame inside COPY (:153-165)
+            if (nf == max_frames) break;
+            state = 1; copied = 0; n_peaks = 0; first = 0;
+            SfFrame f; f.start = i; f.len = 0; f.coarse_cfo = cfo_at(i); f.frame_start = 0; f.fine_cfo = 0.f; f.tag_value = 0; f.n_out = 0; f.pad_ = 0;
+            frames[nf++] = f;
+            continue;                                            // the detection sample itself is the first one copied by the next call
+        }
+        if (state == 1) { copied++; frames[nf - 1].len++; if (copied == p.max_samples) state = 0; }
+        i++;
+    }
+    *n_frames = nf;
+}
+
+__global__ __launch_bounds__(256) void sf_frames_kernel(const float2* __restrict__ xd, int n, const float2* __restrict__ taps, int ntaps,
+                                                        int sync_length, int N, int cp, SfFrame* __restrict__ frames, const int* __restrict__ n_frames,
+                                                        float2* __restrict__ out, long out_stride /* samples per row */)
+{
+#pragma clang fp contract(off)
+    extern __shared__ float2 sf_lds[];                           // [sync_length + ntaps - 1] de-rotated samples, then [sync_length] correlation
+    __shared__ float s_best[16];
+    __shared__ int s_bidx[16];
+    __shared__ int top[4];
+    __shared__ FsSearch sr;
+    const int f = blockIdx.x;
+    if (f >= *n_frames) return;
+    SfFrame fr = frames[f];
+    float2* s_in = sf_lds;
+    float2* s_corr = sf_lds + sync_length + ntaps - 1;
+    auto det_out = [&](int so) -> float2 {                      // what frame_detector hands over: xd de-rotated by the coarse CFO (:178)
+        if (so >= fr.len || fr.start + so >= n) return make_float2(0.f, 0.f);
+        float sn, cs;
+        sincosf(-fr.coarse_cfo * (float)so, &sn, &cs);
+        return cmul(xd[fr.start + so], make_float2(cs, sn));
+    };
+    for (int i = threadIdx.x; i < sync_length + ntaps - 1; i += blockDim.x) s_in[i] = det_out(i);
+    __syncthreads();
+    for (int i = threadIdx.x; i < sync_length; i += blockDim.x) {
+        float2 acc = make_float2(0.f, 0.f);
+        for (int k = 0; k < ntaps; k++) {
+            const float2 p = cmul(taps[k], s_in[i + ntaps - 1 - k]);
+            acc.x = acc.x + p.x; acc.y = acc.y + p.y;
+        }
+        s_corr[i] = acc;
+    }
+    __syncthreads();
+    fs_search_block(s_corr, sync_length, N, &sr, s_best, s_bidx, top);
+    __syncthreads();
+    const int fstart = sr.frame_start;
+    const float fine = (sr.freq_offset == sr.freq_offset) ? sr.freq_offset : 0.f;     // no pair matched on a fresh synchroniser: 0
+    // COPY: the synchroniser sees the segment again through the sync_length delay, sample offsets counted from the tag; the
+    // next tag (or the end of the stream) arrives on the undelayed port sync_length samples before the delayed port has
+    // delivered the segment's tail, so the last sync_length samples of a segment are never copied
+    const long copy_len = (long)fr.len - sync_length;
+    const long kept = fs_kept_before(copy_len - fstart, N, cp);
+    const long n_out = ((kept + N - 1) / N) * N;                  // RESET completes the last symbol with zeros (:204-223)
+    float2* o = out + (size_t)f * out_stride;
+    for (long so = fstart + threadIdx.x; so < copy_len; so += blockDim.x) {
+        const long rel = so - fstart;
+        const bool keep = rel < 2L * N || ((rel - 2L * N) % (N + cp)) > cp - 1;
+        if (!keep) continue;
+        const long oi = fs_kept_before(rel, N, cp);
+        if (oi >= out_stride) continue;
+        float sn, cs;
+        sincosf((float)so * fine, &sn, &cs);
+        o[oi] = cmul(det_out((int)so), make_float2(cs, sn));
+    }
+    for (long oi = kept + threadIdx.x; oi < n_out && oi < out_stride; oi += blockDim.x) o[oi] = make_float2(0.f, 0.f);
+    if (threadIdx.x == 0) {
+        fr.frame_start = fstart; fr.fine_cfo = fine; fr.tag_value = (double)fr.coarse_cfo - (double)fine;   // :186
+        fr.n_out = (int)(n_out < out_stride ? n_out : (out_stride / N) * N);
+        frames[f] = fr;
+    }
+}
+
+extern "C" int jrc_sync_frontend_dev(jrc_ctx* ctx, const jrc_sync_cfg* c, int n_samples, const jrc_cf32* d_x, jrc_cf32* d_work /* 2*n cf32 + n float + n/8+64 bytes */,
+                                     int max_frames, int max_symbols, jrc_cf32* d_frames, jrc_sync_frame* d_info, int* d_n_frames, void* stream)
+{
+    if (!ctx || !c || n_samples < 0 || max_frames < 1 || max_symbols < 2 || !d_x || !d_work || !d_frames || !d_info || !d_n_frames || !c->d_ltf_taps)
+        return JRC_ERR_INVALID_ARG;
+    if (c->fft_len < 4 || c->cp_len < 0 || c->sync_length < 4 || c->sync_length > 4096 || c->n_taps < 1 || c->n_taps > 1024 || c->delay < 0 || c->window < 1 ||
+        c->power_window < 1)
+        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "sync front end: invalid configuration");
+    static_assert(sizeof(jrc_sync_frame) == sizeof(SfFrame), "jrc_sync_frame layout");
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    const size_t n = (size_t)n_samples;
+    float2* d_xd = (float2*)d_work;
+    float2* d_abs = d_xd + n;
+    float* d_cor = (float*)(d_abs + n);
+    unsigned long long* d_marks = (unsigned long long*)(d_cor + ((n + 1) & ~(size_t)1));
+    JRC_TRY(jrc_sync_metrics_dev(ctx, n_samples, c->delay, c->window, c->power_window, c->power_scale, d_x, (jrc_cf32*)d_xd, (jrc_cf32*)d_abs, d_cor, s));
+    FdParams p;
+    p.fft_len = c->fft_len; p.min_n_peaks = (int)c->min_n_peaks; p.ignore_gap = (int)c->ignore_gap; p.threshold = c->threshold; p.max_peak_value = 2.0;
+    p.max_peak_distance = 2 * (c->fft_len + c->cp_len); p.max_samples = 540 * (c->fft_len + c->cp_len);
+    const int nblk = (n_samples + 63 + 255) / 256;
+    hipLaunchKernelGGL(fd_marks_kernel, dim3(nblk > 0 ? nblk : 1), dim3(256), 0, s, (const float*)d_cor, d_marks, n_samples, p.threshold, p.max_peak_value);
+    hipLaunchKernelGGL(fd_scan_all_kernel, dim3(1), dim3(64), 0, s, p, (const unsigned long long*)d_marks, (const float2*)d_abs, n_samples,
+                       (SfFrame*)d_info, max_frames, d_n_frames);
+    const size_t lds = sizeof(float2) * ((size_t)2 * c->sync_length + c->n_taps - 1);
+    hipLaunchKernelGGL(sf_frames_kernel, dim3(max_frames), dim3(256), lds, s, (const float2*)d_xd, n_samples, (const float2*)c->d_ltf_taps, c->n_taps,
+                       c->sync_length, c->fft_len, c->cp_len, (SfFrame*)d_info, (const int*)d_n_frames, (float2*)d_frames, (long)max_symbols * c->fft_len);
+    JRC_HIP(ctx, hipGetLastError());
+    return JRC_OK;
+}
+
+extern "C" size_t jrc_sync_frontend_work_bytes(int n_samples)
+{
+    const size_t n = (size_t)(n_samples > 0 ? n_samples : 0);
+    return 2 * n * sizeof(float2) + ((n + 1) & ~(size_t)1) * sizeof(float) + (n / 64 + 2) * sizeof(unsigned long long) + 64;
 }

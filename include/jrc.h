@@ -394,6 +394,31 @@ int jrc_zero_pad(jrc_ctx* ctx, int n_input, unsigned pad_front, unsigned pad_tai
 int jrc_zero_pad_dev(jrc_ctx* ctx, int n_bursts, int n_input, unsigned pad_front, unsigned pad_tail, uint64_t seed,
                      const jrc_cf32* d_in, jrc_cf32* d_out, void* stream);
 
+/* batched, device-resident form of the whole front end (detection metrics -> frame_detector -> frame_sync run to completion on
+ * one capture): frame k of the capture lands in row k of d_frames ([max_frames][max_symbols * fft_len] time-domain samples,
+ * cyclic prefixes removed, de-rotated, first two symbols = the long training field as frame_sync delivers it). */
+typedef struct {
+    int fft_len, cp_len;
+    double threshold;                 /* frame_detector */
+    unsigned min_n_peaks, ignore_gap;
+    int sync_length, n_taps;          /* frame_sync */
+    const jrc_cf32* d_ltf_taps;       /* [n_taps] on the device */
+    int delay, window, power_window;  /* stock metric blocks: blocks_delay, moving_avg length, moving_average_ff length */
+    float power_scale;                /* moving_average_ff scale */
+} jrc_sync_cfg;
+typedef struct {
+    int start, len;                   /* first sample of the (delayed) capture the detector copied, samples copied */
+    float coarse_cfo;                 /* frame_detector's tag value */
+    int frame_start;                  /* frame_sync d_frame_start */
+    float fine_cfo;                   /* frame_sync d_freq_offset */
+    double tag_value;                 /* frame_sync's frame_start tag: coarse - fine */
+    int n_out;                        /* samples written to the row (a multiple of fft_len) */
+    int pad_;
+} jrc_sync_frame;
+size_t jrc_sync_frontend_work_bytes(int n_samples);
+int jrc_sync_frontend_dev(jrc_ctx* ctx, const jrc_sync_cfg* cfg, int n_samples, const jrc_cf32* d_x, jrc_cf32* d_work, int max_frames,
+                          int max_symbols, jrc_cf32* d_frames, jrc_sync_frame* d_info, int* d_n_frames, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

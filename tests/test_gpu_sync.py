@@ -124,3 +124,40 @@ def test_front_end_delivers_decodable_frames(jrc, ctx, ofdm64):
         assert starts
         got.append(dec.work(r["out"], starts[0]))
     assert [g for g in got if g[0]] == [(True, m[0]) for m in meta]
+
+
+def test_batched_front_end_equals_the_block_chain(jrc, ctx, ofdm64):
+    """jrc_sync_frontend_dev on a capture with three frames against frame_detector + frame_sync run block by block"""
+    import torch
+    x, meta = capture(ofdm64, 6, cfo=-0.012, n_frames=3)
+    fe = jrc.SyncFrontEnd(N, CP, 0.6, 10, 8 * (N + CP), SYNC_LEN, ofdm64["l_ltf_fir"], max_frames=8, max_symbols=80, ctx=ctx)
+    d_x = torch.from_numpy(x.view(np.float32).reshape(-1, 2).copy()).cuda()
+    fe.run(d_x, x.size)
+    n, info = fe.results()
+    assert n == 3
+    rows = fe.frames.cpu().numpy().view(np.complex64)[..., 0].reshape(8, -1)
+    # block chain on the same capture
+    xd, ia, ic = oracle.sync_metrics(x, 16, 32, 48, 1 / 1.5)
+    seg, dtags = oracle.FrameDetector(N, CP, 0.6, 10, 8 * (N + CP)).run(xd, ia, ic)
+    delayed = np.concatenate([np.zeros(SYNC_LEN, np.complex64), seg])[:seg.size]
+    out, otags = oracle.FrameSync(N, CP, SYNC_LEN, ofdm64["l_ltf_fir"]).run(seg, delayed, dtags)
+    assert [t[0] for t in dtags] == list(np.cumsum([0] + [f.len for f in info[:-1]]))
+    for k in range(3):
+        assert abs(info[k].coarse_cfo - dtags[k][1]) < 1e-6 and abs(info[k].tag_value - otags[k][1]) < 1e-5
+        lo = otags[k][0]
+        hi = otags[k + 1][0] if k + 1 < 3 else out.size
+        want = out[lo:hi]
+        m = min(want.size, info[k].n_out)
+        if k < 2:
+            assert want.size == info[k].n_out                   # the block chain's RESET zero-fill included
+        assert m > 20 * N and rel_err(rows[k][:m], want[:m]) < TOL
+    # and the frames decode: FFT -> equalizer -> decoder
+    o = ofdm64
+    eq = jrc.mimo_ofdm_equalizer(0, 24e9, 125e6, N, CP, o["data_subcarriers"], o["pilot_subcarriers"], o["pilot_symbols"], o["ltf_64"],
+                                 o["ltf_mapped_sc__ss_sym"], 4, ctx=ctx)
+    dec = jrc.stream_decoder(48, ctx=ctx)
+    for k in range(3):
+        sym_f = jrc.fft_vcc(N, True, None, True, ctx=ctx).work(rows[k][:info[k].n_out].reshape(-1, N)) / np.float32(np.sqrt(N))
+        r = eq.general_work(sym_f, [(0, info[k].tag_value)])
+        st = [e for e in r["events"] if e["kind"] == 1]
+        assert st and dec.work(r["out"], st[0]) == (True, meta[k][0])
