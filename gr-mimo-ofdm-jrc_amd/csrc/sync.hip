@@ -600,39 +600,110 @@ extern "C" int jrc_frame_sync_work(jrc_frame_sync* f, int noutput_items, int nin
 // symbol like the RESET state does.  frame k of the capture lands in row k of d_frames.
 struct SfFrame { int start, len; float coarse_cfo; int frame_start; float fine_cfo; double tag_value; int n_out; int pad_; };
 
-__global__ void fd_scan_all_kernel(FdParams p, const unsigned long long* __restrict__ marks, const float2* __restrict__ in_abs, int n,
-                                   SfFrame* __restrict__ frames, int max_frames, int* __restrict__ n_frames)
+// one wave: the lanes fetch 64 mask words (4096 samples) at a time, the state machine itself is wave-uniform and steps
+// through them from registers; stretches without a peak bit are skipped a word — or, with no peak run open, a whole fetch —
+// at a time
+__global__ __launch_bounds__(64) void fd_scan_all_kernel(FdParams p, const unsigned long long* __restrict__ marks, const float2* __restrict__ in_abs,
+                                                        int n, SfFrame* __restrict__ frames, int max_frames, int* __restrict__ n_frames)
 {
-    if (threadIdx.x != 0) return;
+    const int lane = threadIdx.x;
     int state = 0, copied = 0, nf = 0;
     unsigned n_peaks = 0;
     long first = 0;
-    auto is_mark = [&](int i) -> bool { return (marks[i >> 6] >> (i & 63)) & 1ull; };
-    auto cfo_at = [&](int i) -> float { const float2 a = in_abs[i]; return (float)((double)atan2f(a.y, a.x) / (p.fft_len / 4.0)); };
-    int i = 0;
-    while (i < n) {
-        if (n_peaks == 0 && (i & 63) == 0 && i + 64 <= n && marks[i >> 6] == 0ull && (state == 0 || copied + 64 <= p.max_samples)) {
-            if (state == 1) { copied += 64; frames[nf - 1].len += 64; if (copied == p.max_samples) state = 0; }
-            i += 64;
-            continue;
+    int cur_len = 0;                                             // samples copied into frame nf-1 so far (flushed on change)
+    float cur_cfo = 0.f; int cur_start = 0;
+    auto flush = [&]() {
+        if (nf > 0 && lane == 0) {
+            SfFrame f; f.start = cur_start; f.len = cur_len; f.coarse_cfo = cur_cfo; f.frame_start = 0; f.fine_cfo = 0.f; f.tag_value = 0; f.n_out = 0; f.pad_ = 0;
+            frames[nf - 1] = f;
         }
-        bool detect = false;
-        if (is_mark(i)) {
-            if (n_peaks < (unsigned)p.min_n_peaks) { n_peaks++; if (n_peaks == 1) first = i; }
-            else if ((i - first) < p.max_peak_distance) { if (state == 0 || copied > p.ignore_gap) detect = true; }
-            else { n_peaks = 0; first = 0; }
-        } else if ((i - first) > p.max_peak_distance) { n_peaks = 0; first = 0; }
-        if (detect) {                                            // SEARCH -> COPY (:108-118) or a new frame inside COPY (:153-165)
-            if (nf == max_frames) break;
-            state = 1; copied = 0; n_peaks = 0; first = 0;
-            SfFrame f; f.start = i; f.len = 0; f.coarse_cfo = cfo_at(i); f.frame_start = 0; f.fine_cfo = 0.f; f.tag_value = 0; f.n_out = 0; f.pad_ = 0;
-            frames[nf++] = f;
-            continue;                                            // the detection sample itself is the first one copied by the next call
+    };
+    const int n_words = (n + 63) >> 6;
+    bool full = false;
+    for (int wb = 0; wb < n_words && !full; wb += 64) {
+        const int wi = wb + lane;
+        const unsigned long long mine = wi < n_words ? marks[wi] : 0ull;
+        const unsigned long long nz = __ballot(mine != 0ull);
+        for (int j = 0; j < 64 && wb + j < n_words && !full; j++) {
+            const int base = (wb + j) << 6;
+            const int cnt = min(64, n - base);
+            if (n_peaks == 0 && cnt == 64) {
+                // no peak run open: every word up to the next one with a peak bit only advances the copy counter
+                const unsigned long long rest = nz >> j;
+                int skip = rest ? __ffsll((long long)rest) - 1 : 64 - j;                 // words without any peak bit from here
+                if (wb + j + skip > n_words - 1) skip = max(0, n_words - 1 - (wb + j)); // keep the (possibly partial) last word for the slow path
+                if (skip > 0) {
+                    if (state == 1) {
+                        const int room = (p.max_samples - copied) / 64;                   // whole words before MAX_SAMPLES
+                        if (skip > room) skip = room;
+                    }
+                    if (skip > 0) {
+                        if (state == 1) { copied += 64 * skip; cur_len += 64 * skip; if (copied == p.max_samples) state = 0; }
+                        j += skip - 1;
+                        continue;
+                    }
+                }
+            }
+            // the word into scalar registers: everything the state machine touches below is wave-uniform, so it runs on the
+            // scalar unit instead of as 64-wide vector code
+            const unsigned long long word = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mine >> 32), j) << 32) |
+                                            (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mine & 0xffffffffull), j);
+            // event driven inside the word: unmarked stretches only move the copy counter and may close an open peak run
+            auto advance = [&](int k) {
+                if (state == 1 && k > 0) {
+                    const int take = min(k, p.max_samples - copied);
+                    copied += take; cur_len += take;
+                    if (copied == p.max_samples) state = 0;
+                }
+            };
+            int pos = 0;
+            while (pos < cnt && !full) {
+                const unsigned long long rem = word >> pos;
+                const int nm = rem ? pos + __ffsll((long long)rem) - 1 : cnt;             // next peak bit, or the end of the word
+                if (nm > pos) {
+                    if (n_peaks > 0 && (long)(base + nm - 1) - first > p.max_peak_distance) { n_peaks = 0; first = 0; }   // :125-129 / :173-177
+                    advance(nm - pos);
+                    pos = nm;
+                    if (pos == cnt) break;
+                }
+                const int i = base + pos;
+                // a run of consecutive peak bits is taken in as few steps as the rules allow
+                const unsigned long long inv = ~rem;
+                int run = inv ? __ffsll((long long)inv) - 1 : 64;
+                if (run > cnt - pos) run = cnt - pos;
+                if (state == 1 && run > p.max_samples - copied) run = p.max_samples - copied;     // the state flips there
+                bool detect = false;
+                if (n_peaks < (unsigned)p.min_n_peaks) {                                          // counting up to min_n_peaks
+                    const int k = min(run, p.min_n_peaks - (int)n_peaks);
+                    if (n_peaks == 0) first = i;
+                    n_peaks += (unsigned)k;
+                    advance(k); pos += k;
+                    continue;
+                } else if ((i - first) < p.max_peak_distance) {
+                    if (state == 0 || copied > p.ignore_gap) detect = true;
+                    else {                                                                        // inside COPY, too early for a new frame: nothing happens
+                        int k = min(run, (int)(first + p.max_peak_distance - i));
+                        k = min(k, p.ignore_gap - copied + 1);
+                        advance(k); pos += k;
+                        continue;
+                    }
+                } else { n_peaks = 0; first = 0; }
+                if (detect) {                                    // SEARCH -> COPY (:108-118) or a new frame inside COPY (:153-165)
+                    if (nf == max_frames) { full = true; break; }
+                    flush();
+                    const float2 av = in_abs[i];
+                    state = 1; copied = 0;
+                    nf++; cur_start = i; cur_len = 0;
+                    cur_cfo = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)((double)atan2f(av.y, av.x) / (p.fft_len / 4.0)))));
+                    n_peaks = 1; first = i;                      // the COPY call that follows examines this sample again with fresh counters
+                }
+                advance(1);
+                pos++;
+            }
         }
-        if (state == 1) { copied++; frames[nf - 1].len++; if (copied == p.max_samples) state = 0; }
-        i++;
     }
-    *n_frames = nf;
+    flush();
+    if (lane == 0) *n_frames = nf;
 }
 
 __global__ __launch_bounds__(256) void sf_frames_kernel(const float2* __restrict__ xd, int n, const float2* __restrict__ taps, int ntaps,
@@ -722,6 +793,24 @@ extern "C" int jrc_sync_frontend_dev(jrc_ctx* ctx, const jrc_sync_cfg* c, int n_
     const size_t lds = sizeof(float2) * ((size_t)2 * c->sync_length + c->n_taps - 1);
     hipLaunchKernelGGL(sf_frames_kernel, dim3(max_frames), dim3(256), lds, s, (const float2*)d_xd, n_samples, (const float2*)c->d_ltf_taps, c->n_taps,
                        c->sync_length, c->fft_len, c->cp_len, (SfFrame*)d_info, (const int*)d_n_frames, (float2*)d_frames, (long)max_symbols * c->fft_len);
+    JRC_HIP(ctx, hipGetLastError());
+    return JRC_OK;
+}
+
+// the detector alone, run to completion on precomputed metric streams: the list of frames (start, samples copied, coarse CFO)
+extern "C" int jrc_frame_detector_scan_dev(jrc_ctx* ctx, int fft_len, int cp_len, double threshold, unsigned min_n_peaks, unsigned ignore_gap,
+                                           int n_samples, const jrc_cf32* d_in_abs, const float* d_in_cor, unsigned long long* d_marks,
+                                           int max_frames, jrc_sync_frame* d_info, int* d_n_frames, void* stream)
+{
+    if (!ctx || n_samples < 0 || max_frames < 1 || !d_in_abs || !d_in_cor || !d_marks || !d_info || !d_n_frames) return JRC_ERR_INVALID_ARG;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    FdParams p;
+    p.fft_len = fft_len; p.min_n_peaks = (int)min_n_peaks; p.ignore_gap = (int)ignore_gap; p.threshold = threshold; p.max_peak_value = 2.0;
+    p.max_peak_distance = 2 * (fft_len + cp_len); p.max_samples = 540 * (fft_len + cp_len);
+    const int nblk = (n_samples + 63 + 255) / 256;
+    hipLaunchKernelGGL(fd_marks_kernel, dim3(nblk > 0 ? nblk : 1), dim3(256), 0, s, d_in_cor, d_marks, n_samples, p.threshold, p.max_peak_value);
+    hipLaunchKernelGGL(fd_scan_all_kernel, dim3(1), dim3(64), 0, s, p, (const unsigned long long*)d_marks, (const float2*)d_in_abs, n_samples,
+                       (SfFrame*)d_info, max_frames, d_n_frames);
     JRC_HIP(ctx, hipGetLastError());
     return JRC_OK;
 }

@@ -416,6 +416,10 @@ typedef struct {
     int pad_;
 } jrc_sync_frame;
 size_t jrc_sync_frontend_work_bytes(int n_samples);
+/* frame_detector alone, run to completion on metric streams already on the device (d_marks: n_samples/64 + 2 words of scratch) */
+int jrc_frame_detector_scan_dev(jrc_ctx* ctx, int fft_len, int cp_len, double threshold, unsigned min_n_peaks, unsigned ignore_gap,
+                                int n_samples, const jrc_cf32* d_in_abs, const float* d_in_cor, unsigned long long* d_marks, int max_frames,
+                                jrc_sync_frame* d_info, int* d_n_frames, void* stream);
 int jrc_sync_frontend_dev(jrc_ctx* ctx, const jrc_sync_cfg* cfg, int n_samples, const jrc_cf32* d_x, jrc_cf32* d_work, int max_frames,
                           int max_symbols, jrc_cf32* d_frames, jrc_sync_frame* d_info, int* d_n_frames, void* stream);
 

@@ -161,3 +161,45 @@ def test_batched_front_end_equals_the_block_chain(jrc, ctx, ofdm64):
         r = eq.general_work(sym_f, [(0, info[k].tag_value)])
         st = [e for e in r["events"] if e["kind"] == 1]
         assert st and dec.work(r["out"], st[0]) == (True, meta[k][0])
+
+
+@pytest.mark.parametrize("seed,density,min_peaks,gap", [(0, 0.02, 10, 640), (1, 0.3, 10, 640), (2, 0.9, 10, 100), (3, 0.5, 1, 0), (4, 0.97, 3, 50000),
+                                                          (5, 0.6, 0, 200), (6, 0.999, 10, 640)])
+def test_run_to_completion_scan_equals_the_call_by_call_detector(jrc, ctx, seed, density, min_peaks, gap):
+    """the wave-cooperative scan (word skipping, run skipping) against the oracle's sample-by-sample state machine on random
+    peak patterns, incl. bursts longer than MAX_SAMPLES and peak values at and above MAX_PEAK_VALUE"""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(seed)
+    n = 120_000
+    ic = np.zeros(n, np.float32)
+    pos = 0
+    while pos < n:                                                       # alternating quiet stretches and peak bursts
+        pos += int(rng.integers(1, 3000))
+        blen = int(rng.integers(1, 400))
+        burst = (rng.random(blen) < density).astype(np.float32) * rng.choice([0.7, 0.7, 0.7, 2.0, 3.0], blen).astype(np.float32)
+        ic[pos:pos + blen] = burst[:max(0, min(blen, n - pos))]
+        pos += blen
+    ia = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    ramp = (np.arange(n) + 1j * 0).astype(np.complex64)                  # out[tag] = in[start] * exp(0): the ramp reveals `start`
+    det = oracle.FrameDetector(N, CP, 0.6, min_peaks, gap)
+    out, tags = det.run(ramp, ia, ic)
+    L = ctx.lib
+    L.jrc_frame_detector_scan_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_uint, C.c_uint, C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3
+    d_ia = torch.from_numpy(ia.view(np.float32).copy()).cuda()
+    d_ic = torch.from_numpy(ic).cuda()
+    d_marks = torch.zeros(n // 64 + 2, dtype=torch.int64, device="cuda")
+    d_info = torch.zeros((4096, C.sizeof(jrc.SyncFrame)), dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ctx.check(L.jrc_frame_detector_scan_dev(ctx.h, N, CP, 0.6, min_peaks, gap, n, d_ia.data_ptr(), d_ic.data_ptr(), d_marks.data_ptr(), 4096,
+                                            d_info.data_ptr(), d_n.data_ptr(), None))
+    ctx.sync()
+    nf = int(d_n.cpu().item())
+    raw = d_info[:nf].cpu().numpy().tobytes()
+    info = [jrc.SyncFrame.from_buffer_copy(raw[i * C.sizeof(jrc.SyncFrame):(i + 1) * C.sizeof(jrc.SyncFrame)]) for i in range(nf)]
+    assert nf == len(tags)
+    offs = [t[0] for t in tags] + [out.size]
+    for k, f in enumerate(info):
+        assert f.len == offs[k + 1] - offs[k], k
+        assert f.len == 0 or f.start == int(round(out[offs[k]].real)), k
+        assert abs(f.coarse_cfo - tags[k][1]) < 1e-6

@@ -94,6 +94,19 @@ def simulated_chain(cfg="B", F=64):
                 frames_per_s=F / t, ms_simulators_only=ts * 1e3, bursts_per_s_simulators=F * sc.T / ts)
 
 
+def sync_front_end(n_frames=512):
+    """capture in HBM -> frames of symbols (detection metrics, frame_detector, frame_sync run to completion)"""
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "sync_probe.py"), "--frames", str(n_frames)],
+                         capture_output=True, text=True).stdout.strip().splitlines()
+    line = [l for l in out if l.startswith("capture")][-1]
+    ms = float(line.split(":")[1].split("ms")[0])
+    nsamp = int(line.split()[2])
+    nf = int(line.split("frames found")[0].split(",")[-1])
+    return dict(what="sync front end (metrics + frame_detector + frame_sync) on a %d-sample capture with %d frames" % (nsamp, nf),
+                ms_per_capture=ms, M_samples_per_s=nsamp / ms / 1e3, frames_per_s=nf / ms * 1e3)
+
+
 def equalizer_config_c(n_frames=2048, lanes=4):
     N, cp, T, S = 256, 64, 4, 64
     rng = np.random.default_rng(0)
@@ -145,5 +158,5 @@ def equalizer_config_c(n_frames=2048, lanes=4):
 
 if __name__ == "__main__":
     for fn in (lambda: radar_with_demod("B", 256), lambda: radar_with_demod("D", 64), lambda: simulated_chain("B", 64),
-               lambda: simulated_chain("D", 8), equalizer_config_c):
+               lambda: simulated_chain("D", 8), equalizer_config_c, sync_front_end):
         print(json.dumps(fn()))
