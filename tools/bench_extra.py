@@ -107,6 +107,14 @@ def sync_front_end(n_frames=512):
                 ms_per_capture=ms, M_samples_per_s=nsamp / ms / 1e3, frames_per_s=nf / ms * 1e3)
 
 
+def comm_rx_chain(n_frames=4096):
+    """capture -> sync front end -> RX FFT -> equalizer -> Viterbi decoder, device-resident (tools/comm_rx_probe.py)"""
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "comm_rx_probe.py"), "--frames", str(n_frames), "--json"],
+                         capture_output=True, text=True).stdout.strip().splitlines()
+    return json.loads([l for l in out if l.startswith("{")][-1])
+
+
 def equalizer_config_c(n_frames=2048, lanes=4):
     N, cp, T, S = 256, 64, 4, 64
     rng = np.random.default_rng(0)
@@ -158,5 +166,5 @@ def equalizer_config_c(n_frames=2048, lanes=4):
 
 if __name__ == "__main__":
     for fn in (lambda: radar_with_demod("B", 256), lambda: radar_with_demod("D", 64), lambda: simulated_chain("B", 64),
-               lambda: simulated_chain("D", 8), equalizer_config_c, sync_front_end):
+               lambda: simulated_chain("D", 8), equalizer_config_c, sync_front_end, comm_rx_chain):
         print(json.dumps(fn()))
