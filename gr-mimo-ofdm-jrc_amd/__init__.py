@@ -1124,3 +1124,66 @@ class SyncFrontEnd:
         raw = self.d_info[:n].cpu().numpy().tobytes()
         info = [SyncFrame.from_buffer_copy(raw[i * C.sizeof(SyncFrame):(i + 1) * C.sizeof(SyncFrame)]) for i in range(n)]
         return n, info
+
+
+class ofdm_frame_generator:
+    """include/mimo_ofdm_jrc/ofdm_frame_generator.h make(fft_len, occupied_carriers, pilot_carriers, pilot_symbols, sync_words, ltf_len,
+    len_tag_key, output_is_shifted); work = lib/ofdm_frame_generator_impl.cc:155-216 (tagged stream block)."""
+
+    def __init__(self, fft_len, occupied_carriers, pilot_carriers, pilot_symbols, sync_words, ltf_len=0, len_tag_key="packet_len",
+                 output_is_shifted=True, ctx=None):
+        self.ctx = ctx or default_context()
+        L = load()
+        ip = C.POINTER(C.c_int)
+        L.jrc_frame_generator_create.restype = _vp
+        L.jrc_frame_generator_create.argtypes = [_vp, C.c_int, C.c_int, ip, ip, C.c_int, ip, ip, C.c_int, ip, _vp, C.c_int, _vp, C.c_int]
+        L.jrc_frame_generator_destroy.argtypes = [_vp]
+        L.jrc_frame_generator_destroy.restype = None
+        L.jrc_frame_generator_output_length.argtypes = [_vp, C.c_int]
+        L.jrc_frame_generator_work.argtypes = [_vp, C.c_int, _vp, _vp]
+        L.jrc_frame_generator_dev.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, _vp]
+        self.L, self.fft_len = L, fft_len
+
+        def flat(sets, dtype):
+            sizes = np.array([len(x) for x in sets], np.int32)
+            vals = np.ascontiguousarray(np.concatenate([np.asarray(x, dtype).ravel() for x in sets]) if sizes.sum() else np.zeros(1, dtype), dtype)
+            return sizes, vals
+        if len(occupied_carriers) == 0:
+            raise ValueError("Occupied carriers must be of type vector of vector i.e. ((),).")
+        if len(pilot_carriers) == 0:
+            raise ValueError("Pilot carriers must be of type vector of vector i.e. ((),).")
+        if len(pilot_symbols) == 0:
+            raise ValueError("Pilot symbols must be of type vector of vector i.e. ((),).")
+        osz, ofl = flat(occupied_carriers, np.int32)
+        psz, pfl = flat(pilot_carriers, np.int32)
+        ssz, sfl = flat(pilot_symbols, np.complex64)
+        sw = _c64(np.asarray(sync_words, np.complex64)) if len(sync_words) else np.zeros((0, fft_len), np.complex64)
+        if sw.size and sw.shape[-1] != fft_len:
+            raise ValueError("sync words must be fft length")
+        swp = sw if sw.size else np.zeros(1, np.complex64)
+        self.h = L.jrc_frame_generator_create(self.ctx.h, fft_len, len(osz), osz.ctypes.data_as(ip), ofl.ctypes.data_as(ip), len(psz),
+                                              psz.ctypes.data_as(ip), pfl.ctypes.data_as(ip), len(ssz), ssz.ctypes.data_as(ip), _ptr(sfl),
+                                              sw.shape[0] if sw.size else 0, _ptr(swp), int(bool(output_is_shifted)))
+        if not self.h:
+            raise ValueError(self.ctx.lib.jrc_last_error(self.ctx.h).decode())
+
+    def calculate_output_stream_length(self, ninput_items):
+        return self.L.jrc_frame_generator_output_length(self.h, ninput_items)
+
+    def work(self, x):
+        x = _c64(x).ravel()
+        out = np.zeros((self.calculate_output_stream_length(x.size), self.fft_len), np.complex64)
+        n = self.ctx.check(self.L.jrc_frame_generator_work(self.h, x.size, _ptr(x) if x.size else None, _ptr(out)))
+        assert n == out.shape[0]
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.jrc_frame_generator_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

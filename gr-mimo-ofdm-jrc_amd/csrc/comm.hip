@@ -940,3 +940,163 @@ extern "C" int jrc_precoder_work(jrc_precoder* p, int ninput_items, const jrc_cf
     for (int t = 0; t < T; t++) memcpy(out[t], hp + sizeof(float2) * (size_t)t * n_total * N, sizeof(float2) * (size_t)n_total * N);
     return n_total;
 }
+
+
+// =====================================================================================================================
+// ofdm_frame_generator (lib/ofdm_frame_generator_impl.cc:155-216): the SISO carrier allocator.  One workgroup per packet:
+// zero fill, sync words, one lane per input symbol scatters it to (OFDM symbol, carrier) through the cyclic carrier sets,
+// one lane per (OFDM symbol, pilot) writes the pilots.
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void frame_generator_kernel(int N, int n_occ_sets, const int* __restrict__ occ_off, const int* __restrict__ occ_flat,
+                                                              int n_pil_sets, const int* __restrict__ pil_off, const int* __restrict__ pil_flat,
+                                                              int n_psym_sets, const int* __restrict__ psym_off, const float2* __restrict__ psym_flat,
+                                                              int n_sync, const float2* __restrict__ sync_words, int n_in, long in_stride,
+                                                              const float2* __restrict__ in, int n_out_sym, long out_stride, float2* __restrict__ out)
+{
+    const size_t b = blockIdx.x;
+    const float2* x = in + b * (size_t)in_stride;
+    float2* o = out + b * (size_t)out_stride;
+    const int tid = threadIdx.x;
+    const int sps = occ_off[n_occ_sets];
+    const long total = (long)n_out_sym * N;
+    for (long i = tid; i < total; i += 256) o[i] = (i < (long)n_sync * N) ? sync_words[i] : make_float2(0.f, 0.f);   // :165-170
+    __syncthreads();
+    float2* d = o + (size_t)n_sync * N;
+    for (int i = tid; i < n_in; i += 256) {                                              // :175-200
+        const int cycle = i / sps, rem = i % sps;
+        int k = 0;
+        while (rem >= occ_off[k + 1]) k++;
+        d[(size_t)(cycle * n_occ_sets + k) * N + occ_flat[rem]] = x[i];
+    }
+    __syncthreads();
+    const int n_ofdm = n_out_sym - n_sync;
+    for (int sy = 0; sy < n_ofdm; sy++) {                                                // :202-208 (after the data: pilots win on a shared carrier)
+        const int pk = sy % n_pil_sets, sk = sy % n_psym_sets;
+        const int np = pil_off[pk + 1] - pil_off[pk];
+        for (int k = tid; k < np; k += 256) d[(size_t)sy * N + pil_flat[pil_off[pk] + k]] = psym_flat[psym_off[sk] + k];
+    }
+}
+
+struct jrc_frame_generator {
+    jrc_ctx* ctx;
+    int N, n_occ_sets, n_pil_sets, n_psym_sets, n_sync, sps;
+    std::vector<int> occ_sizes;
+    int *d_occ_off = nullptr, *d_occ_flat = nullptr, *d_pil_off = nullptr, *d_pil_flat = nullptr, *d_psym_off = nullptr;
+    float2 *d_psym = nullptr, *d_sync = nullptr;
+};
+
+extern "C" void jrc_frame_generator_destroy(jrc_frame_generator* g)
+{
+    if (!g) return;
+    (void)hipStreamSynchronize(g->ctx->stream);
+    (void)hipFree(g->d_occ_off); (void)hipFree(g->d_occ_flat); (void)hipFree(g->d_pil_off); (void)hipFree(g->d_pil_flat);
+    (void)hipFree(g->d_psym_off); (void)hipFree(g->d_psym); (void)hipFree(g->d_sync);
+    delete g;
+}
+
+template <class T> static bool fg_upload(T** dst, const std::vector<T>& v)
+{
+    const size_t n = v.size() ? v.size() : 1;
+    if (hipMalloc((void**)dst, sizeof(T) * n) != hipSuccess) return false;
+    return v.empty() || hipMemcpy(*dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice) == hipSuccess;
+}
+
+// carrier sets are passed flattened with per-set sizes, exactly as given to make(): negative indices wrap (+fft_len), and with
+// output_is_shifted every index is rotated by fft_len/2 (:83-113).  Returns NULL on the constructor's invalid_argument cases.
+extern "C" jrc_frame_generator* jrc_frame_generator_create(jrc_ctx* ctx, int fft_len, int n_occ_sets, const int* occ_sizes, const int* occ_flat,
+                                                           int n_pil_sets, const int* pil_sizes, const int* pil_flat, int n_psym_sets,
+                                                           const int* psym_sizes, const jrc_cf32* psym_flat, int n_sync, const jrc_cf32* sync_words,
+                                                           int output_is_shifted)
+{
+    if (!ctx) return nullptr;
+    auto fail = [&](const char* m) -> jrc_frame_generator* { jrc_fail(ctx, JRC_ERR_INVALID_ARG, "%s", m); return nullptr; };
+    if (fft_len < 1 || n_occ_sets < 1 || !occ_sizes) return fail("Occupied carriers must be of type vector of vector i.e. ((),).");
+    if (n_pil_sets < 1 || !pil_sizes) return fail("Pilot carriers must be of type vector of vector i.e. ((),).");
+    if (n_psym_sets < 1 || !psym_sizes) return fail("Pilot symbols must be of type vector of vector i.e. ((),).");
+    if (n_sync < 0 || (n_sync > 0 && !sync_words)) return fail("sync words must be fft length");
+    std::vector<int> occ_off(1, 0), occ, pil_off(1, 0), pil, ps_off(1, 0);
+    for (int k = 0, p = 0; k < n_occ_sets; k++) {
+        for (int j = 0; j < occ_sizes[k]; j++, p++) {
+            int c = occ_flat[p];
+            if (c < 0) c += fft_len;
+            if (c > fft_len || c < 0) return fail("data carrier index out of bounds");
+            if (output_is_shifted) c = (c + fft_len / 2) % fft_len;
+            occ.push_back(c);
+        }
+        occ_off.push_back((int)occ.size());
+    }
+    for (int k = 0, p = 0; k < n_pil_sets; k++) {
+        for (int j = 0; j < pil_sizes[k]; j++, p++) {
+            int c = pil_flat[p];
+            if (c < 0) c += fft_len;
+            if (c > fft_len || c < 0) return fail("pilot carrier index out of bounds");
+            if (output_is_shifted) c = (c + fft_len / 2) % fft_len;
+            pil.push_back(c);
+        }
+        pil_off.push_back((int)pil.size());
+    }
+    for (int k = 0; k < n_psym_sets; k++) ps_off.push_back(ps_off.back() + psym_sizes[k]);
+    for (int i = 0; i < std::max(n_pil_sets, n_psym_sets); i++)
+        if (pil_sizes[i % n_pil_sets] != psym_sizes[i % n_psym_sets]) return fail("pilot_carriers do not match pilot_symbols");
+    for (size_t i = 0; i < occ.size(); i++) if (occ[i] >= fft_len) return fail("data carrier index out of bounds");     // index == fft_len passes :88 but is no carrier
+    for (size_t i = 0; i < pil.size(); i++) if (pil[i] >= fft_len) return fail("pilot carrier index out of bounds");
+    if (occ.empty()) return fail("Occupied carriers must be of type vector of vector i.e. ((),).");
+    if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+    jrc_frame_generator* g = new jrc_frame_generator();
+    g->ctx = ctx; g->N = fft_len; g->n_occ_sets = n_occ_sets; g->n_pil_sets = n_pil_sets; g->n_psym_sets = n_psym_sets; g->n_sync = n_sync;
+    g->sps = (int)occ.size();
+    g->occ_sizes.assign(occ_sizes, occ_sizes + n_occ_sets);
+    std::vector<float2> ps((const float2*)psym_flat, (const float2*)psym_flat + ps_off.back());
+    std::vector<float2> sw((const float2*)sync_words, (const float2*)sync_words + (size_t)n_sync * fft_len);
+    if (!fg_upload(&g->d_occ_off, occ_off) || !fg_upload(&g->d_occ_flat, occ) || !fg_upload(&g->d_pil_off, pil_off) || !fg_upload(&g->d_pil_flat, pil) ||
+        !fg_upload(&g->d_psym_off, ps_off) || !fg_upload(&g->d_psym, ps) || !fg_upload(&g->d_sync, sw)) {
+        jrc_fail(ctx, JRC_ERR_NOMEM, "ofdm_frame_generator: allocation failed");
+        jrc_frame_generator_destroy(g);
+        return nullptr;
+    }
+    return g;
+}
+
+extern "C" int jrc_frame_generator_output_length(const jrc_frame_generator* g, int ninput_items)        // :143-153
+{
+    if (!g || ninput_items < 0) return JRC_ERR_INVALID_ARG;
+    int nout = (ninput_items / g->sps) * g->n_occ_sets;
+    int k = 0;
+    for (int i = 0; i < ninput_items % g->sps; k++) { nout++; i += g->occ_sizes[k % g->n_occ_sets]; }
+    return nout + g->n_sync;
+}
+
+extern "C" int jrc_frame_generator_dev(jrc_frame_generator* g, int n_packets, int ninput_items, const jrc_cf32* d_in, jrc_cf32* d_out, void* stream)
+{
+    if (!g || n_packets < 0 || ninput_items < 0) return JRC_ERR_INVALID_ARG;
+    const int nout = jrc_frame_generator_output_length(g, ninput_items);
+    if (n_packets == 0) return nout;
+    if ((ninput_items > 0 && !d_in) || !d_out) return jrc_fail(g->ctx, JRC_ERR_INVALID_ARG, "ofdm_frame_generator: null buffers");
+    hipStream_t s = stream ? (hipStream_t)stream : g->ctx->stream;
+    hipLaunchKernelGGL(frame_generator_kernel, dim3(n_packets), dim3(256), 0, s, g->N, g->n_occ_sets, (const int*)g->d_occ_off, (const int*)g->d_occ_flat,
+                       g->n_pil_sets, (const int*)g->d_pil_off, (const int*)g->d_pil_flat, g->n_psym_sets, (const int*)g->d_psym_off,
+                       (const float2*)g->d_psym, g->n_sync, (const float2*)g->d_sync, ninput_items, (long)ninput_items, (const float2*)d_in, nout,
+                       (long)nout * g->N, (float2*)d_out);
+    JRC_HIP(g->ctx, hipGetLastError());
+    return nout;
+}
+
+extern "C" int jrc_frame_generator_work(jrc_frame_generator* g, int ninput_items, const jrc_cf32* in, jrc_cf32* out)
+{
+    if (!g || ninput_items < 0 || (ninput_items > 0 && !in) || !out) return JRC_ERR_INVALID_ARG;
+    jrc_ctx* ctx = g->ctx;
+    JRC_HIP(ctx, hipSetDevice(ctx->device));
+    const int nout = jrc_frame_generator_output_length(g, ninput_items);
+    const size_t ib = sizeof(float2) * (size_t)(ninput_items > 0 ? ninput_items : 1), ob = sizeof(float2) * (size_t)nout * g->N;
+    if (ob == 0) return 0;
+    JRC_TRY(jrc_ensure_pinned(ctx, ib + ob));
+    JRC_TRY(jrc_ensure_scratch(ctx, 0, ib));
+    JRC_TRY(jrc_ensure_scratch(ctx, 1, ob));
+    if (ninput_items) memcpy(ctx->pinned, in, sizeof(float2) * (size_t)ninput_items);
+    JRC_HIP(ctx, hipMemcpyAsync(ctx->scratch[0], ctx->pinned, ib, hipMemcpyHostToDevice, ctx->stream));
+    JRC_TRY(jrc_frame_generator_dev(g, 1, ninput_items, (const jrc_cf32*)ctx->scratch[0], (jrc_cf32*)ctx->scratch[1], ctx->stream));
+    JRC_HIP(ctx, hipMemcpyAsync((char*)ctx->pinned + ib, ctx->scratch[1], ob, hipMemcpyDeviceToHost, ctx->stream));
+    JRC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(out, (char*)ctx->pinned + ib, ob);
+    return nout;
+}

@@ -1106,5 +1106,73 @@ zero_pad::sptr zero_pad::make(bool debug, unsigned int pad_front, unsigned int p
     return JRC_GET_INITIAL_SPTR(new zero_pad_impl(debug, pad_front, pad_tail));
 }
 
+// =================================================================================================
+// ofdm_frame_generator  (lib/ofdm_frame_generator_impl.cc)
+// =================================================================================================
+class ofdm_frame_generator_impl : public ofdm_frame_generator {
+    ctx_holder d_c;
+    jrc_frame_generator* d_gen = nullptr;
+    int d_fft_len;
+    std::vector<int> d_occ_sizes;
+    int d_n_sync;
+
+public:
+    ofdm_frame_generator_impl(int fft_len, const std::vector<std::vector<int>>& occupied_carriers, const std::vector<std::vector<int>>& pilot_carriers,
+                              const std::vector<std::vector<gr_complex>>& pilot_symbols, const std::vector<std::vector<gr_complex>>& sync_words,
+                              int, const std::string& len_tag_key, const bool output_is_shifted)
+        : jrc_rt::tagged_stream_block("ofdm_frame_generator", jrc_rt::io_signature::make(1, 1, sizeof(gr_complex)),
+                                      jrc_rt::io_signature::make(1, 1, sizeof(gr_complex) * fft_len), len_tag_key),
+          d_fft_len(fft_len), d_n_sync((int)sync_words.size())
+    {
+        if (occupied_carriers.empty()) throw std::invalid_argument("Occupied carriers must be of type vector of vector i.e. ((),).");   // :77-82
+        if (pilot_carriers.empty()) throw std::invalid_argument("Pilot carriers must be of type vector of vector i.e. ((),).");
+        if (pilot_symbols.empty()) throw std::invalid_argument("Pilot symbols must be of type vector of vector i.e. ((),).");
+        for (auto& w : sync_words) if (w.size() != (unsigned)fft_len) throw std::invalid_argument("sync words must be fft length");      // :126-130
+        std::vector<int> osz, ofl, psz, pfl, ssz;
+        std::vector<gr_complex> sfl, sw;
+        for (auto& v : occupied_carriers) { osz.push_back((int)v.size()); ofl.insert(ofl.end(), v.begin(), v.end()); }
+        for (auto& v : pilot_carriers) { psz.push_back((int)v.size()); pfl.insert(pfl.end(), v.begin(), v.end()); }
+        for (auto& v : pilot_symbols) { ssz.push_back((int)v.size()); sfl.insert(sfl.end(), v.begin(), v.end()); }
+        for (auto& v : sync_words) sw.insert(sw.end(), v.begin(), v.end());
+        d_occ_sizes = osz;
+        ofl.push_back(0); pfl.push_back(0); sfl.push_back(gr_complex(0, 0)); sw.push_back(gr_complex(0, 0));   // never-empty data() pointers
+        d_gen = jrc_frame_generator_create(d_c.ctx, fft_len, (int)osz.size(), osz.data(), ofl.data(), (int)psz.size(), psz.data(), pfl.data(),
+                                           (int)ssz.size(), ssz.data(), (const jrc_cf32*)sfl.data(), d_n_sync, (const jrc_cf32*)sw.data(),
+                                           output_is_shifted ? 1 : 0);
+        if (!d_gen) throw std::invalid_argument(jrc_last_error(d_c.ctx));
+        set_tag_propagation_policy(TPP_DONT);
+    }
+    ~ofdm_frame_generator_impl() override { jrc_frame_generator_destroy(d_gen); }
+    int calculate_output_stream_length(const gr_vector_int& ninput_items) override { return jrc_frame_generator_output_length(d_gen, ninput_items[0]); }
+    int work(int, gr_vector_int& ninput_items, gr_vector_const_void_star& in, gr_vector_void_star& out) override
+    {
+        // tags travel with the OFDM symbol that carries their item (:177-191)
+        std::vector<jrc_rt::tag_t> tags;
+        long n_ofdm_symbols = 0;
+        int curr_set = 0;
+        for (int i = 0; i < ninput_items[0];) {
+            const int to_alloc = d_occ_sizes[curr_set];
+            get_tags_in_range(tags, 0, nitems_read(0) + i, nitems_read(0) + std::min(i + to_alloc, (int)ninput_items[0]));
+            for (auto& t : tags)
+                add_item_tag(0, nitems_written(0) + n_ofdm_symbols + (n_ofdm_symbols == 0 ? 0 : d_n_sync), t.key, t.value);
+            n_ofdm_symbols++;
+            i += to_alloc;
+            curr_set = (curr_set + 1) % (int)d_occ_sizes.size();
+        }
+        int n = jrc_frame_generator_work(d_gen, ninput_items[0], (const jrc_cf32*)in[0], (jrc_cf32*)out[0]);
+        d_c.check(n);
+        return n;                                                                        // n_ofdm_symbols + sync words (:215)
+    }
+};
+ofdm_frame_generator::sptr ofdm_frame_generator::make(int fft_len, const std::vector<std::vector<int>>& occupied_carriers,
+                                                      const std::vector<std::vector<int>>& pilot_carriers,
+                                                      const std::vector<std::vector<gr_complex>>& pilot_symbols,
+                                                      const std::vector<std::vector<gr_complex>>& sync_words, int ltf_len,
+                                                      const std::string& len_tag_key, const bool output_is_shifted)
+{
+    return JRC_GET_INITIAL_SPTR(new ofdm_frame_generator_impl(fft_len, occupied_carriers, pilot_carriers, pilot_symbols, sync_words, ltf_len,
+                                                              len_tag_key, output_is_shifted));
+}
+
 }  // namespace mimo_ofdm_jrc
 }  // namespace gr

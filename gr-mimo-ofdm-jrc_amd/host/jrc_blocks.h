@@ -16,6 +16,7 @@
 //   include/mimo_ofdm_jrc/frame_detector.h:44-49       gr::mimo_ofdm_jrc::frame_detector
 //   include/mimo_ofdm_jrc/frame_sync.h:44-49           gr::mimo_ofdm_jrc::frame_sync
 //   include/mimo_ofdm_jrc/zero_pad.h                   gr::mimo_ofdm_jrc::zero_pad
+//   include/mimo_ofdm_jrc/ofdm_frame_generator.h       gr::mimo_ofdm_jrc::ofdm_frame_generator
 //
 // Built against GNU Radio 3.8 with -DJRC_WITH_GNURADIO; otherwise against the stand-alone test runtime.
 #pragma once
@@ -140,6 +141,14 @@ public:
     virtual void set_length_and_scale(int length, float scale) = 0;
     virtual void set_length(int length) = 0;
     virtual void set_scale(float scale) = 0;
+};
+
+class ofdm_frame_generator : virtual public jrc_rt::tagged_stream_block {
+public:
+    typedef JRC_SPTR<ofdm_frame_generator> sptr;
+    static sptr make(int fft_len, const std::vector<std::vector<int>>& occupied_carriers, const std::vector<std::vector<int>>& pilot_carriers,
+                     const std::vector<std::vector<gr_complex>>& pilot_symbols, const std::vector<std::vector<gr_complex>>& sync_words,
+                     int ltf_len, const std::string& len_tag_key = "packet_len", const bool output_is_shifted = true);
 };
 
 class zero_pad : virtual public jrc_rt::tagged_stream_block {

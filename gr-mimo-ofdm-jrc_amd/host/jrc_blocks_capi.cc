@@ -92,6 +92,21 @@ void* jrcb_make_target_simulator(const float* range, const float* velocity, cons
                                rndm_phaseshift != 0, self_coupling != 0))); });
 }
 
+// carrier / symbol sets flattened with per-set sizes
+void* jrcb_make_frame_generator(int fft_len, int n_occ, const int* occ_sizes, const int* occ_flat, int n_pil, const int* pil_sizes, const int* pil_flat,
+                                int n_ps, const int* ps_sizes, const float* ps_flat, int n_sync, const float* sync_words, int shifted)
+{
+    return guard_make([&] {
+        std::vector<std::vector<int>> occ, pil;
+        std::vector<std::vector<gr_complex>> ps, sw;
+        for (int k = 0, p = 0; k < n_occ; k++) { occ.emplace_back(occ_flat + p, occ_flat + p + occ_sizes[k]); p += occ_sizes[k]; }
+        for (int k = 0, p = 0; k < n_pil; k++) { pil.emplace_back(pil_flat + p, pil_flat + p + pil_sizes[k]); p += pil_sizes[k]; }
+        for (int k = 0, p = 0; k < n_ps; k++) { ps.emplace_back((const gr_complex*)ps_flat + p, (const gr_complex*)ps_flat + p + ps_sizes[k]); p += ps_sizes[k]; }
+        for (int k = 0; k < n_sync; k++) sw.emplace_back((const gr_complex*)sync_words + (size_t)k * fft_len, (const gr_complex*)sync_words + (size_t)(k + 1) * fft_len);
+        return std::static_pointer_cast<jrc_host::block>(std::shared_ptr<ofdm_frame_generator>(
+            ofdm_frame_generator::make(fft_len, occ, pil, ps, sw, 0, "packet_len", shifted != 0)));
+    });
+}
 void* jrcb_make_zero_pad(unsigned pad_front, unsigned pad_tail)
 {
     return guard_make([&] { return std::static_pointer_cast<jrc_host::block>(std::shared_ptr<zero_pad>(zero_pad::make(false, pad_front, pad_tail))); });

@@ -423,6 +423,20 @@ int jrc_frame_detector_scan_dev(jrc_ctx* ctx, int fft_len, int cp_len, double th
 int jrc_sync_frontend_dev(jrc_ctx* ctx, const jrc_sync_cfg* cfg, int n_samples, const jrc_cf32* d_x, jrc_cf32* d_work, int max_frames,
                           int max_symbols, jrc_cf32* d_frames, jrc_sync_frame* d_info, int* d_n_frames, void* stream);
 
+/* ---- ofdm_frame_generator (lib/ofdm_frame_generator_impl.cc:55-216; make(fft_len, occupied_carriers, pilot_carriers, pilot_symbols,
+ * sync_words, ltf_len, len_tag_key, output_is_shifted)): the SISO carrier allocator.  Carrier / pilot-symbol sets are passed flattened
+ * with per-set sizes, indices as given to make().  create returns NULL for the constructor's std::invalid_argument cases. ---- */
+typedef struct jrc_frame_generator jrc_frame_generator;
+jrc_frame_generator* jrc_frame_generator_create(jrc_ctx* ctx, int fft_len, int n_occ_sets, const int* occ_sizes, const int* occ_flat,
+                                                int n_pil_sets, const int* pil_sizes, const int* pil_flat, int n_psym_sets,
+                                                const int* psym_sizes, const jrc_cf32* psym_flat, int n_sync, const jrc_cf32* sync_words,
+                                                int output_is_shifted);
+void jrc_frame_generator_destroy(jrc_frame_generator* g);
+int jrc_frame_generator_output_length(const jrc_frame_generator* g, int ninput_items);      /* calculate_output_stream_length */
+/* work(): ninput_items symbols -> output_length vectors of fft_len; returns the vectors written */
+int jrc_frame_generator_work(jrc_frame_generator* g, int ninput_items, const jrc_cf32* in, jrc_cf32* out);
+int jrc_frame_generator_dev(jrc_frame_generator* g, int n_packets, int ninput_items, const jrc_cf32* d_in, jrc_cf32* d_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -630,3 +630,57 @@ class FrameSync:
             idle = idle + 1 if (c == 0 and o.size == 0) else 0
             pos += c
         return np.concatenate(outs) if outs else np.zeros(0, np.complex64), otags
+
+
+def _norm_sets(sets, fft_len, shifted):
+    out = []
+    for st in sets:
+        v = [int(c) + fft_len if int(c) < 0 else int(c) for c in st]
+        if any(c > fft_len or c < 0 for c in v):
+            raise ValueError("carrier index out of bounds")
+        out.append([(c + fft_len // 2) % fft_len for c in v] if shifted else v)
+    return out
+
+
+class FrameGenerator:
+    """ofdm_frame_generator_impl (lib/ofdm_frame_generator_impl.cc:55-216) restated: the SISO carrier allocator"""
+
+    def __init__(self, fft_len, occupied_carriers, pilot_carriers, pilot_symbols, sync_words, ltf_len=0, len_tag_key="packet_len",
+                 output_is_shifted=True):
+        self.N = fft_len
+        self.occ = _norm_sets(occupied_carriers, fft_len, output_is_shifted)
+        self.pil = _norm_sets(pilot_carriers, fft_len, output_is_shifted)
+        self.psym = [np.asarray(p, np.complex64) for p in pilot_symbols]
+        self.sync = _c64(np.asarray(sync_words, np.complex64).reshape(-1, fft_len)) if len(sync_words) else np.zeros((0, fft_len), np.complex64)
+        for i in range(max(len(self.pil), len(self.psym))):
+            if len(self.pil[i % len(self.pil)]) != len(self.psym[i % len(self.psym)]):
+                raise ValueError("pilot_carriers do not match pilot_symbols")
+        self.sps = sum(len(o) for o in self.occ)
+
+    def calculate_output_stream_length(self, nin):
+        nout = (nin // self.sps) * len(self.occ)
+        i, k = 0, 0
+        while i < nin % self.sps:
+            nout += 1
+            i += len(self.occ[k % len(self.occ)])
+            k += 1
+        return nout + len(self.sync)
+
+    def work(self, x):
+        L = lib()
+        ip = C.POINTER(C.c_int)
+        L.orc_frame_generator.argtypes = [C.c_int, C.c_int, ip, ip, C.c_int, ip, ip, C.c_int, c_float_p, C.c_int, c_float_p, C.c_int,
+                                          c_float_p, c_float_p, C.c_int]
+        x = _c64(x).ravel()
+        nout = self.calculate_output_stream_length(x.size)
+        out = np.zeros((nout, self.N), np.complex64)
+        osz = np.array([len(o) for o in self.occ], np.int32)
+        ofl = np.array([c for o in self.occ for c in o], np.int32)
+        psz = np.array([len(o) for o in self.pil], np.int32)
+        pfl = np.array([c for o in self.pil for c in o] or [0], np.int32)
+        psf = _c64(np.concatenate(self.psym) if sum(p.size for p in self.psym) else np.zeros(1, np.complex64))
+        sw = _c64(self.sync if self.sync.size else np.zeros((1, self.N), np.complex64))
+        n = L.orc_frame_generator(self.N, len(self.occ), osz.ctypes.data_as(ip), ofl.ctypes.data_as(ip), len(self.pil), psz.ctypes.data_as(ip),
+                                  pfl.ctypes.data_as(ip), len(self.psym), _fp(psf), len(self.sync), _fp(sw), x.size, _fp(x), _fp(out), nout)
+        assert n == nout
+        return out

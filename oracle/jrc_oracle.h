@@ -188,6 +188,11 @@ int  orc_fs_work(orc_fs_state* s, int noutput, int ninput0, int ninput1, const f
                  const uint64_t* tin_off, const double* tin_val, int n_tin, float* out, int* consumed, uint64_t* tag_out_off,
                  double* tag_out_val, int* n_tag_out);
 
+/* ofdm_frame_generator_impl::work (lib/ofdm_frame_generator_impl.cc:155-216) */
+int orc_frame_generator(int fft_len, int n_occ_sets, const int* occ_sizes, const int* occ_flat, int n_pil_sets, const int* pil_sizes,
+                        const int* pil_flat, int n_psym_sets, const float* psym_flat, int n_sync, const float* sync_words, int n_in,
+                        const float* in, float* out, int noutput_items);
+
 #ifdef __cplusplus
 }
 #endif

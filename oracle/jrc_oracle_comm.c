@@ -524,3 +524,43 @@ int orc_precoder_work(const orc_pre_cfg* c, int ninput_items, const float* in_f,
     free(sig); free(dc); free(pc);
     return n_total;
 }
+
+
+/* ------------------------------------------------------------------------------------------
+ * ofdm_frame_generator_impl::work (lib/ofdm_frame_generator_impl.cc:155-216; the SISO carrier allocator): occupied / pilot
+ * carrier sets are flattened with their sizes; indices already normalised (negative + fft_len, shifted) as the constructor
+ * does (:83-113).  Returns the number of OFDM symbols written incl. sync words.
+ * ---------------------------------------------------------------------------------------- */
+int orc_frame_generator(int fft_len, int n_occ_sets, const int* occ_sizes, const int* occ_flat, int n_pil_sets, const int* pil_sizes,
+                        const int* pil_flat, int n_psym_sets, const float* psym_flat, int n_sync, const float* sync_words, int n_in,
+                        const float* in, float* out, int noutput_items)
+{
+    cf* o = (cf*)out;
+    memset(o, 0, sizeof(cf) * (size_t)fft_len * noutput_items);                         /* :165 */
+    for (int i = 0; i < n_sync; i++) memcpy(o + (size_t)i * fft_len, (const cf*)sync_words + (size_t)i * fft_len, sizeof(cf) * fft_len);
+    o += (size_t)n_sync * fft_len;
+    int* occ_off = (int*)malloc(sizeof(int) * (n_occ_sets + 1));
+    occ_off[0] = 0;
+    for (int k = 0; k < n_occ_sets; k++) occ_off[k + 1] = occ_off[k] + occ_sizes[k];
+    long n_ofdm = 0;
+    int curr_set = 0, to_alloc = occ_sizes[0], allocated = 0;
+    for (int i = 0; i < n_in; i++) {                                                    /* :175-200 */
+        if (allocated == 0) n_ofdm++;
+        o[(n_ofdm - 1) * fft_len + occ_flat[occ_off[curr_set] + allocated]] = ((const cf*)in)[i];
+        allocated++;
+        if (allocated == to_alloc) { curr_set = (curr_set + 1) % n_occ_sets; to_alloc = occ_sizes[curr_set]; allocated = 0; }
+    }
+    int* pil_off = (int*)malloc(sizeof(int) * (n_pil_sets + 1));
+    pil_off[0] = 0;
+    for (int k = 0; k < n_pil_sets; k++) pil_off[k + 1] = pil_off[k] + pil_sizes[k];
+    /* pilot symbol sets have the sizes of the pilot carrier sets they pair with (:119-125); offsets by cumulative size */
+    int* ps_off = (int*)malloc(sizeof(int) * (n_psym_sets + 1));
+    ps_off[0] = 0;
+    for (int k = 0; k < n_psym_sets; k++) ps_off[k + 1] = ps_off[k] + pil_sizes[k % n_pil_sets];
+    for (long i = 0; i < n_ofdm; i++) {                                                 /* :202-208 */
+        const int pk = (int)(i % n_pil_sets), sk = (int)(i % n_psym_sets);
+        for (int k = 0; k < pil_sizes[pk]; k++) o[i * fft_len + pil_flat[pil_off[pk] + k]] = ((const cf*)psym_flat)[ps_off[sk] + k];
+    }
+    free(occ_off); free(pil_off); free(ps_off);
+    return (int)n_ofdm + n_sync;
+}

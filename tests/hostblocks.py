@@ -22,7 +22,7 @@ def lib():
         L.jrcb_last_error.restype = C.c_char_p
         for name in ("jrcb_make_radar", "jrcb_make_transpose", "jrcb_make_estimator", "jrcb_make_cp_remover",
                      "jrcb_make_peak_detect", "jrcb_make_equalizer", "jrcb_make_precoder", "jrcb_make_target_simulator", "jrcb_make_stream_encoder", "jrcb_make_stream_decoder",
-                     "jrcb_make_moving_avg", "jrcb_make_frame_detector", "jrcb_make_frame_sync", "jrcb_make_zero_pad"):
+                     "jrcb_make_moving_avg", "jrcb_make_frame_detector", "jrcb_make_frame_sync", "jrcb_make_zero_pad", "jrcb_make_frame_generator"):
             getattr(L, name).restype = _vp
         L.jrcb_make_radar.argtypes = [C.c_int] * 10
         L.jrcb_make_transpose.argtypes = [C.c_int] * 3
@@ -37,6 +37,7 @@ def lib():
         L.jrcb_make_stream_encoder.argtypes = [C.c_int, C.c_int]
         L.jrcb_make_moving_avg.argtypes = [C.c_int, C.c_float, C.c_int]
         L.jrcb_make_zero_pad.argtypes = [C.c_uint, C.c_uint]
+        L.jrcb_make_frame_generator.argtypes = [C.c_int, C.c_int, _ip, _ip, C.c_int, _ip, _ip, C.c_int, _ip, _fp, C.c_int, _fp, C.c_int]
         L.jrcb_make_frame_detector.argtypes = [C.c_int, C.c_int, C.c_double, C.c_uint, C.c_uint]
         L.jrcb_make_frame_sync.argtypes = [C.c_int, C.c_int, C.c_uint, _fp, C.c_int]
         L.jrcb_make_stream_decoder.argtypes = [C.c_int, C.c_char_p, C.c_int]
@@ -144,6 +145,20 @@ def target_simulator(range_m, velocity, rcs, azimuth, position_rx, samp_rate, ce
         raise ValueError("length mismatch")
     return Block(lib().jrcb_make_target_simulator(_f(r), _f(v), _f(s), _f(a), r.size, _f(p), p.size, int(samp_rate),
                                                   float(center_freq), float(self_coupling_db), int(rndm_phaseshift), int(self_coupling)))
+
+
+def frame_generator(fft_len, occupied_carriers, pilot_carriers, pilot_symbols, sync_words, shifted=True):
+    def flat(sets, dt):
+        sz = np.array([len(x) for x in sets], np.int32)
+        fl = np.ascontiguousarray(np.concatenate([np.asarray(x, dt).ravel() for x in sets] + [np.zeros(1, dt)]), dt)
+        return sz, fl
+    osz, ofl = flat(occupied_carriers, np.int32)
+    psz, pfl = flat(pilot_carriers, np.int32)
+    ssz, sfl = flat(pilot_symbols, np.complex64)
+    sw = np.ascontiguousarray(np.concatenate([np.asarray(sync_words, np.complex64).ravel(), np.zeros(1, np.complex64)]))
+    return Block(lib().jrcb_make_frame_generator(fft_len, len(osz), osz.ctypes.data_as(_ip), ofl.ctypes.data_as(_ip), len(psz), psz.ctypes.data_as(_ip),
+                                                 pfl.ctypes.data_as(_ip), len(ssz), ssz.ctypes.data_as(_ip), sfl.view(np.float32).ctypes.data_as(_fp),
+                                                 len(sync_words), sw.view(np.float32).ctypes.data_as(_fp), int(shifted)))
 
 
 def zero_pad(pad_front, pad_tail):
