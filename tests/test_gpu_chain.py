@@ -177,3 +177,27 @@ def test_range_doppler_map_row_d(jrc, ctx, T, R, N, S, Ir, Id, vel):
         bin_d = 2 * vel * sc.fc / 3e8 * (N + sc.cp) / sc.fs * S * Id    # Doppler shift in (interpolated) Doppler bins
         assert abs((d - S * Id // 2) - bin_d) <= 1.5 and abs(bin_d) > 4
         assert abs(rb[k] - 10.0) < 0.7
+
+
+def _random_shapes(n, seed=2024):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        T, R = int(rng.integers(1, 5)), int(rng.integers(1, 5))
+        N = int(rng.choice([32, 48, 64, 96, 128, 256, 512]))
+        S = int(rng.integers(1, 9))
+        Ir, Ia = int(rng.choice([1, 2, 4, 8])), int(rng.choice([1, 2, 3, 4, 8, 16]))
+        NR, NA = N * Ir, T * R * Ia
+        ok = lambda v: v <= 16384 if (v & (v - 1)) == 0 else v <= 4096
+        if ok(NR) and ok(NA) and NR * NA <= 1 << 20:
+            out.append((T, R, N, S, Ir, Ia, bool(rng.integers(0, 2))))
+    return out
+
+
+@pytest.mark.parametrize("T,R,N,S,Ir,Ia,interleave", _random_shapes(24))
+def test_chain_random_shapes(jrc, ctx, T, R, N, S, Ir, Ia, interleave):
+    """a seeded sweep over antenna counts, fft lengths (incl. 48 / 96), symbol counts and interpolation factors: fused kernel,
+    block-by-block path and chirp-z transforms all against the oracle"""
+    from jrc_amd import synth
+    sc = synth.Scenario(N, T, R, S, targets=[(6.0 + N / 40.0, -20.0 + 7.0 * T, 3.0, 60.0)])
+    check(jrc, ctx, sc, Ir, Ia, 2, interleave=interleave)
