@@ -12,7 +12,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
 def main():
@@ -24,15 +24,16 @@ def main():
     a = ap.parse_args()
     import torch
     import jrc_amd
-    from test_oracle_sync import CP, N, make_stream
-    o = np.load(os.path.join(ROOT, "tests", "golden", "ofdm_config_64.npz"))
+    from _streams import CP, N, BurstMaker, ofdm_config
+    o = ofdm_config()
     rng = np.random.default_rng(0)
     mcs, ndc = 2, 48
+    ctx = jrc_amd.Context(0)
+    bm = BurstMaker(ctx, mcs)
     parts, payloads = [], []
     for k in range(8):
         payload = bytes([2]) + rng.integers(0, 256, a.bytes - 1, dtype=np.uint8).tobytes()
-        x, tags, flen = make_stream(o, payload, mcs, rng, lead=500 + 13 * k, tail=1500, cfo=0.01)
-        parts.append(x)
+        parts.append(bm.burst(payload, rng, lead=500 + 13 * k, tail=1500, cfo=0.01))
         payloads.append(payload)
     reps = (a.frames + 7) // 8
     F = reps * 8
@@ -40,7 +41,6 @@ def main():
     n = x.size
     ns = jrc_amd.n_ofdm_sym(mcs, ndc, a.bytes + 4)
     S = 2 + 1 + 4 + ns                                   # LTF x2, SIG, MIMO-LTFs, data
-    ctx = jrc_amd.Context(0)
     L = ctx.lib
     fe = jrc_amd.SyncFrontEnd(N, CP, 0.6, 10, 8 * (N + CP), 4 * (N + CP), o["l_ltf_fir"], max_frames=F, max_symbols=S, ctx=ctx)
     eq = jrc_amd.mimo_ofdm_equalizer(0, 24e9, 125e6, N, CP, o["data_subcarriers"], o["pilot_subcarriers"], o["pilot_symbols"], o["ltf_64"],

@@ -10,7 +10,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
 def main():
@@ -20,20 +20,19 @@ def main():
     a = ap.parse_args()
     import torch
     import jrc_amd
-    import oracle
-    from test_oracle_sync import CP, N, make_stream
-    o = np.load(os.path.join(ROOT, "tests", "golden", "ofdm_config_64.npz"))
+    from _streams import CP, N, BurstMaker, ofdm_config
+    o = ofdm_config()
     rng = np.random.default_rng(0)
+    ctx = jrc_amd.Context(0)
+    bm = BurstMaker(ctx)
     parts = []
     for k in range(8):                                   # eight distinct bursts, tiled
         payload = bytes([2]) + rng.integers(0, 256, 199, dtype=np.uint8).tobytes()
-        x, tags, flen = make_stream(o, payload, 2, rng, lead=500 + 13 * k, tail=1500, cfo=0.01)
-        parts.append(x)
+        parts.append(bm.burst(payload, rng, lead=500 + 13 * k, tail=1500, cfo=0.01))
     unit = np.concatenate(parts)
     reps = (a.frames + 7) // 8
     x = np.tile(unit, reps)
     n = x.size
-    ctx = jrc_amd.Context(0)
     fe = jrc_amd.SyncFrontEnd(N, CP, 0.6, 10, 8 * (N + CP), 4 * (N + CP), o["l_ltf_fir"], max_frames=reps * 8 + 8, max_symbols=64, ctx=ctx)
     d_x = torch.from_numpy(x.view(np.float32).reshape(-1, 2).copy()).cuda()
     fe.run(d_x, n)
