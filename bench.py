@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--distinct", type=int, default=32, help="distinct synthetic frames generated per GPU (tiled to --frames)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prewarm-seconds", type=float, default=0.3,
+                    help="untimed runs before the W warm-up steps so a cold GPU has its clocks up (0 = none)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests of the N>1 path)")
     ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses GPU 0")
     ap.add_argument("--gather-results", action="store_true",
@@ -161,6 +163,11 @@ def main():
             ctx.sync()
             gathered[0] = shard.gather_maps(bufs["map"][:k_maps], world * k_maps)
 
+    if a.prewarm_seconds > 0:                 # untimed: bring a freshly booted GPU out of its idle power state
+        t_pw = time.perf_counter()
+        while time.perf_counter() - t_pw < a.prewarm_seconds:
+            chain.run(bufs, F)
+            ctx.sync()
     for _ in range(a.warmup):
         step()
     ctx.sync()

@@ -165,6 +165,7 @@ def equalizer_config_c(n_frames=2048, lanes=4):
 
 
 if __name__ == "__main__":
-    for fn in (lambda: radar_with_demod("B", 256), lambda: radar_with_demod("D", 64), lambda: simulated_chain("B", 64),
-               lambda: simulated_chain("D", 8), equalizer_config_c, sync_front_end, comm_rx_chain):
+    # the two probes that run as child processes go first: once this process holds a GPU context they would time-slice with it
+    for fn in (sync_front_end, comm_rx_chain, lambda: radar_with_demod("B", 256), lambda: radar_with_demod("D", 64),
+               lambda: simulated_chain("B", 64), lambda: simulated_chain("D", 8), equalizer_config_c):
         print(json.dumps(fn()))

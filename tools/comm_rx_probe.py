@@ -67,7 +67,8 @@ def main():
             dec.decode_dev(out, ns * ndc, d_mcs, d_nb, d_pl, a.bytes, d_st, F, stream=sh)
         return n_out
 
-    step()
+    for _ in range(10):
+        step()
     ts.synchronize(); ctx.sync(); torch.cuda.synchronize()
     nf, info = fe.results()
     ok = int((d_st == 1).sum().item())
