@@ -650,8 +650,6 @@ extern "C" int jrc_equalizer_work(jrc_equalizer* eq, int stream, int noutput_ite
     io.chan_est = (float2*)((unsigned char*)ctx->scratch[2] + b_ev);
     io.stream0 = stream;
     launch_equalizer(eq, 1, ctx->stream, io);
-    if (0) hipLaunchKernelGGL((equalizer_kernel<1024, 4>), dim3(1), dim3(eq->threads), eq->lds_bytes, ctx->stream, eq->d, eq->states, eq->H,
-                       eq->Hm, eq->pre, io);
     JRC_HIP(ctx, hipGetLastError());
     unsigned char* h_out = hp + b_in + b_tag;
     int* h_cnt = (int*)(h_out + b_out + b_ev + b_ce);
@@ -687,8 +685,6 @@ extern "C" int jrc_equalizer_frames_dev(jrc_equalizer* eq, int n_streams, int n_
     io.n_out = d_n_out; io.n_consumed = eq->counters; io.n_events = eq->counters + eq->n_streams;
     io.chan_est_written = nullptr; io.events = d_events; io.max_events = 2; io.chan_est = nullptr; io.stream0 = 0;
     launch_equalizer(eq, n_streams, s, io);
-    if (0) hipLaunchKernelGGL((equalizer_kernel<1024, 4>), dim3(n_streams), dim3(eq->threads), eq->lds_bytes, s, eq->d, eq->states, eq->H,
-                       eq->Hm, eq->pre, io);
     JRC_HIP(ctx, hipGetLastError());
     return JRC_OK;
 }
