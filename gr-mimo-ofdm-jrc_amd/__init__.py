@@ -529,6 +529,15 @@ def n_ofdm_sym(mcs, n_data_carriers, nbytes):
     return _load_comm().jrc_n_ofdm_sym(mcs, n_data_carriers, nbytes)
 
 
+def sig_encode(n_data_carriers, mcs, packet_type, length):
+    """generate_signal_field (lib/mimo_precoder_impl.cc:985-1060): the BPSK SIG symbol on the data carriers (real parts)"""
+    out = np.zeros(n_data_carriers, np.float32)
+    st = _load_comm().jrc_sig_encode(n_data_carriers, mcs, packet_type, length, out.ctypes.data_as(_cfp))
+    if st < 0:
+        raise JrcError(st, "jrc_sig_encode")
+    return out
+
+
 def _event_dict(e):
     d = dict(kind=e.kind, offset=e.offset)
     if e.kind == 1:
