@@ -1,4 +1,4 @@
-// jrc_blocks.cc — work()/general_work() bodies of the seven hot-path blocks over the C ABI (include/jrc.h).
+// jrc_blocks.cc — work()/general_work() bodies of the reference blocks (the seven hot-path blocks of SURVEY 8a, then the 8(f) blocks) over the C ABI (include/jrc.h).
 // Tag, message and file handling is host code that follows the reference line by line (citations are to
 // /root/reference/lib); all sample arithmetic happens in the HIP kernels behind the jrc_* calls.
 #include "jrc_blocks.h"
