@@ -6,7 +6,7 @@
 #include <vector>
 #define RA_L 64
 
-template <int P, int NT, int WPS>
+template <int P, int NT, int WPS, int VAR>
 __global__ __launch_bounds__(NT, WPS) void k2_kernel(const float2* __restrict__ Rc /* [F][C][P][64] */, float2* __restrict__ map,
                                                      PeakPartial* __restrict__ partials, const float2* __restrict__ twA, int NR, int Ia, int F, int WPF)
 {
@@ -49,18 +49,18 @@ __global__ __launch_bounds__(NT, WPS) void k2_kernel(const float2* __restrict__ 
             float2 y[P];
             y[0] = g[ql];
 #pragma unroll
-            for (int p = 1; p < P; p++) y[p] = cmul(g[p * RA_L + ql], ta[p]);
-            fft_fwd_small<P>(y);
+            for (int p = 1; p < P; p++) y[p] = (VAR >= 2) ? g[p * RA_L + ql] : cmul(g[p * RA_L + ql], ta[p]);
+            if (VAR < 3) fft_fwd_small<P>(y);
             float2* row = mapf + (size_t)k * NA;
             float m = -1.0f;
 #pragma unroll
             for (int u = 0; u < P; u++) {
                 const int a = (Ia * u + r + ahalf) & amask;
                 row[a] = y[u];
-                m = fmaxf(m, fast_power(y[u]));
+                if (VAR == 0) m = fmaxf(m, fast_power(y[u]));
             }
-            const float thr = trk.raise(m);
-            if (m >= thr) {
+            const float thr = (VAR == 0) ? trk.raise(m) : 1e30f;
+            if (VAR == 0 && m >= thr) {
                 const unsigned flat0 = (unsigned)k * (unsigned)NA;
 #pragma unroll
                 for (int u = 0; u < P; u++)
@@ -76,15 +76,15 @@ __global__ __launch_bounds__(NT, WPS) void k2_kernel(const float2* __restrict__ 
 }
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
-template <int NT, int WPS>
+template <int NT, int WPS, int VAR>
 static int run(const char* name, int F, int NR, int Ia, int WPF, const float2* Rc, float2* map, PeakPartial* part, const float2* twA)
 {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int groups = (F + 7) / 8;
     dim3 grid(groups * 8 * WPF);
-    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((k2_kernel<16, NT, WPS>), grid, dim3(NT), 0, 0, Rc, map, part, twA, NR, Ia, F, WPF);
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((k2_kernel<16, NT, WPS, VAR>), grid, dim3(NT), 0, 0, Rc, map, part, twA, NR, Ia, F, WPF);
     hipEventRecord(e0);
-    for (int i = 0; i < 10; i++) hipLaunchKernelGGL((k2_kernel<16, NT, WPS>), grid, dim3(NT), 0, 0, Rc, map, part, twA, NR, Ia, F, WPF);
+    for (int i = 0; i < 10; i++) hipLaunchKernelGGL((k2_kernel<16, NT, WPS, VAR>), grid, dim3(NT), 0, 0, Rc, map, part, twA, NR, Ia, F, WPF);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10;
     const double bytes = (double)F * NR * 16 * Ia * 8;
@@ -108,11 +108,11 @@ int main()
         for (int i = 0; i < NA; i++) { tw[i].x = cosf(-2 * 3.14159265f * i / NA); tw[i].y = sinf(-2 * 3.14159265f * i / NA); }
         CK(hipMemcpy(twA, tw.data(), NA * 8, hipMemcpyHostToDevice));
         printf("---- %s\n", cfg ? "config D shape" : "config B shape");
-        for (int wpf : {1, 2, 4, 8, 16}) {
-            if (wpf > C) continue;
-            run<256, 2>("NT=256 wps=2", F, NR, Ia, wpf, Rc, map, part, twA);
-            run<256, 3>("NT=256 wps=3", F, NR, Ia, wpf, Rc, map, part, twA);
-        }
+        const int wpf = cfg ? 4 : 16;
+        run<256, 2, 0>("full", F, NR, Ia, wpf, Rc, map, part, twA);
+        run<256, 2, 1>("no arg-max", F, NR, Ia, wpf, Rc, map, part, twA);
+        run<256, 2, 2>("no arg-max, no twiddle", F, NR, Ia, wpf, Rc, map, part, twA);
+        run<256, 2, 3>("no arg-max, no twiddle, no FFT", F, NR, Ia, wpf, Rc, map, part, twA);
         hipFree(Rc); hipFree(map); hipFree(twA); hipFree(part);
     }
     return 0;

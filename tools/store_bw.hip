@@ -1,6 +1,7 @@
 // store_bw.hip — micro-benchmark of map-store patterns on MI355X (tools only; not part of the product)
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ inline void nt_store(float4 v, float4* p) { v4f w = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(w, (v4f*)p); }
@@ -70,7 +71,7 @@ __global__ void k_rows_contig(float4* out, int C, int F) {
 }
 
 int main() {
-    const int F = 256, C = 32;                          // config B: 256 frames x 2048 rows x 2 KB = 1 GiB
+    const int F = getenv("SB_F") ? atoi(getenv("SB_F")) : 256, C = 32;   // config B: 256 frames x 2048 rows x 2 KB = 1 GiB
     const size_t bytes = (size_t)F * C * 64 * 2048;
     float4* d; CK(hipMalloc(&d, bytes));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
