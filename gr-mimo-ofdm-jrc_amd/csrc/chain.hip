@@ -47,7 +47,8 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
     PeakPartial* __restrict__ partials,  // [F][WPF]
     const float2* __restrict__ twR,      // [NR]  exp(+j 2 pi i / NR)
     const float2* __restrict__ twA,      // [NA]  exp(-j 2 pi i / NA)
-    int N, int NR, int Ia, int F, int WPF)
+    int N, int NR, int Ia, int F, int WPF,
+    int nt_tail)                         // the last nt_tail classes of a workgroup are stored non-temporally (see chain_nt_tail)
 {
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     constexpr int NW = NT / 64;
@@ -106,8 +107,11 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
     const int ahalf = NA >> 1, amask = NA - 1;
     float2* mapf = map + (size_t)f * NR * NA;
 
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const int c_nt = C - nt_tail * WPF;         // classes c >= c_nt are among the last nt_tail of this workgroup
 #pragma unroll 1
     for (int c = slice; c < C; c += WPF) {
+        const bool nt = c >= c_nt;
         if constexpr (TWC_LDS) {
 #pragma unroll
             for (int q = 0; q < NPT; q++) { const int n = tid + NT * q; if (n < N) s_twc[n] = tn[q]; }
@@ -167,7 +171,8 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
 #pragma unroll
             for (int u = 0; u < P; u++) {
                 const int a = (Ia * u + r + ahalf) & amask;   // fftshift: out'[a'] = out[(a' + NA/2) % NA]
-                row[a] = y[u];
+                if (nt) { v2f t = {y[u].x, y[u].y}; __builtin_nontemporal_store(t, reinterpret_cast<v2f*>(row + a)); }
+                else row[a] = y[u];
                 m = fmaxf(m, fast_power(y[u]));
             }
             // estimator arg-max (lib/range_angle_estimator_impl.cc:137-151) on the values still in registers
@@ -229,6 +234,25 @@ static int chain_pick_wpf(const jrc_chain* ch, int n_frames)
     return wpf;
 }
 
+// Map stores that go through the cache hierarchy leave dirty lines behind (L2 / 256 MiB memory-side cache); they are written back
+// while the next kernel — the read-bound channel estimate of the next batch — runs, and the mixed traffic costs that kernel 40 %
+// of its bandwidth (0.168 ms instead of 0.104 ms at config B).  The map is write-once data nobody on the GPU reads before the
+// estimator's few cells, so it is stored non-temporally: the fused kernel itself runs as fast or faster (config D: 0.443 ->
+// 0.413 ms) and the step gains 11-14 %.  Only the tail of a workgroup's classes non-temporal does not help (measured 12-50 %).
+// JRC_NT_FRAC overrides the fraction of classes stored non-temporally (0..1) for experiments.
+static int chain_nt_tail(const jrc_chain* ch, int n_frames, int wpf)
+{
+    const int per_wg = (ch->C + wpf - 1) / wpf;
+    double frac;
+    if (getenv("JRC_NT_FRAC")) frac = atof(getenv("JRC_NT_FRAC"));
+    else frac = 1.0;
+    (void)n_frames;
+    if (frac < 0) frac = 0;
+    if (frac > 1) frac = 1;
+    int k = (int)(frac * per_wg + 0.999);
+    return k > per_wg ? per_wg : k;
+}
+
 template <int P, int NT, int MMAX, bool TWC_LDS>
 static int launch_fused_nt(jrc_chain* ch, int n_frames, int wpf, const float2* d_H, float2* d_map, hipStream_t s)
 {
@@ -241,7 +265,7 @@ static int launch_fused_nt(jrc_chain* ch, int n_frames, int wpf, const float2* d
         attr_bytes = ch->lds_bytes;
     }
     hipLaunchKernelGGL((range_angle_fused_kernel<P, NT, MMAX, TWC_LDS>), grid, dim3(NT), ch->lds_bytes, s, d_H, d_map,
-                       ch->d_partials, ch->twR, ch->twA, ch->cfg.fft_len, ch->NR, ch->cfg.interp_angle, n_frames, wpf);
+                       ch->d_partials, ch->twR, ch->twA, ch->cfg.fft_len, ch->NR, ch->cfg.interp_angle, n_frames, wpf, chain_nt_tail(ch, n_frames, wpf));
     JRC_HIP(ch->ctx, hipGetLastError());
     return JRC_OK;
 }
