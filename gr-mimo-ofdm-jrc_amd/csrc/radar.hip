@@ -100,7 +100,11 @@ __global__ __launch_bounds__(256) void radar_chanest_x2_kernel(const float2* __r
         float4 rx[U], tx[U][T];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            rx[u] = rxp[(size_t)(sym + u) * row4];
+            {   // each RX symbol is read exactly once: non-temporal, so it does not push the TX rows (read by every receiver) out of cache
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(rxp + (size_t)(sym + u) * row4));
+                rx[u] = make_float4(t.x, t.y, t.z, t.w);
+            }
 #pragma unroll
             for (int t = 0; t < T; t++)
                 tx[u][t] = *reinterpret_cast<const float4*>(txb + (size_t)t * g.port_stride + (size_t)(sym + u) * g.N);
