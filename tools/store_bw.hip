@@ -43,6 +43,19 @@ __global__ void k_pattern_x2(float2* out, int C, int F) {
         for (int u = 0; u < 16; u++) row[(16 * u + r + 128) & 255] = make_float2(u, w);
     }
 }
+// (b3) (b2) with non-temporal 8-byte stores (what the fused kernel does since the map became write-around)
+typedef float v2f __attribute__((ext_vector_type(2)));
+__global__ void k_pattern_x2_nt(float2* out, int C, int F) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, f = (j / C) * 8 + xcd, c = j % C;
+    if (f >= F) return;
+    float2* mapf = out + (size_t)f * C * 64 * 256;
+    for (int w = threadIdx.x; w < 1024; w += 256) {
+        int r = w & 15, ql = w >> 4, k = C * ql + c;
+        float2* row = mapf + (size_t)k * 256;
+#pragma unroll
+        for (int u = 0; u < 16; u++) { v2f t = {(float)u, (float)w}; __builtin_nontemporal_store(t, (v2f*)(row + ((16 * u + r + 128) & 255))); }
+    }
+}
 // (d) row-contiguous: each wave writes 1 KB contiguous per instruction; WG writes its 64 rows, 2 instr per row
 template <int NT>
 __global__ void k_rows(float4* out, int C, int F) {
@@ -90,6 +103,7 @@ int main() {
     run("linear grid=65536", [&] { hipLaunchKernelGGL(k_linear, dim3(65536), dim3(256), 0, 0, d, bytes / 16); });
     run("pattern 128B segs", [&] { hipLaunchKernelGGL(k_pattern<0>, dim3(grid), dim3(256), 0, 0, d, C, F); });
     run("pattern 128B segs dwordx2", [&] { hipLaunchKernelGGL(k_pattern_x2, dim3(grid), dim3(256), 0, 0, (float2*)d, C, F); });
+    run("pattern 128B segs dwordx2 nt", [&] { hipLaunchKernelGGL(k_pattern_x2_nt, dim3(grid), dim3(256), 0, 0, (float2*)d, C, F); });
     run("pattern 128B segs nt", [&] { hipLaunchKernelGGL(k_pattern<1>, dim3(grid), dim3(256), 0, 0, d, C, F); });
     run("rows 1KB/instr strided", [&] { hipLaunchKernelGGL(k_rows<0>, dim3(grid), dim3(256), 0, 0, d, C, F); });
     run("rows 1KB/instr strided nt", [&] { hipLaunchKernelGGL(k_rows<1>, dim3(grid), dim3(256), 0, 0, d, C, F); });
