@@ -110,7 +110,7 @@ def main():
     sc = scenario(a.config)
     Ir, Ia = 8, 16
     P, NR, NA = sc.T * sc.R, sc.N * Ir, sc.T * sc.R * Ia
-    F = a.frames or {"A": 4096, "B": 512, "D": 128}[a.config]
+    F = a.frames or {"A": 4096, "B": 512, "D": 256}[a.config]
     rb, ab = jrc_amd.radar_axes(sc.N, sc.fs, Ir, P, Ia)
     ndr = 2 * 3e8 / (2 * sc.fs)
     nda = 2 * float(np.rad2deg(np.arcsin(2 / P))) if P > 2 else 30.0
