@@ -48,7 +48,8 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
     const float2* __restrict__ twR,      // [NR]  exp(+j 2 pi i / NR)
     const float2* __restrict__ twA,      // [NA]  exp(-j 2 pi i / NA)
     int N, int NR, int Ia, int F, int WPF,
-    int nt_tail)                         // the last nt_tail classes of a workgroup are stored non-temporally (see chain_nt_tail)
+    int nt_tail,                         // the last nt_tail classes of a workgroup are stored non-temporally (see chain_nt_tail)
+    int pstride)                         // partial maxima per frame in `partials` (>= WPF; unused slots hold the neutral element)
 {
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     constexpr int NW = NT / 64;
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
     }
     __syncthreads();
     block_reduce_peak(trk, reinterpret_cast<PeakPartial*>(s_g));
-    if (tid == 0) { partials[(size_t)f * WPF + slice].best = trk.best; partials[(size_t)f * WPF + slice].idx = trk.idx; }
+    if (tid == 0) { partials[(size_t)f * pstride + slice].best = trk.best; partials[(size_t)f * pstride + slice].idx = trk.idx; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -254,32 +255,44 @@ static int chain_nt_tail(const jrc_chain* ch, int n_frames, int wpf)
 }
 
 template <int P, int NT, int MMAX, bool TWC_LDS>
-static int launch_fused_nt(jrc_chain* ch, int n_frames, int wpf, const float2* d_H, float2* d_map, hipStream_t s)
+static int launch_fused_nt(jrc_chain* ch, int n_frames, int wpf, int pstride, const float2* d_H, float2* d_map, hipStream_t s)
 {
-    const int groups = (n_frames + 7) / 8;
-    dim3 grid((unsigned)(groups * 8 * wpf));
     static size_t attr_bytes = 64 * 1024;   // dynamic LDS above 64 KiB must be opted into per kernel
     if (ch->lds_bytes > attr_bytes) {
         JRC_HIP(ch->ctx, hipFuncSetAttribute((const void*)range_angle_fused_kernel<P, NT, MMAX, TWC_LDS>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ch->lds_bytes));
         attr_bytes = ch->lds_bytes;
     }
-    hipLaunchKernelGGL((range_angle_fused_kernel<P, NT, MMAX, TWC_LDS>), grid, dim3(NT), ch->lds_bytes, s, d_H, d_map,
-                       ch->d_partials, ch->twR, ch->twA, ch->cfg.fft_len, ch->NR, ch->cfg.interp_angle, n_frames, wpf, chain_nt_tail(ch, n_frames, wpf));
+    // One resident wave of workgroups per launch: a batch that needs more is launched in chunks of that size, and a last,
+    // smaller chunk gets more slices per frame so that it fills the machine as well (a grid twice the resident size runs 20 %
+    // slower than two launches because its second wave of workgroups starts ragged).  `pstride` partial maxima per frame.
+    const int resident = ch->n_cus * ch->wg_per_cu;
+    int chunk = resident / wpf;
+    if (chunk < 8) chunk = 8;
+    chunk &= ~7;                                // keep the XCD decode (8 frames per group) aligned
+    for (int f0 = 0; f0 < n_frames; f0 += chunk) {
+        const int nf = n_frames - f0 < chunk ? n_frames - f0 : chunk;
+        int w = chain_pick_wpf(ch, nf);
+        if (w > pstride) w = pstride;
+        const dim3 grid((unsigned)(((nf + 7) / 8) * 8 * w));
+        hipLaunchKernelGGL((range_angle_fused_kernel<P, NT, MMAX, TWC_LDS>), grid, dim3(NT), ch->lds_bytes, s,
+                           d_H + (size_t)f0 * P * ch->cfg.fft_len, d_map + (size_t)f0 * ch->NR * ch->NA, ch->d_partials + (size_t)f0 * pstride,
+                           ch->twR, ch->twA, ch->cfg.fft_len, ch->NR, ch->cfg.interp_angle, nf, w, chain_nt_tail(ch, nf, w), pstride);
+    }
     JRC_HIP(ch->ctx, hipGetLastError());
     return JRC_OK;
 }
 
 template <int P>
-static int launch_fused(jrc_chain* ch, int n_frames, int wpf, const float2* d_H, float2* d_map, hipStream_t s)
+static int launch_fused(jrc_chain* ch, int n_frames, int wpf, int pstride, const float2* d_H, float2* d_map, hipStream_t s)
 {
     // small frames: 256-thread workgroups, up to three per CU; large frames (H fills most of the LDS): one
     // 512-thread workgroup per CU
-    if (ch->threads == 1024) return launch_fused_nt<P, 1024, 16, true>(ch, n_frames, wpf, d_H, d_map, s);
-    if (ch->threads == 512 && ch->cfg.fft_len <= 256) return launch_fused_nt<P, 512, 4, false>(ch, n_frames, wpf, d_H, d_map, s);
-    if (ch->threads == 512) return launch_fused_nt<P, 512, 16, true>(ch, n_frames, wpf, d_H, d_map, s);
-    if (ch->cfg.fft_len > 256) return launch_fused_nt<P, 256, 16, true>(ch, n_frames, wpf, d_H, d_map, s);
-    return launch_fused_nt<P, 256, 4, false>(ch, n_frames, wpf, d_H, d_map, s);
+    if (ch->threads == 1024) return launch_fused_nt<P, 1024, 16, true>(ch, n_frames, wpf, pstride, d_H, d_map, s);
+    if (ch->threads == 512 && ch->cfg.fft_len <= 256) return launch_fused_nt<P, 512, 4, false>(ch, n_frames, wpf, pstride, d_H, d_map, s);
+    if (ch->threads == 512) return launch_fused_nt<P, 512, 16, true>(ch, n_frames, wpf, pstride, d_H, d_map, s);
+    if (ch->cfg.fft_len > 256) return launch_fused_nt<P, 256, 16, true>(ch, n_frames, wpf, pstride, d_H, d_map, s);
+    return launch_fused_nt<P, 256, 4, false>(ch, n_frames, wpf, pstride, d_H, d_map, s);
 }
 
 extern "C" int jrc_chain_create(jrc_ctx* ctx, const jrc_chain_cfg* cfg, const float* range_bins,
@@ -445,18 +458,25 @@ extern "C" int jrc_chain_run_dev(jrc_chain* ch, int n_frames, const jrc_cf32* d_
                                       ch->d_partials + (size_t)f * ch->gen_blocks, ch->gen_blocks, s));
         partials_per_frame = ch->gen_blocks;
     } else {
-        const int wpf = chain_pick_wpf(ch, n_frames);
+        // slices per frame of a full chunk, and of the last (smaller) chunk, which is the most any frame of this batch gets
+        const int resident = ch->n_cus * ch->wg_per_cu;
+        const int wpf = chain_pick_wpf(ch, n_frames < resident ? n_frames : resident);
+        int chunk = resident / wpf; if (chunk < 8) chunk = 8; chunk &= ~7;
+        const int tail = n_frames % chunk;
+        const int pstride = tail ? chain_pick_wpf(ch, tail) : wpf;
+        if (pstride != wpf)      // frames of full chunks leave slots unused: all-ones = NaN power, never wins a merge
+            JRC_HIP(ctx, hipMemsetAsync(ch->d_partials, 0xFF, sizeof(PeakPartial) * (size_t)n_frames * pstride, s));
         int st;
         switch (ch->P) {
-            case 1: st = launch_fused<1>(ch, n_frames, wpf, (const float2*)d_chanest, (float2*)d_map, s); break;
-            case 2: st = launch_fused<2>(ch, n_frames, wpf, (const float2*)d_chanest, (float2*)d_map, s); break;
-            case 4: st = launch_fused<4>(ch, n_frames, wpf, (const float2*)d_chanest, (float2*)d_map, s); break;
-            case 8: st = launch_fused<8>(ch, n_frames, wpf, (const float2*)d_chanest, (float2*)d_map, s); break;
-            default: st = launch_fused<16>(ch, n_frames, wpf, (const float2*)d_chanest, (float2*)d_map, s); break;
+            case 1: st = launch_fused<1>(ch, n_frames, wpf, pstride, (const float2*)d_chanest, (float2*)d_map, s); break;
+            case 2: st = launch_fused<2>(ch, n_frames, wpf, pstride, (const float2*)d_chanest, (float2*)d_map, s); break;
+            case 4: st = launch_fused<4>(ch, n_frames, wpf, pstride, (const float2*)d_chanest, (float2*)d_map, s); break;
+            case 8: st = launch_fused<8>(ch, n_frames, wpf, pstride, (const float2*)d_chanest, (float2*)d_map, s); break;
+            default: st = launch_fused<16>(ch, n_frames, wpf, pstride, (const float2*)d_chanest, (float2*)d_map, s); break;
         }
         JRC_TRY(st);
         if (ev) JRC_HIP(ctx, hipEventRecord(ev[2], s));
-        partials_per_frame = wpf;
+        partials_per_frame = pstride;
     }
     // rest of A5
     RaParams prm;

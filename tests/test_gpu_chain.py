@@ -201,3 +201,20 @@ def test_chain_random_shapes(jrc, ctx, T, R, N, S, Ir, Ia, interleave):
     from jrc_amd import synth
     sc = synth.Scenario(N, T, R, S, targets=[(6.0 + N / 40.0, -20.0 + 7.0 * T, 3.0, 60.0)])
     check(jrc, ctx, sc, Ir, Ia, 2, interleave=interleave)
+
+
+def test_chain_batches_larger_than_one_resident_wave(jrc, ctx):
+    """a batch that does not fit one resident wave of workgroups is launched in chunks, the last, smaller chunk with more slices per
+    frame (partial-maximum slots of the other frames stay neutral): every frame's map and result equal those of the frame run alone"""
+    from jrc_amd import synth
+    sc = synth.Scenario(64, 2, 2, 4, targets=[(9.0, 15.0, 0.0, 80.0)])
+    F = 700                                                 # 512 resident workgroups on a 256-CU part: 512 + 188
+    base = synth.make_frames(sc, 8)
+    frames = np.concatenate([base] * (F // 8 + 1))[:F].copy()
+    frames[:, sc.T:] *= (1.0 + 0.001 * np.arange(F, dtype=np.float32))[:, None, None, None]    # every frame a little different
+    _, gH, gmap, res, _ = run_chain(jrc, ctx, sc, 8, 16, F, frames=frames)
+    for f in (0, 7, 511, 512, 513, 699):
+        _, _, m1, r1, _ = run_chain(jrc, ctx, sc, 8, 16, 1, frames=frames[f:f + 1])
+        assert np.array_equal(gmap[f], m1[0])
+        for k in ("peak_range_idx", "peak_angle_idx", "angle_null_idx", "n_noise_samples", "peak_power", "noise_power", "snr_est"):
+            assert getattr(res[f], k) == getattr(r1[0], k), (f, k)

@@ -5,7 +5,7 @@ import numpy as np, torch
 import jrc_amd
 from jrc_amd import synth
 ctx = jrc_amd.Context(0)
-for cfg, F in (("B", 512), ("D", 128)):
+for cfg, F in (("B", 512), ("B", 1024), ("D", 128), ("D", 256), ("D", 512)):
     sc = {"B": synth.config_B, "D": synth.config_D}[cfg]()
     n_items = sc.Npre + sc.S
     fr = torch.randn((F, sc.T + sc.R, n_items, sc.N, 2), device="cuda:0")
