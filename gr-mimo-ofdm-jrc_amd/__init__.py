@@ -123,6 +123,17 @@ def load(build_if_missing=False):
     L.jrc_chain_fetch_results.argtypes = [_vp, C.c_int, _vp, C.POINTER(RaResult), _vp]
     L.jrc_range_doppler_dev.argtypes = [_vp, C.POINTER(ChainCfg), C.c_int, C.c_int, _vp, _vp, _vp, _vp]
     L.jrc_chain_set_timing.argtypes = [_vp, C.c_int]
+    L.jrc_chain_feed_create.argtypes = [_vp, C.POINTER(ChainCfg), _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]
+    L.jrc_chain_feed_destroy.argtypes = [_vp]
+    L.jrc_chain_feed_destroy.restype = None
+    for fn in ("jrc_chain_feed_frame_bytes", "jrc_chain_feed_map_bytes"):
+        getattr(L, fn).argtypes = [_vp]
+        getattr(L, fn).restype = C.c_size_t
+    L.jrc_chain_feed_acquire.argtypes = [_vp, C.POINTER(_vp)]
+    L.jrc_chain_feed_submit.argtypes = [_vp, _vp, C.c_int]
+    L.jrc_chain_feed_collect.argtypes = [_vp, C.POINTER(RaResult), _vp, C.POINTER(C.c_int)]
+    L.jrc_chain_feed_pending.argtypes = [_vp]
+    L.jrc_chain_feed_stats.argtypes = [_vp, C.POINTER(C.c_long), C.POINTER(C.c_long)]
     L.jrc_chain_get_timing.argtypes = [_vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     _lib = L
     return L
@@ -460,6 +471,90 @@ class RadarChain:
     def close(self):
         if getattr(self, "h", None):
             self.ctx.lib.jrc_chain_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+FEED_GRAPH = 1
+
+
+class ChainFeed:
+    """jrc_chain_feed: host-fed pipeline over the radar chain — frames in host memory in, per-frame results (and, on
+    request, the first maps of each batch) out, `n_slots` batches in flight on their own streams."""
+
+    def __init__(self, fft_len, N_tx, N_rx, N_sym, N_pre, interp_range, interp_angle, range_bins, angle_bins,
+                 noise_discard_range_m, noise_discard_angle_deg, snr_threshold=0.0, power_threshold=0.0,
+                 n_items=None, enable_tx_interleave=False, n_slots=3, frames_per_slot=32, maps_per_slot=0,
+                 graph=False, ctx=None):
+        self.ctx = ctx or default_context()
+        self.cfg = ChainCfg(fft_len, N_tx, N_rx, N_sym, N_pre, interp_range, interp_angle, int(enable_tx_interleave),
+                            n_items if n_items is not None else N_pre + N_sym,
+                            noise_discard_range_m, noise_discard_angle_deg, snr_threshold, power_threshold)
+        self.P, self.NR, self.NA = N_tx * N_rx, fft_len * interp_range, N_tx * N_rx * interp_angle
+        self.n_slots, self.frames_per_slot, self.maps_per_slot = n_slots, frames_per_slot, maps_per_slot
+        rb = np.ascontiguousarray(range_bins, np.float32)
+        ab = np.ascontiguousarray(angle_bins, np.float32)
+        assert len(rb) == self.NR and len(ab) == self.NA
+        h = _vp()
+        L = self.ctx.lib
+        self.ctx.check(L.jrc_chain_feed_create(self.ctx.h, C.byref(self.cfg), _ptr(rb), _ptr(ab), n_slots, frames_per_slot,
+                                               maps_per_slot, FEED_GRAPH if graph else 0, C.byref(h)))
+        self.h = h
+        self.frame_bytes = L.jrc_chain_feed_frame_bytes(h)
+        self.map_bytes = L.jrc_chain_feed_map_bytes(h)
+
+    def frame_shape(self):
+        c = self.cfg
+        return (c.N_tx + c.N_rx, c.n_items, c.fft_len)
+
+    def acquire(self):
+        """the next slot's pinned staging as a numpy complex64 array [frames_per_slot, T+R, n_items, fft_len] to fill in place"""
+        p = _vp()
+        self.ctx.check(self.ctx.lib.jrc_chain_feed_acquire(self.h, C.byref(p)))
+        n = self.frames_per_slot * self.frame_bytes // 8
+        buf = (C.c_float * (2 * n)).from_address(p.value)
+        return np.frombuffer(buf, dtype=np.complex64).reshape((self.frames_per_slot,) + self.frame_shape())
+
+    def submit(self, frames=None, n_frames=None):
+        """frames: complex64 [n, T+R, n_items, fft_len] in host memory, or None after acquire() + in-place fill"""
+        if frames is None:
+            n = self.frames_per_slot if n_frames is None else n_frames
+            self.ctx.check(self.ctx.lib.jrc_chain_feed_submit(self.h, None, n))
+            return
+        fr = np.ascontiguousarray(frames, np.complex64)
+        n = fr.shape[0] if n_frames is None else n_frames
+        assert fr.size * 8 >= n * self.frame_bytes
+        self.ctx.check(self.ctx.lib.jrc_chain_feed_submit(self.h, _ptr(fr), n))
+
+    def collect(self, want_maps=False):
+        """oldest batch in flight -> (list of RaResult, maps or None); ([], None) when nothing is in flight"""
+        arr = (RaResult * self.frames_per_slot)()
+        n = C.c_int(0)
+        maps = None
+        if want_maps and self.maps_per_slot:
+            maps = np.empty((self.maps_per_slot, self.NR, self.NA), np.complex64)
+        r = self.ctx.lib.jrc_chain_feed_collect(self.h, arr, _ptr(maps) if maps is not None else None, C.byref(n))
+        self.ctx.check(min(r, 0))
+        if maps is not None:
+            maps = maps[:min(n.value, self.maps_per_slot)]
+        return list(arr[:n.value]), maps
+
+    def pending(self):
+        return self.ctx.lib.jrc_chain_feed_pending(self.h)
+
+    def stats(self):
+        g, d = C.c_long(0), C.c_long(0)
+        self.ctx.check(self.ctx.lib.jrc_chain_feed_stats(self.h, C.byref(g), C.byref(d)))
+        return dict(graph_replays=g.value, direct_submits=d.value)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.jrc_chain_feed_destroy(self.h)
             self.h = None
 
     def __del__(self):

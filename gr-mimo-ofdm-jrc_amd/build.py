@@ -16,7 +16,7 @@ OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libjrc_hip.so")
 ARCH = "gfx950"
 
-SOURCES = ["ctx.hip", "radar.hip", "fft.hip", "estimator.hip", "chain.hip", "comm.hip", "tsim.hip", "codec.hip", "sync.hip"]
+SOURCES = ["ctx.hip", "radar.hip", "fft.hip", "estimator.hip", "chain.hip", "feed.hip", "comm.hip", "tsim.hip", "codec.hip", "sync.hip"]
 HEADERS = ["jrc_internal.h", "radar_kernels.h", "fft_device.h", os.path.join("..", "..", "include", "jrc.h")]
 
 HIPCC_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",

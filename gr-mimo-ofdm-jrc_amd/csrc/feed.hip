@@ -1,0 +1,217 @@
+// feed.hip — host-fed pipeline over the radar chain (jrc_chain_feed_* of include/jrc.h).
+//
+// A GNU Radio flowgraph hands work() HOST buffers: the reference's radar branch (mimo_ofdm_radar -> fft -> transpose -> fft ->
+// range_angle_estimator, examples/simulation/radar/mimo_ofdm_jrc_radar_sim.grc:2189-2197) consumes T+R tagged streams from
+// pageable ring buffers and publishes one small PDU per frame (lib/range_angle_estimator_impl.cc:199-235).  The per-block
+// host entry points copy in, run, copy out and wait; a stream of frames is better served by keeping `n_slots` batches in
+// flight: each slot owns pinned staging, device buffers, its own stream and its own jrc_chain (partial-maximum scratch is per
+// chain), so the H2D copy of batch k+1, the kernels of batch k and the D2H of batch k-1's results overlap on the copy
+// engines and the CUs.  With JRC_FEED_GRAPH a full slot is replayed as one hipGraph (copy-in, A1, fused A2-A4, finalize,
+// copy-out: one submit instead of six).  Measured on MI355X / ROCm 7.2 (profiles/r01_i_feed_probe_configB.jsonl): the replay
+// shortens the idle-pipeline latency of a batch by ~16 us (1 frame: 116 us against 133 us) but hipGraphLaunch costs more host
+// time than the six direct submits, so a saturated feed of small batches is slower with it (1-frame batches: 15.9 k against
+// 18.6 k frames/s); from 4 frames per batch up the direct path runs at the PCIe limit (56 GB/s = 50 k config-B frames/s).
+// Hence a flag, off by default: latency-critical callers set it, throughput-bound ones do not.
+//
+// Order is preserved: slots are submitted and collected round-robin, results come back in submission order.
+#include "jrc_internal.h"
+#include "radar_kernels.h"
+
+struct feed_slot {
+    jrc_chain* chain = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    float2* h_frames = nullptr;          // pinned [fps] frames
+    float2* d_frames = nullptr;
+    float2* d_chanest = nullptr;
+    float2* d_map = nullptr;
+    jrc_ra_result* d_results = nullptr;
+    jrc_ra_result* h_results = nullptr;  // pinned
+    float2* h_maps = nullptr;            // pinned [maps_per_slot] maps (optional)
+    hipGraphExec_t graph = nullptr;      // full-slot replay
+    bool graph_failed = false;
+    bool warm = false;                   // one direct pass done (tables cached, nothing left to allocate inside a capture)
+    int n_frames = 0;                    // frames of the batch in flight
+    int state = 0;                       // 0 free, 1 acquired, 2 in flight
+};
+
+struct jrc_chain_feed {
+    jrc_ctx* ctx = nullptr;
+    jrc_chain_cfg cfg;
+    int n_slots = 0, fps = 0, maps_per_slot = 0, flags = 0;
+    size_t frame_elems = 0, chanest_elems = 0, map_elems = 0;
+    std::vector<feed_slot> slots;
+    int head = 0;       // next slot to acquire / submit
+    int tail = 0;       // oldest slot in flight
+    int in_flight = 0;
+    long graph_replays = 0, direct_submits = 0;
+};
+
+static void feed_free_slot(feed_slot& s)
+{
+    if (s.graph) (void)hipGraphExecDestroy(s.graph);
+    if (s.chain) jrc_chain_destroy(s.chain);
+    if (s.done) (void)hipEventDestroy(s.done);
+    if (s.stream) (void)hipStreamDestroy(s.stream);
+    if (s.h_frames) (void)hipHostFree(s.h_frames);
+    if (s.h_results) (void)hipHostFree(s.h_results);
+    if (s.h_maps) (void)hipHostFree(s.h_maps);
+    if (s.d_frames) (void)hipFree(s.d_frames);
+    if (s.d_chanest) (void)hipFree(s.d_chanest);
+    if (s.d_map) (void)hipFree(s.d_map);
+    if (s.d_results) (void)hipFree(s.d_results);
+    s = feed_slot();
+}
+
+extern "C" void jrc_chain_feed_destroy(jrc_chain_feed* fd)
+{
+    if (!fd) return;
+    (void)hipSetDevice(fd->ctx->device);
+    for (auto& s : fd->slots)
+        if (s.stream) (void)hipStreamSynchronize(s.stream);
+    for (auto& s : fd->slots) feed_free_slot(s);
+    delete fd;
+}
+
+extern "C" int jrc_chain_feed_create(jrc_ctx* ctx, const jrc_chain_cfg* cfg, const float* range_bins, const float* angle_bins,
+                                     int n_slots, int frames_per_slot, int maps_per_slot, int flags, jrc_chain_feed** out)
+{
+    if (!ctx || !cfg || !range_bins || !angle_bins || !out) return JRC_ERR_INVALID_ARG;
+    if (n_slots < 1 || n_slots > 16 || frames_per_slot < 1 || maps_per_slot < 0 || maps_per_slot > frames_per_slot)
+        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_feed_create: need 1..16 slots, >= 1 frame per slot, 0 <= maps_per_slot <= frames_per_slot");
+    JRC_HIP(ctx, hipSetDevice(ctx->device));
+    jrc_chain_feed* fd = new jrc_chain_feed();
+    fd->ctx = ctx; fd->cfg = *cfg; fd->n_slots = n_slots; fd->fps = frames_per_slot; fd->maps_per_slot = maps_per_slot; fd->flags = flags;
+    fd->slots.resize((size_t)n_slots);
+    int st = JRC_OK;
+    for (int i = 0; i < n_slots && st == JRC_OK; i++) {
+        feed_slot& s = fd->slots[(size_t)i];
+        st = jrc_chain_create(ctx, cfg, range_bins, angle_bins, frames_per_slot, &s.chain);
+        if (st != JRC_OK) break;
+        if (i == 0) {
+            fd->frame_elems = jrc_chain_frame_bytes(s.chain) / sizeof(float2);
+            fd->chanest_elems = jrc_chain_chanest_bytes(s.chain) / sizeof(float2);
+            fd->map_elems = jrc_chain_map_bytes(s.chain) / sizeof(float2);
+        }
+        const size_t F = (size_t)frames_per_slot;
+        hipError_t e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&s.h_frames, sizeof(float2) * F * fd->frame_elems, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&s.h_results, sizeof(jrc_ra_result) * F, hipHostMallocDefault);
+        if (e == hipSuccess && maps_per_slot)
+            e = hipHostMalloc((void**)&s.h_maps, sizeof(float2) * (size_t)maps_per_slot * fd->map_elems, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc((void**)&s.d_frames, sizeof(float2) * F * fd->frame_elems);
+        if (e == hipSuccess) e = hipMalloc((void**)&s.d_chanest, sizeof(float2) * F * fd->chanest_elems);
+        if (e == hipSuccess) e = hipMalloc((void**)&s.d_map, sizeof(float2) * F * fd->map_elems);
+        if (e == hipSuccess) e = hipMalloc((void**)&s.d_results, sizeof(jrc_ra_result) * F);
+        if (e != hipSuccess) st = jrc_fail(ctx, JRC_ERR_HIP, "jrc_chain_feed_create: %s", hipGetErrorString(e));
+    }
+    if (st != JRC_OK) { jrc_chain_feed_destroy(fd); return st; }
+    *out = fd;
+    return JRC_OK;
+}
+
+extern "C" size_t jrc_chain_feed_frame_bytes(const jrc_chain_feed* fd) { return fd ? fd->frame_elems * sizeof(float2) : 0; }
+extern "C" size_t jrc_chain_feed_map_bytes(const jrc_chain_feed* fd) { return fd ? fd->map_elems * sizeof(float2) : 0; }
+extern "C" int jrc_chain_feed_pending(const jrc_chain_feed* fd) { return fd ? fd->in_flight : JRC_ERR_INVALID_ARG; }
+extern "C" int jrc_chain_feed_stats(const jrc_chain_feed* fd, long* graph_replays, long* direct_submits)
+{
+    if (!fd) return JRC_ERR_INVALID_ARG;
+    if (graph_replays) *graph_replays = fd->graph_replays;
+    if (direct_submits) *direct_submits = fd->direct_submits;
+    return JRC_OK;
+}
+
+extern "C" int jrc_chain_feed_acquire(jrc_chain_feed* fd, jrc_cf32** h_frames)
+{
+    if (!fd || !h_frames) return JRC_ERR_INVALID_ARG;
+    feed_slot& s = fd->slots[(size_t)fd->head];
+    if (s.state == 2)
+        return jrc_fail(fd->ctx, JRC_ERR_INVALID_ARG, "jrc_chain_feed_acquire: all %d slots are in flight, collect one first", fd->n_slots);
+    s.state = 1;
+    *h_frames = (jrc_cf32*)s.h_frames;
+    return JRC_OK;
+}
+
+// the whole slot on its stream: copy in, A1 -> A5, results (and the first maps) out
+static int feed_enqueue(jrc_chain_feed* fd, feed_slot& s, int n)
+{
+    jrc_ctx* ctx = fd->ctx;
+    JRC_HIP(ctx, hipMemcpyAsync(s.d_frames, s.h_frames, sizeof(float2) * (size_t)n * fd->frame_elems, hipMemcpyHostToDevice, s.stream));
+    JRC_TRY(jrc_chain_run_dev(s.chain, n, (const jrc_cf32*)s.d_frames, (jrc_cf32*)s.d_chanest, (jrc_cf32*)s.d_map, s.d_results, (void*)s.stream));
+    JRC_HIP(ctx, hipMemcpyAsync(s.h_results, s.d_results, sizeof(jrc_ra_result) * (size_t)n, hipMemcpyDeviceToHost, s.stream));
+    const int nm = n < fd->maps_per_slot ? n : fd->maps_per_slot;
+    if (nm > 0)
+        JRC_HIP(ctx, hipMemcpyAsync(s.h_maps, s.d_map, sizeof(float2) * (size_t)nm * fd->map_elems, hipMemcpyDeviceToHost, s.stream));
+    return JRC_OK;
+}
+
+extern "C" int jrc_chain_feed_submit(jrc_chain_feed* fd, const jrc_cf32* h_frames, int n_frames)
+{
+    if (!fd) return JRC_ERR_INVALID_ARG;
+    jrc_ctx* ctx = fd->ctx;
+    if (n_frames < 1 || n_frames > fd->fps)
+        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_feed_submit: n_frames %d outside [1, %d]", n_frames, fd->fps);
+    feed_slot& s = fd->slots[(size_t)fd->head];
+    if (s.state == 2)
+        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_feed_submit: all %d slots are in flight, collect one first", fd->n_slots);
+    if (h_frames && (const float2*)h_frames != s.h_frames)      // pageable source (a GNU Radio buffer): stage it
+        memcpy(s.h_frames, h_frames, sizeof(float2) * (size_t)n_frames * fd->frame_elems);
+    else if (!h_frames && s.state != 1)
+        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_feed_submit: no host frames given and no acquired buffer to take them from");
+    JRC_HIP(ctx, hipSetDevice(ctx->device));
+    const bool want_graph = (fd->flags & JRC_FEED_GRAPH) && n_frames == fd->fps && !s.graph_failed && s.warm;
+    if (want_graph && !s.graph) {
+        // record the slot's sequence once; pointers and sizes of a full slot never change
+        hipGraph_t g = nullptr;
+        hipError_t e = hipStreamBeginCapture(s.stream, hipStreamCaptureModeRelaxed);
+        int st = JRC_OK;
+        if (e == hipSuccess) {
+            st = feed_enqueue(fd, s, n_frames);
+            e = hipStreamEndCapture(s.stream, &g);
+        }
+        if (e == hipSuccess && st == JRC_OK) e = hipGraphInstantiate(&s.graph, g, nullptr, nullptr, 0);
+        if (g) (void)hipGraphDestroy(g);
+        if (e != hipSuccess || st != JRC_OK) {       // fall back to direct submission on this slot, loudly in last_error
+            (void)hipGetLastError();
+            s.graph = nullptr; s.graph_failed = true;
+            jrc_fail(ctx, JRC_ERR_HIP, "jrc_chain_feed: graph capture failed (%s), submitting directly", hipGetErrorString(e));
+        }
+    }
+    if (want_graph && s.graph) {
+        JRC_HIP(ctx, hipGraphLaunch(s.graph, s.stream));
+        fd->graph_replays++;
+    } else {
+        JRC_TRY(feed_enqueue(fd, s, n_frames));
+        fd->direct_submits++;
+        s.warm = true;
+    }
+    JRC_HIP(ctx, hipEventRecord(s.done, s.stream));
+    s.n_frames = n_frames;
+    s.state = 2;
+    fd->head = (fd->head + 1) % fd->n_slots;
+    fd->in_flight++;
+    return JRC_OK;
+}
+
+extern "C" int jrc_chain_feed_collect(jrc_chain_feed* fd, jrc_ra_result* results, jrc_cf32* maps, int* n_frames)
+{
+    if (!fd || !results) return JRC_ERR_INVALID_ARG;
+    jrc_ctx* ctx = fd->ctx;
+    if (fd->in_flight == 0) { if (n_frames) *n_frames = 0; return 0; }
+    feed_slot& s = fd->slots[(size_t)fd->tail];
+    JRC_HIP(ctx, hipEventSynchronize(s.done));
+    for (int i = 0; i < s.n_frames; i++) {
+        results[i] = s.h_results[i];
+        // snr_est / published with the host libm's log10f, as jrc_chain_fetch_results does (range_angle_estimator_impl.cc:227)
+        ra_finish_host(&results[i], fd->cfg.snr_threshold, fd->cfg.power_threshold);
+    }
+    const int nm = s.n_frames < fd->maps_per_slot ? s.n_frames : fd->maps_per_slot;
+    if (maps && nm > 0) memcpy(maps, s.h_maps, sizeof(float2) * (size_t)nm * fd->map_elems);
+    if (n_frames) *n_frames = s.n_frames;
+    const int n = s.n_frames;
+    s.state = 0; s.n_frames = 0;
+    fd->tail = (fd->tail + 1) % fd->n_slots;
+    fd->in_flight--;
+    return n;
+}

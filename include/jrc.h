@@ -189,6 +189,32 @@ int  jrc_chain_set_timing(jrc_chain* chain, int enabled);
  * ms[0]=radar_chanest, ms[1]=range_angle_fused, ms[2]=ra_finalize; *launches = runs measured */
 int  jrc_chain_get_timing(jrc_chain* chain, float ms[3], int* launches);
 
+/* ---- host-fed pipeline over the chain: what a GNU Radio work() hands over is HOST memory (the T+R input ring buffers of
+ *      mimo_ofdm_radar, lib/mimo_ofdm_radar_impl.cc:207-238) and what leaves the radar branch is one small record per
+ *      frame (the PDU of lib/range_angle_estimator_impl.cc:199-235).  `n_slots` batches of up to `frames_per_slot` frames
+ *      are kept in flight, each on its own stream with its own pinned staging and device buffers, so copy-in, kernels and
+ *      copy-out of consecutive batches overlap.  Results come back in submission order.  Not thread-safe (one feeder thread).
+ *   JRC_FEED_GRAPH: a full slot is recorded once as a hipGraph (copy-in, A1, fused A2-A4, A5, copy-out) and replayed. */
+enum { JRC_FEED_GRAPH = 1 };
+typedef struct jrc_chain_feed jrc_chain_feed;
+int    jrc_chain_feed_create(jrc_ctx* ctx, const jrc_chain_cfg* cfg, const float* range_bins, const float* angle_bins,
+                             int n_slots, int frames_per_slot, int maps_per_slot /* maps copied back per batch, 0 = none */,
+                             int flags, jrc_chain_feed** feed);
+void   jrc_chain_feed_destroy(jrc_chain_feed* feed);
+size_t jrc_chain_feed_frame_bytes(const jrc_chain_feed* feed);   /* = jrc_chain_frame_bytes */
+size_t jrc_chain_feed_map_bytes(const jrc_chain_feed* feed);
+/* pinned staging of the next slot ([frames_per_slot] frames, layout of jrc_chain_run_dev's d_frames) to fill in place;
+ * fails when every slot is in flight */
+int    jrc_chain_feed_acquire(jrc_chain_feed* feed, jrc_cf32** h_frames);
+/* enqueue the next slot; h_frames = NULL: the acquired buffer was filled in place, else n_frames frames are staged from
+ * h_frames (pageable memory is fine).  Asynchronous. */
+int    jrc_chain_feed_submit(jrc_chain_feed* feed, const jrc_cf32* h_frames, int n_frames);
+/* wait for the OLDEST batch in flight: results[frames_per_slot], maps (may be NULL) [maps_per_slot] maps of its first
+ * frames.  Returns the number of frames (also in *n_frames), 0 when nothing is in flight, < 0 on error. */
+int    jrc_chain_feed_collect(jrc_chain_feed* feed, jrc_ra_result* results, jrc_cf32* maps, int* n_frames);
+int    jrc_chain_feed_pending(const jrc_chain_feed* feed);        /* batches in flight */
+int    jrc_chain_feed_stats(const jrc_chain_feed* feed, long* graph_replays, long* direct_submits);
+
 /* ---- D  range-Doppler map — NO reference counterpart (the reference sums over symbols,
  *          lib/mimo_ofdm_radar_impl.cc:271-274); defined by this build, parity unpinned by construction:
  *   D[p][sym][sc] = rx_r[sym][sc]*conj(tx_t[sym][sc]);  out[f][p][k][d] = fftshift_d FFT_{S*Id}(IFFT_{N*Ir}(D zero-padded))

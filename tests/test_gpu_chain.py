@@ -218,3 +218,77 @@ def test_chain_batches_larger_than_one_resident_wave(jrc, ctx):
         assert np.array_equal(gmap[f], m1[0])
         for k in ("peak_range_idx", "peak_angle_idx", "angle_null_idx", "n_noise_samples", "peak_power", "noise_power", "snr_est"):
             assert getattr(res[f], k) == getattr(r1[0], k), (f, k)
+
+
+RES_KEYS = ("peak_range_idx", "peak_angle_idx", "angle_null_idx", "n_noise_samples", "published",
+            "peak_power", "noise_power", "snr_est", "range_val", "angle_val")
+
+
+def make_feed(jrc, ctx, sc, Ir, Ia, **kw):
+    P = sc.T * sc.R
+    rb, ab = jrc.radar_axes(sc.N, sc.fs, Ir, P, Ia)
+    ndr, nda = 2 * 3e8 / (2 * sc.fs), 2 * float(np.rad2deg(np.arcsin(2 / P))) if P > 2 else 30.0
+    return jrc.ChainFeed(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb, ab, ndr, nda, 15.0, 0.0, ctx=ctx, **kw)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_chain_feed_host_fed_pipeline_matches_the_resident_chain(jrc, ctx, graph):
+    """frames handed over in HOST memory, three batches in flight (own streams, optional hipGraph replay), ragged last batch:
+    results in submission order and identical to the device-resident chain's; maps of the first frames of each batch too"""
+    from jrc_amd import synth
+    sc = synth.Scenario(64, 2, 2, 4, targets=[(9.0, 15.0, 0.0, 80.0)])
+    Ir, Ia, fps, F = 8, 16, 8, 8 * 7 + 3
+    base = synth.make_frames(sc, 8)
+    frames = np.concatenate([base] * (F // 8 + 1))[:F].copy()
+    frames[:, sc.T:] *= (1.0 + 0.01 * np.arange(F, dtype=np.float32))[:, None, None, None]
+    _, _, gmap, res, _ = run_chain(jrc, ctx, sc, Ir, Ia, F, frames=frames)
+    feed = make_feed(jrc, ctx, sc, Ir, Ia, n_slots=3, frames_per_slot=fps, maps_per_slot=2, graph=graph)
+    got, maps, starts = [], [], []
+    f0 = 0
+    while f0 < F or feed.pending():
+        while f0 < F and feed.pending() < feed.n_slots:
+            n = min(fps, F - f0)
+            if (f0 // fps) % 2 == 0:                       # alternate the two hand-over styles
+                feed.submit(frames[f0:f0 + n])
+            else:
+                feed.acquire()[:n] = frames[f0:f0 + n]
+                feed.submit(None, n)
+            starts.append(f0)
+            f0 += n
+        r, m = feed.collect(want_maps=True)
+        got += r
+        maps.append(m)
+    assert len(got) == F and feed.collect()[0] == []
+    for f in range(F):
+        for k in RES_KEYS:
+            assert getattr(got[f], k) == getattr(res[f], k), (f, k)
+    for s, m in zip(starts, maps):
+        for j in range(len(m)):
+            assert np.array_equal(m[j], gmap[s + j])
+    st = feed.stats()
+    if graph:                                              # first full pass of each slot is direct, later full batches replay
+        assert st["graph_replays"] == 7 - 3 and st["direct_submits"] == 3 + 1
+    else:
+        assert st["graph_replays"] == 0
+    feed.close()
+
+
+def test_chain_feed_refuses_overrun_and_bad_sizes(jrc, ctx):
+    from jrc_amd import synth
+    sc = synth.Scenario(64, 1, 1, 2, targets=[(9.0, 0.0, 0.0, 80.0)])
+    feed = make_feed(jrc, ctx, sc, 8, 16, n_slots=2, frames_per_slot=4)
+    fr = synth.make_frames(sc, 4)
+    with pytest.raises(jrc.JrcError):
+        feed.submit(synth.make_frames(sc, 5))              # more than a slot holds
+    with pytest.raises(jrc.JrcError):
+        feed.submit(None, 4)                               # nothing acquired
+    feed.submit(fr)
+    feed.submit(fr)
+    with pytest.raises(jrc.JrcError):
+        feed.submit(fr)                                    # every slot in flight
+    with pytest.raises(jrc.JrcError):
+        feed.acquire()
+    a, _ = feed.collect()
+    b, _ = feed.collect()
+    assert len(a) == len(b) == 4 and all(getattr(a[i], k) == getattr(b[i], k) for i in range(4) for k in RES_KEYS)
+    feed.close()
