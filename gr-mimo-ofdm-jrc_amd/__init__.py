@@ -101,6 +101,8 @@ def load(build_if_missing=False):
     L.jrc_radar_ring_size.argtypes = [_vp]
     L.jrc_radar_work.argtypes = [_vp, C.POINTER(_vp), C.POINTER(_vp), C.c_size_t, C.c_size_t, C.c_size_t, _vp]
     L.jrc_radar_chanest_dev.argtypes = [_vp] + [C.c_int] * 8 + [_vp, _vp, _vp]
+    L.jrc_radar_chanest_td_dev.argtypes = [_vp] + [C.c_int] * 7 + [C.c_long, C.c_int, C.c_int, _vp, _vp, _vp, _vp]
+    L.jrc_chain_run_td_dev.argtypes = [_vp, C.c_int, _vp, _vp, C.c_int, C.c_long, _vp, _vp, _vp, _vp]
     L.jrc_fft_vcc.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, _vp, _vp]
     L.jrc_fft_vcc_dev.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, _vp, _vp, _vp]
     L.jrc_matrix_transpose.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]
@@ -442,6 +444,14 @@ class RadarChain:
         self.ctx.check(self.ctx.lib.jrc_chain_run_dev(self.h, n_frames, bufs["frames"].data_ptr(),
                                                       bufs["chanest"].data_ptr(), bufs["map"].data_ptr(),
                                                       bufs["results"].data_ptr(), stream))
+
+    def run_td(self, bufs, tx, rx_td, n_frames, cp_len, stream=None):
+        """A6 + A7 + A1 fused in front of the chain: tx = torch [n_frames, T, n_items, fft_len, 2] (frequency domain),
+        rx_td = torch [n_frames, R, rx_stream_len, 2] time-domain RX streams with cyclic prefixes; asynchronous on `stream`"""
+        assert tx.is_contiguous() and rx_td.is_contiguous()
+        self.ctx.check(self.ctx.lib.jrc_chain_run_td_dev(self.h, n_frames, tx.data_ptr(), rx_td.data_ptr(), cp_len, rx_td.shape[2],
+                                                         bufs["chanest"].data_ptr(), bufs["map"].data_ptr(),
+                                                         bufs["results"].data_ptr(), stream))
 
     def results(self, bufs, n_frames, stream=None):
         arr = (RaResult * n_frames)()

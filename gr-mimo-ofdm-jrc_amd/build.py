@@ -23,7 +23,7 @@ HIPCC_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", 
                "-fno-gpu-rdc"]
 # per-file extras.  chain.hip: the SLP vectorizer packs the complex butterflies into v_pk_*_f32, which on
 # gfx950 run at the scalar f32 rate but cost ~100 extra v_mov and ~50 VGPRs in the fused kernel.
-EXTRA_FLAGS = {"chain.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"chain.hip": ["-fno-slp-vectorize"], "radar.hip": ["-fno-slp-vectorize"]}
 
 
 def hipcc():

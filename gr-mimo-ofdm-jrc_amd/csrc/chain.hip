@@ -416,15 +416,17 @@ extern "C" int jrc_chain_get_timing(jrc_chain* ch, float ms[3], int* launches)
     return JRC_OK;
 }
 
-extern "C" int jrc_chain_run_dev(jrc_chain* ch, int n_frames, const jrc_cf32* d_frames, jrc_cf32* d_chanest,
-                                 jrc_cf32* d_map, jrc_ra_result* d_results, void* stream)
+// A1 comes in two forms: frequency-domain frames (d_frames), or TX rows + time-domain RX streams (A6 + A7 + A1 fused)
+static int chain_run(jrc_chain* ch, int n_frames, const jrc_cf32* d_frames, const jrc_cf32* d_tx, const jrc_cf32* d_rx_td, int cp_len,
+                     long rx_stream_len, jrc_cf32* d_chanest, jrc_cf32* d_map, jrc_ra_result* d_results, void* stream)
 {
-    if (!ch || !d_frames || !d_chanest || !d_map || !d_results) return JRC_ERR_INVALID_ARG;
     jrc_ctx* ctx = ch->ctx;
     if (n_frames <= 0 || n_frames > ch->max_frames)
         return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_run_dev: n_frames %d outside (0, %d]", n_frames, ch->max_frames);
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     const jrc_chain_cfg& c = ch->cfg;
+    if (!d_frames && (cp_len < 0 || rx_stream_len < (long)c.n_items * (c.fft_len + cp_len)))
+        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_run_td_dev: rx_stream_len %ld shorter than n_items*(fft_len+cp_len)", rx_stream_len);
     hipEvent_t* ev = nullptr;
     if (ch->timing) {
         if (ch->ev_used == jrc_chain::kPool) JRC_TRY(chain_drain_events(ch));
@@ -433,12 +435,21 @@ extern "C" int jrc_chain_run_dev(jrc_chain* ch, int n_frames, const jrc_cf32* d_
         JRC_HIP(ctx, hipEventRecord(ev[0], s));
     }
     // A1
-    ChanestGeom g;
-    g.N = c.fft_len; g.S = c.N_sym;
-    g.port_stride = (long)c.n_items * c.fft_len;
-    g.frame_stride = g.port_stride * (c.N_tx + c.N_rx);
-    g.tx_item0 = c.N_pre; g.rx_item0 = c.N_pre; g.interleave = c.enable_tx_interleave;
-    JRC_TRY(launch_radar_chanest(ctx, c.N_tx, c.N_rx, (const float2*)d_frames, (float2*)d_chanest, g, n_frames, s));
+    if (d_frames) {
+        ChanestGeom g;
+        g.N = c.fft_len; g.S = c.N_sym;
+        g.port_stride = (long)c.n_items * c.fft_len;
+        g.frame_stride = g.port_stride * (c.N_tx + c.N_rx);
+        g.tx_item0 = c.N_pre; g.rx_item0 = c.N_pre; g.interleave = c.enable_tx_interleave;
+        JRC_TRY(launch_radar_chanest(ctx, c.N_tx, c.N_rx, (const float2*)d_frames, (float2*)d_chanest, g, n_frames, s));
+    } else {
+        DemodGeom g;
+        g.N = c.fft_len; g.cp = cp_len; g.S = c.N_sym; g.R = c.N_rx; g.logn = 0;
+        g.tx_port_stride = (long)c.n_items * c.fft_len; g.tx_frame_stride = g.tx_port_stride * c.N_tx;
+        g.rx_stream_stride = rx_stream_len; g.rx_frame_stride = rx_stream_len * c.N_rx;
+        g.tx_item0 = c.N_pre; g.rx_sym0 = c.N_pre; g.interleave = c.enable_tx_interleave; g.blocks_per_frame = 1;
+        JRC_TRY(launch_demod_chanest(ctx, c.N_tx, (const float2*)d_tx, (const float2*)d_rx_td, (float2*)d_chanest, g, n_frames, s));
+    }
     if (ev) JRC_HIP(ctx, hipEventRecord(ev[1], s));
     // A2 + A3 + A4 + arg-max half of A5
     int partials_per_frame;
@@ -486,6 +497,20 @@ extern "C" int jrc_chain_run_dev(jrc_chain* ch, int n_frames, const jrc_cf32* d_
                                ch->d_bins + ch->NR, d_results, n_frames, s));
     if (ev) JRC_HIP(ctx, hipEventRecord(ev[3], s));
     return JRC_OK;
+}
+
+extern "C" int jrc_chain_run_dev(jrc_chain* ch, int n_frames, const jrc_cf32* d_frames, jrc_cf32* d_chanest,
+                                 jrc_cf32* d_map, jrc_ra_result* d_results, void* stream)
+{
+    if (!ch || !d_frames || !d_chanest || !d_map || !d_results) return JRC_ERR_INVALID_ARG;
+    return chain_run(ch, n_frames, d_frames, nullptr, nullptr, 0, 0, d_chanest, d_map, d_results, stream);
+}
+
+extern "C" int jrc_chain_run_td_dev(jrc_chain* ch, int n_frames, const jrc_cf32* d_tx, const jrc_cf32* d_rx_td, int cp_len,
+                                    long rx_stream_len, jrc_cf32* d_chanest, jrc_cf32* d_map, jrc_ra_result* d_results, void* stream)
+{
+    if (!ch || !d_tx || !d_rx_td || !d_chanest || !d_map || !d_results) return JRC_ERR_INVALID_ARG;
+    return chain_run(ch, n_frames, nullptr, d_tx, d_rx_td, cp_len, rx_stream_len, d_chanest, d_map, d_results, stream);
 }
 
 extern "C" int jrc_chain_fetch_results(jrc_chain* ch, int n_frames, const jrc_ra_result* d_results,

@@ -7,6 +7,7 @@
 // order with individually rounded products (no FMA contraction) so the result is bit-identical to
 // the reference's scalar loop.
 #include "radar_kernels.h"
+#include "fft_device.h"
 
 #include <cstdlib>
 
@@ -197,6 +198,210 @@ int launch_radar_chanest(jrc_ctx* ctx, int T, int R, const float2* d_frames, flo
 }
 
 // ------------------------------------------------------------------------------------------------
+// A6 + A7 + A1 in one kernel: RX handed over in the TIME domain (the input of ofdm_cyclic_prefix_remover,
+// lib/ofdm_cyclic_prefix_remover_impl.cc:69-99), each symbol transformed in LDS (the stock fft_vxx forward + shift of the
+// flowgraph, examples/simulation/radar/mimo_ofdm_jrc_radar_sim.grc `fft_vxx_0_0`) and multiplied into the T accumulators of
+// mimo_ofdm_radar (lib/mimo_ofdm_radar_impl.cc:250-274) straight from registers: the frequency-domain RX symbols never go
+// to HBM (unfused: written once, read once), and the N_pre preamble symbols the radar block skips are not transformed at all.
+//
+// One (frame, receiver) stream per group of N threads (N >= 256: one stream per workgroup; smaller N: 256/N streams): the group
+// transforms FOUR symbols at a time, n/4 lanes each, then every thread owns one subcarrier and adds the four products to its T
+// accumulators in symbol order (the accumulation order of the reference).  The butterflies are the Stockham passes of
+// fft_stockham_kernel (same helper, same twiddle table) and the sums run in the same order, so the result agrees with
+// jrc_cp_remove_fft_dev + jrc_radar_chanest_dev to the last bits (1e-7 relative: only the compiler's choice of which product of a
+// complex multiply it fuses into an FMA differs between the two kernels); the next four symbols' samples and this round's TX rows are in flight while the current four go through their LDS passes.
+__device__ __forceinline__ void chanest_mac(float2& a, const float2 rx, const float2 tx)
+{
+#pragma clang fp contract(off)
+    // rx * conj(tx) = (ac + bd) + j(bc - ad), products rounded individually (:273)
+    const float pr = rx.x * tx.x + rx.y * tx.y, pi = rx.y * tx.x - rx.x * tx.y;
+    a.x = a.x + pr; a.y = a.y + pi;
+}
+
+// LDS index hook: padding the Stockham scatter (runs of Ns points at stride 4*Ns) against bank conflicts — i + (i >> 2) — was measured
+// and does not pay: the kernel is bound by instruction issue, not by LDS, and the two extra integer operations per access cost 7 %
+#define DC_PAD(i) (i)
+
+template <int T>
+__global__ __launch_bounds__(1024) void demod_chanest_kernel(const float2* __restrict__ tx, const float2* __restrict__ rx_td,
+                                                             float2* __restrict__ H, const float2* __restrict__ tw_g,
+                                                             DemodGeom g, int n_frames)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    const int n = g.N, tp = n >> 2, per_block = blockDim.x / n;
+    const int ls = threadIdx.x / n, ts = threadIdx.x % n;      // stream within the workgroup, thread within the stream
+    const int u = ts / tp, lt = ts % tp;                       // symbol slot 0..3, lane within the transform
+    float2* tw = lds;
+    const int np = n;                                          // buffer length (see DC_PAD)
+    float2* sbase = lds + n + (size_t)ls * 8 * np;             // per stream: 4 slots x 2 buffers x np
+    float2* bufA = sbase + (size_t)u * 2 * np;
+    float2* bufB = bufA + np;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) tw[i] = tw_g[i];
+
+    // workgroup -> streams; with several workgroups per frame, those of one frame share blockIdx % 8 (one XCD, so the TX rows
+    // every receiver multiplies with are fetched into one L2)
+    long blk = blockIdx.x;
+    if (g.blocks_per_frame > 1) {
+        const long q = blk >> 3, x = blk & 7;
+        blk = ((q / g.blocks_per_frame) * 8 + x) * g.blocks_per_frame + (q % g.blocks_per_frame);
+    }
+    const long b = blk * per_block + ls;
+    const bool live = b < (long)n_frames * g.R;
+    const long f = live ? b / g.R : 0;
+    const int r = live ? (int)(b % g.R) : 0;
+    const float2* src = rx_td + f * g.rx_frame_stride + (long)r * g.rx_stream_stride + (long)g.rx_sym0 * (n + g.cp) + g.cp;
+    const float2* txb = tx + f * g.tx_frame_stride + (long)g.tx_item0 * n + ts;
+    const int half_n = n >> 1;
+
+    float2 acc[T], pn[4] = {};
+#pragma unroll
+    for (int t = 0; t < T; t++) acc[t] = make_float2(0.f, 0.f);
+
+    auto fetch_rx = [&](int sym0) {            // this slot's symbol of the round starting at sym0: read once, non-temporal
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        if (sym0 + u < g.S) {
+            const float2* sp = src + (long)(sym0 + u) * (n + g.cp);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const v2f t = __builtin_nontemporal_load(reinterpret_cast<const v2f*>(sp + lt + q * tp));
+                pn[q] = make_float2(t.x, t.y);
+            }
+        }
+    };
+    if (live && g.S > 0) fetch_rx(0);
+    __syncthreads();
+
+    const bool odd = g.logn & 1;
+    float2* wr = bufA;                 // buffer this slot's next pass writes
+    for (int sym0 = 0; sym0 < g.S; sym0 += 4) {
+        float2 p[4], tc[T][4] = {};
+#pragma unroll
+        for (int q = 0; q < 4; q++) p[q] = pn[q];
+        if (live && sym0 + 4 < g.S) fetch_rx(sym0 + 4);      // next round's samples: in flight during this round's passes
+        if (live) {                                          // this round's TX rows: needed only after the passes
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (sym0 + q < g.S) {
+#pragma unroll
+                    for (int t = 0; t < T; t++) tc[t][q] = txb[(long)t * g.tx_port_stride + (long)(sym0 + q) * n];
+                }
+        }
+
+        // first pass, from registers (Ns = 1: no twiddles); p[q] = x[lt + q*tp]
+        int Ns;
+        if (odd) {         // radix 2: j = lt pairs (p0, p2), j = lt + tp pairs (p1, p3); out[2j], out[2j+1]
+            wr[DC_PAD(2 * lt)] = cadd(p[0], p[2]); wr[DC_PAD(2 * lt + 1)] = csub(p[0], p[2]);
+            wr[DC_PAD(2 * (lt + tp))] = cadd(p[1], p[3]); wr[DC_PAD(2 * (lt + tp) + 1)] = csub(p[1], p[3]);
+            Ns = 2;
+        } else {           // radix 4: out[4j + r]
+            const float2 a = cadd(p[0], p[2]), bb = csub(p[0], p[2]), c = cadd(p[1], p[3]), d = csub(p[1], p[3]);
+            const float2 jd = make_float2(d.y, -d.x);
+            wr[DC_PAD(4 * lt)] = cadd(a, c); wr[DC_PAD(4 * lt + 1)] = cadd(bb, jd);
+            wr[DC_PAD(4 * lt + 2)] = csub(a, c); wr[DC_PAD(4 * lt + 3)] = csub(bb, jd);
+            Ns = 4;
+        }
+        __syncthreads();
+        float2* rd = wr;
+        wr = (wr == bufA) ? bufB : bufA;
+        while (Ns * 4 < n) {           // middle passes, LDS -> LDS: stockham_pass<4> of fft_device.h on the padded layout
+            const int k = lt & (Ns - 1), tws = n / (Ns * 4);
+            float2 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                v[q] = rd[DC_PAD(lt + q * tp)];
+                if (q && k) v[q] = cmul(v[q], tw[(k * q * tws) & (n - 1)]);
+            }
+            const float2 a = cadd(v[0], v[2]), bb = csub(v[0], v[2]), c = cadd(v[1], v[3]), d = csub(v[1], v[3]);
+            const float2 jd = make_float2(d.y, -d.x);
+            const int j0 = ((lt - k) << 2) + k;
+            wr[DC_PAD(j0)] = cadd(a, c); wr[DC_PAD(j0 + Ns)] = cadd(bb, jd);
+            wr[DC_PAD(j0 + 2 * Ns)] = csub(a, c); wr[DC_PAD(j0 + 3 * Ns)] = csub(bb, jd);
+            __syncthreads();
+            float2* t2 = rd; rd = wr; wr = t2;
+            Ns *= 4;
+        }
+        // last pass (Ns = n/4, k = lt): X[lt + q*Ns] goes where fft_vxx's shift puts it, subcarrier (lt + q*Ns + n/2) mod n
+        {
+            float2 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                v[q] = rd[DC_PAD(lt + q * tp)];
+                if (q && lt) v[q] = cmul(v[q], tw[(lt * q) & (n - 1)]);
+            }
+            const float2 a = cadd(v[0], v[2]), bb = csub(v[0], v[2]), c = cadd(v[1], v[3]), d = csub(v[1], v[3]);
+            const float2 jd = make_float2(d.y, -d.x);
+            wr[DC_PAD((lt + half_n) & (n - 1))] = cadd(a, c);
+            wr[DC_PAD((lt + tp + half_n) & (n - 1))] = cadd(bb, jd);
+            wr[DC_PAD((lt + 2 * tp + half_n) & (n - 1))] = csub(a, c);
+            wr[DC_PAD((lt + 3 * tp + half_n) & (n - 1))] = csub(bb, jd);
+        }
+        __syncthreads();
+        // every thread owns subcarrier ts: the four symbols of this round, in order.  Slot q's result sits in the buffer that slot
+        // just wrote (the same one of the pair for every slot); the next round's first pass writes the other one.
+        const int off = (int)(wr - bufA);
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (sym0 + q < g.S) {
+                const float2 xv = sbase[(size_t)q * 2 * np + off + DC_PAD(ts)];
+#pragma unroll
+                for (int t = 0; t < T; t++) chanest_mac(acc[t], xv, tc[t][q]);
+            }
+        wr = rd;
+    }
+    if (!live) return;
+    float2* Hf = H + (size_t)f * T * g.R * n;
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+        const int pidx = g.interleave ? (t * g.R + r) : (r * T + t);   // :262-269
+        Hf[(size_t)pidx * n + ts] = acc[t];
+    }
+}
+
+bool demod_chanest_supported(int N, int T)
+{
+    return jrc_is_pow2(N) && N >= 16 && N <= 1024 && (T == 1 || T == 2 || T == 3 || T == 4 || T == 8);
+}
+
+int launch_demod_chanest(jrc_ctx* ctx, int T, const float2* d_tx, const float2* d_rx_td, float2* d_H, DemodGeom g, int n_frames,
+                         hipStream_t stream)
+{
+    if (n_frames <= 0) return JRC_OK;
+    if (!demod_chanest_supported(g.N, T))
+        return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "time-domain channel estimate: fft_len %d / N_tx %d outside the fused kernel "
+                        "(powers of two 16..1024, N_tx in {1,2,3,4,8}); use jrc_cp_remove_fft_dev + jrc_radar_chanest_dev", g.N, T);
+    const float2* tw = nullptr;
+    JRC_TRY(jrc_get_twiddles(ctx, g.N, -1, &tw));
+    g.logn = jrc_ilog2(g.N);
+    const int threads = g.N >= 256 ? g.N : 256, per_block = threads / g.N;      // streams per workgroup
+    g.blocks_per_frame = per_block < g.R ? (g.R + per_block - 1) / per_block : 1;
+    long blocks = ((long)n_frames * g.R + per_block - 1) / per_block;
+    if (g.blocks_per_frame > 1) {
+        // a frame's receivers must not straddle the remapped groups: whole frames per group of blocks_per_frame workgroups
+        if (g.R % per_block) g.blocks_per_frame = 1;
+        else { const long grp = 8L * g.blocks_per_frame; blocks = (blocks + grp - 1) / grp * grp; }
+    }
+    const size_t lds_bytes = sizeof(float2) * ((size_t)g.N + (size_t)per_block * 8 * g.N);
+    const dim3 grid((unsigned)blocks), block((unsigned)threads);
+    static size_t attr_bytes[9] = {0};
+    if (lds_bytes > 64 * 1024 && lds_bytes > attr_bytes[T]) {
+        const void* fn = T == 1 ? (const void*)demod_chanest_kernel<1> : T == 2 ? (const void*)demod_chanest_kernel<2> :
+                         T == 3 ? (const void*)demod_chanest_kernel<3> : T == 4 ? (const void*)demod_chanest_kernel<4> :
+                                  (const void*)demod_chanest_kernel<8>;
+        JRC_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr_bytes[T] = lds_bytes;
+    }
+    switch (T) {
+        case 1: hipLaunchKernelGGL(demod_chanest_kernel<1>, grid, block, lds_bytes, stream, d_tx, d_rx_td, d_H, tw, g, n_frames); break;
+        case 2: hipLaunchKernelGGL(demod_chanest_kernel<2>, grid, block, lds_bytes, stream, d_tx, d_rx_td, d_H, tw, g, n_frames); break;
+        case 3: hipLaunchKernelGGL(demod_chanest_kernel<3>, grid, block, lds_bytes, stream, d_tx, d_rx_td, d_H, tw, g, n_frames); break;
+        case 4: hipLaunchKernelGGL(demod_chanest_kernel<4>, grid, block, lds_bytes, stream, d_tx, d_rx_td, d_H, tw, g, n_frames); break;
+        default: hipLaunchKernelGGL(demod_chanest_kernel<8>, grid, block, lds_bytes, stream, d_tx, d_rx_td, d_H, tw, g, n_frames); break;
+    }
+    JRC_HIP(ctx, hipGetLastError());
+    return JRC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // background recording / removal (lib/mimo_ofdm_radar_impl.cc:276-293)
 __global__ void radar_background_kernel(float2* __restrict__ est, float2* __restrict__ temp,
                                         const float2* __restrict__ ring, int pn, int ring_size,
@@ -349,5 +554,22 @@ extern "C" int jrc_radar_chanest_dev(jrc_ctx* ctx, int fft_len, int N_tx, int N_
     g.N = fft_len; g.S = N_sym; g.port_stride = (long)n_items * fft_len; g.frame_stride = g.port_stride * (N_tx + N_rx);
     g.tx_item0 = N_pre; g.rx_item0 = N_pre; g.interleave = enable_tx_interleave;
     return launch_radar_chanest(ctx, N_tx, N_rx, (const float2*)d_frames, (float2*)d_chanest, g, n_frames,
+                                stream ? (hipStream_t)stream : ctx->stream);
+}
+
+extern "C" int jrc_radar_chanest_td_dev(jrc_ctx* ctx, int fft_len, int cp_len, int N_tx, int N_rx, int N_sym, int N_pre, int n_items,
+                                        long rx_stream_len, int enable_tx_interleave, int n_frames, const jrc_cf32* d_tx,
+                                        const jrc_cf32* d_rx_td, jrc_cf32* d_chanest, void* stream)
+{
+    if (!ctx || !d_tx || !d_rx_td || !d_chanest) return JRC_ERR_INVALID_ARG;
+    if (fft_len <= 0 || cp_len < 0 || N_tx <= 0 || N_rx <= 0 || N_sym < 0 || N_pre < 0 || n_items < N_pre + N_sym || n_frames < 0 ||
+        rx_stream_len < (long)n_items * (fft_len + cp_len))
+        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_radar_chanest_td_dev: inconsistent sizes");
+    DemodGeom g;
+    g.N = fft_len; g.cp = cp_len; g.S = N_sym; g.R = N_rx; g.logn = 0;
+    g.tx_port_stride = (long)n_items * fft_len; g.tx_frame_stride = g.tx_port_stride * N_tx;
+    g.rx_stream_stride = rx_stream_len; g.rx_frame_stride = rx_stream_len * N_rx;
+    g.tx_item0 = N_pre; g.rx_sym0 = N_pre; g.interleave = enable_tx_interleave; g.blocks_per_frame = 1;
+    return launch_demod_chanest(ctx, N_tx, (const float2*)d_tx, (const float2*)d_rx_td, (float2*)d_chanest, g, n_frames,
                                 stream ? (hipStream_t)stream : ctx->stream);
 }

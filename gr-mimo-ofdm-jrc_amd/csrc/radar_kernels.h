@@ -14,6 +14,19 @@ struct ChanestGeom {
 int launch_radar_chanest(jrc_ctx* ctx, int T, int R, const float2* d_frames, float2* d_H,
                          const ChanestGeom& g, int n_frames, hipStream_t stream);
 
+// A6 + A7 + A1 fused (radar.hip): time-domain RX streams in, channel estimate out
+struct DemodGeom {
+    int  N, cp, S, R, logn;
+    long tx_frame_stride, tx_port_stride;      // cf32 elements
+    long rx_frame_stride, rx_stream_stride;    // cf32 elements (time domain)
+    int  tx_item0, rx_sym0;                    // first symbol used on the TX / RX side
+    int  interleave;
+    int  blocks_per_frame;                     // > 1: a frame's receivers span several workgroups (kept on one XCD)
+};
+bool demod_chanest_supported(int N, int T);
+int launch_demod_chanest(jrc_ctx* ctx, int T, const float2* d_tx, const float2* d_rx_td, float2* d_H, DemodGeom g, int n_frames,
+                         hipStream_t stream);
+
 // generic batched power-of-two FFT with gr::fft::fft_vcc semantics (fft.hip)
 int launch_fft_vcc(jrc_ctx* ctx, int n, int forward, int shift, const float* d_window, size_t batch,
                    const float2* d_in, float2* d_out, long in_stride, int in_offset, hipStream_t stream);

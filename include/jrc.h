@@ -84,6 +84,11 @@ int  jrc_radar_work(jrc_radar* radar, const jrc_cf32* const* tx, const jrc_cf32*
 int  jrc_radar_chanest_dev(jrc_ctx* ctx, int fft_len, int N_tx, int N_rx, int N_sym, int N_pre, int n_items,
                            int enable_tx_interleave, int n_frames, const jrc_cf32* d_frames, jrc_cf32* d_chanest,
                            void* stream);
+/* A6 + A7 + A1 fused: as jrc_radar_chanest_dev with TX rows d_tx [n_frames][T][n_items][fft_len] and time-domain RX streams
+ * d_rx_td [n_frames][R][rx_stream_len] (see jrc_chain_run_td_dev) */
+int  jrc_radar_chanest_td_dev(jrc_ctx* ctx, int fft_len, int cp_len, int N_tx, int N_rx, int N_sym, int N_pre, int n_items,
+                              long rx_stream_len, int enable_tx_interleave, int n_frames, const jrc_cf32* d_tx,
+                              const jrc_cf32* d_rx_td, jrc_cf32* d_chanest, void* stream);
 
 /* ---- A2/A4/A7  stock gr::fft::fft_vcc (FFTW3f in GNU Radio 3.8; flowgraph wiring
  *          examples/simulation/radar/mimo_ofdm_jrc_radar_sim.grc:877-1047) -------------------------
@@ -178,6 +183,16 @@ size_t jrc_chain_map_bytes(const jrc_chain* chain);       /* (fft_len*Ir) * (P*I
  * Asynchronous on `stream`. */
 int  jrc_chain_run_dev(jrc_chain* chain, int n_frames, const jrc_cf32* d_frames,
                        jrc_cf32* d_chanest, jrc_cf32* d_map, jrc_ra_result* d_results, void* stream);
+/* Same chain with the receive side handed over in the TIME domain: A6 (ofdm_cyclic_prefix_remover,
+ * lib/ofdm_cyclic_prefix_remover_impl.cc:69-99) + A7 (stock fft_vxx forward/shift, flowgraph `fft_vxx_0_0`) + A1 run as one
+ * kernel, so the frequency-domain RX symbols never go to HBM and the N_pre preamble symbols A1 skips are not transformed.
+ * d_tx   : [n_frames][T][n_items][fft_len] cf32   frequency-domain TX reference symbols (the TX ports of d_frames)
+ * d_rx_td: [n_frames][R][rx_stream_len] cf32      RX streams, symbol k of a stream at k*(fft_len+cp_len);
+ *                                                 rx_stream_len >= n_items*(fft_len+cp_len)
+ * Results agree with jrc_cp_remove_fft_dev + jrc_chain_run_dev to float rounding (1e-7 relative).  fft_len: power of two 16..1024, N_tx in {1,2,3,4,8};
+ * other shapes fail with JRC_ERR_UNSUPPORTED (run the two calls instead). */
+int  jrc_chain_run_td_dev(jrc_chain* chain, int n_frames, const jrc_cf32* d_tx, const jrc_cf32* d_rx_td, int cp_len,
+                          long rx_stream_len, jrc_cf32* d_chanest, jrc_cf32* d_map, jrc_ra_result* d_results, void* stream);
 /* D2H the results of the last run and complete snr_est / published on the host with libm's log10f
  * (bit-identical to the reference's std::log10, :227). Synchronises `stream`. */
 int  jrc_chain_fetch_results(jrc_chain* chain, int n_frames, const jrc_ra_result* d_results,

@@ -278,17 +278,119 @@ def test_chain_feed_refuses_overrun_and_bad_sizes(jrc, ctx):
     sc = synth.Scenario(64, 1, 1, 2, targets=[(9.0, 0.0, 0.0, 80.0)])
     feed = make_feed(jrc, ctx, sc, 8, 16, n_slots=2, frames_per_slot=4)
     fr = synth.make_frames(sc, 4)
-    with pytest.raises(jrc.JrcError):
+    with pytest.raises(ValueError):                        # std::invalid_argument in the reference's terms
         feed.submit(synth.make_frames(sc, 5))              # more than a slot holds
-    with pytest.raises(jrc.JrcError):
+    with pytest.raises(ValueError):
         feed.submit(None, 4)                               # nothing acquired
     feed.submit(fr)
     feed.submit(fr)
-    with pytest.raises(jrc.JrcError):
+    with pytest.raises(ValueError):
         feed.submit(fr)                                    # every slot in flight
-    with pytest.raises(jrc.JrcError):
+    with pytest.raises(ValueError):
         feed.acquire()
     a, _ = feed.collect()
     b, _ = feed.collect()
     assert len(a) == len(b) == 4 and all(getattr(a[i], k) == getattr(b[i], k) for i in range(4) for k in RES_KEYS)
     feed.close()
+
+
+def _td_case(jrc, ctx, T, R, N, cp, S, Npre, F, interleave, extra, seed):
+    """time-domain RX streams + frequency-domain TX rows -> H three ways: fused kernel, the two device calls, the oracle's blocks"""
+    import torch
+    rng = np.random.default_rng(seed)
+    n_items = Npre + S
+    L = n_items * (N + cp) + extra
+    tx = (rng.standard_normal((F, T, n_items, N)) + 1j * rng.standard_normal((F, T, n_items, N))).astype(np.complex64)
+    rx = (rng.standard_normal((F, R, L)) + 1j * rng.standard_normal((F, R, L))).astype(np.complex64)
+    d_tx = torch.from_numpy(tx.view(np.float32).reshape(F, T, n_items, N, 2)).cuda()
+    d_rx = torch.from_numpy(rx.view(np.float32).reshape(F, R, L, 2)).cuda()
+    H = torch.full((F, T * R, N, 2), float("nan"), dtype=torch.float32, device="cuda:0")
+    lib = ctx.lib
+    ctx.check(lib.jrc_radar_chanest_td_dev(ctx.h, N, cp, T, R, S, Npre, n_items, L, int(interleave), F, d_tx.data_ptr(),
+                                           d_rx.data_ptr(), H.data_ptr(), None))
+    ctx.sync()
+    Hf = H.cpu().numpy().view(np.complex64)[..., 0]
+    # the two separate device calls: A6+A7 per stream, then A1 on assembled frames
+    frames = torch.empty((F, T + R, n_items, N, 2), dtype=torch.float32, device="cuda:0")
+    frames[:, :T] = d_tx
+    rxf = torch.empty((F, R, n_items, N, 2), dtype=torch.float32, device="cuda:0")
+    for f in range(F):
+        for r in range(R):
+            ctx.check(lib.jrc_cp_remove_fft_dev(ctx.h, N, cp, n_items, d_rx[f, r].data_ptr(), rxf[f, r].data_ptr(), None))
+    ctx.sync()
+    frames[:, T:] = rxf
+    H2 = torch.empty_like(H)
+    ctx.check(lib.jrc_radar_chanest_dev(ctx.h, N, T, R, S, Npre, n_items, int(interleave), F, frames.data_ptr(), H2.data_ptr(), None))
+    ctx.sync()
+    Hu = H2.cpu().numpy().view(np.complex64)[..., 0]
+    return tx, rx, Hf, Hu, L
+
+
+@pytest.mark.parametrize("T,R,N,cp,S,Npre,F,interleave,extra", [
+    (4, 4, 256, 64, 8, 5, 3, False, 0),          # config-B shape: one frame per workgroup
+    (4, 2, 64, 16, 4, 5, 9, True, 0),            # reference example shape: 8 frames per workgroup, ragged last one
+    (2, 3, 1024, 256, 3, 1, 5, False, 0),        # one transform per workgroup, three workgroups per frame regrouped onto one XCD
+    (4, 4, 1024, 256, 2, 0, 11, False, 7),       # XCD-regrouped workgroups, grid rounded up past the last frame, padded streams
+    (1, 1, 16, 4, 5, 2, 6, False, 3),            # smallest size (first pass is followed by the last)
+    (3, 2, 128, 32, 6, 2, 4, True, 0),           # odd log2: leading radix-2 pass
+    (8, 2, 512, 0, 2, 0, 3, False, 0),           # no cyclic prefix, two transforms per workgroup, 8 TX
+    (2, 4, 32, 5, 7, 3, 10, False, 1),           # odd prefix length (8-byte aligned loads only)
+])
+def test_time_domain_channel_estimate_fused(jrc, ctx, T, R, N, cp, S, Npre, F, interleave, extra):
+    """A6 + A7 + A1 as one kernel against the separate device calls (same butterflies and accumulation order; only the compiler's
+    fused-multiply-add choices inside the complex products differ) and against the oracle's cyclic-prefix remover -> fft_vcc ->
+    mimo_ofdm_radar, both far inside the 1e-4 of the north star"""
+    tx, rx, Hf, Hu, L = _td_case(jrc, ctx, T, R, N, cp, S, Npre, F, interleave, extra, seed=N + T)
+    assert not np.isnan(Hf.view(np.float32)).any()
+    assert rel_err(Hf, Hu) < 1e-6 < MAP_TOL
+    rad = oracle.Radar(N, T, R, S, Npre, interp_factor=1, enable_tx_interleave=interleave)
+    n_items = Npre + S
+    for f in (0, F - 1):
+        rxf = []
+        for r in range(R):
+            sym = oracle.cp_remove(rx[f, r, :n_items * (N + cp)], N, cp)
+            rxf.append(oracle.fft_vcc(sym, True, True))
+        Ho = rad.work([tx[f, t] for t in range(T)], rxf)
+        assert rel_err(Hf[f], Ho[:, :N]) < FFT_TOL < MAP_TOL
+
+
+def test_chain_with_time_domain_receive_side(jrc, ctx):
+    """jrc_chain_run_td_dev against jrc_cp_remove_fft_dev + jrc_chain_run_dev: same peak cells, maps and powers to float rounding"""
+    import torch
+    from jrc_amd import synth
+    sc = synth.Scenario(64, 4, 2, 4, targets=[(9.0, 15.0, 0.0, 80.0)])
+    Ir, Ia, F = 8, 16, 5
+    n_items, N, cp = sc.Npre + sc.S, sc.N, sc.N // 4
+    fr = synth.make_frames(sc, F)                                   # frequency-domain frames
+    # time-domain RX streams whose demodulation gives back the RX ports: x = ifft(ifftshift(X)), prefix prepended
+    rxf = fr[:, sc.T:]
+    x = np.fft.ifft(np.fft.ifftshift(rxf, axes=-1), axis=-1).astype(np.complex64)
+    td = np.concatenate([x[..., N - cp:], x], axis=-1).reshape(F, sc.R, n_items * (N + cp))
+    d_tx = torch.from_numpy(np.ascontiguousarray(fr[:, :sc.T]).view(np.float32).reshape(F, sc.T, n_items, N, 2)).cuda()
+    d_td = torch.from_numpy(td.view(np.float32).reshape(F, sc.R, -1, 2)).cuda()
+    P = sc.T * sc.R
+    rb, ab = jrc.radar_axes(sc.N, sc.fs, Ir, P, Ia)
+    chain = jrc.RadarChain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb, ab, 2.4, 30.0, 15.0, 0.0, max_frames=F, ctx=ctx)
+    bufs = chain.alloc(F, "cuda:0")
+    chain.run_td(bufs, d_tx, d_td, F, cp)
+    res_td = chain.results(bufs, F)
+    map_td = bufs["map"].cpu().numpy().copy()
+    # unfused: demodulate into the RX ports of a frame buffer, then the frequency-domain chain
+    bufs["frames"][:, :sc.T] = d_tx
+    rx_tmp = torch.empty((F, sc.R, n_items, N, 2), dtype=torch.float32, device="cuda:0")
+    ctx.check(ctx.lib.jrc_cp_remove_fft_dev(ctx.h, N, cp, F * sc.R * n_items, d_td.data_ptr(), rx_tmp.data_ptr(), None))
+    ctx.sync()
+    bufs["frames"][:, sc.T:] = rx_tmp
+    torch.cuda.synchronize()
+    chain.run(bufs, F)
+    res = chain.results(bufs, F)
+    m_td, m_fd = map_td.view(np.complex64)[..., 0], bufs["map"].cpu().numpy().view(np.complex64)[..., 0]
+    assert rel_err(m_td, m_fd) < 1e-6 < MAP_TOL
+    for f in range(F):
+        for k in ("peak_range_idx", "peak_angle_idx", "angle_null_idx", "n_noise_samples", "published", "range_val", "angle_val"):
+            assert getattr(res_td[f], k) == getattr(res[f], k), (f, k)
+        for k in ("peak_power", "noise_power", "snr_est"):
+            assert abs(getattr(res_td[f], k) - getattr(res[f], k)) <= 1e-5 * abs(getattr(res[f], k)), (f, k)
+    assert abs(res[0].range_val - 9.0) < 0.5 and abs(res[0].angle_val - 15.0) < 3.0
+    with pytest.raises(ValueError):
+        chain.run_td(bufs, d_tx, d_td[:, :, :-8].contiguous(), F, cp)      # streams shorter than n_items symbols

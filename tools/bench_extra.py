@@ -53,10 +53,13 @@ def radar_with_demod(cfg="B", F=256):
         # A6+A7 for all F*R streams in one launch (n_symbols = F*R*n_items, symbols are contiguous per stream)
         ctx.check(L.jrc_cp_remove_fft_dev(ctx.h, sc.N, sc.cp, F * sc.R * n_items, td.data_ptr(), rx_tmp.data_ptr(), None))
         chain.run(bufs, F)
-    t = timed(step)
+    t_unfused = timed(step)
     t_chain = timed(lambda: chain.run(bufs, F))
-    return dict(what="radar chain incl. RX OFDM demod (A6+A7 fused) config %s" % cfg, frames_per_step=F,
-                ms_per_step=t * 1e3, frames_per_s=F / t, ms_chain_only=t_chain * 1e3, frames_per_s_chain_only=F / t_chain)
+    d_tx = bufs["frames"][:, :sc.T].contiguous()
+    t = timed(lambda: chain.run_td(bufs, d_tx, td, F, sc.cp))        # A6+A7+A1 in one kernel (jrc_chain_run_td_dev)
+    return dict(what="radar chain incl. RX OFDM demod (A6+A7+A1 one kernel, time-domain RX in) config %s" % cfg, frames_per_step=F,
+                ms_per_step=t * 1e3, frames_per_s=F / t, ms_per_step_separate_demod=t_unfused * 1e3,
+                frames_per_s_separate_demod=F / t_unfused, ms_chain_only=t_chain * 1e3, frames_per_s_chain_only=F / t_chain)
 
 
 def simulated_chain(cfg="B", F=64):
