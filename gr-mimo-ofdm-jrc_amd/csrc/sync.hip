@@ -706,6 +706,191 @@ __global__ __launch_bounds__(64) void fd_scan_all_kernel(FdParams p, const unsig
     if (lane == 0) *n_frames = nf;
 }
 
+// ---- the same scan, many waves --------------------------------------------------------------------------------------------
+// The detector's decisions depend on the past only through the open peak run (n_peaks, first) and through "SEARCH, or more than
+// ignore_gap samples copied since the last detection".  At a marked sample preceded by at least G = ignore_gap + max_peak_distance
+// + 2 unmarked ones both are known without any history: the peak run is stale (it is reset before it is used, :125-129 / :173-177)
+// and the last detection lies more than ignore_gap samples back (detections only happen at marked samples), so the next eligible
+// sample is a detection whatever the state was.  Such samples are anchors.  The capture is cut into segments of 4096 samples; the
+// wave of a segment starts the state machine at the segment's first anchor (wave 0: at sample 0, in SEARCH) and runs it — the very
+// code of the single-wave scan — until the first anchor at or beyond its segment's end, where the next wave has started.  The
+// pieces are disjoint, in order and together cover every detection, so: pass 1 counts the detections of every wave, pass 2 writes
+// them at the prefix sums of the counts, and a last kernel fills in the copy lengths (next detection - start, capped by
+// MAX_SAMPLES and the end of the capture).  A capture without quiet stretches has no anchors: wave 0 then walks it alone, as before.
+#define FD_SEG_WORDS 64
+
+template <bool WRITE>
+__global__ __launch_bounds__(64) void fd_scan_seg_kernel(FdParams p, const unsigned long long* __restrict__ marks, const float2* __restrict__ in_abs,
+                                                         int n, int G, int* __restrict__ counts, SfFrame* __restrict__ frames, int max_frames,
+                                                         int* __restrict__ overflow_start)
+{
+    const int lane = threadIdx.x, w = blockIdx.x;
+    const int n_words = (n + 63) >> 6;
+    const long seg_start = (long)w * FD_SEG_WORDS * 64;
+    const long seg_end = min((long)n, seg_start + (long)FD_SEG_WORDS * 64);
+    int out_idx = 0;
+    if (WRITE) {                                                 // detections of the waves before this one
+        int sum = 0;
+        for (int i = lane; i < w; i += 64) sum += counts[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+        out_idx = __builtin_amdgcn_readfirstlane(sum);
+        if (out_idx > max_frames) return;                        // everything from here on is beyond the caller's list
+    }
+    bool running = (w == 0), done = false;
+    long quiet = 0;                                              // unmarked samples immediately before the current position
+    int state = 0, copied = 0, nd = 0;
+    unsigned n_peaks = 0;
+    long first = 0;
+    int wb0 = 0;
+    if (w > 0) { wb0 = w * FD_SEG_WORDS - (G + 63) / 64; if (wb0 < 0) wb0 = 0; }
+    for (int wb = wb0; wb < n_words && !done; wb += 64) {
+        const int wi = wb + lane;
+        const unsigned long long mine = wi < n_words ? marks[wi] : 0ull;
+        const unsigned long long nz = __ballot(mine != 0ull);
+        for (int j = 0; j < 64 && wb + j < n_words && !done; j++) {
+            const int base = (wb + j) << 6;
+            const int cnt = min(64, n - base);
+            if (!running && base >= seg_end) { done = true; break; }             // no anchor in this segment: nothing to do
+            if (n_peaks == 0 && cnt == 64) {
+                // no peak run open: every word up to the next one with a peak bit only advances the counters
+                const unsigned long long rest = nz >> j;
+                int skip = rest ? __ffsll((long long)rest) - 1 : 64 - j;
+                if (wb + j + skip > n_words - 1) skip = max(0, n_words - 1 - (wb + j));
+                if (skip > 0) {
+                    if (state == 1) {
+                        const int room = (p.max_samples - copied) / 64;
+                        if (skip > room) skip = room;
+                    }
+                    if (skip > 0) {
+                        if (state == 1) { copied += 64 * skip; if (copied == p.max_samples) state = 0; }
+                        quiet += 64L * skip;
+                        j += skip - 1;
+                        continue;
+                    }
+                }
+            }
+            const unsigned long long word = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mine >> 32), j) << 32) |
+                                            (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mine & 0xffffffffull), j);
+            auto advance = [&](int k) {
+                if (state == 1 && k > 0) {
+                    const int take = min(k, p.max_samples - copied);
+                    copied += take;
+                    if (copied == p.max_samples) state = 0;
+                }
+            };
+            int pos = 0;
+            while (pos < cnt) {
+                const unsigned long long rem = word >> pos;
+                const int nm = rem ? pos + __ffsll((long long)rem) - 1 : cnt;
+                if (nm > pos) {
+                    if (n_peaks > 0 && (long)(base + nm - 1) - first > p.max_peak_distance) { n_peaks = 0; first = 0; }
+                    advance(nm - pos);
+                    quiet += nm - pos;
+                    pos = nm;
+                    if (pos == cnt) break;
+                }
+                const int i = base + pos;
+                const unsigned long long inv = ~rem;
+                int run = inv ? __ffsll((long long)inv) - 1 : 64;
+                if (run > cnt - pos) run = cnt - pos;
+                if (!running) {
+                    if (i >= seg_end) { done = true; break; }
+                    if (i >= seg_start && quiet >= G) { running = true; state = 0; copied = 0; n_peaks = 0; first = 0; }   // anchor: start here
+                    else { pos += run; quiet = 0; continue; }                                                              // still hunting
+                } else if (i >= seg_end && quiet >= G) { done = true; break; }                                             // the next piece starts here
+                quiet = 0;
+                if (state == 1 && run > p.max_samples - copied) run = p.max_samples - copied;
+                bool detect = false;
+                if (n_peaks < (unsigned)p.min_n_peaks) {
+                    const int k = min(run, p.min_n_peaks - (int)n_peaks);
+                    if (n_peaks == 0) first = i;
+                    n_peaks += (unsigned)k;
+                    advance(k); pos += k;
+                    continue;
+                } else if ((i - first) < p.max_peak_distance) {
+                    if (state == 0 || copied > p.ignore_gap) detect = true;
+                    else {
+                        int k = min(run, (int)(first + p.max_peak_distance - i));
+                        k = min(k, p.ignore_gap - copied + 1);
+                        advance(k); pos += k;
+                        continue;
+                    }
+                } else { n_peaks = 0; first = 0; }
+                if (detect) {
+                    if (WRITE) {
+                        const int idx = out_idx + nd;
+                        if (idx < max_frames) {
+                            const float2 av = in_abs[i];
+                            if (lane == 0) {
+                                SfFrame f; f.start = i; f.len = 0; f.coarse_cfo = (float)((double)atan2f(av.y, av.x) / (p.fft_len / 4.0));
+                                f.frame_start = 0; f.fine_cfo = 0.f; f.tag_value = 0; f.n_out = 0; f.pad_ = 0;
+                                frames[idx] = f;
+                            }
+                        } else {
+                            if (idx == max_frames && lane == 0) *overflow_start = i;
+                            done = true;
+                            break;
+                        }
+                    }
+                    nd++;
+                    state = 1; copied = 0;
+                    n_peaks = 1; first = i;
+                }
+                advance(1);
+                pos++;
+            }
+        }
+    }
+    if (!WRITE && lane == 0) counts[w] = nd;
+}
+
+__global__ __launch_bounds__(256) void fd_scan_finish_kernel(FdParams p, const int* __restrict__ counts, int n_seg, int n, SfFrame* __restrict__ frames,
+                                                             int max_frames, const int* __restrict__ overflow_start, int* __restrict__ n_frames)
+{
+    __shared__ int s_part[256];
+    int sum = 0;
+    for (int i = threadIdx.x; i < n_seg; i += 256) sum += counts[i];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) s_part[threadIdx.x] += s_part[threadIdx.x + off];
+        __syncthreads();
+    }
+    const int total = s_part[0];
+    const int nf = total < max_frames ? total : max_frames;
+    if (threadIdx.x == 0) *n_frames = nf;
+    for (int k = threadIdx.x; k < nf; k += 256) {
+        const int start = frames[k].start;
+        const int next = (k + 1 < nf) ? frames[k + 1].start : (total > max_frames ? *overflow_start : n);
+        int len = next - start;
+        if (len > p.max_samples) len = p.max_samples;
+        frames[k].len = len;
+    }
+}
+
+// list the frames of a capture: segment-parallel scan (JRC_FD_SERIAL=1: the single-wave scan, kept for cross-checks)
+static int launch_fd_scan(jrc_ctx* ctx, const FdParams& p, const unsigned long long* d_marks, const float2* d_abs, int n_samples, SfFrame* d_info,
+                          int max_frames, int* d_n_frames, hipStream_t s)
+{
+    const int n_seg = (n_samples + FD_SEG_WORDS * 64 - 1) / (FD_SEG_WORDS * 64);
+    if (n_seg <= 1 || getenv("JRC_FD_SERIAL")) {
+        hipLaunchKernelGGL(fd_scan_all_kernel, dim3(1), dim3(64), 0, s, p, d_marks, d_abs, n_samples, d_info, max_frames, d_n_frames);
+        JRC_HIP(ctx, hipGetLastError());
+        return JRC_OK;
+    }
+    JRC_TRY(jrc_ensure_scratch(ctx, 3, sizeof(int) * ((size_t)n_seg + 16)));
+    int* counts = (int*)ctx->scratch[3];
+    int* overflow = counts + n_seg;
+    const int G = p.ignore_gap + p.max_peak_distance + 2;
+    hipLaunchKernelGGL(fd_scan_seg_kernel<false>, dim3(n_seg), dim3(64), 0, s, p, d_marks, d_abs, n_samples, G, counts, d_info, max_frames, overflow);
+    hipLaunchKernelGGL(fd_scan_seg_kernel<true>, dim3(n_seg), dim3(64), 0, s, p, d_marks, d_abs, n_samples, G, counts, d_info, max_frames, overflow);
+    hipLaunchKernelGGL(fd_scan_finish_kernel, dim3(1), dim3(256), 0, s, p, (const int*)counts, n_seg, n_samples, d_info, max_frames, (const int*)overflow,
+                       d_n_frames);
+    JRC_HIP(ctx, hipGetLastError());
+    return JRC_OK;
+}
+
 __global__ __launch_bounds__(256) void sf_frames_kernel(const float2* __restrict__ xd, int n, const float2* __restrict__ taps, int ntaps,
                                                         int sync_length, int N, int cp, SfFrame* __restrict__ frames, const int* __restrict__ n_frames,
                                                         float2* __restrict__ out, long out_stride /* samples per row */)
@@ -788,8 +973,7 @@ extern "C" int jrc_sync_frontend_dev(jrc_ctx* ctx, const jrc_sync_cfg* c, int n_
     p.max_peak_distance = 2 * (c->fft_len + c->cp_len); p.max_samples = 540 * (c->fft_len + c->cp_len);
     const int nblk = (n_samples + 63 + 255) / 256;
     hipLaunchKernelGGL(fd_marks_kernel, dim3(nblk > 0 ? nblk : 1), dim3(256), 0, s, (const float*)d_cor, d_marks, n_samples, p.threshold, p.max_peak_value);
-    hipLaunchKernelGGL(fd_scan_all_kernel, dim3(1), dim3(64), 0, s, p, (const unsigned long long*)d_marks, (const float2*)d_abs, n_samples,
-                       (SfFrame*)d_info, max_frames, d_n_frames);
+    JRC_TRY(launch_fd_scan(ctx, p, (const unsigned long long*)d_marks, (const float2*)d_abs, n_samples, (SfFrame*)d_info, max_frames, d_n_frames, s));
     const size_t lds = sizeof(float2) * ((size_t)2 * c->sync_length + c->n_taps - 1);
     hipLaunchKernelGGL(sf_frames_kernel, dim3(max_frames), dim3(256), lds, s, (const float2*)d_xd, n_samples, (const float2*)c->d_ltf_taps, c->n_taps,
                        c->sync_length, c->fft_len, c->cp_len, (SfFrame*)d_info, (const int*)d_n_frames, (float2*)d_frames, (long)max_symbols * c->fft_len);
@@ -809,8 +993,7 @@ extern "C" int jrc_frame_detector_scan_dev(jrc_ctx* ctx, int fft_len, int cp_len
     p.max_peak_distance = 2 * (fft_len + cp_len); p.max_samples = 540 * (fft_len + cp_len);
     const int nblk = (n_samples + 63 + 255) / 256;
     hipLaunchKernelGGL(fd_marks_kernel, dim3(nblk > 0 ? nblk : 1), dim3(256), 0, s, d_in_cor, d_marks, n_samples, p.threshold, p.max_peak_value);
-    hipLaunchKernelGGL(fd_scan_all_kernel, dim3(1), dim3(64), 0, s, p, (const unsigned long long*)d_marks, (const float2*)d_in_abs, n_samples,
-                       (SfFrame*)d_info, max_frames, d_n_frames);
+    JRC_TRY(launch_fd_scan(ctx, p, (const unsigned long long*)d_marks, (const float2*)d_in_abs, n_samples, (SfFrame*)d_info, max_frames, d_n_frames, s));
     JRC_HIP(ctx, hipGetLastError());
     return JRC_OK;
 }

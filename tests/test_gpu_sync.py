@@ -166,16 +166,29 @@ def test_batched_front_end_equals_the_block_chain(jrc, ctx, ofdm64):
 @pytest.mark.parametrize("seed,density,min_peaks,gap", [(0, 0.02, 10, 640), (1, 0.3, 10, 640), (2, 0.9, 10, 100), (3, 0.5, 1, 0), (4, 0.97, 3, 50000),
                                                           (5, 0.6, 0, 200), (6, 0.999, 10, 640)])
 def test_run_to_completion_scan_equals_the_call_by_call_detector(jrc, ctx, seed, density, min_peaks, gap):
-    """the wave-cooperative scan (word skipping, run skipping) against the oracle's sample-by-sample state machine on random
-    peak patterns, incl. bursts longer than MAX_SAMPLES and peak values at and above MAX_PEAK_VALUE"""
+    """the segment-parallel, wave-cooperative scan (word skipping, run skipping, one wave per 4096-sample segment starting at its first
+    history-free sample) against the oracle's sample-by-sample state machine on random peak patterns, incl. bursts longer than
+    MAX_SAMPLES, peak values at and above MAX_PEAK_VALUE, an ignore_gap longer than several segments, and captures without quiet stretches"""
+    _scan_case(jrc, ctx, seed, density, min_peaks, gap, 4096, 3000)
+
+
+@pytest.mark.parametrize("seed,density,min_peaks,gap,max_frames,max_quiet", [(10, 0.5, 10, 640, 7, 3000), (11, 0.9, 10, 640, 1, 9000), (12, 0.8, 5, 300, 23, 20000),
+                                                                             (13, 0.7, 10, 640, 4096, 12), (14, 0.9, 10, 640, 4096, 60000)])
+def test_scan_with_a_short_frame_list_and_other_spacings(jrc, ctx, seed, density, min_peaks, gap, max_frames, max_quiet):
+    """the caller's list ends before the capture does (the last listed frame's length runs to the detection that did not fit); bursts
+    12 samples apart (no quiet stretch anywhere: one wave walks the capture) and up to 60000 apart (most segments empty)"""
+    _scan_case(jrc, ctx, seed, density, min_peaks, gap, max_frames, max_quiet)
+
+
+def _scan_case(jrc, ctx, seed, density, min_peaks, gap, max_frames, max_quiet):
     import ctypes as C
     import torch
     rng = np.random.default_rng(seed)
-    n = 120_000
+    n = 200_000
     ic = np.zeros(n, np.float32)
     pos = 0
     while pos < n:                                                       # alternating quiet stretches and peak bursts
-        pos += int(rng.integers(1, 3000))
+        pos += int(rng.integers(1, max_quiet))
         blen = int(rng.integers(1, 400))
         burst = (rng.random(blen) < density).astype(np.float32) * rng.choice([0.7, 0.7, 0.7, 2.0, 3.0], blen).astype(np.float32)
         ic[pos:pos + blen] = burst[:max(0, min(blen, n - pos))]
@@ -189,15 +202,15 @@ def test_run_to_completion_scan_equals_the_call_by_call_detector(jrc, ctx, seed,
     d_ia = torch.from_numpy(ia.view(np.float32).copy()).cuda()
     d_ic = torch.from_numpy(ic).cuda()
     d_marks = torch.zeros(n // 64 + 2, dtype=torch.int64, device="cuda")
-    d_info = torch.zeros((4096, C.sizeof(jrc.SyncFrame)), dtype=torch.uint8, device="cuda")
+    d_info = torch.zeros((max_frames, C.sizeof(jrc.SyncFrame)), dtype=torch.uint8, device="cuda")
     d_n = torch.zeros(1, dtype=torch.int32, device="cuda")
-    ctx.check(L.jrc_frame_detector_scan_dev(ctx.h, N, CP, 0.6, min_peaks, gap, n, d_ia.data_ptr(), d_ic.data_ptr(), d_marks.data_ptr(), 4096,
+    ctx.check(L.jrc_frame_detector_scan_dev(ctx.h, N, CP, 0.6, min_peaks, gap, n, d_ia.data_ptr(), d_ic.data_ptr(), d_marks.data_ptr(), max_frames,
                                             d_info.data_ptr(), d_n.data_ptr(), None))
     ctx.sync()
     nf = int(d_n.cpu().item())
     raw = d_info[:nf].cpu().numpy().tobytes()
     info = [jrc.SyncFrame.from_buffer_copy(raw[i * C.sizeof(jrc.SyncFrame):(i + 1) * C.sizeof(jrc.SyncFrame)]) for i in range(nf)]
-    assert nf == len(tags)
+    assert nf == min(len(tags), max_frames)
     offs = [t[0] for t in tags] + [out.size]
     for k, f in enumerate(info):
         assert f.len == offs[k + 1] - offs[k], k
