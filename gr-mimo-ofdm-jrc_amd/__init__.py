@@ -624,6 +624,7 @@ def _load_comm():
         L.jrc_precoder_destroy.argtypes = [_vp]
         L.jrc_precoder_output_length.argtypes = [_vp, C.c_int]
         L.jrc_precoder_work.argtypes = [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.POINTER(_vp)]
+        L.jrc_precoder_frames_dev.argtypes = [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]
         L.jrc_n_ofdm_sym.argtypes = [C.c_int, C.c_int, C.c_int]
         L.jrc_sig_encode.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _cfp]
         L._comm_ready = True
@@ -780,6 +781,23 @@ class mimo_precoder:
         self.ctx.check(st)
         assert st == n_total
         return out
+
+    def frames_dev(self, d_in, mcs, packet_type, pdu_len, steer_mode=0, d_Q_mean=None, d_Q_sc=None, d_radar_streams=None, d_out=None,
+                   stream=None):
+        """batched, device-resident: d_in torch float32 [n_frames, n_sym*n_data, 2]; Q matrices torch, already column-major per
+        matrix ([T*T, 2] / [fft_len, T*T, 2]); returns torch [n_frames, T, n_total, fft_len, 2] (asynchronous on `stream`)"""
+        import torch
+        F, nin = d_in.shape[0], d_in.shape[1]
+        n_total = nin // self.n_data + self.n_sync + self.T + 1
+        if d_out is None:
+            d_out = torch.empty((F, self.T, n_total, self.N, 2), dtype=torch.float32, device=d_in.device)
+        ptr = lambda t: None if t is None else t.data_ptr()
+        st = self.ctx.lib.jrc_precoder_frames_dev(self.h, F, nin, d_in.data_ptr(), mcs, packet_type, pdu_len, steer_mode, ptr(d_Q_mean),
+                                                  ptr(d_Q_sc), ptr(d_radar_streams), d_out.data_ptr(), stream)
+        if st == -8:
+            raise RuntimeError(self.ctx.lib.jrc_last_error(self.ctx.h).decode())   # std::runtime_error (:327-333)
+        self.ctx.check(st)
+        return d_out
 
     def close(self):
         if getattr(self, "h", None):

@@ -787,12 +787,16 @@ struct PreDev {
 __global__ __launch_bounds__(256) void precoder_kernel(PreDev d, const float2* __restrict__ in, const float* __restrict__ sig,
                                                        int n_sym, int packet_type, int steer_mode,
                                                        const float2* __restrict__ Qm, const float2* __restrict__ Qsc,
-                                                       const float2* __restrict__ rs, float2* __restrict__ out /* [T][n_total][N] */)
+                                                       const float2* __restrict__ rs, float2* __restrict__ out /* [T][n_total][N] */,
+                                                       size_t in_stride, size_t rs_stride, size_t out_stride /* per frame (blockIdx.y) */)
 {
     const int N = d.N, T = d.T, NL = d.T;
     const int n_total = n_sym + d.NS + T + 1;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)n_total * N) return;
+    in += (size_t)blockIdx.y * in_stride;
+    if (rs) rs += (size_t)blockIdx.y * rs_stride;
+    out += (size_t)blockIdx.y * out_stride;
     const int k = (int)(idx / N), sc = (int)(idx % N);
     const short role = d.role[sc];
     float2 o[8];
@@ -841,12 +845,133 @@ __global__ __launch_bounds__(256) void precoder_kernel(PreDev d, const float2* _
     for (int t = 0; t < T; t++) out[((size_t)t * n_total + k) * N + sc] = o[t];
 }
 
+// The same cell arithmetic with the steering matrix of the lane's subcarrier held in registers: one lane per subcarrier, the four
+// waves of a workgroup (times gridDim.y workgroups) walk the OFDM symbols, so Q[sc] — T*T values at a 8*T*T-byte stride between
+// lanes, the one uncoalesced read of the block — is fetched once per lane instead of once per cell, and every store and every
+// radar-stream load is a full 512-byte wave access.  N_tx in {1, 2, 4, 8}; other sizes run precoder_kernel.
+template <int T>
+__global__ __launch_bounds__(256) void precoder_frames_kernel(PreDev d, const float2* __restrict__ in, const float* __restrict__ sig,
+                                                              int n_sym, int packet_type, int steer_mode,
+                                                              const float2* __restrict__ Qm, const float2* __restrict__ Qsc,
+                                                              const float2* __restrict__ rs, float2* __restrict__ out,
+                                                              size_t in_stride, size_t rs_stride, size_t out_stride)
+{
+    const int N = d.N, NL = T;
+    const int n_total = n_sym + d.NS + T + 1;
+    const int sc = blockIdx.x * 64 + (threadIdx.x & 63);
+    if (sc >= N) return;
+    in += (size_t)blockIdx.z * in_stride;
+    if (rs) rs += (size_t)blockIdx.z * rs_stride;
+    out += (size_t)blockIdx.z * out_stride;
+    const short role = d.role[sc];
+    float2 q[T * T];
+    {
+        const float2* Q = steer_mode == 2 ? Qsc + (size_t)sc * T * T : Qm;
+#pragma unroll
+        for (int i = 0; i < T * T; i++) q[i] = Q[i];
+    }
+    const int kstep = 4 * gridDim.y;
+    for (int k = blockIdx.y * 4 + (threadIdx.x >> 6); k < n_total; k += kstep) {
+        float2 o[T];
+#pragma unroll
+        for (int t = 0; t < T; t++) o[t] = make_float2(0.f, 0.f);                         // memset :337
+        if (k < d.NS) {                                                                   // sync words, ports 0,1 only :340-347
+            const float2 v = d.sync[(size_t)k * N + sc];
+#pragma unroll
+            for (int t = 0; t < T && t < 2; t++) o[t] = v;
+        } else if (k == d.NS) {                                                           // SIG :353-371
+            float2 v = make_float2(0.f, 0.f);
+            if (role >= 0 && !(role & 0x4000)) v = make_float2(sig[role], 0.f);
+            else if (role >= 0) v = d.pilot_sym[role & 0x3fff];
+#pragma unroll
+            for (int t = 0; t < T && t < 2; t++) o[t] = v;
+        } else if (k < d.NS + 1 + T) {                                                    // MIMO-LTFs
+            const int l = k - d.NS - 1;
+            const float2* X = d.mapped + (size_t)sc * T * NL;                             // row-major T x NL
+            if (packet_type == 1) {                                                       // NDP :379-388
+#pragma unroll
+                for (int t = 0; t < T; t++) o[t] = X[t * NL + l];
+            } else {                                                                      // DATA :536-581
+                bool zero = true;
+                for (int i = 0; i < T * NL; i++) if (X[i].x != 0.f || X[i].y != 0.f) zero = false;
+                if (!zero) {
+#pragma unroll
+                    for (int t = 0; t < T; t++) {
+                        float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+                        for (int j = 0; j < T; j++) acc = cadd(acc, cmul(q[j * T + t], X[j * NL + l]));
+                        o[t] = acc;
+                    }
+                }
+            }
+        } else if (role >= 0) {                                                           // data / pilot carriers
+            const int m = k - d.NS - 1 - T;
+            float2 s0;
+            if (role & 0x4000) s0 = d.pilot_sym[(size_t)(m % d.n_pilot_rows) * d.NP + (role & 0x3fff)];
+            else s0 = in[(size_t)m * d.ND + role];
+            if (packet_type == 1) {                                                       // NDP :394-428
+#pragma unroll
+                for (int t = 0; t < T && t < 2; t++) o[t] = s0;
+            } else {                                                                      // DATA :589-712
+                float2 r[T];
+                if (rs) {
+#pragma unroll
+                    for (int j = 1; j < T; j++) r[j] = rs[((size_t)(j - 1) * n_sym + m) * N + sc];
+                }
+#pragma unroll
+                for (int t = 0; t < T; t++) {
+                    float2 acc = cmul(q[t], s0);                                          // column 0 = the data stream
+                    if (rs) {
+#pragma unroll
+                        for (int j = 1; j < T; j++) acc = cadd(acc, cmul(q[j * T + t], r[j]));
+                    }
+                    o[t] = acc;
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < T; t++) out[((size_t)t * n_total + k) * N + sc] = o[t];
+    }
+}
+
+// one launch for n_frames packets (gridDim.z / gridDim.y = frame); k_blocks workgroups share a packet's symbols
+static int launch_precoder(jrc_ctx* ctx, const PreDev& d, int n_frames, int k_blocks, const float2* in, const float* sig, int n_sym, int packet_type,
+                           int steer_mode, const float2* Qm, const float2* Qsc, const float2* rs, float2* out, hipStream_t s)
+{
+    const int N = d.N, T = d.T;
+    const int n_total = n_sym + d.NS + T + 1;
+    const size_t total = (size_t)n_total * N;
+    const size_t in_stride = (size_t)n_sym * d.ND, rs_stride = (size_t)(T - 1) * n_sym * N, out_stride = (size_t)T * n_total * N;
+    for (int f0 = 0; f0 < n_frames; f0 += 65535) {
+        const int nf = n_frames - f0 < 65535 ? n_frames - f0 : 65535;
+        const float2* in_f = in + (size_t)f0 * in_stride;
+        const float2* rs_f = rs ? rs + (size_t)f0 * rs_stride : nullptr;
+        float2* out_f = out + (size_t)f0 * out_stride;
+        const dim3 g((unsigned)((N + 63) / 64), (unsigned)k_blocks, (unsigned)nf), b(256);
+        switch (T) {
+            case 1: hipLaunchKernelGGL(precoder_frames_kernel<1>, g, b, 0, s, d, in_f, sig, n_sym, packet_type, steer_mode, Qm, Qsc, rs_f, out_f, in_stride, rs_stride, out_stride); break;
+            case 2: hipLaunchKernelGGL(precoder_frames_kernel<2>, g, b, 0, s, d, in_f, sig, n_sym, packet_type, steer_mode, Qm, Qsc, rs_f, out_f, in_stride, rs_stride, out_stride); break;
+            case 4: hipLaunchKernelGGL(precoder_frames_kernel<4>, g, b, 0, s, d, in_f, sig, n_sym, packet_type, steer_mode, Qm, Qsc, rs_f, out_f, in_stride, rs_stride, out_stride); break;
+            case 8: hipLaunchKernelGGL(precoder_frames_kernel<8>, g, b, 0, s, d, in_f, sig, n_sym, packet_type, steer_mode, Qm, Qsc, rs_f, out_f, in_stride, rs_stride, out_stride); break;
+            default:
+                hipLaunchKernelGGL(precoder_kernel, dim3((unsigned)((total + 255) / 256), (unsigned)nf), dim3(256), 0, s, d, in_f, sig, n_sym, packet_type,
+                                   steer_mode, Qm, Qsc, rs_f, out_f, in_stride, rs_stride, out_stride);
+        }
+    }
+    JRC_HIP(ctx, hipGetLastError());
+    return JRC_OK;
+}
+
 struct jrc_precoder {
     jrc_ctx* ctx;
     PreDev d;
     void* tables = nullptr;
     float2 dft[64];
     std::vector<int> dc, pc;
+    // batched entry point: SIG field of the last (mcs, packet_type, pdu_len) and the DFT matrix, on the device
+    float* d_sig = nullptr;
+    float2* d_dft = nullptr;
+    int sig_key[3] = {-1, -1, -1};
 };
 
 extern "C" int jrc_precoder_create(jrc_ctx* ctx, const jrc_pre_cfg* c, jrc_precoder** out)
@@ -907,6 +1032,8 @@ extern "C" void jrc_precoder_destroy(jrc_precoder* p)
     if (!p) return;
     (void)hipStreamSynchronize(p->ctx->stream);
     if (p->tables) (void)hipFree(p->tables);
+    if (p->d_sig) (void)hipFree(p->d_sig);
+    if (p->d_dft) (void)hipFree(p->d_dft);
     delete p;
 }
 
@@ -950,15 +1077,55 @@ extern "C" int jrc_precoder_work(jrc_precoder* p, int ninput_items, const jrc_cf
     if (b_rs) memcpy(hp + b_in + b_sig + b_qm + b_qsc, radar_streams, b_rs);
     JRC_HIP(ctx, hipMemcpyAsync(ctx->scratch[0], hp, b_up, hipMemcpyHostToDevice, ctx->stream));
     unsigned char* dp = (unsigned char*)ctx->scratch[0];
-    const size_t total = (size_t)n_total * N;
-    hipLaunchKernelGGL(precoder_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, p->d,
-                       (const float2*)dp, (const float*)(dp + b_in), n_sym, packet_type, steer_mode,
-                       (const float2*)(dp + b_in + b_sig), b_qsc ? (const float2*)(dp + b_in + b_sig + b_qm) : nullptr,
-                       b_rs ? (const float2*)(dp + b_in + b_sig + b_qm + b_qsc) : nullptr, (float2*)ctx->scratch[1]);
-    JRC_HIP(ctx, hipGetLastError());
+    // one packet: spread its symbols over up to 16 workgroups per subcarrier tile
+    int kb = (n_total + 3) / 4; if (kb > 16) kb = 16;
+    JRC_TRY(launch_precoder(ctx, p->d, 1, kb, (const float2*)dp, (const float*)(dp + b_in), n_sym, packet_type, steer_mode,
+                            (const float2*)(dp + b_in + b_sig), b_qsc ? (const float2*)(dp + b_in + b_sig + b_qm) : nullptr,
+                            b_rs ? (const float2*)(dp + b_in + b_sig + b_qm + b_qsc) : nullptr, (float2*)ctx->scratch[1], ctx->stream));
     JRC_HIP(ctx, hipMemcpyAsync(hp, ctx->scratch[1], b_out, hipMemcpyDeviceToHost, ctx->stream));
     JRC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int t = 0; t < T; t++) memcpy(out[t], hp + sizeof(float2) * (size_t)t * n_total * N, sizeof(float2) * (size_t)n_total * N);
+    return n_total;
+}
+
+// Batched, device-resident C2: n_frames packets of one (mcs, packet_type, pdu_len) per launch, symbols in and port buffers out in
+// HBM; grid.y = frame.  Same kernel, same arithmetic as jrc_precoder_work.
+extern "C" int jrc_precoder_frames_dev(jrc_precoder* p, int n_frames, int ninput_items, const jrc_cf32* d_in, int mcs, int packet_type,
+                                       int pdu_len, int steer_mode, const jrc_cf32* d_Q_mean, const jrc_cf32* d_Q_sc,
+                                       const jrc_cf32* d_radar_streams, jrc_cf32* d_out, void* stream)
+{
+    if (!p || !d_in || !d_out || n_frames < 0) return JRC_ERR_INVALID_ARG;
+    jrc_ctx* ctx = p->ctx;
+    const PreDev& d = p->d;
+    const int T = d.T;
+    if (packet_type != 1 && packet_type != 2)
+        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "[MIMO PRECODER] packet type is not defined!");              // :716-719
+    if (mcs < 0 || mcs > 5) return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "[MIMO PRECODER] unknown mcs");
+    const int n_sym = ninput_items / d.ND;
+    if (n_ofdm_sym_dev(mcs, d.ND, pdu_len) != n_sym)
+        return jrc_fail(ctx, JRC_ERR_SIG_FIELD, "%s", jrc_strerror(JRC_ERR_SIG_FIELD));                         // :327-333
+    if (steer_mode < 0 || steer_mode > 2 || (steer_mode == 1 && !d_Q_mean) || (steer_mode == 2 && !d_Q_sc))
+        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "mimo_precoder: steering matrices missing for steer_mode %d", steer_mode);
+    if (n_frames == 0) return 0;
+    JRC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    if (!p->d_sig) {
+        JRC_HIP(ctx, hipMalloc((void**)&p->d_sig, sizeof(float) * (size_t)d.ND));
+        JRC_HIP(ctx, hipMalloc((void**)&p->d_dft, sizeof(float2) * (size_t)T * T));
+        JRC_HIP(ctx, hipMemcpy(p->d_dft, p->dft, sizeof(float2) * (size_t)T * T, hipMemcpyHostToDevice));
+    }
+    if (p->sig_key[0] != mcs || p->sig_key[1] != packet_type || p->sig_key[2] != pdu_len) {                    // generate_signal_field, once per format
+        std::vector<float> sig((size_t)d.ND);
+        JRC_TRY(jrc_sig_encode(d.ND, mcs, packet_type, pdu_len, sig.data()));
+        JRC_HIP(ctx, hipStreamSynchronize(s));                                                                  // earlier launches may still read the old field
+        JRC_HIP(ctx, hipMemcpy(p->d_sig, sig.data(), sizeof(float) * (size_t)d.ND, hipMemcpyHostToDevice));
+        p->sig_key[0] = mcs; p->sig_key[1] = packet_type; p->sig_key[2] = pdu_len;
+    }
+    const int n_total = n_sym + d.NS + T + 1;
+    JRC_TRY(launch_precoder(ctx, p->d, n_frames, n_frames >= 64 ? 1 : 4, (const float2*)d_in, (const float*)p->d_sig, n_sym, packet_type, steer_mode,
+                            steer_mode == 1 ? (const float2*)d_Q_mean : (const float2*)p->d_dft, steer_mode == 2 ? (const float2*)d_Q_sc : nullptr,
+                            (const float2*)d_radar_streams, (float2*)d_out, s));
+    JRC_HIP(ctx, hipGetLastError());
     return n_total;
 }
 

@@ -323,6 +323,13 @@ int  jrc_precoder_work(jrc_precoder* pre, int ninput_items, const jrc_cf32* in, 
                        int pdu_len, int steer_mode, const jrc_cf32* Q_mean, const jrc_cf32* Q_sc,
                        const jrc_cf32* radar_streams, jrc_cf32* const* out);
 
+/* batched, device-resident: n_frames packets of one format per launch.  d_in [n_frames][ninput_items], d_radar_streams NULL or
+ * [n_frames][T-1][n_sym][fft_len], d_out [n_frames][T][n_sync + 1 + N_tx + n_sym][fft_len]; Q matrices on the device (column-major,
+ * shared by all frames).  Asynchronous on `stream`; returns items per port per frame. */
+int  jrc_precoder_frames_dev(jrc_precoder* pre, int n_frames, int ninput_items, const jrc_cf32* d_in, int mcs, int packet_type,
+                             int pdu_len, int steer_mode, const jrc_cf32* d_Q_mean, const jrc_cf32* d_Q_sc,
+                             const jrc_cf32* d_radar_streams, jrc_cf32* d_out, void* stream);
+
 /* SIG-field helpers shared by C1/C2 (host side; lib/utils.cc:26-111, lib/mimo_precoder_impl.cc:985-1060) */
 int  jrc_n_ofdm_sym(int mcs, int n_data_carriers, int data_size_byte);
 int  jrc_sig_encode(int n_data_carriers, int mcs, int packet_type, int length, float* out_re);

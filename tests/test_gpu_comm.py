@@ -238,3 +238,52 @@ def test_config_c_equalizer_and_precoder_256_subcarriers_64_symbols(jrc, ctx, es
     if steer != "sc" and est == LS:
         ref = s.reshape(S, nd)                                      # and the frame really decodes: QPSK decisions match
         assert np.mean((np.sign(g["out"].real) == np.sign(ref.real)) & (np.sign(g["out"].imag) == np.sign(ref.imag))) > 0.999
+
+
+@pytest.mark.parametrize("ptype,steer", [(NDP, "dft"), (DATA, "dft"), (DATA, "mean"), (DATA, "sc"), (DATA, "radar")])
+def test_precoder_batched_device_resident(jrc, ctx, ptype, steer):
+    """jrc_precoder_frames_dev: a batch of config-C packets (4 TX, 256 subcarriers, 64 data symbols) in one launch, symbols in and
+    port buffers out in HBM, equals the per-packet work() bit for bit and the oracle within 1e-6; format change between calls"""
+    import torch
+    N, T, S, F = 256, 4, 64, 5
+    rng = np.random.default_rng(21)
+    data, pilots, pil, ltf, mapped, sync = config_c_tables(N, T)
+    nd, mcs = len(data), 2
+    nbytes = (S * nd - 22) // 8
+    gp = jrc.mimo_precoder(N, T, 1, data, pilots, pil, sync, mapped, ctx=ctx)
+    op = oracle.Precoder(N, T, 1, data, pilots, pil, sync, mapped)
+    s = np.stack([qpsk(rng, S * nd) for _ in range(F)])
+    kw, dkw = {}, {}
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.float32).reshape(a.shape + (2,))).cuda()
+    if steer in ("mean", "radar"):
+        Q = oracle.steering_from_channel(crandn(rng, T))
+        kw = dict(steer_mode=1, Q_mean=Q)
+        dkw = dict(steer_mode=1, d_Q_mean=up(np.ascontiguousarray(Q.T).reshape(-1)))                 # column-major
+    if steer == "sc":
+        Q = np.stack([oracle.steering_from_channel(crandn(rng, T)) for _ in range(N)])
+        kw = dict(steer_mode=2, Q_sc=Q)
+        dkw = dict(steer_mode=2, d_Q_sc=up(np.ascontiguousarray(np.transpose(Q, (0, 2, 1))).reshape(N, -1)))
+    rs = None
+    if steer == "radar":
+        rs = np.stack([qpsk(rng, (T - 1) * S * N).reshape(T - 1, S, N) for _ in range(F)])
+        dkw["d_radar_streams"] = up(rs)
+    out = gp.frames_dev(up(s), mcs, ptype, nbytes, **dkw)
+    ctx.sync()
+    got = out.cpu().numpy().view(np.complex64)[..., 0]
+    assert got.shape == (F, T, S + 9, N)
+    for f in range(F):
+        kwf = dict(kw)
+        if rs is not None:
+            kwf["radar_streams"] = rs[f]
+        assert np.array_equal(got[f], gp.work(s[f], mcs, ptype, nbytes, **kwf))
+        if f in (0, F - 1):
+            assert rel_err(got[f], op.work(s[f], mcs, ptype, nbytes, **kwf)) < 1e-6
+    # another format on the same block: the cached SIG field is rebuilt
+    nb2 = nbytes - 3 * nd // 8 - 40
+    S2 = oracle.n_ofdm_sym(mcs, nd, nb2)
+    s2 = np.stack([qpsk(rng, S2 * nd) for _ in range(2)])
+    dkw.pop("d_radar_streams", None)
+    got2 = gp.frames_dev(up(s2), mcs, ptype, nb2, **dkw).cpu().numpy().view(np.complex64)[..., 0]
+    assert np.array_equal(got2[1], gp.work(s2[1], mcs, ptype, nb2, **kw))
+    with pytest.raises(RuntimeError, match="MIMO PRECODER"):
+        gp.frames_dev(up(s2), mcs, ptype, nbytes, **dkw)

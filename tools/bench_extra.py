@@ -119,6 +119,36 @@ def comm_rx_chain(n_frames=4096):
     return json.loads([l for l in out if l.startswith("{")][-1])
 
 
+def precoder_config_c(n_frames=2048):
+    """C2 batched: 4 TX, 256 subcarriers, 64 data symbols per packet, DATA, per-subcarrier steering + 3 radar streams"""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    N, T, S = 256, 4, 64
+    rng = np.random.default_rng(0)
+    guard = N // 16
+    act = [c for c in range(-N // 2 + guard, N // 2 - guard + 1) if c != 0]
+    pilots = [c for c in act if c % 32 == 16][:8]
+    data = [c for c in act if c not in pilots]
+    ltf = np.zeros(N, np.complex64)
+    ltf[np.array(act) + N // 2] = rng.choice([-1.0, 1.0], len(act))
+    mapped = np.stack([(synth.hadamard(T) * ltf[sc]).reshape(-1) for sc in range(N)]).astype(np.complex64)
+    pil = np.array([[1, 1, 1, -1, 1, 1, 1, -1], [-1, -1, -1, 1, -1, -1, -1, 1], [1, 1, 1, -1, 1, 1, 1, -1]], np.complex64)[:, :len(pilots)]
+    sync = np.stack([ltf, ltf, ltf, ltf])
+    nd = len(data)
+    nbytes = (S * nd - 22) // 8
+    ctx = jrc_amd.Context(0)
+    pre = jrc_amd.mimo_precoder(N, T, 1, data, pilots, pil, sync, mapped, ctx=ctx)
+    d_in = torch.randn((n_frames, S * nd, 2), dtype=torch.float32, device="cuda:0")
+    d_rs = torch.randn((n_frames, T - 1, S, N, 2), dtype=torch.float32, device="cuda:0")
+    d_q = torch.randn((N, T * T, 2), dtype=torch.float32, device="cuda:0")
+    d_out = torch.empty((n_frames, T, S + 9, N, 2), dtype=torch.float32, device="cuda:0")
+    out = {}
+    for name, kw in (("dft", {}), ("per-subcarrier steering + radar streams", dict(steer_mode=2, d_Q_sc=d_q, d_radar_streams=d_rs))):
+        t = timed(lambda: pre.frames_dev(d_in, 2, 2, nbytes, d_out=d_out, **kw), steps=20, warm=3)
+        byts = d_in.numel() * 4 + d_out.numel() * 4 + (d_rs.numel() * 4 if kw else 0)
+        out[name] = dict(ms_per_step=t * 1e3, frames_per_s=n_frames / t, GBps=byts / t / 1e9)
+    return dict(what="precoder config C: %d packets x 4 TX, 73 symbols x 256 sc, DATA" % n_frames, **{k.replace(" ", "_"): v for k, v in out.items()})
+
+
 def equalizer_config_c(n_frames=2048, lanes=4):
     N, cp, T, S = 256, 64, 4, 64
     rng = np.random.default_rng(0)
@@ -170,6 +200,6 @@ def equalizer_config_c(n_frames=2048, lanes=4):
 
 if __name__ == "__main__":
     # the two probes that run as child processes go first: once this process holds a GPU context they would time-slice with it
-    for fn in (sync_front_end, comm_rx_chain, lambda: radar_with_demod("B", 256), lambda: radar_with_demod("D", 64),
+    for fn in (sync_front_end, comm_rx_chain, lambda: radar_with_demod("B", 512), lambda: radar_with_demod("D", 256), precoder_config_c,
                lambda: simulated_chain("B", 64), lambda: simulated_chain("D", 8), equalizer_config_c):
         print(json.dumps(fn()))
