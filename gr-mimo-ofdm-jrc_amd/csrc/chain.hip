@@ -244,12 +244,8 @@ static int chain_pick_wpf(const jrc_chain* ch, int n_frames)
 static int chain_nt_tail(const jrc_chain* ch, int n_frames, int wpf)
 {
     const int per_wg = (ch->C + wpf - 1) / wpf;
-    double frac;
-    if (getenv("JRC_NT_FRAC")) frac = atof(getenv("JRC_NT_FRAC"));
-    else frac = 1.0;
+    const double frac = ch->ctx->tune.nt_frac;
     (void)n_frames;
-    if (frac < 0) frac = 0;
-    if (frac > 1) frac = 1;
     int k = (int)(frac * per_wg + 0.999);
     return k > per_wg ? per_wg : k;
 }
@@ -257,12 +253,7 @@ static int chain_nt_tail(const jrc_chain* ch, int n_frames, int wpf)
 template <int P, int NT, int MMAX, bool TWC_LDS>
 static int launch_fused_nt(jrc_chain* ch, int n_frames, int wpf, int pstride, const float2* d_H, float2* d_map, hipStream_t s)
 {
-    static size_t attr_bytes = 64 * 1024;   // dynamic LDS above 64 KiB must be opted into per kernel
-    if (ch->lds_bytes > attr_bytes) {
-        JRC_HIP(ch->ctx, hipFuncSetAttribute((const void*)range_angle_fused_kernel<P, NT, MMAX, TWC_LDS>,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)ch->lds_bytes));
-        attr_bytes = ch->lds_bytes;
-    }
+    JRC_TRY(jrc_ensure_dyn_lds(ch->ctx, (const void*)range_angle_fused_kernel<P, NT, MMAX, TWC_LDS>, ch->lds_bytes));
     // One resident wave of workgroups per launch: a batch that needs more is launched in chunks of that size, and a last,
     // smaller chunk gets more slices per frame so that it fills the machine as well (a grid twice the resident size runs 20 %
     // slower than two launches because its second wave of workgroups starts ragged).  `pstride` partial maxima per frame.
@@ -327,9 +318,7 @@ extern "C" int jrc_chain_create(jrc_ctx* ctx, const jrc_chain_cfg* cfg, const fl
     if (getenv("JRC_THREADS")) { int t = atoi(getenv("JRC_THREADS")); if (t == 512 || (t == 1024 && N > 256)) ch->threads = t; else ch->threads = 256; }
     ch->wpf_override = getenv("JRC_WPF") ? atoi(getenv("JRC_WPF")) : 0;
     {
-        hipDeviceProp_t prop;
-        JRC_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
-        ch->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        ch->n_cus = ctx->n_cus;
         int by_lds = (int)((160 * 1024) / (ch->lds_bytes + 64));
         int by_regs = ch->threads == 256 ? 3 : 1;          // __launch_bounds__ of the kernel variants
         ch->wg_per_cu = by_lds < by_regs ? by_lds : by_regs;

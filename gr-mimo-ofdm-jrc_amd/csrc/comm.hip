@@ -565,13 +565,11 @@ extern "C" int jrc_equalizer_create(jrc_ctx* ctx, const jrc_eq_cfg* c, int n_str
         d.lds_tables = (int)off;
         eq->lds_bytes = off + sizeof(int) * (size_t)(ND + NP + ac.size() + 1) + sizeof(float2) * (size_t)(N + NP) + 16;
     }
-    if (eq->lds_bytes > 64 * 1024) {
-        JRC_HIP(ctx, hipFuncSetAttribute((const void*)equalizer_kernel<1024, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eq->lds_bytes));
-        JRC_HIP(ctx, hipFuncSetAttribute((const void*)equalizer_kernel<256, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eq->lds_bytes));
-        JRC_HIP(ctx, hipFuncSetAttribute((const void*)equalizer_kernel<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eq->lds_bytes));
-        JRC_HIP(ctx, hipFuncSetAttribute((const void*)equalizer_kernel<256, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eq->lds_bytes));
-        JRC_HIP(ctx, hipFuncSetAttribute((const void*)equalizer_kernel<256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eq->lds_bytes));
-    }
+    JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)equalizer_kernel<1024, 4>, eq->lds_bytes));
+    JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)equalizer_kernel<256, 4>, eq->lds_bytes));
+    JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)equalizer_kernel<256, 2>, eq->lds_bytes));
+    JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)equalizer_kernel<256, 6>, eq->lds_bytes));
+    JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)equalizer_kernel<256, 8>, eq->lds_bytes));
     *out = eq;
     return JRC_OK;
 }

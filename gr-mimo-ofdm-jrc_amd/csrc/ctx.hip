@@ -1,6 +1,8 @@
 // ctx.hip — context, error reporting, staging memory and twiddle tables for include/jrc.h
 #include "jrc_internal.h"
 
+#include <cstdlib>
+
 #include <cmath>
 
 int jrc_fail(jrc_ctx* ctx, int status, const char* fmt, ...)
@@ -54,6 +56,12 @@ extern "C" int jrc_create(int device, jrc_ctx** out)
         delete ctx;
         return JRC_ERR_NO_DEVICE;
     }
+    if (hipDeviceGetAttribute(&ctx->n_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ctx->n_cus <= 0) ctx->n_cus = 256;
+    if (const char* e = getenv("JRC_NT_FRAC")) { ctx->tune.nt_frac = atof(e); if (ctx->tune.nt_frac < 0) ctx->tune.nt_frac = 0; if (ctx->tune.nt_frac > 1) ctx->tune.nt_frac = 1; }
+    if (const char* e = getenv("JRC_CHANEST_CHUNK")) ctx->tune.chanest_chunk = atoi(e);
+    ctx->tune.chanest_x1 = getenv("JRC_CHANEST_X1") != nullptr;
+    ctx->tune.fd_serial = getenv("JRC_FD_SERIAL") != nullptr;
+    ctx->tune.sync_naive = getenv("JRC_SYNC_NAIVE") != nullptr;
     *out = ctx;
     return JRC_OK;
 }
@@ -130,6 +138,16 @@ extern "C" int jrc_memcpy_d2h(jrc_ctx* ctx, void* hptr, const void* dptr, size_t
     if (!ctx) return JRC_ERR_INVALID_ARG;
     JRC_HIP(ctx, hipMemcpyAsync(hptr, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
     JRC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JRC_OK;
+}
+
+int jrc_ensure_dyn_lds(jrc_ctx* ctx, const void* kernel, size_t bytes)
+{
+    if (bytes <= 64 * 1024) return JRC_OK;
+    auto it = ctx->dyn_lds.find(kernel);
+    if (it != ctx->dyn_lds.end() && it->second >= bytes) return JRC_OK;
+    JRC_HIP(ctx, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    ctx->dyn_lds[kernel] = bytes;
     return JRC_OK;
 }
 

@@ -237,11 +237,7 @@ static int launch_fft_vcc_ex(jrc_ctx* ctx, int n, int forward, int shift, const 
         const int per_block = 256 / tp;
         const size_t blocks = (batch + per_block - 1) / per_block;
         const size_t lds_bytes = sizeof(float2) * 2 * (size_t)bt.M * per_block;
-        static size_t attr_bytes3 = 64 * 1024;
-        if (lds_bytes > attr_bytes3) {
-            JRC_HIP(ctx, hipFuncSetAttribute((const void*)fft_bluestein_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            attr_bytes3 = lds_bytes;
-        }
+        JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)fft_bluestein_kernel, lds_bytes));
         hipLaunchKernelGGL(fft_bluestein_kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, stream, d_in, d_out, (const float2*)bt.chirp,
                            (const float2*)bt.bhat, twf, twi, d_window, n, bt.M, jrc_ilog2(bt.M), forward, shift, batch, in_stride,
                            in_offset, tp, out_stride, cp_out);
@@ -256,11 +252,7 @@ static int launch_fft_vcc_ex(jrc_ctx* ctx, int n, int forward, int shift, const 
         const int per_block = 256 / tp;
         const size_t blocks = (batch + per_block - 1) / per_block;
         const size_t lds_bytes = sizeof(float2) * 2 * (size_t)n * per_block;
-        static size_t attr_bytes2 = 64 * 1024;
-        if (lds_bytes > attr_bytes2) {
-            JRC_HIP(ctx, hipFuncSetAttribute((const void*)fft_stockham_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            attr_bytes2 = lds_bytes;
-        }
+        JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)fft_stockham_kernel, lds_bytes));
         hipLaunchKernelGGL(fft_stockham_kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, stream, d_in, d_out, tw,
                            d_window, n, logn, forward, shift, batch, in_stride, in_offset, tp, out_stride, cp_out);
         JRC_HIP(ctx, hipGetLastError());
@@ -270,11 +262,7 @@ static int launch_fft_vcc_ex(jrc_ctx* ctx, int n, int forward, int shift, const 
     const int per_block = 256 / tp;
     const size_t blocks = (batch + per_block - 1) / per_block;
     const size_t lds_bytes = sizeof(float2) * (size_t)n * per_block;
-    static size_t attr_bytes = 64 * 1024;   // dynamic LDS above 64 KiB must be opted into per kernel
-    if (lds_bytes > attr_bytes) {
-        JRC_HIP(ctx, hipFuncSetAttribute((const void*)fft_pow2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        attr_bytes = lds_bytes;
-    }
+    JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)fft_pow2_kernel, lds_bytes));
     hipLaunchKernelGGL(fft_pow2_kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, stream, d_in, d_out, tw,
                        d_window, n, logn, forward, shift, batch, in_stride, in_offset, tp, out_stride, cp_out);
     JRC_HIP(ctx, hipGetLastError());

@@ -27,11 +27,24 @@ struct jrc_ctx {
     // chirp-z tables for fft sizes that are not powers of two, keyed by sign*n
     struct bluestein_tab { float2* chirp; float2* bhat; int M; };
     std::map<long, bluestein_tab> bluestein;
+    // dynamic-LDS opt-in granted so far, per kernel (hipFuncAttributeMaxDynamicSharedMemorySize is per device: kept per context)
+    std::map<const void*, size_t> dyn_lds;
+    int n_cus = 0;
+    // experiment switches, read once in jrc_create (environment JRC_*)
+    struct {
+        double nt_frac = 1.0;        // JRC_NT_FRAC: fraction of a workgroup's map classes stored non-temporally
+        int chanest_chunk = 0;       // JRC_CHANEST_CHUNK: frames per A1 launch (0 = four workgroups per CU)
+        bool chanest_x1 = false;     // JRC_CHANEST_X1: one subcarrier per lane in A1
+        bool fd_serial = false;      // JRC_FD_SERIAL: single-wave detector scan
+        bool sync_naive = false;     // JRC_SYNC_NAIVE: detection metrics without the LDS tile
+    } tune;
 };
 
 int  jrc_fail(jrc_ctx* ctx, int status, const char* fmt, ...);
 int  jrc_ensure_pinned(jrc_ctx* ctx, size_t bytes);
 int  jrc_ensure_scratch(jrc_ctx* ctx, int slot, size_t bytes);
+// dynamic LDS above 64 KiB must be opted into per kernel: raises the kernel's limit to `bytes` if it is not there yet
+int  jrc_ensure_dyn_lds(jrc_ctx* ctx, const void* kernel, size_t bytes);
 // full-circle table of n entries: tw[k] = exp(sign * j * 2*pi * k / n), computed in double
 int  jrc_get_twiddles(jrc_ctx* ctx, int n, int sign, const float2** out);
 // chirp c[k] = exp(sign*j*pi*k^2/n) (k < n) and bhat = FFT_M(conj(c) wrapped to M)/M, M = 2^k >= 2n-1, computed in double

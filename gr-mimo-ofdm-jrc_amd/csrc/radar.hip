@@ -161,13 +161,11 @@ int launch_radar_chanest(jrc_ctx* ctx, int T, int R, const float2* d_frames, flo
     if (n_frames <= 0 || g.N <= 0) return JRC_OK;
     const bool aligned16 = (g.N % 2 == 0) && (g.port_stride % 2 == 0) && (g.frame_stride % 2 == 0) &&
                            ((reinterpret_cast<size_t>(d_frames) | reinterpret_cast<size_t>(d_H)) & 15) == 0;
-    if (R <= 4 && (T == 1 || T == 2 || T == 4) && aligned16 && g.N >= 128 && !getenv("JRC_CHANEST_X1")) {
+    if (R <= 4 && (T == 1 || T == 2 || T == 4) && aligned16 && g.N >= 128 && !ctx->tune.chanest_x1) {
         // launched in chunks of at most four workgroups per CU: with every workgroup resident from the start the frame reads
         // advance evenly (5.4 TB/s); a grid twice that size loses 10-15 % to its second, ragged wave of workgroups
-        static int n_cus = 0;
-        if (!n_cus) { if (hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || n_cus <= 0) n_cus = 256; }
         const int wg_per_frame = (g.N / 2 + 63) / 64;
-        int chunk = getenv("JRC_CHANEST_CHUNK") ? atoi(getenv("JRC_CHANEST_CHUNK")) : (4 * n_cus) / wg_per_frame;
+        int chunk = ctx->tune.chanest_chunk > 0 ? ctx->tune.chanest_chunk : (4 * ctx->n_cus) / wg_per_frame;
         if (chunk < 1) chunk = 1;
         const dim3 block(64, R, 1);
         for (int f0 = 0; f0 < n_frames; f0 += chunk) {
@@ -382,13 +380,11 @@ int launch_demod_chanest(jrc_ctx* ctx, int T, const float2* d_tx, const float2* 
     }
     const size_t lds_bytes = sizeof(float2) * ((size_t)g.N + (size_t)per_block * 8 * g.N);
     const dim3 grid((unsigned)blocks), block((unsigned)threads);
-    static size_t attr_bytes[9] = {0};
-    if (lds_bytes > 64 * 1024 && lds_bytes > attr_bytes[T]) {
+    {
         const void* fn = T == 1 ? (const void*)demod_chanest_kernel<1> : T == 2 ? (const void*)demod_chanest_kernel<2> :
                          T == 3 ? (const void*)demod_chanest_kernel<3> : T == 4 ? (const void*)demod_chanest_kernel<4> :
                                   (const void*)demod_chanest_kernel<8>;
-        JRC_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        attr_bytes[T] = lds_bytes;
+        JRC_TRY(jrc_ensure_dyn_lds(ctx, fn, lds_bytes));
     }
     switch (T) {
         case 1: hipLaunchKernelGGL(demod_chanest_kernel<1>, grid, block, lds_bytes, stream, d_tx, d_rx_td, d_H, tw, g, n_frames); break;

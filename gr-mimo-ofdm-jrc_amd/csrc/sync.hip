@@ -165,12 +165,8 @@ extern "C" int jrc_sync_metrics_dev(jrc_ctx* ctx, int n, int delay, int window, 
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     const size_t L = (size_t)SM_TILE + (size_t)(window > pwindow ? window : pwindow) - 1 + (size_t)delay;
     const size_t lds = L * (3 * sizeof(float2) + 3 * sizeof(float));
-    if (lds <= 150 * 1024 && !getenv("JRC_SYNC_NAIVE")) {
-        static size_t attr_bytes = 64 * 1024;
-        if (lds > attr_bytes) {
-            JRC_HIP(ctx, hipFuncSetAttribute((const void*)sync_metrics_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_bytes = lds;
-        }
+    if (lds <= 150 * 1024 && !ctx->tune.sync_naive) {
+        JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)sync_metrics_tiled_kernel, lds));
         hipLaunchKernelGGL(sync_metrics_tiled_kernel, dim3((n + SM_TILE - 1) / SM_TILE), dim3(256), lds, s, (const float2*)d_x, n, delay, window, pwindow,
                            pscale, (float2*)d_xd, (float2*)d_in_abs, d_in_cor);
     } else {        // windows too long for an LDS tile: one lane per output, window + power_window loads each
@@ -958,7 +954,7 @@ static int launch_fd_scan(jrc_ctx* ctx, const FdParams& p, const unsigned long l
                           int max_frames, int* d_n_frames, hipStream_t s)
 {
     const int n_seg = (n_samples + FD_SEG_WORDS * 64 - 1) / (FD_SEG_WORDS * 64);
-    if (n_seg <= 1 || getenv("JRC_FD_SERIAL")) {
+    if (n_seg <= 1 || ctx->tune.fd_serial) {
         hipLaunchKernelGGL(fd_scan_all_kernel, dim3(1), dim3(64), 0, s, p, d_marks, d_abs, n_samples, d_info, max_frames, d_n_frames);
         JRC_HIP(ctx, hipGetLastError());
         return JRC_OK;

@@ -532,19 +532,12 @@ static int tsim_rows_launch(jrc_tsim* h, bool fwd_only, float2* X, int conj_b, s
     const int per_block = 256 / tp;
     const size_t blocks = (rows + per_block - 1) / per_block;
     const size_t lds_bytes = sizeof(float2) * 2 * (size_t)n2 * per_block;
-    static size_t attr_a = 64 * 1024, attr_b = 64 * 1024;
     if (fwd_only) {
-        if (lds_bytes > attr_a) {
-            JRC_HIP(ctx, hipFuncSetAttribute((const void*)tsim_rowconv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            attr_a = lds_bytes;
-        }
+        JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)tsim_rowconv_kernel<true>, lds_bytes));
         hipLaunchKernelGGL(tsim_rowconv_kernel<true>, dim3((unsigned)blocks), dim3(256), lds_bytes, stream, X,
                            (const float2*)nullptr, 0, twf, twi, n2, jrc_ilog2(n2), rows, tp);
     } else {
-        if (lds_bytes > attr_b) {
-            JRC_HIP(ctx, hipFuncSetAttribute((const void*)tsim_rowconv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            attr_b = lds_bytes;
-        }
+        JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)tsim_rowconv_kernel<false>, lds_bytes));
         hipLaunchKernelGGL(tsim_rowconv_kernel<false>, dim3((unsigned)blocks), dim3(256), lds_bytes, stream, X,
                            (const float2*)h->d_bhat, conj_b, twf, twi, n2, jrc_ilog2(n2), rows, tp);
     }
