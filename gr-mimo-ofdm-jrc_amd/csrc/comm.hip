@@ -40,7 +40,16 @@ __device__ __forceinline__ float2 c_expj(double x)   // std::exp(gr_complex(0, x
 {
     const float xf = (float)x;
     float sn, cs;
-    sincosf(xf, &sn, &cs);                             // one argument reduction for both
+    if (fabsf(xf) <= 0.78539816f) {
+        // |x| <= pi/4 — every sampling-offset and residual-phase rotation of a sane link: no argument reduction, the two
+        // single-precision minimax polynomials (Cephes sinf / cosf kernels, < 1 ulp here — the same error class as any libm's
+        // sincosf, which is all the reference's std::exp guarantees)
+        const float z = xf * xf;
+        sn = fmaf(xf * z, fmaf(z, fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), xf);
+        cs = fmaf(z * z, fmaf(z, fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f), fmaf(z, -0.5f, 1.0f));
+    } else {
+        sincosf(xf, &sn, &cs);                         // one argument reduction for both
+    }
     return make_float2(cs, sn);
 }
 
@@ -131,8 +140,10 @@ __device__ __forceinline__ float2 demod_point(int bps, float2 z)
     return make_float2((z.x > 0 ? a : -a) / 2.0f, (z.y > 0 ? a : -a) / 2.0f);
 }
 
+#define EQ_BATCH 64   // data symbols per three-phase pass of the equalizer
+
 // NTMAX = workgroup size the variant is compiled for, WPE = waves per SIMD it must allow (register budget 512 / WPE)
-template <int NTMAX, int WPE>
+template <int NTMAX, int WPE, int EPT /* subcarriers per lane: fft_len <= EPT * blockDim */>
 __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState* states, float2* H_all, float2* Hm_all,
                                                          float2* pre_all, EqIo io)
 {
@@ -158,6 +169,8 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
     __shared__ float2 s_rot;
     __shared__ int s_flag;
     __shared__ double s_dred[32];
+    __shared__ float2 s_brot[EQ_BATCH];
+    __shared__ double s_bsig[EQ_BATCH], s_bnoi[EQ_BATCH];
 
     const int tid = threadIdx.x, NT = blockDim.x;
     const int b = blockIdx.x;
@@ -181,7 +194,6 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
     int n_in = 0, n_out = 0, nev = 0, ce_written = 0, advance = 0;
     // input symbols are prefetched one symbol ahead into registers: a symbol is only a few microseconds of work, so
     // an HBM round trip per symbol would otherwise dominate the per-frame latency
-    constexpr int EPT = 4;                                                              // fft_len <= 4 * blockDim
     float2 xin[EPT];
 #pragma unroll
     for (int e = 0; e < EPT; e++) { const int i = tid + e * NT; if (i < N && io.ninput > 0) xin[e] = in[i]; }
@@ -210,6 +222,116 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
         __syncthreads();
         const int sym = S.symbol_ind;
         if (sym > S.n_ofdm_symbols_SIG + 2 + NL || !S.sig_ok) { n_in++; advance = 0; __syncthreads(); continue; }   // :250-255
+
+        // ---- data symbols without decision feedback (LS, or 16-QAM under STA): all that this call holds, in three phases -----------
+        // A data symbol depends on the ones before it only through the running noise / signal sums (:484-493, :545), so: (A) each
+        // wavefront takes symbols and does their pilot work — residual CFO (:908-922) and the two sums; (B) one lane accumulates the
+        // sums in symbol order; (C) every lane equalises its subcarriers symbol after symbol with no barrier in between.  Same
+        // expressions as the symbol-at-a-time path below, which keeps the STA estimator and single symbols.
+        {
+            const int bps_b = (S.mcs <= 1) ? 1 : (S.mcs <= 3 ? 2 : 4);
+            const bool sta_b = d.estimator == 1 && bps_b <= 2;
+            int nb = 0;
+            if (sym > 2 + NL && !sta_b && (S.packet_type == 1 || S.packet_type == 2)) {
+                nb = io.ninput - n_in;
+                nb = min(nb, io.noutput - n_out);
+                nb = min(nb, S.n_ofdm_symbols_SIG + 2 + NL - sym + 1);
+                if (io.tag_offsets)
+                    for (int t = 0; t < io.n_tags; t++) {
+                        const long long off = io.tag_offsets[t];
+                        if (off > n_in && off - n_in < nb) nb = (int)(off - n_in);
+                    }
+                nb = min(nb, EQ_BATCH);
+            }
+            if (nb >= 2) {
+                const int ln = tid & 63, wv = tid >> 6, NW = NT >> 6;
+                const int ptype = S.packet_type;
+                const float2* Hsel = ptype == 1 ? H : Hm;
+                const double eps = S.epsilon0 + S.er;
+                for (int j = wv; j < nb; j += NW) {                                     // (A)
+                    const int sy = sym + j;
+                    const float2* prow = d.pilot_sym + (size_t)((sy - 3 - NL) % d.n_pilot_rows) * NP;
+                    const double k0 = 2 * M_PI * sy * ((N + d.cp) * 1.0 / N) * eps;
+                    const float2* x = in + (size_t)(n_in + j) * N;
+                    float2 sum = make_float2(0.f, 0.f);
+                    for (int k = ln; k < NP; k += 64) {
+                        const int c = pc[k];
+                        const float2 yk = c_mul(x[c], c_expj(k0 * (c - N / 2)));
+                        const float2 e = c_mul(Hsel[c], prow[k]);
+                        const float2 pp = c_mul(yk, c_conj(e));
+                        sum.x = sum.x + pp.x; sum.y = sum.y + pp.y;
+                    }
+                    for (int off = 32; off > 0; off >>= 1) { sum.x += __shfl_xor(sum.x, off); sum.y += __shfl_xor(sum.y, off); }
+                    const float2 r0 = c_expj(-(double)atan2f(sum.y, sum.x));
+                    double sig = 0, noi = 0;
+                    for (int k = ln; k < NP; k += 64) {
+                        const int c = pc[k];
+                        const float2 yk = c_mul(x[c], c_expj(k0 * (c - N / 2)));
+                        const float2 e = c_mul(Hsel[c], prow[k]);
+                        sig += (double)c_mul(e, c_conj(e)).x;
+                        const float2 yr = c_mul(yk, r0);
+                        const float2 er = make_float2(e.x - yr.x, e.y - yr.y);
+                        noi += (double)c_mul(er, c_conj(er)).x;
+                    }
+                    for (int off = 32; off > 0; off >>= 1) { sig += __shfl_xor(sig, off); noi += __shfl_xor(noi, off); }
+                    if (ln == 0) { s_brot[j] = r0; s_bsig[j] = sig; s_bnoi[j] = noi; }
+                }
+                __syncthreads();
+                if (tid == 0) {                                                         // (B)
+                    for (int j = 0; j < nb; j++) {
+                        S.signal_power_sum += s_bsig[j]; S.noise_power_sum += s_bnoi[j]; S.snr_est_count += NP;
+                        s_bnoi[j] = S.noise_power_sum / S.snr_est_count;                // nvar of symbol j (:545)
+                    }
+                    S.symbol_ind = sym + nb - 1;
+                }
+                __syncthreads();
+                int scv[EPT];                                                           // (C)
+                float2 hv[EPT], xn[EPT];
+                double hm2[EPT];
+#pragma unroll
+                for (int e = 0; e < EPT; e++) {
+                    const int i = tid + e * NT;
+                    if (i < ND) {
+                        scv[e] = dc[i];
+                        hv[e] = Hsel[scv[e]];
+                        hm2[e] = (double)c_mul(hv[e], c_conj(hv[e])).x;
+                        xn[e] = in[(size_t)n_in * N + scv[e]];
+                    }
+                }
+                for (int j = 0; j < nb; j++) {
+                    float2 xc[EPT];
+#pragma unroll
+                    for (int e = 0; e < EPT; e++) {
+                        xc[e] = xn[e];
+                        if (tid + e * NT < ND && j + 1 < nb) xn[e] = in[(size_t)(n_in + j + 1) * N + scv[e]];
+                    }
+                    const double k0 = 2 * M_PI * (sym + j) * ((N + d.cp) * 1.0 / N) * eps;
+                    const float2 rot = s_brot[j];
+                    const double nvar = s_bnoi[j];
+                    float2* o = out + (size_t)(n_out + j) * ND;
+#pragma unroll
+                    for (int e = 0; e < EPT; e++) {
+                        const int i = tid + e * NT;
+                        if (i < ND) {
+                            const float2 yr = c_mul(c_mul(xc[e], c_expj(k0 * (scv[e] - N / 2))), rot);
+                            float2 z;
+                            if (ptype == 1) z = c_div(yr, hv[e]);                       // symbol_equalize :900-906
+                            else {                                                      // :540-550
+                                const float csi = (float)(hm2[e] + nvar);
+                                const float2 num = c_mul(yr, c_conj(hv[e]));
+                                z = make_float2(num.x / csi, num.y / csi);
+                            }
+                            o[i] = z;                                                   // :602
+                        }
+                    }
+                }
+                n_in += nb; n_out += nb; advance = 1;
+#pragma unroll
+                for (int e = 0; e < EPT; e++) { const int i = tid + e * NT; if (i < N && n_in < io.ninput) xin[e] = in[(size_t)n_in * N + i]; }
+                __syncthreads();
+                continue;
+            }
+        }
 
         if (sym >= 2 && tid < NP) {   // pilot row of this symbol (SIG: row 0; data symbol m: row m mod n_rows), read by lane 0 below
             const int row = sym == 2 ? 0 : (sym > 2 + NL ? (sym - 3 - NL) % d.n_pilot_rows : 0);
@@ -284,12 +406,23 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
                     const int om = __shfl_xor(best, off), os = __shfl_xor(bs, off);
                     if (om < best || (om == best && os < bs)) { best = om; bs = os; }
                 }
-                if (tid == 0) {
-                    int s = bs;
-                    for (int i = nd - 1; i >= 0; i--) {
-                        dec[i] = (unsigned char)(s & 1);
-                        s = (s >> 1) | ((int)((surv[i] >> s) & 1ull) << 5);
+                // traceback: a chain of nd dependent steps.  The survivor words go back into lanes (word i in lane i % 64) and the chain
+                // runs on the scalar unit off v_readlane; walking them in LDS cost a load latency per step
+                {
+                    int s = __builtin_amdgcn_readfirstlane(bs);
+                    for (int blk = (nd - 1) >> 6; blk >= 0; blk--) {
+                        const int wi = (blk << 6) + tid;
+                        const unsigned long long mine = wi < nd ? surv[wi] : 0ull;
+                        const int hi_i = min(nd - 1, (blk << 6) + 63);
+                        for (int i = hi_i; i >= (blk << 6); i--) {
+                            const unsigned long long w = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mine >> 32), i & 63) << 32) |
+                                                         (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mine & 0xffffffffull), i & 63);
+                            if (tid == 0) dec[i] = (unsigned char)(s & 1);
+                            s = (s >> 1) | ((int)((w >> s) & 1ull) << 5);
+                        }
                     }
+                }
+                if (tid == 0) {
                     // parse :669-781
                     int rate = 0, pt = 0, len = 0, parity = 0;
                     for (int i = 0; i < 17; i++) {
@@ -372,12 +505,12 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
                             acc.x = acc.x + p.x; acc.y = acc.y + p.y;
                         }
                         Hm[sc] = make_float2(acc.x / (float)NL, acc.y / (float)NL);
+                        Y[k] = Hm[sc];                                                  // in summation order (Y is free: the symbol sits in `pre`)
                     }
                     __syncthreads();
-                    if (tid == 0) {
+                    if (tid == 0) {                                                     // the mean is a sequential sum: contiguous operands, no index chasing
                         float2 m = make_float2(0.f, 0.f);
-                        for (int k = 0; k < ND; k++) { m.x = m.x + Hm[dc[k]].x; m.y = m.y + Hm[dc[k]].y; }
-                        for (int k = 0; k < NP; k++) { m.x = m.x + Hm[pc[k]].x; m.y = m.y + Hm[pc[k]].y; }
+                        for (int k = 0; k < d.NAct; k++) { m.x = m.x + Y[k].x; m.y = m.y + Y[k].y; }
                         S.chan_mean[0] = make_float2(m.x / (float)d.NAct, m.y / (float)d.NAct);
                         S.n_chan_mean = 1;
                     }
@@ -565,24 +698,26 @@ extern "C" int jrc_equalizer_create(jrc_ctx* ctx, const jrc_eq_cfg* c, int n_str
         d.lds_tables = (int)off;
         eq->lds_bytes = off + sizeof(int) * (size_t)(ND + NP + ac.size() + 1) + sizeof(float2) * (size_t)(N + NP) + 16;
     }
-    JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)equalizer_kernel<1024, 4>, eq->lds_bytes));
-    JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)equalizer_kernel<256, 4>, eq->lds_bytes));
-    JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)equalizer_kernel<256, 2>, eq->lds_bytes));
-    JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)equalizer_kernel<256, 6>, eq->lds_bytes));
-    JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)equalizer_kernel<256, 8>, eq->lds_bytes));
+    JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)equalizer_kernel<1024, 4, 4>, eq->lds_bytes));
+    JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)equalizer_kernel<1024, 4, 1>, eq->lds_bytes));
+    JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)equalizer_kernel<256, 4, 1>, eq->lds_bytes));
+    JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)equalizer_kernel<256, 2, 1>, eq->lds_bytes));
+    JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)equalizer_kernel<256, 6, 1>, eq->lds_bytes));
+    JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)equalizer_kernel<256, 8, 1>, eq->lds_bytes));
     *out = eq;
     return JRC_OK;
 }
 
 static void launch_equalizer(jrc_equalizer* eq, int grid, hipStream_t s, const EqIo& io)
 {
-    static const int wpe = getenv("JRC_EQ_WPE") ? atoi(getenv("JRC_EQ_WPE")) : 8;   // measured on config C: 8 waves/SIMD (64 VGPRs, some spills) beats 4 by 9 %
-#define EQ_LAUNCH(NTM, W) hipLaunchKernelGGL((equalizer_kernel<NTM, W>), dim3(grid), dim3(eq->threads), eq->lds_bytes, s, eq->d, eq->states, eq->H, eq->Hm, eq->pre, io)
-    if (eq->threads > 256) EQ_LAUNCH(1024, 4);
-    else if (wpe == 2) EQ_LAUNCH(256, 2);
-    else if (wpe == 6) EQ_LAUNCH(256, 6);
-    else if (wpe == 8) EQ_LAUNCH(256, 8);
-    else EQ_LAUNCH(256, 4);
+    static const int wpe = getenv("JRC_EQ_WPE") ? atoi(getenv("JRC_EQ_WPE")) : 4;   // measured on config C (frames/s): 8 waves/SIMD 1.27 M, 6: 1.35 M, 4: 1.44 M, 2: 1.32 M
+#define EQ_LAUNCH(NTM, W, E) hipLaunchKernelGGL((equalizer_kernel<NTM, W, E>), dim3(grid), dim3(eq->threads), eq->lds_bytes, s, eq->d, eq->states, eq->H, eq->Hm, eq->pre, io)
+    if (eq->d.N > eq->threads) EQ_LAUNCH(1024, 4, 4);          // fft_len 2048 / 4096: several subcarriers per lane
+    else if (eq->threads > 256) EQ_LAUNCH(1024, 4, 1);
+    else if (wpe == 2) EQ_LAUNCH(256, 2, 1);
+    else if (wpe == 6) EQ_LAUNCH(256, 6, 1);
+    else if (wpe == 8) EQ_LAUNCH(256, 8, 1);
+    else EQ_LAUNCH(256, 4, 1);
 #undef EQ_LAUNCH
 }
 

@@ -149,8 +149,8 @@ def precoder_config_c(n_frames=2048):
     return dict(what="precoder config C: %d packets x 4 TX, 73 symbols x 256 sc, DATA" % n_frames, **{k.replace(" ", "_"): v for k, v in out.items()})
 
 
-def equalizer_config_c(n_frames=2048, lanes=4):
-    N, cp, T, S = 256, 64, 4, 64
+def equalizer_config_c(n_frames=2048, lanes=4, S=64):
+    N, cp, T = 256, 64, 4
     rng = np.random.default_rng(0)
     guard = 16
     act = [c for c in range(-N // 2 + guard, N // 2 - guard + 1) if c != 0]
