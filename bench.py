@@ -35,6 +35,9 @@ def parse():
     ap.add_argument("--distinct", type=int, default=32, help="distinct synthetic frames generated per GPU (tiled to --frames)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary figures of SURVEY §8(d) (chain incl. RX demod, equalizer / precoder config C) that rank 0 "
+                         "appends at N=1 after the timed region")
     ap.add_argument("--prewarm-seconds", type=float, default=0.3,
                     help="untimed runs before the W warm-up steps so a cold GPU has its clocks up (0 = none)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests of the N>1 path)")
@@ -89,6 +92,28 @@ def cpu_baseline(sc, Ir, Ia, frames, axes, budget_s):
                             "sample": "%d frames over %d processes" % (sum(d for d, _ in res), n)}
     except Exception as e:      # the single-thread figure above is the contract; this one is extra
         out["all_cores"] = {"error": str(e)}
+    return out
+
+
+def secondary_figures(cfg):
+    """the same chain with the RX OFDM demod in front (time-domain RX in), and the comm-side config C — measured after
+    the timed region by tools/bench_extra.py's routines (their own batches, a few seconds in total); never part of `value`"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    out = {}
+    try:
+        import bench_extra as be
+        r = be.radar_with_demod(cfg if cfg in ("B", "D") else "B", 512 if cfg != "D" else 256)
+        out["chain_with_rx_demod"] = {"frames_per_s": r["frames_per_s"], "ms_per_step": r["ms_per_step"], "frames_per_step": r["frames_per_step"],
+                                      "what": "A6+A7+A1 as one kernel (time-domain RX in) -> A2..A5, config " + (cfg if cfg in ("B", "D") else "B")}
+        e = be.equalizer_config_c()
+        out["equalizer_config_c"] = {"frames_per_s": e["frames_per_s"], "lane_frames_per_s": e["lane_frames_per_s"], "GBps": e["GBps"],
+                                     "what": e["what"]}
+        p = be.precoder_config_c()
+        out["precoder_config_c"] = {"packets_per_s_dft": p["dft"]["frames_per_s"],
+                                    "packets_per_s_steering_and_radar_streams": p["per-subcarrier_steering_+_radar_streams"]["frames_per_s"],
+                                    "what": p["what"]}
+    except Exception as ex:            # secondary figures must never take the headline line down with them
+        out["error"] = repr(ex)
     return out
 
 
@@ -222,6 +247,8 @@ def main():
         }
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
+        if world == 1 and not a.no_secondary:
+            out["secondary"] = secondary_figures(a.config)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
