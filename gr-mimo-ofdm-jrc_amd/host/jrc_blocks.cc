@@ -237,6 +237,129 @@ range_angle_estimator::sptr range_angle_estimator::make(int vlen, std::vector<fl
 }
 
 // =================================================================================================
+// radar_chain: mimo_ofdm_radar + fft_vxx + matrix_transpose + fft_vxx + range_angle_estimator in one block, over the host-fed
+// pipeline of the device-resident chain (jrc_chain_feed_*).  Input side = lib/mimo_ofdm_radar_impl.cc:160-238 (tags, stale TX
+// packets discarded), output side = lib/range_angle_estimator_impl.cc:234-279 (message + log line per published frame).
+// =================================================================================================
+class radar_chain_impl : public radar_chain {
+    ctx_holder d_c;
+    jrc_chain_feed* d_feed = nullptr;
+    int d_fft_len, d_N_tx, d_N_rx, d_n_items, d_fpb, d_slots;
+    std::string d_stats_path;
+    bool d_stats_record, d_new_stat_started = false;
+    int d_frames_done = 0;
+    std::vector<jrc_ra_result> d_res;
+
+    static pmt::pmt_t pack(const char* key, float v) { return pmt::list2(pmt::string_to_symbol(key), pmt::init_f32vector(1, &v)); }
+
+    void publish(int n)
+    {
+        for (int i = 0; i < n; i++) {
+            const jrc_ra_result& r = d_res[i];
+            d_frames_done++;
+            if (!r.published) continue;
+            message_port_pub(pmt::mp("params"), pmt::list4(pack("range", r.range_val), pack("angle", r.angle_val),
+                                                           pack("power", r.peak_power), pack("snr", r.snr_est)));
+            if (d_stats_record) {
+                std::ofstream f(d_stats_path, std::ofstream::app);
+                if (!f.is_open()) throw std::runtime_error("[STREAM DECODER] Could not open file!!");
+                if (!d_new_stat_started) { f << "\n NEW RECORD - " << current_date_time() << "\n"; d_new_stat_started = true; }
+                f << current_date_time2() << ", \t" << r.peak_power << ", \t" << r.snr_est << ", \t" << r.range_val << ", \t"
+                  << r.angle_val << "\n";
+            }
+        }
+    }
+    void collect_one()
+    {
+        int n = 0;
+        d_c.check(jrc_chain_feed_collect(d_feed, d_res.data(), nullptr, &n));
+        publish(n);
+    }
+
+public:
+    radar_chain_impl(int fft_len, int N_tx, int N_rx, int N_sym, int N_pre, int interp_range, int interp_angle, bool interleave,
+                     const std::vector<float>& range_bins, const std::vector<float>& angle_bins, float ndr, float nda, float snr_threshold,
+                     float power_threshold, const std::string& stats_path, bool stats_record, int frames_per_batch, int batches_in_flight)
+        : jrc_rt::block("radar_chain", jrc_rt::io_signature::make(N_tx + N_rx, N_tx + N_rx, sizeof(gr_complex) * fft_len),
+                        jrc_rt::io_signature::make(0, 0, 0)),
+          d_fft_len(fft_len), d_N_tx(N_tx), d_N_rx(N_rx), d_n_items(N_pre + N_sym), d_fpb(frames_per_batch), d_slots(batches_in_flight),
+          d_stats_path(stats_path), d_stats_record(stats_record)
+    {
+        if ((int)range_bins.size() != fft_len * interp_range || (int)angle_bins.size() != N_tx * N_rx * interp_angle)
+            throw std::invalid_argument("[RADAR CHAIN] range_bins / angle_bins do not match the map size");
+        jrc_chain_cfg cfg;
+        cfg.fft_len = fft_len; cfg.N_tx = N_tx; cfg.N_rx = N_rx; cfg.N_sym = N_sym; cfg.N_pre = N_pre;
+        cfg.interp_range = interp_range; cfg.interp_angle = interp_angle; cfg.enable_tx_interleave = interleave;
+        cfg.n_items = d_n_items; cfg.noise_discard_range_m = ndr; cfg.noise_discard_angle_deg = nda;
+        cfg.snr_threshold = snr_threshold; cfg.power_threshold = power_threshold;
+        d_c.check(jrc_chain_feed_create(d_c.ctx, &cfg, range_bins.data(), angle_bins.data(), d_slots, d_fpb, 0, 0, &d_feed));
+        d_res.resize((size_t)d_fpb);
+        message_port_register_out(pmt::mp("params"));
+        set_tag_propagation_policy(TPP_DONT);
+        std::ofstream f(d_stats_path, std::ofstream::app);
+        if (stats_record && !f.is_open()) std::cerr << "[RADAR CHAIN] Could not open log file at " << d_stats_path << std::endl;
+    }
+    ~radar_chain_impl() override { jrc_chain_feed_destroy(d_feed); }
+    int frames_done() const override { return d_frames_done; }
+
+    int general_work(int, gr_vector_int& ninput_items, gr_vector_const_void_star& input_items, gr_vector_void_star&) override
+    {
+        std::vector<jrc_rt::tag_t> rx_tags, tx_tags;
+        get_tags_in_range(rx_tags, d_N_tx, nitems_read(d_N_tx), nitems_read(d_N_tx) + ninput_items[d_N_tx], pmt::mp("packet_len"));
+        if (rx_tags.empty()) {                                                                        // no frame in sight (:219-234)
+            for (int i = 0; i < d_N_tx + d_N_rx; i++) consume(i, ninput_items[i]);
+            return 0;
+        }
+        get_tags_in_range(tx_tags, 0, nitems_read(0), nitems_read(0) + ninput_items[0], pmt::mp("packet_len"));
+        const size_t tx_skip = tx_tags.size() > rx_tags.size() ? tx_tags.size() - rx_tags.size() : 0;   // stale TX packets (:191-198)
+        if (tx_tags.size() <= tx_skip) throw std::runtime_error("[MIMO OFDM RADAR] no packet_len tag on TX input");
+        const size_t n_frames = std::min(rx_tags.size(), tx_tags.size() - tx_skip);
+        const size_t item = (size_t)d_fft_len;
+        long rx_end = 0, tx_end = 0;
+        size_t f = 0;
+        while (f < n_frames) {
+            jrc_cf32* stage = nullptr;
+            if (jrc_chain_feed_pending(d_feed) == d_slots) collect_one();
+            d_c.check(jrc_chain_feed_acquire(d_feed, &stage));
+            int nb = 0;
+            for (; f < n_frames && nb < d_fpb; f++) {
+                const long rx0 = (long)(rx_tags[f].offset - nitems_read(d_N_tx)), tx0 = (long)(tx_tags[f + tx_skip].offset - nitems_read(0));
+                const long rx_len = (long)pmt::to_uint64(rx_tags[f].value), tx_len = (long)pmt::to_uint64(tx_tags[f + tx_skip].value);
+                if (rx_len < d_n_items || tx_len < d_n_items) throw std::runtime_error("[RADAR CHAIN] packet shorter than N_pre + N_sym items");
+                if (rx0 + rx_len > ninput_items[d_N_tx] || tx0 + tx_len > ninput_items[0]) break;
+                jrc_cf32* dst = stage + (size_t)nb * (d_N_tx + d_N_rx) * d_n_items * item;
+                for (int t = 0; t < d_N_tx; t++)
+                    memcpy(dst + (size_t)t * d_n_items * item, (const jrc_cf32*)input_items[t] + (size_t)tx0 * item, sizeof(jrc_cf32) * d_n_items * item);
+                for (int r = 0; r < d_N_rx; r++)
+                    memcpy(dst + (size_t)(d_N_tx + r) * d_n_items * item, (const jrc_cf32*)input_items[d_N_tx + r] + (size_t)rx0 * item,
+                           sizeof(jrc_cf32) * d_n_items * item);
+                rx_end = rx0 + rx_len; tx_end = tx0 + tx_len;
+                nb++;
+            }
+            if (nb == 0) break;                                                                       // the next frame is not complete yet
+            d_c.check(jrc_chain_feed_submit(d_feed, nullptr, nb));
+            if (nb < d_fpb) break;
+        }
+        while (jrc_chain_feed_pending(d_feed) > 0) collect_one();                                     // results of this turn, in frame order
+        if (rx_end == 0 && tx_end == 0) return 0;                                                      // first frame incomplete: wait for more input
+        for (int r = 0; r < d_N_rx; r++) consume(r + d_N_tx, (int)rx_end);
+        for (int t = 0; t < d_N_tx; t++) consume(t, (int)tx_end);
+        return 0;
+    }
+};
+
+radar_chain::sptr radar_chain::make(int fft_len, int N_tx, int N_rx, int N_sym, int N_pre, int interp_range, int interp_angle,
+                                    bool enable_tx_interleave, std::vector<float> range_bins, std::vector<float> angle_bins,
+                                    float noise_discard_range_m, float noise_discard_angle_deg, float snr_threshold, float power_threshold,
+                                    const std::string& stats_path, bool stats_record, int frames_per_batch, int batches_in_flight,
+                                    const std::string&, bool)
+{
+    return JRC_GET_INITIAL_SPTR(new radar_chain_impl(fft_len, N_tx, N_rx, N_sym, N_pre, interp_range, interp_angle, enable_tx_interleave,
+                                                     range_bins, angle_bins, noise_discard_range_m, noise_discard_angle_deg, snr_threshold,
+                                                     power_threshold, stats_path, stats_record, frames_per_batch, batches_in_flight));
+}
+
+// =================================================================================================
 // ofdm_cyclic_prefix_remover  (lib/ofdm_cyclic_prefix_remover_impl.cc)
 // =================================================================================================
 class ofdm_cyclic_prefix_remover_impl : public ofdm_cyclic_prefix_remover {

@@ -18,6 +18,8 @@
 //   include/mimo_ofdm_jrc/zero_pad.h                   gr::mimo_ofdm_jrc::zero_pad
 //   include/mimo_ofdm_jrc/ofdm_frame_generator.h       gr::mimo_ofdm_jrc::ofdm_frame_generator
 //
+//   (none: the five-block radar branch as one block)   gr::mimo_ofdm_jrc::radar_chain
+//
 // Built against GNU Radio 3.8 with -DJRC_WITH_GNURADIO; otherwise against the stand-alone test runtime.
 #pragma once
 
@@ -41,6 +43,22 @@ public:
                      const std::string& radar_chan_file, const std::string& len_tag_key = "packet_len", bool debug = false);
     virtual void set_background_record(bool background_record) = 0;
     virtual void capture_radar_data(bool capture_sig) = 0;
+};
+
+// The radar branch of the flowgraphs as ONE block: mimo_ofdm_radar -> fft_vxx(reverse) -> matrix_transpose -> fft_vxx(forward,
+// shift) -> range_angle_estimator (examples/simulation/radar/mimo_ofdm_jrc_radar_sim.grc:2189-2197).  Same input ports and tags as
+// mimo_ofdm_radar (N_tx + N_rx streams of fft_len vectors, `packet_len`), same `params` message port and log file as
+// range_angle_estimator; no stream output — the range-angle map stays on the device.  Every frame offered in a scheduler turn goes
+// through the host-fed pipeline (jrc_chain_feed_*): batches in flight on their own streams, results published in frame order.
+class radar_chain : virtual public jrc_rt::block {
+public:
+    typedef JRC_SPTR<radar_chain> sptr;
+    static sptr make(int fft_len, int N_tx, int N_rx, int N_sym, int N_pre, int interp_range, int interp_angle, bool enable_tx_interleave,
+                     std::vector<float> range_bins, std::vector<float> angle_bins, float noise_discard_range_m,
+                     float noise_discard_angle_deg, float snr_threshold, float power_threshold, const std::string& stats_path,
+                     bool stats_record, int frames_per_batch = 16, int batches_in_flight = 3,
+                     const std::string& len_tag_key = "packet_len", bool debug = false);
+    virtual int frames_done() const = 0;
 };
 
 class matrix_transpose : virtual public jrc_rt::tagged_stream_block {

@@ -36,6 +36,15 @@ void* jrcb_make_radar(int fft_len, int N_tx, int N_rx, int N_sym, int N_pre, int
     return guard_make([&] { return std::static_pointer_cast<jrc_host::block>(std::shared_ptr<mimo_ofdm_radar>(
         mimo_ofdm_radar::make(fft_len, N_tx, N_rx, N_sym, N_pre, bg_removal, bg_recording, record_len, interp_factor, interleave, ""))); });
 }
+void* jrcb_make_radar_chain(int fft_len, int N_tx, int N_rx, int N_sym, int N_pre, int interp_range, int interp_angle, int interleave,
+                            const float* rb, int n_rb, const float* ab, int n_ab, float ndr, float nda, float snr_thr, float pow_thr,
+                            const char* stats_path, int stats_record, int frames_per_batch, int batches_in_flight)
+{
+    return guard_make([&] { return std::static_pointer_cast<jrc_host::block>(std::shared_ptr<radar_chain>(
+        radar_chain::make(fft_len, N_tx, N_rx, N_sym, N_pre, interp_range, interp_angle, interleave != 0, std::vector<float>(rb, rb + n_rb),
+                          std::vector<float>(ab, ab + n_ab), ndr, nda, snr_thr, pow_thr, stats_path, stats_record != 0, frames_per_batch,
+                          batches_in_flight))); });
+}
 void* jrcb_make_transpose(int input_len, int output_len, int interp)
 {
     return guard_make([&] { return std::static_pointer_cast<jrc_host::block>(std::shared_ptr<matrix_transpose>(

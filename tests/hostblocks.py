@@ -20,12 +20,13 @@ def lib():
             jrc_amd._build.build_host()
         L = C.CDLL(LIB)
         L.jrcb_last_error.restype = C.c_char_p
-        for name in ("jrcb_make_radar", "jrcb_make_transpose", "jrcb_make_estimator", "jrcb_make_cp_remover",
+        for name in ("jrcb_make_radar", "jrcb_make_radar_chain", "jrcb_make_transpose", "jrcb_make_estimator", "jrcb_make_cp_remover",
                      "jrcb_make_peak_detect", "jrcb_make_equalizer", "jrcb_make_precoder", "jrcb_make_target_simulator", "jrcb_make_stream_encoder", "jrcb_make_stream_decoder",
                      "jrcb_make_moving_avg", "jrcb_make_frame_detector", "jrcb_make_frame_sync", "jrcb_make_zero_pad", "jrcb_make_frame_generator"):
             getattr(L, name).restype = _vp
         L.jrcb_make_radar.argtypes = [C.c_int] * 10
         L.jrcb_make_transpose.argtypes = [C.c_int] * 3
+        L.jrcb_make_radar_chain.argtypes = [C.c_int] * 8 + [_fp, C.c_int, _fp, C.c_int] + [C.c_float] * 4 + [C.c_char_p, C.c_int, C.c_int, C.c_int]
         L.jrcb_make_estimator.argtypes = [C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_char_p, C.c_int]
         L.jrcb_make_cp_remover.argtypes = [C.c_int, C.c_int]
         L.jrcb_make_peak_detect.argtypes = [C.c_int, C.c_float, C.c_float, C.c_int]
@@ -122,6 +123,15 @@ class Block:
 
 def radar(fft_len, N_tx, N_rx, N_sym, N_pre, bg_removal=False, bg_recording=False, record_len=8, interp=1, interleave=False):
     return Block(lib().jrcb_make_radar(fft_len, N_tx, N_rx, N_sym, N_pre, int(bg_removal), int(bg_recording), record_len, interp, int(interleave)))
+
+
+def radar_chain(fft_len, N_tx, N_rx, N_sym, N_pre, interp_range, interp_angle, rb, ab, ndr, nda, snr_thr, pow_thr, stats_path="",
+                stats_record=False, interleave=False, frames_per_batch=16, batches_in_flight=3):
+    rb = np.ascontiguousarray(rb, np.float32)
+    ab = np.ascontiguousarray(ab, np.float32)
+    return Block(lib().jrcb_make_radar_chain(fft_len, N_tx, N_rx, N_sym, N_pre, interp_range, interp_angle, int(interleave), _f(rb), len(rb),
+                                             _f(ab), len(ab), ndr, nda, snr_thr, pow_thr, stats_path.encode(), int(stats_record),
+                                             frames_per_batch, batches_in_flight))
 
 
 def transpose(input_len, output_len, interp):

@@ -450,3 +450,60 @@ def test_ofdm_frame_generator_block(jrc):
         hb.frame_generator(N, occ, pil, [[1 + 0j], [1j]], sync)
     with pytest.raises(ValueError, match="index out of bounds"):
         jrc.ofdm_frame_generator(N, [[17]], pil, psym, sync)
+
+
+@gpu
+def test_radar_chain_block_runs_the_five_block_branch_in_one(jrc, ctx, tmp_path):
+    """radar_chain: the ports and tags of mimo_ofdm_radar in, the messages and log lines of range_angle_estimator out, every frame
+    offered in a turn through the host-fed pipeline (batches of 4, 3 in flight), a trailing incomplete frame left for the next turn"""
+    import hostblocks as hb
+    import torch
+    from jrc_amd import synth
+    sc = synth.Scenario(64, 4, 2, 4, targets=[(9.0, 15.0, 0.0, 80.0)])
+    Ir, Ia, P, F = 8, 16, sc.T * sc.R, 11
+    n_items = sc.Npre + sc.S
+    rb, ab = jrc.radar_axes(sc.N, sc.fs, Ir, P, Ia)
+    frames = synth.make_frames(sc, 8)
+    frames = np.concatenate([frames, frames])[:F].copy()
+    frames[:, sc.T:] *= (1.0 + 0.02 * np.arange(F, dtype=np.float32))[:, None, None, None]
+    # reference results: the device-resident chain on the same frames
+    chain = jrc.RadarChain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb, ab, 2.4, 28.96, 15.0, 0.0, max_frames=F, ctx=ctx)
+    bufs = chain.alloc(F, "cuda:0")
+    bufs["frames"].copy_(torch.from_numpy(frames.view(np.float32).reshape(bufs["frames"].shape)))
+    torch.cuda.synchronize()
+    chain.run(bufs, F)
+    want = chain.results(bufs, F)
+
+    log = str(tmp_path / "radar_log.csv")
+    blk = hb.radar_chain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb, ab, 2.4, 28.96, 15.0, 0.0, log, True, frames_per_batch=4)
+    stale, plen = 3, n_items + 2                                       # packets two items longer than the block needs; one stale TX packet
+    def port_stream(p, n_fr, extra_tail=0):
+        parts = [frames[f, p] if True else None for f in range(n_fr)]
+        padded = [np.concatenate([x, np.zeros((plen - n_items, sc.N), np.complex64)]) for x in parts]
+        return np.ascontiguousarray(np.concatenate(padded)[:n_fr * plen - extra_tail])
+    tx = [np.concatenate([np.zeros((stale, sc.N), np.complex64), port_stream(t, F)]) for t in range(sc.T)]
+    rx = [port_stream(sc.T + r, F, extra_tail=5) for r in range(sc.R)]    # the last RX packet is cut short: not complete in this turn
+    blk.tag(0, 0, "packet_len", stale)
+    for f in range(F):
+        blk.tag(0, stale + f * plen, "packet_len", plen)
+        blk.tag(sc.T, f * plen, "packet_len", plen)
+    assert blk.run(0, tx + rx, []) == 0
+    done = F - 1
+    assert [blk.consumed(p) for p in range(sc.T + sc.R)] == [stale + done * plen] * sc.T + [done * plen] * sc.R
+    msgs = blk.state()["published"]
+    assert len(msgs) == done and all(m["port"] == "params" for m in msgs)
+    for f in range(done):
+        got = {k: v[0] for k, v in msgs[f]["msg"]}
+        assert got == {"range": want[f].range_val, "angle": want[f].angle_val, "power": want[f].peak_power, "snr": want[f].snr_est}, f
+    assert abs(want[0].range_val - 9.0) < 0.5
+    lines = [l for l in open(log).read().split("\n") if l.strip()]
+    assert lines[0].startswith(" NEW RECORD - ") and len(lines) == 1 + done
+    # next turn: the cut frame arrives whole (its tags from the first turn are still at the head of the streams)
+    tx2 = [port_stream(t, F)[done * plen:] for t in range(sc.T)]
+    rx2 = [port_stream(sc.T + r, F)[done * plen:] for r in range(sc.R)]
+    assert blk.run(0, tx2 + rx2, []) == 0
+    msgs = blk.state()["published"]
+    assert len(msgs) == F
+    assert {k: v[0] for k, v in msgs[-1]["msg"]}["snr"] == want[F - 1].snr_est
+    with pytest.raises(ValueError, match="RADAR CHAIN"):
+        hb.radar_chain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb[:-1], ab, 2.4, 28.96, 15.0, 0.0)
