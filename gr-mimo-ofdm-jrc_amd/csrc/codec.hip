@@ -154,7 +154,9 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void stream_decode_kernel(int n_dc,
 {
     __shared__ unsigned char ring[DEC_WAVES][10][64];
     __shared__ unsigned crc_tab[256];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // the wave index is uniform, but only this tells the compiler: without it
+                                                                              // every per-frame quantity below is compiled as exec-masked vector code
     const int f = blockIdx.x * DEC_WAVES + w;
     for (int i = threadIdx.x; i < 256; i += blockDim.x) crc_tab[i] = crc_table_entry(i);
     for (int i = lane; i < 10 * 64; i += 64) (&ring[w][0][0])[i] = 0;                   // d_ppresult zeroed (:333-337)
@@ -175,9 +177,9 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void stream_decode_kernel(int n_dc,
     const int bpsc = p.n_bpsc, half_rate = p.half_rate;
 
     // coded-bit source
-    auto load_sym = [&](int c0) -> float2 {
-        const int c = c0 + lane;
-        return (c < n_coded) ? s[c / bpsc] : make_float2(-1.f, -1.f);                  // past the frame: decides to 0
+    auto load_sym = [&](int c0) -> float2 {     // unconditional (index clamped): a select on the loaded value would force the wait right here,
+        const int c = max(0, min(c0 + lane, n_coded - 1));     // and the load is issued a block ahead precisely to avoid that; decide_word
+        return s[c / bpsc];                                    // zeroes the bits past the frame
     };
     auto decide_word = [&](float2 z, int c0) -> unsigned long long {
         const int c = c0 + lane;
@@ -274,6 +276,237 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void stream_decode_kernel(int n_dc,
     if (lane == 0) status[f] = ((crc ^ 0xFFFFFFFFu) == 558161692u) ? 1 : 0;              // :245-246
 }
 
+// ---- decoder, two frames per wave -----------------------------------------------------------------------------------
+// The add-compare-select of a trellis step is a dozen 8-bit operations per state; a 32-bit lane register holds the state of TWO
+// frames (bits 0-7 / 16-23 path metrics, bits 8-15 / 24-31 path chunks), so the two cross-lane fetches, the branch-metric
+// arithmetic and the select of a step serve both frames: the halves never carry into each other (metric + increment < 2^9 is
+// masked back to 8 bits, the compare subtracts with a guard bit per half).  Everything per frame that is wave-uniform — the bit
+// FIFO, depuncturing phase, traceback position, descrambler, CRC — stays on the scalar unit, once per frame.  Same arithmetic,
+// same outputs as stream_decode_kernel (which keeps the single-frame host call).
+#define DEC2_WAVES 4      // waves per workgroup, two frames each
+
+typedef unsigned short dec_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(dec_us2, a), __builtin_bit_cast(dec_us2, b)));
+}
+__device__ __forceinline__ unsigned pk_min_u16(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(dec_us2, a), __builtin_bit_cast(dec_us2, b)));
+}
+
+// wave-wide maximum / minimum of both 16-bit halves with DPP row shifts and row broadcasts (no LDS crossbar): the result sits in lane 63
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ unsigned dpp_pk_max(unsigned v) { return pk_max_u16(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROWMASK, 0xf, false)); }
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ unsigned dpp_pk_min(unsigned v) { return pk_min_u16(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROWMASK, 0xf, false)); }
+__device__ __forceinline__ unsigned wave_pk_max_u16(unsigned v)
+{
+    v = dpp_pk_max<0x111, 0xf>(v); v = dpp_pk_max<0x112, 0xf>(v); v = dpp_pk_max<0x114, 0xf>(v); v = dpp_pk_max<0x118, 0xf>(v);   // row_shr 1, 2, 4, 8
+    v = dpp_pk_max<0x142, 0xa>(v); v = dpp_pk_max<0x143, 0xc>(v);                                                                 // row_bcast 15, 31
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned wave_pk_min_u16(unsigned v)
+{
+    v = dpp_pk_min<0x111, 0xf>(v); v = dpp_pk_min<0x112, 0xf>(v); v = dpp_pk_min<0x114, 0xf>(v); v = dpp_pk_min<0x118, 0xf>(v);
+    v = dpp_pk_min<0x142, 0xa>(v); v = dpp_pk_min<0x143, 0xc>(v);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__global__ __launch_bounds__(64 * DEC2_WAVES) void stream_decode2_kernel(int n_dc, int n_frames, const float2* __restrict__ sym, long sym_stride,
+                                                                         const int* __restrict__ mcs_arr, const int* __restrict__ bytes_arr,
+                                                                         unsigned char* __restrict__ payload, long payload_stride,
+                                                                         int* __restrict__ status)
+{
+    // decoded bytes collect in LDS and go out in one coalesced copy per frame: a byte store per output inside the loop sits in the same
+    // in-order memory counter as the symbol prefetch, whose wait would then also wait for every store behind it
+    __shared__ unsigned char obuf[DEC2_WAVES][2][(CODEC_MAX_PAYLOAD + 7) & ~7];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // the wave index is uniform, but only this tells the compiler: without it
+                                                                              // every per-frame quantity below is compiled as exec-masked vector code
+    const int f0 = (blockIdx.x * DEC2_WAVES + w) * 2;
+    if (f0 >= n_frames) return;
+    // CRC-32 table in registers: entry e in lane e % 64 of tabv[e / 64], fetched with v_readlane (the index is wave-uniform)
+    unsigned tabv[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) tabv[j] = crc_table_entry(64 * j + lane);
+    auto crc_entry = [&](unsigned e) -> unsigned {
+        const int l = (int)(e & 63u);
+        const unsigned x0 = (unsigned)__builtin_amdgcn_readlane((int)tabv[0], l), x1 = (unsigned)__builtin_amdgcn_readlane((int)tabv[1], l);
+        const unsigned x2 = (unsigned)__builtin_amdgcn_readlane((int)tabv[2], l), x3 = (unsigned)__builtin_amdgcn_readlane((int)tabv[3], l);
+        const unsigned hi = e >> 6;
+        return hi == 0 ? x0 : (hi == 1 ? x1 : (hi == 2 ? x2 : x3));
+    };
+    // the last ten path chunks of every state (both frames per register), newest first: d_ppresult (:333-337) as a shift register, so
+    // the traceback walks registers with v_readlane instead of chasing bytes through LDS
+    unsigned rr[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) rr[i] = 0;
+
+    // per-frame, wave-uniform
+    int act[2], bpsc[2], half_rate[2], nt[2], ndb[2], n_coded[2], dsb[2], n_steps[2];
+    const float2* sp[2];
+    unsigned char* pl[2];
+    int steps = 0;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int f = f0 + q;
+        act[q] = f < n_frames;
+        bpsc[q] = 1; half_rate[q] = 1; nt[q] = 5; ndb[q] = 0; n_coded[q] = 0; dsb[q] = 0; n_steps[q] = 0; sp[q] = sym; pl[q] = payload;
+        if (act[q]) {
+            const int mcs = __builtin_amdgcn_readfirstlane(mcs_arr[f]);
+            dsb[q] = __builtin_amdgcn_readfirstlane(bytes_arr[f]);
+            McsParams p;
+            if (!mcs_params(mcs, n_dc, p) || dsb[q] < 0 || dsb[q] > CODEC_MAX_PAYLOAD || n_sym_for(dsb[q], p.n_dbps) > CODEC_MAX_SYM) {   // :133-146
+                if (lane == 0) status[f] = -1;
+                act[q] = 0;
+            } else {
+                const int n_sym = n_sym_for(dsb[q], p.n_dbps);
+                ndb[q] = n_sym * p.n_dbps; n_coded[q] = n_sym * p.n_cbps;
+                bpsc[q] = p.n_bpsc; half_rate[q] = p.half_rate;
+                nt[q] = p.half_rate ? 5 : 10;                                           // reset() (:293-315)
+                const int n_calls = nt[q] + (ndb[q] + 7) / 8;                           // get_output calls until n_decoded >= n_data_bits
+                n_steps[q] = 6 + 8 * (n_calls - 1);
+                sp[q] = sym + (size_t)f * sym_stride;
+                pl[q] = payload + (size_t)f * payload_stride;
+                steps = max(steps, n_steps[q]);
+            }
+        }
+    }
+    if (!act[0] && !act[1]) return;
+
+    auto load_sym = [&](int q, int c0) -> float2 {  // unconditional (index clamped): a select on the loaded value would force the wait right
+        const int c = max(0, min(c0 + lane, n_coded[q] - 1));  // here, and the load is issued a block ahead precisely to avoid that;
+        return sp[q][c / bpsc[q]];                             // decide_word zeroes the bits past the frame
+    };
+    auto decide_word = [&](int q, float2 z, int c0) -> unsigned long long {
+        const int c = c0 + lane;
+        const int bit = (c < n_coded[q]) ? ((constellation_decide(bpsc[q], z) >> (c % bpsc[q])) & 1) : 0;
+        return __ballot(bit);
+    };
+    // The soft-bit pair of a trellis step (depuncturing included, :236-252) is prepared a block at a time by the lanes: one 64-bit word
+    // of hard decisions feeds 32 steps at rate 1/2 or 48 steps at rate 3/4 (pattern 1,1,1,0,0,1 — a block starts at phase 0); lane i
+    // works out the pair of step blk_t0 + i as four flags (bit 0 / 1: the two bits, bit 2 / 3: transmitted or punctured).  A step then
+    // costs the scalar unit one v_readlane per frame instead of a bit FIFO with its shifts and branches.
+    float2 zp[2];
+    int wbase[2] = {0, 0}, blk_t0[2] = {0, 0}, out_count[2] = {0, 0}, lfsr[2] = {0, 0};
+    unsigned ctl[2];
+    unsigned crc[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+    auto make_ctl = [&](int q, unsigned long long word, int t0) -> unsigned {
+        int p0, p1, e0 = 1, e1 = 1;
+        if (half_rate[q]) { p0 = 2 * lane; p1 = 2 * lane + 1; }
+        else {
+            const int g = lane / 3, ph = lane - 3 * g;
+            p0 = 4 * g + (ph == 1 ? 2 : 0); p1 = 4 * g + (ph == 2 ? 3 : 1);
+            e0 = ph != 2; e1 = ph != 1;
+        }
+        unsigned b0 = (unsigned)((word >> (p0 & 63)) & 1ull) & (unsigned)e0, b1 = (unsigned)((word >> (p1 & 63)) & 1ull) & (unsigned)e1;
+        if (t0 + lane >= ndb[q]) { b0 = 0; b1 = 0; e0 = 1; e1 = 1; }                   // past the end of the frame: 0, 0 (fresh buffers)
+        return b0 | (b1 << 1) | ((unsigned)e0 << 2) | ((unsigned)e1 << 3);
+    };
+    int blk_len[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        blk_len[q] = half_rate[q] ? 32 : 48;
+        zp[q] = load_sym(q, 0);
+        ctl[q] = make_ctl(q, decide_word(q, zp[q], 0), 0);
+        zp[q] = load_sym(q, 64);
+    }
+
+    // trellis: lane = new state; butterfly k = lane >> 1 reads old states k and k + 32 (viterbi_butterfly2_sse2, :87-180)
+    const int k = lane >> 1, odd = lane & 1;
+    const unsigned bt0p = (unsigned)(__popc((2 * k) & 0x6d) & 1) * 0x00010001u;         // d_branchtab27_sse2 (:323-326), both halves
+    const unsigned bt1p = (unsigned)(__popc((2 * k) & 0x4f) & 1) * 0x00010001u;
+    unsigned st = 0;                                                                    // per half: metric | path << 8
+    for (int t = 0; t < steps; t++) {
+        unsigned cc = 0;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            if (t == blk_t0[q] + blk_len[q]) {                                          // next word of decisions
+                blk_t0[q] = t; wbase[q] += 64;
+                ctl[q] = make_ctl(q, decide_word(q, zp[q], wbase[q]), t);
+                zp[q] = load_sym(q, wbase[q] + 64);
+            }
+            cc |= (unsigned)__builtin_amdgcn_readlane((int)ctl[q], t - blk_t0[q]) << (16 * q);
+        }
+        const unsigned s0p = cc & 0x00010001u, s1p = (cc >> 1) & 0x00010001u, e0p = (cc >> 2) & 0x00010001u, e1p = (cc >> 3) & 0x00010001u;
+        // branch metrics of both frames: metsvm = (bt0 ^ s0) + (bt1 ^ s1) over the transmitted bits, metsv = (their number) - metsvm
+        const unsigned m = ((bt0p ^ s0p) & e0p) + ((bt1p ^ s1p) & e1p);
+        const unsigned totp = e0p + e1p;
+        const unsigned xadd = odd ? m : totp - m;                                       // even new state: ma + metsv vs mb + metsvm; odd: the other way
+        const unsigned yadd = totp - xadd;
+        const unsigned a = __shfl(st, k), b = __shfl(st, k + 32);
+        const unsigned ca = ((a + xadd) & 0x00ff00ffu) | ((a & 0x7f007f00u) << 1);
+        const unsigned cb = ((b + yadd) & 0x00ff00ffu) | ((b & 0x7f007f00u) << 1) | 0x01000100u;
+        // _mm_cmpgt_epi8(_mm_sub_epi8(m0, m1), 0) per half: d = (x - y) mod 256 in 1..127
+        const unsigned d = (((ca & 0x00ff00ffu) | 0x01000100u) - (cb & 0x00ff00ffu)) & 0x00ff00ffu;
+        const unsigned dec7 = ((d & 0x007f007fu) + 0x007f007fu) & ~d & 0x00800080u;
+        const unsigned mask = (dec7 >> 7) * 0xffffu;
+        st = (ca & mask) | (cb & ~mask);
+        if (t >= 5 && ((t - 5) & 7) == 0) {                                             // viterbi_get_output_sse2 (:183-225) after steps 6, 14, 22, ...
+            int live[2];
+#pragma unroll
+            for (int q = 0; q < 2; q++) live[q] = act[q] && t < n_steps[q];
+#pragma unroll
+            for (int i = 9; i > 0; i--) rr[i] = rr[i - 1];
+            rr[0] = (st >> 8) & 0x00ff00ffu;
+            const unsigned mp = st & 0x00ff00ffu;
+            const unsigned mx = wave_pk_max_u16(mp), mn = wave_pk_min_u16(mp);
+            int c[2] = {0, 0};
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+                if (live[q]) {
+                    const unsigned metric = (mp >> (16 * q)) & 0xffu, best = (mx >> (16 * q)) & 0xffu;
+                    int bs = __ffsll((unsigned long long)__ballot(metric == best)) - 1;        // first maximum (strict > in the scan)
+#pragma unroll
+                    for (int i = 0; i < 9; i++)
+                        if (i < nt[q] - 1) bs = (int)((((unsigned)__builtin_amdgcn_readlane((int)rr[i], bs) >> (16 * q)) & 0xffu) >> 2);
+                    const unsigned last = half_rate[q] ? (unsigned)__builtin_amdgcn_readlane((int)rr[4], bs) : (unsigned)__builtin_amdgcn_readlane((int)rr[9], bs);
+                    c[q] = (int)((last >> (16 * q)) & 0xffu);
+                }
+            // paths zeroed, metrics renormalised (each half >= its minimum: no borrow)
+            {
+                const unsigned keep = (live[0] ? 0x0000ffffu : 0u) | (live[1] ? 0xffff0000u : 0u);
+                st = (st & ~keep) | ((mp - mn) & 0x00ff00ffu & keep);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+                if (live[q]) {
+                    if (out_count[q] >= nt[q]) {                                        // decoded bits, MSB first (:277-281)
+                        const int j = out_count[q] - nt[q];                             // byte j = stream bits 8j .. 8j+7
+                        int ob = 0;
+                        if (j == 0) {                                                   // descramble (:406-433): state from bits 0..6
+                            lfsr[q] = (c[q] >> 1) & 0x7f;
+                            const int fb = (!!(lfsr[q] & 64)) ^ (!!(lfsr[q] & 8));      // bit 7 belongs to out_bytes[0] (unused)
+                            lfsr[q] = ((lfsr[q] << 1) & 0x7e) | fb;
+                        } else {
+#pragma unroll
+                            for (int bb = 0; bb < 8; bb++) {
+                                const int fb = (!!(lfsr[q] & 64)) ^ (!!(lfsr[q] & 8));
+                                ob |= (fb ^ ((c[q] >> (7 - bb)) & 1)) << bb;
+                                lfsr[q] = ((lfsr[q] << 1) & 0x7e) | fb;
+                            }
+                        }
+                        const int by = j - 2;                                           // out_bytes + 2 = PSDU incl. CRC
+                        if (by >= 0 && by < dsb[q]) {
+                            crc[q] = crc_entry((crc[q] ^ (unsigned)ob) & 0xffu) ^ (crc[q] >> 8);
+                            if (by < dsb[q] - 4 && lane == 0) obuf[w][q][by] = (unsigned char)ob;
+                        }
+                    }
+                    out_count[q]++;
+                }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+        if (act[q])
+            for (int i = lane; i < dsb[q] - 4; i += 64) pl[q][i] = obuf[w][q][i];
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+        if (act[q] && lane == 0) status[f0 + q] = ((crc[q] ^ 0xFFFFFFFFu) == 558161692u) ? 1 : 0;   // :245-246
+}
+
 // ---- C ABI ------------------------------------------------------------------------------------------
 extern "C" int jrc_stream_n_ofdm_sym(int mcs, int n_data_carriers, int data_size_byte)
 {
@@ -312,8 +545,14 @@ extern "C" int jrc_stream_decode_dev(jrc_ctx* ctx, int n_data_carriers, int n_fr
     if (n_frames == 0) return JRC_OK;
     JRC_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-    hipLaunchKernelGGL(stream_decode_kernel, dim3((n_frames + DEC_WAVES - 1) / DEC_WAVES), dim3(64 * DEC_WAVES), 0, s, n_data_carriers,
-                       n_frames, (const float2*)d_sym, sym_stride, d_mcs, d_data_bytes, d_payload, payload_stride, d_status);
+    if (n_frames >= 2 && !ctx->tune.dec_single) {
+        const int per_wg = 2 * DEC2_WAVES;
+        hipLaunchKernelGGL(stream_decode2_kernel, dim3((n_frames + per_wg - 1) / per_wg), dim3(64 * DEC2_WAVES), 0, s, n_data_carriers,
+                           n_frames, (const float2*)d_sym, sym_stride, d_mcs, d_data_bytes, d_payload, payload_stride, d_status);
+    } else {
+        hipLaunchKernelGGL(stream_decode_kernel, dim3((n_frames + DEC_WAVES - 1) / DEC_WAVES), dim3(64 * DEC_WAVES), 0, s, n_data_carriers,
+                           n_frames, (const float2*)d_sym, sym_stride, d_mcs, d_data_bytes, d_payload, payload_stride, d_status);
+    }
     JRC_HIP(ctx, hipGetLastError());
     return JRC_OK;
 }

@@ -62,6 +62,7 @@ extern "C" int jrc_create(int device, jrc_ctx** out)
     ctx->tune.chanest_x1 = getenv("JRC_CHANEST_X1") != nullptr;
     ctx->tune.fd_serial = getenv("JRC_FD_SERIAL") != nullptr;
     ctx->tune.sync_naive = getenv("JRC_SYNC_NAIVE") != nullptr;
+    ctx->tune.dec_single = getenv("JRC_DEC_SINGLE") != nullptr;
     *out = ctx;
     return JRC_OK;
 }

@@ -37,6 +37,7 @@ struct jrc_ctx {
         bool chanest_x1 = false;     // JRC_CHANEST_X1: one subcarrier per lane in A1
         bool fd_serial = false;      // JRC_FD_SERIAL: single-wave detector scan
         bool sync_naive = false;     // JRC_SYNC_NAIVE: detection metrics without the LDS tile
+        bool dec_single = false;     // JRC_DEC_SINGLE: Viterbi decoder with one frame per wave
     } tune;
 };
 
