@@ -547,6 +547,161 @@ __global__ void rd_product_pad_kernel(const float2* __restrict__ frames, float2*
     }
 }
 
+// ---- row D, fused: Doppler first (compact), range last (streamed) ------------------------------------------------------------
+// The 2-D transform is separable, so the order is chosen for traffic: (1) rd_product_t_kernel forms D and transposes it to
+// [pair][subcarrier][symbol] (zero-padded to ND), (2) the stock FFT runs over the symbol axis in place (forward, shifted) — both on
+// S*Id*N points per pair, 1/Ir of the output — and (3) range_doppler_fused_kernel does the zero-padded range IFFT exactly like the
+// range-angle kernel does (twiddled fold to 64 points + 64-point inverse FFT across the wavefront, one residue class of range bins
+// at a time) for a tile of 16 Doppler bins held in LDS, and streams the [range][Doppler] map out once, non-temporally.
+#define RD_DT 16   // Doppler bins per workgroup tile (= one 128-byte segment of an output row)
+
+__global__ __launch_bounds__(256) void rd_product_t_kernel(const float2* __restrict__ frames, float2* __restrict__ Dt, ChanestGeom g, int T, int R, int ND)
+{
+    __shared__ float2 tile[64][65];
+    const int P = T * R;
+    const size_t fp = blockIdx.z;
+    const int p = (int)(fp % P);
+    const size_t f = fp / P;
+    const int r = g.interleave ? p % R : p / T, t = g.interleave ? p / R : p % T;
+    const float2* fb = frames + f * g.frame_stride;
+    const float2* rxp = fb + (size_t)(T + r) * g.port_stride + (size_t)g.rx_item0 * g.N;
+    const float2* txp = fb + (size_t)t * g.port_stride + (size_t)g.tx_item0 * g.N;
+    const int n0 = blockIdx.x * 64, s0 = blockIdx.y * 64;
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    for (int ss = ly; ss < 64; ss += 4) {
+        const int sym = s0 + ss, n = n0 + lx;
+        float2 v = make_float2(0.f, 0.f);
+        if (sym < g.S && n < g.N) {
+            const float2 a = rxp[(size_t)sym * g.N + n], b = txp[(size_t)sym * g.N + n];
+            v = make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);               // rx * conj(tx)
+        }
+        tile[ss][lx] = v;
+    }
+    __syncthreads();
+    float2* dst = Dt + fp * (size_t)g.N * ND;
+    for (int ll = ly; ll < 64; ll += 4) {
+        const int n = n0 + ll, sym = s0 + lx;
+        if (n < g.N && sym < ND) dst[(size_t)n * ND + sym] = tile[lx][ll];
+    }
+}
+
+template <int NT, int MMAX, bool TWC_LDS>
+__global__ __launch_bounds__(NT) void range_doppler_fused_kernel(const float2* __restrict__ E,     // [units/(ND/16)][N][ND]
+                                                                 float2* __restrict__ out,         // [units/(ND/16)][NR][ND]
+                                                                 const float2* __restrict__ twR, int N, int NR, int ND, long n_units, int WPF)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    constexpr int NW = NT / 64, P = RD_DT;
+    const int C = NR / RA_L;
+    const int xcd = blockIdx.x & 7;
+    const long j = blockIdx.x >> 3;
+    const long u = (j / WPF) * 8 + xcd;
+    const int slice = (int)(j % WPF);
+    if (u >= n_units) return;
+    const int tiles = ND / RD_DT;
+    const long fp = u / tiles;
+    const int d0 = (int)(u % tiles) * RD_DT;
+
+    float2* s_H = smem;                         // [16][N]: the tile's Doppler bins, subcarrier-contiguous
+    float2* s_g = s_H + (size_t)P * N;          // [16][64] range bins of the current class
+    float2* s_twc = s_g + P * RA_L;             // [N] class twiddles (TWC_LDS only)
+    constexpr int NPT = TWC_LDS ? 4 : 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int M = N / RA_L;
+
+    float2 tc[TWC_LDS ? 1 : MMAX];
+    float2 tn[NPT];
+    if constexpr (TWC_LDS) {
+#pragma unroll
+        for (int q = 0; q < NPT; q++) { const int n = tid + NT * q; if (n < N) tn[q] = twR[(n * slice) & (NR - 1)]; }
+    } else {
+#pragma unroll
+        for (int m = 0; m < MMAX; m++)
+            if (m < M) tc[m] = twR[((lane + RA_L * m) * slice) & (NR - 1)];
+    }
+    {   // stage the tile: row n of E holds the 16 bins as one 128-byte segment; eight lanes fetch it as 16-byte pieces
+        const float2* Eb = E + (size_t)fp * N * ND + d0;
+        for (int i = tid; i < N * 8; i += NT) {
+            const int n = i >> 3, part = i & 7;
+            const float4 v = *reinterpret_cast<const float4*>(Eb + (size_t)n * ND + 2 * part);
+            s_H[(size_t)(2 * part) * N + n] = make_float2(v.x, v.y);
+            s_H[(size_t)(2 * part + 1) * N + n] = make_float2(v.z, v.w);
+        }
+    }
+    float2 t64[6];
+#pragma unroll
+    for (int st = 0; st < 6; st++) {
+        const int half = 32 >> st;
+        t64[st] = twR[((lane & (half - 1)) * (32 / half)) * (NR / 64)];
+    }
+    float2* outp = out + (size_t)fp * NR * ND + d0;
+    typedef float v2f __attribute__((ext_vector_type(2)));
+#pragma unroll 1
+    for (int c = slice; c < C; c += WPF) {
+        if constexpr (TWC_LDS) {
+#pragma unroll
+            for (int q = 0; q < NPT; q++) { const int n = tid + NT * q; if (n < N) s_twc[n] = tn[q]; }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int p = wave; p < P; p += NW) {    // range axis: fold to 64 points, 64-point inverse FFT across the wavefront
+            const float2* Hp = s_H + (size_t)p * N + lane;
+            float2 v = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int m = 0; m < MMAX; m++)
+                if (m < M) {
+                    float2 w;
+                    if constexpr (TWC_LDS) w = s_twc[lane + RA_L * m]; else w = tc[m];
+                    const float2 h = Hp[RA_L * m];
+                    v.x = fmaf(h.x, w.x, fmaf(-h.y, w.y, v.x));
+                    v.y = fmaf(h.x, w.y, fmaf(h.y, w.x, v.y));
+                }
+#pragma unroll
+            for (int st = 0; st < 6; st++) {
+                const int half = 32 >> st;
+                const float2 o = make_float2(__shfl_xor(v.x, half), __shfl_xor(v.y, half));
+                v = (lane & half) ? cmul(csub(o, v), t64[st]) : cadd(v, o);
+            }
+            s_g[p * RA_L + (__brev((unsigned)lane) >> 26)] = v;
+        }
+        {
+            const int cn = c + WPF;
+            if (cn < C) {
+                if constexpr (TWC_LDS) {
+#pragma unroll
+                    for (int q = 0; q < NPT; q++) { const int n = tid + NT * q; if (n < N) tn[q] = twR[(n * cn) & (NR - 1)]; }
+                } else {
+#pragma unroll
+                    for (int m = 0; m < MMAX; m++)
+                        if (m < M) tc[m] = twR[((lane + RA_L * m) * cn) & (NR - 1)];
+                }
+            }
+        }
+        __syncthreads();
+        // 64 range bins x 16 Doppler bins: 16 lanes write one 128-byte segment of a map row
+        for (int w0 = tid; w0 < RA_L * RD_DT; w0 += NT) {
+            const int ql = w0 >> 4, di = w0 & 15;
+            const float2 y = s_g[di * RA_L + ql];
+            const v2f tv = {y.x, y.y};
+            __builtin_nontemporal_store(tv, reinterpret_cast<v2f*>(outp + (size_t)(C * ql + c) * ND + di));
+        }
+    }
+}
+
+template <int NT, int MMAX, bool TWC_LDS>
+static int launch_rd_fused(jrc_ctx* ctx, const float2* E, float2* out, const float2* twR, int N, int NR, int ND, long n_units, size_t lds, hipStream_t s)
+{
+    JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)range_doppler_fused_kernel<NT, MMAX, TWC_LDS>, lds));
+    const int C = NR / RA_L;
+    const long target = (long)ctx->n_cus * (lds > 80 * 1024 ? 1 : 2);
+    int wpf = 1;
+    while (wpf * 2 <= C && (long)wpf * 2 * n_units <= target) wpf *= 2;
+    const long groups = (n_units + 7) / 8;
+    hipLaunchKernelGGL((range_doppler_fused_kernel<NT, MMAX, TWC_LDS>), dim3((unsigned)(groups * wpf * 8)), dim3(NT), lds, s, E, out, twR, N, NR, ND, n_units, wpf);
+    JRC_HIP(ctx, hipGetLastError());
+    return JRC_OK;
+}
+
 extern "C" int jrc_range_doppler_dev(jrc_ctx* ctx, const jrc_chain_cfg* c, int interp_doppler, int n_frames,
                                      const jrc_cf32* d_frames, jrc_cf32* d_work, jrc_cf32* d_out, void* stream)
 {
@@ -560,6 +715,22 @@ extern "C" int jrc_range_doppler_dev(jrc_ctx* ctx, const jrc_chain_cfg* c, int i
     ChanestGeom g;
     g.N = N; g.S = S; g.port_stride = (long)c->n_items * N; g.frame_stride = g.port_stride * (T + R);
     g.tx_item0 = c->N_pre; g.rx_item0 = c->N_pre; g.interleave = c->enable_tx_interleave;
+    // fused path: Doppler FFT on the compact data, zero-padded range IFFT streamed out once (d_work holds [pair][N][ND] <= its size)
+    if (jrc_is_pow2(N) && N >= RA_L && N <= 1024 && jrc_is_pow2(NR) && NR >= RA_L && jrc_is_pow2(ND) && ND >= RD_DT && ND <= 8192 &&
+        interp_doppler <= c->interp_range && ((reinterpret_cast<size_t>(d_work) & 15) == 0) && !getenv("JRC_RD_GENERIC")) {
+        const size_t fp = (size_t)n_frames * P;
+        hipLaunchKernelGGL(rd_product_t_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((ND + 63) / 64), (unsigned)fp), dim3(256), 0, s,
+                           (const float2*)d_frames, (float2*)d_work, g, T, R, (int)ND);
+        JRC_HIP(ctx, hipGetLastError());
+        JRC_TRY(launch_fft_vcc(ctx, (int)ND, 1, 1, nullptr, fp * N, (const float2*)d_work, (float2*)d_work, ND, 0, s));        // Doppler
+        const float2* twR = nullptr;
+        JRC_TRY(jrc_get_twiddles(ctx, (int)NR, +1, &twR));
+        const size_t lds = sizeof(float2) * ((size_t)RD_DT * N + (size_t)RD_DT * RA_L + (N > 256 ? (size_t)N : 0));
+        const long n_units = (long)fp * (ND / RD_DT);
+        if (lds > 80 * 1024) return launch_rd_fused<512, 16, true>(ctx, (const float2*)d_work, (float2*)d_out, twR, N, (int)NR, (int)ND, n_units, lds, s);
+        if (N > 256) return launch_rd_fused<256, 16, true>(ctx, (const float2*)d_work, (float2*)d_out, twR, N, (int)NR, (int)ND, n_units, lds, s);
+        return launch_rd_fused<256, 4, false>(ctx, (const float2*)d_work, (float2*)d_out, twR, N, (int)NR, (int)ND, n_units, lds, s);
+    }
     const size_t rows = (size_t)n_frames * P * S, total = rows * NR;
     unsigned pb = (unsigned)((total + 255) / 256); if (pb > 16384) pb = 16384;
     hipLaunchKernelGGL(rd_product_pad_kernel, dim3(pb), dim3(256), 0, s, (const float2*)d_frames, (float2*)d_work, g, T, R, (int)NR, total);

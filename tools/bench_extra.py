@@ -62,6 +62,32 @@ def radar_with_demod(cfg="B", F=256):
                 frames_per_s_separate_demod=F / t_unfused, ms_chain_only=t_chain * 1e3, frames_per_s_chain_only=F / t_chain)
 
 
+def range_doppler(cfg="D", F=8, Id=1):
+    """row D (no reference counterpart): D[p][sym][sc] = rx conj(tx) -> IFFT over subcarriers (N*Ir) -> FFT over symbols (S*Id, shifted)"""
+    sc = {"B": synth.config_B, "D": synth.config_D}[cfg]()
+    Ir, Ia, P = 8, 16, sc.T * sc.R
+    rb, ab = jrc_amd.radar_axes(sc.N, sc.fs, Ir, P, Ia)
+    ctx = jrc_amd.Context(0)
+    chain = jrc_amd.RadarChain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb, ab, 2.4, 14.36, 15.0, 0.0, max_frames=F, ctx=ctx)
+    bufs = chain.alloc(F, "cuda:0")
+    fr = synth.make_frames(sc, min(F, 8))
+    hf = torch.from_numpy(fr.view(np.float32).reshape((fr.shape[0],) + tuple(bufs["frames"].shape[1:])))
+    for f0 in range(0, F, fr.shape[0]):
+        bufs["frames"][f0:f0 + fr.shape[0]].copy_(hf[:min(fr.shape[0], F - f0)])
+    c = chain.cfg
+    work = torch.empty((F, P, c.N_sym, chain.NR, 2), dtype=torch.float32, device="cuda:0")
+    out = torch.empty((F, P, chain.NR, c.N_sym * Id, 2), dtype=torch.float32, device="cuda:0")
+    L = ctx.lib
+    import ctypes as C
+
+    def step():
+        ctx.check(L.jrc_range_doppler_dev(ctx.h, C.byref(chain.cfg), Id, F, bufs["frames"].data_ptr(), work.data_ptr(), out.data_ptr(), None))
+    t = timed(step, steps=10, warm=2)
+    alg = F * ((sc.T + sc.R) * sc.S * sc.N * 8 + P * chain.NR * sc.S * Id * 8)
+    return dict(what="range-Doppler map (row D, build's own definition) config %s: %d pairs x %d range bins x %d Doppler bins per frame" % (cfg, P, chain.NR, sc.S * Id),
+                frames_per_step=F, ms_per_step=t * 1e3, frames_per_s=F / t, GBps_algorithmic=alg / t / 1e9)
+
+
 def simulated_chain(cfg="B", F=64):
     """T target simulators (accumulating into the RX bursts) + RX demod + radar chain per frame, everything in HBM"""
     sc = {"B": synth.config_B, "D": synth.config_D}[cfg]()
@@ -200,6 +226,6 @@ def equalizer_config_c(n_frames=2048, lanes=4, S=64):
 
 if __name__ == "__main__":
     # the two probes that run as child processes go first: once this process holds a GPU context they would time-slice with it
-    for fn in (sync_front_end, comm_rx_chain, lambda: radar_with_demod("B", 512), lambda: radar_with_demod("D", 256), precoder_config_c,
+    for fn in (sync_front_end, comm_rx_chain, lambda: radar_with_demod("B", 512), lambda: radar_with_demod("D", 256), precoder_config_c, lambda: range_doppler("D", 8), lambda: range_doppler("B", 64),
                lambda: simulated_chain("B", 64), lambda: simulated_chain("D", 8), equalizer_config_c):
         print(json.dumps(fn()))
