@@ -305,6 +305,7 @@ def _td_case(jrc, ctx, T, R, N, cp, S, Npre, F, interleave, extra, seed):
     d_tx = torch.from_numpy(tx.view(np.float32).reshape(F, T, n_items, N, 2)).cuda()
     d_rx = torch.from_numpy(rx.view(np.float32).reshape(F, R, L, 2)).cuda()
     H = torch.full((F, T * R, N, 2), float("nan"), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()            # the library runs on its own stream: torch's fill must have landed before it writes H
     lib = ctx.lib
     ctx.check(lib.jrc_radar_chanest_td_dev(ctx.h, N, cp, T, R, S, Npre, n_items, L, int(interleave), F, d_tx.data_ptr(),
                                            d_rx.data_ptr(), H.data_ptr(), None))
@@ -314,12 +315,14 @@ def _td_case(jrc, ctx, T, R, N, cp, S, Npre, F, interleave, extra, seed):
     frames = torch.empty((F, T + R, n_items, N, 2), dtype=torch.float32, device="cuda:0")
     frames[:, :T] = d_tx
     rxf = torch.empty((F, R, n_items, N, 2), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
     for f in range(F):
         for r in range(R):
             ctx.check(lib.jrc_cp_remove_fft_dev(ctx.h, N, cp, n_items, d_rx[f, r].data_ptr(), rxf[f, r].data_ptr(), None))
     ctx.sync()
     frames[:, T:] = rxf
     H2 = torch.empty_like(H)
+    torch.cuda.synchronize()
     ctx.check(lib.jrc_radar_chanest_dev(ctx.h, N, T, R, S, Npre, n_items, int(interleave), F, frames.data_ptr(), H2.data_ptr(), None))
     ctx.sync()
     Hu = H2.cpu().numpy().view(np.complex64)[..., 0]
@@ -372,12 +375,14 @@ def test_chain_with_time_domain_receive_side(jrc, ctx):
     rb, ab = jrc.radar_axes(sc.N, sc.fs, Ir, P, Ia)
     chain = jrc.RadarChain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb, ab, 2.4, 30.0, 15.0, 0.0, max_frames=F, ctx=ctx)
     bufs = chain.alloc(F, "cuda:0")
+    torch.cuda.synchronize()
     chain.run_td(bufs, d_tx, d_td, F, cp)
-    res_td = chain.results(bufs, F)
+    res_td = chain.results(bufs, F)                                  # synchronises the library's stream
     map_td = bufs["map"].cpu().numpy().copy()
     # unfused: demodulate into the RX ports of a frame buffer, then the frequency-domain chain
     bufs["frames"][:, :sc.T] = d_tx
     rx_tmp = torch.empty((F, sc.R, n_items, N, 2), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
     ctx.check(ctx.lib.jrc_cp_remove_fft_dev(ctx.h, N, cp, F * sc.R * n_items, d_td.data_ptr(), rx_tmp.data_ptr(), None))
     ctx.sync()
     bufs["frames"][:, sc.T:] = rx_tmp

@@ -283,7 +283,9 @@ def test_precoder_batched_device_resident(jrc, ctx, ptype, steer):
     S2 = oracle.n_ofdm_sym(mcs, nd, nb2)
     s2 = np.stack([qpsk(rng, S2 * nd) for _ in range(2)])
     dkw.pop("d_radar_streams", None)
-    got2 = gp.frames_dev(up(s2), mcs, ptype, nb2, **dkw).cpu().numpy().view(np.complex64)[..., 0]
+    out2 = gp.frames_dev(up(s2), mcs, ptype, nb2, **dkw)
+    ctx.sync()                                                       # the library's stream, not torch's
+    got2 = out2.cpu().numpy().view(np.complex64)[..., 0]
     assert np.array_equal(got2[1], gp.work(s2[1], mcs, ptype, nb2, **kw))
     with pytest.raises(RuntimeError, match="MIMO PRECODER"):
         gp.frames_dev(up(s2), mcs, ptype, nbytes, **dkw)
