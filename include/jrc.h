@@ -13,7 +13,9 @@
  *   - "host" entry points take caller-owned host memory (GNU Radio ring buffers), stage through
  *     pinned memory, run the HIP kernels and are synchronous on return.
  *   - "_dev" entry points take device pointers (hipMalloc / torch.cuda tensors) and a stream
- *     (hipStream_t passed as void*; NULL = the context's own stream) and are asynchronous.
+ *     (hipStream_t passed as void*; NULL = the context's own, non-blocking stream, which does NOT order against
+ *     the legacy default stream other libraries may be using: pass hipStreamLegacy = (void*)1 to run on that one)
+ *     and are asynchronous.
  *   - One jrc_ctx per host thread; a ctx is bound to one GPU.  There is no CPU fallback: without a
  *     usable HIP device jrc_create() fails with JRC_ERR_NO_DEVICE.
  */
