@@ -2,6 +2,7 @@
 #include "jrc_internal.h"
 
 #include <cstdlib>
+#include <thread>
 
 #include <cmath>
 
@@ -150,6 +151,20 @@ int jrc_ensure_dyn_lds(jrc_ctx* ctx, const void* kernel, size_t bytes)
     JRC_HIP(ctx, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     ctx->dyn_lds[kernel] = bytes;
     return JRC_OK;
+}
+
+void jrc_host_copy(void* dst, const void* src, size_t bytes)
+{
+    const int n_thr = bytes >= ((size_t)16 << 20) ? 4 : (bytes >= ((size_t)4 << 20) ? 2 : 1);
+    if (n_thr == 1) { if (bytes) memcpy(dst, src, bytes); return; }
+    std::thread th[3];
+    const size_t part = ((bytes / n_thr) + 4095) & ~(size_t)4095;
+    for (int i = 1; i < n_thr; i++) {
+        const size_t off = part * i, len = off < bytes ? (off + part < bytes ? part : bytes - off) : 0;
+        th[i - 1] = std::thread([=]() { if (len) memcpy((char*)dst + off, (const char*)src + off, len); });
+    }
+    memcpy(dst, src, part < bytes ? part : bytes);
+    for (int i = 1; i < n_thr; i++) th[i - 1].join();
 }
 
 int jrc_ensure_pinned(jrc_ctx* ctx, size_t bytes)

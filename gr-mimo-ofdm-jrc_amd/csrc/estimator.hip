@@ -180,7 +180,7 @@ extern "C" int jrc_ra_estimate(jrc_ctx* ctx, int vlen, int n_inputs, const jrc_c
     JRC_TRY(jrc_ensure_scratch(ctx, 1, bins_bytes));
     JRC_TRY(jrc_ensure_scratch(ctx, 2, sizeof(PeakPartial) * n_blocks + sizeof(jrc_ra_result)));
     char* hp = (char*)ctx->pinned;
-    memcpy(hp, in, map_bytes);
+    jrc_host_copy(hp, in, map_bytes);
     memcpy(hp + map_bytes, range_bins, sizeof(float) * n_range_bins);
     memcpy(hp + map_bytes + sizeof(float) * n_range_bins, angle_bins, sizeof(float) * n_angle_bins);
     JRC_HIP(ctx, hipMemcpyAsync(ctx->scratch[0], hp, map_bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -252,7 +252,7 @@ extern "C" int jrc_fft_peak_detect(jrc_ctx* ctx, int samp_rate, float interp_fac
         JRC_TRY(jrc_ensure_pinned(ctx, bytes + sizeof(MagPartial) * n_blocks));
         JRC_TRY(jrc_ensure_scratch(ctx, 0, bytes));
         JRC_TRY(jrc_ensure_scratch(ctx, 1, sizeof(MagPartial) * n_blocks));
-        memcpy(ctx->pinned, in, bytes);
+        jrc_host_copy(ctx->pinned, in, bytes);
         JRC_HIP(ctx, hipMemcpyAsync(ctx->scratch[0], ctx->pinned, bytes, hipMemcpyHostToDevice, ctx->stream));
         const double thr = pow(10, threshold / 10.0);        // std::pow(10, d_threshold / 10.0)
         hipLaunchKernelGGL(peak_mag_partial_kernel, dim3(n_blocks), dim3(256), 0, ctx->stream,

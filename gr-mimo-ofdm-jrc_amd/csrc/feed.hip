@@ -17,7 +17,6 @@
 #include "jrc_internal.h"
 #include "radar_kernels.h"
 
-#include <thread>
 
 struct feed_slot {
     jrc_chain* chain = nullptr;
@@ -158,20 +157,7 @@ extern "C" int jrc_chain_feed_submit(jrc_chain_feed* fd, const jrc_cf32* h_frame
     if (s.state == 2)
         return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_feed_submit: all %d slots are in flight, collect one first", fd->n_slots);
     if (h_frames && (const float2*)h_frames != s.h_frames) {    // pageable source (a GNU Radio buffer): stage it
-        // one thread copies ~25 GB/s, half of what the link takes: large batches are staged by up to four
-        const size_t bytes = sizeof(float2) * (size_t)n_frames * fd->frame_elems;
-        const int n_thr = bytes >= ((size_t)16 << 20) ? 4 : (bytes >= ((size_t)4 << 20) ? 2 : 1);
-        if (n_thr == 1) memcpy(s.h_frames, h_frames, bytes);
-        else {
-            std::thread th[3];
-            const size_t part = ((bytes / n_thr) + 4095) & ~(size_t)4095;
-            for (int i = 1; i < n_thr; i++) {
-                const size_t off = part * i, len = off < bytes ? (off + part < bytes ? part : bytes - off) : 0;
-                th[i - 1] = std::thread([=, &s]() { if (len) memcpy((char*)s.h_frames + off, (const char*)h_frames + off, len); });
-            }
-            memcpy(s.h_frames, h_frames, part < bytes ? part : bytes);
-            for (int i = 1; i < n_thr; i++) th[i - 1].join();
-        }
+        jrc_host_copy(s.h_frames, h_frames, sizeof(float2) * (size_t)n_frames * fd->frame_elems);   // threaded for large batches
     }
     if (!h_frames && s.state != 1)
         return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_feed_submit: no host frames given and no acquired buffer to take them from");

@@ -291,7 +291,7 @@ extern "C" int jrc_fft_vcc(jrc_ctx* ctx, int fft_size, int forward, int shift, c
     JRC_TRY(jrc_ensure_scratch(ctx, 0, bytes));
     JRC_TRY(jrc_ensure_scratch(ctx, 1, bytes));
     JRC_TRY(jrc_ensure_scratch(ctx, 2, wbytes ? wbytes : 4));
-    memcpy(ctx->pinned, in, bytes);
+    jrc_host_copy(ctx->pinned, in, bytes);
     if (window) memcpy((char*)ctx->pinned + bytes, window, wbytes);
     if (bytes) JRC_HIP(ctx, hipMemcpyAsync(ctx->scratch[0], ctx->pinned, bytes, hipMemcpyHostToDevice, ctx->stream));
     if (window) JRC_HIP(ctx, hipMemcpyAsync(ctx->scratch[2], (char*)ctx->pinned + bytes, wbytes, hipMemcpyHostToDevice, ctx->stream));
@@ -299,7 +299,7 @@ extern "C" int jrc_fft_vcc(jrc_ctx* ctx, int fft_size, int forward, int shift, c
                            (const float2*)ctx->scratch[0], (float2*)ctx->scratch[1], fft_size, 0, ctx->stream));
     if (bytes) JRC_HIP(ctx, hipMemcpyAsync(ctx->pinned, ctx->scratch[1], bytes, hipMemcpyDeviceToHost, ctx->stream));
     JRC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    memcpy(out, ctx->pinned, bytes);
+    jrc_host_copy(out, ctx->pinned, bytes);
     return JRC_OK;
 }
 
@@ -373,14 +373,14 @@ extern "C" int jrc_matrix_transpose(jrc_ctx* ctx, int input_len, int output_len,
     JRC_TRY(jrc_ensure_pinned(ctx, in_bytes > out_bytes ? in_bytes : out_bytes));
     JRC_TRY(jrc_ensure_scratch(ctx, 0, in_bytes ? in_bytes : 8));
     JRC_TRY(jrc_ensure_scratch(ctx, 1, out_bytes));
-    memcpy(ctx->pinned, in, in_bytes);
+    jrc_host_copy(ctx->pinned, in, in_bytes);
     if (in_bytes) JRC_HIP(ctx, hipMemcpyAsync(ctx->scratch[0], ctx->pinned, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     int r = jrc_matrix_transpose_dev(ctx, input_len, output_len, interp_factor, ninput_items, 1,
                                      (const jrc_cf32*)ctx->scratch[0], (jrc_cf32*)ctx->scratch[1], nullptr);
     if (r < 0) return r;
     JRC_HIP(ctx, hipMemcpyAsync(ctx->pinned, ctx->scratch[1], out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     JRC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    memcpy(out, ctx->pinned, out_bytes);
+    jrc_host_copy(out, ctx->pinned, out_bytes);
     return input_len;
 }
 
@@ -411,7 +411,7 @@ extern "C" int jrc_cp_remove(jrc_ctx* ctx, int fft_len, int cp_len, size_t ninpu
     JRC_TRY(jrc_ensure_pinned(ctx, in_bytes));
     JRC_TRY(jrc_ensure_scratch(ctx, 0, in_bytes));
     JRC_TRY(jrc_ensure_scratch(ctx, 1, out_bytes));
-    memcpy(ctx->pinned, in, in_bytes);
+    jrc_host_copy(ctx->pinned, in, in_bytes);
     JRC_HIP(ctx, hipMemcpyAsync(ctx->scratch[0], ctx->pinned, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     const size_t total = nsym * (size_t)fft_len;
     unsigned blocks = (unsigned)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
@@ -420,7 +420,7 @@ extern "C" int jrc_cp_remove(jrc_ctx* ctx, int fft_len, int cp_len, size_t ninpu
     JRC_HIP(ctx, hipGetLastError());
     JRC_HIP(ctx, hipMemcpyAsync(ctx->pinned, ctx->scratch[1], out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     JRC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    memcpy(out, ctx->pinned, out_bytes);
+    jrc_host_copy(out, ctx->pinned, out_bytes);
     return (int)nsym;
 }
 
@@ -449,14 +449,14 @@ extern "C" int jrc_cp_remove_fft(jrc_ctx* ctx, int fft_len, int cp_len, size_t n
     JRC_TRY(jrc_ensure_pinned(ctx, in_bytes));
     JRC_TRY(jrc_ensure_scratch(ctx, 0, in_bytes));
     JRC_TRY(jrc_ensure_scratch(ctx, 1, out_bytes));
-    memcpy(ctx->pinned, in, in_bytes);
+    jrc_host_copy(ctx->pinned, in, in_bytes);
     JRC_HIP(ctx, hipMemcpyAsync(ctx->scratch[0], ctx->pinned, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     int r = jrc_cp_remove_fft_dev(ctx, fft_len, cp_len, nsym, (const jrc_cf32*)ctx->scratch[0],
                                   (jrc_cf32*)ctx->scratch[1], nullptr);
     if (r < 0) return r;
     JRC_HIP(ctx, hipMemcpyAsync(ctx->pinned, ctx->scratch[1], out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     JRC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    memcpy(out, ctx->pinned, out_bytes);
+    jrc_host_copy(out, ctx->pinned, out_bytes);
     return (int)nsym;
 }
 
@@ -488,7 +488,7 @@ extern "C" int jrc_ofdm_mod(jrc_ctx* ctx, int fft_len, int cp_len, const float* 
     JRC_TRY(jrc_ensure_scratch(ctx, 0, in_bytes));
     JRC_TRY(jrc_ensure_scratch(ctx, 1, out_bytes));
     JRC_TRY(jrc_ensure_scratch(ctx, 2, wbytes ? wbytes : 4));
-    memcpy(ctx->pinned, in, in_bytes);
+    jrc_host_copy(ctx->pinned, in, in_bytes);
     if (window) memcpy((char*)ctx->pinned + in_bytes, window, wbytes);
     JRC_HIP(ctx, hipMemcpyAsync(ctx->scratch[0], ctx->pinned, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     if (window) JRC_HIP(ctx, hipMemcpyAsync(ctx->scratch[2], (char*)ctx->pinned + in_bytes, wbytes, hipMemcpyHostToDevice, ctx->stream));
@@ -497,6 +497,6 @@ extern "C" int jrc_ofdm_mod(jrc_ctx* ctx, int fft_len, int cp_len, const float* 
     if (r < 0) return r;
     JRC_HIP(ctx, hipMemcpyAsync(ctx->pinned, ctx->scratch[1], out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     JRC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    memcpy(out, ctx->pinned, out_bytes);
+    jrc_host_copy(out, ctx->pinned, out_bytes);
     return (int)n_symbols;
 }

@@ -43,6 +43,9 @@ struct jrc_ctx {
 
 int  jrc_fail(jrc_ctx* ctx, int status, const char* fmt, ...);
 int  jrc_ensure_pinned(jrc_ctx* ctx, size_t bytes);
+// staging copy between pageable and pinned host memory: one thread moves ~25 GB/s, half of what the PCIe link takes, so
+// copies of 4 MiB and more are split over up to four threads
+void jrc_host_copy(void* dst, const void* src, size_t bytes);
 int  jrc_ensure_scratch(jrc_ctx* ctx, int slot, size_t bytes);
 // dynamic LDS above 64 KiB must be opted into per kernel: raises the kernel's limit to `bytes` if it is not there yet
 int  jrc_ensure_dyn_lds(jrc_ctx* ctx, const void* kernel, size_t bytes);
