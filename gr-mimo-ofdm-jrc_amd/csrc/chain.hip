@@ -17,11 +17,10 @@
 //   i.e. a twiddled fold of the N inputs down to 64 points followed by one 64-point transform per
 //   virtual-array pair, done by one wavefront with one point per lane (cross-lane shuffles, no LDS).
 //   Angle axis.  For each of the workgroup's 64 range bins the P inputs x[p] are zero-padded to
-//   NA = P*Ia: out[Ia u + r] = FFT_P( x[p] e^{-j2pi p r / NA} )[u].  One lane computes two adjacent
-//   residues r = 2i, 2i+1 (two P-point FFTs in registers) so that it owns adjacent output bins and
-//   stores them as one 16-byte access; 8 lanes cover a full 128-byte line of the map row.
-//   fftshift is a rotation of u.  The transpose + zero padding of matrix_transpose never touches
-//   memory.
+//   NA = P*Ia: out[Ia u + r] = FFT_P( x[p] e^{-j2pi p r / NA} )[u].  One lane owns one residue r (its P-1
+//   twiddles live in registers) and computes one P-point FFT in registers; the Ia = 16 lanes of a range
+//   bin cover one full 128-byte line of the map row per store, u after u.  fftshift is a rotation of u.
+//   The transpose + zero padding of matrix_transpose never touches memory.
 #include "radar_kernels.h"
 #include "fft_device.h"
 
@@ -35,8 +34,9 @@
 // The frame's channel estimate H (P x N) is staged in LDS once per workgroup and reused for every class;
 // the class twiddles of the NEXT class are prefetched into registers while the current class is being
 // stored, so the only exposed global-memory latency is the one H fetch per workgroup.
-// LDS = P*N*8 (H) + P*64*8 (range bins of the current class): 40 KiB for config B -> 4 workgroups per CU;
-// 136 KiB for config D -> one 1024-thread workgroup per CU.
+// LDS = P*N*8 (H) + P*64*8 (range bins of the current class) [+ N*8 class twiddles for N > 256]: 40 KiB for config B ->
+// 256-thread workgroups, two resident per CU (more, shorter-lived ones measured slower); 144 KiB for config D -> one
+// 512-thread workgroup per CU.
 template <int P, int NT, int MMAX, bool TWC_LDS>
 #ifndef JRC_WPS256
 #define JRC_WPS256 3
