@@ -409,6 +409,7 @@ extern "C" int jrc_chain_get_timing(jrc_chain* ch, float ms[3], int* launches)
 static int chain_run(jrc_chain* ch, int n_frames, const jrc_cf32* d_frames, const jrc_cf32* d_tx, const jrc_cf32* d_rx_td, int cp_len,
                      long rx_stream_len, jrc_cf32* d_chanest, jrc_cf32* d_map, jrc_ra_result* d_results, void* stream)
 {
+    JRC_TRACE("jrc_chain_run");
     jrc_ctx* ctx = ch->ctx;
     if (n_frames <= 0 || n_frames > ch->max_frames)
         return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_run_dev: n_frames %d outside (0, %d]", n_frames, ch->max_frames);
@@ -705,6 +706,7 @@ static int launch_rd_fused(jrc_ctx* ctx, const float2* E, float2* out, const flo
 extern "C" int jrc_range_doppler_dev(jrc_ctx* ctx, const jrc_chain_cfg* c, int interp_doppler, int n_frames,
                                      const jrc_cf32* d_frames, jrc_cf32* d_work, jrc_cf32* d_out, void* stream)
 {
+    JRC_TRACE("jrc_range_doppler_dev");
     if (!ctx || !c || !d_frames || !d_work || !d_out || n_frames <= 0 || interp_doppler <= 0) return JRC_ERR_INVALID_ARG;
     const int N = c->fft_len, T = c->N_tx, R = c->N_rx, P = T * R, S = c->N_sym;
     const long NR = (long)N * c->interp_range, ND = (long)S * interp_doppler;

@@ -519,6 +519,7 @@ extern "C" int jrc_stream_encode_dev(jrc_ctx* ctx, int mcs, int n_data_carriers,
                                      const int* d_len, const uint8_t* d_scrambler, jrc_cf32* d_out, long sym_stride, int* d_n_sym,
                                      void* stream)
 {
+    JRC_TRACE("jrc_stream_encode_dev");
     if (!ctx) return JRC_ERR_INVALID_ARG;
     McsParams p;
     if (!mcs_params(mcs, n_data_carriers, p) || n_data_carriers < 1)
@@ -539,6 +540,7 @@ extern "C" int jrc_stream_decode_dev(jrc_ctx* ctx, int n_data_carriers, int n_fr
                                      const int* d_mcs, const int* d_data_bytes, uint8_t* d_payload, long payload_stride, int* d_status,
                                      void* stream)
 {
+    JRC_TRACE("jrc_stream_decode_dev");
     if (!ctx) return JRC_ERR_INVALID_ARG;
     if (n_data_carriers < 1 || n_frames < 0 || (n_frames > 0 && (!d_sym || !d_mcs || !d_data_bytes || !d_payload || !d_status)))
         return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "stream_decoder: invalid arguments");

@@ -806,6 +806,7 @@ extern "C" int jrc_equalizer_frames_dev(jrc_equalizer* eq, int n_streams, int n_
                                         const double* d_phase, int max_out, jrc_cf32* d_out, int32_t* d_n_out,
                                         jrc_eq_event* d_events, void* stream)
 {
+    JRC_TRACE("jrc_equalizer_frames_dev");
     if (!eq || !d_in || !d_phase || !d_out || !d_n_out || !d_events) return JRC_ERR_INVALID_ARG;
     jrc_ctx* ctx = eq->ctx;
     if (n_streams <= 0 || n_streams > eq->n_streams || n_symbols <= 0 || max_out <= 0)
@@ -1227,6 +1228,7 @@ extern "C" int jrc_precoder_frames_dev(jrc_precoder* p, int n_frames, int ninput
                                        int pdu_len, int steer_mode, const jrc_cf32* d_Q_mean, const jrc_cf32* d_Q_sc,
                                        const jrc_cf32* d_radar_streams, jrc_cf32* d_out, void* stream)
 {
+    JRC_TRACE("jrc_precoder_frames_dev");
     if (!p || !d_in || !d_out || n_frames < 0) return JRC_ERR_INVALID_ARG;
     jrc_ctx* ctx = p->ctx;
     const PreDev& d = p->d;

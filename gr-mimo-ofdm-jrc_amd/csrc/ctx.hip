@@ -1,6 +1,8 @@
 // ctx.hip — context, error reporting, staging memory and twiddle tables for include/jrc.h
 #include "jrc_internal.h"
 
+#include <dlfcn.h>
+
 #include <cstdlib>
 #include <thread>
 
@@ -152,6 +154,30 @@ int jrc_ensure_dyn_lds(jrc_ctx* ctx, const void* kernel, size_t bytes)
     ctx->dyn_lds[kernel] = bytes;
     return JRC_OK;
 }
+
+namespace {
+typedef int (*roctx_push_fn)(const char*);
+typedef int (*roctx_pop_fn)();
+struct roctx_api {
+    roctx_push_fn push = nullptr;
+    roctx_pop_fn pop = nullptr;
+    roctx_api()
+    {
+        if (!getenv("JRC_ROCTX")) return;
+        void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        push = (roctx_push_fn)dlsym(h, "roctxRangePushA");
+        pop = (roctx_pop_fn)dlsym(h, "roctxRangePop");
+        if (!push || !pop) { push = nullptr; pop = nullptr; }
+    }
+};
+const roctx_api& roctx() { static const roctx_api api; return api; }
+}  // namespace
+
+void jrc_trace_push(const char* name) { if (roctx().push) roctx().push(name); }
+void jrc_trace_pop() { if (roctx().pop) roctx().pop(); }
+jrc_trace_range::jrc_trace_range(const char* name) : on(roctx().push != nullptr) { if (on) jrc_trace_push(name); }
 
 void jrc_host_copy(void* dst, const void* src, size_t bytes)
 {

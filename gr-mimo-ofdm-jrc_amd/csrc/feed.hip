@@ -149,6 +149,7 @@ static int feed_enqueue(jrc_chain_feed* fd, feed_slot& s, int n)
 
 extern "C" int jrc_chain_feed_submit(jrc_chain_feed* fd, const jrc_cf32* h_frames, int n_frames)
 {
+    JRC_TRACE("jrc_chain_feed_submit");
     if (!fd) return JRC_ERR_INVALID_ARG;
     jrc_ctx* ctx = fd->ctx;
     if (n_frames < 1 || n_frames > fd->fps)
@@ -198,6 +199,7 @@ extern "C" int jrc_chain_feed_submit(jrc_chain_feed* fd, const jrc_cf32* h_frame
 
 extern "C" int jrc_chain_feed_collect(jrc_chain_feed* fd, jrc_ra_result* results, jrc_cf32* maps, int* n_frames)
 {
+    JRC_TRACE("jrc_chain_feed_collect");
     if (!fd || !results) return JRC_ERR_INVALID_ARG;
     jrc_ctx* ctx = fd->ctx;
     if (fd->in_flight == 0) { if (n_frames) *n_frames = 0; return 0; }

@@ -54,6 +54,18 @@ int  jrc_get_twiddles(jrc_ctx* ctx, int n, int sign, const float2** out);
 // chirp c[k] = exp(sign*j*pi*k^2/n) (k < n) and bhat = FFT_M(conj(c) wrapped to M)/M, M = 2^k >= 2n-1, computed in double
 int  jrc_get_bluestein(jrc_ctx* ctx, int n, int sign, jrc_ctx::bluestein_tab* out);
 
+// Tracing hook: with JRC_ROCTX=1 in the environment every batched entry point brackets itself with a roctx range
+// (librocprofiler-sdk-roctx / libroctx64, loaded lazily with dlopen so the library has no link-time dependency on a profiler);
+// `rocprofv3 --marker-trace` then shows the C-ABI calls above the kernels they launch.  Off: one predictable branch.
+void jrc_trace_push(const char* name);
+void jrc_trace_pop();
+struct jrc_trace_range {
+    bool on;
+    explicit jrc_trace_range(const char* name);
+    ~jrc_trace_range() { if (on) jrc_trace_pop(); }
+};
+#define JRC_TRACE(name) jrc_trace_range _jrc_trace_range_(name)
+
 #define JRC_HIP(ctx, expr)                                                                      \
     do {                                                                                        \
         hipError_t _e = (expr);                                                                 \

@@ -557,6 +557,7 @@ extern "C" int jrc_radar_chanest_td_dev(jrc_ctx* ctx, int fft_len, int cp_len, i
                                         long rx_stream_len, int enable_tx_interleave, int n_frames, const jrc_cf32* d_tx,
                                         const jrc_cf32* d_rx_td, jrc_cf32* d_chanest, void* stream)
 {
+    JRC_TRACE("jrc_radar_chanest_td_dev");
     if (!ctx || !d_tx || !d_rx_td || !d_chanest) return JRC_ERR_INVALID_ARG;
     if (fft_len <= 0 || cp_len < 0 || N_tx <= 0 || N_rx <= 0 || N_sym < 0 || N_pre < 0 || n_items < N_pre + N_sym || n_frames < 0 ||
         rx_stream_len < (long)n_items * (fft_len + cp_len))

@@ -1035,6 +1035,7 @@ __global__ __launch_bounds__(256) void sf_frames_kernel(const float2* __restrict
 extern "C" int jrc_sync_frontend_dev(jrc_ctx* ctx, const jrc_sync_cfg* c, int n_samples, const jrc_cf32* d_x, jrc_cf32* d_work /* 2*n cf32 + n float + n/8+64 bytes */,
                                      int max_frames, int max_symbols, jrc_cf32* d_frames, jrc_sync_frame* d_info, int* d_n_frames, void* stream)
 {
+    JRC_TRACE("jrc_sync_frontend_dev");
     if (!ctx || !c || n_samples < 0 || max_frames < 1 || max_symbols < 2 || !d_x || !d_work || !d_frames || !d_info || !d_n_frames || !c->d_ltf_taps)
         return JRC_ERR_INVALID_ARG;
     if (c->fft_len < 4 || c->cp_len < 0 || c->sync_length < 4 || c->sync_length > 4096 || c->n_taps < 1 || c->n_taps > 1024 || c->delay < 0 || c->window < 1 ||

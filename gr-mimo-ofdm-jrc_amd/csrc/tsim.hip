@@ -668,6 +668,7 @@ extern "C" void jrc_tsim_destroy(jrc_tsim* h)
 extern "C" int jrc_tsim_run_dev(jrc_tsim* h, int n_bursts, int n_input, const jrc_cf32* d_in, jrc_cf32* d_out,
                                 const jrc_cf32* target_phase, int accumulate_out, void* stream)
 {
+    JRC_TRACE("jrc_tsim_run_dev");
     if (!h) return JRC_ERR_INVALID_ARG;
     jrc_ctx* ctx = h->ctx;
     if (n_bursts < 0 || n_input < 0 || (n_bursts > 0 && n_input > 0 && (!d_in || !d_out)))
