@@ -248,7 +248,35 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
                 const int ptype = S.packet_type;
                 const float2* Hsel = ptype == 1 ? H : Hm;
                 const double eps = S.epsilon0 + S.er;
-                for (int j = wv; j < nb; j += NW) {                                     // (A)
+                if (NP <= 64) {                                                         // (A) 64 / G symbols per wavefront pass, G = NP rounded up
+                    const int G = NP <= 1 ? 1 : (1 << (32 - __clz(NP - 1)));            //     to a power of two lanes per symbol
+                    const int spw = 64 / G, kk = ln & (G - 1), sl = ln / G;
+                    for (int j0 = wv * spw; j0 < nb; j0 += NW * spw) {
+                        const int j = j0 + sl;
+                        const bool on = j < nb && kk < NP;
+                        const int jc = j < nb ? j : nb - 1, kc = kk < NP ? kk : 0;
+                        const int sy = sym + jc;
+                        const float2* prow = d.pilot_sym + (size_t)((sy - 3 - NL) % d.n_pilot_rows) * NP;
+                        const double k0 = 2 * M_PI * sy * ((N + d.cp) * 1.0 / N) * eps;
+                        const int c = pc[kc];
+                        const float2 yk = c_mul(in[(size_t)(n_in + jc) * N + c], c_expj(k0 * (c - N / 2)));
+                        const float2 e = c_mul(Hsel[c], prow[kc]);
+                        float2 sum = make_float2(0.f, 0.f);
+                        if (on) { const float2 pp = c_mul(yk, c_conj(e)); sum.x = sum.x + pp.x; sum.y = sum.y + pp.y; }
+                        for (int off = G >> 1; off > 0; off >>= 1) { sum.x += __shfl_xor(sum.x, off); sum.y += __shfl_xor(sum.y, off); }
+                        const float2 r0 = c_expj(-(double)atan2f(sum.y, sum.x));
+                        double sig = 0, noi = 0;
+                        if (on) {
+                            sig += (double)c_mul(e, c_conj(e)).x;
+                            const float2 yr = c_mul(yk, r0);
+                            const float2 er = make_float2(e.x - yr.x, e.y - yr.y);
+                            noi += (double)c_mul(er, c_conj(er)).x;
+                        }
+                        for (int off = G >> 1; off > 0; off >>= 1) { sig += __shfl_xor(sig, off); noi += __shfl_xor(noi, off); }
+                        if (kk == 0 && j < nb) { s_brot[j] = r0; s_bsig[j] = sig; s_bnoi[j] = noi; }
+                    }
+                } else
+                for (int j = wv; j < nb; j += NW) {                                     // (A) more than 64 pilots: one symbol per pass, lanes stride the pilots
                     const int sy = sym + j;
                     const float2* prow = d.pilot_sym + (size_t)((sy - 3 - NL) % d.n_pilot_rows) * NP;
                     const double k0 = 2 * M_PI * sy * ((N + d.cp) * 1.0 / N) * eps;
@@ -392,6 +420,9 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
                 int metric = s6 ? (1 << 28) : 0;
                 const int e0a = popc8(s6 & 0155) & 1, e1a = popc8(s6 & 0117) & 1;                 // predecessor bit h = 0
                 const int e0b = popc8((s6 | 64) & 0155) & 1, e1b = popc8((s6 | 64) & 0117) & 1;   // h = 1
+                // survivor word of step i stays in lane i % 64 (two words per lane cover the 128 steps of a 256-carrier SIG symbol; longer
+                // symbols spill the rest to LDS): no store, no branch inside the recursion
+                unsigned long long keep0 = 0, keep1 = 0;
                 for (int i = 0; i < nd; i++) {
                     const int r0 = bits[2 * i], r1 = bits[2 * i + 1];
                     const int m0 = __shfl(metric, s6 >> 1) + (e0a != r0) + (e1a != r1);
@@ -399,20 +430,21 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
                     const int pick = m1 < m0;
                     metric = pick ? m1 : m0;
                     const unsigned long long mask = __ballot(pick);
-                    if (tid == 0) surv[i] = mask;
+                    if (i < 64) keep0 = (tid == i) ? mask : keep0;
+                    else if (i < 128) keep1 = (tid == i - 64) ? mask : keep1;
+                    else if (tid == 0) surv[i] = mask;
                 }
                 int best = metric, bs = s6;                                             // lowest state among minima
                 for (int off = 32; off > 0; off >>= 1) {
                     const int om = __shfl_xor(best, off), os = __shfl_xor(bs, off);
                     if (om < best || (om == best && os < bs)) { best = om; bs = os; }
                 }
-                // traceback: a chain of nd dependent steps.  The survivor words go back into lanes (word i in lane i % 64) and the chain
-                // runs on the scalar unit off v_readlane; walking them in LDS cost a load latency per step
+                // traceback: a chain of nd dependent steps on the scalar unit off v_readlane
                 {
                     int s = __builtin_amdgcn_readfirstlane(bs);
                     for (int blk = (nd - 1) >> 6; blk >= 0; blk--) {
                         const int wi = (blk << 6) + tid;
-                        const unsigned long long mine = wi < nd ? surv[wi] : 0ull;
+                        const unsigned long long mine = blk == 0 ? keep0 : (blk == 1 ? keep1 : (wi < nd ? surv[wi] : 0ull));
                         const int hi_i = min(nd - 1, (blk << 6) + 63);
                         for (int i = hi_i; i >= (blk << 6); i--) {
                             const unsigned long long w = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mine >> 32), i & 63) << 32) |
