@@ -337,6 +337,20 @@ __global__ __launch_bounds__(64 * DEC2_WAVES) void stream_decode2_kernel(int n_d
         const unsigned hi = e >> 6;
         return hi == 0 ? x0 : (hi == 1 ? x1 : (hi == 2 ? x2 : x3));
     };
+    // descrambler (:406-433) a byte at a time: for each of the 128 register states, the eight feedback bits it emits (bit b = b-th) and
+    // the state after them — entry s in lane s % 64 of scrv[s / 64]
+    unsigned scrv[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        int l = 64 * j + lane, fb8 = 0;
+#pragma unroll
+        for (int bb = 0; bb < 8; bb++) {
+            const int fb = (!!(l & 64)) ^ (!!(l & 8));
+            fb8 |= fb << bb;
+            l = ((l << 1) & 0x7e) | fb;
+        }
+        scrv[j] = (unsigned)fb8 | ((unsigned)l << 8);
+    }
     // the last ten path chunks of every state (both frames per register), newest first: d_ppresult (:333-337) as a shift register, so
     // the traceback walks registers with v_readlane instead of chasing bytes through LDS
     unsigned rr[10];
@@ -404,13 +418,17 @@ __global__ __launch_bounds__(64 * DEC2_WAVES) void stream_decode2_kernel(int n_d
         if (t0 + lane >= ndb[q]) { b0 = 0; b1 = 0; e0 = 1; e1 = 1; }                   // past the end of the frame: 0, 0 (fresh buffers)
         return b0 | (b1 << 1) | ((unsigned)e0 << 2) | ((unsigned)e1 << 3);
     };
+    // two blocks of soft-bit pairs are kept (current, next) so that a group of eight steps never has to stop for a refill in the middle
     int blk_len[2];
+    unsigned ctl_nxt[2];
 #pragma unroll
     for (int q = 0; q < 2; q++) {
         blk_len[q] = half_rate[q] ? 32 : 48;
         zp[q] = load_sym(q, 0);
         ctl[q] = make_ctl(q, decide_word(q, zp[q], 0), 0);
         zp[q] = load_sym(q, 64);
+        ctl_nxt[q] = make_ctl(q, decide_word(q, zp[q], 64), blk_len[q]);
+        zp[q] = load_sym(q, 128);
     }
 
     // trellis: lane = new state; butterfly k = lane >> 1 reads old states k and k + 32 (viterbi_butterfly2_sse2, :87-180)
@@ -418,16 +436,14 @@ __global__ __launch_bounds__(64 * DEC2_WAVES) void stream_decode2_kernel(int n_d
     const unsigned bt0p = (unsigned)(__popc((2 * k) & 0x6d) & 1) * 0x00010001u;         // d_branchtab27_sse2 (:323-326), both halves
     const unsigned bt1p = (unsigned)(__popc((2 * k) & 0x4f) & 1) * 0x00010001u;
     unsigned st = 0;                                                                    // per half: metric | path << 8
-    for (int t = 0; t < steps; t++) {
+    auto acs_step = [&](int t) {
         unsigned cc = 0;
 #pragma unroll
         for (int q = 0; q < 2; q++) {
-            if (t == blk_t0[q] + blk_len[q]) {                                          // next word of decisions
-                blk_t0[q] = t; wbase[q] += 64;
-                ctl[q] = make_ctl(q, decide_word(q, zp[q], wbase[q]), t);
-                zp[q] = load_sym(q, wbase[q] + 64);
-            }
-            cc |= (unsigned)__builtin_amdgcn_readlane((int)ctl[q], t - blk_t0[q]) << (16 * q);
+            const int idx = t - blk_t0[q];
+            const int v0 = __builtin_amdgcn_readlane((int)ctl[q], idx < blk_len[q] ? idx : 0);
+            const int v1 = __builtin_amdgcn_readlane((int)ctl_nxt[q], idx < blk_len[q] ? 0 : idx - blk_len[q]);
+            cc |= (unsigned)(idx < blk_len[q] ? v0 : v1) << (16 * q);
         }
         const unsigned s0p = cc & 0x00010001u, s1p = (cc >> 1) & 0x00010001u, e0p = (cc >> 2) & 0x00010001u, e1p = (cc >> 3) & 0x00010001u;
         // branch metrics of both frames: metsvm = (bt0 ^ s0) + (bt1 ^ s1) over the transmitted bits, metsv = (their number) - metsvm
@@ -443,7 +459,9 @@ __global__ __launch_bounds__(64 * DEC2_WAVES) void stream_decode2_kernel(int n_d
         const unsigned dec7 = ((d & 0x007f007fu) + 0x007f007fu) & ~d & 0x00800080u;
         const unsigned mask = (dec7 >> 7) * 0xffffu;
         st = (ca & mask) | (cb & ~mask);
-        if (t >= 5 && ((t - 5) & 7) == 0) {                                             // viterbi_get_output_sse2 (:183-225) after steps 6, 14, 22, ...
+    };
+    auto output_event = [&](int t) {                                                    // viterbi_get_output_sse2 (:183-225) after steps 6, 14, 22, ...
+        {
             int live[2];
 #pragma unroll
             for (int q = 0; q < 2; q++) live[q] = act[q] && t < n_steps[q];
@@ -480,12 +498,11 @@ __global__ __launch_bounds__(64 * DEC2_WAVES) void stream_decode2_kernel(int n_d
                             const int fb = (!!(lfsr[q] & 64)) ^ (!!(lfsr[q] & 8));      // bit 7 belongs to out_bytes[0] (unused)
                             lfsr[q] = ((lfsr[q] << 1) & 0x7e) | fb;
                         } else {
-#pragma unroll
-                            for (int bb = 0; bb < 8; bb++) {
-                                const int fb = (!!(lfsr[q] & 64)) ^ (!!(lfsr[q] & 8));
-                                ob |= (fb ^ ((c[q] >> (7 - bb)) & 1)) << bb;
-                                lfsr[q] = ((lfsr[q] << 1) & 0x7e) | fb;
-                            }
+                            const unsigned e0 = (unsigned)__builtin_amdgcn_readlane((int)scrv[0], lfsr[q] & 63);
+                            const unsigned e1 = (unsigned)__builtin_amdgcn_readlane((int)scrv[1], lfsr[q] & 63);
+                            const unsigned e = (lfsr[q] & 64) ? e1 : e0;
+                            ob = (int)((e & 0xffu) ^ (__brev((unsigned)c[q]) >> 24));      // bit b of ob = b-th feedback bit ^ bit (7 - b) of c
+                            lfsr[q] = (int)(e >> 8);
                         }
                         const int by = j - 2;                                           // out_bytes + 2 = PSDU incl. CRC
                         if (by >= 0 && by < dsb[q]) {
@@ -496,6 +513,26 @@ __global__ __launch_bounds__(64 * DEC2_WAVES) void stream_decode2_kernel(int n_d
                     out_count[q]++;
                 }
         }
+    };
+    // the trellis runs in groups that end with an output: steps 0..5, then eight at a time; soft-bit blocks rotate between groups only
+    auto rotate = [&](int g0) {
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+            if (g0 >= blk_t0[q] + blk_len[q]) {
+                blk_t0[q] += blk_len[q]; wbase[q] += 64;
+                ctl[q] = ctl_nxt[q];
+                ctl_nxt[q] = make_ctl(q, decide_word(q, zp[q], wbase[q] + 64), blk_t0[q] + blk_len[q]);
+                zp[q] = load_sym(q, wbase[q] + 128);
+            }
+    };
+#pragma unroll
+    for (int i = 0; i < 6; i++) acs_step(i);
+    output_event(5);
+    for (int g0 = 6; g0 < steps; g0 += 8) {
+        rotate(g0);
+#pragma unroll
+        for (int i = 0; i < 8; i++) acs_step(g0 + i);
+        output_event(g0 + 7);
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
