@@ -145,6 +145,7 @@ static void dft_rec(int n, int stride, const double complex* in, double complex*
 /* in-place double-precision form for orc_fft_vcc's non-power-of-two sizes */
 void orc_dft_any_f64(int n, int sign, double* re, double* im)
 {
+    if (n <= 0) return;
     double complex* a = (double complex*)malloc(sizeof(double complex) * (size_t)n);
     double complex* b = (double complex*)malloc(sizeof(double complex) * (size_t)n);
     double complex* w = (double complex*)malloc(sizeof(double complex) * (size_t)n);
@@ -160,6 +161,7 @@ void orc_dft_any_f64(int n, int sign, double* re, double* im)
 
 void orc_dft_any(int n, int forward, const float* in, float* out)
 {
+    if (n <= 0) return;
     double complex* a = (double complex*)malloc(sizeof(double complex) * (size_t)n);
     double complex* b = (double complex*)malloc(sizeof(double complex) * (size_t)n);
     double complex* w = (double complex*)malloc(sizeof(double complex) * (size_t)n);
