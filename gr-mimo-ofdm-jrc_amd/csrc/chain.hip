@@ -324,6 +324,7 @@ extern "C" int jrc_chain_create(jrc_ctx* ctx, const jrc_chain_cfg* cfg, const fl
         ch->wg_per_cu = by_lds < by_regs ? by_lds : by_regs;
         if (ch->wg_per_cu < 1) ch->wg_per_cu = 1;
         if (ch->wg_per_cu > 2) ch->wg_per_cu = 2;          // measured: 2 long-lived workgroups per CU beat 3-4 short ones
+        if (getenv("JRC_WG_PER_CU")) { const int v = atoi(getenv("JRC_WG_PER_CU")); if (v >= 1 && v <= by_lds && v <= by_regs) ch->wg_per_cu = v; }
     }
     if (ch->generic) {
         if (!generic_ok) { delete ch; return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "JRC_CHAIN_GENERIC: transform sizes out of range"); }
