@@ -253,7 +253,18 @@ def main():
                 traffic = pt["hbm_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             pass
-        k_ms = kt["range_angle_fused"]
+        # a batch beyond one resident wave of workgroups runs as several launches of the dominant kernel: roofline per launch
+        n_launch = max(1, chain.launches_per_run(F))
+        f_launch = F // n_launch if F % n_launch == 0 else None
+        k_ms = kt["range_angle_fused"] / n_launch
+        alg_bytes = alg_bytes / n_launch
+        if traffic is None and f_launch is not None:
+            try:
+                pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(a.config)
+                if pt and pt["frames_per_launch"] == f_launch:
+                    traffic = pt["hbm_bytes_per_launch"]
+            except (OSError, ValueError, KeyError):
+                pass
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         out = {
             "metric": "ofdm_frames_per_sec", "value": total_frames / elapsed, "unit": "frames/s",
@@ -269,7 +280,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "range_angle_fused_kernel<%d>" % P, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
-                         "avg_launch_ms": k_ms, "launches_timed": kt["launches"]},
+                         "avg_launch_ms": k_ms, "launches_timed": kt["launches"] * n_launch,
+                         "launches_per_step": n_launch, "frames_per_launch": F / n_launch},
             "kernels_ms": {k: kt[k] for k in ("radar_chanest", "range_angle_fused", "ra_finalize")},
             "check": {"range_m": res[0].range_val, "angle_deg": res[0].angle_val, "snr_db": res[0].snr_est},
             "device": ctx.device_name(),

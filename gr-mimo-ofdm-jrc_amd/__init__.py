@@ -125,6 +125,7 @@ def load(build_if_missing=False):
     L.jrc_chain_fetch_results.argtypes = [_vp, C.c_int, _vp, C.POINTER(RaResult), _vp]
     L.jrc_range_doppler_dev.argtypes = [_vp, C.POINTER(ChainCfg), C.c_int, C.c_int, _vp, _vp, _vp, _vp]
     L.jrc_chain_set_timing.argtypes = [_vp, C.c_int]
+    L.jrc_chain_launches_per_run.argtypes = [_vp, C.c_int]
     L.jrc_chain_feed_create.argtypes = [_vp, C.POINTER(ChainCfg), _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]
     L.jrc_chain_feed_destroy.argtypes = [_vp]
     L.jrc_chain_feed_destroy.restype = None
@@ -468,6 +469,9 @@ class RadarChain:
         self.ctx.check(self.ctx.lib.jrc_range_doppler_dev(self.ctx.h, C.byref(self.cfg), interp_doppler, n_frames,
                                                          bufs["frames"].data_ptr(), work.data_ptr(), out.data_ptr(), stream))
         return out
+
+    def launches_per_run(self, n_frames):
+        return self.ctx.check(self.ctx.lib.jrc_chain_launches_per_run(self.h, n_frames))
 
     def set_timing(self, on):
         self.ctx.check(self.ctx.lib.jrc_chain_set_timing(self.h, int(on)))

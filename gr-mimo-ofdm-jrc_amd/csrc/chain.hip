@@ -366,6 +366,18 @@ extern "C" size_t jrc_chain_frame_bytes(const jrc_chain* ch)
 extern "C" size_t jrc_chain_chanest_bytes(const jrc_chain* ch) { return ch ? sizeof(float2) * (size_t)ch->P * ch->cfg.fft_len : 0; }
 extern "C" size_t jrc_chain_map_bytes(const jrc_chain* ch) { return ch ? sizeof(float2) * (size_t)ch->NR * ch->NA : 0; }
 
+// how many launches of the dominant kernel one jrc_chain_run_dev of n_frames makes (batches beyond one resident wave of
+// workgroups are launched in chunks; bench.py reports the roofline per launch)
+extern "C" int jrc_chain_launches_per_run(const jrc_chain* ch, int n_frames)
+{
+    if (!ch || n_frames <= 0) return JRC_ERR_INVALID_ARG;
+    if (ch->generic) return 1;
+    const int resident = ch->n_cus * ch->wg_per_cu;
+    const int wpf = chain_pick_wpf(ch, n_frames < resident ? n_frames : resident);
+    int chunk = resident / wpf; if (chunk < 8) chunk = 8; chunk &= ~7;
+    return (n_frames + chunk - 1) / chunk;
+}
+
 extern "C" int jrc_chain_set_timing(jrc_chain* ch, int enabled)
 {
     if (!ch) return JRC_ERR_INVALID_ARG;

@@ -205,6 +205,8 @@ int  jrc_chain_set_timing(jrc_chain* chain, int enabled);
 /* mean milliseconds per launch since timing was enabled/reset, per kernel:
  * ms[0]=radar_chanest, ms[1]=range_angle_fused, ms[2]=ra_finalize; *launches = runs measured */
 int  jrc_chain_get_timing(jrc_chain* chain, float ms[3], int* launches);
+/* launches of the dominant kernel per jrc_chain_run_dev of n_frames (a batch beyond one resident wave of workgroups runs in chunks) */
+int  jrc_chain_launches_per_run(const jrc_chain* chain, int n_frames);
 
 /* ---- host-fed pipeline over the chain: what a GNU Radio work() hands over is HOST memory (the T+R input ring buffers of
  *      mimo_ofdm_radar, lib/mimo_ofdm_radar_impl.cc:207-238) and what leaves the radar branch is one small record per
