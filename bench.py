@@ -137,6 +137,10 @@ def secondary_figures(cfg):
         e = be.equalizer_config_c()
         out["equalizer_config_c"] = {"frames_per_s": e["frames_per_s"], "lane_frames_per_s": e["lane_frames_per_s"], "GBps": e["GBps"],
                                      "what": e["what"]}
+        import comm_rx_probe
+        c = comm_rx_probe.run(4096, 200, 5)
+        out["comm_rx_chain"] = {"frames_per_s": c["frames_per_s"], "M_samples_per_s": c["M_samples_per_s"], "crc_ok": c["crc_ok"],
+                                "frames": c["frames"], "payloads_intact": c["payloads_intact"], "what": c["what"] + " (200-byte PDUs, QPSK 1/2)"}
         p = be.precoder_config_c()
         out["precoder_config_c"] = {"packets_per_s_dft": p["dft"]["frames_per_s"],
                                     "packets_per_s_steering_and_radar_streams": p["per-subcarrier_steering_+_radar_streams"]["frames_per_s"],

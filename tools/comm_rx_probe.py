@@ -22,6 +22,22 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--json", action="store_true")
     a = ap.parse_args()
+    res = run(a.frames, a.bytes, a.iters)
+    if a.json:
+        import json
+        print(json.dumps(res))
+    else:
+        print("%d-sample capture, %d frames of %d-byte PDUs: %.2f ms -> %.0f k frames/s, %.0f M samples/s; crc ok %d/%d, payloads intact %s"
+              % (res["samples"], res["frames_found"], res["pdu_bytes"], res["ms_per_capture"], res["frames_per_s"] / 1e3, res["M_samples_per_s"],
+                 res["crc_ok"], res["frames"], res["payloads_intact"]))
+
+
+def run(frames=1024, nbytes=200, iters=5):
+    """build a capture of `frames` PDUs, run the device-resident receive chain on it `iters` times, check every PDU; returns the figures"""
+    class _A:
+        pass
+    a = _A()
+    a.frames, a.bytes, a.iters = frames, nbytes, iters
     import torch
     import jrc_amd
     from _streams import CP, N, BurstMaker, ofdm_config
@@ -86,12 +102,7 @@ def main():
     res = dict(what="comm receive chain, device-resident: capture -> sync front end -> RX FFT -> equalizer -> Viterbi decoder",
                samples=n, frames_found=nf, frames=F, pdu_bytes=a.bytes, crc_ok=ok, payloads_intact=same, ms_per_capture=dt * 1e3,
                frames_per_s=F / dt, M_samples_per_s=n / dt / 1e6)
-    if a.json:
-        import json
-        print(json.dumps(res))
-    else:
-        print("%d-sample capture, %d frames of %d-byte PDUs: %.2f ms -> %.0f k frames/s, %.0f M samples/s; crc ok %d/%d, payloads intact %s"
-              % (n, nf, a.bytes, dt * 1e3, F / dt / 1e3, n / dt / 1e6, ok, F, same))
+    return res
 
 
 if __name__ == "__main__":
