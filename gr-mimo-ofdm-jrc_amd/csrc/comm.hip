@@ -157,7 +157,6 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
     float2* est = Z + ND;                     // [NP]
     unsigned long long* surv = reinterpret_cast<unsigned long long*>(est + NP);   // [ND/2]
     unsigned char* bits = reinterpret_cast<unsigned char*>(surv + ND / 2);        // [ND]
-    unsigned char* dec = bits + ND;                                               // [ND/2]
     // constant tables staged in LDS: the serial (one-lane) sections below walk them with dependent loads, which from
     // global memory cost microseconds each once every CU is busy
     int* dc = reinterpret_cast<int*>(eq_smem + d.lds_tables);                     // [ND] data carriers
@@ -440,6 +439,7 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
                     if (om < best || (om == best && os < bs)) { best = om; bs = os; }
                 }
                 // traceback: a chain of nd dependent steps on the scalar unit off v_readlane
+                unsigned sig_word = 0;                                                  // decoded bits 0..31 (the field is bits 0..23)
                 {
                     int s = __builtin_amdgcn_readfirstlane(bs);
                     for (int blk = (nd - 1) >> 6; blk >= 0; blk--) {
@@ -449,25 +449,19 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
                         for (int i = hi_i; i >= (blk << 6); i--) {
                             const unsigned long long w = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mine >> 32), i & 63) << 32) |
                                                          (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mine & 0xffffffffull), i & 63);
-                            if (tid == 0) dec[i] = (unsigned char)(s & 1);
+                            if (i < 32) sig_word |= (unsigned)(s & 1) << i;
                             s = (s >> 1) | ((int)((w >> s) & 1ull) << 5);
                         }
                     }
                 }
                 if (tid == 0) {
                     // parse :669-781
-                    int rate = 0, pt = 0, len = 0, parity = 0;
-                    for (int i = 0; i < 17; i++) {
-                        parity ^= dec[i];
-                        if (i < 4 && dec[i]) rate |= 1 << i;
-                        if (i == 4 && dec[i]) pt |= 1;
-                        if (dec[i] && i > 4) len |= 1 << (i - 5);
-                    }
-                    int trailing_ok = 1;
-                    for (int i = 17; i < 23; i++) if (dec[i]) trailing_ok = 0;
+                    const int rate = (int)(sig_word & 0xfu), pt = (int)((sig_word >> 4) & 1u), len = (int)((sig_word >> 5) & 0xfffu);
+                    const int parity = __popc(sig_word & 0x1ffffu) & 1, dec17 = (int)((sig_word >> 17) & 1u);
+                    const int trailing_ok = ((sig_word >> 17) & 0x3fu) == 0;                // bits 17..22, as the reference tests them (:702)
                     int ok = 1, mcs = 0;
                     S.data_length = len;
-                    if (parity != dec[17] && trailing_ok) { ok = 0; S.data_length = 0; S.n_ofdm_symbols_SIG = 0; }
+                    if (parity != dec17 && trailing_ok) { ok = 0; S.data_length = 0; S.n_ofdm_symbols_SIG = 0; }
                     else {
                         switch (rate) {
                             case 11: mcs = 0; break; case 15: mcs = 1; break; case 10: mcs = 2; break;
