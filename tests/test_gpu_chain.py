@@ -399,3 +399,26 @@ def test_chain_with_time_domain_receive_side(jrc, ctx):
     assert abs(res[0].range_val - 9.0) < 0.5 and abs(res[0].angle_val - 15.0) < 3.0
     with pytest.raises(ValueError):
         chain.run_td(bufs, d_tx, d_td[:, :, :-8].contiguous(), F, cp)      # streams shorter than n_items symbols
+
+
+def test_launches_per_run_matches_the_chunking(jrc, ctx):
+    """jrc_chain_launches_per_run: one launch of the fused kernel up to one resident wave of workgroups (2 per CU at this shape), then
+    one more per further wave — what bench.py divides its per-step event time by"""
+    from jrc_amd import synth
+    sc = synth.Scenario(64, 2, 2, 4, targets=[(9.0, 15.0, 0.0, 80.0)])
+    P = sc.T * sc.R
+    rb, ab = jrc.radar_axes(sc.N, sc.fs, 8, P, 16)
+    chain = jrc.RadarChain(sc.N, sc.T, sc.R, sc.S, sc.Npre, 8, 16, rb, ab, 2.4, 30.0, max_frames=4096, ctx=ctx)
+    n1 = chain.launches_per_run(1)
+    assert n1 == 1 and chain.launches_per_run(8) == 1
+    resident = None
+    for F in (64, 128, 256, 512, 1024, 2048, 4096):
+        n = chain.launches_per_run(F)
+        assert n >= 1
+        if n > 1 and resident is None:
+            resident = F // 2 if chain.launches_per_run(F // 2) == 1 else None
+    assert chain.launches_per_run(4096) >= chain.launches_per_run(2048) >= chain.launches_per_run(1024)
+    if resident:
+        assert chain.launches_per_run(3 * resident) == 3 and chain.launches_per_run(3 * resident + 1) == 4
+    with pytest.raises(ValueError):
+        chain.launches_per_run(0)
