@@ -313,6 +313,7 @@ __device__ __forceinline__ unsigned wave_pk_min_u16(unsigned v)
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+template <int NQ /* frames per wave: 2 = throughput (both halves of the lane register), 1 = shortest dependent chain per step */>
 __global__ __launch_bounds__(64 * DEC2_WAVES) void stream_decode2_kernel(int n_dc, int n_frames, const float2* __restrict__ sym, long sym_stride,
                                                                          const int* __restrict__ mcs_arr, const int* __restrict__ bytes_arr,
                                                                          unsigned char* __restrict__ payload, long payload_stride,
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(64 * DEC2_WAVES) void stream_decode2_kernel(int n_d
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // the wave index is uniform, but only this tells the compiler: without it
                                                                               // every per-frame quantity below is compiled as exec-masked vector code
-    const int f0 = (blockIdx.x * DEC2_WAVES + w) * 2;
+    const int f0 = (blockIdx.x * DEC2_WAVES + w) * NQ;
     if (f0 >= n_frames) return;
     // CRC-32 table in registers: entry e in lane e % 64 of tabv[e / 64], fetched with v_readlane (the index is wave-uniform)
     unsigned tabv[4];
@@ -362,8 +363,9 @@ __global__ __launch_bounds__(64 * DEC2_WAVES) void stream_decode2_kernel(int n_d
     const float2* sp[2];
     unsigned char* pl[2];
     int steps = 0;
+    act[1] = 0; bpsc[1] = 1; half_rate[1] = 1; nt[1] = 5; ndb[1] = 0; n_coded[1] = 0; dsb[1] = 0; n_steps[1] = 0; sp[1] = sym; pl[1] = payload;
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
+    for (int q = 0; q < NQ; q++) {
         const int f = f0 + q;
         act[q] = f < n_frames;
         bpsc[q] = 1; half_rate[q] = 1; nt[q] = 5; ndb[q] = 0; n_coded[q] = 0; dsb[q] = 0; n_steps[q] = 0; sp[q] = sym; pl[q] = payload;
@@ -387,7 +389,7 @@ __global__ __launch_bounds__(64 * DEC2_WAVES) void stream_decode2_kernel(int n_d
             }
         }
     }
-    if (!act[0] && !act[1]) return;
+    if (!act[0] && (NQ == 1 || !act[1])) return;
 
     auto load_sym = [&](int q, int c0) -> float2 {  // unconditional (index clamped): a select on the loaded value would force the wait right
         const int c = max(0, min(c0 + lane, n_coded[q] - 1));  // here, and the load is issued a block ahead precisely to avoid that;
@@ -422,7 +424,7 @@ __global__ __launch_bounds__(64 * DEC2_WAVES) void stream_decode2_kernel(int n_d
     int blk_len[2];
     unsigned ctl_nxt[2];
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
+    for (int q = 0; q < NQ; q++) {
         blk_len[q] = half_rate[q] ? 32 : 48;
         zp[q] = load_sym(q, 0);
         ctl[q] = make_ctl(q, decide_word(q, zp[q], 0), 0);
@@ -439,7 +441,7 @@ __global__ __launch_bounds__(64 * DEC2_WAVES) void stream_decode2_kernel(int n_d
     auto acs_step = [&](int t) {
         unsigned cc = 0;
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
+        for (int q = 0; q < NQ; q++) {
             const int idx = t - blk_t0[q];
             const int v0 = __builtin_amdgcn_readlane((int)ctl[q], idx < blk_len[q] ? idx : 0);
             const int v1 = __builtin_amdgcn_readlane((int)ctl_nxt[q], idx < blk_len[q] ? 0 : idx - blk_len[q]);
@@ -452,19 +454,27 @@ __global__ __launch_bounds__(64 * DEC2_WAVES) void stream_decode2_kernel(int n_d
         const unsigned xadd = odd ? m : totp - m;                                       // even new state: ma + metsv vs mb + metsvm; odd: the other way
         const unsigned yadd = totp - xadd;
         const unsigned a = __shfl(st, k), b = __shfl(st, k + 32);
-        const unsigned ca = ((a + xadd) & 0x00ff00ffu) | ((a & 0x7f007f00u) << 1);
-        const unsigned cb = ((b + yadd) & 0x00ff00ffu) | ((b & 0x7f007f00u) << 1) | 0x01000100u;
-        // _mm_cmpgt_epi8(_mm_sub_epi8(m0, m1), 0) per half: d = (x - y) mod 256 in 1..127
-        const unsigned d = (((ca & 0x00ff00ffu) | 0x01000100u) - (cb & 0x00ff00ffu)) & 0x00ff00ffu;
-        const unsigned dec7 = ((d & 0x007f007fu) + 0x007f007fu) & ~d & 0x00800080u;
-        const unsigned mask = (dec7 >> 7) * 0xffffu;
-        st = (ca & mask) | (cb & ~mask);
+        if constexpr (NQ == 1) {
+            // one frame: the reference's byte compare directly — sign of the 8-bit difference — a chain of six operations behind the fetch
+            const unsigned x = (a + xadd) & 0xffu, y = (b + yadd) & 0xffu;
+            const bool dec = (int)__builtin_amdgcn_sbfe((int)(x - y), 0, 8) > 0;        // _mm_cmpgt_epi8(_mm_sub_epi8(m0, m1), 0)
+            const unsigned pa = (a & 0x7f00u) << 1, pb = ((b & 0x7f00u) << 1) | 0x0100u;
+            st = dec ? (x | pa) : (y | pb);
+        } else {
+            const unsigned ca = ((a + xadd) & 0x00ff00ffu) | ((a & 0x7f007f00u) << 1);
+            const unsigned cb = ((b + yadd) & 0x00ff00ffu) | ((b & 0x7f007f00u) << 1) | 0x01000100u;
+            // _mm_cmpgt_epi8(_mm_sub_epi8(m0, m1), 0) per half: d = (x - y) mod 256 in 1..127
+            const unsigned d = (((ca & 0x00ff00ffu) | 0x01000100u) - (cb & 0x00ff00ffu)) & 0x00ff00ffu;
+            const unsigned dec7 = ((d & 0x007f007fu) + 0x007f007fu) & ~d & 0x00800080u;
+            const unsigned mask = (dec7 >> 7) * 0xffffu;
+            st = (ca & mask) | (cb & ~mask);
+        }
     };
     auto output_event = [&](int t) {                                                    // viterbi_get_output_sse2 (:183-225) after steps 6, 14, 22, ...
         {
-            int live[2];
+            int live[2] = {0, 0};
 #pragma unroll
-            for (int q = 0; q < 2; q++) live[q] = act[q] && t < n_steps[q];
+            for (int q = 0; q < NQ; q++) live[q] = act[q] && t < n_steps[q];
 #pragma unroll
             for (int i = 9; i > 0; i--) rr[i] = rr[i - 1];
             rr[0] = (st >> 8) & 0x00ff00ffu;
@@ -472,7 +482,7 @@ __global__ __launch_bounds__(64 * DEC2_WAVES) void stream_decode2_kernel(int n_d
             const unsigned mx = wave_pk_max_u16(mp), mn = wave_pk_min_u16(mp);
             int c[2] = {0, 0};
 #pragma unroll
-            for (int q = 0; q < 2; q++)
+            for (int q = 0; q < NQ; q++)
                 if (live[q]) {
                     const unsigned metric = (mp >> (16 * q)) & 0xffu, best = (mx >> (16 * q)) & 0xffu;
                     int bs = __ffsll((unsigned long long)__ballot(metric == best)) - 1;        // first maximum (strict > in the scan)
@@ -488,7 +498,7 @@ __global__ __launch_bounds__(64 * DEC2_WAVES) void stream_decode2_kernel(int n_d
                 st = (st & ~keep) | ((mp - mn) & 0x00ff00ffu & keep);
             }
 #pragma unroll
-            for (int q = 0; q < 2; q++)
+            for (int q = 0; q < NQ; q++)
                 if (live[q]) {
                     if (out_count[q] >= nt[q]) {                                        // decoded bits, MSB first (:277-281)
                         const int j = out_count[q] - nt[q];                             // byte j = stream bits 8j .. 8j+7
@@ -517,7 +527,7 @@ __global__ __launch_bounds__(64 * DEC2_WAVES) void stream_decode2_kernel(int n_d
     // the trellis runs in groups that end with an output: steps 0..5, then eight at a time; soft-bit blocks rotate between groups only
     auto rotate = [&](int g0) {
 #pragma unroll
-        for (int q = 0; q < 2; q++)
+        for (int q = 0; q < NQ; q++)
             if (g0 >= blk_t0[q] + blk_len[q]) {
                 blk_t0[q] += blk_len[q]; wbase[q] += 64;
                 ctl[q] = ctl_nxt[q];
@@ -536,11 +546,11 @@ __global__ __launch_bounds__(64 * DEC2_WAVES) void stream_decode2_kernel(int n_d
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int q = 0; q < 2; q++)
+    for (int q = 0; q < NQ; q++)
         if (act[q])
             for (int i = lane; i < dsb[q] - 4; i += 64) pl[q][i] = obuf[w][q][i];
 #pragma unroll
-    for (int q = 0; q < 2; q++)
+    for (int q = 0; q < NQ; q++)
         if (act[q] && lane == 0) status[f0 + q] = ((crc[q] ^ 0xFFFFFFFFu) == 558161692u) ? 1 : 0;   // :245-246
 }
 
@@ -584,9 +594,15 @@ extern "C" int jrc_stream_decode_dev(jrc_ctx* ctx, int n_data_carriers, int n_fr
     if (n_frames == 0) return JRC_OK;
     JRC_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-    if (n_frames >= 2 && !ctx->tune.dec_single) {
+    // few frames: one per wave (the decoder is a latency chain; twice the waves, each with the shorter chain); many: two per wave
+    int nq = ctx->tune.dec_frames_per_wave;
+    if (nq != 1 && nq != 2) nq = n_frames >= 4 * ctx->n_cus * 4 * 2 ? 2 : 1;
+    if (nq == 2) {
         const int per_wg = 2 * DEC2_WAVES;
-        hipLaunchKernelGGL(stream_decode2_kernel, dim3((n_frames + per_wg - 1) / per_wg), dim3(64 * DEC2_WAVES), 0, s, n_data_carriers,
+        hipLaunchKernelGGL(stream_decode2_kernel<2>, dim3((n_frames + per_wg - 1) / per_wg), dim3(64 * DEC2_WAVES), 0, s, n_data_carriers,
+                           n_frames, (const float2*)d_sym, sym_stride, d_mcs, d_data_bytes, d_payload, payload_stride, d_status);
+    } else if (!ctx->tune.dec_single) {
+        hipLaunchKernelGGL(stream_decode2_kernel<1>, dim3((n_frames + DEC2_WAVES - 1) / DEC2_WAVES), dim3(64 * DEC2_WAVES), 0, s, n_data_carriers,
                            n_frames, (const float2*)d_sym, sym_stride, d_mcs, d_data_bytes, d_payload, payload_stride, d_status);
     } else {
         hipLaunchKernelGGL(stream_decode_kernel, dim3((n_frames + DEC_WAVES - 1) / DEC_WAVES), dim3(64 * DEC_WAVES), 0, s, n_data_carriers,

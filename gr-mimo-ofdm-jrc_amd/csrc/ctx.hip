@@ -66,6 +66,7 @@ extern "C" int jrc_create(int device, jrc_ctx** out)
     ctx->tune.fd_serial = getenv("JRC_FD_SERIAL") != nullptr;
     ctx->tune.sync_naive = getenv("JRC_SYNC_NAIVE") != nullptr;
     ctx->tune.dec_single = getenv("JRC_DEC_SINGLE") != nullptr;
+    if (const char* e = getenv("JRC_DEC_FPW")) ctx->tune.dec_frames_per_wave = atoi(e);
     *out = ctx;
     return JRC_OK;
 }

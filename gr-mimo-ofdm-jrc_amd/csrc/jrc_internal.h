@@ -37,7 +37,8 @@ struct jrc_ctx {
         bool chanest_x1 = false;     // JRC_CHANEST_X1: one subcarrier per lane in A1
         bool fd_serial = false;      // JRC_FD_SERIAL: single-wave detector scan
         bool sync_naive = false;     // JRC_SYNC_NAIVE: detection metrics without the LDS tile
-        bool dec_single = false;     // JRC_DEC_SINGLE: Viterbi decoder with one frame per wave
+        bool dec_single = false;     // JRC_DEC_SINGLE: the first-generation Viterbi decoder kernel (one frame per wave, LDS path ring)
+        int dec_frames_per_wave = 0; // JRC_DEC_FPW: 1 or 2 frames per wave in the decoder (0 = by batch size)
     } tune;
 };
 
