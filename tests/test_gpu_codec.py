@@ -71,10 +71,16 @@ def test_decoder_refuses_and_checks_arguments(jrc, ctx):
         dec.work(np.zeros(10, np.complex64), dict(mcs=2, data_bytes=100))                            # fewer symbols than the frame needs
 
 
-def test_batched_device_round_trip_with_mixed_mcs(jrc, ctx):
+@pytest.mark.parametrize("fpw", [0, 1, 2])
+def test_batched_device_round_trip_with_mixed_mcs(jrc, ctx, fpw, monkeypatch):
+    """fpw: frames per wave in the decoder — 0 = chosen by batch size (one per wave here), 1 / 2 forced (two frames share a lane
+    register above 8192 frames); an odd batch leaves the last wave of the two-frame variant half empty"""
     import torch
+    if fpw:
+        monkeypatch.setenv("JRC_DEC_FPW", str(fpw))
+        ctx = jrc.Context(0)                        # the switch is read when a context is created
     rng = np.random.default_rng(9)
-    F, stride_b = 96, 512
+    F, stride_b = 97, 512
     lens = rng.integers(1, 400, F).astype(np.int32)
     lens[5] = 3200                                  # one oversized PDU in the batch: dropped, the rest unaffected
     psdu = np.zeros((F, 3328), np.uint8)
@@ -92,7 +98,7 @@ def test_batched_device_round_trip_with_mixed_mcs(jrc, ctx):
         ns = d_ns.cpu().numpy()
         assert ns[5] == 0
         sym = d_sym.cpu().numpy()
-        for f in (0, 17, 95):
+        for f in (0, 17, 96):
             want, _ = oracle.stream_encode(mcs, N_DC, psdu[f, :lens[f]].tobytes(), int(scr[f]))
             np.testing.assert_array_equal(sym[f, :ns[f]], want)
         # decode the whole batch, every third frame through a noisy channel
