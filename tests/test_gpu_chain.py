@@ -422,3 +422,18 @@ def test_launches_per_run_matches_the_chunking(jrc, ctx):
         assert chain.launches_per_run(3 * resident) == 3 and chain.launches_per_run(3 * resident + 1) == 4
     with pytest.raises(ValueError):
         chain.launches_per_run(0)
+
+
+def test_time_domain_entry_refuses_shapes_outside_the_fused_kernel(jrc, ctx):
+    """fft_len 48 (not a power of two) and 5 TX have no fused A6+A7+A1 kernel: the entry point says so instead of falling back"""
+    import torch
+    for N, T in ((48, 2), (64, 5), (2048, 2)):
+        n_items, R, cp = 3, 2, N // 4
+        L = n_items * (N + cp)
+        d_tx = torch.zeros((1, T, n_items, N, 2), dtype=torch.float32, device="cuda:0")
+        d_rx = torch.zeros((1, R, L, 2), dtype=torch.float32, device="cuda:0")
+        H = torch.zeros((1, T * R, N, 2), dtype=torch.float32, device="cuda:0")
+        torch.cuda.synchronize()
+        st = ctx.lib.jrc_radar_chanest_td_dev(ctx.h, N, cp, T, R, 2, 1, n_items, L, 0, 1, d_tx.data_ptr(), d_rx.data_ptr(), H.data_ptr(), None)
+        assert st == jrc.JRC_ERR_UNSUPPORTED
+        assert b"jrc_cp_remove_fft_dev" in ctx.lib.jrc_last_error(ctx.h)
