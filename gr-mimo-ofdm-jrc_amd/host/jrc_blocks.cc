@@ -80,14 +80,17 @@ class mimo_ofdm_radar_impl : public mimo_ofdm_radar {
     jrc_radar* d_radar = nullptr;
     int d_fft_len, d_N_tx, d_N_rx, d_N_sym, d_N_pre, d_interp_factor;
     bool new_radar_frame = false;   // uninitialised in the reference (lib/mimo_ofdm_radar_impl.h:59)
+    std::string d_radar_chan_file;
+    std::vector<gr_complex> d_last_est;   // radar_chan_est of the last frame, [P][fft_len]
 
 public:
     mimo_ofdm_radar_impl(int fft_len, int N_tx, int N_rx, int N_sym, int N_pre, bool background_removal,
                          bool background_recording, int record_len, int interp_factor, bool enable_tx_interleave,
-                         const std::string&, const std::string&, bool)
+                         const std::string& radar_chan_file, const std::string&, bool)
         : jrc_rt::block("mimo_ofdm_radar", jrc_rt::io_signature::make(N_tx + N_rx, N_tx + N_rx, sizeof(gr_complex) * fft_len),
                         jrc_rt::io_signature::make(1, 1, sizeof(gr_complex) * fft_len * interp_factor)),   // :81-83
-          d_fft_len(fft_len), d_N_tx(N_tx), d_N_rx(N_rx), d_N_sym(N_sym), d_N_pre(N_pre), d_interp_factor(interp_factor)
+          d_fft_len(fft_len), d_N_tx(N_tx), d_N_rx(N_rx), d_N_sym(N_sym), d_N_pre(N_pre), d_interp_factor(interp_factor),
+          d_radar_chan_file(radar_chan_file), d_last_est((size_t)N_tx * N_rx * fft_len)          // vector::resize value-initialises (:115)
     {
         d_c.check(jrc_radar_create(d_c.ctx, fft_len, N_tx, N_rx, N_sym, N_pre, background_removal, background_recording,
                                    record_len, interp_factor, enable_tx_interleave, &d_radar));
@@ -125,6 +128,9 @@ public:
                                (jrc_cf32*)output_items[0]);
         d_c.check(n);
         (void)noutput_items;
+        for (int p = 0; p < d_N_tx * d_N_rx; p++)                                                     // radar_chan_est, kept for capture_radar_data
+            memcpy(&d_last_est[(size_t)p * d_fft_len], (const gr_complex*)output_items[0] + (size_t)p * d_fft_len * d_interp_factor,
+                   sizeof(gr_complex) * d_fft_len);
         add_item_tag(0, nitems_written(0), pmt::string_to_symbol("packet_len"), pmt::from_long(n),
                      pmt::string_to_symbol(alias()));                                                 // :303-309
         for (int r = 0; r < d_N_rx; r++) consume(r + d_N_tx, (int)rx_packet_len);                    // :326-334
@@ -133,7 +139,24 @@ public:
         return n;
     }
     void set_background_record(bool b) override { jrc_radar_set_background_record(d_radar, b); }      // :342-346
-    void capture_radar_data(bool) override {}   // CSV dump of the estimate (:348-387) is a debug side channel, not rebuilt
+    // radar_chan.csv (:348-387): one line per capture, "HH:MM:SS.mmm, N_tx, N_rx, fft_len:(re,im);(re,im);...;" + an empty line —
+    // Eigen's IOFormat(FullPrecision, DontAlignCols, ";", ":", "", "", "", ";\n") of the P*fft_len row vector.  Eigen prints 6-7
+    // significant digits depending on its version; 9 are written here (float round trip), as for chan_est.csv.
+    void capture_radar_data(bool capture_sig) override
+    {
+        if (!capture_sig) return;
+        std::ofstream f(d_radar_chan_file, std::ofstream::app);
+        if (!f.is_open()) throw std::runtime_error("[MIMO OFDM RADAR] Could not open file!!");
+        f << current_date_time2() << ", " << d_N_tx << ", " << d_N_rx << ", " << d_fft_len << ":";
+        char buf[96];
+        for (size_t i = 0; i < d_last_est.size(); i++) {
+            snprintf(buf, sizeof(buf), "%s(%.9g,%.9g)", i ? ";" : "", d_last_est[i].real(), d_last_est[i].imag());
+            f << buf;
+        }
+        f << ";\n" << "\n";
+        f.flush();
+        std::cout << "[MIMO OFDM RADAR] Radar image captured!" << std::endl;
+    }
 };
 
 mimo_ofdm_radar::sptr mimo_ofdm_radar::make(int fft_len, int N_tx, int N_rx, int N_sym, int N_pre, bool background_removal,

@@ -30,11 +30,17 @@ extern "C" {
 const char* jrcb_last_error() { return g_err.c_str(); }
 void jrcb_destroy(void* h) { delete (handle*)h; }
 
+void* jrcb_make_radar2(int fft_len, int N_tx, int N_rx, int N_sym, int N_pre, int bg_removal, int bg_recording, int record_len,
+                       int interp_factor, int interleave, const char* radar_chan_file)
+{
+    return guard_make([&] { return std::static_pointer_cast<jrc_host::block>(std::shared_ptr<mimo_ofdm_radar>(
+        mimo_ofdm_radar::make(fft_len, N_tx, N_rx, N_sym, N_pre, bg_removal, bg_recording, record_len, interp_factor, interleave,
+                              radar_chan_file ? radar_chan_file : ""))); });
+}
 void* jrcb_make_radar(int fft_len, int N_tx, int N_rx, int N_sym, int N_pre, int bg_removal, int bg_recording, int record_len,
                       int interp_factor, int interleave)
 {
-    return guard_make([&] { return std::static_pointer_cast<jrc_host::block>(std::shared_ptr<mimo_ofdm_radar>(
-        mimo_ofdm_radar::make(fft_len, N_tx, N_rx, N_sym, N_pre, bg_removal, bg_recording, record_len, interp_factor, interleave, ""))); });
+    return jrcb_make_radar2(fft_len, N_tx, N_rx, N_sym, N_pre, bg_removal, bg_recording, record_len, interp_factor, interleave, "");
 }
 void* jrcb_make_radar_chain(int fft_len, int N_tx, int N_rx, int N_sym, int N_pre, int interp_range, int interp_angle, int interleave,
                             const float* rb, int n_rb, const float* ab, int n_ab, float ndr, float nda, float snr_thr, float pow_thr,
@@ -242,7 +248,10 @@ int jrcb_call_setter(void* h, const char* name, double v)
     auto& b = ((handle*)h)->b;
     std::string n(name);
     try {
-        if (auto* r = dynamic_cast<mimo_ofdm_radar*>(b.get())) { if (n == "set_background_record") { r->set_background_record(v != 0); return 0; } }
+        if (auto* r = dynamic_cast<mimo_ofdm_radar*>(b.get())) {
+            if (n == "set_background_record") { r->set_background_record(v != 0); return 0; }
+            if (n == "capture_radar_data") { r->capture_radar_data(v != 0); return 0; }
+        }
         if (auto* e = dynamic_cast<range_angle_estimator*>(b.get())) {
             if (n == "set_snr_threshold") { e->set_snr_threshold((float)v); return 0; }
             if (n == "set_power_threshold") { e->set_power_threshold((float)v); return 0; }

@@ -20,11 +20,12 @@ def lib():
             jrc_amd._build.build_host()
         L = C.CDLL(LIB)
         L.jrcb_last_error.restype = C.c_char_p
-        for name in ("jrcb_make_radar", "jrcb_make_radar_chain", "jrcb_make_transpose", "jrcb_make_estimator", "jrcb_make_cp_remover",
+        for name in ("jrcb_make_radar", "jrcb_make_radar2", "jrcb_make_radar_chain", "jrcb_make_transpose", "jrcb_make_estimator", "jrcb_make_cp_remover",
                      "jrcb_make_peak_detect", "jrcb_make_equalizer", "jrcb_make_precoder", "jrcb_make_target_simulator", "jrcb_make_stream_encoder", "jrcb_make_stream_decoder",
                      "jrcb_make_moving_avg", "jrcb_make_frame_detector", "jrcb_make_frame_sync", "jrcb_make_zero_pad", "jrcb_make_frame_generator"):
             getattr(L, name).restype = _vp
         L.jrcb_make_radar.argtypes = [C.c_int] * 10
+        L.jrcb_make_radar2.argtypes = [C.c_int] * 10 + [C.c_char_p]
         L.jrcb_make_transpose.argtypes = [C.c_int] * 3
         L.jrcb_make_radar_chain.argtypes = [C.c_int] * 8 + [_fp, C.c_int, _fp, C.c_int] + [C.c_float] * 4 + [C.c_char_p, C.c_int, C.c_int, C.c_int]
         L.jrcb_make_estimator.argtypes = [C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_char_p, C.c_int]
@@ -121,8 +122,9 @@ class Block:
         assert r == 0, name
 
 
-def radar(fft_len, N_tx, N_rx, N_sym, N_pre, bg_removal=False, bg_recording=False, record_len=8, interp=1, interleave=False):
-    return Block(lib().jrcb_make_radar(fft_len, N_tx, N_rx, N_sym, N_pre, int(bg_removal), int(bg_recording), record_len, interp, int(interleave)))
+def radar(fft_len, N_tx, N_rx, N_sym, N_pre, bg_removal=False, bg_recording=False, record_len=8, interp=1, interleave=False, radar_chan_file=""):
+    return Block(lib().jrcb_make_radar2(fft_len, N_tx, N_rx, N_sym, N_pre, int(bg_removal), int(bg_recording), record_len, interp, int(interleave),
+                                        radar_chan_file.encode()))
 
 
 def radar_chain(fft_len, N_tx, N_rx, N_sym, N_pre, interp_range, interp_angle, rb, ab, ndr, nda, snr_thr, pow_thr, stats_path="",

@@ -507,3 +507,40 @@ def test_radar_chain_block_runs_the_five_block_branch_in_one(jrc, ctx, tmp_path)
     assert {k: v[0] for k, v in msgs[-1]["msg"]}["snr"] == want[F - 1].snr_est
     with pytest.raises(ValueError, match="RADAR CHAIN"):
         hb.radar_chain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb[:-1], ab, 2.4, 28.96, 15.0, 0.0)
+
+
+@gpu
+def test_radar_block_capture_writes_radar_chan_csv(jrc, tmp_path):
+    """capture_radar_data (lib/mimo_ofdm_radar_impl.cc:348-387): 'HH:MM:SS.mmm, N_tx, N_rx, fft_len:(re,im);...;' + an empty line per
+    capture, appended; the values are the last frame's channel estimate (row p = r*T + t, without the zero padding)"""
+    import hostblocks as hb
+    rng = np.random.default_rng(5)
+    N, T, R, S, Npre, Ir = 64, 2, 2, 3, 1, 4
+    path = str(tmp_path / "radar_chan.csv")
+    blk = hb.radar(N, T, R, S, Npre, interp=Ir, radar_chan_file=path)
+    n_items = Npre + S
+    tx = [crandn(rng, n_items, N) for _ in range(T)]
+    rx = [crandn(rng, n_items, N) for _ in range(R)]
+    out = np.zeros((T * R, N * Ir), np.complex64)
+    blk.tag(0, 0, "packet_len", n_items)
+    blk.tag(T, 0, "packet_len", n_items)
+    assert blk.run(T * R, tx + rx, [out]) == T * R
+    blk.set("capture_radar_data", 0)                               # false: nothing happens
+    assert not os.path.exists(path)
+    blk.set("capture_radar_data", 1)
+    blk.set("capture_radar_data", 1)                               # appended
+    text = open(path).read()
+    lines = text.split("\n")
+    assert len(lines) == 5 and lines[1] == "" and lines[3] == "" and lines[4] == ""
+    head, body = lines[0].split(":", 3)[:3], lines[0].split(":", 3)[3]
+    stamp = ":".join(head)                                          # the time stamp itself contains two colons
+    m = re.fullmatch(r"(\d\d:\d\d:\d\d\.\d\d\d), (\d+), (\d+), (\d+)", stamp)
+    assert m and (int(m.group(2)), int(m.group(3)), int(m.group(4))) == (T, R, N)
+    assert body.endswith(";")
+    vals = [complex(*map(float, v.strip("()").split(","))) for v in body[:-1].split(";")]
+    assert len(vals) == T * R * N
+    np.testing.assert_array_equal(np.array(vals, np.complex64).reshape(T * R, N), out[:, :N])
+    assert lines[2].split(":", 3)[3] == body
+    bad = hb.radar(N, T, R, S, Npre, interp=Ir, radar_chan_file=str(tmp_path / "no_such_dir" / "x.csv"))
+    with pytest.raises(RuntimeError, match="Could not open file"):
+        bad.set("capture_radar_data", 1)
