@@ -710,7 +710,7 @@ class mimo_ofdm_equalizer:
         ns = d_in.shape[0]
         out = torch.empty((ns, max_out, self.n_data, 2), dtype=torch.float32, device=d_in.device)
         n_out = torch.empty((ns,), dtype=torch.int32, device=d_in.device)
-        ev = torch.zeros((ns, 2, C.sizeof(EqEvent)), dtype=torch.uint8, device=d_in.device)
+        ev = torch.empty((ns, 2, C.sizeof(EqEvent)), dtype=torch.uint8, device=d_in.device)   # the kernel defines every slot (kind 0 = unused)
         self.ctx.check(self.ctx.lib.jrc_equalizer_frames_dev(self.h, ns, n_symbols, d_in.data_ptr(), d_phase.data_ptr(), max_out,
                                                              out.data_ptr(), n_out.data_ptr(), ev.data_ptr(), stream))
         return out, n_out, ev
@@ -1242,6 +1242,7 @@ class SyncFrontEnd:
         self.frames = torch.zeros((max_frames, max_symbols, fft_len, 2), dtype=torch.float32, device="cuda")
         self.d_info = torch.zeros((max_frames, C.sizeof(SyncFrame)), dtype=torch.uint8, device="cuda")
         self.d_n = torch.zeros(1, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()     # the fills above ran on torch's stream; the library launches on its own
         self._work = None
 
     def run(self, d_x, n_samples, stream=None):

@@ -360,9 +360,9 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
             }
         }
 
-        if (sym >= 2 && tid < NP) {   // pilot row of this symbol (SIG: row 0; data symbol m: row m mod n_rows), read by lane 0 below
+        if (sym >= 2) {               // pilot row of this symbol (SIG: row 0; data symbol m: row m mod n_rows), read by lane 0 below
             const int row = sym == 2 ? 0 : (sym > 2 + NL ? (sym - 3 - NL) % d.n_pilot_rows : 0);
-            s_ref[tid] = d.pilot_sym[(size_t)row * NP + tid];
+            for (int k = tid; k < NP; k += NT) s_ref[k] = d.pilot_sym[(size_t)row * NP + k];
         }
         {   // sampling-offset de-rotation :261-264
             const double k0 = 2 * M_PI * sym * ((N + d.cp) * 1.0 / N) * (S.epsilon0 + S.er);
@@ -642,6 +642,7 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
             }
             S.equalize_done = 1;
         }
+        for (int k = nev; k < io.max_events; k++) events[k].kind = 0;   // every slot defined: callers need not clear the array
         *gst = S;
         io.n_out[b] = n_out;
         io.n_consumed[b] = n_in;
@@ -730,20 +731,41 @@ extern "C" int jrc_equalizer_create(jrc_ctx* ctx, const jrc_eq_cfg* c, int n_str
     JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)equalizer_kernel<256, 2, 1>, eq->lds_bytes));
     JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)equalizer_kernel<256, 6, 1>, eq->lds_bytes));
     JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)equalizer_kernel<256, 8, 1>, eq->lds_bytes));
+    JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)equalizer_kernel<256, 2, 2>, eq->lds_bytes));
+    JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)equalizer_kernel<256, 2, 4>, eq->lds_bytes));
+    JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)equalizer_kernel<256, 4, 2>, eq->lds_bytes));
+    JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)equalizer_kernel<256, 4, 4>, eq->lds_bytes));
     *out = eq;
     return JRC_OK;
 }
 
+// Launch geometry.  "Wide": one lane per subcarrier (fft_len threads, 128 VGPRs) — the shortest time for a single stream, used by the
+// per-block entry point.  "Narrow": a quarter of the lanes with up to four subcarriers each and 256 VGPRs (no spills) — the sections of
+// a frame that only one wavefront or one lane can work on (SIG Viterbi, running sums, channel means) then hold up a quarter of the
+// waves, and twice as many streams are in flight per CU; used when a launch has at least a workgroup per CU.  Config C (fft_len 256,
+// 8192 streams): 64 threads x 4 subcarriers 2.89 M frames/s, 128 x 2 2.53 M, wide 2.01 M (narrow at 168 VGPRs, with spills: 2.50 M).
+// JRC_EQ_THREADS forces a workgroup size (-1: always wide), JRC_EQ_WPE the register budget (waves per SIMD: 2, 4; wide also 6, 8).
 static void launch_equalizer(jrc_equalizer* eq, int grid, hipStream_t s, const EqIo& io)
 {
-    static const int wpe = getenv("JRC_EQ_WPE") ? atoi(getenv("JRC_EQ_WPE")) : 4;   // measured on config C (frames/s): 8 waves/SIMD 1.27 M, 6: 1.35 M, 4: 1.44 M, 2: 1.32 M
-#define EQ_LAUNCH(NTM, W, E) hipLaunchKernelGGL((equalizer_kernel<NTM, W, E>), dim3(grid), dim3(eq->threads), eq->lds_bytes, s, eq->d, eq->states, eq->H, eq->Hm, eq->pre, io)
-    if (eq->d.N > eq->threads) EQ_LAUNCH(1024, 4, 4);          // fft_len 2048 / 4096: several subcarriers per lane
-    else if (eq->threads > 256) EQ_LAUNCH(1024, 4, 1);
+    const int N = eq->d.N, forced = eq->ctx->tune.eq_threads;
+    int threads = eq->threads, wpe = eq->ctx->tune.eq_wpe;
+    if (forced > 0 && forced % 64 == 0 && forced <= 256 && forced < threads && N <= 4 * forced) threads = forced;
+    else if (forced == 0 && N > 64 && N <= 1024 && grid >= eq->ctx->n_cus) {
+        threads = N <= 128 ? 64 : ((N / 4 + 63) / 64) * 64;
+        if (!wpe) wpe = 2;
+    }
+    if (!wpe) wpe = 4;
+#define EQ_LAUNCH(NTM, W, E) hipLaunchKernelGGL((equalizer_kernel<NTM, W, E>), dim3(grid), dim3(threads), eq->lds_bytes, s, eq->d, eq->states, eq->H, eq->Hm, eq->pre, io)
+    if (N > threads && threads <= 256) {        // narrow
+        if (N > 2 * threads) { if (wpe == 2) EQ_LAUNCH(256, 2, 4); else EQ_LAUNCH(256, 4, 4); }
+        else { if (wpe == 2) EQ_LAUNCH(256, 2, 2); else EQ_LAUNCH(256, 4, 2); }
+    }
+    else if (N > threads) EQ_LAUNCH(1024, 4, 4);               // fft_len 2048 / 4096: several subcarriers per lane
+    else if (threads > 256) EQ_LAUNCH(1024, 4, 1);
     else if (wpe == 2) EQ_LAUNCH(256, 2, 1);
     else if (wpe == 6) EQ_LAUNCH(256, 6, 1);
     else if (wpe == 8) EQ_LAUNCH(256, 8, 1);
-    else EQ_LAUNCH(256, 4, 1);
+    else EQ_LAUNCH(256, 4, 1);                                  // wide, measured on config C (frames/s): 8 waves/SIMD 1.27 M, 6: 1.35 M, 4: 1.44 M, 2: 1.32 M
 #undef EQ_LAUNCH
 }
 

@@ -287,7 +287,8 @@ int  jrc_equalizer_work(jrc_equalizer* eq, int stream, int noutput_items, int ni
                         jrc_cf32* chan_est, int* chan_est_written);
 /* Batched, device-resident: every stream s gets one frame of n_symbols vectors starting at
  * d_in + s*n_symbols*fft_len with a frame_start tag of value d_phase[s] on its first item.
- * d_out: [n_streams][max_out][n_data]; d_n_out: [n_streams] items produced; d_events: [n_streams][2]. */
+ * d_out: [n_streams][max_out][n_data]; d_n_out: [n_streams] items produced; d_events: [n_streams][2], every slot
+ * written (kind 0 = unused), so the array needs no clearing by the caller. */
 int  jrc_equalizer_frames_dev(jrc_equalizer* eq, int n_streams, int n_symbols, const jrc_cf32* d_in,
                               const double* d_phase, int max_out, jrc_cf32* d_out, int32_t* d_n_out,
                               jrc_eq_event* d_events, void* stream);

@@ -19,14 +19,19 @@ from jrc_amd import synth
 
 
 def timed(fn, steps=30, warm=5):
+    """seconds per call: median of three timed thirds of `steps` (a one-off stall on the box then does not move the figure)"""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / steps
+    per = []
+    k = max(1, steps // 3)
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        torch.cuda.synchronize()
+        per.append((time.perf_counter() - t0) / k)
+    return sorted(per)[1]
 
 
 def radar_with_demod(cfg="B", F=256):
@@ -175,10 +180,10 @@ def precoder_config_c(n_frames=2048):
     return dict(what="precoder config C: %d packets x 4 TX, 73 symbols x 256 sc, DATA" % n_frames, **{k.replace(" ", "_"): v for k, v in out.items()})
 
 
-def equalizer_config_c(n_frames=2048, lanes=4, S=64):
-    N, cp, T = 256, 64, 4
+def equalizer_config_c(n_frames=2048, lanes=4, S=64, N=256):
+    cp, T = N // 4, 4
     rng = np.random.default_rng(0)
-    guard = 16
+    guard = N // 16
     act = [c for c in range(-N // 2 + guard, N // 2 - guard + 1) if c != 0]
     pilots = [c for c in act if c % 32 == 16][:8]
     data = [c for c in act if c not in pilots]
