@@ -141,6 +141,9 @@ __device__ __forceinline__ float2 demod_point(int bps, float2 z)
 }
 
 #define EQ_BATCH 64   // data symbols per three-phase pass of the equalizer
+#ifndef EQ_PD
+#define EQ_PD 4       // input symbols in flight per lane in the equalisation phase
+#endif
 
 // NTMAX = workgroup size the variant is compiled for, WPE = waves per SIMD it must allow (register budget 512 / WPE)
 template <int NTMAX, int WPE, int EPT /* subcarriers per lane: fft_len <= EPT * blockDim */>
@@ -313,8 +316,10 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
                 }
                 __syncthreads();
                 int scv[EPT];                                                           // (C)
-                float2 hv[EPT], xn[EPT];
+                float2 hv[EPT];
                 double hm2[EPT];
+                // EQ_PD symbols of input in flight per lane: one symbol is ~0.3 us of arithmetic against a ~2 us HBM round trip
+                float2 xq[EQ_PD][EPT];
 #pragma unroll
                 for (int e = 0; e < EPT; e++) {
                     const int i = tid + e * NT;
@@ -322,33 +327,40 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
                         scv[e] = dc[i];
                         hv[e] = Hsel[scv[e]];
                         hm2[e] = (double)c_mul(hv[e], c_conj(hv[e])).x;
-                        xn[e] = in[(size_t)n_in * N + scv[e]];
+#pragma unroll
+                        for (int q = 0; q < EQ_PD; q++)
+                            if (q < nb) xq[q][e] = in[(size_t)(n_in + q) * N + scv[e]];
                     }
                 }
-                for (int j = 0; j < nb; j++) {
-                    float2 xc[EPT];
+                for (int j0 = 0; j0 < nb; j0 += EQ_PD) {
 #pragma unroll
-                    for (int e = 0; e < EPT; e++) {
-                        xc[e] = xn[e];
-                        if (tid + e * NT < ND && j + 1 < nb) xn[e] = in[(size_t)(n_in + j + 1) * N + scv[e]];
-                    }
-                    const double k0 = 2 * M_PI * (sym + j) * ((N + d.cp) * 1.0 / N) * eps;
-                    const float2 rot = s_brot[j];
-                    const double nvar = s_bnoi[j];
-                    float2* o = out + (size_t)(n_out + j) * ND;
+                    for (int q = 0; q < EQ_PD; q++) {
+                        const int j = j0 + q;
+                        if (j >= nb) break;
+                        float2 xc[EPT];
 #pragma unroll
-                    for (int e = 0; e < EPT; e++) {
-                        const int i = tid + e * NT;
-                        if (i < ND) {
-                            const float2 yr = c_mul(c_mul(xc[e], c_expj(k0 * (scv[e] - N / 2))), rot);
-                            float2 z;
-                            if (ptype == 1) z = c_div(yr, hv[e]);                       // symbol_equalize :900-906
-                            else {                                                      // :540-550
-                                const float csi = (float)(hm2[e] + nvar);
-                                const float2 num = c_mul(yr, c_conj(hv[e]));
-                                z = make_float2(num.x / csi, num.y / csi);
+                        for (int e = 0; e < EPT; e++) {
+                            xc[e] = xq[q][e];
+                            if (tid + e * NT < ND && j + EQ_PD < nb) xq[q][e] = in[(size_t)(n_in + j + EQ_PD) * N + scv[e]];
+                        }
+                        const double k0 = 2 * M_PI * (sym + j) * ((N + d.cp) * 1.0 / N) * eps;
+                        const float2 rot = s_brot[j];
+                        const double nvar = s_bnoi[j];
+                        float2* o = out + (size_t)(n_out + j) * ND;
+#pragma unroll
+                        for (int e = 0; e < EPT; e++) {
+                            const int i = tid + e * NT;
+                            if (i < ND) {
+                                const float2 yr = c_mul(c_mul(xc[e], c_expj(k0 * (scv[e] - N / 2))), rot);
+                                float2 z;
+                                if (ptype == 1) z = c_div(yr, hv[e]);                   // symbol_equalize :900-906
+                                else {                                                  // :540-550
+                                    const float csi = (float)(hm2[e] + nvar);
+                                    const float2 num = c_mul(yr, c_conj(hv[e]));
+                                    z = make_float2(num.x / csi, num.y / csi);
+                                }
+                                o[i] = z;                                               // :602
                             }
-                            o[i] = z;                                                   // :602
                         }
                     }
                 }
