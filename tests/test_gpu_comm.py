@@ -56,6 +56,53 @@ def test_steering_matrices(jrc, ctx, T):
         assert np.allclose(Q[i].conj().T @ Q[i], np.eye(T), atol=5e-6)
 
 
+@pytest.mark.parametrize("N,est,ptype", [(256, LS, DATA), (256, LS, NDP), (256, STA, DATA), (128, LS, DATA), (512, LS, DATA)])
+def test_equalizer_batched_launch_with_a_workgroup_per_cu_or_more(jrc, ctx, N, est, ptype):
+    """a batch of at least one stream per CU runs the equalizer in its narrow geometry (a quarter of the lanes, several subcarriers per
+    lane — `launch_equalizer` in comm.hip): every stream against the oracle's general_work on the same frame"""
+    import torch
+    cp, T, S = N // 4, 4, 12
+    rng = np.random.default_rng(21)
+    data, pilots, pil, ltf, mapped, sync = config_c_tables(N, T)
+    nd = len(data)
+    mcs = 2
+    nbytes = (S * nd - 22) // 8
+    assert oracle.n_ofdm_sym(mcs, nd, nbytes) == S
+    op = oracle.Precoder(N, T, 1, data, pilots, pil, sync, mapped)
+    n_distinct, n_streams = 6, 320
+    frames, refs, phases = [], [], []
+    for i in range(n_distinct):
+        tx = op.work(qpsk(rng, S * nd), mcs, ptype, nbytes)
+        y = np.tensordot(crandn(rng, T), tx, axes=(0, 0))
+        y = np.concatenate([y[3:4], y[3:]], axis=0)
+        y = (y + 2e-3 * (rng.standard_normal(y.shape) + 1j * rng.standard_normal(y.shape))).astype(np.complex64)
+        ph = 0.002 * i
+        oe = oracle.Equalizer(est, 24e9, 125e6, N, cp, data, pilots, pil, ltf, mapped, T)
+        refs.append(oe.general_work(y, [(0, ph)]))
+        frames.append(y)
+        phases.append(ph)
+    n_sym = frames[0].shape[0]
+    x = np.stack([frames[i % n_distinct] for i in range(n_streams)])
+    ge = jrc.mimo_ofdm_equalizer(est, 24e9, 125e6, N, cp, data, pilots, pil, ltf, mapped, T, n_streams=n_streams, ctx=ctx)
+    d_in = torch.from_numpy(x.view(np.float32).reshape(n_streams, n_sym, N, 2)).to("cuda:0")
+    d_ph = torch.tensor([phases[i % n_distinct] for i in range(n_streams)], dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    out, n_out, ev = ge.frames_dev(d_in, d_ph, n_sym, S)
+    ctx.sync()
+    out = out.cpu().numpy().view(np.complex64)[..., 0]
+    assert n_out.cpu().tolist() == [S] * n_streams
+    evb = ev.cpu().numpy()
+    for i in range(n_streams):
+        r = refs[i % n_distinct]
+        assert r["out"].shape == (S, nd)
+        assert rel_err(out[i], r["out"]) < 1e-4
+        e0 = jrc.EqEvent.from_buffer_copy(evb[i, 0].tobytes())
+        e1 = jrc.EqEvent.from_buffer_copy(evb[i, 1].tobytes())
+        assert (e0.kind, e1.kind) == (1, 2)
+        assert (e0.data_bytes, e0.mcs, e0.packet_type) == tuple(r["events"][0][k] for k in ("data_bytes", "mcs", "packet_type"))
+        assert close(e1.snr_data, r["events"][1]["snr_data"])
+
+
 @pytest.mark.parametrize("ptype,steer", [(NDP, "dft"), (DATA, "dft"), (DATA, "mean"), (DATA, "sc"), (DATA, "radar")])
 def test_precoder_work(jrc, ctx, ofdm64, ptype, steer):
     rng = np.random.default_rng(7)
@@ -238,6 +285,53 @@ def test_config_c_equalizer_and_precoder_256_subcarriers_64_symbols(jrc, ctx, es
     if steer != "sc" and est == LS:
         ref = s.reshape(S, nd)                                      # and the frame really decodes: QPSK decisions match
         assert np.mean((np.sign(g["out"].real) == np.sign(ref.real)) & (np.sign(g["out"].imag) == np.sign(ref.imag))) > 0.999
+
+
+@pytest.mark.parametrize("N,est,ptype", [(256, LS, DATA), (256, LS, NDP), (256, STA, DATA), (128, LS, DATA), (512, LS, DATA)])
+def test_equalizer_batched_launch_with_a_workgroup_per_cu_or_more(jrc, ctx, N, est, ptype):
+    """a batch of at least one stream per CU runs the equalizer in its narrow geometry (a quarter of the lanes, several subcarriers per
+    lane — `launch_equalizer` in comm.hip): every stream against the oracle's general_work on the same frame"""
+    import torch
+    cp, T, S = N // 4, 4, 12
+    rng = np.random.default_rng(21)
+    data, pilots, pil, ltf, mapped, sync = config_c_tables(N, T)
+    nd = len(data)
+    mcs = 2
+    nbytes = (S * nd - 22) // 8
+    assert oracle.n_ofdm_sym(mcs, nd, nbytes) == S
+    op = oracle.Precoder(N, T, 1, data, pilots, pil, sync, mapped)
+    n_distinct, n_streams = 6, 320
+    frames, refs, phases = [], [], []
+    for i in range(n_distinct):
+        tx = op.work(qpsk(rng, S * nd), mcs, ptype, nbytes)
+        y = np.tensordot(crandn(rng, T), tx, axes=(0, 0))
+        y = np.concatenate([y[3:4], y[3:]], axis=0)
+        y = (y + 2e-3 * (rng.standard_normal(y.shape) + 1j * rng.standard_normal(y.shape))).astype(np.complex64)
+        ph = 0.002 * i
+        oe = oracle.Equalizer(est, 24e9, 125e6, N, cp, data, pilots, pil, ltf, mapped, T)
+        refs.append(oe.general_work(y, [(0, ph)]))
+        frames.append(y)
+        phases.append(ph)
+    n_sym = frames[0].shape[0]
+    x = np.stack([frames[i % n_distinct] for i in range(n_streams)])
+    ge = jrc.mimo_ofdm_equalizer(est, 24e9, 125e6, N, cp, data, pilots, pil, ltf, mapped, T, n_streams=n_streams, ctx=ctx)
+    d_in = torch.from_numpy(x.view(np.float32).reshape(n_streams, n_sym, N, 2)).to("cuda:0")
+    d_ph = torch.tensor([phases[i % n_distinct] for i in range(n_streams)], dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    out, n_out, ev = ge.frames_dev(d_in, d_ph, n_sym, S)
+    ctx.sync()
+    out = out.cpu().numpy().view(np.complex64)[..., 0]
+    assert n_out.cpu().tolist() == [S] * n_streams
+    evb = ev.cpu().numpy()
+    for i in range(n_streams):
+        r = refs[i % n_distinct]
+        assert r["out"].shape == (S, nd)
+        assert rel_err(out[i], r["out"]) < 1e-4
+        e0 = jrc.EqEvent.from_buffer_copy(evb[i, 0].tobytes())
+        e1 = jrc.EqEvent.from_buffer_copy(evb[i, 1].tobytes())
+        assert (e0.kind, e1.kind) == (1, 2)
+        assert (e0.data_bytes, e0.mcs, e0.packet_type) == tuple(r["events"][0][k] for k in ("data_bytes", "mcs", "packet_type"))
+        assert close(e1.snr_data, r["events"][1]["snr_data"])
 
 
 @pytest.mark.parametrize("ptype,steer", [(NDP, "dft"), (DATA, "dft"), (DATA, "mean"), (DATA, "sc"), (DATA, "radar")])
