@@ -702,6 +702,114 @@ __global__ __launch_bounds__(NT) void range_doppler_fused_kernel(const float2* _
     }
 }
 
+// Range axis as a pruned FFT, for fft_len = 4^k (64, 256, 1024): output bin Ir*q + c of the zero-padded inverse transform is bin q of
+// the fft_len-point inverse FFT of x[n] * exp(+j 2 pi n c / NR), so a workgroup keeps its tile (fft_len rows x 16 Doppler bins) in
+// registers, and per residue c < Ir twiddles it into LDS, runs log4(fft_len) in-place radix-4 decimation-in-frequency passes (rows are
+// the transform axis, the 16 bins of a row ride along as two-bin float4 segments) and stores row i — which then holds bin rev4(i) — as the
+// 128-byte line of output row Ir*rev4(i) + c.  5 log2(fft_len) + 6 flops per output instead of the fold's 8 fft_len / 64 + 30.
+template <int NT /* == fft_len */>
+__global__ __launch_bounds__(NT) void range_doppler_pruned_kernel(const float2* __restrict__ E,     // [units/(ND/16)][N][ND]
+                                                                  float2* __restrict__ out,         // [units/(ND/16)][NR][ND]
+                                                                  const float2* __restrict__ twR, int NR, int ND, long n_units, int WPF)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 s_t[];          // [N][8]: row n = 16 bins
+    constexpr int N = NT, LOG4 = (NT == 64 ? 3 : (NT == 256 ? 4 : 5)), RSTEP = NT / 8;
+    const int Ir = NR / N;
+    const int xcd = blockIdx.x & 7;
+    const long jb = blockIdx.x >> 3;
+    const long u = (jb / WPF) * 8 + xcd;
+    const int slice = (int)(jb % WPF);
+    if (u >= n_units) return;
+    const int tiles = ND / RD_DT;
+    const long fp = u / tiles;
+    const int d0 = (int)(u % tiles) * RD_DT;
+    const int tid = threadIdx.x, seg = tid & 7, r0 = tid >> 3;           // this lane's rows: r0 + j * NT/8, its two bins: 2 seg, 2 seg + 1
+
+    float4 e[8];
+    {
+        const float2* Eb = E + (size_t)fp * N * ND + d0 + 2 * seg;
+#pragma unroll
+        for (int j = 0; j < 8; j++) e[j] = *reinterpret_cast<const float4*>(Eb + (size_t)(r0 + j * RSTEP) * ND);
+    }
+    // pass twiddles: every pass reads exp(+j 2 pi jj / L) = W[jj * N / L] from one table W[i] = exp(+j 2 pi i / N), i < N/4, in LDS;
+    // squares / cubes are formed on the fly
+    float2* s_w = reinterpret_cast<float2*>(s_t + (size_t)N * 8);
+    for (int i = tid; i < N / 4; i += NT) s_w[i] = twR[(size_t)i * Ir];
+    // class twiddles exp(+j 2 pi row c / NR), row = r0 + j * NT/8: the lane's first row from the table, the others by the (uniform)
+    // step exp(+j 2 pi (NT/8) c / NR); both are fetched one class ahead
+    float2 cw0 = twR[(r0 * slice) & (NR - 1)], cstep = twR[(RSTEP * slice) & (NR - 1)];
+    float2* outp = out + (size_t)fp * NR * ND + d0 + 2 * seg;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+#pragma unroll 1
+    for (int c = slice; c < Ir; c += WPF) {
+        {
+            float2 w = cw0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float2 a = cmul(make_float2(e[j].x, e[j].y), w), b = cmul(make_float2(e[j].z, e[j].w), w);
+                s_t[(r0 + j * RSTEP) * 8 + seg] = make_float4(a.x, a.y, b.x, b.y);
+                w = cmul(w, cstep);
+            }
+        }
+        if (c + WPF < Ir) { cw0 = twR[(r0 * (c + WPF)) & (NR - 1)]; cstep = twR[(RSTEP * (c + WPF)) & (NR - 1)]; }
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < LOG4; ps++) {
+            const int L = N >> (2 * ps), q = L >> 2;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int t = tid + h * NT, b = t >> 3;
+                const int base = (b / q) * L + (b & (q - 1));
+                float4* p0 = s_t + (size_t)base * 8 + seg;
+                const float4 a0 = p0[0], a1 = p0[(size_t)q * 8], a2 = p0[(size_t)2 * q * 8], a3 = p0[(size_t)3 * q * 8];
+                // inverse radix-4: y_m = sum_l a_l (+j)^(l m)
+                const float4 t0 = make_float4(a0.x + a2.x, a0.y + a2.y, a0.z + a2.z, a0.w + a2.w);
+                const float4 t1 = make_float4(a0.x - a2.x, a0.y - a2.y, a0.z - a2.z, a0.w - a2.w);
+                const float4 t2 = make_float4(a1.x + a3.x, a1.y + a3.y, a1.z + a3.z, a1.w + a3.w);
+                const float4 t3 = make_float4(a1.x - a3.x, a1.y - a3.y, a1.z - a3.z, a1.w - a3.w);
+                float4 y0 = make_float4(t0.x + t2.x, t0.y + t2.y, t0.z + t2.z, t0.w + t2.w);
+                float4 y2 = make_float4(t0.x - t2.x, t0.y - t2.y, t0.z - t2.z, t0.w - t2.w);
+                float4 y1 = make_float4(t1.x - t3.y, t1.y + t3.x, t1.z - t3.w, t1.w + t3.z);     // t1 + j t3
+                float4 y3 = make_float4(t1.x + t3.y, t1.y - t3.x, t1.z + t3.w, t1.w - t3.z);     // t1 - j t3
+                if (ps < LOG4 - 1) {
+                    const float2 w1 = s_w[(b & (q - 1)) << (2 * ps)], w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+                    float2 v;
+                    v = cmul(make_float2(y1.x, y1.y), w1); y1.x = v.x; y1.y = v.y; v = cmul(make_float2(y1.z, y1.w), w1); y1.z = v.x; y1.w = v.y;
+                    v = cmul(make_float2(y2.x, y2.y), w2); y2.x = v.x; y2.y = v.y; v = cmul(make_float2(y2.z, y2.w), w2); y2.z = v.x; y2.w = v.y;
+                    v = cmul(make_float2(y3.x, y3.y), w3); y3.x = v.x; y3.y = v.y; v = cmul(make_float2(y3.z, y3.w), w3); y3.z = v.x; y3.w = v.y;
+                }
+                p0[0] = y0; p0[(size_t)q * 8] = y1; p0[(size_t)2 * q * 8] = y2; p0[(size_t)3 * q * 8] = y3;
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int row = r0 + j * RSTEP;
+            unsigned k = __brev((unsigned)row) >> (32 - 2 * LOG4);                  // base-4 digit reversal = bit reversal with the bits of
+            k = ((k & 0xAAAAAAAAu) >> 1) | ((k & 0x55555555u) << 1);              // every pair swapped back
+            const float4 v = s_t[row * 8 + seg];
+            v4f t = {v.x, v.y, v.z, v.w};
+            __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(outp + ((size_t)Ir * k + c) * ND));
+        }
+        __syncthreads();
+    }
+}
+
+template <int NT>
+static int launch_rd_pruned(jrc_ctx* ctx, const float2* E, float2* out, const float2* twR, int NR, int ND, long n_units, hipStream_t s)
+{
+    const size_t lds = sizeof(float4) * 8 * (size_t)NT + sizeof(float2) * (NT / 4);
+    JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)range_doppler_pruned_kernel<NT>, lds));
+    const int Ir = NR / NT;
+    const long target = (long)ctx->n_cus * (NT == 1024 ? 1 : 4);
+    int wpf = 1;
+    while (wpf * 2 <= Ir && (long)wpf * 2 * n_units <= target) wpf *= 2;
+    const long groups = (n_units + 7) / 8;
+    hipLaunchKernelGGL((range_doppler_pruned_kernel<NT>), dim3((unsigned)(groups * wpf * 8)), dim3(NT), lds, s, E, out, twR, NR, ND, n_units, wpf);
+    JRC_HIP(ctx, hipGetLastError());
+    return JRC_OK;
+}
+
 template <int NT, int MMAX, bool TWC_LDS>
 static int launch_rd_fused(jrc_ctx* ctx, const float2* E, float2* out, const float2* twR, int N, int NR, int ND, long n_units, size_t lds, hipStream_t s)
 {
@@ -732,7 +840,7 @@ extern "C" int jrc_range_doppler_dev(jrc_ctx* ctx, const jrc_chain_cfg* c, int i
     g.tx_item0 = c->N_pre; g.rx_item0 = c->N_pre; g.interleave = c->enable_tx_interleave;
     // fused path: Doppler FFT on the compact data, zero-padded range IFFT streamed out once (d_work holds [pair][N][ND] <= its size)
     if (jrc_is_pow2(N) && N >= RA_L && N <= 1024 && jrc_is_pow2(NR) && NR >= RA_L && jrc_is_pow2(ND) && ND >= RD_DT && ND <= 8192 &&
-        interp_doppler <= c->interp_range && ((reinterpret_cast<size_t>(d_work) & 15) == 0) && !getenv("JRC_RD_GENERIC")) {
+        interp_doppler <= c->interp_range && ((reinterpret_cast<size_t>(d_work) & 15) == 0) && !ctx->tune.rd_generic) {
         const size_t fp = (size_t)n_frames * P;
         hipLaunchKernelGGL(rd_product_t_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((ND + 63) / 64), (unsigned)fp), dim3(256), 0, s,
                            (const float2*)d_frames, (float2*)d_work, g, T, R, (int)ND);
@@ -742,6 +850,11 @@ extern "C" int jrc_range_doppler_dev(jrc_ctx* ctx, const jrc_chain_cfg* c, int i
         JRC_TRY(jrc_get_twiddles(ctx, (int)NR, +1, &twR));
         const size_t lds = sizeof(float2) * ((size_t)RD_DT * N + (size_t)RD_DT * RA_L + (N > 256 ? (size_t)N : 0));
         const long n_units = (long)fp * (ND / RD_DT);
+        if (!ctx->tune.rd_fold) {      // fft_len = 4^k: pruned FFT instead of the fold
+            if (N == 1024) return launch_rd_pruned<1024>(ctx, (const float2*)d_work, (float2*)d_out, twR, (int)NR, (int)ND, n_units, s);
+            if (N == 256) return launch_rd_pruned<256>(ctx, (const float2*)d_work, (float2*)d_out, twR, (int)NR, (int)ND, n_units, s);
+            if (N == 64) return launch_rd_pruned<64>(ctx, (const float2*)d_work, (float2*)d_out, twR, (int)NR, (int)ND, n_units, s);
+        }
         if (lds > 80 * 1024) return launch_rd_fused<512, 16, true>(ctx, (const float2*)d_work, (float2*)d_out, twR, N, (int)NR, (int)ND, n_units, lds, s);
         if (N > 256) return launch_rd_fused<256, 16, true>(ctx, (const float2*)d_work, (float2*)d_out, twR, N, (int)NR, (int)ND, n_units, lds, s);
         return launch_rd_fused<256, 4, false>(ctx, (const float2*)d_work, (float2*)d_out, twR, N, (int)NR, (int)ND, n_units, lds, s);

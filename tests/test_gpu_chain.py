@@ -149,7 +149,12 @@ def test_chain_generic_and_fused_modes_agree(jrc, ctx, monkeypatch):
         assert abs(a.snr_est - b.snr_est) < 1e-2
 
 
-@pytest.mark.parametrize("T,R,N,S,Ir,Id,vel", [(2, 2, 64, 16, 4, 4, 30.0), (4, 4, 256, 64, 2, 1, -20.0), (1, 1, 64, 64, 2, 2, 600.0)])
+@pytest.mark.parametrize("T,R,N,S,Ir,Id,vel", [(2, 2, 64, 16, 4, 4, 30.0), (4, 4, 256, 64, 2, 1, -20.0), (1, 1, 64, 64, 2, 2, 600.0),
+                                               (1, 2, 1024, 16, 8, 1, 200.0),     # fft_len 1024: pruned-FFT range kernel, 8 classes
+                                               (2, 1, 256, 32, 1, 1, -50.0),      # no range interpolation (one class)
+                                               (1, 2, 128, 16, 4, 2, 1000.0),     # fft_len not a power of four: the fold kernel
+                                               (1, 1, 512, 32, 2, 1, 300.0),
+                                               (2, 1, 96, 8, 2, 1, 10.0)])        # not a power of two: block by block
 def test_range_doppler_map_row_d(jrc, ctx, T, R, N, S, Ir, Id, vel):
     """row D has no reference counterpart (the reference sums over symbols): checked against the numpy definition
     fftshift(FFT_sym(IFFT_sc(rx*conj(tx), zero-padded))) and, for one TX, against the Doppler of the synthetic target"""
