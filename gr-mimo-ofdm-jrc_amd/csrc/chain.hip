@@ -704,9 +704,11 @@ __global__ __launch_bounds__(NT) void range_doppler_fused_kernel(const float2* _
 
 // Range axis as a pruned FFT, for fft_len = 4^k (64, 256, 1024): output bin Ir*q + c of the zero-padded inverse transform is bin q of
 // the fft_len-point inverse FFT of x[n] * exp(+j 2 pi n c / NR), so a workgroup keeps its tile (fft_len rows x 16 Doppler bins) in
-// registers, and per residue c < Ir twiddles it into LDS, runs log4(fft_len) in-place radix-4 decimation-in-frequency passes (rows are
-// the transform axis, the 16 bins of a row ride along as two-bin float4 segments) and stores row i — which then holds bin rev4(i) — as the
-// 128-byte line of output row Ir*rev4(i) + c.  5 log2(fft_len) + 6 flops per output instead of the fold's 8 fft_len / 64 + 30.
+// registers, and per residue c < Ir twiddles it into LDS, transforms it in place along the rows by decimation in frequency — radix-16
+// passes in registers (one lane = one bin of one 16-point butterfly), then radix-4 passes on two-bin segments — and stores row
+// i, which then holds the bin whose mixed-radix digits are those of i reversed, as the 128-byte line of its output row.  The tile is kept
+// conjugated so that the inverse transform runs on the forward butterflies of fft_device.h.  5 log2(fft_len) + 6 flops per output
+// instead of the fold's 8 fft_len / 64 + 30.
 template <int NT /* == fft_len */>
 __global__ __launch_bounds__(NT) void range_doppler_pruned_kernel(const float2* __restrict__ E,     // [units/(ND/16)][N][ND]
                                                                   float2* __restrict__ out,         // [units/(ND/16)][NR][ND]
@@ -714,6 +716,10 @@ __global__ __launch_bounds__(NT) void range_doppler_pruned_kernel(const float2* 
 {
     extern __shared__ __attribute__((aligned(16))) float4 s_t[];          // [N][8]: row n = 16 bins
     constexpr int N = NT, LOG4 = (NT == 64 ? 3 : (NT == 256 ? 4 : 5)), RSTEP = NT / 8;
+    // radix-16 passes, then radix-4 passes.  At 1024 threads (128 VGPRs) the 16-point butterfly next to the resident tile spills
+    // (measured: 0.393 ms per 8 config-D frames against 0.345 ms with radix-4 passes only), so fft_len 1024 stays on radix 4.
+    constexpr int R16 = NT == 1024 ? 0 : LOG4 / 2;
+    constexpr int R4 = LOG4 - 2 * R16;
     const int Ir = NR / N;
     const int xcd = blockIdx.x & 7;
     const long jb = blockIdx.x >> 3;
@@ -731,10 +737,10 @@ __global__ __launch_bounds__(NT) void range_doppler_pruned_kernel(const float2* 
 #pragma unroll
         for (int j = 0; j < 8; j++) e[j] = *reinterpret_cast<const float4*>(Eb + (size_t)(r0 + j * RSTEP) * ND);
     }
-    // pass twiddles: every pass reads exp(+j 2 pi jj / L) = W[jj * N / L] from one table W[i] = exp(+j 2 pi i / N), i < N/4, in LDS;
-    // squares / cubes are formed on the fly
-    float2* s_w = reinterpret_cast<float2*>(s_t + (size_t)N * 8);
-    for (int i = tid; i < N / 4; i += NT) s_w[i] = twR[(size_t)i * Ir];
+    // pass twiddles: W[i] = exp(+j 2 pi i / N) in LDS (used conjugated)
+    float2* s_f = reinterpret_cast<float2*>(s_t);                         // the tile as [N][16]
+    float2* s_w = s_f + (size_t)N * 16;
+    for (int i = tid; i < N; i += NT) s_w[i] = twR[(size_t)i * Ir];
     // class twiddles exp(+j 2 pi row c / NR), row = r0 + j * NT/8: the lane's first row from the table, the others by the (uniform)
     // step exp(+j 2 pi (NT/8) c / NR); both are fetched one class ahead
     float2 cw0 = twR[(r0 * slice) & (NR - 1)], cstep = twR[(RSTEP * slice) & (NR - 1)];
@@ -747,36 +753,56 @@ __global__ __launch_bounds__(NT) void range_doppler_pruned_kernel(const float2* 
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const float2 a = cmul(make_float2(e[j].x, e[j].y), w), b = cmul(make_float2(e[j].z, e[j].w), w);
-                s_t[(r0 + j * RSTEP) * 8 + seg] = make_float4(a.x, a.y, b.x, b.y);
+                s_t[(r0 + j * RSTEP) * 8 + seg] = make_float4(a.x, -a.y, b.x, -b.y);      // conjugated
                 w = cmul(w, cstep);
             }
         }
         if (c + WPF < Ir) { cw0 = twR[(r0 * (c + WPF)) & (NR - 1)]; cstep = twR[(RSTEP * (c + WPF)) & (NR - 1)]; }
         __syncthreads();
 #pragma unroll
-        for (int ps = 0; ps < LOG4; ps++) {
-            const int L = N >> (2 * ps), q = L >> 2;
+        for (int ps = 0; ps < R16; ps++) {
+            const int L = N >> (4 * ps), q = L >> 4;
+            const int bin = tid & 15, b = tid >> 4;                       // N/16 butterflies x 16 bins: one per lane
+            const int jj = b & (q - 1);
+            float2* p0 = s_f + ((size_t)(b / q) * L + jj) * 16 + bin;
+            float2 v[16];
+#pragma unroll
+            for (int l = 0; l < 16; l++) v[l] = p0[(size_t)l * q * 16];
+            fft_fwd_small<16>(v);
+            if (q > 1) {
+#pragma unroll
+                for (int m = 1; m < 16; m++) {
+                    const float2 w = s_w[(jj * m) << (4 * ps)];           // exp(+j 2 pi jj m / L); the forward pass needs its conjugate
+                    v[m] = make_float2(v[m].x * w.x + v[m].y * w.y, v[m].y * w.x - v[m].x * w.y);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 16; m++) p0[(size_t)m * q * 16] = v[m];
+            __syncthreads();
+        }
+#pragma unroll
+        for (int ps = 0; ps < R4; ps++) {                                 // two-bin segments, two butterflies per lane
+            const int L = (N >> (4 * R16)) >> (2 * ps), q = L >> 2;
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                const int t = tid + h * NT, b = t >> 3;
-                const int base = (b / q) * L + (b & (q - 1));
-                float4* p0 = s_t + (size_t)base * 8 + seg;
+                const int b = (tid + h * NT) >> 3, jj = b & (q - 1);
+                float4* p0 = s_t + ((size_t)(b / q) * L + jj) * 8 + seg;
                 const float4 a0 = p0[0], a1 = p0[(size_t)q * 8], a2 = p0[(size_t)2 * q * 8], a3 = p0[(size_t)3 * q * 8];
-                // inverse radix-4: y_m = sum_l a_l (+j)^(l m)
                 const float4 t0 = make_float4(a0.x + a2.x, a0.y + a2.y, a0.z + a2.z, a0.w + a2.w);
                 const float4 t1 = make_float4(a0.x - a2.x, a0.y - a2.y, a0.z - a2.z, a0.w - a2.w);
                 const float4 t2 = make_float4(a1.x + a3.x, a1.y + a3.y, a1.z + a3.z, a1.w + a3.w);
                 const float4 t3 = make_float4(a1.x - a3.x, a1.y - a3.y, a1.z - a3.z, a1.w - a3.w);
                 float4 y0 = make_float4(t0.x + t2.x, t0.y + t2.y, t0.z + t2.z, t0.w + t2.w);
                 float4 y2 = make_float4(t0.x - t2.x, t0.y - t2.y, t0.z - t2.z, t0.w - t2.w);
-                float4 y1 = make_float4(t1.x - t3.y, t1.y + t3.x, t1.z - t3.w, t1.w + t3.z);     // t1 + j t3
-                float4 y3 = make_float4(t1.x + t3.y, t1.y - t3.x, t1.z + t3.w, t1.w - t3.z);     // t1 - j t3
-                if (ps < LOG4 - 1) {
-                    const float2 w1 = s_w[(b & (q - 1)) << (2 * ps)], w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+                float4 y1 = make_float4(t1.x + t3.y, t1.y - t3.x, t1.z + t3.w, t1.w - t3.z);     // t1 - j t3 (forward)
+                float4 y3 = make_float4(t1.x - t3.y, t1.y + t3.x, t1.z - t3.w, t1.w + t3.z);     // t1 + j t3
+                if (q > 1) {
+                    const float2 w1 = s_w[jj * (N / L)], w2 = cmul(w1, w1), w3 = cmul(w2, w1);   // used conjugated
+                    auto cmulc = [](float x, float y, float2 w) { return make_float2(x * w.x + y * w.y, y * w.x - x * w.y); };
                     float2 v;
-                    v = cmul(make_float2(y1.x, y1.y), w1); y1.x = v.x; y1.y = v.y; v = cmul(make_float2(y1.z, y1.w), w1); y1.z = v.x; y1.w = v.y;
-                    v = cmul(make_float2(y2.x, y2.y), w2); y2.x = v.x; y2.y = v.y; v = cmul(make_float2(y2.z, y2.w), w2); y2.z = v.x; y2.w = v.y;
-                    v = cmul(make_float2(y3.x, y3.y), w3); y3.x = v.x; y3.y = v.y; v = cmul(make_float2(y3.z, y3.w), w3); y3.z = v.x; y3.w = v.y;
+                    v = cmulc(y1.x, y1.y, w1); y1.x = v.x; y1.y = v.y; v = cmulc(y1.z, y1.w, w1); y1.z = v.x; y1.w = v.y;
+                    v = cmulc(y2.x, y2.y, w2); y2.x = v.x; y2.y = v.y; v = cmulc(y2.z, y2.w, w2); y2.z = v.x; y2.w = v.y;
+                    v = cmulc(y3.x, y3.y, w3); y3.x = v.x; y3.y = v.y; v = cmulc(y3.z, y3.w, w3); y3.z = v.x; y3.w = v.y;
                 }
                 p0[0] = y0; p0[(size_t)q * 8] = y1; p0[(size_t)2 * q * 8] = y2; p0[(size_t)3 * q * 8] = y3;
             }
@@ -785,10 +811,14 @@ __global__ __launch_bounds__(NT) void range_doppler_pruned_kernel(const float2* 
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int row = r0 + j * RSTEP;
-            unsigned k = __brev((unsigned)row) >> (32 - 2 * LOG4);                  // base-4 digit reversal = bit reversal with the bits of
-            k = ((k & 0xAAAAAAAAu) >> 1) | ((k & 0x55555555u) << 1);              // every pair swapped back
+            // row = sum_s d_s * N / (r_0 ... r_s) holds bin k = sum_s d_s * (r_0 ... r_{s-1})
+            int rem = row, k = 0, span = N, mult = 1;
+#pragma unroll
+            for (int ps = 0; ps < R16; ps++) { span >>= 4; const int d = rem / span; rem -= d * span; k += d * mult; mult <<= 4; }
+#pragma unroll
+            for (int ps = 0; ps < R4; ps++) { span >>= 2; const int d = rem / span; rem -= d * span; k += d * mult; mult <<= 2; }
             const float4 v = s_t[row * 8 + seg];
-            v4f t = {v.x, v.y, v.z, v.w};
+            v4f t = {v.x, -v.y, v.z, -v.w};
             __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(outp + ((size_t)Ir * k + c) * ND));
         }
         __syncthreads();
@@ -798,7 +828,7 @@ __global__ __launch_bounds__(NT) void range_doppler_pruned_kernel(const float2* 
 template <int NT>
 static int launch_rd_pruned(jrc_ctx* ctx, const float2* E, float2* out, const float2* twR, int NR, int ND, long n_units, hipStream_t s)
 {
-    const size_t lds = sizeof(float4) * 8 * (size_t)NT + sizeof(float2) * (NT / 4);
+    const size_t lds = sizeof(float4) * 8 * (size_t)NT + sizeof(float2) * NT;
     JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)range_doppler_pruned_kernel<NT>, lds));
     const int Ir = NR / NT;
     const long target = (long)ctx->n_cus * (NT == 1024 ? 1 : 4);
