@@ -145,6 +145,9 @@ def secondary_figures(cfg):
         out["precoder_config_c"] = {"packets_per_s_dft": p["dft"]["frames_per_s"],
                                     "packets_per_s_steering_and_radar_streams": p["per-subcarrier_steering_+_radar_streams"]["frames_per_s"],
                                     "what": p["what"]}
+        d = be.range_doppler("D", 16)
+        out["range_doppler_config_d"] = {"frames_per_s": d["frames_per_s"], "GBps_algorithmic": d["GBps_algorithmic"],
+                                         "frames_per_step": d["frames_per_step"], "what": d["what"]}
     except Exception as ex:            # secondary figures must never take the headline line down with them
         out["error"] = repr(ex)
     return out

@@ -731,38 +731,96 @@ __global__ __launch_bounds__(NT) void range_doppler_pruned_kernel(const float2* 
     const int d0 = (int)(u % tiles) * RD_DT;
     const int tid = threadIdx.x, seg = tid & 7, r0 = tid >> 3;           // this lane's rows: r0 + j * NT/8, its two bins: 2 seg, 2 seg + 1
 
-    float4 e[8];
-    {
+    // The tile stays in registers in the layout of the FIRST pass's butterflies, which therefore runs straight from them (no LDS
+    // round trip for the class twiddle): radix 16 — one bin of rows b0 + l N/16; radix 4 — two bins of rows r0 + j N/8 (butterfly h of
+    // the lane takes j = h, h + 2, h + 4, h + 6).
+    constexpr int NE = R16 > 0 ? 16 : 8;
+    constexpr int ESTEP = R16 > 0 ? N / 16 : N / 8;
+    const int bin = tid & 15, b0 = tid >> 4;
+    const int erow0 = R16 > 0 ? b0 : r0;
+    float4 e[8];            // radix-4 layout
+    float2 e16[16];         // radix-16 layout
+    if constexpr (R16 > 0) {
+        const float2* Eb = E + (size_t)fp * N * ND + d0 + bin;
+#pragma unroll
+        for (int l = 0; l < 16; l++) e16[l] = Eb[(size_t)(b0 + l * ESTEP) * ND];
+    } else {
         const float2* Eb = E + (size_t)fp * N * ND + d0 + 2 * seg;
 #pragma unroll
         for (int j = 0; j < 8; j++) e[j] = *reinterpret_cast<const float4*>(Eb + (size_t)(r0 + j * RSTEP) * ND);
     }
+    (void)NE;
     // pass twiddles: W[i] = exp(+j 2 pi i / N) in LDS (used conjugated)
     float2* s_f = reinterpret_cast<float2*>(s_t);                         // the tile as [N][16]
     float2* s_w = s_f + (size_t)N * 16;
     for (int i = tid; i < N; i += NT) s_w[i] = twR[(size_t)i * Ir];
-    // class twiddles exp(+j 2 pi row c / NR), row = r0 + j * NT/8: the lane's first row from the table, the others by the (uniform)
-    // step exp(+j 2 pi (NT/8) c / NR); both are fetched one class ahead
-    float2 cw0 = twR[(r0 * slice) & (NR - 1)], cstep = twR[(RSTEP * slice) & (NR - 1)];
+    __syncthreads();
+    // class twiddles exp(+j 2 pi row c / NR) of the lane's rows: the first row from the table, the others by the (uniform) step
+    // exp(+j 2 pi ESTEP c / NR); both are fetched one class ahead
+    float2 cw0 = twR[(erow0 * slice) & (NR - 1)], cstep = twR[(ESTEP * slice) & (NR - 1)];
     float2* outp = out + (size_t)fp * NR * ND + d0 + 2 * seg;
     typedef float v4f __attribute__((ext_vector_type(4)));
 #pragma unroll 1
     for (int c = slice; c < Ir; c += WPF) {
-        {
-            float2 w = cw0;
+        if constexpr (R16 > 0) {                                          // first pass: radix 16 from registers
+            constexpr int q = N / 16;
+            float2 v[16];
+            {
+                float2 w = cw0;
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const float2 a = cmul(make_float2(e[j].x, e[j].y), w), b = cmul(make_float2(e[j].z, e[j].w), w);
-                s_t[(r0 + j * RSTEP) * 8 + seg] = make_float4(a.x, -a.y, b.x, -b.y);      // conjugated
-                w = cmul(w, cstep);
+                for (int l = 0; l < 16; l++) { const float2 a = cmul(e16[l], w); v[l] = make_float2(a.x, -a.y); w = cmul(w, cstep); }   // conjugated
+            }
+            fft_fwd_small<16>(v);
+            if (q > 1) {
+#pragma unroll
+                for (int m = 1; m < 16; m++) {
+                    const float2 w = s_w[b0 * m];
+                    v[m] = make_float2(v[m].x * w.x + v[m].y * w.y, v[m].y * w.x - v[m].x * w.y);
+                }
+            }
+            float2* p0 = s_f + (size_t)b0 * 16 + bin;
+#pragma unroll
+            for (int m = 0; m < 16; m++) p0[(size_t)m * q * 16] = v[m];
+        } else {                                                          // first pass: radix 4 from registers
+            constexpr int q = N / 4;
+            float4 a[8];
+            {
+                float2 w = cw0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float2 x = cmul(make_float2(e[j].x, e[j].y), w), y = cmul(make_float2(e[j].z, e[j].w), w);
+                    a[j] = make_float4(x.x, -x.y, y.x, -y.y);            // conjugated
+                    w = cmul(w, cstep);
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int jj = r0 + h * RSTEP;
+                const float4 a0 = a[h], a1 = a[h + 2], a2 = a[h + 4], a3 = a[h + 6];
+                const float4 t0 = make_float4(a0.x + a2.x, a0.y + a2.y, a0.z + a2.z, a0.w + a2.w);
+                const float4 t1 = make_float4(a0.x - a2.x, a0.y - a2.y, a0.z - a2.z, a0.w - a2.w);
+                const float4 t2 = make_float4(a1.x + a3.x, a1.y + a3.y, a1.z + a3.z, a1.w + a3.w);
+                const float4 t3 = make_float4(a1.x - a3.x, a1.y - a3.y, a1.z - a3.z, a1.w - a3.w);
+                float4 y0 = make_float4(t0.x + t2.x, t0.y + t2.y, t0.z + t2.z, t0.w + t2.w);
+                float4 y2 = make_float4(t0.x - t2.x, t0.y - t2.y, t0.z - t2.z, t0.w - t2.w);
+                float4 y1 = make_float4(t1.x + t3.y, t1.y - t3.x, t1.z + t3.w, t1.w - t3.z);     // t1 - j t3 (forward)
+                float4 y3 = make_float4(t1.x - t3.y, t1.y + t3.x, t1.z - t3.w, t1.w + t3.z);     // t1 + j t3
+                const float2 w1 = s_w[jj], w2 = cmul(w1, w1), w3 = cmul(w2, w1);                 // used conjugated
+                auto cmulc = [](float x, float y, float2 w) { return make_float2(x * w.x + y * w.y, y * w.x - x * w.y); };
+                float2 v;
+                v = cmulc(y1.x, y1.y, w1); y1.x = v.x; y1.y = v.y; v = cmulc(y1.z, y1.w, w1); y1.z = v.x; y1.w = v.y;
+                v = cmulc(y2.x, y2.y, w2); y2.x = v.x; y2.y = v.y; v = cmulc(y2.z, y2.w, w2); y2.z = v.x; y2.w = v.y;
+                v = cmulc(y3.x, y3.y, w3); y3.x = v.x; y3.y = v.y; v = cmulc(y3.z, y3.w, w3); y3.z = v.x; y3.w = v.y;
+                float4* p0 = s_t + (size_t)jj * 8 + seg;
+                p0[0] = y0; p0[(size_t)q * 8] = y1; p0[(size_t)2 * q * 8] = y2; p0[(size_t)3 * q * 8] = y3;
             }
         }
-        if (c + WPF < Ir) { cw0 = twR[(r0 * (c + WPF)) & (NR - 1)]; cstep = twR[(RSTEP * (c + WPF)) & (NR - 1)]; }
+        if (c + WPF < Ir) { cw0 = twR[(erow0 * (c + WPF)) & (NR - 1)]; cstep = twR[(ESTEP * (c + WPF)) & (NR - 1)]; }
         __syncthreads();
 #pragma unroll
-        for (int ps = 0; ps < R16; ps++) {
+        for (int ps = 1; ps < R16; ps++) {
             const int L = N >> (4 * ps), q = L >> 4;
-            const int bin = tid & 15, b = tid >> 4;                       // N/16 butterflies x 16 bins: one per lane
+            const int b = tid >> 4;                                       // N/16 butterflies x 16 bins: one per lane
             const int jj = b & (q - 1);
             float2* p0 = s_f + ((size_t)(b / q) * L + jj) * 16 + bin;
             float2 v[16];
@@ -781,7 +839,7 @@ __global__ __launch_bounds__(NT) void range_doppler_pruned_kernel(const float2* 
             __syncthreads();
         }
 #pragma unroll
-        for (int ps = 0; ps < R4; ps++) {                                 // two-bin segments, two butterflies per lane
+        for (int ps = (R16 > 0 ? 0 : 1); ps < R4; ps++) {                 // two-bin segments, two butterflies per lane
             const int L = (N >> (4 * R16)) >> (2 * ps), q = L >> 2;
 #pragma unroll
             for (int h = 0; h < 2; h++) {
