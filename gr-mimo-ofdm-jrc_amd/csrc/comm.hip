@@ -359,7 +359,9 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
                                     const float2 num = c_mul(yr, c_conj(hv[e]));
                                     z = make_float2(num.x / csi, num.y / csi);
                                 }
-                                o[i] = z;                                               // :602
+                                typedef float v2f __attribute__((ext_vector_type(2)));     // :602; write-once output: around the caches
+                                const v2f zz = {z.x, z.y};
+                                __builtin_nontemporal_store(zz, reinterpret_cast<v2f*>(o + i));
                             }
                         }
                     }
@@ -1110,7 +1112,11 @@ __global__ __launch_bounds__(256) void precoder_frames_kernel(PreDev d, const fl
                 float2 r[T];
                 if (rs) {
 #pragma unroll
-                    for (int j = 1; j < T; j++) r[j] = rs[((size_t)(j - 1) * n_sym + m) * N + sc];
+                    for (int j = 1; j < T; j++) {      // read once: around the caches
+                        typedef float v2f __attribute__((ext_vector_type(2)));
+                        const v2f v = __builtin_nontemporal_load(reinterpret_cast<const v2f*>(rs + ((size_t)(j - 1) * n_sym + m) * N + sc));
+                        r[j] = make_float2(v.x, v.y);
+                    }
                 }
 #pragma unroll
                 for (int t = 0; t < T; t++) {
@@ -1123,8 +1129,12 @@ __global__ __launch_bounds__(256) void precoder_frames_kernel(PreDev d, const fl
                 }
             }
         }
+        typedef float v2f __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int t = 0; t < T; t++) out[((size_t)t * n_total + k) * N + sc] = o[t];
+        for (int t = 0; t < T; t++) {            // write-once output, far larger than the caches for a batch: stored around them
+            v2f v = {o[t].x, o[t].y};
+            __builtin_nontemporal_store(v, reinterpret_cast<v2f*>(out + ((size_t)t * n_total + k) * N + sc));
+        }
     }
 }
 
