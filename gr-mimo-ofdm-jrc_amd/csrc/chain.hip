@@ -717,7 +717,9 @@ __global__ __launch_bounds__(NT) void range_doppler_pruned_kernel(const float2* 
     extern __shared__ __attribute__((aligned(16))) float4 s_t[];          // [N][8]: row n = 16 bins
     constexpr int N = NT, LOG4 = (NT == 64 ? 3 : (NT == 256 ? 4 : 5)), RSTEP = NT / 8;
     // radix-16 passes, then radix-4 passes.  At 1024 threads (128 VGPRs) the 16-point butterfly next to the resident tile spills
-    // (measured: 0.393 ms per 8 config-D frames against 0.345 ms with radix-4 passes only), so fft_len 1024 stays on radix 4.
+    // (measured: 0.393 ms per 8 config-D frames against 0.345 ms with radix-4 passes only), so fft_len 1024 stays on radix 4; a
+    // 512-thread variant with two 16-point butterflies per lane (243 VGPRs, three passes = six sweeps of the tile instead of ten)
+    // measured the same as this one (0.316 against 0.319 ms): the sweeps are not what bounds it.
     constexpr int R16 = NT == 1024 ? 0 : LOG4 / 2;
     constexpr int R4 = LOG4 - 2 * R16;
     const int Ir = NR / N;
