@@ -83,6 +83,23 @@ __global__ void k_rows_contig(float4* out, int C, int F) {
     }
 }
 
+// (f) range-Doppler layout: unit (fp, tile) writes, per class c < Ir, the 128-byte line `tile` of rows Ir*k + c, k < N (row pitch ND*8 B);
+// 8 lanes per line (16-byte non-temporal stores), rows in the scattered order of a digit-reversed FFT or in natural order
+template <int NT_, bool SCATTER>
+__global__ void k_rd(float4* out, int N, int Ir, int ND, long n_units) {
+    const int xcd = blockIdx.x & 7; const long u = (long)(blockIdx.x >> 3) * 8 + xcd;
+    if (u >= n_units) return;
+    const int tiles = ND / 16; const long fp = u / tiles; const int tile = (int)(u % tiles);
+    float4* base = out + ((size_t)fp * N * Ir * ND + tile * 16) / 2;
+    const int seg = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+    for (int c = 0; c < Ir; c++)
+        for (int j = 0; j < 8; j++) {
+            int row = r0 + j * (NT_ / 8);
+            if (SCATTER) { unsigned k = __brev((unsigned)row) >> (32 - (NT_ == 1024 ? 10 : 8)); row = (int)k; }
+            nt_store(make_float4(row, c, seg, 1.f), base + ((size_t)(Ir * row + c) * ND) / 2 + seg);
+        }
+}
+
 int main() {
     const int F = getenv("SB_F") ? atoi(getenv("SB_F")) : 256, C = 32;   // config B: 256 frames x 2048 rows x 2 KB = 1 GiB
     const size_t bytes = (size_t)F * C * 64 * 2048;
@@ -110,6 +127,13 @@ int main() {
     run("rows contiguous per WG", [&] { hipLaunchKernelGGL(k_rows_contig, dim3(grid), dim3(256), 0, 0, d, C, F); });
     CK(hipMemset(d, 0, bytes));
     run("memset-like linear again", [&] { hipLaunchKernelGGL(k_linear, dim3(8192), dim3(256), 0, 0, d, bytes / 16); });
+    {   // config D: 8 frames x 16 pairs, 1024 x 8 rows x 128 bins = 1 GiB; config B: 64 x 16, 256 x 8 x 64
+        const long nuD = 8L * 16 * 8, nuB = 64L * 16 * 4;
+        run("rd config D scattered rows", [&] { hipLaunchKernelGGL((k_rd<1024, true>), dim3((unsigned)nuD), dim3(1024), 0, 0, d, 1024, 8, 128, nuD); });
+        run("rd config D natural rows", [&] { hipLaunchKernelGGL((k_rd<1024, false>), dim3((unsigned)nuD), dim3(1024), 0, 0, d, 1024, 8, 128, nuD); });
+        run("rd config B scattered rows", [&] { hipLaunchKernelGGL((k_rd<256, true>), dim3((unsigned)nuB), dim3(256), 0, 0, d, 256, 8, 64, nuB); });
+        run("rd config B natural rows", [&] { hipLaunchKernelGGL((k_rd<256, false>), dim3((unsigned)nuB), dim3(256), 0, 0, d, 256, 8, 64, nuB); });
+    }
     hipFree(d);
     return 0;
 }
