@@ -70,7 +70,10 @@ __global__ __launch_bounds__(256) void ra_finalize_kernel(const float2* __restri
 {
     __shared__ PeakPartial red[4];
     __shared__ int s_win[5];     // start_range, end_range, start_angle, end_angle, valid
-    __shared__ float s_h[RA_CHUNK];
+    __shared__ float s_null;
+    __shared__ int s_cnt[16];
+    __shared__ __attribute__((aligned(16))) float s_h[RA_CHUNK];
+    __shared__ __attribute__((aligned(16))) float s_run[RA_CHUNK];   // running sums of the fast chain
     const int f = blockIdx.x;
     const float2* map = maps + (size_t)f * map_stride;
     const int vlen = prm.vlen, n_inputs = prm.n_inputs;
@@ -82,7 +85,6 @@ __global__ __launch_bounds__(256) void ra_finalize_kernel(const float2* __restri
 
     jrc_ra_result r;
     if (threadIdx.x == 0) {
-        const int nab = prm.n_angle_bins, nrb = prm.n_range_bins;
         r.peak_range_idx = (int)(t.idx / (unsigned)vlen);
         r.peak_angle_idx = (int)(t.idx % (unsigned)vlen);
         r.peak_power = t.best;
@@ -90,8 +92,23 @@ __global__ __launch_bounds__(256) void ra_finalize_kernel(const float2* __restri
         r.range_val = range_bins[r.peak_range_idx];
         float angle_null = r.angle_val + 90;                 // :155-160
         if (angle_null >= 90) angle_null = angle_null - 180;
-        int lo = 0, hi = nab;                                // std::lower_bound (:163-167)
-        while (lo < hi) { int mid = lo + (hi - lo) / 2; if (angle_bins[mid] < angle_null) lo = mid + 1; else hi = mid; }
+        s_null = angle_null;
+    }
+    __syncthreads();
+    {   // std::lower_bound (:163-167) on the sorted bins = the number of bins below the value: counted by all lanes at once instead of
+        // a binary search of log2(n) dependent global loads on one lane
+        const float angle_null = s_null;
+        int below = 0;
+        for (int i = threadIdx.x; i < prm.n_angle_bins; i += blockDim.x) below += angle_bins[i] < angle_null;
+        for (int off = 32; off > 0; off >>= 1) below += __shfl_xor(below, off);
+        if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = below;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nab = prm.n_angle_bins, nrb = prm.n_range_bins;
+        const float angle_null = s_null;
+        int lo = 0;
+        for (int w = 0; w < (int)((blockDim.x + 63) >> 6); w++) lo += s_cnt[w];
         int null_idx;
         if (lo == 0) null_idx = 0;                           // :172-173
         else if (lo == nab) null_idx = nab - 1;              // iter == end(): defined as size-1
@@ -125,11 +142,43 @@ __global__ __launch_bounds__(256) void ra_finalize_kernel(const float2* __restri
             s_h[j] = ref_hypotf(map[(size_t)a_idx + (size_t)vlen * r_idx]);
         }
         __syncthreads();
-        if (threadIdx.x == 0)
-            for (int j = 0; j < cnt; j++) {
-                double h = (double)s_h[j];
-                noise = (float)((double)noise + h * h);     // float += double, rounded every step (:216)
+        // The reference adds in order, `float += double` rounded at every step (:216): a chain of three dependent double-precision
+        // operations per cell on one lane.  fmaf(h, h, noise) rounds the same exact sum once instead of twice and differs from it only
+        // when the intermediate double lands on a float tie (~2^-29 per step), so: one lane runs the chain with fmaf and records the
+        // running sums, all lanes then check their steps against the reference expression in parallel, and a chunk with any mismatch
+        // is redone the slow way.  Bit-exact, ~2.5x shorter.
+        if (threadIdx.x == 0) {
+            float sacc = noise;
+            int j = 0;
+            for (; j + 8 <= cnt; j += 8) {                  // eight values per trip: the LDS reads run ahead of the dependent chain
+                const float4 a = *reinterpret_cast<const float4*>(s_h + j), b = *reinterpret_cast<const float4*>(s_h + j + 4);
+                float4 ra, rb;
+                sacc = fmaf(a.x, a.x, sacc); ra.x = sacc; sacc = fmaf(a.y, a.y, sacc); ra.y = sacc;
+                sacc = fmaf(a.z, a.z, sacc); ra.z = sacc; sacc = fmaf(a.w, a.w, sacc); ra.w = sacc;
+                sacc = fmaf(b.x, b.x, sacc); rb.x = sacc; sacc = fmaf(b.y, b.y, sacc); rb.y = sacc;
+                sacc = fmaf(b.z, b.z, sacc); rb.z = sacc; sacc = fmaf(b.w, b.w, sacc); rb.w = sacc;
+                *reinterpret_cast<float4*>(s_run + j) = ra; *reinterpret_cast<float4*>(s_run + j + 4) = rb;
             }
+            for (; j < cnt; j++) { const float h = s_h[j]; sacc = fmaf(h, h, sacc); s_run[j] = sacc; }
+        }
+        __syncthreads();
+        int bad = 0;
+        for (int j = threadIdx.x; j < cnt; j += blockDim.x) {
+            const float prev = j ? s_run[j - 1] : noise;
+            const double h = (double)s_h[j];
+            bad |= ((float)((double)prev + h * h) != s_run[j]);
+        }
+        if (__syncthreads_or(bad)) {
+            if (threadIdx.x == 0) {
+                for (int j = 0; j < cnt; j++) {
+                    double h = (double)s_h[j];
+                    noise = (float)((double)noise + h * h);
+                }
+                s_run[cnt - 1] = noise;
+            }
+            __syncthreads();
+        }
+        noise = s_run[cnt - 1];                             // every lane carries the sum: lane j = 0 of the next chunk checks against it
         __syncthreads();
     }
     if (threadIdx.x == 0) {
