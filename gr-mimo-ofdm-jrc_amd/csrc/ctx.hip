@@ -67,6 +67,7 @@ extern "C" int jrc_create(int device, jrc_ctx** out)
     ctx->tune.sync_naive = getenv("JRC_SYNC_NAIVE") != nullptr;
     ctx->tune.dec_single = getenv("JRC_DEC_SINGLE") != nullptr;
     if (const char* e = getenv("JRC_DEC_FPW")) ctx->tune.dec_frames_per_wave = atoi(e);
+    ctx->tune.ra_ref_sum = getenv("JRC_RA_REF_SUM") != nullptr;
     ctx->tune.rd_generic = getenv("JRC_RD_GENERIC") != nullptr;
     ctx->tune.rd_fold = getenv("JRC_RD_FOLD") != nullptr;
     if (const char* e = getenv("JRC_EQ_WPE")) ctx->tune.eq_wpe = atoi(e);

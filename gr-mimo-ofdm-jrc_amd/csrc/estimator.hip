@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256) void ra_finalize_kernel(const float2* __restri
                                                           const PeakPartial* __restrict__ partials, int ppf,
                                                           RaParams prm, const float* __restrict__ range_bins,
                                                           const float* __restrict__ angle_bins,
-                                                          jrc_ra_result* __restrict__ results)
+                                                          jrc_ra_result* __restrict__ results,
+                                                          int force_ref_sum)   // tests: take the reference-order double sum for every chunk
 {
     __shared__ PeakPartial red[4];
     __shared__ int s_win[5];     // start_range, end_range, start_angle, end_angle, valid
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256) void ra_finalize_kernel(const float2* __restri
             for (; j < cnt; j++) { const float h = s_h[j]; sacc = fmaf(h, h, sacc); s_run[j] = sacc; }
         }
         __syncthreads();
-        int bad = 0;
+        int bad = force_ref_sum;
         for (int j = threadIdx.x; j < cnt; j += blockDim.x) {
             const float prev = j ? s_run[j - 1] : noise;
             const double h = (double)s_h[j];
@@ -195,7 +196,7 @@ int launch_ra_finalize(jrc_ctx* ctx, const float2* d_map, size_t map_stride, con
                        const float* d_angle_bins, jrc_ra_result* d_results, int n_frames, hipStream_t stream)
 {
     hipLaunchKernelGGL(ra_finalize_kernel, dim3(n_frames), dim3(256), 0, stream, d_map, map_stride, d_partials,
-                       partials_per_frame, prm, d_range_bins, d_angle_bins, d_results);
+                       partials_per_frame, prm, d_range_bins, d_angle_bins, d_results, ctx->tune.ra_ref_sum ? 1 : 0);
     JRC_HIP(ctx, hipGetLastError());
     return JRC_OK;
 }

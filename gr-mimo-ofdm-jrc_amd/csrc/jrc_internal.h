@@ -39,6 +39,7 @@ struct jrc_ctx {
         bool sync_naive = false;     // JRC_SYNC_NAIVE: detection metrics without the LDS tile
         bool dec_single = false;     // JRC_DEC_SINGLE: the first-generation Viterbi decoder kernel (one frame per wave, LDS path ring)
         int dec_frames_per_wave = 0; // JRC_DEC_FPW: 1 or 2 frames per wave in the decoder (0 = by batch size)
+        bool ra_ref_sum = false;     // JRC_RA_REF_SUM: the estimator's noise sum always by the reference-order double chain (tests)
         bool rd_generic = false;     // JRC_RD_GENERIC: range-Doppler block by block (stock FFTs + transpose)
         bool rd_fold = false;        // JRC_RD_FOLD: range-Doppler with the fold kernel also where the pruned-FFT kernel applies
         int eq_wpe = 0;              // JRC_EQ_WPE: waves per SIMD the equalizer kernel is compiled for (2, 4, 6, 8; 0 = by geometry)

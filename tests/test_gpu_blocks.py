@@ -157,6 +157,20 @@ def test_range_angle_estimator_random_maps_bit_exact(jrc, ctx, seed):
     _same_result(est.work(m), oracle.ra_estimate(m, rb, ab, 2.4, 28.96, 15.0, 0.0))
 
 
+def test_range_angle_estimator_reference_order_sum_path(jrc, monkeypatch):
+    """the noise sum normally runs as an fmaf chain that every lane then verifies against the reference's `float += double` expression; a
+    chunk with a mismatch is redone in the reference's order.  JRC_RA_REF_SUM takes that path for every chunk: same results, bit for bit"""
+    monkeypatch.setenv("JRC_RA_REF_SUM", "1")
+    ctx2 = jrc.Context(0)
+    rng = np.random.default_rng(77)
+    rb, ab = _axes(jrc)
+    for scale in (0.05, 40.0, 1e-6):
+        m = crandn(rng, 512, 128, scale=scale)
+        m[int(rng.integers(0, 512)), int(rng.integers(0, 128))] += 60 * scale
+        est = jrc.range_angle_estimator(128, rb, ab, 9.0, 28.96, 15.0, 0.0, ctx=ctx2)          # > 2048 cells: several chunks
+        _same_result(est.work(m), oracle.ra_estimate(m, rb, ab, 9.0, 28.96, 15.0, 0.0))
+
+
 @pytest.mark.parametrize("bin_", [0, 1, 60, 63, 64, 100, 126, 127])
 def test_range_angle_estimator_null_angle_paths(jrc, ctx, bin_):
     rb, ab = _axes(jrc)
