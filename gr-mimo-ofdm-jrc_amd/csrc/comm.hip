@@ -768,7 +768,7 @@ static void launch_equalizer(jrc_equalizer* eq, int grid, hipStream_t s, const E
         threads = N <= 128 ? 64 : ((N / 4 + 63) / 64) * 64;
         if (!wpe) wpe = 2;
     }
-    if (!wpe) wpe = 4;
+    if (!wpe) wpe = threads <= 64 ? 2 : 4;      // a single wavefront (fft_len <= 64): 171 VGPRs without spills beat 128 with 29 (comm receive chain, 1024 frames: 0.56 -> 0.53 ms)
 #define EQ_LAUNCH(NTM, W, E) hipLaunchKernelGGL((equalizer_kernel<NTM, W, E>), dim3(grid), dim3(threads), eq->lds_bytes, s, eq->d, eq->states, eq->H, eq->Hm, eq->pre, io)
     if (N > threads && threads <= 256) {        // narrow
         if (N > 2 * threads) { if (wpe == 2) EQ_LAUNCH(256, 2, 4); else EQ_LAUNCH(256, 4, 4); }
