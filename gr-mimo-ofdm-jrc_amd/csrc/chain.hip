@@ -702,10 +702,10 @@ __global__ __launch_bounds__(NT) void range_doppler_fused_kernel(const float2* _
     }
 }
 
-// Range axis as a pruned FFT, for fft_len = 4^k (64, 256, 1024): output bin Ir*q + c of the zero-padded inverse transform is bin q of
+// Range axis as a pruned FFT, for fft_len = 64 ... 1024 (powers of two): output bin Ir*q + c of the zero-padded inverse transform is bin q of
 // the fft_len-point inverse FFT of x[n] * exp(+j 2 pi n c / NR), so a workgroup keeps its tile (fft_len rows x 16 Doppler bins) in
 // registers, and per residue c < Ir twiddles it into LDS, transforms it in place along the rows by decimation in frequency — radix-16
-// passes in registers (one lane = one bin of one 16-point butterfly), then radix-4 passes on two-bin segments — and stores row
+// passes in registers (one lane = one bin of one 16-point butterfly), then radix-4 / radix-2 passes on two-bin segments — and stores row
 // i, which then holds the bin whose mixed-radix digits are those of i reversed, as the 128-byte line of its output row.  The tile is kept
 // conjugated so that the inverse transform runs on the forward butterflies of fft_device.h.  5 log2(fft_len) + 6 flops per output
 // instead of the fold's 8 fft_len / 64 + 30.
@@ -715,13 +715,14 @@ __global__ __launch_bounds__(NT) void range_doppler_pruned_kernel(const float2* 
                                                                   const float2* __restrict__ twR, int NR, int ND, long n_units, int WPF)
 {
     extern __shared__ __attribute__((aligned(16))) float4 s_t[];          // [N][8]: row n = 16 bins
-    constexpr int N = NT, LOG4 = (NT == 64 ? 3 : (NT == 256 ? 4 : 5)), RSTEP = NT / 8;
+    constexpr int N = NT, LOG2 = (NT == 64 ? 6 : (NT == 128 ? 7 : (NT == 256 ? 8 : (NT == 512 ? 9 : 10)))), RSTEP = NT / 8;
     // radix-16 passes, then radix-4 passes.  At 1024 threads (128 VGPRs) the 16-point butterfly next to the resident tile spills
     // (measured: 0.393 ms per 8 config-D frames against 0.345 ms with radix-4 passes only), so fft_len 1024 stays on radix 4; a
     // 512-thread variant with two 16-point butterflies per lane (243 VGPRs, three passes = six sweeps of the tile instead of ten)
     // measured the same as this one (0.316 against 0.319 ms): the sweeps are not what bounds it.
-    constexpr int R16 = NT == 1024 ? 0 : LOG4 / 2;
-    constexpr int R4 = LOG4 - 2 * R16;
+    constexpr int R16 = NT == 1024 ? 0 : LOG2 / 4;
+    constexpr int R4 = (LOG2 - 4 * R16) / 2;
+    constexpr int R2 = (LOG2 - 4 * R16) & 1;                              // fft_len 128, 512: one last radix-2 pass
     const int Ir = NR / N;
     const int xcd = blockIdx.x & 7;
     const long jb = blockIdx.x >> 3;
@@ -868,6 +869,16 @@ __global__ __launch_bounds__(NT) void range_doppler_pruned_kernel(const float2* 
             }
             __syncthreads();
         }
+        if constexpr (R2 > 0) {                                           // span 2: no twiddles; two-bin segments, four butterflies per lane
+#pragma unroll
+            for (int h = 0; h < 4; h++) {
+                float4* p0 = s_t + (size_t)((tid + h * NT) >> 3) * 2 * 8 + seg;
+                const float4 a0 = p0[0], a1 = p0[8];
+                p0[0] = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+                p0[8] = make_float4(a0.x - a1.x, a0.y - a1.y, a0.z - a1.z, a0.w - a1.w);
+            }
+            __syncthreads();
+        }
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int row = r0 + j * RSTEP;
@@ -877,6 +888,7 @@ __global__ __launch_bounds__(NT) void range_doppler_pruned_kernel(const float2* 
             for (int ps = 0; ps < R16; ps++) { span >>= 4; const int d = rem / span; rem -= d * span; k += d * mult; mult <<= 4; }
 #pragma unroll
             for (int ps = 0; ps < R4; ps++) { span >>= 2; const int d = rem / span; rem -= d * span; k += d * mult; mult <<= 2; }
+            if constexpr (R2 > 0) k += rem * mult;                        // the last digit (span 1)
             const float4 v = s_t[row * 8 + seg];
             v4f t = {v.x, -v.y, v.z, -v.w};
             __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(outp + ((size_t)Ir * k + c) * ND));
@@ -891,7 +903,7 @@ static int launch_rd_pruned(jrc_ctx* ctx, const float2* E, float2* out, const fl
     const size_t lds = sizeof(float4) * 8 * (size_t)NT + sizeof(float2) * NT;
     JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)range_doppler_pruned_kernel<NT>, lds));
     const int Ir = NR / NT;
-    const long target = (long)ctx->n_cus * (NT == 1024 ? 1 : 4);
+    const long target = (long)ctx->n_cus * (NT == 1024 ? 1 : (NT == 512 ? 2 : 4));
     int wpf = 1;
     while (wpf * 2 <= Ir && (long)wpf * 2 * n_units <= target) wpf *= 2;
     const long groups = (n_units + 7) / 8;
@@ -940,9 +952,11 @@ extern "C" int jrc_range_doppler_dev(jrc_ctx* ctx, const jrc_chain_cfg* c, int i
         JRC_TRY(jrc_get_twiddles(ctx, (int)NR, +1, &twR));
         const size_t lds = sizeof(float2) * ((size_t)RD_DT * N + (size_t)RD_DT * RA_L + (N > 256 ? (size_t)N : 0));
         const long n_units = (long)fp * (ND / RD_DT);
-        if (!ctx->tune.rd_fold) {      // fft_len = 4^k: pruned FFT instead of the fold
+        if (!ctx->tune.rd_fold) {      // pruned FFT instead of the fold
             if (N == 1024) return launch_rd_pruned<1024>(ctx, (const float2*)d_work, (float2*)d_out, twR, (int)NR, (int)ND, n_units, s);
             if (N == 256) return launch_rd_pruned<256>(ctx, (const float2*)d_work, (float2*)d_out, twR, (int)NR, (int)ND, n_units, s);
+            if (N == 512) return launch_rd_pruned<512>(ctx, (const float2*)d_work, (float2*)d_out, twR, (int)NR, (int)ND, n_units, s);
+            if (N == 128) return launch_rd_pruned<128>(ctx, (const float2*)d_work, (float2*)d_out, twR, (int)NR, (int)ND, n_units, s);
             if (N == 64) return launch_rd_pruned<64>(ctx, (const float2*)d_work, (float2*)d_out, twR, (int)NR, (int)ND, n_units, s);
         }
         if (lds > 80 * 1024) return launch_rd_fused<512, 16, true>(ctx, (const float2*)d_work, (float2*)d_out, twR, N, (int)NR, (int)ND, n_units, lds, s);
