@@ -99,6 +99,21 @@ __global__ void k_rd(float4* out, int N, int Ir, int ND, long n_units) {
             nt_store(make_float4(row, c, seg, 1.f), base + ((size_t)(Ir * row + c) * ND) / 2 + seg);
         }
 }
+// (g) like (f) with 8-bin tiles: 64-byte half lines, 4 lanes per row
+template <int NT_>
+__global__ void k_rd64(float4* out, int N, int Ir, int ND, long n_units) {
+    const int xcd = blockIdx.x & 7; const long u = (long)(blockIdx.x >> 3) * 8 + xcd;
+    if (u >= n_units) return;
+    const int tiles = ND / 8; const long fp = u / tiles; const int tile = (int)(u % tiles);
+    float4* base = out + ((size_t)fp * N * Ir * ND + tile * 8) / 2;
+    const int seg = threadIdx.x & 3, r0 = threadIdx.x >> 2;
+    for (int c = 0; c < Ir; c++)
+        for (int j = 0; j < N / (NT_ / 4); j++) {
+            int row = r0 + j * (NT_ / 4);
+            unsigned k = __brev((unsigned)row) >> 22; row = (int)k;
+            nt_store(make_float4(row, c, seg, 1.f), base + ((size_t)(Ir * row + c) * ND) / 2 + seg);
+        }
+}
 
 int main() {
     const int F = getenv("SB_F") ? atoi(getenv("SB_F")) : 256, C = 32;   // config B: 256 frames x 2048 rows x 2 KB = 1 GiB
@@ -131,6 +146,7 @@ int main() {
         const long nuD = 8L * 16 * 8, nuB = 64L * 16 * 4;
         run("rd config D scattered rows", [&] { hipLaunchKernelGGL((k_rd<1024, true>), dim3((unsigned)nuD), dim3(1024), 0, 0, d, 1024, 8, 128, nuD); });
         run("rd config D natural rows", [&] { hipLaunchKernelGGL((k_rd<1024, false>), dim3((unsigned)nuD), dim3(1024), 0, 0, d, 1024, 8, 128, nuD); });
+        run("rd config D 64-byte half lines, 512 thr", [&] { hipLaunchKernelGGL((k_rd64<512>), dim3((unsigned)(nuD * 2)), dim3(512), 0, 0, d, 1024, 8, 128, nuD * 2); });
         run("rd config B scattered rows", [&] { hipLaunchKernelGGL((k_rd<256, true>), dim3((unsigned)nuB), dim3(256), 0, 0, d, 256, 8, 64, nuB); });
         run("rd config B natural rows", [&] { hipLaunchKernelGGL((k_rd<256, false>), dim3((unsigned)nuB), dim3(256), 0, 0, d, 256, 8, 64, nuB); });
     }
