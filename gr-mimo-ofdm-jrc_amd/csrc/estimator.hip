@@ -71,14 +71,14 @@ __global__ __launch_bounds__(256) void ra_finalize_kernel(const float2* __restri
 {
     __shared__ PeakPartial red[4];
     __shared__ int s_win[5];     // start_range, end_range, start_angle, end_angle, valid
-    __shared__ float s_null;
-    __shared__ int s_cnt[16];
     __shared__ __attribute__((aligned(16))) float s_h[RA_CHUNK];
     __shared__ __attribute__((aligned(16))) float s_run[RA_CHUNK];   // running sums of the fast chain
     const int f = blockIdx.x;
     const float2* map = maps + (size_t)f * map_stride;
     const int vlen = prm.vlen, n_inputs = prm.n_inputs;
 
+    if (prm.n_angle_bins <= RA_CHUNK)         // angle bins -> LDS (s_run is free until the noise sum); visible after the barrier in the reduction
+        for (int i = threadIdx.x; i < prm.n_angle_bins; i += blockDim.x) s_run[i] = angle_bins[i];
     PeakTracker t;
     t.init();
     for (int i = threadIdx.x; i < ppf; i += blockDim.x) t.merge(partials[(size_t)f * ppf + i].best, partials[(size_t)f * ppf + i].idx);
@@ -86,41 +86,29 @@ __global__ __launch_bounds__(256) void ra_finalize_kernel(const float2* __restri
 
     jrc_ra_result r;
     if (threadIdx.x == 0) {
+        const int nab = prm.n_angle_bins, nrb = prm.n_range_bins;
         r.peak_range_idx = (int)(t.idx / (unsigned)vlen);
         r.peak_angle_idx = (int)(t.idx % (unsigned)vlen);
         r.peak_power = t.best;
-        r.angle_val = angle_bins[r.peak_angle_idx];
+        // the angle bins were staged in LDS at kernel entry (more bins than the staging buffer holds: read in place)
+        const float* ab = nab <= RA_CHUNK ? s_run : angle_bins;
+        r.angle_val = ab[r.peak_angle_idx];
         r.range_val = range_bins[r.peak_range_idx];
         float angle_null = r.angle_val + 90;                 // :155-160
         if (angle_null >= 90) angle_null = angle_null - 180;
-        s_null = angle_null;
-    }
-    __syncthreads();
-    {   // std::lower_bound (:163-167) on the sorted bins = the number of bins below the value: counted by all lanes at once instead of
-        // a binary search of log2(n) dependent global loads on one lane
-        const float angle_null = s_null;
-        int below = 0;
-        for (int i = threadIdx.x; i < prm.n_angle_bins; i += blockDim.x) below += angle_bins[i] < angle_null;
-        for (int off = 32; off > 0; off >>= 1) below += __shfl_xor(below, off);
-        if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = below;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int nab = prm.n_angle_bins, nrb = prm.n_range_bins;
-        const float angle_null = s_null;
-        int lo = 0;
-        for (int w = 0; w < (int)((blockDim.x + 63) >> 6); w++) lo += s_cnt[w];
+        int lo = 0, hi = nab;                                // std::lower_bound (:163-167): log2(n) dependent LDS reads instead of global loads
+        while (lo < hi) { int mid = lo + (hi - lo) / 2; if (ab[mid] < angle_null) lo = mid + 1; else hi = mid; }
         int null_idx;
         if (lo == 0) null_idx = 0;                           // :172-173
         else if (lo == nab) null_idx = nab - 1;              // iter == end(): defined as size-1
         else {
-            double a = angle_bins[lo - 1], b = angle_bins[lo];
+            double a = ab[lo - 1], b = ab[lo];
             null_idx = (fabs(angle_null - a) < fabs(angle_null - b)) ? lo - 1 : lo;   // :175-180
         }
         if (null_idx == nab - 1) null_idx = nab - 2;         // :184-187
         r.angle_null_idx = null_idx;
         int dr = (int)(prm.noise_discard_range_m / (range_bins[1] - range_bins[0]));                          // :189
-        int da = (int)(prm.noise_discard_angle_deg / (angle_bins[(null_idx + 1) % nab] - angle_bins[null_idx])); // :190
+        int da = (int)(prm.noise_discard_angle_deg / (ab[(null_idx + 1) % nab] - ab[null_idx])); // :190
         if (da <= 0) da = 1;                                 // :192-195
         r.discard_range_idx = dr; r.discard_angle_idx = da;
         s_win[0] = r.peak_range_idx + nrb / 2 - dr;          // :197-201
