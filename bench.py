@@ -9,11 +9,18 @@ kernel and a CPU baseline beside it.
 A "step" = one pass of the fused chain (mimo_ofdm_radar -> range IFFT -> transpose/pad -> angle FFT ->
 range_angle_estimator) over one batch of F synthetic frames already resident in HBM.  Frames are
 independent, so N GPUs each process their own batch (weak scaling, no data-path collective); the only
-collectives are the barriers / MAX-reduce of the timing contract.  Rank 0 prints ONE JSON line.
+collectives are the barriers / MAX-reduce of the timing contract (and the optional --gather-* exchange).
+Rank 0 prints ONE JSON line.
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches the N ranks itself: this
+process — which never touches the GPU — starts N fresh children (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set),
+relays rank 0's line and exits non-zero if any child does.  Nothing is ever exec'ed from a process that holds a GPU.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,9 +30,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MAP_TOL = 1e-4                 # north_star: outputs within 1e-4 (relative, complex float) of the reference
+N_WINDOWS = 5                  # timed windows of --steps steps each; the first one is the contract's timed region
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -36,17 +45,67 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
-                    help="skip the secondary figures of SURVEY §8(d) (chain incl. RX demod, equalizer / precoder config C) that rank 0 "
-                         "appends at N=1 after the timed region")
+                    help="skip the secondary figures of SURVEY §8(d) (config-D roofline, host-fed rate, chain incl. RX demod, detect-only "
+                         "mode, equalizer / precoder config C) that rank 0 appends at N=1 after the timed region")
+    ap.add_argument("--no-check", action="store_true", help="skip the post-run verification of all F results (tiles bit-equal, distinct frames vs the oracle)")
+    ap.add_argument("--oracle-frames", type=int, default=-1, help="distinct frames compared with the oracle after the timed region (-1 = per config)")
+    ap.add_argument("--windows", type=int, default=N_WINDOWS, help="timed windows of --steps steps (>= 1; the first is the contract's timed region)")
     ap.add_argument("--prewarm-seconds", type=float, default=0.3,
                     help="untimed runs before the W warm-up steps so a cold GPU has its clocks up (0 = none)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests of the N>1 path)")
     ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses GPU 0")
+    ap.add_argument("--spawn", action="store_true", help="launch the ranks from this process even for --gpus 1 (the self-launch path)")
     ap.add_argument("--gather-results", action="store_true",
                     help="also RCCL all-gather the per-frame results every step (optional exchange, off by default)")
     ap.add_argument("--gather-maps", type=int, default=0, metavar="K",
                     help="also RCCL all-gather the range-angle maps of the first K frames of every rank each step (optional exchange, off by default)")
-    return ap.parse_args()
+    ap.add_argument("--dump", default="", metavar="PATH.npz",
+                    help="rank 0 writes the frame-ordered results of all ranks (and the first --dump-maps maps of every rank) after the timed region")
+    ap.add_argument("--dump-maps", type=int, default=0)
+    return ap.parse_args(argv)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# self-launch: N ranks as fresh child processes of a parent that never initialises the GPU
+# ----------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(a, argv):
+    port = _free_port()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   LOCAL_WORLD_SIZE=str(a.gpus), JRC_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
+    out0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    deadline = time.time() + 120
+    for p in procs[1:]:
+        try:
+            p.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()                      # exactly the child this process started
+            p.wait()
+        rc = rc or p.returncode
+    lines = [l for l in (out0 or "").splitlines() if l.startswith("{")]
+    for l in (out0 or "").splitlines():
+        if not l.startswith("{"):
+            sys.stderr.write(l + "\n")
+    if lines:
+        print(lines[-1])
+    sys.stdout.flush()
+    if rc == 0 and not lines:
+        rc = 1
+    return rc
 
 
 def scenario(name):
@@ -54,6 +113,9 @@ def scenario(name):
     return {"A": synth.config_A, "B": synth.config_B, "D": synth.config_D}[name]()
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# CPU leg (oracle): baseline timing and the expected outputs of the distinct frames
+# ----------------------------------------------------------------------------------------------------------------------
 def _cpu_worker(args):
     """one host core: the oracle's block-by-block chain on its share of the sample"""
     import oracle
@@ -103,7 +165,8 @@ def cpu_baseline(sc, Ir, Ia, frames, axes, budget_s):
     sc_args = (sc.N, sc.T, sc.R, sc.S, sc.Npre)
     done, el = _cpu_worker((sc_args, Ir, Ia, frames, axes, budget_s * 0.6))
     out = {"value": done / el, "unit": "frames/s", "cores": 1, "kind": "port",
-           "sample": "%d frames of the same workload, oracle C port (float32 radix-2 FFTs), 1 thread, %.1f s" % (done, el)}
+           "sample": "%d frames of the same workload, oracle C port (float32 radix-2 FFTs, not FFTW: the reference's stock fft_vxx blocks are "
+                     "faster than this port), 1 thread, %.1f s" % (done, el)}
     try:
         # (b) pipeline-ideal: GNU Radio runs one thread per block, so a saturated flowgraph moves at the pace of its slowest block
         st = _cpu_stage_times(sc_args, Ir, Ia, frames[:3], axes)
@@ -124,44 +187,250 @@ def cpu_baseline(sc, Ir, Ia, frames, axes, budget_s):
     return out
 
 
-def secondary_figures(cfg):
-    """the same chain with the RX OFDM demod in front (time-domain RX in), and the comm-side config C — measured after
-    the timed region by tools/bench_extra.py's routines (their own batches, a few seconds in total); never part of `value`"""
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    out = {}
-    try:
-        import bench_extra as be
-        r = be.radar_with_demod(cfg if cfg in ("B", "D") else "B", 512 if cfg != "D" else 256)
-        out["chain_with_rx_demod"] = {"frames_per_s": r["frames_per_s"], "ms_per_step": r["ms_per_step"], "frames_per_step": r["frames_per_step"],
-                                      "what": "A6+A7+A1 as one kernel (time-domain RX in) -> A2..A5, config " + (cfg if cfg in ("B", "D") else "B")}
-        e = be.equalizer_config_c()
-        out["equalizer_config_c"] = {"frames_per_s": e["frames_per_s"], "lane_frames_per_s": e["lane_frames_per_s"], "GBps": e["GBps"],
-                                     "what": e["what"]}
-        import comm_rx_probe
-        c = comm_rx_probe.run(4096, 200, 5)
-        out["comm_rx_chain"] = {"frames_per_s": c["frames_per_s"], "M_samples_per_s": c["M_samples_per_s"], "crc_ok": c["crc_ok"],
-                                "frames": c["frames"], "payloads_intact": c["payloads_intact"], "what": c["what"] + " (200-byte PDUs, QPSK 1/2)"}
-        p = be.precoder_config_c()
-        out["precoder_config_c"] = {"packets_per_s_dft": p["dft"]["frames_per_s"],
-                                    "packets_per_s_steering_and_radar_streams": p["per-subcarrier_steering_+_radar_streams"]["frames_per_s"],
-                                    "what": p["what"]}
-        d = be.range_doppler("D", 16)
-        out["range_doppler_config_d"] = {"frames_per_s": d["frames_per_s"], "GBps_algorithmic": d["GBps_algorithmic"],
-                                         "frames_per_step": d["frames_per_step"], "what": d["what"]}
-    except Exception as ex:            # secondary figures must never take the headline line down with them
-        out["error"] = repr(ex)
+def oracle_expect(sc, Ir, Ia, frames):
+    """the checker's outputs for the given distinct frames: channel estimate H (A1) and range-angle map (A2..A4)"""
+    import oracle
+    oracle.build()
+    exp = []
+    for fr in frames:
+        rad = oracle.Radar(sc.N, sc.T, sc.R, sc.S, sc.Npre, interp_factor=Ir)
+        tx = [fr[t] for t in range(sc.T)]
+        rx = [fr[sc.T + r] for r in range(sc.R)]
+        H = rad.work(tx, rx)
+        m = oracle.fft_vcc(oracle.matrix_transpose(oracle.fft_vcc(H, False, False), sc.N * Ir, sc.T * sc.R, Ia), True, True)
+        exp.append((H[:, :sc.N].copy(), m.astype(np.complex64)))
+    return exp
+
+
+def verify(torch, bufs, res_bytes, res, F, n_distinct, expect, axes, sc):
+    """after the timed region: every one of the F frames of the batch is checked.
+    (1) the batch is n_distinct frames tiled: frame f must equal frame f % n_distinct BIT FOR BIT in all three outputs
+        (channel estimate, map, result record) — so the frames compared with the oracle stand for every position of the launch
+        geometry that was timed (first/last workgroup of an XCD group, first/last frame of the batch);
+    (2) the distinct frames in `expect` against the oracle: A1 bit-exact, map within MAP_TOL, A5 record exact on the same map."""
+    import oracle
+    rb, ab, ndr, nda = axes
+    out = {"frames_checked": int(F), "tiles": int(-(-F // n_distinct))}
+    ok = True
+    tiled = True
+    for name in ("chanest", "map"):
+        t = bufs[name]
+        base = t[:n_distinct]
+        for f0 in range(n_distinct, F, n_distinct):
+            n = min(n_distinct, F - f0)
+            if not torch.equal(t[f0:f0 + n], base[:n]):
+                tiled = False
+    rb_all = res_bytes.cpu().numpy()
+    for f0 in range(n_distinct, F, n_distinct):
+        n = min(n_distinct, F - f0)
+        if not np.array_equal(rb_all[f0:f0 + n], rb_all[:n]):
+            tiled = False
+    out["tiled_bit_equal"] = tiled
+    ok = ok and tiled
+    if expect:
+        import ctypes
+        k = len(expect)
+        h_exact, est_exact, worst = True, True, 0.0
+        tiles = -(-F // n_distinct)
+        for i, (H, m) in enumerate(expect):
+            # take distinct frame i from a tile that moves through the batch (first tile, last full tile, ...)
+            pos = i + n_distinct * ((i * 7) % tiles)
+            if pos >= F:
+                pos = i
+            gH = bufs["chanest"][pos].cpu().numpy().view(np.complex64)[..., 0]
+            gm = bufs["map"][pos].cpu().numpy().view(np.complex64)[..., 0]
+            if not np.array_equal(gH, H):
+                h_exact = False
+            d = float(np.abs(m).max())
+            worst = max(worst, float(np.abs(gm - m).max() / (d if d > 0 else 1.0)))
+            ro = oracle.ra_estimate(gm, rb, ab, ndr, nda, 15.0, 0.0)          # the oracle's estimator on the SAME map
+            # jrc_ra_result and the oracle's record have the same twelve fields; `res` is the host-finished record (snr_est, published)
+            want = ctypes.string_at(ctypes.byref(ro), ctypes.sizeof(ro))
+            got = ctypes.string_at(ctypes.byref(res[pos]), ctypes.sizeof(res[pos]))
+            if got != want:
+                est_exact = False
+        out.update(oracle_frames=k, chanest_bit_exact=h_exact, map_max_rel_err=worst, map_tol=MAP_TOL, estimator_fields_exact=est_exact)
+        ok = ok and h_exact and est_exact and worst <= MAP_TOL
+    else:
+        out["oracle_frames"] = 0
+    out["ok"] = bool(ok)
     return out
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# secondary figures (rank 0, N = 1, after the timed region; never part of `value`)
+# ----------------------------------------------------------------------------------------------------------------------
+def pmc_traffic(cfg, frames_per_launch):
+    """PMC-measured HBM bytes per launch of the dominant kernel, collected by tools/profile_round.sh in separate rocprofv3 --pmc passes and
+    stamped with the hash of the kernel sources it was measured at: returns (bytes or None, stale flag)"""
+    from jrc_amd import build as jb
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        pt = d.get(cfg)
+        if not pt or pt.get("frames_per_launch") != frames_per_launch:
+            return None, False
+        if d.get("source_hash") != jb.source_hash():
+            return None, True
+        return pt["hbm_bytes_per_launch"], False
+    except (OSError, ValueError, KeyError):
+        return None, False
+
+
+def roofline_of(chain, kt, cfg, sc, Ir, Ia, F):
+    P, NR, NA = sc.T * sc.R, sc.N * Ir, sc.T * sc.R * Ia
+    # a batch beyond one resident wave of workgroups runs as several launches of the dominant kernel: roofline per launch
+    n_launch = max(1, chain.launches_per_run(F))
+    f_launch = F // n_launch if F % n_launch == 0 else None
+    k_ms = kt["range_angle_fused"] / n_launch
+    # algorithmic bytes of the dominant kernel (SURVEY.md §8(d)): unpadded H in, complex map out
+    alg_bytes = F * (P * sc.N * 8 + NR * NA * 8) / n_launch
+    traffic, stale = pmc_traffic(cfg, f_launch if f_launch is not None else F)
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    r = {"bound": "hbm", "kernel": "range_angle_fused_kernel<%d>" % P, "achieved": achieved,
+         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+         "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+         "avg_launch_ms": k_ms, "launches_timed": kt["launches"] * n_launch,
+         "launches_per_step": n_launch, "frames_per_launch": F / n_launch}
+    if stale:
+        r["traffic_stale"] = True      # profiles/pmc_traffic.json was measured at other kernel sources: re-run tools/profile_round.sh
+    return r
+
+
+def config_d_roofline(ctx, steps=20):
+    """Metric 2's home configuration (4x4, 1024 subcarriers, 128 symbols, 8 targets): the same chain on a resident batch of 256 frames"""
+    import torch
+    import jrc_amd
+    from jrc_amd import synth
+    sc = synth.config_D()
+    Ir, Ia, F = 8, 16, 256
+    P = sc.T * sc.R
+    rb, ab = jrc_amd.radar_axes(sc.N, sc.fs, Ir, P, Ia)
+    chain = jrc_amd.RadarChain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb, ab, 2.4, 14.36, 15.0, 0.0, max_frames=F, ctx=ctx)
+    bufs = chain.alloc(F, "cuda:%d" % ctx.device)
+    fr = synth.make_frames(sc, 8)
+    hf = torch.from_numpy(fr.view(np.float32).reshape((8,) + tuple(bufs["frames"].shape[1:])))
+    for f0 in range(0, F, 8):
+        bufs["frames"][f0:f0 + 8].copy_(hf)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        chain.run(bufs, F)
+    ctx.sync()
+    chain.set_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        chain.run(bufs, F)
+    ctx.sync()
+    el = time.perf_counter() - t0
+    kt = chain.get_timing()
+    r = roofline_of(chain, kt, "D", sc, Ir, Ia, F)
+    r.update(frames_per_s=F * steps / el, ms_per_step=1e3 * el / steps, frames_per_step=F,
+             what="config D (4x4, 1024 sc, 128 sym, 8 targets): chain A1..A5 on %d resident frames, %d steps" % (F, steps))
+    chain.close()
+    del bufs
+    torch.cuda.empty_cache()
+    return r
+
+
+def host_fed_rate(ctx, cfg, sc, axes, seconds=1.5):
+    """PCIe-inclusive rate (SURVEY §8(d) 'with and without H2D/D2H'): frames start in pinned HOST memory, results (48 B/frame) come back
+    to the host; three batches in flight, hipGraph replay"""
+    import jrc_amd
+    from jrc_amd import synth
+    rb, ab, ndr, nda = axes
+    fps = 64 if cfg != "D" else 16
+    slots = 3
+    src = synth.make_frames(sc, 8)
+    src = np.concatenate([src] * (fps // 8))[:fps].copy()
+    feed = jrc_amd.ChainFeed(sc.N, sc.T, sc.R, sc.S, sc.Npre, 8, 16, rb, ab, ndr, nda, 15.0, 0.0, ctx=ctx, n_slots=slots, frames_per_slot=fps, graph=True)
+    for _ in range(slots):
+        feed.acquire()[:] = src
+        feed.submit(None, fps)
+    for _ in range(slots):
+        feed.collect()
+    done = 0
+    t0 = time.perf_counter()
+    while True:
+        while feed.pending() < slots:
+            feed.acquire()
+            feed.submit(None, fps)
+        r, _ = feed.collect()
+        done += len(r)
+        if time.perf_counter() - t0 > seconds:
+            break
+    while feed.pending():
+        done += len(feed.collect()[0])
+    el = time.perf_counter() - t0
+    out = {"frames_per_s": done / el, "host_GBps": done * feed.frame_bytes / el / 1e9, "frames_per_batch": fps, "batches_in_flight": slots,
+           "what": "config %s, frames in pinned host memory -> H2D -> chain -> 48-byte results D2H, hipGraph replay (jrc_chain_feed_*)" % cfg}
+    feed.close()
+    return out
+
+
+def secondary_figures(cfg, ctx, sc, axes):
+    """Metric 2 on its home config D, the PCIe-inclusive rate, the same chain with the RX OFDM demod in front (time-domain RX in),
+    and the comm-side config C — measured after the timed region (their own batches, a few seconds in total); never part of `value`"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    out = {}
+
+    def leg(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as ex:            # a secondary figure must never take the headline line down with it
+            out[name] = {"error": repr(ex)}
+
+    if cfg != "D":
+        leg("roofline_config_d", lambda: config_d_roofline(ctx))
+    leg("host_fed_chain", lambda: host_fed_rate(ctx, cfg, sc, axes))
+    try:
+        import bench_extra as be
+    except Exception as ex:
+        out["error"] = repr(ex)
+        return out
+
+    def _demod():
+        r = be.radar_with_demod(cfg if cfg in ("B", "D") else "B", 512 if cfg != "D" else 256)
+        return {"frames_per_s": r["frames_per_s"], "ms_per_step": r["ms_per_step"], "frames_per_step": r["frames_per_step"],
+                "what": "A6+A7+A1 as one kernel (time-domain RX in) -> A2..A5, config " + (cfg if cfg in ("B", "D") else "B")}
+
+    def _eq():
+        e = be.equalizer_config_c()
+        return {"frames_per_s": e["frames_per_s"], "lane_frames_per_s": e["lane_frames_per_s"], "GBps": e["GBps"], "what": e["what"]}
+
+    def _comm():
+        import comm_rx_probe
+        c = comm_rx_probe.run(4096, 200, 5)
+        return {"frames_per_s": c["frames_per_s"], "M_samples_per_s": c["M_samples_per_s"], "crc_ok": c["crc_ok"],
+                "frames": c["frames"], "payloads_intact": c["payloads_intact"], "what": c["what"] + " (200-byte PDUs, QPSK 1/2)"}
+
+    def _pre():
+        p = be.precoder_config_c()
+        return {"packets_per_s_dft": p["dft"]["frames_per_s"],
+                "packets_per_s_steering_and_radar_streams": p["per-subcarrier_steering_+_radar_streams"]["frames_per_s"], "what": p["what"]}
+
+    def _rd():
+        d = be.range_doppler("D", 16)
+        return {"frames_per_s": d["frames_per_s"], "GBps_algorithmic": d["GBps_algorithmic"], "frames_per_step": d["frames_per_step"], "what": d["what"]}
+
+    leg("chain_with_rx_demod", _demod)
+    if hasattr(be, "detect_only"):
+        leg("detect_only_chain", lambda: be.detect_only(cfg if cfg in ("B", "D") else "B"))
+    leg("equalizer_config_c", _eq)
+    leg("comm_rx_chain", _comm)
+    leg("precoder_config_c", _pre)
+    leg("range_doppler_config_d", _rd)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 def main():
-    a = parse()
+    argv = sys.argv[1:]
+    a = parse(argv)
+    if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or a.spawn):
+        sys.exit(self_launch(a, [x for x in argv if x != "--spawn"]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
-        a.gpus = world
+    a.gpus = world
 
     import torch
     import torch.distributed as dist
@@ -175,14 +444,19 @@ def main():
     rb, ab = jrc_amd.radar_axes(sc.N, sc.fs, Ir, P, Ia)
     ndr = 2 * 3e8 / (2 * sc.fs)
     nda = 2 * float(np.rad2deg(np.arcsin(2 / P))) if P > 2 else 30.0
+    axes = (rb, ab, ndr, nda)
     n_distinct = min(a.distinct, F)
     first_frame = shard.frame_shard(world * F, rank, world)[0]      # this rank's block of the global frame stream
     host_frames = synth.make_frames(sc, n_distinct, first_frame=first_frame)
     cpu_base = None
+    expect = []
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         # CPU leg first: it forks worker processes, which must happen before this process initialises the GPU
-        cpu_base = cpu_baseline(sc, Ir, Ia, host_frames, (rb, ab, ndr, nda), a.cpu_seconds)
+        cpu_base = cpu_baseline(sc, Ir, Ia, host_frames, axes, a.cpu_seconds)
         cpu_base["host_cpus"] = os.cpu_count()
+    if rank == 0 and not a.no_check:
+        k = a.oracle_frames if a.oracle_frames >= 0 else {"A": 32, "B": 32, "D": 8}[a.config]
+        expect = oracle_expect(sc, Ir, Ia, host_frames[:min(k, n_distinct)])
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP path is mandatory; there is no CPU fallback)")
@@ -196,6 +470,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device(dev))
         else:
             dist.init_process_group(a.backend)
+    coll_dev = dev if a.backend == "nccl" else "cpu"
 
     ctx = jrc_amd.Context(local_rank)
     chain = jrc_amd.RadarChain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb, ab, ndr, nda, 15.0, 0.0,
@@ -217,12 +492,15 @@ def main():
 
     def step():
         chain.run(bufs, F)
-        if do_gather:                         # optional exchange step: per-frame result records over RCCL
+        if do_gather or k_maps:
+            # optional exchange step (RCCL / xGMI).  The chain runs on the context's stream, the collective on torch's: both are
+            # drained around it so that the exchange reads finished maps and its cost is part of the step.
             ctx.sync()
-            gathered[0] = shard.gather_results(bufs["results"], world * F)
-        if k_maps:                            # optional exchange step: K maps per rank over RCCL / xGMI
-            ctx.sync()
-            gathered[0] = shard.gather_maps(bufs["map"][:k_maps], world * k_maps)
+            if do_gather:                     # per-frame result records
+                gathered[0] = shard.gather_results(bufs["results"], world * F)
+            if k_maps:                        # K maps per rank
+                gathered[0] = shard.gather_maps(bufs["map"][:k_maps], world * k_maps)
+            torch.cuda.synchronize()
 
     if a.prewarm_seconds > 0:                 # untimed: bring a freshly booted GPU out of its idle power state
         t_pw = time.perf_counter()
@@ -234,45 +512,44 @@ def main():
     ctx.sync()
     torch.cuda.synchronize()
     chain.set_timing(True)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    ctx.sync()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    windows = []
+    for w in range(max(1, a.windows)):        # window 0 is the contract's timed region: exactly K steps between barrier + synchronize
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        ctx.sync()
+        torch.cuda.synchronize()
+        barrier()
+        windows.append(time.perf_counter() - t0)
     kt = chain.get_timing()
     res = chain.results(bufs, F)
 
-    elapsed = shard.max_over_ranks(elapsed, dev if a.backend == "nccl" else "cpu")
+    windows = shard.max_over_ranks_vec(windows, coll_dev)
+    elapsed = windows[0]
 
+    check = None
+    if not a.no_check:
+        check = verify(torch, bufs, bufs["results"], res, F, n_distinct, expect, axes, sc)
+        ok_all = shard.min_over_ranks(1.0 if check["ok"] else 0.0, coll_dev)
+        check["ok_all_ranks"] = bool(ok_all > 0.5)
+
+    if a.dump:
+        ctx.sync()
+        allr = shard.gather_results(bufs["results"], world * F)
+        km = min(a.dump_maps, F)
+        allm = shard.gather_maps(bufs["map"][:km].contiguous(), world * km) if km else None
+        allh = shard.gather_results(bufs["chanest"], world * F)
+        if rank == 0:
+            np.savez(a.dump, results=allr.cpu().numpy(), chanest=allh.cpu().numpy(),
+                     maps=(allm.cpu().numpy() if allm is not None else np.zeros(0, np.float32)))
+
+    rc = 0
     if rank == 0:
         total_frames = F * a.steps * world
         ms_step = 1e3 * elapsed / a.steps
-        # algorithmic bytes of the dominant kernel: unpadded H in, complex map out
-        alg_bytes = F * (P * sc.N * 8 + NR * NA * 8)
-        traffic = None
-        try:   # PMC-measured HBM bytes of the same kernel/config, collected in separate rocprofv3 --pmc passes
-            pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(a.config)
-            if pt and pt["frames_per_launch"] == F:
-                traffic = pt["hbm_bytes_per_launch"]
-        except (OSError, ValueError, KeyError):
-            pass
-        # a batch beyond one resident wave of workgroups runs as several launches of the dominant kernel: roofline per launch
-        n_launch = max(1, chain.launches_per_run(F))
-        f_launch = F // n_launch if F % n_launch == 0 else None
-        k_ms = kt["range_angle_fused"] / n_launch
-        alg_bytes = alg_bytes / n_launch
-        if traffic is None and f_launch is not None:
-            try:
-                pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(a.config)
-                if pt and pt["frames_per_launch"] == f_launch:
-                    traffic = pt["hbm_bytes_per_launch"]
-            except (OSError, ValueError, KeyError):
-                pass
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        per = sorted(1e3 * w / a.steps for w in windows)
         out = {
             "metric": "ofdm_frames_per_sec", "value": total_frames / elapsed, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
@@ -283,24 +560,31 @@ def main():
                                    "range_angle_estimator), %d frames/GPU/step resident in HBM"
                                    % (a.config, sc.T, sc.R, sc.N, sc.S, Ir, Ia, NR, NA, F),
                        "frames_per_gpu_per_step": F, "parallelism": "frame-sharded x%d, no data-path collective" % world,
-                       "gather_results": bool(do_gather), "gather_maps_per_gpu": int(k_maps)},
-            "roofline": {"bound": "hbm", "kernel": "range_angle_fused_kernel<%d>" % P, "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
-                         "avg_launch_ms": k_ms, "launches_timed": kt["launches"] * n_launch,
-                         "launches_per_step": n_launch, "frames_per_launch": F / n_launch},
+                       "gather_results": bool(do_gather), "gather_maps_per_gpu": int(k_maps),
+                       "launcher": "self-launched children" if os.environ.get("JRC_BENCH_CHILD") else ("torch.distributed.run" if world > 1 else "direct")},
+            "windows": {"n": len(per), "steps_each": a.steps, "ms_per_step_median": per[len(per) // 2], "ms_per_step_min": per[0],
+                        "ms_per_step_max": per[-1], "note": "`value` / `ms_per_step` are window 0 (the contract's timed region); max over ranks per window"},
+            "roofline": roofline_of(chain, kt, a.config, sc, Ir, Ia, F),
             "kernels_ms": {k: kt[k] for k in ("radar_chanest", "range_angle_fused", "ra_finalize")},
-            "check": {"range_m": res[0].range_val, "angle_deg": res[0].angle_val, "snr_db": res[0].snr_est},
+            "host_epilogue": "snr_est = 10 log10(peak/noise) and the publish decision of A5 (one log10f per frame) are finished on the host in "
+                             "jrc_chain_fetch_results, after the timed region; everything else of A1..A5 is inside it",
+            "check": dict(check or {}, range_m=res[0].range_val, angle_deg=res[0].angle_val, snr_db=res[0].snr_est),
             "device": ctx.device_name(),
         }
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
         if world == 1 and not a.no_secondary:
-            out["secondary"] = secondary_figures(a.config)
+            chain.set_timing(False)
+            out["secondary"] = secondary_figures(a.config, ctx, sc, axes)
         print(json.dumps(out))
+        sys.stdout.flush()
+    if check is not None and not check.get("ok_all_ranks", check["ok"]):
+        sys.stderr.write("bench.py: result check FAILED on rank %d: %s\n" % (rank, json.dumps(check)))
+        rc = 3
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    sys.exit(rc)
 
 
 if __name__ == "__main__":

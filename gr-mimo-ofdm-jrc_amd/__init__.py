@@ -464,10 +464,17 @@ class RadarChain:
         import torch
         c = self.cfg
         dev = bufs["frames"].device
-        work = torch.empty((n_frames, self.P, c.N_sym, self.NR, 2), dtype=torch.float32, device=dev)
+        # the work buffer stays with the object: the kernels run on the context's stream (or `stream`), which torch's caching
+        # allocator does not know about, so a temporary could be handed out again while they still use it
+        key = (n_frames, str(dev))
+        if getattr(self, "_rd_work_key", None) != key:
+            self._rd_work = torch.empty((n_frames, self.P, c.N_sym, self.NR, 2), dtype=torch.float32, device=dev)
+            self._rd_work_key = key
         out = torch.empty((n_frames, self.P, self.NR, c.N_sym * interp_doppler, 2), dtype=torch.float32, device=dev)
         self.ctx.check(self.ctx.lib.jrc_range_doppler_dev(self.ctx.h, C.byref(self.cfg), interp_doppler, n_frames,
-                                                         bufs["frames"].data_ptr(), work.data_ptr(), out.data_ptr(), stream))
+                                                         bufs["frames"].data_ptr(), self._rd_work.data_ptr(), out.data_ptr(), stream))
+        if stream is None:
+            self.ctx.sync()               # `out` is complete on return; with an explicit stream the caller orders its own use
         return out
 
     def launches_per_run(self, n_frames):

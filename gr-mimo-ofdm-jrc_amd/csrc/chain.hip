@@ -350,6 +350,7 @@ extern "C" int jrc_chain_create(jrc_ctx* ctx, const jrc_chain_cfg* cfg, const fl
 extern "C" void jrc_chain_destroy(jrc_chain* ch)
 {
     if (!ch) return;
+    (void)hipSetDevice(ch->ctx->device);
     (void)hipDeviceSynchronize();
     for (auto& e : ch->ev) (void)hipEventDestroy(e);
     if (ch->d_bins) (void)hipFree(ch->d_bins);
@@ -382,6 +383,7 @@ extern "C" int jrc_chain_set_timing(jrc_chain* ch, int enabled)
 {
     if (!ch) return JRC_ERR_INVALID_ARG;
     jrc_ctx* ctx = ch->ctx;
+    JRC_BIND(ctx);
     if (enabled && ch->ev.empty()) {
         ch->ev.resize((size_t)jrc_chain::kPool * 4);
         for (auto& e : ch->ev) JRC_HIP(ctx, hipEventCreate(&e));
@@ -395,6 +397,7 @@ extern "C" int jrc_chain_set_timing(jrc_chain* ch, int enabled)
 static int chain_drain_events(jrc_chain* ch)
 {
     jrc_ctx* ctx = ch->ctx;
+    JRC_BIND(ctx);
     for (int i = 0; i < ch->ev_used; i++) {
         hipEvent_t* e = &ch->ev[(size_t)i * 4];
         JRC_HIP(ctx, hipEventSynchronize(e[3]));
@@ -426,6 +429,7 @@ static int chain_run(jrc_chain* ch, int n_frames, const jrc_cf32* d_frames, cons
     jrc_ctx* ctx = ch->ctx;
     if (n_frames <= 0 || n_frames > ch->max_frames)
         return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_run_dev: n_frames %d outside (0, %d]", n_frames, ch->max_frames);
+    JRC_BIND(ctx);
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     const jrc_chain_cfg& c = ch->cfg;
     if (!d_frames && (cp_len < 0 || rx_stream_len < (long)c.n_items * (c.fft_len + cp_len)))
@@ -522,6 +526,7 @@ extern "C" int jrc_chain_fetch_results(jrc_chain* ch, int n_frames, const jrc_ra
     if (!ch || !d_results || !h_results) return JRC_ERR_INVALID_ARG;
     jrc_ctx* ctx = ch->ctx;
     if (n_frames <= 0 || n_frames > ch->max_frames) return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_fetch_results: bad n_frames");
+    JRC_BIND(ctx);
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     JRC_HIP(ctx, hipMemcpyAsync(ch->h_pinned, d_results, sizeof(jrc_ra_result) * (size_t)n_frames, hipMemcpyDeviceToHost, s));
     JRC_HIP(ctx, hipStreamSynchronize(s));
@@ -569,11 +574,12 @@ __global__ void rd_product_pad_kernel(const float2* __restrict__ frames, float2*
 // at a time) for a tile of 16 Doppler bins held in LDS, and streams the [range][Doppler] map out once, non-temporally.
 #define RD_DT 16   // Doppler bins per workgroup tile (= one 128-byte segment of an output row)
 
-__global__ __launch_bounds__(256) void rd_product_t_kernel(const float2* __restrict__ frames, float2* __restrict__ Dt, ChanestGeom g, int T, int R, int ND)
+__global__ __launch_bounds__(256) void rd_product_t_kernel(const float2* __restrict__ frames, float2* __restrict__ Dt, ChanestGeom g, int T, int R, int ND,
+                                                           size_t z0)
 {
     __shared__ float2 tile[64][65];
     const int P = T * R;
-    const size_t fp = blockIdx.z;
+    const size_t fp = z0 + blockIdx.z;
     const int p = (int)(fp % P);
     const size_t f = fp / P;
     const int r = g.interleave ? p % R : p / T, t = g.interleave ? p / R : p % T;
@@ -936,6 +942,7 @@ extern "C" int jrc_range_doppler_dev(jrc_ctx* ctx, const jrc_chain_cfg* c, int i
     auto size_ok = [](long n) { return n >= 1 && (jrc_is_pow2(n) ? n <= 16384 : n <= 4096); };
     if (!size_ok(NR) || !size_ok(ND) || c->n_items < c->N_pre + S)
         return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "range-Doppler: fft_len*interp_range and N_sym*interp_doppler must be <= 16384 (powers of two) or <= 4096");
+    JRC_BIND(ctx);
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     ChanestGeom g;
     g.N = N; g.S = S; g.port_stride = (long)c->n_items * N; g.frame_stride = g.port_stride * (T + R);
@@ -944,8 +951,11 @@ extern "C" int jrc_range_doppler_dev(jrc_ctx* ctx, const jrc_chain_cfg* c, int i
     if (jrc_is_pow2(N) && N >= RA_L && N <= 1024 && jrc_is_pow2(NR) && NR >= RA_L && jrc_is_pow2(ND) && ND >= RD_DT && ND <= 8192 &&
         interp_doppler <= c->interp_range && ((reinterpret_cast<size_t>(d_work) & 15) == 0) && !ctx->tune.rd_generic) {
         const size_t fp = (size_t)n_frames * P;
-        hipLaunchKernelGGL(rd_product_t_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((ND + 63) / 64), (unsigned)fp), dim3(256), 0, s,
-                           (const float2*)d_frames, (float2*)d_work, g, T, R, (int)ND);
+        for (size_t z0 = 0; z0 < fp; z0 += 65535) {      // gridDim.z (frame, pair) is limited to 65535: chunks
+            const size_t nz = fp - z0 < 65535 ? fp - z0 : 65535;
+            hipLaunchKernelGGL(rd_product_t_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((ND + 63) / 64), (unsigned)nz), dim3(256), 0, s,
+                               (const float2*)d_frames, (float2*)d_work, g, T, R, (int)ND, z0);
+        }
         JRC_HIP(ctx, hipGetLastError());
         JRC_TRY(launch_fft_vcc(ctx, (int)ND, 1, 1, nullptr, fp * N, (const float2*)d_work, (float2*)d_work, ND, 0, s));        // Doppler
         const float2* twR = nullptr;

@@ -575,6 +575,7 @@ extern "C" int jrc_stream_encode_dev(jrc_ctx* ctx, int mcs, int n_data_carriers,
         return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "stream_encoder: invalid arguments");
     if (n_frames == 0) return JRC_OK;
     JRC_HIP(ctx, hipSetDevice(ctx->device));
+    JRC_BIND(ctx);
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     const size_t lds = (size_t)CODEC_MAX_DATA_BITS;
     hipLaunchKernelGGL(stream_encode_kernel, dim3(n_frames), dim3(256), lds, s, mcs, n_data_carriers, d_psdu, psdu_stride, d_len,
@@ -593,6 +594,7 @@ extern "C" int jrc_stream_decode_dev(jrc_ctx* ctx, int n_data_carriers, int n_fr
         return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "stream_decoder: invalid arguments");
     if (n_frames == 0) return JRC_OK;
     JRC_HIP(ctx, hipSetDevice(ctx->device));
+    JRC_BIND(ctx);
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     // few frames: one per wave (the decoder is a latency chain; twice the waves, each with the shorter chain); many: two per wave
     int nq = ctx->tune.dec_frames_per_wave;

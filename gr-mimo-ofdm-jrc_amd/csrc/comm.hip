@@ -786,6 +786,7 @@ static void launch_equalizer(jrc_equalizer* eq, int grid, hipStream_t s, const E
 extern "C" void jrc_equalizer_destroy(jrc_equalizer* eq)
 {
     if (!eq) return;
+    (void)hipSetDevice(eq->ctx->device);
     (void)hipStreamSynchronize(eq->ctx->stream);
     if (eq->tables) (void)hipFree(eq->tables);
     if (eq->states) (void)hipFree(eq->states);
@@ -873,6 +874,7 @@ extern "C" int jrc_equalizer_frames_dev(jrc_equalizer* eq, int n_streams, int n_
     jrc_ctx* ctx = eq->ctx;
     if (n_streams <= 0 || n_streams > eq->n_streams || n_symbols <= 0 || max_out <= 0)
         return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_equalizer_frames_dev: bad sizes");
+    JRC_BIND(ctx);
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     EqIo io;
     io.in = (const float2*)d_in; io.in_stride = (long)n_symbols * eq->d.N; io.ninput = n_symbols;
@@ -1234,6 +1236,7 @@ extern "C" int jrc_precoder_create(jrc_ctx* ctx, const jrc_pre_cfg* c, jrc_preco
 extern "C" void jrc_precoder_destroy(jrc_precoder* p)
 {
     if (!p) return;
+    (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
     if (p->tables) (void)hipFree(p->tables);
     if (p->d_sig) (void)hipFree(p->d_sig);
@@ -1313,6 +1316,7 @@ extern "C" int jrc_precoder_frames_dev(jrc_precoder* p, int n_frames, int ninput
         return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "mimo_precoder: steering matrices missing for steer_mode %d", steer_mode);
     if (n_frames == 0) return 0;
     JRC_HIP(ctx, hipSetDevice(ctx->device));
+    JRC_BIND(ctx);
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     if (!p->d_sig) {
         JRC_HIP(ctx, hipMalloc((void**)&p->d_sig, sizeof(float) * (size_t)d.ND));
@@ -1381,6 +1385,7 @@ struct jrc_frame_generator {
 extern "C" void jrc_frame_generator_destroy(jrc_frame_generator* g)
 {
     if (!g) return;
+    (void)hipSetDevice(g->ctx->device);
     (void)hipStreamSynchronize(g->ctx->stream);
     (void)hipFree(g->d_occ_off); (void)hipFree(g->d_occ_flat); (void)hipFree(g->d_pil_off); (void)hipFree(g->d_pil_flat);
     (void)hipFree(g->d_psym_off); (void)hipFree(g->d_psym); (void)hipFree(g->d_sync);
@@ -1465,6 +1470,7 @@ extern "C" int jrc_frame_generator_dev(jrc_frame_generator* g, int n_packets, in
     const int nout = jrc_frame_generator_output_length(g, ninput_items);
     if (n_packets == 0) return nout;
     if ((ninput_items > 0 && !d_in) || !d_out) return jrc_fail(g->ctx, JRC_ERR_INVALID_ARG, "ofdm_frame_generator: null buffers");
+    JRC_BIND(g->ctx);
     hipStream_t s = stream ? (hipStream_t)stream : g->ctx->stream;
     hipLaunchKernelGGL(frame_generator_kernel, dim3(n_packets), dim3(256), 0, s, g->N, g->n_occ_sets, (const int*)g->d_occ_off, (const int*)g->d_occ_flat,
                        g->n_pil_sets, (const int*)g->d_pil_off, (const int*)g->d_pil_flat, g->n_psym_sets, (const int*)g->d_psym_off,

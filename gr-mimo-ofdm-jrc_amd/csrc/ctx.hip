@@ -104,6 +104,7 @@ extern "C" int jrc_device_name(const jrc_ctx* ctx, char* buf, size_t len)
 extern "C" int jrc_sync(jrc_ctx* ctx)
 {
     if (!ctx) return JRC_ERR_INVALID_ARG;
+    JRC_BIND(ctx);
     JRC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return JRC_OK;
 }
@@ -123,6 +124,7 @@ extern "C" int jrc_dev_malloc(jrc_ctx* ctx, size_t bytes, void** dptr)
 extern "C" int jrc_dev_free(jrc_ctx* ctx, void* dptr)
 {
     if (!ctx) return JRC_ERR_INVALID_ARG;
+    JRC_BIND(ctx);
     if (dptr) JRC_HIP(ctx, hipFree(dptr));
     return JRC_OK;
 }
@@ -130,6 +132,7 @@ extern "C" int jrc_dev_free(jrc_ctx* ctx, void* dptr)
 extern "C" int jrc_dev_memset(jrc_ctx* ctx, void* dptr, int value, size_t bytes)
 {
     if (!ctx) return JRC_ERR_INVALID_ARG;
+    JRC_BIND(ctx);
     JRC_HIP(ctx, hipMemsetAsync(dptr, value, bytes, ctx->stream));
     JRC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return JRC_OK;
@@ -138,6 +141,7 @@ extern "C" int jrc_dev_memset(jrc_ctx* ctx, void* dptr, int value, size_t bytes)
 extern "C" int jrc_memcpy_h2d(jrc_ctx* ctx, void* dptr, const void* hptr, size_t bytes)
 {
     if (!ctx) return JRC_ERR_INVALID_ARG;
+    JRC_BIND(ctx);
     JRC_HIP(ctx, hipMemcpyAsync(dptr, hptr, bytes, hipMemcpyHostToDevice, ctx->stream));
     JRC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return JRC_OK;
@@ -146,6 +150,7 @@ extern "C" int jrc_memcpy_h2d(jrc_ctx* ctx, void* dptr, const void* hptr, size_t
 extern "C" int jrc_memcpy_d2h(jrc_ctx* ctx, void* hptr, const void* dptr, size_t bytes)
 {
     if (!ctx) return JRC_ERR_INVALID_ARG;
+    JRC_BIND(ctx);
     JRC_HIP(ctx, hipMemcpyAsync(hptr, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
     JRC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return JRC_OK;

@@ -202,6 +202,7 @@ extern "C" int jrc_chain_feed_collect(jrc_chain_feed* fd, jrc_ra_result* results
     JRC_TRACE("jrc_chain_feed_collect");
     if (!fd || !results) return JRC_ERR_INVALID_ARG;
     jrc_ctx* ctx = fd->ctx;
+    JRC_BIND(ctx);
     if (fd->in_flight == 0) { if (n_frames) *n_frames = 0; return 0; }
     feed_slot& s = fd->slots[(size_t)fd->tail];
     JRC_HIP(ctx, hipEventSynchronize(s.done));

@@ -273,6 +273,7 @@ extern "C" int jrc_fft_vcc_dev(jrc_ctx* ctx, int fft_size, int forward, int shif
                                size_t batch, const jrc_cf32* d_in, jrc_cf32* d_out, void* stream)
 {
     if (!ctx || !d_in || !d_out) return JRC_ERR_INVALID_ARG;
+    JRC_BIND(ctx);
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     return launch_fft_vcc(ctx, fft_size, forward, shift, d_window, batch, (const float2*)d_in, (float2*)d_out,
                           fft_size, 0, s);
@@ -353,11 +354,16 @@ extern "C" int jrc_matrix_transpose_dev(jrc_ctx* ctx, int input_len, int output_
     if (!ctx || !d_in || !d_out) return JRC_ERR_INVALID_ARG;
     JRC_TRY(transpose_check(ctx, input_len, output_len, interp_factor, ninput_items));
     if (batch == 0) return input_len;
+    JRC_BIND(ctx);
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     const int W = output_len * interp_factor;
-    dim3 grid((input_len + 63) / 64, (W + 63) / 64, (unsigned)batch);
-    hipLaunchKernelGGL(transpose_pad_kernel, grid, dim3(256), 0, s, (const float2*)d_in, (float2*)d_out, input_len,
-                       ninput_items, W);
+    // gridDim.z carries the batch and is limited to 65535: larger batches go in chunks
+    for (size_t b0 = 0; b0 < batch; b0 += 65535) {
+        const size_t nb = batch - b0 < 65535 ? batch - b0 : 65535;
+        dim3 grid((input_len + 63) / 64, (W + 63) / 64, (unsigned)nb);
+        hipLaunchKernelGGL(transpose_pad_kernel, grid, dim3(256), 0, s, (const float2*)d_in + b0 * (size_t)ninput_items * input_len,
+                           (float2*)d_out + b0 * (size_t)input_len * W, input_len, ninput_items, W);
+    }
     JRC_HIP(ctx, hipGetLastError());
     return input_len;
 }
@@ -430,6 +436,7 @@ extern "C" int jrc_cp_remove_fft_dev(jrc_ctx* ctx, int fft_len, int cp_len, size
 {
     if (!ctx || !d_in || !d_out) return JRC_ERR_INVALID_ARG;
     if (cp_len < 0) return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "cp_remover: bad cp_len");
+    JRC_BIND(ctx);
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     JRC_TRY(launch_fft_vcc(ctx, fft_len, 1, 1, nullptr, n_symbols, (const float2*)d_in, (float2*)d_out,
                            (long)fft_len + cp_len, cp_len, s));
@@ -469,6 +476,7 @@ extern "C" int jrc_ofdm_mod_dev(jrc_ctx* ctx, int fft_len, int cp_len, const flo
 {
     if (!ctx || !d_in || !d_out) return JRC_ERR_INVALID_ARG;
     if (cp_len < 0 || cp_len > fft_len) return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "ofdm_mod: bad cp_len");
+    JRC_BIND(ctx);
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     JRC_TRY(launch_fft_vcc_ex(ctx, fft_len, 0, 1, d_window, n_symbols, (const float2*)d_in, (float2*)d_out, fft_len, 0,
                               (long)fft_len + cp_len, cp_len, s));

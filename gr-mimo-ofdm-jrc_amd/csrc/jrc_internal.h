@@ -80,6 +80,10 @@ struct jrc_trace_range {
                             hipGetErrorString(_e), __FILE__, __LINE__);                         \
     } while (0)
 
+// hipSetDevice is per host thread (GNU Radio runs one thread per block, and a process may hold contexts on several GPUs): every
+// entry point that allocates, copies or launches binds the calling thread to its context's GPU first
+#define JRC_BIND(ctx) JRC_HIP((ctx), hipSetDevice((ctx)->device))
+
 #define JRC_TRY(expr)                       \
     do {                                    \
         int _s = (expr);                    \

@@ -463,6 +463,7 @@ extern "C" int jrc_radar_create(jrc_ctx* ctx, int fft_len, int N_tx, int N_rx, i
 extern "C" void jrc_radar_destroy(jrc_radar* r)
 {
     if (!r) return;
+    (void)hipSetDevice(r->ctx->device);
     (void)hipStreamSynchronize(r->ctx->stream);
     if (r->d_in) (void)hipFree(r->d_in);
     if (r->d_est) (void)hipFree(r->d_est);
@@ -546,6 +547,7 @@ extern "C" int jrc_radar_chanest_dev(jrc_ctx* ctx, int fft_len, int N_tx, int N_
     if (!ctx || !d_frames || !d_chanest) return JRC_ERR_INVALID_ARG;
     if (fft_len <= 0 || N_tx <= 0 || N_rx <= 0 || N_sym < 0 || N_pre < 0 || n_items < N_pre + N_sym || n_frames < 0)
         return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_radar_chanest_dev: inconsistent sizes");
+    JRC_BIND(ctx);
     ChanestGeom g;
     g.N = fft_len; g.S = N_sym; g.port_stride = (long)n_items * fft_len; g.frame_stride = g.port_stride * (N_tx + N_rx);
     g.tx_item0 = N_pre; g.rx_item0 = N_pre; g.interleave = enable_tx_interleave;
@@ -562,6 +564,7 @@ extern "C" int jrc_radar_chanest_td_dev(jrc_ctx* ctx, int fft_len, int cp_len, i
     if (fft_len <= 0 || cp_len < 0 || N_tx <= 0 || N_rx <= 0 || N_sym < 0 || N_pre < 0 || n_items < N_pre + N_sym || n_frames < 0 ||
         rx_stream_len < (long)n_items * (fft_len + cp_len))
         return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_radar_chanest_td_dev: inconsistent sizes");
+    JRC_BIND(ctx);
     DemodGeom g;
     g.N = fft_len; g.cp = cp_len; g.S = N_sym; g.R = N_rx; g.logn = 0;
     g.tx_port_stride = (long)n_items * fft_len; g.tx_frame_stride = g.tx_port_stride * N_tx;

@@ -34,6 +34,7 @@ extern "C" int jrc_moving_avg_dev(jrc_ctx* ctx, int length, float scale, int n_o
 {
     if (!ctx || length < 1 || n_out < 0 || (n_out > 0 && (!d_in || !d_out))) return JRC_ERR_INVALID_ARG;
     if (n_out == 0) return 0;
+    JRC_BIND(ctx);
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     hipLaunchKernelGGL(moving_avg_kernel, dim3((n_out + 255) / 256), dim3(256), 0, s, (const float2*)d_in, (float2*)d_out, length, scale, n_out);
     JRC_HIP(ctx, hipGetLastError());
@@ -162,6 +163,7 @@ extern "C" int jrc_sync_metrics_dev(jrc_ctx* ctx, int n, int delay, int window, 
 {
     if (!ctx || n < 0 || delay < 0 || window < 1 || pwindow < 1 || (n > 0 && (!d_x || !d_xd || !d_in_abs || !d_in_cor))) return JRC_ERR_INVALID_ARG;
     if (n == 0) return JRC_OK;
+    JRC_BIND(ctx);
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     const size_t L = (size_t)SM_TILE + (size_t)(window > pwindow ? window : pwindow) - 1 + (size_t)delay;
     const size_t lds = L * (3 * sizeof(float2) + 3 * sizeof(float));
@@ -334,6 +336,7 @@ extern "C" jrc_frame_detector* jrc_frame_detector_create(jrc_ctx* ctx, int fft_l
 extern "C" void jrc_frame_detector_destroy(jrc_frame_detector* d)
 {
     if (!d) return;
+    (void)hipSetDevice(d->ctx->device);
     (void)hipStreamSynchronize(d->ctx->stream);
     (void)hipFree(d->d_state); (void)hipFree(d->d_res); (void)hipHostFree(d->h_res);
     delete d;
@@ -538,6 +541,7 @@ extern "C" jrc_frame_sync* jrc_frame_sync_create(jrc_ctx* ctx, int fft_len, int 
 extern "C" void jrc_frame_sync_destroy(jrc_frame_sync* f)
 {
     if (!f) return;
+    (void)hipSetDevice(f->ctx->device);
     (void)hipStreamSynchronize(f->ctx->stream);
     (void)hipFree(f->d_taps); (void)hipFree(f->d_res); (void)hipHostFree(f->h_res);
     delete f;
@@ -1042,6 +1046,7 @@ extern "C" int jrc_sync_frontend_dev(jrc_ctx* ctx, const jrc_sync_cfg* c, int n_
         c->power_window < 1)
         return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "sync front end: invalid configuration");
     static_assert(sizeof(jrc_sync_frame) == sizeof(SfFrame), "jrc_sync_frame layout");
+    JRC_BIND(ctx);
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     const size_t n = (size_t)n_samples;
     float2* d_xd = (float2*)d_work;
@@ -1068,6 +1073,7 @@ extern "C" int jrc_frame_detector_scan_dev(jrc_ctx* ctx, int fft_len, int cp_len
                                            int max_frames, jrc_sync_frame* d_info, int* d_n_frames, void* stream)
 {
     if (!ctx || n_samples < 0 || max_frames < 1 || !d_in_abs || !d_in_cor || !d_marks || !d_info || !d_n_frames) return JRC_ERR_INVALID_ARG;
+    JRC_BIND(ctx);
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     FdParams p;
     p.fft_len = fft_len; p.min_n_peaks = (int)min_n_peaks; p.ignore_gap = (int)ignore_gap; p.threshold = threshold; p.max_peak_value = 2.0;

@@ -659,6 +659,7 @@ extern "C" void jrc_tsim_destroy(jrc_tsim* h)
 {
     if (!h) return;
     (void)hipSetDevice(h->ctx->device);
+    (void)hipSetDevice(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
     tsim_free_tables(h);
     (void)hipFree(h->d_u); (void)hipFree(h->d_g); (void)hipFree(h->d_phase);
@@ -677,6 +678,7 @@ extern "C" int jrc_tsim_run_dev(jrc_tsim* h, int n_bursts, int n_input, const jr
         return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "target_simulator: %d bursts exceed max_bursts %d", n_bursts, h->max_bursts);
     if (n_bursts == 0 || n_input == 0) return JRC_OK;
     JRC_HIP(ctx, hipSetDevice(ctx->device));
+    JRC_BIND(ctx);
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     const int n = n_input, K = h->K, R = h->R;
     const float2* in = (const float2*)d_in;
@@ -803,6 +805,7 @@ extern "C" int jrc_zero_pad_dev(jrc_ctx* ctx, int n_bursts, int n_input, unsigne
     const long n_out = (long)n_input + pad_front + pad_tail;
     if (n_bursts == 0 || n_out == 0) return (int)n_out;
     if ((n_input > 0 && !d_in) || !d_out) return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "zero_pad: null buffers");
+    JRC_BIND(ctx);
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     hipLaunchKernelGGL(zero_pad_kernel, dim3((unsigned)((n_out + 255) / 256), n_bursts), dim3(256), 0, s, (const float2*)d_in, (float2*)d_out,
                        n_input, (int)pad_front, (int)pad_tail, (unsigned long long)seed, 1e-2f, (long)n_input, n_out);

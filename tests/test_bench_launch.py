@@ -1,0 +1,88 @@
+"""bench.py's N>1 launch path (BASELINE.json config 5: frame stream sharded over GPUs).
+
+CPU tier: `python bench.py --gpus N` without WORLD_SIZE starts its ranks itself; without a GPU every rank refuses to run
+(there is no CPU fallback) and the parent must relay that as a non-zero exit, with no JSON line and without hanging.
+GPU tier: two ranks on the one GPU of the box (--same-device, gloo) go through the whole multi-rank path — process group,
+frame shards, barriers, MAX-reduce of the timings, all-gather of results and maps — and every frame must come out bit for bit
+as in a single-rank run of the same frame stream."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, timeout=600, env=None):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, timeout=timeout, env=e, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, lines
+
+
+def test_self_launch_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-tier check of the failure path")
+    r, lines = _run(["--gpus", "2", "--config", "A", "--frames", "8", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-secondary",
+                     "--no-check"], timeout=300)
+    assert r.returncode != 0
+    assert not lines                                   # no result line from a run that did not happen
+    assert "needs a GPU" in r.stderr
+
+
+def test_argument_surface():
+    sys.path.insert(0, ROOT)
+    import bench
+    a = bench.parse(["--gpus", "4", "--steps", "7", "--warmup", "2"])
+    assert (a.gpus, a.steps, a.warmup, a.config) == (4, 7, 2, "B")
+    a = bench.parse([])
+    assert a.gpus == 1 and a.windows >= 5
+
+
+COMMON = ["--config", "A", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-secondary", "--windows", "2", "--prewarm-seconds", "0"]
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path):
+    F = 48
+    one = str(tmp_path / "one.npz")
+    two = str(tmp_path / "two.npz")
+    r1, l1 = _run(COMMON + ["--frames", str(2 * F), "--distinct", str(2 * F), "--dump", one, "--dump-maps", str(2 * F), "--oracle-frames", "4"])
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    j1 = json.loads(l1[-1])
+    assert j1["n_gpus"] == 1 and j1["check"]["ok"] and j1["config"]["launcher"] == "direct"
+    r2, l2 = _run(COMMON + ["--gpus", "2", "--same-device", "--backend", "gloo", "--frames", str(F), "--distinct", str(F), "--dump", two,
+                            "--dump-maps", "3", "--oracle-frames", "4", "--gather-results", "--gather-maps", "2"])
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    assert len(l2) == 1                                # ONE JSON line, from rank 0
+    j2 = json.loads(l2[-1])
+    assert j2["n_gpus"] == 2 and j2["scaling"] == "weak" and j2["check"]["ok"] and j2["check"]["ok_all_ranks"]
+    assert j2["config"]["launcher"] == "self-launched children" and j2["config"]["gather_results"] and j2["config"]["gather_maps_per_gpu"] == 2
+    assert j2["value"] > 0 and abs(j2["value"] - 2 * F * 3 / (j2["ms_per_step"] * 3e-3)) < 1e-6 * j2["value"]
+    a, b = np.load(one), np.load(two)
+    # rank 0 owns frames [0, F), rank 1 frames [F, 2F) of the same seeded stream: gathered in frame order
+    assert np.array_equal(a["results"], b["results"])
+    assert np.array_equal(a["chanest"], b["chanest"])
+    want_maps = np.concatenate([a["maps"][0:3], a["maps"][F:F + 3]])
+    assert np.array_equal(want_maps, b["maps"])
+
+
+@pytest.mark.gpu
+def test_self_launched_single_rank_matches_direct():
+    args = ["--config", "B", "--frames", "512", "--steps", "30", "--warmup", "3", "--no-cpu-baseline", "--no-secondary", "--oracle-frames", "2"]
+    rd, ld = _run(args)
+    rs, ls = _run(args + ["--spawn"])
+    assert rd.returncode == 0 and rs.returncode == 0, (rd.stderr[-1500:], rs.stderr[-1500:])
+    jd, js = json.loads(ld[-1]), json.loads(ls[-1])
+    assert jd["config"]["launcher"] == "direct" and js["config"]["launcher"] == "self-launched children"
+    assert js["check"]["ok"] and jd["check"]["ok"]
+    md, ms = jd["windows"]["ms_per_step_median"], js["windows"]["ms_per_step_median"]
+    assert abs(md - ms) / md < 0.05, (md, ms)          # same work per step whichever way the rank was started

@@ -442,3 +442,57 @@ def test_time_domain_entry_refuses_shapes_outside_the_fused_kernel(jrc, ctx):
         st = ctx.lib.jrc_radar_chanest_td_dev(ctx.h, N, cp, T, R, 2, 1, n_items, L, 0, 1, d_tx.data_ptr(), d_rx.data_ptr(), H.data_ptr(), None)
         assert st == jrc.JRC_ERR_UNSUPPORTED
         assert b"jrc_cp_remove_fft_dev" in ctx.lib.jrc_last_error(ctx.h)
+
+
+@pytest.mark.parametrize("cfg,F,nd", [("B", 512, 16), ("D", 256, 8)])
+def test_chain_at_the_benchmarked_launch_geometry(jrc, ctx, cfg, F, nd):
+    """bench.py's launches: config B at 512 frames per launch (one slice per frame: every workgroup walks all classes of its
+    frame) and config D at 256 (one 512-thread workgroup per CU).  Sampled frames — first / last of an XCD group of eight,
+    first / last of the batch, the middle — against the oracle chain (A1 bit-exact, map <= MAP_TOL, A5 fields exact), and EVERY
+    frame of the batch bit-identical in all three outputs to the same frame run alone (a launch of one frame, 32 slices)."""
+    import ctypes
+    import torch
+    from jrc_amd import synth
+    sc = {"B": synth.config_B, "D": synth.config_D}[cfg]()
+    Ir, Ia, P = 8, 16, sc.T * sc.R
+    distinct = synth.make_frames(sc, nd)
+    rb, ab = jrc.radar_axes(sc.N, sc.fs, Ir, P, Ia)
+    ndr, nda = 2 * 3e8 / (2 * sc.fs), 2 * float(np.rad2deg(np.arcsin(2 / P)))
+    chain = jrc.RadarChain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb, ab, ndr, nda, 15.0, 0.0, max_frames=F, ctx=ctx)
+    assert chain.launches_per_run(F) == 1
+    bufs = chain.alloc(F, "cuda:0")
+    which = [(f + f // nd) % nd for f in range(F)]                  # distinct frame held by batch position f
+    hd = torch.from_numpy(distinct.view(np.float32).reshape((nd,) + tuple(bufs["frames"].shape[1:]))).to("cuda:0")
+    bufs["frames"].copy_(hd[torch.tensor(which, device="cuda:0")])
+    bufs["map"].fill_(float("nan"))
+    torch.cuda.synchronize()
+    chain.run(bufs, F)
+    res = chain.results(bufs, F)
+    rec = [ctypes.string_at(ctypes.byref(r), ctypes.sizeof(r)) for r in res]
+    assert not torch.isnan(bufs["map"]).any()
+
+    # every frame == the same frame run alone
+    one = jrc.RadarChain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb, ab, ndr, nda, 15.0, 0.0, max_frames=1, ctx=ctx)
+    b1 = one.alloc(1, "cuda:0")
+    alone = []
+    for d in range(nd):
+        b1["frames"].copy_(hd[d:d + 1])
+        torch.cuda.synchronize()
+        one.run(b1, 1)
+        r1 = one.results(b1, 1)[0]
+        alone.append((b1["chanest"][0].clone(), b1["map"][0].clone(), ctypes.string_at(ctypes.byref(r1), ctypes.sizeof(r1))))
+    for f in range(F):
+        H1, m1, r1 = alone[which[f]]
+        assert torch.equal(bufs["chanest"][f], H1), f
+        assert torch.equal(bufs["map"][f], m1), f
+        assert rec[f] == r1, f
+
+    # sampled positions against the oracle
+    for f in sorted({0, 7, 8, 15, F // 2 - 1, F // 2, F - 8, F - 1}):
+        H, m = oracle_chain(sc, Ir, Ia, distinct[which[f]])
+        gH = bufs["chanest"][f].cpu().numpy().view(np.complex64)[..., 0]
+        gm = bufs["map"][f].cpu().numpy().view(np.complex64)[..., 0]
+        assert np.array_equal(gH, H[:, :sc.N])
+        assert rel_err(gm, m) < FFT_TOL < MAP_TOL
+        o = oracle.ra_estimate(gm, rb, ab, ndr, nda, 15.0, 0.0)
+        assert rec[f] == ctypes.string_at(ctypes.byref(o), ctypes.sizeof(o))

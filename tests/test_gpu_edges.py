@@ -83,3 +83,41 @@ def test_largest_supported_transform_and_map(jrc, ctx):
     rb, ab = jrc.radar_axes(1024, 125e6, 8, 16, 16)
     g = jrc.range_angle_estimator(256, rb, ab, 2.4, 14.36, 15.0, 0.0, ctx=ctx).work(m)
     assert (g.peak_range_idx, g.peak_angle_idx) == (8191, 255)
+
+
+def test_entry_points_bind_their_context_from_any_thread(jrc, ctx):
+    """GNU Radio calls every block from its own thread, and hipSetDevice is per thread: the device-resident entry points bind the
+    context's GPU themselves.  A chain created in this thread runs from a fresh thread, and after a second context was created,
+    with the same results bit for bit."""
+    import threading
+    import torch
+    from jrc_amd import synth
+    sc = synth.Scenario(64, 2, 2, 4, targets=[(9.0, 15.0, 0.0, 60.0)])
+    F, Ir, Ia, P = 5, 4, 8, 4
+    rb, ab = jrc.radar_axes(sc.N, sc.fs, Ir, P, Ia)
+    chain = jrc.RadarChain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb, ab, 2.4, 29.0, max_frames=F, ctx=ctx)
+    bufs = chain.alloc(F, "cuda:0")
+    fr = synth.make_frames(sc, F)
+    bufs["frames"].copy_(torch.from_numpy(fr.view(np.float32).reshape(bufs["frames"].shape)))
+    torch.cuda.synchronize()
+    chain.run(bufs, F)
+    ctx.sync()
+    want = (bufs["chanest"].clone(), bufs["map"].clone(), bufs["results"].clone())
+    other = jrc.Context(jrc._device_count() - 1)           # the last GPU of the box (GPU 0 again on a one-GPU box)
+    other.sync()
+    err = []
+
+    def worker():
+        try:
+            bufs["map"].zero_()
+            torch.cuda.synchronize()
+            chain.run(bufs, F)
+            ctx.sync()
+        except Exception as e:              # pragma: no cover
+            err.append(e)
+    t = threading.Thread(target=worker)
+    t.start()
+    t.join()
+    assert not err
+    assert torch.equal(bufs["chanest"], want[0]) and torch.equal(bufs["map"], want[1]) and torch.equal(bufs["results"], want[2])
+    other.close()
