@@ -138,6 +138,13 @@ def load(build_if_missing=False):
     L.jrc_chain_feed_pending.argtypes = [_vp]
     L.jrc_chain_feed_stats.argtypes = [_vp, C.POINTER(C.c_long), C.POINTER(C.c_long)]
     L.jrc_chain_get_timing.argtypes = [_vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    L.jrc_chain_set_background.argtypes = [_vp, C.c_int, C.c_int, C.c_int]
+    L.jrc_chain_share_background.argtypes = [_vp, _vp]
+    L.jrc_chain_background_size.argtypes = [_vp]
+    L.jrc_chain_prime_background_dev.argtypes = [_vp, C.c_int, _vp, _vp]
+    L.jrc_chain_set_write_map.argtypes = [_vp, C.c_int]
+    L.jrc_chain_feed_set_background.argtypes = [_vp, C.c_int, C.c_int, C.c_int]
+    L.jrc_chain_feed_set_write_map.argtypes = [_vp, C.c_int]
     _lib = L
     return L
 
@@ -429,29 +436,56 @@ class RadarChain:
         c = self.cfg
         return (c.N_tx + c.N_rx, c.n_items, c.fft_len)
 
-    def alloc(self, n_frames, device):
-        """device buffers as torch tensors (complex64 viewed as float32 pairs)"""
+    def alloc(self, n_frames, device, with_map=True):
+        """device buffers as torch tensors (complex64 viewed as float32 pairs); with_map=False for detect-only mode"""
         import torch
         c = self.cfg
         return dict(
             frames=torch.empty((n_frames, c.N_tx + c.N_rx, c.n_items, c.fft_len, 2), dtype=torch.float32, device=device),
             chanest=torch.empty((n_frames, self.P, c.fft_len, 2), dtype=torch.float32, device=device),
-            map=torch.empty((n_frames, self.NR, self.NA, 2), dtype=torch.float32, device=device),
+            map=torch.empty((n_frames, self.NR, self.NA, 2), dtype=torch.float32, device=device) if with_map else None,
             results=torch.empty((n_frames, C.sizeof(RaResult)), dtype=torch.uint8, device=device),
         )
 
     def run(self, bufs, n_frames, stream=None):
         """asynchronous on `stream` (an int hipStream_t handle, e.g. torch.cuda.current_stream().cuda_stream)"""
         self.ctx.check(self.ctx.lib.jrc_chain_run_dev(self.h, n_frames, bufs["frames"].data_ptr(),
-                                                      bufs["chanest"].data_ptr(), bufs["map"].data_ptr(),
+                                                      bufs["chanest"].data_ptr(),
+                                                      bufs["map"].data_ptr() if bufs.get("map") is not None else None,
                                                       bufs["results"].data_ptr(), stream))
+
+    def set_background(self, background_removal, background_recording, record_len):
+        """mimo_ofdm_radar's background_removal / background_recording / record_len (include/mimo_ofdm_jrc/mimo_ofdm_radar.h:52-56) for
+        the batched chain: the frames of a batch are consecutive frames of one radar stream"""
+        self.ctx.check(self.ctx.lib.jrc_chain_set_background(self.h, int(background_removal), int(background_recording), record_len))
+        self._bg = (bool(background_removal), record_len)
+
+    def set_background_record(self, background_record):
+        """mimo_ofdm_radar::set_background_record (lib/mimo_ofdm_radar_impl.cc:122-125), between batches"""
+        removal, record_len = getattr(self, "_bg", (False, 0))
+        self.set_background(removal, background_record, record_len)
+
+    def share_background(self, owner):
+        self.ctx.check(self.ctx.lib.jrc_chain_share_background(self.h, owner.h))
+
+    def background_size(self):
+        return self.ctx.check(self.ctx.lib.jrc_chain_background_size(self.h))
+
+    def prime_background(self, frames, n_frames, stream=None):
+        """channel estimate + history update only (frames: torch tensor laid out like bufs["frames"])"""
+        self.ctx.check(self.ctx.lib.jrc_chain_prime_background_dev(self.h, n_frames, frames.data_ptr(), stream))
+
+    def set_write_map(self, write_map):
+        """write_map=False: detect-only mode — no range-angle map is stored, results are bit-identical"""
+        self.ctx.check(self.ctx.lib.jrc_chain_set_write_map(self.h, int(write_map)))
 
     def run_td(self, bufs, tx, rx_td, n_frames, cp_len, stream=None):
         """A6 + A7 + A1 fused in front of the chain: tx = torch [n_frames, T, n_items, fft_len, 2] (frequency domain),
         rx_td = torch [n_frames, R, rx_stream_len, 2] time-domain RX streams with cyclic prefixes; asynchronous on `stream`"""
         assert tx.is_contiguous() and rx_td.is_contiguous()
         self.ctx.check(self.ctx.lib.jrc_chain_run_td_dev(self.h, n_frames, tx.data_ptr(), rx_td.data_ptr(), cp_len, rx_td.shape[2],
-                                                         bufs["chanest"].data_ptr(), bufs["map"].data_ptr(),
+                                                         bufs["chanest"].data_ptr(),
+                                                         bufs["map"].data_ptr() if bufs.get("map") is not None else None,
                                                          bufs["results"].data_ptr(), stream))
 
     def results(self, bufs, n_frames, stream=None):
@@ -564,6 +598,12 @@ class ChainFeed:
         if maps is not None:
             maps = maps[:min(n.value, self.maps_per_slot)]
         return list(arr[:n.value]), maps
+
+    def set_background(self, background_removal, background_recording, record_len):
+        self.ctx.check(self.ctx.lib.jrc_chain_feed_set_background(self.h, int(background_removal), int(background_recording), record_len))
+
+    def set_write_map(self, write_map):
+        self.ctx.check(self.ctx.lib.jrc_chain_feed_set_write_map(self.h, int(write_map)))
 
     def pending(self):
         return self.ctx.lib.jrc_chain_feed_pending(self.h)

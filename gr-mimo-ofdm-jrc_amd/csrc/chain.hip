@@ -37,21 +37,33 @@
 // LDS = P*N*8 (H) + P*64*8 (range bins of the current class) [+ N*8 class twiddles for N > 256]: 40 KiB for config B ->
 // 256-thread workgroups, two resident per CU (more, shorter-lived ones measured slower); 144 KiB for config D -> one
 // 512-thread workgroup per CU.
-template <int P, int NT, int MMAX, bool TWC_LDS>
+//
+// MODE 0: the map is stored and scanned (the roofline kernel).
+// MODE 1, "detect only" (jrc_chain_set_write_map(chain, 0)): the same transforms and the same arg-max on the values in registers,
+//         but the map is never stored — a consumer that only takes range_angle_estimator's message (lib/range_angle_estimator_impl.cc:
+//         234-253) does not pay the 4-16 MiB per frame.
+// MODE 2, window pass of detect-only mode: one workgroup per frame re-computes the rows of the estimator's noise window only
+//         (range bins [peak + NR/2 - dr, peak + NR/2 + dr), :197-226) THROUGH THE SAME CODE — the class fold, the 64-point transform across
+//         the wavefront and the P-point angle transform of this very template — and stores them as full rows of NA cells into a
+//         compact buffer win[frame][row][NA] that ra_finalize_kernel reads instead of the map: same instructions on the same inputs,
+//         so the noise sum, and with it every field of the result, is bit-identical to MODE 0.
+template <int P, int NT, int MMAX, bool TWC_LDS, int MODE>
 #ifndef JRC_WPS256
 #define JRC_WPS256 3
 #endif
 __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))) void range_angle_fused_kernel(
     const float2* __restrict__ H,        // [F][P][N]
-    float2* __restrict__ map,            // [F][NR][NA]
-    PeakPartial* __restrict__ partials,  // [F][WPF]
+    float2* __restrict__ map,            // MODE 0: [F][NR][NA]; MODE 2: win [F][win_rows][NA]; MODE 1: unused
+    PeakPartial* __restrict__ partials,  // [F][pstride]: written by MODE 0/1, read by MODE 2
     const float2* __restrict__ twR,      // [NR]  exp(+j 2 pi i / NR)
     const float2* __restrict__ twA,      // [NA]  exp(-j 2 pi i / NA)
     int N, int NR, int Ia, int F, int WPF,
     int nt_tail,                         // the last nt_tail classes of a workgroup are stored non-temporally (see chain_nt_tail)
-    int pstride)                         // partial maxima per frame in `partials` (>= WPF; unused slots hold the neutral element)
+    int pstride,                         // partial maxima per frame in `partials` (>= WPF; unused slots hold the neutral element)
+    int win_rows, int win_off)           // MODE 2: rows of the noise window (2 dr) and its offset from the peak's range bin (NR/2 - dr)
 {
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    __shared__ int s_row0;
     constexpr int NW = NT / 64;
     const int NA = P * Ia;
     const int C = NR / RA_L;
@@ -71,17 +83,34 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int M = N / RA_L;                     // fold length per lane, <= MMAX
 
+    int row0 = 0;                               // MODE 2: first range bin of the window (before wrapping)
+    if constexpr (MODE == 2) {
+        PeakTracker pk;
+        pk.init();
+        for (int i = tid; i < pstride; i += NT) pk.merge(partials[(size_t)f * pstride + i].best, partials[(size_t)f * pstride + i].idx);
+        block_reduce_peak(pk, reinterpret_cast<PeakPartial*>(s_g));
+        if (tid == 0) s_row0 = (int)(pk.idx / (unsigned)NA) + win_off;
+        __syncthreads();
+        row0 = s_row0;
+    }
+    auto class_of = [&](int it) -> int {        // the class this workgroup works on in its it-th trip
+        if constexpr (MODE == 2) return (((row0 + it) % NR + NR) % NR) % C;
+        else return slice + it * WPF;
+    };
+    const int n_iter = MODE == 2 ? win_rows : (C - slice + WPF - 1) / WPF;
+    const int c_first = class_of(0);
+
     // class twiddles for this lane's fold inputs n = lane + 64 m:  exp(+j 2 pi n c / NR)
     // (large N: staged through LDS one class ahead instead of living in registers across the store phase)
     float2 tc[TWC_LDS ? 1 : MMAX];
     float2 tn[NPT];
     if constexpr (TWC_LDS) {
 #pragma unroll
-        for (int q = 0; q < NPT; q++) { const int n = tid + NT * q; if (n < N) tn[q] = twR[(n * slice) & (NR - 1)]; }
+        for (int q = 0; q < NPT; q++) { const int n = tid + NT * q; if (n < N) tn[q] = twR[(n * c_first) & (NR - 1)]; }
     } else {
 #pragma unroll
         for (int m = 0; m < MMAX; m++)
-            if (m < M) tc[m] = twR[((lane + RA_L * m) * slice) & (NR - 1)];     // n*c < 2^31
+            if (m < M) tc[m] = twR[((lane + RA_L * m) * c_first) & (NR - 1)];     // n*c < 2^31
     }
     {
         // stage H: 16-byte loads, fully coalesced
@@ -106,12 +135,13 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
     trk.init();
     const int items = RA_L * Ia;                // (range bin, residue) pairs per class; a multiple of 64
     const int ahalf = NA >> 1, amask = NA - 1;
-    float2* mapf = map + (size_t)f * NR * NA;
+    float2* mapf = MODE == 2 ? map + (size_t)f * win_rows * NA : map + (size_t)f * NR * NA;
 
     typedef float v2f __attribute__((ext_vector_type(2)));
     const int c_nt = C - nt_tail * WPF;         // classes c >= c_nt are among the last nt_tail of this workgroup
 #pragma unroll 1
-    for (int c = slice; c < C; c += WPF) {
+    for (int it = 0; it < n_iter; it++) {
+        const int c = class_of(it);
         const bool nt = c >= c_nt;
         if constexpr (TWC_LDS) {
 #pragma unroll
@@ -140,21 +170,35 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
             }
             s_g[p * RA_L + (__brev((unsigned)lane) >> 26)] = v;   // lane holds X[bitrev6(lane)]
         }
-        {
-            const int cn = c + WPF;             // prefetch the next class's twiddles; they land during the stores
-            if (cn < C) {
-                if constexpr (TWC_LDS) {
+        if (it + 1 < n_iter) {                  // prefetch the next class's twiddles; they land during the stores
+            const int cn = class_of(it + 1);
+            if constexpr (TWC_LDS) {
 #pragma unroll
-                    for (int q = 0; q < NPT; q++) { const int n = tid + NT * q; if (n < N) tn[q] = twR[(n * cn) & (NR - 1)]; }
-                } else {
+                for (int q = 0; q < NPT; q++) { const int n = tid + NT * q; if (n < N) tn[q] = twR[(n * cn) & (NR - 1)]; }
+            } else {
 #pragma unroll
-                    for (int m = 0; m < MMAX; m++)
-                        if (m < M) tc[m] = twR[((lane + RA_L * m) * cn) & (NR - 1)];
-                }
+                for (int m = 0; m < MMAX; m++)
+                    if (m < M) tc[m] = twR[((lane + RA_L * m) * cn) & (NR - 1)];
             }
         }
         __syncthreads();
 
+        if constexpr (MODE == 2) {
+            // ---- window row: the one range bin of this class that lies in the noise window, all NA angle cells -----------
+            if (tid < Ia) {
+                const int k = ((row0 + it) % NR + NR) % NR;
+                const int ql = k / C;
+                float2 y[P];
+                y[0] = s_g[ql];
+#pragma unroll
+                for (int p = 1; p < P; p++) y[p] = cmul(s_g[p * RA_L + ql], ta[p]);
+                fft_fwd_small<P>(y);
+                float2* row = mapf + (size_t)it * NA;
+#pragma unroll
+                for (int u = 0; u < P; u++) row[(Ia * u + r + ahalf) & amask] = y[u];
+            }
+            continue;
+        }
         // ---- angle axis + fftshift + store + arg-max ---------------------------------------------
 #pragma unroll 1
         for (int w0 = 0; w0 < items; w0 += NT) {     // whole waves are in or out
@@ -167,13 +211,15 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
 #pragma unroll
             for (int p = 1; p < P; p++) y[p] = cmul(s_g[p * RA_L + ql], ta[p]);
             fft_fwd_small<P>(y);
-            float2* row = mapf + (size_t)k * NA;
             float m = -1.0f;
 #pragma unroll
             for (int u = 0; u < P; u++) {
-                const int a = (Ia * u + r + ahalf) & amask;   // fftshift: out'[a'] = out[(a' + NA/2) % NA]
-                if (nt) { v2f t = {y[u].x, y[u].y}; __builtin_nontemporal_store(t, reinterpret_cast<v2f*>(row + a)); }
-                else row[a] = y[u];
+                if constexpr (MODE == 0) {
+                    float2* row = mapf + (size_t)k * NA;
+                    const int a = (Ia * u + r + ahalf) & amask;   // fftshift: out'[a'] = out[(a' + NA/2) % NA]
+                    if (nt) { v2f t = {y[u].x, y[u].y}; __builtin_nontemporal_store(t, reinterpret_cast<v2f*>(row + a)); }
+                    else row[a] = y[u];
+                }
                 m = fmaxf(m, fast_power(y[u]));
             }
             // estimator arg-max (lib/range_angle_estimator_impl.cc:137-151) on the values still in registers
@@ -186,12 +232,15 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
             }
         }
     }
-    __syncthreads();
-    block_reduce_peak(trk, reinterpret_cast<PeakPartial*>(s_g));
-    if (tid == 0) { partials[(size_t)f * pstride + slice].best = trk.best; partials[(size_t)f * pstride + slice].idx = trk.idx; }
+    if constexpr (MODE != 2) {
+        __syncthreads();
+        block_reduce_peak(trk, reinterpret_cast<PeakPartial*>(s_g));
+        if (tid == 0) { partials[(size_t)f * pstride + slice].best = trk.best; partials[(size_t)f * pstride + slice].idx = trk.idx; }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
+struct jrc_bg_state;
 struct jrc_chain {
     jrc_ctx* ctx;
     jrc_chain_cfg cfg;
@@ -212,7 +261,75 @@ struct jrc_chain {
     double ms_acc[3] = {0, 0, 0};
     int launches = 0;
     jrc_ra_result* h_pinned = nullptr;
+    // detect-only mode (jrc_chain_set_write_map): the map is not stored; the estimator's noise-window rows are re-computed
+    bool write_map = true;
+    int win_dr = 0;                   // the estimator's discard_range_idx (:189), computed as the device does
+    float2* d_win = nullptr;          // [max_frames][2 win_dr][NA]
+    // background recording / removal (jrc_chain_set_background)
+    jrc_bg_state* bg = nullptr;
+    float2* d_raw = nullptr;          // [max_frames][P][N] estimates before the subtraction
 };
+
+// ---- background state of one radar stream (lib/mimo_ofdm_radar_impl.cc:276-300) on the device --------------------------------
+// The reference keeps radar_chan_est_temp (the last RECORDED raw estimate, zero at construction :115) and a boost::circular_buffer of
+// record_len past temps; frame f's mean runs over the buffer as it stood before f, oldest entry first, each term divided by the
+// entry count (:281-292), and temp is pushed after every frame while removal is on (:297-300).  Here the history lives in HBM oldest
+// first ([count][P*N], double buffered), a batch of frames is handled by one kernel (a thread per (frame, element) walks its own
+// window: entries older than the batch come from the history, the others from the batch's raw estimates), and a second kernel
+// writes the history the next batch will see.  One state may be shared by several chains (the slots of a jrc_chain_feed): an event
+// orders consecutive batches across their streams.
+struct jrc_bg_state {
+    int removal = 0, recording = 0, record_len = 0;
+    size_t pn = 0;
+    float2* hist[2] = {nullptr, nullptr};
+    int cur = 0, count = 0;
+    float2* temp = nullptr;
+    hipEvent_t updated = nullptr;
+    bool pending = false;
+    int refs = 1;
+};
+
+__global__ __launch_bounds__(256) void chain_background_kernel(const float2* __restrict__ raw, float2* __restrict__ est,
+                                                               const float2* __restrict__ hist, const float2* __restrict__ temp,
+                                                               int pn, int n0, int L, int recording)
+{
+#pragma clang fp contract(off)
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y;
+    if (idx >= pn) return;
+    const float2 e = raw[(size_t)f * pn + idx];
+    const int c = min(L, n0 + f);                      // entries in the buffer before frame f
+    float2 m = make_float2(0.f, 0.f);
+    const float n = (float)c;
+    for (int j = f - c; j < f; j++) {                  // oldest first (:286-290)
+        const float2 v = j < 0 ? hist[(size_t)(n0 + j) * pn + idx] : (recording ? raw[(size_t)j * pn + idx] : temp[idx]);
+        m.x = m.x + v.x / n;                           // complex / float divides each component (:289)
+        m.y = m.y + v.y / n;
+    }
+    est[(size_t)f * pn + idx] = make_float2(e.x - m.x, e.y - m.y);   // :292
+}
+
+// history after a batch of F frames: the last min(L, n0 + F) entries of (old history, then one push per frame)
+__global__ __launch_bounds__(256) void chain_background_push_kernel(const float2* __restrict__ raw, const float2* __restrict__ hist,
+                                                                    float2* __restrict__ hist_new, const float2* __restrict__ temp,
+                                                                    int pn, int n0, int F, int n1, int recording)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int slot = blockIdx.y;
+    if (idx >= pn) return;
+    const int j = F - n1 + slot;                       // position in the push sequence of this batch (negative: old history)
+    hist_new[(size_t)slot * pn + idx] = j < 0 ? hist[(size_t)(n0 + j) * pn + idx] : (recording ? raw[(size_t)j * pn + idx] : temp[idx]);
+}
+
+static void bg_release(jrc_bg_state* b)
+{
+    if (!b || --b->refs > 0) return;
+    if (b->hist[0]) (void)hipFree(b->hist[0]);
+    if (b->hist[1]) (void)hipFree(b->hist[1]);
+    if (b->temp) (void)hipFree(b->temp);
+    if (b->updated) (void)hipEventDestroy(b->updated);
+    delete b;
+}
 
 // generic mode helper: rows of H -> zero-padded rows of length NR (the padding mimo_ofdm_radar emits, :243, :312-315)
 __global__ void pad_rows_kernel(const float2* __restrict__ H, float2* __restrict__ out, int N, int NR, size_t rows)
@@ -250,10 +367,20 @@ static int chain_nt_tail(const jrc_chain* ch, int n_frames, int wpf)
     return k > per_wg ? per_wg : k;
 }
 
-template <int P, int NT, int MMAX, bool TWC_LDS>
-static int launch_fused_nt(jrc_chain* ch, int n_frames, int wpf, int pstride, const float2* d_H, float2* d_map, hipStream_t s)
+template <int P, int NT, int MMAX, bool TWC_LDS, int MODE>
+static int launch_fused_mode(jrc_chain* ch, int n_frames, int wpf, int pstride, const float2* d_H, float2* d_map, hipStream_t s)
 {
-    JRC_TRY(jrc_ensure_dyn_lds(ch->ctx, (const void*)range_angle_fused_kernel<P, NT, MMAX, TWC_LDS>, ch->lds_bytes));
+    JRC_TRY(jrc_ensure_dyn_lds(ch->ctx, (const void*)range_angle_fused_kernel<P, NT, MMAX, TWC_LDS, MODE>, ch->lds_bytes));
+    if (MODE == 2) {
+        // window pass of detect-only mode: one workgroup per frame walks the 2 dr rows of its noise window
+        const int rows = 2 * ch->win_dr;
+        if (rows <= 0) return JRC_OK;
+        const dim3 grid((unsigned)(((n_frames + 7) / 8) * 8));
+        hipLaunchKernelGGL((range_angle_fused_kernel<P, NT, MMAX, TWC_LDS, MODE>), grid, dim3(NT), ch->lds_bytes, s, d_H, ch->d_win, ch->d_partials,
+                           ch->twR, ch->twA, ch->cfg.fft_len, ch->NR, ch->cfg.interp_angle, n_frames, 1, 0, pstride, rows, ch->NR / 2 - ch->win_dr);
+        JRC_HIP(ch->ctx, hipGetLastError());
+        return JRC_OK;
+    }
     // One resident wave of workgroups per launch: a batch that needs more is launched in chunks of that size, and a last,
     // smaller chunk gets more slices per frame so that it fills the machine as well (a grid twice the resident size runs 20 %
     // slower than two launches because its second wave of workgroups starts ragged).  `pstride` partial maxima per frame.
@@ -266,24 +393,44 @@ static int launch_fused_nt(jrc_chain* ch, int n_frames, int wpf, int pstride, co
         int w = chain_pick_wpf(ch, nf);
         if (w > pstride) w = pstride;
         const dim3 grid((unsigned)(((nf + 7) / 8) * 8 * w));
-        hipLaunchKernelGGL((range_angle_fused_kernel<P, NT, MMAX, TWC_LDS>), grid, dim3(NT), ch->lds_bytes, s,
-                           d_H + (size_t)f0 * P * ch->cfg.fft_len, d_map + (size_t)f0 * ch->NR * ch->NA, ch->d_partials + (size_t)f0 * pstride,
-                           ch->twR, ch->twA, ch->cfg.fft_len, ch->NR, ch->cfg.interp_angle, nf, w, chain_nt_tail(ch, nf, w), pstride);
+        hipLaunchKernelGGL((range_angle_fused_kernel<P, NT, MMAX, TWC_LDS, MODE>), grid, dim3(NT), ch->lds_bytes, s,
+                           d_H + (size_t)f0 * P * ch->cfg.fft_len, MODE == 0 ? d_map + (size_t)f0 * ch->NR * ch->NA : nullptr,
+                           ch->d_partials + (size_t)f0 * pstride,
+                           ch->twR, ch->twA, ch->cfg.fft_len, ch->NR, ch->cfg.interp_angle, nf, w, chain_nt_tail(ch, nf, w), pstride, 0, 0);
     }
     JRC_HIP(ch->ctx, hipGetLastError());
     return JRC_OK;
 }
 
+template <int P, int NT, int MMAX, bool TWC_LDS>
+static int launch_fused_nt(jrc_chain* ch, int mode, int n_frames, int wpf, int pstride, const float2* d_H, float2* d_map, hipStream_t s)
+{
+    if (mode == 0) return launch_fused_mode<P, NT, MMAX, TWC_LDS, 0>(ch, n_frames, wpf, pstride, d_H, d_map, s);
+    if (mode == 1) return launch_fused_mode<P, NT, MMAX, TWC_LDS, 1>(ch, n_frames, wpf, pstride, d_H, d_map, s);
+    return launch_fused_mode<P, NT, MMAX, TWC_LDS, 2>(ch, n_frames, wpf, pstride, d_H, d_map, s);
+}
+
 template <int P>
-static int launch_fused(jrc_chain* ch, int n_frames, int wpf, int pstride, const float2* d_H, float2* d_map, hipStream_t s)
+static int launch_fused(jrc_chain* ch, int mode, int n_frames, int wpf, int pstride, const float2* d_H, float2* d_map, hipStream_t s)
 {
     // small frames: 256-thread workgroups, up to three per CU; large frames (H fills most of the LDS): one
     // 512-thread workgroup per CU
-    if (ch->threads == 1024) return launch_fused_nt<P, 1024, 16, true>(ch, n_frames, wpf, pstride, d_H, d_map, s);
-    if (ch->threads == 512 && ch->cfg.fft_len <= 256) return launch_fused_nt<P, 512, 4, false>(ch, n_frames, wpf, pstride, d_H, d_map, s);
-    if (ch->threads == 512) return launch_fused_nt<P, 512, 16, true>(ch, n_frames, wpf, pstride, d_H, d_map, s);
-    if (ch->cfg.fft_len > 256) return launch_fused_nt<P, 256, 16, true>(ch, n_frames, wpf, pstride, d_H, d_map, s);
-    return launch_fused_nt<P, 256, 4, false>(ch, n_frames, wpf, pstride, d_H, d_map, s);
+    if (ch->threads == 1024) return launch_fused_nt<P, 1024, 16, true>(ch, mode, n_frames, wpf, pstride, d_H, d_map, s);
+    if (ch->threads == 512 && ch->cfg.fft_len <= 256) return launch_fused_nt<P, 512, 4, false>(ch, mode, n_frames, wpf, pstride, d_H, d_map, s);
+    if (ch->threads == 512) return launch_fused_nt<P, 512, 16, true>(ch, mode, n_frames, wpf, pstride, d_H, d_map, s);
+    if (ch->cfg.fft_len > 256) return launch_fused_nt<P, 256, 16, true>(ch, mode, n_frames, wpf, pstride, d_H, d_map, s);
+    return launch_fused_nt<P, 256, 4, false>(ch, mode, n_frames, wpf, pstride, d_H, d_map, s);
+}
+
+static int launch_fused_any(jrc_chain* ch, int mode, int n_frames, int wpf, int pstride, const float2* d_H, float2* d_map, hipStream_t s)
+{
+    switch (ch->P) {
+        case 1: return launch_fused<1>(ch, mode, n_frames, wpf, pstride, d_H, d_map, s);
+        case 2: return launch_fused<2>(ch, mode, n_frames, wpf, pstride, d_H, d_map, s);
+        case 4: return launch_fused<4>(ch, mode, n_frames, wpf, pstride, d_H, d_map, s);
+        case 8: return launch_fused<8>(ch, mode, n_frames, wpf, pstride, d_H, d_map, s);
+        default: return launch_fused<16>(ch, mode, n_frames, wpf, pstride, d_H, d_map, s);
+    }
 }
 
 extern "C" int jrc_chain_create(jrc_ctx* ctx, const jrc_chain_cfg* cfg, const float* range_bins,
@@ -326,6 +473,7 @@ extern "C" int jrc_chain_create(jrc_ctx* ctx, const jrc_chain_cfg* cfg, const fl
         if (ch->wg_per_cu > 2) ch->wg_per_cu = 2;          // measured: 2 long-lived workgroups per CU beat 3-4 short ones
         if (getenv("JRC_WG_PER_CU")) { const int v = atoi(getenv("JRC_WG_PER_CU")); if (v >= 1 && v <= by_lds && v <= by_regs) ch->wg_per_cu = v; }
     }
+    ch->win_dr = NR >= 2 ? (int)(cfg->noise_discard_range_m / (range_bins[1] - range_bins[0])) : 0;   // :189, float arithmetic as on the device
     if (ch->generic) {
         if (!generic_ok) { delete ch; return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "JRC_CHAIN_GENERIC: transform sizes out of range"); }
         ch->C = 1;
@@ -356,6 +504,9 @@ extern "C" void jrc_chain_destroy(jrc_chain* ch)
     if (ch->d_bins) (void)hipFree(ch->d_bins);
     if (ch->d_partials) (void)hipFree(ch->d_partials);
     if (ch->d_pad) (void)hipFree(ch->d_pad);
+    if (ch->d_win) (void)hipFree(ch->d_win);
+    if (ch->d_raw) (void)hipFree(ch->d_raw);
+    bg_release(ch->bg);
     if (ch->h_pinned) (void)hipHostFree(ch->h_pinned);
     delete ch;
 }
@@ -421,6 +572,125 @@ extern "C" int jrc_chain_get_timing(jrc_chain* ch, float ms[3], int* launches)
     return JRC_OK;
 }
 
+// one batch through the background state: est = raw - mean(buffer before the frame) when removal is on, then the pushes of the
+// batch (:297-300) and the new radar_chan_est_temp (:276-279).  est == nullptr: state update only (jrc_chain_prime_background_dev).
+static int chain_background_step(jrc_chain* ch, int n_frames, const float2* raw, float2* est, hipStream_t s)
+{
+    jrc_ctx* ctx = ch->ctx;
+    jrc_bg_state* b = ch->bg;
+    const int pn = (int)b->pn;
+    if (b->pending) JRC_HIP(ctx, hipStreamWaitEvent(s, b->updated, 0));      // the batch before this one may be on another stream
+    const dim3 blk(256);
+    if (b->removal) {
+        if (n_frames > 65535) return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "background removal: at most 65535 frames per batch");
+        if (est)
+            hipLaunchKernelGGL(chain_background_kernel, dim3((pn + 255) / 256, n_frames), blk, 0, s, raw, est, b->hist[b->cur], b->temp, pn, b->count,
+                               b->record_len, b->recording);
+        const int n1 = b->record_len < b->count + n_frames ? b->record_len : b->count + n_frames;
+        if (n1 > 0) {
+            hipLaunchKernelGGL(chain_background_push_kernel, dim3((pn + 255) / 256, n1), blk, 0, s, raw, b->hist[b->cur], b->hist[b->cur ^ 1], b->temp,
+                               pn, b->count, n_frames, n1, b->recording);
+            b->cur ^= 1;
+        }
+        b->count = n1;
+    }
+    JRC_HIP(ctx, hipGetLastError());
+    if (b->recording)      // radar_chan_est_temp <- this frame's raw estimate (:276-279): after the batch it holds the last frame's
+        JRC_HIP(ctx, hipMemcpyAsync(b->temp, raw + (size_t)(n_frames - 1) * pn, sizeof(float2) * pn, hipMemcpyDeviceToDevice, s));
+    JRC_HIP(ctx, hipEventRecord(b->updated, s));
+    b->pending = true;
+    return JRC_OK;
+}
+
+extern "C" int jrc_chain_set_background(jrc_chain* ch, int background_removal, int background_recording, int record_len)
+{
+    if (!ch || record_len < 0) return JRC_ERR_INVALID_ARG;
+    jrc_ctx* ctx = ch->ctx;
+    JRC_BIND(ctx);
+    const size_t pn = (size_t)ch->P * ch->cfg.fft_len;
+    if (!ch->bg) {
+        if (!background_removal && !background_recording) return JRC_OK;
+        jrc_bg_state* b = new jrc_bg_state();
+        b->pn = pn; b->record_len = record_len;
+        const size_t hb = sizeof(float2) * pn * (size_t)(record_len ? record_len : 1);
+        hipError_t e = hipMalloc((void**)&b->hist[0], hb);
+        if (e == hipSuccess) e = hipMalloc((void**)&b->hist[1], hb);
+        if (e == hipSuccess) e = hipMalloc((void**)&b->temp, sizeof(float2) * pn);
+        if (e == hipSuccess) e = hipMemset(b->temp, 0, sizeof(float2) * pn);            // vector::resize value-initialises (:115)
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&b->updated, hipEventDisableTiming);
+        if (e != hipSuccess) { bg_release(b); return jrc_fail(ctx, JRC_ERR_HIP, "jrc_chain_set_background: %s", hipGetErrorString(e)); }
+        ch->bg = b;
+    } else if (record_len != ch->bg->record_len) {
+        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_set_background: record_len is fixed once the state exists (%d)", ch->bg->record_len);
+    }
+    if (background_removal && !ch->d_raw) {
+        hipError_t e = hipMalloc((void**)&ch->d_raw, sizeof(float2) * pn * (size_t)ch->max_frames);
+        if (e != hipSuccess) return jrc_fail(ctx, JRC_ERR_HIP, "jrc_chain_set_background: %s", hipGetErrorString(e));
+    }
+    ch->bg->removal = background_removal != 0;
+    ch->bg->recording = background_recording != 0;
+    return JRC_OK;
+}
+
+// several chains, one radar stream (the slots of a feed): `ch` uses — and advances — the background state of `owner`
+extern "C" int jrc_chain_share_background(jrc_chain* ch, jrc_chain* owner)
+{
+    if (!ch || !owner || !owner->bg || ch == owner) return JRC_ERR_INVALID_ARG;
+    jrc_ctx* ctx = ch->ctx;
+    if (ch->P != owner->P || ch->cfg.fft_len != owner->cfg.fft_len || ch->ctx->device != owner->ctx->device)
+        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_share_background: chains of different shape or device");
+    JRC_BIND(ctx);
+    if (!ch->d_raw) {
+        hipError_t e = hipMalloc((void**)&ch->d_raw, sizeof(float2) * owner->bg->pn * (size_t)ch->max_frames);
+        if (e != hipSuccess) return jrc_fail(ctx, JRC_ERR_HIP, "jrc_chain_share_background: %s", hipGetErrorString(e));
+    }
+    bg_release(ch->bg);
+    ch->bg = owner->bg;
+    ch->bg->refs++;
+    return JRC_OK;
+}
+
+extern "C" int jrc_chain_background_size(const jrc_chain* ch) { return ch ? (ch->bg ? ch->bg->count : 0) : JRC_ERR_INVALID_ARG; }
+
+// A1 + state update only, outputs dropped: what a GPU replays in front of its block of a sharded stream (the
+// <= record_len estimates at the block boundary), and what `background_recording` without consumers amounts to
+extern "C" int jrc_chain_prime_background_dev(jrc_chain* ch, int n_frames, const jrc_cf32* d_frames, void* stream)
+{
+    if (!ch || !d_frames) return JRC_ERR_INVALID_ARG;
+    jrc_ctx* ctx = ch->ctx;
+    if (!ch->bg || !ch->bg->removal) return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_prime_background_dev: background removal is not enabled");
+    if (n_frames <= 0 || n_frames > ch->max_frames) return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_prime_background_dev: bad n_frames");
+    JRC_BIND(ctx);
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    const jrc_chain_cfg& c = ch->cfg;
+    ChanestGeom g;
+    g.N = c.fft_len; g.S = c.N_sym;
+    g.port_stride = (long)c.n_items * c.fft_len;
+    g.frame_stride = g.port_stride * (c.N_tx + c.N_rx);
+    g.tx_item0 = c.N_pre; g.rx_item0 = c.N_pre; g.interleave = c.enable_tx_interleave;
+    JRC_TRY(launch_radar_chanest(ctx, c.N_tx, c.N_rx, (const float2*)d_frames, ch->d_raw, g, n_frames, s));
+    return chain_background_step(ch, n_frames, ch->d_raw, nullptr, s);
+}
+
+// detect-only mode: write_map = 0 -> jrc_chain_run_dev ignores d_map (may be NULL) and stores no map; results are bit-identical
+extern "C" int jrc_chain_set_write_map(jrc_chain* ch, int write_map)
+{
+    if (!ch) return JRC_ERR_INVALID_ARG;
+    jrc_ctx* ctx = ch->ctx;
+    if (write_map) { ch->write_map = true; return JRC_OK; }
+    if (ch->generic) return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "detect-only mode: this shape runs block by block and needs the map");
+    if (2 * ch->win_dr > ch->NR || ch->win_dr < 0)
+        return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "detect-only mode: the noise window (%d range bins) is larger than the map", 2 * ch->win_dr);
+    JRC_BIND(ctx);
+    if (!ch->d_win) {
+        const size_t bytes = sizeof(float2) * (size_t)ch->max_frames * (size_t)(2 * ch->win_dr ? 2 * ch->win_dr : 1) * ch->NA;
+        hipError_t e = hipMalloc((void**)&ch->d_win, bytes);
+        if (e != hipSuccess) return jrc_fail(ctx, JRC_ERR_HIP, "jrc_chain_set_write_map: %s", hipGetErrorString(e));
+    }
+    ch->write_map = false;
+    return JRC_OK;
+}
+
 // A1 comes in two forms: frequency-domain frames (d_frames), or TX rows + time-domain RX streams (A6 + A7 + A1 fused)
 static int chain_run(jrc_chain* ch, int n_frames, const jrc_cf32* d_frames, const jrc_cf32* d_tx, const jrc_cf32* d_rx_td, int cp_len,
                      long rx_stream_len, jrc_cf32* d_chanest, jrc_cf32* d_map, jrc_ra_result* d_results, void* stream)
@@ -441,7 +711,11 @@ static int chain_run(jrc_chain* ch, int n_frames, const jrc_cf32* d_frames, cons
         ch->ev_used++;
         JRC_HIP(ctx, hipEventRecord(ev[0], s));
     }
-    // A1
+    // A1 (into the raw-estimate buffer when the background mean is subtracted afterwards)
+    jrc_bg_state* bg = ch->bg;
+    const bool bg_sub = bg && bg->removal;
+    jrc_cf32* d_est_out = d_chanest;
+    if (bg_sub) d_chanest = (jrc_cf32*)ch->d_raw;
     if (d_frames) {
         ChanestGeom g;
         g.N = c.fft_len; g.S = c.N_sym;
@@ -457,7 +731,13 @@ static int chain_run(jrc_chain* ch, int n_frames, const jrc_cf32* d_frames, cons
         g.tx_item0 = c.N_pre; g.rx_sym0 = c.N_pre; g.interleave = c.enable_tx_interleave; g.blocks_per_frame = 1;
         JRC_TRY(launch_demod_chanest(ctx, c.N_tx, (const float2*)d_tx, (const float2*)d_rx_td, (float2*)d_chanest, g, n_frames, s));
     }
+    if (bg && (bg->removal || bg->recording)) {
+        JRC_TRY(chain_background_step(ch, n_frames, (const float2*)d_chanest, (float2*)d_est_out, s));
+        d_chanest = d_est_out;
+    }
     if (ev) JRC_HIP(ctx, hipEventRecord(ev[1], s));
+    if (!ch->write_map && ch->generic) return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "detect-only mode needs the fused kernel");
+    if (ch->write_map && !d_map) return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_run_dev: d_map is NULL but the chain stores the map (jrc_chain_set_write_map)");
     // A2 + A3 + A4 + arg-max half of A5
     int partials_per_frame;
     if (ch->generic) {
@@ -484,15 +764,9 @@ static int chain_run(jrc_chain* ch, int n_frames, const jrc_cf32* d_frames, cons
         const int pstride = tail ? chain_pick_wpf(ch, tail) : wpf;
         if (pstride != wpf)      // frames of full chunks leave slots unused: all-ones = NaN power, never wins a merge
             JRC_HIP(ctx, hipMemsetAsync(ch->d_partials, 0xFF, sizeof(PeakPartial) * (size_t)n_frames * pstride, s));
-        int st;
-        switch (ch->P) {
-            case 1: st = launch_fused<1>(ch, n_frames, wpf, pstride, (const float2*)d_chanest, (float2*)d_map, s); break;
-            case 2: st = launch_fused<2>(ch, n_frames, wpf, pstride, (const float2*)d_chanest, (float2*)d_map, s); break;
-            case 4: st = launch_fused<4>(ch, n_frames, wpf, pstride, (const float2*)d_chanest, (float2*)d_map, s); break;
-            case 8: st = launch_fused<8>(ch, n_frames, wpf, pstride, (const float2*)d_chanest, (float2*)d_map, s); break;
-            default: st = launch_fused<16>(ch, n_frames, wpf, pstride, (const float2*)d_chanest, (float2*)d_map, s); break;
-        }
-        JRC_TRY(st);
+        JRC_TRY(launch_fused_any(ch, ch->write_map ? 0 : 1, n_frames, wpf, pstride, (const float2*)d_chanest, (float2*)d_map, s));
+        if (!ch->write_map)      // the noise-window rows, through the same transforms, into the compact window buffer
+            JRC_TRY(launch_fused_any(ch, 2, n_frames, 1, pstride, (const float2*)d_chanest, nullptr, s));
         if (ev) JRC_HIP(ctx, hipEventRecord(ev[2], s));
         partials_per_frame = pstride;
     }
@@ -500,8 +774,12 @@ static int chain_run(jrc_chain* ch, int n_frames, const jrc_cf32* d_frames, cons
     RaParams prm;
     prm.vlen = ch->NA; prm.n_inputs = ch->NR; prm.n_range_bins = ch->NR; prm.n_angle_bins = ch->NA;
     prm.noise_discard_range_m = c.noise_discard_range_m; prm.noise_discard_angle_deg = c.noise_discard_angle_deg;
-    JRC_TRY(launch_ra_finalize(ctx, (const float2*)d_map, (size_t)ch->NR * ch->NA, ch->d_partials, partials_per_frame, prm, ch->d_bins,
-                               ch->d_bins + ch->NR, d_results, n_frames, s));
+    if (ch->write_map)
+        JRC_TRY(launch_ra_finalize(ctx, (const float2*)d_map, (size_t)ch->NR * ch->NA, ch->d_partials, partials_per_frame, prm, ch->d_bins,
+                                   ch->d_bins + ch->NR, d_results, n_frames, 0, s));
+    else
+        JRC_TRY(launch_ra_finalize(ctx, ch->d_win, (size_t)2 * ch->win_dr * ch->NA, ch->d_partials, partials_per_frame, prm, ch->d_bins,
+                                   ch->d_bins + ch->NR, d_results, n_frames, 2 * ch->win_dr, s));
     if (ev) JRC_HIP(ctx, hipEventRecord(ev[3], s));
     return JRC_OK;
 }
@@ -509,14 +787,14 @@ static int chain_run(jrc_chain* ch, int n_frames, const jrc_cf32* d_frames, cons
 extern "C" int jrc_chain_run_dev(jrc_chain* ch, int n_frames, const jrc_cf32* d_frames, jrc_cf32* d_chanest,
                                  jrc_cf32* d_map, jrc_ra_result* d_results, void* stream)
 {
-    if (!ch || !d_frames || !d_chanest || !d_map || !d_results) return JRC_ERR_INVALID_ARG;
+    if (!ch || !d_frames || !d_chanest || !d_results) return JRC_ERR_INVALID_ARG;
     return chain_run(ch, n_frames, d_frames, nullptr, nullptr, 0, 0, d_chanest, d_map, d_results, stream);
 }
 
 extern "C" int jrc_chain_run_td_dev(jrc_chain* ch, int n_frames, const jrc_cf32* d_tx, const jrc_cf32* d_rx_td, int cp_len,
                                     long rx_stream_len, jrc_cf32* d_chanest, jrc_cf32* d_map, jrc_ra_result* d_results, void* stream)
 {
-    if (!ch || !d_tx || !d_rx_td || !d_chanest || !d_map || !d_results) return JRC_ERR_INVALID_ARG;
+    if (!ch || !d_tx || !d_rx_td || !d_chanest || !d_results) return JRC_ERR_INVALID_ARG;
     return chain_run(ch, n_frames, nullptr, d_tx, d_rx_td, cp_len, rx_stream_len, d_chanest, d_map, d_results, stream);
 }
 

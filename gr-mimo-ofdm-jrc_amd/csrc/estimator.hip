@@ -67,7 +67,9 @@ __global__ __launch_bounds__(256) void ra_finalize_kernel(const float2* __restri
                                                           RaParams prm, const float* __restrict__ range_bins,
                                                           const float* __restrict__ angle_bins,
                                                           jrc_ra_result* __restrict__ results,
-                                                          int force_ref_sum)   // tests: take the reference-order double sum for every chunk
+                                                          int force_ref_sum,   // tests: take the reference-order double sum for every chunk
+                                                          int win_rows)        // > 0 (detect-only mode): `maps` holds only the noise-window rows of each
+                                                                               // frame, [win_rows][vlen], row i = range bin start_range + i (chain.hip MODE 2)
 {
     __shared__ PeakPartial red[4];
     __shared__ int s_win[5];     // start_range, end_range, start_angle, end_angle, valid
@@ -120,6 +122,10 @@ __global__ __launch_bounds__(256) void ra_finalize_kernel(const float2* __restri
     const int sr = s_win[0], er = s_win[1], sa = s_win[2], ea = s_win[3];
     const int wr = er > sr ? er - sr : 0, wa = ea > sa ? ea - sa : 0;
     const int ncells = wr * wa;
+    if (win_rows > 0 && wr != win_rows) {       // the host sized the window buffer with another discard_range_idx than the device computes: refuse
+        if (threadIdx.x == 0) { r.n_noise_samples = -1; r.noise_power = nanf(""); r.snr_est = 0.f; r.published = 0; results[f] = r; }
+        return;
+    }
     float noise = 0.f;
     for (int base = 0; base < ncells; base += RA_CHUNK) {
         const int cnt = min(RA_CHUNK, ncells - base);
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(256) void ra_finalize_kernel(const float2* __restri
             const int ir = sr + c / wa, ia = sa + c % wa;
             const int r_idx = ((ir % n_inputs) + n_inputs) % n_inputs;      // :211
             const int a_idx = ((ia % vlen) + vlen) % vlen;                  // :215
-            s_h[j] = ref_hypotf(map[(size_t)a_idx + (size_t)vlen * r_idx]);
+            s_h[j] = ref_hypotf(win_rows > 0 ? map[(size_t)a_idx + (size_t)vlen * (c / wa)] : map[(size_t)a_idx + (size_t)vlen * r_idx]);
         }
         __syncthreads();
         // The reference adds in order, `float += double` rounded at every step (:216): a chain of three dependent double-precision
@@ -181,10 +187,10 @@ __global__ __launch_bounds__(256) void ra_finalize_kernel(const float2* __restri
 
 int launch_ra_finalize(jrc_ctx* ctx, const float2* d_map, size_t map_stride, const PeakPartial* d_partials,
                        int partials_per_frame, const RaParams& prm, const float* d_range_bins,
-                       const float* d_angle_bins, jrc_ra_result* d_results, int n_frames, hipStream_t stream)
+                       const float* d_angle_bins, jrc_ra_result* d_results, int n_frames, int win_rows, hipStream_t stream)
 {
     hipLaunchKernelGGL(ra_finalize_kernel, dim3(n_frames), dim3(256), 0, stream, d_map, map_stride, d_partials,
-                       partials_per_frame, prm, d_range_bins, d_angle_bins, d_results, ctx->tune.ra_ref_sum ? 1 : 0);
+                       partials_per_frame, prm, d_range_bins, d_angle_bins, d_results, ctx->tune.ra_ref_sum ? 1 : 0, win_rows);
     JRC_HIP(ctx, hipGetLastError());
     return JRC_OK;
 }
@@ -231,7 +237,7 @@ extern "C" int jrc_ra_estimate(jrc_ctx* ctx, int vlen, int n_inputs, const jrc_c
     prm.noise_discard_range_m = noise_discard_range_m; prm.noise_discard_angle_deg = noise_discard_angle_deg;
     const float* d_rb = (const float*)ctx->scratch[1];
     JRC_TRY(launch_ra_finalize(ctx, (const float2*)ctx->scratch[0], total, d_part, n_blocks, prm, d_rb,
-                               d_rb + n_range_bins, d_res, 1, ctx->stream));
+                               d_rb + n_range_bins, d_res, 1, 0, ctx->stream));
     jrc_ra_result* h_res = (jrc_ra_result*)(hp + map_bytes + bins_bytes);
     JRC_HIP(ctx, hipMemcpyAsync(h_res, d_res, sizeof(jrc_ra_result), hipMemcpyDeviceToHost, ctx->stream));
     JRC_HIP(ctx, hipStreamSynchronize(ctx->stream));

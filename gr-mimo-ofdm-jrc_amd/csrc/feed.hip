@@ -123,6 +123,32 @@ extern "C" int jrc_chain_feed_stats(const jrc_chain_feed* fd, long* graph_replay
     return JRC_OK;
 }
 
+extern "C" int jrc_chain_feed_set_background(jrc_chain_feed* fd, int background_removal, int background_recording, int record_len)
+{
+    if (!fd) return JRC_ERR_INVALID_ARG;
+    if (fd->in_flight) return jrc_fail(fd->ctx, JRC_ERR_INVALID_ARG, "jrc_chain_feed_set_background: collect the batches in flight first");
+    JRC_TRY(jrc_chain_set_background(fd->slots[0].chain, background_removal, background_recording, record_len));
+    if (!background_removal && !background_recording && jrc_chain_background_size(fd->slots[0].chain) == 0) return JRC_OK;
+    for (int i = 1; i < fd->n_slots; i++) JRC_TRY(jrc_chain_share_background(fd->slots[(size_t)i].chain, fd->slots[0].chain));
+    for (auto& s : fd->slots) {          // the history buffers alternate from batch to batch: no fixed graph
+        if (s.graph) { (void)hipGraphExecDestroy(s.graph); s.graph = nullptr; }
+        s.graph_failed = true;
+    }
+    return JRC_OK;
+}
+
+extern "C" int jrc_chain_feed_set_write_map(jrc_chain_feed* fd, int write_map)
+{
+    if (!fd) return JRC_ERR_INVALID_ARG;
+    if (fd->in_flight) return jrc_fail(fd->ctx, JRC_ERR_INVALID_ARG, "jrc_chain_feed_set_write_map: collect the batches in flight first");
+    if (!write_map && fd->maps_per_slot) return jrc_fail(fd->ctx, JRC_ERR_INVALID_ARG, "jrc_chain_feed_set_write_map: the feed copies maps back (maps_per_slot > 0)");
+    for (auto& s : fd->slots) {
+        JRC_TRY(jrc_chain_set_write_map(s.chain, write_map));
+        if (s.graph) { (void)hipGraphExecDestroy(s.graph); s.graph = nullptr; }      // recorded with the other kernels: record again
+    }
+    return JRC_OK;
+}
+
 extern "C" int jrc_chain_feed_acquire(jrc_chain_feed* fd, jrc_cf32** h_frames)
 {
     if (!fd || !h_frames) return JRC_ERR_INVALID_ARG;

@@ -40,5 +40,6 @@ int launch_ra_partial(jrc_ctx* ctx, const float2* d_map, size_t total, PeakParti
                       hipStream_t stream);
 int launch_ra_finalize(jrc_ctx* ctx, const float2* d_map, size_t map_stride, const PeakPartial* d_partials,
                        int partials_per_frame, const RaParams& prm, const float* d_range_bins,
-                       const float* d_angle_bins, jrc_ra_result* d_results, int n_frames, hipStream_t stream);
+                       const float* d_angle_bins, jrc_ra_result* d_results, int n_frames, int win_rows /* 0: d_map is the full map */,
+                       hipStream_t stream);
 void ra_finish_host(jrc_ra_result* r, float snr_threshold, float power_threshold);

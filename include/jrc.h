@@ -208,6 +208,28 @@ int  jrc_chain_get_timing(jrc_chain* chain, float ms[3], int* launches);
 /* launches of the dominant kernel per jrc_chain_run_dev of n_frames (a batch beyond one resident wave of workgroups runs in chunks) */
 int  jrc_chain_launches_per_run(const jrc_chain* chain, int n_frames);
 
+/* Background recording / removal of mimo_ofdm_radar (lib/mimo_ofdm_radar_impl.cc:276-300; make() arguments background_removal,
+ * background_recording, record_len, include/mimo_ofdm_jrc/mimo_ofdm_radar.h:52-56; setter set_background_record :61) for the batched
+ * chain.  The frames of a batch are consecutive frames of ONE radar stream: frame f's estimate has the mean of the <= record_len
+ * estimates recorded before it subtracted (oldest first, each term divided by the count, exactly :281-292), across batches; the
+ * history lives on the device.  Without this call the chain behaves as a block built with both flags false.  May be called between
+ * batches to switch recording / removal; record_len is fixed by the first call. */
+int  jrc_chain_set_background(jrc_chain* chain, int background_removal, int background_recording, int record_len);
+/* `chain` continues the stream of `owner` (same shape, same GPU): both advance one history; batches are ordered by an event, so the
+ * chains may run on different streams (the slots of a jrc_chain_feed) */
+int  jrc_chain_share_background(jrc_chain* chain, jrc_chain* owner);
+/* entries in the history (the reference's radar_chan_est_buffer.size()) */
+int  jrc_chain_background_size(const jrc_chain* chain);
+/* channel estimate + history update only, outputs dropped.  A GPU that owns frames [lo, hi) of a sharded stream first primes with
+ * frames [lo - min(record_len, lo), lo): its history then equals the one a single GPU would hold at frame lo. */
+int  jrc_chain_prime_background_dev(jrc_chain* chain, int n_frames, const jrc_cf32* d_frames, void* stream);
+
+/* Detect-only mode.  write_map = 0: jrc_chain_run_dev / _td_dev store no range-angle map (d_map is ignored and may be NULL); the
+ * arg-max runs on the values in registers and the estimator's noise-window rows (lib/range_angle_estimator_impl.cc:197-226) are
+ * re-computed by the same kernel code into a small buffer, so d_results is bit-identical to write_map = 1.  For consumers that only
+ * take range_angle_estimator's `params` message (:234-253).  Fused-kernel shapes only (else JRC_ERR_UNSUPPORTED). */
+int  jrc_chain_set_write_map(jrc_chain* chain, int write_map);
+
 /* ---- host-fed pipeline over the chain: what a GNU Radio work() hands over is HOST memory (the T+R input ring buffers of
  *      mimo_ofdm_radar, lib/mimo_ofdm_radar_impl.cc:207-238) and what leaves the radar branch is one small record per
  *      frame (the PDU of lib/range_angle_estimator_impl.cc:199-235).  `n_slots` batches of up to `frames_per_slot` frames
@@ -233,6 +255,11 @@ int    jrc_chain_feed_submit(jrc_chain_feed* feed, const jrc_cf32* h_frames, int
 int    jrc_chain_feed_collect(jrc_chain_feed* feed, jrc_ra_result* results, jrc_cf32* maps, int* n_frames);
 int    jrc_chain_feed_pending(const jrc_chain_feed* feed);        /* batches in flight */
 int    jrc_chain_feed_stats(const jrc_chain_feed* feed, long* graph_replays, long* direct_submits);
+/* background recording / removal for the stream the feed carries (see jrc_chain_set_background): the slots share one history and
+ * consecutive batches are ordered across their streams; hipGraph replay is switched off (the history pointers alternate) */
+int    jrc_chain_feed_set_background(jrc_chain_feed* feed, int background_removal, int background_recording, int record_len);
+/* detect-only mode for every slot (see jrc_chain_set_write_map); maps_per_slot must be 0 */
+int    jrc_chain_feed_set_write_map(jrc_chain_feed* feed, int write_map);
 
 /* ---- D  range-Doppler map — NO reference counterpart (the reference sums over symbols,
  *          lib/mimo_ofdm_radar_impl.cc:271-274); defined by this build, parity unpinned by construction:

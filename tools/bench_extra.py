@@ -67,6 +67,42 @@ def radar_with_demod(cfg="B", F=256):
                 frames_per_s_separate_demod=F / t_unfused, ms_chain_only=t_chain * 1e3, frames_per_s_chain_only=F / t_chain)
 
 
+def detect_only(cfg="B", F=None):
+    """detect-only chain mode (SURVEY §8(d) 'if the map is not materialised'): A1 -> fused transforms + arg-max without map stores ->
+    noise-window rows -> estimator epilogue; algorithmic bytes per frame = inputs + the 48-byte result"""
+    sc = {"B": synth.config_B, "D": synth.config_D}[cfg]()
+    F = F or (512 if cfg == "B" else 256)
+    Ir, Ia, P = 8, 16, sc.T * sc.R
+    rb, ab = jrc_amd.radar_axes(sc.N, sc.fs, Ir, P, Ia)
+    ctx = jrc_amd.Context(0)
+    chain = jrc_amd.RadarChain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb, ab, 2.4, 14.36, 15.0, 0.0, max_frames=F, ctx=ctx)
+    bufs = chain.alloc(F, "cuda:0")
+    fr = synth.make_frames(sc, 8)
+    hf = torch.from_numpy(fr.view(np.float32).reshape((8,) + tuple(bufs["frames"].shape[1:])))
+    for f0 in range(0, F, 8):
+        bufs["frames"][f0:f0 + 8].copy_(hf[:min(8, F - f0)])
+    torch.cuda.synchronize()
+    chain.run(bufs, F)
+    want = bytes(bufs["results"].cpu().numpy().tobytes())
+    t_map = timed(lambda: chain.run(bufs, F))
+    chain.set_write_map(False)
+    del bufs["map"]
+    bufs["map"] = None
+    torch.cuda.empty_cache()
+    chain.run(bufs, F)
+    ctx.sync()
+    same = bytes(bufs["results"].cpu().numpy().tobytes()) == want
+    chain.set_timing(True)
+    t = timed(lambda: chain.run(bufs, F))
+    kt = chain.get_timing()
+    alg = F * ((sc.T + sc.R) * sc.S * sc.N * 8 + 48)
+    return dict(what="detect-only chain (no map stored; results bit-identical to map mode), config %s, %d frames per step" % (cfg, F),
+                frames_per_step=F, ms_per_step=t * 1e3, frames_per_s=F / t, results_equal_map_mode=bool(same),
+                algorithmic_bytes_per_frame=alg // F, GBps_algorithmic=alg / t / 1e9, frac_of_hbm_peak=alg / t / 1e9 / 8000.0,
+                kernels_ms={"radar_chanest": kt["radar_chanest"], "fused_detect_plus_window": kt["range_angle_fused"], "ra_finalize": kt["ra_finalize"]},
+                ms_per_step_map_mode=t_map * 1e3)
+
+
 def range_doppler(cfg="D", F=8, Id=1):
     """row D (no reference counterpart): D[p][sym][sc] = rx conj(tx) -> IFFT over subcarriers (N*Ir) -> FFT over symbols (S*Id, shifted)"""
     sc = {"B": synth.config_B, "D": synth.config_D}[cfg]()
@@ -231,6 +267,6 @@ def equalizer_config_c(n_frames=2048, lanes=4, S=64, N=256):
 
 if __name__ == "__main__":
     # the two probes that run as child processes go first: once this process holds a GPU context they would time-slice with it
-    for fn in (sync_front_end, comm_rx_chain, lambda: radar_with_demod("B", 512), lambda: radar_with_demod("D", 256), precoder_config_c, lambda: range_doppler("D", 8), lambda: range_doppler("B", 64),
+    for fn in (sync_front_end, comm_rx_chain, lambda: detect_only("B"), lambda: detect_only("D"), lambda: radar_with_demod("B", 512), lambda: radar_with_demod("D", 256), precoder_config_c, lambda: range_doppler("D", 8), lambda: range_doppler("B", 64),
                lambda: simulated_chain("B", 64), lambda: simulated_chain("D", 8), equalizer_config_c):
         print(json.dumps(fn()))
