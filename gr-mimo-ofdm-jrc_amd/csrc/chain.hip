@@ -62,6 +62,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
     int pstride,                         // partial maxima per frame in `partials` (>= WPF; unused slots hold the neutral element)
     int win_rows, int win_off)           // MODE 2: rows of the noise window (2 dr) and its offset from the peak's range bin (NR/2 - dr)
 {
+#pragma clang fp contract(off)          // every rounding of this kernel is spelled out (fmaf / cmul_pin / fft_fwd_small_pin): the three MODEs agree bit for bit
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     __shared__ int s_row0;
     constexpr int NW = NT / 64;
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
             for (int st = 0; st < 6; st++) {   // radix-2 DIF
                 const int half = 32 >> st;
                 const float2 o = make_float2(__shfl_xor(v.x, half), __shfl_xor(v.y, half));
-                v = (lane & half) ? cmul(csub(o, v), t64[st]) : cadd(v, o);
+                v = (lane & half) ? cmul_pin(csub(o, v), t64[st]) : cadd(v, o);
             }
             s_g[p * RA_L + (__brev((unsigned)lane) >> 26)] = v;   // lane holds X[bitrev6(lane)]
         }
@@ -191,8 +192,8 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
                 float2 y[P];
                 y[0] = s_g[ql];
 #pragma unroll
-                for (int p = 1; p < P; p++) y[p] = cmul(s_g[p * RA_L + ql], ta[p]);
-                fft_fwd_small<P>(y);
+                for (int p = 1; p < P; p++) y[p] = cmul_pin(s_g[p * RA_L + ql], ta[p]);
+                fft_fwd_small_pin<P>(y);
                 float2* row = mapf + (size_t)it * NA;
 #pragma unroll
                 for (int u = 0; u < P; u++) row[(Ia * u + r + ahalf) & amask] = y[u];
@@ -209,8 +210,8 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
             float2 y[P];
             y[0] = s_g[ql];
 #pragma unroll
-            for (int p = 1; p < P; p++) y[p] = cmul(s_g[p * RA_L + ql], ta[p]);
-            fft_fwd_small<P>(y);
+            for (int p = 1; p < P; p++) y[p] = cmul_pin(s_g[p * RA_L + ql], ta[p]);
+            fft_fwd_small_pin<P>(y);
             float m = -1.0f;
 #pragma unroll
             for (int u = 0; u < P; u++) {

@@ -47,6 +47,65 @@ __device__ __forceinline__ void fft_fwd_small(float2 (&x)[P])
     }
 }
 
+// ---- the same transform with its arithmetic pinned instruction by instruction -------------------------------------------------------
+// Under hipcc's default -ffp-contract=fast the compiler decides per call site which multiply of a complex product or of a twiddled
+// butterfly it fuses into an FMA, so two kernels that inline the very same source may round differently in the last bit.  The range-angle
+// kernel is instantiated in a map-writing and a detect-only variant whose results must be bit-identical (chain.hip): its complex
+// products and butterflies are spelled out here with explicit fmaf under contraction off — the same instruction count the compiler
+// reaches on its own (2 mul + 2 fma per complex product; one fma per twiddled butterfly output).
+__device__ __forceinline__ float2 cmul_pin(float2 a, float2 b)
+{
+#pragma clang fp contract(off)
+    return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
+}
+
+template <int P, int K>
+struct BflyPin {
+    static __device__ __forceinline__ void run(float2* x, const float2* e, const float2* o)
+    {
+#pragma clang fp contract(off)
+        constexpr int idx = K * (16 / P);   // w_P^K in sixteenths of a turn, 0..7
+        constexpr float R2 = 0.70710678118654752440f;
+        constexpr float C1 = 0.92387953251128675613f, S1 = 0.38268343236508977173f;
+        const float2 v = o[K], a = e[K];
+        float2 lo, hi;                      // a + w v, a - w v
+        if constexpr (idx == 0) {
+            lo = make_float2(a.x + v.x, a.y + v.y); hi = make_float2(a.x - v.x, a.y - v.y);
+        } else if constexpr (idx == 4) {    // w v = (v.y, -v.x)
+            lo = make_float2(a.x + v.y, a.y - v.x); hi = make_float2(a.x - v.y, a.y + v.x);
+        } else if constexpr (idx == 2) {    // w v = ((v.x + v.y) R2, (v.y - v.x) R2)
+            const float s = v.x + v.y, d = v.y - v.x;
+            lo = make_float2(fmaf(s, R2, a.x), fmaf(d, R2, a.y)); hi = make_float2(fmaf(-s, R2, a.x), fmaf(-d, R2, a.y));
+        } else if constexpr (idx == 6) {    // w v = ((v.y - v.x) R2, -(v.x + v.y) R2)
+            const float s = v.x + v.y, d = v.y - v.x;
+            lo = make_float2(fmaf(d, R2, a.x), fmaf(-s, R2, a.y)); hi = make_float2(fmaf(-d, R2, a.x), fmaf(s, R2, a.y));
+        } else {
+            float tx, ty;
+            if constexpr (idx == 1) { tx = fmaf(v.x, C1, v.y * S1); ty = fmaf(v.y, C1, -(v.x * S1)); }
+            else if constexpr (idx == 3) { tx = fmaf(v.x, S1, v.y * C1); ty = fmaf(v.y, S1, -(v.x * C1)); }
+            else if constexpr (idx == 5) { tx = fmaf(v.y, C1, -(v.x * S1)); ty = -fmaf(v.x, C1, v.y * S1); }
+            else { tx = fmaf(v.y, S1, -(v.x * C1)); ty = -fmaf(v.x, S1, v.y * C1); }   // idx == 7
+            lo = make_float2(a.x + tx, a.y + ty); hi = make_float2(a.x - tx, a.y - ty);
+        }
+        x[K] = lo;
+        x[K + P / 2] = hi;
+        if constexpr (K + 1 < P / 2) BflyPin<P, K + 1>::run(x, e, o);
+    }
+};
+
+template <int P>
+__device__ __forceinline__ void fft_fwd_small_pin(float2 (&x)[P])
+{
+    if constexpr (P > 1) {
+        float2 e[P / 2], o[P / 2];
+#pragma unroll
+        for (int k = 0; k < P / 2; k++) { e[k] = x[2 * k]; o[k] = x[2 * k + 1]; }
+        fft_fwd_small_pin<P / 2>(e);
+        fft_fwd_small_pin<P / 2>(o);
+        BflyPin<P, 0>::run(x, e, o);
+    }
+}
+
 // ---- one Stockham autosort pass (radix R in {2,4}) over n points; sources / destinations may be global or LDS ----
 template <int R>
 __device__ __forceinline__ void stockham_pass(const float2* __restrict__ src_g, long src_wrap /* n if ifftshift else 0 */,

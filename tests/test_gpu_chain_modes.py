@@ -192,7 +192,7 @@ def _both_modes(jrc, ctx, sc, Ir, Ia, F, frames=None, interleave=False):
     return full, det, again, ch.results(bufs, F)
 
 
-@pytest.mark.parametrize("cfg,F", [("A", 5), ("A", 300), ("B", 3), ("B", 40), ("D", 2), ("D", 9)])
+@pytest.mark.parametrize("cfg,F", [("A", 5), ("A", 300), ("B", 3), ("B", 40), ("B", 512), ("D", 2), ("D", 9), ("D", 256)])
 def test_detect_only_results_equal_map_mode(jrc, ctx, cfg, F):
     from jrc_amd import synth
     sc = {"A": synth.config_A, "B": synth.config_B, "D": synth.config_D}[cfg]()

@@ -83,6 +83,7 @@ def detect_only(cfg="B", F=None):
         bufs["frames"][f0:f0 + 8].copy_(hf[:min(8, F - f0)])
     torch.cuda.synchronize()
     chain.run(bufs, F)
+    ctx.sync()
     want = bytes(bufs["results"].cpu().numpy().tobytes())
     t_map = timed(lambda: chain.run(bufs, F))
     chain.set_write_map(False)
