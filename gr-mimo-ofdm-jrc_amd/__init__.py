@@ -145,6 +145,9 @@ def load(build_if_missing=False):
     L.jrc_chain_set_write_map.argtypes = [_vp, C.c_int]
     L.jrc_chain_feed_set_background.argtypes = [_vp, C.c_int, C.c_int, C.c_int]
     L.jrc_chain_feed_set_write_map.argtypes = [_vp, C.c_int]
+    L.jrc_chain_feed_create_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(ChainCfg), _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]
+    L.jrc_chain_feed_n_devices.argtypes = [_vp]
+    L.jrc_chain_feed_submit_many.argtypes = [_vp, C.POINTER(_vp), C.POINTER(C.c_int), C.c_int]
     _lib = L
     return L
 
@@ -545,7 +548,9 @@ class ChainFeed:
     def __init__(self, fft_len, N_tx, N_rx, N_sym, N_pre, interp_range, interp_angle, range_bins, angle_bins,
                  noise_discard_range_m, noise_discard_angle_deg, snr_threshold=0.0, power_threshold=0.0,
                  n_items=None, enable_tx_interleave=False, n_slots=3, frames_per_slot=32, maps_per_slot=0,
-                 graph=False, ctx=None):
+                 graph=False, ctx=None, devices=None):
+        """devices=[0, 1, ...]: one host process feeds several GPUs (jrc_chain_feed_create_multi): `n_slots` slots per device, batch k on
+        devices[k % len(devices)], results in submission order"""
         self.ctx = ctx or default_context()
         self.cfg = ChainCfg(fft_len, N_tx, N_rx, N_sym, N_pre, interp_range, interp_angle, int(enable_tx_interleave),
                             n_items if n_items is not None else N_pre + N_sym,
@@ -557,8 +562,16 @@ class ChainFeed:
         assert len(rb) == self.NR and len(ab) == self.NA
         h = _vp()
         L = self.ctx.lib
-        self.ctx.check(L.jrc_chain_feed_create(self.ctx.h, C.byref(self.cfg), _ptr(rb), _ptr(ab), n_slots, frames_per_slot,
-                                               maps_per_slot, FEED_GRAPH if graph else 0, C.byref(h)))
+        if devices:
+            dv = (C.c_int * len(devices))(*devices)
+            st = L.jrc_chain_feed_create_multi(dv, len(devices), C.byref(self.cfg), _ptr(rb), _ptr(ab), n_slots, frames_per_slot,
+                                               maps_per_slot, FEED_GRAPH if graph else 0, C.byref(h))
+            if st != JRC_OK:
+                raise JrcError(st, L.jrc_strerror(st).decode())
+            self.n_slots = n_slots * len(devices)
+        else:
+            self.ctx.check(L.jrc_chain_feed_create(self.ctx.h, C.byref(self.cfg), _ptr(rb), _ptr(ab), n_slots, frames_per_slot,
+                                                   maps_per_slot, FEED_GRAPH if graph else 0, C.byref(h)))
         self.h = h
         self.frame_bytes = L.jrc_chain_feed_frame_bytes(h)
         self.map_bytes = L.jrc_chain_feed_map_bytes(h)
@@ -585,6 +598,17 @@ class ChainFeed:
         n = fr.shape[0] if n_frames is None else n_frames
         assert fr.size * 8 >= n * self.frame_bytes
         self.ctx.check(self.ctx.lib.jrc_chain_feed_submit(self.h, _ptr(fr), n))
+
+    def submit_many(self, batches):
+        """batches: list of complex64 arrays [n_k, T+R, n_items, fft_len]; one per free slot at most; staged and enqueued by the per-device
+        host threads in parallel"""
+        keep = [np.ascontiguousarray(b, np.complex64) for b in batches]
+        ptrs = (_vp * len(keep))(*[_ptr(b) for b in keep])
+        ns = (C.c_int * len(keep))(*[b.shape[0] for b in keep])
+        self.ctx.check(self.ctx.lib.jrc_chain_feed_submit_many(self.h, ptrs, ns, len(keep)))
+
+    def n_devices(self):
+        return self.ctx.lib.jrc_chain_feed_n_devices(self.h)
 
     def collect(self, want_maps=False):
         """oldest batch in flight -> (list of RaResult, maps or None); ([], None) when nothing is in flight"""

@@ -136,6 +136,13 @@ struct EqIo {
 __device__ __forceinline__ float2 demod_point(int bps, float2 z)
 {
     if (bps == 1) return make_float2(z.x > 0 ? 1.0f : -1.0f, 0.f);       // constellation_bpsk
+    if (bps == 4) {
+        // constellation_16qam (gr-digital 3.8, not in the reference tree: recollection, parity unpinned — the table of codec.hip):
+        // decide (re > 0, |re| < 2 level, im > 0, |im| < 2 level) and map back: (+-1|3, +-1|3) * level, not scaled (:511, :567)
+        const float level = 0.316227766016837933f;                         // sqrt(float(0.1)) rounded to float
+        const float a = (fabsf(z.x) < 2 * level) ? 1.0f : 3.0f, b = (fabsf(z.y) < 2 * level) ? 1.0f : 3.0f;
+        return make_float2((z.x > 0 ? a : -a) * level, (z.y > 0 ? b : -b) * level);
+    }
     const float a = 0.707107f;                                             // constellation_qpsk, then /2 (:511-514)
     return make_float2((z.x > 0 ? a : -a) / 2.0f, (z.y > 0 ? a : -a) / 2.0f);
 }
@@ -225,14 +232,13 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
         const int sym = S.symbol_ind;
         if (sym > S.n_ofdm_symbols_SIG + 2 + NL || !S.sig_ok) { n_in++; advance = 0; __syncthreads(); continue; }   // :250-255
 
-        // ---- data symbols without decision feedback (LS, or 16-QAM under STA): all that this call holds, in three phases -----------
+        // ---- data symbols without decision feedback (LS): all that this call holds, in three phases -----------
         // A data symbol depends on the ones before it only through the running noise / signal sums (:484-493, :545), so: (A) each
         // wavefront takes symbols and does their pilot work — residual CFO (:908-922) and the two sums; (B) one lane accumulates the
         // sums in symbol order; (C) every lane equalises its subcarriers symbol after symbol with no barrier in between.  Same
         // expressions as the symbol-at-a-time path below, which keeps the STA estimator and single symbols.
         {
-            const int bps_b = (S.mcs <= 1) ? 1 : (S.mcs <= 3 ? 2 : 4);
-            const bool sta_b = d.estimator == 1 && bps_b <= 2;
+            const bool sta_b = d.estimator == 1;
             int nb = 0;
             if (sym > 2 + NL && !sta_b && (S.packet_type == 1 || S.packet_type == 2)) {
                 nb = io.ninput - n_in;
@@ -584,7 +590,7 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
             __syncthreads();
             const float2 rot = s_rot;           // Y is de-rotated on the fly (:480-482): it is not needed after this symbol
             const int bps = (S.mcs <= 1) ? 1 : (S.mcs <= 3 ? 2 : 4);
-            const bool sta = d.estimator == 1 && bps <= 2;
+            const bool sta = d.estimator == 1;
             float2* o = out + (size_t)n_out * ND;
             if (S.packet_type == 1) {
                 const float alpha = 0.5f;                                               // STA :498-535

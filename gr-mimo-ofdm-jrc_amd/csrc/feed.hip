@@ -14,11 +14,23 @@
 // Hence a flag, off by default: latency-critical callers set it, throughput-bound ones do not.
 //
 // Order is preserved: slots are submitted and collected round-robin, results come back in submission order.
+//
+// Several GPUs from one host process (jrc_chain_feed_create_multi): the slots are dealt round-robin over the devices — batch k runs on
+// device k mod n — each device with its own context, streams and buffers, and ONE HOST THREAD PER GPU: jrc_chain_feed_submit_many hands
+// one batch to every device's thread, which stages it (pageable -> pinned copy, the host-side cost that does not overlap otherwise),
+// enqueues it and returns the caller's buffers; submission order, hence result order, is that of the batches.  Frames are independent
+// (SURVEY.md §8(e)), so there is no exchange between the devices.
 #include "jrc_internal.h"
 #include "radar_kernels.h"
 
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+
 
 struct feed_slot {
+    jrc_ctx* ctx = nullptr;              // the context (GPU) this slot lives on
     jrc_chain* chain = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
@@ -46,7 +58,34 @@ struct jrc_chain_feed {
     int tail = 0;       // oldest slot in flight
     int in_flight = 0;
     long graph_replays = 0, direct_submits = 0;
+    // multi-device feeds own their contexts and one worker thread per device
+    std::vector<jrc_ctx*> owned_ctx;
+    struct worker {
+        std::thread th;
+        std::mutex m;
+        std::condition_variable cv;
+        std::function<int()> job;        // at most one job at a time per device
+        bool has_job = false, done = false, stop = false;
+        int status = JRC_OK;
+    };
+    std::vector<worker*> workers;
+    int n_devices = 1;
 };
+
+static void feed_worker_main(jrc_chain_feed::worker* w)
+{
+    std::unique_lock<std::mutex> lk(w->m);
+    for (;;) {
+        w->cv.wait(lk, [&] { return w->has_job || w->stop; });
+        if (w->stop) return;
+        std::function<int()> job = std::move(w->job);
+        lk.unlock();
+        const int st = job();
+        lk.lock();
+        w->status = st; w->has_job = false; w->done = true;
+        w->cv.notify_all();
+    }
+}
 
 static void feed_free_slot(feed_slot& s)
 {
@@ -67,35 +106,45 @@ static void feed_free_slot(feed_slot& s)
 extern "C" void jrc_chain_feed_destroy(jrc_chain_feed* fd)
 {
     if (!fd) return;
-    (void)hipSetDevice(fd->ctx->device);
-    for (auto& s : fd->slots)
+    for (auto* w : fd->workers) {
+        { std::lock_guard<std::mutex> lk(w->m); w->stop = true; }
+        w->cv.notify_all();
+        if (w->th.joinable()) w->th.join();
+        delete w;
+    }
+    for (auto& s : fd->slots) {
+        if (s.ctx) (void)hipSetDevice(s.ctx->device);
         if (s.stream) (void)hipStreamSynchronize(s.stream);
-    for (auto& s : fd->slots) feed_free_slot(s);
+    }
+    for (auto& s : fd->slots) { if (s.ctx) (void)hipSetDevice(s.ctx->device); feed_free_slot(s); }
+    for (auto* c : fd->owned_ctx) jrc_destroy(c);
     delete fd;
 }
 
-extern "C" int jrc_chain_feed_create(jrc_ctx* ctx, const jrc_chain_cfg* cfg, const float* range_bins, const float* angle_bins,
-                                     int n_slots, int frames_per_slot, int maps_per_slot, int flags, jrc_chain_feed** out)
+static int feed_create(const std::vector<jrc_ctx*>& ctxs, bool own, const jrc_chain_cfg* cfg, const float* range_bins, const float* angle_bins,
+                       int n_slots, int frames_per_slot, int maps_per_slot, int flags, jrc_chain_feed** out)
 {
-    if (!ctx || !cfg || !range_bins || !angle_bins || !out) return JRC_ERR_INVALID_ARG;
-    if (n_slots < 1 || n_slots > 16 || frames_per_slot < 1 || maps_per_slot < 0 || maps_per_slot > frames_per_slot)
-        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_feed_create: need 1..16 slots, >= 1 frame per slot, 0 <= maps_per_slot <= frames_per_slot");
-    JRC_HIP(ctx, hipSetDevice(ctx->device));
+    jrc_ctx* ctx = ctxs[0];
     jrc_chain_feed* fd = new jrc_chain_feed();
     fd->ctx = ctx; fd->cfg = *cfg; fd->n_slots = n_slots; fd->fps = frames_per_slot; fd->maps_per_slot = maps_per_slot; fd->flags = flags;
+    fd->n_devices = (int)ctxs.size();
+    if (own) fd->owned_ctx = ctxs;
     fd->slots.resize((size_t)n_slots);
     int st = JRC_OK;
     for (int i = 0; i < n_slots && st == JRC_OK; i++) {
         feed_slot& s = fd->slots[(size_t)i];
-        st = jrc_chain_create(ctx, cfg, range_bins, angle_bins, frames_per_slot, &s.chain);
-        if (st != JRC_OK) break;
+        s.ctx = ctxs[(size_t)i % ctxs.size()];                 // batch k -> device k mod n
+        hipError_t e = hipSetDevice(s.ctx->device);
+        if (e != hipSuccess) { st = jrc_fail(ctx, JRC_ERR_HIP, "jrc_chain_feed_create: %s", hipGetErrorString(e)); break; }
+        st = jrc_chain_create(s.ctx, cfg, range_bins, angle_bins, frames_per_slot, &s.chain);
+        if (st != JRC_OK) { if (s.ctx != ctx) jrc_fail(ctx, st, "%s", jrc_last_error(s.ctx)); break; }
         if (i == 0) {
             fd->frame_elems = jrc_chain_frame_bytes(s.chain) / sizeof(float2);
             fd->chanest_elems = jrc_chain_chanest_bytes(s.chain) / sizeof(float2);
             fd->map_elems = jrc_chain_map_bytes(s.chain) / sizeof(float2);
         }
         const size_t F = (size_t)frames_per_slot;
-        hipError_t e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+        e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
         if (e == hipSuccess) e = hipHostMalloc((void**)&s.h_frames, sizeof(float2) * F * fd->frame_elems, hipHostMallocDefault);
         if (e == hipSuccess) e = hipHostMalloc((void**)&s.h_results, sizeof(jrc_ra_result) * F, hipHostMallocDefault);
@@ -107,10 +156,52 @@ extern "C" int jrc_chain_feed_create(jrc_ctx* ctx, const jrc_chain_cfg* cfg, con
         if (e == hipSuccess) e = hipMalloc((void**)&s.d_results, sizeof(jrc_ra_result) * F);
         if (e != hipSuccess) st = jrc_fail(ctx, JRC_ERR_HIP, "jrc_chain_feed_create: %s", hipGetErrorString(e));
     }
-    if (st != JRC_OK) { jrc_chain_feed_destroy(fd); return st; }
+    if (st == JRC_OK && fd->n_devices > 1)
+        for (int d = 0; d < fd->n_devices; d++) {
+            auto* w = new jrc_chain_feed::worker();
+            w->th = std::thread(feed_worker_main, w);
+            fd->workers.push_back(w);
+        }
+    if (st != JRC_OK) {
+        std::string msg = ctx->last_error;
+        if (own) fd->owned_ctx.clear();                         // the caller of feed_create destroys them after reading the message
+        jrc_chain_feed_destroy(fd);
+        ctx->last_error = msg;
+        return st;
+    }
     *out = fd;
     return JRC_OK;
 }
+
+extern "C" int jrc_chain_feed_create(jrc_ctx* ctx, const jrc_chain_cfg* cfg, const float* range_bins, const float* angle_bins,
+                                     int n_slots, int frames_per_slot, int maps_per_slot, int flags, jrc_chain_feed** out)
+{
+    if (!ctx || !cfg || !range_bins || !angle_bins || !out) return JRC_ERR_INVALID_ARG;
+    if (n_slots < 1 || n_slots > 16 || frames_per_slot < 1 || maps_per_slot < 0 || maps_per_slot > frames_per_slot)
+        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_feed_create: need 1..16 slots, >= 1 frame per slot, 0 <= maps_per_slot <= frames_per_slot");
+    return feed_create(std::vector<jrc_ctx*>{ctx}, false, cfg, range_bins, angle_bins, n_slots, frames_per_slot, maps_per_slot, flags, out);
+}
+
+extern "C" int jrc_chain_feed_create_multi(const int* devices, int n_devices, const jrc_chain_cfg* cfg, const float* range_bins,
+                                           const float* angle_bins, int slots_per_device, int frames_per_slot, int maps_per_slot, int flags,
+                                           jrc_chain_feed** out)
+{
+    if (!devices || n_devices < 1 || n_devices > 64 || !cfg || !range_bins || !angle_bins || !out) return JRC_ERR_INVALID_ARG;
+    if (slots_per_device < 1 || slots_per_device * n_devices > 128 || frames_per_slot < 1 || maps_per_slot < 0 || maps_per_slot > frames_per_slot)
+        return JRC_ERR_INVALID_ARG;
+    std::vector<jrc_ctx*> ctxs;
+    int st = JRC_OK;
+    for (int d = 0; d < n_devices && st == JRC_OK; d++) {
+        jrc_ctx* c = nullptr;
+        st = jrc_create(devices[d], &c);
+        if (st == JRC_OK) ctxs.push_back(c);
+    }
+    if (st == JRC_OK) st = feed_create(ctxs, true, cfg, range_bins, angle_bins, slots_per_device * n_devices, frames_per_slot, maps_per_slot, flags, out);
+    if (st != JRC_OK) for (auto* c : ctxs) jrc_destroy(c);
+    return st;
+}
+
+extern "C" int jrc_chain_feed_n_devices(const jrc_chain_feed* fd) { return fd ? fd->n_devices : JRC_ERR_INVALID_ARG; }
 
 extern "C" size_t jrc_chain_feed_frame_bytes(const jrc_chain_feed* fd) { return fd ? fd->frame_elems * sizeof(float2) : 0; }
 extern "C" size_t jrc_chain_feed_map_bytes(const jrc_chain_feed* fd) { return fd ? fd->map_elems * sizeof(float2) : 0; }
@@ -127,6 +218,9 @@ extern "C" int jrc_chain_feed_set_background(jrc_chain_feed* fd, int background_
 {
     if (!fd) return JRC_ERR_INVALID_ARG;
     if (fd->in_flight) return jrc_fail(fd->ctx, JRC_ERR_INVALID_ARG, "jrc_chain_feed_set_background: collect the batches in flight first");
+    if (fd->n_devices > 1 && (background_removal || background_recording))
+        return jrc_fail(fd->ctx, JRC_ERR_UNSUPPORTED, "background removal: the frames of one radar stream stay in order on one GPU (one feed per stream; "
+                        "shard streams, or blocks primed with jrc_chain_prime_background_dev, over GPUs)");
     JRC_TRY(jrc_chain_set_background(fd->slots[0].chain, background_removal, background_recording, record_len));
     if (!background_removal && !background_recording && jrc_chain_background_size(fd->slots[0].chain) == 0) return JRC_OK;
     for (int i = 1; i < fd->n_slots; i++) JRC_TRY(jrc_chain_share_background(fd->slots[(size_t)i].chain, fd->slots[0].chain));
@@ -163,7 +257,7 @@ extern "C" int jrc_chain_feed_acquire(jrc_chain_feed* fd, jrc_cf32** h_frames)
 // the whole slot on its stream: copy in, A1 -> A5, results (and the first maps) out
 static int feed_enqueue(jrc_chain_feed* fd, feed_slot& s, int n)
 {
-    jrc_ctx* ctx = fd->ctx;
+    jrc_ctx* ctx = s.ctx;
     JRC_HIP(ctx, hipMemcpyAsync(s.d_frames, s.h_frames, sizeof(float2) * (size_t)n * fd->frame_elems, hipMemcpyHostToDevice, s.stream));
     JRC_TRY(jrc_chain_run_dev(s.chain, n, (const jrc_cf32*)s.d_frames, (jrc_cf32*)s.d_chanest, (jrc_cf32*)s.d_map, s.d_results, (void*)s.stream));
     JRC_HIP(ctx, hipMemcpyAsync(s.h_results, s.d_results, sizeof(jrc_ra_result) * (size_t)n, hipMemcpyDeviceToHost, s.stream));
@@ -173,21 +267,15 @@ static int feed_enqueue(jrc_chain_feed* fd, feed_slot& s, int n)
     return JRC_OK;
 }
 
-extern "C" int jrc_chain_feed_submit(jrc_chain_feed* fd, const jrc_cf32* h_frames, int n_frames)
+// stage (when the frames come from pageable memory) and enqueue one slot; runs on the calling thread or on the slot's device thread
+static int feed_launch_slot(jrc_chain_feed* fd, feed_slot& s, const jrc_cf32* h_frames, int n_frames, bool threaded_copy, bool* replayed)
 {
-    JRC_TRACE("jrc_chain_feed_submit");
-    if (!fd) return JRC_ERR_INVALID_ARG;
-    jrc_ctx* ctx = fd->ctx;
-    if (n_frames < 1 || n_frames > fd->fps)
-        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_feed_submit: n_frames %d outside [1, %d]", n_frames, fd->fps);
-    feed_slot& s = fd->slots[(size_t)fd->head];
-    if (s.state == 2)
-        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_feed_submit: all %d slots are in flight, collect one first", fd->n_slots);
+    jrc_ctx* ctx = s.ctx;
     if (h_frames && (const float2*)h_frames != s.h_frames) {    // pageable source (a GNU Radio buffer): stage it
-        jrc_host_copy(s.h_frames, h_frames, sizeof(float2) * (size_t)n_frames * fd->frame_elems);   // threaded for large batches
+        const size_t bytes = sizeof(float2) * (size_t)n_frames * fd->frame_elems;
+        if (threaded_copy) jrc_host_copy(s.h_frames, h_frames, bytes);     // one feeder thread: split large copies
+        else memcpy(s.h_frames, h_frames, bytes);                           // a thread per device is already copying
     }
-    if (!h_frames && s.state != 1)
-        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_feed_submit: no host frames given and no acquired buffer to take them from");
     JRC_HIP(ctx, hipSetDevice(ctx->device));
     const bool want_graph = (fd->flags & JRC_FEED_GRAPH) && n_frames == fd->fps && !s.graph_failed && s.warm;
     if (want_graph && !s.graph) {
@@ -207,19 +295,101 @@ extern "C" int jrc_chain_feed_submit(jrc_chain_feed* fd, const jrc_cf32* h_frame
             jrc_fail(ctx, JRC_ERR_HIP, "jrc_chain_feed: graph capture failed (%s), submitting directly", hipGetErrorString(e));
         }
     }
+    *replayed = false;
     if (want_graph && s.graph) {
         JRC_HIP(ctx, hipGraphLaunch(s.graph, s.stream));
-        fd->graph_replays++;
+        *replayed = true;
     } else {
         JRC_TRY(feed_enqueue(fd, s, n_frames));
-        fd->direct_submits++;
         s.warm = true;
     }
     JRC_HIP(ctx, hipEventRecord(s.done, s.stream));
+    return JRC_OK;
+}
+
+static int feed_check_submit(jrc_chain_feed* fd, const feed_slot& s, const jrc_cf32* h_frames, int n_frames)
+{
+    jrc_ctx* ctx = fd->ctx;
+    if (n_frames < 1 || n_frames > fd->fps)
+        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_feed_submit: n_frames %d outside [1, %d]", n_frames, fd->fps);
+    if (s.state == 2)
+        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_feed_submit: all %d slots are in flight, collect one first", fd->n_slots);
+    if (!h_frames && s.state != 1)
+        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_feed_submit: no host frames given and no acquired buffer to take them from");
+    return JRC_OK;
+}
+
+static void feed_mark_submitted(jrc_chain_feed* fd, feed_slot& s, int n_frames, bool replayed)
+{
+    if (replayed) fd->graph_replays++; else fd->direct_submits++;
     s.n_frames = n_frames;
     s.state = 2;
     fd->head = (fd->head + 1) % fd->n_slots;
     fd->in_flight++;
+}
+
+extern "C" int jrc_chain_feed_submit(jrc_chain_feed* fd, const jrc_cf32* h_frames, int n_frames)
+{
+    JRC_TRACE("jrc_chain_feed_submit");
+    if (!fd) return JRC_ERR_INVALID_ARG;
+    feed_slot& s = fd->slots[(size_t)fd->head];
+    JRC_TRY(feed_check_submit(fd, s, h_frames, n_frames));
+    bool replayed = false;
+    const int st = feed_launch_slot(fd, s, h_frames, n_frames, true, &replayed);
+    if (st != JRC_OK) { if (s.ctx != fd->ctx) jrc_fail(fd->ctx, st, "%s", jrc_last_error(s.ctx)); return st; }
+    feed_mark_submitted(fd, s, n_frames, replayed);
+    return JRC_OK;
+}
+
+// up to one batch per device in one call: batch k goes to the next slot (device (head + k) mod n) and is staged and enqueued by that
+// device's own host thread, all of them at once; returns when every batch has left the caller's buffers.  n_batches <= free slots.
+extern "C" int jrc_chain_feed_submit_many(jrc_chain_feed* fd, const jrc_cf32* const* h_frames, const int* n_frames, int n_batches)
+{
+    JRC_TRACE("jrc_chain_feed_submit_many");
+    if (!fd || !h_frames || !n_frames || n_batches < 0) return JRC_ERR_INVALID_ARG;
+    jrc_ctx* ctx = fd->ctx;
+    if (n_batches > fd->n_slots - fd->in_flight)
+        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_feed_submit_many: %d batches but only %d free slots", n_batches, fd->n_slots - fd->in_flight);
+    for (int k = 0; k < n_batches; k++) {
+        if (!h_frames[k]) return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_feed_submit_many: batch %d has no frames", k);
+        JRC_TRY(feed_check_submit(fd, fd->slots[(size_t)((fd->head + k) % fd->n_slots)], h_frames[k], n_frames[k]));
+    }
+    if (fd->workers.empty()) {                                   // single device: one after the other on this thread
+        for (int k = 0; k < n_batches; k++) JRC_TRY(jrc_chain_feed_submit(fd, h_frames[k], n_frames[k]));
+        return JRC_OK;
+    }
+    int done = 0, st_all = JRC_OK;
+    while (done < n_batches) {
+        // a wave of at most one batch per device, so that every device thread holds one job
+        const int wave = n_batches - done < fd->n_devices ? n_batches - done : fd->n_devices;
+        std::vector<bool> replayed((size_t)wave, false);
+        std::vector<char> rp((size_t)wave, 0);
+        for (int k = 0; k < wave; k++) {
+            const int si = (fd->head + k) % fd->n_slots;
+            feed_slot* sp = &fd->slots[(size_t)si];
+            auto* w = fd->workers[(size_t)si % fd->workers.size()];
+            const jrc_cf32* src = h_frames[done + k];
+            const int n = n_frames[done + k];
+            char* flag = &rp[(size_t)k];
+            std::lock_guard<std::mutex> lk(w->m);
+            w->job = [fd, sp, src, n, flag]() { bool r = false; const int st = feed_launch_slot(fd, *sp, src, n, false, &r); *flag = r ? 1 : 0; return st; };
+            w->has_job = true; w->done = false;
+            w->cv.notify_all();
+        }
+        for (int k = 0; k < wave; k++) {
+            const int si = (fd->head + k) % fd->n_slots;
+            auto* w = fd->workers[(size_t)si % fd->workers.size()];
+            std::unique_lock<std::mutex> lk(w->m);
+            w->cv.wait(lk, [&] { return w->done; });
+            if (w->status != JRC_OK && st_all == JRC_OK) { st_all = w->status; jrc_fail(ctx, st_all, "%s", jrc_last_error(fd->slots[(size_t)si].ctx)); }
+        }
+        if (st_all != JRC_OK) return st_all;
+        for (int k = 0; k < wave; k++) {
+            feed_slot& s = fd->slots[(size_t)fd->head];
+            feed_mark_submitted(fd, s, n_frames[done + k], rp[(size_t)k] != 0);
+        }
+        done += wave;
+    }
     return JRC_OK;
 }
 
@@ -227,10 +397,10 @@ extern "C" int jrc_chain_feed_collect(jrc_chain_feed* fd, jrc_ra_result* results
 {
     JRC_TRACE("jrc_chain_feed_collect");
     if (!fd || !results) return JRC_ERR_INVALID_ARG;
-    jrc_ctx* ctx = fd->ctx;
-    JRC_BIND(ctx);
     if (fd->in_flight == 0) { if (n_frames) *n_frames = 0; return 0; }
     feed_slot& s = fd->slots[(size_t)fd->tail];
+    jrc_ctx* ctx = s.ctx;
+    JRC_BIND(ctx);
     JRC_HIP(ctx, hipEventSynchronize(s.done));
     for (int i = 0; i < s.n_frames; i++) {
         results[i] = s.h_results[i];

@@ -30,6 +30,23 @@ int device_from_env()
     return d ? atoi(d) : 0;
 }
 
+// JRC_DEVICES=0,1,2,...: the GPUs a frame-parallel block deals its batches over (empty / unset: the one of JRC_DEVICE)
+std::vector<int> devices_from_env()
+{
+    std::vector<int> out;
+    const char* d = getenv("JRC_DEVICES");
+    if (d)
+        for (const char* p = d; *p;) {
+            char* end = nullptr;
+            const long v = strtol(p, &end, 10);
+            if (end == p) break;
+            out.push_back((int)v);
+            p = *end == ',' ? end + 1 : end;
+        }
+    if (out.empty()) out.push_back(device_from_env());
+    return out;
+}
+
 // one context per block = per scheduler thread
 struct ctx_holder {
     jrc_ctx* ctx = nullptr;
@@ -270,7 +287,8 @@ class radar_chain_impl : public radar_chain {
     int d_fft_len, d_N_tx, d_N_rx, d_n_items, d_fpb, d_slots;
     std::string d_stats_path;
     bool d_stats_record, d_new_stat_started = false;
-    int d_frames_done = 0;
+    int d_frames_done = 0, d_n_devices = 1, d_record_len = 0;
+    bool d_bg_removal = false;
     std::vector<jrc_ra_result> d_res;
 
     static pmt::pmt_t pack(const char* key, float v) { return pmt::list2(pmt::string_to_symbol(key), pmt::init_f32vector(1, &v)); }
@@ -302,7 +320,8 @@ class radar_chain_impl : public radar_chain {
 public:
     radar_chain_impl(int fft_len, int N_tx, int N_rx, int N_sym, int N_pre, int interp_range, int interp_angle, bool interleave,
                      const std::vector<float>& range_bins, const std::vector<float>& angle_bins, float ndr, float nda, float snr_threshold,
-                     float power_threshold, const std::string& stats_path, bool stats_record, int frames_per_batch, int batches_in_flight)
+                     float power_threshold, const std::string& stats_path, bool stats_record, int frames_per_batch, int batches_in_flight,
+                     bool background_removal, bool background_recording, int record_len)
         : jrc_rt::block("radar_chain", jrc_rt::io_signature::make(N_tx + N_rx, N_tx + N_rx, sizeof(gr_complex) * fft_len),
                         jrc_rt::io_signature::make(0, 0, 0)),
           d_fft_len(fft_len), d_N_tx(N_tx), d_N_rx(N_rx), d_n_items(N_pre + N_sym), d_fpb(frames_per_batch), d_slots(batches_in_flight),
@@ -315,7 +334,23 @@ public:
         cfg.interp_range = interp_range; cfg.interp_angle = interp_angle; cfg.enable_tx_interleave = interleave;
         cfg.n_items = d_n_items; cfg.noise_discard_range_m = ndr; cfg.noise_discard_angle_deg = nda;
         cfg.snr_threshold = snr_threshold; cfg.power_threshold = power_threshold;
-        d_c.check(jrc_chain_feed_create(d_c.ctx, &cfg, range_bins.data(), angle_bins.data(), d_slots, d_fpb, 0, 0, &d_feed));
+        const std::vector<int> devs = devices_from_env();
+        if (devs.size() > 1) {         // one host process, several GPUs: batch k on device k mod n, results in frame order (jrc_chain_feed_create_multi)
+            if (background_removal || background_recording)
+                throw std::invalid_argument("[RADAR CHAIN] background removal keeps the frames of a stream on one GPU: unset JRC_DEVICES");
+            int st = jrc_chain_feed_create_multi(devs.data(), (int)devs.size(), &cfg, range_bins.data(), angle_bins.data(), batches_in_flight, d_fpb, 0, 0, &d_feed);
+            if (st != JRC_OK) throw std::runtime_error(std::string("[RADAR CHAIN] jrc_chain_feed_create_multi: ") + jrc_strerror(st));
+            d_slots = batches_in_flight * (int)devs.size();
+        } else {
+            d_c.check(jrc_chain_feed_create(d_c.ctx, &cfg, range_bins.data(), angle_bins.data(), d_slots, d_fpb, 0, 0, &d_feed));
+        }
+        d_n_devices = (int)devs.size();
+        // the block has no stream output: nobody reads the range-angle map, so it is not stored (results are bit-identical); shapes
+        // outside the fused kernel keep the map (JRC_ERR_UNSUPPORTED) — as does JRC_CHAIN_WRITE_MAP=1
+        if (!getenv("JRC_CHAIN_WRITE_MAP")) (void)jrc_chain_feed_set_write_map(d_feed, 0);
+        d_bg_removal = background_removal; d_record_len = record_len;
+        if (background_removal || background_recording)
+            d_c.check(jrc_chain_feed_set_background(d_feed, background_removal, background_recording, record_len));
         d_res.resize((size_t)d_fpb);
         message_port_register_out(pmt::mp("params"));
         set_tag_propagation_policy(TPP_DONT);
@@ -324,6 +359,12 @@ public:
     }
     ~radar_chain_impl() override { jrc_chain_feed_destroy(d_feed); }
     int frames_done() const override { return d_frames_done; }
+    int n_devices() const override { return d_n_devices; }
+    void set_background_record(bool background_record) override
+    {
+        jrc_rt::thread::scoped_lock guard(d_setlock);      // between two general_work calls: every batch of a turn is collected before it returns
+        d_c.check(jrc_chain_feed_set_background(d_feed, d_bg_removal, background_record, d_record_len));
+    }
 
     int general_work(int, gr_vector_int& ninput_items, gr_vector_const_void_star& input_items, gr_vector_void_star&) override
     {
@@ -375,11 +416,12 @@ radar_chain::sptr radar_chain::make(int fft_len, int N_tx, int N_rx, int N_sym, 
                                     bool enable_tx_interleave, std::vector<float> range_bins, std::vector<float> angle_bins,
                                     float noise_discard_range_m, float noise_discard_angle_deg, float snr_threshold, float power_threshold,
                                     const std::string& stats_path, bool stats_record, int frames_per_batch, int batches_in_flight,
-                                    const std::string&, bool)
+                                    const std::string&, bool, bool background_removal, bool background_recording, int record_len)
 {
     return JRC_GET_INITIAL_SPTR(new radar_chain_impl(fft_len, N_tx, N_rx, N_sym, N_pre, interp_range, interp_angle, enable_tx_interleave,
                                                      range_bins, angle_bins, noise_discard_range_m, noise_discard_angle_deg, snr_threshold,
-                                                     power_threshold, stats_path, stats_record, frames_per_batch, batches_in_flight));
+                                                     power_threshold, stats_path, stats_record, frames_per_batch, batches_in_flight,
+                                                     background_removal, background_recording, record_len));
 }
 
 // =================================================================================================

@@ -57,8 +57,12 @@ public:
                      std::vector<float> range_bins, std::vector<float> angle_bins, float noise_discard_range_m,
                      float noise_discard_angle_deg, float snr_threshold, float power_threshold, const std::string& stats_path,
                      bool stats_record, int frames_per_batch = 16, int batches_in_flight = 3,
-                     const std::string& len_tag_key = "packet_len", bool debug = false);
+                     const std::string& len_tag_key = "packet_len", bool debug = false,
+                     // mimo_ofdm_radar's background arguments (include/mimo_ofdm_jrc/mimo_ofdm_radar.h:52-56)
+                     bool background_removal = false, bool background_recording = false, int record_len = 0);
     virtual int frames_done() const = 0;
+    virtual void set_background_record(bool background_record) = 0;      // mimo_ofdm_radar::set_background_record
+    virtual int n_devices() const = 0;                                     // GPUs the block feeds (environment JRC_DEVICES=0,1,...)
 };
 
 class matrix_transpose : virtual public jrc_rt::tagged_stream_block {

@@ -51,6 +51,16 @@ void* jrcb_make_radar_chain(int fft_len, int N_tx, int N_rx, int N_sym, int N_pr
                           std::vector<float>(ab, ab + n_ab), ndr, nda, snr_thr, pow_thr, stats_path, stats_record != 0, frames_per_batch,
                           batches_in_flight))); });
 }
+void* jrcb_make_radar_chain_bg(int fft_len, int N_tx, int N_rx, int N_sym, int N_pre, int interp_range, int interp_angle, int interleave,
+                               const float* rb, int n_rb, const float* ab, int n_ab, float ndr, float nda, float snr_thr, float pow_thr,
+                               const char* stats_path, int stats_record, int frames_per_batch, int batches_in_flight, int bg_removal,
+                               int bg_recording, int record_len)
+{
+    return guard_make([&] { return std::static_pointer_cast<jrc_host::block>(std::shared_ptr<radar_chain>(
+        radar_chain::make(fft_len, N_tx, N_rx, N_sym, N_pre, interp_range, interp_angle, interleave != 0, std::vector<float>(rb, rb + n_rb),
+                          std::vector<float>(ab, ab + n_ab), ndr, nda, snr_thr, pow_thr, stats_path, stats_record != 0, frames_per_batch,
+                          batches_in_flight, "packet_len", false, bg_removal != 0, bg_recording != 0, record_len))); });
+}
 void* jrcb_make_transpose(int input_len, int output_len, int interp)
 {
     return guard_make([&] { return std::static_pointer_cast<jrc_host::block>(std::shared_ptr<matrix_transpose>(
@@ -251,6 +261,11 @@ int jrcb_call_setter(void* h, const char* name, double v)
         if (auto* r = dynamic_cast<mimo_ofdm_radar*>(b.get())) {
             if (n == "set_background_record") { r->set_background_record(v != 0); return 0; }
             if (n == "capture_radar_data") { r->capture_radar_data(v != 0); return 0; }
+        }
+        if (auto* rc = dynamic_cast<radar_chain*>(b.get())) {
+            if (n == "set_background_record") { rc->set_background_record(v != 0); return 0; }
+            if (n == "n_devices") return rc->n_devices();
+            if (n == "frames_done") return rc->frames_done();
         }
         if (auto* e = dynamic_cast<range_angle_estimator*>(b.get())) {
             if (n == "set_snr_threshold") { e->set_snr_threshold((float)v); return 0; }

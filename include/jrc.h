@@ -255,6 +255,17 @@ int    jrc_chain_feed_submit(jrc_chain_feed* feed, const jrc_cf32* h_frames, int
 int    jrc_chain_feed_collect(jrc_chain_feed* feed, jrc_ra_result* results, jrc_cf32* maps, int* n_frames);
 int    jrc_chain_feed_pending(const jrc_chain_feed* feed);        /* batches in flight */
 int    jrc_chain_feed_stats(const jrc_chain_feed* feed, long* graph_replays, long* direct_submits);
+/* Several GPUs fed from one host process.  `devices[n_devices]` (a device may be listed more than once) each get their own context,
+ * `slots_per_device` slots and one host thread; batch k of the submission order runs on devices[k mod n_devices]; results come back in
+ * submission order through the same jrc_chain_feed_acquire / _submit / _collect calls.  Frames are independent units:
+ * there is no exchange between the devices. */
+int    jrc_chain_feed_create_multi(const int* devices, int n_devices, const jrc_chain_cfg* cfg, const float* range_bins,
+                                   const float* angle_bins, int slots_per_device, int frames_per_slot, int maps_per_slot, int flags,
+                                   jrc_chain_feed** feed);
+int    jrc_chain_feed_n_devices(const jrc_chain_feed* feed);
+/* n_batches (<= free slots) batches at once: batch k is staged from h_frames[k] (pageable memory is fine) and enqueued by the host
+ * thread of the device it lands on, all devices in parallel; returns when every batch has left the caller's buffers */
+int    jrc_chain_feed_submit_many(jrc_chain_feed* feed, const jrc_cf32* const* h_frames, const int* n_frames, int n_batches);
 /* background recording / removal for the stream the feed carries (see jrc_chain_set_background): the slots share one history and
  * consecutive batches are ordered across their streams; hipGraph replay is switched off (the history pointers alternate) */
 int    jrc_chain_feed_set_background(jrc_chain_feed* feed, int background_removal, int background_recording, int record_len);

@@ -199,6 +199,15 @@ static cf cexp_f(double x) { float xf = (float)x; return cosf(xf) + I * sinf(xf)
 static cf demod_point(int bps, cf z)
 {
     if (bps == 1) return crealf(z) > 0 ? 1.0f : -1.0f;
+    if (bps == 4) {
+        /* constellation_16qam (gr-digital 3.8, NOT in the tree: recollection, PARITY UNPINNED — same table as oracle/jrc_oracle_codec.c):
+         * decision bits re > 0, |re| < 2 level, im > 0, |im| < 2 level; the point of that value is (+-1|3, +-1|3) * level, level = sqrt(0.1).
+         * The reference does not scale it (bits_per_symbol() != qpsk's, :511, :567). */
+        const float level = sqrtf(0.1f);
+        const float re = crealf(z), im = cimagf(z);
+        const float a = (fabsf(re) < 2 * level) ? 1.0f : 3.0f, b = (fabsf(im) < 2 * level) ? 1.0f : 3.0f;
+        return ((re > 0 ? a : -a) * level) + I * ((im > 0 ? b : -b) * level);
+    }
     /* QPSK: index 2*(im>0)+(re>0) -> (+-0.707107, +-0.707107); the reference then divides by 2 (:511-514) */
     const float a = 0.707107f;
     cf p = (crealf(z) > 0 ? a : -a) + I * (cimagf(z) > 0 ? a : -a);

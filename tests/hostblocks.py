@@ -20,7 +20,7 @@ def lib():
             jrc_amd._build.build_host()
         L = C.CDLL(LIB)
         L.jrcb_last_error.restype = C.c_char_p
-        for name in ("jrcb_make_radar", "jrcb_make_radar2", "jrcb_make_radar_chain", "jrcb_make_transpose", "jrcb_make_estimator", "jrcb_make_cp_remover",
+        for name in ("jrcb_make_radar", "jrcb_make_radar2", "jrcb_make_radar_chain", "jrcb_make_radar_chain_bg", "jrcb_make_transpose", "jrcb_make_estimator", "jrcb_make_cp_remover",
                      "jrcb_make_peak_detect", "jrcb_make_equalizer", "jrcb_make_precoder", "jrcb_make_target_simulator", "jrcb_make_stream_encoder", "jrcb_make_stream_decoder",
                      "jrcb_make_moving_avg", "jrcb_make_frame_detector", "jrcb_make_frame_sync", "jrcb_make_zero_pad", "jrcb_make_frame_generator"):
             getattr(L, name).restype = _vp
@@ -28,6 +28,7 @@ def lib():
         L.jrcb_make_radar2.argtypes = [C.c_int] * 10 + [C.c_char_p]
         L.jrcb_make_transpose.argtypes = [C.c_int] * 3
         L.jrcb_make_radar_chain.argtypes = [C.c_int] * 8 + [_fp, C.c_int, _fp, C.c_int] + [C.c_float] * 4 + [C.c_char_p, C.c_int, C.c_int, C.c_int]
+        L.jrcb_make_radar_chain_bg.argtypes = L.jrcb_make_radar_chain.argtypes + [C.c_int] * 3
         L.jrcb_make_estimator.argtypes = [C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_char_p, C.c_int]
         L.jrcb_make_cp_remover.argtypes = [C.c_int, C.c_int]
         L.jrcb_make_peak_detect.argtypes = [C.c_int, C.c_float, C.c_float, C.c_int]
@@ -115,6 +116,10 @@ class Block:
         assert n > 0
         return json.loads(buf.value.decode())
 
+    def query(self, name):
+        """integer properties of the block behind the setter entry point (n_devices, frames_done)"""
+        return lib().jrcb_call_setter(self.h, name.encode(), 0.0)
+
     def set(self, name, v):
         r = lib().jrcb_call_setter(self.h, name.encode(), float(v))
         if r == -1000:
@@ -128,9 +133,13 @@ def radar(fft_len, N_tx, N_rx, N_sym, N_pre, bg_removal=False, bg_recording=Fals
 
 
 def radar_chain(fft_len, N_tx, N_rx, N_sym, N_pre, interp_range, interp_angle, rb, ab, ndr, nda, snr_thr, pow_thr, stats_path="",
-                stats_record=False, interleave=False, frames_per_batch=16, batches_in_flight=3):
+                stats_record=False, interleave=False, frames_per_batch=16, batches_in_flight=3, bg_removal=False, bg_recording=False, record_len=0):
     rb = np.ascontiguousarray(rb, np.float32)
     ab = np.ascontiguousarray(ab, np.float32)
+    if bg_removal or bg_recording:
+        return Block(lib().jrcb_make_radar_chain_bg(fft_len, N_tx, N_rx, N_sym, N_pre, interp_range, interp_angle, int(interleave), _f(rb), len(rb),
+                                                    _f(ab), len(ab), ndr, nda, snr_thr, pow_thr, stats_path.encode(), int(stats_record),
+                                                    frames_per_batch, batches_in_flight, int(bg_removal), int(bg_recording), record_len))
     return Block(lib().jrcb_make_radar_chain(fft_len, N_tx, N_rx, N_sym, N_pre, interp_range, interp_angle, int(interleave), _f(rb), len(rb),
                                              _f(ab), len(ab), ndr, nda, snr_thr, pow_thr, stats_path.encode(), int(stats_record),
                                              frames_per_batch, batches_in_flight))

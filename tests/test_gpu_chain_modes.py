@@ -263,3 +263,63 @@ def test_feed_in_detect_only_mode(jrc, ctx):
         out[mode] = [_rec(r) for r in got]
         feed.close()
     assert out[True] == out[False] and len(out[True]) == 8
+
+
+# ---- one host process, several GPUs ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0]])
+def test_multi_device_feed_equals_single_device_feed(jrc, ctx, devices):
+    """jrc_chain_feed_create_multi deals the batches round-robin over per-device contexts (here the one GPU of the box, listed several
+    times) and returns results in submission order: result for result what the single-device feed returns, for single submits, in-place
+    (acquire) submits and submit_many (the per-device host threads stage and enqueue in parallel)"""
+    from jrc_amd import synth
+    sc = synth.Scenario(128, 2, 2, 4, targets=[(12.0, -25.0, 0.0, 100.0)])
+    P = sc.T * sc.R
+    rb, ab = jrc.radar_axes(sc.N, sc.fs, 4, P, 8)
+    fps, nb = 3, 11
+    frames = synth.make_frames(sc, fps * nb)
+    frames[:, sc.T:] *= (1.0 + 0.03 * np.arange(fps * nb, dtype=np.float32))[:, None, None, None]
+    batches = [frames[b * fps:(b + 1) * fps] for b in range(nb)]
+    batches[-1] = batches[-1][:2]                                   # a short last batch
+
+    def drain(feed, out, maps):
+        r, m = feed.collect(want_maps=True)
+        out += [_rec(x) for x in r]
+        maps.append(m)
+
+    def run(feed, mode):
+        out, maps = [], []
+        if mode == "many":
+            k = 0
+            while k < nb:
+                free = feed.n_slots - feed.pending()
+                if free == 0:
+                    drain(feed, out, maps)
+                    continue
+                n = min(free, nb - k, len(devices))
+                feed.submit_many(batches[k:k + n])
+                k += n
+        else:
+            for b in range(nb):
+                if feed.pending() == feed.n_slots:
+                    drain(feed, out, maps)
+                if mode == "inplace" and len(batches[b]) == fps:
+                    feed.acquire()[:] = batches[b]
+                    feed.submit(None, fps)
+                else:
+                    feed.submit(batches[b])
+        while feed.pending():
+            drain(feed, out, maps)
+        return out, np.concatenate(maps)
+
+    single = jrc.ChainFeed(sc.N, sc.T, sc.R, sc.S, sc.Npre, 4, 8, rb, ab, 2.4, 29.0, 15.0, 0.0, ctx=ctx, n_slots=2, frames_per_slot=fps, maps_per_slot=1)
+    want, want_maps = run(single, "single")
+    assert len(want) == fps * (nb - 1) + 2
+    for mode in ("single", "inplace", "many"):
+        multi = jrc.ChainFeed(sc.N, sc.T, sc.R, sc.S, sc.Npre, 4, 8, rb, ab, 2.4, 29.0, 15.0, 0.0, ctx=ctx, n_slots=2, frames_per_slot=fps, maps_per_slot=1,
+                              devices=devices, graph=(mode == "inplace"))
+        assert multi.n_devices() == len(devices) and multi.n_slots == 2 * len(devices)
+        got, got_maps = run(multi, mode)
+        assert got == want, mode
+        assert np.array_equal(got_maps, want_maps), mode
+        multi.close()
+    single.close()

@@ -8,7 +8,7 @@ import pytest
 
 import oracle
 from conftest import crandn, rel_err
-from test_oracle_comm import qpsk, through_channel
+from test_oracle_comm import qam16, qpsk, through_channel
 
 pytestmark = pytest.mark.gpu
 NDP, DATA, LS, STA = 1, 2, 0, 1
@@ -128,13 +128,15 @@ def test_precoder_work(jrc, ctx, ofdm64, ptype, steer):
 
 @pytest.mark.parametrize("est", [LS, STA])
 @pytest.mark.parametrize("ptype", [NDP, DATA])
-@pytest.mark.parametrize("mcs", [0, 2, 3])
+@pytest.mark.parametrize("mcs", [0, 2, 3, 4, 5])
 def test_equalizer_whole_frame(jrc, ctx, ofdm64, est, ptype, mcs):
+    """every MCS under both estimators; with 16-QAM (mcs 4, 5) the STA estimator takes its decisions from gr-digital's
+    constellation_16qam (lib/mimo_ofdm_equalizer_impl.cc:127, :505-521, :563-570; table recollected, parity unpinned)"""
     rng = np.random.default_rng(est * 10 + ptype + mcs)
     gp, ge, op, oe = blocks(jrc, ctx, ofdm64, est)
     nbytes = 45
     ns = oracle.n_ofdm_sym(mcs, 48, nbytes)
-    s = qpsk(rng, ns * 48) if mcs >= 2 else (rng.integers(0, 2, ns * 48) * 2 - 1).astype(np.complex64)
+    s = qam16(rng, ns * 48) if mcs >= 4 else qpsk(rng, ns * 48) if mcs >= 2 else (rng.integers(0, 2, ns * 48) * 2 - 1).astype(np.complex64)
     y = through_channel(op.work(s, mcs, ptype, nbytes), crandn(rng, 4), 2e-3, rng)
     y = np.concatenate([crandn(rng, 2, 64), y, crandn(rng, 3, 64)])        # junk before the tag and after the frame
     g = ge.general_work(y, [(2, 0.013)])

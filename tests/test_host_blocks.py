@@ -509,6 +509,60 @@ def test_radar_chain_block_runs_the_five_block_branch_in_one(jrc, ctx, tmp_path)
         hb.radar_chain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb[:-1], ab, 2.4, 28.96, 15.0, 0.0)
 
 
+def _radar_chain_streams(sc, frames, n_items):
+    F = len(frames)
+    tx = [np.ascontiguousarray(np.concatenate([frames[f, t] for f in range(F)])) for t in range(sc.T)]
+    rx = [np.ascontiguousarray(np.concatenate([frames[f, sc.T + r] for f in range(F)])) for r in range(sc.R)]
+    return tx + rx
+
+
+@gpu
+def test_radar_chain_block_over_several_devices_and_with_background(jrc, ctx, monkeypatch):
+    """JRC_DEVICES=0,0: the block deals its batches over two contexts (one host process, a host thread per GPU) and publishes the same
+    messages in the same order as on one device; with background removal the block equals the device chain with the same history"""
+    import hostblocks as hb
+    import torch
+    from jrc_amd import synth
+    sc = synth.Scenario(64, 2, 2, 4, targets=[(9.0, 15.0, 0.0, 80.0)])
+    Ir, Ia, P, F = 4, 8, sc.T * sc.R, 13
+    n_items = sc.Npre + sc.S
+    rb, ab = jrc.radar_axes(sc.N, sc.fs, Ir, P, Ia)
+    frames = synth.make_frames(sc, F)
+    frames[:, sc.T:] *= (1.0 + 0.05 * np.arange(F, dtype=np.float32))[:, None, None, None]
+    ports = _radar_chain_streams(sc, frames, n_items)
+
+    def run_block(**kw):
+        blk = hb.radar_chain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb, ab, 2.4, 28.96, -100.0, 0.0, frames_per_batch=2, batches_in_flight=2, **kw)
+        for f in range(F):
+            blk.tag(0, f * n_items, "packet_len", n_items)
+            blk.tag(sc.T, f * n_items, "packet_len", n_items)
+        assert blk.run(0, ports, []) == 0
+        return blk, [{k: v[0] for k, v in m["msg"]} for m in blk.state()["published"]]
+
+    one, m1 = run_block()
+    assert one.query("n_devices") == 1 and len(m1) == F
+    monkeypatch.setenv("JRC_DEVICES", "0,0")
+    two, m2 = run_block()
+    assert two.query("n_devices") == 2 and two.query("frames_done") == F
+    assert m2 == m1
+    with pytest.raises(ValueError, match="background"):
+        run_block(bg_removal=True, bg_recording=True, record_len=3)
+    monkeypatch.delenv("JRC_DEVICES")
+    # background removal: the chain with the same history is the reference for the block
+    chain = jrc.RadarChain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb, ab, 2.4, 28.96, -100.0, 0.0, max_frames=F, ctx=ctx)
+    chain.set_background(True, True, 3)
+    bufs = chain.alloc(F, "cuda:0")
+    bufs["frames"].copy_(torch.from_numpy(frames.view(np.float32).reshape(bufs["frames"].shape)))
+    torch.cuda.synchronize()
+    chain.run(bufs, F)
+    want = chain.results(bufs, F)
+    blk, mb = run_block(bg_removal=True, bg_recording=True, record_len=3)
+    assert len(mb) == F
+    for f in range(F):
+        assert mb[f] == {"range": want[f].range_val, "angle": want[f].angle_val, "power": want[f].peak_power, "snr": want[f].snr_est}, f
+    assert mb != m1
+
+
 @gpu
 def test_radar_block_capture_writes_radar_chan_csv(jrc, tmp_path):
     """capture_radar_data (lib/mimo_ofdm_radar_impl.cc:348-387): 'HH:MM:SS.mmm, N_tx, N_rx, fft_len:(re,im);...;' + an empty line per

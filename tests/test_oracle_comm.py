@@ -104,6 +104,35 @@ def qpsk(rng, n):
     return pts[rng.integers(0, 4, n)].astype(np.complex64)
 
 
+def qam16(rng, n):
+    return np.array([oracle.constellation_point(4, int(v)) for v in rng.integers(0, 16, n)], np.complex64)
+
+
+@pytest.mark.parametrize("ptype", [NDP, DATA])
+def test_sta_estimator_with_16qam_takes_decisions_from_the_16qam_table(ofdm64, ptype):
+    """STA x 16-QAM (lib/mimo_ofdm_equalizer_impl.cc:505-521, :563-570): the decision-directed update divides by the decided 16-QAM
+    point (unscaled: only QPSK is halved, :511).  On a noise-free channel the decisions are right, so the update leaves the estimate
+    where it is: the STA output equals the LS output to rounding, and both return the transmitted points.  A QPSK-style decision
+    (the former behaviour of this restatement) would pull the estimate away."""
+    rng = np.random.default_rng(5)
+    nbytes, mcs = 60, 4
+    ns = oracle.n_ofdm_sym(mcs, 48, nbytes)
+    s = qam16(rng, ns * 48)
+    assert len(np.unique(np.round(np.abs(s) ** 2 * 10))) == 3               # 0.2, 1.0, 1.8: all three rings present
+    out = {}
+    for est in (LS, STA):
+        pre, eq = make_blocks(ofdm64, est)
+        tx = pre.work(s, mcs, ptype, nbytes)
+        h = crandn(rng, 4) if est == LS else h
+        out[est] = eq.general_work(through_channel(tx, h), [(0, 0.0)])["out"]
+    assert rel_err(out[LS], s.reshape(ns, 48)) < 1e-5
+    assert rel_err(out[STA], out[LS]) < 1e-5
+    # decisions and points agree with the codec's table
+    for z in (0.1 + 0.1j, 0.7 - 0.2j, -0.64 + 0.9j, -0.2 - 0.63j):
+        v = oracle.constellation_decide(4, z)
+        assert abs(oracle.constellation_point(4, v) - z) == min(abs(oracle.constellation_point(4, k) - z) for k in range(16))
+
+
 @pytest.mark.parametrize("est", [LS, STA])
 def test_ndp_frame_round_trip_and_channel_estimate(ofdm64, est):
     rng = np.random.default_rng(1)
