@@ -187,6 +187,7 @@ def _both_modes(jrc, ctx, sc, Ir, Ia, F, frames=None, interleave=False):
     assert torch.equal(b2["chanest"], H)
     ch.set_write_map(True)                       # and back
     bufs["map"].zero_()
+    torch.cuda.synchronize()                     # zero_ runs on torch's stream, the chain on the context's
     ch.run(bufs, F)
     again = [_rec(r) for r in ch.results(bufs, F)]
     return full, det, again, ch.results(bufs, F)
