@@ -66,26 +66,48 @@ struct ctx_holder {
     }
 };
 
-std::string current_date_time()   // lib/utils.cc:295-305
+// Wall-clock stamps of the log files.  Only the two formats are the reference's wire format (lib/utils.cc:302 "%m-%d-%Y %H:%M:%S" for the
+// "NEW RECORD" header lines, :316-317 "%H:%M:%S" + ".mmm" for the per-frame lines read back by mimo_precoder, lib/mimo_precoder_impl.cc:913-953).
+std::string wall_clock(const char* fmt, bool with_millis)
 {
-    time_t now = time(0);
-    struct tm tstruct = *localtime(&now);
-    char buf[80];
-    strftime(buf, sizeof(buf), "%m-%d-%Y %H:%M:%S", &tstruct);
-    return buf;
+    using namespace std::chrono;
+    const system_clock::time_point tp = system_clock::now();
+    const std::time_t secs = system_clock::to_time_t(tp);
+    std::tm parts;
+    localtime_r(&secs, &parts);
+    char text[96];
+    size_t n = std::strftime(text, sizeof(text) - 8, fmt, &parts);
+    if (with_millis) {
+        const long ms = (long)(duration_cast<milliseconds>(tp.time_since_epoch()).count() % 1000);
+        n += (size_t)std::snprintf(text + n, 8, ".%03ld", ms);
+    }
+    return std::string(text, n);
 }
+inline std::string current_date_time() { return wall_clock("%m-%d-%Y %H:%M:%S", false); }
+inline std::string current_date_time2() { return wall_clock("%H:%M:%S", true); }
 
-std::string current_date_time2()   // lib/utils.cc:307-319
-{
-    auto now = std::chrono::system_clock::now();
-    auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(now.time_since_epoch()) % 1000;
-    auto timer = std::chrono::system_clock::to_time_t(now);
-    std::tm bt = *std::localtime(&timer);
-    std::ostringstream oss;
-    oss << std::put_time(&bt, "%H:%M:%S");
-    oss << '.' << std::setfill('0') << std::setw(3) << ms.count();
-    return oss.str();
-}
+// The payload of a message on a PDU port: either a pmt symbol (its characters) or a pair whose cdr is a blob — the two forms
+// stream_encoder accepts (lib/stream_encoder_impl.cc:103-125); anything else is refused with the reference's message.
+struct pdu_view {
+    std::string owned;                   // keeps a symbol's characters alive
+    const uint8_t* bytes = nullptr;
+    int size = 0;
+    explicit pdu_view(const pmt::pmt_t& msg)
+    {
+        if (pmt::is_symbol(msg)) {
+            owned = pmt::symbol_to_string(msg);
+            bytes = reinterpret_cast<const uint8_t*>(owned.data());
+            size = (int)owned.size();
+        } else if (pmt::is_pair(msg)) {
+            const pmt::pmt_t blob = pmt::cdr(msg);
+            bytes = static_cast<const uint8_t*>(pmt::blob_data(blob));
+            size = (int)pmt::blob_length(blob);
+        } else {
+            throw std::invalid_argument("[STREAM ENCODER] Encoder expects PDUs or strings");
+        }
+    }
+    int first_byte() const { return size ? bytes[0] : 0; }      // the packet type travels in the first payload byte (:110, :117)
+};
 
 }  // namespace
 
@@ -920,25 +942,13 @@ public:
     int general_work(int noutput_items, gr_vector_int&, gr_vector_const_void_star&, gr_vector_void_star& output_items) override
     {
         gr_complex* out = (gr_complex*)output_items[0];
-        while (!d_offset) {                                                                          // :88
-            pmt::pmt_t msg(delete_head_nowait(pmt::intern("pdu_in")));
+        if (d_offset == 0) {                                      // nothing left of the previous PDU: fetch the next one (:88-100)
+            const pmt::pmt_t msg = delete_head_nowait(pmt::intern("pdu_in"));
             if (!msg.get()) return 0;
             std::unique_lock<std::mutex> lock(d_mutex);
-            std::string str;
-            const char* data_packet;
-            int packet_size_byte;
-            if (pmt::is_symbol(msg)) {                                                               // :103-112
-                str = pmt::symbol_to_string(msg);
-                packet_size_byte = (int)str.length();
-                data_packet = str.data();
-            } else if (pmt::is_pair(msg)) {                                                          // :113-120
-                packet_size_byte = (int)pmt::blob_length(pmt::cdr(msg));
-                data_packet = reinterpret_cast<const char*>(pmt::blob_data(pmt::cdr(msg)));
-            } else {
-                throw std::invalid_argument("[STREAM ENCODER] Encoder expects PDUs or strings");   // :123
-            }
-            const int packet_type = packet_size_byte ? (unsigned char)data_packet[0] : 0;            // (PACKET_TYPE) first byte
-            if (packet_size_byte + 4 > MAX_PAYLOAD_SIZE) {                                           // :139-143
+            const pdu_view pdu(msg);
+            const int packet_size_byte = pdu.size, packet_type = pdu.first_byte();
+            if (packet_size_byte + 4 > MAX_PAYLOAD_SIZE) {         // payload + CRC-32 beyond the codec's buffers (:139-143)
                 std::cout << "[STREAM ENCODER] Data Packet too Large -> Maximun Packet Size (byte): " << MAX_PAYLOAD_SIZE << std::endl;
                 return 0;
             }
@@ -946,7 +956,7 @@ public:
             if (n_sym < 0) throw std::invalid_argument("wrong encoding");                            // :206-208
             d_symbol_len = n_sym * d_data_len;                                                       // :186
             d_complex_symbols.assign((size_t)d_symbol_len, gr_complex(0, 0));
-            int n = jrc_stream_encode(d_c.ctx, d_mod_encode, d_data_len, (const uint8_t*)data_packet, packet_size_byte, d_scrambler++,
+            int n = jrc_stream_encode(d_c.ctx, d_mod_encode, d_data_len, pdu.bytes, packet_size_byte, d_scrambler++,
                                       (jrc_cf32*)d_complex_symbols.data(), d_symbol_len);
             if (d_scrambler > 127) d_scrambler = 1;                                                  // :171-175
             d_c.check(n);
@@ -955,7 +965,6 @@ public:
             add_item_tag(0, nitems_written(0), pmt::mp("packet_type"), pmt::from_long(packet_type), srcid);
             add_item_tag(0, nitems_written(0), pmt::mp("mcs"), pmt::from_long(d_mod_encode), srcid);
             add_item_tag(0, nitems_written(0), pmt::mp("pdu_len"), pmt::from_long(packet_size_byte + 4), srcid);
-            break;
         }
         const int n_out = std::min(noutput_items, d_symbol_len - d_offset);                          // :253-266
         std::memcpy(out, d_complex_symbols.data() + d_offset, n_out * sizeof(gr_complex));
