@@ -138,3 +138,52 @@ def test_hip_comm_and_next_rows_match_fixtures(jrc, ctx, fx, ofdm64):
     dout, dtags = jrc.frame_detector(64, 16, 0.6, 10, 640, ctx=ctx).run(fx["fd_in"], fx["fd_in_abs"], fx["fd_in_cor"])
     assert dout.shape == fx["fd_out"].shape and rel_err(dout, fx["fd_out"]) < TOL
     assert [t[0] for t in dtags] == list(fx["fd_tags"][:, 0].astype(int)) and np.allclose([t[1] for t in dtags], fx["fd_tags"][:, 1], atol=1e-6)
+
+
+# ---------------------------------------------------------------- the reference flowgraph's own operating point (its Python expressions)
+@pytest.fixture(scope="module")
+def fg():
+    """tests/golden/radar_flowgraph_point.npz: the numbers the reference's radar simulation flowgraph evaluates its block parameters to
+    (minted by tests/golden/make_flowgraph_point_golden.py from the .grc's own Python expressions)"""
+    return np.load(os.path.join(GOLDEN, "radar_flowgraph_point.npz"))
+
+
+def test_host_side_axes_equal_the_flowgraphs_expressions(fg):
+    """jrc_amd.radar_axes is what every test, the bench and the examples hand to the estimator: it must be the flowgraph's
+    range_bins / angle_bins (examples/simulation/radar/mimo_ofdm_jrc_radar_sim.grc:1390-1400) bit for bit as float32"""
+    import jrc_amd
+    N, T, R, S, Npre, rec_len, Ir = (int(v) for v in fg["radar_ints"])
+    Ia = int(fg["var_interp_factor_angle"])
+    rb, ab = jrc_amd.radar_axes(N, float(fg["var_samp_rate"]), Ir, T * R, Ia)
+    assert rb.dtype == np.float32 and np.array_equal(rb, fg["estimator_range_bins_f32"])
+    assert ab.dtype == np.float32 and np.array_equal(ab, fg["estimator_angle_bins_f32"])
+    assert np.array_equal(np.asarray(fg["var_angle_axis"], np.float32), ab)        # the GUI axis is the same expression
+    vlen, ndr, nda, snr_thr, pow_thr = fg["estimator_scalars"]
+    assert (int(vlen), snr_thr, pow_thr) == (T * R * Ia, 15.0, 0.0)
+    assert ndr == 2 * 3e8 / (2 * float(fg["var_samp_rate"])) and nda == 2 * float(np.rad2deg(np.arcsin(2 / (T * R))))
+    # the chain between the blocks: transpose geometry and the two stock FFTs (sizes, direction, shift, rectangular windows)
+    assert list(fg["transpose_ints"]) == [N * Ir, T * R, Ia]
+    assert list(fg["fft_range_size_forward_shift"]) == [N * Ir, 0, 0] and list(fg["fft_angle_size_forward_shift"]) == [T * R * Ia, 1, 1]
+    assert np.all(fg["fft_range_window"] == 1.0) and np.all(fg["fft_angle_window"] == 1.0)
+    assert list(fg["fft_rx_demod_size_forward_shift"]) == [N, 1, 1] and fg["fft_rx_demod_window"].size == 0
+    assert list(fg["fft_tx_mod_size_forward_shift"]) == [N, 0, 1] and np.all(fg["fft_tx_mod_window"] == 1 / 64 ** 0.5)
+    assert (Npre, S, rec_len) == (5, T, 8) and not fg["radar_flags"].any()
+    assert list(fg["cp_remover_ints"]) == [N, N // 4] and int(fg["zero_pad_tail"]) == 3 * (N + N // 4)
+
+
+def test_synthetic_scenario_follows_the_flowgraphs_channel_parameters(fg):
+    """synth.py (the frames the bench and the parity tests consume) uses the flowgraph's noise variance, carrier frequency and virtual
+    array: TXn_RXs of the .grc (:107-153) are element positions (1 + t/2 + 2 r) wavelengths = (r T + t + 2) half-wavelengths"""
+    from jrc_amd import synth
+    T, R = int(fg["var_N_tx"]), int(fg["var_N_rx"])
+    sc = synth.Scenario(int(fg["var_fft_len"]), T, R, T, samp_rate=float(fg["var_samp_rate"]), center_freq=float(fg["var_rf_freq"]),
+                        noise_figure_db=float(fg["var_noise_figure_dB"]))
+    assert sc.noise_var == float(fg["var_noise_var"])
+    assert sc.cp == int(fg["var_cp_len"]) and sc.R_max == float(fg["var_R_max"])
+    lam = float(fg["var_wavelength"])
+    assert lam == synth.C0 / sc.fc
+    for t in range(T):
+        pos = fg["var_TX%d_RXs" % (t + 1)]
+        for r in range(R):
+            assert abs(pos[r] - (r * T + t + 2) * lam / 2) < 1e-15
+    assert float(fg["tsim_scalars"][0]) == 10 ** (float(fg["var_trgt_rcs_dbsm"]) / 10.0)
