@@ -16,7 +16,7 @@ import numpy as np
 from . import build as _build
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libjrc_hip.so")
+LIB_PATH = os.environ.get("JRC_LIB_PATH") or os.path.join(_HERE, "lib", "libjrc_hip.so")    # JRC_LIB_PATH: kernel-variant experiments (tools/ra_variants.py)
 INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
 JRC_OK = 0

@@ -58,7 +58,6 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
     const float2* __restrict__ twR,      // [NR]  exp(+j 2 pi i / NR)
     const float2* __restrict__ twA,      // [NA]  exp(-j 2 pi i / NA)
     int N, int NR, int Ia, int F, int WPF,
-    int nt_tail,                         // the last nt_tail classes of a workgroup are stored non-temporally (see chain_nt_tail)
     int pstride,                         // partial maxima per frame in `partials` (>= WPF; unused slots hold the neutral element)
     int win_rows, int win_off)           // MODE 2: rows of the noise window (2 dr) and its offset from the peak's range bin (NR/2 - dr)
 {
@@ -94,11 +93,11 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
         __syncthreads();
         row0 = s_row0;
     }
+    const int n_iter = MODE == 2 ? win_rows : (C - slice + WPF - 1) / WPF;
     auto class_of = [&](int it) -> int {        // the class this workgroup works on in its it-th trip
         if constexpr (MODE == 2) return (((row0 + it) % NR + NR) % NR) % C;
         else return slice + it * WPF;
     };
-    const int n_iter = MODE == 2 ? win_rows : (C - slice + WPF - 1) / WPF;
     const int c_first = class_of(0);
 
     // class twiddles for this lane's fold inputs n = lane + 64 m:  exp(+j 2 pi n c / NR)
@@ -139,11 +138,9 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
     float2* mapf = MODE == 2 ? map + (size_t)f * win_rows * NA : map + (size_t)f * NR * NA;
 
     typedef float v2f __attribute__((ext_vector_type(2)));
-    const int c_nt = C - nt_tail * WPF;         // classes c >= c_nt are among the last nt_tail of this workgroup
 #pragma unroll 1
     for (int it = 0; it < n_iter; it++) {
         const int c = class_of(it);
-        const bool nt = c >= c_nt;
         if constexpr (TWC_LDS) {
 #pragma unroll
             for (int q = 0; q < NPT; q++) { const int n = tid + NT * q; if (n < N) s_twc[n] = tn[q]; }
@@ -214,14 +211,23 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
             fft_fwd_small_pin<P>(y);
             float m = -1.0f;
 #pragma unroll
-            for (int u = 0; u < P; u++) {
-                if constexpr (MODE == 0) {
-                    float2* row = mapf + (size_t)k * NA;
+            for (int u = 0; u < P; u++) m = fmaxf(m, fast_power(y[u]));
+            if constexpr (MODE == 0) {
+                // The map is write-once data nothing on the GPU reads back except the estimator's few cells: it is stored non-temporally, so
+                // that no dirty lines are left behind for the next (read-bound) kernel to compete with.
+                // Each of a lane's P stores sits behind a wave-uniform branch on a kernel argument (always taken): measured, not cosmetic.
+                // The same stores issued back to back run 10 % slower at config B (0.448 against 0.405 ms per 512 frames), handed out one
+                // by one between the butterflies of the last stage 30 % slower, and with interp_angle compiled in (row offsets as
+                // immediates, 30 fewer registers, no spills) 15-25 % slower in every arrangement — the taken branches space a wave's
+                // stores and keep the workgroups of a launch in step on their classes, which is what the memory system rewards here
+                // (rotating the class order per frame costs 7 %).  tools/ra_variants.py holds the harness; DESIGN.md §3.1 the numbers.
+                float2* row = mapf + (size_t)k * NA;
+#pragma unroll
+                for (int u = 0; u < P; u++) {
                     const int a = (Ia * u + r + ahalf) & amask;   // fftshift: out'[a'] = out[(a' + NA/2) % NA]
-                    if (nt) { v2f t = {y[u].x, y[u].y}; __builtin_nontemporal_store(t, reinterpret_cast<v2f*>(row + a)); }
+                    if (WPF > 0) { const v2f t = {y[u].x, y[u].y}; __builtin_nontemporal_store(t, reinterpret_cast<v2f*>(row + a)); }
                     else row[a] = y[u];
                 }
-                m = fmaxf(m, fast_power(y[u]));
             }
             // estimator arg-max (lib/range_angle_estimator_impl.cc:137-151) on the values still in registers
             const float thr = trk.raise(m);
@@ -353,21 +359,6 @@ static int chain_pick_wpf(const jrc_chain* ch, int n_frames)
     return wpf;
 }
 
-// Map stores that go through the cache hierarchy leave dirty lines behind (L2 / 256 MiB memory-side cache); they are written back
-// while the next kernel — the read-bound channel estimate of the next batch — runs, and the mixed traffic costs that kernel 40 %
-// of its bandwidth (0.168 ms instead of 0.104 ms at config B).  The map is write-once data nobody on the GPU reads before the
-// estimator's few cells, so it is stored non-temporally: the fused kernel itself runs as fast or faster (config D: 0.443 ->
-// 0.413 ms) and the step gains 11-14 %.  Only the tail of a workgroup's classes non-temporal does not help (measured 12-50 %).
-// JRC_NT_FRAC overrides the fraction of classes stored non-temporally (0..1) for experiments.
-static int chain_nt_tail(const jrc_chain* ch, int n_frames, int wpf)
-{
-    const int per_wg = (ch->C + wpf - 1) / wpf;
-    const double frac = ch->ctx->tune.nt_frac;
-    (void)n_frames;
-    int k = (int)(frac * per_wg + 0.999);
-    return k > per_wg ? per_wg : k;
-}
-
 template <int P, int NT, int MMAX, bool TWC_LDS, int MODE>
 static int launch_fused_mode(jrc_chain* ch, int n_frames, int wpf, int pstride, const float2* d_H, float2* d_map, hipStream_t s)
 {
@@ -378,7 +369,7 @@ static int launch_fused_mode(jrc_chain* ch, int n_frames, int wpf, int pstride, 
         if (rows <= 0) return JRC_OK;
         const dim3 grid((unsigned)(((n_frames + 7) / 8) * 8));
         hipLaunchKernelGGL((range_angle_fused_kernel<P, NT, MMAX, TWC_LDS, MODE>), grid, dim3(NT), ch->lds_bytes, s, d_H, ch->d_win, ch->d_partials,
-                           ch->twR, ch->twA, ch->cfg.fft_len, ch->NR, ch->cfg.interp_angle, n_frames, 1, 0, pstride, rows, ch->NR / 2 - ch->win_dr);
+                           ch->twR, ch->twA, ch->cfg.fft_len, ch->NR, ch->cfg.interp_angle, n_frames, 1, pstride, rows, ch->NR / 2 - ch->win_dr);
         JRC_HIP(ch->ctx, hipGetLastError());
         return JRC_OK;
     }
@@ -397,7 +388,7 @@ static int launch_fused_mode(jrc_chain* ch, int n_frames, int wpf, int pstride, 
         hipLaunchKernelGGL((range_angle_fused_kernel<P, NT, MMAX, TWC_LDS, MODE>), grid, dim3(NT), ch->lds_bytes, s,
                            d_H + (size_t)f0 * P * ch->cfg.fft_len, MODE == 0 ? d_map + (size_t)f0 * ch->NR * ch->NA : nullptr,
                            ch->d_partials + (size_t)f0 * pstride,
-                           ch->twR, ch->twA, ch->cfg.fft_len, ch->NR, ch->cfg.interp_angle, nf, w, chain_nt_tail(ch, nf, w), pstride, 0, 0);
+                           ch->twR, ch->twA, ch->cfg.fft_len, ch->NR, ch->cfg.interp_angle, nf, w, pstride, 0, 0);
     }
     JRC_HIP(ch->ctx, hipGetLastError());
     return JRC_OK;

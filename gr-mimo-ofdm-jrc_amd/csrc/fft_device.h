@@ -59,36 +59,39 @@ __device__ __forceinline__ float2 cmul_pin(float2 a, float2 b)
     return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
 }
 
+// one butterfly of the last stage: lo = a + w_P^K v, hi = a - w_P^K v
+template <int P, int K>
+__device__ __forceinline__ void bfly_pin_one(const float2 a, const float2 v, float2& lo, float2& hi)
+{
+#pragma clang fp contract(off)
+    constexpr int idx = K * (16 / P);   // w_P^K in sixteenths of a turn, 0..7
+    constexpr float R2 = 0.70710678118654752440f;
+    constexpr float C1 = 0.92387953251128675613f, S1 = 0.38268343236508977173f;
+    if constexpr (idx == 0) {
+        lo = make_float2(a.x + v.x, a.y + v.y); hi = make_float2(a.x - v.x, a.y - v.y);
+    } else if constexpr (idx == 4) {    // w v = (v.y, -v.x)
+        lo = make_float2(a.x + v.y, a.y - v.x); hi = make_float2(a.x - v.y, a.y + v.x);
+    } else if constexpr (idx == 2) {    // w v = ((v.x + v.y) R2, (v.y - v.x) R2)
+        const float s = v.x + v.y, d = v.y - v.x;
+        lo = make_float2(fmaf(s, R2, a.x), fmaf(d, R2, a.y)); hi = make_float2(fmaf(-s, R2, a.x), fmaf(-d, R2, a.y));
+    } else if constexpr (idx == 6) {    // w v = ((v.y - v.x) R2, -(v.x + v.y) R2)
+        const float s = v.x + v.y, d = v.y - v.x;
+        lo = make_float2(fmaf(d, R2, a.x), fmaf(-s, R2, a.y)); hi = make_float2(fmaf(-d, R2, a.x), fmaf(s, R2, a.y));
+    } else {
+        float tx, ty;
+        if constexpr (idx == 1) { tx = fmaf(v.x, C1, v.y * S1); ty = fmaf(v.y, C1, -(v.x * S1)); }
+        else if constexpr (idx == 3) { tx = fmaf(v.x, S1, v.y * C1); ty = fmaf(v.y, S1, -(v.x * C1)); }
+        else if constexpr (idx == 5) { tx = fmaf(v.y, C1, -(v.x * S1)); ty = -fmaf(v.x, C1, v.y * S1); }
+        else { tx = fmaf(v.y, S1, -(v.x * C1)); ty = -fmaf(v.x, S1, v.y * C1); }   // idx == 7
+        lo = make_float2(a.x + tx, a.y + ty); hi = make_float2(a.x - tx, a.y - ty);
+    }
+}
+
 template <int P, int K>
 struct BflyPin {
     static __device__ __forceinline__ void run(float2* x, const float2* e, const float2* o)
     {
-#pragma clang fp contract(off)
-        constexpr int idx = K * (16 / P);   // w_P^K in sixteenths of a turn, 0..7
-        constexpr float R2 = 0.70710678118654752440f;
-        constexpr float C1 = 0.92387953251128675613f, S1 = 0.38268343236508977173f;
-        const float2 v = o[K], a = e[K];
-        float2 lo, hi;                      // a + w v, a - w v
-        if constexpr (idx == 0) {
-            lo = make_float2(a.x + v.x, a.y + v.y); hi = make_float2(a.x - v.x, a.y - v.y);
-        } else if constexpr (idx == 4) {    // w v = (v.y, -v.x)
-            lo = make_float2(a.x + v.y, a.y - v.x); hi = make_float2(a.x - v.y, a.y + v.x);
-        } else if constexpr (idx == 2) {    // w v = ((v.x + v.y) R2, (v.y - v.x) R2)
-            const float s = v.x + v.y, d = v.y - v.x;
-            lo = make_float2(fmaf(s, R2, a.x), fmaf(d, R2, a.y)); hi = make_float2(fmaf(-s, R2, a.x), fmaf(-d, R2, a.y));
-        } else if constexpr (idx == 6) {    // w v = ((v.y - v.x) R2, -(v.x + v.y) R2)
-            const float s = v.x + v.y, d = v.y - v.x;
-            lo = make_float2(fmaf(d, R2, a.x), fmaf(-s, R2, a.y)); hi = make_float2(fmaf(-d, R2, a.x), fmaf(s, R2, a.y));
-        } else {
-            float tx, ty;
-            if constexpr (idx == 1) { tx = fmaf(v.x, C1, v.y * S1); ty = fmaf(v.y, C1, -(v.x * S1)); }
-            else if constexpr (idx == 3) { tx = fmaf(v.x, S1, v.y * C1); ty = fmaf(v.y, S1, -(v.x * C1)); }
-            else if constexpr (idx == 5) { tx = fmaf(v.y, C1, -(v.x * S1)); ty = -fmaf(v.x, C1, v.y * S1); }
-            else { tx = fmaf(v.y, S1, -(v.x * C1)); ty = -fmaf(v.x, S1, v.y * C1); }   // idx == 7
-            lo = make_float2(a.x + tx, a.y + ty); hi = make_float2(a.x - tx, a.y - ty);
-        }
-        x[K] = lo;
-        x[K + P / 2] = hi;
+        bfly_pin_one<P, K>(e[K], o[K], x[K], x[K + P / 2]);
         if constexpr (K + 1 < P / 2) BflyPin<P, K + 1>::run(x, e, o);
     }
 };
