@@ -153,7 +153,27 @@ def _cpu_stage_times(sc_args, Ir, Ia, frames, axes):
         oracle.ra_estimate(m, rb, ab, ndr, nda, 15.0, 0.0); t.append(time.perf_counter())
         for k, name in enumerate(acc):
             acc[name] += t[k + 1] - t[k]
-    return {k: v / len(frames) for k, v in acc.items()}
+    out = {k: v / len(frames) for k, v in acc.items()}
+    # The reference's two FFT stages are FFTW3f behind gr::fft::fft_vcc, not a scalar radix-2 loop.  FFTW is not in this image; scipy's
+    # pocketfft (C++, SIMD, native float32) is the closest tuned library here: the same two padded transforms through it, for scale.
+    try:
+        import scipy.fft as sfft
+        Hs = [rad.work([fr[k] for k in range(sc.T)], [fr[sc.T + r] for r in range(sc.R)]) for fr in frames]
+        sfft.fft(oracle.matrix_transpose(sfft.ifft(Hs[0], axis=-1, norm="forward", workers=1).astype(np.complex64, copy=False), sc.N * Ir, P, Ia),
+                 axis=-1, workers=1)                                   # plans and twiddles: not timed
+        t0 = time.perf_counter()
+        rngs = [sfft.ifft(H, axis=-1, norm="forward", workers=1).astype(np.complex64, copy=False) for H in Hs]
+        t1 = time.perf_counter()
+        trs = [oracle.matrix_transpose(r_, sc.N * Ir, P, Ia) for r_ in rngs]
+        t2 = time.perf_counter()
+        for tr in trs:
+            sfft.fftshift(sfft.fft(tr, axis=-1, workers=1), axes=-1)
+        t3 = time.perf_counter()
+        out["fft_range_pocketfft"] = (t1 - t0) / len(frames)
+        out["fft_angle_pocketfft"] = (t3 - t2) / len(frames)
+    except Exception:
+        pass
+    return out
 
 
 def cpu_baseline(sc, Ir, Ia, frames, axes, budget_s):
@@ -170,9 +190,15 @@ def cpu_baseline(sc, Ir, Ia, frames, axes, budget_s):
     try:
         # (b) pipeline-ideal: GNU Radio runs one thread per block, so a saturated flowgraph moves at the pace of its slowest block
         st = _cpu_stage_times(sc_args, Ir, Ia, frames[:3], axes)
-        out["pipeline_ideal"] = {"value": 1.0 / max(st.values()), "unit": "frames/s", "cores": len(st),
+        five = {k: v for k, v in st.items() if not k.endswith("_pocketfft")}
+        out["pipeline_ideal"] = {"value": 1.0 / max(five.values()), "unit": "frames/s", "cores": len(five),
                                  "stage_ms": {k: 1e3 * v for k, v in st.items()},
                                  "sample": "1 / slowest block of the five (thread-per-block scheduling), %d frames block by block" % len(frames[:3])}
+        if "fft_angle_pocketfft" in st:      # the same pipeline with a tuned FFT library in the two FFT blocks (the reference uses FFTW3f there)
+            tuned = dict(five, fft_range=st["fft_range_pocketfft"], fft_angle=st["fft_angle_pocketfft"])
+            out["pipeline_ideal"]["value_with_tuned_fft"] = 1.0 / max(tuned.values())
+            out["pipeline_ideal"]["single_thread_with_tuned_fft"] = 1.0 / sum(tuned.values())
+            out["pipeline_ideal"]["tuned_fft"] = "scipy.fft (pocketfft, float32, 1 worker) in place of the port's radix-2 loops for the two FFT stages"
     except Exception as e:
         out["pipeline_ideal"] = {"error": str(e)}
     try:

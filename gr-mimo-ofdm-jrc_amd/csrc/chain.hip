@@ -59,7 +59,8 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
     const float2* __restrict__ twA,      // [NA]  exp(-j 2 pi i / NA)
     int N, int NR, int Ia, int F, int WPF,
     int pstride,                         // partial maxima per frame in `partials` (>= WPF; unused slots hold the neutral element)
-    int win_rows, int win_off)           // MODE 2: rows of the noise window (2 dr) and its offset from the peak's range bin (NR/2 - dr)
+    int win_rows, int win_off,
+    int nx)                              // XCDs the hardware deals consecutive workgroups over (jrc_ctx::n_xcd)           // MODE 2: rows of the noise window (2 dr) and its offset from the peak's range bin (NR/2 - dr)
 {
 #pragma clang fp contract(off)          // every rounding of this kernel is spelled out (fmaf / cmul_pin / fft_fwd_small_pin): the three MODEs agree bit for bit
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
@@ -67,11 +68,11 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
     constexpr int NW = NT / 64;
     const int NA = P * Ia;
     const int C = NR / RA_L;
-    // XCD-aware decode: block b runs on XCD b%8; the slices of a frame share that frame's H,
+    // XCD-aware decode: block b runs on XCD b % nx; the slices of a frame share that frame's H,
     // so keep a frame's workgroups on one XCD (one L2).
-    const int xcd = blockIdx.x & 7;
-    const int j = blockIdx.x >> 3;
-    const int f = (j / WPF) * 8 + xcd;
+    const int xcd = blockIdx.x % nx;
+    const int j = blockIdx.x / nx;
+    const int f = (j / WPF) * nx + xcd;
     const int slice = j % WPF;
     if (f >= F) return;
 
@@ -359,6 +360,15 @@ static int chain_pick_wpf(const jrc_chain* ch, int n_frames)
     return wpf;
 }
 
+// frames per launch: one resident wave of workgroups, a multiple of the XCD count (the decode deals frames over the XCDs in groups)
+static int chain_chunk(const jrc_chain* ch, int wpf)
+{
+    const int nx = ch->ctx->n_xcd;
+    int chunk = (ch->n_cus * ch->wg_per_cu) / wpf;
+    if (chunk < nx) chunk = nx;
+    return chunk - chunk % nx;
+}
+
 template <int P, int NT, int MMAX, bool TWC_LDS, int MODE>
 static int launch_fused_mode(jrc_chain* ch, int n_frames, int wpf, int pstride, const float2* d_H, float2* d_map, hipStream_t s)
 {
@@ -367,28 +377,27 @@ static int launch_fused_mode(jrc_chain* ch, int n_frames, int wpf, int pstride, 
         // window pass of detect-only mode: one workgroup per frame walks the 2 dr rows of its noise window
         const int rows = 2 * ch->win_dr;
         if (rows <= 0) return JRC_OK;
-        const dim3 grid((unsigned)(((n_frames + 7) / 8) * 8));
+        const int nx = ch->ctx->n_xcd;
+        const dim3 grid((unsigned)(((n_frames + nx - 1) / nx) * nx));
         hipLaunchKernelGGL((range_angle_fused_kernel<P, NT, MMAX, TWC_LDS, MODE>), grid, dim3(NT), ch->lds_bytes, s, d_H, ch->d_win, ch->d_partials,
-                           ch->twR, ch->twA, ch->cfg.fft_len, ch->NR, ch->cfg.interp_angle, n_frames, 1, pstride, rows, ch->NR / 2 - ch->win_dr);
+                           ch->twR, ch->twA, ch->cfg.fft_len, ch->NR, ch->cfg.interp_angle, n_frames, 1, pstride, rows, ch->NR / 2 - ch->win_dr, nx);
         JRC_HIP(ch->ctx, hipGetLastError());
         return JRC_OK;
     }
     // One resident wave of workgroups per launch: a batch that needs more is launched in chunks of that size, and a last,
     // smaller chunk gets more slices per frame so that it fills the machine as well (a grid twice the resident size runs 20 %
     // slower than two launches because its second wave of workgroups starts ragged).  `pstride` partial maxima per frame.
-    const int resident = ch->n_cus * ch->wg_per_cu;
-    int chunk = resident / wpf;
-    if (chunk < 8) chunk = 8;
-    chunk &= ~7;                                // keep the XCD decode (8 frames per group) aligned
+    const int nx = ch->ctx->n_xcd;
+    const int chunk = chain_chunk(ch, wpf);
     for (int f0 = 0; f0 < n_frames; f0 += chunk) {
         const int nf = n_frames - f0 < chunk ? n_frames - f0 : chunk;
         int w = chain_pick_wpf(ch, nf);
         if (w > pstride) w = pstride;
-        const dim3 grid((unsigned)(((nf + 7) / 8) * 8 * w));
+        const dim3 grid((unsigned)(((nf + nx - 1) / nx) * nx * w));
         hipLaunchKernelGGL((range_angle_fused_kernel<P, NT, MMAX, TWC_LDS, MODE>), grid, dim3(NT), ch->lds_bytes, s,
                            d_H + (size_t)f0 * P * ch->cfg.fft_len, MODE == 0 ? d_map + (size_t)f0 * ch->NR * ch->NA : nullptr,
                            ch->d_partials + (size_t)f0 * pstride,
-                           ch->twR, ch->twA, ch->cfg.fft_len, ch->NR, ch->cfg.interp_angle, nf, w, pstride, 0, 0);
+                           ch->twR, ch->twA, ch->cfg.fft_len, ch->NR, ch->cfg.interp_angle, nf, w, pstride, 0, 0, nx);
     }
     JRC_HIP(ch->ctx, hipGetLastError());
     return JRC_OK;
@@ -518,7 +527,7 @@ extern "C" int jrc_chain_launches_per_run(const jrc_chain* ch, int n_frames)
     if (ch->generic) return 1;
     const int resident = ch->n_cus * ch->wg_per_cu;
     const int wpf = chain_pick_wpf(ch, n_frames < resident ? n_frames : resident);
-    int chunk = resident / wpf; if (chunk < 8) chunk = 8; chunk &= ~7;
+    const int chunk = chain_chunk(ch, wpf);
     return (n_frames + chunk - 1) / chunk;
 }
 
@@ -751,7 +760,7 @@ static int chain_run(jrc_chain* ch, int n_frames, const jrc_cf32* d_frames, cons
         // slices per frame of a full chunk, and of the last (smaller) chunk, which is the most any frame of this batch gets
         const int resident = ch->n_cus * ch->wg_per_cu;
         const int wpf = chain_pick_wpf(ch, n_frames < resident ? n_frames : resident);
-        int chunk = resident / wpf; if (chunk < 8) chunk = 8; chunk &= ~7;
+        const int chunk = chain_chunk(ch, wpf);
         const int tail = n_frames % chunk;
         const int pstride = tail ? chain_pick_wpf(ch, tail) : wpf;
         if (pstride != wpf)      // frames of full chunks leave slots unused: all-ones = NaN power, never wins a merge
@@ -878,14 +887,14 @@ __global__ __launch_bounds__(256) void rd_product_t_kernel(const float2* __restr
 template <int NT, int MMAX, bool TWC_LDS>
 __global__ __launch_bounds__(NT) void range_doppler_fused_kernel(const float2* __restrict__ E,     // [units/(ND/16)][N][ND]
                                                                  float2* __restrict__ out,         // [units/(ND/16)][NR][ND]
-                                                                 const float2* __restrict__ twR, int N, int NR, int ND, long n_units, int WPF)
+                                                                 const float2* __restrict__ twR, int N, int NR, int ND, long n_units, int WPF, int nx)
 {
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     constexpr int NW = NT / 64, P = RD_DT;
     const int C = NR / RA_L;
-    const int xcd = blockIdx.x & 7;
-    const long j = blockIdx.x >> 3;
-    const long u = (j / WPF) * 8 + xcd;
+    const int xcd = blockIdx.x % nx;
+    const long j = blockIdx.x / nx;
+    const long u = (j / WPF) * nx + xcd;
     const int slice = (int)(j % WPF);
     if (u >= n_units) return;
     const int tiles = ND / RD_DT;
@@ -988,7 +997,7 @@ __global__ __launch_bounds__(NT) void range_doppler_fused_kernel(const float2* _
 template <int NT /* == fft_len */>
 __global__ __launch_bounds__(NT) void range_doppler_pruned_kernel(const float2* __restrict__ E,     // [units/(ND/16)][N][ND]
                                                                   float2* __restrict__ out,         // [units/(ND/16)][NR][ND]
-                                                                  const float2* __restrict__ twR, int NR, int ND, long n_units, int WPF)
+                                                                  const float2* __restrict__ twR, int NR, int ND, long n_units, int WPF, int nx)
 {
     extern __shared__ __attribute__((aligned(16))) float4 s_t[];          // [N][8]: row n = 16 bins
     constexpr int N = NT, LOG2 = (NT == 64 ? 6 : (NT == 128 ? 7 : (NT == 256 ? 8 : (NT == 512 ? 9 : 10)))), RSTEP = NT / 8;
@@ -1000,9 +1009,9 @@ __global__ __launch_bounds__(NT) void range_doppler_pruned_kernel(const float2* 
     constexpr int R4 = (LOG2 - 4 * R16) / 2;
     constexpr int R2 = (LOG2 - 4 * R16) & 1;                              // fft_len 128, 512: one last radix-2 pass
     const int Ir = NR / N;
-    const int xcd = blockIdx.x & 7;
-    const long jb = blockIdx.x >> 3;
-    const long u = (jb / WPF) * 8 + xcd;
+    const int xcd = blockIdx.x % nx;
+    const long jb = blockIdx.x / nx;
+    const long u = (jb / WPF) * nx + xcd;
     const int slice = (int)(jb % WPF);
     if (u >= n_units) return;
     const int tiles = ND / RD_DT;
@@ -1182,8 +1191,9 @@ static int launch_rd_pruned(jrc_ctx* ctx, const float2* E, float2* out, const fl
     const long target = (long)ctx->n_cus * (NT == 1024 ? 1 : (NT == 512 ? 2 : 4));
     int wpf = 1;
     while (wpf * 2 <= Ir && (long)wpf * 2 * n_units <= target) wpf *= 2;
-    const long groups = (n_units + 7) / 8;
-    hipLaunchKernelGGL((range_doppler_pruned_kernel<NT>), dim3((unsigned)(groups * wpf * 8)), dim3(NT), lds, s, E, out, twR, NR, ND, n_units, wpf);
+    const int nx = ctx->n_xcd;
+    const long groups = (n_units + nx - 1) / nx;
+    hipLaunchKernelGGL((range_doppler_pruned_kernel<NT>), dim3((unsigned)(groups * wpf * nx)), dim3(NT), lds, s, E, out, twR, NR, ND, n_units, wpf, nx);
     JRC_HIP(ctx, hipGetLastError());
     return JRC_OK;
 }
@@ -1196,8 +1206,9 @@ static int launch_rd_fused(jrc_ctx* ctx, const float2* E, float2* out, const flo
     const long target = (long)ctx->n_cus * (lds > 80 * 1024 ? 1 : 2);
     int wpf = 1;
     while (wpf * 2 <= C && (long)wpf * 2 * n_units <= target) wpf *= 2;
-    const long groups = (n_units + 7) / 8;
-    hipLaunchKernelGGL((range_doppler_fused_kernel<NT, MMAX, TWC_LDS>), dim3((unsigned)(groups * wpf * 8)), dim3(NT), lds, s, E, out, twR, N, NR, ND, n_units, wpf);
+    const int nx = ctx->n_xcd;
+    const long groups = (n_units + nx - 1) / nx;
+    hipLaunchKernelGGL((range_doppler_fused_kernel<NT, MMAX, TWC_LDS>), dim3((unsigned)(groups * wpf * nx)), dim3(NT), lds, s, E, out, twR, N, NR, ND, n_units, wpf, nx);
     JRC_HIP(ctx, hipGetLastError());
     return JRC_OK;
 }

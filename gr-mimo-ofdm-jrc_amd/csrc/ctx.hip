@@ -60,7 +60,8 @@ extern "C" int jrc_create(int device, jrc_ctx** out)
         return JRC_ERR_NO_DEVICE;
     }
     if (hipDeviceGetAttribute(&ctx->n_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ctx->n_cus <= 0) ctx->n_cus = 256;
-    if (const char* e = getenv("JRC_NT_FRAC")) { ctx->tune.nt_frac = atof(e); if (ctx->tune.nt_frac < 0) ctx->tune.nt_frac = 0; if (ctx->tune.nt_frac > 1) ctx->tune.nt_frac = 1; }
+    ctx->n_xcd = ctx->n_cus >= 64 ? ctx->n_cus / 32 : 1;
+    if (const char* e = getenv("JRC_XCDS")) { const int v = atoi(e); if (v >= 1 && v <= 64) ctx->n_xcd = v; }
     if (const char* e = getenv("JRC_CHANEST_CHUNK")) ctx->tune.chanest_chunk = atoi(e);
     ctx->tune.chanest_x1 = getenv("JRC_CHANEST_X1") != nullptr;
     ctx->tune.fd_serial = getenv("JRC_FD_SERIAL") != nullptr;

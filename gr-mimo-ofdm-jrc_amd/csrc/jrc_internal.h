@@ -30,9 +30,11 @@ struct jrc_ctx {
     // dynamic-LDS opt-in granted so far, per kernel (hipFuncAttributeMaxDynamicSharedMemorySize is per device: kept per context)
     std::map<const void*, size_t> dyn_lds;
     int n_cus = 0;
+    // XCDs (L2 domains) workgroups are dealt over round-robin: 8 on an MI355X in SPX mode (256 CUs), 1 per 32 CUs in the smaller
+    // partition modes; JRC_XCDS overrides.  Only locality depends on it (a frame's workgroups share one L2), never results.
+    int n_xcd = 8;
     // experiment switches, read once in jrc_create (environment JRC_*)
     struct {
-        double nt_frac = 1.0;        // JRC_NT_FRAC: fraction of a workgroup's map classes stored non-temporally
         int chanest_chunk = 0;       // JRC_CHANEST_CHUNK: frames per A1 launch (0 = four workgroups per CU)
         bool chanest_x1 = false;     // JRC_CHANEST_X1: one subcarrier per lane in A1
         bool fd_serial = false;      // JRC_FD_SERIAL: single-wave detector scan

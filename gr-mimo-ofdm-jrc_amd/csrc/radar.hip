@@ -240,8 +240,8 @@ __global__ __launch_bounds__(1024) void demod_chanest_kernel(const float2* __res
     // every receiver multiplies with are fetched into one L2)
     long blk = blockIdx.x;
     if (g.blocks_per_frame > 1) {
-        const long q = blk >> 3, x = blk & 7;
-        blk = ((q / g.blocks_per_frame) * 8 + x) * g.blocks_per_frame + (q % g.blocks_per_frame);
+        const long q = blk / g.n_xcd, x = blk % g.n_xcd;
+        blk = ((q / g.blocks_per_frame) * g.n_xcd + x) * g.blocks_per_frame + (q % g.blocks_per_frame);
     }
     const long b = blk * per_block + ls;
     const bool live = b < (long)n_frames * g.R;
@@ -370,13 +370,14 @@ int launch_demod_chanest(jrc_ctx* ctx, int T, const float2* d_tx, const float2* 
     const float2* tw = nullptr;
     JRC_TRY(jrc_get_twiddles(ctx, g.N, -1, &tw));
     g.logn = jrc_ilog2(g.N);
+    g.n_xcd = ctx->n_xcd;
     const int threads = g.N >= 256 ? g.N : 256, per_block = threads / g.N;      // streams per workgroup
     g.blocks_per_frame = per_block < g.R ? (g.R + per_block - 1) / per_block : 1;
     long blocks = ((long)n_frames * g.R + per_block - 1) / per_block;
     if (g.blocks_per_frame > 1) {
         // a frame's receivers must not straddle the remapped groups: whole frames per group of blocks_per_frame workgroups
         if (g.R % per_block) g.blocks_per_frame = 1;
-        else { const long grp = 8L * g.blocks_per_frame; blocks = (blocks + grp - 1) / grp * grp; }
+        else { const long grp = (long)g.n_xcd * g.blocks_per_frame; blocks = (blocks + grp - 1) / grp * grp; }
     }
     const size_t lds_bytes = sizeof(float2) * ((size_t)g.N + (size_t)per_block * 8 * g.N);
     const dim3 grid((unsigned)blocks), block((unsigned)threads);

@@ -22,6 +22,7 @@ struct DemodGeom {
     int  tx_item0, rx_sym0;                    // first symbol used on the TX / RX side
     int  interleave;
     int  blocks_per_frame;                     // > 1: a frame's receivers span several workgroups (kept on one XCD)
+    int  n_xcd;                                // filled in by launch_demod_chanest from the context
 };
 bool demod_chanest_supported(int N, int T);
 int launch_demod_chanest(jrc_ctx* ctx, int T, const float2* d_tx, const float2* d_rx_td, float2* d_H, DemodGeom g, int n_frames,

@@ -496,3 +496,33 @@ def test_chain_at_the_benchmarked_launch_geometry(jrc, ctx, cfg, F, nd):
         assert rel_err(gm, m) < FFT_TOL < MAP_TOL
         o = oracle.ra_estimate(gm, rb, ab, ndr, nda, 15.0, 0.0)
         assert rec[f] == ctypes.string_at(ctypes.byref(o), ctypes.sizeof(o))
+
+
+@pytest.mark.parametrize("xcds", ["1", "3", "8"])
+def test_chain_results_do_not_depend_on_the_xcd_count(jrc, ctx, monkeypatch, xcds):
+    """the workgroup -> (frame, slice) decode deals frames over the XCDs of the partition mode (8 in SPX, fewer in CPX/DPX; JRC_XCDS
+    overrides): locality only — maps and results are the same for any count, also one that does not divide the batch"""
+    import torch
+    from jrc_amd import synth
+    sc = synth.Scenario(128, 2, 2, 4, targets=[(11.0, -12.0, 0.0, 70.0)])
+    F = 21
+    fr = synth.make_frames(sc, F)
+    _, H0, m0, r0, _ = run_chain(jrc, ctx, sc, 4, 8, F, frames=fr)
+    monkeypatch.setenv("JRC_XCDS", xcds)
+    c2 = jrc.Context(0)
+    _, H1, m1, r1, _ = run_chain(jrc, c2, sc, 4, 8, F, frames=fr)
+    assert np.array_equal(H0, H1) and np.array_equal(m0, m1)
+    for a, b in zip(r0, r1):
+        assert (a.peak_range_idx, a.peak_angle_idx, a.peak_power, a.noise_power, a.snr_est) == (b.peak_range_idx, b.peak_angle_idx, b.peak_power, b.noise_power, b.snr_est)
+    # range-Doppler and the time-domain front kernel use the same decode
+    bufs = None
+    chain = jrc.RadarChain(sc.N, sc.T, sc.R, sc.S, sc.Npre, 4, 2, *jrc.radar_axes(sc.N, sc.fs, 4, 4, 2), 2.4, 30.0, max_frames=3, ctx=c2)
+    bufs = chain.alloc(3, "cuda:0")
+    bufs["frames"].copy_(torch.from_numpy(fr[:3].view(np.float32).reshape(bufs["frames"].shape)))
+    torch.cuda.synchronize()
+    rd1 = chain.range_doppler(bufs, 3, 1).cpu().numpy()
+    chain0 = jrc.RadarChain(sc.N, sc.T, sc.R, sc.S, sc.Npre, 4, 2, *jrc.radar_axes(sc.N, sc.fs, 4, 4, 2), 2.4, 30.0, max_frames=3, ctx=ctx)
+    rd0 = chain0.range_doppler(bufs, 3, 1).cpu().numpy()
+    assert np.array_equal(rd0, rd1)
+    chain.close()
+    c2.close()
