@@ -322,7 +322,7 @@ def roofline_of(chain, kt, cfg, sc, Ir, Ia, F):
     return r
 
 
-def config_d_roofline(ctx, steps=20):
+def config_d_roofline(ctx, steps=30, warm=8):
     """Metric 2's home configuration (4x4, 1024 subcarriers, 128 symbols, 8 targets): the same chain on a resident batch of 256 frames"""
     import torch
     import jrc_amd
@@ -338,7 +338,7 @@ def config_d_roofline(ctx, steps=20):
     for f0 in range(0, F, 8):
         bufs["frames"][f0:f0 + 8].copy_(hf)
     torch.cuda.synchronize()
-    for _ in range(3):
+    for _ in range(warm):
         chain.run(bufs, F)
     ctx.sync()
     chain.set_timing(True)

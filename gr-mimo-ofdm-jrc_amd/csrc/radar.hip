@@ -220,23 +220,29 @@ __device__ __forceinline__ void chanest_mac(float2& a, const float2 rx, const fl
 // and does not pay: the kernel is bound by instruction issue, not by LDS, and the two extra integer operations per access cost 7 %
 #define DC_PAD(i) (i)
 
-template <int T>
-__global__ __launch_bounds__(1024) void demod_chanest_kernel(const float2* __restrict__ tx, const float2* __restrict__ rx_td,
-                                                             float2* __restrict__ H, const float2* __restrict__ tw_g,
-                                                             DemodGeom g, int n_frames)
+// SPR = symbols a stream's thread group transforms per round (n/4 lanes each): 4 -> n threads per stream, one subcarrier per thread in the
+// accumulation; 2 -> n/2 threads per stream, two subcarriers per thread.  At fft_len 1024 the 4-symbol form is one 1024-thread workgroup
+// with 72 KiB of LDS — a single resident workgroup per CU, so nothing runs while it sits in one of its six barriers per round; the
+// 2-symbol form is a 512-thread workgroup with 40 KiB: two to three per CU, whose barrier waits overlap.
+template <int T, int SPR>
+__global__ __launch_bounds__(SPR == 4 ? 1024 : 512) void demod_chanest_kernel(const float2* __restrict__ tx, const float2* __restrict__ rx_td,
+                                                                             float2* __restrict__ H, const float2* __restrict__ tw_g,
+                                                                             DemodGeom g, int n_frames)
 {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
-    const int n = g.N, tp = n >> 2, per_block = blockDim.x / n;
-    const int ls = threadIdx.x / n, ts = threadIdx.x % n;      // stream within the workgroup, thread within the stream
-    const int u = ts / tp, lt = ts % tp;                       // symbol slot 0..3, lane within the transform
+    constexpr int SPT = 4 / SPR;                               // subcarriers per thread in the accumulation
+    const int n = g.N, tp = n >> 2, ns = SPR * tp;             // lanes per transform, threads per stream
+    const int per_block = blockDim.x / ns;
+    const int ls = threadIdx.x / ns, ts = threadIdx.x % ns;    // stream within the workgroup, thread within the stream
+    const int u = ts / tp, lt = ts % tp;                       // symbol slot 0..SPR-1, lane within the transform
     float2* tw = lds;
     const int np = n;                                          // buffer length (see DC_PAD)
-    float2* sbase = lds + n + (size_t)ls * 8 * np;             // per stream: 4 slots x 2 buffers x np
+    float2* sbase = lds + n + (size_t)ls * (2 * SPR) * np;     // per stream: SPR slots x 2 buffers x np
     float2* bufA = sbase + (size_t)u * 2 * np;
     float2* bufB = bufA + np;
     for (int i = threadIdx.x; i < n; i += blockDim.x) tw[i] = tw_g[i];
 
-    // workgroup -> streams; with several workgroups per frame, those of one frame share blockIdx % 8 (one XCD, so the TX rows
+    // workgroup -> streams; with several workgroups per frame, those of one frame share blockIdx % n_xcd (one XCD, so the TX rows
     // every receiver multiplies with are fetched into one L2)
     long blk = blockIdx.x;
     if (g.blocks_per_frame > 1) {
@@ -251,9 +257,11 @@ __global__ __launch_bounds__(1024) void demod_chanest_kernel(const float2* __res
     const float2* txb = tx + f * g.tx_frame_stride + (long)g.tx_item0 * n + ts;
     const int half_n = n >> 1;
 
-    float2 acc[T], pn[4] = {};
+    float2 acc[SPT][T], pn[4] = {};
 #pragma unroll
-    for (int t = 0; t < T; t++) acc[t] = make_float2(0.f, 0.f);
+    for (int j = 0; j < SPT; j++)
+#pragma unroll
+        for (int t = 0; t < T; t++) acc[j][t] = make_float2(0.f, 0.f);
 
     auto fetch_rx = [&](int sym0) {            // this slot's symbol of the round starting at sym0: read once, non-temporal
         typedef float v2f __attribute__((ext_vector_type(2)));
@@ -271,17 +279,19 @@ __global__ __launch_bounds__(1024) void demod_chanest_kernel(const float2* __res
 
     const bool odd = g.logn & 1;
     float2* wr = bufA;                 // buffer this slot's next pass writes
-    for (int sym0 = 0; sym0 < g.S; sym0 += 4) {
-        float2 p[4], tc[T][4] = {};
+    for (int sym0 = 0; sym0 < g.S; sym0 += SPR) {
+        float2 p[4], tc[SPT][T][SPR] = {};
 #pragma unroll
         for (int q = 0; q < 4; q++) p[q] = pn[q];
-        if (live && sym0 + 4 < g.S) fetch_rx(sym0 + 4);      // next round's samples: in flight during this round's passes
+        if (live && sym0 + SPR < g.S) fetch_rx(sym0 + SPR);  // next round's samples: in flight during this round's passes
         if (live) {                                          // this round's TX rows: needed only after the passes
 #pragma unroll
-            for (int q = 0; q < 4; q++)
+            for (int q = 0; q < SPR; q++)
                 if (sym0 + q < g.S) {
 #pragma unroll
-                    for (int t = 0; t < T; t++) tc[t][q] = txb[(long)t * g.tx_port_stride + (long)(sym0 + q) * n];
+                    for (int j = 0; j < SPT; j++)
+#pragma unroll
+                        for (int t = 0; t < T; t++) tc[j][t][q] = txb[(long)t * g.tx_port_stride + (long)(sym0 + q) * n + j * ns];
                 }
         }
 
@@ -334,30 +344,55 @@ __global__ __launch_bounds__(1024) void demod_chanest_kernel(const float2* __res
             wr[DC_PAD((lt + 3 * tp + half_n) & (n - 1))] = csub(bb, jd);
         }
         __syncthreads();
-        // every thread owns subcarrier ts: the four symbols of this round, in order.  Slot q's result sits in the buffer that slot
+        // every thread owns subcarriers ts (+ ns): the symbols of this round, in order.  Slot q's result sits in the buffer that slot
         // just wrote (the same one of the pair for every slot); the next round's first pass writes the other one.
         const int off = (int)(wr - bufA);
 #pragma unroll
-        for (int q = 0; q < 4; q++)
+        for (int q = 0; q < SPR; q++)
             if (sym0 + q < g.S) {
-                const float2 xv = sbase[(size_t)q * 2 * np + off + DC_PAD(ts)];
 #pragma unroll
-                for (int t = 0; t < T; t++) chanest_mac(acc[t], xv, tc[t][q]);
+                for (int j = 0; j < SPT; j++) {
+                    const float2 xv = sbase[(size_t)q * 2 * np + off + DC_PAD(ts + j * ns)];
+#pragma unroll
+                    for (int t = 0; t < T; t++) chanest_mac(acc[j][t], xv, tc[j][t][q]);
+                }
             }
         wr = rd;
     }
     if (!live) return;
     float2* Hf = H + (size_t)f * T * g.R * n;
 #pragma unroll
-    for (int t = 0; t < T; t++) {
-        const int pidx = g.interleave ? (t * g.R + r) : (r * T + t);   // :262-269
-        Hf[(size_t)pidx * n + ts] = acc[t];
-    }
+    for (int j = 0; j < SPT; j++)
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            const int pidx = g.interleave ? (t * g.R + r) : (r * T + t);   // :262-269
+            Hf[(size_t)pidx * n + ts + j * ns] = acc[j][t];
+        }
 }
 
 bool demod_chanest_supported(int N, int T)
 {
     return jrc_is_pow2(N) && N >= 16 && N <= 1024 && (T == 1 || T == 2 || T == 3 || T == 4 || T == 8);
+}
+
+template <int T, int SPR>
+static int launch_demod_chanest_t(jrc_ctx* ctx, const float2* d_tx, const float2* d_rx_td, float2* d_H, const float2* tw, DemodGeom g, int n_frames,
+                                  hipStream_t stream)
+{
+    const int ns = SPR * (g.N / 4);                                             // threads per stream
+    const int threads = ns >= 256 ? ns : 256, per_block = threads / ns;         // streams per workgroup
+    g.blocks_per_frame = per_block < g.R ? (g.R + per_block - 1) / per_block : 1;
+    long blocks = ((long)n_frames * g.R + per_block - 1) / per_block;
+    if (g.blocks_per_frame > 1) {
+        // a frame's receivers must not straddle the remapped groups: whole frames per group of blocks_per_frame workgroups
+        if (g.R % per_block) g.blocks_per_frame = 1;
+        else { const long grp = (long)g.n_xcd * g.blocks_per_frame; blocks = (blocks + grp - 1) / grp * grp; }
+    }
+    const size_t lds_bytes = sizeof(float2) * ((size_t)g.N + (size_t)per_block * (2 * SPR) * g.N);
+    JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)demod_chanest_kernel<T, SPR>, lds_bytes));
+    hipLaunchKernelGGL((demod_chanest_kernel<T, SPR>), dim3((unsigned)blocks), dim3((unsigned)threads), lds_bytes, stream, d_tx, d_rx_td, d_H, tw, g, n_frames);
+    JRC_HIP(ctx, hipGetLastError());
+    return JRC_OK;
 }
 
 int launch_demod_chanest(jrc_ctx* ctx, int T, const float2* d_tx, const float2* d_rx_td, float2* d_H, DemodGeom g, int n_frames,
@@ -371,31 +406,23 @@ int launch_demod_chanest(jrc_ctx* ctx, int T, const float2* d_tx, const float2* 
     JRC_TRY(jrc_get_twiddles(ctx, g.N, -1, &tw));
     g.logn = jrc_ilog2(g.N);
     g.n_xcd = ctx->n_xcd;
-    const int threads = g.N >= 256 ? g.N : 256, per_block = threads / g.N;      // streams per workgroup
-    g.blocks_per_frame = per_block < g.R ? (g.R + per_block - 1) / per_block : 1;
-    long blocks = ((long)n_frames * g.R + per_block - 1) / per_block;
-    if (g.blocks_per_frame > 1) {
-        // a frame's receivers must not straddle the remapped groups: whole frames per group of blocks_per_frame workgroups
-        if (g.R % per_block) g.blocks_per_frame = 1;
-        else { const long grp = (long)g.n_xcd * g.blocks_per_frame; blocks = (blocks + grp - 1) / grp * grp; }
-    }
-    const size_t lds_bytes = sizeof(float2) * ((size_t)g.N + (size_t)per_block * 8 * g.N);
-    const dim3 grid((unsigned)blocks), block((unsigned)threads);
-    {
-        const void* fn = T == 1 ? (const void*)demod_chanest_kernel<1> : T == 2 ? (const void*)demod_chanest_kernel<2> :
-                         T == 3 ? (const void*)demod_chanest_kernel<3> : T == 4 ? (const void*)demod_chanest_kernel<4> :
-                                  (const void*)demod_chanest_kernel<8>;
-        JRC_TRY(jrc_ensure_dyn_lds(ctx, fn, lds_bytes));
-    }
+    // two symbols per round (half the threads per stream) from fft_len 512 up: more, smaller workgroups per CU; JRC_DEMOD_SPR overrides
+    int spr = g.N >= 512 ? 2 : 4;
+    if (ctx->tune.demod_spr == 2 || ctx->tune.demod_spr == 4) spr = ctx->tune.demod_spr;
+    if (g.N < 8) spr = 4;
+#define JRC_DEMOD_CASE(TT)                                                                                               \
+    case TT: return spr == 2 ? launch_demod_chanest_t<TT, 2>(ctx, d_tx, d_rx_td, d_H, tw, g, n_frames, stream)          \
+                             : launch_demod_chanest_t<TT, 4>(ctx, d_tx, d_rx_td, d_H, tw, g, n_frames, stream);
     switch (T) {
-        case 1: hipLaunchKernelGGL(demod_chanest_kernel<1>, grid, block, lds_bytes, stream, d_tx, d_rx_td, d_H, tw, g, n_frames); break;
-        case 2: hipLaunchKernelGGL(demod_chanest_kernel<2>, grid, block, lds_bytes, stream, d_tx, d_rx_td, d_H, tw, g, n_frames); break;
-        case 3: hipLaunchKernelGGL(demod_chanest_kernel<3>, grid, block, lds_bytes, stream, d_tx, d_rx_td, d_H, tw, g, n_frames); break;
-        case 4: hipLaunchKernelGGL(demod_chanest_kernel<4>, grid, block, lds_bytes, stream, d_tx, d_rx_td, d_H, tw, g, n_frames); break;
-        default: hipLaunchKernelGGL(demod_chanest_kernel<8>, grid, block, lds_bytes, stream, d_tx, d_rx_td, d_H, tw, g, n_frames); break;
+        JRC_DEMOD_CASE(1)
+        JRC_DEMOD_CASE(2)
+        JRC_DEMOD_CASE(3)
+        JRC_DEMOD_CASE(4)
+        default: break;
     }
-    JRC_HIP(ctx, hipGetLastError());
-    return JRC_OK;
+    return spr == 2 ? launch_demod_chanest_t<8, 2>(ctx, d_tx, d_rx_td, d_H, tw, g, n_frames, stream)
+                    : launch_demod_chanest_t<8, 4>(ctx, d_tx, d_rx_td, d_H, tw, g, n_frames, stream);
+#undef JRC_DEMOD_CASE
 }
 
 // ------------------------------------------------------------------------------------------------
