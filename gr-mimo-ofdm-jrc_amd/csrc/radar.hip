@@ -220,12 +220,14 @@ __device__ __forceinline__ void chanest_mac(float2& a, const float2 rx, const fl
 // and does not pay: the kernel is bound by instruction issue, not by LDS, and the two extra integer operations per access cost 7 %
 #define DC_PAD(i) (i)
 
-// SPR = symbols a stream's thread group transforms per round (n/4 lanes each): 4 -> n threads per stream, one subcarrier per thread in the
-// accumulation; 2 -> n/2 threads per stream, two subcarriers per thread.  At fft_len 1024 the 4-symbol form is one 1024-thread workgroup
-// with 72 KiB of LDS — a single resident workgroup per CU, so nothing runs while it sits in one of its six barriers per round; the
-// 2-symbol form is a 512-thread workgroup with 40 KiB: two to three per CU, whose barrier waits overlap.
+// SPR = symbols a stream's thread group transforms per round (n/4 lanes each): 4 -> n threads per stream and one subcarrier per thread in
+// the accumulation; 2 -> n/2 threads and two subcarriers; 1 -> n/4 threads and four.  At fft_len 1024 the 4-symbol form is one 1024-thread
+// workgroup with 72 KiB of LDS — a single resident workgroup per CU, so nothing runs while it sits in one of its six barriers per round
+// (0.868 ms per 256 config-D frames, 2.5 TB/s).  The 1-symbol form is a 256-thread workgroup with 24 KiB and 112 registers: four per CU,
+// whose barrier waits overlap (0.651 ms, 3.35 TB/s; 2 symbols: 0.707 ms).  At fft_len 256 the 4-symbol form already has 8 workgroups per CU
+// and stays best (3.43 TB/s against 3.32 / 2.81).  Register budgets below the natural ones (more workgroups per CU) spill and lose.
 template <int T, int SPR>
-__global__ __launch_bounds__(SPR == 4 ? 1024 : 512) void demod_chanest_kernel(const float2* __restrict__ tx, const float2* __restrict__ rx_td,
+__global__ __launch_bounds__(SPR == 4 ? 1024 : (SPR == 2 ? 512 : 256), SPR == 4 ? 1 : (SPR == 2 ? 2 : 4)) void demod_chanest_kernel(const float2* __restrict__ tx, const float2* __restrict__ rx_td,
                                                                              float2* __restrict__ H, const float2* __restrict__ tw_g,
                                                                              DemodGeom g, int n_frames)
 {
@@ -406,12 +408,14 @@ int launch_demod_chanest(jrc_ctx* ctx, int T, const float2* d_tx, const float2* 
     JRC_TRY(jrc_get_twiddles(ctx, g.N, -1, &tw));
     g.logn = jrc_ilog2(g.N);
     g.n_xcd = ctx->n_xcd;
-    // two symbols per round (half the threads per stream) from fft_len 512 up: more, smaller workgroups per CU; JRC_DEMOD_SPR overrides
-    int spr = g.N >= 512 ? 2 : 4;
-    if (ctx->tune.demod_spr == 2 || ctx->tune.demod_spr == 4) spr = ctx->tune.demod_spr;
+    // fewer symbols per round (fewer threads per stream, more subcarriers per thread) as fft_len grows: more, smaller workgroups per CU;
+    // JRC_DEMOD_SPR overrides
+    int spr = g.N >= 1024 ? 1 : (g.N >= 512 ? 2 : 4);
+    if (ctx->tune.demod_spr == 1 || ctx->tune.demod_spr == 2 || ctx->tune.demod_spr == 4) spr = ctx->tune.demod_spr;
     if (g.N < 8) spr = 4;
 #define JRC_DEMOD_CASE(TT)                                                                                               \
-    case TT: return spr == 2 ? launch_demod_chanest_t<TT, 2>(ctx, d_tx, d_rx_td, d_H, tw, g, n_frames, stream)          \
+    case TT: return spr == 1 ? launch_demod_chanest_t<TT, 1>(ctx, d_tx, d_rx_td, d_H, tw, g, n_frames, stream)          \
+                  : spr == 2 ? launch_demod_chanest_t<TT, 2>(ctx, d_tx, d_rx_td, d_H, tw, g, n_frames, stream)          \
                              : launch_demod_chanest_t<TT, 4>(ctx, d_tx, d_rx_td, d_H, tw, g, n_frames, stream);
     switch (T) {
         JRC_DEMOD_CASE(1)

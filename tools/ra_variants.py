@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Kernel-variant experiments for the fused range-angle kernel: builds libjrc_hip.so variants with extra -D flags for chain.hip into
+"""Kernel-variant experiments: builds libjrc_hip.so variants with extra -D flags for one source file (chain.hip unless given) into
 gr-mimo-ofdm-jrc_amd/lib/variants/<name>/ (CPU side: `build`), and benches each of them on the GPU box (`run`), one bench.py child per
 variant (JRC_LIB_PATH selects the library).
 
-  python tools/ra_variants.py build name1:"-DX=1 -DY" name2:"..."      # here (hipcc cross-compiles)
+  python tools/ra_variants.py build name1:"-DX=1 -DY" name2:radar.hip:"-DZ=2"      # here (hipcc cross-compiles)
   python tools/ra_variants.py run [--config B]                           # on the GPU box: every variant found + the default library
 """
 import json
@@ -22,12 +22,15 @@ def build(specs):
     jb.build()
     for spec in specs:
         name, _, defs = spec.partition(":")
+        src = "chain.hip"
+        if defs.split(":")[0].endswith(".hip"):            # name:file.hip:defs
+            src, _, defs = defs.partition(":")
         d = os.path.join(VDIR, name)
         os.makedirs(d, exist_ok=True)
-        obj = os.path.join(d, "chain.o")
-        cmd = [jb.hipcc()] + jb.HIPCC_FLAGS + jb.EXTRA_FLAGS.get("chain.hip", []) + defs.split() + ["-c", os.path.join(jb.CSRC, "chain.hip"), "-o", obj]
+        obj = os.path.join(d, os.path.splitext(src)[0] + ".o")
+        cmd = [jb.hipcc()] + jb.HIPCC_FLAGS + jb.EXTRA_FLAGS.get(src, []) + defs.split() + ["-c", os.path.join(jb.CSRC, src), "-o", obj]
         subprocess.check_call(cmd)
-        objs = [os.path.join(jb.OBJDIR, os.path.splitext(s)[0] + ".o") for s in jb.SOURCES if s != "chain.hip"] + [obj]
+        objs = [os.path.join(jb.OBJDIR, os.path.splitext(s)[0] + ".o") for s in jb.SOURCES if s != src] + [obj]
         subprocess.check_call([jb.hipcc(), "--offload-arch=" + jb.ARCH, "-shared", "-fPIC", "-o", os.path.join(d, "libjrc_hip.so")] + objs)
         open(os.path.join(d, "defs.txt"), "w").write(defs + "\n")
         print("built", name, defs)
