@@ -86,3 +86,37 @@ def test_self_launched_single_rank_matches_direct():
     assert js["check"]["ok"] and jd["check"]["ok"]
     md, ms = jd["windows"]["ms_per_step_median"], js["windows"]["ms_per_step_median"]
     assert abs(md - ms) / md < 0.05, (md, ms)          # same work per step whichever way the rank was started
+
+
+@pytest.mark.gpu
+def test_rccl_initialises_and_runs_the_collectives_the_bench_uses(tmp_path):
+    """the box has one GPU, and RCCL refuses two ranks on one device, so the N > 1 tests above run over gloo; this one brings up the
+    `nccl` (= RCCL) backend itself with a world of one — process group with device_id as bench.py creates it, the MAX / MIN all-reduce of
+    the timing contract, all_gather_into_tensor of shard.gather_results, barrier — on device tensors"""
+    script = tmp_path / "rccl_one.py"
+    script.write_text('''
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+import jrc_amd
+from jrc_amd import shard
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda:0"))
+assert dist.get_backend() == "nccl"
+t = torch.tensor([0.25, 3.0], dtype=torch.float64, device="cuda:0")
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+dist.all_reduce(t, op=dist.ReduceOp.MIN)
+assert t.tolist() == [0.25, 3.0]
+assert shard.max_over_ranks_vec([1.0, 2.0], "cuda:0") == [1.0, 2.0] and shard.min_over_ranks(0.5, "cuda:0") == 0.5
+x = torch.arange(48 * 5, dtype=torch.uint8, device="cuda:0").reshape(5, 48)
+out = torch.empty_like(x)
+dist.all_gather_into_tensor(out, x)
+assert torch.equal(out, x) and torch.equal(shard.gather_results(x, 5), x)
+dist.barrier()
+dist.destroy_process_group()
+print("rccl ok")
+''' % ROOT)
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=e, cwd=ROOT)
+    assert r.returncode == 0 and "rccl ok" in r.stdout, r.stderr[-3000:]
