@@ -26,6 +26,55 @@ class _Window:
         return [1.0] * int(n)
 
 
+COMM_GRC = "/root/reference/examples/simulation/communication/mimo_ofdm_jrc_comm_sim.grc"
+
+
+def evaluate(grc):
+    """namespace of a flowgraph: its embedded module(s) executed, its variables evaluated; returns (namespace, blocks by name)"""
+    d = yaml.safe_load(open(grc))
+    ns = {"np": np, "numpy": np, "cmath": cmath, "math": math, "os": os, "window": _Window}
+    for b in d["blocks"]:
+        if b["id"] == "epy_module":
+            mod = {}
+            exec(compile(b["parameters"]["source_code"], grc + ":" + b["name"], "exec"), mod)
+            ns[b["name"]] = type("module", (), mod)
+    pending = {}
+    for b in d["blocks"]:
+        if b["id"] == "variable":
+            pending[b["name"]] = b["parameters"]["value"]
+        elif b["id"].startswith("variable_qtgui"):
+            pending[b["name"]] = b["parameters"].get("value", b["parameters"].get("false", "0"))
+    for _ in range(20):
+        for k in list(pending):
+            try:
+                ns[k] = eval(str(pending[k]), ns)
+                del pending[k]
+            except (NameError, AttributeError):
+                pass
+    return ns, {b["name"]: b for b in d["blocks"]}
+
+
+def comm_point(out):
+    """the comm simulation flowgraph's sync front end and codec parameters (frame_detector, frame_sync, moving_avg, zero_pad, decoder)"""
+    ns, blocks = evaluate(COMM_GRC)
+
+    def par(block, key):
+        return eval(str(blocks[block]["parameters"][key]), ns)
+
+    fd, fs, ma, zp = "mimo_ofdm_jrc_frame_detector_0", "mimo_ofdm_jrc_frame_sync_0", "mimo_ofdm_jrc_moving_avg_0", "mimo_ofdm_jrc_zero_pad_0"
+    out["comm_frame_detector"] = np.array([par(fd, "fft_len"), par(fd, "cp_len"), par(fd, "threshold"), par(fd, "min_n_peaks"), par(fd, "ignore_gap")], np.float64)
+    out["comm_frame_sync_ints"] = np.array([par(fs, "fft_len"), par(fs, "cp_len"), par(fs, "sync_length")], np.int64)
+    out["comm_frame_sync_ltf_fir"] = np.asarray(par(fs, "ltf_seq_time"), np.complex64)
+    out["comm_moving_avg"] = np.array([par(ma, "length"), par(ma, "scale"), par(ma, "max_iter")], np.float64)
+    out["comm_zero_pad"] = np.array([par(zp, "pad_front"), par(zp, "pad_tail")], np.int64)
+    eq = "mimo_ofdm_jrc_mimo_ofdm_equalizer_0"
+    out["comm_equalizer_scalars"] = np.array([par(eq, "freq"), par(eq, "bw"), par(eq, "fft_len"), par(eq, "cp_len"), par(eq, "n_mimo_ltf")], np.float64)
+    out["comm_equalizer_long_seq"] = np.asarray(par(eq, "long_seq"), np.complex64)
+    out["comm_decoder_n_data_carriers"] = np.int64(par("mimo_ofdm_jrc_stream_decoder_0", "n_data_carriers"))
+    out["comm_encoder_data_len"] = np.int64(par("mimo_ofdm_jrc_stream_encoder_1", "data_len"))
+    out["comm_noise_var_path_loss"] = np.array([ns["noise_var"], ns["path_loss"], ns["wavelength"], ns["distance"]], np.float64)
+
+
 def main():
     d = yaml.safe_load(open(GRC))
     ns = {"np": np, "numpy": np, "cmath": cmath, "math": math, "os": os, "window": _Window}
@@ -79,6 +128,7 @@ def main():
     out["zero_pad_tail"] = np.int64(par("mimo_ofdm_jrc_zero_pad_0", "pad_tail"))
     cpr = "mimo_ofdm_jrc_ofdm_cyclic_prefix_remover_0"
     out["cp_remover_ints"] = np.array([par(cpr, "fft_len"), par(cpr, "cp_len")], np.int64)
+    comm_point(out)
     dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "radar_flowgraph_point.npz")
     np.savez_compressed(dst, **out)
     print("wrote", dst)

@@ -187,3 +187,20 @@ def test_synthetic_scenario_follows_the_flowgraphs_channel_parameters(fg):
         for r in range(R):
             assert abs(pos[r] - (r * T + t + 2) * lam / 2) < 1e-15
     assert float(fg["tsim_scalars"][0]) == 10 ** (float(fg["var_trgt_rcs_dbsm"]) / 10.0)
+
+
+def test_comm_flowgraph_operating_point(fg, ofdm64):
+    """the comm simulation flowgraph's sync front end as its own expressions evaluate (frame_detector threshold / peaks / ignore_gap,
+    frame_sync length and matched-filter taps, moving-average window, padding): what examples/comm_sim_flowgraph.py and the sync tests use"""
+    N, cp = (int(v) for v in fg["comm_frame_sync_ints"][:2])
+    T = int(ofdm64["N_tx"])
+    assert (N, cp) == (64, 16) and int(fg["comm_frame_sync_ints"][2]) == 4 * (N + cp)
+    fft_len, cp_len, thr, peaks, gap = fg["comm_frame_detector"]
+    assert (fft_len, cp_len, thr, peaks) == (N, cp, 0.6, 10) and gap == (len(ofdm64["l_stf_ltf_64"]) + T) * (N + cp)
+    assert np.array_equal(fg["comm_frame_sync_ltf_fir"], np.asarray(ofdm64["l_ltf_fir"], np.complex64))
+    assert list(fg["comm_moving_avg"]) == [N // 2, 1.0, 16000.0]
+    assert list(fg["comm_zero_pad"]) == [5, 6 * (N + cp) + 10]
+    freq, bw, n, c, nl = fg["comm_equalizer_scalars"]
+    assert (freq, bw, n, c, nl) == (24e9, 125e6, N, cp, T)
+    assert np.array_equal(fg["comm_equalizer_long_seq"], np.asarray(ofdm64["l_stf_ltf_64"][3], np.complex64))      # long_seq = sync word 3
+    assert int(fg["comm_decoder_n_data_carriers"]) == int(fg["comm_encoder_data_len"]) == len(ofdm64["data_subcarriers"]) == 48
