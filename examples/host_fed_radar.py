@@ -40,6 +40,25 @@ def main():
     print("%d frames from host memory in %.1f ms: %.0f k frames/s" % (n_batches * 32, dt * 1e3, n_batches * 32 / dt / 1e3))
     feed.close()
 
+    # The same stream for a consumer of the detections only: no map is stored (detect-only mode, results bit-identical), the batches are
+    # dealt over every GPU of the node from this one process (a host thread per GPU stages and enqueues: submit_many), and the clutter
+    # that does not move is removed with mimo_ofdm_radar's background history when the stream stays on one GPU.
+    devices = list(range(jrc_amd._device_count()))
+    feed = jrc_amd.ChainFeed(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb, ab, 2.4, 28.96, 15.0, 0.0, n_slots=2, frames_per_slot=32,
+                             devices=devices if len(devices) > 1 else None)
+    feed.set_write_map(False)
+    if len(devices) == 1:
+        feed.set_background(True, True, 8)
+    done, t0 = 0, time.perf_counter()
+    for _ in range(10):
+        free = feed.n_slots - feed.pending()
+        feed.submit_many([frames] * free)
+        while feed.pending():
+            done += len(feed.collect()[0])
+    dt = time.perf_counter() - t0
+    print("detect-only on %d GPU(s)%s: %d frames in %.1f ms" % (len(devices), ", background removal on" if len(devices) == 1 else "", done, dt * 1e3))
+    feed.close()
+
 
 if __name__ == "__main__":
     main()
