@@ -324,3 +324,45 @@ def test_multi_device_feed_equals_single_device_feed(jrc, ctx, devices):
         assert np.array_equal(got_maps, want_maps), mode
         multi.close()
     single.close()
+
+
+def test_time_domain_entry_with_background_and_detect_only(jrc, ctx):
+    """jrc_chain_run_td_dev (A6 + A7 + A1 as one kernel) goes through the same background step and the same detect-only modes as the
+    frequency-domain entry: its detect-only records equal its own map-mode records byte for byte, and its background-free estimates
+    agree with the frequency-domain entry's to the rounding of the two A1 kernels (relative to the raw estimate's magnitude)"""
+    import torch
+    from jrc_amd import synth
+    sc = synth.Scenario(64, 4, 2, 4, targets=[(9.0, 15.0, 0.0, 80.0)])
+    Ir, Ia, F, L = 8, 16, 6, 2
+    n_items, N, cp = sc.Npre + sc.S, sc.N, sc.N // 4
+    fr = synth.make_frames(sc, F)
+    fr[:, sc.T:] *= (1.0 + 0.1 * np.arange(F, dtype=np.float32))[:, None, None, None]
+    x = np.fft.ifft(np.fft.ifftshift(fr[:, sc.T:], axes=-1), axis=-1).astype(np.complex64)
+    td = np.concatenate([x[..., N - cp:], x], axis=-1).reshape(F, sc.R, n_items * (N + cp))
+    d_tx = torch.from_numpy(np.ascontiguousarray(fr[:, :sc.T]).view(np.float32).reshape(F, sc.T, n_items, N, 2)).cuda()
+    d_td = torch.from_numpy(td.view(np.float32).reshape(F, sc.R, -1, 2)).cuda()
+    out = {}
+    for mode in ("td_map", "td_detect", "fd_map"):
+        ch, _ = _chain(jrc, ctx, sc, Ir, Ia, F)
+        ch.set_background(True, True, L)
+        ch.set_write_map(mode != "td_detect")
+        bufs = ch.alloc(F, "cuda:0", with_map=(mode != "td_detect"))
+        if mode == "fd_map":
+            rx_tmp = torch.empty((F, sc.R, n_items, N, 2), dtype=torch.float32, device="cuda:0")
+            torch.cuda.synchronize()
+            ctx.check(ctx.lib.jrc_cp_remove_fft_dev(ctx.h, N, cp, F * sc.R * n_items, d_td.data_ptr(), rx_tmp.data_ptr(), None))
+            ctx.sync()
+            bufs["frames"][:, :sc.T] = d_tx
+            bufs["frames"][:, sc.T:] = rx_tmp
+            torch.cuda.synchronize()
+            ch.run(bufs, F)
+        else:
+            torch.cuda.synchronize()
+            ch.run_td(bufs, d_tx, d_td, F, cp)
+        res = ch.results(bufs, F)
+        out[mode] = ([_rec(r) for r in res], bufs["chanest"].cpu().numpy().view(np.complex64)[..., 0].copy())
+        assert ch.background_size() == L
+    assert out["td_detect"][0] == out["td_map"][0]
+    assert np.array_equal(out["td_detect"][1], out["td_map"][1])
+    raw = np.abs(np.einsum("frsn,ftsn->frtn", fr[:, sc.T:, sc.Npre:], np.conj(fr[:, :sc.T, sc.Npre:]))).max()
+    assert np.abs(out["td_map"][1] - out["fd_map"][1]).max() < 2e-6 * raw
