@@ -132,6 +132,7 @@ def test_sharded_stream_with_background_equals_one_gpu(jrc, ctx):
         if lo > first:
             _load(bufs, frames[first:lo], lo - first)
             ch.prime_background(bufs["frames"], lo - first)
+            ctx.sync()                                # the library's stream reads the frame buffer torch is about to overwrite
         _load(bufs, frames[lo:hi], hi - lo)
         ch.run(bufs, hi - lo)
         ctx.sync()
