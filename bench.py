@@ -440,6 +440,8 @@ def secondary_figures(cfg, ctx, sc, axes):
     leg("chain_with_rx_demod", _demod)
     if hasattr(be, "detect_only"):
         leg("detect_only_chain", lambda: be.detect_only(cfg if cfg in ("B", "D") else "B"))
+    if hasattr(be, "power_map"):
+        leg("power_map_chain", lambda: be.power_map(cfg if cfg in ("B", "D") else "B"))
     leg("equalizer_config_c", _eq)
     leg("comm_rx_chain", _comm)
     leg("precoder_config_c", _pre)

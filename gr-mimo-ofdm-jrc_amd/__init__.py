@@ -143,6 +143,7 @@ def load(build_if_missing=False):
     L.jrc_chain_background_size.argtypes = [_vp]
     L.jrc_chain_prime_background_dev.argtypes = [_vp, C.c_int, _vp, _vp]
     L.jrc_chain_set_write_map.argtypes = [_vp, C.c_int]
+    L.jrc_chain_set_map_format.argtypes = [_vp, C.c_int]
     L.jrc_chain_feed_set_background.argtypes = [_vp, C.c_int, C.c_int, C.c_int]
     L.jrc_chain_feed_set_write_map.argtypes = [_vp, C.c_int]
     L.jrc_chain_feed_create_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(ChainCfg), _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]
@@ -439,10 +440,15 @@ class RadarChain:
         c = self.cfg
         return (c.N_tx + c.N_rx, c.n_items, c.fft_len)
 
-    def alloc(self, n_frames, device, with_map=True):
-        """device buffers as torch tensors (complex64 viewed as float32 pairs); with_map=False for detect-only mode"""
+    def alloc(self, n_frames, device, with_map=True, power_map=False):
+        """device buffers as torch tensors (complex64 viewed as float32 pairs); with_map=False for detect-only mode, power_map=True
+        for the float |z|^2 format"""
         import torch
         c = self.cfg
+        if power_map:
+            b = self.alloc(n_frames, device, with_map=False)
+            b["map"] = torch.empty((n_frames, self.NR, self.NA), dtype=torch.float32, device=device)
+            return b
         return dict(
             frames=torch.empty((n_frames, c.N_tx + c.N_rx, c.n_items, c.fft_len, 2), dtype=torch.float32, device=device),
             chanest=torch.empty((n_frames, self.P, c.fft_len, 2), dtype=torch.float32, device=device),
@@ -481,6 +487,11 @@ class RadarChain:
     def set_write_map(self, write_map):
         """write_map=False: detect-only mode — no range-angle map is stored, results are bit-identical"""
         self.ctx.check(self.ctx.lib.jrc_chain_set_write_map(self.h, int(write_map)))
+
+    def set_map_format(self, power):
+        """power=True: bufs["map"] is the float |z|^2 map [n_frames, NR, NA] (alloc(..., power_map=True)), results bit-identical"""
+        self.ctx.check(self.ctx.lib.jrc_chain_set_map_format(self.h, 1 if power else 0))
+        self.map_bytes = self.ctx.lib.jrc_chain_map_bytes(self.h)
 
     def run_td(self, bufs, tx, rx_td, n_frames, cp_len, stream=None):
         """A6 + A7 + A1 fused in front of the chain: tx = torch [n_frames, T, n_items, fft_len, 2] (frequency domain),

@@ -42,29 +42,34 @@
 // MODE 1, "detect only" (jrc_chain_set_write_map(chain, 0)): the same transforms and the same arg-max on the values in registers,
 //         but the map is never stored — a consumer that only takes range_angle_estimator's message (lib/range_angle_estimator_impl.cc:
 //         234-253) does not pay the 4-16 MiB per frame.
-// MODE 2, window pass of detect-only mode: one workgroup per frame re-computes the rows of the estimator's noise window only
-//         (range bins [peak + NR/2 - dr, peak + NR/2 + dr), :197-226) THROUGH THE SAME CODE — the class fold, the 64-point transform across
-//         the wavefront and the P-point angle transform of this very template — and stores them as full rows of NA cells into a
-//         compact buffer win[frame][row][NA] that ra_finalize_kernel reads instead of the map: same instructions on the same inputs,
-//         so the noise sum, and with it every field of the result, is bit-identical to MODE 0.
-template <int P, int NT, int MMAX, bool TWC_LDS, int MODE>
+//         Both map-less modes (1 and 3) also write the range profiles they pass through LDS — s_g, the 64 range bins of the class for every
+//         pair, 8 KiB per class, 6 % of the map's bytes — to a buffer rng[frame][class][pair][64]: ra_window_rows_kernel (below) re-computes
+//         the rows of the estimator's noise window (range bins [peak + NR/2 - dr, peak + NR/2 + dr), :197-226) from them with the same
+//         angle-axis code (same twiddles, cmul_pin, fft_fwd_small_pin), as full rows of a compact buffer win[frame][2 dr][NA] that
+//         ra_finalize_kernel reads instead of the map: same instructions on the same inputs, so the noise sum, and with it every field of
+//         the result, is bit-identical to MODE 0.
+// MODE 3, power map (jrc_chain_set_map_format(chain, JRC_MAP_POWER)): MODE 1 plus the map as float |z|^2 — what the flowgraph's display
+//         branch consumes (blocks_complex_to_mag_squared -> gui_heatmap_plot, examples/simulation/radar/mimo_ofdm_jrc_radar_sim.grc:2192) —
+//         at half the bytes of the complex map.  A lane's 4-byte cells would make 64-byte store segments, so each wave turns its cells
+//         through a private LDS tile ([rows of this trip][NA] floats) and stores whole 16-byte pieces of full rows; the estimator reads
+//         the MODE 2 window rows as in detect-only mode.  ROWS1: the tile holds one row at a time (when LDS is short: fft_len 1024).
+template <int P, int NT, int MMAX, bool TWC_LDS, int MODE, bool ROWS1 = false>
 #ifndef JRC_WPS256
 #define JRC_WPS256 3
 #endif
 __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))) void range_angle_fused_kernel(
     const float2* __restrict__ H,        // [F][P][N]
-    float2* __restrict__ map,            // MODE 0: [F][NR][NA]; MODE 2: win [F][win_rows][NA]; MODE 1: unused
-    PeakPartial* __restrict__ partials,  // [F][pstride]: written by MODE 0/1, read by MODE 2
+    float2* __restrict__ map,            // MODE 0: [F][NR][NA]; MODE 3: float [F][NR][NA]; MODE 1: unused
+    PeakPartial* __restrict__ partials,  // [F][pstride]
     const float2* __restrict__ twR,      // [NR]  exp(+j 2 pi i / NR)
     const float2* __restrict__ twA,      // [NA]  exp(-j 2 pi i / NA)
     int N, int NR, int Ia, int F, int WPF,
     int pstride,                         // partial maxima per frame in `partials` (>= WPF; unused slots hold the neutral element)
-    int win_rows, int win_off,
+    float2* __restrict__ rng_out,        // MODE 1 / 3: [F][C][P][64] range profiles for the window pass
     int nx)                              // XCDs the hardware deals consecutive workgroups over (jrc_ctx::n_xcd)           // MODE 2: rows of the noise window (2 dr) and its offset from the peak's range bin (NR/2 - dr)
 {
 #pragma clang fp contract(off)          // every rounding of this kernel is spelled out (fmaf / cmul_pin / fft_fwd_small_pin): the three MODEs agree bit for bit
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
-    __shared__ int s_row0;
     constexpr int NW = NT / 64;
     const int NA = P * Ia;
     const int C = NR / RA_L;
@@ -84,21 +89,8 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int M = N / RA_L;                     // fold length per lane, <= MMAX
 
-    int row0 = 0;                               // MODE 2: first range bin of the window (before wrapping)
-    if constexpr (MODE == 2) {
-        PeakTracker pk;
-        pk.init();
-        for (int i = tid; i < pstride; i += NT) pk.merge(partials[(size_t)f * pstride + i].best, partials[(size_t)f * pstride + i].idx);
-        block_reduce_peak(pk, reinterpret_cast<PeakPartial*>(s_g));
-        if (tid == 0) s_row0 = (int)(pk.idx / (unsigned)NA) + win_off;
-        __syncthreads();
-        row0 = s_row0;
-    }
-    const int n_iter = MODE == 2 ? win_rows : (C - slice + WPF - 1) / WPF;
-    auto class_of = [&](int it) -> int {        // the class this workgroup works on in its it-th trip
-        if constexpr (MODE == 2) return (((row0 + it) % NR + NR) % NR) % C;
-        else return slice + it * WPF;
-    };
+    const int n_iter = (C - slice + WPF - 1) / WPF;
+    auto class_of = [&](int it) -> int { return slice + it * WPF; };     // the class this workgroup works on in its it-th trip
     const int c_first = class_of(0);
 
     // class twiddles for this lane's fold inputs n = lane + 64 m:  exp(+j 2 pi n c / NR)
@@ -136,7 +128,9 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
     trk.init();
     const int items = RA_L * Ia;                // (range bin, residue) pairs per class; a multiple of 64
     const int ahalf = NA >> 1, amask = NA - 1;
-    float2* mapf = MODE == 2 ? map + (size_t)f * win_rows * NA : map + (size_t)f * NR * NA;
+    float2* mapf = map + (size_t)f * NR * NA;
+    float* mapp = reinterpret_cast<float*>(map) + (size_t)f * NR * NA;          // MODE 3
+    float* s_pw = reinterpret_cast<float*>(s_twc + (TWC_LDS ? N : 0)) + (size_t)wave * (ROWS1 ? NA : RA_L * P);   // MODE 3: this wave's tile
 
     typedef float v2f __attribute__((ext_vector_type(2)));
 #pragma unroll 1
@@ -182,21 +176,10 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
         }
         __syncthreads();
 
-        if constexpr (MODE == 2) {
-            // ---- window row: the one range bin of this class that lies in the noise window, all NA angle cells -----------
-            if (tid < Ia) {
-                const int k = ((row0 + it) % NR + NR) % NR;
-                const int ql = k / C;
-                float2 y[P];
-                y[0] = s_g[ql];
-#pragma unroll
-                for (int p = 1; p < P; p++) y[p] = cmul_pin(s_g[p * RA_L + ql], ta[p]);
-                fft_fwd_small_pin<P>(y);
-                float2* row = mapf + (size_t)it * NA;
-#pragma unroll
-                for (int u = 0; u < P; u++) row[(Ia * u + r + ahalf) & amask] = y[u];
-            }
-            continue;
+        if constexpr (MODE == 1 || MODE == 3) {      // the class's range profiles for the estimator's window pass: 8 KiB, coalesced 16-byte pieces
+            float4* dst = reinterpret_cast<float4*>(rng_out + ((size_t)f * C + c) * (P * RA_L));
+            const float4* src = reinterpret_cast<const float4*>(s_g);
+            for (int i = tid; i < (P * RA_L) / 2; i += NT) dst[i] = src[i];
         }
         // ---- angle axis + fftshift + store + arg-max ---------------------------------------------
 #pragma unroll 1
@@ -213,6 +196,43 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
             float m = -1.0f;
 #pragma unroll
             for (int u = 0; u < P; u++) m = fmaxf(m, fast_power(y[u]));
+            if constexpr (MODE == 3) {
+                // |z|^2 as blocks_complex_to_mag_squared computes it (volk_32fc_magnitude_squared_32f, generic: re*re + im*im, unfused)
+                const int rw = 64 / Ia;                       // range rows of this wave in this trip: ql0 .. ql0 + rw - 1
+                const int rb = lane / Ia;                     // this lane's row among them
+                const int ql0 = ql - rb;
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                if constexpr (!ROWS1) {
+                    float* trow = s_pw + rb * NA;
+#pragma unroll
+                    for (int u = 0; u < P; u++) trow[(Ia * u + r + ahalf) & amask] = y[u].x * y[u].x + y[u].y * y[u].y;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const int n4 = rw * NA / 4;               // 16-byte pieces in the tile = 16 P
+                    for (int i = lane; i < n4; i += 64) {
+                        const int row = (4 * i) / NA, col = (4 * i) % NA;
+                        const float4 v = *reinterpret_cast<const float4*>(s_pw + 4 * i);
+                        const v4f t = {v.x, v.y, v.z, v.w};
+                        __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(mapp + (size_t)(C * (ql0 + row) + c) * NA + col));
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                } else {
+                    for (int row = 0; row < rw; row++) {
+                        if (rb == row) {
+#pragma unroll
+                            for (int u = 0; u < P; u++) s_pw[(Ia * u + r + ahalf) & amask] = y[u].x * y[u].x + y[u].y * y[u].y;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        for (int i = lane; i < NA / 4; i += 64) {
+                            const float4 v = *reinterpret_cast<const float4*>(s_pw + 4 * i);
+                            const v4f t = {v.x, v.y, v.z, v.w};
+                            __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(mapp + (size_t)(C * (ql0 + row) + c) * NA + 4 * i));
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+            }
             if constexpr (MODE == 0) {
                 // The map is write-once data nothing on the GPU reads back except the estimator's few cells: it is stored non-temporally, so
                 // that no dirty lines are left behind for the next (read-bound) kernel to compete with.
@@ -240,10 +260,48 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
             }
         }
     }
-    if constexpr (MODE != 2) {
-        __syncthreads();
-        block_reduce_peak(trk, reinterpret_cast<PeakPartial*>(s_g));
-        if (tid == 0) { partials[(size_t)f * pstride + slice].best = trk.best; partials[(size_t)f * pstride + slice].idx = trk.idx; }
+    __syncthreads();
+    block_reduce_peak(trk, reinterpret_cast<PeakPartial*>(s_g));
+    if (tid == 0) { partials[(size_t)f * pstride + slice].best = trk.best; partials[(size_t)f * pstride + slice].idx = trk.idx; }
+}
+
+// The estimator's noise-window rows for the map-less modes: one workgroup per frame merges the frame's partial maxima into the peak, and
+// for each of the 2 dr range bins of the window takes the P range bins the fused kernel left in rng and runs the angle axis exactly as
+// the fused kernel does (a lane per residue r: twiddle, P-point transform, fftshift) into win[frame][row][NA].
+template <int P>
+__global__ __launch_bounds__(256) void ra_window_rows_kernel(const float2* __restrict__ rng, const PeakPartial* __restrict__ partials, int pstride,
+                                                             float2* __restrict__ win, const float2* __restrict__ twA, int NR, int Ia,
+                                                             int win_rows, int win_off)
+{
+#pragma clang fp contract(off)
+    __shared__ PeakPartial red[4];
+    __shared__ int s_row0;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int NA = P * Ia, C = NR / RA_L;
+    PeakTracker pk;
+    pk.init();
+    for (int i = tid; i < pstride; i += blockDim.x) pk.merge(partials[(size_t)f * pstride + i].best, partials[(size_t)f * pstride + i].idx);
+    block_reduce_peak(pk, red);
+    if (tid == 0) s_row0 = (int)(pk.idx / (unsigned)NA) + win_off;
+    __syncthreads();
+    const int row0 = s_row0;
+    const int r = tid % Ia;
+    float2 ta[P];
+#pragma unroll
+    for (int p = 1; p < P; p++) ta[p] = twA[(p * r) & (NA - 1)];
+    const int ahalf = NA >> 1, amask = NA - 1;
+    for (int row = tid / Ia; row < win_rows; row += blockDim.x / Ia) {
+        const int k = ((row0 + row) % NR + NR) % NR;
+        const int c = k % C, ql = k / C;                   // k = C ql + c
+        const float2* g = rng + ((size_t)f * C + c) * (P * RA_L) + ql;
+        float2 y[P];
+        y[0] = g[0];
+#pragma unroll
+        for (int p = 1; p < P; p++) y[p] = cmul_pin(g[p * RA_L], ta[p]);
+        fft_fwd_small_pin<P>(y);
+        float2* out = win + ((size_t)f * win_rows + row) * NA;
+#pragma unroll
+        for (int u = 0; u < P; u++) out[(Ia * u + r + ahalf) & amask] = y[u];
     }
 }
 
@@ -271,8 +329,12 @@ struct jrc_chain {
     jrc_ra_result* h_pinned = nullptr;
     // detect-only mode (jrc_chain_set_write_map): the map is not stored; the estimator's noise-window rows are re-computed
     bool write_map = true;
+    int map_format = JRC_MAP_COMPLEX;  // JRC_MAP_POWER: float |z|^2 map (MODE 3)
+    size_t lds_power = 0;             // dynamic LDS of the MODE 3 instantiation (fused-kernel LDS + a tile per wave)
+    bool power_rows1 = false;         // the tile holds one row at a time (LDS short)
     int win_dr = 0;                   // the estimator's discard_range_idx (:189), computed as the device does
     float2* d_win = nullptr;          // [max_frames][2 win_dr][NA]
+    float2* d_rng = nullptr;          // [max_frames][C][P][64] range profiles the map-less modes leave for the window pass
     // background recording / removal (jrc_chain_set_background)
     jrc_bg_state* bg = nullptr;
     float2* d_raw = nullptr;          // [max_frames][P][N] estimates before the subtraction
@@ -369,21 +431,11 @@ static int chain_chunk(const jrc_chain* ch, int wpf)
     return chunk - chunk % nx;
 }
 
-template <int P, int NT, int MMAX, bool TWC_LDS, int MODE>
+template <int P, int NT, int MMAX, bool TWC_LDS, int MODE, bool ROWS1 = false>
 static int launch_fused_mode(jrc_chain* ch, int n_frames, int wpf, int pstride, const float2* d_H, float2* d_map, hipStream_t s)
 {
-    JRC_TRY(jrc_ensure_dyn_lds(ch->ctx, (const void*)range_angle_fused_kernel<P, NT, MMAX, TWC_LDS, MODE>, ch->lds_bytes));
-    if (MODE == 2) {
-        // window pass of detect-only mode: one workgroup per frame walks the 2 dr rows of its noise window
-        const int rows = 2 * ch->win_dr;
-        if (rows <= 0) return JRC_OK;
-        const int nx = ch->ctx->n_xcd;
-        const dim3 grid((unsigned)(((n_frames + nx - 1) / nx) * nx));
-        hipLaunchKernelGGL((range_angle_fused_kernel<P, NT, MMAX, TWC_LDS, MODE>), grid, dim3(NT), ch->lds_bytes, s, d_H, ch->d_win, ch->d_partials,
-                           ch->twR, ch->twA, ch->cfg.fft_len, ch->NR, ch->cfg.interp_angle, n_frames, 1, pstride, rows, ch->NR / 2 - ch->win_dr, nx);
-        JRC_HIP(ch->ctx, hipGetLastError());
-        return JRC_OK;
-    }
+    const size_t lds_bytes = MODE == 3 ? ch->lds_power : ch->lds_bytes;
+    JRC_TRY(jrc_ensure_dyn_lds(ch->ctx, (const void*)range_angle_fused_kernel<P, NT, MMAX, TWC_LDS, MODE, ROWS1>, lds_bytes));
     // One resident wave of workgroups per launch: a batch that needs more is launched in chunks of that size, and a last,
     // smaller chunk gets more slices per frame so that it fills the machine as well (a grid twice the resident size runs 20 %
     // slower than two launches because its second wave of workgroups starts ragged).  `pstride` partial maxima per frame.
@@ -394,10 +446,13 @@ static int launch_fused_mode(jrc_chain* ch, int n_frames, int wpf, int pstride, 
         int w = chain_pick_wpf(ch, nf);
         if (w > pstride) w = pstride;
         const dim3 grid((unsigned)(((nf + nx - 1) / nx) * nx * w));
-        hipLaunchKernelGGL((range_angle_fused_kernel<P, NT, MMAX, TWC_LDS, MODE>), grid, dim3(NT), ch->lds_bytes, s,
-                           d_H + (size_t)f0 * P * ch->cfg.fft_len, MODE == 0 ? d_map + (size_t)f0 * ch->NR * ch->NA : nullptr,
+        float2* mp = MODE == 0 ? d_map + (size_t)f0 * ch->NR * ch->NA
+                   : (MODE == 3 ? reinterpret_cast<float2*>(reinterpret_cast<float*>(d_map) + (size_t)f0 * ch->NR * ch->NA) : nullptr);
+        hipLaunchKernelGGL((range_angle_fused_kernel<P, NT, MMAX, TWC_LDS, MODE, ROWS1>), grid, dim3(NT), lds_bytes, s,
+                           d_H + (size_t)f0 * P * ch->cfg.fft_len, mp,
                            ch->d_partials + (size_t)f0 * pstride,
-                           ch->twR, ch->twA, ch->cfg.fft_len, ch->NR, ch->cfg.interp_angle, nf, w, pstride, 0, 0, nx);
+                           ch->twR, ch->twA, ch->cfg.fft_len, ch->NR, ch->cfg.interp_angle, nf, w, pstride,
+                           (MODE == 1 || MODE == 3) ? ch->d_rng + (size_t)f0 * ch->NR * P : nullptr, nx);
     }
     JRC_HIP(ch->ctx, hipGetLastError());
     return JRC_OK;
@@ -408,7 +463,8 @@ static int launch_fused_nt(jrc_chain* ch, int mode, int n_frames, int wpf, int p
 {
     if (mode == 0) return launch_fused_mode<P, NT, MMAX, TWC_LDS, 0>(ch, n_frames, wpf, pstride, d_H, d_map, s);
     if (mode == 1) return launch_fused_mode<P, NT, MMAX, TWC_LDS, 1>(ch, n_frames, wpf, pstride, d_H, d_map, s);
-    return launch_fused_mode<P, NT, MMAX, TWC_LDS, 2>(ch, n_frames, wpf, pstride, d_H, d_map, s);
+    return ch->power_rows1 ? launch_fused_mode<P, NT, MMAX, TWC_LDS, 3, true>(ch, n_frames, wpf, pstride, d_H, d_map, s)
+                           : launch_fused_mode<P, NT, MMAX, TWC_LDS, 3, false>(ch, n_frames, wpf, pstride, d_H, d_map, s);
 }
 
 template <int P>
@@ -421,6 +477,23 @@ static int launch_fused(jrc_chain* ch, int mode, int n_frames, int wpf, int pstr
     if (ch->threads == 512) return launch_fused_nt<P, 512, 16, true>(ch, mode, n_frames, wpf, pstride, d_H, d_map, s);
     if (ch->cfg.fft_len > 256) return launch_fused_nt<P, 256, 16, true>(ch, mode, n_frames, wpf, pstride, d_H, d_map, s);
     return launch_fused_nt<P, 256, 4, false>(ch, mode, n_frames, wpf, pstride, d_H, d_map, s);
+}
+
+// the window pass of the map-less modes: 2 dr rows per frame from the range profiles in d_rng into d_win
+static int launch_window_rows(jrc_chain* ch, int n_frames, int pstride, hipStream_t s)
+{
+    const int rows = 2 * ch->win_dr;
+    if (rows <= 0) return JRC_OK;
+#define JRC_WIN_CASE(PP) case PP: hipLaunchKernelGGL(ra_window_rows_kernel<PP>, dim3(n_frames), dim3(256), 0, s, ch->d_rng, ch->d_partials, pstride, ch->d_win, \
+                                                     ch->twA, ch->NR, ch->cfg.interp_angle, rows, ch->NR / 2 - ch->win_dr); break;
+    switch (ch->P) {
+        JRC_WIN_CASE(1) JRC_WIN_CASE(2) JRC_WIN_CASE(4) JRC_WIN_CASE(8)
+        default: hipLaunchKernelGGL(ra_window_rows_kernel<16>, dim3(n_frames), dim3(256), 0, s, ch->d_rng, ch->d_partials, pstride, ch->d_win, ch->twA,
+                                    ch->NR, ch->cfg.interp_angle, rows, ch->NR / 2 - ch->win_dr);
+    }
+#undef JRC_WIN_CASE
+    JRC_HIP(ch->ctx, hipGetLastError());
+    return JRC_OK;
 }
 
 static int launch_fused_any(jrc_chain* ch, int mode, int n_frames, int wpf, int pstride, const float2* d_H, float2* d_map, hipStream_t s)
@@ -506,6 +579,7 @@ extern "C" void jrc_chain_destroy(jrc_chain* ch)
     if (ch->d_partials) (void)hipFree(ch->d_partials);
     if (ch->d_pad) (void)hipFree(ch->d_pad);
     if (ch->d_win) (void)hipFree(ch->d_win);
+    if (ch->d_rng) (void)hipFree(ch->d_rng);
     if (ch->d_raw) (void)hipFree(ch->d_raw);
     bg_release(ch->bg);
     if (ch->h_pinned) (void)hipHostFree(ch->h_pinned);
@@ -517,7 +591,10 @@ extern "C" size_t jrc_chain_frame_bytes(const jrc_chain* ch)
     return ch ? sizeof(float2) * (size_t)(ch->cfg.N_tx + ch->cfg.N_rx) * ch->cfg.n_items * ch->cfg.fft_len : 0;
 }
 extern "C" size_t jrc_chain_chanest_bytes(const jrc_chain* ch) { return ch ? sizeof(float2) * (size_t)ch->P * ch->cfg.fft_len : 0; }
-extern "C" size_t jrc_chain_map_bytes(const jrc_chain* ch) { return ch ? sizeof(float2) * (size_t)ch->NR * ch->NA : 0; }
+extern "C" size_t jrc_chain_map_bytes(const jrc_chain* ch)
+{
+    return ch ? (ch->map_format == JRC_MAP_POWER ? sizeof(float) : sizeof(float2)) * (size_t)ch->NR * ch->NA : 0;
+}
 
 // how many launches of the dominant kernel one jrc_chain_run_dev of n_frames makes (batches beyond one resident wave of
 // workgroups are launched in chunks; bench.py reports the roofline per launch)
@@ -673,22 +750,46 @@ extern "C" int jrc_chain_prime_background_dev(jrc_chain* ch, int n_frames, const
     return chain_background_step(ch, n_frames, ch->d_raw, nullptr, s);
 }
 
-// detect-only mode: write_map = 0 -> jrc_chain_run_dev ignores d_map (may be NULL) and stores no map; results are bit-identical
-extern "C" int jrc_chain_set_write_map(jrc_chain* ch, int write_map)
+// the estimator's window buffer, needed whenever no complex map is stored (detect-only and power-map modes)
+static int chain_need_window(jrc_chain* ch, const char* what)
 {
-    if (!ch) return JRC_ERR_INVALID_ARG;
     jrc_ctx* ctx = ch->ctx;
-    if (write_map) { ch->write_map = true; return JRC_OK; }
-    if (ch->generic) return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "detect-only mode: this shape runs block by block and needs the map");
+    if (ch->generic) return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "%s: this shape runs block by block and needs the complex map", what);
     if (2 * ch->win_dr > ch->NR || ch->win_dr < 0)
-        return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "detect-only mode: the noise window (%d range bins) is larger than the map", 2 * ch->win_dr);
+        return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "%s: the noise window (%d range bins) is larger than the map", what, 2 * ch->win_dr);
     JRC_BIND(ctx);
     if (!ch->d_win) {
         const size_t bytes = sizeof(float2) * (size_t)ch->max_frames * (size_t)(2 * ch->win_dr ? 2 * ch->win_dr : 1) * ch->NA;
         hipError_t e = hipMalloc((void**)&ch->d_win, bytes);
-        if (e != hipSuccess) return jrc_fail(ctx, JRC_ERR_HIP, "jrc_chain_set_write_map: %s", hipGetErrorString(e));
+        if (e == hipSuccess) e = hipMalloc((void**)&ch->d_rng, sizeof(float2) * (size_t)ch->max_frames * ch->NR * ch->P);
+        if (e != hipSuccess) return jrc_fail(ctx, JRC_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
     }
+    return JRC_OK;
+}
+
+// detect-only mode: write_map = 0 -> jrc_chain_run_dev ignores d_map (may be NULL) and stores no map; results are bit-identical
+extern "C" int jrc_chain_set_write_map(jrc_chain* ch, int write_map)
+{
+    if (!ch) return JRC_ERR_INVALID_ARG;
+    if (write_map) { ch->write_map = true; return JRC_OK; }
+    JRC_TRY(chain_need_window(ch, "detect-only mode"));
     ch->write_map = false;
+    return JRC_OK;
+}
+
+// map format: JRC_MAP_COMPLEX (the estimator's input, default) or JRC_MAP_POWER (float |z|^2, the heat-map branch's input)
+extern "C" int jrc_chain_set_map_format(jrc_chain* ch, int format)
+{
+    if (!ch || (format != JRC_MAP_COMPLEX && format != JRC_MAP_POWER)) return JRC_ERR_INVALID_ARG;
+    if (format == JRC_MAP_COMPLEX) { ch->map_format = format; return JRC_OK; }
+    JRC_TRY(chain_need_window(ch, "power-map mode"));
+    // a tile of floats per wave on top of the fused kernel's LDS: all rows of a trip (64 P floats) when that fits, else one row (NA floats)
+    const size_t waves = (size_t)ch->threads / 64, cap = 160 * 1024 - 256;
+    const size_t full = ch->lds_bytes + sizeof(float) * waves * RA_L * ch->P, one = ch->lds_bytes + sizeof(float) * waves * ch->NA;
+    if (full <= cap) { ch->lds_power = full; ch->power_rows1 = false; }
+    else if (one <= cap) { ch->lds_power = one; ch->power_rows1 = true; }
+    else return jrc_fail(ch->ctx, JRC_ERR_UNSUPPORTED, "power-map mode: no LDS left for the store tile at this shape (%zu bytes needed)", one);
+    ch->map_format = format;
     return JRC_OK;
 }
 
@@ -737,7 +838,7 @@ static int chain_run(jrc_chain* ch, int n_frames, const jrc_cf32* d_frames, cons
         d_chanest = d_est_out;
     }
     if (ev) JRC_HIP(ctx, hipEventRecord(ev[1], s));
-    if (!ch->write_map && ch->generic) return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "detect-only mode needs the fused kernel");
+    if ((!ch->write_map || ch->map_format != JRC_MAP_COMPLEX) && ch->generic) return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "detect-only / power-map mode needs the fused kernel");
     if (ch->write_map && !d_map) return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_run_dev: d_map is NULL but the chain stores the map (jrc_chain_set_write_map)");
     // A2 + A3 + A4 + arg-max half of A5
     int partials_per_frame;
@@ -765,9 +866,10 @@ static int chain_run(jrc_chain* ch, int n_frames, const jrc_cf32* d_frames, cons
         const int pstride = tail ? chain_pick_wpf(ch, tail) : wpf;
         if (pstride != wpf)      // frames of full chunks leave slots unused: all-ones = NaN power, never wins a merge
             JRC_HIP(ctx, hipMemsetAsync(ch->d_partials, 0xFF, sizeof(PeakPartial) * (size_t)n_frames * pstride, s));
-        JRC_TRY(launch_fused_any(ch, ch->write_map ? 0 : 1, n_frames, wpf, pstride, (const float2*)d_chanest, (float2*)d_map, s));
-        if (!ch->write_map)      // the noise-window rows, through the same transforms, into the compact window buffer
-            JRC_TRY(launch_fused_any(ch, 2, n_frames, 1, pstride, (const float2*)d_chanest, nullptr, s));
+        const int mode = !ch->write_map ? 1 : (ch->map_format == JRC_MAP_POWER ? 3 : 0);
+        JRC_TRY(launch_fused_any(ch, mode, n_frames, wpf, pstride, (const float2*)d_chanest, (float2*)d_map, s));
+        if (mode != 0)           // no complex map to read: the noise-window rows, through the same angle-axis code, into the compact window buffer
+            JRC_TRY(launch_window_rows(ch, n_frames, pstride, s));
         if (ev) JRC_HIP(ctx, hipEventRecord(ev[2], s));
         partials_per_frame = pstride;
     }
@@ -775,7 +877,7 @@ static int chain_run(jrc_chain* ch, int n_frames, const jrc_cf32* d_frames, cons
     RaParams prm;
     prm.vlen = ch->NA; prm.n_inputs = ch->NR; prm.n_range_bins = ch->NR; prm.n_angle_bins = ch->NA;
     prm.noise_discard_range_m = c.noise_discard_range_m; prm.noise_discard_angle_deg = c.noise_discard_angle_deg;
-    if (ch->write_map)
+    if (ch->write_map && ch->map_format == JRC_MAP_COMPLEX)
         JRC_TRY(launch_ra_finalize(ctx, (const float2*)d_map, (size_t)ch->NR * ch->NA, ch->d_partials, partials_per_frame, prm, ch->d_bins,
                                    ch->d_bins + ch->NR, d_results, n_frames, 0, s));
     else

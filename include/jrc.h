@@ -229,6 +229,13 @@ int  jrc_chain_prime_background_dev(jrc_chain* chain, int n_frames, const jrc_cf
  * re-computed by the same kernel code into a small buffer, so d_results is bit-identical to write_map = 1.  For consumers that only
  * take range_angle_estimator's `params` message (:234-253).  Fused-kernel shapes only (else JRC_ERR_UNSUPPORTED). */
 int  jrc_chain_set_write_map(jrc_chain* chain, int write_map);
+/* Map format.  JRC_MAP_COMPLEX (default): d_map is the complex map the reference's estimator reads.  JRC_MAP_POWER: d_map is
+ * float [n_frames][fft_len*Ir][P*Ia] holding |z|^2 = re*re + im*im — the stream the flowgraph's display branch consumes
+ * (blocks_complex_to_mag_squared -> gui_heatmap_plot, examples/simulation/radar/mimo_ofdm_jrc_radar_sim.grc:2192) — at half the bytes;
+ * d_results is bit-identical to the complex format (the estimator's window rows are re-computed as in detect-only mode).
+ * jrc_chain_map_bytes follows the format.  Fused-kernel shapes only. */
+enum { JRC_MAP_COMPLEX = 0, JRC_MAP_POWER = 1 };
+int  jrc_chain_set_map_format(jrc_chain* chain, int format);
 
 /* ---- host-fed pipeline over the chain: what a GNU Radio work() hands over is HOST memory (the T+R input ring buffers of
  *      mimo_ofdm_radar, lib/mimo_ofdm_radar_impl.cc:207-238) and what leaves the radar branch is one small record per

@@ -367,3 +367,62 @@ def test_time_domain_entry_with_background_and_detect_only(jrc, ctx):
     assert np.array_equal(out["td_detect"][1], out["td_map"][1])
     raw = np.abs(np.einsum("frsn,ftsn->frtn", fr[:, sc.T:, sc.Npre:], np.conj(fr[:, :sc.T, sc.Npre:]))).max()
     assert np.abs(out["td_map"][1] - out["fd_map"][1]).max() < 2e-6 * raw
+
+
+# ---- power-map format (the heat-map branch's stream) -----------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg,F", [("A", 7), ("B", 5), ("B", 512), ("D", 3), ("D", 256)])
+def test_power_map_equals_magnitude_squared_of_the_complex_map(jrc, ctx, cfg, F):
+    """JRC_MAP_POWER: the map as float |z|^2 = re*re + im*im (blocks_complex_to_mag_squared, ...radar_sim.grc:2192) — every cell equal to
+    that expression on the complex map's cell bit for bit, result records byte-identical to the complex format; config D takes the
+    one-row-at-a-time store tile (LDS), the others the full tile"""
+    import torch
+    from jrc_amd import synth
+    sc = {"A": synth.config_A, "B": synth.config_B, "D": synth.config_D}[cfg]()
+    nd = min(F, 4)
+    base = synth.make_frames(sc, nd)
+    frames = np.concatenate([base] * (F // nd + 1))[:F]
+    frames = (frames * (1.0 + 0.25 * np.arange(F, dtype=np.float32))[:, None, None, None]).astype(np.complex64)
+    ch, _ = _chain(jrc, ctx, sc, 8, 16, F)
+    bufs = ch.alloc(F, "cuda:0")
+    _load(bufs, frames, F)
+    ch.run(bufs, F)
+    want = [_rec(r) for r in ch.results(bufs, F)]
+    ch.set_map_format(True)
+    assert ch.map_bytes * 2 == ch.NR * ch.NA * 8
+    pb = ch.alloc(F, "cuda:0", power_map=True)
+    pb["frames"].copy_(bufs["frames"])
+    pb["map"].fill_(float("nan"))
+    torch.cuda.synchronize()
+    ch.run(pb, F)
+    got = [_rec(r) for r in ch.results(pb, F)]
+    assert got == want
+    re, im = bufs["map"][..., 0], bufs["map"][..., 1]
+    assert torch.equal(pb["map"], re * re + im * im)          # two roundings of the products, one of the sum: no FMA
+    assert torch.equal(pb["chanest"], bufs["chanest"])
+    ch.set_map_format(False)                                   # back to the complex format
+    bufs["map"].zero_()
+    torch.cuda.synchronize()
+    ch.run(bufs, F)
+    assert [_rec(r) for r in ch.results(bufs, F)] == want
+
+
+@pytest.mark.parametrize("T,R,N,S,Ir,Ia,interleave", _shapes(10, seed=5))
+def test_power_map_random_shapes(jrc, ctx, T, R, N, S, Ir, Ia, interleave):
+    import torch
+    from jrc_amd import synth
+    sc = synth.Scenario(N, T, R, S, targets=[(0.3 * 3e8 * N / (2 * 125e6) * 0.5, 25.0, 0.0, 90.0)])
+    F = 3
+    ch, _ = _chain(jrc, ctx, sc, Ir, Ia, F, enable_tx_interleave=interleave)
+    bufs = ch.alloc(F, "cuda:0")
+    _load(bufs, synth.make_frames(sc, F), F)
+    ch.run(bufs, F)
+    want = [_rec(r) for r in ch.results(bufs, F)]
+    ch.set_map_format(True)
+    pb = ch.alloc(F, "cuda:0", power_map=True)
+    pb["frames"].copy_(bufs["frames"])
+    pb["map"].fill_(float("nan"))
+    torch.cuda.synchronize()
+    ch.run(pb, F)
+    assert [_rec(r) for r in ch.results(pb, F)] == want
+    re, im = bufs["map"][..., 0], bufs["map"][..., 1]
+    assert torch.equal(pb["map"], re * re + im * im)

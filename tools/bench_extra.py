@@ -104,6 +104,32 @@ def detect_only(cfg="B", F=None):
                 ms_per_step_map_mode=t_map * 1e3)
 
 
+def power_map(cfg="B", F=None):
+    """power-map format: the chain with the map stored as float |z|^2 (the heat-map branch's stream), half the map bytes"""
+    sc = {"B": synth.config_B, "D": synth.config_D}[cfg]()
+    F = F or (512 if cfg == "B" else 256)
+    Ir, Ia, P = 8, 16, sc.T * sc.R
+    rb, ab = jrc_amd.radar_axes(sc.N, sc.fs, Ir, P, Ia)
+    ctx = jrc_amd.Context(0)
+    chain = jrc_amd.RadarChain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb, ab, 2.4, 14.36, 15.0, 0.0, max_frames=F, ctx=ctx)
+    chain.set_map_format(True)
+    bufs = chain.alloc(F, "cuda:0", power_map=True)
+    fr = synth.make_frames(sc, 8)
+    hf = torch.from_numpy(fr.view(np.float32).reshape((8,) + tuple(bufs["frames"].shape[1:])))
+    for f0 in range(0, F, 8):
+        bufs["frames"][f0:f0 + 8].copy_(hf[:min(8, F - f0)])
+    torch.cuda.synchronize()
+    chain.run(bufs, F)
+    ctx.sync()
+    chain.set_timing(True)
+    t = timed(lambda: chain.run(bufs, F))
+    kt = chain.get_timing()
+    alg = F * ((sc.T + sc.R) * sc.S * sc.N * 8 + chain.NR * chain.NA * 4 + 48)
+    return dict(what="chain with the map as float |z|^2 (heat-map stream), config %s, %d frames per step" % (cfg, F), frames_per_step=F,
+                ms_per_step=t * 1e3, frames_per_s=F / t, algorithmic_bytes_per_frame=alg // F, GBps_algorithmic=alg / t / 1e9,
+                kernels_ms={"radar_chanest": kt["radar_chanest"], "fused_power_plus_window": kt["range_angle_fused"], "ra_finalize": kt["ra_finalize"]})
+
+
 def range_doppler(cfg="D", F=8, Id=1):
     """row D (no reference counterpart): D[p][sym][sc] = rx conj(tx) -> IFFT over subcarriers (N*Ir) -> FFT over symbols (S*Id, shifted)"""
     sc = {"B": synth.config_B, "D": synth.config_D}[cfg]()
@@ -270,7 +296,7 @@ if __name__ == "__main__":
     # the two probes that run as child processes go first: once this process holds a GPU context they would time-slice with it
     only = os.environ.get("JRC_BENCH_EXTRA_ONLY")
     if only == "detect":
-        print(json.dumps(detect_only("B"))); print(json.dumps(detect_only("D"))); sys.exit(0)
+        print(json.dumps(detect_only("B"))); print(json.dumps(detect_only("D"))); print(json.dumps(power_map("B"))); print(json.dumps(power_map("D"))); sys.exit(0)
     for fn in (sync_front_end, comm_rx_chain, lambda: detect_only("B"), lambda: detect_only("D"), lambda: radar_with_demod("B", 512), lambda: radar_with_demod("D", 256), precoder_config_c, lambda: range_doppler("D", 8), lambda: range_doppler("B", 64),
                lambda: simulated_chain("B", 64), lambda: simulated_chain("D", 8), equalizer_config_c):
         print(json.dumps(fn()))
