@@ -53,7 +53,8 @@
 //         at half the bytes of the complex map.  A lane's 4-byte cells would make 64-byte store segments, so each wave turns its cells
 //         through a private LDS tile ([rows of this trip][NA] floats) and stores whole 16-byte pieces of full rows; the estimator reads
 //         the MODE 2 window rows as in detect-only mode.  ROWS1: the tile holds one row at a time (when LDS is short: fft_len 1024).
-template <int P, int NT, int MMAX, bool TWC_LDS, int MODE, bool ROWS1 = false>
+// IA: interp_angle known at compile time (16, the flowgraphs' interp_factor_angle), or 0 for the runtime argument
+template <int P, int NT, int MMAX, bool TWC_LDS, int MODE, int IA, bool ROWS1 = false>
 #ifndef JRC_WPS256
 #define JRC_WPS256 3
 #endif
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
     PeakPartial* __restrict__ partials,  // [F][pstride]
     const float2* __restrict__ twR,      // [NR]  exp(+j 2 pi i / NR)
     const float2* __restrict__ twA,      // [NA]  exp(-j 2 pi i / NA)
-    int N, int NR, int Ia, int F, int WPF,
+    int N, int NR, int Ia_arg, int F, int WPF,
     int pstride,                         // partial maxima per frame in `partials` (>= WPF; unused slots hold the neutral element)
     float2* __restrict__ rng_out,        // MODE 1 / 3: [F][C][P][64] range profiles for the window pass
     int nx)                              // XCDs the hardware deals consecutive workgroups over (jrc_ctx::n_xcd)           // MODE 2: rows of the noise window (2 dr) and its offset from the peak's range bin (NR/2 - dr)
@@ -71,6 +72,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
 #pragma clang fp contract(off)          // every rounding of this kernel is spelled out (fmaf / cmul_pin / fft_fwd_small_pin): the three MODEs agree bit for bit
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     constexpr int NW = NT / 64;
+    const int Ia = IA > 0 ? IA : Ia_arg;
     const int NA = P * Ia;
     const int C = NR / RA_L;
     // XCD-aware decode: block b runs on XCD b % nx; the slices of a frame share that frame's H,
@@ -236,18 +238,24 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
             if constexpr (MODE == 0) {
                 // The map is write-once data nothing on the GPU reads back except the estimator's few cells: it is stored non-temporally, so
                 // that no dirty lines are left behind for the next (read-bound) kernel to compete with.
-                // Each of a lane's P stores sits behind a wave-uniform branch on a kernel argument (always taken): measured, not cosmetic.
-                // The same stores issued back to back run 10 % slower at config B (0.448 against 0.405 ms per 512 frames), handed out one
-                // by one between the butterflies of the last stage 30 % slower, and with interp_angle compiled in (row offsets as
-                // immediates, 30 fewer registers, no spills) 15-25 % slower in every arrangement — the taken branches space a wave's
-                // stores and keep the workgroups of a launch in step on their classes, which is what the memory system rewards here
-                // (rotating the class order per frame costs 7 %).  tools/ra_variants.py holds the harness; DESIGN.md §3.1 the numbers.
+                // How a lane's P stores are issued is measured, not cosmetic (tools/ra_variants.py; DESIGN.md §3.1 has the table).  The memory
+                // system rewards a wave that keeps FEW stores in flight: with interp_angle compiled in (row offsets as immediates, no
+                // spills) the stores go out back to back with an `s_waitcnt vmcnt(1)` after every eighth — 0.362 ms per 512 config-B frames
+                // (74.6 % of the HBM peak) against 0.488 ms unthrottled and 0.405 ms for the round-1 shape.  That shape — kept for the
+                // runtime interp_angle — puts every store behind a wave-uniform branch on a kernel argument (always taken): the taken
+                // branches, and the vmcnt(0) waits of its spill reloads, throttle a wave in the same way, by accident.
                 float2* row = mapf + (size_t)k * NA;
 #pragma unroll
                 for (int u = 0; u < P; u++) {
                     const int a = (Ia * u + r + ahalf) & amask;   // fftshift: out'[a'] = out[(a' + NA/2) % NA]
-                    if (WPF > 0) { const v2f t = {y[u].x, y[u].y}; __builtin_nontemporal_store(t, reinterpret_cast<v2f*>(row + a)); }
-                    else row[a] = y[u];
+                    if constexpr (IA > 0) {
+                        const v2f t = {y[u].x, y[u].y};
+                        __builtin_nontemporal_store(t, reinterpret_cast<v2f*>(row + a));
+                        if ((u & 7) == 7) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                    } else {
+                        if (WPF > 0) { const v2f t = {y[u].x, y[u].y}; __builtin_nontemporal_store(t, reinterpret_cast<v2f*>(row + a)); }
+                        else row[a] = y[u];
+                    }
                 }
             }
             // estimator arg-max (lib/range_angle_estimator_impl.cc:137-151) on the values still in registers
@@ -431,11 +439,11 @@ static int chain_chunk(const jrc_chain* ch, int wpf)
     return chunk - chunk % nx;
 }
 
-template <int P, int NT, int MMAX, bool TWC_LDS, int MODE, bool ROWS1 = false>
+template <int P, int NT, int MMAX, bool TWC_LDS, int MODE, int IA, bool ROWS1 = false>
 static int launch_fused_mode(jrc_chain* ch, int n_frames, int wpf, int pstride, const float2* d_H, float2* d_map, hipStream_t s)
 {
     const size_t lds_bytes = MODE == 3 ? ch->lds_power : ch->lds_bytes;
-    JRC_TRY(jrc_ensure_dyn_lds(ch->ctx, (const void*)range_angle_fused_kernel<P, NT, MMAX, TWC_LDS, MODE, ROWS1>, lds_bytes));
+    JRC_TRY(jrc_ensure_dyn_lds(ch->ctx, (const void*)range_angle_fused_kernel<P, NT, MMAX, TWC_LDS, MODE, IA, ROWS1>, lds_bytes));
     // One resident wave of workgroups per launch: a batch that needs more is launched in chunks of that size, and a last,
     // smaller chunk gets more slices per frame so that it fills the machine as well (a grid twice the resident size runs 20 %
     // slower than two launches because its second wave of workgroups starts ragged).  `pstride` partial maxima per frame.
@@ -448,7 +456,7 @@ static int launch_fused_mode(jrc_chain* ch, int n_frames, int wpf, int pstride, 
         const dim3 grid((unsigned)(((nf + nx - 1) / nx) * nx * w));
         float2* mp = MODE == 0 ? d_map + (size_t)f0 * ch->NR * ch->NA
                    : (MODE == 3 ? reinterpret_cast<float2*>(reinterpret_cast<float*>(d_map) + (size_t)f0 * ch->NR * ch->NA) : nullptr);
-        hipLaunchKernelGGL((range_angle_fused_kernel<P, NT, MMAX, TWC_LDS, MODE, ROWS1>), grid, dim3(NT), lds_bytes, s,
+        hipLaunchKernelGGL((range_angle_fused_kernel<P, NT, MMAX, TWC_LDS, MODE, IA, ROWS1>), grid, dim3(NT), lds_bytes, s,
                            d_H + (size_t)f0 * P * ch->cfg.fft_len, mp,
                            ch->d_partials + (size_t)f0 * pstride,
                            ch->twR, ch->twA, ch->cfg.fft_len, ch->NR, ch->cfg.interp_angle, nf, w, pstride,
@@ -461,10 +469,18 @@ static int launch_fused_mode(jrc_chain* ch, int n_frames, int wpf, int pstride, 
 template <int P, int NT, int MMAX, bool TWC_LDS>
 static int launch_fused_nt(jrc_chain* ch, int mode, int n_frames, int wpf, int pstride, const float2* d_H, float2* d_map, hipStream_t s)
 {
-    if (mode == 0) return launch_fused_mode<P, NT, MMAX, TWC_LDS, 0>(ch, n_frames, wpf, pstride, d_H, d_map, s);
-    if (mode == 1) return launch_fused_mode<P, NT, MMAX, TWC_LDS, 1>(ch, n_frames, wpf, pstride, d_H, d_map, s);
-    return ch->power_rows1 ? launch_fused_mode<P, NT, MMAX, TWC_LDS, 3, true>(ch, n_frames, wpf, pstride, d_H, d_map, s)
-                           : launch_fused_mode<P, NT, MMAX, TWC_LDS, 3, false>(ch, n_frames, wpf, pstride, d_H, d_map, s);
+    // interp_angle = 16 (the flowgraphs' interp_factor_angle, examples/simulation/radar/mimo_ofdm_jrc_radar_sim.grc) is compiled in; any other
+    // value takes the runtime argument
+    if (ch->cfg.interp_angle == 16) {
+        if (mode == 0) return launch_fused_mode<P, NT, MMAX, TWC_LDS, 0, 16>(ch, n_frames, wpf, pstride, d_H, d_map, s);
+        if (mode == 1) return launch_fused_mode<P, NT, MMAX, TWC_LDS, 1, 16>(ch, n_frames, wpf, pstride, d_H, d_map, s);
+        return ch->power_rows1 ? launch_fused_mode<P, NT, MMAX, TWC_LDS, 3, 16, true>(ch, n_frames, wpf, pstride, d_H, d_map, s)
+                               : launch_fused_mode<P, NT, MMAX, TWC_LDS, 3, 16, false>(ch, n_frames, wpf, pstride, d_H, d_map, s);
+    }
+    if (mode == 0) return launch_fused_mode<P, NT, MMAX, TWC_LDS, 0, 0>(ch, n_frames, wpf, pstride, d_H, d_map, s);
+    if (mode == 1) return launch_fused_mode<P, NT, MMAX, TWC_LDS, 1, 0>(ch, n_frames, wpf, pstride, d_H, d_map, s);
+    return ch->power_rows1 ? launch_fused_mode<P, NT, MMAX, TWC_LDS, 3, 0, true>(ch, n_frames, wpf, pstride, d_H, d_map, s)
+                           : launch_fused_mode<P, NT, MMAX, TWC_LDS, 3, 0, false>(ch, n_frames, wpf, pstride, d_H, d_map, s);
 }
 
 template <int P>
