@@ -27,6 +27,12 @@
 #include <cmath>
 #include <cstdlib>
 
+#ifndef RA_TH_EVERY
+#define RA_TH_EVERY 8
+#endif
+#ifndef RA_TH_CNT
+#define RA_TH_CNT 1
+#endif
 #define RA_L 64   // range bins (and fold length) per workgroup
 
 // ---- the fused kernel ------------------------------------------------------------------------
@@ -67,7 +73,8 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
     int N, int NR, int Ia_arg, int F, int WPF,
     int pstride,                         // partial maxima per frame in `partials` (>= WPF; unused slots hold the neutral element)
     float2* __restrict__ rng_out,        // MODE 1 / 3: [F][C][P][64] range profiles for the window pass
-    int nx)                              // XCDs the hardware deals consecutive workgroups over (jrc_ctx::n_xcd)           // MODE 2: rows of the noise window (2 dr) and its offset from the peak's range bin (NR/2 - dr)
+    int nx,                              // XCDs the hardware deals consecutive workgroups over (jrc_ctx::n_xcd)
+    int pace)                            // MODE 0 store pacing: bits 0-11 ticks of 10 ns between a wave's groups of eight stores (0 = off), 12-15 groups it may catch up, 16-17 wave priorities
 {
 #pragma clang fp contract(off)          // every rounding of this kernel is spelled out (fmaf / cmul_pin / fft_fwd_small_pin): the three MODEs agree bit for bit
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
@@ -135,6 +142,16 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
     float* s_pw = reinterpret_cast<float*>(s_twc + (TWC_LDS ? N : 0)) + (size_t)wave * (ROWS1 ? NA : RA_L * P);   // MODE 3: this wave's tile
 
     typedef float v2f __attribute__((ext_vector_type(2)));
+    // store pacing (MODE 0): release time of the wave's next group of stores, in ticks of the 100 MHz real-time counter
+    const int pace_T = pace & 0xfff, pace_K = (pace >> 12) & 0xf;
+    long long t_next = 0;
+    if constexpr (MODE == 0 && IA > 0) {
+        if (pace_T) t_next = (long long)wall_clock64();
+        if ((pace >> 16) & 3) {            // the waves that share a SIMD get different priorities, so that one computes while the other waits on its stores
+            const bool first = NT >= 512 ? (wave < NW / 2) : (((j >> 5) & 1) == 0);
+            if (first) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+        }
+    }
 #pragma unroll 1
     for (int it = 0; it < n_iter; it++) {
         const int c = class_of(it);
@@ -144,26 +161,41 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
         }
         __syncthreads();                        // s_H staged (first trip) / previous class's s_g reads done
         // ---- range axis: fold to 64 points, 64-point inverse FFT across the wavefront -------------
-#pragma unroll 1
-        for (int p = wave; p < P; p += NW) {
-            const float2* Hp = s_H + (size_t)p * N + lane;
-            float2 v = make_float2(0.f, 0.f);
+        {   // the wave's pairs p = wave + NW j side by side: they share the class twiddle of a fold term, and their butterfly chains interleave
+            constexpr int PPW = (P + NW - 1) / NW;
+            constexpr bool full = (P % NW) == 0;    // every wave has PPW pairs
+            float2 v[PPW];
+#pragma unroll
+            for (int j = 0; j < PPW; j++) v[j] = make_float2(0.f, 0.f);
 #pragma unroll
             for (int m = 0; m < MMAX; m++)
                 if (m < M) {
                     float2 w;
                     if constexpr (TWC_LDS) w = s_twc[lane + RA_L * m]; else w = tc[m];
-                    const float2 h = Hp[RA_L * m];
-                    v.x = fmaf(h.x, w.x, fmaf(-h.y, w.y, v.x));
-                    v.y = fmaf(h.x, w.y, fmaf(h.y, w.x, v.y));
-                }
 #pragma unroll
-            for (int st = 0; st < 6; st++) {   // radix-2 DIF
-                const int half = 32 >> st;
-                const float2 o = make_float2(__shfl_xor(v.x, half), __shfl_xor(v.y, half));
-                v = (lane & half) ? cmul_pin(csub(o, v), t64[st]) : cadd(v, o);
-            }
-            s_g[p * RA_L + (__brev((unsigned)lane) >> 26)] = v;   // lane holds X[bitrev6(lane)]
+                    for (int j = 0; j < PPW; j++)
+                        if (full || wave + NW * j < P) {
+                            const float2 h = s_H[(size_t)(wave + NW * j) * N + lane + RA_L * m];
+                            v[j].x = fmaf(h.x, w.x, fmaf(-h.y, w.y, v[j].x));
+                            v[j].y = fmaf(h.x, w.y, fmaf(h.y, w.x, v[j].y));
+                        }
+                }
+            // radix-2 DIF across the wavefront, stage st pairs lanes that differ in bit 5 - st: v + o below, (o - v) t above
+#pragma unroll
+            for (int j = 0; j < PPW; j++) v[j] = wave_dif_stage<5>(v[j], t64[0], lane);
+#pragma unroll
+            for (int j = 0; j < PPW; j++) v[j] = wave_dif_stage<4>(v[j], t64[1], lane);
+#pragma unroll
+            for (int j = 0; j < PPW; j++) v[j] = wave_dif_stage<3>(v[j], t64[2], lane);
+#pragma unroll
+            for (int j = 0; j < PPW; j++) v[j] = wave_dif_stage<2>(v[j], t64[3], lane);
+#pragma unroll
+            for (int j = 0; j < PPW; j++) v[j] = wave_dif_stage<1>(v[j], t64[4], lane);
+#pragma unroll
+            for (int j = 0; j < PPW; j++) v[j] = wave_dif_stage<0>(v[j], t64[5], lane);
+#pragma unroll
+            for (int j = 0; j < PPW; j++)
+                if (full || wave + NW * j < P) s_g[(wave + NW * j) * RA_L + (__brev((unsigned)lane) >> 26)] = v[j];   // lane holds X[bitrev6(lane)]
         }
         if (it + 1 < n_iter) {                  // prefetch the next class's twiddles; they land during the stores
             const int cn = class_of(it + 1);
@@ -249,9 +281,15 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
                 for (int u = 0; u < P; u++) {
                     const int a = (Ia * u + r + ahalf) & amask;   // fftshift: out'[a'] = out[(a' + NA/2) % NA]
                     if constexpr (IA > 0) {
+                        if ((u % RA_TH_EVERY) == 0 && pace_T) {
+                            long long now = (long long)wall_clock64();
+                            t_next += pace_T;
+                            if (now - t_next > (long long)pace_K * pace_T) t_next = now - (long long)pace_K * pace_T;
+                            while (now < t_next) { asm volatile("s_sleep 1"); now = (long long)wall_clock64(); }
+                        }
                         const v2f t = {y[u].x, y[u].y};
                         __builtin_nontemporal_store(t, reinterpret_cast<v2f*>(row + a));
-                        if ((u & 7) == 7) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                        if ((u % RA_TH_EVERY) == RA_TH_EVERY - 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(RA_TH_CNT) : "memory");
                     } else {
                         if (WPF > 0) { const v2f t = {y[u].x, y[u].y}; __builtin_nontemporal_store(t, reinterpret_cast<v2f*>(row + a)); }
                         else row[a] = y[u];
@@ -439,6 +477,16 @@ static int chain_chunk(const jrc_chain* ch, int wpf)
     return chunk - chunk % nx;
 }
 
+static int chain_pace(const jrc_chain* ch)
+{
+    if (ch->ctx->tune.ra_pace >= 0) return ch->ctx->tune.ra_pace;      // JRC_RA_PACE
+    // measured (tools/pace_sweep.sh): eight waves per CU, each releasing 8 x 512 B every 1.21 us and allowed to catch up one
+    // group — 7 TB/s offered — hold the map stream at the rate of a pure store stream (0.341 ms per 512 config-B frames, 79 % of the HBM
+    // peak; 0.366 ms unpaced); other geometries are not paced
+    if (ch->P == 16 && ch->cfg.interp_angle == 16 && ch->threads == 256 && ch->wg_per_cu == 2) return (1 << 12) | 121;
+    return 0;
+}
+
 template <int P, int NT, int MMAX, bool TWC_LDS, int MODE, int IA, bool ROWS1 = false>
 static int launch_fused_mode(jrc_chain* ch, int n_frames, int wpf, int pstride, const float2* d_H, float2* d_map, hipStream_t s)
 {
@@ -460,7 +508,7 @@ static int launch_fused_mode(jrc_chain* ch, int n_frames, int wpf, int pstride, 
                            d_H + (size_t)f0 * P * ch->cfg.fft_len, mp,
                            ch->d_partials + (size_t)f0 * pstride,
                            ch->twR, ch->twA, ch->cfg.fft_len, ch->NR, ch->cfg.interp_angle, nf, w, pstride,
-                           (MODE == 1 || MODE == 3) ? ch->d_rng + (size_t)f0 * ch->NR * P : nullptr, nx);
+                           (MODE == 1 || MODE == 3) ? ch->d_rng + (size_t)f0 * ch->NR * P : nullptr, nx, chain_pace(ch));
     }
     JRC_HIP(ch->ctx, hipGetLastError());
     return JRC_OK;

@@ -8,6 +8,7 @@
 // per-frame sequential state machine over OFDM symbols, so the parallel axes are subcarriers (lanes) and
 // independent RX streams / frames (workgroups); its state lives in LDS for the duration of a launch.
 #include "jrc_internal.h"
+#include "fft_device.h"
 
 #include <algorithm>
 #include <cmath>
@@ -147,6 +148,108 @@ __device__ __forceinline__ float2 demod_point(int bps, float2 z)
     return make_float2((z.x > 0 ? a : -a) / 2.0f, (z.y > 0 ? a : -a) / 2.0f);
 }
 
+// ---- SIG-field Viterbi on one wavefront, in place ---------------------------------------------------------------------------
+// K = 7 (0155, 0117), hard decisions, 64 states = 64 lanes.  The two predecessors of states 2j and 2j+1 are states j and j+32, so when
+// the pair (j, j+32) sits in two lanes, the pair (2j, 2j+1) can take their place: after step i lane L holds state rol6(L, (i+1) % 6), the
+// lanes of a pair differ in bit 5 - i % 6, and the exchange is lane_pair (fft_device.h: a permlane swap or one DPP move per side) instead
+// of two ds_bpermute round trips through the LDS crossbar.  Metrics, comparisons (m1 < m0: the upper predecessor wins only when
+// strictly better) and the survivor bits are those of the lane-per-state form; only where a bit is kept differs, and the traceback walks
+// lanes instead of states.
+struct VitLane { int eb[6]; };          // expected coded pair (bit 0: 0155, bit 1: 0117; predecessor bit 0) of the state the lane holds after a step of phase t
+
+template <int T> __device__ __forceinline__ void vit_step(int& metric, const VitLane& c, unsigned rx, unsigned& hist)
+{
+    int lo, hi;
+    lane_pair<5 - T>(metric, lo, hi);
+    const int x = c.eb[T] ^ (int)rx;                                  // bits that differ from the received pair when the predecessor bit is 0;
+    const int m0 = __builtin_popcount(x) + lo;                        // with predecessor bit 1 both coded bits flip (both polynomials tap it)
+    const int m1 = __builtin_popcount(x ^ 3) + hi;
+    const bool pick = m1 < m0;
+    metric = pick ? m1 : m0;
+    hist = hist + hist + (pick ? 1u : 0u);                            // the lane's own survivor bits, newest lowest: one add-with-carry
+}
+
+__host__ __device__ inline int eq_surv_words(int ND) { return ((ND / 2 + 59) / 60) * 64; }
+__host__ __device__ inline int eq_pair_bytes(int ND) { return ((ND / 2 + 5) / 6 + 1) * 8; }
+#define VIT_WORD 30     // trellis steps per survivor word: five rounds of the six exchange patterns; step i of a lane is bit 29 - i % 30 of its word i / 30
+
+// five rounds (or what is left of them before step i1) into one survivor word
+__device__ __forceinline__ unsigned vit_word(int& metric, const VitLane& c, const unsigned long long* rw, int i, int i1)
+{
+    unsigned hist = 0;
+    const int n = min(VIT_WORD, i1 - i);
+    if (n <= 0) return 0;
+    unsigned long long wn = rw[i / 6];
+    int k = 0;
+    for (; k + 6 <= n; k += 6) {
+        const unsigned long long w = wn;
+        wn = rw[(i + k) / 6 + 1];                                     // the next round's pairs are on their way while this round runs (the scratch has a spare word)
+        const unsigned wl = __builtin_amdgcn_readfirstlane((unsigned)w), wh = __builtin_amdgcn_readfirstlane((unsigned)(w >> 32));
+        vit_step<0>(metric, c, wl & 3u, hist);
+        vit_step<1>(metric, c, (wl >> 8) & 3u, hist);
+        vit_step<2>(metric, c, (wl >> 16) & 3u, hist);
+        vit_step<3>(metric, c, (wl >> 24) & 3u, hist);
+        vit_step<4>(metric, c, wh & 3u, hist);
+        vit_step<5>(metric, c, (wh >> 8) & 3u, hist);
+    }
+    if (k < n) {                                                      // the last, partial round of the field
+        const unsigned wl = __builtin_amdgcn_readfirstlane((unsigned)wn), wh = __builtin_amdgcn_readfirstlane((unsigned)(wn >> 32));
+        const int r = n - k;
+        vit_step<0>(metric, c, wl & 3u, hist);
+        if (r > 1) vit_step<1>(metric, c, (wl >> 8) & 3u, hist);
+        if (r > 2) vit_step<2>(metric, c, (wl >> 16) & 3u, hist);
+        if (r > 3) vit_step<3>(metric, c, (wl >> 24) & 3u, hist);
+        if (r > 4) vit_step<4>(metric, c, wh & 3u, hist);
+    }
+    return hist << (VIT_WORD - n);
+}
+
+// wave 0 only (tid < 64).  Z: the nd*2 equalised SIG cells; rxp: scratch, 8 bytes per 6 steps; surv: 64 double words per 60 steps.  Returns decoded bits 0..31.
+__device__ __forceinline__ unsigned sig_viterbi_wave(const float2* Z, int nd, unsigned long long* surv, unsigned char* rxp, int tid)
+{
+    for (int k = tid; k < nd; k += 64)                                // received hard-decision pairs, six steps to an 8-byte word
+        rxp[(k / 6) * 8 + k % 6] = (unsigned char)((Z[2 * k].x > 0 ? 1 : 0) | (Z[2 * k + 1].x > 0 ? 2 : 0));
+    VitLane c;
+#pragma unroll
+    for (int t = 0; t < 6; t++) {
+        const int r = (t + 1) % 6, st = ((tid << r) | (tid >> (6 - r))) & 63;
+        c.eb[t] = (popc8(st & 0155) & 1) | ((popc8(st & 0117) & 1) << 1);
+    }
+    int metric = tid ? (1 << 28) : 0;
+    const unsigned long long* rw = reinterpret_cast<const unsigned long long*>(rxp);
+    const int n_blk = (nd + 2 * VIT_WORD - 1) / (2 * VIT_WORD);
+    for (int blk = 0; blk < n_blk; blk++) {
+        const unsigned a = vit_word(metric, c, rw, blk * 2 * VIT_WORD, nd);
+        const unsigned b = vit_word(metric, c, rw, blk * 2 * VIT_WORD + VIT_WORD, nd);
+        surv[blk * 64 + tid] = ((unsigned long long)b << 32) | (unsigned long long)a;
+    }
+    // lowest state among the minima (the lane-per-state form's choice); the lane that holds it starts the traceback
+    const int rn = nd % 6;
+    int best = metric, bs = ((tid << rn) | (tid >> (6 - rn))) & 63, bl = tid;
+    for (int off = 32; off > 0; off >>= 1) {
+        const int om = __shfl_xor(best, off), os = __shfl_xor(bs, off), ol = __shfl_xor(bl, off);
+        if (om < best || (om == best && os < bs)) { best = om; bs = os; bl = ol; }
+    }
+    // traceback on the scalar unit: the survivor bit of the lane says which lane of its pair the path came from, and the bit of the lane
+    // index the pair differs in is the decoded bit
+    unsigned sig_word = 0;
+    int L = __builtin_amdgcn_readfirstlane(bl);
+    for (int wd = (nd - 1) / VIT_WORD; wd >= 0; wd--) {
+        const unsigned long long both = surv[(wd >> 1) * 64 + tid];
+        const int mine = (int)(unsigned)((wd & 1) ? (both >> 32) : (both & 0xffffffffull));
+        const int i0 = wd * VIT_WORD, i1 = min(nd, i0 + VIT_WORD);
+        int B = 5 - (i1 - 1) % 6;
+        for (int i = i1 - 1; i >= i0; i--) {
+            const unsigned w = (unsigned)__builtin_amdgcn_readlane(mine, L);
+            const int h = (int)((w >> (VIT_WORD - 1 - (i - i0))) & 1u);
+            if (i < 32) sig_word |= (unsigned)((L >> B) & 1) << i;
+            L = (L & ~(1 << B)) | (h << B);
+            B = B == 5 ? 0 : B + 1;
+        }
+    }
+    return sig_word;
+}
+
 #define EQ_BATCH 64   // data symbols per three-phase pass of the equalizer
 #ifndef EQ_PD
 #define EQ_PD 4       // input symbols in flight per lane in the equalisation phase
@@ -165,8 +268,8 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
     float2* Hm = H + N;
     float2* Z = Hm + N;                       // [ND]
     float2* est = Z + ND;                     // [NP]
-    unsigned long long* surv = reinterpret_cast<unsigned long long*>(est + NP);   // [ND/2]
-    unsigned char* bits = reinterpret_cast<unsigned char*>(surv + ND / 2);        // [ND]
+    unsigned long long* surv = reinterpret_cast<unsigned long long*>(est + NP);   // [eq_surv_words(ND)]: survivor masks of the SIG Viterbi
+    unsigned char* bits = reinterpret_cast<unsigned char*>(surv + eq_surv_words(ND));   // [eq_pair_bytes(ND)]: its received pairs
     // constant tables staged in LDS: the serial (one-lane) sections below walk them with dependent loads, which from
     // global memory cost microseconds each once every CU is busy
     int* dc = reinterpret_cast<int*>(eq_smem + d.lds_tables);                     // [ND] data carriers
@@ -430,50 +533,11 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
             for (int i = tid; i < N; i += NT) Y[i] = c_mul(Y[i], s_rot);
             __syncthreads();
             for (int i = tid; i < ND; i += NT) {
-                Z[i] = c_div(Y[dc[i]], H[dc[i]]);                           // symbol_equalize :900-906
-                bits[i] = Z[i].x > 0;                                                   // BPSK decision
+                Z[i] = c_div(Y[dc[i]], H[dc[i]]);                           // symbol_equalize :900-906 (BPSK decision: sig_viterbi_wave)
             }
             __syncthreads();
-            if (tid < 64) {   // K=7 (0155,0117) hard-decision Viterbi: one lane per trellis state
-                const int s6 = tid, nd = ND / 2;
-                int metric = s6 ? (1 << 28) : 0;
-                const int e0a = popc8(s6 & 0155) & 1, e1a = popc8(s6 & 0117) & 1;                 // predecessor bit h = 0
-                const int e0b = popc8((s6 | 64) & 0155) & 1, e1b = popc8((s6 | 64) & 0117) & 1;   // h = 1
-                // survivor word of step i stays in lane i % 64 (two words per lane cover the 128 steps of a 256-carrier SIG symbol; longer
-                // symbols spill the rest to LDS): no store, no branch inside the recursion
-                unsigned long long keep0 = 0, keep1 = 0;
-                for (int i = 0; i < nd; i++) {
-                    const int r0 = bits[2 * i], r1 = bits[2 * i + 1];
-                    const int m0 = __shfl(metric, s6 >> 1) + (e0a != r0) + (e1a != r1);
-                    const int m1 = __shfl(metric, (s6 >> 1) | 32) + (e0b != r0) + (e1b != r1);
-                    const int pick = m1 < m0;
-                    metric = pick ? m1 : m0;
-                    const unsigned long long mask = __ballot(pick);
-                    if (i < 64) keep0 = (tid == i) ? mask : keep0;
-                    else if (i < 128) keep1 = (tid == i - 64) ? mask : keep1;
-                    else if (tid == 0) surv[i] = mask;
-                }
-                int best = metric, bs = s6;                                             // lowest state among minima
-                for (int off = 32; off > 0; off >>= 1) {
-                    const int om = __shfl_xor(best, off), os = __shfl_xor(bs, off);
-                    if (om < best || (om == best && os < bs)) { best = om; bs = os; }
-                }
-                // traceback: a chain of nd dependent steps on the scalar unit off v_readlane
-                unsigned sig_word = 0;                                                  // decoded bits 0..31 (the field is bits 0..23)
-                {
-                    int s = __builtin_amdgcn_readfirstlane(bs);
-                    for (int blk = (nd - 1) >> 6; blk >= 0; blk--) {
-                        const int wi = (blk << 6) + tid;
-                        const unsigned long long mine = blk == 0 ? keep0 : (blk == 1 ? keep1 : (wi < nd ? surv[wi] : 0ull));
-                        const int hi_i = min(nd - 1, (blk << 6) + 63);
-                        for (int i = hi_i; i >= (blk << 6); i--) {
-                            const unsigned long long w = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mine >> 32), i & 63) << 32) |
-                                                         (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mine & 0xffffffffull), i & 63);
-                            if (i < 32) sig_word |= (unsigned)(s & 1) << i;
-                            s = (s >> 1) | ((int)((w >> s) & 1ull) << 5);
-                        }
-                    }
-                }
+            if (tid < 64) {   // K=7 (0155,0117) hard-decision Viterbi over the nd = ND / 2 coded pairs: one wavefront, in place (above)
+                const unsigned sig_word = sig_viterbi_wave(Z, ND / 2, surv, bits, tid);
                 if (tid == 0) {
                     // parse :669-781
                     const int rate = (int)(sig_word & 0xfu), pt = (int)((sig_word >> 4) & 1u), len = (int)((sig_word >> 5) & 0xfffu);
@@ -740,7 +804,7 @@ extern "C" int jrc_equalizer_create(jrc_ctx* ctx, const jrc_eq_cfg* c, int n_str
     d.mapped = (const float2*)(tb + off_ps + b_ps + b_ltf);
     eq->threads = N >= 1024 ? 1024 : ((N + 63) / 64) * 64;
     {
-        size_t off = sizeof(float2) * (size_t)(3 * N + ND + NP) + sizeof(unsigned long long) * (ND / 2) + ND + ND / 2;
+        size_t off = sizeof(float2) * (size_t)(3 * N + ND + NP) + sizeof(unsigned long long) * eq_surv_words(ND) + eq_pair_bytes(ND);
         off = (off + 15) & ~size_t(15);
         d.lds_tables = (int)off;
         eq->lds_bytes = off + sizeof(int) * (size_t)(ND + NP + ac.size() + 1) + sizeof(float2) * (size_t)(N + NP) + 16;

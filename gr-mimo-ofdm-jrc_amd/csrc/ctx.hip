@@ -71,6 +71,7 @@ extern "C" int jrc_create(int device, jrc_ctx** out)
     ctx->tune.ra_ref_sum = getenv("JRC_RA_REF_SUM") != nullptr;
     ctx->tune.rd_generic = getenv("JRC_RD_GENERIC") != nullptr;
     ctx->tune.rd_fold = getenv("JRC_RD_FOLD") != nullptr;
+    if (const char* e = getenv("JRC_RA_PACE")) ctx->tune.ra_pace = (int)strtol(e, nullptr, 0);
     if (const char* e = getenv("JRC_DEMOD_SPR")) ctx->tune.demod_spr = atoi(e);
     if (const char* e = getenv("JRC_EQ_WPE")) ctx->tune.eq_wpe = atoi(e);
     if (const char* e = getenv("JRC_EQ_THREADS")) ctx->tune.eq_threads = atoi(e);

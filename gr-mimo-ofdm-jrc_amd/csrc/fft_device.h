@@ -109,6 +109,41 @@ __device__ __forceinline__ void fft_fwd_small_pin(float2 (&x)[P])
     }
 }
 
+// ---- lane pairs without the LDS crossbar -----------------------------------------------------------------------------------------
+// lo / hi = the values held by the lower / upper lane of the pair of lanes that differ in bit B of the lane index — what a radix-2
+// butterfly across the wavefront (or an in-place trellis step, comm.hip) needs from `x`.  Bits 5 and 4 are gfx950's permlane swaps
+// (one instruction yields both), bits 3..0 one DPP move per side; a __shfl_xor is a ds_bpermute round trip (~100+ cycles) instead.
+template <int B>
+__device__ __forceinline__ void lane_pair(int x, int& lo, int& hi)
+{
+    if constexpr (B == 5) { const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false); lo = r[0]; hi = r[1]; }
+    else if constexpr (B == 4) { const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false); lo = r[0]; hi = r[1]; }
+    else if constexpr (B == 3) { lo = __builtin_amdgcn_update_dpp(x, x, 0x118, 0xf, 0xc, false); hi = __builtin_amdgcn_update_dpp(x, x, 0x108, 0xf, 0x3, false); }   // row_shr:8 into lanes 8-15, row_shl:8 into lanes 0-7
+    else if constexpr (B == 2) { lo = __builtin_amdgcn_update_dpp(x, x, 0x114, 0xf, 0xa, false); hi = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xf, 0x5, false); }   // row_shr:4 into banks 1, 3; row_shl:4 into banks 0, 2
+    else if constexpr (B == 1) { lo = __builtin_amdgcn_mov_dpp(x, 0x44, 0xf, 0xf, false); hi = __builtin_amdgcn_mov_dpp(x, 0xee, 0xf, 0xf, false); }                  // quad_perm [0,1,0,1], [2,3,2,3]
+    else { lo = __builtin_amdgcn_mov_dpp(x, 0xa0, 0xf, 0xf, false); hi = __builtin_amdgcn_mov_dpp(x, 0xf5, 0xf, 0xf, false); }                                         // quad_perm [0,0,2,2], [1,1,3,3]
+}
+template <int B>
+__device__ __forceinline__ void lane_pair(float2 v, float2& lo, float2& hi)
+{
+    int a, b, c, d;
+    lane_pair<B>(__float_as_int(v.x), a, b);
+    lane_pair<B>(__float_as_int(v.y), c, d);
+    lo = make_float2(__int_as_float(a), __int_as_float(c));
+    hi = make_float2(__int_as_float(b), __int_as_float(d));
+}
+
+// one radix-2 DIF stage of a 64-point transform held one point per lane: the lanes of a pair differ in bit B; `t` is this lane's twiddle
+template <int B>
+__device__ __forceinline__ float2 wave_dif_stage(float2 v, float2 t, int lane)
+{
+#pragma clang fp contract(off)
+    float2 lo, hi;
+    lane_pair<B>(v, lo, hi);
+    const float2 s = make_float2(lo.x + hi.x, lo.y + hi.y), d = cmul_pin(make_float2(lo.x - hi.x, lo.y - hi.y), t);
+    return (lane & (1 << B)) ? d : s;
+}
+
 // ---- one Stockham autosort pass (radix R in {2,4}) over n points; sources / destinations may be global or LDS ----
 template <int R>
 __device__ __forceinline__ void stockham_pass(const float2* __restrict__ src_g, long src_wrap /* n if ifftshift else 0 */,

@@ -44,6 +44,7 @@ struct jrc_ctx {
         bool ra_ref_sum = false;     // JRC_RA_REF_SUM: the estimator's noise sum always by the reference-order double chain (tests)
         bool rd_generic = false;     // JRC_RD_GENERIC: range-Doppler block by block (stock FFTs + transpose)
         bool rd_fold = false;        // JRC_RD_FOLD: range-Doppler with the fold kernel also where the pruned-FFT kernel applies
+        int ra_pace = -1;            // JRC_RA_PACE: store pacing word of the fused range-angle kernel (chain.hip; -1 = by geometry)
         int demod_spr = 0;           // JRC_DEMOD_SPR: symbols per round (2 or 4) of the A6+A7+A1 kernel (0 = by fft_len)
         int eq_wpe = 0;              // JRC_EQ_WPE: waves per SIMD the equalizer kernel is compiled for (2, 4, 6, 8; 0 = by geometry)
         int eq_threads = 0;          // JRC_EQ_THREADS: equalizer workgroup size (64, 128, 256; 0 = by launch size, -1 = one lane per subcarrier)

@@ -297,6 +297,10 @@ if __name__ == "__main__":
     only = os.environ.get("JRC_BENCH_EXTRA_ONLY")
     if only == "detect":
         print(json.dumps(detect_only("B"))); print(json.dumps(detect_only("D"))); print(json.dumps(power_map("B"))); print(json.dumps(power_map("D"))); sys.exit(0)
+    if only == "equalizer":
+        print(json.dumps(equalizer_config_c())); sys.exit(0)
+    if only == "comm":
+        print(json.dumps(comm_rx_chain())); print(json.dumps(equalizer_config_c())); print(json.dumps(precoder_config_c())); sys.exit(0)
     for fn in (sync_front_end, comm_rx_chain, lambda: detect_only("B"), lambda: detect_only("D"), lambda: radar_with_demod("B", 512), lambda: radar_with_demod("D", 256), precoder_config_c, lambda: range_doppler("D", 8), lambda: range_doppler("B", 64),
                lambda: simulated_chain("B", 64), lambda: simulated_chain("D", 8), equalizer_config_c):
         print(json.dumps(fn()))
