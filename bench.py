@@ -41,6 +41,7 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="B", choices=["A", "B", "D"])
     ap.add_argument("--frames", type=int, default=0, help="frames per GPU per step (0 = per-config default)")
+    ap.add_argument("--interp-range", type=int, default=8, help="interp_factor of the range axis (the flowgraph's 8; other values are for kernel experiments)")
     ap.add_argument("--distinct", type=int, default=32, help="distinct synthetic frames generated per GPU (tiled to --frames)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -470,7 +471,7 @@ def main():
     from jrc_amd import shard, synth
 
     sc = scenario(a.config)
-    Ir, Ia = 8, 16
+    Ir, Ia = a.interp_range, 16
     P, NR, NA = sc.T * sc.R, sc.N * Ir, sc.T * sc.R * Ia
     F = a.frames or {"A": 4096, "B": 512, "D": 256}[a.config]
     rb, ab = jrc_amd.radar_axes(sc.N, sc.fs, Ir, P, Ia)

@@ -27,12 +27,7 @@
 #include <cmath>
 #include <cstdlib>
 
-#ifndef RA_TH_EVERY
-#define RA_TH_EVERY 8
-#endif
-#ifndef RA_TH_CNT
-#define RA_TH_CNT 1
-#endif
+#define RA_GROUP 8   // map stores a wave issues back to back; then it waits until all but one have completed
 #define RA_L 64   // range bins (and fold length) per workgroup
 
 // ---- the fused kernel ------------------------------------------------------------------------
@@ -60,7 +55,10 @@
 //         through a private LDS tile ([rows of this trip][NA] floats) and stores whole 16-byte pieces of full rows; the estimator reads
 //         the MODE 2 window rows as in detect-only mode.  ROWS1: the tile holds one row at a time (when LDS is short: fft_len 1024).
 // IA: interp_angle known at compile time (16, the flowgraphs' interp_factor_angle), or 0 for the runtime argument
-template <int P, int NT, int MMAX, bool TWC_LDS, int MODE, int IA, bool ROWS1 = false>
+// G: groups of NT / 64 / G wavefronts that share the staged H but take classes of their own, each with its range-bin buffer and its own
+//    barrier (an LDS counter): with one workgroup per CU (fft_len 1024: H fills the LDS) a single group would stop the CU's map stream at
+//    every range phase; two groups alternate, as the two resident workgroups of the smaller shapes do.
+template <int P, int NT, int MMAX, bool TWC_LDS, int MODE, int IA, bool ROWS1 = false, int G = 1>
 #ifndef JRC_WPS256
 #define JRC_WPS256 3
 #endif
@@ -78,7 +76,8 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
 {
 #pragma clang fp contract(off)          // every rounding of this kernel is spelled out (fmaf / cmul_pin / fft_fwd_small_pin): the three MODEs agree bit for bit
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
-    constexpr int NW = NT / 64;
+    constexpr int NW = NT / 64, NWG = NW / G, NTG = NT / G;     // waves / threads of a group
+    static_assert(G == 1 || !TWC_LDS, "groups keep their class twiddles in registers");
     const int Ia = IA > 0 ? IA : Ia_arg;
     const int NA = P * Ia;
     const int C = NR / RA_L;
@@ -90,16 +89,31 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
     const int slice = j % WPF;
     if (f >= F) return;
 
-    float2* s_H = smem;                         // [P][N]
-    float2* s_g = s_H + (size_t)P * N;          // [P][64]; reused as reduction scratch at the end
-    float2* s_twc = s_g + P * RA_L;             // [N] class twiddles (TWC_LDS only)
-    constexpr int NPT = TWC_LDS ? 4 : 1;        // class twiddles prefetched per thread (N <= NT*NPT)
-
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = G == 1 ? 0 : wave / NWG, wg = wave - grp * NWG, tg = tid - grp * NTG;   // group, wave in the group, thread in the group
+    float2* s_H = smem;                         // [P][N]
+    float2* s_g0 = s_H + (size_t)P * N;         // [G][P][64]; group 0's reused as reduction scratch at the end
+    float2* s_g = s_g0 + grp * (P * RA_L);
+    float2* s_twc = s_g0 + G * P * RA_L;        // [N] class twiddles (TWC_LDS only)
+    constexpr int NPT = TWC_LDS ? 4 : 1;        // class twiddles prefetched per thread (N <= NT*NPT)
+    __shared__ int s_arrived[2];                // G == 2: wavefronts that have reached the group's barriers so far
+    int bar_target = 0;
+    auto group_barrier = [&]() {
+        if constexpr (G == 1) __syncthreads();
+        else {
+            // a wave's LDS operations complete in order, so its arrival (one atomic add) is seen after its writes; the counter only grows
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            bar_target += NWG;
+            if (lane == 0) __hip_atomic_fetch_add(&s_arrived[grp], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            while (__hip_atomic_load(&s_arrived[grp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < bar_target) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+    };
     const int M = N / RA_L;                     // fold length per lane, <= MMAX
 
-    const int n_iter = (C - slice + WPF - 1) / WPF;
-    auto class_of = [&](int it) -> int { return slice + it * WPF; };     // the class this workgroup works on in its it-th trip
+    const int n_cls = (C - slice + WPF - 1) / WPF;                       // classes of this workgroup: c = slice + WPF i
+    const int n_iter = (n_cls - grp + G - 1) / G;                        // ... of this group: i = G it + grp
+    auto class_of = [&](int it) -> int { return slice + (it * G + grp) * WPF; };     // the class this group works on in its it-th trip
     const int c_first = class_of(0);
 
     // class twiddles for this lane's fold inputs n = lane + 64 m:  exp(+j 2 pi n c / NR)
@@ -120,6 +134,10 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
         float4* sH4 = reinterpret_cast<float4*>(s_H);
         for (int i = tid; i < (P * N) / 2; i += NT) sH4[i] = Hf4[i];
     }
+    if constexpr (G > 1) {
+        if (tid < 2) s_arrived[tid] = 0;
+        __syncthreads();                        // H staged, counters zeroed: from here on the groups only meet at the end
+    }
     // 64-point inverse FFT twiddles of this lane, one per radix-2 stage: exp(+j 2 pi k / (2 half))
     float2 t64[6];
 #pragma unroll
@@ -128,7 +146,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
         t64[st] = twR[((lane & (half - 1)) * (32 / half)) * (NR / 64)];
     }
     // angle twiddles of this lane's residue r = tid % Ia:  exp(-j 2 pi p r / NA)
-    const int r = tid % Ia;
+    const int r = tg % Ia;
     float2 ta[P];
 #pragma unroll
     for (int p = 1; p < P; p++) ta[p] = twA[(p * r) & (NA - 1)];
@@ -159,11 +177,11 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
 #pragma unroll
             for (int q = 0; q < NPT; q++) { const int n = tid + NT * q; if (n < N) s_twc[n] = tn[q]; }
         }
-        __syncthreads();                        // s_H staged (first trip) / previous class's s_g reads done
+        group_barrier();                        // s_H staged (first trip) / previous class's s_g reads done
         // ---- range axis: fold to 64 points, 64-point inverse FFT across the wavefront -------------
-        {   // the wave's pairs p = wave + NW j side by side: they share the class twiddle of a fold term, and their butterfly chains interleave
-            constexpr int PPW = (P + NW - 1) / NW;
-            constexpr bool full = (P % NW) == 0;    // every wave has PPW pairs
+        {   // the wave's pairs p = wg + NWG j side by side: they share the class twiddle of a fold term, and their butterfly chains interleave
+            constexpr int PPW = (P + NWG - 1) / NWG;
+            constexpr bool full = (P % NWG) == 0;   // every wave has PPW pairs
             float2 v[PPW];
 #pragma unroll
             for (int j = 0; j < PPW; j++) v[j] = make_float2(0.f, 0.f);
@@ -174,8 +192,8 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
                     if constexpr (TWC_LDS) w = s_twc[lane + RA_L * m]; else w = tc[m];
 #pragma unroll
                     for (int j = 0; j < PPW; j++)
-                        if (full || wave + NW * j < P) {
-                            const float2 h = s_H[(size_t)(wave + NW * j) * N + lane + RA_L * m];
+                        if (full || wg + NWG * j < P) {
+                            const float2 h = s_H[(size_t)(wg + NWG * j) * N + lane + RA_L * m];
                             v[j].x = fmaf(h.x, w.x, fmaf(-h.y, w.y, v[j].x));
                             v[j].y = fmaf(h.x, w.y, fmaf(h.y, w.x, v[j].y));
                         }
@@ -195,7 +213,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
             for (int j = 0; j < PPW; j++) v[j] = wave_dif_stage<0>(v[j], t64[5], lane);
 #pragma unroll
             for (int j = 0; j < PPW; j++)
-                if (full || wave + NW * j < P) s_g[(wave + NW * j) * RA_L + (__brev((unsigned)lane) >> 26)] = v[j];   // lane holds X[bitrev6(lane)]
+                if (full || wg + NWG * j < P) s_g[(wg + NWG * j) * RA_L + (__brev((unsigned)lane) >> 26)] = v[j];   // lane holds X[bitrev6(lane)]
         }
         if (it + 1 < n_iter) {                  // prefetch the next class's twiddles; they land during the stores
             const int cn = class_of(it + 1);
@@ -208,19 +226,19 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
                     if (m < M) tc[m] = twR[((lane + RA_L * m) * cn) & (NR - 1)];
             }
         }
-        __syncthreads();
+        group_barrier();
 
         if constexpr (MODE == 1 || MODE == 3) {      // the class's range profiles for the estimator's window pass: 8 KiB, coalesced 16-byte pieces
             float4* dst = reinterpret_cast<float4*>(rng_out + ((size_t)f * C + c) * (P * RA_L));
             const float4* src = reinterpret_cast<const float4*>(s_g);
-            for (int i = tid; i < (P * RA_L) / 2; i += NT) dst[i] = src[i];
+            for (int i = tg; i < (P * RA_L) / 2; i += NTG) dst[i] = src[i];
         }
         // ---- angle axis + fftshift + store + arg-max ---------------------------------------------
 #pragma unroll 1
-        for (int w0 = 0; w0 < items; w0 += NT) {     // whole waves are in or out
-            const int w = w0 + tid;
+        for (int w0 = 0; w0 < items; w0 += NTG) {    // whole waves are in or out
+            const int w = w0 + tg;
             if (w >= items) break;
-            const int ql = w / Ia;               // (w % Ia == r because Ia divides NT)
+            const int ql = w / Ia;               // (w % Ia == r because Ia divides the group's threads)
             const int k = C * ql + c;            // global range bin
             float2 y[P];
             y[0] = s_g[ql];
@@ -281,7 +299,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
                 for (int u = 0; u < P; u++) {
                     const int a = (Ia * u + r + ahalf) & amask;   // fftshift: out'[a'] = out[(a' + NA/2) % NA]
                     if constexpr (IA > 0) {
-                        if ((u % RA_TH_EVERY) == 0 && pace_T) {
+                        if ((u % RA_GROUP) == 0 && pace_T) {
                             long long now = (long long)wall_clock64();
                             t_next += pace_T;
                             if (now - t_next > (long long)pace_K * pace_T) t_next = now - (long long)pace_K * pace_T;
@@ -289,7 +307,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
                         }
                         const v2f t = {y[u].x, y[u].y};
                         __builtin_nontemporal_store(t, reinterpret_cast<v2f*>(row + a));
-                        if ((u % RA_TH_EVERY) == RA_TH_EVERY - 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(RA_TH_CNT) : "memory");
+                        if ((u % RA_GROUP) == RA_GROUP - 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
                     } else {
                         if (WPF > 0) { const v2f t = {y[u].x, y[u].y}; __builtin_nontemporal_store(t, reinterpret_cast<v2f*>(row + a)); }
                         else row[a] = y[u];
@@ -307,7 +325,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
         }
     }
     __syncthreads();
-    block_reduce_peak(trk, reinterpret_cast<PeakPartial*>(s_g));
+    block_reduce_peak(trk, reinterpret_cast<PeakPartial*>(s_g0));
     if (tid == 0) { partials[(size_t)f * pstride + slice].best = trk.best; partials[(size_t)f * pstride + slice].idx = trk.idx; }
 }
 
@@ -358,6 +376,7 @@ struct jrc_chain {
     jrc_chain_cfg cfg;
     int P, NR, NA, C, threads, wg_per_cu, n_cus, wpf_override, max_frames;
     bool generic = false;             // shapes the fused kernel does not cover: block-by-block kernels on the device
+    bool split = false;               // fused kernel with two wavefront groups per workgroup (G = 2: 16 pairs x fft_len 1024 x interp_angle 16, config D)
     float2* d_pad = nullptr;          // generic mode: [max_frames][P][NR] zero-padded rows / range profiles
     int gen_blocks = 0;               // generic mode: partial-maximum blocks per frame
     float* d_bins = nullptr;          // range_bins (NR) then angle_bins (NA)
@@ -483,15 +502,17 @@ static int chain_pace(const jrc_chain* ch)
     // measured (tools/pace_sweep.sh): eight waves per CU, each releasing 8 x 512 B every 1.21 us and allowed to catch up one
     // group — 7 TB/s offered — hold the map stream at the rate of a pure store stream (0.341 ms per 512 config-B frames, 79 % of the HBM
     // peak; 0.366 ms unpaced); other geometries are not paced
-    if (ch->P == 16 && ch->cfg.interp_angle == 16 && ch->threads == 256 && ch->wg_per_cu == 2) return (1 << 12) | 121;
+    if (ch->P == 16 && ch->cfg.interp_angle == 16 && ch->threads == 256 && ch->wg_per_cu == 2 && ch->cfg.interp_range <= 8) return (1 << 12) | 121;
+    // config D's shape (one 512-thread workgroup per CU): 1.0 us, no catching up — 0.777 ms per 256 frames against 0.85 unpaced
+    if (ch->P == 16 && ch->cfg.interp_angle == 16 && ch->threads == 512 && ch->cfg.fft_len == 1024 && ch->cfg.interp_range <= 8) return 100;
     return 0;
 }
 
-template <int P, int NT, int MMAX, bool TWC_LDS, int MODE, int IA, bool ROWS1 = false>
+template <int P, int NT, int MMAX, bool TWC_LDS, int MODE, int IA, bool ROWS1 = false, int G = 1>
 static int launch_fused_mode(jrc_chain* ch, int n_frames, int wpf, int pstride, const float2* d_H, float2* d_map, hipStream_t s)
 {
     const size_t lds_bytes = MODE == 3 ? ch->lds_power : ch->lds_bytes;
-    JRC_TRY(jrc_ensure_dyn_lds(ch->ctx, (const void*)range_angle_fused_kernel<P, NT, MMAX, TWC_LDS, MODE, IA, ROWS1>, lds_bytes));
+    JRC_TRY(jrc_ensure_dyn_lds(ch->ctx, (const void*)range_angle_fused_kernel<P, NT, MMAX, TWC_LDS, MODE, IA, ROWS1, G>, lds_bytes));
     // One resident wave of workgroups per launch: a batch that needs more is launched in chunks of that size, and a last,
     // smaller chunk gets more slices per frame so that it fills the machine as well (a grid twice the resident size runs 20 %
     // slower than two launches because its second wave of workgroups starts ragged).  `pstride` partial maxima per frame.
@@ -504,7 +525,7 @@ static int launch_fused_mode(jrc_chain* ch, int n_frames, int wpf, int pstride, 
         const dim3 grid((unsigned)(((nf + nx - 1) / nx) * nx * w));
         float2* mp = MODE == 0 ? d_map + (size_t)f0 * ch->NR * ch->NA
                    : (MODE == 3 ? reinterpret_cast<float2*>(reinterpret_cast<float*>(d_map) + (size_t)f0 * ch->NR * ch->NA) : nullptr);
-        hipLaunchKernelGGL((range_angle_fused_kernel<P, NT, MMAX, TWC_LDS, MODE, IA, ROWS1>), grid, dim3(NT), lds_bytes, s,
+        hipLaunchKernelGGL((range_angle_fused_kernel<P, NT, MMAX, TWC_LDS, MODE, IA, ROWS1, G>), grid, dim3(NT), lds_bytes, s,
                            d_H + (size_t)f0 * P * ch->cfg.fft_len, mp,
                            ch->d_partials + (size_t)f0 * pstride,
                            ch->twR, ch->twA, ch->cfg.fft_len, ch->NR, ch->cfg.interp_angle, nf, w, pstride,
@@ -519,6 +540,12 @@ static int launch_fused_nt(jrc_chain* ch, int mode, int n_frames, int wpf, int p
 {
     // interp_angle = 16 (the flowgraphs' interp_factor_angle, examples/simulation/radar/mimo_ofdm_jrc_radar_sim.grc) is compiled in; any other
     // value takes the runtime argument
+    if constexpr (P == 16 && NT == 512 && MMAX == 16 && !TWC_LDS) {     // config D's shape: two groups of four wavefronts (ch->split)
+        if (mode == 0) return launch_fused_mode<P, NT, MMAX, false, 0, 16, false, 2>(ch, n_frames, wpf, pstride, d_H, d_map, s);
+        if (mode == 1) return launch_fused_mode<P, NT, MMAX, false, 1, 16, false, 2>(ch, n_frames, wpf, pstride, d_H, d_map, s);
+        return ch->power_rows1 ? launch_fused_mode<P, NT, MMAX, false, 3, 16, true, 2>(ch, n_frames, wpf, pstride, d_H, d_map, s)
+                               : launch_fused_mode<P, NT, MMAX, false, 3, 16, false, 2>(ch, n_frames, wpf, pstride, d_H, d_map, s);
+    }
     if (ch->cfg.interp_angle == 16) {
         if (mode == 0) return launch_fused_mode<P, NT, MMAX, TWC_LDS, 0, 16>(ch, n_frames, wpf, pstride, d_H, d_map, s);
         if (mode == 1) return launch_fused_mode<P, NT, MMAX, TWC_LDS, 1, 16>(ch, n_frames, wpf, pstride, d_H, d_map, s);
@@ -538,6 +565,9 @@ static int launch_fused(jrc_chain* ch, int mode, int n_frames, int wpf, int pstr
     // 512-thread workgroup per CU
     if (ch->threads == 1024) return launch_fused_nt<P, 1024, 16, true>(ch, mode, n_frames, wpf, pstride, d_H, d_map, s);
     if (ch->threads == 512 && ch->cfg.fft_len <= 256) return launch_fused_nt<P, 512, 4, false>(ch, mode, n_frames, wpf, pstride, d_H, d_map, s);
+    // config D's shape (ch->split): the map-less modes run as two wavefront groups per workgroup (detect-only 242 -> 255 k frames/s); the map
+    // stream itself measured the same or slower that way (0.79 against 0.78 ms per 256 frames) and stays one group, paced
+    if constexpr (P == 16) { if (ch->split && mode != 0) return launch_fused_nt<P, 512, 16, false>(ch, mode, n_frames, wpf, pstride, d_H, d_map, s); }
     if (ch->threads == 512) return launch_fused_nt<P, 512, 16, true>(ch, mode, n_frames, wpf, pstride, d_H, d_map, s);
     if (ch->cfg.fft_len > 256) return launch_fused_nt<P, 256, 16, true>(ch, mode, n_frames, wpf, pstride, d_H, d_map, s);
     return launch_fused_nt<P, 256, 4, false>(ch, mode, n_frames, wpf, pstride, d_H, d_map, s);
@@ -601,6 +631,9 @@ extern "C" int jrc_chain_create(jrc_ctx* ctx, const jrc_chain_cfg* cfg, const fl
     ch->lds_bytes = sizeof(float2) * ((size_t)P * N + (size_t)P * RA_L + (N > 256 ? (size_t)N : 0));
     ch->threads = (ch->lds_bytes > 80 * 1024) ? 512 : 256;
     if (getenv("JRC_THREADS")) { int t = atoi(getenv("JRC_THREADS")); if (t == 512 || (t == 1024 && N > 256)) ch->threads = t; else ch->threads = 256; }
+    ch->split = ch->threads == 512 && N > 256 && P == 16 && cfg->interp_angle == 16 && !getenv("JRC_NO_SPLIT");
+    // (the split variant's LDS — H + a range-bin buffer per group, class twiddles in registers — is what lds_bytes already holds at this shape:
+    //  P * 64 == fft_len)
     ch->wpf_override = getenv("JRC_WPF") ? atoi(getenv("JRC_WPF")) : 0;
     {
         ch->n_cus = ctx->n_cus;
