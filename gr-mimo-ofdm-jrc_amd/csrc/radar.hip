@@ -372,6 +372,170 @@ __global__ __launch_bounds__(SPR == 4 ? 1024 : (SPR == 2 ? 512 : 256), SPR == 4 
         }
 }
 
+// ---- the same block for fft_len 256 and 1024 with radix-16 passes in registers -------------------------------------------------------
+// demod_chanest_kernel moves a symbol through log4(n) radix-4 passes, LDS -> LDS with a workgroup barrier after each; what bounds it is
+// instruction issue (~110 vector instructions per point at fft_len 1024).  Here one symbol belongs to n/16 lanes of ONE wavefront — 16
+// points per lane — and goes through Stockham passes of radix 16, 16 (and 4 at fft_len 1024) with the 16-point transforms in registers
+// (fft_fwd_small<16>): two (three) LDS exchanges per symbol, synchronised inside the wavefront only, then the workgroup meets once per
+// round to add the round's symbols — 4096 / n of them — to the accumulators in symbol order, every thread owning n / 256 subcarriers as
+// before.  A symbol's buffer is padded by one element per sixteen (the first pass writes at a stride of sixteen).  Same transform, same
+// accumulation order; the factorisation differs from fft_stockham_kernel's, so the estimate agrees with the unfused path to rounding
+// (1e-6 relative), as the radix-4 kernel's does.
+template <int T, int LOGN>
+// register budgets and TX batch sizes measured on configs B / D (256 frames x 4 streams, tools/td_kernel_probe.py): fft_len 256: 4 waves per
+// SIMD, TX rows of 2 symbols per batch 0.134 ms per 512 frames (3: 0.137; batches of 8: 0.142, of 16: spills); fft_len 1024: 2 waves per SIMD,
+// batches of 2 0.560 ms per 256 frames (of 4: 0.590 at 256 VGPRs; 3 waves per SIMD spill: 0.73-2.2 ms)
+__global__ __launch_bounds__(256, LOGN == 10 ? 2 : 4) void demod_chanest16_kernel(const float2* __restrict__ tx, const float2* __restrict__ rx_td,
+                                                                 float2* __restrict__ H, const float2* __restrict__ tw_g,
+                                                                 DemodGeom g, int n_frames)
+{
+    constexpr int N = 1 << LOGN, LPS = N / 16, SPW = 64 / LPS, NSYM = 4 * SPW, SPT = N / 256, NP = N + N / 16;
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    float2* tw = lds;                                          // [N] exp(-j 2 pi i / N)
+    float2* buf = lds + N;                                     // [NSYM][NP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l = lane % LPS, slot = wave * SPW + lane / LPS;  // lane within the symbol's transform, symbol slot of the round
+    float2* my = buf + (size_t)slot * NP;
+    auto ph = [](int i) { return i + (i >> 4); };
+    for (int i = tid; i < N; i += 256) tw[i] = tw_g[i];
+
+    // workgroup -> (frame, receiver); the receivers of a frame share blockIdx % n_xcd, so its TX rows are fetched into one L2
+    long blk = blockIdx.x;
+    {
+        const long q = blk / g.n_xcd, x = blk % g.n_xcd;
+        blk = ((q / g.R) * g.n_xcd + x) * g.R + (q % g.R);
+    }
+    if (blk >= (long)n_frames * g.R) return;
+    const long f = blk / g.R;
+    const int r = (int)(blk % g.R);
+    const float2* src = rx_td + f * g.rx_frame_stride + (long)r * g.rx_stream_stride + (long)g.rx_sym0 * (N + g.cp) + g.cp + l;
+    const float2* txb = tx + f * g.tx_frame_stride + (long)g.tx_item0 * N + tid;
+
+    float2 acc[SPT][T], pn[16];
+#pragma unroll
+    for (int m = 0; m < SPT; m++)
+#pragma unroll
+        for (int t = 0; t < T; t++) acc[m][t] = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int q = 0; q < 16; q++) pn[q] = make_float2(0.f, 0.f);
+    auto fetch_rx = [&](int sym0) {            // this slot's symbol of the round starting at sym0: read once, non-temporal
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        if (sym0 + slot < g.S) {
+            const float2* sp = src + (long)(sym0 + slot) * (N + g.cp);
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const v2f t = __builtin_nontemporal_load(reinterpret_cast<const v2f*>(sp + q * LPS));
+                pn[q] = make_float2(t.x, t.y);
+            }
+        }
+    };
+    auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
+    fetch_rx(0);
+    __syncthreads();
+
+    for (int sym0 = 0; sym0 < g.S; sym0 += NSYM) {
+        float2 v[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] = pn[q];             // v[q] = x[l + q n/16]
+        if (sym0 + NSYM < g.S) fetch_rx(sym0 + NSYM);          // next round's samples: in flight during this round's passes
+        // pass 1 (radix 16, Ns = 1: no twiddles): out[16 l + q]
+        fft_fwd_small<16>(v);
+#pragma unroll
+        for (int q = 0; q < 16; q++) my[ph(16 * l + q)] = v[q];
+        wave_sync();
+        // pass 2 (radix 16, Ns = 16): k = l mod 16, twiddles exp(-j 2 pi k q / 256), out[16 (l - k + q) + k]
+        const int k = l & 15;
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] = my[ph(l + q * LPS)];
+#pragma unroll
+        for (int q = 1; q < 16; q++) v[q] = cmul(v[q], tw[(k * q * (N / 256)) & (N - 1)]);
+        fft_fwd_small<16>(v);
+        if constexpr (LOGN == 8) {                             // done: X[l + 16 q] goes where fft_vxx's shift puts it
+#pragma unroll
+            for (int q = 0; q < 16; q++) my[ph((l + 16 * q + N / 2) & (N - 1))] = v[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; q++) my[ph(16 * ((l - k) + q) + k)] = v[q];
+            wave_sync();
+            // pass 3 (radix 4, Ns = 256): four butterflies per lane, j = l + 64 i: twiddles exp(-j 2 pi j q / 1024), X[j + 256 q], shifted
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int j = l + 64 * i;
+#pragma unroll
+                for (int q = 0; q < 4; q++) v[4 * i + q] = my[ph(j + 256 * q)];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int j = l + 64 * i;
+                float2* a = v + 4 * i;
+#pragma unroll
+                for (int q = 1; q < 4; q++) a[q] = cmul(a[q], tw[(j * q) & (N - 1)]);
+                const float2 s0 = cadd(a[0], a[2]), d0 = csub(a[0], a[2]), s1 = cadd(a[1], a[3]), d1 = csub(a[1], a[3]);
+                const float2 jd = make_float2(d1.y, -d1.x);
+                a[0] = cadd(s0, s1); a[1] = cadd(d0, jd); a[2] = csub(s0, s1); a[3] = csub(d0, jd);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) my[ph((l + 64 * i + 256 * q + N / 2) & (N - 1))] = v[4 * i + q];
+        }
+        // every thread owns subcarriers tid + 256 m: the symbols of this round, in order (mimo_ofdm_radar_impl.cc:250-274).  The TX rows
+        // of TXD symbols are requested together — the first batch before the workgroup meets, so the barrier wait and the L2 round trip
+        // overlap — and multiplied in once they are all here: one exposed round trip per batch instead of one per symbol.
+        constexpr int TXD = 2;
+        float2 tc[TXD][SPT][T];
+        auto fetch_tx = [&](int q0) {
+#pragma unroll
+            for (int q = 0; q < TXD; q++)
+                if (sym0 + q0 + q < g.S) {
+#pragma unroll
+                    for (int m = 0; m < SPT; m++)
+#pragma unroll
+                        for (int t = 0; t < T; t++) tc[q][m][t] = txb[(long)t * g.tx_port_stride + (long)(sym0 + q0 + q) * N + 256 * m];
+                }
+        };
+        fetch_tx(0);
+        __syncthreads();
+#pragma unroll
+        for (int q0 = 0; q0 < NSYM; q0 += TXD) {
+            if (q0) fetch_tx(q0);
+#pragma unroll
+            for (int q = 0; q < TXD; q++)
+                if (sym0 + q0 + q < g.S) {
+#pragma unroll
+                    for (int m = 0; m < SPT; m++) {
+                        const float2 xv = buf[(size_t)(q0 + q) * NP + ph(tid + 256 * m)];
+#pragma unroll
+                        for (int t = 0; t < T; t++) chanest_mac(acc[m][t], xv, tc[q][m][t]);
+                    }
+                }
+        }
+        __syncthreads();
+    }
+    float2* Hf = H + (size_t)f * T * g.R * N;
+#pragma unroll
+    for (int m = 0; m < SPT; m++)
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            const int pidx = g.interleave ? (t * g.R + r) : (r * T + t);   // :262-269
+            Hf[(size_t)pidx * N + tid + 256 * m] = acc[m][t];
+        }
+}
+
+template <int T, int LOGN>
+static int launch_demod_chanest16(jrc_ctx* ctx, const float2* d_tx, const float2* d_rx_td, float2* d_H, const float2* tw, DemodGeom g, int n_frames,
+                                  hipStream_t stream)
+{
+    constexpr int N = 1 << LOGN, NSYM = 4096 / N;
+    const long grp = (long)g.n_xcd * g.R;
+    const long blocks = (((long)n_frames * g.R + grp - 1) / grp) * grp;          // whole frames per group of R workgroups of an XCD
+    const size_t lds_bytes = sizeof(float2) * ((size_t)N + (size_t)NSYM * (N + N / 16));
+    JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)demod_chanest16_kernel<T, LOGN>, lds_bytes));
+    hipLaunchKernelGGL((demod_chanest16_kernel<T, LOGN>), dim3((unsigned)blocks), dim3(256), lds_bytes, stream, d_tx, d_rx_td, d_H, tw, g, n_frames);
+    JRC_HIP(ctx, hipGetLastError());
+    return JRC_OK;
+}
+
 bool demod_chanest_supported(int N, int T)
 {
     return jrc_is_pow2(N) && N >= 16 && N <= 1024 && (T == 1 || T == 2 || T == 3 || T == 4 || T == 8);
@@ -410,6 +574,17 @@ int launch_demod_chanest(jrc_ctx* ctx, int T, const float2* d_tx, const float2* 
     g.n_xcd = ctx->n_xcd;
     // fewer symbols per round (fewer threads per stream, more subcarriers per thread) as fft_len grows: more, smaller workgroups per CU;
     // JRC_DEMOD_SPR overrides
+    if ((g.N == 256 || g.N == 1024) && (T == 1 || T == 2 || T == 4) && ctx->tune.demod_spr != 1 && ctx->tune.demod_spr != 2 && ctx->tune.demod_spr != 4) {
+        // radix-16 passes in registers (JRC_DEMOD_SPR = 1 / 2 / 4 selects the radix-4 kernel instead)
+        if (g.N == 256) {
+            if (T == 1) return launch_demod_chanest16<1, 8>(ctx, d_tx, d_rx_td, d_H, tw, g, n_frames, stream);
+            if (T == 2) return launch_demod_chanest16<2, 8>(ctx, d_tx, d_rx_td, d_H, tw, g, n_frames, stream);
+            return launch_demod_chanest16<4, 8>(ctx, d_tx, d_rx_td, d_H, tw, g, n_frames, stream);
+        }
+        if (T == 1) return launch_demod_chanest16<1, 10>(ctx, d_tx, d_rx_td, d_H, tw, g, n_frames, stream);
+        if (T == 2) return launch_demod_chanest16<2, 10>(ctx, d_tx, d_rx_td, d_H, tw, g, n_frames, stream);
+        return launch_demod_chanest16<4, 10>(ctx, d_tx, d_rx_td, d_H, tw, g, n_frames, stream);
+    }
     int spr = g.N >= 1024 ? 1 : (g.N >= 512 ? 2 : 4);
     if (ctx->tune.demod_spr == 1 || ctx->tune.demod_spr == 2 || ctx->tune.demod_spr == 4) spr = ctx->tune.demod_spr;
     if (g.N < 8) spr = 4;

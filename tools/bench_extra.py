@@ -299,6 +299,8 @@ if __name__ == "__main__":
         print(json.dumps(detect_only("B"))); print(json.dumps(detect_only("D"))); print(json.dumps(power_map("B"))); print(json.dumps(power_map("D"))); sys.exit(0)
     if only == "equalizer":
         print(json.dumps(equalizer_config_c())); sys.exit(0)
+    if only == "demod":
+        print(json.dumps(radar_with_demod("B", 512))); print(json.dumps(radar_with_demod("D", 256))); sys.exit(0)
     if only == "comm":
         print(json.dumps(comm_rx_chain())); print(json.dumps(equalizer_config_c())); print(json.dumps(precoder_config_c())); sys.exit(0)
     for fn in (sync_front_end, comm_rx_chain, lambda: detect_only("B"), lambda: detect_only("D"), lambda: radar_with_demod("B", 512), lambda: radar_with_demod("D", 256), precoder_config_c, lambda: range_doppler("D", 8), lambda: range_doppler("B", 64),
