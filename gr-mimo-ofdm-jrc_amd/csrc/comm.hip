@@ -1117,8 +1117,10 @@ __global__ __launch_bounds__(256) void precoder_kernel(PreDev d, const float2* _
 // waves of a workgroup (times gridDim.y workgroups) walk the OFDM symbols, so Q[sc] — T*T values at a 8*T*T-byte stride between
 // lanes, the one uncoalesced read of the block — is fetched once per lane instead of once per cell, and every store and every
 // radar-stream load is a full 512-byte wave access.  N_tx in {1, 2, 4, 8}; other sizes run precoder_kernel.
+// four waves per SIMD (128 VGPRs): left to itself the compiler takes 178 and two waves fit (measured, config C: 0.304 ms at two, 0.271 at
+// three, 0.260 at four; five and six spill: 0.55 / 0.78); eight TX antennas (64 matrix entries per lane) keep two
 template <int T>
-__global__ __launch_bounds__(256) void precoder_frames_kernel(PreDev d, const float2* __restrict__ in, const float* __restrict__ sig,
+__global__ __launch_bounds__(256, T <= 4 ? 4 : 2) void precoder_frames_kernel(PreDev d, const float2* __restrict__ in, const float* __restrict__ sig,
                                                               int n_sym, int packet_type, int steer_mode,
                                                               const float2* __restrict__ Qm, const float2* __restrict__ Qsc,
                                                               const float2* __restrict__ rs, float2* __restrict__ out,
@@ -1139,7 +1141,35 @@ __global__ __launch_bounds__(256) void precoder_frames_kernel(PreDev d, const fl
         for (int i = 0; i < T * T; i++) q[i] = Q[i];
     }
     const int kstep = 4 * gridDim.y;
+    // the data symbol (and the radar streams) of the NEXT trip are requested before this trip's stores go out: the wait counter is in
+    // order, so a load issued behind the stores would only come back after they have all completed
+    const int k_data0 = d.NS + 1 + T;
+    const bool want_rs = rs != nullptr && packet_type != 1;
+    float2 s0n = make_float2(0.f, 0.f), rn[T];
+#pragma unroll
+    for (int j = 0; j < T; j++) rn[j] = make_float2(0.f, 0.f);
+    auto fetch = [&](int kk) {
+        if (kk >= k_data0 && kk < n_total && role >= 0) {
+            const int m = kk - k_data0;
+            if (role & 0x4000) s0n = d.pilot_sym[(size_t)(m % d.n_pilot_rows) * d.NP + (role & 0x3fff)];
+            else s0n = in[(size_t)m * d.ND + role];
+            if (want_rs) {
+#pragma unroll
+                for (int j = 1; j < T; j++) {          // read once: around the caches
+                    typedef float v2f __attribute__((ext_vector_type(2)));
+                    const v2f v = __builtin_nontemporal_load(reinterpret_cast<const v2f*>(rs + ((size_t)(j - 1) * n_sym + m) * N + sc));
+                    rn[j] = make_float2(v.x, v.y);
+                }
+            }
+        }
+    };
+    fetch(blockIdx.y * 4 + (threadIdx.x >> 6));
     for (int k = blockIdx.y * 4 + (threadIdx.x >> 6); k < n_total; k += kstep) {
+        const float2 s0 = s0n;
+        float2 r[T];
+#pragma unroll
+        for (int j = 0; j < T; j++) r[j] = rn[j];
+        fetch(k + kstep);
         float2 o[T];
 #pragma unroll
         for (int t = 0; t < T; t++) o[t] = make_float2(0.f, 0.f);                         // memset :337
@@ -1173,23 +1203,10 @@ __global__ __launch_bounds__(256) void precoder_frames_kernel(PreDev d, const fl
                 }
             }
         } else if (role >= 0) {                                                           // data / pilot carriers
-            const int m = k - d.NS - 1 - T;
-            float2 s0;
-            if (role & 0x4000) s0 = d.pilot_sym[(size_t)(m % d.n_pilot_rows) * d.NP + (role & 0x3fff)];
-            else s0 = in[(size_t)m * d.ND + role];
             if (packet_type == 1) {                                                       // NDP :394-428
 #pragma unroll
                 for (int t = 0; t < T && t < 2; t++) o[t] = s0;
             } else {                                                                      // DATA :589-712
-                float2 r[T];
-                if (rs) {
-#pragma unroll
-                    for (int j = 1; j < T; j++) {      // read once: around the caches
-                        typedef float v2f __attribute__((ext_vector_type(2)));
-                        const v2f v = __builtin_nontemporal_load(reinterpret_cast<const v2f*>(rs + ((size_t)(j - 1) * n_sym + m) * N + sc));
-                        r[j] = make_float2(v.x, v.y);
-                    }
-                }
 #pragma unroll
                 for (int t = 0; t < T; t++) {
                     float2 acc = cmul(q[t], s0);                                          // column 0 = the data stream
@@ -1202,6 +1219,7 @@ __global__ __launch_bounds__(256) void precoder_frames_kernel(PreDev d, const fl
             }
         }
         typedef float v2f __attribute__((ext_vector_type(2)));
+        asm volatile("" ::: "memory");           // keeps the next trip's loads (above) ahead of these stores in the instruction stream
 #pragma unroll
         for (int t = 0; t < T; t++) {            // write-once output, far larger than the caches for a batch: stored around them
             v2f v = {o[t].x, o[t].y};
