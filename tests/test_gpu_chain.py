@@ -343,6 +343,9 @@ def _td_case(jrc, ctx, T, R, N, cp, S, Npre, F, interleave, extra, seed):
     (3, 2, 128, 32, 6, 2, 4, True, 0),           # odd log2: leading radix-2 pass
     (8, 2, 512, 0, 2, 0, 3, False, 0),           # no cyclic prefix, two transforms per workgroup, 8 TX
     (2, 4, 32, 5, 7, 3, 10, False, 1),           # odd prefix length (8-byte aligned loads only)
+    (4, 4, 256, 64, 37, 5, 3, False, 0),         # radix-16 kernel, fft_len 256: rounds of 16 symbols, ragged last round (16 + 16 + 5)
+    (1, 2, 1024, 256, 9, 1, 4, True, 5),         # radix-16 kernel, fft_len 1024: rounds of 4 symbols (4 + 4 + 1), one TX antenna
+    (2, 1, 256, 0, 16, 0, 2, False, 0),          # exactly one round, a single receiver per frame
 ])
 def test_time_domain_channel_estimate_fused(jrc, ctx, T, R, N, cp, S, Npre, F, interleave, extra):
     """A6 + A7 + A1 as one kernel against the separate device calls (same butterflies and accumulation order; only the compiler's
