@@ -55,10 +55,7 @@
 //         through a private LDS tile ([rows of this trip][NA] floats) and stores whole 16-byte pieces of full rows; the estimator reads
 //         the MODE 2 window rows as in detect-only mode.  ROWS1: the tile holds one row at a time (when LDS is short: fft_len 1024).
 // IA: interp_angle known at compile time (16, the flowgraphs' interp_factor_angle), or 0 for the runtime argument
-// G: groups of NT / 64 / G wavefronts that share the staged H but take classes of their own, each with its range-bin buffer and its own
-//    barrier (an LDS counter): with one workgroup per CU (fft_len 1024: H fills the LDS) a single group would stop the CU's map stream at
-//    every range phase; two groups alternate, as the two resident workgroups of the smaller shapes do.
-template <int P, int NT, int MMAX, bool TWC_LDS, int MODE, int IA, bool ROWS1 = false, int G = 1>
+template <int P, int NT, int MMAX, bool TWC_LDS, int MODE, int IA, bool ROWS1 = false>
 #ifndef JRC_WPS256
 #define JRC_WPS256 3
 #endif
@@ -76,8 +73,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
 {
 #pragma clang fp contract(off)          // every rounding of this kernel is spelled out (fmaf / cmul_pin / fft_fwd_small_pin): the three MODEs agree bit for bit
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
-    constexpr int NW = NT / 64, NWG = NW / G, NTG = NT / G;     // waves / threads of a group
-    static_assert(G == 1 || !TWC_LDS, "groups keep their class twiddles in registers");
+    constexpr int NW = NT / 64;
     const int Ia = IA > 0 ? IA : Ia_arg;
     const int NA = P * Ia;
     const int C = NR / RA_L;
@@ -90,30 +86,14 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
     if (f >= F) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int grp = G == 1 ? 0 : wave / NWG, wg = wave - grp * NWG, tg = tid - grp * NTG;   // group, wave in the group, thread in the group
     float2* s_H = smem;                         // [P][N]
-    float2* s_g0 = s_H + (size_t)P * N;         // [G][P][64]; group 0's reused as reduction scratch at the end
-    float2* s_g = s_g0 + grp * (P * RA_L);
-    float2* s_twc = s_g0 + G * P * RA_L;        // [N] class twiddles (TWC_LDS only)
+    float2* s_g = s_H + (size_t)P * N;          // [P][64]; reused as reduction scratch at the end
+    float2* s_twc = s_g + P * RA_L;             // [N] class twiddles (TWC_LDS only)
     constexpr int NPT = TWC_LDS ? 4 : 1;        // class twiddles prefetched per thread (N <= NT*NPT)
-    __shared__ int s_arrived[2];                // G == 2: wavefronts that have reached the group's barriers so far
-    int bar_target = 0;
-    auto group_barrier = [&]() {
-        if constexpr (G == 1) __syncthreads();
-        else {
-            // a wave's LDS operations complete in order, so its arrival (one atomic add) is seen after its writes; the counter only grows
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            bar_target += NWG;
-            if (lane == 0) __hip_atomic_fetch_add(&s_arrived[grp], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            while (__hip_atomic_load(&s_arrived[grp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < bar_target) __builtin_amdgcn_s_sleep(1);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        }
-    };
     const int M = N / RA_L;                     // fold length per lane, <= MMAX
 
-    const int n_cls = (C - slice + WPF - 1) / WPF;                       // classes of this workgroup: c = slice + WPF i
-    const int n_iter = (n_cls - grp + G - 1) / G;                        // ... of this group: i = G it + grp
-    auto class_of = [&](int it) -> int { return slice + (it * G + grp) * WPF; };     // the class this group works on in its it-th trip
+    const int n_iter = (C - slice + WPF - 1) / WPF;
+    auto class_of = [&](int it) -> int { return slice + it * WPF; };     // the class this workgroup works on in its it-th trip
     const int c_first = class_of(0);
 
     // class twiddles for this lane's fold inputs n = lane + 64 m:  exp(+j 2 pi n c / NR)
@@ -134,10 +114,6 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
         float4* sH4 = reinterpret_cast<float4*>(s_H);
         for (int i = tid; i < (P * N) / 2; i += NT) sH4[i] = Hf4[i];
     }
-    if constexpr (G > 1) {
-        if (tid < 2) s_arrived[tid] = 0;
-        __syncthreads();                        // H staged, counters zeroed: from here on the groups only meet at the end
-    }
     // 64-point inverse FFT twiddles of this lane, one per radix-2 stage: exp(+j 2 pi k / (2 half))
     float2 t64[6];
 #pragma unroll
@@ -146,7 +122,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
         t64[st] = twR[((lane & (half - 1)) * (32 / half)) * (NR / 64)];
     }
     // angle twiddles of this lane's residue r = tid % Ia:  exp(-j 2 pi p r / NA)
-    const int r = tg % Ia;
+    const int r = tid % Ia;
     float2 ta[P];
 #pragma unroll
     for (int p = 1; p < P; p++) ta[p] = twA[(p * r) & (NA - 1)];
@@ -177,11 +153,11 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
 #pragma unroll
             for (int q = 0; q < NPT; q++) { const int n = tid + NT * q; if (n < N) s_twc[n] = tn[q]; }
         }
-        group_barrier();                        // s_H staged (first trip) / previous class's s_g reads done
+        __syncthreads();                        // s_H staged (first trip) / previous class's s_g reads done
         // ---- range axis: fold to 64 points, 64-point inverse FFT across the wavefront -------------
-        {   // the wave's pairs p = wg + NWG j side by side: they share the class twiddle of a fold term, and their butterfly chains interleave
-            constexpr int PPW = (P + NWG - 1) / NWG;
-            constexpr bool full = (P % NWG) == 0;   // every wave has PPW pairs
+        {   // the wave's pairs p = wave + NW j side by side: they share the class twiddle of a fold term, and their butterfly chains interleave
+            constexpr int PPW = (P + NW - 1) / NW;
+            constexpr bool full = (P % NW) == 0;    // every wave has PPW pairs
             float2 v[PPW];
 #pragma unroll
             for (int j = 0; j < PPW; j++) v[j] = make_float2(0.f, 0.f);
@@ -192,8 +168,8 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
                     if constexpr (TWC_LDS) w = s_twc[lane + RA_L * m]; else w = tc[m];
 #pragma unroll
                     for (int j = 0; j < PPW; j++)
-                        if (full || wg + NWG * j < P) {
-                            const float2 h = s_H[(size_t)(wg + NWG * j) * N + lane + RA_L * m];
+                        if (full || wave + NW * j < P) {
+                            const float2 h = s_H[(size_t)(wave + NW * j) * N + lane + RA_L * m];
                             v[j].x = fmaf(h.x, w.x, fmaf(-h.y, w.y, v[j].x));
                             v[j].y = fmaf(h.x, w.y, fmaf(h.y, w.x, v[j].y));
                         }
@@ -213,7 +189,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
             for (int j = 0; j < PPW; j++) v[j] = wave_dif_stage<0>(v[j], t64[5], lane);
 #pragma unroll
             for (int j = 0; j < PPW; j++)
-                if (full || wg + NWG * j < P) s_g[(wg + NWG * j) * RA_L + (__brev((unsigned)lane) >> 26)] = v[j];   // lane holds X[bitrev6(lane)]
+                if (full || wave + NW * j < P) s_g[(wave + NW * j) * RA_L + (__brev((unsigned)lane) >> 26)] = v[j];   // lane holds X[bitrev6(lane)]
         }
         if (it + 1 < n_iter) {                  // prefetch the next class's twiddles; they land during the stores
             const int cn = class_of(it + 1);
@@ -226,19 +202,19 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
                     if (m < M) tc[m] = twR[((lane + RA_L * m) * cn) & (NR - 1)];
             }
         }
-        group_barrier();
+        __syncthreads();
 
         if constexpr (MODE == 1 || MODE == 3) {      // the class's range profiles for the estimator's window pass: 8 KiB, coalesced 16-byte pieces
             float4* dst = reinterpret_cast<float4*>(rng_out + ((size_t)f * C + c) * (P * RA_L));
             const float4* src = reinterpret_cast<const float4*>(s_g);
-            for (int i = tg; i < (P * RA_L) / 2; i += NTG) dst[i] = src[i];
+            for (int i = tid; i < (P * RA_L) / 2; i += NT) dst[i] = src[i];
         }
         // ---- angle axis + fftshift + store + arg-max ---------------------------------------------
 #pragma unroll 1
-        for (int w0 = 0; w0 < items; w0 += NTG) {    // whole waves are in or out
-            const int w = w0 + tg;
+        for (int w0 = 0; w0 < items; w0 += NT) {     // whole waves are in or out
+            const int w = w0 + tid;
             if (w >= items) break;
-            const int ql = w / Ia;               // (w % Ia == r because Ia divides the group's threads)
+            const int ql = w / Ia;               // (w % Ia == r because Ia divides NT)
             const int k = C * ql + c;            // global range bin
             float2 y[P];
             y[0] = s_g[ql];
@@ -325,7 +301,196 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
         }
     }
     __syncthreads();
-    block_reduce_peak(trk, reinterpret_cast<PeakPartial*>(s_g0));
+    block_reduce_peak(trk, reinterpret_cast<PeakPartial*>(s_g));
+    if (tid == 0) { partials[(size_t)f * pstride + slice].best = trk.best; partials[(size_t)f * pstride + slice].idx = trk.idx; }
+}
+
+// ---- the fused kernel for fft_len 1024 (config D): classes of 256 range bins, H in registers ---------------------------------------
+// At fft_len 1024 the kernel above keeps the 128 KiB of H in LDS: one 512-thread workgroup per CU, two barriers around the range phase
+// of every 128 KiB class with nothing to overlap them, and — NR / 64 = 128 classes — the rows a wave stores together lie 256 KiB apart,
+// which the memory system serves at 65-70 % of its peak where config B's 64 KiB get 80 %.  Here a class is
+// k = C q + c with C = NR / 256 and q < 256:
+//     R[p][C q + c] = IFFT_256( g_c[p] )[q],   g_c[p][n'] = sum_{m < 4} H[p][n' + 256 m] e^{+j 2 pi (n' + 256 m) c / NR}
+// The fold inputs of a lane — H[p][lane + 64 j + 256 m], the same for every class — live in registers (2 pairs per wave: 64 VGPRs), so H
+// needs no LDS at all; the 256-point transform is one radix-4 step across a lane's four points (q = 4 a + b: twiddle e^{+j 2 pi lane b /
+// 256}) and four 64-point transforms across the wavefront (a = bitrev6(lane)).  The range bins of a class (32 KiB for 16 pairs) are
+// double-buffered, so ONE barrier per 512 KiB class separates the waves that fill a buffer from those that read it, the waves drift
+// apart and the range phase of some overlaps the stores of others; rows stored together are NR / 256 = 32 rows = 64 KiB apart.
+// Same angle axis, arg-max, pacing and MODEs as above; rng[frame][class][pair][(q & 3) * 64 + (q >> 2)] for the window pass.
+#define RW_L 256
+template <int P, int MODE, int IA>
+__global__ __launch_bounds__(512, 2) void range_angle_wide_kernel(
+    const float2* __restrict__ H, float2* __restrict__ map, PeakPartial* __restrict__ partials,
+    const float2* __restrict__ twR, const float2* __restrict__ twA,
+    int NR, int F, int WPF, int pstride, float2* __restrict__ rng_out, int nx, int pace)
+{
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    constexpr int NT = 512, NW = NT / 64, PPW = P / NW, N = 1024, MM = N / RW_L, Ia = IA, NA = P * Ia;
+    static_assert(P % NW == 0, "whole pairs per wave");
+    const int C = NR / RW_L;
+    const int xcd = blockIdx.x % nx;
+    const int jb = blockIdx.x / nx;
+    const int f = (jb / WPF) * nx + xcd;
+    const int slice = jb % WPF;
+    if (f >= F) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float2* s_g = smem;                                         // [2][P][256]
+    float* s_pw = reinterpret_cast<float*>(s_g + 2 * P * RW_L) + (size_t)wave * (64 * P);   // MODE 3: this wave's tile (its four rows)
+
+    // this wave's share of H, for good
+    float2 h[PPW][4][MM];
+    {
+        const float2* Hf = H + (size_t)f * P * N;
+#pragma unroll
+        for (int jj = 0; jj < PPW; jj++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int m = 0; m < MM; m++) h[jj][j][m] = Hf[(size_t)(wave + NW * jj) * N + lane + 64 * j + RW_L * m];
+    }
+    const int n_iter = (C - slice + WPF - 1) / WPF;
+    auto class_of = [&](int it) -> int { return slice + it * WPF; };
+    float2 tc[4][MM];                                           // class twiddles exp(+j 2 pi n c / NR), n = lane + 64 j + 256 m
+    auto fetch_tc = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int m = 0; m < MM; m++) tc[j][m] = twR[((lane + 64 * j + RW_L * m) * c) & (NR - 1)];
+    };
+    fetch_tc(class_of(0));
+    float2 t64[6];                                              // 64-point inverse FFT twiddles of this lane, one per radix-2 stage
+#pragma unroll
+    for (int st = 0; st < 6; st++) {
+        const int half = 32 >> st;
+        t64[st] = twR[((lane & (half - 1)) * (32 / half)) * (NR / 64)];
+    }
+    float2 t256[4];                                             // exp(+j 2 pi lane b / 256)
+#pragma unroll
+    for (int b = 1; b < 4; b++) t256[b] = twR[(lane * b) * (NR / RW_L)];
+    const int r = tid % Ia;
+    float2 ta[P];
+#pragma unroll
+    for (int p = 1; p < P; p++) ta[p] = twA[(p * r) & (NA - 1)];
+
+    PeakTracker trk;
+    trk.init();
+    constexpr int items = RW_L * Ia;
+    constexpr int ahalf = NA >> 1, amask = NA - 1;
+    float2* mapf = map + (size_t)f * NR * NA;
+    float* mapp = reinterpret_cast<float*>(map) + (size_t)f * NR * NA;          // MODE 3
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const int pace_T = pace & 0xfff, pace_K = (pace >> 12) & 0xf;
+    long long t_next = 0;
+    if constexpr (MODE == 0) { if (pace_T) t_next = (long long)wall_clock64(); }
+
+#pragma unroll 1
+    for (int it = 0; it < n_iter; it++) {
+        const int c = class_of(it);
+        float2* sg = s_g + (size_t)(it & 1) * (P * RW_L);
+        // ---- range axis ---------------------------------------------------------------------------------------------------------
+        {
+            float2 v[PPW][4];
+#pragma unroll
+            for (int jj = 0; jj < PPW; jj++) {
+                float2 g[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    g[j] = make_float2(0.f, 0.f);
+#pragma unroll
+                    for (int m = 0; m < MM; m++) {
+                        const float2 hh = h[jj][j][m], w = tc[j][m];
+                        g[j].x = fmaf(hh.x, w.x, fmaf(-hh.y, w.y, g[j].x));
+                        g[j].y = fmaf(hh.x, w.y, fmaf(hh.y, w.x, g[j].y));
+                    }
+                }
+                // inverse radix-4 across the lane's four points: y_b = sum_j g[j] (+j)^(j b)
+                const float2 a0 = make_float2(g[0].x + g[2].x, g[0].y + g[2].y), a1 = make_float2(g[0].x - g[2].x, g[0].y - g[2].y);
+                const float2 b0 = make_float2(g[1].x + g[3].x, g[1].y + g[3].y), b1 = make_float2(g[1].x - g[3].x, g[1].y - g[3].y);
+                v[jj][0] = make_float2(a0.x + b0.x, a0.y + b0.y);
+                v[jj][1] = cmul_pin(make_float2(a1.x - b1.y, a1.y + b1.x), t256[1]);      // a1 + j b1
+                v[jj][2] = cmul_pin(make_float2(a0.x - b0.x, a0.y - b0.y), t256[2]);
+                v[jj][3] = cmul_pin(make_float2(a1.x + b1.y, a1.y - b1.x), t256[3]);      // a1 - j b1
+            }
+#define RW_STAGE(B, ST)                                                                                   \
+            _Pragma("unroll") for (int jj = 0; jj < PPW; jj++)                                            \
+                _Pragma("unroll") for (int b = 0; b < 4; b++) v[jj][b] = wave_dif_stage<B>(v[jj][b], t64[ST], lane);
+            RW_STAGE(5, 0) RW_STAGE(4, 1) RW_STAGE(3, 2) RW_STAGE(2, 3) RW_STAGE(1, 4) RW_STAGE(0, 5)
+#undef RW_STAGE
+            const int a = (int)(__brev((unsigned)lane) >> 26);   // lane holds X[4 a + b]
+#pragma unroll
+            for (int jj = 0; jj < PPW; jj++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) sg[(wave + NW * jj) * RW_L + b * 64 + a] = v[jj][b];
+        }
+        if (it + 1 < n_iter) fetch_tc(class_of(it + 1));          // they land during the stores
+        __syncthreads();                                          // the one barrier of the class: its range bins are complete; the buffer the next
+                                                                  // range phase fills was last read before this barrier
+        if constexpr (MODE == 1 || MODE == 3) {
+            float4* dst = reinterpret_cast<float4*>(rng_out + ((size_t)f * C + c) * (P * RW_L));
+            const float4* src = reinterpret_cast<const float4*>(sg);
+            for (int i = tid; i < (P * RW_L) / 2; i += NT) dst[i] = src[i];
+        }
+        // ---- angle axis + fftshift + store + arg-max -------------------------------------------------------------------------
+#pragma unroll 1
+        for (int w0 = 0; w0 < items; w0 += NT) {
+            const int w = w0 + tid;
+            const int q = w / Ia;                                 // (w % Ia == r); a wave's four range bins q .. q + 3 are the four b of one a
+            const int qi = (q & 3) * 64 + (q >> 2);
+            const int k = C * q + c;
+            float2 y[P];
+            y[0] = sg[qi];
+#pragma unroll
+            for (int p = 1; p < P; p++) y[p] = cmul_pin(sg[p * RW_L + qi], ta[p]);
+            fft_fwd_small_pin<P>(y);
+            float m = -1.0f;
+#pragma unroll
+            for (int u = 0; u < P; u++) m = fmaxf(m, fast_power(y[u]));
+            if constexpr (MODE == 3) {
+                constexpr int rw = 64 / Ia;
+                const int rb = lane / Ia, q0 = q - rb;
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                float* trow = s_pw + rb * NA;
+#pragma unroll
+                for (int u = 0; u < P; u++) trow[(Ia * u + r + ahalf) & amask] = y[u].x * y[u].x + y[u].y * y[u].y;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                constexpr int n4 = rw * NA / 4;
+                for (int i = lane; i < n4; i += 64) {
+                    const int row = (4 * i) / NA, col = (4 * i) % NA;
+                    const float4 vv = *reinterpret_cast<const float4*>(s_pw + 4 * i);
+                    const v4f t = {vv.x, vv.y, vv.z, vv.w};
+                    __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(mapp + (size_t)(C * (q0 + row) + c) * NA + col));
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if constexpr (MODE == 0) {
+                float2* row = mapf + (size_t)k * NA;
+#pragma unroll
+                for (int u = 0; u < P; u++) {
+                    const int aa = (Ia * u + r + ahalf) & amask;  // fftshift
+                    if ((u % RA_GROUP) == 0 && pace_T) {
+                        long long now = (long long)wall_clock64();
+                        t_next += pace_T;
+                        if (now - t_next > (long long)pace_K * pace_T) t_next = now - (long long)pace_K * pace_T;
+                        while (now < t_next) { asm volatile("s_sleep 1"); now = (long long)wall_clock64(); }
+                    }
+                    const v2f t = {y[u].x, y[u].y};
+                    __builtin_nontemporal_store(t, reinterpret_cast<v2f*>(row + aa));
+                    if ((u % RA_GROUP) == RA_GROUP - 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                }
+            }
+            const float thr = trk.raise(m);
+            if (m >= thr) {
+                const unsigned flat0 = (unsigned)k * (unsigned)NA;
+#pragma unroll
+                for (int u = 0; u < P; u++)
+                    if (fast_power(y[u]) >= thr) trk.exact(y[u], flat0 + ((Ia * u + r + ahalf) & amask));
+            }
+        }
+    }
+    __syncthreads();
+    block_reduce_peak(trk, reinterpret_cast<PeakPartial*>(s_g));
     if (tid == 0) { partials[(size_t)f * pstride + slice].best = trk.best; partials[(size_t)f * pstride + slice].idx = trk.idx; }
 }
 
@@ -335,13 +500,13 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
 template <int P>
 __global__ __launch_bounds__(256) void ra_window_rows_kernel(const float2* __restrict__ rng, const PeakPartial* __restrict__ partials, int pstride,
                                                              float2* __restrict__ win, const float2* __restrict__ twA, int NR, int Ia,
-                                                             int win_rows, int win_off)
+                                                             int win_rows, int win_off, int L /* range bins per class: 64, or 256 (range_angle_wide_kernel) */)
 {
 #pragma clang fp contract(off)
     __shared__ PeakPartial red[4];
     __shared__ int s_row0;
     const int f = blockIdx.x, tid = threadIdx.x;
-    const int NA = P * Ia, C = NR / RA_L;
+    const int NA = P * Ia, C = NR / L;
     PeakTracker pk;
     pk.init();
     for (int i = tid; i < pstride; i += blockDim.x) pk.merge(partials[(size_t)f * pstride + i].best, partials[(size_t)f * pstride + i].idx);
@@ -357,11 +522,11 @@ __global__ __launch_bounds__(256) void ra_window_rows_kernel(const float2* __res
     for (int row = tid / Ia; row < win_rows; row += blockDim.x / Ia) {
         const int k = ((row0 + row) % NR + NR) % NR;
         const int c = k % C, ql = k / C;                   // k = C ql + c
-        const float2* g = rng + ((size_t)f * C + c) * (P * RA_L) + ql;
+        const float2* g = rng + ((size_t)f * C + c) * (size_t)(P * L) + (L == RA_L ? ql : (ql & 3) * 64 + (ql >> 2));
         float2 y[P];
         y[0] = g[0];
 #pragma unroll
-        for (int p = 1; p < P; p++) y[p] = cmul_pin(g[p * RA_L], ta[p]);
+        for (int p = 1; p < P; p++) y[p] = cmul_pin(g[p * L], ta[p]);
         fft_fwd_small_pin<P>(y);
         float2* out = win + ((size_t)f * win_rows + row) * NA;
 #pragma unroll
@@ -376,7 +541,7 @@ struct jrc_chain {
     jrc_chain_cfg cfg;
     int P, NR, NA, C, threads, wg_per_cu, n_cus, wpf_override, max_frames;
     bool generic = false;             // shapes the fused kernel does not cover: block-by-block kernels on the device
-    bool split = false;               // fused kernel with two wavefront groups per workgroup (G = 2: 16 pairs x fft_len 1024 x interp_angle 16, config D)
+    bool wide = false;                // range_angle_wide_kernel: 16 pairs x fft_len 1024 x interp_angle 16 (config D): classes of 256 range bins, H in registers
     float2* d_pad = nullptr;          // generic mode: [max_frames][P][NR] zero-padded rows / range profiles
     int gen_blocks = 0;               // generic mode: partial-maximum blocks per frame
     float* d_bins = nullptr;          // range_bins (NR) then angle_bins (NA)
@@ -503,16 +668,17 @@ static int chain_pace(const jrc_chain* ch)
     // group — 7 TB/s offered — hold the map stream at the rate of a pure store stream (0.341 ms per 512 config-B frames, 79 % of the HBM
     // peak; 0.366 ms unpaced); other geometries are not paced
     if (ch->P == 16 && ch->cfg.interp_angle == 16 && ch->threads == 256 && ch->wg_per_cu == 2 && ch->cfg.interp_range <= 8) return (1 << 12) | 121;
-    // config D's shape (one 512-thread workgroup per CU): 1.0 us, no catching up — 0.777 ms per 256 frames against 0.85 unpaced
-    if (ch->P == 16 && ch->cfg.interp_angle == 16 && ch->threads == 512 && ch->cfg.fft_len == 1024 && ch->cfg.interp_range <= 8) return 100;
+    // fft_len 1024 without range_angle_wide_kernel (JRC_NO_WIDE; one 512-thread workgroup per CU): 1.0 us, no catching up — 0.777 ms per 256
+    // frames against 0.85 unpaced.  The wide kernel itself runs the same paced or not (0.689-0.695 ms for T = 60 ... 100): not paced.
+    if (!ch->wide && ch->P == 16 && ch->cfg.interp_angle == 16 && ch->threads == 512 && ch->cfg.fft_len == 1024 && ch->cfg.interp_range <= 8) return 100;
     return 0;
 }
 
-template <int P, int NT, int MMAX, bool TWC_LDS, int MODE, int IA, bool ROWS1 = false, int G = 1>
+template <int P, int NT, int MMAX, bool TWC_LDS, int MODE, int IA, bool ROWS1 = false>
 static int launch_fused_mode(jrc_chain* ch, int n_frames, int wpf, int pstride, const float2* d_H, float2* d_map, hipStream_t s)
 {
     const size_t lds_bytes = MODE == 3 ? ch->lds_power : ch->lds_bytes;
-    JRC_TRY(jrc_ensure_dyn_lds(ch->ctx, (const void*)range_angle_fused_kernel<P, NT, MMAX, TWC_LDS, MODE, IA, ROWS1, G>, lds_bytes));
+    JRC_TRY(jrc_ensure_dyn_lds(ch->ctx, (const void*)range_angle_fused_kernel<P, NT, MMAX, TWC_LDS, MODE, IA, ROWS1>, lds_bytes));
     // One resident wave of workgroups per launch: a batch that needs more is launched in chunks of that size, and a last,
     // smaller chunk gets more slices per frame so that it fills the machine as well (a grid twice the resident size runs 20 %
     // slower than two launches because its second wave of workgroups starts ragged).  `pstride` partial maxima per frame.
@@ -525,11 +691,33 @@ static int launch_fused_mode(jrc_chain* ch, int n_frames, int wpf, int pstride, 
         const dim3 grid((unsigned)(((nf + nx - 1) / nx) * nx * w));
         float2* mp = MODE == 0 ? d_map + (size_t)f0 * ch->NR * ch->NA
                    : (MODE == 3 ? reinterpret_cast<float2*>(reinterpret_cast<float*>(d_map) + (size_t)f0 * ch->NR * ch->NA) : nullptr);
-        hipLaunchKernelGGL((range_angle_fused_kernel<P, NT, MMAX, TWC_LDS, MODE, IA, ROWS1, G>), grid, dim3(NT), lds_bytes, s,
+        hipLaunchKernelGGL((range_angle_fused_kernel<P, NT, MMAX, TWC_LDS, MODE, IA, ROWS1>), grid, dim3(NT), lds_bytes, s,
                            d_H + (size_t)f0 * P * ch->cfg.fft_len, mp,
                            ch->d_partials + (size_t)f0 * pstride,
                            ch->twR, ch->twA, ch->cfg.fft_len, ch->NR, ch->cfg.interp_angle, nf, w, pstride,
                            (MODE == 1 || MODE == 3) ? ch->d_rng + (size_t)f0 * ch->NR * P : nullptr, nx, chain_pace(ch));
+    }
+    JRC_HIP(ch->ctx, hipGetLastError());
+    return JRC_OK;
+}
+
+template <int MODE>
+static int launch_fused_wide(jrc_chain* ch, int n_frames, int wpf, int pstride, const float2* d_H, float2* d_map, hipStream_t s)
+{
+    const size_t lds_bytes = MODE == 3 ? ch->lds_power : ch->lds_bytes;
+    JRC_TRY(jrc_ensure_dyn_lds(ch->ctx, (const void*)range_angle_wide_kernel<16, MODE, 16>, lds_bytes));
+    const int nx = ch->ctx->n_xcd;
+    const int chunk = chain_chunk(ch, wpf);
+    for (int f0 = 0; f0 < n_frames; f0 += chunk) {
+        const int nf = n_frames - f0 < chunk ? n_frames - f0 : chunk;
+        int w = chain_pick_wpf(ch, nf);
+        if (w > pstride) w = pstride;
+        const dim3 grid((unsigned)(((nf + nx - 1) / nx) * nx * w));
+        float2* mp = MODE == 0 ? d_map + (size_t)f0 * ch->NR * ch->NA
+                   : (MODE == 3 ? reinterpret_cast<float2*>(reinterpret_cast<float*>(d_map) + (size_t)f0 * ch->NR * ch->NA) : nullptr);
+        hipLaunchKernelGGL((range_angle_wide_kernel<16, MODE, 16>), grid, dim3(512), lds_bytes, s,
+                           d_H + (size_t)f0 * 16 * ch->cfg.fft_len, mp, ch->d_partials + (size_t)f0 * pstride, ch->twR, ch->twA,
+                           ch->NR, nf, w, pstride, (MODE == 1 || MODE == 3) ? ch->d_rng + (size_t)f0 * ch->NR * 16 : nullptr, nx, chain_pace(ch));
     }
     JRC_HIP(ch->ctx, hipGetLastError());
     return JRC_OK;
@@ -540,12 +728,6 @@ static int launch_fused_nt(jrc_chain* ch, int mode, int n_frames, int wpf, int p
 {
     // interp_angle = 16 (the flowgraphs' interp_factor_angle, examples/simulation/radar/mimo_ofdm_jrc_radar_sim.grc) is compiled in; any other
     // value takes the runtime argument
-    if constexpr (P == 16 && NT == 512 && MMAX == 16 && !TWC_LDS) {     // config D's shape: two groups of four wavefronts (ch->split)
-        if (mode == 0) return launch_fused_mode<P, NT, MMAX, false, 0, 16, false, 2>(ch, n_frames, wpf, pstride, d_H, d_map, s);
-        if (mode == 1) return launch_fused_mode<P, NT, MMAX, false, 1, 16, false, 2>(ch, n_frames, wpf, pstride, d_H, d_map, s);
-        return ch->power_rows1 ? launch_fused_mode<P, NT, MMAX, false, 3, 16, true, 2>(ch, n_frames, wpf, pstride, d_H, d_map, s)
-                               : launch_fused_mode<P, NT, MMAX, false, 3, 16, false, 2>(ch, n_frames, wpf, pstride, d_H, d_map, s);
-    }
     if (ch->cfg.interp_angle == 16) {
         if (mode == 0) return launch_fused_mode<P, NT, MMAX, TWC_LDS, 0, 16>(ch, n_frames, wpf, pstride, d_H, d_map, s);
         if (mode == 1) return launch_fused_mode<P, NT, MMAX, TWC_LDS, 1, 16>(ch, n_frames, wpf, pstride, d_H, d_map, s);
@@ -565,9 +747,6 @@ static int launch_fused(jrc_chain* ch, int mode, int n_frames, int wpf, int pstr
     // 512-thread workgroup per CU
     if (ch->threads == 1024) return launch_fused_nt<P, 1024, 16, true>(ch, mode, n_frames, wpf, pstride, d_H, d_map, s);
     if (ch->threads == 512 && ch->cfg.fft_len <= 256) return launch_fused_nt<P, 512, 4, false>(ch, mode, n_frames, wpf, pstride, d_H, d_map, s);
-    // config D's shape (ch->split): the map-less modes run as two wavefront groups per workgroup (detect-only 242 -> 255 k frames/s); the map
-    // stream itself measured the same or slower that way (0.79 against 0.78 ms per 256 frames) and stays one group, paced
-    if constexpr (P == 16) { if (ch->split && mode != 0) return launch_fused_nt<P, 512, 16, false>(ch, mode, n_frames, wpf, pstride, d_H, d_map, s); }
     if (ch->threads == 512) return launch_fused_nt<P, 512, 16, true>(ch, mode, n_frames, wpf, pstride, d_H, d_map, s);
     if (ch->cfg.fft_len > 256) return launch_fused_nt<P, 256, 16, true>(ch, mode, n_frames, wpf, pstride, d_H, d_map, s);
     return launch_fused_nt<P, 256, 4, false>(ch, mode, n_frames, wpf, pstride, d_H, d_map, s);
@@ -579,11 +758,11 @@ static int launch_window_rows(jrc_chain* ch, int n_frames, int pstride, hipStrea
     const int rows = 2 * ch->win_dr;
     if (rows <= 0) return JRC_OK;
 #define JRC_WIN_CASE(PP) case PP: hipLaunchKernelGGL(ra_window_rows_kernel<PP>, dim3(n_frames), dim3(256), 0, s, ch->d_rng, ch->d_partials, pstride, ch->d_win, \
-                                                     ch->twA, ch->NR, ch->cfg.interp_angle, rows, ch->NR / 2 - ch->win_dr); break;
+                                                     ch->twA, ch->NR, ch->cfg.interp_angle, rows, ch->NR / 2 - ch->win_dr, ch->wide ? RW_L : RA_L); break;
     switch (ch->P) {
         JRC_WIN_CASE(1) JRC_WIN_CASE(2) JRC_WIN_CASE(4) JRC_WIN_CASE(8)
         default: hipLaunchKernelGGL(ra_window_rows_kernel<16>, dim3(n_frames), dim3(256), 0, s, ch->d_rng, ch->d_partials, pstride, ch->d_win, ch->twA,
-                                    ch->NR, ch->cfg.interp_angle, rows, ch->NR / 2 - ch->win_dr);
+                                    ch->NR, ch->cfg.interp_angle, rows, ch->NR / 2 - ch->win_dr, ch->wide ? RW_L : RA_L);
     }
 #undef JRC_WIN_CASE
     JRC_HIP(ch->ctx, hipGetLastError());
@@ -592,6 +771,11 @@ static int launch_window_rows(jrc_chain* ch, int n_frames, int pstride, hipStrea
 
 static int launch_fused_any(jrc_chain* ch, int mode, int n_frames, int wpf, int pstride, const float2* d_H, float2* d_map, hipStream_t s)
 {
+    if (ch->wide) {
+        if (mode == 0) return launch_fused_wide<0>(ch, n_frames, wpf, pstride, d_H, d_map, s);
+        if (mode == 1) return launch_fused_wide<1>(ch, n_frames, wpf, pstride, d_H, d_map, s);
+        return launch_fused_wide<3>(ch, n_frames, wpf, pstride, d_H, d_map, s);
+    }
     switch (ch->P) {
         case 1: return launch_fused<1>(ch, mode, n_frames, wpf, pstride, d_H, d_map, s);
         case 2: return launch_fused<2>(ch, mode, n_frames, wpf, pstride, d_H, d_map, s);
@@ -631,9 +815,12 @@ extern "C" int jrc_chain_create(jrc_ctx* ctx, const jrc_chain_cfg* cfg, const fl
     ch->lds_bytes = sizeof(float2) * ((size_t)P * N + (size_t)P * RA_L + (N > 256 ? (size_t)N : 0));
     ch->threads = (ch->lds_bytes > 80 * 1024) ? 512 : 256;
     if (getenv("JRC_THREADS")) { int t = atoi(getenv("JRC_THREADS")); if (t == 512 || (t == 1024 && N > 256)) ch->threads = t; else ch->threads = 256; }
-    ch->split = ch->threads == 512 && N > 256 && P == 16 && cfg->interp_angle == 16 && !getenv("JRC_NO_SPLIT");
-    // (the split variant's LDS — H + a range-bin buffer per group, class twiddles in registers — is what lds_bytes already holds at this shape:
-    //  P * 64 == fft_len)
+    ch->wide = !ch->generic && N == 1024 && P == 16 && cfg->interp_angle == 16 && NR >= RW_L && !getenv("JRC_NO_WIDE");
+    if (ch->wide) {               // no H in LDS: two buffers of range bins; the registers (H share + transforms) allow one 512-thread workgroup per CU
+        ch->threads = 512;
+        ch->lds_bytes = sizeof(float2) * 2 * (size_t)P * RW_L;
+        ch->C = (int)(NR / RW_L);
+    }
     ch->wpf_override = getenv("JRC_WPF") ? atoi(getenv("JRC_WPF")) : 0;
     {
         ch->n_cus = ctx->n_cus;
