@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Writes pmc_traffic.json from the FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh: HBM bytes per launch of the
-dominant kernel (range_angle_fused_kernel), stamped with the hash of the kernel sources it was measured at, the kernel's
+dominant kernel (range_angle_fused_kernel, or range_angle_wide_kernel at fft_len 1024), stamped with the hash of the kernel sources it was measured at, the kernel's
 full name as rocprofv3 reports it, and the tag of the profile set.  bench.py reports `roofline.traffic` from this file only
 when the stamp equals the hash of the tree it runs in (else traffic: null, traffic_stale: true).
 
@@ -18,7 +18,7 @@ from jrc_amd import build as jb  # noqa: E402
 def avg_kib(db, counter):
     cur = sqlite3.connect(db).cursor()
     q = ("select kernel_name, avg(value), count(*) from counters_collection where counter_name = ? and kernel_name like "
-         "'%range_angle_fused_kernel%' group by kernel_name")
+         "'%range_angle_%_kernel%' group by kernel_name")
     rows = list(cur.execute(q, (counter,)))
     rows.sort(key=lambda r: -r[2])
     return rows[0]
@@ -26,7 +26,7 @@ def avg_kib(db, counter):
 
 def main():
     out_path, tag = sys.argv[1], sys.argv[2]
-    out = {"_comment": "HBM bytes per launch of range_angle_fused_kernel from rocprofv3 PMC passes (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE "
+    out = {"_comment": "HBM bytes per launch of range_angle_fused_kernel / range_angle_wide_kernel from rocprofv3 PMC passes (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE "
                        "runs; KiB per dispatch; FETCH_SIZE doubled per MI355X_MICROARCH.md gfx950 correction).",
            "source_hash": jb.source_hash(), "profile_set": tag}
     for spec in sys.argv[3:]:
