@@ -35,7 +35,7 @@ struct jrc_ctx {
     int n_xcd = 8;
     // experiment switches, read once in jrc_create (environment JRC_*)
     struct {
-        int chanest_chunk = 0;       // JRC_CHANEST_CHUNK: frames per A1 launch (0 = four workgroups per CU)
+        int chanest_chunk = 0;       // JRC_CHANEST_CHUNK: frames per A1 launch (0 = two workgroups per CU)
         bool chanest_x1 = false;     // JRC_CHANEST_X1: one subcarrier per lane in A1
         bool fd_serial = false;      // JRC_FD_SERIAL: single-wave detector scan
         bool sync_naive = false;     // JRC_SYNC_NAIVE: detection metrics without the LDS tile

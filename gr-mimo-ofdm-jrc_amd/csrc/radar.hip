@@ -162,10 +162,12 @@ int launch_radar_chanest(jrc_ctx* ctx, int T, int R, const float2* d_frames, flo
     const bool aligned16 = (g.N % 2 == 0) && (g.port_stride % 2 == 0) && (g.frame_stride % 2 == 0) &&
                            ((reinterpret_cast<size_t>(d_frames) | reinterpret_cast<size_t>(d_H)) & 15) == 0;
     if (R <= 4 && (T == 1 || T == 2 || T == 4) && aligned16 && g.N >= 128 && !ctx->tune.chanest_x1) {
-        // launched in chunks of at most four workgroups per CU: with every workgroup resident from the start the frame reads
-        // advance evenly (5.4 TB/s); a grid twice that size loses 10-15 % to its second, ragged wave of workgroups
+        // launched in chunks of two workgroups per CU: with every workgroup resident from the start the frame reads advance evenly; a
+        // grid beyond one resident wave loses 10-15 % to its second, ragged wave of workgroups.  Two per CU against four: the same at
+        // fft_len 256 (0.093 ms per 512 config-B frames), 10 % faster at fft_len 1024 (0.362-0.372 against 0.402 ms per 256 config-D
+        // frames, 5.8 TB/s; any chunk that is not a whole number of workgroups per CU loses: 0.46-0.49 ms)
         const int wg_per_frame = (g.N / 2 + 63) / 64;
-        int chunk = ctx->tune.chanest_chunk > 0 ? ctx->tune.chanest_chunk : (4 * ctx->n_cus) / wg_per_frame;
+        int chunk = ctx->tune.chanest_chunk > 0 ? ctx->tune.chanest_chunk : (2 * ctx->n_cus) / wg_per_frame;
         if (chunk < 1) chunk = 1;
         const dim3 block(64, R, 1);
         for (int f0 = 0; f0 < n_frames; f0 += chunk) {
@@ -528,9 +530,10 @@ static int launch_demod_chanest16(jrc_ctx* ctx, const float2* d_tx, const float2
 {
     constexpr int N = 1 << LOGN, NSYM = 4096 / N;
     const long grp = (long)g.n_xcd * g.R;
-    const long blocks = (((long)n_frames * g.R + grp - 1) / grp) * grp;          // whole frames per group of R workgroups of an XCD
     const size_t lds_bytes = sizeof(float2) * ((size_t)N + (size_t)NSYM * (N + N / 16));
     JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)demod_chanest16_kernel<T, LOGN>, lds_bytes));
+    // one launch for the whole batch: chunks of 1 ... 8 workgroups per CU were measured and are the same or slower
+    const long blocks = (((long)n_frames * g.R + grp - 1) / grp) * grp;          // whole frames per group of R workgroups of an XCD
     hipLaunchKernelGGL((demod_chanest16_kernel<T, LOGN>), dim3((unsigned)blocks), dim3(256), lds_bytes, stream, d_tx, d_rx_td, d_H, tw, g, n_frames);
     JRC_HIP(ctx, hipGetLastError());
     return JRC_OK;
