@@ -11,6 +11,7 @@
 #include "fft_device.h"
 
 #include <algorithm>
+#include <type_traits>
 #include <cmath>
 
 // ------------------------------------------------------------------------------------------------
@@ -424,45 +425,48 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
                     S.symbol_ind = sym + nb - 1;
                 }
                 __syncthreads();
-                int scv[EPT];                                                           // (C)
+                // (C) no branch around a load or a store: the memory counter is in order, and with loads or stores that may or may not be
+                // issued the compiler cannot count what lies between a load and its use — it drains the counter (vmcnt(0)) at every symbol,
+                // which turns the EQ_PD symbols of prefetch into none.  So: lanes past the last data carrier repeat the last one (they
+                // compute the same value and store it to the same address), the prefetch index is clamped to the last symbol (read again
+                // from cache), and the packet type selects one of two copies of the loop instead of a branch per cell.
+                int scv[EPT], oi[EPT];
                 float2 hv[EPT];
                 double hm2[EPT];
                 // EQ_PD symbols of input in flight per lane: one symbol is ~0.3 us of arithmetic against a ~2 us HBM round trip
                 float2 xq[EQ_PD][EPT];
 #pragma unroll
                 for (int e = 0; e < EPT; e++) {
-                    const int i = tid + e * NT;
-                    if (i < ND) {
-                        scv[e] = dc[i];
-                        hv[e] = Hsel[scv[e]];
-                        hm2[e] = (double)c_mul(hv[e], c_conj(hv[e])).x;
+                    oi[e] = min(tid + e * NT, ND - 1);
+                    scv[e] = dc[oi[e]];
+                    hv[e] = Hsel[scv[e]];
+                    hm2[e] = (double)c_mul(hv[e], c_conj(hv[e])).x;
 #pragma unroll
-                        for (int q = 0; q < EQ_PD; q++)
-                            if (q < nb) xq[q][e] = in[(size_t)(n_in + q) * N + scv[e]];
-                    }
+                    for (int q = 0; q < EQ_PD; q++) xq[q][e] = in[(size_t)(n_in + min(q, nb - 1)) * N + scv[e]];
                 }
-                for (int j0 = 0; j0 < nb; j0 += EQ_PD) {
+                auto equalise = [&](auto PT) {
+                    constexpr int pt = decltype(PT)::value;
+                    for (int j0 = 0; j0 < nb; j0 += EQ_PD) {
 #pragma unroll
-                    for (int q = 0; q < EQ_PD; q++) {
-                        const int j = j0 + q;
-                        if (j >= nb) break;
-                        float2 xc[EPT];
+                        for (int q = 0; q < EQ_PD; q++) {
+                            const int j = j0 + q;
+                            if (j >= nb) break;
+                            float2 xc[EPT];
+                            const size_t nxt = (size_t)(n_in + min(j + EQ_PD, nb - 1)) * N;
 #pragma unroll
-                        for (int e = 0; e < EPT; e++) {
-                            xc[e] = xq[q][e];
-                            if (tid + e * NT < ND && j + EQ_PD < nb) xq[q][e] = in[(size_t)(n_in + j + EQ_PD) * N + scv[e]];
-                        }
-                        const double k0 = 2 * M_PI * (sym + j) * ((N + d.cp) * 1.0 / N) * eps;
-                        const float2 rot = s_brot[j];
-                        const double nvar = s_bnoi[j];
-                        float2* o = out + (size_t)(n_out + j) * ND;
+                            for (int e = 0; e < EPT; e++) {
+                                xc[e] = xq[q][e];
+                                xq[q][e] = in[nxt + scv[e]];
+                            }
+                            const double k0 = 2 * M_PI * (sym + j) * ((N + d.cp) * 1.0 / N) * eps;
+                            const float2 rot = s_brot[j];
+                            const double nvar = s_bnoi[j];
+                            float2* o = out + (size_t)(n_out + j) * ND;
 #pragma unroll
-                        for (int e = 0; e < EPT; e++) {
-                            const int i = tid + e * NT;
-                            if (i < ND) {
+                            for (int e = 0; e < EPT; e++) {
                                 const float2 yr = c_mul(c_mul(xc[e], c_expj(k0 * (scv[e] - N / 2))), rot);
                                 float2 z;
-                                if (ptype == 1) z = c_div(yr, hv[e]);                   // symbol_equalize :900-906
+                                if constexpr (pt == 1) z = c_div(yr, hv[e]);            // symbol_equalize :900-906
                                 else {                                                  // :540-550
                                     const float csi = (float)(hm2[e] + nvar);
                                     const float2 num = c_mul(yr, c_conj(hv[e]));
@@ -470,11 +474,12 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
                                 }
                                 typedef float v2f __attribute__((ext_vector_type(2)));     // :602; write-once output: around the caches
                                 const v2f zz = {z.x, z.y};
-                                __builtin_nontemporal_store(zz, reinterpret_cast<v2f*>(o + i));
+                                __builtin_nontemporal_store(zz, reinterpret_cast<v2f*>(o + oi[e]));
                             }
                         }
                     }
-                }
+                };
+                if (ptype == 1) equalise(std::integral_constant<int, 1>{}); else equalise(std::integral_constant<int, 2>{});
                 n_in += nb; n_out += nb; advance = 1;
 #pragma unroll
                 for (int e = 0; e < EPT; e++) { const int i = tid + e * NT; if (i < N && n_in < io.ninput) xin[e] = in[(size_t)n_in * N + i]; }
