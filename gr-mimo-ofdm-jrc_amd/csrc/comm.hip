@@ -55,6 +55,15 @@ __device__ __forceinline__ float2 c_expj(double x)   // std::exp(gr_complex(0, x
     return make_float2(cs, sn);
 }
 
+__device__ __forceinline__ float2 c_expj_small(double x)   // c_expj for |(float)x| <= pi/4, which the caller has established: the same two polynomials, no test
+{
+    const float xf = (float)x;
+    const float z = xf * xf;
+    const float sn = fmaf(xf * z, fmaf(z, fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), xf);
+    const float cs = fmaf(z * z, fmaf(z, fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f), fmaf(z, -0.5f, 1.0f));
+    return make_float2(cs, sn);
+}
+
 __host__ __device__ inline int popc8(int n) { int s = 0; for (int i = 0; i < 8; i++) s += (n >> i) & 1; return s; }
 
 // ------------------------------------------------------------------------------------------------
@@ -253,7 +262,7 @@ __device__ __forceinline__ unsigned sig_viterbi_wave(const float2* Z, int nd, un
 
 #define EQ_BATCH 64   // data symbols per three-phase pass of the equalizer
 #ifndef EQ_PD
-#define EQ_PD 4       // input symbols in flight per lane in the equalisation phase
+#define EQ_PD 2       // input symbols in flight per lane in the equalisation phase (measured at config C once the loop had no branch around its loads: 1: 0.602-0.613 ms, 2: 0.593-0.599, 3: 0.596, 4: 0.602-0.65 with 31 spilled registers)
 #endif
 
 // NTMAX = workgroup size the variant is compiled for, WPE = waves per SIMD it must allow (register budget 512 / WPE)
@@ -444,8 +453,14 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
 #pragma unroll
                     for (int q = 0; q < EQ_PD; q++) xq[q][e] = in[(size_t)(n_in + min(q, nb - 1)) * N + scv[e]];
                 }
-                auto equalise = [&](auto PT) {
+                // The rotation angle of a cell is k0 (sc - N/2) with |sc - N/2| <= N/2 and |k0| growing with the symbol index: when the last
+                // symbol's k0 * N/2 rounds to at most pi/4 every angle of the batch does (rounding is monotonic), and the loop runs on
+                // the polynomial alone — no test, no exec-masked slow path splitting the cell's code into blocks.
+                const double k0_last = 2 * M_PI * (sym + nb - 1) * ((N + d.cp) * 1.0 / N) * eps;
+                const bool all_small = fabsf((float)(k0_last * (N / 2))) <= 0.78539816f;
+                auto equalise = [&](auto PT, auto SMALL) {
                     constexpr int pt = decltype(PT)::value;
+                    constexpr bool small = decltype(SMALL)::value;
                     for (int j0 = 0; j0 < nb; j0 += EQ_PD) {
 #pragma unroll
                         for (int q = 0; q < EQ_PD; q++) {
@@ -464,7 +479,8 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
                             float2* o = out + (size_t)(n_out + j) * ND;
 #pragma unroll
                             for (int e = 0; e < EPT; e++) {
-                                const float2 yr = c_mul(c_mul(xc[e], c_expj(k0 * (scv[e] - N / 2))), rot);
+                                const double ang = k0 * (scv[e] - N / 2);
+                                const float2 yr = c_mul(c_mul(xc[e], small ? c_expj_small(ang) : c_expj(ang)), rot);
                                 float2 z;
                                 if constexpr (pt == 1) z = c_div(yr, hv[e]);            // symbol_equalize :900-906
                                 else {                                                  // :540-550
@@ -479,7 +495,11 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
                         }
                     }
                 };
-                if (ptype == 1) equalise(std::integral_constant<int, 1>{}); else equalise(std::integral_constant<int, 2>{});
+                if (all_small) {
+                    if (ptype == 1) equalise(std::integral_constant<int, 1>{}, std::true_type{}); else equalise(std::integral_constant<int, 2>{}, std::true_type{});
+                } else {
+                    if (ptype == 1) equalise(std::integral_constant<int, 1>{}, std::false_type{}); else equalise(std::integral_constant<int, 2>{}, std::false_type{});
+                }
                 n_in += nb; n_out += nb; advance = 1;
 #pragma unroll
                 for (int e = 0; e < EPT; e++) { const int i = tid + e * NT; if (i < N && n_in < io.ninput) xin[e] = in[(size_t)n_in * N + i]; }
