@@ -305,7 +305,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
     if (tid == 0) { partials[(size_t)f * pstride + slice].best = trk.best; partials[(size_t)f * pstride + slice].idx = trk.idx; }
 }
 
-// ---- the fused kernel for fft_len 1024 (config D): classes of 256 range bins, H in registers ---------------------------------------
+// ---- the fused kernel for fft_len 1024 (config D) and for long range axes: classes of 256 range bins, H in registers ---------------
 // At fft_len 1024 the kernel above keeps the 128 KiB of H in LDS: one 512-thread workgroup per CU, two barriers around the range phase
 // of every 128 KiB class with nothing to overlap them, and — NR / 64 = 128 classes — the rows a wave stores together lie 256 KiB apart,
 // which the memory system serves at 65-70 % of its peak where config B's 64 KiB get 80 %.  Here a class is
@@ -317,8 +317,10 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
 // double-buffered, so ONE barrier per 512 KiB class separates the waves that fill a buffer from those that read it, the waves drift
 // apart and the range phase of some overlaps the stores of others; rows stored together are NR / 256 = 32 rows = 64 KiB apart.
 // Same angle axis, arg-max, pacing and MODEs as above; rng[frame][class][pair][(q & 3) * 64 + (q >> 2)] for the window pass.
+// fft_len 256 / 512 (one / two fold terms) take this kernel too when the range axis is long (NR >= 4096): the 64-bin classes would put
+// their rows 128 KiB and more apart (config-B shape with interp_range 16 / 32: 57-65 % of the peak).
 #define RW_L 256
-template <int P, int MODE, int IA>
+template <int P, int MODE, int IA, int LOGN>
 __global__ __launch_bounds__(512, 2) void range_angle_wide_kernel(
     const float2* __restrict__ H, float2* __restrict__ map, PeakPartial* __restrict__ partials,
     const float2* __restrict__ twR, const float2* __restrict__ twA,
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(512, 2) void range_angle_wide_kernel(
 {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
-    constexpr int NT = 512, NW = NT / 64, PPW = P / NW, N = 1024, MM = N / RW_L, Ia = IA, NA = P * Ia;
+    constexpr int NT = 512, NW = NT / 64, PPW = P / NW, N = 1 << LOGN, MM = N / RW_L, Ia = IA, NA = P * Ia;
     static_assert(P % NW == 0, "whole pairs per wave");
     const int C = NR / RW_L;
     const int xcd = blockIdx.x % nx;
@@ -701,11 +703,11 @@ static int launch_fused_mode(jrc_chain* ch, int n_frames, int wpf, int pstride, 
     return JRC_OK;
 }
 
-template <int MODE>
+template <int MODE, int LOGN>
 static int launch_fused_wide(jrc_chain* ch, int n_frames, int wpf, int pstride, const float2* d_H, float2* d_map, hipStream_t s)
 {
     const size_t lds_bytes = MODE == 3 ? ch->lds_power : ch->lds_bytes;
-    JRC_TRY(jrc_ensure_dyn_lds(ch->ctx, (const void*)range_angle_wide_kernel<16, MODE, 16>, lds_bytes));
+    JRC_TRY(jrc_ensure_dyn_lds(ch->ctx, (const void*)range_angle_wide_kernel<16, MODE, 16, LOGN>, lds_bytes));
     const int nx = ch->ctx->n_xcd;
     const int chunk = chain_chunk(ch, wpf);
     for (int f0 = 0; f0 < n_frames; f0 += chunk) {
@@ -715,7 +717,7 @@ static int launch_fused_wide(jrc_chain* ch, int n_frames, int wpf, int pstride, 
         const dim3 grid((unsigned)(((nf + nx - 1) / nx) * nx * w));
         float2* mp = MODE == 0 ? d_map + (size_t)f0 * ch->NR * ch->NA
                    : (MODE == 3 ? reinterpret_cast<float2*>(reinterpret_cast<float*>(d_map) + (size_t)f0 * ch->NR * ch->NA) : nullptr);
-        hipLaunchKernelGGL((range_angle_wide_kernel<16, MODE, 16>), grid, dim3(512), lds_bytes, s,
+        hipLaunchKernelGGL((range_angle_wide_kernel<16, MODE, 16, LOGN>), grid, dim3(512), lds_bytes, s,
                            d_H + (size_t)f0 * 16 * ch->cfg.fft_len, mp, ch->d_partials + (size_t)f0 * pstride, ch->twR, ch->twA,
                            ch->NR, nf, w, pstride, (MODE == 1 || MODE == 3) ? ch->d_rng + (size_t)f0 * ch->NR * 16 : nullptr, nx, chain_pace(ch));
     }
@@ -772,9 +774,14 @@ static int launch_window_rows(jrc_chain* ch, int n_frames, int pstride, hipStrea
 static int launch_fused_any(jrc_chain* ch, int mode, int n_frames, int wpf, int pstride, const float2* d_H, float2* d_map, hipStream_t s)
 {
     if (ch->wide) {
-        if (mode == 0) return launch_fused_wide<0>(ch, n_frames, wpf, pstride, d_H, d_map, s);
-        if (mode == 1) return launch_fused_wide<1>(ch, n_frames, wpf, pstride, d_H, d_map, s);
-        return launch_fused_wide<3>(ch, n_frames, wpf, pstride, d_H, d_map, s);
+#define JRC_WIDE_CASE(LG)                                                                                   \
+        if (mode == 0) return launch_fused_wide<0, LG>(ch, n_frames, wpf, pstride, d_H, d_map, s);          \
+        if (mode == 1) return launch_fused_wide<1, LG>(ch, n_frames, wpf, pstride, d_H, d_map, s);          \
+        return launch_fused_wide<3, LG>(ch, n_frames, wpf, pstride, d_H, d_map, s);
+        if (ch->cfg.fft_len == 1024) { JRC_WIDE_CASE(10) }
+        if (ch->cfg.fft_len == 512) { JRC_WIDE_CASE(9) }
+        JRC_WIDE_CASE(8)
+#undef JRC_WIDE_CASE
     }
     switch (ch->P) {
         case 1: return launch_fused<1>(ch, mode, n_frames, wpf, pstride, d_H, d_map, s);
@@ -815,7 +822,10 @@ extern "C" int jrc_chain_create(jrc_ctx* ctx, const jrc_chain_cfg* cfg, const fl
     ch->lds_bytes = sizeof(float2) * ((size_t)P * N + (size_t)P * RA_L + (N > 256 ? (size_t)N : 0));
     ch->threads = (ch->lds_bytes > 80 * 1024) ? 512 : 256;
     if (getenv("JRC_THREADS")) { int t = atoi(getenv("JRC_THREADS")); if (t == 512 || (t == 1024 && N > 256)) ch->threads = t; else ch->threads = 256; }
-    ch->wide = !ch->generic && N == 1024 && P == 16 && cfg->interp_angle == 16 && NR >= RW_L && !getenv("JRC_NO_WIDE");
+    // range_angle_wide_kernel: fft_len 1024 always (H would fill the LDS); fft_len 256 / 512 when the 64-bin classes would put the rows a
+    // wave stores together 128 KiB or more apart (NR >= 4096)
+    ch->wide = !ch->generic && P == 16 && cfg->interp_angle == 16 && !getenv("JRC_NO_WIDE") &&
+               ((N == 1024 && NR >= RW_L) || ((N == 256 || N == 512) && NR >= 4096));
     if (ch->wide) {               // no H in LDS: two buffers of range bins; the registers (H share + transforms) allow one 512-thread workgroup per CU
         ch->threads = 512;
         ch->lds_bytes = sizeof(float2) * 2 * (size_t)P * RW_L;

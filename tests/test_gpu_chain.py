@@ -98,6 +98,34 @@ def test_chain_other_shapes(jrc, ctx, T, R, N, S, Ir, Ia, interleave):
     check(jrc, ctx, sc, Ir, Ia, 2, interleave=interleave)
 
 
+@pytest.mark.parametrize("N,S,Ir,F", [(256, 4, 16, 3), (256, 3, 32, 2), (512, 4, 8, 3), (512, 2, 16, 5), (1024, 3, 4, 2), (1024, 2, 1, 3)])
+def test_chain_long_range_axes_take_the_wide_kernel(jrc, ctx, N, S, Ir, F, monkeypatch):
+    """16 pairs x interp_angle 16 with fft_len 1024, or fft_len 256 / 512 and fft_len * interp_range >= 4096: range_angle_wide_kernel (classes of
+    256 range bins, H in registers) — against the oracle chain, and against the 64-bin kernel (JRC_NO_WIDE) on the same frames: same peak
+    cell, maps equal to rounding"""
+    import torch
+    from jrc_amd import synth
+    sc = synth.Scenario(N, 4, 4, S, targets=[(12.0, -15.0, 3.0, 60.0)])
+    check(jrc, ctx, sc, Ir, 16, F, interleave=bool(Ir & 16))
+    fr = synth.make_frames(sc, F)
+    P = 16
+    rb, ab = jrc.radar_axes(N, sc.fs, Ir, P, 16)
+    out = []
+    for no_wide in (False, True):
+        if no_wide:
+            monkeypatch.setenv("JRC_NO_WIDE", "1")
+        ch = jrc.RadarChain(N, 4, 4, S, sc.Npre, Ir, 16, rb, ab, 2.4, 20.0, 15.0, 0.0, max_frames=F, ctx=ctx)
+        bufs = ch.alloc(F, "cuda:0")
+        bufs["frames"][:F].copy_(torch.from_numpy(fr.view(np.float32).reshape((F,) + tuple(bufs["frames"].shape[1:]))))
+        torch.cuda.synchronize()
+        ch.run(bufs, F)
+        res = ch.results(bufs, F)
+        out.append((bufs["map"].cpu().numpy().view(np.complex64)[..., 0].copy(), [(r.peak_range_idx, r.peak_angle_idx) for r in res]))
+        ch.close()
+    assert out[0][1] == out[1][1]
+    assert rel_err(out[0][0], out[1][0]) < 1e-5
+
+
 def test_chain_linearity_and_frame_independence(jrc, ctx):
     """size-independent properties at config-B size: map(a*rx) = a*map(rx); a frame's result does not depend
     on its neighbours in the batch or on its slot."""

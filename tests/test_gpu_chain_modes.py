@@ -207,6 +207,32 @@ def test_detect_only_results_equal_map_mode(jrc, ctx, cfg, F):
     assert all(r.n_noise_samples > 0 for r in res)
 
 
+@pytest.mark.parametrize("N,S,Ir,F", [(256, 3, 16, 5), (512, 2, 8, 4), (256, 2, 32, 3)])
+def test_detect_only_and_power_map_on_the_wide_kernel_at_smaller_fft_len(jrc, ctx, N, S, Ir, F):
+    """range_angle_wide_kernel at fft_len 256 / 512 (long range axis): the three MODEs agree bit for bit as everywhere else"""
+    import torch
+    from jrc_amd import synth
+    sc = synth.Scenario(N, 4, 4, S, targets=[(9.0, 25.0, 0.0, 40.0)])
+    frames = synth.make_frames(sc, F)
+    frames = (frames * (1.0 + 0.5 * np.arange(F, dtype=np.float32))[:, None, None, None]).astype(np.complex64)
+    full, det, again, res = _both_modes(jrc, ctx, sc, Ir, 16, F, frames=frames)
+    assert det == full and again == full
+    ch, axes = _chain(jrc, ctx, sc, Ir, 16, F)
+    bufs = ch.alloc(F, "cuda:0")
+    _load(bufs, frames, F)
+    ch.run(bufs, F)
+    want = [_rec(r) for r in ch.results(bufs, F)]
+    cmap = bufs["map"].cpu().numpy().view(np.complex64)[..., 0]
+    ch.set_map_format(True)
+    bp = ch.alloc(F, "cuda:0", power_map=True)
+    _load(bp, frames, F)
+    ch.run(bp, F)
+    assert [_rec(r) for r in ch.results(bp, F)] == want
+    pw = bp["map"].cpu().numpy()
+    ref = (cmap.real.astype(np.float32) * cmap.real.astype(np.float32)) + (cmap.imag.astype(np.float32) * cmap.imag.astype(np.float32))
+    assert np.array_equal(pw.reshape(ref.shape), ref)
+
+
 def _shapes(n, seed=77):
     rng = np.random.default_rng(seed)
     out = []
