@@ -823,9 +823,11 @@ extern "C" int jrc_chain_create(jrc_ctx* ctx, const jrc_chain_cfg* cfg, const fl
     ch->threads = (ch->lds_bytes > 80 * 1024) ? 512 : 256;
     if (getenv("JRC_THREADS")) { int t = atoi(getenv("JRC_THREADS")); if (t == 512 || (t == 1024 && N > 256)) ch->threads = t; else ch->threads = 256; }
     // range_angle_wide_kernel: fft_len 1024 always (H would fill the LDS); fft_len 256 / 512 when the 64-bin classes would put the rows a
-    // wave stores together 128 KiB or more apart (NR >= 4096)
+    // wave stores together 128 KiB or more apart (NR >= 4096).  JRC_FORCE_WIDE takes it for any NR >= 256 at those sizes — measured at config B:
+    // map mode 0.351 ms per 512 frames against 0.340 for the paced 64-bin kernel, detect-only 1.51 against 1.37 M frames/s; the modes of a chain
+    // must agree bit for bit, so they share one kernel family, and the map stream decides.
     ch->wide = !ch->generic && P == 16 && cfg->interp_angle == 16 && !getenv("JRC_NO_WIDE") &&
-               ((N == 1024 && NR >= RW_L) || ((N == 256 || N == 512) && NR >= 4096));
+               ((N == 1024 && NR >= RW_L) || ((N == 256 || N == 512) && (NR >= 4096 || (getenv("JRC_FORCE_WIDE") && NR >= RW_L))));
     if (ch->wide) {               // no H in LDS: two buffers of range bins; the registers (H share + transforms) allow one 512-thread workgroup per CU
         ch->threads = 512;
         ch->lds_bytes = sizeof(float2) * 2 * (size_t)P * RW_L;
