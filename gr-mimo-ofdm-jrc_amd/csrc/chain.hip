@@ -320,15 +320,15 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
 // fft_len 256 / 512 (one / two fold terms) take this kernel too when the range axis is long (NR >= 4096): the 64-bin classes would put
 // their rows 128 KiB and more apart (config-B shape with interp_range 16 / 32: 57-65 % of the peak).
 #define RW_L 256
-template <int P, int MODE, int IA, int LOGN>
-__global__ __launch_bounds__(512, 2) void range_angle_wide_kernel(
+template <int P, int MODE, int IA, int LOGN, int NT_ = 512>
+__global__ __launch_bounds__(NT_, 2) void range_angle_wide_kernel(
     const float2* __restrict__ H, float2* __restrict__ map, PeakPartial* __restrict__ partials,
     const float2* __restrict__ twR, const float2* __restrict__ twA,
     int NR, int F, int WPF, int pstride, float2* __restrict__ rng_out, int nx, int pace)
 {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
-    constexpr int NT = 512, NW = NT / 64, PPW = P / NW, N = 1 << LOGN, MM = N / RW_L, Ia = IA, NA = P * Ia;
+    constexpr int NT = NT_, NW = NT / 64, PPW = P / NW, N = 1 << LOGN, MM = N / RW_L, Ia = IA, NA = P * Ia;
     static_assert(P % NW == 0, "whole pairs per wave");
     const int C = NR / RW_L;
     const int xcd = blockIdx.x % nx;
@@ -543,7 +543,7 @@ struct jrc_chain {
     jrc_chain_cfg cfg;
     int P, NR, NA, C, threads, wg_per_cu, n_cus, wpf_override, max_frames;
     bool generic = false;             // shapes the fused kernel does not cover: block-by-block kernels on the device
-    bool wide = false;                // range_angle_wide_kernel: 16 pairs x fft_len 1024 x interp_angle 16 (config D): classes of 256 range bins, H in registers
+    bool wide = false;                // range_angle_wide_kernel: 16 pairs x interp_angle 16 at fft_len 256 / 512 / 1024 (configs B, D): classes of 256 range bins, H in registers
     float2* d_pad = nullptr;          // generic mode: [max_frames][P][NR] zero-padded rows / range profiles
     int gen_blocks = 0;               // generic mode: partial-maximum blocks per frame
     float* d_bins = nullptr;          // range_bins (NR) then angle_bins (NA)
@@ -669,7 +669,10 @@ static int chain_pace(const jrc_chain* ch)
     // measured (tools/pace_sweep.sh): eight waves per CU, each releasing 8 x 512 B every 1.21 us and allowed to catch up one
     // group — 7 TB/s offered — hold the map stream at the rate of a pure store stream (0.341 ms per 512 config-B frames, 79 % of the HBM
     // peak; 0.366 ms unpaced); other geometries are not paced
-    if (ch->P == 16 && ch->cfg.interp_angle == 16 && ch->threads == 256 && ch->wg_per_cu == 2 && ch->cfg.interp_range <= 8) return (1 << 12) | 121;
+    // the wide kernel as two 256-thread workgroups per CU (fft_len 256 / 512): a group of stores per wave every 1.08 us, no catching up —
+    // a plateau from 1.02 to 1.12 us (config B: 0.328-0.332 ms per 512 frames, 82 % of the HBM peak; 0.352 unpaced, 0.340 at 1.16 us)
+    if (ch->wide && ch->threads == 256) return 108;
+    if (!ch->wide && ch->P == 16 && ch->cfg.interp_angle == 16 && ch->threads == 256 && ch->wg_per_cu == 2 && ch->cfg.interp_range <= 8) return (1 << 12) | 121;
     // fft_len 1024 without range_angle_wide_kernel (JRC_NO_WIDE; one 512-thread workgroup per CU): 1.0 us, no catching up — 0.777 ms per 256
     // frames against 0.85 unpaced.  The wide kernel itself runs the same paced or not (0.689-0.695 ms for T = 60 ... 100): not paced.
     if (!ch->wide && ch->P == 16 && ch->cfg.interp_angle == 16 && ch->threads == 512 && ch->cfg.fft_len == 1024 && ch->cfg.interp_range <= 8) return 100;
@@ -703,11 +706,11 @@ static int launch_fused_mode(jrc_chain* ch, int n_frames, int wpf, int pstride, 
     return JRC_OK;
 }
 
-template <int MODE, int LOGN>
+template <int MODE, int LOGN, int NT_ = 512>
 static int launch_fused_wide(jrc_chain* ch, int n_frames, int wpf, int pstride, const float2* d_H, float2* d_map, hipStream_t s)
 {
     const size_t lds_bytes = MODE == 3 ? ch->lds_power : ch->lds_bytes;
-    JRC_TRY(jrc_ensure_dyn_lds(ch->ctx, (const void*)range_angle_wide_kernel<16, MODE, 16, LOGN>, lds_bytes));
+    JRC_TRY(jrc_ensure_dyn_lds(ch->ctx, (const void*)range_angle_wide_kernel<16, MODE, 16, LOGN, NT_>, lds_bytes));
     const int nx = ch->ctx->n_xcd;
     const int chunk = chain_chunk(ch, wpf);
     for (int f0 = 0; f0 < n_frames; f0 += chunk) {
@@ -717,7 +720,7 @@ static int launch_fused_wide(jrc_chain* ch, int n_frames, int wpf, int pstride, 
         const dim3 grid((unsigned)(((nf + nx - 1) / nx) * nx * w));
         float2* mp = MODE == 0 ? d_map + (size_t)f0 * ch->NR * ch->NA
                    : (MODE == 3 ? reinterpret_cast<float2*>(reinterpret_cast<float*>(d_map) + (size_t)f0 * ch->NR * ch->NA) : nullptr);
-        hipLaunchKernelGGL((range_angle_wide_kernel<16, MODE, 16, LOGN>), grid, dim3(512), lds_bytes, s,
+        hipLaunchKernelGGL((range_angle_wide_kernel<16, MODE, 16, LOGN, NT_>), grid, dim3(NT_), lds_bytes, s,
                            d_H + (size_t)f0 * 16 * ch->cfg.fft_len, mp, ch->d_partials + (size_t)f0 * pstride, ch->twR, ch->twA,
                            ch->NR, nf, w, pstride, (MODE == 1 || MODE == 3) ? ch->d_rng + (size_t)f0 * ch->NR * 16 : nullptr, nx, chain_pace(ch));
     }
@@ -774,13 +777,13 @@ static int launch_window_rows(jrc_chain* ch, int n_frames, int pstride, hipStrea
 static int launch_fused_any(jrc_chain* ch, int mode, int n_frames, int wpf, int pstride, const float2* d_H, float2* d_map, hipStream_t s)
 {
     if (ch->wide) {
-#define JRC_WIDE_CASE(LG)                                                                                   \
-        if (mode == 0) return launch_fused_wide<0, LG>(ch, n_frames, wpf, pstride, d_H, d_map, s);          \
-        if (mode == 1) return launch_fused_wide<1, LG>(ch, n_frames, wpf, pstride, d_H, d_map, s);          \
-        return launch_fused_wide<3, LG>(ch, n_frames, wpf, pstride, d_H, d_map, s);
-        if (ch->cfg.fft_len == 1024) { JRC_WIDE_CASE(10) }
-        if (ch->cfg.fft_len == 512) { JRC_WIDE_CASE(9) }
-        JRC_WIDE_CASE(8)
+#define JRC_WIDE_CASE(LG, THREADS)                                                                              \
+        if (mode == 0) return launch_fused_wide<0, LG, THREADS>(ch, n_frames, wpf, pstride, d_H, d_map, s);      \
+        if (mode == 1) return launch_fused_wide<1, LG, THREADS>(ch, n_frames, wpf, pstride, d_H, d_map, s);      \
+        return launch_fused_wide<3, LG, THREADS>(ch, n_frames, wpf, pstride, d_H, d_map, s);
+        if (ch->cfg.fft_len == 1024) { JRC_WIDE_CASE(10, 512) }
+        if (ch->cfg.fft_len == 512) { JRC_WIDE_CASE(9, 256) }
+        JRC_WIDE_CASE(8, 256)
 #undef JRC_WIDE_CASE
     }
     switch (ch->P) {
@@ -822,14 +825,13 @@ extern "C" int jrc_chain_create(jrc_ctx* ctx, const jrc_chain_cfg* cfg, const fl
     ch->lds_bytes = sizeof(float2) * ((size_t)P * N + (size_t)P * RA_L + (N > 256 ? (size_t)N : 0));
     ch->threads = (ch->lds_bytes > 80 * 1024) ? 512 : 256;
     if (getenv("JRC_THREADS")) { int t = atoi(getenv("JRC_THREADS")); if (t == 512 || (t == 1024 && N > 256)) ch->threads = t; else ch->threads = 256; }
-    // range_angle_wide_kernel: fft_len 1024 always (H would fill the LDS); fft_len 256 / 512 when the 64-bin classes would put the rows a
-    // wave stores together 128 KiB or more apart (NR >= 4096).  JRC_FORCE_WIDE takes it for any NR >= 256 at those sizes — measured at config B:
-    // map mode 0.351 ms per 512 frames against 0.340 for the paced 64-bin kernel, detect-only 1.51 against 1.37 M frames/s; the modes of a chain
-    // must agree bit for bit, so they share one kernel family, and the map stream decides.
-    ch->wide = !ch->generic && P == 16 && cfg->interp_angle == 16 && !getenv("JRC_NO_WIDE") &&
-               ((N == 1024 && NR >= RW_L) || ((N == 256 || N == 512) && (NR >= 4096 || (getenv("JRC_FORCE_WIDE") && NR >= RW_L))));
-    if (ch->wide) {               // no H in LDS: two buffers of range bins; the registers (H share + transforms) allow one 512-thread workgroup per CU
-        ch->threads = 512;
+    // range_angle_wide_kernel for 16 pairs x interp_angle 16 at fft_len 256 / 512 / 1024 (JRC_NO_WIDE: the 64-bin kernel).  fft_len 1024: one
+    // 512-thread workgroup per CU (a lane's share of H is 64 VGPRs); 256 / 512: two 256-thread workgroups per CU (16 / 32 VGPRs of H, four
+    // pairs per wave).  Measured against the 64-bin kernel, 512 frames: fft_len 256 with interp_range 4 / 8 / 16 / 32:
+    // 0.75 / 0.82 / 0.82 / 0.82 of the HBM peak against 0.72 / 0.80 / 0.60 / 0.65; fft_len 512 with 4 / 8: 0.78 / 0.80 against 0.74 / 0.71.
+    ch->wide = !ch->generic && P == 16 && cfg->interp_angle == 16 && !getenv("JRC_NO_WIDE") && (N == 256 || N == 512 || N == 1024) && NR >= RW_L;
+    if (ch->wide) {               // no H in LDS: two buffers of range bins
+        ch->threads = N == 1024 ? 512 : 256;
         ch->lds_bytes = sizeof(float2) * 2 * (size_t)P * RW_L;
         ch->C = (int)(NR / RW_L);
     }

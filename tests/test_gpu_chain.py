@@ -98,11 +98,12 @@ def test_chain_other_shapes(jrc, ctx, T, R, N, S, Ir, Ia, interleave):
     check(jrc, ctx, sc, Ir, Ia, 2, interleave=interleave)
 
 
-@pytest.mark.parametrize("N,S,Ir,F", [(256, 4, 16, 3), (256, 3, 32, 2), (512, 4, 8, 3), (512, 2, 16, 5), (1024, 3, 4, 2), (1024, 2, 1, 3)])
-def test_chain_long_range_axes_take_the_wide_kernel(jrc, ctx, N, S, Ir, F, monkeypatch):
-    """16 pairs x interp_angle 16 with fft_len 1024, or fft_len 256 / 512 and fft_len * interp_range >= 4096: range_angle_wide_kernel (classes of
-    256 range bins, H in registers) — against the oracle chain, and against the 64-bin kernel (JRC_NO_WIDE) on the same frames: same peak
-    cell, maps equal to rounding"""
+@pytest.mark.parametrize("N,S,Ir,F", [(256, 4, 8, 5), (256, 2, 1, 3), (256, 4, 16, 3), (256, 3, 32, 2), (512, 4, 8, 3), (512, 3, 2, 4), (512, 2, 16, 5),
+                                      (1024, 3, 4, 2), (1024, 2, 1, 3)])
+def test_chain_wide_kernel_against_oracle_and_64_bin_kernel(jrc, ctx, N, S, Ir, F, monkeypatch):
+    """16 pairs x interp_angle 16 at fft_len 256 / 512 / 1024: range_angle_wide_kernel (classes of 256 range bins, H in registers; two
+    256-thread workgroups per CU below fft_len 1024) — against the oracle chain, and against the 64-bin kernel (JRC_NO_WIDE) on the same
+    frames: same peak cell, maps equal to rounding"""
     import torch
     from jrc_amd import synth
     sc = synth.Scenario(N, 4, 4, S, targets=[(12.0, -15.0, 3.0, 60.0)])
