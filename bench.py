@@ -313,7 +313,7 @@ def roofline_of(chain, kt, cfg, sc, Ir, Ia, F):
     alg_bytes = F * (P * sc.N * 8 + NR * NA * 8) / n_launch
     traffic, stale = pmc_traffic(cfg, f_launch if f_launch is not None else F)
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-    wide = P == 16 and Ia == 16 and not os.environ.get("JRC_NO_WIDE") and sc.N in (256, 512, 1024) and NR >= 256       # chain.hip: jrc_chain::wide
+    wide = P in (8, 16) and Ia == 16 and not os.environ.get("JRC_NO_WIDE") and sc.N in (256, 512, 1024) and NR >= 256       # chain.hip: jrc_chain::wide
     r = {"bound": "hbm", "kernel": ("range_angle_wide_kernel<%d>" if wide else "range_angle_fused_kernel<%d>") % P, "achieved": achieved,
          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
          "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,

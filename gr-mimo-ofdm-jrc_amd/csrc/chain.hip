@@ -328,7 +328,8 @@ __global__ __launch_bounds__(NT_, 2) void range_angle_wide_kernel(
 {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
-    constexpr int NT = NT_, NW = NT / 64, PPW = P / NW, N = 1 << LOGN, MM = N / RW_L, Ia = IA, NA = P * Ia;
+    constexpr int NT = NT_, NW = NT / 64, PPW = P / NW, N = 1 << LOGN, MM = N >= RW_L ? N / RW_L : 1, Ia = IA, NA = P * Ia;
+    constexpr int NJ = N >= RW_L ? 4 : N / 64;                  // fft_len 64 / 128: only the first one / two of a lane's four points are inputs, the rest zero
     static_assert(P % NW == 0, "whole pairs per wave");
     const int C = NR / RW_L;
     const int xcd = blockIdx.x % nx;
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(NT_, 2) void range_angle_wide_kernel(
 #pragma unroll
             for (int j = 0; j < 4; j++)
 #pragma unroll
-                for (int m = 0; m < MM; m++) h[jj][j][m] = Hf[(size_t)(wave + NW * jj) * N + lane + 64 * j + RW_L * m];
+                for (int m = 0; m < MM; m++) h[jj][j][m] = j < NJ ? Hf[(size_t)(wave + NW * jj) * N + lane + 64 * j + RW_L * m] : make_float2(0.f, 0.f);
     }
     const int n_iter = (C - slice + WPF - 1) / WPF;
     auto class_of = [&](int it) -> int { return slice + it * WPF; };
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(NT_, 2) void range_angle_wide_kernel(
 #pragma unroll
         for (int j = 0; j < 4; j++)
 #pragma unroll
-            for (int m = 0; m < MM; m++) tc[j][m] = twR[((lane + 64 * j + RW_L * m) * c) & (NR - 1)];
+            for (int m = 0; m < MM; m++) tc[j][m] = j < NJ ? twR[((lane + 64 * j + RW_L * m) * c) & (NR - 1)] : make_float2(0.f, 0.f);
     };
     fetch_tc(class_of(0));
     float2 t64[6];                                              // 64-point inverse FFT twiddles of this lane, one per radix-2 stage
@@ -706,11 +707,11 @@ static int launch_fused_mode(jrc_chain* ch, int n_frames, int wpf, int pstride, 
     return JRC_OK;
 }
 
-template <int MODE, int LOGN, int NT_ = 512>
+template <int P, int MODE, int LOGN, int NT_>
 static int launch_fused_wide(jrc_chain* ch, int n_frames, int wpf, int pstride, const float2* d_H, float2* d_map, hipStream_t s)
 {
     const size_t lds_bytes = MODE == 3 ? ch->lds_power : ch->lds_bytes;
-    JRC_TRY(jrc_ensure_dyn_lds(ch->ctx, (const void*)range_angle_wide_kernel<16, MODE, 16, LOGN, NT_>, lds_bytes));
+    JRC_TRY(jrc_ensure_dyn_lds(ch->ctx, (const void*)range_angle_wide_kernel<P, MODE, 16, LOGN, NT_>, lds_bytes));
     const int nx = ch->ctx->n_xcd;
     const int chunk = chain_chunk(ch, wpf);
     for (int f0 = 0; f0 < n_frames; f0 += chunk) {
@@ -720,9 +721,9 @@ static int launch_fused_wide(jrc_chain* ch, int n_frames, int wpf, int pstride, 
         const dim3 grid((unsigned)(((nf + nx - 1) / nx) * nx * w));
         float2* mp = MODE == 0 ? d_map + (size_t)f0 * ch->NR * ch->NA
                    : (MODE == 3 ? reinterpret_cast<float2*>(reinterpret_cast<float*>(d_map) + (size_t)f0 * ch->NR * ch->NA) : nullptr);
-        hipLaunchKernelGGL((range_angle_wide_kernel<16, MODE, 16, LOGN, NT_>), grid, dim3(NT_), lds_bytes, s,
-                           d_H + (size_t)f0 * 16 * ch->cfg.fft_len, mp, ch->d_partials + (size_t)f0 * pstride, ch->twR, ch->twA,
-                           ch->NR, nf, w, pstride, (MODE == 1 || MODE == 3) ? ch->d_rng + (size_t)f0 * ch->NR * 16 : nullptr, nx, chain_pace(ch));
+        hipLaunchKernelGGL((range_angle_wide_kernel<P, MODE, 16, LOGN, NT_>), grid, dim3(NT_), lds_bytes, s,
+                           d_H + (size_t)f0 * P * ch->cfg.fft_len, mp, ch->d_partials + (size_t)f0 * pstride, ch->twR, ch->twA,
+                           ch->NR, nf, w, pstride, (MODE == 1 || MODE == 3) ? ch->d_rng + (size_t)f0 * ch->NR * P : nullptr, nx, chain_pace(ch));
     }
     JRC_HIP(ch->ctx, hipGetLastError());
     return JRC_OK;
@@ -777,13 +778,19 @@ static int launch_window_rows(jrc_chain* ch, int n_frames, int pstride, hipStrea
 static int launch_fused_any(jrc_chain* ch, int mode, int n_frames, int wpf, int pstride, const float2* d_H, float2* d_map, hipStream_t s)
 {
     if (ch->wide) {
-#define JRC_WIDE_CASE(LG, THREADS)                                                                              \
-        if (mode == 0) return launch_fused_wide<0, LG, THREADS>(ch, n_frames, wpf, pstride, d_H, d_map, s);      \
-        if (mode == 1) return launch_fused_wide<1, LG, THREADS>(ch, n_frames, wpf, pstride, d_H, d_map, s);      \
-        return launch_fused_wide<3, LG, THREADS>(ch, n_frames, wpf, pstride, d_H, d_map, s);
-        if (ch->cfg.fft_len == 1024) { JRC_WIDE_CASE(10, 512) }
-        if (ch->cfg.fft_len == 512) { JRC_WIDE_CASE(9, 256) }
-        JRC_WIDE_CASE(8, 256)
+#define JRC_WIDE_CASE(PP, LG, THREADS)                                                                              \
+        { if (mode == 0) return launch_fused_wide<PP, 0, LG, THREADS>(ch, n_frames, wpf, pstride, d_H, d_map, s);    \
+          if (mode == 1) return launch_fused_wide<PP, 1, LG, THREADS>(ch, n_frames, wpf, pstride, d_H, d_map, s);    \
+          return launch_fused_wide<PP, 3, LG, THREADS>(ch, n_frames, wpf, pstride, d_H, d_map, s); }
+        const int lg = jrc_ilog2(ch->cfg.fft_len);
+        if (ch->P == 16) {
+            if (lg == 10) JRC_WIDE_CASE(16, 10, 512)
+            if (lg == 9) JRC_WIDE_CASE(16, 9, 256)
+            JRC_WIDE_CASE(16, 8, 256)
+        }
+        if (lg == 10) JRC_WIDE_CASE(8, 10, 256)
+        if (lg == 9) JRC_WIDE_CASE(8, 9, 256)
+        JRC_WIDE_CASE(8, 8, 256)
 #undef JRC_WIDE_CASE
     }
     switch (ch->P) {
@@ -825,13 +832,17 @@ extern "C" int jrc_chain_create(jrc_ctx* ctx, const jrc_chain_cfg* cfg, const fl
     ch->lds_bytes = sizeof(float2) * ((size_t)P * N + (size_t)P * RA_L + (N > 256 ? (size_t)N : 0));
     ch->threads = (ch->lds_bytes > 80 * 1024) ? 512 : 256;
     if (getenv("JRC_THREADS")) { int t = atoi(getenv("JRC_THREADS")); if (t == 512 || (t == 1024 && N > 256)) ch->threads = t; else ch->threads = 256; }
-    // range_angle_wide_kernel for 16 pairs x interp_angle 16 at fft_len 256 / 512 / 1024 (JRC_NO_WIDE: the 64-bin kernel).  fft_len 1024: one
-    // 512-thread workgroup per CU (a lane's share of H is 64 VGPRs); 256 / 512: two 256-thread workgroups per CU (16 / 32 VGPRs of H, four
-    // pairs per wave).  Measured against the 64-bin kernel, 512 frames: fft_len 256 with interp_range 4 / 8 / 16 / 32:
-    // 0.75 / 0.82 / 0.82 / 0.82 of the HBM peak against 0.72 / 0.80 / 0.60 / 0.65; fft_len 512 with 4 / 8: 0.78 / 0.80 against 0.74 / 0.71.
-    ch->wide = !ch->generic && P == 16 && cfg->interp_angle == 16 && !getenv("JRC_NO_WIDE") && (N == 256 || N == 512 || N == 1024) && NR >= RW_L;
+    // range_angle_wide_kernel for 8 or 16 pairs x interp_angle 16 (the flowgraphs' 4 x 2 and the benchmark's 4 x 4) at fft_len 256 / 512 / 1024
+    // (JRC_NO_WIDE: the 64-bin kernel; fft_len 64 / 128 were measured on it as well — zero inputs beyond fft_len — and stay on the 64-bin
+    // kernel: 4 x 2 at fft_len 64 0.60-0.62 against 0.58-0.59, but 4 x 4 at fft_len 64 / 128 0.44 / 0.72 against 0.66 / 0.74).  Two 256-thread workgroups per CU while a lane's share of H
+    // stays within 64 VGPRs (pairs per wave x fold terms <= 8), else one 512-thread workgroup (16 pairs at fft_len 1024).  Measured against
+    // the 64-bin kernel, of the HBM peak: 16 pairs, fft_len 256, interp_range 4 / 8 / 16 / 32: 0.75 / 0.82 / 0.82 / 0.82
+    // against 0.72 / 0.80 / 0.60 / 0.65; fft_len 512 with 4 / 8: 0.78 / 0.80 against 0.74 / 0.71; 8 pairs, interp_range 8: fft_len 256 0.76
+    // against 0.65, fft_len 1024 0.68-0.75 against 0.56.
+    ch->wide = !ch->generic && (P == 16 || P == 8) && cfg->interp_angle == 16 && !getenv("JRC_NO_WIDE") && (N == 256 || N == 512 || N == 1024) && NR >= RW_L;
     if (ch->wide) {               // no H in LDS: two buffers of range bins
-        ch->threads = N == 1024 ? 512 : 256;
+        const int fold = N >= RW_L ? N / RW_L : 1;
+        ch->threads = (P / 4) * fold <= 8 ? 256 : 512;
         ch->lds_bytes = sizeof(float2) * 2 * (size_t)P * RW_L;
         ch->C = (int)(NR / RW_L);
     }

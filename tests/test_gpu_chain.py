@@ -98,24 +98,25 @@ def test_chain_other_shapes(jrc, ctx, T, R, N, S, Ir, Ia, interleave):
     check(jrc, ctx, sc, Ir, Ia, 2, interleave=interleave)
 
 
-@pytest.mark.parametrize("N,S,Ir,F", [(256, 4, 8, 5), (256, 2, 1, 3), (256, 4, 16, 3), (256, 3, 32, 2), (512, 4, 8, 3), (512, 3, 2, 4), (512, 2, 16, 5),
-                                      (1024, 3, 4, 2), (1024, 2, 1, 3)])
-def test_chain_wide_kernel_against_oracle_and_64_bin_kernel(jrc, ctx, N, S, Ir, F, monkeypatch):
-    """16 pairs x interp_angle 16 at fft_len 256 / 512 / 1024: range_angle_wide_kernel (classes of 256 range bins, H in registers; two
+@pytest.mark.parametrize("N,S,Ir,F,T,R", [(256, 4, 8, 5, 4, 4), (256, 2, 1, 3, 4, 4), (256, 4, 16, 3, 4, 4), (256, 3, 32, 2, 4, 4), (512, 4, 8, 3, 4, 4),
+                                          (512, 3, 2, 4, 4, 4), (512, 2, 16, 5, 4, 4), (1024, 3, 4, 2, 4, 4), (1024, 2, 1, 3, 4, 4),
+                                          (256, 4, 8, 5, 4, 2), (512, 4, 4, 3, 2, 4), (1024, 4, 8, 3, 4, 2), (1024, 2, 2, 2, 2, 4)])
+def test_chain_wide_kernel_against_oracle_and_64_bin_kernel(jrc, ctx, N, S, Ir, F, T, R, monkeypatch):
+    """8 or 16 pairs x interp_angle 16 at fft_len 256 / 512 / 1024: range_angle_wide_kernel (classes of 256 range bins, H in registers; two
     256-thread workgroups per CU below fft_len 1024) — against the oracle chain, and against the 64-bin kernel (JRC_NO_WIDE) on the same
     frames: same peak cell, maps equal to rounding"""
     import torch
     from jrc_amd import synth
-    sc = synth.Scenario(N, 4, 4, S, targets=[(12.0, -15.0, 3.0, 60.0)])
+    sc = synth.Scenario(N, T, R, S, targets=[(12.0, -15.0, 3.0, 60.0)])
     check(jrc, ctx, sc, Ir, 16, F, interleave=bool(Ir & 16))
     fr = synth.make_frames(sc, F)
-    P = 16
+    P = T * R
     rb, ab = jrc.radar_axes(N, sc.fs, Ir, P, 16)
     out = []
     for no_wide in (False, True):
         if no_wide:
             monkeypatch.setenv("JRC_NO_WIDE", "1")
-        ch = jrc.RadarChain(N, 4, 4, S, sc.Npre, Ir, 16, rb, ab, 2.4, 20.0, 15.0, 0.0, max_frames=F, ctx=ctx)
+        ch = jrc.RadarChain(N, T, R, S, sc.Npre, Ir, 16, rb, ab, 2.4, 20.0, 15.0, 0.0, max_frames=F, ctx=ctx)
         bufs = ch.alloc(F, "cuda:0")
         bufs["frames"][:F].copy_(torch.from_numpy(fr.view(np.float32).reshape((F,) + tuple(bufs["frames"].shape[1:]))))
         torch.cuda.synchronize()
