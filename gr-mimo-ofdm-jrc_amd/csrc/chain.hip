@@ -7,8 +7,8 @@
 //   -> fft_vxx forward/shift, size P*Ia         (...radar_sim.grc:963-985)
 //   -> range_angle_estimator (lib/range_angle_estimator_impl.cc:121-284)
 //
-// range_angle_fused_kernel is the roofline kernel: it reads the P x N channel estimate (L2 resident)
-// and streams the (N*Ir) x (P*Ia) complex map to HBM exactly once, doing both zero-padded FFTs and the
+// range_angle_fused_kernel / range_angle_wide_kernel (configs B and D) are the roofline kernels: they read the P x N channel estimate (L2 resident)
+// and stream the (N*Ir) x (P*Ia) complex map to HBM exactly once, doing both zero-padded FFTs and the
 // estimator's arg-max scan on chip.
 //
 //   Range axis.  R[p][k] = sum_{n<N} H[p][n] e^{+j2pi nk/NR}, NR = N*Ir, is needed only through its
@@ -305,20 +305,21 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
     if (tid == 0) { partials[(size_t)f * pstride + slice].best = trk.best; partials[(size_t)f * pstride + slice].idx = trk.idx; }
 }
 
-// ---- the fused kernel for fft_len 1024 (config D) and for long range axes: classes of 256 range bins, H in registers ---------------
-// At fft_len 1024 the kernel above keeps the 128 KiB of H in LDS: one 512-thread workgroup per CU, two barriers around the range phase
-// of every 128 KiB class with nothing to overlap them, and — NR / 64 = 128 classes — the rows a wave stores together lie 256 KiB apart,
-// which the memory system serves at 65-70 % of its peak where config B's 64 KiB get 80 %.  Here a class is
+// ---- the roofline kernel of configs B and D: classes of 256 range bins, H in registers ------------------------------------------------
+// (8 or 16 pairs x interp_angle 16 at fft_len 256 / 512 / 1024; everything else runs the 64-bin kernel above.)
+// With classes of 64 range bins the rows a wave stores together lie NR / 64 rows apart — 64 KiB at config B, 256 KiB at config D — and at
+// fft_len 1024 the 128 KiB of H in LDS leave one workgroup per CU with two barriers around the range phase of every 128 KiB class: 80 % of
+// the HBM peak at config B only with paced stores, 65-70 % at config D or with longer range axes.  Here a class is
 // k = C q + c with C = NR / 256 and q < 256:
-//     R[p][C q + c] = IFFT_256( g_c[p] )[q],   g_c[p][n'] = sum_{m < 4} H[p][n' + 256 m] e^{+j 2 pi (n' + 256 m) c / NR}
-// The fold inputs of a lane — H[p][lane + 64 j + 256 m], the same for every class — live in registers (2 pairs per wave: 64 VGPRs), so H
-// needs no LDS at all; the 256-point transform is one radix-4 step across a lane's four points (q = 4 a + b: twiddle e^{+j 2 pi lane b /
-// 256}) and four 64-point transforms across the wavefront (a = bitrev6(lane)).  The range bins of a class (32 KiB for 16 pairs) are
-// double-buffered, so ONE barrier per 512 KiB class separates the waves that fill a buffer from those that read it, the waves drift
-// apart and the range phase of some overlaps the stores of others; rows stored together are NR / 256 = 32 rows = 64 KiB apart.
-// Same angle axis, arg-max, pacing and MODEs as above; rng[frame][class][pair][(q & 3) * 64 + (q >> 2)] for the window pass.
-// fft_len 256 / 512 (one / two fold terms) take this kernel too when the range axis is long (NR >= 4096): the 64-bin classes would put
-// their rows 128 KiB and more apart (config-B shape with interp_range 16 / 32: 57-65 % of the peak).
+//     R[p][C q + c] = IFFT_256( g_c[p] )[q],   g_c[p][n'] = sum_{m < fft_len/256} H[p][n' + 256 m] e^{+j 2 pi (n' + 256 m) c / NR}
+// The fold inputs of a lane — H[p][lane + 64 j + 256 m], the same for every class — live in registers, so H needs no LDS at all; the
+// 256-point transform is one radix-4 step across a lane's four points (q = 4 a + b: twiddle e^{+j 2 pi lane b / 256}) and four 64-point
+// transforms across the wavefront (a = bitrev6(lane)).  The range bins of a class (32 KiB for 16 pairs) are double-buffered, so ONE barrier
+// per 512 KiB class separates the waves that fill a buffer from those that read it, the waves drift apart and the range phase of some
+// overlaps the stores of others; rows stored together are NR / 256 rows apart (16 KiB at config B, 64 KiB at config D).
+// Geometry: a wave takes P / (NT / 64) pairs.  fft_len 256 / 512: 256 threads, four (two) pairs per wave, 16-32 VGPRs of H, two workgroups
+// per CU, stores paced (chain_pace); 16 pairs at fft_len 1024: 512 threads, two pairs per wave, 64 VGPRs of H, one workgroup per CU.
+// Same angle axis, arg-max and MODEs as above; rng[frame][class][pair][(q & 3) * 64 + (q >> 2)] for the window pass.
 #define RW_L 256
 template <int P, int MODE, int IA, int LOGN, int NT_ = 512>
 __global__ __launch_bounds__(NT_, 2) void range_angle_wide_kernel(
