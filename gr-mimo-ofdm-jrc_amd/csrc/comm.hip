@@ -22,21 +22,15 @@ __device__ __forceinline__ float2 c_mul(float2 a, float2 b)
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 __device__ __forceinline__ float2 c_conj(float2 a) { return make_float2(a.x, -a.y); }
-__device__ __forceinline__ float2 c_div(float2 n, float2 dn)   // libgcc __divsc3 (Smith), finite inputs
+// std::complex<float> operator/ = __divsc3.  A g++ build of the reference links it from libgcc_s.so.1 (ahead of the static libgcc), and that
+// library (GCC >= 12; the image's is 12.3) forms the float quotient in double and rounds once — not Smith's method in float, which is what
+// gcc <= 11 and its static libgcc.a have.  tests/test_second_source.py pins the formula against the box's libgcc_s bit for bit.
+__host__ __device__ __forceinline__ float2 c_div(float2 n, float2 dn)
 {
 #pragma clang fp contract(off)
-    const float a = n.x, b = n.y, c = dn.x, d = dn.y;
-    float x, y;
-    if (fabsf(c) < fabsf(d)) {
-        const float ratio = c / d, denom = (c * ratio) + d;
-        x = ((a * ratio) + b) / denom;
-        y = ((b * ratio) - a) / denom;
-    } else {
-        const float ratio = d / c, denom = (d * ratio) + c;
-        x = ((b * ratio) + a) / denom;
-        y = (b - (a * ratio)) / denom;
-    }
-    return make_float2(x, y);
+    const double a = n.x, b = n.y, c = dn.x, d = dn.y;
+    const double denom = (c * c) + (d * d);
+    return make_float2((float)(((a * c) + (b * d)) / denom), (float)(((b * c) - (a * d)) / denom));
 }
 __device__ __forceinline__ float2 c_expj(double x)   // std::exp(gr_complex(0, x)): the double is narrowed first
 {
@@ -158,106 +152,70 @@ __device__ __forceinline__ float2 demod_point(int bps, float2 z)
     return make_float2((z.x > 0 ? a : -a) / 2.0f, (z.y > 0 ? a : -a) / 2.0f);
 }
 
-// ---- SIG-field Viterbi on one wavefront, in place ---------------------------------------------------------------------------
-// K = 7 (0155, 0117), hard decisions, 64 states = 64 lanes.  The two predecessors of states 2j and 2j+1 are states j and j+32, so when
-// the pair (j, j+32) sits in two lanes, the pair (2j, 2j+1) can take their place: after step i lane L holds state rol6(L, (i+1) % 6), the
-// lanes of a pair differ in bit 5 - i % 6, and the exchange is lane_pair (fft_device.h: a permlane swap or one DPP move per side) instead
-// of two ds_bpermute round trips through the LDS crossbar.  Metrics, comparisons (m1 < m0: the upper predecessor wins only when
-// strictly better) and the survivor bits are those of the lane-per-state form; only where a bit is kept differs, and the traceback walks
-// lanes instead of states.
-struct VitLane { int eb[6]; };          // expected coded pair (bit 0: 0155, bit 1: 0117; predecessor bit 0) of the state the lane holds after a step of phase t
-
-template <int T> __device__ __forceinline__ void vit_step(int& metric, const VitLane& c, unsigned rx, unsigned& hist)
-{
-    int lo, hi;
-    lane_pair<5 - T>(metric, lo, hi);
-    const int x = c.eb[T] ^ (int)rx;                                  // bits that differ from the received pair when the predecessor bit is 0;
-    const int m0 = __builtin_popcount(x) + lo;                        // with predecessor bit 1 both coded bits flip (both polynomials tap it)
-    const int m1 = __builtin_popcount(x ^ 3) + hi;
-    const bool pick = m1 < m0;
-    metric = pick ? m1 : m0;
-    hist = hist + hist + (pick ? 1u : 0u);                            // the lane's own survivor bits, newest lowest: one add-with-carry
-}
-
-__host__ __device__ inline int eq_surv_words(int ND) { return ((ND / 2 + 59) / 60) * 64; }
+// ---- SIG-field Viterbi on one wavefront ------------------------------------------------------------------------------------
+// decode_signal_field (lib/mimo_ofdm_equalizer_impl.cc:650-667) hands the hard BPSK decisions of the ND data cells to the reference's
+// windowed SSE2 decoder (lib/viterbi_decoder.cc:99-331; ofdm_mcs(BPSK_1_2, ND) -> d_ntraceback 5, no depuncturing).  Its byte lanes map
+// one to one onto the wavefront, lane = new trellis state, as in stream_decode_kernel (codec.hip): 8-bit metrics with wrap-around adds,
+// the signed-byte compare of the difference (:118-120), 8-bit path chunks, viterbi_get_output_sse2 (:183-225) after steps 6, 14, 22, ...
+// with the first maximum as best state and a traceback over 4 stored chunks.  Output byte j leaves at call 5 + j, so the 24 header
+// bits need calls 0..7 = 62 trellis steps = coded bits 0..123: the decoder runs past the ND coded bits of a 48-carrier SIG symbol, where
+// the reference reads whatever lies behind calloc(ND) (:175) — 0 here, as in the oracle.  Bit errors therefore resolve exactly as in the
+// reference's decoder (ties, window truncation), not as a maximum-likelihood decoder would.
+__host__ __device__ inline int eq_surv_words(int ND) { return ((ND / 2 + 59) / 60) * 64; }     // LDS scratch: >= 512 bytes, the ring takes 320
 __host__ __device__ inline int eq_pair_bytes(int ND) { return ((ND / 2 + 5) / 6 + 1) * 8; }
-#define VIT_WORD 30     // trellis steps per survivor word: five rounds of the six exchange patterns; step i of a lane is bit 29 - i % 30 of its word i / 30
 
-// five rounds (or what is left of them before step i1) into one survivor word
-__device__ __forceinline__ unsigned vit_word(int& metric, const VitLane& c, const unsigned long long* rw, int i, int i1)
-{
-    unsigned hist = 0;
-    const int n = min(VIT_WORD, i1 - i);
-    if (n <= 0) return 0;
-    unsigned long long wn = rw[i / 6];
-    int k = 0;
-    for (; k + 6 <= n; k += 6) {
-        const unsigned long long w = wn;
-        wn = rw[(i + k) / 6 + 1];                                     // the next round's pairs are on their way while this round runs (the scratch has a spare word)
-        const unsigned wl = __builtin_amdgcn_readfirstlane((unsigned)w), wh = __builtin_amdgcn_readfirstlane((unsigned)(w >> 32));
-        vit_step<0>(metric, c, wl & 3u, hist);
-        vit_step<1>(metric, c, (wl >> 8) & 3u, hist);
-        vit_step<2>(metric, c, (wl >> 16) & 3u, hist);
-        vit_step<3>(metric, c, (wl >> 24) & 3u, hist);
-        vit_step<4>(metric, c, wh & 3u, hist);
-        vit_step<5>(metric, c, (wh >> 8) & 3u, hist);
-    }
-    if (k < n) {                                                      // the last, partial round of the field
-        const unsigned wl = __builtin_amdgcn_readfirstlane((unsigned)wn), wh = __builtin_amdgcn_readfirstlane((unsigned)(wn >> 32));
-        const int r = n - k;
-        vit_step<0>(metric, c, wl & 3u, hist);
-        if (r > 1) vit_step<1>(metric, c, (wl >> 8) & 3u, hist);
-        if (r > 2) vit_step<2>(metric, c, (wl >> 16) & 3u, hist);
-        if (r > 3) vit_step<3>(metric, c, (wl >> 24) & 3u, hist);
-        if (r > 4) vit_step<4>(metric, c, wh & 3u, hist);
-    }
-    return hist << (VIT_WORD - n);
-}
+__device__ __forceinline__ int sig_wave_max(int v) { for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off)); return v; }
+__device__ __forceinline__ int sig_wave_min(int v) { for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off)); return v; }
 
-// wave 0 only (tid < 64).  Z: the nd*2 equalised SIG cells; rxp: scratch, 8 bytes per 6 steps; surv: 64 double words per 60 steps.  Returns decoded bits 0..31.
-__device__ __forceinline__ unsigned sig_viterbi_wave(const float2* Z, int nd, unsigned long long* surv, unsigned char* rxp, int tid)
+// wave 0 only (lane = tid < 64).  Z: the ND equalised SIG cells; ring: 5 x 64 bytes of scratch.  Returns decoded bits 0..23 (bit i of the word = header bit i).
+__device__ __forceinline__ unsigned sig_viterbi_wave(const float2* Z, int ND, unsigned char* ring, int lane)
 {
-    for (int k = tid; k < nd; k += 64)                                // received hard-decision pairs, six steps to an 8-byte word
-        rxp[(k / 6) * 8 + k % 6] = (unsigned char)((Z[2 * k].x > 0 ? 1 : 0) | (Z[2 * k + 1].x > 0 ? 2 : 0));
-    VitLane c;
+    const unsigned long long w0 = __ballot(lane < ND && Z[min(lane, ND - 1)].x > 0);                 // constellation_bpsk::decision_maker: re > 0
+    const unsigned long long w1 = __ballot(lane + 64 < ND && Z[min(lane + 64, ND - 1)].x > 0);
+    for (int i = lane; i < 5 * 64; i += 64) ring[i] = 0;                                            // d_ppresult zeroed (:333-337)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int k = lane >> 1, odd = lane & 1;
+    const int bt0 = __popc((2 * k) & 0x6d) & 1, bt1 = __popc((2 * k) & 0x4f) & 1;                    // d_branchtab27_sse2 (:323-326)
+    const int nt = 5;
+    unsigned st = 0, sig = 0;                                                                        // metric | path << 8
+    int store_pos = 0, out_count = 0;
+    for (int t = 0; t < 62; t++) {
+        const unsigned long long w = t < 32 ? w0 : w1;
+        const int sh = (2 * t) & 63;
+        const int s0 = (int)((w >> sh) & 1ull), s1 = (int)((w >> (sh + 1)) & 1ull);
+        const int metsvm = (bt0 ^ s0) + (bt1 ^ s1), metsv = 2 - metsvm;                             // :110-112
+        const unsigned a = __shfl(st, k), b = __shfl(st, k + 32);
+        const int ma = a & 0xff, mb = b & 0xff;
+        const int x = (ma + (odd ? metsvm : metsv)) & 0xff, y = (mb + (odd ? metsv : metsvm)) & 0xff;
+        const int dec = (signed char)((x - y) & 0xff) > 0;                                           // _mm_cmpgt_epi8(_mm_sub_epi8(m0, m1), 0)
+        const unsigned pa = ((a >> 8) << 1) & 0xff, pb = ((((b >> 8) << 1) & 0xff) + 1) & 0xff;
+        st = (unsigned)(dec ? x : y) | ((dec ? pa : pb) << 8);
+        if (t >= 5 && ((t - 5) & 7) == 0) {                                                          // viterbi_get_output_sse2
+            store_pos = (store_pos + 1 == nt) ? 0 : store_pos + 1;
+            const int metric = st & 0xff;
+            ring[store_pos * 64 + lane] = (unsigned char)(st >> 8);
+            const int best = sig_wave_max(metric), mn = sig_wave_min(metric);
+            int beststate = __ffsll((unsigned long long)__ballot(metric == best)) - 1;               // first maximum (strict > in the scan)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            int pos = store_pos;
+            for (int i = 0; i < nt - 1; i++) {
+                beststate = ring[pos * 64 + beststate] >> 2;
+                pos = (pos == 0) ? nt - 1 : pos - 1;
+            }
+            const unsigned c = ring[pos * 64 + beststate];
+            st = (unsigned)((metric - mn) & 0xff);                                                   // paths zeroed, metrics renormalised
+            if (out_count >= nt) {                                                                   // decoded bits, MSB first (:277-281)
+                const int j = out_count - nt;
 #pragma unroll
-    for (int t = 0; t < 6; t++) {
-        const int r = (t + 1) % 6, st = ((tid << r) | (tid >> (6 - r))) & 63;
-        c.eb[t] = (popc8(st & 0155) & 1) | ((popc8(st & 0117) & 1) << 1);
-    }
-    int metric = tid ? (1 << 28) : 0;
-    const unsigned long long* rw = reinterpret_cast<const unsigned long long*>(rxp);
-    const int n_blk = (nd + 2 * VIT_WORD - 1) / (2 * VIT_WORD);
-    for (int blk = 0; blk < n_blk; blk++) {
-        const unsigned a = vit_word(metric, c, rw, blk * 2 * VIT_WORD, nd);
-        const unsigned b = vit_word(metric, c, rw, blk * 2 * VIT_WORD + VIT_WORD, nd);
-        surv[blk * 64 + tid] = ((unsigned long long)b << 32) | (unsigned long long)a;
-    }
-    // lowest state among the minima (the lane-per-state form's choice); the lane that holds it starts the traceback
-    const int rn = nd % 6;
-    int best = metric, bs = ((tid << rn) | (tid >> (6 - rn))) & 63, bl = tid;
-    for (int off = 32; off > 0; off >>= 1) {
-        const int om = __shfl_xor(best, off), os = __shfl_xor(bs, off), ol = __shfl_xor(bl, off);
-        if (om < best || (om == best && os < bs)) { best = om; bs = os; bl = ol; }
-    }
-    // traceback on the scalar unit: the survivor bit of the lane says which lane of its pair the path came from, and the bit of the lane
-    // index the pair differs in is the decoded bit
-    unsigned sig_word = 0;
-    int L = __builtin_amdgcn_readfirstlane(bl);
-    for (int wd = (nd - 1) / VIT_WORD; wd >= 0; wd--) {
-        const unsigned long long both = surv[(wd >> 1) * 64 + tid];
-        const int mine = (int)(unsigned)((wd & 1) ? (both >> 32) : (both & 0xffffffffull));
-        const int i0 = wd * VIT_WORD, i1 = min(nd, i0 + VIT_WORD);
-        int B = 5 - (i1 - 1) % 6;
-        for (int i = i1 - 1; i >= i0; i--) {
-            const unsigned w = (unsigned)__builtin_amdgcn_readlane(mine, L);
-            const int h = (int)((w >> (VIT_WORD - 1 - (i - i0))) & 1u);
-            if (i < 32) sig_word |= (unsigned)((L >> B) & 1) << i;
-            L = (L & ~(1 << B)) | (h << B);
-            B = B == 5 ? 0 : B + 1;
+                for (int bb = 0; bb < 8; bb++) sig |= ((c >> (7 - bb)) & 1u) << (8 * j + bb);
+            }
+            out_count++;
+            __builtin_amdgcn_wave_barrier();
         }
     }
-    return sig_word;
+    return sig;
 }
 
 #define EQ_BATCH 64   // data symbols per three-phase pass of the equalizer
@@ -561,8 +519,8 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
                 Z[i] = c_div(Y[dc[i]], H[dc[i]]);                           // symbol_equalize :900-906 (BPSK decision: sig_viterbi_wave)
             }
             __syncthreads();
-            if (tid < 64) {   // K=7 (0155,0117) hard-decision Viterbi over the nd = ND / 2 coded pairs: one wavefront, in place (above)
-                const unsigned sig_word = sig_viterbi_wave(Z, ND / 2, surv, bits, tid);
+            if (tid < 64) {   // the reference's windowed K=7 decoder over the ND hard decisions: one wavefront (above)
+                const unsigned sig_word = sig_viterbi_wave(Z, ND, reinterpret_cast<unsigned char*>(surv), tid);
                 if (tid == 0) {
                     // parse :669-781
                     const int rate = (int)(sig_word & 0xfu), pt = (int)((sig_word >> 4) & 1u), len = (int)((sig_word >> 5) & 0xfffu);
@@ -1057,8 +1015,7 @@ static void dft_matrix_host(int T, float2* F)   // get_dft_matrix_eigen :761-772
     for (int r = 0; r < T; r++)
         for (int c = 0; c < T; c++) {
             const float ang = (float)(-2 * M_PI * float(r * c) / float(T));
-            const float s = (float)std::sqrt((double)T);
-            F[(size_t)c * T + r] = make_float2(cosf(ang) / s, sinf(ang) / s);
+            F[(size_t)c * T + r] = c_div(make_float2(cosf(ang), sinf(ang)), make_float2((float)std::sqrt((double)T), 0.f));   // std::exp(.) / (gr_complex) std::sqrt(N)
         }
 }
 

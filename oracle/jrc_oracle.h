@@ -93,6 +93,7 @@ int  orc_mcs_params(int mcs, int n_data_carriers, int* n_bpsc, int* n_cbps, int*
 int  orc_n_ofdm_sym(int mcs, int n_data_carriers, int data_size_byte);
 int  orc_sig_encode(int n_data_carriers, int mcs, int packet_type, int length, float* out_re);
 void orc_viterbi_k7(const uint8_t* coded, int n_decoded, uint8_t* decoded);
+void orc_cdiv(const float* a, const float* b, float* q);   /* std::complex<float> operator/ as a g++ build on this image evaluates it (libgcc_s 12: double, rounded once) */
 int  orc_sig_parse(const uint8_t* bits, int n_data_carriers, int* mcs, int* packet_type, int* length, int* n_ofdm_sym);
 
 /* ---- C1: mimo_ofdm_equalizer_impl::general_work (lib/mimo_ofdm_equalizer_impl.cc:191-648) ---- */

@@ -5,8 +5,9 @@
  * here.  Third-party pieces restated from their published behaviour:
  *   - gr::digital::constellation_bpsk / _qpsk (GNU Radio 3.8.5): points and decision rules
  *   - Eigen3 JacobiSVD of a 1 x T row (unversioned find_package(Eigen3)): Householder construction, C3 below
- *   - the windowed SSE2 Viterbi (lib/viterbi_decoder.cc) is restated as a full-traceback hard-decision
- *     decoder: identical on error-free SIG fields; tie-breaks under bit errors are not reproduced.
+ *   - the SIG field goes through the windowed SSE2 Viterbi of lib/viterbi_decoder.cc as restated lane by lane in
+ *     jrc_oracle_codec.c (orc_viterbi_windowed), symbols read beyond the coded bits = 0; orc_viterbi_k7 (full traceback,
+ *     maximum likelihood) stays as a cross-check for the tests.
  */
 #include "jrc_oracle.h"
 
@@ -195,6 +196,20 @@ void orc_eq_set_estimator(orc_eq_state* s, int algo) { s->c.estimator = algo; }
 
 static cf cexp_f(double x) { float xf = (float)x; return cosf(xf) + I * sinf(xf); }   /* std::exp(gr_complex(0, x)) */
 
+/* std::complex<float> operator/ is libgcc's __divsc3.  A g++ build of the reference takes it from libgcc_s.so.1 (g++ links -lgcc_s
+ * ahead of -lgcc; this image: libgcc-s1 12.3), whose float version evaluates the textbook quotient in double and rounds once
+ * (libgcc2.c since GCC 12: "float is handled with double precision").  gcc links C programs against the static libgcc.a of the
+ * compiler (11.4 here), which still has Smith's method in float: `a / b` in this file would differ from the reference in the last
+ * bits.  Written out so the oracle does not depend on the linker's choice; tests/test_second_source.py pins it, bit for bit,
+ * against the __divsc3 exported by the box's libgcc_s.so.1. */
+static cf c_div(cf x, cf y)
+{
+    const double aa = crealf(x), bb = cimagf(x), cc = crealf(y), dd = cimagf(y);
+    const double denom = (cc * cc) + (dd * dd);
+    return CMPLXF((float)(((aa * cc) + (bb * dd)) / denom), (float)(((bb * cc) - (aa * dd)) / denom));
+}
+void orc_cdiv(const float* a, const float* b, float* q) { cf r = c_div(CMPLXF(a[0], a[1]), CMPLXF(b[0], b[1])); q[0] = crealf(r); q[1] = cimagf(r); }
+
 /* gr::digital constellation decisions (GNU Radio 3.8.5) */
 static cf demod_point(int bps, cf z)
 {
@@ -262,7 +277,7 @@ int orc_eq_work(orc_eq_state* s, int noutput_items, int ninput_items, const floa
                 noise += pow((double)cabsf(s->H[c] - Y[c]), 2.0);
                 signal += pow((double)cabsf(s->H[c] + Y[c]), 2.0);
                 s->H[c] += Y[c];
-                s->H[c] /= s->ltf[c] * (cf)(2.0f);
+                s->H[c] = c_div(s->H[c], s->ltf[c] * (cf)(2.0f));
             }
             /* the CPE computed and applied to Y here (:288-303) is discarded with Y */
             s->snr_est = 10 * log10(signal / noise / 2);
@@ -270,10 +285,15 @@ int orc_eq_work(orc_eq_state* s, int noutput_items, int ninput_items, const floa
             double cfo = residual_cfo(s, Y, s->H, s->pilot_sym, est);
             cf rot = cexp_f(-cfo);
             for (int i = 0; i < N; i++) Y[i] *= rot;
-            for (int i = 0; i < ND; i++) Z[i] = Y[s->data_c[i]] / s->H[s->data_c[i]];        /* symbol_equalize */
-            uint8_t* bits = (uint8_t*)malloc(ND); uint8_t* dec = (uint8_t*)calloc(ND, 1);
+            for (int i = 0; i < ND; i++) Z[i] = c_div(Y[s->data_c[i]], s->H[s->data_c[i]]);   /* symbol_equalize */
+            /* decode_signal_field (:650-667): BPSK decisions -> d_decoder.decode(ofdm_mcs(BPSK_1_2, ND), packet_param(., 0, NDP), rx_bits):
+             * the windowed decoder of lib/viterbi_decoder.cc (oracle/jrc_oracle_codec.c), which runs until n_ofdm_sym * ND/2 bits are out
+             * and so reads 5 traceback chunks past the ND coded bits; rx_bits is calloc(ND) (:175), what lies behind it is undefined
+             * in the reference and 0 here */
+            const int sig_dbps = ND / 2, sig_nsym = (int)ceil(22 / (double)sig_dbps);
+            uint8_t* bits = (uint8_t*)calloc((size_t)sig_nsym * ND + 8, 1); uint8_t* dec = (uint8_t*)calloc((size_t)sig_nsym * sig_dbps + 64, 1);
             for (int i = 0; i < ND; i++) bits[i] = crealf(Z[i]) > 0;
-            orc_viterbi_k7(bits, ND / 2, dec);
+            orc_viterbi_windowed(0, sig_nsym, ND, sig_nsym * sig_dbps, bits, dec);
             s->sig_ok = orc_sig_parse(dec, ND, &s->mcs, &s->packet_type, &s->data_length, &s->n_ofdm_symbols_SIG);
             free(bits); free(dec);
             if (s->sig_ok && nev < max_events) {
@@ -333,18 +353,18 @@ int orc_eq_work(orc_eq_state* s, int noutput_items, int ninput_items, const floa
             }
             int bps = (s->mcs <= 1) ? 1 : (s->mcs <= 3 ? 2 : 4);
             if (s->packet_type == 1) {
-                for (int i = 0; i < ND; i++) Z[i] = Y[s->data_c[i]] / s->H[s->data_c[i]];
+                for (int i = 0; i < ND; i++) Z[i] = c_div(Y[s->data_c[i]], s->H[s->data_c[i]]);
                 if (s->c.estimator == 1) {                                                   /* STA :498-535 */
                     const float alpha = 0.5f;
                     for (int i = 0; i < ND; i++) {
                         int sc = s->data_c[i];
                         cf X = demod_point(bps, Z[i]);
-                        cf upd = Y[sc] / X;
+                        cf upd = c_div(Y[sc], X);
                         s->H[sc] = (cf)(1 - alpha) * s->H[sc] + (cf)(alpha) * upd;
                     }
                     for (int k = 0; k < NP; k++) {
                         int sc = s->pilot_c[k];
-                        s->H[sc] = (cf)(1 - alpha) * s->H[sc] + (cf)(alpha) * Y[sc] / ref[k];
+                        s->H[sc] = (cf)(1 - alpha) * s->H[sc] + c_div((cf)(alpha) * Y[sc], ref[k]);
                     }
                 }
             } else if (s->packet_type == 2) {
@@ -358,11 +378,11 @@ int orc_eq_work(orc_eq_state* s, int noutput_items, int ninput_items, const floa
                     for (int i = 0; i < ND; i++) {
                         int sc = s->data_c[i];
                         cf X = demod_point(bps, Z[i]);
-                        s->H_mimo[sc] = (cf)(1 - alpha) * s->H_mimo[sc] + (cf)(alpha) * Y[sc] / X;
+                        s->H_mimo[sc] = (cf)(1 - alpha) * s->H_mimo[sc] + c_div((cf)(alpha) * Y[sc], X);
                     }
                     for (int k = 0; k < NP; k++) {
                         int sc = s->pilot_c[k];
-                        s->H_mimo[sc] = (cf)(1 - alpha) * s->H_mimo[sc] + (cf)(alpha) * Y[sc] / ref[k];
+                        s->H_mimo[sc] = (cf)(1 - alpha) * s->H_mimo[sc] + c_div((cf)(alpha) * Y[sc], ref[k]);
                     }
                 }
             }
@@ -423,8 +443,8 @@ void orc_steering_from_channel(int T, const float* h_f, int phased, float* Q_f)
     } else {
         beta = sqrtf(crealf(c0 * conjf(c0)) + tail);
         if (crealf(c0) >= 0) beta = -beta;
-        for (int t = 1; t < T; t++) v[t] = x[t] / (c0 - beta);
-        tau = conjf((beta - c0) / beta);
+        for (int t = 1; t < T; t++) v[t] = c_div(x[t], c0 - beta);
+        tau = conjf((beta - c0) / beta);   /* complex / real */
     }
     /* V = H^H = I - conj(tau) v v^H */
     for (int col = 0; col < T; col++)
@@ -446,7 +466,7 @@ void orc_dft_matrix(int T, float* F_f)
     for (int r = 0; r < T; r++)
         for (int c = 0; c < T; c++) {
             float ang = (float)(-2 * M_PI * (float)(r * c) / (float)T);
-            F[(size_t)c * T + r] = (cosf(ang) + I * sinf(ang)) / (cf)sqrt((double)T);
+            F[(size_t)c * T + r] = c_div(cosf(ang) + I * sinf(ang), (cf)sqrt((double)T));
         }
 }
 

@@ -1,4 +1,4 @@
-"""Mints tests/golden/path_fixtures_v1.npz: seeded inputs and the outputs the CPU oracle produces for them, one small case per
+"""Mints tests/golden/path_fixtures_v2.npz: seeded inputs and the outputs the CPU oracle produces for them, one small case per
 row of SURVEY.md §8(c)'s fixture list (the reference ships no vectors of its own).  These are regression fixtures of the
 restatement — they pin the oracle against silent change and give the GPU tier committed data to compare with; they are
 not reference outputs (the reference cannot be built here, see oracle/jrc_oracle.h).
@@ -132,7 +132,7 @@ def main():
     fx["fd_in"], fx["fd_in_abs"], fx["fd_in_cor"], fx["fd_out"] = xs, ia, ic, dout
     fx["fd_tags"] = np.array([[t[0], t[1]] for t in dtags], np.float64)
 
-    path = os.path.join(HERE, "path_fixtures_v1.npz")
+    path = os.path.join(HERE, "path_fixtures_v2.npz")
     np.savez_compressed(path, **fx)
     print("wrote %s: %d arrays, %.0f KiB" % (path, len(fx), os.path.getsize(path) / 1024))
 

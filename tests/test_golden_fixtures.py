@@ -1,4 +1,4 @@
-"""The committed fixture set tests/golden/path_fixtures_v1.npz (minted by tests/golden/make_path_fixtures.py from the CPU oracle, one
+"""The committed fixture set tests/golden/path_fixtures_v2.npz (minted by tests/golden/make_path_fixtures.py from the CPU oracle, one
 small case per row of SURVEY.md §8(c)'s list): the oracle must keep reproducing it (CPU tier), and the HIP path must match it
 through the C ABI (GPU tier) — bit-exact for integer / index work and the A1 accumulation, 1e-4 for floating point."""
 import os
@@ -19,7 +19,7 @@ gpu = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def fx():
-    return np.load(os.path.join(GOLDEN, "path_fixtures_v1.npz"))
+    return np.load(os.path.join(GOLDEN, "path_fixtures_v2.npz"))
 
 
 RA_INT = ("peak_range_idx", "peak_angle_idx", "angle_null_idx", "n_noise_samples", "published")

@@ -56,53 +56,6 @@ def test_steering_matrices(jrc, ctx, T):
         assert np.allclose(Q[i].conj().T @ Q[i], np.eye(T), atol=5e-6)
 
 
-@pytest.mark.parametrize("N,est,ptype", [(256, LS, DATA), (256, LS, NDP), (256, STA, DATA), (128, LS, DATA), (512, LS, DATA)])
-def test_equalizer_batched_launch_with_a_workgroup_per_cu_or_more(jrc, ctx, N, est, ptype):
-    """a batch of at least one stream per CU runs the equalizer in its narrow geometry (a quarter of the lanes, several subcarriers per
-    lane — `launch_equalizer` in comm.hip): every stream against the oracle's general_work on the same frame"""
-    import torch
-    cp, T, S = N // 4, 4, 12
-    rng = np.random.default_rng(21)
-    data, pilots, pil, ltf, mapped, sync = config_c_tables(N, T)
-    nd = len(data)
-    mcs = 2
-    nbytes = (S * nd - 22) // 8
-    assert oracle.n_ofdm_sym(mcs, nd, nbytes) == S
-    op = oracle.Precoder(N, T, 1, data, pilots, pil, sync, mapped)
-    n_distinct, n_streams = 6, 320
-    frames, refs, phases = [], [], []
-    for i in range(n_distinct):
-        tx = op.work(qpsk(rng, S * nd), mcs, ptype, nbytes)
-        y = np.tensordot(crandn(rng, T), tx, axes=(0, 0))
-        y = np.concatenate([y[3:4], y[3:]], axis=0)
-        y = (y + 2e-3 * (rng.standard_normal(y.shape) + 1j * rng.standard_normal(y.shape))).astype(np.complex64)
-        ph = 0.002 * i
-        oe = oracle.Equalizer(est, 24e9, 125e6, N, cp, data, pilots, pil, ltf, mapped, T)
-        refs.append(oe.general_work(y, [(0, ph)]))
-        frames.append(y)
-        phases.append(ph)
-    n_sym = frames[0].shape[0]
-    x = np.stack([frames[i % n_distinct] for i in range(n_streams)])
-    ge = jrc.mimo_ofdm_equalizer(est, 24e9, 125e6, N, cp, data, pilots, pil, ltf, mapped, T, n_streams=n_streams, ctx=ctx)
-    d_in = torch.from_numpy(x.view(np.float32).reshape(n_streams, n_sym, N, 2)).to("cuda:0")
-    d_ph = torch.tensor([phases[i % n_distinct] for i in range(n_streams)], dtype=torch.float64, device="cuda:0")
-    torch.cuda.synchronize()
-    out, n_out, ev = ge.frames_dev(d_in, d_ph, n_sym, S)
-    ctx.sync()
-    out = out.cpu().numpy().view(np.complex64)[..., 0]
-    assert n_out.cpu().tolist() == [S] * n_streams
-    evb = ev.cpu().numpy()
-    for i in range(n_streams):
-        r = refs[i % n_distinct]
-        assert r["out"].shape == (S, nd)
-        assert rel_err(out[i], r["out"]) < 1e-4
-        e0 = jrc.EqEvent.from_buffer_copy(evb[i, 0].tobytes())
-        e1 = jrc.EqEvent.from_buffer_copy(evb[i, 1].tobytes())
-        assert (e0.kind, e1.kind) == (1, 2)
-        assert (e0.data_bytes, e0.mcs, e0.packet_type) == tuple(r["events"][0][k] for k in ("data_bytes", "mcs", "packet_type"))
-        assert close(e1.snr_data, r["events"][1]["snr_data"])
-
-
 @pytest.mark.parametrize("ptype,steer", [(NDP, "dft"), (DATA, "dft"), (DATA, "mean"), (DATA, "sc"), (DATA, "radar")])
 def test_precoder_work(jrc, ctx, ofdm64, ptype, steer):
     rng = np.random.default_rng(7)
@@ -385,3 +338,23 @@ def test_precoder_batched_device_resident(jrc, ctx, ptype, steer):
     assert np.array_equal(got2[1], gp.work(s2[1], mcs, ptype, nb2, **kw))
     with pytest.raises(RuntimeError, match="MIMO PRECODER"):
         gp.frames_dev(up(s2), mcs, ptype, nbytes, **dkw)
+
+
+@pytest.mark.parametrize("n_err", [1, 2, 3, 5, 8])
+def test_sig_field_with_bit_errors_resolves_as_the_windowed_decoder_does(jrc, ctx, ofdm64, n_err):
+    """SIG symbols with flipped BPSK decisions through sig_viterbi_wave (the reference's windowed decoder on one
+    wavefront, comm.hip) and through the oracle (lane-by-lane restatement of lib/viterbi_decoder.cc, itself equal to the second source,
+    tests/test_second_source.py): same header fields, same success / failure, same number of output symbols - for error counts the
+    code corrects and for counts it cannot, where a maximum-likelihood decoder would answer differently"""
+    from test_second_source import sig_frame
+    rng = np.random.default_rng(50 + n_err)
+    for trial in range(12):
+        mcs, ptype, length = int(rng.integers(0, 6)), int(rng.integers(1, 3)), int(rng.integers(1, 300))
+        flips = rng.choice(48, n_err, replace=False)
+        y = sig_frame(ofdm64, mcs, ptype, length, flips, rng)
+        _, ge, _, oe = blocks(jrc, ctx, ofdm64)
+        rg, ro = ge.general_work(y, [(0, 0.0)]), oe.general_work(y, [(0, 0.0)])
+        assert rg["consumed"] == ro["consumed"] and rg["out"].shape == ro["out"].shape
+        same_events(rg["events"], ro["events"])
+        if ro["out"].size:
+            assert rel_err(rg["out"], ro["out"]) < TOL

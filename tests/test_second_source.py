@@ -1,0 +1,236 @@
+"""CPU tier: the C oracle (oracle/*.c) against an independent second reading of the reference (tests/second_source.py: numpy
+float32 / pure Python, written from /root/reference/lib/*.cc) and against the third-party code the reference would link on this
+image (libgcc_s __divsc3 / __mulsc3).  The reference itself cannot be built here (parity unpinned); what this
+tier adds is that the oracle and the second source agree BIT FOR BIT on the equalizer's symbol loop (sampling-offset
+derotation, L-LTF and MIMO-LTF LS, residual CFO, pilot SNR sums, DATA / NDP equalisation, STA updates), on the precoder's output
+assembly and on SIG decoding through the reference's windowed Viterbi decoder with bit errors."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle
+import second_source as ss
+from conftest import crandn
+from test_oracle_comm import qpsk, qam16, through_channel
+
+NDP, DATA, LS, STA = 1, 2, 0, 1
+
+
+class _CF(ctypes.Structure):
+    _fields_ = [("re", ctypes.c_float), ("im", ctypes.c_float)]
+
+
+def _libgcc_s():
+    lg = ctypes.CDLL("libgcc_s.so.1")
+    for fn in (lg.__divsc3, lg.__mulsc3):
+        fn.restype = _CF
+        fn.argtypes = [ctypes.c_float] * 4
+    return lg
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.complex64).view(np.uint32)
+
+
+def test_complex_division_and_product_are_the_ones_of_the_boxs_libgcc_s():
+    """std::complex<float> operator/ and operator* of a g++ build resolve to libgcc_s.so.1 (g++ links it ahead of the static libgcc):
+    the oracle's c_div, the second source's cdiv / cmul and that library agree bit for bit, magnitudes 1e-6 ... 1e6"""
+    lg = _libgcc_s()
+    rng = np.random.default_rng(0)
+    n = 4000
+    a = crandn(rng, n)
+    b = (crandn(rng, n) * 10.0 ** rng.integers(-6, 7, n)).astype(np.complex64)
+    q, m = ss.cdiv(a, b), ss.cmul(a, b)
+    L = oracle.lib()
+    L.orc_cdiv.argtypes = [ctypes.POINTER(ctypes.c_float)] * 3
+    fp = lambda v: v.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+    for i in range(n):
+        r = lg.__divsc3(a[i].real, a[i].imag, b[i].real, b[i].imag)
+        assert (np.float32(r.re), np.float32(r.im)) == (q[i].real, q[i].imag)
+        r = lg.__mulsc3(a[i].real, a[i].imag, b[i].real, b[i].imag)
+        assert (np.float32(r.re), np.float32(r.im)) == (m[i].real, m[i].imag)
+        ai, bi, qi = (np.array([v.real, v.imag], np.float32) for v in (a[i], b[i], 0j))
+        L.orc_cdiv(fp(ai), fp(bi), fp(qi))
+        assert (qi[0], qi[1]) == (q[i].real, q[i].imag)
+
+
+@pytest.mark.parametrize("mcs", range(6))
+def test_windowed_viterbi_two_restatements_agree_on_random_bits(mcs):
+    """lib/viterbi_decoder.cc:99-331 restated twice (C byte lanes, numpy uint8 lanes): on random hard bits - far beyond the code's
+    correction radius, so every add-compare-select tie and every traceback window matters - the decoded bits are identical"""
+    rng = np.random.default_rng(10 + mcs)
+    v = ss.ViterbiWindowed()
+    for n_dc, n_sym in ((48, 1), (48, 4), (52, 3), (216, 2)):
+        _, cbps, dbps = ss.mcs_params(mcs, n_dc)
+        bits = rng.integers(0, 2, n_sym * cbps).astype(np.uint8)
+        a = v.decode(mcs, n_sym, cbps, n_sym * dbps, bits)
+        b = oracle.viterbi_windowed(mcs, n_sym, cbps, n_sym * dbps, bits)
+        assert a.size == b.size >= n_sym * dbps and np.array_equal(a, b)
+
+
+def test_windowed_viterbi_corrects_what_the_code_can_and_differs_from_ml_only_in_ties():
+    """error-free and lightly corrupted codewords: windowed decoder == maximum-likelihood full traceback == the message"""
+    rng = np.random.default_rng(3)
+    v = ss.ViterbiWindowed()
+    for trial in range(20):
+        msg = np.concatenate([rng.integers(0, 2, 90), np.zeros(6, int)]).astype(np.uint8)
+        code = ss.conv_encode(msg)
+        bad = code.copy()
+        bad[rng.choice(code.size, 3, replace=False)] ^= 1
+        for c in (code, bad):
+            d = v.decode(0, 2, 96, 96, c)
+            assert np.array_equal(d[:96], oracle.viterbi_windowed(0, 2, 96, 96, c)[:96])
+            if c is code or np.array_equal(oracle.viterbi_k7(c), msg):
+                assert np.array_equal(d[:90], msg[:90])
+
+
+def make_pair(o, est, n_tx=4):
+    dc, pc = o["data_subcarriers"], o["pilot_subcarriers"]
+    ps, ltf, ml = o["pilot_symbols"], o["ltf_64"], o["ltf_mapped_sc__ss_sym"]
+    a = oracle.Equalizer(est, 24e9, 125e6, 64, 16, dc, pc, ps, ltf, ml, n_tx)
+    b = ss.EqualizerRef(est, 24e9, 125e6, 64, 16, dc, pc, ps, ltf, ml, n_tx)
+    return a, b
+
+
+def assert_same_run(ra, rb):
+    assert ra["consumed"] == rb["consumed"] and ra["out"].shape == rb["out"].shape
+    assert np.array_equal(_bits(ra["out"]), _bits(rb["out"])), "equalised symbols differ in %d cells" % int((_bits(ra["out"]) != _bits(rb["out"])).any(-1).sum())
+    assert (ra["chan_est"] is None) == (rb["chan_est"] is None)
+    if ra["chan_est"] is not None:
+        assert np.array_equal(_bits(ra["chan_est"]), _bits(rb["chan_est"]))
+    assert [e["kind"] for e in ra["events"]] == [e["kind"] for e in rb["events"]]
+    for ea, eb in zip(ra["events"], rb["events"]):
+        assert ea["offset"] == eb["offset"]
+        if ea["kind"] == 1:
+            assert (ea["data_bytes"], ea["mcs"], ea["packet_type"]) == (eb["data_bytes"], eb["mcs"], eb["packet_type"])
+            assert ea["snr"] == eb["snr"] and ea["freq_offset"] == eb["freq_offset"]          # double arithmetic, same libm
+        else:
+            assert ea["snr_data"] == eb["snr_data"]
+            assert np.array_equal(_bits(ea["chan_mean"]), _bits(eb["chan_mean"]))
+
+
+@pytest.fixture(scope="module")
+def fx():
+    import os
+    from conftest import GOLDEN
+    return np.load(os.path.join(GOLDEN, "path_fixtures_v2.npz"))
+
+
+@pytest.mark.parametrize("tag,est", [("ndp_ls", LS), ("data_ls", LS), ("ndp_sta", STA)])
+def test_equalizer_oracle_equals_second_source_on_the_comm_fixtures(ofdm64, fx, tag, est):
+    """the three committed precoder -> channel -> equalizer inputs (noise 2e-3, frame_start phase 0.011 -> non-zero sampling offset)"""
+    a, b = make_pair(ofdm64, est)
+    rx = fx["comm_%s_rx" % tag]
+    assert_same_run(a.general_work(rx, [(0, 0.011)]), b.general_work(rx, [(0, 0.011)]))
+
+
+@pytest.mark.parametrize("ptype", [NDP, DATA])
+@pytest.mark.parametrize("est", [LS, STA])
+@pytest.mark.parametrize("mcs", [0, 2, 3, 4])
+def test_equalizer_oracle_equals_second_source(ofdm64, ptype, est, mcs):
+    """packet type x estimator x modulation, noisy channel, large carrier offset, trailing garbage after the frame"""
+    rng = np.random.default_rng(100 * ptype + 10 * est + mcs)
+    o = ofdm64
+    pre = oracle.Precoder(64, 4, 1, o["data_subcarriers"], o["pilot_subcarriers"], o["pilot_symbols"], o["l_stf_ltf_64"], o["ltf_mapped_sc__ss_sym"])
+    nbytes = 33
+    ns = oracle.n_ofdm_sym(mcs, 48, nbytes)
+    s = {0: lambda n: (2.0 * rng.integers(0, 2, n) - 1).astype(np.complex64), 2: lambda n: qpsk(rng, n), 3: lambda n: qpsk(rng, n),
+         4: lambda n: qam16(rng, n)}[mcs](ns * 48)
+    h = crandn(rng, 4)
+    y = through_channel(pre.work(s, mcs, ptype, nbytes), h, 3e-3, rng)
+    y = np.concatenate([y, crandn(rng, 3, 64)])
+    a, b = make_pair(o, est)
+    assert_same_run(a.general_work(y, [(0, -0.37)]), b.general_work(y, [(0, -0.37)]))
+
+
+def test_equalizer_split_calls_and_two_frames(ofdm64):
+    """state carried across general_work calls and reset by the next frame_start tag: both restatements step identically"""
+    rng = np.random.default_rng(7)
+    o = ofdm64
+    pre = oracle.Precoder(64, 4, 1, o["data_subcarriers"], o["pilot_subcarriers"], o["pilot_symbols"], o["l_stf_ltf_64"], o["ltf_mapped_sc__ss_sym"])
+    frames = []
+    for ptype, nbytes in ((DATA, 40), (NDP, 12)):
+        ns = oracle.n_ofdm_sym(2, 48, nbytes)
+        frames.append(through_channel(pre.work(qpsk(rng, ns * 48), 2, ptype, nbytes), crandn(rng, 4), 1e-3, rng))
+    y = np.concatenate(frames)
+    tags = [(0, 0.02), (len(frames[0]), -0.05)]
+    a, b = make_pair(o, STA)
+    pos = 0
+    for step in (5, 9, 1, 100):
+        chunk = y[pos:pos + step]
+        t = [(o_ - pos, v) for o_, v in tags if pos <= o_ < pos + len(chunk)]
+        assert_same_run(a.general_work(chunk, t), b.general_work(chunk, t))
+        pos += len(chunk)
+    assert pos == len(y)
+
+
+def sig_frame(o, mcs, ptype, length, flips, rng):
+    """L-LTF x 2 + a SIG symbol whose BPSK bits are flipped at `flips` + MIMO-LTFs + data, flat unit channel"""
+    pre = oracle.Precoder(64, 4, 1, o["data_subcarriers"], o["pilot_subcarriers"], o["pilot_symbols"], o["l_stf_ltf_64"], o["ltf_mapped_sc__ss_sym"])
+    ns = oracle.n_ofdm_sym(mcs, 48, length)
+    tx = pre.work(qpsk(rng, ns * 48), mcs, ptype, length)
+    y = through_channel(tx, np.array([1, 0, 0, 0], np.complex64))
+    dc = np.asarray(o["data_subcarriers"]) + 32
+    y[2, dc[flips]] *= -1
+    return y
+
+
+@pytest.mark.parametrize("n_err", [1, 2, 3, 5, 8])
+def test_sig_field_with_bit_errors_decodes_the_same_through_both_restatements(ofdm64, n_err):
+    """SIG fields with bit errors go through the reference's WINDOWED decoder (traceback depth 5 chunks,
+    8-bit wrap-around metrics, symbols beyond the 48 coded bits = 0) in the oracle and in the second source - same decoded
+    header, same success / failure, same frame length - including error counts the code cannot correct"""
+    rng = np.random.default_rng(50 + n_err)
+    same_as_sent = 0
+    for trial in range(12):
+        mcs, ptype, length = int(rng.integers(0, 6)), int(rng.integers(1, 3)), int(rng.integers(1, 300))
+        flips = rng.choice(48, n_err, replace=False)
+        y = sig_frame(ofdm64, mcs, ptype, length, flips, rng)
+        a, b = make_pair(ofdm64, LS)
+        ra, rb = a.general_work(y, [(0, 0.0)]), b.general_work(y, [(0, 0.0)])
+        assert_same_run(ra, rb)
+        ev = [e for e in ra["events"] if e["kind"] == 1]
+        same_as_sent += bool(ev) and (ev[0]["mcs"], ev[0]["packet_type"], ev[0]["data_bytes"]) == (mcs, ptype, length)
+    if n_err <= 2:
+        assert same_as_sent == 12          # free distance 10: up to 4 errors are corrected when they are not clustered in a window
+
+
+def make_precoders(o, N=64, T=4):
+    args = (o["data_subcarriers"], o["pilot_subcarriers"], o["pilot_symbols"], o["l_stf_ltf_64"], o["ltf_mapped_sc__ss_sym"])
+    return oracle.Precoder(N, T, 1, *args), ss.PrecoderRef(N, T, *args)
+
+
+@pytest.mark.parametrize("ptype", [NDP, DATA])
+@pytest.mark.parametrize("steer", ["dft", "mean", "per_sc", "mean+streams", "per_sc+streams", "dft+streams"])
+def test_precoder_oracle_equals_second_source(ofdm64, ptype, steer):
+    """mimo_precoder_impl::work output assembly (lib/mimo_precoder_impl.cc:336-712): legacy preamble, SIG symbol, MIMO-LTFs
+    (plain for NDP, steered for DATA), data + pilots through F / Q_mean / Q[sc], with and without radar streams"""
+    if ptype == NDP and steer != "dft":
+        pytest.skip("NDP frames are not steered")
+    rng = np.random.default_rng(hash(steer) % 1000 + ptype)
+    a, b = make_precoders(ofdm64)
+    nbytes, mcs = 57, 3
+    ns = oracle.n_ofdm_sym(mcs, 48, nbytes)
+    s = qpsk(rng, ns * 48)
+    kw = {}
+    if steer.startswith("mean"):
+        kw = dict(steer_mode=1, Q_mean=crandn(rng, 4, 4))
+    elif steer.startswith("per_sc"):
+        kw = dict(steer_mode=2, Q_sc=crandn(rng, 64, 4, 4))
+    if steer.endswith("streams"):
+        kw["radar_streams"] = qpsk(rng, 3 * ns * 64).reshape(3, ns, 64)
+    ta, tb = a.work(s, mcs, ptype, nbytes, **kw), b.work(s, mcs, ptype, nbytes, **kw)
+    assert ta.shape == tb.shape and np.array_equal(_bits(ta), _bits(tb))
+    with pytest.raises(RuntimeError):
+        b.work(s[:48], mcs, ptype, nbytes)
+
+
+def test_dft_matrix_and_signal_field_second_source(ofdm64):
+    for T in (1, 2, 3, 4, 8):
+        assert np.array_equal(_bits(oracle.dft_matrix(T)), _bits(ss.dft_matrix(T)))
+    for mcs in range(6):
+        for ptype in (NDP, DATA):
+            for length in (0, 1, 77, 4095):
+                for nd in (48, 52, 216):
+                    assert np.array_equal(oracle.sig_encode(nd, mcs, ptype, length), ss.signal_field(nd, mcs, ptype, length))
