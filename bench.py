@@ -78,6 +78,10 @@ def _free_port():
 
 
 def self_launch(a, argv):
+    # the ranks start together: build (or find built) the extension ONCE here, before any of them looks for it.  Compiling is not a GPU
+    # call; the build is also flock-guarded (build.build_lock) for ranks that a launcher other than this one starts on an unbuilt tree.
+    from jrc_amd import build as jb
+    jb.build()
     port = _free_port()
     procs = []
     for r in range(a.gpus):
@@ -107,6 +111,24 @@ def self_launch(a, argv):
     if rc == 0 and not lines:
         rc = 1
     return rc
+
+
+def rank_identity(torch, rank, local_rank, dev_index, my_windows, steps):
+    """what makes the N > 1 line self-proving: which physical device this rank ran on and how long ITS OWN timed windows took"""
+    p = torch.cuda.get_device_properties(dev_index)
+    bus = "%04x:%02x:%02x" % tuple(int(getattr(p, k, -1)) & 0xffff for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+    return {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "device_name": p.name, "pci_bus_id": bus,
+            "uuid": str(getattr(p, "uuid", "")), "compute_units": int(getattr(p, "multi_processor_count", 0)),
+            "host": socket.gethostname(), "pid": os.getpid(),
+            "ms_per_step_window0": 1e3 * my_windows[0] / steps, "ms_per_step_windows": [1e3 * w / steps for w in my_windows]}
+
+
+def gather_identities(dist, world, mine):
+    if world == 1:
+        return [mine]
+    allr = [None] * world
+    dist.all_gather_object(allr, mine)          # pickled through the backend's own tensors (RCCL: on this rank's device)
+    return sorted(allr, key=lambda r: r["rank"])
 
 
 def scenario(name):
@@ -560,8 +582,11 @@ def main():
     kt = chain.get_timing()
     res = chain.results(bufs, F)
 
+    ranks = gather_identities(dist, world, rank_identity(torch, rank, local_rank, torch.cuda.current_device(), windows, a.steps))
     windows = shard.max_over_ranks_vec(windows, coll_dev)
     elapsed = windows[0]
+    same_bus = sorted(r["pci_bus_id"] for r in ranks)
+    shared_device = any(x == y for x, y in zip(same_bus, same_bus[1:]))
 
     check = None
     if not a.no_check:
@@ -604,7 +629,16 @@ def main():
                              "jrc_chain_fetch_results, after the timed region; everything else of A1..A5 is inside it",
             "check": dict(check or {}, range_m=res[0].range_val, angle_deg=res[0].angle_val, snr_db=res[0].snr_est),
             "device": ctx.device_name(),
+            # who took part: one entry per rank with the physical device it ran on and ITS OWN clock over the same windows
+            "ranks": ranks,
+            "backend": (dist.get_backend() if world > 1 else None),
+            "collective_world": (dist.get_world_size() if world > 1 else 1),
+            "distinct_devices": len(set(r["pci_bus_id"] for r in ranks)),
         }
+        slowest = max(r["ms_per_step_window0"] for r in ranks)
+        # consistency of the line with its parts (barrier cost + start skew), NOT the scaling efficiency (the driver computes that from the
+        # per-N lines): whole-job value over N x the rate the slowest rank measured on its own clock
+        out["value_over_n_times_slowest_rank"] = (total_frames / elapsed) / (world * F / (slowest * 1e-3))
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
         if world == 1 and not a.no_secondary:
@@ -615,6 +649,9 @@ def main():
             out["secondary"] = secondary_figures(a.config, ctx, sc, axes)
         print(json.dumps(out))
         sys.stdout.flush()
+    if shared_device and not a.same_device:
+        sys.stderr.write("bench.py: two ranks ran on the same device (%s): not an N-GPU measurement\n" % ", ".join(same_bus))
+        rc = 4
     if check is not None and not check.get("ok_all_ranks", check["ok"]):
         sys.stderr.write("bench.py: result check FAILED on rank %d: %s\n" % (rank, json.dumps(check)))
         rc = 3

@@ -4,6 +4,8 @@ In-tree build: the .so lands in gr-mimo-ofdm-jrc_amd/lib/ (git-ignored, but it t
 hipcc cross-compiles without a GPU, so this runs in the CPU-only container as the "does it build" check.
 """
 import concurrent.futures
+import contextlib
+import fcntl
 import os
 import shutil
 import subprocess
@@ -66,7 +68,38 @@ def _compile(src):
     return obj, True
 
 
+_lock_depth = 0
+
+
+@contextlib.contextmanager
+def build_lock():
+    """one builder at a time across processes (N ranks started together on a tree without the .so, pytest-xdist workers): an flock on
+    lib/.build.lock; whoever waited re-checks the time stamps afterwards and finds the work done.  Re-entrant within a process."""
+    global _lock_depth
+    if _lock_depth:
+        _lock_depth += 1
+        try:
+            yield
+        finally:
+            _lock_depth -= 1
+        return
+    os.makedirs(LIBDIR, exist_ok=True)
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as fh:
+        fcntl.flock(fh, fcntl.LOCK_EX)
+        _lock_depth = 1
+        try:
+            yield
+        finally:
+            _lock_depth = 0
+            fcntl.flock(fh, fcntl.LOCK_UN)
+
+
 def build(force=False, verbose=False):
+    with build_lock():
+        return _build_locked(force, verbose)
+
+
+def _build_locked(force, verbose):
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
     if force:
@@ -95,6 +128,11 @@ HOST_SOURCES = ["jrc_blocks.cc", "jrc_blocks_capi.cc"]
 def build_host(force=False, verbose=False):
     """host-side C++ blocks (reference block interface over the C ABI) + their C test harness, with g++ against the
     stand-alone runtime (no GNU Radio in this image); links libjrc_hip.so"""
+    with build_lock():
+        return _build_host_locked(force, verbose)
+
+
+def _build_host_locked(force, verbose):
     build()
     srcs = [os.path.join(HOST_DIR, s) for s in HOST_SOURCES]
     deps = srcs + [os.path.join(HOST_DIR, h) for h in ("jrc_blocks.h", "jrc_block_runtime.h")] + [os.path.join(HERE, "..", "include", "jrc.h")]

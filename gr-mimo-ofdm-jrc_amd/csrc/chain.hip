@@ -341,6 +341,8 @@ __global__ __launch_bounds__(NT_, 2) void range_angle_wide_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float2* s_g = smem;                                         // [2][P][256]
     float* s_pw = reinterpret_cast<float*>(s_g + 2 * P * RW_L) + (size_t)wave * (64 * P);   // MODE 3: this wave's tile (its four rows)
+    __shared__ unsigned s_run;                                  // MODE 1: the workgroup's running maximum (float bits), see the angle axis
+    if (tid == 0) s_run = 0u;                                   // ordered before its first use by the barrier of the first class
 
     // this wave's share of H, for good
     float2 h[PPW][4][MM];
@@ -431,13 +433,60 @@ __global__ __launch_bounds__(NT_, 2) void range_angle_wide_kernel(
         __syncthreads();                                          // the one barrier of the class: its range bins are complete; the buffer the next
                                                                   // range phase fills was last read before this barrier
         if constexpr (MODE == 1 || MODE == 3) {
-            float4* dst = reinterpret_cast<float4*>(rng_out + ((size_t)f * C + c) * (P * RW_L));
+            // write-once for the window pass: around the caches — a cached store would sit dirty in the Infinity Cache and be written back
+            // while the NEXT step's A1 streams its input (A1 0.098 -> 0.13 ms per 512 config-B frames behind 128 MB of cached stores)
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            v4f* dst = reinterpret_cast<v4f*>(rng_out + ((size_t)f * C + c) * (P * RW_L));
             const float4* src = reinterpret_cast<const float4*>(sg);
-            for (int i = tid; i < (P * RW_L) / 2; i += NT) dst[i] = src[i];
+            for (int i = tid; i < (P * RW_L) / 2; i += NT) {
+                const float4 vv = src[i];
+                const v4f t = {vv.x, vv.y, vv.z, vv.w};
+                __builtin_nontemporal_store(t, dst + i);
+            }
         }
         // ---- angle axis + fftshift + store + arg-max -------------------------------------------------------------------------
+        // MODE 1 (nothing stored): a range bin whose bound B_k = (sum_p |R[p][k]|)^2 >= every |cell|^2 of its row lies below the running
+        // maximum cannot hold the arg-max, and its Ia P-point transforms are skipped.  Exact: a row is skipped only when
+        // B_k (1 + 1e-4) < run_max (1 - 1e-5) with run_max <= the final maximum, so every cell the unpruned scan evaluates exactly near
+        // the final maximum is still evaluated, and PeakTracker resolves ties by flat index, not by visiting order — the records stay
+        // byte-identical to map mode (tests/test_gpu_chain_modes.py).  The workgroup shares its running maximum through LDS (s_run), and
+        // each wave visits first the trip holding its strongest bound, so from the second trip of the first class on almost every row
+        // of a frame with a target is skipped; a frame of noise alone prunes little (the bound is then ~P / ln(cells) above the maximum).
+        constexpr int TRIPS = items / NT;
+        int t_first = 0;
+        auto row_bound = [&](int w0) -> float {
+            const int q = (w0 + tid) / Ia;
+            const int qi = (q & 3) * 64 + (q >> 2);
+            float sum = 0.f;
+            for (int p = r; p < P; p += Ia) { const float2 v = sg[p * RW_L + qi]; sum += __fsqrt_rn(fmaf(v.x, v.x, v.y * v.y)); }
+            if constexpr (Ia == 16) {          // the Ia lanes of a range bin are one DPP row: quad xor 1, xor 2, half-row mirror, row mirror
+                sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0xB1, 0xf, 0xf, false));
+                sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x4E, 0xf, 0xf, false));
+                sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x141, 0xf, 0xf, false));
+                sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x140, 0xf, 0xf, false));
+            } else {
+                for (int off = Ia >> 1; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+            }
+            return sum * sum;
+        };
+        if constexpr (MODE == 1) {
+            float b_first = -1.0f;
 #pragma unroll 1
-        for (int w0 = 0; w0 < items; w0 += NT) {
+            for (int t = 0; t < TRIPS; t++) {
+                const float b = wave_max_f32(row_bound(t * NT));
+                if (b > b_first) { b_first = b; t_first = t; }
+            }
+        }
+#pragma unroll 1
+        for (int tt = 0; tt < TRIPS; tt++) {
+            int w0 = tt * NT;
+            if constexpr (MODE == 1) {
+                const int t = tt == 0 ? t_first : (tt <= t_first ? tt - 1 : tt);      // the strongest trip first, then the others in order
+                w0 = t * NT;
+                trk.run_max = fmaxf(trk.run_max, __uint_as_float(*reinterpret_cast<volatile unsigned*>(&s_run)));
+                const float b2 = row_bound(w0);
+                if (__ballot(b2 * (1.0f + 1e-4f) >= trk.run_max * (1.0f - 1e-5f)) == 0ull) continue;
+            }
             const int w = w0 + tid;
             const int q = w / Ia;                                 // (w % Ia == r); a wave's four range bins q .. q + 3 are the four b of one a
             const int qi = (q & 3) * 64 + (q >> 2);
@@ -484,7 +533,9 @@ __global__ __launch_bounds__(NT_, 2) void range_angle_wide_kernel(
                     if ((u % RA_GROUP) == RA_GROUP - 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
                 }
             }
+            const float before = trk.run_max;
             const float thr = trk.raise(m);
+            if constexpr (MODE == 1) { if (trk.run_max > before && lane == 0) atomicMax(&s_run, __float_as_uint(trk.run_max)); }   // non-negative floats order as their bit patterns
             if (m >= thr) {
                 const unsigned flat0 = (unsigned)k * (unsigned)NA;
 #pragma unroll

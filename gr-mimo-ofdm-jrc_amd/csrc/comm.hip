@@ -236,8 +236,7 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
     float2* Hm = H + N;
     float2* Z = Hm + N;                       // [ND]
     float2* est = Z + ND;                     // [NP]
-    unsigned long long* surv = reinterpret_cast<unsigned long long*>(est + NP);   // [eq_surv_words(ND)]: survivor masks of the SIG Viterbi
-    unsigned char* bits = reinterpret_cast<unsigned char*>(surv + eq_surv_words(ND));   // [eq_pair_bytes(ND)]: its received pairs
+    unsigned long long* surv = reinterpret_cast<unsigned long long*>(est + NP);   // [eq_surv_words(ND)]: scratch of the SIG Viterbi (its 5 x 64-byte path ring)
     // constant tables staged in LDS: the serial (one-lane) sections below walk them with dependent loads, which from
     // global memory cost microseconds each once every CU is busy
     int* dc = reinterpret_cast<int*>(eq_smem + d.lds_tables);                     // [ND] data carriers

@@ -34,10 +34,19 @@ class RaResult(C.Structure):
 def build(force=False):
     """Compile oracle/jrc_oracle*.c with gcc (the checker, not the product)."""
     srcs = [os.path.join(_HERE, f) for f in ("jrc_oracle.c", "jrc_oracle_comm.c", "jrc_oracle_tsim.c", "jrc_oracle_codec.c", "jrc_oracle_sync.c", "jrc_oracle.h", "Makefile")]
-    if (not force and os.path.exists(_LIB_PATH)
-            and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
+    def fresh():
+        return os.path.exists(_LIB_PATH) and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs)
+    if not force and fresh():
         return _LIB_PATH
-    subprocess.check_call(["make", "-s", "-C", _HERE])
+    import fcntl
+    os.makedirs(os.path.join(_HERE, "_build"), exist_ok=True)
+    with open(os.path.join(_HERE, "_build", ".build.lock"), "w") as fh:       # one builder at a time across processes
+        fcntl.flock(fh, fcntl.LOCK_EX)
+        try:
+            if force or not fresh():
+                subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))
+        finally:
+            fcntl.flock(fh, fcntl.LOCK_UN)
     return _LIB_PATH
 
 

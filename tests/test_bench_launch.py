@@ -59,6 +59,7 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path):
     assert r1.returncode == 0, r1.stderr[-2000:]
     j1 = json.loads(l1[-1])
     assert j1["n_gpus"] == 1 and j1["check"]["ok"] and j1["config"]["launcher"] == "direct"
+    assert len(j1["ranks"]) == 1 and j1["collective_world"] == 1 and j1["backend"] is None and j1["distinct_devices"] == 1
     r2, l2 = _run(COMMON + ["--gpus", "2", "--same-device", "--backend", "gloo", "--frames", str(F), "--distinct", str(F), "--dump", two,
                             "--dump-maps", "3", "--oracle-frames", "4", "--gather-results", "--gather-maps", "2"])
     assert r2.returncode == 0, r2.stderr[-2000:]
@@ -67,12 +68,36 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path):
     assert j2["n_gpus"] == 2 and j2["scaling"] == "weak" and j2["check"]["ok"] and j2["check"]["ok_all_ranks"]
     assert j2["config"]["launcher"] == "self-launched children" and j2["config"]["gather_results"] and j2["config"]["gather_maps_per_gpu"] == 2
     assert j2["value"] > 0 and abs(j2["value"] - 2 * F * 3 / (j2["ms_per_step"] * 3e-3)) < 1e-6 * j2["value"]
+    # the line proves who took part: one entry per rank (device identity, own clock), the backend and the size of the process group
+    rk = j2["ranks"]
+    assert [r["rank"] for r in rk] == [0, 1] and j2["collective_world"] == 2 and j2["backend"] == "gloo"
+    assert all(r["device_name"] and r["pci_bus_id"] and r["pid"] > 0 and r["ms_per_step_window0"] > 0 for r in rk)
+    assert rk[0]["pid"] != rk[1]["pid"] and rk[0]["pci_bus_id"] == rk[1]["pci_bus_id"] and j2["distinct_devices"] == 1   # --same-device
+    assert max(r["ms_per_step_window0"] for r in rk) <= j2["ms_per_step"] * (1 + 1e-9)      # the line's time is the MAX over ranks
+    assert 0.3 < j2["value_over_n_times_slowest_rank"] <= 1.0 + 1e-9
     a, b = np.load(one), np.load(two)
     # rank 0 owns frames [0, F), rank 1 frames [F, 2F) of the same seeded stream: gathered in frame order
     assert np.array_equal(a["results"], b["results"])
     assert np.array_equal(a["chanest"], b["chanest"])
     want_maps = np.concatenate([a["maps"][0:3], a["maps"][F:F + 3]])
     assert np.array_equal(want_maps, b["maps"])
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_device_without_the_test_flag_is_refused():
+    """an N-GPU line whose ranks share a physical device is not an N-GPU measurement: without --same-device (where every rank is
+    pinned to GPU 0 on purpose) bench.py must exit non-zero.  On this one-GPU box LOCAL_RANK 1 has no device of its own, so the ranks are
+    started by hand with LOCAL_RANK 0 twice - what a mis-set launcher would do."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(2):
+        e = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, BENCH] + COMMON + ["--gpus", "2", "--backend", "gloo", "--frames", "16", "--no-check"],
+                                      env=e, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 4 for p in procs), [(p.returncode, o[1][-500:]) for p, o in zip(procs, outs)]
+    assert "same device" in outs[0][1]
 
 
 @pytest.mark.gpu
