@@ -225,8 +225,15 @@ def cpu_baseline(sc, Ir, Ia, frames, axes, budget_s):
     except Exception as e:
         out["pipeline_ideal"] = {"error": str(e)}
     try:
+        # every host core this process may run on; the only cap is memory: a worker holds the oracle's double-precision
+        # work buffers for one frame (a few map sizes), so leave each 64 map-sizes of the MemAvailable the box reports
         ncpu = len(os.sched_getaffinity(0))
-        n = max(1, min(ncpu, 64))
+        per_worker = 64 * (sc.N * Ir) * (sc.T * sc.R * Ia) * 16
+        try:
+            avail = [int(l.split()[1]) * 1024 for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0]
+        except (OSError, IndexError, ValueError):
+            avail = 8 << 30
+        n = max(1, min(ncpu, int(avail * 0.5 // per_worker)))
         with mp.get_context("fork").Pool(n) as pool:
             res = pool.map(_cpu_worker, [(sc_args, Ir, Ia, frames[:4], axes, budget_s * 0.3)] * n)
         out["all_cores"] = {"value": sum(d / e for d, e in res), "unit": "frames/s", "cores": n,

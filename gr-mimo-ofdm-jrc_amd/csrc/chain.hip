@@ -381,6 +381,8 @@ __global__ __launch_bounds__(NT_, 2) void range_angle_wide_kernel(
 
     PeakTracker trk;
     trk.init();
+    bool prune_on = MODE == 1 && !(pace & 8);                   // MODE 1: rows are skipped by their bounds (angle axis below) until that stops paying in this frame
+    unsigned seen = 0u;                                         // s_run as last read
     constexpr int items = RW_L * Ia;
     constexpr int ahalf = NA >> 1, amask = NA - 1;
     float2* mapf = map + (size_t)f * NR * NA;
@@ -435,25 +437,32 @@ __global__ __launch_bounds__(NT_, 2) void range_angle_wide_kernel(
         if constexpr (MODE == 1 || MODE == 3) {
             // write-once for the window pass: around the caches — a cached store would sit dirty in the Infinity Cache and be written back
             // while the NEXT step's A1 streams its input (A1 0.098 -> 0.13 ms per 512 config-B frames behind 128 MB of cached stores)
+            // (MODE 3 streams the power map itself at the memory system's pace: there the cached form is the faster one — 0.28 against 0.39 ms)
             typedef float v4f __attribute__((ext_vector_type(4)));
             v4f* dst = reinterpret_cast<v4f*>(rng_out + ((size_t)f * C + c) * (P * RW_L));
             const float4* src = reinterpret_cast<const float4*>(sg);
+            if (!(MODE == 1 && (pace & 2)))
             for (int i = tid; i < (P * RW_L) / 2; i += NT) {
                 const float4 vv = src[i];
                 const v4f t = {vv.x, vv.y, vv.z, vv.w};
-                __builtin_nontemporal_store(t, dst + i);
+                if constexpr (MODE == 1) __builtin_nontemporal_store(t, dst + i);
+                else dst[i] = t;
             }
         }
+        if (MODE == 1 && (pace & 1)) continue;                    // experiment (JRC_DETECT_EXP bit 0): no angle stage at all — the floor of the range phase
         // ---- angle axis + fftshift + store + arg-max -------------------------------------------------------------------------
         // MODE 1 (nothing stored): a range bin whose bound B_k = (sum_p |R[p][k]|)^2 >= every |cell|^2 of its row lies below the running
         // maximum cannot hold the arg-max, and its Ia P-point transforms are skipped.  Exact: a row is skipped only when
         // B_k (1 + 1e-4) < run_max (1 - 1e-5) with run_max <= the final maximum, so every cell the unpruned scan evaluates exactly near
         // the final maximum is still evaluated, and PeakTracker resolves ties by flat index, not by visiting order — the records stay
-        // byte-identical to map mode (tests/test_gpu_chain_modes.py).  The workgroup shares its running maximum through LDS (s_run), and
-        // each wave visits first the trip holding its strongest bound, so from the second trip of the first class on almost every row
-        // of a frame with a target is skipped; a frame of noise alone prunes little (the bound is then ~P / ln(cells) above the maximum).
+        // byte-identical to map mode (tests/test_gpu_chain_modes.py).  Per class a wave computes the bounds of its TRIPS x 4 rows once
+        // (one LDS read, a square root and a DPP row sum per lane and trip, all trips in flight together) and turns them into a bit mask
+        // of trips still worth computing against the workgroup's running maximum (s_run, shared through LDS).  The workgroup's FIRST
+        // class has nothing to compare with: every wave computes the trip with its largest bound, the maxima meet at one extra barrier,
+        // and only then is the mask formed.  A frame with a target is left with the main-lobe rows; in a frame of noise alone (or of
+        // targets too weak to stand out) the bound is ~P / ln(cells) above the maximum and most rows stay: a wave that finds more than
+        // half of a class's trips still to do stops computing bounds for the rest of the frame, so such frames pay them once.
         constexpr int TRIPS = items / NT;
-        int t_first = 0;
         auto row_bound = [&](int w0) -> float {
             const int q = (w0 + tid) / Ia;
             const int qi = (q & 3) * 64 + (q >> 2);
@@ -467,25 +476,59 @@ __global__ __launch_bounds__(NT_, 2) void range_angle_wide_kernel(
             } else {
                 for (int off = Ia >> 1; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
             }
-            return sum * sum;
+            return (sum * sum) * (1.0f + 1e-4f);
         };
-        if constexpr (MODE == 1) {
-            float b_first = -1.0f;
-#pragma unroll 1
-            for (int t = 0; t < TRIPS; t++) {
-                const float b = wave_max_f32(row_bound(t * NT));
-                if (b > b_first) { b_first = b; t_first = t; }
+        float bnd[TRIPS];                                         // MODE 1: bound of this lane's row in trip t (the same in the Ia lanes of the row)
+        unsigned todo = TRIPS >= 32 ? 0xffffffffu : (1u << TRIPS) - 1u;
+        int t_first = -1;
+        auto candidates = [&]() -> unsigned {
+            trk.run_max = fmaxf(trk.run_max, __uint_as_float(*reinterpret_cast<volatile unsigned*>(&s_run)));
+            const float thr = trk.run_max * (1.0f - 1e-5f);
+            unsigned m = 0;
+#pragma unroll
+            for (int t = 0; t < TRIPS; t++) m |= (__ballot(bnd[t] >= thr) != 0ull ? 1u : 0u) << t;
+            return m;
+        };
+        if (MODE == 1 && prune_on) {
+#pragma unroll
+            for (int t = 0; t < TRIPS; t++) bnd[t] = row_bound(t * NT);
+            if (it == 0) {
+                float bm = bnd[0];
+#pragma unroll
+                for (int t = 1; t < TRIPS; t++) bm = fmaxf(bm, bnd[t]);
+                bm = wave_max_f32(bm);
+                t_first = 0;
+#pragma unroll
+                for (int t = TRIPS - 1; t >= 0; t--) if (__ballot(bnd[t] == bm) != 0ull) t_first = t;
+                todo = 1u << t_first;
+            } else {
+                todo = candidates();
+                seen = *reinterpret_cast<volatile unsigned*>(&s_run);
+                if (2 * __popc(todo) > TRIPS) prune_on = false;  // nothing stands out in this frame (noise, weak targets): the bounds cost more than they save
             }
         }
 #pragma unroll 1
-        for (int tt = 0; tt < TRIPS; tt++) {
-            int w0 = tt * NT;
+        for (int tt = 0; ; tt++) {
+            int w0;
             if constexpr (MODE == 1) {
-                const int t = tt == 0 ? t_first : (tt <= t_first ? tt - 1 : tt);      // the strongest trip first, then the others in order
-                w0 = t * NT;
-                trk.run_max = fmaxf(trk.run_max, __uint_as_float(*reinterpret_cast<volatile unsigned*>(&s_run)));
-                const float b2 = row_bound(w0);
-                if (__ballot(b2 * (1.0f + 1e-4f) >= trk.run_max * (1.0f - 1e-5f)) == 0ull) continue;
+                if (tt > 0 && t_first < 0 && prune_on) {          // a trip was computed: has the workgroup's maximum moved?
+                    const unsigned now = *reinterpret_cast<volatile unsigned*>(&s_run);
+                    if (now != seen) { seen = now; todo &= candidates(); }
+                }
+                if (todo == 0u) {
+                    if (t_first < 0) break;
+                    __syncthreads();                              // first class of the workgroup: every wave has published the maximum of its strongest trip
+                    todo = candidates() & ~(1u << t_first);
+                    seen = *reinterpret_cast<volatile unsigned*>(&s_run);
+                    t_first = -1;
+                    if (2 * __popc(todo) > TRIPS) prune_on = false;
+                    if (todo == 0u) break;
+                }
+                w0 = (__ffs((int)todo) - 1) * NT;
+                todo &= todo - 1u;
+            } else {
+                if (tt >= TRIPS) break;
+                w0 = tt * NT;
             }
             const int w = w0 + tid;
             const int q = w / Ia;                                 // (w % Ia == r); a wave's four range bins q .. q + 3 are the four b of one a
@@ -585,7 +628,11 @@ __global__ __launch_bounds__(256) void ra_window_rows_kernel(const float2* __res
         fft_fwd_small_pin<P>(y);
         float2* out = win + ((size_t)f * win_rows + row) * NA;
 #pragma unroll
-        for (int u = 0; u < P; u++) out[(Ia * u + r + ahalf) & amask] = y[u];
+        for (int u = 0; u < P; u++) {                           // read once by ra_finalize, never again: around the caches (see the range profiles above)
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            const v2f t = {y[u].x, y[u].y};
+            __builtin_nontemporal_store(t, reinterpret_cast<v2f*>(out + ((Ia * u + r + ahalf) & amask)));
+        }
     }
 }
 
@@ -716,20 +763,34 @@ static int chain_chunk(const jrc_chain* ch, int wpf)
     return chunk - chunk % nx;
 }
 
-static int chain_pace(const jrc_chain* ch)
+// Store pacing of the map-writing kernels: every wave releases its map stores in groups of RA_GROUP x 512 B, one group per T
+// ticks of wall_clock64().  What the sweeps (tools/pace_sweep.sh) found is a property of the memory system, an OFFERED BYTE RATE at which the map
+// stream runs at the pace of a pure store stream — not a tick count: so the word is derived from that rate, the bytes of a group, the waves
+// actually resident for this launch and the clock of the counter,
+//     T = group_bytes x resident_waves / offered_rate   [ticks],
+// and a partition with fewer CUs (CPX / DPX), another SKU or a last, smaller launch of a batch gets the word that offers the same rate.
+//   wide kernel as two 256-thread workgroups per CU (fft_len 256 / 512): 7.77 TB/s offered, no catching up — the plateau measured at config B on 256
+//     CUs was T = 102 ... 112 ticks of 10 ns (0.328-0.332 ms per 512 frames, 82 % of the HBM peak; 0.352 unpaced), which this gives as 108;
+//   64-bin kernel, 16 pairs x interp_angle 16, two 256-thread workgroups per CU: 6.93 TB/s, one group of catching up (T = 121: 0.341 against 0.366 ms);
+//   fft_len 1024 on the 64-bin kernel (JRC_NO_WIDE; one 512-thread workgroup per CU): 8.39 TB/s (T = 100: 0.777 ms per 256 frames against 0.85).
+// The wide kernel at fft_len 1024 runs the same paced or not (0.689-0.695 ms for T = 60 ... 100) and every other geometry was never found to gain: 0.
+// JRC_RA_OFFERED_TBPS replaces the rate, JRC_RA_PACE the whole word.
+static int chain_pace(const jrc_chain* ch, int resident_workgroups)
 {
-    if (ch->ctx->tune.ra_pace >= 0) return ch->ctx->tune.ra_pace;      // JRC_RA_PACE
-    // measured (tools/pace_sweep.sh): eight waves per CU, each releasing 8 x 512 B every 1.21 us and allowed to catch up one
-    // group — 7 TB/s offered — hold the map stream at the rate of a pure store stream (0.341 ms per 512 config-B frames, 79 % of the HBM
-    // peak; 0.366 ms unpaced); other geometries are not paced
-    // the wide kernel as two 256-thread workgroups per CU (fft_len 256 / 512): a group of stores per wave every 1.08 us, no catching up —
-    // a plateau from 1.02 to 1.12 us (config B: 0.328-0.332 ms per 512 frames, 82 % of the HBM peak; 0.352 unpaced, 0.340 at 1.16 us)
-    if (ch->wide && ch->threads == 256) return 108;
-    if (!ch->wide && ch->P == 16 && ch->cfg.interp_angle == 16 && ch->threads == 256 && ch->wg_per_cu == 2 && ch->cfg.interp_range <= 8) return (1 << 12) | 121;
-    // fft_len 1024 without range_angle_wide_kernel (JRC_NO_WIDE; one 512-thread workgroup per CU): 1.0 us, no catching up — 0.777 ms per 256
-    // frames against 0.85 unpaced.  The wide kernel itself runs the same paced or not (0.689-0.695 ms for T = 60 ... 100): not paced.
-    if (!ch->wide && ch->P == 16 && ch->cfg.interp_angle == 16 && ch->threads == 512 && ch->cfg.fft_len == 1024 && ch->cfg.interp_range <= 8) return 100;
-    return 0;
+    if (ch->ctx->tune.ra_pace >= 0) return ch->ctx->tune.ra_pace;
+    double offered = 0;
+    int catch_up = 0;
+    if (ch->wide && ch->threads == 256) offered = 7.77e12;
+    else if (!ch->wide && ch->P == 16 && ch->cfg.interp_angle == 16 && ch->threads == 256 && ch->wg_per_cu == 2 && ch->cfg.interp_range <= 8) { offered = 6.93e12; catch_up = 1; }
+    else if (!ch->wide && ch->P == 16 && ch->cfg.interp_angle == 16 && ch->threads == 512 && ch->cfg.fft_len == 1024 && ch->cfg.interp_range <= 8) offered = 8.39e12;
+    if (offered == 0) return 0;
+    if (ch->ctx->tune.ra_offered_tbps > 0) offered = ch->ctx->tune.ra_offered_tbps * 1e12;
+    const double group_bytes = (double)RA_GROUP * 64 * sizeof(float2);
+    const double waves = (double)resident_workgroups * (ch->threads / 64);
+    long T = lround(group_bytes * waves / offered * (ch->ctx->wall_clock_khz * 1e3));
+    if (T < 0) T = 0;
+    if (T > 0xfff) T = 0xfff;
+    return (catch_up << 12) | (int)T;
 }
 
 template <int P, int NT, int MMAX, bool TWC_LDS, int MODE, int IA, bool ROWS1 = false>
@@ -753,7 +814,8 @@ static int launch_fused_mode(jrc_chain* ch, int n_frames, int wpf, int pstride, 
                            d_H + (size_t)f0 * P * ch->cfg.fft_len, mp,
                            ch->d_partials + (size_t)f0 * pstride,
                            ch->twR, ch->twA, ch->cfg.fft_len, ch->NR, ch->cfg.interp_angle, nf, w, pstride,
-                           (MODE == 1 || MODE == 3) ? ch->d_rng + (size_t)f0 * ch->NR * P : nullptr, nx, chain_pace(ch));
+                           (MODE == 1 || MODE == 3) ? ch->d_rng + (size_t)f0 * ch->NR * P : nullptr, nx,
+                           chain_pace(ch, (int)grid.x < ch->n_cus * ch->wg_per_cu ? (int)grid.x : ch->n_cus * ch->wg_per_cu));
     }
     JRC_HIP(ch->ctx, hipGetLastError());
     return JRC_OK;
@@ -775,7 +837,8 @@ static int launch_fused_wide(jrc_chain* ch, int n_frames, int wpf, int pstride, 
                    : (MODE == 3 ? reinterpret_cast<float2*>(reinterpret_cast<float*>(d_map) + (size_t)f0 * ch->NR * ch->NA) : nullptr);
         hipLaunchKernelGGL((range_angle_wide_kernel<P, MODE, 16, LOGN, NT_>), grid, dim3(NT_), lds_bytes, s,
                            d_H + (size_t)f0 * P * ch->cfg.fft_len, mp, ch->d_partials + (size_t)f0 * pstride, ch->twR, ch->twA,
-                           ch->NR, nf, w, pstride, (MODE == 1 || MODE == 3) ? ch->d_rng + (size_t)f0 * ch->NR * P : nullptr, nx, chain_pace(ch));
+                           ch->NR, nf, w, pstride, (MODE == 1 || MODE == 3) ? ch->d_rng + (size_t)f0 * ch->NR * P : nullptr, nx,
+                           MODE == 1 ? ch->ctx->tune.detect_exp : chain_pace(ch, (int)grid.x < ch->n_cus * ch->wg_per_cu ? (int)grid.x : ch->n_cus * ch->wg_per_cu));
     }
     JRC_HIP(ch->ctx, hipGetLastError());
     return JRC_OK;

@@ -1,5 +1,6 @@
 // ctx.hip — context, error reporting, staging memory and twiddle tables for include/jrc.h
 #include "jrc_internal.h"
+#include <cstring>
 
 #include <dlfcn.h>
 
@@ -60,8 +61,21 @@ extern "C" int jrc_create(int device, jrc_ctx** out)
         return JRC_ERR_NO_DEVICE;
     }
     if (hipDeviceGetAttribute(&ctx->n_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ctx->n_cus <= 0) ctx->n_cus = 256;
-    ctx->n_xcd = ctx->n_cus >= 64 ? ctx->n_cus / 32 : 1;
+    if (const char* e = getenv("JRC_NCUS")) { const int v = atoi(e); if (v >= 1 && v <= ctx->n_cus) ctx->n_cus = v; }   // experiments: size the resident grids for fewer CUs
+    // XCDs = L2 domains consecutive workgroups are dealt over.  CUs per XCD is a property of the part, not of the CU count: 32 on gfx950
+    // (MI355X / MI350X: 8 x 32; DPX / QPX / CPX partitions expose 4 / 2 / 1 of them), 38 on gfx942 (MI300X 8 x 38, MI300A 6 x 38).  An unknown
+    // architecture gets 1: results never depend on it, and a wrong guess would split a frame's workgroups over several L2s for nothing.
+    {
+        hipDeviceProp_t prop;
+        int per_xcd = 0;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+            if (strncmp(prop.gcnArchName, "gfx950", 6) == 0) per_xcd = 32;
+            else if (strncmp(prop.gcnArchName, "gfx942", 6) == 0) per_xcd = 38;
+        }
+        ctx->n_xcd = (per_xcd && ctx->n_cus % per_xcd == 0) ? ctx->n_cus / per_xcd : 1;
+    }
     if (const char* e = getenv("JRC_XCDS")) { const int v = atoi(e); if (v >= 1 && v <= 64) ctx->n_xcd = v; }
+    { int khz = 0; if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) ctx->wall_clock_khz = khz; }
     if (const char* e = getenv("JRC_CHANEST_CHUNK")) ctx->tune.chanest_chunk = atoi(e);
     ctx->tune.chanest_x1 = getenv("JRC_CHANEST_X1") != nullptr;
     ctx->tune.fd_serial = getenv("JRC_FD_SERIAL") != nullptr;
@@ -72,6 +86,8 @@ extern "C" int jrc_create(int device, jrc_ctx** out)
     ctx->tune.rd_generic = getenv("JRC_RD_GENERIC") != nullptr;
     ctx->tune.rd_fold = getenv("JRC_RD_FOLD") != nullptr;
     if (const char* e = getenv("JRC_RA_PACE")) ctx->tune.ra_pace = (int)strtol(e, nullptr, 0);
+    if (const char* e = getenv("JRC_DETECT_EXP")) ctx->tune.detect_exp = atoi(e);
+    if (const char* e = getenv("JRC_RA_OFFERED_TBPS")) ctx->tune.ra_offered_tbps = atof(e);
     if (const char* e = getenv("JRC_DEMOD_SPR")) ctx->tune.demod_spr = atoi(e);
     if (const char* e = getenv("JRC_EQ_WPE")) ctx->tune.eq_wpe = atoi(e);
     if (const char* e = getenv("JRC_EQ_THREADS")) ctx->tune.eq_threads = atoi(e);

@@ -33,6 +33,7 @@ struct jrc_ctx {
     // XCDs (L2 domains) workgroups are dealt over round-robin: 8 on an MI355X in SPX mode (256 CUs), 1 per 32 CUs in the smaller
     // partition modes; JRC_XCDS overrides.  Only locality depends on it (a frame's workgroups share one L2), never results.
     int n_xcd = 8;
+    int wall_clock_khz = 100000;     // rate of wall_clock64() (hipDeviceAttributeWallClockRate): the unit of the store-pacing word
     // experiment switches, read once in jrc_create (environment JRC_*)
     struct {
         int chanest_chunk = 0;       // JRC_CHANEST_CHUNK: frames per A1 launch (0 = two workgroups per CU)
@@ -44,7 +45,9 @@ struct jrc_ctx {
         bool ra_ref_sum = false;     // JRC_RA_REF_SUM: the estimator's noise sum always by the reference-order double chain (tests)
         bool rd_generic = false;     // JRC_RD_GENERIC: range-Doppler block by block (stock FFTs + transpose)
         bool rd_fold = false;        // JRC_RD_FOLD: range-Doppler with the fold kernel also where the pruned-FFT kernel applies
-        int ra_pace = -1;            // JRC_RA_PACE: store pacing word of the fused range-angle kernel (chain.hip; -1 = by geometry)
+        int ra_pace = -1;            // JRC_RA_PACE: store pacing word of the fused range-angle kernel (chain.hip; -1 = derived, chain_pace)
+        int detect_exp = 0;          // JRC_DETECT_EXP: timing experiments on the detect-only kernel (1: no angle stage, 2: no range-profile stores — both give WRONG RESULTS, timing only; 8: no pruning)
+        double ra_offered_tbps = 0;  // JRC_RA_OFFERED_TBPS: offered store rate the pacing word is derived from (0 = the kernel's measured optimum)
         int demod_spr = 0;           // JRC_DEMOD_SPR: symbols per round (2 or 4) of the A6+A7+A1 kernel (0 = by fft_len)
         int eq_wpe = 0;              // JRC_EQ_WPE: waves per SIMD the equalizer kernel is compiled for (2, 4, 6, 8; 0 = by geometry)
         int eq_threads = 0;          // JRC_EQ_THREADS: equalizer workgroup size (64, 128, 256; 0 = by launch size, -1 = one lane per subcarrier)

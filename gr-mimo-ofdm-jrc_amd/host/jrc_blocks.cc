@@ -1312,16 +1312,27 @@ class ofdm_frame_generator_impl : public ofdm_frame_generator {
     int d_fft_len;
     std::vector<int> d_occ_sizes;
     int d_n_sync;
+    std::string d_len_tag_key;
+    std::vector<std::vector<int>> d_occupied;          // normalised as the reference keeps them (lib/ofdm_frame_generator_impl.cc:83-96): what its getter returns
 
 public:
+    std::string len_tag_key() override { return d_len_tag_key; }
+    const int fft_len() override { return d_fft_len; }
+    std::vector<std::vector<int>> occupied_carriers() override { return d_occupied; }
     ofdm_frame_generator_impl(int fft_len, const std::vector<std::vector<int>>& occupied_carriers, const std::vector<std::vector<int>>& pilot_carriers,
                               const std::vector<std::vector<gr_complex>>& pilot_symbols, const std::vector<std::vector<gr_complex>>& sync_words,
                               int, const std::string& len_tag_key, const bool output_is_shifted)
         : jrc_rt::tagged_stream_block("ofdm_frame_generator", jrc_rt::io_signature::make(1, 1, sizeof(gr_complex)),
                                       jrc_rt::io_signature::make(1, 1, sizeof(gr_complex) * fft_len), len_tag_key),
-          d_fft_len(fft_len), d_n_sync((int)sync_words.size())
+          d_fft_len(fft_len), d_n_sync((int)sync_words.size()), d_len_tag_key(len_tag_key), d_occupied(occupied_carriers)
     {
         if (occupied_carriers.empty()) throw std::invalid_argument("Occupied carriers must be of type vector of vector i.e. ((),).");   // :77-82
+        for (auto& set : d_occupied)                                                                                                     // :83-96
+            for (auto& c : set) {
+                if (c < 0) c += fft_len;
+                if (c > fft_len || c < 0) throw std::invalid_argument("data carrier index out of bounds");
+                if (output_is_shifted) c = (c + fft_len / 2) % fft_len;
+            }
         if (pilot_carriers.empty()) throw std::invalid_argument("Pilot carriers must be of type vector of vector i.e. ((),).");
         if (pilot_symbols.empty()) throw std::invalid_argument("Pilot symbols must be of type vector of vector i.e. ((),).");
         for (auto& w : sync_words) if (w.size() != (unsigned)fft_len) throw std::invalid_argument("sync words must be fft length");      // :126-130

@@ -28,14 +28,31 @@
 
 #include "jrc_block_runtime.h"
 
+// export decoration of the reference's public classes (include/mimo_ofdm_jrc/api.h:27-31): the GNU Radio build takes it from
+// <gnuradio/attributes.h>, exactly as api.h does; the stand-alone test runtime needs none
+#ifndef MIMO_OFDM_JRC_API
+#ifdef JRC_WITH_GNURADIO
+#include <gnuradio/attributes.h>
+#ifdef gnuradio_mimo_ofdm_jrc_EXPORTS
+#define MIMO_OFDM_JRC_API __GR_ATTR_EXPORT
+#else
+#define MIMO_OFDM_JRC_API __GR_ATTR_IMPORT
+#endif
+#else
+#define MIMO_OFDM_JRC_API
+#endif
+#endif
+
+// the global enums of the reference's public headers (mimo_ofdm_equalizer.h:27-36, stream_encoder.h:27-39)
 enum ChannelEstimator { LS = 0, STA = 1 };
+enum Modulation { BPSK = 0, QPSK = 1, QAM16 = 2 };
 enum MCS : uint8_t { BPSK_1_2 = 0, BPSK_3_4 = 1, QPSK_1_2 = 2, QPSK_3_4 = 3, QAM16_1_2 = 4, QAM16_3_4 = 5 };
 enum PACKET_TYPE : uint8_t { NDP = 1, DATA = 2 };
 
 namespace gr {
 namespace mimo_ofdm_jrc {
 
-class mimo_ofdm_radar : virtual public jrc_rt::block {
+class MIMO_OFDM_JRC_API mimo_ofdm_radar : virtual public jrc_rt::block {
 public:
     typedef JRC_SPTR<mimo_ofdm_radar> sptr;
     static sptr make(int fft_len, int N_tx, int N_rx, int N_sym, int N_pre, bool background_removal,
@@ -50,7 +67,7 @@ public:
 // mimo_ofdm_radar (N_tx + N_rx streams of fft_len vectors, `packet_len`), same `params` message port and log file as
 // range_angle_estimator; no stream output — the range-angle map stays on the device.  Every frame offered in a scheduler turn goes
 // through the host-fed pipeline (jrc_chain_feed_*): batches in flight on their own streams, results published in frame order.
-class radar_chain : virtual public jrc_rt::block {
+class MIMO_OFDM_JRC_API radar_chain : virtual public jrc_rt::block {
 public:
     typedef JRC_SPTR<radar_chain> sptr;
     static sptr make(int fft_len, int N_tx, int N_rx, int N_sym, int N_pre, int interp_range, int interp_angle, bool enable_tx_interleave,
@@ -65,13 +82,13 @@ public:
     virtual int n_devices() const = 0;                                     // GPUs the block feeds (environment JRC_DEVICES=0,1,...)
 };
 
-class matrix_transpose : virtual public jrc_rt::tagged_stream_block {
+class MIMO_OFDM_JRC_API matrix_transpose : virtual public jrc_rt::tagged_stream_block {
 public:
     typedef JRC_SPTR<matrix_transpose> sptr;
     static sptr make(int input_len, int output_len, int interp_factor, bool debug, std::string len_key = "packet_len");
 };
 
-class range_angle_estimator : virtual public jrc_rt::tagged_stream_block {
+class MIMO_OFDM_JRC_API range_angle_estimator : virtual public jrc_rt::tagged_stream_block {
 public:
     typedef JRC_SPTR<range_angle_estimator> sptr;
     static sptr make(int vlen, std::vector<float> range_bins, std::vector<float> angle_bins, float noise_discard_range_m,
@@ -83,13 +100,13 @@ public:
     virtual void set_stats_record(bool stats_record) = 0;
 };
 
-class ofdm_cyclic_prefix_remover : virtual public jrc_rt::tagged_stream_block {
+class MIMO_OFDM_JRC_API ofdm_cyclic_prefix_remover : virtual public jrc_rt::tagged_stream_block {
 public:
     typedef JRC_SPTR<ofdm_cyclic_prefix_remover> sptr;
     static sptr make(int fft_len, int cp_len, std::string len_key = "packet_len");
 };
 
-class fft_peak_detect : virtual public jrc_rt::tagged_stream_block {
+class MIMO_OFDM_JRC_API fft_peak_detect : virtual public jrc_rt::tagged_stream_block {
 public:
     typedef JRC_SPTR<fft_peak_detect> sptr;
     static sptr make(int samp_rate, float interp_factor, float threshold, int samp_protect, std::vector<float> max_freq,
@@ -99,7 +116,7 @@ public:
     virtual void set_max_freq(std::vector<float> freq) = 0;
 };
 
-class mimo_ofdm_equalizer : virtual public jrc_rt::block {
+class MIMO_OFDM_JRC_API mimo_ofdm_equalizer : virtual public jrc_rt::block {
 public:
     typedef JRC_SPTR<mimo_ofdm_equalizer> sptr;
     virtual void set_estimator(ChannelEstimator algo) = 0;
@@ -113,7 +130,7 @@ public:
                      const std::string& chan_est_file, const std::string& comm_log_file, bool stats_record, bool debug);
 };
 
-class mimo_precoder : virtual public jrc_rt::tagged_stream_block {
+class MIMO_OFDM_JRC_API mimo_precoder : virtual public jrc_rt::tagged_stream_block {
 public:
     typedef JRC_SPTR<mimo_precoder> sptr;
     static sptr make(int fft_len, int N_tx, int N_ss, const std::vector<int>& data_carriers,
@@ -128,7 +145,7 @@ public:
     virtual void set_phased_steering(bool phased_steering) = 0;
 };
 
-class target_simulator : virtual public jrc_rt::tagged_stream_block {
+class MIMO_OFDM_JRC_API target_simulator : virtual public jrc_rt::tagged_stream_block {
 public:
     typedef JRC_SPTR<target_simulator> sptr;
     static sptr make(std::vector<float> range, std::vector<float> velocity, std::vector<float> rcs, std::vector<float> azimuth,
@@ -140,21 +157,21 @@ public:
                                float self_coupling_db, bool rndm_phaseshift, bool self_coupling) = 0;
 };
 
-class stream_encoder : virtual public jrc_rt::block {
+class MIMO_OFDM_JRC_API stream_encoder : virtual public jrc_rt::block {
 public:
     typedef JRC_SPTR<stream_encoder> sptr;
     static sptr make(MCS mod_encode, int data_len, int N_ss_radar, bool debug);
     virtual void set_mcs(MCS mod_encode) = 0;
 };
 
-class stream_decoder : virtual public jrc_rt::block {
+class MIMO_OFDM_JRC_API stream_decoder : virtual public jrc_rt::block {
 public:
     typedef JRC_SPTR<stream_decoder> sptr;
     static sptr make(int n_data_carriers, const std::string& comm_log_file, bool stats_record, bool debug);
     virtual void set_stats_record(bool stats_record) = 0;
 };
 
-class moving_avg : virtual public jrc_rt::sync_block {
+class MIMO_OFDM_JRC_API moving_avg : virtual public jrc_rt::sync_block {
 public:
     typedef JRC_SPTR<moving_avg> sptr;
     static sptr make(int length, float scale, int max_iter, bool debug);
@@ -165,27 +182,30 @@ public:
     virtual void set_scale(float scale) = 0;
 };
 
-class ofdm_frame_generator : virtual public jrc_rt::tagged_stream_block {
+class MIMO_OFDM_JRC_API ofdm_frame_generator : virtual public jrc_rt::tagged_stream_block {
 public:
     typedef JRC_SPTR<ofdm_frame_generator> sptr;
+    virtual std::string len_tag_key() = 0;
+    virtual const int fft_len() = 0;
+    virtual std::vector<std::vector<int>> occupied_carriers() = 0;
     static sptr make(int fft_len, const std::vector<std::vector<int>>& occupied_carriers, const std::vector<std::vector<int>>& pilot_carriers,
                      const std::vector<std::vector<gr_complex>>& pilot_symbols, const std::vector<std::vector<gr_complex>>& sync_words,
                      int ltf_len, const std::string& len_tag_key = "packet_len", const bool output_is_shifted = true);
 };
 
-class zero_pad : virtual public jrc_rt::tagged_stream_block {
+class MIMO_OFDM_JRC_API zero_pad : virtual public jrc_rt::tagged_stream_block {
 public:
     typedef JRC_SPTR<zero_pad> sptr;
     static sptr make(bool debug, unsigned int pad_front, unsigned int pad_tail);
 };
 
-class frame_detector : virtual public jrc_rt::block {
+class MIMO_OFDM_JRC_API frame_detector : virtual public jrc_rt::block {
 public:
     typedef JRC_SPTR<frame_detector> sptr;
     static sptr make(int fft_len, int cp_len, double threshold, unsigned int min_n_peaks, unsigned int ignore_gap, bool debug);
 };
 
-class frame_sync : virtual public jrc_rt::block {
+class MIMO_OFDM_JRC_API frame_sync : virtual public jrc_rt::block {
 public:
     typedef JRC_SPTR<frame_sync> sptr;
     static sptr make(int fft_len, int cp_len, unsigned int sync_length, std::vector<gr_complex> ltf_seq_time, bool debug);

@@ -84,7 +84,7 @@ def test_chain_config_b(jrc, ctx):
 
 def test_chain_config_d_eight_targets(jrc, ctx):
     from jrc_amd import synth
-    check(jrc, ctx, synth.config_D(), 8, 16, 3, n_check=2)
+    check(jrc, ctx, synth.config_D(), 8, 16, 3, n_check=3)          # every frame of the batch against the oracle
 
 
 @pytest.mark.parametrize("T,R,N,S,Ir,Ia,interleave", [(2, 1, 128, 3, 4, 8, False), (2, 2, 64, 2, 2, 2, True),

@@ -233,6 +233,43 @@ def test_detect_only_and_power_map_on_the_wide_kernel_at_smaller_fft_len(jrc, ct
     assert np.array_equal(pw.reshape(ref.shape), ref)
 
 
+@pytest.mark.parametrize("case", ["noise_only", "two_equal_targets", "exact_duplicate_rows", "all_zero", "weak_target_in_noise", "late_peak"])
+@pytest.mark.parametrize("cfg,F", [("B", 6), ("B", 300), ("D", 3)])
+def test_detect_only_bound_pruning_keeps_the_records_exact(jrc, ctx, cfg, F, case):
+    """detect-only mode skips the angle transforms of range bins whose bound (sum_p |R[p][k]|)^2 lies below the running maximum
+    (range_angle_wide_kernel, MODE 1).  Inputs chosen against that shortcut: nothing to prune with (noise only), maxima that tie to the
+    last bit in different range bins (two equal targets; frames whose RX ports are exact copies, so map cells repeat bit for bit), an
+    all-zero frame (every bound equals the maximum, 0), a target a few dB over the noise, and a peak in the last class / last bins of
+    the scan order.  The records must stay byte-identical to map mode (lib/range_angle_estimator_impl.cc:137-151: first maximum in
+    scan order)."""
+    from jrc_amd import synth
+    sc0 = {"B": synth.config_B, "D": synth.config_D}[cfg]()
+    rng = np.random.default_rng(sum(map(ord, cfg + case)) * 1000 + F)
+    R_max = 3e8 * sc0.N / (2 * sc0.fs)
+    if case == "two_equal_targets":
+        sc = synth.Scenario(sc0.N, sc0.T, sc0.R, sc0.S, targets=[(0.2 * R_max, 20.0, 0.0, 100.0), (0.55 * R_max, -20.0, 0.0, 100.0)])
+    elif case == "late_peak":
+        sc = synth.Scenario(sc0.N, sc0.T, sc0.R, sc0.S, targets=[(0.9995 * R_max, 58.0, 0.0, 100.0)])
+    else:
+        sc = synth.Scenario(sc0.N, sc0.T, sc0.R, sc0.S, targets=[(0.31 * R_max, -12.0, 0.0, 100.0)])
+    nd = min(F, 3)
+    base = synth.make_frames(sc, nd)
+    if case == "noise_only":
+        base[:, sc.T:] = (rng.standard_normal(base[:, sc.T:].shape) + 1j * rng.standard_normal(base[:, sc.T:].shape)).astype(np.complex64) * 1e-3
+    elif case == "weak_target_in_noise":
+        sig = np.abs(base[:, sc.T:]).mean()
+        base[:, sc.T:] += ((rng.standard_normal(base[:, sc.T:].shape) + 1j * rng.standard_normal(base[:, sc.T:].shape)) * 6.0 * sig).astype(np.complex64)
+    elif case == "exact_duplicate_rows":
+        base[:, sc.T + 1:] = base[:, sc.T:sc.T + 1]            # every RX port carries the same samples: the angle axis has exact repeats
+    elif case == "all_zero":
+        base[:] = 0
+    frames = np.concatenate([base] * (F // nd + 1))[:F]
+    if case != "all_zero":
+        frames = frames * (1.0 + 0.5 * (np.arange(F, dtype=np.float32) % 7))[:, None, None, None]
+    full, det, again, res = _both_modes(jrc, ctx, sc, 8, 16, F, frames=frames.astype(np.complex64))
+    assert det == full and again == full
+
+
 def _shapes(n, seed=77):
     rng = np.random.default_rng(seed)
     out = []

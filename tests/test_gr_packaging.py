@@ -86,6 +86,66 @@ def test_make_signature_equals_the_reference(blk):
         assert n_call <= len(ours), (blk, n_call, len(ours))
 
 
+def _class_body(header_text, cls):
+    m = re.search(r"class\s+(?:\w+\s+)?%s\s*:[^{]*\{(.*?)\n\s*\};" % cls, header_text, flags=re.S)
+    assert m, cls
+    return m.group(1)
+
+
+def _virtuals(header_text, cls):
+    """the pure-virtual members of class `cls` (setters / getters of the public interface) as normalised 'ret name(types) [const]' strings"""
+    out = []
+    for ret, name, args, const in re.findall(r"virtual\s+([\w:<>\s]+?)\s+(\w+)\s*\(([^)]*)\)\s*(const)?\s*=\s*0\s*;", _class_body(header_text, cls)):
+        types = []
+        for a in [x for x in args.split(",") if x.strip()]:
+            a = re.sub(r"\s+", " ", a.split("=")[0].strip())
+            a = re.sub(r"\s*([&*<>,])\s*", r"\1", a)
+            types.append(re.sub(r"(\w+)$", "", a).strip().replace("std::", ""))
+        out.append("%s %s(%s)%s" % (re.sub(r"\s+", " ", ret).replace("std::", ""), name, ",".join(types), " const" if const else ""))
+    return sorted(out)
+
+
+def _enums(header_text):
+    """{enum name: [(enumerator, value), ...]} of the global enums a header declares"""
+    out = {}
+    for name, body in re.findall(r"enum\s+(\w+)\s*(?::\s*\w+\s*)?\{([^}]*)\}", header_text):
+        vals, nxt = [], 0
+        for item in [x.strip() for x in body.split(",") if x.strip()]:
+            k, _, v = item.partition("=")
+            nxt = int(v.strip(), 0) if v.strip() else nxt
+            vals.append((k.strip(), nxt))
+            nxt += 1
+        out[name] = vals
+    return out
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "include")), reason="reference tree not present (GPU box): compared in the build container")
+@pytest.mark.parametrize("blk", BLOCKS)
+def test_setters_and_class_decoration_equal_the_reference(blk):
+    """beyond make(): every pure-virtual member of the reference's public class (set_*, getters) is declared here with the same
+    signature, and the class carries the MIMO_OFDM_JRC_API decoration"""
+    ours_h, ref_h = _strip_comments(_read(HOST, "jrc_blocks.h")), _strip_comments(_read(REF, "include", "mimo_ofdm_jrc", blk + ".h"))
+    assert _virtuals(ours_h, blk) == _virtuals(ref_h, blk), blk
+    assert re.search(r"class\s+MIMO_OFDM_JRC_API\s+%s\s*:" % blk, ours_h) and re.search(r"class\s+MIMO_OFDM_JRC_API\s+%s\s*:" % blk, ref_h)
+    base_o = re.search(r"class\s+MIMO_OFDM_JRC_API\s+%s\s*:\s*virtual\s+public\s+(?:jrc_rt|gr)::(\w+)" % blk, ours_h).group(1)
+    base_r = re.search(r"class\s+MIMO_OFDM_JRC_API\s+%s\s*:\s*virtual\s+public\s+gr::(\w+)" % blk, ref_h).group(1)
+    assert base_o == base_r, (blk, base_o, base_r)         # gr::block / gr::sync_block / gr::tagged_stream_block, as the reference's
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "include")), reason="reference tree not present (GPU box): compared in the build container")
+def test_public_enums_equal_the_reference():
+    """ChannelEstimator, Modulation (mimo_ofdm_equalizer.h:27-36), MCS, PACKET_TYPE (stream_encoder.h:27-39): same names, same values"""
+    ours = _enums(_strip_comments(_read(HOST, "jrc_blocks.h")))
+    ref = {}
+    for f in ("mimo_ofdm_equalizer.h", "stream_encoder.h"):
+        ref.update(_enums(_strip_comments(_read(REF, "include", "mimo_ofdm_jrc", f))))
+    assert set(ref) == {"ChannelEstimator", "Modulation", "MCS", "PACKET_TYPE"}
+    for name, vals in ref.items():
+        assert ours.get(name) == vals, (name, ours.get(name), vals)
+    hdr = _read(HOST, "jrc_blocks.h")
+    assert "#define MIMO_OFDM_JRC_API __GR_ATTR_EXPORT" in hdr and "gnuradio_mimo_ofdm_jrc_EXPORTS" in hdr     # api.h:27-31
+
+
 def test_cmake_and_swig_cover_what_the_tree_builds():
     import importlib
     jb = importlib.import_module("gr-mimo-ofdm-jrc_amd.build")
@@ -96,7 +156,7 @@ def test_cmake_and_swig_cover_what_the_tree_builds():
         assert flag in cm and flag in jb.HIPCC_FLAGS
     assert "JRC_WITH_GNURADIO" in cm and "gnuradio-mimo_ofdm_jrc" in cm
     hdr = _strip_comments(_read(HOST, "jrc_blocks.h"))
-    classes = re.findall(r"class\s+(\w+)\s*:\s*virtual\s+public\s+jrc_rt::", hdr)
+    classes = re.findall(r"class\s+(?:MIMO_OFDM_JRC_API\s+)?(\w+)\s*:\s*virtual\s+public\s+jrc_rt::", hdr)
     swig = _read(ROOT, "gr", "swig", "mimo_ofdm_jrc_swig.i")
     wrapped = re.findall(r"GR_SWIG_BLOCK_MAGIC2\(mimo_ofdm_jrc,\s*(\w+)\)", swig)
     assert sorted(classes) == sorted(wrapped)

@@ -67,9 +67,10 @@ def radar_with_demod(cfg="B", F=256):
                 frames_per_s_separate_demod=F / t_unfused, ms_chain_only=t_chain * 1e3, frames_per_s_chain_only=F / t_chain)
 
 
-def detect_only(cfg="B", F=None):
+def detect_only(cfg="B", F=None, noise_only=False):
     """detect-only chain mode (SURVEY §8(d) 'if the map is not materialised'): A1 -> fused transforms + arg-max without map stores ->
-    noise-window rows -> estimator epilogue; algorithmic bytes per frame = inputs + the 48-byte result"""
+    noise-window rows -> estimator epilogue; algorithmic bytes per frame = inputs + the 48-byte result.
+    noise_only: RX ports hold noise alone — the worst case of the bound-pruned angle stage (nothing stands out, little is skipped)"""
     sc = {"B": synth.config_B, "D": synth.config_D}[cfg]()
     F = F or (512 if cfg == "B" else 256)
     Ir, Ia, P = 8, 16, sc.T * sc.R
@@ -78,6 +79,9 @@ def detect_only(cfg="B", F=None):
     chain = jrc_amd.RadarChain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb, ab, 2.4, 14.36, 15.0, 0.0, max_frames=F, ctx=ctx)
     bufs = chain.alloc(F, "cuda:0")
     fr = synth.make_frames(sc, 8)
+    if noise_only:
+        g = np.random.default_rng(5)
+        fr[:, sc.T:] = ((g.standard_normal(fr[:, sc.T:].shape) + 1j * g.standard_normal(fr[:, sc.T:].shape)) * 1e-3).astype(np.complex64)
     hf = torch.from_numpy(fr.view(np.float32).reshape((8,) + tuple(bufs["frames"].shape[1:])))
     for f0 in range(0, F, 8):
         bufs["frames"][f0:f0 + 8].copy_(hf[:min(8, F - f0)])
@@ -97,7 +101,7 @@ def detect_only(cfg="B", F=None):
     t = timed(lambda: chain.run(bufs, F))
     kt = chain.get_timing()
     alg = F * ((sc.T + sc.R) * sc.S * sc.N * 8 + 48)
-    return dict(what="detect-only chain (no map stored; results bit-identical to map mode), config %s, %d frames per step" % (cfg, F),
+    return dict(what="detect-only chain (no map stored; results bit-identical to map mode), config %s, %d frames per step%s" % (cfg, F, ", NOISE-ONLY frames (worst case of the pruned angle stage)" if noise_only else ""),
                 frames_per_step=F, ms_per_step=t * 1e3, frames_per_s=F / t, results_equal_map_mode=bool(same),
                 algorithmic_bytes_per_frame=alg // F, GBps_algorithmic=alg / t / 1e9, frac_of_hbm_peak=alg / t / 1e9 / 8000.0,
                 kernels_ms={"radar_chanest": kt["radar_chanest"], "fused_detect_plus_window": kt["range_angle_fused"], "ra_finalize": kt["ra_finalize"]},
@@ -295,14 +299,18 @@ def equalizer_config_c(n_frames=2048, lanes=4, S=64, N=256):
 if __name__ == "__main__":
     # the two probes that run as child processes go first: once this process holds a GPU context they would time-slice with it
     only = os.environ.get("JRC_BENCH_EXTRA_ONLY")
-    if only == "detect":
-        print(json.dumps(detect_only("B"))); print(json.dumps(detect_only("D"))); print(json.dumps(power_map("B"))); print(json.dumps(power_map("D"))); sys.exit(0)
-    if only == "equalizer":
-        print(json.dumps(equalizer_config_c())); sys.exit(0)
-    if only == "demod":
-        print(json.dumps(radar_with_demod("B", 512))); print(json.dumps(radar_with_demod("D", 256))); sys.exit(0)
-    if only == "comm":
-        print(json.dumps(comm_rx_chain())); print(json.dumps(equalizer_config_c())); print(json.dumps(precoder_config_c())); sys.exit(0)
+    LEGS = {"detectB": lambda: detect_only("B"), "detectB_noise": lambda: detect_only("B", noise_only=True), "detectD": lambda: detect_only("D"),
+            "detectD_noise": lambda: detect_only("D", noise_only=True), "powerB": lambda: power_map("B"), "powerD": lambda: power_map("D"),
+            "equalizer": equalizer_config_c, "precoder": precoder_config_c, "rdD": lambda: range_doppler("D", 16), "rdB": lambda: range_doppler("B", 64),
+            "demodB": lambda: radar_with_demod("B", 512), "demodD": lambda: radar_with_demod("D", 256), "comm_rx": comm_rx_chain,
+            "simB": lambda: simulated_chain("B", 64), "simD": lambda: simulated_chain("D", 8)}
+    GROUPS = {"detect": ["detectB", "detectB_noise", "detectD", "detectD_noise", "powerB", "powerD"], "demod": ["demodB", "demodD"],
+              "comm": ["comm_rx", "equalizer", "precoder"]}
+    if only:
+        for name in only.split(","):
+            for leg in GROUPS.get(name, [name]):
+                print(json.dumps(LEGS[leg]()))
+        sys.exit(0)
     for fn in (sync_front_end, comm_rx_chain, lambda: detect_only("B"), lambda: detect_only("D"), lambda: radar_with_demod("B", 512), lambda: radar_with_demod("D", 256), precoder_config_c, lambda: range_doppler("D", 8), lambda: range_doppler("B", 64),
                lambda: simulated_chain("B", 64), lambda: simulated_chain("D", 8), equalizer_config_c):
         print(json.dumps(fn()))
