@@ -148,6 +148,8 @@ def load(build_if_missing=False):
     L.jrc_chain_feed_set_write_map.argtypes = [_vp, C.c_int]
     L.jrc_chain_feed_create_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(ChainCfg), _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]
     L.jrc_chain_feed_n_devices.argtypes = [_vp]
+    L.jrc_chain_feed_last_error.argtypes = [_vp]
+    L.jrc_chain_feed_last_error.restype = C.c_char_p
     L.jrc_chain_feed_submit_many.argtypes = [_vp, C.POINTER(_vp), C.POINTER(C.c_int), C.c_int]
     _lib = L
     return L
@@ -562,7 +564,10 @@ class ChainFeed:
                  graph=False, ctx=None, devices=None):
         """devices=[0, 1, ...]: one host process feeds several GPUs (jrc_chain_feed_create_multi): `n_slots` slots per device, batch k on
         devices[k % len(devices)], results in submission order"""
-        self.ctx = ctx or default_context()
+        # a multi-device feed owns one context per listed GPU: no default context (on device 0) is opened for it
+        self.ctx = None if devices else (ctx or default_context())
+        self.lib = self.ctx.lib if self.ctx is not None else load()
+        self.h = None
         self.cfg = ChainCfg(fft_len, N_tx, N_rx, N_sym, N_pre, interp_range, interp_angle, int(enable_tx_interleave),
                             n_items if n_items is not None else N_pre + N_sym,
                             noise_discard_range_m, noise_discard_angle_deg, snr_threshold, power_threshold)
@@ -572,7 +577,7 @@ class ChainFeed:
         ab = np.ascontiguousarray(angle_bins, np.float32)
         assert len(rb) == self.NR and len(ab) == self.NA
         h = _vp()
-        L = self.ctx.lib
+        L = self.lib
         if devices:
             dv = (C.c_int * len(devices))(*devices)
             st = L.jrc_chain_feed_create_multi(dv, len(devices), C.byref(self.cfg), _ptr(rb), _ptr(ab), n_slots, frames_per_slot,
@@ -587,6 +592,13 @@ class ChainFeed:
         self.frame_bytes = L.jrc_chain_feed_frame_bytes(h)
         self.map_bytes = L.jrc_chain_feed_map_bytes(h)
 
+    def _check(self, st):
+        """negative status -> JrcError carrying the FEED's last error (its contexts are its own: jrc_chain_feed_last_error)"""
+        if st < 0:
+            msg = self.lib.jrc_chain_feed_last_error(self.h).decode() or self.lib.jrc_strerror(st).decode()
+            raise JrcError(st, msg)
+        return st
+
     def frame_shape(self):
         c = self.cfg
         return (c.N_tx + c.N_rx, c.n_items, c.fft_len)
@@ -594,7 +606,7 @@ class ChainFeed:
     def acquire(self):
         """the next slot's pinned staging as a numpy complex64 array [frames_per_slot, T+R, n_items, fft_len] to fill in place"""
         p = _vp()
-        self.ctx.check(self.ctx.lib.jrc_chain_feed_acquire(self.h, C.byref(p)))
+        self._check(self.lib.jrc_chain_feed_acquire(self.h, C.byref(p)))
         n = self.frames_per_slot * self.frame_bytes // 8
         buf = (C.c_float * (2 * n)).from_address(p.value)
         return np.frombuffer(buf, dtype=np.complex64).reshape((self.frames_per_slot,) + self.frame_shape())
@@ -603,12 +615,12 @@ class ChainFeed:
         """frames: complex64 [n, T+R, n_items, fft_len] in host memory, or None after acquire() + in-place fill"""
         if frames is None:
             n = self.frames_per_slot if n_frames is None else n_frames
-            self.ctx.check(self.ctx.lib.jrc_chain_feed_submit(self.h, None, n))
+            self._check(self.lib.jrc_chain_feed_submit(self.h, None, n))
             return
         fr = np.ascontiguousarray(frames, np.complex64)
         n = fr.shape[0] if n_frames is None else n_frames
         assert fr.size * 8 >= n * self.frame_bytes
-        self.ctx.check(self.ctx.lib.jrc_chain_feed_submit(self.h, _ptr(fr), n))
+        self._check(self.lib.jrc_chain_feed_submit(self.h, _ptr(fr), n))
 
     def submit_many(self, batches):
         """batches: list of complex64 arrays [n_k, T+R, n_items, fft_len]; one per free slot at most; staged and enqueued by the per-device
@@ -616,10 +628,10 @@ class ChainFeed:
         keep = [np.ascontiguousarray(b, np.complex64) for b in batches]
         ptrs = (_vp * len(keep))(*[_ptr(b) for b in keep])
         ns = (C.c_int * len(keep))(*[b.shape[0] for b in keep])
-        self.ctx.check(self.ctx.lib.jrc_chain_feed_submit_many(self.h, ptrs, ns, len(keep)))
+        self._check(self.lib.jrc_chain_feed_submit_many(self.h, ptrs, ns, len(keep)))
 
     def n_devices(self):
-        return self.ctx.lib.jrc_chain_feed_n_devices(self.h)
+        return self.lib.jrc_chain_feed_n_devices(self.h)
 
     def collect(self, want_maps=False):
         """oldest batch in flight -> (list of RaResult, maps or None); ([], None) when nothing is in flight"""
@@ -628,29 +640,29 @@ class ChainFeed:
         maps = None
         if want_maps and self.maps_per_slot:
             maps = np.empty((self.maps_per_slot, self.NR, self.NA), np.complex64)
-        r = self.ctx.lib.jrc_chain_feed_collect(self.h, arr, _ptr(maps) if maps is not None else None, C.byref(n))
-        self.ctx.check(min(r, 0))
+        r = self.lib.jrc_chain_feed_collect(self.h, arr, _ptr(maps) if maps is not None else None, C.byref(n))
+        self._check(min(r, 0))
         if maps is not None:
             maps = maps[:min(n.value, self.maps_per_slot)]
         return list(arr[:n.value]), maps
 
     def set_background(self, background_removal, background_recording, record_len):
-        self.ctx.check(self.ctx.lib.jrc_chain_feed_set_background(self.h, int(background_removal), int(background_recording), record_len))
+        self._check(self.lib.jrc_chain_feed_set_background(self.h, int(background_removal), int(background_recording), record_len))
 
     def set_write_map(self, write_map):
-        self.ctx.check(self.ctx.lib.jrc_chain_feed_set_write_map(self.h, int(write_map)))
+        self._check(self.lib.jrc_chain_feed_set_write_map(self.h, int(write_map)))
 
     def pending(self):
-        return self.ctx.lib.jrc_chain_feed_pending(self.h)
+        return self.lib.jrc_chain_feed_pending(self.h)
 
     def stats(self):
         g, d = C.c_long(0), C.c_long(0)
-        self.ctx.check(self.ctx.lib.jrc_chain_feed_stats(self.h, C.byref(g), C.byref(d)))
+        self._check(self.lib.jrc_chain_feed_stats(self.h, C.byref(g), C.byref(d)))
         return dict(graph_replays=g.value, direct_submits=d.value)
 
     def close(self):
         if getattr(self, "h", None):
-            self.ctx.lib.jrc_chain_feed_destroy(self.h)
+            self.lib.jrc_chain_feed_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -1104,6 +1104,16 @@ static int chain_background_step(jrc_chain* ch, int n_frames, const float2* raw,
     return JRC_OK;
 }
 
+// the raw-estimate buffer of a chain that subtracts the background.  The switch (bg->removal) belongs to the shared state, so any chain of
+// the group may have turned it on: each chain makes sure of its own buffer where it is about to use it (a recording-only owner has none)
+static int chain_ensure_raw(jrc_chain* ch)
+{
+    if (ch->d_raw) return JRC_OK;
+    hipError_t e = hipMalloc((void**)&ch->d_raw, sizeof(float2) * (size_t)ch->P * ch->cfg.fft_len * (size_t)ch->max_frames);
+    if (e != hipSuccess) return jrc_fail(ch->ctx, JRC_ERR_HIP, "background removal: %s", hipGetErrorString(e));
+    return JRC_OK;
+}
+
 extern "C" int jrc_chain_set_background(jrc_chain* ch, int background_removal, int background_recording, int record_len)
 {
     if (!ch || record_len < 0) return JRC_ERR_INVALID_ARG;
@@ -1125,10 +1135,7 @@ extern "C" int jrc_chain_set_background(jrc_chain* ch, int background_removal, i
     } else if (record_len != ch->bg->record_len) {
         return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_set_background: record_len is fixed once the state exists (%d)", ch->bg->record_len);
     }
-    if (background_removal && !ch->d_raw) {
-        hipError_t e = hipMalloc((void**)&ch->d_raw, sizeof(float2) * pn * (size_t)ch->max_frames);
-        if (e != hipSuccess) return jrc_fail(ctx, JRC_ERR_HIP, "jrc_chain_set_background: %s", hipGetErrorString(e));
-    }
+    if (background_removal) JRC_TRY(chain_ensure_raw(ch));
     ch->bg->removal = background_removal != 0;
     ch->bg->recording = background_recording != 0;
     return JRC_OK;
@@ -1170,6 +1177,7 @@ extern "C" int jrc_chain_prime_background_dev(jrc_chain* ch, int n_frames, const
     g.port_stride = (long)c.n_items * c.fft_len;
     g.frame_stride = g.port_stride * (c.N_tx + c.N_rx);
     g.tx_item0 = c.N_pre; g.rx_item0 = c.N_pre; g.interleave = c.enable_tx_interleave;
+    JRC_TRY(chain_ensure_raw(ch));
     JRC_TRY(launch_radar_chanest(ctx, c.N_tx, c.N_rx, (const float2*)d_frames, ch->d_raw, g, n_frames, s));
     return chain_background_step(ch, n_frames, ch->d_raw, nullptr, s);
 }
@@ -1241,7 +1249,7 @@ static int chain_run(jrc_chain* ch, int n_frames, const jrc_cf32* d_frames, cons
     jrc_bg_state* bg = ch->bg;
     const bool bg_sub = bg && bg->removal;
     jrc_cf32* d_est_out = d_chanest;
-    if (bg_sub) d_chanest = (jrc_cf32*)ch->d_raw;
+    if (bg_sub) { JRC_TRY(chain_ensure_raw(ch)); d_chanest = (jrc_cf32*)ch->d_raw; }
     if (d_frames) {
         ChanestGeom g;
         g.N = c.fft_len; g.S = c.N_sym;

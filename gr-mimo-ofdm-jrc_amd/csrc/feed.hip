@@ -72,6 +72,15 @@ struct jrc_chain_feed {
     int n_devices = 1;
 };
 
+// a failure inside one slot's context (a multi-device feed has one per GPU) is repeated in the feed's own, which is where
+// jrc_chain_feed_last_error looks: the caller of a feed never holds the slot contexts
+static int feed_relay(jrc_chain_feed* fd, jrc_ctx* where, int st)
+{
+    if (st < 0 && where && where != fd->ctx) jrc_fail(fd->ctx, st, "%s", jrc_last_error(where));
+    return st;
+}
+#define FEED_TRY(fd, where, expr) do { const int st__ = feed_relay((fd), (where), (expr)); if (st__ < 0) return st__; } while (0)
+
 static void feed_worker_main(jrc_chain_feed::worker* w)
 {
     std::unique_lock<std::mutex> lk(w->m);
@@ -202,6 +211,7 @@ extern "C" int jrc_chain_feed_create_multi(const int* devices, int n_devices, co
 }
 
 extern "C" int jrc_chain_feed_n_devices(const jrc_chain_feed* fd) { return fd ? fd->n_devices : JRC_ERR_INVALID_ARG; }
+extern "C" const char* jrc_chain_feed_last_error(const jrc_chain_feed* fd) { return fd ? jrc_last_error(fd->ctx) : ""; }
 
 extern "C" size_t jrc_chain_feed_frame_bytes(const jrc_chain_feed* fd) { return fd ? fd->frame_elems * sizeof(float2) : 0; }
 extern "C" size_t jrc_chain_feed_map_bytes(const jrc_chain_feed* fd) { return fd ? fd->map_elems * sizeof(float2) : 0; }
@@ -221,9 +231,9 @@ extern "C" int jrc_chain_feed_set_background(jrc_chain_feed* fd, int background_
     if (fd->n_devices > 1 && (background_removal || background_recording))
         return jrc_fail(fd->ctx, JRC_ERR_UNSUPPORTED, "background removal: the frames of one radar stream stay in order on one GPU (one feed per stream; "
                         "shard streams, or blocks primed with jrc_chain_prime_background_dev, over GPUs)");
-    JRC_TRY(jrc_chain_set_background(fd->slots[0].chain, background_removal, background_recording, record_len));
+    FEED_TRY(fd, fd->slots[0].ctx, jrc_chain_set_background(fd->slots[0].chain, background_removal, background_recording, record_len));
     if (!background_removal && !background_recording && jrc_chain_background_size(fd->slots[0].chain) == 0) return JRC_OK;
-    for (int i = 1; i < fd->n_slots; i++) JRC_TRY(jrc_chain_share_background(fd->slots[(size_t)i].chain, fd->slots[0].chain));
+    for (int i = 1; i < fd->n_slots; i++) FEED_TRY(fd, fd->slots[(size_t)i].ctx, jrc_chain_share_background(fd->slots[(size_t)i].chain, fd->slots[0].chain));
     for (auto& s : fd->slots) {          // the history buffers alternate from batch to batch: no fixed graph
         if (s.graph) { (void)hipGraphExecDestroy(s.graph); s.graph = nullptr; }
         s.graph_failed = true;
@@ -237,7 +247,7 @@ extern "C" int jrc_chain_feed_set_write_map(jrc_chain_feed* fd, int write_map)
     if (fd->in_flight) return jrc_fail(fd->ctx, JRC_ERR_INVALID_ARG, "jrc_chain_feed_set_write_map: collect the batches in flight first");
     if (!write_map && fd->maps_per_slot) return jrc_fail(fd->ctx, JRC_ERR_INVALID_ARG, "jrc_chain_feed_set_write_map: the feed copies maps back (maps_per_slot > 0)");
     for (auto& s : fd->slots) {
-        JRC_TRY(jrc_chain_set_write_map(s.chain, write_map));
+        FEED_TRY(fd, s.ctx, jrc_chain_set_write_map(s.chain, write_map));
         if (s.graph) { (void)hipGraphExecDestroy(s.graph); s.graph = nullptr; }      // recorded with the other kernels: record again
     }
     return JRC_OK;
@@ -376,18 +386,30 @@ extern "C" int jrc_chain_feed_submit_many(jrc_chain_feed* fd, const jrc_cf32* co
             w->has_job = true; w->done = false;
             w->cv.notify_all();
         }
+        const int head0 = fd->head;
+        int first_bad = wave;
+        std::vector<int> sts((size_t)wave, JRC_OK);
         for (int k = 0; k < wave; k++) {
-            const int si = (fd->head + k) % fd->n_slots;
+            const int si = (head0 + k) % fd->n_slots;
             auto* w = fd->workers[(size_t)si % fd->workers.size()];
             std::unique_lock<std::mutex> lk(w->m);
             w->cv.wait(lk, [&] { return w->done; });
-            if (w->status != JRC_OK && st_all == JRC_OK) { st_all = w->status; jrc_fail(ctx, st_all, "%s", jrc_last_error(fd->slots[(size_t)si].ctx)); }
+            sts[(size_t)k] = w->status;
+            if (w->status != JRC_OK && st_all == JRC_OK) { st_all = w->status; first_bad = k; jrc_fail(ctx, st_all, "%s", jrc_last_error(fd->slots[(size_t)si].ctx)); }
         }
-        if (st_all != JRC_OK) return st_all;
-        for (int k = 0; k < wave; k++) {
+        // batches ahead of the first failure are in flight like any other: they are marked and will be collected, in order.  A batch BEHIND
+        // it that did launch cannot be (results come back in submission order, and its predecessor never ran): its stream is drained so that
+        // the pinned staging buffer and the slot are free again, and its work is dropped.
+        for (int k = 0; k < first_bad; k++) {
             feed_slot& s = fd->slots[(size_t)fd->head];
             feed_mark_submitted(fd, s, n_frames[done + k], rp[(size_t)k] != 0);
         }
+        for (int k = first_bad + 1; k < wave; k++) {
+            if (sts[(size_t)k] != JRC_OK) continue;
+            feed_slot& s = fd->slots[(size_t)((head0 + k) % fd->n_slots)];
+            if (hipSetDevice(s.ctx->device) == hipSuccess) (void)hipStreamSynchronize(s.stream);
+        }
+        if (st_all != JRC_OK) return st_all;
         done += wave;
     }
     return JRC_OK;
@@ -400,8 +422,11 @@ extern "C" int jrc_chain_feed_collect(jrc_chain_feed* fd, jrc_ra_result* results
     if (fd->in_flight == 0) { if (n_frames) *n_frames = 0; return 0; }
     feed_slot& s = fd->slots[(size_t)fd->tail];
     jrc_ctx* ctx = s.ctx;
-    JRC_BIND(ctx);
-    JRC_HIP(ctx, hipEventSynchronize(s.done));
+    {
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e == hipSuccess) e = hipEventSynchronize(s.done);
+        if (e != hipSuccess) return feed_relay(fd, ctx, jrc_fail(ctx, JRC_ERR_HIP, "jrc_chain_feed_collect: %s", hipGetErrorString(e)));
+    }
     for (int i = 0; i < s.n_frames; i++) {
         results[i] = s.h_results[i];
         // snr_est / published with the host libm's log10f, as jrc_chain_fetch_results does (range_angle_estimator_impl.cc:227)

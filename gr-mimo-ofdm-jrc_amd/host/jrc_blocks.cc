@@ -56,14 +56,15 @@ struct ctx_holder {
         if (st != JRC_OK) throw std::runtime_error(std::string("jrc_create: ") + jrc_strerror(st));
     }
     ~ctx_holder() { jrc_destroy(ctx); }
-    void check(int st) const
+    static void raise(int st, std::string msg)
     {
-        if (st >= 0) return;
-        std::string msg = jrc_last_error(ctx);
         if (msg.empty()) msg = jrc_strerror(st);
         if (st == JRC_ERR_INVALID_ARG) throw std::invalid_argument(msg);
         throw std::runtime_error(msg);
     }
+    void check(int st) const { if (st < 0) raise(st, jrc_last_error(ctx)); }
+    // calls on a feed report through the feed (a multi-GPU feed owns its contexts: this block's context knows nothing of their failures)
+    static void check_feed(const jrc_chain_feed* fd, int st) { if (st < 0) raise(st, jrc_chain_feed_last_error(fd)); }
 };
 
 // Wall-clock stamps of the log files.  Only the two formats are the reference's wire format (lib/utils.cc:302 "%m-%d-%Y %H:%M:%S" for the
@@ -335,7 +336,7 @@ class radar_chain_impl : public radar_chain {
     void collect_one()
     {
         int n = 0;
-        d_c.check(jrc_chain_feed_collect(d_feed, d_res.data(), nullptr, &n));
+        ctx_holder::check_feed(d_feed, jrc_chain_feed_collect(d_feed, d_res.data(), nullptr, &n));
         publish(n);
     }
 
@@ -372,7 +373,7 @@ public:
         if (!getenv("JRC_CHAIN_WRITE_MAP")) (void)jrc_chain_feed_set_write_map(d_feed, 0);
         d_bg_removal = background_removal; d_record_len = record_len;
         if (background_removal || background_recording)
-            d_c.check(jrc_chain_feed_set_background(d_feed, background_removal, background_recording, record_len));
+            ctx_holder::check_feed(d_feed, jrc_chain_feed_set_background(d_feed, background_removal, background_recording, record_len));
         d_res.resize((size_t)d_fpb);
         message_port_register_out(pmt::mp("params"));
         set_tag_propagation_policy(TPP_DONT);
@@ -385,7 +386,7 @@ public:
     void set_background_record(bool background_record) override
     {
         jrc_rt::thread::scoped_lock guard(d_setlock);      // between two general_work calls: every batch of a turn is collected before it returns
-        d_c.check(jrc_chain_feed_set_background(d_feed, d_bg_removal, background_record, d_record_len));
+        ctx_holder::check_feed(d_feed, jrc_chain_feed_set_background(d_feed, d_bg_removal, background_record, d_record_len));
     }
 
     int general_work(int, gr_vector_int& ninput_items, gr_vector_const_void_star& input_items, gr_vector_void_star&) override
@@ -405,8 +406,12 @@ public:
         size_t f = 0;
         while (f < n_frames) {
             jrc_cf32* stage = nullptr;
+            // Batches are staged by this (the scheduler's) thread straight into the slot's PINNED buffer and submitted in place, one after the
+            // other, also when JRC_DEVICES lists several GPUs: what jrc_chain_feed_submit_many's per-device threads parallelise is the
+            // pageable -> pinned staging copy, and there is none here; an in-place submit only enqueues (H2D + kernels + D2H, asynchronous),
+            // so consecutive batches still overlap on their devices.
             if (jrc_chain_feed_pending(d_feed) == d_slots) collect_one();
-            d_c.check(jrc_chain_feed_acquire(d_feed, &stage));
+            ctx_holder::check_feed(d_feed, jrc_chain_feed_acquire(d_feed, &stage));
             int nb = 0;
             for (; f < n_frames && nb < d_fpb; f++) {
                 const long rx0 = (long)(rx_tags[f].offset - nitems_read(d_N_tx)), tx0 = (long)(tx_tags[f + tx_skip].offset - nitems_read(0));
@@ -423,7 +428,7 @@ public:
                 nb++;
             }
             if (nb == 0) break;                                                                       // the next frame is not complete yet
-            d_c.check(jrc_chain_feed_submit(d_feed, nullptr, nb));
+            ctx_holder::check_feed(d_feed, jrc_chain_feed_submit(d_feed, nullptr, nb));
             if (nb < d_fpb) break;
         }
         while (jrc_chain_feed_pending(d_feed) > 0) collect_one();                                     // results of this turn, in frame order

@@ -270,6 +270,8 @@ int    jrc_chain_feed_create_multi(const int* devices, int n_devices, const jrc_
                                    const float* angle_bins, int slots_per_device, int frames_per_slot, int maps_per_slot, int flags,
                                    jrc_chain_feed** feed);
 int    jrc_chain_feed_n_devices(const jrc_chain_feed* feed);
+/* message of the last failing jrc_chain_feed_* call on this feed (a multi-device feed owns its contexts: this is the way to its errors) */
+const char* jrc_chain_feed_last_error(const jrc_chain_feed* feed);
 /* n_batches (<= free slots) batches at once: batch k is staged from h_frames[k] (pageable memory is fine) and enqueued by the host
  * thread of the device it lands on, all devices in parallel; returns when every batch has left the caller's buffers */
 int    jrc_chain_feed_submit_many(jrc_chain_feed* feed, const jrc_cf32* const* h_frames, const int* n_frames, int n_batches);

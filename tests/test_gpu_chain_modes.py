@@ -167,6 +167,53 @@ def test_feed_with_background_shares_one_history(jrc, ctx):
         assert rel_err(maps[f], m) < 5e-6, f
 
 
+def test_background_removal_switched_on_through_a_sharing_chain(jrc, ctx):
+    """the removal switch belongs to the shared state: a chain created recording-only (no raw-estimate buffer of its own) must be able to run
+    after ANOTHER chain of the group turned removal on (it wrote its raw estimates to a null pointer).  Two chains alternating
+    over one stream must produce what ONE chain produces going through the same switches (recording only, then removal on)."""
+    from jrc_amd import synth
+    sc = synth.Scenario(64, 2, 2, 3, targets=[(15.0, -20.0, 0.0, 50.0)])
+    L, n = 3, 4
+    frames = synth.make_frames(sc, 3 * n)
+    raw, _ = _oracle_stream(sc, frames[:n], L, removal=False)     # recording only: the outputs are the raw estimates
+
+    def chanest(b):
+        return b["chanest"].cpu().numpy().view(np.complex64)[..., 0].copy()
+
+    single, _ = _chain(jrc, ctx, sc, 2, 4, n)
+    single.set_background(False, True, L)
+    b1 = single.alloc(n, "cuda:0")
+    want = []
+    for k in range(3):
+        if k == 1:
+            single.set_background(True, True, L)
+        _load(b1, frames[k * n:(k + 1) * n], n)
+        single.run(b1, n)
+        ctx.sync()
+        want.append(chanest(b1))
+    assert np.array_equal(want[0], raw)
+
+    owner, _ = _chain(jrc, ctx, sc, 2, 4, n)
+    other, _ = _chain(jrc, ctx, sc, 2, 4, n)
+    owner.set_background(False, True, L)                          # recording only: allocates no raw buffer
+    other.share_background(owner)
+    bo, bs = owner.alloc(n, "cuda:0"), other.alloc(n, "cuda:0")
+    _load(bo, frames[:n], n)
+    owner.run(bo, n)
+    ctx.sync()
+    assert np.array_equal(chanest(bo), want[0])
+    other.set_background(True, True, L)                           # the sharer switches removal on for the group
+    _load(bs, frames[n:2 * n], n)
+    other.run(bs, n)
+    ctx.sync()
+    assert np.array_equal(chanest(bs), want[1])
+    _load(bo, frames[2 * n:], n)
+    owner.run(bo, n)                                              # the owner now subtracts too: needs its own raw buffer
+    ctx.sync()
+    assert np.array_equal(chanest(bo), want[2])
+    assert not np.array_equal(want[2], _oracle_stream(sc, frames[2 * n:], L, removal=False)[0])    # something was subtracted
+
+
 # ---- detect-only mode -----------------------------------------------------------------------------------------------------------
 def _both_modes(jrc, ctx, sc, Ir, Ia, F, frames=None, interleave=False):
     import torch
