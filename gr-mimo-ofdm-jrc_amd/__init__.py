@@ -596,6 +596,10 @@ class ChainFeed:
         """negative status -> JrcError carrying the FEED's last error (its contexts are its own: jrc_chain_feed_last_error)"""
         if st < 0:
             msg = self.lib.jrc_chain_feed_last_error(self.h).decode() or self.lib.jrc_strerror(st).decode()
+            if st == JRC_ERR_LENGTH_MISMATCH:
+                raise RuntimeError(msg)       # the same mapping as Context.check
+            if st == JRC_ERR_INVALID_ARG:
+                raise ValueError(msg)
             raise JrcError(st, msg)
         return st
 

@@ -321,6 +321,14 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
 // per CU, stores paced (chain_pace); 16 pairs at fft_len 1024: 512 threads, two pairs per wave, 64 VGPRs of H, one workgroup per CU.
 // Same angle axis, arg-max and MODEs as above; rng[frame][class][pair][(q & 3) * 64 + (q >> 2)] for the window pass.
 #define RW_L 256
+// the workgroup-shared word of MODE 1 lives in a function of its own, so that only the kernels that use it carry the static LDS: the
+// MODE 3 form at fft_len 256 / 512 takes 80 KiB of dynamic LDS, two workgroups fill the CU's 160 KiB to the last allocation unit, and four
+// more static bytes left one workgroup per CU (0.28 -> 0.39 ms per 512 config-B frames, measured)
+template <bool ON> __device__ __forceinline__ unsigned* wide_run_max()
+{
+    if constexpr (ON) { __shared__ unsigned v; return &v; }
+    else return nullptr;
+}
 template <int P, int MODE, int IA, int LOGN, int NT_ = 512>
 __global__ __launch_bounds__(NT_, 2) void range_angle_wide_kernel(
     const float2* __restrict__ H, float2* __restrict__ map, PeakPartial* __restrict__ partials,
@@ -341,8 +349,8 @@ __global__ __launch_bounds__(NT_, 2) void range_angle_wide_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float2* s_g = smem;                                         // [2][P][256]
     float* s_pw = reinterpret_cast<float*>(s_g + 2 * P * RW_L) + (size_t)wave * (64 * P);   // MODE 3: this wave's tile (its four rows)
-    __shared__ unsigned s_run;                                  // MODE 1: the workgroup's running maximum (float bits), see the angle axis
-    if (tid == 0) s_run = 0u;                                   // ordered before its first use by the barrier of the first class
+    unsigned* const s_run = wide_run_max<MODE == 1>();          // MODE 1: the workgroup's running maximum (float bits), see the angle axis
+    if constexpr (MODE == 1) { if (tid == 0) *s_run = 0u; }                    // ordered before its first use by the barrier of the first class
 
     // this wave's share of H, for good
     float2 h[PPW][4][MM];
@@ -482,7 +490,7 @@ __global__ __launch_bounds__(NT_, 2) void range_angle_wide_kernel(
         unsigned todo = TRIPS >= 32 ? 0xffffffffu : (1u << TRIPS) - 1u;
         int t_first = -1;
         auto candidates = [&]() -> unsigned {
-            trk.run_max = fmaxf(trk.run_max, __uint_as_float(*reinterpret_cast<volatile unsigned*>(&s_run)));
+            trk.run_max = fmaxf(trk.run_max, __uint_as_float(*reinterpret_cast<volatile unsigned*>(s_run)));
             const float thr = trk.run_max * (1.0f - 1e-5f);
             unsigned m = 0;
 #pragma unroll
@@ -503,7 +511,7 @@ __global__ __launch_bounds__(NT_, 2) void range_angle_wide_kernel(
                 todo = 1u << t_first;
             } else {
                 todo = candidates();
-                seen = *reinterpret_cast<volatile unsigned*>(&s_run);
+                seen = *reinterpret_cast<volatile unsigned*>(s_run);
                 if (2 * __popc(todo) > TRIPS) prune_on = false;  // nothing stands out in this frame (noise, weak targets): the bounds cost more than they save
             }
         }
@@ -512,14 +520,14 @@ __global__ __launch_bounds__(NT_, 2) void range_angle_wide_kernel(
             int w0;
             if constexpr (MODE == 1) {
                 if (tt > 0 && t_first < 0 && prune_on) {          // a trip was computed: has the workgroup's maximum moved?
-                    const unsigned now = *reinterpret_cast<volatile unsigned*>(&s_run);
+                    const unsigned now = *reinterpret_cast<volatile unsigned*>(s_run);
                     if (now != seen) { seen = now; todo &= candidates(); }
                 }
                 if (todo == 0u) {
                     if (t_first < 0) break;
                     __syncthreads();                              // first class of the workgroup: every wave has published the maximum of its strongest trip
                     todo = candidates() & ~(1u << t_first);
-                    seen = *reinterpret_cast<volatile unsigned*>(&s_run);
+                    seen = *reinterpret_cast<volatile unsigned*>(s_run);
                     t_first = -1;
                     if (2 * __popc(todo) > TRIPS) prune_on = false;
                     if (todo == 0u) break;
@@ -578,7 +586,7 @@ __global__ __launch_bounds__(NT_, 2) void range_angle_wide_kernel(
             }
             const float before = trk.run_max;
             const float thr = trk.raise(m);
-            if constexpr (MODE == 1) { if (trk.run_max > before && lane == 0) atomicMax(&s_run, __float_as_uint(trk.run_max)); }   // non-negative floats order as their bit patterns
+            if constexpr (MODE == 1) { if (trk.run_max > before && lane == 0) atomicMax(s_run, __float_as_uint(trk.run_max)); }   // non-negative floats order as their bit patterns
             if (m >= thr) {
                 const unsigned flat0 = (unsigned)k * (unsigned)NA;
 #pragma unroll
