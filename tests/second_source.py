@@ -550,3 +550,83 @@ class PrecoderRef:
                 else:
                     out[:, k0 + NL + m, sc] = cmul(W[:, 0], S[0, m, sc])                      # Q.col(0) * scalar
         return out
+
+
+# ------------------------------------------------------------------------------------------------ lib/range_angle_estimator_impl.cc, lib/fft_peak_detect_impl.cc
+_libm.log10f.restype = ctypes.c_float
+_libm.log10f.argtypes = [ctypes.c_float]
+
+
+def _pow2_abs(z):
+    """std::pow(std::abs(z), 2) on a std::complex<float>: hypotf in float, the square in double (pow(float, int) promotes)"""
+    h = float(_libm.hypotf(float(np.real(z)), float(np.imag(z))))
+    return h * h
+
+
+def ra_estimate_ref(m, range_bins, angle_bins, noise_discard_range_m, noise_discard_angle_deg, snr_threshold=0.0, power_threshold=0.0):
+    """range_angle_estimator_impl::work (lib/range_angle_estimator_impl.cc:122-283) on a [n_inputs][vlen] complex64 map.
+    `iter_geq == end()` dereferences past the vector in the reference (:169-170); as everywhere in this build that case is
+    angle_null_idx = size - 1, then the clamp of :184-187."""
+    m = np.asarray(m, c64)
+    n_inputs, vlen = m.shape
+    rb, ab = np.asarray(range_bins, f32), np.asarray(angle_bins, f32)
+    peak_power, pr, pa = f32(-1), -1, -1
+    for i_range in range(n_inputs):                                                           # :137-151
+        for i_angle in range(vlen):
+            curr = f32(_pow2_abs(m[i_range, i_angle]))
+            if curr > peak_power:
+                peak_power, pr, pa = curr, i_range, i_angle
+    angle_val, range_val = ab[pa], rb[pr]
+    angle_null = f32(angle_val + f32(90))                                                     # :155-160
+    if angle_null >= 90:
+        angle_null = f32(angle_null - f32(180))
+    it = int(np.searchsorted(ab, angle_null, side="left"))                                    # std::lower_bound
+    if it == 0:                                                                               # :172-180
+        null_idx = 0
+    elif it == len(ab):
+        null_idx = len(ab) - 1
+    elif abs(float(angle_null) - float(ab[it - 1])) < abs(float(angle_null) - float(ab[it])):
+        null_idx = it - 1
+    else:
+        null_idx = it
+    if null_idx == len(ab) - 1:                                                               # :184-187
+        null_idx = len(ab) - 2
+    with np.errstate(all="ignore"):
+        dr = int(f32(noise_discard_range_m) / f32(rb[1] - rb[0]))                             # :189 (truncation)
+        da = int(f32(noise_discard_angle_deg) / f32(ab[(null_idx + 1) % len(ab)] - ab[null_idx]))
+    if da <= 0:
+        da = 1
+    r0, r1 = pr + len(rb) // 2 - dr, pr + len(rb) // 2 + dr                                    # :197-201
+    a0, a1 = null_idx - da, null_idx + da
+    noise, n = f32(0), 0
+    for i_range in range(r0, r1):                                                             # :209-221; C's % then the fix-up = Python's %
+        r_idx = i_range % n_inputs
+        for i_angle in range(a0, a1):
+            noise = f32(float(noise) + _pow2_abs(m[r_idx, i_angle % vlen]))                   # float += double
+            n += 1
+    with np.errstate(all="ignore"):
+        noise = f32(noise / f32(n)) if n else f32(np.nan)
+        snr = f32(f32(10) * f32(_libm.log10f(float(f32(peak_power / noise)))))                # :227
+    return dict(peak_range_idx=pr, peak_angle_idx=pa, angle_null_idx=null_idx, discard_range_idx=dr, discard_angle_idx=da,
+                n_noise_samples=n, peak_power=peak_power, noise_power=noise, snr_est=snr, range_val=range_val, angle_val=angle_val,
+                published=int(bool(snr >= f32(snr_threshold) and peak_power >= f32(power_threshold))))
+
+
+def fft_peak_detect_ref(x, samp_rate, interp_factor, threshold, samp_protect):
+    """fft_peak_detect_impl::work (lib/fft_peak_detect_impl.cc:77-113): (k, freq, phase, mag); k = -1 leaves the outputs untouched"""
+    x = np.asarray(x, c64)
+    n = x.size
+    k, hold = -1, f32(-1)
+    thr = 10.0 ** (float(f32(threshold)) / 10.0)                                              # std::pow(10, d_threshold / 10.0): double
+    for p in range(samp_protect, n - samp_protect):
+        h = f32(_libm.hypotf(float(x[p].real), float(x[p].imag)))
+        if h > hold and float(h) * float(h) > thr:
+            hold, k = h, p
+    if k == -1:
+        return -1, None, None, None
+    fs_i = f32(f32(samp_rate) * f32(interp_factor))                                           # int * float -> float
+    if k <= n // 2:
+        freq = f32(f32(f32(k) / f32(n)) * fs_i)                                               # k / (float) n * (samp_rate * interp)
+    else:
+        freq = f32(-fs_i + f32(f32(k) * f32(fs_i / f32(n))))
+    return k, freq, f32(_libm.atan2f(float(x[k].imag), float(x[k].real))), f32(_libm.hypotf(float(x[k].real), float(x[k].imag)))

@@ -234,3 +234,50 @@ def test_dft_matrix_and_signal_field_second_source(ofdm64):
             for length in (0, 1, 77, 4095):
                 for nd in (48, 52, 216):
                     assert np.array_equal(oracle.sig_encode(nd, mcs, ptype, length), ss.signal_field(nd, mcs, ptype, length))
+
+
+RA_FIELDS = ("peak_range_idx", "peak_angle_idx", "angle_null_idx", "discard_range_idx", "discard_angle_idx", "n_noise_samples",
+             "peak_power", "noise_power", "snr_est", "range_val", "angle_val", "published")
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_range_angle_estimator_oracle_equals_second_source(seed):
+    """lib/range_angle_estimator_impl.cc:122-283 read twice: random maps with the peak forced into every region of the angle axis
+    (both sides of 0 degrees, first / last bins: the lower_bound corner cases), windows that wrap in range and angle, float += double
+    noise sums, log10f - all twelve fields of the record equal, floats bit for bit"""
+    import jrc_amd
+    rng = np.random.default_rng(seed)
+    nr, P, Ia = 64, 4, 8
+    rb, ab = jrc_amd.radar_axes(nr // 4, 125e6, 4, P, Ia)
+    na = P * Ia
+    m = crandn(rng, nr, na, scale=0.1)
+    kr, ka = int(rng.integers(0, nr)), [0, 1, na // 2 - 1, na // 2, na - 2, na - 1, 5, 20, 11, 30, 16, 17][seed]
+    m[kr, ka] = (3 + 2j) * (1 + seed)
+    if seed % 3 == 0:
+        m[(kr + 7) % nr, (ka + 3) % na] = m[kr, ka]                     # an exact tie later (or earlier) in scan order
+    ndr, nda = float(rng.uniform(1.0, 9.0)), float(rng.uniform(5.0, 40.0))
+    thr = (15.0, 0.0) if seed % 2 else (40.0, 1e3)
+    a = oracle.ra_estimate(m, rb, ab, ndr, nda, *thr)
+    b = ss.ra_estimate_ref(m, rb, ab, ndr, nda, *thr)
+    for k in RA_FIELDS:
+        va, vb = getattr(a, k), b[k]
+        if isinstance(vb, (np.floating, float)):
+            assert np.float32(va).tobytes() == np.float32(vb).tobytes(), (k, va, vb)
+        else:
+            assert va == vb, (k, va, vb)
+
+
+def test_fft_peak_detect_oracle_equals_second_source():
+    rng = np.random.default_rng(4)
+    for trial in range(20):
+        n = int(rng.integers(40, 600))
+        x = crandn(rng, n, scale=0.05)
+        for _ in range(int(rng.integers(0, 3))):
+            x[int(rng.integers(0, n))] = crandn(rng, 1)[0] * 5
+        prot = int(rng.integers(0, 8))
+        thr = float(rng.choice([-30.0, -3.0, 5.0, 30.0]))
+        ka, fa, pa, ma = oracle.fft_peak_detect(x, 125000000, 8.0, thr, prot)
+        kb, fb, pb, mb = ss.fft_peak_detect_ref(x, 125000000, 8.0, thr, prot)
+        assert ka == kb
+        if kb >= 0:
+            assert (np.float32(fa).tobytes(), np.float32(pa).tobytes(), np.float32(ma).tobytes()) == (fb.tobytes(), pb.tobytes(), mb.tobytes())

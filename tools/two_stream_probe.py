@@ -16,7 +16,10 @@ def setup(F, n):
     for i in range(n):
         ctx = jrc_amd.Context(0)
         ch = jrc_amd.RadarChain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb, ab, 2.4, 14.4, 15.0, 0.0, max_frames=F, ctx=ctx)
-        b = ch.alloc(F, "cuda:0")
+        detect = bool(os.environ.get("JRC_TSP_DETECT"))
+        if detect:
+            ch.set_write_map(False)
+        b = ch.alloc(F, "cuda:0", with_map=not detect)
         hf = torch.from_numpy(fr.view(np.float32).reshape((16,) + tuple(b["frames"].shape[1:])))
         for f0 in range(0, F, 16):
             b["frames"][f0:f0 + 16].copy_(hf)
@@ -38,7 +41,9 @@ def run(parts, steps):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
-for n in (1, 2, 4):
-    parts = setup(256 // n, n)
-    print("streams=%d  ms per 256 frames: %.4f" % (n, run(parts, 50)))
+TOTAL = int(os.environ.get("JRC_TSP_FRAMES", "256"))
+for n in (1, 2, 4, 8):
+    parts = setup(TOTAL // n, n)
+    t = run(parts, 50)
+    print("streams=%d  ms per %d frames: %.4f  (%.3f M frames/s)" % (n, TOTAL, t, TOTAL / t / 1e3))
     del parts
