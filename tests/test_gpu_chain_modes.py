@@ -241,8 +241,9 @@ def _both_modes(jrc, ctx, sc, Ir, Ia, F, frames=None, interleave=False):
     return full, det, again, ch.results(bufs, F)
 
 
-@pytest.mark.parametrize("cfg,F", [("A", 5), ("A", 300), ("B", 3), ("B", 40), ("B", 512), ("D", 2), ("D", 9), ("D", 256)])
+@pytest.mark.parametrize("cfg,F", [("A", 5), ("A", 300), ("B", 3), ("B", 40), ("B", 512), ("B", 1100), ("D", 2), ("D", 9), ("D", 256)])
 def test_detect_only_results_equal_map_mode(jrc, ctx, cfg, F):
+    """B x 1100: three launches of the fused kernel (512 + 512 + a ragged 76-frame tail with more slices per frame)"""
     from jrc_amd import synth
     sc = {"A": synth.config_A, "B": synth.config_B, "D": synth.config_D}[cfg]()
     nd = min(F, 4)
@@ -281,7 +282,7 @@ def test_detect_only_and_power_map_on_the_wide_kernel_at_smaller_fft_len(jrc, ct
 
 
 @pytest.mark.parametrize("case", ["noise_only", "two_equal_targets", "exact_duplicate_rows", "all_zero", "weak_target_in_noise", "late_peak"])
-@pytest.mark.parametrize("cfg,F", [("B", 6), ("B", 300), ("D", 3)])
+@pytest.mark.parametrize("cfg,F", [("B", 6), ("B", 300), ("B", 700), ("D", 3)])
 def test_detect_only_bound_pruning_keeps_the_records_exact(jrc, ctx, cfg, F, case):
     """detect-only mode skips the angle transforms of range bins whose bound (sum_p |R[p][k]|)^2 lies below the running maximum
     (range_angle_wide_kernel, MODE 1).  Inputs chosen against that shortcut: nothing to prune with (noise only), maxima that tie to the

@@ -72,7 +72,7 @@ def detect_only(cfg="B", F=None, noise_only=False):
     noise-window rows -> estimator epilogue; algorithmic bytes per frame = inputs + the 48-byte result.
     noise_only: RX ports hold noise alone — the worst case of the bound-pruned angle stage (nothing stands out, little is skipped)"""
     sc = {"B": synth.config_B, "D": synth.config_D}[cfg]()
-    F = F or (512 if cfg == "B" else 256)
+    F = F or int(os.environ.get("JRC_DETECT_FRAMES", "0")) or (512 if cfg == "B" else 256)
     Ir, Ia, P = 8, 16, sc.T * sc.R
     rb, ab = jrc_amd.radar_axes(sc.N, sc.fs, Ir, P, Ia)
     ctx = jrc_amd.Context(0)
