@@ -318,6 +318,23 @@ def test_detect_only_bound_pruning_keeps_the_records_exact(jrc, ctx, cfg, F, cas
     assert det == full and again == full
 
 
+@pytest.mark.parametrize("T,R,N,F", [(4, 2, 256, 7), (4, 2, 1024, 3), (2, 4, 512, 5), (4, 2, 256, 600)])
+@pytest.mark.parametrize("case", ["target", "noise_only"])
+def test_detect_only_pruning_with_eight_pairs(jrc, ctx, T, R, N, F, case):
+    """the wide kernel's 8-pair geometry (two pairs per wave; only half of a range bin's 16 lanes hold a pair when the bound is summed)
+    in detect-only mode against map mode, with and without something to prune"""
+    from jrc_amd import synth
+    sc = synth.Scenario(N, T, R, 4, targets=[(0.4 * 3e8 * N / (2 * 125e6), 17.0, 0.0, 100.0)])
+    base = synth.make_frames(sc, min(F, 3))
+    if case == "noise_only":
+        rng = np.random.default_rng(N + F)
+        base[:, T:] = ((rng.standard_normal(base[:, T:].shape) + 1j * rng.standard_normal(base[:, T:].shape)) * 1e-3).astype(np.complex64)
+    frames = np.concatenate([base] * (F // len(base) + 1))[:F]
+    frames = (frames * (1.0 + 0.5 * (np.arange(F, dtype=np.float32) % 5))[:, None, None, None]).astype(np.complex64)
+    full, det, again, res = _both_modes(jrc, ctx, sc, 8, 16, F, frames=frames)
+    assert det == full and again == full
+
+
 def _shapes(n, seed=77):
     rng = np.random.default_rng(seed)
     out = []
