@@ -1,0 +1,197 @@
+"""GPU tier: randomised differential tests — HIP path against the oracle on shapes, modes and inputs drawn at random.
+The fixed-shape tests pin the configurations BASELINE names; this file looks for what they do not think of: odd batch sizes
+(ragged launch tails), every chain mode on every kernel family, equalizer frames of random length / MCS / carrier offset / noise split
+at random places, precoder steering variants.  JRC_FUZZ_N scales the number of draws (default: a few seconds on the box);
+JRC_FUZZ_SEED moves the sequence.  A failure prints the draw, so it can be replayed."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import crandn, rel_err
+from test_oracle_comm import qam16, qpsk, through_channel
+
+pytestmark = pytest.mark.gpu
+N_DRAWS = int(os.environ.get("JRC_FUZZ_N", "24"))
+SEED = int(os.environ.get("JRC_FUZZ_SEED", "20261002"))
+
+
+def _rec(r):
+    return ctypes.string_at(ctypes.byref(r), ctypes.sizeof(r))
+
+
+def _draw_chain(rng):
+    T, R = int(rng.choice([1, 2, 4])), int(rng.choice([1, 2, 4]))
+    N = int(rng.choice([64, 128, 256, 512, 1024]))
+    Ir = int(rng.choice([2, 4, 8, 16]))
+    Ia = int(rng.choice([4, 8, 16, 16, 16, 32]))
+    while N * Ir * T * R * Ia > 1 << 21:
+        Ir = max(1, Ir // 2)
+    S = int(rng.integers(1, 7))
+    F = int(rng.choice([1, 2, 3, 5, 17, 64]))
+    return dict(T=T, R=R, N=N, Ir=Ir, Ia=Ia, S=S, F=F, interleave=bool(rng.integers(0, 2)),
+                kind=str(rng.choice(["target", "two", "noise", "weak"])), rel_range=float(rng.uniform(0.02, 0.97)), az=float(rng.uniform(-60, 60)))
+
+
+def _draw_wide(rng):
+    """the geometries of range_angle_wide_kernel (configs B and D live here) with batch sizes around the launch boundaries: one resident wave of
+    workgroups is 512 frames at fft_len 256 / 512 and 256 at fft_len 1024, so 513 / 600 / 300 leave ragged tails with more slices per frame"""
+    T, R = [(4, 4), (4, 4), (4, 2), (2, 4)][int(rng.integers(0, 4))]
+    N = int(rng.choice([256, 512, 1024]))
+    Ir = int(rng.choice([4, 8, 8, 16])) if N < 1024 else int(rng.choice([2, 4, 8]))
+    F = int(rng.choice([1, 7, 130, 300, 513, 600])) if N < 1024 else int(rng.choice([1, 5, 130, 257, 300]))
+    return dict(T=T, R=R, N=N, Ir=Ir, Ia=16, S=int(rng.integers(1, 5)), F=F, interleave=bool(rng.integers(0, 2)),
+                kind=str(rng.choice(["target", "two", "noise", "weak"])), rel_range=float(rng.uniform(0.02, 0.97)), az=float(rng.uniform(-60, 60)))
+
+
+@pytest.mark.parametrize("i", range(max(1, N_DRAWS // 3)))
+def test_wide_kernel_batches_against_oracle_and_each_other(jrc, ctx, i):
+    _chain_case(jrc, ctx, _draw_wide(np.random.default_rng(SEED + 5000 + i)), np.random.default_rng(SEED + 6000 + i))
+
+
+@pytest.mark.parametrize("i", range(N_DRAWS))
+def test_chain_modes_against_oracle_and_each_other(jrc, ctx, i):
+    """map mode against the oracle's block-by-block chain (A1 bit-exact, map <= 5e-6, A5 record exact on the same map); detect-only and
+    power-map modes against map mode (records byte-identical, power cells == re^2 + im^2 of the complex cells bit for bit)"""
+    rng = np.random.default_rng(SEED + i)
+    _chain_case(jrc, ctx, _draw_chain(rng), rng)
+
+
+def _chain_case(jrc, ctx, d, rng):
+    import torch
+    from jrc_amd import synth
+    R_max = 3e8 * d["N"] / (2 * 125e6)
+    tg = [(d["rel_range"] * R_max, d["az"], 0.0, 100.0)]
+    if d["kind"] == "two":
+        tg.append(((1 - d["rel_range"]) * R_max * 0.9 + 1.0, -d["az"], 0.0, 100.0))
+    sc = synth.Scenario(d["N"], d["T"], d["R"], d["S"], targets=tg)
+    F, P = d["F"], d["T"] * d["R"]
+    base = synth.make_frames(sc, min(F, 6))
+    frames = np.concatenate([base] * (F // len(base) + 1))[:F]
+    frames = (frames * (1.0 + 0.25 * (np.arange(F, dtype=np.float32) % 9))[:, None, None, None]).astype(np.complex64)   # exact scalings: distinct peaks
+    if d["kind"] in ("noise", "weak"):
+        amp = (np.abs(frames[:, sc.T:]).mean() * (8.0 if d["kind"] == "weak" else 1.0)) or 1e-3
+        noise = ((rng.standard_normal(frames[:, sc.T:].shape) + 1j * rng.standard_normal(frames[:, sc.T:].shape)) * amp).astype(np.complex64)
+        frames[:, sc.T:] = noise if d["kind"] == "noise" else frames[:, sc.T:] + noise
+    rb, ab = jrc.radar_axes(sc.N, sc.fs, d["Ir"], P, d["Ia"])
+    ndr, nda = 2 * 3e8 / (2 * sc.fs), 2 * float(np.rad2deg(np.arcsin(2 / P))) if P > 2 else 30.0
+    ch = jrc.RadarChain(sc.N, sc.T, sc.R, sc.S, sc.Npre, d["Ir"], d["Ia"], rb, ab, ndr, nda, 15.0, 0.0, enable_tx_interleave=d["interleave"],
+                        max_frames=F, ctx=ctx)
+    bufs = ch.alloc(F, "cuda:0")
+    bufs["frames"].copy_(torch.from_numpy(frames.view(np.float32).reshape(bufs["frames"].shape)))
+    bufs["map"].fill_(float("nan"))
+    torch.cuda.synchronize()
+    ch.run(bufs, F)
+    res = ch.results(bufs, F)
+    assert not torch.isnan(bufs["map"]).any().item(), d
+    gmap = {f: bufs["map"][f].cpu().numpy().view(np.complex64)[..., 0] for f in sorted(set([0, F - 1, F // 2]))}
+    gH = bufs["chanest"].cpu().numpy().view(np.complex64)[..., 0]
+    for f in sorted(set([0, F - 1, F // 2])):
+        rad = oracle.Radar(sc.N, sc.T, sc.R, sc.S, sc.Npre, interp_factor=d["Ir"], enable_tx_interleave=d["interleave"])
+        H = rad.work([frames[f][t] for t in range(sc.T)], [frames[f][sc.T + r] for r in range(sc.R)])
+        m = oracle.fft_vcc(oracle.matrix_transpose(oracle.fft_vcc(H, False, False), sc.N * d["Ir"], P, d["Ia"]), True, True)
+        assert np.array_equal(gH[f], H[:, :sc.N]), d
+        assert rel_err(gmap[f], m) < 5e-6, d
+        assert _rec(res[f]) == _rec(oracle.ra_estimate(gmap[f], rb, ab, ndr, nda, 15.0, 0.0)), d
+    want = [_rec(r) for r in res]
+    try:
+        ch.set_write_map(False)
+    except jrc.JrcError as e:                                   # shapes that run block by block keep the complex map
+        assert e.status == jrc.JRC_ERR_UNSUPPORTED, d
+        return
+    b2 = ch.alloc(F, "cuda:0", with_map=False)
+    b2["frames"].copy_(bufs["frames"])
+    torch.cuda.synchronize()
+    ch.run(b2, F)
+    assert [_rec(r) for r in ch.results(b2, F)] == want, d
+    ch.set_write_map(True)
+    try:
+        ch.set_map_format(True)
+    except jrc.JrcError as e:
+        assert e.status == jrc.JRC_ERR_UNSUPPORTED, d
+        return
+    b3 = ch.alloc(F, "cuda:0", power_map=True)
+    b3["frames"].copy_(bufs["frames"])
+    torch.cuda.synchronize()
+    ch.run(b3, F)
+    assert [_rec(r) for r in ch.results(b3, F)] == want, d
+    for f in sorted(set([0, F - 1, F // 2])):                   # (whole batches of 16 MiB maps would take the host minutes)
+        pw = b3["map"][f].cpu().numpy().reshape(gmap[f].shape)
+        ref = gmap[f].real.astype(np.float32) * gmap[f].real.astype(np.float32) + gmap[f].imag.astype(np.float32) * gmap[f].imag.astype(np.float32)
+        assert np.array_equal(pw, ref), d
+
+
+@pytest.mark.parametrize("i", range(N_DRAWS))
+def test_equalizer_against_oracle(jrc, ctx, ofdm64, i):
+    """random frame (packet type, MCS, length, estimator), random channel / noise / carrier-phase tag, junk in front and behind,
+    handed over in random pieces: consumed / produced counts, events and symbols against the oracle's general_work on the same pieces"""
+    rng = np.random.default_rng(SEED + 1000 + i)
+    o = ofdm64
+    est, ptype, mcs = int(rng.integers(0, 2)), int(rng.integers(1, 3)), int(rng.integers(0, 6))
+    nbytes = int(rng.integers(1, 260))
+    draw = dict(est=est, ptype=ptype, mcs=mcs, nbytes=nbytes)
+    dc, pc = o["data_subcarriers"], o["pilot_subcarriers"]
+    ps, sw, ml, ltf = o["pilot_symbols"], o["l_stf_ltf_64"], o["ltf_mapped_sc__ss_sym"], o["ltf_64"]
+    op = oracle.Precoder(64, 4, 1, dc, pc, ps, sw, ml)
+    ge = jrc.mimo_ofdm_equalizer(est, 24e9, 125e6, 64, 16, dc, pc, ps, ltf, ml, 4, ctx=ctx)
+    oe = oracle.Equalizer(est, 24e9, 125e6, 64, 16, dc, pc, ps, ltf, ml, 4)
+    ns = oracle.n_ofdm_sym(mcs, 48, nbytes)
+    s = qam16(rng, ns * 48) if mcs >= 4 else qpsk(rng, ns * 48) if mcs >= 2 else (rng.integers(0, 2, ns * 48) * 2 - 1).astype(np.complex64)
+    y = through_channel(op.work(s, mcs, ptype, nbytes), crandn(rng, 4), float(rng.choice([0.0, 1e-3, 5e-3])), rng)
+    lead = int(rng.integers(0, 4))
+    y = np.concatenate([crandn(rng, lead, 64), y, crandn(rng, int(rng.integers(0, 4)), 64)])
+    phase = float(rng.uniform(-0.3, 0.3))
+    pos, go, oo = 0, [], []
+    while pos < len(y):
+        step = int(rng.choice([1, 2, 3, 5, 8, 40, 400]))
+        part = y[pos:pos + step]
+        tags = [(lead - pos, phase)] if pos <= lead < pos + len(part) else []
+        g, r = ge.general_work(part, tags), oe.general_work(part, tags)
+        assert g["consumed"] == r["consumed"] == len(part) and g["out"].shape == r["out"].shape, draw
+        assert [e["kind"] for e in g["events"]] == [e["kind"] for e in r["events"]], draw
+        for a, b in zip(g["events"], r["events"]):
+            assert a["offset"] == b["offset"], draw
+            if a["kind"] == 1:
+                assert (a["data_bytes"], a["mcs"], a["packet_type"]) == (b["data_bytes"], b["mcs"], b["packet_type"]), draw
+        go.append(g["out"]); oo.append(r["out"])
+        pos += len(part)
+    go, oo = np.concatenate(go), np.concatenate(oo)
+    assert go.shape == (ns, 48), draw
+    assert rel_err(go, oo) < 2e-5, draw
+
+
+@pytest.mark.parametrize("i", range(N_DRAWS))
+def test_precoder_and_codec_against_oracle(jrc, ctx, ofdm64, i):
+    rng = np.random.default_rng(SEED + 2000 + i)
+    o = ofdm64
+    args = (o["data_subcarriers"], o["pilot_subcarriers"], o["pilot_symbols"], o["l_stf_ltf_64"], o["ltf_mapped_sc__ss_sym"])
+    gp, op = jrc.mimo_precoder(64, 4, 1, *args, ctx=ctx), oracle.Precoder(64, 4, 1, *args)
+    mcs, ptype, nbytes = int(rng.integers(0, 6)), int(rng.integers(1, 3)), int(rng.integers(1, 400))
+    ns = oracle.n_ofdm_sym(mcs, 48, nbytes)
+    s = qpsk(rng, ns * 48)
+    kw = {}
+    mode = int(rng.integers(0, 3)) if ptype == 2 else 0
+    if mode == 1:
+        kw = dict(steer_mode=1, Q_mean=crandn(rng, 4, 4))
+    elif mode == 2:
+        kw = dict(steer_mode=2, Q_sc=crandn(rng, 64, 4, 4))
+    if ptype == 2 and rng.integers(0, 2):
+        kw["radar_streams"] = qpsk(rng, 3 * ns * 64).reshape(3, ns, 64)
+    a, b = gp.work(s, mcs, ptype, nbytes, **kw), op.work(s, mcs, ptype, nbytes, **kw)
+    assert a.shape == b.shape and rel_err(a, b) < 1e-6, (mcs, ptype, nbytes, mode)
+    assert np.array_equal(a[:, :5], b[:, :5])
+    # bit codec: encoder exact; decoder on clean and on noisy symbols
+    pdu = bytes([int(rng.integers(1, 3))]) + rng.integers(0, 256, int(rng.integers(1, 300)), dtype=np.uint8).tobytes()
+    enc = jrc.stream_encoder(mcs, 48, ctx=ctx)
+    seed = int(rng.integers(1, 128))
+    enc.d_scrambler = seed                                     # work() uses it, then counts on (scramble(..., d_scrambler++))
+    sym, tags = enc.work(pdu)
+    osym, otags = oracle.stream_encode(mcs, 48, pdu, seed)
+    assert np.array_equal(sym, osym) and tags["pdu_len"] == otags["pdu_len"], (mcs, len(pdu))
+    noisy = sym + crandn(rng, sym.size, scale=float(rng.choice([0.0, 0.05, 0.3])))
+    dec = jrc.stream_decoder(48, ctx=ctx)
+    ok, payload = dec.work(noisy, dict(mcs=mcs, data_bytes=len(pdu) + 4))
+    ook, opayload = oracle.stream_decode(mcs, 48, len(pdu) + 4, noisy)
+    assert bool(ok) == bool(ook) and payload == opayload, (mcs, len(pdu))
