@@ -630,3 +630,71 @@ def fft_peak_detect_ref(x, samp_rate, interp_factor, threshold, samp_protect):
     else:
         freq = f32(-fs_i + f32(f32(k) * f32(fs_i / f32(n))))
     return k, freq, f32(_libm.atan2f(float(x[k].imag), float(x[k].real))), f32(_libm.hypotf(float(x[k].real), float(x[k].imag)))
+
+
+# ------------------------------------------------------------------------------------------------ lib/stream_encoder_impl.cc, lib/stream_decoder_impl.cc
+def stream_encode_values(mcs, n_dc, pdu, scrambler):
+    """stream_encoder_impl::general_work (lib/stream_encoder_impl.cc:126-207) up to d_symbol_values: CRC-32 appended (boost::crc_32_type =
+    the zlib polynomial, little-endian bytes), generate_bits (16 zero bits + bytes LSB first, lib/utils.cc:137-173), scramble (:175-187),
+    reset_tail_bits (:190-193), convolutional_encoding (:207-217), puncturing (:220-250), split_symbols (:281-297; no interleaving).
+    Returns (symbol values [n_ofdm_sym * n_dc], n_ofdm_sym, pdu_len tag)."""
+    import zlib
+    pdu = bytes(pdu)
+    size = len(pdu) + 4
+    n_bpsc, n_cbps, n_dbps = mcs_params(mcs, n_dc)
+    n_sym = int(np.ceil((16 + 8 * size + 6) / float(n_dbps)))
+    n_data_bits = n_sym * n_dbps
+    n_pad = n_data_bits - (16 + 8 * size + 6)
+    data = pdu + int(zlib.crc32(pdu) & 0xffffffff).to_bytes(4, "little")
+    bits = np.zeros(n_data_bits, np.uint8)
+    for i, byte in enumerate(data):
+        for b in range(8):
+            bits[16 + i * 8 + b] = (byte >> b) & 1
+    state, scr = int(scrambler), np.zeros(n_data_bits, np.uint8)
+    for i in range(n_data_bits):
+        fb = (1 if state & 64 else 0) ^ (1 if state & 8 else 0)
+        scr[i] = fb ^ bits[i]
+        state = ((state << 1) & 0x7e) | fb
+    scr[n_data_bits - n_pad - 6:n_data_bits - n_pad] = 0
+    enc = conv_encode(scr)
+    if mcs in (0, 2, 4):
+        punct = enc
+    else:
+        punct = np.array([enc[i] for i in range(2 * n_data_bits) if i % 6 not in (3, 4)], np.uint8)
+    assert punct.size == n_sym * n_cbps
+    vals = np.zeros(n_sym * n_dc, np.uint8)
+    for i in range(vals.size):
+        for k in range(n_bpsc):
+            vals[i] |= punct[i * n_bpsc + k] << k
+    return vals, n_sym, size
+
+
+def stream_decode_values(mcs, n_dc, data_size_byte, values):
+    """stream_decoder_impl::decode (lib/stream_decoder_impl.cc:258-292) + descramble (:406-433) from the decided symbol values:
+    bits LSB first per symbol, the windowed Viterbi decoder, descrambler seeded by the first seven decoded bits, CRC-32 residue.
+    Returns (crc_ok, payload without the CRC)."""
+    import zlib
+    n_bpsc, n_cbps, n_dbps = mcs_params(mcs, n_dc)
+    n_sym = int(np.ceil((16 + 8 * data_size_byte + 6) / float(n_dbps)))
+    vals = np.asarray(values, np.uint8)[:n_sym * n_dc]
+    bits = np.zeros(n_sym * n_cbps, np.uint8)
+    for i, v in enumerate(vals):
+        for k in range(n_bpsc):
+            bits[i * n_bpsc + k] = (int(v) >> k) & 1
+    dec = ViterbiWindowed().decode(mcs, n_sym, n_cbps, n_sym * n_dbps, bits)
+    dec = np.concatenate([dec, np.zeros(64, np.uint8)])
+    state = 0
+    for i in range(7):
+        if dec[i]:
+            state |= 1 << (6 - i)
+    out = bytearray(data_size_byte + 2 + 8)
+    out[0] = state
+    for i in range(7, data_size_byte * 8 + 16):
+        fb = (1 if state & 64 else 0) ^ (1 if state & 8 else 0)
+        bit = fb ^ int(dec[i] & 1)
+        out[i // 8] |= bit << (i % 8)
+        state = ((state << 1) & 0x7e) | fb
+    body = bytes(out[2:2 + data_size_byte])
+    # boost::crc_32_type over message + little-endian CRC leaves the residue 558161692 (= 0x2144DF1C) exactly when the CRC matches
+    ok = (zlib.crc32(body) & 0xffffffff) == 558161692
+    return ok, body[:max(data_size_byte - 4, 0)]

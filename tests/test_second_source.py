@@ -281,3 +281,33 @@ def test_fft_peak_detect_oracle_equals_second_source():
         assert ka == kb
         if kb >= 0:
             assert (np.float32(fa).tobytes(), np.float32(pa).tobytes(), np.float32(ma).tobytes()) == (fb.tobytes(), pb.tobytes(), mb.tobytes())
+
+
+@pytest.mark.parametrize("mcs", range(6))
+def test_bit_codec_oracle_equals_second_source(mcs):
+    """stream_encoder / stream_decoder (lib/stream_encoder_impl.cc:126-207, lib/stream_decoder_impl.cc:258-292, :406-433, lib/utils.cc) read
+    twice: the encoder's integer pipeline symbol value for symbol value (mapped through the same constellation table), the decoder on
+    clean and on corrupted symbols - CRC verdict and payload bytes"""
+    rng = np.random.default_rng(200 + mcs)
+    bpsc = ss.mcs_params(mcs, 48)[0]
+    for trial in range(6):
+        pdu = bytes([int(rng.integers(1, 3))]) + rng.integers(0, 256, int(rng.integers(1, 180)), dtype=np.uint8).tobytes()
+        seed = int(rng.integers(1, 128))
+        vals, n_sym, size = ss.stream_encode_values(mcs, 48, pdu, seed)
+        sym, tags = oracle.stream_encode(mcs, 48, pdu, seed)
+        assert tags["pdu_len"] == size and sym.size == vals.size == n_sym * 48
+        pts = np.array([oracle.constellation_point(bpsc, int(v)) for v in range(1 << bpsc)], np.complex64)
+        assert np.array_equal(sym, pts[vals])
+        if bpsc == 1:
+            assert np.array_equal(pts, np.array([-1, 1], np.complex64))                      # constellation_bpsk
+        if bpsc == 2:                                                                        # constellation_qpsk / 2 (:218-221)
+            assert np.allclose(pts, np.array([-1 - 1j, 1 - 1j, -1 + 1j, 1 + 1j]) * (0.707107 / 2), atol=1e-7)
+        for n_bad in (0, 2, 25):
+            v2 = vals.copy()
+            if n_bad:
+                v2[rng.choice(v2.size, n_bad, replace=False)] ^= 1
+            ok_b, pay_b = ss.stream_decode_values(mcs, 48, size, v2)
+            ok_a, pay_a = oracle.stream_decode(mcs, 48, size, pts[v2])
+            assert bool(ok_a) == ok_b and pay_a == pay_b
+            if n_bad == 0:
+                assert ok_b and pay_b == pdu
