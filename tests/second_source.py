@@ -698,3 +698,88 @@ def stream_decode_values(mcs, n_dc, data_size_byte, values):
     # boost::crc_32_type over message + little-endian CRC leaves the residue 558161692 (= 0x2144DF1C) exactly when the CRC matches
     ok = (zlib.crc32(body) & 0xffffffff) == 558161692
     return ok, body[:max(data_size_byte - 4, 0)]
+
+
+# ------------------------------------------------------------------------------------------------ lib/moving_avg_impl.cc, lib/frame_detector_impl.cc
+def moving_avg_ref(buf, length, scale, n_out, max_iter=16000):
+    """moving_avg_impl::work (lib/moving_avg_impl.cc:62-98): `buf` = the length-1 history items followed by the new ones (set_history)"""
+    buf = np.asarray(buf, c64)
+    n = min(n_out, max_iter)
+    sr, si = f32(buf[0].real), f32(buf[0].imag)
+    for i in range(1, length - 1):
+        sr, si = f32(sr + buf[i].real), f32(si + buf[i].imag)
+    out = np.zeros(n, c64)
+    for i in range(n):
+        sr, si = f32(sr + buf[i + length - 1].real), f32(si + buf[i + length - 1].imag)
+        out[i] = complex(f32(sr * f32(scale)), f32(si * f32(scale)))
+        sr, si = f32(sr - buf[i].real), f32(si - buf[i].imag)
+    return out
+
+
+class FrameDetectorRef:
+    """frame_detector_impl::general_work (lib/frame_detector_impl.cc:70-193), one call per work(); nitems_read / nitems_written kept here"""
+
+    def __init__(self, fft_len, cp_len, threshold, min_n_peaks, ignore_gap):
+        self.fft_len, self.threshold, self.min_n_peaks, self.ignore_gap = fft_len, float(threshold), int(min_n_peaks), int(ignore_gap)
+        self.MAX_PEAK_VALUE, self.MAX_PEAK_DISTANCE, self.MAX_SAMPLES = 2.0, 2 * (fft_len + cp_len), 540 * (fft_len + cp_len)
+        self.state, self.n_peaks, self.cfo, self.copied, self.first_peak = "SEARCH", 0, f32(0), 0, 0
+        self.nread = self.nwritten = 0
+
+    def work(self, x, in_abs, in_cor, noutput):
+        x, in_abs, in_cor = np.asarray(x, c64), np.asarray(in_abs, c64), np.asarray(in_cor, f32)
+        ninput = min(x.size, in_abs.size, in_cor.size)
+        tags = []
+
+        def is_peak(v):
+            return float(v) > self.threshold and float(v) < self.MAX_PEAK_VALUE
+
+        def u64(v):                                   # nitems_read(0) + n - first_peak_ind is uint64_t arithmetic
+            return v & 0xFFFFFFFFFFFFFFFF
+
+        if self.state == "SEARCH":                                                             # :89-130
+            n_in = 0
+            while n_in < ninput:
+                if is_peak(in_cor[n_in]):
+                    if self.n_peaks < self.min_n_peaks:
+                        self.n_peaks += 1
+                        if self.n_peaks == 1:
+                            self.first_peak = self.nread + n_in
+                    elif u64(self.nread + n_in - self.first_peak) < self.MAX_PEAK_DISTANCE:
+                        self.state, self.copied = "COPY", 0
+                        self.cfo = f32(float(f32(carg(in_abs[n_in]))) / (self.fft_len / 4.0))
+                        self.n_peaks, self.first_peak = 0, 0
+                        tags.append((self.nwritten, float(self.cfo)))
+                        break
+                    else:
+                        self.n_peaks, self.first_peak = 0, 0
+                elif u64(self.nread + n_in - self.first_peak) > self.MAX_PEAK_DISTANCE:
+                    self.n_peaks, self.first_peak = 0, 0
+                n_in += 1
+            self.nread += n_in
+            return np.zeros(0, c64), n_in, tags
+        out = []                                                                               # COPY :132-186
+        n_out = 0
+        while n_out < ninput and n_out < noutput and self.copied < self.MAX_SAMPLES:
+            if is_peak(in_cor[n_out]):
+                if self.n_peaks < self.min_n_peaks:
+                    self.n_peaks += 1
+                    if self.n_peaks == 1:
+                        self.first_peak = self.nread + n_out
+                elif u64(self.nread + n_out - self.first_peak) < self.MAX_PEAK_DISTANCE:
+                    if self.copied > self.ignore_gap:
+                        self.copied, self.n_peaks, self.first_peak = 0, 0, 0
+                        self.cfo = f32(float(f32(carg(in_abs[n_out]))) / (self.fft_len / 4.0))
+                        tags.append((self.nwritten + n_out, float(self.cfo)))
+                        break
+                else:
+                    self.n_peaks, self.first_peak = 0, 0
+            elif u64(self.nread + n_out - self.first_peak) > self.MAX_PEAK_DISTANCE:
+                self.n_peaks, self.first_peak = 0, 0
+            out.append(cmul(x[n_out], cexp_j(f32(-self.cfo * f32(self.copied))))[()])          # float * int -> float
+            n_out += 1
+            self.copied += 1
+        if self.copied == self.MAX_SAMPLES:
+            self.state = "SEARCH"
+        self.nread += n_out
+        self.nwritten += n_out
+        return np.array(out, c64), n_out, tags

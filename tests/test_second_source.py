@@ -311,3 +311,39 @@ def test_bit_codec_oracle_equals_second_source(mcs):
             assert bool(ok_a) == ok_b and pay_a == pay_b
             if n_bad == 0:
                 assert ok_b and pay_b == pdu
+
+
+def test_moving_avg_and_frame_detector_oracle_equals_second_source():
+    """lib/moving_avg_impl.cc:62-98 (running sum, float drift and all) and the frame_detector state machine (lib/frame_detector_impl.cc:70-193)
+    read twice: random peak patterns, scheduler chunks of random size, min_n_peaks 0..6, frames inside and outside the ignore gap, a copy that
+    runs into MAX_SAMPLES - outputs bit for bit, consumed counts, tag offsets and values"""
+    rng = np.random.default_rng(8)
+    for length in (2, 3, 16, 48):
+        x = crandn(rng, 400)
+        hist = crandn(rng, length - 1)
+        a = oracle.moving_avg(x, length, 0.37, history=hist)
+        b = ss.moving_avg_ref(np.concatenate([hist, x]), length, 0.37, x.size)
+        assert np.array_equal(_bits(a), _bits(b))
+    for trial in range(10):
+        fft_len, cp = (64, 16) if trial % 2 else (32, 8)
+        min_peaks, gap = int(rng.integers(0, 7)), int(rng.integers(0, 600))
+        n = int(rng.integers(3000, 9000)) if trial < 8 else 540 * (fft_len + cp) + 3000        # the last two run into MAX_SAMPLES
+        cor = rng.uniform(0.0, 0.5, n).astype(np.float32)
+        for _ in range(int(rng.integers(1, 6))):
+            p0 = int(rng.integers(0, n - 200))
+            cor[p0:p0 + int(rng.integers(1, 3 * (fft_len + cp)))] = rng.uniform(0.65, 1.5)
+        cor[rng.integers(0, n, 5)] = 2.5                                                       # above MAX_PEAK_VALUE: not peaks
+        x, ia = crandn(rng, n), crandn(rng, n)
+        a, b = oracle.FrameDetector(fft_len, cp, 0.6, min_peaks, gap), ss.FrameDetectorRef(fft_len, cp, 0.6, min_peaks, gap)
+        pos, stalled = 0, 0
+        while pos < n:
+            step = int(rng.choice([1, 7, 100, 333, 4096]))
+            nout = int(rng.choice([step, max(1, step // 2)]))
+            sl = slice(pos, pos + step)
+            oa, ca, ta = a.work(x[sl], ia[sl], cor[sl], nout)
+            ob, cb, tb = b.work(x[sl], ia[sl], cor[sl], nout)
+            assert ca == cb and oa.size == ob.size and np.array_equal(_bits(oa), _bits(ob)), (trial, pos)
+            assert [t[0] for t in ta] == [t[0] for t in tb] and [t[1] for t in ta] == [t[1] for t in tb], (trial, pos, ta, tb)
+            stalled = stalled + 1 if ca == 0 else 0            # a detection on the first sample offered consumes nothing and switches to COPY:
+            assert stalled < 3                                 # the scheduler offers the same samples again
+            pos += ca
