@@ -324,9 +324,14 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
 // the workgroup-shared word of MODE 1 lives in a function of its own, so that only the kernels that use it carry the static LDS: the
 // MODE 3 form at fft_len 256 / 512 takes 80 KiB of dynamic LDS, two workgroups fill the CU's 160 KiB to the last allocation unit, and four
 // more static bytes left one workgroup per CU (0.28 -> 0.39 ms per 512 config-B frames, measured)
-template <bool ON> __device__ __forceinline__ unsigned* wide_run_max()
+template <bool ON> __device__ __forceinline__ unsigned* wide_run_max()        // [0] running maximum, [1], [2] pruning-mode votes for odd / even classes
 {
-    if constexpr (ON) { __shared__ unsigned v; return &v; }
+    if constexpr (ON) { __shared__ unsigned v[3]; return v; }
+    else return nullptr;
+}
+template <bool ON> __device__ __forceinline__ float2* wide_sample_twiddles()      // MODE 1: angle twiddles of the three sampled residues, [3][16]
+{
+    if constexpr (ON) { __shared__ float2 v[3 * 16]; return v; }
     else return nullptr;
 }
 template <int P, int MODE, int IA, int LOGN, int NT_ = 512>
@@ -350,7 +355,9 @@ __global__ __launch_bounds__(NT_, 2) void range_angle_wide_kernel(
     float2* s_g = smem;                                         // [2][P][256]
     float* s_pw = reinterpret_cast<float*>(s_g + 2 * P * RW_L) + (size_t)wave * (64 * P);   // MODE 3: this wave's tile (its four rows)
     unsigned* const s_run = wide_run_max<MODE == 1>();          // MODE 1: the workgroup's running maximum (float bits), see the angle axis
-    if constexpr (MODE == 1) { if (tid == 0) *s_run = 0u; }                    // ordered before its first use by the barrier of the first class
+    if constexpr (MODE == 1) { if (tid < 3) s_run[tid] = 0u; }                 // ordered before their first use by the barrier of the first class
+    float2* const s_tw1 = wide_sample_twiddles<MODE == 1>();    // exp(-j 2 pi p r / NA) for r = Ia/4, Ia/2, 3 Ia/4 (the sampling bound of the angle axis); same barrier
+    if constexpr (MODE == 1) { if (tid < 3 * 16) s_tw1[tid] = twA[((tid & 15) * ((tid >> 4) + 1) * (IA / 4)) & (P * IA - 1)]; }
 
     // this wave's share of H, for good
     float2 h[PPW][4][MM];
@@ -390,6 +397,11 @@ __global__ __launch_bounds__(NT_, 2) void range_angle_wide_kernel(
     PeakTracker trk;
     trk.init();
     bool prune_on = MODE == 1 && !(pace & 8);                   // MODE 1: rows are skipped by their bounds (angle axis below) until that stops paying in this frame
+    // The way a class is pruned is the same for every wave of the workgroup (the sampling bound deals the rows to the waves differently from
+    // the trips, so a class is covered only if all waves work it the same way): 0 = sum bound, trip by trip; 1 = sampling bound, row by row;
+    // 2 = not at all.  A wave that finds its bound useless votes for the next one in the word of the NEXT class's parity (s_run[1 + parity]):
+    // the votes of a class are all cast before the next class's barrier and read after it, and the mode only ever goes up.
+    unsigned pmode = 0u;
     unsigned seen = 0u;                                         // s_run as last read
     constexpr int items = RW_L * Ia;
     constexpr int ahalf = NA >> 1, amask = NA - 1;
@@ -486,7 +498,13 @@ __global__ __launch_bounds__(NT_, 2) void range_angle_wide_kernel(
             }
             return (sum * sum) * (1.0f + 1e-4f);
         };
+        unsigned long long rows = 0ull;                           // MODE 1 after the sampling bound: the wave's rows still to compute (bit = trip * 4 + row of the trip)
+        bool use_rows = false;
         float bnd[TRIPS];                                         // MODE 1: bound of this lane's row in trip t (the same in the Ia lanes of the row)
+        if constexpr (MODE == 1) pmode = max(pmode, *reinterpret_cast<volatile unsigned*>(s_run + 1 + (it & 1)));
+        if ((pace & 16) && pmode == 1u) pmode = 2u;               // JRC_DETECT_EXP bit 4: sum bound only
+        const bool l1_live = pmode == 0u;                         // ... formed for this class
+        unsigned* const vote = MODE == 1 ? s_run + 1 + ((it + 1) & 1) : nullptr;
         unsigned todo = TRIPS >= 32 ? 0xffffffffu : (1u << TRIPS) - 1u;
         int t_first = -1;
         auto candidates = [&]() -> unsigned {
@@ -497,49 +515,129 @@ __global__ __launch_bounds__(NT_, 2) void range_angle_wide_kernel(
             for (int t = 0; t < TRIPS; t++) m |= (__ballot(bnd[t] >= thr) != 0ull ? 1u : 0u) << t;
             return m;
         };
+        // Second bound, for frames in which nothing stands out (noise, weak or many targets) and sum_p |R[p][k]| says little: the angle axis of a
+        // row is a trigonometric polynomial f(theta) = sum_p R[p][k] e^{-j p theta} of degree P - 1, and the cells r = 0, Ia/4, Ia/2, 3 Ia/4 (mod Ia)
+        // are its values at 4 P equispaced angles.  By the Ehlich-Zeller inequality (a trigonometric polynomial of degree n is bounded between
+        // N > 2 n equidistant nodes by its largest node value over cos(pi n / N); applied to e^{j (P-1) phi} f(2 phi), degree P - 1 on 8 P nodes)
+        //     max over all theta of |f|^2  <=  max over those 4 P cells of |f|^2 / cos^2(pi (P - 1) / (8 P))          (P = 16: x 1.1488)
+        // so four of the Ia P-point transforms of a row decide whether the other Ia - 4 can hold the maximum (tests/test_oracle_radar.py checks the
+        // constant numerically).  A lane takes one row of the wave's TRIPS x 4 (both halves of the wave share the rows when there are only 32);
+        // the values are bounds with 1e-4 of slack, so this pass runs on the plain butterflies.
+        // rows of the class as the sampling pass deals them to the waves (not the trips' dealing: a row's 16 lanes read one LDS address there; here
+        // 32 lanes read 32 rows, which must fall into 32 different banks — q >> 2 runs over 32 consecutive values): bit i of a wave's row mask <-> row_of(i)
+        auto row_of = [&](int i) -> int {
+            constexpr int RPW_ = TRIPS * 4;
+            const int rl = i & 31, hi = i >> 5;
+            return RPW_ >= 64 ? 4 * (rl + 32 * (wave >> 1)) + 2 * (wave & 1) + hi : 4 * (rl + 32 * (wave & 1)) + (wave >> 1);
+        };
+        auto refine = [&](unsigned cand) -> unsigned {
+            constexpr int RPW = TRIPS * 4, PASSES = RPW >= 64 ? 4 : 2;
+            static_assert(RPW == 64 || RPW == 32, "a wave's rows fill the wave or half of it");
+            const int half = RPW >= 64 ? 0 : lane >> 5;
+            const int q = row_of(lane);                                          // a row per lane, 32 consecutive values of q >> 2 per half wave: no LDS bank conflicts
+            const int qi = (q & 3) * 64 + (q >> 2);
+            float rowmax = 0.f;
+#pragma unroll 1
+            for (int ps = 0; ps < PASSES; ps++) {
+                const int ri = RPW >= 64 ? ps : ps + 2 * half;     // residue r = ri Ia / 4
+                float2 y[P];
+                y[0] = sg[qi];
+                if (ri == 0) {
+#pragma unroll
+                    for (int p = 1; p < P; p++) y[p] = sg[p * RW_L + qi];
+                } else {
+                    const float2* tw = s_tw1 + (ri - 1) * 16;
+#pragma unroll
+                    for (int p = 1; p < P; p++) y[p] = cmul(sg[p * RW_L + qi], tw[p]);
+                }
+                fft_fwd_small<P>(y);
+#pragma unroll
+                for (int u = 0; u < P; u++) rowmax = fmaxf(rowmax, fast_power(y[u]));
+            }
+            if constexpr (RPW < 64) rowmax = fmaxf(rowmax, __shfl_xor(rowmax, 32));
+            static_assert(P == 16 || P == 8, "1 / cos^2(pi (P - 1) / (8 P)), rounded up, is tabulated for the pair counts of this kernel");
+            constexpr float EZ = P == 16 ? 1.14880f : 1.12803f;
+            {   // the sampled cells ARE cells of the map (to the last bits: plain instead of pinned butterflies, < 2e-6), so the largest of them is a
+                // lower bound of the maximum: it raises the filter threshold (never the tracked candidates) before anything else of the class is computed
+                const float wm = wave_max_f32(rowmax) * (1.0f - 4e-6f);
+                if (wm > trk.run_max) { trk.run_max = wm; if (lane == 0) atomicMax(s_run, __float_as_uint(wm)); }
+            }
+            unsigned long long surv = __ballot(rowmax * (EZ * (1.0f + 1e-4f)) >= trk.run_max * (1.0f - 1e-5f));
+            if constexpr (RPW < 64) surv &= 0xffffffffull;
+            rows = (pace & 32) ? 0ull : surv;                     // from here on the class is worked row by row: four surviving rows to a trip, whichever they are (JRC_DETECT_EXP bit 5: none - timing only)
+            use_rows = true;
+            return cand;
+        };
+        constexpr int S1_COST = TRIPS * 4 >= 64 ? 4 : 2;          // the sampling pass costs as much as this many trips
         if (MODE == 1 && prune_on) {
+            if (pmode == 0u) {
 #pragma unroll
-            for (int t = 0; t < TRIPS; t++) bnd[t] = row_bound(t * NT);
-            if (it == 0) {
-                float bm = bnd[0];
+                for (int t = 0; t < TRIPS; t++) bnd[t] = row_bound(t * NT);
+                if (it == 0) {
+                    float bm = bnd[0];
 #pragma unroll
-                for (int t = 1; t < TRIPS; t++) bm = fmaxf(bm, bnd[t]);
-                bm = wave_max_f32(bm);
-                t_first = 0;
+                    for (int t = 1; t < TRIPS; t++) bm = fmaxf(bm, bnd[t]);
+                    bm = wave_max_f32(bm);
+                    t_first = 0;
 #pragma unroll
-                for (int t = TRIPS - 1; t >= 0; t--) if (__ballot(bnd[t] == bm) != 0ull) t_first = t;
-                todo = 1u << t_first;
-            } else {
-                todo = candidates();
-                seen = *reinterpret_cast<volatile unsigned*>(s_run);
-                if (2 * __popc(todo) > TRIPS) prune_on = false;  // nothing stands out in this frame (noise, weak targets): the bounds cost more than they save
+                    for (int t = TRIPS - 1; t >= 0; t--) if (__ballot(bnd[t] == bm) != 0ull) t_first = t;
+                    todo = 1u << t_first;
+                } else {
+                    todo = candidates();
+                    seen = *reinterpret_cast<volatile unsigned*>(s_run);
+                    if (__popc(todo) > S1_COST + 1 && lane == 0) atomicMax(vote, 1u);     // the sums say little here: sample the rows from the next class on
+                }
+            } else if (pmode == 1u) {
+                trk.run_max = fmaxf(trk.run_max, __uint_as_float(*reinterpret_cast<volatile unsigned*>(s_run)));
+                refine(todo);
+                if (4 * __popcll(rows) > 3 * TRIPS * 4 && lane == 0) atomicMax(vote, 2u); // most rows survive the sampling too: leave the rest of the frame alone
             }
         }
 #pragma unroll 1
         for (int tt = 0; ; tt++) {
-            int w0;
+            int q;                                                // this lane's range bin of the class ((w0 + tid) % Ia == r; a wave's four bins q .. q + 3 are the four b of one a)
             if constexpr (MODE == 1) {
-                if (tt > 0 && t_first < 0 && prune_on) {          // a trip was computed: has the workgroup's maximum moved?
+                if (tt > 0 && t_first < 0 && prune_on && l1_live) {   // a trip was computed: has the workgroup's maximum moved?
                     const unsigned now = *reinterpret_cast<volatile unsigned*>(s_run);
                     if (now != seen) { seen = now; todo &= candidates(); }
                 }
-                if (todo == 0u) {
+                if (!use_rows && todo == 0u) {
                     if (t_first < 0) break;
                     __syncthreads();                              // first class of the workgroup: every wave has published the maximum of its strongest trip
                     todo = candidates() & ~(1u << t_first);
                     seen = *reinterpret_cast<volatile unsigned*>(s_run);
                     t_first = -1;
-                    if (2 * __popc(todo) > TRIPS) prune_on = false;
-                    if (todo == 0u) break;
+                    // the first class can still change its mind, all waves together: votes into this class's own word (read by everybody before the
+                    // barrier above, not read again), a second barrier, and whoever finds a vote samples its rows instead of computing its trips
+                    if (__popc(todo) > S1_COST + 1 && lane == 0) atomicMax(s_run + 1 + (it & 1), 1u);
+                    __syncthreads();
+                    if (!(pace & 16) && *reinterpret_cast<volatile unsigned*>(s_run + 1 + (it & 1)) >= 1u) {
+                        pmode = 1u;
+                        trk.run_max = fmaxf(trk.run_max, __uint_as_float(*reinterpret_cast<volatile unsigned*>(s_run)));
+                        refine(todo);
+                        if (4 * __popcll(rows) > 3 * TRIPS * 4 && lane == 0) atomicMax(vote, 2u);
+                    }
+                    if (!use_rows && todo == 0u) break;
                 }
-                w0 = (__ffs((int)todo) - 1) * NT;
-                todo &= todo - 1u;
+                if (use_rows) {                                   // four surviving rows, one per 16 lanes (a short last group repeats a row: the tracker does not mind)
+                    if (rows == 0ull) break;
+                    int rsel[4];
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        rsel[g] = rows ? __ffsll(rows) - 1 : rsel[g > 0 ? g - 1 : 0];
+                        if (rows) rows &= rows - 1ull;
+                    }
+                    const int g = lane >> 4;
+                    q = row_of(g == 0 ? rsel[0] : (g == 1 ? rsel[1] : (g == 2 ? rsel[2] : rsel[3])));
+                } else {
+                    const int w0 = (__ffs((int)todo) - 1) * NT;
+                    todo &= todo - 1u;
+                    q = (w0 + tid) / Ia;
+                }
             } else {
                 if (tt >= TRIPS) break;
-                w0 = tt * NT;
+                q = (tt * NT + tid) / Ia;
             }
-            const int w = w0 + tid;
-            const int q = w / Ia;                                 // (w % Ia == r); a wave's four range bins q .. q + 3 are the four b of one a
             const int qi = (q & 3) * 64 + (q >> 2);
             const int k = C * q + c;
             float2 y[P];

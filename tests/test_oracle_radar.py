@@ -179,3 +179,34 @@ def test_golden_tables_shape_the_generator(ofdm64):
         assert np.array_equal(m[sc].reshape(4, 4), P * ltf[sc])     # [sc][t*N_ltf + l] = P[t][l]*ltf[sc]
     assert np.allclose(ofdm64["P_ltf"] @ ofdm64["P_ltf"].conj().T, 4 * np.eye(4))
     assert list(ofdm64["pilot_subcarriers"]) == [-21, -7, 7, 21] and len(ofdm64["data_subcarriers"]) == 48
+
+
+@pytest.mark.parametrize("P", [8, 16])
+def test_sampling_bound_of_the_detect_only_angle_stage(P):
+    """chain.hip (range_angle_wide_kernel, MODE 1, `refine`): the angle axis of one range bin is f(theta) = sum_p R[p] e^{-j p theta}; its
+    cells r = 0, Ia/4, Ia/2, 3 Ia/4 (mod Ia) are 4 P equispaced samples, and the kernel skips a row when
+    max_samples |f|^2 / cos^2(pi (P-1) / (8 P)) is below the running maximum (Ehlich-Zeller inequality on e^{j(P-1)phi} f(2 phi)).
+    Numerical check of the constant it compiles in: random, sparse and optimised coefficient vectors never exceed it, and the
+    margin to the worst case found is small enough that a looser constant would be noticed."""
+    from scipy.optimize import minimize
+    const = {16: 1.14880, 8: 1.12803}[P]
+    exact = 1.0 / np.cos(np.pi * (P - 1) / (8.0 * P)) ** 2
+    assert exact <= const < exact * (1 + 1e-4)
+    rng = np.random.default_rng(P)
+
+    def ratio(a):
+        if not np.any(a):
+            return 0.0
+        return float((np.abs(np.fft.fft(a, 16384)) ** 2).max() / (np.abs(np.fft.fft(a, 4 * P)) ** 2).max())
+
+    worst = 0.0
+    for trial in range(1500):
+        a = rng.standard_normal(P) + 1j * rng.standard_normal(P)
+        if trial % 3 == 0:
+            a = a * (rng.random(P) < 0.3)
+        worst = max(worst, ratio(a))
+    for start in range(12):
+        r = minimize(lambda x: -ratio(x[:P] + 1j * x[P:]), rng.standard_normal(2 * P), method="Nelder-Mead",
+                     options=dict(maxiter=3000, xatol=1e-6, fatol=1e-9))
+        worst = max(worst, -r.fun)
+    assert 1.05 < worst <= const

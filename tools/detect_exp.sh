@@ -1,6 +1,6 @@
 #!/bin/bash
 # detect-only kernel timing experiments (GPU box): JRC_DETECT_EXP variants of tools/bench_extra.py's detect legs
-for E in ${DETECT_EXPS:-0 8}; do
+for E in ${DETECT_EXPS:-0 16 8}; do
   echo "== JRC_DETECT_EXP=$E"
   JRC_DETECT_EXP=$E JRC_BENCH_EXTRA_ONLY=detect python3 tools/bench_extra.py 2>/dev/null | python3 -c "
 import sys, json
