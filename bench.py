@@ -475,6 +475,8 @@ def secondary_figures(cfg, ctx, sc, axes):
     leg("chain_with_rx_demod", _demod)
     if hasattr(be, "detect_only"):
         leg("detect_only_chain", lambda: be.detect_only(cfg if cfg in ("B", "D") else "B"))
+        # the same mode on frames of noise alone: the case its exact pruning of the angle stage gains least from
+        leg("detect_only_chain_noise_only_frames", lambda: be.detect_only(cfg if cfg in ("B", "D") else "B", noise_only=True))
     if hasattr(be, "power_map"):
         leg("power_map_chain", lambda: be.power_map(cfg if cfg in ("B", "D") else "B"))
     leg("equalizer_config_c", _eq)
