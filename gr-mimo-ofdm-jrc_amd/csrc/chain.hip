@@ -1524,6 +1524,92 @@ __global__ __launch_bounds__(256) void rd_product_t_kernel(const float2* __restr
     }
 }
 
+// Product and Doppler transform as one kernel, for ND = S * Id in {32, 64, 128, 256}: a workgroup takes 4096 / ND subcarriers of one
+// (frame, pair), forms rx conj(tx) symbol by symbol (coalesced along the subcarriers) into a [subcarrier][symbol] tile in LDS — zero-padded to
+// ND — and transforms every row in two in-register passes, ND = 16 * R2 with n = R2 a + b, k = k1 + 16 k2:
+//     X[k1 + 16 k2] = sum_b W_R2^(b k2) W_ND^(b k1) ( sum_a x[R2 a + b] W_16^(a k1) )
+// (a 16-point transform per (row, b), in place; then an R2-point transform per (row, k1), stored fftshifted as 128-byte pieces of row
+// [subcarrier] of E).  The compact array is written once and never read back by this stage: 402 MB instead of 938 MB of traffic per 16
+// config-D frames against rd_product_t_kernel + the stock FFT in place.
+template <int ND>
+__global__ __launch_bounds__(256) void rd_product_doppler_kernel(const float2* __restrict__ frames, float2* __restrict__ E, ChanestGeom g, int T, int R,
+                                                                 const float2* __restrict__ twD /* exp(-j 2 pi i / ND) */, int nblk)
+{
+    constexpr int R2 = ND / 16, SCB = 4096 / ND, PITCH = ND + R2 + 1, LY = 256 / SCB;
+    static_assert(ND == 32 || ND == 64 || ND == 128 || ND == 256, "16 x {2, 4, 8, 16} points");
+    __shared__ float2 tile[SCB * PITCH];
+    __shared__ float2 s_tw[ND];
+    const int tid = threadIdx.x;
+    const int P = T * R;
+    const size_t fp = blockIdx.x / (unsigned)nblk;
+    const int n0 = (int)(blockIdx.x % (unsigned)nblk) * SCB;
+    const int p = (int)(fp % P);
+    const size_t f = fp / P;
+    const int r = g.interleave ? p % R : p / T, t = g.interleave ? p / R : p % T;
+    const float2* fb = frames + f * g.frame_stride;
+    const float2* rxp = fb + (size_t)(T + r) * g.port_stride + (size_t)g.rx_item0 * g.N;
+    const float2* txp = fb + (size_t)t * g.port_stride + (size_t)g.tx_item0 * g.N;
+    for (int i = tid; i < ND; i += 256) s_tw[i] = twD[i];
+    {   // all of a lane's loads go out before the first product: no branch around a load (symbols past S and subcarriers past fft_len repeat the
+        // last one and are zeroed afterwards), so ND / LY = 16 symbols x two streams are in flight per lane
+        constexpr int NIT = ND / LY;
+        const int lx = tid % SCB, ly = tid / SCB, n = n0 + lx, nc = n < g.N ? n : g.N - 1;
+        float2 a[NIT], b[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; i++) {
+            const int sym = ly + i * LY, sc = sym < g.S ? sym : g.S - 1;
+            a[i] = rxp[(size_t)sc * g.N + nc];
+            b[i] = txp[(size_t)sc * g.N + nc];
+        }
+#pragma unroll
+        for (int i = 0; i < NIT; i++) {
+            const int sym = ly + i * LY;
+            const bool on = sym < g.S && n < g.N;
+            tile[lx * PITCH + sym] = on ? make_float2(a[i].x * b[i].x + a[i].y * b[i].y, a[i].y * b[i].x - a[i].x * b[i].y)      // rx * conj(tx)
+                                        : make_float2(0.f, 0.f);
+        }
+    }
+    __syncthreads();
+    {   // 16-point transforms over a, one (row, b) per lane, in place; twiddled for the second pass
+        const int b = tid % R2, col = tid / R2;
+        float2* x0 = tile + col * PITCH + b;
+        float2 x[16];
+#pragma unroll
+        for (int a = 0; a < 16; a++) x[a] = x0[R2 * a];
+        fft_fwd_small<16>(x);
+#pragma unroll
+        for (int k1 = 1; k1 < 16; k1++) x[k1] = cmul(x[k1], s_tw[b * k1]);
+#pragma unroll
+        for (int k1 = 0; k1 < 16; k1++) x0[R2 * k1] = x[k1];
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int task = tid; task < SCB * 16; task += 256) {                   // R2-point transforms over b, one (row, k1) per lane
+        const int k1 = task & 15, col = task >> 4;
+        const float2* y0 = tile + col * PITCH + R2 * k1;
+        float2 y[R2];
+#pragma unroll
+        for (int b = 0; b < R2; b++) y[b] = y0[b];
+        fft_fwd_small<R2>(y);
+        if (n0 + col < g.N) {
+            float2* dst = E + (fp * (size_t)g.N + n0 + col) * ND;
+#pragma unroll
+            for (int k2 = 0; k2 < R2; k2++) dst[(k1 + 16 * k2 + ND / 2) & (ND - 1)] = y[k2];     // fftshift; cached: the range kernel reads E next
+        }
+    }
+}
+
+template <int ND>
+static int launch_rd_product_doppler(jrc_ctx* ctx, const float2* frames, float2* E, const ChanestGeom& g, int T, int R, size_t fp, hipStream_t s)
+{
+    const float2* twD = nullptr;
+    JRC_TRY(jrc_get_twiddles(ctx, ND, -1, &twD));
+    const int nblk = (g.N + 4096 / ND - 1) / (4096 / ND);
+    hipLaunchKernelGGL(rd_product_doppler_kernel<ND>, dim3((unsigned)(fp * nblk)), dim3(256), 0, s, frames, E, g, T, R, twD, nblk);
+    JRC_HIP(ctx, hipGetLastError());
+    return JRC_OK;
+}
+
 template <int NT, int MMAX, bool TWC_LDS>
 __global__ __launch_bounds__(NT) void range_doppler_fused_kernel(const float2* __restrict__ E,     // [units/(ND/16)][N][ND]
                                                                  float2* __restrict__ out,         // [units/(ND/16)][NR][ND]
@@ -1634,10 +1720,23 @@ __global__ __launch_bounds__(NT) void range_doppler_fused_kernel(const float2* _
 // i, which then holds the bin whose mixed-radix digits are those of i reversed, as the 128-byte line of its output row.  The tile is kept
 // conjugated so that the inverse transform runs on the forward butterflies of fft_device.h.  5 log2(fft_len) + 6 flops per output
 // instead of the fold's 8 fft_len / 64 + 30.
+// row -> bin of the in-place decimation-in-frequency transform: row = sum_s d_s * N / (r_0 ... r_s) holds bin k = sum_s d_s * (r_0 ... r_{s-1})
+template <int N, int R16, int R4, int R2>
+__device__ __forceinline__ int rd_bin_of_row(int row)
+{
+    int rem = row, k = 0, span = N, mult = 1;
+#pragma unroll
+    for (int ps = 0; ps < R16; ps++) { span >>= 4; const int d = rem / span; rem -= d * span; k += d * mult; mult <<= 4; }
+#pragma unroll
+    for (int ps = 0; ps < R4; ps++) { span >>= 2; const int d = rem / span; rem -= d * span; k += d * mult; mult <<= 2; }
+    if constexpr (R2 > 0) k += rem * mult;                                // the last digit (span 1)
+    return k;
+}
+
 template <int NT /* == fft_len */>
 __global__ __launch_bounds__(NT) void range_doppler_pruned_kernel(const float2* __restrict__ E,     // [units/(ND/16)][N][ND]
                                                                   float2* __restrict__ out,         // [units/(ND/16)][NR][ND]
-                                                                  const float2* __restrict__ twR, int NR, int ND, long n_units, int WPF, int nx)
+                                                                  const float2* __restrict__ twR, int NR, int ND, long n_units, int WPF, int nx, int exp)
 {
     extern __shared__ __attribute__((aligned(16))) float4 s_t[];          // [N][8]: row n = 16 bins
     constexpr int N = NT, LOG2 = (NT == 64 ? 6 : (NT == 128 ? 7 : (NT == 256 ? 8 : (NT == 512 ? 9 : 10)))), RSTEP = NT / 8;
@@ -1686,8 +1785,16 @@ __global__ __launch_bounds__(NT) void range_doppler_pruned_kernel(const float2* 
     // class twiddles exp(+j 2 pi row c / NR) of the lane's rows: the first row from the table, the others by the (uniform) step
     // exp(+j 2 pi ESTEP c / NR); both are fetched one class ahead
     float2 cw0 = twR[(erow0 * slice) & (NR - 1)], cstep = twR[(ESTEP * slice) & (NR - 1)];
-    float2* outp = out + (size_t)fp * NR * ND + d0 + 2 * seg;
+    float2* outb = out + (size_t)fp * NR * ND + d0;
+    float2* outp = outb + 2 * seg;
     typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    // which pass is the last one: it has span 1 (no twiddles) and stores its butterflies' outputs straight from registers — row i holds the
+    // bin rd_bin_of_row(i) — so a class's 128 KiB (fft_len 1024) leave while the NEXT class's passes run: nothing waits for a store, and
+    // the barrier that frees the tile for the next class's first pass sits between that pass's arithmetic and its LDS writes
+    constexpr int LAST = R2 > 0 ? 2 : (R4 > 0 ? 4 : 16);
+    static_assert(LAST != 16 || R16 >= 2, "a lone radix-16 pass would be first and last pass at once");
+    static_assert(LAST != 4 || R16 > 0 || R4 >= 2, "a lone radix-4 pass would be first and last pass at once");
 #pragma unroll 1
     for (int c = slice; c < Ir; c += WPF) {
         if constexpr (R16 > 0) {                                          // first pass: radix 16 from registers
@@ -1706,25 +1813,29 @@ __global__ __launch_bounds__(NT) void range_doppler_pruned_kernel(const float2* 
                     v[m] = make_float2(v[m].x * w.x + v[m].y * w.y, v[m].y * w.x - v[m].x * w.y);
                 }
             }
+            __syncthreads();                                              // the previous class's last pass has read the tile
             float2* p0 = s_f + (size_t)b0 * 16 + bin;
 #pragma unroll
             for (int m = 0; m < 16; m++) p0[(size_t)m * q * 16] = v[m];
-        } else {                                                          // first pass: radix 4 from registers
+        } else {                                                          // first pass: radix 4 from registers (fft_len 1024), one butterfly at a time
             constexpr int q = N / 4;
-            float4 a[8];
-            {
-                float2 w = cw0;
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const float2 x = cmul(make_float2(e[j].x, e[j].y), w), y = cmul(make_float2(e[j].z, e[j].w), w);
-                    a[j] = make_float4(x.x, -x.y, y.x, -y.y);            // conjugated
-                    w = cmul(w, cstep);
-                }
-            }
+            __syncthreads();                                              // the previous class's last pass has read the tile
+            const float2 cs2 = cmul(cstep, cstep);
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const int jj = r0 + h * RSTEP;
-                const float4 a0 = a[h], a1 = a[h + 2], a2 = a[h + 4], a3 = a[h + 6];
+                float4 a[4];
+                {
+                    float2 w = h == 0 ? cw0 : cmul(cw0, cstep);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const float4 ee = e[h + 2 * j];
+                        const float2 x = cmul(make_float2(ee.x, ee.y), w), y = cmul(make_float2(ee.z, ee.w), w);
+                        a[j] = make_float4(x.x, -x.y, y.x, -y.y);        // conjugated
+                        w = cmul(w, cs2);
+                    }
+                }
+                const float4 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
                 const float4 t0 = make_float4(a0.x + a2.x, a0.y + a2.y, a0.z + a2.z, a0.w + a2.w);
                 const float4 t1 = make_float4(a0.x - a2.x, a0.y - a2.y, a0.z - a2.z, a0.w - a2.w);
                 const float4 t2 = make_float4(a1.x + a3.x, a1.y + a3.y, a1.z + a3.z, a1.w + a3.w);
@@ -1755,24 +1866,37 @@ __global__ __launch_bounds__(NT) void range_doppler_pruned_kernel(const float2* 
 #pragma unroll
             for (int l = 0; l < 16; l++) v[l] = p0[(size_t)l * q * 16];
             fft_fwd_small<16>(v);
-            if (q > 1) {
+            if ((exp & 2) && !(LAST == 16 && ps == R16 - 1)) continue;
+            if (LAST == 16 && ps == R16 - 1) {                            // span 1: rows 16 b + m leave as eight-byte pieces, 16 lanes to a 128-byte line
 #pragma unroll
-                for (int m = 1; m < 16; m++) {
-                    const float2 w = s_w[(jj * m) << (4 * ps)];           // exp(+j 2 pi jj m / L); the forward pass needs its conjugate
-                    v[m] = make_float2(v[m].x * w.x + v[m].y * w.y, v[m].y * w.x - v[m].x * w.y);
+                for (int m = 0; m < 16; m++) {
+                    const int k = rd_bin_of_row<N, R16, R4, R2>(16 * b + m);
+                    const v2f t = {v[m].x, -v[m].y};
+                    if (!(exp & 1)) __builtin_nontemporal_store(t, reinterpret_cast<v2f*>(outb + ((size_t)Ir * k + c) * ND + bin));
                 }
-            }
+            } else {
+                if (q > 1) {
 #pragma unroll
-            for (int m = 0; m < 16; m++) p0[(size_t)m * q * 16] = v[m];
-            __syncthreads();
+                    for (int m = 1; m < 16; m++) {
+                        const float2 w = s_w[(jj * m) << (4 * ps)];       // exp(+j 2 pi jj m / L); the forward pass needs its conjugate
+                        v[m] = make_float2(v[m].x * w.x + v[m].y * w.y, v[m].y * w.x - v[m].x * w.y);
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < 16; m++) p0[(size_t)m * q * 16] = v[m];
+                __syncthreads();
+            }
         }
 #pragma unroll
         for (int ps = (R16 > 0 ? 0 : 1); ps < R4; ps++) {                 // two-bin segments, two butterflies per lane
             const int L = (N >> (4 * R16)) >> (2 * ps), q = L >> 2;
+            const bool last = LAST == 4 && ps == R4 - 1;                  // then q == 1
+            if ((exp & 2) && !last) continue;
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const int b = (tid + h * NT) >> 3, jj = b & (q - 1);
-                float4* p0 = s_t + ((size_t)(b / q) * L + jj) * 8 + seg;
+                const int row0 = (b / q) * L + jj;
+                float4* p0 = s_t + (size_t)row0 * 8 + seg;
                 const float4 a0 = p0[0], a1 = p0[(size_t)q * 8], a2 = p0[(size_t)2 * q * 8], a3 = p0[(size_t)3 * q * 8];
                 const float4 t0 = make_float4(a0.x + a2.x, a0.y + a2.y, a0.z + a2.z, a0.w + a2.w);
                 const float4 t1 = make_float4(a0.x - a2.x, a0.y - a2.y, a0.z - a2.z, a0.w - a2.w);
@@ -1782,43 +1906,40 @@ __global__ __launch_bounds__(NT) void range_doppler_pruned_kernel(const float2* 
                 float4 y2 = make_float4(t0.x - t2.x, t0.y - t2.y, t0.z - t2.z, t0.w - t2.w);
                 float4 y1 = make_float4(t1.x + t3.y, t1.y - t3.x, t1.z + t3.w, t1.w - t3.z);     // t1 - j t3 (forward)
                 float4 y3 = make_float4(t1.x - t3.y, t1.y + t3.x, t1.z - t3.w, t1.w + t3.z);     // t1 + j t3
-                if (q > 1) {
-                    const float2 w1 = s_w[jj * (N / L)], w2 = cmul(w1, w1), w3 = cmul(w2, w1);   // used conjugated
-                    auto cmulc = [](float x, float y, float2 w) { return make_float2(x * w.x + y * w.y, y * w.x - x * w.y); };
-                    float2 v;
-                    v = cmulc(y1.x, y1.y, w1); y1.x = v.x; y1.y = v.y; v = cmulc(y1.z, y1.w, w1); y1.z = v.x; y1.w = v.y;
-                    v = cmulc(y2.x, y2.y, w2); y2.x = v.x; y2.y = v.y; v = cmulc(y2.z, y2.w, w2); y2.z = v.x; y2.w = v.y;
-                    v = cmulc(y3.x, y3.y, w3); y3.x = v.x; y3.y = v.y; v = cmulc(y3.z, y3.w, w3); y3.z = v.x; y3.w = v.y;
+                if (last) {
+                    const float4 ys[4] = {y0, y1, y2, y3};
+#pragma unroll
+                    for (int m = 0; m < 4; m++) {
+                        const int k = rd_bin_of_row<N, R16, R4, R2>(row0 + m);
+                        const v4f t = {ys[m].x, -ys[m].y, ys[m].z, -ys[m].w};
+                        if (!(exp & 1)) __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(outp + ((size_t)Ir * k + c) * ND));
+                    }
+                } else {
+                    if (q > 1) {
+                        const float2 w1 = s_w[jj * (N / L)], w2 = cmul(w1, w1), w3 = cmul(w2, w1);   // used conjugated
+                        auto cmulc = [](float x, float y, float2 w) { return make_float2(x * w.x + y * w.y, y * w.x - x * w.y); };
+                        float2 v;
+                        v = cmulc(y1.x, y1.y, w1); y1.x = v.x; y1.y = v.y; v = cmulc(y1.z, y1.w, w1); y1.z = v.x; y1.w = v.y;
+                        v = cmulc(y2.x, y2.y, w2); y2.x = v.x; y2.y = v.y; v = cmulc(y2.z, y2.w, w2); y2.z = v.x; y2.w = v.y;
+                        v = cmulc(y3.x, y3.y, w3); y3.x = v.x; y3.y = v.y; v = cmulc(y3.z, y3.w, w3); y3.z = v.x; y3.w = v.y;
+                    }
+                    p0[0] = y0; p0[(size_t)q * 8] = y1; p0[(size_t)2 * q * 8] = y2; p0[(size_t)3 * q * 8] = y3;
                 }
-                p0[0] = y0; p0[(size_t)q * 8] = y1; p0[(size_t)2 * q * 8] = y2; p0[(size_t)3 * q * 8] = y3;
             }
-            __syncthreads();
+            if (!last) __syncthreads();
         }
-        if constexpr (R2 > 0) {                                           // span 2: no twiddles; two-bin segments, four butterflies per lane
+        if constexpr (R2 > 0) {                                           // span 2: no twiddles; two-bin segments, four butterflies per lane; the last pass
 #pragma unroll
             for (int h = 0; h < 4; h++) {
-                float4* p0 = s_t + (size_t)((tid + h * NT) >> 3) * 2 * 8 + seg;
+                const int row0 = ((tid + h * NT) >> 3) * 2;
+                const float4* p0 = s_t + (size_t)row0 * 8 + seg;
                 const float4 a0 = p0[0], a1 = p0[8];
-                p0[0] = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
-                p0[8] = make_float4(a0.x - a1.x, a0.y - a1.y, a0.z - a1.z, a0.w - a1.w);
+                const v4f lo = {a0.x + a1.x, -(a0.y + a1.y), a0.z + a1.z, -(a0.w + a1.w)};
+                const v4f hi = {a0.x - a1.x, -(a0.y - a1.y), a0.z - a1.z, -(a0.w - a1.w)};
+                if (!(exp & 1)) __builtin_nontemporal_store(lo, reinterpret_cast<v4f*>(outp + ((size_t)Ir * rd_bin_of_row<N, R16, R4, R2>(row0) + c) * ND));
+                if (!(exp & 1)) __builtin_nontemporal_store(hi, reinterpret_cast<v4f*>(outp + ((size_t)Ir * rd_bin_of_row<N, R16, R4, R2>(row0 + 1) + c) * ND));
             }
-            __syncthreads();
         }
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int row = r0 + j * RSTEP;
-            // row = sum_s d_s * N / (r_0 ... r_s) holds bin k = sum_s d_s * (r_0 ... r_{s-1})
-            int rem = row, k = 0, span = N, mult = 1;
-#pragma unroll
-            for (int ps = 0; ps < R16; ps++) { span >>= 4; const int d = rem / span; rem -= d * span; k += d * mult; mult <<= 4; }
-#pragma unroll
-            for (int ps = 0; ps < R4; ps++) { span >>= 2; const int d = rem / span; rem -= d * span; k += d * mult; mult <<= 2; }
-            if constexpr (R2 > 0) k += rem * mult;                        // the last digit (span 1)
-            const float4 v = s_t[row * 8 + seg];
-            v4f t = {v.x, -v.y, v.z, -v.w};
-            __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(outp + ((size_t)Ir * k + c) * ND));
-        }
-        __syncthreads();
     }
 }
 
@@ -1833,7 +1954,7 @@ static int launch_rd_pruned(jrc_ctx* ctx, const float2* E, float2* out, const fl
     while (wpf * 2 <= Ir && (long)wpf * 2 * n_units <= target) wpf *= 2;
     const int nx = ctx->n_xcd;
     const long groups = (n_units + nx - 1) / nx;
-    hipLaunchKernelGGL((range_doppler_pruned_kernel<NT>), dim3((unsigned)(groups * wpf * nx)), dim3(NT), lds, s, E, out, twR, NR, ND, n_units, wpf, nx);
+    hipLaunchKernelGGL((range_doppler_pruned_kernel<NT>), dim3((unsigned)(groups * wpf * nx)), dim3(NT), lds, s, E, out, twR, NR, ND, n_units, wpf, nx, ctx->tune.rd_exp);
     JRC_HIP(ctx, hipGetLastError());
     return JRC_OK;
 }
@@ -1872,13 +1993,20 @@ extern "C" int jrc_range_doppler_dev(jrc_ctx* ctx, const jrc_chain_cfg* c, int i
     if (jrc_is_pow2(N) && N >= RA_L && N <= 1024 && jrc_is_pow2(NR) && NR >= RA_L && jrc_is_pow2(ND) && ND >= RD_DT && ND <= 8192 &&
         interp_doppler <= c->interp_range && ((reinterpret_cast<size_t>(d_work) & 15) == 0) && !ctx->tune.rd_generic) {
         const size_t fp = (size_t)n_frames * P;
-        for (size_t z0 = 0; z0 < fp; z0 += 65535) {      // gridDim.z (frame, pair) is limited to 65535: chunks
-            const size_t nz = fp - z0 < 65535 ? fp - z0 : 65535;
-            hipLaunchKernelGGL(rd_product_t_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((ND + 63) / 64), (unsigned)nz), dim3(256), 0, s,
-                               (const float2*)d_frames, (float2*)d_work, g, T, R, (int)ND, z0);
+        const bool one_kernel = !ctx->tune.rd_two_step && fp * ((size_t)N * ND / 4096 + 1) < 0x7fffffffull;
+        if (one_kernel && ND == 128) { JRC_TRY(launch_rd_product_doppler<128>(ctx, (const float2*)d_frames, (float2*)d_work, g, T, R, fp, s)); }
+        else if (one_kernel && ND == 64) { JRC_TRY(launch_rd_product_doppler<64>(ctx, (const float2*)d_frames, (float2*)d_work, g, T, R, fp, s)); }
+        else if (one_kernel && ND == 256) { JRC_TRY(launch_rd_product_doppler<256>(ctx, (const float2*)d_frames, (float2*)d_work, g, T, R, fp, s)); }
+        else if (one_kernel && ND == 32) { JRC_TRY(launch_rd_product_doppler<32>(ctx, (const float2*)d_frames, (float2*)d_work, g, T, R, fp, s)); }
+        else {
+            for (size_t z0 = 0; z0 < fp; z0 += 65535) {      // gridDim.z (frame, pair) is limited to 65535: chunks
+                const size_t nz = fp - z0 < 65535 ? fp - z0 : 65535;
+                hipLaunchKernelGGL(rd_product_t_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((ND + 63) / 64), (unsigned)nz), dim3(256), 0, s,
+                                   (const float2*)d_frames, (float2*)d_work, g, T, R, (int)ND, z0);
+            }
+            JRC_HIP(ctx, hipGetLastError());
+            JRC_TRY(launch_fft_vcc(ctx, (int)ND, 1, 1, nullptr, fp * N, (const float2*)d_work, (float2*)d_work, ND, 0, s));        // Doppler
         }
-        JRC_HIP(ctx, hipGetLastError());
-        JRC_TRY(launch_fft_vcc(ctx, (int)ND, 1, 1, nullptr, fp * N, (const float2*)d_work, (float2*)d_work, ND, 0, s));        // Doppler
         const float2* twR = nullptr;
         JRC_TRY(jrc_get_twiddles(ctx, (int)NR, +1, &twR));
         const size_t lds = sizeof(float2) * ((size_t)RD_DT * N + (size_t)RD_DT * RA_L + (N > 256 ? (size_t)N : 0));

@@ -85,8 +85,10 @@ extern "C" int jrc_create(int device, jrc_ctx** out)
     ctx->tune.ra_ref_sum = getenv("JRC_RA_REF_SUM") != nullptr;
     ctx->tune.rd_generic = getenv("JRC_RD_GENERIC") != nullptr;
     ctx->tune.rd_fold = getenv("JRC_RD_FOLD") != nullptr;
+    ctx->tune.rd_two_step = getenv("JRC_RD_TWO_STEP") != nullptr;
     if (const char* e = getenv("JRC_RA_PACE")) ctx->tune.ra_pace = (int)strtol(e, nullptr, 0);
     if (const char* e = getenv("JRC_DETECT_EXP")) ctx->tune.detect_exp = atoi(e);
+    if (const char* e = getenv("JRC_RD_EXP")) ctx->tune.rd_exp = atoi(e);
     if (const char* e = getenv("JRC_RA_OFFERED_TBPS")) ctx->tune.ra_offered_tbps = atof(e);
     if (const char* e = getenv("JRC_DEMOD_SPR")) ctx->tune.demod_spr = atoi(e);
     if (const char* e = getenv("JRC_EQ_WPE")) ctx->tune.eq_wpe = atoi(e);

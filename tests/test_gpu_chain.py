@@ -179,11 +179,38 @@ def test_chain_generic_and_fused_modes_agree(jrc, ctx, monkeypatch):
         assert abs(a.snr_est - b.snr_est) < 1e-2
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,S,Ir,Id", [(256, 64, 8, 1), (1024, 128, 8, 1), (128, 32, 4, 2), (64, 64, 4, 4)])
+def test_range_doppler_one_kernel_front_equals_two_step(jrc, N, S, Ir, Id, monkeypatch):
+    """product + Doppler FFT as one kernel (the default where S * Id is 32 ... 256) against rd_product_t_kernel + the stock FFT (JRC_RD_TWO_STEP)"""
+    import torch
+    from jrc_amd import synth
+    sc = synth.Scenario(N, 2, 2, S, targets=[(12.0, 10.0, 150.0, 100.0), (30.0, -20.0, -80.0, 60.0)])
+    F = 3
+    frames = synth.make_frames(sc, F)
+    rb, ab = jrc.radar_axes(N, sc.fs, Ir, 4, 2)
+    outs = []
+    for two_step in (False, True):
+        if two_step:
+            monkeypatch.setenv("JRC_RD_TWO_STEP", "1")
+        c = jrc.Context(0)
+        chain = jrc.RadarChain(N, 2, 2, S, sc.Npre, Ir, 2, rb, ab, 2.4, 30.0, max_frames=F, ctx=c)
+        bufs = chain.alloc(F, "cuda:0")
+        bufs["frames"].copy_(torch.from_numpy(frames.view(np.float32).reshape(bufs["frames"].shape)))
+        torch.cuda.synchronize()
+        outs.append(chain.range_doppler(bufs, F, Id).cpu().numpy().view(np.complex64)[..., 0])
+        chain.close()
+        c.close()
+    assert outs[0].shape == outs[1].shape and rel_err(outs[0], outs[1]) < 2e-6
+
+
 @pytest.mark.parametrize("T,R,N,S,Ir,Id,vel", [(2, 2, 64, 16, 4, 4, 30.0), (4, 4, 256, 64, 2, 1, -20.0), (1, 1, 64, 64, 2, 2, 600.0),
                                                (1, 2, 1024, 16, 8, 1, 200.0),     # fft_len 1024: pruned-FFT range kernel, 8 classes
                                                (2, 1, 256, 32, 1, 1, -50.0),      # no range interpolation (one class)
                                                (1, 2, 128, 16, 4, 2, 1000.0),     # fft_len not a power of four: the fold kernel
                                                (1, 1, 512, 32, 2, 1, 300.0),
+                                               (1, 1, 64, 64, 4, 4, 400.0),       # 256 Doppler bins: 16 x 16 points in the product + Doppler kernel
+                                               (1, 1, 64, 32, 2, 1, 3000.0),      # fewer subcarriers than a workgroup of that kernel takes
                                                (2, 1, 96, 8, 2, 1, 10.0)])        # not a power of two: block by block
 def test_range_doppler_map_row_d(jrc, ctx, T, R, N, S, Ir, Id, vel):
     """row D has no reference counterpart (the reference sums over symbols): checked against the numpy definition

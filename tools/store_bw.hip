@@ -115,6 +115,42 @@ __global__ void k_rd64(float4* out, int N, int Ir, int ND, long n_units) {
         }
 }
 
+// (h) like (f) with DT-bin tiles: DT*8-byte pieces of the rows (DT/2 lanes per piece), scattered row order
+template <int NT_, int DT, bool ROT = false>
+__global__ void k_rdw(float4* out, int N, int Ir, int ND, long n_units) {
+    const int xcd = blockIdx.x & 7; const long u = (long)(blockIdx.x >> 3) * 8 + xcd;
+    if (u >= n_units) return;
+    constexpr int LPR = DT / 2, RPI = NT_ / LPR;
+    const int tiles = ND / DT; const long fp = u / tiles; const int tile = (int)(u % tiles);
+    float4* base = out + ((size_t)fp * N * Ir * ND + tile * DT) / 2;
+    const int seg = threadIdx.x % LPR, r0 = threadIdx.x / LPR;
+    for (int ci = 0; ci < Ir; ci++) {
+        const int c = ROT ? (int)((ci + u) % Ir) : ci;                      // ROT: the workgroups do not all work on the same class at the same time
+        for (int j = 0; j < N / RPI; j++) {
+            int row = r0 + j * RPI;
+            unsigned k = __brev((unsigned)row) >> 22; row = (int)k;
+            nt_store(make_float4(row, c, seg, 1.f), base + ((size_t)(Ir * row + c) * ND) / 2 + seg);
+        }
+    }
+}
+
+// (i) like (h), one class per workgroup: the Ir workgroups of a unit run side by side on one XCD, so the rows Ir*k + 0 .. Ir*k + Ir-1 are
+// written at about the same time
+template <int NT_, int DT>
+__global__ void k_rdc(float4* out, int N, int Ir, int ND, long n_units) {
+    const int xcd = blockIdx.x & 7; const long j = blockIdx.x >> 3; const int c = (int)(j % Ir); const long u = (j / Ir) * 8 + xcd;
+    if (u >= n_units) return;
+    constexpr int LPR = DT / 2, RPI = NT_ / LPR;
+    const int tiles = ND / DT; const long fp = u / tiles; const int tile = (int)(u % tiles);
+    float4* base = out + ((size_t)fp * N * Ir * ND + tile * DT) / 2;
+    const int seg = threadIdx.x % LPR, r0 = threadIdx.x / LPR;
+    for (int jj = 0; jj < N / RPI; jj++) {
+        int row = r0 + jj * RPI;
+        unsigned k = __brev((unsigned)row) >> 22; row = (int)k;
+        nt_store(make_float4(row, c, seg, 1.f), base + ((size_t)(Ir * row + c) * ND) / 2 + seg);
+    }
+}
+
 int main() {
     const int F = getenv("SB_F") ? atoi(getenv("SB_F")) : 256, C = 32;   // config B: 256 frames x 2048 rows x 2 KB = 1 GiB
     const size_t bytes = (size_t)F * C * 64 * 2048;
@@ -147,6 +183,31 @@ int main() {
         run("rd config D scattered rows", [&] { hipLaunchKernelGGL((k_rd<1024, true>), dim3((unsigned)nuD), dim3(1024), 0, 0, d, 1024, 8, 128, nuD); });
         run("rd config D natural rows", [&] { hipLaunchKernelGGL((k_rd<1024, false>), dim3((unsigned)nuD), dim3(1024), 0, 0, d, 1024, 8, 128, nuD); });
         run("rd config D 64-byte half lines, 512 thr", [&] { hipLaunchKernelGGL((k_rd64<512>), dim3((unsigned)(nuD * 2)), dim3(512), 0, 0, d, 1024, 8, 128, nuD * 2); });
+        {   // wider tiles on 32 frames (4 GiB), so that the 128-bin case still has 512 workgroups
+            float4* d4; const size_t b4 = (size_t)32 * 16 * 8192 * 128 * 8;
+            CK(hipMalloc(&d4, b4));
+            const long nu = 32L * 16 * 8;
+            auto run4 = [&](const char* name, auto launch) {
+                for (int i = 0; i < 2; i++) launch();
+                hipEventRecord(e0);
+                for (int i = 0; i < 5; i++) launch();
+                hipEventRecord(e1); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+                printf("%-44s %8.3f ms  %7.1f GB/s\n", name, ms, b4 / ms / 1e6);
+            };
+            run4("rd config D x32 frames, 16-bin tiles (128 B)", [&] { hipLaunchKernelGGL((k_rdw<1024, 16>), dim3((unsigned)nu), dim3(1024), 0, 0, d4, 1024, 8, 128, nu); });
+            run4("rd config D x32 frames, 32-bin tiles (256 B)", [&] { hipLaunchKernelGGL((k_rdw<1024, 32>), dim3((unsigned)(nu / 2)), dim3(1024), 0, 0, d4, 1024, 8, 128, nu / 2); });
+            run4("rd config D x32 frames, 64-bin tiles (512 B)", [&] { hipLaunchKernelGGL((k_rdw<1024, 64>), dim3((unsigned)(nu / 4)), dim3(1024), 0, 0, d4, 1024, 8, 128, nu / 4); });
+            run4("rd config D x32 frames, 128-bin tiles (1 KB)", [&] { hipLaunchKernelGGL((k_rdw<1024, 128>), dim3((unsigned)(nu / 8)), dim3(1024), 0, 0, d4, 1024, 8, 128, nu / 8); });
+            run4("rd config D x32 frames, 16-bin tiles, classes rotated", [&] { hipLaunchKernelGGL((k_rdw<1024, 16, true>), dim3((unsigned)nu), dim3(1024), 0, 0, d4, 1024, 8, 128, nu); });
+            run4("rd config D x32 frames, 128-bin tiles, classes rotated", [&] { hipLaunchKernelGGL((k_rdw<1024, 128, true>), dim3((unsigned)(nu / 8)), dim3(1024), 0, 0, d4, 1024, 8, 128, nu / 8); });
+            run4("rd config D x32 frames, 16-bin tiles, WG per class", [&] { hipLaunchKernelGGL((k_rdc<1024, 16>), dim3((unsigned)(nu * 8)), dim3(1024), 0, 0, d4, 1024, 8, 128, nu); });
+            run4("rd config D x32 frames, 16-bin tiles, WG per class 256 thr", [&] { hipLaunchKernelGGL((k_rdc<256, 16>), dim3((unsigned)(nu * 8)), dim3(256), 0, 0, d4, 1024, 8, 128, nu); });
+            run4("rd config D x32 frames, 128-bin tiles, WG per class", [&] { hipLaunchKernelGGL((k_rdc<1024, 128>), dim3((unsigned)(nu)), dim3(1024), 0, 0, d4, 1024, 8, 128, nu / 8); });
+            run4("rd config D x32 frames, 32-bin tiles, 512 thr", [&] { hipLaunchKernelGGL((k_rdw<512, 32>), dim3((unsigned)(nu / 2)), dim3(512), 0, 0, d4, 1024, 8, 128, nu / 2); });
+            run4("rd config D x32 frames, 32-bin tiles, 256 thr", [&] { hipLaunchKernelGGL((k_rdw<256, 32>), dim3((unsigned)(nu / 2)), dim3(256), 0, 0, d4, 1024, 8, 128, nu / 2); });
+            hipFree(d4);
+        }
         run("rd config B scattered rows", [&] { hipLaunchKernelGGL((k_rd<256, true>), dim3((unsigned)nuB), dim3(256), 0, 0, d, 256, 8, 64, nuB); });
         run("rd config B natural rows", [&] { hipLaunchKernelGGL((k_rd<256, false>), dim3((unsigned)nuB), dim3(256), 0, 0, d, 256, 8, 64, nuB); });
     }
