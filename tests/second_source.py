@@ -783,3 +783,192 @@ class FrameDetectorRef:
         self.nread += n_out
         self.nwritten += n_out
         return np.array(out, c64), n_out, tags
+
+
+# ------------------------------------------------------------------------------------------------ lib/target_simulator_impl.cc
+_libm.sin.restype = ctypes.c_double
+_libm.sin.argtypes = [ctypes.c_double]
+_libm.fmod.restype = ctypes.c_double
+_libm.fmod.argtypes = [ctypes.c_double, ctypes.c_double]
+_libm.pow.restype = ctypes.c_double
+_libm.pow.argtypes = [ctypes.c_double, ctypes.c_double]
+_libm.sqrtf.restype = ctypes.c_float
+_libm.sqrtf.argtypes = [ctypes.c_float]
+GR_M_PI = 3.14159265358979323846
+
+
+class TargetSimulatorRef:
+    """target_simulator_impl: setup_targets (lib/target_simulator_impl.cc:127-198) and work (:201-384), float / double promotions as written.
+    The two gr::fft::fft_complex calls (FFTW3f, not in the tree) are numpy's complex128 transform of the float data rounded once to float,
+    the VOLK products the generic kernel's (ac - bd, ad + bc) in float: the outputs agree with a GNU Radio build to FFT rounding, the
+    set-up vectors and the two filters are meant bit for bit."""
+    C_LIGHT = f32(3e8)                                  # target_simulator_impl.h:87 constexpr static float
+    FOUR_PI_CUBED_SQRT = 44.54662397465366              # :33
+
+    def __init__(self, range_m, velocity, rcs, azimuth, position_rx, samp_rate, center_freq, self_coupling_db, rndm_phaseshift, self_coupling):
+        self.range, self.velocity, self.rcs, self.azimuth, self.position_rx = (np.asarray(v, f32) for v in (range_m, velocity, rcs, azimuth, position_rx))
+        self.samp_rate, self.center_freq = int(samp_rate), f32(center_freq)
+        self.self_coupling_db, self.rndm_phaseshift, self.self_coupling = f32(self_coupling_db), bool(rndm_phaseshift), bool(self_coupling)
+        K, R = self.range.size, self.position_rx.size
+        # :164  2 * d_velocity[k] * d_center_freq / c_light — int * float, all float
+        self.doppler = np.array([f32(f32(f32(f32(2) * v) * self.center_freq) / self.C_LIGHT) for v in self.velocity], f32)
+        # :177  (2.0 * range - position * std::sin(azimuth * GR_M_PI / 180.0)) / c_light — double, stored into a vector<float>
+        self.timeshift = np.zeros((R, K), f32)
+        for l in range(R):
+            for k in range(K):
+                s = _libm.sin(float(self.azimuth[k]) * GR_M_PI / 180.0)
+                self.timeshift[l, k] = f32((2.0 * float(self.range[k]) - float(self.position_rx[l]) * s) / float(self.C_LIGHT))
+        # :188  c_light * std::sqrt(rcs) [float] / FOUR_PI_CUBED_SQRT [double] / (range * range) [float product] / center_freq
+        self.scale_ampl = np.array([f32(float(f32(self.C_LIGHT * f32(_libm.sqrtf(float(s))))) / self.FOUR_PI_CUBED_SQRT / float(f32(r * r)) / float(self.center_freq))
+                                    for s, r in zip(self.rcs, self.range)], f32)
+        self.buff_size = 2                               # constructor :89
+
+    def filters(self, n):
+        """:249-305"""
+        K, R = self.range.size, self.position_rx.size
+        sr = f32(self.samp_rate)
+        i = np.arange(n)
+        base = (i.astype(f32) * sr) / f32(n)             # i * (float)d_samp_rate / (float)n_input: int * float, / float
+        self.freq = np.where(i < n // 2, base, base - sr).astype(f32)
+        self.filt_doppler = np.zeros((K, n), c64)
+        self.filt_time = np.zeros((R, K, n), c64)
+        for k in range(K):
+            phase = f32(0)                                # imag(d_phase_doppler)
+            step = 2 * GR_M_PI * float(self.doppler[k]) / float(sr)
+            for j in range(n):
+                e = cexp_j(phase)
+                self.filt_doppler[k, j] = cplx(f32(e.real) * self.scale_ampl[k], f32(e.imag) * self.scale_ampl[k])    # complex<float> * float
+                phase = f32(_libm.fmod(float(phase) + step, 2 * GR_M_PI))
+            for l in range(R):
+                for j in range(n):
+                    ph = f32(_libm.fmod(2 * GR_M_PI * float(self.timeshift[l, k]) * float(f32(self.freq[j] + self.center_freq)), 2 * GR_M_PI))
+                    e = cexp_j(-ph)                       # std::exp(-d_phase_time): (0, ph) negated is (-0, -ph); cexpf(-0 - j ph) = (cos, -sin)
+                    self.filt_time[l, k, j] = cplx(f32(e.real) / f32(n), f32(e.imag) / f32(n))
+        self.buff_size = n
+
+    @staticmethod
+    def _fft(x, forward):
+        z = np.asarray(x, c64).astype(np.complex128)
+        y = np.fft.fft(z) if forward else np.fft.ifft(z) * z.size            # fft_complex(n, false) is the unnormalised backward transform
+        return y.astype(c64)
+
+    def work(self, x, target_phase=None):
+        x = np.asarray(x, c64)
+        n = x.size
+        if self.buff_size != n:
+            self.filters(n)
+        R, K = self.position_rx.size, self.range.size
+        out = np.zeros((R, n), c64)
+        for l in range(R):
+            o = np.zeros(n, c64)                          # :338
+            for k in range(K):
+                bt = cmul(x, self.filt_doppler[k])        # :345
+                fo = self._fft(bt, True)
+                bf = cmul(fo, self.filt_time[l, k])       # :352
+                fo = self._fft(bf, False)
+                if self.rndm_phaseshift and target_phase is not None:
+                    o = cmul(fo, np.full(n, target_phase[k], c64))       # :360: the product is written to `out`
+                else:
+                    o = fo.copy()                         # :364 memcpy: every target OVERWRITES out, the last one leaves the block
+            if self.self_coupling:                        # :372-378  out[i] += (gr_complex)pow(10, db / 20.0) * in[i]
+                sc = c64(complex(f32(_libm.pow(10.0, float(self.self_coupling_db) / 20.0)), 0.0))
+                o = cadd(o, cmul(np.full(n, sc, c64), x))
+            out[l] = o
+        return out
+
+
+# ------------------------------------------------------------------------------------------------ lib/frame_sync_impl.cc
+class FrameSyncRef:
+    """frame_sync_impl::general_work (lib/frame_sync_impl.cc:89-229) and search_frame_start (:231-287), one call = work().
+    gr::filter::kernel::fir_filter_ccc::filterN (gr-filter 3.8, not in the tree) is taken as out[i] = sum_k taps[k] in[i + ntaps - 1 - k]
+    summed in index order (VOLK's dot product may order the sum differently: last bits of the correlation, which only ranks peaks);
+    std::list::sort is a stable merge sort, as Python's sorted()."""
+
+    def __init__(self, fft_len, cp_len, sync_length, ltf_seq_time):
+        self.fft_len, self.cp_len, self.SYNC_LENGTH = int(fft_len), int(cp_len), int(sync_length)
+        self.taps = np.asarray(ltf_seq_time, c64)
+        self.state = "SYNC"
+        self.sample_offset = 0
+        self.cor = []
+        self.frame_start = 0
+        self.freq_offset = f32(0)                        # frame_sync_impl.h: float d_freq_offset
+        self.cfo_coarse_est = 0.0                        # double
+        self.total_out_count = 0
+        self.nread = self.nwritten = 0
+
+    def _search_frame_start(self):
+        assert len(self.cor) == self.SYNC_LENGTH
+        vec = sorted(self.cor, key=lambda p: -cabs(p[0]))                # compare_abs2: abs(first) > abs(second), stable
+        self.cor = []
+        self.frame_start = self.SYNC_LENGTH                             # :242
+        N = self.fft_len
+        for i in range(3):
+            for k in range(i + 1, 4):
+                if vec[i][1] > vec[k][1]:
+                    first, second = vec[k][0], vec[i][0]
+                else:
+                    first, second = vec[i][0], vec[k][0]
+                diff = abs(vec[i][1] - vec[k][1])
+                if diff in (N, N - 1, N + 1):
+                    self.frame_start = min(vec[i][1], vec[k][1])
+                    self.freq_offset = f32(f32(carg(cmul(first, cconj(second))[()])) / f32(diff))      # float / int
+                    if diff == N:
+                        return                                          # :264 "nice match found, return immediately"
+
+    def work(self, x, x_delayed, tags, noutput):
+        x, xd = np.asarray(x, c64), np.asarray(x_delayed, c64)
+        ninput = min(x.size, xd.size, 8192)                             # :111
+        out, otags = [], []
+        hits = sorted(t for t in tags if self.nread <= t[0] < self.nread + ninput)
+        if hits:                                                        # :116-146
+            off, val = hits[0]
+            if off > self.nread:
+                ninput = off - self.nread
+            else:
+                if self.sample_offset and self.state == "SYNC":
+                    raise RuntimeError("[FRAME SYNC] Something is wrong!")
+                if self.state == "COPY":
+                    self.state = "RESET"
+                self.cfo_coarse_est = float(val)
+        n_in = n_out = 0
+        if self.state == "SYNC":                                        # :153-181
+            ncor = min(self.SYNC_LENGTH, max(ninput - self.fft_len - 1, 0))
+            nt = self.taps.size
+            corr = np.zeros(self.SYNC_LENGTH + 8192, c64)               # d_correlation keeps what earlier calls left; positions >= ncor are
+            for i in range(ncor):                                       # read below only when ninput is within two samples of fft_len
+                acc = c64(0)
+                for k in range(nt):
+                    acc = cadd(acc, cmul(self.taps[k], x[i + nt - 1 - k]))[()]
+                corr[i] = acc
+            while n_in + self.fft_len - 1 < ninput:
+                self.cor.append((corr[n_in], self.sample_offset))
+                n_in += 1
+                self.sample_offset += 1
+                if self.sample_offset == self.SYNC_LENGTH:
+                    self._search_frame_start()
+                    self.sample_offset = 0
+                    self.total_out_count = 0
+                    self.state = "COPY"
+                    break
+        elif self.state == "COPY":                                      # :183-204
+            while n_in < ninput and n_out < noutput:
+                rel = self.sample_offset - self.frame_start
+                if rel == 0:
+                    otags.append((self.nwritten, self.cfo_coarse_est - float(self.freq_offset)))
+                if rel >= 0 and (rel < 2 * self.fft_len or ((rel - 2 * self.fft_len) % (self.fft_len + self.cp_len)) > self.cp_len - 1):
+                    out.append(cmul(xd[n_in], cexp_j(f32(f32(self.sample_offset) * self.freq_offset)))[()])     # int * float -> float
+                    n_out += 1
+                n_in += 1
+                self.sample_offset += 1
+        else:                                                           # RESET :206-222
+            while n_out < noutput:
+                if (self.total_out_count + n_out) % self.fft_len == 0:
+                    self.sample_offset = 0
+                    self.state = "SYNC"
+                    break
+                out.append(c64(0))
+                n_out += 1
+        self.total_out_count += n_out
+        self.nread += n_in
+        self.nwritten += n_out
+        return np.array(out, c64), n_in, otags

@@ -347,3 +347,72 @@ def test_moving_avg_and_frame_detector_oracle_equals_second_source():
             stalled = stalled + 1 if ca == 0 else 0            # a detection on the first sample offered consumes nothing and switches to COPY:
             assert stalled < 3                                 # the scheduler offers the same samples again
             pos += ca
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_target_simulator_oracle_equals_second_source(seed):
+    """lib/target_simulator_impl.cc:127-384 read twice: set-up vectors and both channel filters bit for bit (glibc sinf / cosf / fmod / pow on
+    both sides), the outputs to the rounding of the two transforms (the oracle's mixed-radix double DFT against numpy's), incl. the reference's
+    overwrite of `out` by every target, the random phase and the self coupling"""
+    rng = np.random.default_rng(100 + seed)
+    K, R = [(1, 1), (3, 2), (8, 4)][seed]
+    n = [240, 400, 1150][seed]                            # burst lengths of the flowgraph kind: not powers of two
+    rg = rng.uniform(5, 60, K).astype(np.float32)
+    vel = rng.uniform(-40, 40, K).astype(np.float32)
+    rcs = rng.uniform(1, 200, K).astype(np.float32)
+    az = rng.uniform(-60, 60, K).astype(np.float32)
+    pos = (np.arange(R) * 0.00625).astype(np.float32)
+    for rp, sc in ((False, False), (True, True)):
+        o = oracle.TargetSimulator(rg, vel, rcs, az, pos, 125000000, 24e9, -37.5, rp, sc)
+        s = ss.TargetSimulatorRef(rg, vel, rcs, az, pos, 125000000, 24e9, -37.5, rp, sc)
+        x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+        tp = np.exp(2j * np.pi * rng.integers(1, 1001, K) / 1000.0).astype(np.complex64) if rp else None
+        got = o.work(x, target_phase=tp)
+        want = s.work(x, target_phase=tp)
+        for k in range(K):
+            assert np.array_equal(o.filt_doppler(n, k).view(np.uint32), s.filt_doppler[k].view(np.uint32))
+            for l in range(R):
+                assert np.array_equal(o.filt_time(n, l, k).view(np.uint32), s.filt_time[l, k].view(np.uint32))
+        scale = np.abs(want).max()
+        assert np.abs(got - want).max() <= 2e-6 * scale
+        assert np.mean(got.view(np.uint32) == want.view(np.uint32)) > 0.5      # most cells to the bit: the double transforms differ below float's last place
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_frame_sync_oracle_equals_second_source(seed):
+    """lib/frame_sync_impl.cc:89-287 read twice, call by call over random scheduler chunks: SYNC (LTF correlation, the four largest peaks,
+    pairs fft_len or fft_len +- 1 apart, fine CFO), COPY (cyclic prefixes dropped, de-rotation by sample_offset * d_freq_offset) and RESET on the
+    next frame tag — items consumed / produced, output samples bit for bit, the frame_start tag's offset and value"""
+    rng = np.random.default_rng(300 + seed)
+    N, cp, SL = 64, 16, 160
+    ltf = (rng.choice([-1.0, 1.0], N) + 0j).astype(np.complex64)
+    taps = np.conj(ltf[::-1]).astype(np.complex64)                       # matched filter of the long training symbol
+    frames, tags, pos = [], [], 0
+    for fidx in range(4):                                                # as behind frame_detector: a frame's first sample carries the tag
+        lead = int(rng.integers(4, 28))                                  # what is left of the short training part before the two LTF periods
+        shift = [0, 1, -1, 0][(seed + fidx) % 4]                         # second period fft_len, fft_len + 1 or fft_len - 1 after the first
+        sig = np.concatenate([crandn(rng, lead) * 0.3, ltf, crandn(rng, max(shift, 0)) * 0.05, ltf[max(-shift, 0):],
+                              crandn(rng, int(rng.integers(4, 7)) * (N + cp) + int(rng.integers(0, 30))) * 0.5])
+        cfo = rng.uniform(-0.02, 0.02)
+        sig = (sig * np.exp(1j * cfo * np.arange(sig.size))).astype(np.complex64)
+        frames.append((sig + crandn(rng, sig.size) * 0.02).astype(np.complex64))
+        tags.append((pos, float(rng.uniform(-0.1, 0.1))))
+        pos += frames[-1].size
+    x = np.concatenate(frames + [crandn(rng, 400) * 0.02]).astype(np.complex64)
+    xd = np.concatenate([np.zeros(7, np.complex64), x[:-7]])             # the delayed branch of the flowgraph
+    o, s = oracle.FrameSync(N, cp, SL, taps), ss.FrameSyncRef(N, cp, SL, taps)
+    p, idle, n_tags = 0, 0, 0
+    while p < x.size and idle < 4:
+        m = int(min(rng.integers(N + cp, 700), x.size - p))              # forecast: at least fft_len + cp_len items
+        nout = int(rng.integers(1, 600))
+        go, co, to = o.work(x[p:p + m], xd[p:p + m], tags, nout)
+        gs, cs, ts = s.work(x[p:p + m], xd[p:p + m], tags, nout)
+        assert co == cs and go.size == gs.size and np.array_equal(go.view(np.uint32), gs.view(np.uint32))
+        assert len(to) == len(ts)
+        for a, b in zip(to, ts):
+            assert a[0] == b[0] and a[1] == b[1]
+            n_tags += 1
+        assert o.frame_start == s.frame_start and np.float32(o.freq_offset) == s.freq_offset
+        idle = idle + 1 if (co == 0 and go.size == 0) else 0
+        p += co
+    assert n_tags >= 2                                                   # frames were found and copied, not only searched for
