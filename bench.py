@@ -469,7 +469,7 @@ def secondary_figures(cfg, ctx, sc, axes):
                 "packets_per_s_steering_and_radar_streams": p["per-subcarrier_steering_+_radar_streams"]["frames_per_s"], "what": p["what"]}
 
     def _rd():
-        d = be.range_doppler("D", 16)
+        d = be.range_doppler("D", 64)      # a device-resident batch of >= 64 config-D frames (8.6 GB of map)
         return {"frames_per_s": d["frames_per_s"], "GBps_algorithmic": d["GBps_algorithmic"], "frames_per_step": d["frames_per_step"], "what": d["what"]}
 
     leg("chain_with_rx_demod", _demod)

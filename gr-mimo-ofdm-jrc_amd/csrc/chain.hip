@@ -1992,6 +1992,21 @@ extern "C" int jrc_range_doppler_dev(jrc_ctx* ctx, const jrc_chain_cfg* c, int i
     // fused path: Doppler FFT on the compact data, zero-padded range IFFT streamed out once (d_work holds [pair][N][ND] <= its size)
     if (jrc_is_pow2(N) && N >= RA_L && N <= 1024 && jrc_is_pow2(NR) && NR >= RA_L && jrc_is_pow2(ND) && ND >= RD_DT && ND <= 8192 &&
         interp_doppler <= c->interp_range && ((reinterpret_cast<size_t>(d_work) & 15) == 0) && !ctx->tune.rd_generic) {
+        // frames go through in chunks whose compact array stays in the Infinity Cache between the kernel that writes it and the one that reads it
+        // (the chunks reuse the start of d_work; JRC_RD_CHUNK_MB, 0 = one chunk)
+        {
+            const size_t per_frame = sizeof(float2) * (size_t)P * N * ND;
+            const long chunk = ctx->tune.rd_chunk_mb > 0 ? (long)(((size_t)ctx->tune.rd_chunk_mb << 20) / per_frame) : 0;
+            if (chunk >= 1 && n_frames > chunk) {
+                for (long f0 = 0; f0 < n_frames; f0 += chunk) {
+                    const int nf = (int)(n_frames - f0 < chunk ? n_frames - f0 : chunk);
+                    const int rc = jrc_range_doppler_dev(ctx, c, interp_doppler, nf, d_frames + (size_t)f0 * g.frame_stride, d_work,
+                                                         d_out + (size_t)f0 * P * NR * ND, stream);
+                    if (rc < 0) return rc;
+                }
+                return JRC_OK;
+            }
+        }
         const size_t fp = (size_t)n_frames * P;
         const bool one_kernel = !ctx->tune.rd_two_step && fp * ((size_t)N * ND / 4096 + 1) < 0x7fffffffull;
         if (one_kernel && ND == 128) { JRC_TRY(launch_rd_product_doppler<128>(ctx, (const float2*)d_frames, (float2*)d_work, g, T, R, fp, s)); }

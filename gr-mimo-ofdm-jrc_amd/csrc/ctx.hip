@@ -89,6 +89,7 @@ extern "C" int jrc_create(int device, jrc_ctx** out)
     if (const char* e = getenv("JRC_RA_PACE")) ctx->tune.ra_pace = (int)strtol(e, nullptr, 0);
     if (const char* e = getenv("JRC_DETECT_EXP")) ctx->tune.detect_exp = atoi(e);
     if (const char* e = getenv("JRC_RD_EXP")) ctx->tune.rd_exp = atoi(e);
+    if (const char* e = getenv("JRC_RD_CHUNK_MB")) ctx->tune.rd_chunk_mb = atoi(e);
     if (const char* e = getenv("JRC_RA_OFFERED_TBPS")) ctx->tune.ra_offered_tbps = atof(e);
     if (const char* e = getenv("JRC_DEMOD_SPR")) ctx->tune.demod_spr = atoi(e);
     if (const char* e = getenv("JRC_EQ_WPE")) ctx->tune.eq_wpe = atoi(e);

@@ -47,6 +47,7 @@ struct jrc_ctx {
         bool rd_fold = false;        // JRC_RD_FOLD: range-Doppler with the fold kernel also where the pruned-FFT kernel applies
         int ra_pace = -1;            // JRC_RA_PACE: store pacing word of the fused range-angle kernel (chain.hip; -1 = derived, chain_pace)
         bool rd_two_step = false;    // JRC_RD_TWO_STEP: range-Doppler product and Doppler FFT as two kernels also where the one-kernel form applies
+        int rd_chunk_mb = 160;       // JRC_RD_CHUNK_MB: range-Doppler frames per pass = this many MiB of the compact [pair][subcarrier][Doppler] array, which then stays in the 256 MiB Infinity Cache between its two kernels (0: all frames at once)
         int rd_exp = 0;              // JRC_RD_EXP: range-Doppler pruned-FFT kernel experiments, TIMING ONLY, WRONG RESULTS: 1: no stores; 2: first and last pass only
         int detect_exp = 0;          // JRC_DETECT_EXP: detect-only kernel experiments (chain.hip, MODE 1). 8: no pruning; 16: sum bound only. TIMING ONLY, WRONG RESULTS: 1: no angle stage; 2: no range-profile stores; 32: sampled rows never computed
         double ra_offered_tbps = 0;  // JRC_RA_OFFERED_TBPS: offered store rate the pacing word is derived from (0 = the kernel's measured optimum)

@@ -204,6 +204,30 @@ def test_range_doppler_one_kernel_front_equals_two_step(jrc, N, S, Ir, Id, monke
     assert outs[0].shape == outs[1].shape and rel_err(outs[0], outs[1]) < 2e-6
 
 
+@pytest.mark.gpu
+def test_range_doppler_in_chunks_equals_one_pass(jrc, monkeypatch):
+    """jrc_range_doppler_dev takes the frames in chunks whose compact array fits the Infinity Cache (JRC_RD_CHUNK_MB, default 160): the same kernels
+    frame by frame, so the map must not depend on the chunk size - here 1 MiB = two frames per chunk, with a last chunk of one"""
+    import torch
+    from jrc_amd import synth
+    N, S, Ir, F = 256, 64, 4, 5
+    sc = synth.Scenario(N, 2, 2, S, targets=[(12.0, 10.0, 150.0, 100.0)])
+    frames = synth.make_frames(sc, F)
+    rb, ab = jrc.radar_axes(N, sc.fs, Ir, 4, 2)
+    outs = []
+    for mb in ("0", "1"):
+        monkeypatch.setenv("JRC_RD_CHUNK_MB", mb)
+        c = jrc.Context(0)
+        chain = jrc.RadarChain(N, 2, 2, S, sc.Npre, Ir, 2, rb, ab, 2.4, 30.0, max_frames=F, ctx=c)
+        bufs = chain.alloc(F, "cuda:0")
+        bufs["frames"].copy_(torch.from_numpy(frames.view(np.float32).reshape(bufs["frames"].shape)))
+        torch.cuda.synchronize()
+        outs.append(chain.range_doppler(bufs, F, 1).cpu().numpy())
+        chain.close()
+        c.close()
+    assert np.array_equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("T,R,N,S,Ir,Id,vel", [(2, 2, 64, 16, 4, 4, 30.0), (4, 4, 256, 64, 2, 1, -20.0), (1, 1, 64, 64, 2, 2, 600.0),
                                                (1, 2, 1024, 16, 8, 1, 200.0),     # fft_len 1024: pruned-FFT range kernel, 8 classes
                                                (2, 1, 256, 32, 1, 1, -50.0),      # no range interpolation (one class)

@@ -301,7 +301,7 @@ if __name__ == "__main__":
     only = os.environ.get("JRC_BENCH_EXTRA_ONLY")
     LEGS = {"detectB": lambda: detect_only("B"), "detectB_noise": lambda: detect_only("B", noise_only=True), "detectD": lambda: detect_only("D"),
             "detectD_noise": lambda: detect_only("D", noise_only=True), "powerB": lambda: power_map("B"), "powerD": lambda: power_map("D"),
-            "equalizer": equalizer_config_c, "precoder": precoder_config_c, "rdD": lambda: range_doppler("D", 16), "rdB": lambda: range_doppler("B", 64),
+            "equalizer": equalizer_config_c, "precoder": precoder_config_c, "rdD": lambda: range_doppler("D", 64), "rdB": lambda: range_doppler("B", 64),
             "demodB": lambda: radar_with_demod("B", 512), "demodD": lambda: radar_with_demod("D", 256), "comm_rx": comm_rx_chain,
             "simB": lambda: simulated_chain("B", 64), "simD": lambda: simulated_chain("D", 8)}
     GROUPS = {"detect": ["detectB", "detectB_noise", "detectD", "detectD_noise", "powerB", "powerD"], "demod": ["demodB", "demodD"],
