@@ -457,7 +457,7 @@ __global__ __launch_bounds__(NT_, 2) void range_angle_wide_kernel(
         if constexpr (MODE == 1 || MODE == 3) {
             // write-once for the window pass: around the caches — a cached store would sit dirty in the Infinity Cache and be written back
             // while the NEXT step's A1 streams its input (A1 0.098 -> 0.13 ms per 512 config-B frames behind 128 MB of cached stores)
-            // (MODE 3 streams the power map itself at the memory system's pace: there the cached form is the faster one — 0.28 against 0.39 ms)
+            // (MODE 3: cached or non-temporal measures the same, 0.284 ms per 512 config-B frames, and the A1 behind it 0.127 ms either way)
             typedef float v4f __attribute__((ext_vector_type(4)));
             v4f* dst = reinterpret_cast<v4f*>(rng_out + ((size_t)f * C + c) * (P * RW_L));
             const float4* src = reinterpret_cast<const float4*>(sg);
