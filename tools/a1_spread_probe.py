@@ -120,6 +120,11 @@ if scenario("power"):
     b3 = chain3.alloc(F, "cuda:0", power_map=True)
     fill(b3)
     out["power"] = measure(chain3, b3)
+    out["power_idle"] = measure(chain3, b3, between=lambda: time.sleep(0.002))
+    chain3.set_write_map(False)                               # the same chain and buffers in detect-only mode: is it the buffers or the kernel before?
+    out["power_buffers_detect_mode"] = measure(chain3, b3)
+    chain3.set_write_map(True)
+    out["power_again"] = measure(chain3, b3)
     chain3.close()
 
 if scenario("map_again"):
