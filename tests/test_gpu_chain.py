@@ -205,6 +205,41 @@ def test_range_doppler_one_kernel_front_equals_two_step(jrc, N, S, Ir, Id, monke
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(10))
+def test_range_doppler_random_shapes(jrc, ctx, seed):
+    """row D on drawn shapes (fft_len, symbols, pairs, both interpolation factors, TX interleave, frames per call) against the numpy definition"""
+    import torch
+    from jrc_amd import synth
+    rng = np.random.default_rng(7000 + seed)
+    N = int(rng.choice([64, 128, 256, 512, 1024]))
+    S = int(rng.choice([16, 32, 64, 128] if N < 1024 else [16, 32]))
+    Ir = int(rng.choice([1, 2, 4, 8] if N <= 256 else [2, 4]))
+    Id = int(rng.choice([d for d in (1, 2, 4) if d <= Ir and S * d <= 256]))
+    T, R = int(rng.integers(1, 3)), int(rng.integers(1, 3))
+    F = int(rng.integers(1, 4))
+    il = bool(rng.integers(0, 2))
+    sc = synth.Scenario(N, T, R, S, targets=[(float(rng.uniform(5, 30)), float(rng.uniform(-40, 40)), float(rng.uniform(-300, 300)), 100.0)])
+    P = T * R
+    frames = synth.make_frames(sc, F)
+    rb, ab = jrc.radar_axes(N, sc.fs, Ir, P, 2)
+    chain = jrc.RadarChain(N, T, R, S, sc.Npre, Ir, 2, rb, ab, 2.4, 30.0, max_frames=F, ctx=ctx, enable_tx_interleave=il)
+    bufs = chain.alloc(F, "cuda:0")
+    bufs["frames"].copy_(torch.from_numpy(frames.view(np.float32).reshape(bufs["frames"].shape)))
+    torch.cuda.synchronize()
+    got = chain.range_doppler(bufs, F, Id).cpu().numpy().view(np.complex64)[..., 0]
+    tx = frames[:, :T, sc.Npre:].astype(np.complex128)
+    rx = frames[:, T:, sc.Npre:].astype(np.complex128)
+    D = np.einsum("frsn,ftsn->frtsn", rx, np.conj(tx))                                  # [F][R][T][S][N], pair r * T + t
+    if il:
+        D = np.swapaxes(D, 1, 2)                                                        # pair t * R + r (mimo_ofdm_radar_impl.cc:262-269)
+    D = D.reshape(F, P, S, N)
+    rngp = np.fft.ifft(D, n=N * Ir, axis=-1) * (N * Ir)
+    ref = np.fft.fftshift(np.fft.fft(np.swapaxes(rngp, -1, -2), n=S * Id, axis=-1), axes=-1)
+    assert got.shape == ref.shape and rel_err(got, ref) < FFT_TOL, (N, S, Ir, Id, T, R, F, il)
+    chain.close()
+
+
+@pytest.mark.gpu
 def test_range_doppler_in_chunks_equals_one_pass(jrc, monkeypatch):
     """jrc_range_doppler_dev takes the frames in chunks whose compact array fits the Infinity Cache (JRC_RD_CHUNK_MB, default 160): the same kernels
     frame by frame, so the map must not depend on the chunk size - here 1 MiB = two frames per chunk, with a last chunk of one"""
