@@ -4,6 +4,7 @@
 
 #include <dlfcn.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <thread>
 
@@ -94,6 +95,10 @@ extern "C" int jrc_create(int device, jrc_ctx** out)
     if (const char* e = getenv("JRC_DEMOD_SPR")) ctx->tune.demod_spr = atoi(e);
     if (const char* e = getenv("JRC_EQ_WPE")) ctx->tune.eq_wpe = atoi(e);
     if (const char* e = getenv("JRC_EQ_THREADS")) ctx->tune.eq_threads = atoi(e);
+    // the timing experiments leave work out: say so where nobody can miss it
+    if ((ctx->tune.detect_exp & (1 | 2 | 32)) || (ctx->tune.rd_exp & (1 | 2)))
+        fprintf(stderr, "libjrc_hip: JRC_DETECT_EXP=%d / JRC_RD_EXP=%d select TIMING-ONLY kernel experiments on this context: RESULTS ARE WRONG\n",
+                ctx->tune.detect_exp, ctx->tune.rd_exp);
     *out = ctx;
     return JRC_OK;
 }

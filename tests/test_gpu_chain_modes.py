@@ -554,3 +554,16 @@ def test_power_map_random_shapes(jrc, ctx, T, R, N, S, Ir, Ia, interleave):
     assert [_rec(r) for r in ch.results(pb, F)] == want
     re, im = bufs["map"][..., 0], bufs["map"][..., 1]
     assert torch.equal(pb["map"], re * re + im * im)
+
+
+@pytest.mark.gpu
+def test_timing_only_experiment_switches_announce_themselves():
+    """JRC_DETECT_EXP / JRC_RD_EXP bits that leave work out of a kernel (tools/detect_exp.sh, tools/rd_exp.sh) must not pass unnoticed in a process
+    that happens to inherit them: the context says so on stderr; the switches that keep the results (8, 16) stay silent"""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import sys; sys.path.insert(0, %r); import jrc_amd; c = jrc_amd.Context(0); c.close()" % root
+    for env, loud in (({"JRC_RD_EXP": "1"}, True), ({"JRC_DETECT_EXP": "32"}, True), ({"JRC_DETECT_EXP": "8"}, False), ({}, False)):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-1000:]
+        assert ("RESULTS ARE WRONG" in r.stderr) == loud, (env, r.stderr[-500:])
