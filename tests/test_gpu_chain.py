@@ -266,7 +266,7 @@ def test_range_doppler_in_chunks_equals_one_pass(jrc, monkeypatch):
 @pytest.mark.parametrize("T,R,N,S,Ir,Id,vel", [(2, 2, 64, 16, 4, 4, 30.0), (4, 4, 256, 64, 2, 1, -20.0), (1, 1, 64, 64, 2, 2, 600.0),
                                                (1, 2, 1024, 16, 8, 1, 200.0),     # fft_len 1024: pruned-FFT range kernel, 8 classes
                                                (2, 1, 256, 32, 1, 1, -50.0),      # no range interpolation (one class)
-                                               (1, 2, 128, 16, 4, 2, 1000.0),     # fft_len not a power of four: the fold kernel
+                                               (1, 2, 128, 16, 4, 2, 1000.0),     # fft_len not a power of four: a last radix-2 pass in the pruned range FFT
                                                (1, 1, 512, 32, 2, 1, 300.0),
                                                (1, 1, 64, 64, 4, 4, 400.0),       # 256 Doppler bins: 16 x 16 points in the product + Doppler kernel
                                                (1, 1, 64, 32, 2, 1, 3000.0),      # fewer subcarriers than a workgroup of that kernel takes
