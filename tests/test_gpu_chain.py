@@ -240,6 +240,33 @@ def test_range_doppler_random_shapes(jrc, ctx, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("switch", ["JRC_RD_FOLD", "JRC_RD_GENERIC"])
+@pytest.mark.parametrize("N,S,Ir,Id", [(256, 64, 8, 1), (1024, 32, 4, 2), (64, 16, 2, 1)])
+def test_range_doppler_earlier_range_stages_still_agree(jrc, switch, N, S, Ir, Id, monkeypatch):
+    """the range stages kept behind switches — the fold + wavefront FFT kernel (JRC_RD_FOLD) and the block-by-block path (JRC_RD_GENERIC, which
+    shapes outside the fused path take anyway) — against the default pruned-FFT kernel"""
+    import torch
+    from jrc_amd import synth
+    sc = synth.Scenario(N, 2, 1, S, targets=[(15.0, -10.0, 120.0, 100.0)])
+    F = 2
+    frames = synth.make_frames(sc, F)
+    rb, ab = jrc.radar_axes(N, sc.fs, Ir, 2, 2)
+    outs = []
+    for on in (False, True):
+        if on:
+            monkeypatch.setenv(switch, "1")
+        c = jrc.Context(0)
+        chain = jrc.RadarChain(N, 2, 1, S, sc.Npre, Ir, 2, rb, ab, 2.4, 30.0, max_frames=F, ctx=c)
+        bufs = chain.alloc(F, "cuda:0")
+        bufs["frames"].copy_(torch.from_numpy(frames.view(np.float32).reshape(bufs["frames"].shape)))
+        torch.cuda.synchronize()
+        outs.append(chain.range_doppler(bufs, F, Id).cpu().numpy().view(np.complex64)[..., 0])
+        chain.close()
+        c.close()
+    assert outs[0].shape == outs[1].shape and rel_err(outs[0], outs[1]) < FFT_TOL
+
+
+@pytest.mark.gpu
 def test_range_doppler_in_chunks_equals_one_pass(jrc, monkeypatch):
     """jrc_range_doppler_dev takes the frames in chunks whose compact array fits the Infinity Cache (JRC_RD_CHUNK_MB, default 160): the same kernels
     frame by frame, so the map must not depend on the chunk size - here 1 MiB = two frames per chunk, with a last chunk of one"""
