@@ -261,7 +261,7 @@ class mimo_ofdm_radar:
         return out
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and getattr(getattr(self, "ctx", None), "h", None):   # a context closed first took its objects with it
             self.ctx.lib.jrc_radar_destroy(self.h)
             self.h = None
 
@@ -540,7 +540,7 @@ class RadarChain:
         return dict(radar_chanest=ms[0], range_angle_fused=ms[1], ra_finalize=ms[2], launches=n.value)
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and getattr(getattr(self, "ctx", None), "h", None):   # a context closed first took its objects with it
             self.ctx.lib.jrc_chain_destroy(self.h)
             self.h = None
 
@@ -665,7 +665,7 @@ class ChainFeed:
         return dict(graph_replays=g.value, direct_submits=d.value)
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and (self.ctx is None or getattr(self.ctx, "h", None)):   # multi-device feeds own their contexts
             self.lib.jrc_chain_feed_destroy(self.h)
             self.h = None
 
@@ -814,7 +814,7 @@ class mimo_ofdm_equalizer:
         return out, n_out, ev
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and getattr(getattr(self, "ctx", None), "h", None):   # a context closed first took its objects with it
             self.ctx.lib.jrc_equalizer_destroy(self.h)
             self.h = None
 
@@ -902,7 +902,7 @@ class mimo_precoder:
         return d_out
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and getattr(getattr(self, "ctx", None), "h", None):   # a context closed first took its objects with it
             self.ctx.lib.jrc_precoder_destroy(self.h)
             self.h = None
 
@@ -1010,7 +1010,7 @@ class target_simulator:
                                                      None if tp is None else _ptr(tp), int(accumulate_out), stream))
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and getattr(getattr(self, "ctx", None), "h", None):   # a context closed first took its objects with it
             self.ctx.lib.jrc_tsim_destroy(self.h)
             self.h = None
 
@@ -1037,6 +1037,11 @@ def _load_codec():
         L.jrc_stream_decode_dev.argtypes = [_vp, C.c_int, C.c_int, _vp, C.c_long, _vp, _vp, _vp, C.c_long, _vp, _vp]
         L._codec_ready = True
     return L
+
+
+def stream_n_ofdm_sym(mcs, n_data_carriers, data_bytes):
+    """packet_param::n_ofdm_sym for a frame of `data_bytes` (payload + CRC) bytes (lib/utils.cc:79-111); < 0 = not a valid frame"""
+    return _load_codec().jrc_stream_n_ofdm_sym(int(mcs), int(n_data_carriers), int(data_bytes))
 
 
 class stream_encoder:
@@ -1216,7 +1221,7 @@ class frame_detector:
         return (np.concatenate(outs) if outs else np.zeros(0, np.complex64)), tags
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and getattr(getattr(self, "ctx", None), "h", None):   # a context closed first took its objects with it
             self.L.jrc_frame_detector_destroy(self.h)
             self.h = None
 
@@ -1274,7 +1279,7 @@ class frame_sync:
         return (np.concatenate(outs) if outs else np.zeros(0, np.complex64)), otags
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and getattr(getattr(self, "ctx", None), "h", None):   # a context closed first took its objects with it
             self.L.jrc_frame_sync_destroy(self.h)
             self.h = None
 
@@ -1413,7 +1418,7 @@ class ofdm_frame_generator:
         return out
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and getattr(getattr(self, "ctx", None), "h", None):   # a context closed first took its objects with it
             self.L.jrc_frame_generator_destroy(self.h)
             self.h = None
 

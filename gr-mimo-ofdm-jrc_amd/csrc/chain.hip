@@ -776,6 +776,12 @@ struct jrc_chain {
     // background recording / removal (jrc_chain_set_background)
     jrc_bg_state* bg = nullptr;
     float2* d_raw = nullptr;          // [max_frames][P][N] estimates before the subtraction
+    // detect-only pipeline (chain_run): the batch in slices, A1 of slice i+1 (HBM-bound) beside the transforms of slice i (issue-bound)
+    static const int kMaxSlices = 16;
+    int slices = 1;                   // JRC_DETECT_SLICES: slices of the detect-only pipeline (default 1: none, see chain_pick_slices)
+    hipStream_t side[2] = {nullptr, nullptr};
+    hipEvent_t ev_a1[kMaxSlices] = {};
+    hipEvent_t ev_side[2] = {nullptr, nullptr};
 };
 
 // ---- background state of one radar stream (lib/mimo_ofdm_radar_impl.cc:276-300) on the device --------------------------------
@@ -1068,6 +1074,9 @@ extern "C" int jrc_chain_create(jrc_ctx* ctx, const jrc_chain_cfg* cfg, const fl
         ch->C = (int)(NR / RW_L);
     }
     ch->wpf_override = getenv("JRC_WPF") ? atoi(getenv("JRC_WPF")) : 0;
+    ch->slices = getenv("JRC_DETECT_SLICES") ? atoi(getenv("JRC_DETECT_SLICES")) : 1;
+    if (ch->slices < 1) ch->slices = 1;
+    if (ch->slices > jrc_chain::kMaxSlices) ch->slices = jrc_chain::kMaxSlices;
     {
         ch->n_cus = ctx->n_cus;
         int by_lds = (int)((160 * 1024) / (ch->lds_bytes + 64));
@@ -1105,6 +1114,11 @@ extern "C" void jrc_chain_destroy(jrc_chain* ch)
     (void)hipSetDevice(ch->ctx->device);
     (void)hipDeviceSynchronize();
     for (auto& e : ch->ev) (void)hipEventDestroy(e);
+    for (auto& e : ch->ev_a1) if (e) (void)hipEventDestroy(e);
+    for (int k = 0; k < 2; k++) {
+        if (ch->ev_side[k]) (void)hipEventDestroy(ch->ev_side[k]);
+        if (ch->side[k]) (void)hipStreamDestroy(ch->side[k]);
+    }
     if (ch->d_bins) (void)hipFree(ch->d_bins);
     if (ch->d_partials) (void)hipFree(ch->d_partials);
     if (ch->d_pad) (void)hipFree(ch->d_pad);
@@ -1332,6 +1346,127 @@ extern "C" int jrc_chain_set_map_format(jrc_chain* ch, int format)
 }
 
 // A1 comes in two forms: frequency-domain frames (d_frames), or TX rows + time-domain RX streams (A6 + A7 + A1 fused)
+// A1 of frames [f0, f0 + nf) of a batch on stream s (frequency-domain frames, or the RX side in the time domain when d_frames is NULL)
+static int chain_a1_stage(jrc_chain* ch, int f0, int nf, const jrc_cf32* d_frames, const jrc_cf32* d_tx, const jrc_cf32* d_rx_td, int cp_len,
+                          long rx_stream_len, jrc_cf32* d_chanest, hipStream_t s)
+{
+    jrc_ctx* ctx = ch->ctx;
+    const jrc_chain_cfg& c = ch->cfg;
+    float2* out = (float2*)d_chanest + (size_t)f0 * ch->P * c.fft_len;
+    if (d_frames) {
+        ChanestGeom g;
+        g.N = c.fft_len; g.S = c.N_sym;
+        g.port_stride = (long)c.n_items * c.fft_len;
+        g.frame_stride = g.port_stride * (c.N_tx + c.N_rx);
+        g.tx_item0 = c.N_pre; g.rx_item0 = c.N_pre; g.interleave = c.enable_tx_interleave;
+        return launch_radar_chanest(ctx, c.N_tx, c.N_rx, (const float2*)d_frames + (size_t)f0 * g.frame_stride, out, g, nf, s);
+    }
+    DemodGeom g;
+    g.N = c.fft_len; g.cp = cp_len; g.S = c.N_sym; g.R = c.N_rx; g.logn = 0;
+    g.tx_port_stride = (long)c.n_items * c.fft_len; g.tx_frame_stride = g.tx_port_stride * c.N_tx;
+    g.rx_stream_stride = rx_stream_len; g.rx_frame_stride = rx_stream_len * c.N_rx;
+    g.tx_item0 = c.N_pre; g.rx_sym0 = c.N_pre; g.interleave = c.enable_tx_interleave; g.blocks_per_frame = 1;
+    return launch_demod_chanest(ctx, c.N_tx, (const float2*)d_tx + (size_t)f0 * g.tx_frame_stride, (const float2*)d_rx_td + (size_t)f0 * g.rx_frame_stride,
+                                out, g, nf, s);
+}
+
+// A2 + A3 + A4 + A5 of frames [f0, f0 + nf) on stream s.  The per-frame work buffers (partial maxima, range profiles, window rows) are
+// addressed from the slice's first frame: a slice's partial maxima start at f0 x its own slices-per-frame count, which keeps equal
+// slices followed by one smaller slice (more slices per frame) apart.  ev2: recorded between the transforms and the estimator epilogue.
+static int chain_transform_stage(jrc_chain* ch, int f0, int nf, const jrc_cf32* d_chanest_all, jrc_cf32* d_map_all, jrc_ra_result* d_results_all,
+                                 hipStream_t s, hipEvent_t ev2)
+{
+    jrc_ctx* ctx = ch->ctx;
+    const jrc_chain_cfg& c = ch->cfg;
+    const float2* d_chanest = (const float2*)d_chanest_all + (size_t)f0 * ch->P * c.fft_len;
+    const bool power = ch->map_format == JRC_MAP_POWER;
+    float2* d_map = !d_map_all ? nullptr
+                  : (power ? reinterpret_cast<float2*>(reinterpret_cast<float*>(d_map_all) + (size_t)f0 * ch->NR * ch->NA)
+                           : (float2*)d_map_all + (size_t)f0 * ch->NR * ch->NA);
+    jrc_ra_result* d_results = d_results_all + f0;
+    // the launch helpers address the work buffers from their base: hand them the slice's view for the duration of this call
+    struct view {
+        jrc_chain* ch; PeakPartial* p; float2* r; float2* w; float2* pad;
+        explicit view(jrc_chain* c_) : ch(c_), p(c_->d_partials), r(c_->d_rng), w(c_->d_win), pad(c_->d_pad) {}
+        ~view() { ch->d_partials = p; ch->d_rng = r; ch->d_win = w; ch->d_pad = pad; }
+    } keep(ch);
+    int partials_per_frame;
+    if (ch->generic) {
+        ch->d_partials += (size_t)f0 * ch->gen_blocks;
+        if (ch->d_pad) ch->d_pad += (size_t)f0 * ch->P * ch->NR;
+        // A1 output -> zero pad -> A2 fft_vxx reverse (NR) -> A3 matrix_transpose -> A4 fft_vxx forward+shift (NA), in place
+        const size_t rows = (size_t)nf * ch->P;
+        unsigned pb = (unsigned)((rows * ch->NR + 255) / 256); if (pb > 8192) pb = 8192;
+        hipLaunchKernelGGL(pad_rows_kernel, dim3(pb), dim3(256), 0, s, d_chanest, ch->d_pad, c.fft_len, ch->NR, rows);
+        JRC_HIP(ctx, hipGetLastError());
+        JRC_TRY(launch_fft_vcc(ctx, ch->NR, 0, 0, nullptr, rows, ch->d_pad, ch->d_pad, ch->NR, 0, s));
+        int tr = jrc_matrix_transpose_dev(ctx, ch->NR, ch->P, c.interp_angle, ch->P, (size_t)nf, (const jrc_cf32*)ch->d_pad, (jrc_cf32*)d_map, (void*)s);
+        if (tr < 0) return tr;
+        JRC_TRY(launch_fft_vcc(ctx, ch->NA, 1, 1, nullptr, (size_t)nf * ch->NR, (const float2*)d_map, (float2*)d_map, ch->NA, 0, s));
+        if (ev2) JRC_HIP(ctx, hipEventRecord(ev2, s));
+        for (int f = 0; f < nf; f++)
+            JRC_TRY(launch_ra_partial(ctx, (const float2*)d_map + (size_t)f * ch->NR * ch->NA, (size_t)ch->NR * ch->NA,
+                                      ch->d_partials + (size_t)f * ch->gen_blocks, ch->gen_blocks, s));
+        partials_per_frame = ch->gen_blocks;
+    } else {
+        // slices per frame of a full chunk, and of the last (smaller) chunk, which is the most any frame of this batch gets
+        const int resident = ch->n_cus * ch->wg_per_cu;
+        const int wpf = chain_pick_wpf(ch, nf < resident ? nf : resident);
+        const int chunk = chain_chunk(ch, wpf);
+        const int tail = nf % chunk;
+        const int pstride = tail ? chain_pick_wpf(ch, tail) : wpf;
+        ch->d_partials += (size_t)f0 * pstride;
+        if (ch->d_rng) ch->d_rng += (size_t)f0 * ch->NR * ch->P;
+        if (ch->d_win) ch->d_win += (size_t)f0 * 2 * ch->win_dr * ch->NA;
+        if (pstride != wpf)      // frames of full chunks leave slots unused: all-ones = NaN power, never wins a merge
+            JRC_HIP(ctx, hipMemsetAsync(ch->d_partials, 0xFF, sizeof(PeakPartial) * (size_t)nf * pstride, s));
+        const int mode = !ch->write_map ? 1 : (power ? 3 : 0);
+        JRC_TRY(launch_fused_any(ch, mode, nf, wpf, pstride, d_chanest, d_map, s));
+        if (mode != 0)           // no complex map to read: the noise-window rows, through the same angle-axis code, into the compact window buffer
+            JRC_TRY(launch_window_rows(ch, nf, pstride, s));
+        if (ev2) JRC_HIP(ctx, hipEventRecord(ev2, s));
+        partials_per_frame = pstride;
+    }
+    // rest of A5
+    RaParams prm;
+    prm.vlen = ch->NA; prm.n_inputs = ch->NR; prm.n_range_bins = ch->NR; prm.n_angle_bins = ch->NA;
+    prm.noise_discard_range_m = c.noise_discard_range_m; prm.noise_discard_angle_deg = c.noise_discard_angle_deg;
+    if (ch->write_map && !power)
+        JRC_TRY(launch_ra_finalize(ctx, (const float2*)d_map, (size_t)ch->NR * ch->NA, ch->d_partials, partials_per_frame, prm, ch->d_bins,
+                                   ch->d_bins + ch->NR, d_results, nf, 0, s));
+    else
+        JRC_TRY(launch_ra_finalize(ctx, ch->d_win, (size_t)2 * ch->win_dr * ch->NA, ch->d_partials, partials_per_frame, prm, ch->d_bins,
+                                   ch->d_bins + ch->NR, d_results, nf, 2 * ch->win_dr, s));
+    return JRC_OK;
+}
+
+// how many slices the detect-only pipeline cuts a batch into (1 = the kernels one after the other on the caller's stream: the default).
+// Measured at round 4 (tools/detect_slices.sh, profiles/r04_detect_slices.txt): per 512 config-B frames 0.219 ms unsliced against 0.232 / 0.270 /
+// 0.377 ms for 2 / 4 / 8 slices (config D, 256 frames: 0.691 against 0.773 / 0.760 / 1.057) — the detect kernel's two workgroups per CU hold
+// 2 x 216 of a SIMD's 512 VGPRs, A1's waves (104) do not fit beside them, and an A1 form that does (two symbols in flight, 72 VGPRs:
+// JRC_CHANEST_U2) runs at 0.110 ms alone and gains nothing beside it either, while every slice pays its own launch ramp, a smaller pruning
+// horizon and two cross-stream event hand-offs.  The pipeline stays behind JRC_DETECT_SLICES for the record and is covered by the switch tests.
+static int chain_pick_slices(const jrc_chain* ch, int n_frames)
+{
+    if (ch->slices <= 1) return 1;
+    int n = ch->slices;
+    const int nx = ch->ctx->n_xcd;
+    while (n > 1 && n_frames / n < nx) n--;
+    return n < 1 ? 1 : n;
+}
+
+static int chain_pipeline_resources(jrc_chain* ch)
+{
+    jrc_ctx* ctx = ch->ctx;
+    if (ch->side[0]) return JRC_OK;
+    for (int k = 0; k < 2; k++) {
+        JRC_HIP(ctx, hipStreamCreateWithFlags(&ch->side[k], hipStreamNonBlocking));
+        JRC_HIP(ctx, hipEventCreateWithFlags(&ch->ev_side[k], hipEventDisableTiming));
+    }
+    for (auto& e : ch->ev_a1) JRC_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return JRC_OK;
+}
+
 static int chain_run(jrc_chain* ch, int n_frames, const jrc_cf32* d_frames, const jrc_cf32* d_tx, const jrc_cf32* d_rx_td, int cp_len,
                      long rx_stream_len, jrc_cf32* d_chanest, jrc_cf32* d_map, jrc_ra_result* d_results, void* stream)
 {
@@ -1344,6 +1479,45 @@ static int chain_run(jrc_chain* ch, int n_frames, const jrc_cf32* d_frames, cons
     const jrc_chain_cfg& c = ch->cfg;
     if (!d_frames && (cp_len < 0 || rx_stream_len < (long)c.n_items * (c.fft_len + cp_len)))
         return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_run_td_dev: rx_stream_len %ld shorter than n_items*(fft_len+cp_len)", rx_stream_len);
+    if ((!ch->write_map || ch->map_format != JRC_MAP_COMPLEX) && ch->generic) return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "detect-only / power-map mode needs the fused kernel");
+    if (ch->write_map && !d_map) return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_run_dev: d_map is NULL but the chain stores the map (jrc_chain_set_write_map)");
+    jrc_bg_state* bg = ch->bg;
+    const bool bg_on = bg && (bg->removal || bg->recording);
+    // Detect-only mode, no per-kernel timing, no background state (its kernels walk the whole batch), JRC_DETECT_SLICES > 1: the batch runs as a
+    // pipeline of slices — A1 of slice i+1 on the caller's stream beside A2..A5 of slice i on a side stream (A1 is HBM-bound, the detect kernel
+    // instruction-issue-bound).  The caller's stream waits for the side streams before this call returns control of it: the
+    // stream-order contract of the entry point is unchanged.  Off by default: measured slower than the kernels in series (chain_pick_slices).
+    int n_slices = 1;
+    if (!ch->write_map && !ch->generic && !ch->timing && !bg_on) {
+        n_slices = chain_pick_slices(ch, n_frames);
+        if (n_slices > 1) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) n_slices = 1;   // a capturing caller keeps one stream
+        }
+    }
+    if (n_slices > 1) {
+        JRC_TRY(chain_pipeline_resources(ch));
+        const int nx = ctx->n_xcd;
+        int per = (n_frames + n_slices - 1) / n_slices;
+        per = ((per + nx - 1) / nx) * nx;                   // slices in whole XCD groups of frames, a smaller one last
+        int i = 0;
+        bool used[2] = {false, false};
+        for (int f0 = 0; f0 < n_frames; f0 += per, i++) {
+            const int nf = n_frames - f0 < per ? n_frames - f0 : per;
+            JRC_TRY(chain_a1_stage(ch, f0, nf, d_frames, d_tx, d_rx_td, cp_len, rx_stream_len, d_chanest, s));
+            JRC_HIP(ctx, hipEventRecord(ch->ev_a1[i], s));
+            hipStream_t t = ch->side[i & 1];
+            JRC_HIP(ctx, hipStreamWaitEvent(t, ch->ev_a1[i], 0));
+            JRC_TRY(chain_transform_stage(ch, f0, nf, d_chanest, d_map, d_results, t, nullptr));
+            used[i & 1] = true;
+        }
+        for (int k = 0; k < 2; k++)
+            if (used[k]) {
+                JRC_HIP(ctx, hipEventRecord(ch->ev_side[k], ch->side[k]));
+                JRC_HIP(ctx, hipStreamWaitEvent(s, ch->ev_side[k], 0));
+            }
+        return JRC_OK;
+    }
     hipEvent_t* ev = nullptr;
     if (ch->timing) {
         if (ch->ev_used == jrc_chain::kPool) JRC_TRY(chain_drain_events(ch));
@@ -1352,75 +1526,16 @@ static int chain_run(jrc_chain* ch, int n_frames, const jrc_cf32* d_frames, cons
         JRC_HIP(ctx, hipEventRecord(ev[0], s));
     }
     // A1 (into the raw-estimate buffer when the background mean is subtracted afterwards)
-    jrc_bg_state* bg = ch->bg;
     const bool bg_sub = bg && bg->removal;
     jrc_cf32* d_est_out = d_chanest;
     if (bg_sub) { JRC_TRY(chain_ensure_raw(ch)); d_chanest = (jrc_cf32*)ch->d_raw; }
-    if (d_frames) {
-        ChanestGeom g;
-        g.N = c.fft_len; g.S = c.N_sym;
-        g.port_stride = (long)c.n_items * c.fft_len;
-        g.frame_stride = g.port_stride * (c.N_tx + c.N_rx);
-        g.tx_item0 = c.N_pre; g.rx_item0 = c.N_pre; g.interleave = c.enable_tx_interleave;
-        JRC_TRY(launch_radar_chanest(ctx, c.N_tx, c.N_rx, (const float2*)d_frames, (float2*)d_chanest, g, n_frames, s));
-    } else {
-        DemodGeom g;
-        g.N = c.fft_len; g.cp = cp_len; g.S = c.N_sym; g.R = c.N_rx; g.logn = 0;
-        g.tx_port_stride = (long)c.n_items * c.fft_len; g.tx_frame_stride = g.tx_port_stride * c.N_tx;
-        g.rx_stream_stride = rx_stream_len; g.rx_frame_stride = rx_stream_len * c.N_rx;
-        g.tx_item0 = c.N_pre; g.rx_sym0 = c.N_pre; g.interleave = c.enable_tx_interleave; g.blocks_per_frame = 1;
-        JRC_TRY(launch_demod_chanest(ctx, c.N_tx, (const float2*)d_tx, (const float2*)d_rx_td, (float2*)d_chanest, g, n_frames, s));
-    }
-    if (bg && (bg->removal || bg->recording)) {
+    JRC_TRY(chain_a1_stage(ch, 0, n_frames, d_frames, d_tx, d_rx_td, cp_len, rx_stream_len, d_chanest, s));
+    if (bg_on) {
         JRC_TRY(chain_background_step(ch, n_frames, (const float2*)d_chanest, (float2*)d_est_out, s));
         d_chanest = d_est_out;
     }
     if (ev) JRC_HIP(ctx, hipEventRecord(ev[1], s));
-    if ((!ch->write_map || ch->map_format != JRC_MAP_COMPLEX) && ch->generic) return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "detect-only / power-map mode needs the fused kernel");
-    if (ch->write_map && !d_map) return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_run_dev: d_map is NULL but the chain stores the map (jrc_chain_set_write_map)");
-    // A2 + A3 + A4 + arg-max half of A5
-    int partials_per_frame;
-    if (ch->generic) {
-        // A1 output -> zero pad -> A2 fft_vxx reverse (NR) -> A3 matrix_transpose -> A4 fft_vxx forward+shift (NA), in place
-        const size_t rows = (size_t)n_frames * ch->P;
-        unsigned pb = (unsigned)((rows * ch->NR + 255) / 256); if (pb > 8192) pb = 8192;
-        hipLaunchKernelGGL(pad_rows_kernel, dim3(pb), dim3(256), 0, s, (const float2*)d_chanest, ch->d_pad, c.fft_len, ch->NR, rows);
-        JRC_HIP(ctx, hipGetLastError());
-        JRC_TRY(launch_fft_vcc(ctx, ch->NR, 0, 0, nullptr, rows, ch->d_pad, ch->d_pad, ch->NR, 0, s));
-        int tr = jrc_matrix_transpose_dev(ctx, ch->NR, ch->P, c.interp_angle, ch->P, (size_t)n_frames, (const jrc_cf32*)ch->d_pad, d_map, (void*)s);
-        if (tr < 0) return tr;
-        JRC_TRY(launch_fft_vcc(ctx, ch->NA, 1, 1, nullptr, (size_t)n_frames * ch->NR, (const float2*)d_map, (float2*)d_map, ch->NA, 0, s));
-        if (ev) JRC_HIP(ctx, hipEventRecord(ev[2], s));
-        for (int f = 0; f < n_frames; f++)
-            JRC_TRY(launch_ra_partial(ctx, (const float2*)d_map + (size_t)f * ch->NR * ch->NA, (size_t)ch->NR * ch->NA,
-                                      ch->d_partials + (size_t)f * ch->gen_blocks, ch->gen_blocks, s));
-        partials_per_frame = ch->gen_blocks;
-    } else {
-        // slices per frame of a full chunk, and of the last (smaller) chunk, which is the most any frame of this batch gets
-        const int resident = ch->n_cus * ch->wg_per_cu;
-        const int wpf = chain_pick_wpf(ch, n_frames < resident ? n_frames : resident);
-        const int chunk = chain_chunk(ch, wpf);
-        const int tail = n_frames % chunk;
-        const int pstride = tail ? chain_pick_wpf(ch, tail) : wpf;
-        if (pstride != wpf)      // frames of full chunks leave slots unused: all-ones = NaN power, never wins a merge
-            JRC_HIP(ctx, hipMemsetAsync(ch->d_partials, 0xFF, sizeof(PeakPartial) * (size_t)n_frames * pstride, s));
-        const int mode = !ch->write_map ? 1 : (ch->map_format == JRC_MAP_POWER ? 3 : 0);
-        JRC_TRY(launch_fused_any(ch, mode, n_frames, wpf, pstride, (const float2*)d_chanest, (float2*)d_map, s));
-        if (mode != 0)           // no complex map to read: the noise-window rows, through the same angle-axis code, into the compact window buffer
-            JRC_TRY(launch_window_rows(ch, n_frames, pstride, s));
-        if (ev) JRC_HIP(ctx, hipEventRecord(ev[2], s));
-        partials_per_frame = pstride;
-    }
-    // rest of A5
-    RaParams prm;
-    prm.vlen = ch->NA; prm.n_inputs = ch->NR; prm.n_range_bins = ch->NR; prm.n_angle_bins = ch->NA;
-    prm.noise_discard_range_m = c.noise_discard_range_m; prm.noise_discard_angle_deg = c.noise_discard_angle_deg;
-    if (ch->write_map && ch->map_format == JRC_MAP_COMPLEX)
-        JRC_TRY(launch_ra_finalize(ctx, (const float2*)d_map, (size_t)ch->NR * ch->NA, ch->d_partials, partials_per_frame, prm, ch->d_bins,
-                                   ch->d_bins + ch->NR, d_results, n_frames, 0, s));
-    else
-        JRC_TRY(launch_ra_finalize(ctx, ch->d_win, (size_t)2 * ch->win_dr * ch->NA, ch->d_partials, partials_per_frame, prm, ch->d_bins,
-                                   ch->d_bins + ch->NR, d_results, n_frames, 2 * ch->win_dr, s));
+    JRC_TRY(chain_transform_stage(ch, 0, n_frames, d_chanest, d_map, d_results, s, ev ? ev[2] : nullptr));
     if (ev) JRC_HIP(ctx, hipEventRecord(ev[3], s));
     return JRC_OK;
 }

@@ -79,6 +79,7 @@ extern "C" int jrc_create(int device, jrc_ctx** out)
     { int khz = 0; if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) ctx->wall_clock_khz = khz; }
     if (const char* e = getenv("JRC_CHANEST_CHUNK")) ctx->tune.chanest_chunk = atoi(e);
     ctx->tune.chanest_x1 = getenv("JRC_CHANEST_X1") != nullptr;
+    ctx->tune.chanest_u2 = getenv("JRC_CHANEST_U2") != nullptr;
     ctx->tune.fd_serial = getenv("JRC_FD_SERIAL") != nullptr;
     ctx->tune.sync_naive = getenv("JRC_SYNC_NAIVE") != nullptr;
     ctx->tune.dec_single = getenv("JRC_DEC_SINGLE") != nullptr;

@@ -49,6 +49,7 @@ struct jrc_ctx {
         bool rd_two_step = false;    // JRC_RD_TWO_STEP: range-Doppler product and Doppler FFT as two kernels also where the one-kernel form applies
         int rd_chunk_mb = 160;       // JRC_RD_CHUNK_MB: range-Doppler frames per pass = this many MiB of the compact [pair][subcarrier][Doppler] array, which then stays in the 256 MiB Infinity Cache between its two kernels (0: all frames at once)
         int rd_exp = 0;              // JRC_RD_EXP: range-Doppler pruned-FFT kernel experiments, TIMING ONLY, WRONG RESULTS: 1: no stores; 2: first and last pass only
+        bool chanest_u2 = false;     // JRC_CHANEST_U2: A1 with two symbols in flight per lane instead of four (<= 80 VGPRs: a wave fits a SIMD beside two waves of the detect-only kernel)
         int detect_exp = 0;          // JRC_DETECT_EXP: detect-only kernel experiments (chain.hip, MODE 1). 8: no pruning; 16: sum bound only. TIMING ONLY, WRONG RESULTS: 1: no angle stage; 2: no range-profile stores; 32: sampled rows never computed
         double ra_offered_tbps = 0;  // JRC_RA_OFFERED_TBPS: offered store rate the pacing word is derived from (0 = the kernel's measured optimum)
         int demod_spr = 0;           // JRC_DEMOD_SPR: symbols per round (2 or 4) of the A6+A7+A1 kernel (0 = by fft_len)

@@ -177,6 +177,7 @@ int launch_radar_chanest(jrc_ctx* ctx, int T, int R, const float2* d_frames, flo
             float2* Hc = d_H + (size_t)f0 * T * R * g.N;
             if (T == 1) hipLaunchKernelGGL((radar_chanest_x2_kernel<1, 8>), grid, block, 0, stream, fr, Hc, g, R);
             else if (T == 2) hipLaunchKernelGGL((radar_chanest_x2_kernel<2, 4>), grid, block, 0, stream, fr, Hc, g, R);
+            else if (ctx->tune.chanest_u2) hipLaunchKernelGGL((radar_chanest_x2_kernel<4, 2>), grid, block, 0, stream, fr, Hc, g, R);
             else hipLaunchKernelGGL((radar_chanest_x2_kernel<4, 4>), grid, block, 0, stream, fr, Hc, g, R);
         }
         JRC_HIP(ctx, hipGetLastError());

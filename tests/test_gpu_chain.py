@@ -290,6 +290,49 @@ def test_range_doppler_in_chunks_equals_one_pass(jrc, monkeypatch):
     assert np.array_equal(outs[0], outs[1])
 
 
+@pytest.mark.gpu
+def test_range_doppler_at_the_benchmarked_config_d_shape(jrc, monkeypatch):
+    """row D at exactly the shape bench.py quotes it on (BASELINE config 4: 4x4, 1024 subcarriers, 128 symbols, 8 targets, Ir 8, Id 1):
+    eleven frames, so the default 160 MiB chunking of the compact array (16 MiB per frame: ten frames fill it exactly) splits them 10 + 1.
+    Frame 0 and the first frame of the second chunk against the numpy definition; every frame bit-equal to the unchunked pass
+    (JRC_RD_CHUNK_MB=0)."""
+    import torch
+    from jrc_amd import synth
+    sc = synth.config_D()
+    N, T, R, S, Ir, Id, F = sc.N, sc.T, sc.R, sc.S, 8, 1, 11
+    assert (N, T, R, S) == (1024, 4, 4, 128)
+    P = T * R
+    frames = synth.make_frames(sc, F)
+    rb, ab = jrc.radar_axes(N, sc.fs, Ir, P, 16)
+    maps = []
+    for mb in (None, "0"):
+        if mb is None:
+            monkeypatch.delenv("JRC_RD_CHUNK_MB", raising=False)
+        else:
+            monkeypatch.setenv("JRC_RD_CHUNK_MB", mb)
+        c = jrc.Context(0)
+        chain = jrc.RadarChain(N, T, R, S, sc.Npre, Ir, 16, rb, ab, 2.4, 30.0, max_frames=F, ctx=c)
+        bufs = chain.alloc(F, "cuda:0", with_map=False)
+        bufs["frames"].copy_(torch.from_numpy(frames.view(np.float32).reshape(bufs["frames"].shape)))
+        torch.cuda.synchronize()
+        rd = chain.range_doppler(bufs, F, Id)
+        c.sync()
+        maps.append(rd.clone())
+        chain.close()
+        c.close()
+    assert tuple(maps[0].shape[:4]) == (F, P, N * Ir, S * Id)
+    assert P * N * S * 8 * 10 <= 160 << 20 < P * N * S * 8 * 11       # the default chunk holds ten frames, not eleven
+    assert torch.equal(maps[0], maps[1])                             # chunked == one pass, all eleven frames, bit for bit
+    for f in (0, 10):
+        got = maps[0][f].cpu().numpy().view(np.complex64)[..., 0]
+        tx = frames[f, :T, sc.Npre:].astype(np.complex128)
+        rx = frames[f, T:, sc.Npre:].astype(np.complex128)
+        D = np.einsum("rsn,tsn->rtsn", rx, np.conj(tx)).reshape(P, S, N)
+        rng = np.fft.ifft(D, n=N * Ir, axis=-1) * (N * Ir)
+        ref = np.fft.fftshift(np.fft.fft(np.swapaxes(rng, -1, -2), n=S * Id, axis=-1), axes=-1)
+        assert got.shape == ref.shape and rel_err(got, ref) < FFT_TOL, f
+
+
 @pytest.mark.parametrize("T,R,N,S,Ir,Id,vel", [(2, 2, 64, 16, 4, 4, 30.0), (4, 4, 256, 64, 2, 1, -20.0), (1, 1, 64, 64, 2, 2, 600.0),
                                                (1, 2, 1024, 16, 8, 1, 200.0),     # fft_len 1024: pruned-FFT range kernel, 8 classes
                                                (2, 1, 256, 32, 1, 1, -50.0),      # no range interpolation (one class)

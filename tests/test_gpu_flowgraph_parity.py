@@ -1,0 +1,297 @@
+"""GPU tier, the acceptance scenario of BASELINE.json's north_star: the reference's simulation flowgraphs
+(examples/simulation/radar/mimo_ofdm_jrc_radar_sim.grc:2165-2232, examples/simulation/communication/mimo_ofdm_jrc_comm_sim.grc)
+wired twice by the SAME wiring code (examples/radar_sim_flowgraph.py, examples/comm_sim_flowgraph.py) — once over the HIP blocks,
+once over the CPU oracle's blocks (tests/oracle_blocks.py) — fed identical symbols and identical draws of the random sources
+(zero_pad noise, noise sources), and compared edge by edge:
+
+  * chained: each graph runs on its own upstream results, so an edge's error is everything accumulated from the PDU to it;
+    complex-float edges  ||a-b||_inf / ||b||_inf <= 1e-4 (north_star's tolerance), integer edges bit-exact (lengths announced by the
+    tagged-stream blocks, items consumed, SIG fields, tag offsets, estimator indices, decoded bytes, CRC flag);
+  * block by block: the oracle graph re-run with every block reading the HIP graph's tensor on its input edge (`force=`), which
+    isolates each block's own error (the number DESIGN.md §5.2 tabulates).
+
+Shapes: the reference's operating point (4x2, N=64, N_pre=5, N_sym=4; tests/golden/radar_flowgraph_point.npz), BASELINE config A
+(1x1, 64 subcarriers, 16 symbols) and a config-B scale-up (4x4, 256 subcarriers, 64 symbols).  The per-edge errors of the run are
+written to gpurun_out/flowgraph_parity.json."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle
+import oracle_blocks
+from conftest import GOLDEN, ROOT, rel_err
+
+sys.path.insert(0, os.path.join(ROOT, "examples"))
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4                                     # north_star: 1e-4 relative complex-float tolerance
+REPORT = {}
+
+
+def teardown_module(module):
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "flowgraph_parity.json"), "w") as fh:
+            json.dump(REPORT, fh, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def tables_64(ofdm64, T):
+    """the reference's 64-carrier tables; for T != 4 the MIMO-LTF mapping P_ltf shrinks to its leading T x T block"""
+    o = {k: ofdm64[k] for k in ofdm64.files}
+    if T != 4:
+        P = np.asarray(ofdm64["P_ltf"])[:T, :T]
+        o["ltf_mapped_sc__ss_sym"] = np.stack([(P * ofdm64["ltf_64"][sc]).reshape(-1) for sc in range(64)]).astype(np.complex64)
+        o["N_tx"] = np.int32(T)
+    return o
+
+
+def tables_256(T=4):
+    """config_c_tables (test_gpu_comm.py) plus the 802.11-style sync words the sync front end needs, scaled like the 64-carrier
+    ones: STF on every 4th carrier (period N/4 in time, what the detector's delay-N/4 autocorrelation looks for), then the LTF
+    advanced by N/4 samples ((-j)^i phase ramp, as l_stf_ltf_64[2] is of l_stf_ltf_64[3]) and the LTF itself"""
+    from test_gpu_comm import config_c_tables
+    N = 256
+    data, pilots, pil, ltf, mapped, _ = config_c_tables(N, T)
+    rng = np.random.default_rng(77)
+    act = np.flatnonzero(ltf)
+    stf = np.zeros(N, np.complex64)
+    idx = np.array([i for i in act if i % 4 == 0])
+    stf[idx] = rng.choice([-1.0, 1.0], idx.size) * (1 + 1j) * np.sqrt(act.size / (2.0 * idx.size))
+    ltf_rot = (ltf * (-1j) ** np.arange(N)).astype(np.complex64)
+    sync = np.stack([stf, stf, ltf_rot, ltf]).astype(np.complex64)
+    l_ltf_time = N * np.fft.ifft(np.fft.fftshift(ltf)) / np.sqrt(np.count_nonzero(ltf))      # the ofdm_config module's l_ltf_fir rule
+    return dict(N_tx=np.int32(T), data_subcarriers=np.array(data, np.int32), pilot_subcarriers=np.array(pilots, np.int32),
+                pilot_symbols=pil, l_stf_ltf_64=sync, ltf_64=ltf, ltf_mapped_sc__ss_sym=mapped,
+                l_ltf_fir=np.conj(l_ltf_time)[::-1].astype(np.complex64))
+
+
+def qpsk(rng, n):
+    pts = np.array([-1 - 1j, 1 - 1j, -1 + 1j, 1 + 1j]) * (0.707107 / 2)
+    return pts[rng.integers(0, 4, n)].astype(np.complex64)
+
+
+RADAR_CF32_EDGES = ("tx_f", "tx_t", "bursts", "sims", "rx_t", "rx_f", "H", "range_profile", "transposed", "map")
+RESULT_INTS = ("peak_range_idx", "peak_angle_idx", "angle_null_idx", "discard_range_idx", "discard_angle_idx", "n_noise_samples", "published")
+RESULT_FLOATS = ("peak_power", "noise_power", "snr_est", "range_val", "angle_val")
+
+
+def compare_results(g, o, exact_floats):
+    for k in RESULT_INTS:
+        assert getattr(g, k) == getattr(o, k), k
+    for k in RESULT_FLOATS:
+        a, b = getattr(g, k), getattr(o, k)
+        if exact_floats or k in ("range_val", "angle_val"):      # bin values are table look-ups: exact once the indices agree
+            assert a == b, (k, a, b)
+        else:
+            assert abs(a - b) <= TOL * abs(b), (k, a, b)
+
+
+RADAR_SHAPES = {
+    # name: (tables, fft_len, N_rx, n data symbols, radar N_sym, targets (range, velocity, rcs dBsm, angle))
+    "operating_point_4x2_N64": (lambda o: tables_64(o, 4), 64, 2, None, None, ([10.0], [0.0], [20.0], [0.0])),
+    "operating_point_moving_target": (lambda o: tables_64(o, 4), 64, 2, None, None, ([17.0], [12.0], [20.0], [-30.0])),
+    "config_A_1x1_N64_S16": (lambda o: tables_64(o, 1), 64, 1, 15, 16, ([10.0], [0.0], [20.0], [0.0])),
+    "config_B_4x4_N256_S64": (lambda o: tables_256(4), 256, 4, 60, 64, ([10.0], [0.0], [20.0], [20.0])),
+    "two_targets_2x2_N128": (None, 128, 2, 10, 8, ([12.0, 30.0], [0.0, -8.0], [20.0, 23.0], [25.0, -40.0])),
+}
+
+
+def tables_128(T=2):
+    from test_gpu_comm import config_c_tables
+    from jrc_amd import synth
+    N = 128
+    data, pilots, pil, ltf, mapped, sync = config_c_tables(N, 4, seed=3)
+    mapped = np.stack([(synth.hadamard(T) * ltf[sc]).reshape(-1) for sc in range(N)]).astype(np.complex64)
+    return dict(N_tx=np.int32(T), data_subcarriers=np.array(data, np.int32), pilot_subcarriers=np.array(pilots, np.int32),
+                pilot_symbols=pil[:, :len(pilots)], l_stf_ltf_64=sync.astype(np.complex64), ltf_64=ltf, ltf_mapped_sc__ss_sym=mapped)
+
+
+@pytest.mark.parametrize("fused_demod", [True, False], ids=["fused_demod", "block_demod"])
+@pytest.mark.parametrize("shape", list(RADAR_SHAPES))
+def test_radar_flowgraph_edge_by_edge(jrc, ctx, ofdm64, shape, fused_demod):
+    import radar_sim_flowgraph as fgm
+    mk, N, R, n_data, S_radar, (rng_m, vel, rcs, az) = RADAR_SHAPES[shape]
+    o = tables_128(2) if mk is None else mk(ofdm64)
+    T = int(o["N_tx"])
+    kw = dict(trgt_range=rng_m, trgt_velocity=vel, trgt_rcs_dbsm=rcs, trgt_angle=az, N_rx=R, fft_len=N, N_sym_radar=S_radar, seed=5)
+    if shape.startswith("operating_point"):                      # the .grc's values, as minted from it (tests/golden)
+        fgp = np.load(os.path.join(GOLDEN, "radar_flowgraph_point.npz"))
+        assert [N, T, R] == [int(fgp["radar_ints"][0]), int(fgp["radar_ints"][1]), int(fgp["radar_ints"][2])]
+    hip = fgm.RadarSimFlowgraph(o, ctx=ctx, fused_demod=fused_demod, **kw)
+    orc = fgm.RadarSimFlowgraph(o, blocks=oracle_blocks, fused_demod=fused_demod, **kw)
+    if shape.startswith("operating_point"):
+        assert (hip.N_pre, hip.N_sym_radar, hip.Ir, hip.Ia) == (int(fgp["radar_ints"][4]), int(fgp["radar_ints"][3]), 8, 16)
+        assert np.array_equal(hip.range_bins, fgp["estimator_range_bins_f32"]) and np.array_equal(hip.angle_bins, fgp["estimator_angle_bins_f32"])
+        assert hip.pad_tail == int(fgp["zero_pad_tail"]) and abs(hip.noise_var - float(fgp["var_noise_var"])) < 1e-18
+        assert np.allclose(np.array(hip.TX_RXs), np.stack([fgp["var_TX%d_RXs" % (t + 1)] for t in range(4)]), rtol=1e-12)
+    rng = np.random.default_rng(11)
+    nd = len(o["data_subcarriers"])
+    mcs = 2
+    if n_data is None:
+        nbytes = 100
+        n_data = jrc.n_ofdm_sym(mcs, nd, nbytes)
+    else:
+        nbytes = (n_data * nd - 22) // 8
+        assert jrc.n_ofdm_sym(mcs, nd, nbytes) == n_data
+    rep = REPORT.setdefault("radar/%s/%s" % (shape, "fused" if fused_demod else "blocks"), {})
+    for ptype in (fgm.DATA, fgm.NDP):
+        sym = qpsk(rng, n_data * nd)
+        gres, ge = hip.run_packet(sym, mcs, ptype, nbytes)
+        src = dict(pads=ge["pads"], noise=ge["noise"])
+        for t in range(T):                                       # zero_pad passes the burst through untouched
+            assert np.array_equal(ge["bursts"][t][:ge["tx_t"].shape[1]], ge["tx_t"][t])
+            assert 0.007 < ge["pads"][t].real.std() < 0.014 and 0.007 < ge["pads"][t].imag.std() < 0.014   # normal_distribution(0, 1e-2): sigma 0.01
+        # (1) chained: the oracle graph on its own upstream results
+        ores, oe = orc.run_packet(sym, mcs, ptype, nbytes, sources=src)
+        assert ge["lengths"] == oe["lengths"]                     # every announced packet length / consumed count, bit-exact
+        P = T * R
+        assert ge["lengths"]["radar_out"] == P and ge["lengths"]["transpose_out"] == N * 8 and ge["lengths"]["map_rows"] == N * 8
+        n_total = hip.n_sync + 1 + T + n_data
+        assert ge["lengths"]["precoder_out"] == n_total and ge["lengths"]["cp_remover_out"] == n_total + 3
+        for k in RADAR_CF32_EDGES:
+            assert ge[k].shape == oe[k].shape and ge[k].dtype == np.complex64, k
+            err = rel_err(ge[k], oe[k])
+            rep["chained:" + k] = max(rep.get("chained:" + k, 0.0), err)
+            assert err <= TOL, (k, err)
+        compare_results(gres, ores, exact_floats=False)
+        # (2) block by block: every oracle block on the HIP graph's input edge
+        bres, be = orc.run_packet(sym, mcs, ptype, nbytes, sources=src, force={k: ge[k] for k in RADAR_CF32_EDGES})
+        for k in RADAR_CF32_EDGES:
+            err = rel_err(ge[k], be[k])
+            rep["block:" + k] = max(rep.get("block:" + k, 0.0), err)
+            assert err <= 2e-5, (k, err)
+        assert np.array_equal(ge["bursts"], be["bursts"]) and np.array_equal(ge["transposed"], be["transposed"])   # copies: bit-equal
+        assert np.array_equal(ge["H"], be["H"])                   # A1: the reference's own evaluation order, bit-exact
+        compare_results(gres, bres, exact_floats=True)            # A5 on the same map: every field exact
+        if ptype == fgm.DATA and "moving" not in shape and len(rng_m) == 1 and T > 1:
+            assert gres.published == 1 and abs(gres.range_val - rng_m[0]) < 0.8 and abs(gres.angle_val - az[0]) < 2.5
+
+
+COMM_CF32_EDGES = ("symbols", "tx_f", "tx_t", "padded", "rx", "detector_out", "sync_out", "y", "eq_out")
+
+
+def same_events(ge, oe, tol):
+    assert len(ge) == len(oe)
+    for g, o in zip(ge, oe):
+        assert g["kind"] == o["kind"] and g["offset"] == o["offset"]
+        if g["kind"] == 1:
+            assert (g["data_bytes"], g["mcs"], g["packet_type"]) == (o["data_bytes"], o["mcs"], o["packet_type"])
+            assert abs(g["snr"] - o["snr"]) <= max(tol * abs(o["snr"]), 1e-3) and abs(g["freq_offset"] - o["freq_offset"]) <= tol * max(1.0, abs(o["freq_offset"]))
+        else:
+            assert abs(g["snr_data"] - o["snr_data"]) <= max(tol * abs(o["snr_data"]), 1e-3)
+            assert g["chan_mean"].shape == o["chan_mean"].shape
+            if g["chan_mean"].size:
+                assert rel_err(g["chan_mean"], o["chan_mean"]) <= tol
+
+
+def compare_comm_edges(ge, oe, rep, tag, tol, live=48, norm_tol=1e-3):
+    assert ge["encoder_tags"] == oe["encoder_tags"]               # packet_len, packet_type, mcs, pdu_len
+    for k in COMM_CF32_EDGES:
+        assert k in ge and k in oe, k
+        assert ge[k].shape == oe[k].shape, (k, ge[k].shape, oe[k].shape)
+        err = rel_err(ge[k], oe[k]) if ge[k].size else 0.0
+        rep[tag + k] = max(rep.get(tag + k, 0.0), err)
+        assert err <= tol, (k, err)
+    assert np.array_equal(ge["symbols"], oe["symbols"])           # constellation points: exact
+    for i, name in enumerate(("metric_delayed", "metric_corr", "metric_norm")):
+        a, b = ge["metrics"][i], oe["metrics"][i]
+        if name == "metric_norm":
+            # float edge |corr| / power: the stock blocks_moving_average_ff keeps a RUNNING sum whose round-off depends on everything that
+            # went through it (worst behind the 40 dB step from pad noise to burst); the device adds each window afresh (sync.hip) and is
+            # the more accurate of the two.  The first window of samples divides by a near-empty power window.  DESIGN.md §5.2.
+            a, b = a[live:], b[live:]
+            err = float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
+            rep[tag + name] = max(rep.get(tag + name, 0.0), err)
+            assert err <= norm_tol, (name, err)
+            continue
+        err = rel_err(a, b)
+        rep[tag + name] = max(rep.get(tag + name, 0.0), err)
+        assert err <= tol, (name, err)
+    for key in ("detector_tags", "sync_tags"):                    # tag offsets bit-exact, the CFO values they carry to tolerance
+        assert [t[0] for t in ge[key]] == [t[0] for t in oe[key]], key
+        for a, b in zip(ge[key], oe[key]):
+            assert abs(a[1] - b[1]) <= tol * max(1.0, abs(b[1])), key
+    assert ge["eq_consumed"] == oe["eq_consumed"]
+    same_events(ge["eq_events"], oe["eq_events"], tol)
+    if oe["chan_est"] is None:
+        assert ge["chan_est"] is None
+    else:
+        err = rel_err(ge["chan_est"], oe["chan_est"])
+        rep[tag + "chan_est"] = max(rep.get(tag + "chan_est", 0.0), err)
+        assert err <= tol
+    assert ge.get("crc_ok") == oe.get("crc_ok") and ge.get("payload") == oe.get("payload")       # decoded PDU bytes + CRC flag
+
+
+@pytest.mark.parametrize("est", [0, 1], ids=["LS", "STA"])
+@pytest.mark.parametrize("mcs", [0, 2, 3, 5])
+def test_comm_flowgraph_edge_by_edge_at_the_grc_operating_point(jrc, ctx, ofdm64, mcs, est):
+    """4 TX, N=64, line-of-sight channel of the .grc (distance 20 m, theta 20 deg, tx_multiplier 0.5, NF 10 dB): NDP (channel
+    sounding) then DATA packets without and with the steering derived from the sounding (per subcarrier = chan_est_smoothing
+    False as in the .grc, and from the mean channel)."""
+    import comm_sim_flowgraph as cfm
+    fgp = np.load(os.path.join(GOLDEN, "radar_flowgraph_point.npz"))
+    rep = REPORT.setdefault("comm/N64/mcs%d/%s" % (mcs, "STA" if est else "LS"), {})
+    for smoothing in (False, True):
+        hip = cfm.CommSimFlowgraph(ofdm64, mcs=mcs, estimator=est, seed=2, ctx=ctx, channel="los", smoothing=smoothing)
+        orc = cfm.CommSimFlowgraph(ofdm64, mcs=mcs, estimator=est, seed=2, blocks=oracle_blocks, channel="los", smoothing=smoothing)
+        orcb = cfm.CommSimFlowgraph(ofdm64, mcs=mcs, estimator=est, seed=2, blocks=oracle_blocks, channel="los", smoothing=smoothing)   # block by block
+        assert [hip.pad_front, hip.pad_tail] == list(fgp["comm_zero_pad"]) and hip.sync_length == int(fgp["comm_frame_sync_ints"][2])
+        assert hip.ignore_gap == int(fgp["comm_frame_detector"][4]) and hip.corr_window_size == int(fgp["comm_moving_avg"][0])
+        assert abs(1 / abs(hip.h[0]) - float(fgp["comm_noise_var_path_loss"][1])) < 1e-5 * float(fgp["comm_noise_var_path_loss"][1])
+        assert abs(hip.noise_var - float(fgp["comm_noise_var_path_loss"][0])) < 1e-18
+        rng = np.random.default_rng(100 + mcs)
+        pdus = [(bytes([1]) + b"sounding packet", False)]
+        pdus += [(bytes([2]) + rng.integers(0, 256, 80 + 57 * i, dtype=np.uint8).tobytes(), i >= 1) for i in range(3)]
+        for pdu, steer in pdus:
+            gok, gpay, ginfo = hip.send(pdu, steer=steer)
+            ge = ginfo["edges"]
+            src = dict(pads=ge["pads"], noise=ge["noise"])
+            T = hip.T
+            for t in range(T):                                    # zero_pad: the burst untouched between the pads
+                assert np.array_equal(ge["padded"][t][hip.pad_front:hip.pad_front + ge["tx_t"].shape[1]], ge["tx_t"][t])
+            ook, opay, oinfo = orc.send(pdu, steer=steer, sources=src)
+            oe = oinfo["edges"]
+            assert (gok, gpay) == (ook, opay)
+            if steer:
+                err = rel_err(ge["steering"], oe["steering"])
+                rep["chained:steering"] = max(rep.get("chained:steering", 0.0), err)
+                assert err <= TOL
+            compare_comm_edges(ge, oe, rep, "chained:", TOL)
+            if pdu[0] == 2 and mcs < 5:
+                assert gok and gpay == pdu                        # and the link works: the PDU comes back (16-QAM 3/4 may fail at this SNR)
+            # block by block: a second oracle graph in lockstep (the encoder's scrambler seed and the decoder's PER window are state),
+            # every block reading the HIP graph's input edge; the sounding it steers with is the HIP graph's as well
+            keys = [k for k in COMM_CF32_EDGES + ("metrics", "detector_tags", "sync_tags", "eq_events", "chan_est") if ge.get(k) is not None]
+            if steer:
+                orcb.chan_est = hip.chan_est
+            bok, bpay, binfo = orcb.send(pdu, steer=steer, sources=src, force={k: ge[k] for k in keys})
+            compare_comm_edges(ge, binfo["edges"], rep, "block:", 2e-5)
+            assert (bok, bpay) == (gok, gpay)
+
+
+def test_comm_flowgraph_edge_by_edge_256_subcarriers(jrc, ctx):
+    """the same graph scaled to BASELINE config C's carrier count (4 TX, N=256, cp 64) on the flat drawn channel"""
+    import comm_sim_flowgraph as cfm
+    o = tables_256(4)
+    rep = REPORT.setdefault("comm/N256/mcs2/LS", {})
+    hip = cfm.CommSimFlowgraph(o, mcs=2, estimator=0, seed=4, ctx=ctx, fft_len=256, channel="flat")
+    orc = cfm.CommSimFlowgraph(o, mcs=2, estimator=0, seed=4, blocks=oracle_blocks, fft_len=256, channel="flat")
+    assert np.array_equal(hip.h, orc.h)
+    rng = np.random.default_rng(9)
+    for pdu, steer in [(bytes([1]) + b"sounding", False), (bytes([2]) + rng.integers(0, 256, 900, dtype=np.uint8).tobytes(), False),
+                       (bytes([2]) + rng.integers(0, 256, 1400, dtype=np.uint8).tobytes(), True)]:
+        gok, gpay, ginfo = hip.send(pdu, snr_db=30.0, steer=steer, lead=2560)
+        ge = ginfo["edges"]
+        ook, opay, oinfo = orc.send(pdu, snr_db=30.0, steer=steer, lead=2560, sources=dict(pads=None, noise=ge["noise"]))
+        assert "y" in ge, ginfo.keys()
+        # behind the burst (30 dB over the noise that follows) the reference's running power sum keeps the burst's round-off: 2e-3 of the metric there
+        compare_comm_edges(ge, oinfo["edges"], rep, "chained:", TOL, live=192, norm_tol=5e-3)
+        assert (gok, gpay) == (ook, opay)
+        if pdu[0] == 2:
+            assert gok and gpay == pdu

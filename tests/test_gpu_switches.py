@@ -5,7 +5,8 @@ import numpy as np
 import pytest
 
 SWITCHES = [{"JRC_WPF": "2"}, {"JRC_WPF": "8"}, {"JRC_WG_PER_CU": "1"}, {"JRC_RA_PACE": "0"}, {"JRC_RA_PACE": "60"}, {"JRC_RA_OFFERED_TBPS": "5.5"},
-            {"JRC_NCUS": "96"}, {"JRC_XCDS": "4"}, {"JRC_XCDS": "1"}, {"JRC_CHANEST_CHUNK": "16"}, {"JRC_CHANEST_X1": "1"}, {"JRC_THREADS": "512"}]
+            {"JRC_NCUS": "96"}, {"JRC_XCDS": "4"}, {"JRC_XCDS": "1"}, {"JRC_CHANEST_CHUNK": "16"}, {"JRC_CHANEST_X1": "1"}, {"JRC_THREADS": "512"},
+            {"JRC_DETECT_SLICES": "2"}, {"JRC_DETECT_SLICES": "5"}, {"JRC_DETECT_SLICES": "3", "JRC_CHANEST_U2": "1"}]
 
 
 def _run(jrc, env, monkeypatch, cfg):
