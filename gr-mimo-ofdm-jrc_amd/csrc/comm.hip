@@ -117,6 +117,8 @@ extern "C" int jrc_sig_encode(int n_data, int mcs, int packet_type, int length, 
 // C1 equalizer
 struct EqDev {
     int N, cp, ND, NP, NAct, NL, T, mapped_cols, n_pilot_rows, estimator, lds_tables;
+    int exp;            // JRC_EQ_EXP (timing experiments, WRONG RESULTS): 1 = the pilot phase reads the batch's first symbol for every symbol
+    int sig_full;       // JRC_EQ_SIG_FULL: always run the windowed Viterbi on the SIG field (no codeword shortcut)
     double freq, bw;
     const int* data_c; const int* pilot_c; const int* active_c;
     const float2* pilot_sym; const float2* ltf; const float2* mapped;
@@ -168,10 +170,30 @@ __device__ __forceinline__ int sig_wave_max(int v) { for (int off = 32; off > 0;
 __device__ __forceinline__ int sig_wave_min(int v) { for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off)); return v; }
 
 // wave 0 only (lane = tid < 64).  Z: the ND equalised SIG cells; ring: 5 x 64 bytes of scratch.  Returns decoded bits 0..23 (bit i of the word = header bit i).
-__device__ __forceinline__ unsigned sig_viterbi_wave(const float2* Z, int ND, unsigned char* ring, int lane)
+//
+// Codeword shortcut (round 4).  When the 124 hard decisions the decoder would read ARE the encoder's output for some input sequence, that
+// sequence is what the decoder returns: its path scores 2 on every step, any path ending in another state has lost 2 at the step where the two
+// inputs first differed (both generators tap the newest bit, 0155 and 0117 are odd), so the true state is the strict maximum at every
+// viterbi_get_output call and every traceback follows the true path, whatever the window.  The input sequence comes straight from the coded
+// bits — g0 = 1+D^2+D^3+D^5+D^6 and g1 = 1+D+D^2+D^3+D^6 are coprime, (D^2+D^4) g0 + (1+D+D^2+D^3+D^4) g1 = 1 over GF(2), hence
+// u_t = c0_{t-2} ^ c0_{t-4} ^ c1_t ^ c1_{t-1} ^ c1_{t-2} ^ c1_{t-3} ^ c1_{t-4} — a lane per step, and is accepted only if re-encoding it gives back
+// every one of the 124 bits; one flipped decision anywhere and the trellis below runs as before.  tests/test_oracle_comm.py checks the claim
+// against the oracle's windowed decoder, tests/test_gpu_comm.py that both ways agree on clean and corrupted fields (JRC_EQ_SIG_FULL).
+__device__ __forceinline__ unsigned sig_viterbi_wave(const float2* Z, int ND, unsigned char* ring, int lane, bool full_only)
 {
     const unsigned long long w0 = __ballot(lane < ND && Z[min(lane, ND - 1)].x > 0);                 // constellation_bpsk::decision_maker: re > 0
     const unsigned long long w1 = __ballot(lane + 64 < ND && Z[min(lane + 64, ND - 1)].x > 0);
+    if (!full_only) {
+        auto cb = [&](int j) -> unsigned { return j < 0 ? 0u : (j < 64 ? (unsigned)((w0 >> j) & 1ull) : (unsigned)((w1 >> (j - 64)) & 1ull)); };
+        const int t = lane;
+        const unsigned u = t < 62 ? (cb(2 * t - 4) ^ cb(2 * t - 8) ^ cb(2 * t + 1) ^ cb(2 * t - 1) ^ cb(2 * t - 3) ^ cb(2 * t - 5) ^ cb(2 * t - 7)) : 0u;
+        const unsigned long long U = __ballot(u != 0);
+        auto ub = [&](int i) -> unsigned { return i < 0 ? 0u : (unsigned)((U >> i) & 1ull); };
+        const unsigned e0 = ub(t) ^ ub(t - 2) ^ ub(t - 3) ^ ub(t - 5) ^ ub(t - 6);                   // state & 0155
+        const unsigned e1 = ub(t) ^ ub(t - 1) ^ ub(t - 2) ^ ub(t - 3) ^ ub(t - 6);                   // state & 0117
+        const bool same = t >= 62 || (e0 == cb(2 * t) && e1 == cb(2 * t + 1));
+        if (__all(same)) return (unsigned)(U & 0xffffffull);
+    }
     for (int i = lane; i < 5 * 64; i += 64) ring[i] = 0;                                            // d_ppresult zeroed (:333-337)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -218,7 +240,9 @@ __device__ __forceinline__ unsigned sig_viterbi_wave(const float2* Z, int ND, un
     return sig;
 }
 
+#ifndef EQ_BATCH
 #define EQ_BATCH 64   // data symbols per three-phase pass of the equalizer
+#endif
 #ifndef EQ_PD
 #define EQ_PD 2       // input symbols in flight per lane in the equalisation phase (measured at config C once the loop had no branch around its loads: 1: 0.602-0.613 ms, 2: 0.593-0.599, 3: 0.596, 4: 0.602-0.65 with 31 spilled registers)
 #endif
@@ -337,7 +361,7 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
                         const float2* prow = d.pilot_sym + (size_t)((sy - 3 - NL) % d.n_pilot_rows) * NP;
                         const double k0 = 2 * M_PI * sy * ((N + d.cp) * 1.0 / N) * eps;
                         const int c = pc[kc];
-                        const float2 yk = c_mul(in[(size_t)(n_in + jc) * N + c], c_expj(k0 * (c - N / 2)));
+                        const float2 yk = c_mul(in[(size_t)(n_in + (d.exp == 1 ? 0 : jc)) * N + c], c_expj(k0 * (c - N / 2)));
                         const float2 e = c_mul(Hsel[c], prow[kc]);
                         float2 sum = make_float2(0.f, 0.f);
                         if (on) { const float2 pp = c_mul(yk, c_conj(e)); sum.x = sum.x + pp.x; sum.y = sum.y + pp.y; }
@@ -519,7 +543,7 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
             }
             __syncthreads();
             if (tid < 64) {   // the reference's windowed K=7 decoder over the ND hard decisions: one wavefront (above)
-                const unsigned sig_word = sig_viterbi_wave(Z, ND, reinterpret_cast<unsigned char*>(surv), tid);
+                const unsigned sig_word = sig_viterbi_wave(Z, ND, reinterpret_cast<unsigned char*>(surv), tid, d.sig_full != 0);
                 if (tid == 0) {
                     // parse :669-781
                     const int rate = (int)(sig_word & 0xfu), pt = (int)((sig_word >> 4) & 1u), len = (int)((sig_word >> 5) & 0xfffu);
@@ -781,6 +805,8 @@ extern "C" int jrc_equalizer_create(jrc_ctx* ctx, const jrc_eq_cfg* c, int n_str
     d.N = N; d.cp = c->cp_len; d.ND = ND; d.NP = NP; d.NAct = (int)ac.size(); d.NL = c->n_mimo_ltf; d.T = T;
     d.mapped_cols = c->mapped_cols; d.n_pilot_rows = c->n_pilot_rows; d.estimator = c->estimator;
     d.freq = c->freq; d.bw = c->bw;
+    d.sig_full = ctx->tune.eq_sig_full ? 1 : 0;
+    d.exp = getenv("JRC_EQ_EXP") ? atoi(getenv("JRC_EQ_EXP")) : 0;
     d.data_c = (const int*)tb; d.pilot_c = d.data_c + ND; d.active_c = d.pilot_c + NP;
     d.pilot_sym = (const float2*)(tb + off_ps); d.ltf = (const float2*)(tb + off_ps + b_ps);
     d.mapped = (const float2*)(tb + off_ps + b_ps + b_ltf);

@@ -94,6 +94,7 @@ extern "C" int jrc_create(int device, jrc_ctx** out)
     if (const char* e = getenv("JRC_RD_CHUNK_MB")) ctx->tune.rd_chunk_mb = atoi(e);
     if (const char* e = getenv("JRC_RA_OFFERED_TBPS")) ctx->tune.ra_offered_tbps = atof(e);
     if (const char* e = getenv("JRC_DEMOD_SPR")) ctx->tune.demod_spr = atoi(e);
+    ctx->tune.eq_sig_full = getenv("JRC_EQ_SIG_FULL") != nullptr;
     if (const char* e = getenv("JRC_EQ_WPE")) ctx->tune.eq_wpe = atoi(e);
     if (const char* e = getenv("JRC_EQ_THREADS")) ctx->tune.eq_threads = atoi(e);
     // the timing experiments leave work out: say so where nobody can miss it

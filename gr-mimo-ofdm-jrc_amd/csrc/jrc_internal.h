@@ -53,6 +53,7 @@ struct jrc_ctx {
         int detect_exp = 0;          // JRC_DETECT_EXP: detect-only kernel experiments (chain.hip, MODE 1). 8: no pruning; 16: sum bound only. TIMING ONLY, WRONG RESULTS: 1: no angle stage; 2: no range-profile stores; 32: sampled rows never computed
         double ra_offered_tbps = 0;  // JRC_RA_OFFERED_TBPS: offered store rate the pacing word is derived from (0 = the kernel's measured optimum)
         int demod_spr = 0;           // JRC_DEMOD_SPR: symbols per round (2 or 4) of the A6+A7+A1 kernel (0 = by fft_len)
+        bool eq_sig_full = false;    // JRC_EQ_SIG_FULL: the equalizer's SIG decoder always runs its trellis (comm.hip sig_viterbi_wave: no codeword shortcut)
         int eq_wpe = 0;              // JRC_EQ_WPE: waves per SIMD the equalizer kernel is compiled for (2, 4, 6, 8; 0 = by geometry)
         int eq_threads = 0;          // JRC_EQ_THREADS: equalizer workgroup size (64, 128, 256; 0 = by launch size, -1 = one lane per subcarrier)
     } tune;

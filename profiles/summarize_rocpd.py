@@ -14,8 +14,8 @@ def main():
         out.append(",".join('"%s"' % x if isinstance(x, str) else str(x) for x in r))
     for db in sys.argv[4:]:
         cur = sqlite3.connect(db).cursor()
-        out += ["", "# PMC pass %s (separate run; FETCH_SIZE/WRITE_SIZE in KiB per dispatch; on gfx950 FETCH_SIZE "
-                "under-reports wide coalesced reads by 2x -> double it)" % db.split("/")[-2],
+        out += ["", "# PMC pass %s (separate run; FETCH_SIZE/WRITE_SIZE in KiB per dispatch; on gfx950 bytes = FETCH_SIZE x 1024 x 2.0 "
+                "and WRITE_SIZE x 1024 x 1.0 for 4 / 8 / 16 B per lane alike: profiles/r04_pmc_calibration.json, tools/pmc_calib.sh)" % db.split("/")[-2],
                 "kernel,counter,dispatches,avg,min,max"]
         q = ("select kernel_name, counter_name, count(*), avg(value), min(value), max(value) "
              "from counters_collection group by kernel_name, counter_name")

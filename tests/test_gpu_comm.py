@@ -358,3 +358,32 @@ def test_sig_field_with_bit_errors_resolves_as_the_windowed_decoder_does(jrc, ct
         same_events(rg["events"], ro["events"])
         if ro["out"].size:
             assert rel_err(rg["out"], ro["out"]) < TOL
+
+
+@pytest.mark.parametrize("n_err", [0, 1, 4])
+def test_sig_codeword_shortcut_agrees_with_the_trellis(jrc, ofdm64, n_err, monkeypatch):
+    """round 4: a SIG word that is a codeword skips the trellis (comm.hip sig_viterbi_wave); JRC_EQ_SIG_FULL=1 always runs it.  Same frames,
+    both ways: events, consumed counts and equalised symbols byte for byte — clean fields take the shortcut, corrupted ones cannot."""
+    from test_second_source import sig_frame
+    outs = []
+    for full in (False, True):
+        if full:
+            monkeypatch.setenv("JRC_EQ_SIG_FULL", "1")
+        c = jrc.Context(0)
+        rng = np.random.default_rng(90 + n_err)
+        res = []
+        for trial in range(10):
+            mcs, ptype, length = int(rng.integers(0, 6)), int(rng.integers(1, 3)), int(rng.integers(1, 300))
+            flips = rng.choice(48, n_err, replace=False)
+            y = sig_frame(ofdm64, mcs, ptype, length, flips, rng)
+            o = ofdm64
+            ge = jrc.mimo_ofdm_equalizer(LS, 24e9, 125e6, 64, 16, o["data_subcarriers"], o["pilot_subcarriers"], o["pilot_symbols"], o["ltf_64"],
+                                         o["ltf_mapped_sc__ss_sym"], 4, ctx=c)
+            r = ge.general_work(y, [(0, 0.0)])
+            res.append((r["consumed"], r["out"].tobytes(), [(e["kind"], e["offset"], e.get("data_bytes"), e.get("mcs"), e.get("packet_type")) for e in r["events"]]))
+            if n_err == 0:
+                assert r["events"] and r["events"][0]["data_bytes"] == length and r["events"][0]["mcs"] == mcs
+            ge.close()
+        outs.append(res)
+        c.close()
+    assert outs[0] == outs[1]

@@ -211,3 +211,46 @@ def test_equalizer_skips_without_frame_start_and_after_frame_end(ofdm64):
     r = eq.general_work(y2, [(0, 0.0)])
     assert r["consumed"] == len(y2) and r["out"].shape == (ns, 48)
     assert rel_err(r["out"], s.reshape(ns, 48)) < 1e-5
+
+
+def test_windowed_decoder_returns_the_input_of_any_clean_codeword():
+    """the claim behind the equalizer's SIG shortcut (comm.hip sig_viterbi_wave): when the 124 hard decisions the reference's windowed
+    decoder reads (zeros beyond the symbol's cells) are the K=7 encoder's output for some input sequence, the decoder returns that
+    sequence — and the sequence is u_t = c0[t-2] ^ c0[t-4] ^ c1[t] ^ c1[t-1] ^ c1[t-2] ^ c1[t-3] ^ c1[t-4]
+    ((D^2 + D^4) g0 + (1 + D + D^2 + D^3 + D^4) g1 = 1 over GF(2)).  Clean fields, fields with a non-zero tail (not flushed: rejected at
+    48 cells, a codeword at 224), and single flipped decisions (always rejected: the shortcut never fires on a word that is not a codeword)."""
+    def encode(u, nsteps):
+        st, out = 0, []
+        for i in range(nsteps):
+            st = ((st << 1) & 0x7e) | (int(u[i]) if i < len(u) else 0)
+            out += [bin(st & 0o155).count("1") & 1, bin(st & 0o117).count("1") & 1]
+        return np.array(out, np.uint8)
+
+    def shortcut(word124):
+        c0, c1 = word124[0::2].astype(int), word124[1::2].astype(int)
+        g = lambda a, i: a[i] if i >= 0 else 0
+        u = [g(c0, t - 2) ^ g(c0, t - 4) ^ g(c1, t) ^ g(c1, t - 1) ^ g(c1, t - 2) ^ g(c1, t - 3) ^ g(c1, t - 4) for t in range(62)]
+        return u if np.array_equal(encode(u, 62), word124) else None
+
+    rng = np.random.default_rng(0)
+    fired = rejected = 0
+    for ND in (48, 112, 224):
+        for trial in range(400):
+            u = rng.integers(0, 2, 24)
+            if trial % 2 == 0:
+                u[18:] = 0                                        # a proper header: tail zeros
+            cells = encode(u, ND // 2)                            # generate_signal_field: the encoder runs over all ND cells (:1040-1054)
+            word = np.zeros(124, np.uint8)
+            word[:min(ND, 124)] = cells[:124]
+            got = shortcut(word)
+            dec = oracle.viterbi_windowed(0, 1, ND, 24, cells)[:24]
+            if got is not None:
+                fired += 1
+                assert np.array_equal(dec, np.array(got[:24], np.uint8)) and np.array_equal(dec, u)
+            else:
+                rejected += 1
+                assert ND == 48 and u[18:].any()                  # only an unflushed tail cut off by the symbol's end
+            k = int(rng.integers(0, min(ND, 124)))
+            word[k] ^= 1
+            assert shortcut(word) is None                         # distance 1 from a codeword is not a codeword (d_free = 10)
+    assert fired > 1000 and rejected > 50

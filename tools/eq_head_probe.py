@@ -6,7 +6,7 @@ import jrc_amd
 from jrc_amd import synth
 import bench_extra as be
 
-N, cp, T, S = 256, 64, 4, 8
+N, cp, T, S = 256, 64, 4, int(os.environ.get("EQ_HEAD_S", "8"))
 rng = np.random.default_rng(0)
 guard = 16
 act = [c for c in range(-N // 2 + guard, N // 2 - guard + 1) if c != 0]
@@ -28,7 +28,7 @@ streams = 8192
 x = np.stack([y] * streams)
 eq = jrc_amd.mimo_ofdm_equalizer(jrc_amd.LS, 24e9, 125e6, N, cp, data, pilots, pil, ltf, mapped, T, n_streams=streams, ctx=ctx)
 d_ph = torch.zeros(streams, dtype=torch.float64, device="cuda:0")
-for k in (1, 2, 3, 4, 7, 8, 9, 15):
+for k in [int(v) for v in os.environ.get("EQ_HEAD_KS", "1,2,3,4,7,8,9,15").split(",")]:
     d_in = torch.from_numpy(np.ascontiguousarray(x[:, :k]).view(np.float32).reshape(streams, k, N, 2)).to("cuda:0")
     t = be.timed(lambda: eq.frames_dev(d_in, d_ph, k, S), steps=20, warm=3)
     print("symbols in = %2d: %.4f ms" % (k, t * 1e3), flush=True)
