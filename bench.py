@@ -353,6 +353,23 @@ def roofline_of(chain, kt, cfg, sc, Ir, Ia, F):
     return r
 
 
+def chain_roofline(sc, Ir, Ia, F, ms_step, kt):
+    """the whole step against the HBM roofline (SURVEY.md §8(d) 'full radar chain A1-A5 with map written': inputs read once, H written and
+    read once is NOT compulsory, map written once), next to the dominant kernel's own figure above; and A1 alone on its read stream"""
+    P, NR, NA = sc.T * sc.R, sc.N * Ir, sc.T * sc.R * Ia
+    per_frame = (sc.T + sc.R) * sc.S * sc.N * 8 + P * sc.N * 8 + NR * NA * 8            # B: 5,275,648  D: 25,296,896
+    a1_bytes = (sc.T + sc.R) * sc.S * sc.N * 8 + P * sc.N * 8                            # inputs read, H written
+    out = {"compulsory_bytes_per_frame": per_frame, "compulsory_bytes_per_step": per_frame * F,
+           "achieved": per_frame * F / (ms_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": per_frame * F / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms_per_step": ms_step,
+           "kernels_sum_ms": kt["radar_chanest"] + kt["range_angle_fused"] + kt["ra_finalize"]}
+    if kt["radar_chanest"] > 0:
+        g = a1_bytes * F / (kt["radar_chanest"] * 1e-3) / 1e9
+        out["a1"] = {"kernel": "radar_chanest_x2_kernel", "bound": "hbm (read)", "algorithmic_bytes_per_step": a1_bytes * F, "avg_ms": kt["radar_chanest"],
+                     "achieved": g, "frac": g / HBM_PEAK_GBS}
+    return out
+
+
 def config_d_roofline(ctx, steps=30, warm=8):
     """Metric 2's home configuration (4x4, 1024 subcarriers, 128 symbols, 8 targets): the same chain on a resident batch of 256 frames"""
     import torch
@@ -427,6 +444,148 @@ def host_fed_rate(ctx, cfg, sc, axes, seconds=1.5):
     return out
 
 
+def host_fed_tx_resident_rate(ctx, cfg, sc, axes, seconds=1.5):
+    """the same pipeline when the T reference ports repeat from frame to frame (the reference flowgraph's radar block is pointed at the MIMO-LTF
+    rows, …radar_sim.grc:1292-1295): they are handed over once (jrc_chain_feed_set_tx), every batch uploads its receive ports only
+    (jrc_chain_feed_submit_rx) and leaves out the N_pre preamble symbols mimo_ofdm_radar never reads.  Results checked against a full upload."""
+    import jrc_amd
+    from jrc_amd import synth
+    rb, ab, ndr, nda = axes
+    fps = 64 if cfg != "D" else 16
+    slots = 3
+    src = synth.make_frames(sc, 8)
+    src = np.concatenate([src] * (fps // 8))[:fps].copy()
+    src[:, :sc.T] = src[0, :sc.T]
+    used = np.ascontiguousarray(src[:, :, sc.Npre:])                          # the N_sym symbols the radar block reads
+    feed = jrc_amd.ChainFeed(sc.N, sc.T, sc.R, sc.S, 0, 8, 16, rb, ab, ndr, nda, 15.0, 0.0, ctx=ctx, n_slots=slots, frames_per_slot=fps)
+    feed.submit(used)
+    want, _ = feed.collect()
+    feed.set_tx(used[0, :sc.T])
+    for _ in range(slots):
+        feed.acquire()[:, sc.T:] = used[:, sc.T:]
+        feed.submit(None, fps, rx_only=True)
+    got = []
+    for _ in range(slots):
+        got = feed.collect()[0]
+    same = all((a.peak_range_idx, a.peak_angle_idx, a.snr_est, a.noise_power) == (b.peak_range_idx, b.peak_angle_idx, b.snr_est, b.noise_power)
+               for a, b in zip(got, want))
+    done = 0
+    t0 = time.perf_counter()
+    while True:
+        while feed.pending() < slots:
+            feed.acquire()
+            feed.submit(None, fps, rx_only=True)
+        done += len(feed.collect()[0])
+        if time.perf_counter() - t0 > seconds:
+            break
+    while feed.pending():
+        done += len(feed.collect()[0])
+    el = time.perf_counter() - t0
+    rx_bytes = sc.R * sc.S * sc.N * 8
+    out = {"frames_per_s": done / el, "host_GBps": done * rx_bytes / el / 1e9, "bytes_per_frame_over_pcie": rx_bytes,
+           "bytes_per_frame_full_upload": (sc.T + sc.R) * (sc.Npre + sc.S) * sc.N * 8, "results_equal_full_upload": bool(same),
+           "frames_per_batch": fps, "batches_in_flight": slots,
+           "what": "config %s with the TX reference ports resident on the device (jrc_chain_feed_set_tx / _submit_rx): receive ports of the "
+                   "N_sym used symbols in pinned host memory -> H2D -> chain -> results D2H" % cfg}
+    feed.close()
+    return out
+
+
+def flowgraph_shape_host_fed(ctx, seconds=1.0):
+    """the only shape the reference's flowgraphs run (…radar_sim.grc: 4 TX x 2 RX, fft_len 64, N_pre 5, N_sym 4, interp 8 / 16): 27 KB per
+    packet, a latency regime.  Through jrc_chain_feed_* — one packet per batch for latency (p50 / p99 of submit -> collect with an idle
+    pipeline), 16 per batch and three batches in flight for throughput — through the radar_chain block (host/jrc_blocks.cc, one scheduler turn
+    of 64 packets at a time), and the CPU port (the oracle's A1..A5 on one core) on the same packets."""
+    import ctypes as C
+    import jrc_amd
+    from jrc_amd import synth
+    sc = synth.Scenario(64, 4, 2, 4, targets=[(10.0, 20.0, 0.0, 100.0)])
+    Ir, Ia, P = 8, 16, 8
+    rb, ab = jrc_amd.radar_axes(sc.N, sc.fs, Ir, P, Ia)
+    ndr, nda = 2 * 3e8 / (2 * sc.fs), 2 * float(np.rad2deg(np.arcsin(2 / P)))
+    frames = synth.make_frames(sc, 64)
+    frames[:, :sc.T] = frames[0, :sc.T]                                       # the MIMO-LTF rows: the same in every packet
+    n_items = sc.Npre + sc.S
+    out = {"shape": "4 TX x 2 RX, fft_len 64, N_pre 5, N_sym 4, interp 8 x 16 (512 x 128 map), %d B per packet on the block's ports" % (6 * n_items * 64 * 8)}
+    # (1) latency, idle pipeline, one packet per batch, map not stored (what the radar_chain block asks for)
+    feed = jrc_amd.ChainFeed(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb, ab, ndr, nda, 15.0, 0.0, ctx=ctx, n_slots=2, frames_per_slot=1, graph=True)
+    feed.set_write_map(False)
+    lat = []
+    for i in range(600):
+        st = feed.acquire()
+        st[0] = frames[i % 64]
+        t0 = time.perf_counter()
+        feed.submit(None, 1)
+        feed.collect()
+        lat.append(time.perf_counter() - t0)
+    lat = np.sort(np.array(lat[100:])) * 1e6
+    out["feed_latency_us_one_packet"] = {"p50": float(lat[len(lat) // 2]), "p99": float(lat[int(len(lat) * 0.99)]), "min": float(lat[0]),
+                                         "what": "submit -> collect of a single packet, pinned staging, hipGraph replay, idle pipeline"}
+    feed.close()
+    # (2) throughput, 16 packets per batch, three in flight
+    feed = jrc_amd.ChainFeed(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb, ab, ndr, nda, 15.0, 0.0, ctx=ctx, n_slots=3, frames_per_slot=16)
+    feed.set_write_map(False)
+    done, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        while feed.pending() < 3:
+            feed.acquire()[:] = frames[:16]
+            feed.submit(None, 16)
+        done += len(feed.collect()[0])
+    while feed.pending():
+        done += len(feed.collect()[0])
+    out["feed_frames_per_s"] = done / (time.perf_counter() - t0)
+    feed.close()
+    # (3) the radar_chain block: 64 packets per scheduler turn on its T+R ports, tags on ports 0 and T
+    lib = os.path.join(ROOT, "gr-mimo-ofdm-jrc_amd", "lib", "libjrc_blocks.so")
+    if os.path.exists(lib):
+        L = C.CDLL(lib)
+        fp, vp = C.POINTER(C.c_float), C.c_void_p
+        L.jrcb_make_radar_chain.restype = vp
+        L.jrcb_make_radar_chain.argtypes = [C.c_int] * 8 + [fp, C.c_int, fp, C.c_int] + [C.c_float] * 4 + [C.c_char_p, C.c_int, C.c_int, C.c_int]
+        L.jrcb_add_in_tag.argtypes = [vp, C.c_int, C.c_uint64, C.c_char_p, C.c_int, C.c_long, C.c_double]
+        L.jrcb_run.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(vp), C.c_int, C.POINTER(vp)]
+        L.jrcb_call_setter.argtypes = [vp, C.c_char_p, C.c_double]
+        L.jrcb_destroy.argtypes = [vp]
+        rbf, abf = np.ascontiguousarray(rb, np.float32), np.ascontiguousarray(ab, np.float32)
+        h = L.jrcb_make_radar_chain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, 0, rbf.ctypes.data_as(fp), len(rbf), abf.ctypes.data_as(fp), len(abf),
+                                    ndr, nda, 15.0, 0.0, b"", 0, 16, 3)
+        if h:
+            ports = [np.ascontiguousarray(np.concatenate([frames[f, p] for f in range(64)])) for p in range(sc.T + sc.R)]
+            nin = (C.c_int * 6)(*[64 * n_items] * 6)
+            pin = (vp * 6)(*[a.ctypes.data for a in ports])
+            pout = (vp * 1)()
+            turns, pos, t0 = 0, 0, None
+            while True:
+                for k in range(64):
+                    L.jrcb_add_in_tag(h, 0, pos + k * n_items, b"packet_len", 0, n_items, 0.0)
+                    L.jrcb_add_in_tag(h, sc.T, pos + k * n_items, b"packet_len", 0, n_items, 0.0)
+                if L.jrcb_run(h, 0, nin, 6, pin, 0, pout) < 0:
+                    break
+                pos += 64 * n_items
+                turns += 1
+                if turns == 20:
+                    t0, t_turns = time.perf_counter(), turns
+                if t0 is not None and time.perf_counter() - t0 > seconds:
+                    break
+            L.jrcb_call_setter(h, b"flush", 0.0)
+            el = time.perf_counter() - t0
+            out["radar_chain_block_frames_per_s"] = (turns - t_turns) * 64 / el
+            out["radar_chain_block_rx_only_batches"] = int(L.jrcb_call_setter(h, b"rx_only_batches", 0.0))
+            out["radar_chain_block_frames_done"] = int(L.jrcb_call_setter(h, b"frames_done", 0.0))
+            L.jrcb_destroy(h)
+    # (4) the CPU port on the same packets, one core
+    import oracle
+    n_cpu, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < min(seconds, 1.0):
+        f = frames[n_cpu % 64]
+        rad = oracle.Radar(sc.N, sc.T, sc.R, sc.S, sc.Npre, interp_factor=Ir)
+        m = rad.chain([f[t] for t in range(sc.T)], [f[sc.T + r] for r in range(sc.R)], Ia)
+        oracle.ra_estimate(m, rb, ab, ndr, nda, 15.0, 0.0)
+        n_cpu += 1
+    out["cpu_port_frames_per_s_one_core"] = n_cpu / (time.perf_counter() - t0)
+    return out
+
+
 def secondary_figures(cfg, ctx, sc, axes):
     """Metric 2 on its home config D, the PCIe-inclusive rate, the same chain with the RX OFDM demod in front (time-domain RX in),
     and the comm-side config C — measured after the timed region (their own batches, a few seconds in total); never part of `value`"""
@@ -442,6 +601,8 @@ def secondary_figures(cfg, ctx, sc, axes):
     if cfg != "D":
         leg("roofline_config_d", lambda: config_d_roofline(ctx))
     leg("host_fed_chain", lambda: host_fed_rate(ctx, cfg, sc, axes))
+    leg("host_fed_chain_tx_resident", lambda: host_fed_tx_resident_rate(ctx, cfg, sc, axes))
+    leg("host_fed_reference_flowgraph_shape", lambda: flowgraph_shape_host_fed(ctx))
     try:
         import bench_extra as be
     except Exception as ex:
@@ -591,6 +752,49 @@ def main():
     kt = chain.get_timing()
     res = chain.results(bufs, F)
 
+    # The same steps with A5 finished INSIDE the timed region (a frame counts "through A5"): the records of step n are
+    # copied on the chain's copy stream while step n+1 runs (two record buffers alternate), and the host completes snr_est / published
+    # of step n-1 (one log10f per frame, the reference's own libm call) — every step's records are on the host, complete, when the
+    # window closes.  Timed without the per-kernel events.
+    with_results = None
+    if world == 1 and not (do_gather or k_maps):
+        chain.set_timing(False)
+        rbuf = [bufs["results"], torch.empty_like(bufs["results"])]
+        views = [dict(bufs, results=rbuf[0]), dict(bufs, results=rbuf[1])]
+        host = [(jrc_amd.RaResult * F)() for _ in range(2)]              # the host's record arrays, alternating like the device's
+        counts = []
+
+        def step_r(i):
+            chain.run(views[i & 1], F)
+            chain.results_begin(rbuf[i & 1], F)
+            if i >= 1:
+                counts.append(chain.results_end(into=host[(i - 1) & 1]))
+
+        for i in range(4):
+            step_r(i)
+        chain.results_end(into=host[1])
+        ctx.sync()
+        torch.cuda.synchronize()
+        wr = []
+        for w in range(max(1, a.windows)):
+            counts.clear()
+            t0 = time.perf_counter()
+            for i in range(a.steps):
+                step_r(i)
+            counts.append(chain.results_end(into=host[(a.steps - 1) & 1]))   # the last step's records: the window ends with everything on the host
+            wr.append(time.perf_counter() - t0)
+        last = host[(a.steps - 1) & 1]
+        same = all((r.peak_range_idx, r.peak_angle_idx, r.snr_est, r.published, r.noise_power) ==
+                   (q.peak_range_idx, q.peak_angle_idx, q.snr_est, q.published, q.noise_power) for r, q in zip(last, res))
+        wr_ms = sorted(1e3 * w / a.steps for w in wr)
+        with_results = {"what": "the same %d steps with every step's records copied to the host and A5's snr_est / published completed there "
+                                "INSIDE the timed region (copy of step n beside the kernels of step n+1; jrc_chain_fetch_results_begin / _end)" % a.steps,
+                        "frames_per_s": F * a.steps / wr[0], "ms_per_step": 1e3 * wr[0] / a.steps, "ms_per_step_median": wr_ms[len(wr_ms) // 2],
+                        "ms_per_step_min": wr_ms[0], "ms_per_step_max": wr_ms[-1],
+                        "records_complete_on_host": len(counts) == a.steps and all(c == F for c in counts),
+                        "records_equal_headline_run": bool(same)}
+        chain.set_timing(True)
+
     ranks = gather_identities(dist, world, rank_identity(torch, rank, local_rank, torch.cuda.current_device(), windows, a.steps))
     windows = shard.max_over_ranks_vec(windows, coll_dev)
     elapsed = windows[0]
@@ -632,10 +836,12 @@ def main():
                        "launcher": "self-launched children" if os.environ.get("JRC_BENCH_CHILD") else ("torch.distributed.run" if world > 1 else "direct")},
             "windows": {"n": len(per), "steps_each": a.steps, "ms_per_step_median": per[len(per) // 2], "ms_per_step_min": per[0],
                         "ms_per_step_max": per[-1], "note": "`value` / `ms_per_step` are window 0 (the contract's timed region); max over ranks per window"},
-            "roofline": roofline_of(chain, kt, a.config, sc, Ir, Ia, F),
+            "roofline": dict(roofline_of(chain, kt, a.config, sc, Ir, Ia, F), chain=chain_roofline(sc, Ir, Ia, F, ms_step, kt)),
             "kernels_ms": {k: kt[k] for k in ("radar_chanest", "range_angle_fused", "ra_finalize")},
             "host_epilogue": "snr_est = 10 log10(peak/noise) and the publish decision of A5 (one log10f per frame) are finished on the host in "
-                             "jrc_chain_fetch_results, after the timed region; everything else of A1..A5 is inside it",
+                             "jrc_chain_fetch_results, after the timed region of `value`; `with_results_on_host` times the same steps with that "
+                             "inside the region",
+            "with_results_on_host": with_results,
             "check": dict(check or {}, range_m=res[0].range_val, angle_deg=res[0].angle_val, snr_db=res[0].snr_est),
             "device": ctx.device_name(),
             # who took part: one entry per rank with the physical device it ran on and ITS OWN clock over the same windows

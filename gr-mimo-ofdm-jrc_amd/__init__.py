@@ -123,6 +123,8 @@ def load(build_if_missing=False):
         getattr(L, fn).argtypes = [_vp]
     L.jrc_chain_run_dev.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp]
     L.jrc_chain_fetch_results.argtypes = [_vp, C.c_int, _vp, C.POINTER(RaResult), _vp]
+    L.jrc_chain_fetch_results_begin.argtypes = [_vp, C.c_int, _vp, _vp]
+    L.jrc_chain_fetch_results_end.argtypes = [_vp, C.POINTER(RaResult), C.POINTER(C.c_int)]
     L.jrc_range_doppler_dev.argtypes = [_vp, C.POINTER(ChainCfg), C.c_int, C.c_int, _vp, _vp, _vp, _vp]
     L.jrc_chain_set_timing.argtypes = [_vp, C.c_int]
     L.jrc_chain_launches_per_run.argtypes = [_vp, C.c_int]
@@ -134,6 +136,9 @@ def load(build_if_missing=False):
         getattr(L, fn).restype = C.c_size_t
     L.jrc_chain_feed_acquire.argtypes = [_vp, C.POINTER(_vp)]
     L.jrc_chain_feed_submit.argtypes = [_vp, _vp, C.c_int]
+    L.jrc_chain_feed_submit_rx.argtypes = [_vp, _vp, C.c_int]
+    L.jrc_chain_feed_set_tx.argtypes = [_vp, _vp]
+    L.jrc_chain_feed_poll.argtypes = [_vp]
     L.jrc_chain_feed_collect.argtypes = [_vp, C.POINTER(RaResult), _vp, C.POINTER(C.c_int)]
     L.jrc_chain_feed_pending.argtypes = [_vp]
     L.jrc_chain_feed_stats.argtypes = [_vp, C.POINTER(C.c_long), C.POINTER(C.c_long)]
@@ -509,6 +514,19 @@ class RadarChain:
         self.ctx.check(self.ctx.lib.jrc_chain_fetch_results(self.h, n_frames, bufs["results"].data_ptr(), arr, stream))
         return list(arr)
 
+    def results_begin(self, d_results, n_frames, stream=None):
+        """starts the copy of a run's records behind the work queued so far, without blocking the stream (at most two in flight);
+        d_results: torch uint8 tensor [n_frames, sizeof(RaResult)] that stays untouched until the matching results_end()"""
+        self.ctx.check(self.ctx.lib.jrc_chain_fetch_results_begin(self.h, n_frames, d_results.data_ptr(), stream))
+
+    def results_end(self, into=None):
+        """the oldest copy begun: waits for it and returns the completed records (a list; with `into` = a (RaResult * max_frames)() array of
+        the caller's, the records are left there and their count is returned: no Python object per record on a hot path)"""
+        arr = into if into is not None else (RaResult * self.max_frames)()
+        n = C.c_int(0)
+        self.ctx.check(self.ctx.lib.jrc_chain_fetch_results_end(self.h, arr, C.byref(n)))
+        return n.value if into is not None else list(arr[:n.value])
+
     def range_doppler(self, bufs, n_frames, interp_doppler=1, stream=None):
         """row D: [n_frames, P, N*Ir, S*Id] complex range-Doppler map of the frames in bufs["frames"] (torch, on device)"""
         import torch
@@ -615,16 +633,32 @@ class ChainFeed:
         buf = (C.c_float * (2 * n)).from_address(p.value)
         return np.frombuffer(buf, dtype=np.complex64).reshape((self.frames_per_slot,) + self.frame_shape())
 
-    def submit(self, frames=None, n_frames=None):
-        """frames: complex64 [n, T+R, n_items, fft_len] in host memory, or None after acquire() + in-place fill"""
+    def submit(self, frames=None, n_frames=None, rx_only=False):
+        """frames: complex64 [n, T+R, n_items, fft_len] in host memory, or None after acquire() + in-place fill.
+        rx_only: the frames' TX ports equal the rows given to set_tx(): only their receive ports are uploaded (jrc_chain_feed_submit_rx)"""
+        fn = self.lib.jrc_chain_feed_submit_rx if rx_only else self.lib.jrc_chain_feed_submit
         if frames is None:
             n = self.frames_per_slot if n_frames is None else n_frames
-            self._check(self.lib.jrc_chain_feed_submit(self.h, None, n))
+            self._check(fn(self.h, None, n))
             return
         fr = np.ascontiguousarray(frames, np.complex64)
         n = fr.shape[0] if n_frames is None else n_frames
         assert fr.size * 8 >= n * self.frame_bytes
-        self._check(self.lib.jrc_chain_feed_submit(self.h, _ptr(fr), n))
+        self._check(fn(self.h, _ptr(fr), n))
+
+    def set_tx(self, tx):
+        """tx: complex64 [T, n_items, fft_len] = the reference ports every following rx_only frame shares (None: off)"""
+        if tx is None:
+            self._check(self.lib.jrc_chain_feed_set_tx(self.h, None))
+            return
+        t = np.ascontiguousarray(tx, np.complex64)
+        c = self.cfg
+        assert t.shape == (c.N_tx, c.n_items, c.fft_len)
+        self._check(self.lib.jrc_chain_feed_set_tx(self.h, _ptr(t)))
+
+    def poll(self):
+        """True when collect() would not block"""
+        return self.lib.jrc_chain_feed_poll(self.h) == 1
 
     def submit_many(self, batches):
         """batches: list of complex64 arrays [n_k, T+R, n_items, fft_len]; one per free slot at most; staged and enqueued by the per-device

@@ -782,6 +782,11 @@ struct jrc_chain {
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t ev_a1[kMaxSlices] = {};
     hipEvent_t ev_side[2] = {nullptr, nullptr};
+    // results in flight (jrc_chain_fetch_results_begin / _end): a copy stream, two pinned buffers, FIFO of at most two
+    hipStream_t copy_stream = nullptr;
+    jrc_ra_result* h_ring[2] = {nullptr, nullptr};
+    hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
+    int ring_n[2] = {0, 0}, ring_head = 0, ring_count = 0;
 };
 
 // ---- background state of one radar stream (lib/mimo_ofdm_radar_impl.cc:276-300) on the device --------------------------------
@@ -1115,6 +1120,12 @@ extern "C" void jrc_chain_destroy(jrc_chain* ch)
     (void)hipDeviceSynchronize();
     for (auto& e : ch->ev) (void)hipEventDestroy(e);
     for (auto& e : ch->ev_a1) if (e) (void)hipEventDestroy(e);
+    for (int k = 0; k < 2; k++) {
+        if (ch->ev_ready[k]) (void)hipEventDestroy(ch->ev_ready[k]);
+        if (ch->ev_copied[k]) (void)hipEventDestroy(ch->ev_copied[k]);
+        if (ch->h_ring[k]) (void)hipHostFree(ch->h_ring[k]);
+    }
+    if (ch->copy_stream) (void)hipStreamDestroy(ch->copy_stream);
     for (int k = 0; k < 2; k++) {
         if (ch->ev_side[k]) (void)hipEventDestroy(ch->ev_side[k]);
         if (ch->side[k]) (void)hipStreamDestroy(ch->side[k]);
@@ -1568,6 +1579,51 @@ extern "C" int jrc_chain_fetch_results(jrc_chain* ch, int n_frames, const jrc_ra
         h_results[i] = ch->h_pinned[i];
         ra_finish_host(&h_results[i], ch->cfg.snr_threshold, ch->cfg.power_threshold);
     }
+    return JRC_OK;
+}
+
+extern "C" int jrc_chain_fetch_results_begin(jrc_chain* ch, int n_frames, const jrc_ra_result* d_results, void* stream)
+{
+    if (!ch || !d_results) return JRC_ERR_INVALID_ARG;
+    jrc_ctx* ctx = ch->ctx;
+    if (n_frames <= 0 || n_frames > ch->max_frames) return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_fetch_results_begin: bad n_frames");
+    if (ch->ring_count == 2) return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_fetch_results_begin: two copies already in flight (call _end first)");
+    JRC_BIND(ctx);
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    if (!ch->copy_stream) {
+        JRC_HIP(ctx, hipStreamCreateWithFlags(&ch->copy_stream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; k++) {
+            JRC_HIP(ctx, hipHostMalloc((void**)&ch->h_ring[k], sizeof(jrc_ra_result) * (size_t)ch->max_frames, hipHostMallocDefault));
+            JRC_HIP(ctx, hipEventCreateWithFlags(&ch->ev_ready[k], hipEventDisableTiming));
+            JRC_HIP(ctx, hipEventCreateWithFlags(&ch->ev_copied[k], hipEventDisableTiming));
+        }
+    }
+    const int slot = (ch->ring_head + ch->ring_count) & 1;
+    JRC_HIP(ctx, hipEventRecord(ch->ev_ready[slot], s));
+    JRC_HIP(ctx, hipStreamWaitEvent(ch->copy_stream, ch->ev_ready[slot], 0));
+    JRC_HIP(ctx, hipMemcpyAsync(ch->h_ring[slot], d_results, sizeof(jrc_ra_result) * (size_t)n_frames, hipMemcpyDeviceToHost, ch->copy_stream));
+    JRC_HIP(ctx, hipEventRecord(ch->ev_copied[slot], ch->copy_stream));
+    ch->ring_n[slot] = n_frames;
+    ch->ring_count++;
+    return JRC_OK;
+}
+
+extern "C" int jrc_chain_fetch_results_end(jrc_chain* ch, jrc_ra_result* h_results, int* n_frames)
+{
+    if (!ch || !h_results) return JRC_ERR_INVALID_ARG;
+    jrc_ctx* ctx = ch->ctx;
+    if (ch->ring_count == 0) return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_fetch_results_end: no copy in flight");
+    JRC_BIND(ctx);
+    const int slot = ch->ring_head;
+    JRC_HIP(ctx, hipEventSynchronize(ch->ev_copied[slot]));
+    const int n = ch->ring_n[slot];
+    for (int i = 0; i < n; i++) {
+        h_results[i] = ch->h_ring[slot][i];
+        ra_finish_host(&h_results[i], ch->cfg.snr_threshold, ch->cfg.power_threshold);
+    }
+    if (n_frames) *n_frames = n;
+    ch->ring_head ^= 1;
+    ch->ring_count--;
     return JRC_OK;
 }
 

@@ -46,6 +46,8 @@ struct feed_slot {
     bool warm = false;                   // one direct pass done (tables cached, nothing left to allocate inside a capture)
     int n_frames = 0;                    // frames of the batch in flight
     int state = 0;                       // 0 free, 1 acquired, 2 in flight
+    float2* d_tx = nullptr;              // resident TX reference ports [T][n_items][N] (jrc_chain_feed_set_tx)
+    bool tx_in_frames = false;           // every frame of d_frames holds the resident TX ports (nothing overwrote them since the broadcast)
 };
 
 struct jrc_chain_feed {
@@ -70,6 +72,8 @@ struct jrc_chain_feed {
     };
     std::vector<worker*> workers;
     int n_devices = 1;
+    bool tx_resident = false;            // jrc_chain_feed_set_tx: the slots hold a copy of the TX reference ports
+    size_t tx_elems = 0;                 // T * n_items * N
 };
 
 // a failure inside one slot's context (a multi-device feed has one per GPU) is repeated in the feed's own, which is where
@@ -109,6 +113,7 @@ static void feed_free_slot(feed_slot& s)
     if (s.d_chanest) (void)hipFree(s.d_chanest);
     if (s.d_map) (void)hipFree(s.d_map);
     if (s.d_results) (void)hipFree(s.d_results);
+    if (s.d_tx) (void)hipFree(s.d_tx);
     s = feed_slot();
 }
 
@@ -148,6 +153,7 @@ static int feed_create(const std::vector<jrc_ctx*>& ctxs, bool own, const jrc_ch
         st = jrc_chain_create(s.ctx, cfg, range_bins, angle_bins, frames_per_slot, &s.chain);
         if (st != JRC_OK) { if (s.ctx != ctx) jrc_fail(ctx, st, "%s", jrc_last_error(s.ctx)); break; }
         if (i == 0) {
+            fd->tx_elems = (size_t)cfg->N_tx * cfg->n_items * cfg->fft_len;
             fd->frame_elems = jrc_chain_frame_bytes(s.chain) / sizeof(float2);
             fd->chanest_elems = jrc_chain_chanest_bytes(s.chain) / sizeof(float2);
             fd->map_elems = jrc_chain_map_bytes(s.chain) / sizeof(float2);
@@ -264,11 +270,33 @@ extern "C" int jrc_chain_feed_acquire(jrc_chain_feed* fd, jrc_cf32** h_frames)
     return JRC_OK;
 }
 
-// the whole slot on its stream: copy in, A1 -> A5, results (and the first maps) out
-static int feed_enqueue(jrc_chain_feed* fd, feed_slot& s, int n)
+// the resident TX reference ports into the TX part of every frame of a slot's device buffer
+__global__ __launch_bounds__(256) void feed_broadcast_tx_kernel(const float4* __restrict__ tx, float4* __restrict__ frames, size_t tx4, size_t frame4)
+{
+    float4* dst = frames + (size_t)blockIdx.y * frame4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < tx4; i += (size_t)gridDim.x * blockDim.x) dst[i] = tx[i];
+}
+
+// the whole slot on its stream: copy in, A1 -> A5, results (and the first maps) out.  rx_only: the T reference ports of every frame are the
+// resident copy (broadcast into the slot's frames once, again after a full submission overwrote them); only the R receive ports cross PCIe
+static int feed_enqueue(jrc_chain_feed* fd, feed_slot& s, int n, bool rx_only = false)
 {
     jrc_ctx* ctx = s.ctx;
-    JRC_HIP(ctx, hipMemcpyAsync(s.d_frames, s.h_frames, sizeof(float2) * (size_t)n * fd->frame_elems, hipMemcpyHostToDevice, s.stream));
+    if (rx_only) {
+        if (!s.tx_in_frames) {
+            if ((fd->tx_elems % 2) || (fd->frame_elems % 2)) return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "jrc_chain_feed_submit_rx: odd port size");
+            const unsigned gx = (unsigned)std::min<size_t>((fd->tx_elems / 2 + 255) / 256, 64);
+            hipLaunchKernelGGL(feed_broadcast_tx_kernel, dim3(gx, (unsigned)fd->fps), dim3(256), 0, s.stream, (const float4*)s.d_tx, (float4*)s.d_frames,
+                               fd->tx_elems / 2, fd->frame_elems / 2);
+            JRC_HIP(ctx, hipGetLastError());
+            s.tx_in_frames = true;
+        }
+        const size_t pitch = sizeof(float2) * fd->frame_elems, width = sizeof(float2) * (fd->frame_elems - fd->tx_elems);
+        JRC_HIP(ctx, hipMemcpy2DAsync(s.d_frames + fd->tx_elems, pitch, s.h_frames + fd->tx_elems, pitch, width, (size_t)n, hipMemcpyHostToDevice, s.stream));
+    } else {
+        JRC_HIP(ctx, hipMemcpyAsync(s.d_frames, s.h_frames, sizeof(float2) * (size_t)n * fd->frame_elems, hipMemcpyHostToDevice, s.stream));
+        s.tx_in_frames = false;
+    }
     JRC_TRY(jrc_chain_run_dev(s.chain, n, (const jrc_cf32*)s.d_frames, (jrc_cf32*)s.d_chanest, (jrc_cf32*)s.d_map, s.d_results, (void*)s.stream));
     JRC_HIP(ctx, hipMemcpyAsync(s.h_results, s.d_results, sizeof(jrc_ra_result) * (size_t)n, hipMemcpyDeviceToHost, s.stream));
     const int nm = n < fd->maps_per_slot ? n : fd->maps_per_slot;
@@ -278,15 +306,28 @@ static int feed_enqueue(jrc_chain_feed* fd, feed_slot& s, int n)
 }
 
 // stage (when the frames come from pageable memory) and enqueue one slot; runs on the calling thread or on the slot's device thread
-static int feed_launch_slot(jrc_chain_feed* fd, feed_slot& s, const jrc_cf32* h_frames, int n_frames, bool threaded_copy, bool* replayed)
+static int feed_launch_slot(jrc_chain_feed* fd, feed_slot& s, const jrc_cf32* h_frames, int n_frames, bool threaded_copy, bool* replayed, bool rx_only = false)
 {
     jrc_ctx* ctx = s.ctx;
     if (h_frames && (const float2*)h_frames != s.h_frames) {    // pageable source (a GNU Radio buffer): stage it
-        const size_t bytes = sizeof(float2) * (size_t)n_frames * fd->frame_elems;
-        if (threaded_copy) jrc_host_copy(s.h_frames, h_frames, bytes);     // one feeder thread: split large copies
-        else memcpy(s.h_frames, h_frames, bytes);                           // a thread per device is already copying
+        if (rx_only) {                                          // only the receive ports of each frame
+            for (int f = 0; f < n_frames; f++)
+                memcpy(s.h_frames + (size_t)f * fd->frame_elems + fd->tx_elems, (const float2*)h_frames + (size_t)f * fd->frame_elems + fd->tx_elems,
+                       sizeof(float2) * (fd->frame_elems - fd->tx_elems));
+        } else {
+            const size_t bytes = sizeof(float2) * (size_t)n_frames * fd->frame_elems;
+            if (threaded_copy) jrc_host_copy(s.h_frames, h_frames, bytes);     // one feeder thread: split large copies
+            else memcpy(s.h_frames, h_frames, bytes);                           // a thread per device is already copying
+        }
     }
     JRC_HIP(ctx, hipSetDevice(ctx->device));
+    if (rx_only) {                                              // submitted directly: the recorded graph is the full-copy sequence
+        JRC_TRY(feed_enqueue(fd, s, n_frames, true));
+        s.warm = true;
+        *replayed = false;
+        JRC_HIP(ctx, hipEventRecord(s.done, s.stream));
+        return JRC_OK;
+    }
     const bool want_graph = (fd->flags & JRC_FEED_GRAPH) && n_frames == fd->fps && !s.graph_failed && s.warm;
     if (want_graph && !s.graph) {
         // record the slot's sequence once; pointers and sizes of a full slot never change
@@ -308,6 +349,7 @@ static int feed_launch_slot(jrc_chain_feed* fd, feed_slot& s, const jrc_cf32* h_
     *replayed = false;
     if (want_graph && s.graph) {
         JRC_HIP(ctx, hipGraphLaunch(s.graph, s.stream));
+        s.tx_in_frames = false;
         *replayed = true;
     } else {
         JRC_TRY(feed_enqueue(fd, s, n_frames));
@@ -349,6 +391,53 @@ extern "C" int jrc_chain_feed_submit(jrc_chain_feed* fd, const jrc_cf32* h_frame
     if (st != JRC_OK) { if (s.ctx != fd->ctx) jrc_fail(fd->ctx, st, "%s", jrc_last_error(s.ctx)); return st; }
     feed_mark_submitted(fd, s, n_frames, replayed);
     return JRC_OK;
+}
+
+// TX-resident submission (round 4).  In the reference's flowgraph the radar block is pointed at the MIMO-LTF symbols (N_pre = 5, N_sym = N_tx,
+// examples/simulation/radar/mimo_ofdm_jrc_radar_sim.grc:1292-1295): the T reference ports it correlates with are the same rows, packet after
+// packet.  jrc_chain_feed_set_tx hands the feed those rows once; jrc_chain_feed_submit_rx then uploads only the R receive ports of each frame
+// (half of a frame's bytes at T = R) — the caller's promise is that the frames' own TX ports equal the resident rows, which a block checks with
+// a memcmp per frame (radar_chain, host/jrc_blocks.cc).  Full submissions stay possible at any time; they overwrite the slot's TX ports, which
+// the next receive-only batch on that slot restores from the resident copy first.
+extern "C" int jrc_chain_feed_set_tx(jrc_chain_feed* fd, const jrc_cf32* h_tx)
+{
+    if (!fd) return JRC_ERR_INVALID_ARG;
+    if (fd->in_flight) return jrc_fail(fd->ctx, JRC_ERR_INVALID_ARG, "jrc_chain_feed_set_tx: collect the batches in flight first");
+    fd->tx_resident = h_tx != nullptr;
+    for (auto& s : fd->slots) {
+        s.tx_in_frames = false;
+        if (!h_tx) continue;
+        jrc_ctx* ctx = s.ctx;
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e == hipSuccess && !s.d_tx) e = hipMalloc((void**)&s.d_tx, sizeof(float2) * fd->tx_elems);
+        if (e == hipSuccess) e = hipMemcpy(s.d_tx, h_tx, sizeof(float2) * fd->tx_elems, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { fd->tx_resident = false; return feed_relay(fd, ctx, jrc_fail(ctx, JRC_ERR_HIP, "jrc_chain_feed_set_tx: %s", hipGetErrorString(e))); }
+    }
+    return JRC_OK;
+}
+
+extern "C" int jrc_chain_feed_submit_rx(jrc_chain_feed* fd, const jrc_cf32* h_frames, int n_frames)
+{
+    JRC_TRACE("jrc_chain_feed_submit_rx");
+    if (!fd) return JRC_ERR_INVALID_ARG;
+    if (!fd->tx_resident) return jrc_fail(fd->ctx, JRC_ERR_INVALID_ARG, "jrc_chain_feed_submit_rx: no resident TX ports (jrc_chain_feed_set_tx)");
+    feed_slot& s = fd->slots[(size_t)fd->head];
+    JRC_TRY(feed_check_submit(fd, s, h_frames, n_frames));
+    bool replayed = false;
+    const int st = feed_launch_slot(fd, s, h_frames, n_frames, true, &replayed, true);
+    if (st != JRC_OK) { if (s.ctx != fd->ctx) jrc_fail(fd->ctx, st, "%s", jrc_last_error(s.ctx)); return st; }
+    feed_mark_submitted(fd, s, n_frames, replayed);
+    return JRC_OK;
+}
+
+// 1 when the oldest batch in flight has finished (jrc_chain_feed_collect will not block), 0 when it has not or nothing is in flight
+extern "C" int jrc_chain_feed_poll(const jrc_chain_feed* fd)
+{
+    if (!fd) return JRC_ERR_INVALID_ARG;
+    if (fd->in_flight == 0) return 0;
+    const feed_slot& s = fd->slots[(size_t)fd->tail];
+    if (hipSetDevice(s.ctx->device) != hipSuccess) return 0;
+    return hipEventQuery(s.done) == hipSuccess ? 1 : 0;
 }
 
 // up to one batch per device in one call: batch k goes to the next slot (device (head + k) mod n) and is staged and enqueued by that
@@ -399,13 +488,12 @@ extern "C" int jrc_chain_feed_submit_many(jrc_chain_feed* fd, const jrc_cf32* co
         }
         // batches ahead of the first failure are in flight like any other: they are marked and will be collected, in order.  A batch BEHIND
         // it that did launch cannot be (results come back in submission order, and its predecessor never ran): its stream is drained so that
-        // the pinned staging buffer and the slot are free again, and its work is dropped.
+        // the pinned staging buffer and the slot are free again, and its work is dropped.  The failing batches themselves are drained as well.
         for (int k = 0; k < first_bad; k++) {
             feed_slot& s = fd->slots[(size_t)fd->head];
             feed_mark_submitted(fd, s, n_frames[done + k], rp[(size_t)k] != 0);
         }
-        for (int k = first_bad + 1; k < wave; k++) {
-            if (sts[(size_t)k] != JRC_OK) continue;
+        for (int k = first_bad; k < wave; k++) {       // failed launches too: their copy from the pinned buffer may already be queued
             feed_slot& s = fd->slots[(size_t)((head0 + k) % fd->n_slots)];
             if (hipSetDevice(s.ctx->device) == hipSuccess) (void)hipStreamSynchronize(s.stream);
         }

@@ -137,6 +137,8 @@ public:
     virtual int general_work(int noutput_items, gr_vector_int& ninput_items, gr_vector_const_void_star& input_items,
                              gr_vector_void_star& output_items) = 0;
     virtual void forecast(int noutput_items, gr_vector_int& req) { for (auto& r : req) r = noutput_items; }
+    virtual bool start() { return true; }                         // gr::block::start / stop: called by the scheduler around a run
+    virtual bool stop() { return true; }
     std::string name() const { return d_name; }
     std::string alias() const { return d_name + "0"; }
     io_signature::sptr input_signature() const { return d_in; }
@@ -155,6 +157,10 @@ public:
         int n = general_work(noutput_items, nin, in, out);
         for (size_t i = 0; i < t_read.size(); i++) t_read[i] += t_consumed[i];
         if (n > 0) for (auto& w : t_written) w += n;
+        for (size_t i = 0; i < t_in_tags.size() && i < t_read.size(); i++) {      // the scheduler drops the tags of consumed items
+            auto& v = t_in_tags[i];
+            v.erase(std::remove_if(v.begin(), v.end(), [&](const tag_t& t) { return t.offset < t_read[i]; }), v.end());
+        }
         return n;
     }
 

@@ -307,12 +307,24 @@ range_angle_estimator::sptr range_angle_estimator::make(int vlen, std::vector<fl
 class radar_chain_impl : public radar_chain {
     ctx_holder d_c;
     jrc_chain_feed* d_feed = nullptr;
-    int d_fft_len, d_N_tx, d_N_rx, d_n_items, d_fpb, d_slots;
+    int d_fft_len, d_N_tx, d_N_rx, d_N_sym, d_N_pre, d_n_items, d_fpb, d_slots;
     std::string d_stats_path;
     bool d_stats_record, d_new_stat_started = false;
     int d_frames_done = 0, d_n_devices = 1, d_record_len = 0;
     bool d_bg_removal = false;
     std::vector<jrc_ra_result> d_res;
+    // batches stay in flight across general_work calls (at most d_slots), published in frame order as they complete; one older than
+    // d_max_age_us is waited for at the end of a call, stop() / flush() wait for all.  JRC_RADAR_CHAIN_MAX_AGE_US, 0 = every call drains.
+    std::deque<std::chrono::steady_clock::time_point> d_submitted;
+    long d_max_age_us = 2000;
+    // TX-resident submission: the reference rows the radar correlates with (the N_sym symbols behind N_pre of every TX port) are the MIMO-LTFs
+    // in the reference's flowgraph, the same for every packet.  The block keeps the rows of the last full submission; a batch whose frames all
+    // carry exactly those rows (memcmp, a few KB per frame) uploads its receive ports only.  Rows that keep changing (data symbols inside the
+    // radar's window) switch the comparison off for a while.  JRC_RADAR_CHAIN_TX_RESIDENT=0 disables it.
+    bool d_tx_res_enabled = true, d_tx_ref_valid = false, d_tx_ref_on_device = false;
+    std::vector<jrc_cf32> d_tx_ref;
+    int d_tx_misses = 0, d_tx_backoff = 0;
+    long d_rx_only_batches = 0, d_full_batches = 0;
 
     static pmt::pmt_t pack(const char* key, float v) { return pmt::list2(pmt::string_to_symbol(key), pmt::init_f32vector(1, &v)); }
 
@@ -337,7 +349,19 @@ class radar_chain_impl : public radar_chain {
     {
         int n = 0;
         ctx_holder::check_feed(d_feed, jrc_chain_feed_collect(d_feed, d_res.data(), nullptr, &n));
+        if (!d_submitted.empty()) d_submitted.pop_front();
         publish(n);
+    }
+    // finished batches, and (wait) those in flight for longer than the age bound; all: everything
+    void collect_ready(bool all)
+    {
+        while (jrc_chain_feed_pending(d_feed) > 0) {
+            if (!all && jrc_chain_feed_poll(d_feed) != 1) {
+                const auto age = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - d_submitted.front()).count();
+                if (age <= d_max_age_us) break;
+            }
+            collect_one();
+        }
     }
 
 public:
@@ -347,15 +371,18 @@ public:
                      bool background_removal, bool background_recording, int record_len)
         : jrc_rt::block("radar_chain", jrc_rt::io_signature::make(N_tx + N_rx, N_tx + N_rx, sizeof(gr_complex) * fft_len),
                         jrc_rt::io_signature::make(0, 0, 0)),
-          d_fft_len(fft_len), d_N_tx(N_tx), d_N_rx(N_rx), d_n_items(N_pre + N_sym), d_fpb(frames_per_batch), d_slots(batches_in_flight),
-          d_stats_path(stats_path), d_stats_record(stats_record)
+          d_fft_len(fft_len), d_N_tx(N_tx), d_N_rx(N_rx), d_N_sym(N_sym), d_N_pre(N_pre), d_n_items(N_pre + N_sym), d_fpb(frames_per_batch),
+          d_slots(batches_in_flight), d_stats_path(stats_path), d_stats_record(stats_record)
     {
         if ((int)range_bins.size() != fft_len * interp_range || (int)angle_bins.size() != N_tx * N_rx * interp_angle)
             throw std::invalid_argument("[RADAR CHAIN] range_bins / angle_bins do not match the map size");
+        // Only the N_sym symbols behind the preamble are read by mimo_ofdm_radar (lib/mimo_ofdm_radar_impl.cc:250-274: N_pre + sym): the
+        // frames handed to the device hold just those (N_pre = 0, n_items = N_sym).  At the reference flowgraph's point (N_pre 5, N_sym 4)
+        // that is 4 of 9 symbols per port and packet across PCIe.
         jrc_chain_cfg cfg;
-        cfg.fft_len = fft_len; cfg.N_tx = N_tx; cfg.N_rx = N_rx; cfg.N_sym = N_sym; cfg.N_pre = N_pre;
+        cfg.fft_len = fft_len; cfg.N_tx = N_tx; cfg.N_rx = N_rx; cfg.N_sym = N_sym; cfg.N_pre = 0;
         cfg.interp_range = interp_range; cfg.interp_angle = interp_angle; cfg.enable_tx_interleave = interleave;
-        cfg.n_items = d_n_items; cfg.noise_discard_range_m = ndr; cfg.noise_discard_angle_deg = nda;
+        cfg.n_items = N_sym; cfg.noise_discard_range_m = ndr; cfg.noise_discard_angle_deg = nda;
         cfg.snr_threshold = snr_threshold; cfg.power_threshold = power_threshold;
         const std::vector<int> devs = devices_from_env();
         if (devs.size() > 1) {         // one host process, several GPUs: batch k on device k mod n, results in frame order (jrc_chain_feed_create_multi)
@@ -374,6 +401,9 @@ public:
         d_bg_removal = background_removal; d_record_len = record_len;
         if (background_removal || background_recording)
             ctx_holder::check_feed(d_feed, jrc_chain_feed_set_background(d_feed, background_removal, background_recording, record_len));
+        if (const char* e = getenv("JRC_RADAR_CHAIN_MAX_AGE_US")) d_max_age_us = atol(e);
+        if (const char* e = getenv("JRC_RADAR_CHAIN_TX_RESIDENT")) d_tx_res_enabled = atoi(e) != 0;
+        d_tx_ref.resize((size_t)N_tx * N_sym * fft_len);
         d_res.resize((size_t)d_fpb);
         message_port_register_out(pmt::mp("params"));
         set_tag_propagation_policy(TPP_DONT);
@@ -383,14 +413,25 @@ public:
     ~radar_chain_impl() override { jrc_chain_feed_destroy(d_feed); }
     int frames_done() const override { return d_frames_done; }
     int n_devices() const override { return d_n_devices; }
+    long rx_only_batches() const override { return d_rx_only_batches; }
+    int pending_batches() const override { return jrc_chain_feed_pending(d_feed); }
+    void flush() override
+    {
+        jrc_rt::thread::scoped_lock guard(d_setlock);
+        collect_ready(true);
+    }
+    bool stop() override { flush(); return true; }                      // the scheduler is done with the block: publish what is still in flight
     void set_background_record(bool background_record) override
     {
-        jrc_rt::thread::scoped_lock guard(d_setlock);      // between two general_work calls: every batch of a turn is collected before it returns
+        jrc_rt::thread::scoped_lock guard(d_setlock);      // between two general_work calls; batches of earlier calls are published first
+        collect_ready(true);
         ctx_holder::check_feed(d_feed, jrc_chain_feed_set_background(d_feed, d_bg_removal, background_record, d_record_len));
     }
 
     int general_work(int, gr_vector_int& ninput_items, gr_vector_const_void_star& input_items, gr_vector_void_star&) override
     {
+        jrc_rt::thread::scoped_lock guard(d_setlock);
+        collect_ready(false);                                                                         // what finished since the last call
         std::vector<jrc_rt::tag_t> rx_tags, tx_tags;
         get_tags_in_range(rx_tags, d_N_tx, nitems_read(d_N_tx), nitems_read(d_N_tx) + ninput_items[d_N_tx], pmt::mp("packet_len"));
         if (rx_tags.empty()) {                                                                        // no frame in sight (:219-234)
@@ -401,7 +442,8 @@ public:
         const size_t tx_skip = tx_tags.size() > rx_tags.size() ? tx_tags.size() - rx_tags.size() : 0;   // stale TX packets (:191-198)
         if (tx_tags.size() <= tx_skip) throw std::runtime_error("[MIMO OFDM RADAR] no packet_len tag on TX input");
         const size_t n_frames = std::min(rx_tags.size(), tx_tags.size() - tx_skip);
-        const size_t item = (size_t)d_fft_len;
+        const size_t item = (size_t)d_fft_len, port = (size_t)d_N_sym * item;                          // a port of a staged frame: the N_sym used symbols
+        const size_t port_bytes = sizeof(jrc_cf32) * port;
         long rx_end = 0, tx_end = 0;
         size_t f = 0;
         while (f < n_frames) {
@@ -413,25 +455,56 @@ public:
             if (jrc_chain_feed_pending(d_feed) == d_slots) collect_one();
             ctx_holder::check_feed(d_feed, jrc_chain_feed_acquire(d_feed, &stage));
             int nb = 0;
+            const bool try_resident = d_tx_res_enabled && d_tx_ref_valid && d_tx_backoff == 0;
+            bool tx_same = try_resident;                                                              // all frames of the batch carry the resident rows
             for (; f < n_frames && nb < d_fpb; f++) {
                 const long rx0 = (long)(rx_tags[f].offset - nitems_read(d_N_tx)), tx0 = (long)(tx_tags[f + tx_skip].offset - nitems_read(0));
                 const long rx_len = (long)pmt::to_uint64(rx_tags[f].value), tx_len = (long)pmt::to_uint64(tx_tags[f + tx_skip].value);
                 if (rx_len < d_n_items || tx_len < d_n_items) throw std::runtime_error("[RADAR CHAIN] packet shorter than N_pre + N_sym items");
                 if (rx0 + rx_len > ninput_items[d_N_tx] || tx0 + tx_len > ninput_items[0]) break;
-                jrc_cf32* dst = stage + (size_t)nb * (d_N_tx + d_N_rx) * d_n_items * item;
-                for (int t = 0; t < d_N_tx; t++)
-                    memcpy(dst + (size_t)t * d_n_items * item, (const jrc_cf32*)input_items[t] + (size_t)tx0 * item, sizeof(jrc_cf32) * d_n_items * item);
+                jrc_cf32* dst = stage + (size_t)nb * (d_N_tx + d_N_rx) * port;
+                for (int t = 0; t < d_N_tx; t++) {
+                    const jrc_cf32* src = (const jrc_cf32*)input_items[t] + (size_t)(tx0 + d_N_pre) * item;
+                    if (tx_same && memcmp(src, d_tx_ref.data() + (size_t)t * port, port_bytes) != 0) {
+                        tx_same = false;                                                              // this batch goes up whole: fill in the TX ports skipped so far
+                        for (int fb = 0; fb < nb; fb++)
+                            memcpy(stage + (size_t)fb * (d_N_tx + d_N_rx) * port, d_tx_ref.data(), port_bytes * d_N_tx);
+                        for (int tb = 0; tb < t; tb++) memcpy(dst + (size_t)tb * port, d_tx_ref.data() + (size_t)tb * port, port_bytes);
+                    }
+                    if (!tx_same) memcpy(dst + (size_t)t * port, src, port_bytes);
+                }
                 for (int r = 0; r < d_N_rx; r++)
-                    memcpy(dst + (size_t)(d_N_tx + r) * d_n_items * item, (const jrc_cf32*)input_items[d_N_tx + r] + (size_t)rx0 * item,
-                           sizeof(jrc_cf32) * d_n_items * item);
+                    memcpy(dst + (size_t)(d_N_tx + r) * port, (const jrc_cf32*)input_items[d_N_tx + r] + (size_t)(rx0 + d_N_pre) * item, port_bytes);
                 rx_end = rx0 + rx_len; tx_end = tx0 + tx_len;
                 nb++;
             }
             if (nb == 0) break;                                                                       // the next frame is not complete yet
-            ctx_holder::check_feed(d_feed, jrc_chain_feed_submit(d_feed, nullptr, nb));
+            if (tx_same) {
+                if (!d_tx_ref_on_device) {                                                            // first use of these rows: hand them to the feed (nothing may be in flight)
+                    collect_ready(true);
+                    ctx_holder::check_feed(d_feed, jrc_chain_feed_set_tx(d_feed, d_tx_ref.data()));
+                    d_tx_ref_on_device = true;
+                }
+                ctx_holder::check_feed(d_feed, jrc_chain_feed_submit_rx(d_feed, nullptr, nb));
+                d_rx_only_batches++; d_tx_misses = 0;
+            } else {
+                ctx_holder::check_feed(d_feed, jrc_chain_feed_submit(d_feed, nullptr, nb));
+                d_full_batches++;
+                if (d_tx_res_enabled) {
+                    // the rows of this batch's last frame become the candidate for the next batches; rows that never repeat (data symbols in
+                    // the radar's window) stop the comparing for 64 batches at a time
+                    const jrc_cf32* last = stage + (size_t)(nb - 1) * (d_N_tx + d_N_rx) * port;
+                    const bool repeated = d_tx_ref_valid && memcmp(last, d_tx_ref.data(), port_bytes * d_N_tx) == 0;
+                    if (!repeated) { memcpy(d_tx_ref.data(), last, port_bytes * d_N_tx); d_tx_ref_on_device = false; }
+                    d_tx_ref_valid = true;
+                    if (try_resident && ++d_tx_misses >= 4) { d_tx_backoff = 64; d_tx_misses = 0; }
+                    else if (d_tx_backoff > 0) d_tx_backoff--;
+                }
+            }
+            d_submitted.push_back(std::chrono::steady_clock::now());
             if (nb < d_fpb) break;
         }
-        while (jrc_chain_feed_pending(d_feed) > 0) collect_one();                                     // results of this turn, in frame order
+        collect_ready(d_max_age_us <= 0);                                                             // finished or overdue batches, in frame order
         if (rx_end == 0 && tx_end == 0) return 0;                                                      // first frame incomplete: wait for more input
         for (int r = 0; r < d_N_rx; r++) consume(r + d_N_tx, (int)rx_end);
         for (int t = 0; t < d_N_tx; t++) consume(t, (int)tx_end);

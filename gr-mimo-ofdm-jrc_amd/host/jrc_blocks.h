@@ -80,6 +80,11 @@ public:
     virtual int frames_done() const = 0;
     virtual void set_background_record(bool background_record) = 0;      // mimo_ofdm_radar::set_background_record
     virtual int n_devices() const = 0;                                     // GPUs the block feeds (environment JRC_DEVICES=0,1,...)
+    // batches stay in flight across general_work calls and are published in frame order as they finish (a batch older than
+    // JRC_RADAR_CHAIN_MAX_AGE_US, default 2000, is waited for at the end of a call; stop() publishes the rest): flush() does so now
+    virtual void flush() = 0;
+    virtual int pending_batches() const = 0;
+    virtual long rx_only_batches() const = 0;                              // batches whose TX reference rows were already on the device
 };
 
 class MIMO_OFDM_JRC_API matrix_transpose : virtual public jrc_rt::tagged_stream_block {

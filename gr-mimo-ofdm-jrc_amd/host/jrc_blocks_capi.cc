@@ -266,6 +266,10 @@ int jrcb_call_setter(void* h, const char* name, double v)
             if (n == "set_background_record") { rc->set_background_record(v != 0); return 0; }
             if (n == "n_devices") return rc->n_devices();
             if (n == "frames_done") return rc->frames_done();
+            if (n == "flush") { rc->flush(); return 0; }
+            if (n == "stop") { return rc->stop() ? 0 : -1; }
+            if (n == "pending_batches") return rc->pending_batches();
+            if (n == "rx_only_batches") return (int)rc->rx_only_batches();
         }
         if (auto* e = dynamic_cast<range_angle_estimator*>(b.get())) {
             if (n == "set_snr_threshold") { e->set_snr_threshold((float)v); return 0; }

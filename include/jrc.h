@@ -199,6 +199,12 @@ int  jrc_chain_run_td_dev(jrc_chain* chain, int n_frames, const jrc_cf32* d_tx, 
  * (bit-identical to the reference's std::log10, :227). Synchronises `stream`. */
 int  jrc_chain_fetch_results(jrc_chain* chain, int n_frames, const jrc_ra_result* d_results,
                              jrc_ra_result* h_results, void* stream);
+/* The same in two halves, for a caller that keeps batches in flight: _begin orders the copy of the records behind the work queued on
+ * `stream` so far and runs it on the chain's own copy stream (the caller's stream is not blocked and goes on with the next batch);
+ * _end waits for the oldest copy begun and completes snr_est / published as above.  At most two copies may be in flight (the third
+ * _begin fails with JRC_ERR_INVALID_ARG); d_results must stay untouched until the matching _end, so a caller alternates two buffers. */
+int  jrc_chain_fetch_results_begin(jrc_chain* chain, int n_frames, const jrc_ra_result* d_results, void* stream);
+int  jrc_chain_fetch_results_end(jrc_chain* chain, jrc_ra_result* h_results, int* n_frames);
 /* HIP-event timing of the dominant kernel (range-angle FFT + detect) for bench.py's roofline:
  * when enabled every jrc_chain_run_dev brackets each kernel with events on `stream`. */
 int  jrc_chain_set_timing(jrc_chain* chain, int enabled);
@@ -261,6 +267,16 @@ int    jrc_chain_feed_submit(jrc_chain_feed* feed, const jrc_cf32* h_frames, int
  * frames.  Returns the number of frames (also in *n_frames), 0 when nothing is in flight, < 0 on error. */
 int    jrc_chain_feed_collect(jrc_chain_feed* feed, jrc_ra_result* results, jrc_cf32* maps, int* n_frames);
 int    jrc_chain_feed_pending(const jrc_chain_feed* feed);        /* batches in flight */
+/* 1 when the oldest batch in flight has finished (jrc_chain_feed_collect will not block), else 0 */
+int    jrc_chain_feed_poll(const jrc_chain_feed* feed);
+/* TX-resident submission.  mimo_ofdm_radar correlates every packet with its T reference ports (lib/mimo_ofdm_radar_impl.cc:250-274); in the
+ * reference's flowgraph those are the MIMO-LTF rows, identical from packet to packet (N_pre = 5, N_sym = N_tx,
+ * examples/simulation/radar/mimo_ofdm_jrc_radar_sim.grc:1292-1295).  _set_tx keeps a copy of them on the device (h_tx: [N_tx][n_items][fft_len],
+ * the first N_tx ports of a frame; NULL switches it off; no batch may be in flight); _submit_rx is jrc_chain_feed_submit for frames whose TX
+ * ports EQUAL that copy (the caller's promise): only the N_rx receive ports of each frame are read from h_frames / the acquired buffer and
+ * cross PCIe.  Full and receive-only submissions may alternate; results are those of a full submission of the same frames. */
+int    jrc_chain_feed_set_tx(jrc_chain_feed* feed, const jrc_cf32* h_tx);
+int    jrc_chain_feed_submit_rx(jrc_chain_feed* feed, const jrc_cf32* h_frames, int n_frames);
 int    jrc_chain_feed_stats(const jrc_chain_feed* feed, long* graph_replays, long* direct_submits);
 /* Several GPUs fed from one host process.  `devices[n_devices]` (a device may be listed more than once) each get their own context,
  * `slots_per_device` slots and one host thread; batch k of the submission order runs on devices[k mod n_devices]; results come back in

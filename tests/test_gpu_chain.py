@@ -1,9 +1,11 @@
 """GPU tier: the fused device-resident radar chain (A1->A5) against the oracle's block-by-block chain."""
+import os
+
 import numpy as np
 import pytest
 
 import oracle
-from conftest import rel_err
+from conftest import ROOT, rel_err
 
 pytestmark = pytest.mark.gpu
 MAP_TOL = 1e-4        # north-star tolerance on ||a-b||_inf / ||b||_inf for complex-float tensors
@@ -464,6 +466,69 @@ def test_chain_feed_host_fed_pipeline_matches_the_resident_chain(jrc, ctx, graph
     feed.close()
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_chain_feed_tx_resident_submission(jrc, ctx, graph):
+    """jrc_chain_feed_set_tx / _submit_rx: frames whose T reference ports equal the resident rows upload their receive ports only (the TX part of
+    what the caller hands over is never read: poisoned here); full and receive-only batches alternate on the same slots, pageable and
+    in-place; records and maps equal the device-resident chain's on the complete frames.  poll() never claims an unfinished batch."""
+    from jrc_amd import synth
+    sc = synth.Scenario(64, 4, 2, 4, targets=[(11.0, -20.0, 0.0, 80.0)])
+    Ir, Ia, fps, F = 8, 16, 6, 6 * 9 + 2
+    base = synth.make_frames(sc, 8)
+    frames = np.concatenate([base] * (F // 8 + 1))[:F].copy()
+    frames[:, :sc.T] = base[0, :sc.T]                       # one set of reference rows for every frame (the MIMO-LTFs of the flowgraph)
+    frames[:, sc.T:] *= (1.0 + 0.01 * np.arange(F, dtype=np.float32))[:, None, None, None]
+    other = frames.copy()
+    other[:, :sc.T] = base[3, :sc.T]                        # batches with other rows go up whole
+    _, _, gmap, res, _ = run_chain(jrc, ctx, sc, Ir, Ia, F, frames=frames)
+    _, _, gmap_o, res_o, _ = run_chain(jrc, ctx, sc, Ir, Ia, F, frames=other)
+    feed = make_feed(jrc, ctx, sc, Ir, Ia, n_slots=3, frames_per_slot=fps, maps_per_slot=1, graph=graph)
+    with pytest.raises(ValueError, match="no resident TX"):
+        feed.submit(frames[:2], rx_only=True)
+    feed.set_tx(frames[0, :sc.T])
+    got, maps, kinds = [], [], []
+    f0, b = 0, 0
+    assert not feed.poll()
+    while f0 < F or feed.pending():
+        while f0 < F and feed.pending() < feed.n_slots:
+            n = min(fps, F - f0)
+            kind = ("rx", "rx_inplace", "full_other", "rx", "full_same")[b % 5]
+            if kind == "rx":
+                x = frames[f0:f0 + n].copy()
+                x[:, :sc.T] = np.nan                         # never read
+                feed.submit(x, rx_only=True)
+            elif kind == "rx_inplace":
+                st = feed.acquire()
+                st[:n, sc.T:] = frames[f0:f0 + n, sc.T:]
+                st[:n, :sc.T] = np.nan
+                feed.submit(None, n, rx_only=True)
+            elif kind == "full_other":
+                feed.submit(other[f0:f0 + n])
+            else:
+                feed.submit(frames[f0:f0 + n])
+            kinds.append((f0, n, kind))
+            f0 += n
+            b += 1
+        if feed.poll():
+            pass                                             # a finished batch: collect() below returns at once
+        r, m = feed.collect(want_maps=True)
+        got += r
+        maps.append(m)
+    with pytest.raises(ValueError, match="in flight"):
+        feed.acquire(); feed.submit(None, 1); feed.set_tx(None)
+    feed.collect()
+    for (s0, n, kind), m in zip(kinds, maps):
+        want_r, want_m = (res_o, gmap_o) if kind == "full_other" else (res, gmap)
+        for f in range(s0, s0 + n):
+            for k in RES_KEYS:
+                assert getattr(got[f], k) == getattr(want_r[f], k), (f, k, kind)
+        assert np.array_equal(m[0], want_m[s0]), kind
+    feed.set_tx(None)
+    with pytest.raises(ValueError, match="no resident TX"):
+        feed.submit(frames[:2], rx_only=True)
+    feed.close()
+
+
 def test_chain_feed_refuses_overrun_and_bad_sizes(jrc, ctx):
     from jrc_amd import synth
     sc = synth.Scenario(64, 1, 1, 2, targets=[(9.0, 0.0, 0.0, 80.0)])
@@ -715,3 +780,96 @@ def test_chain_results_do_not_depend_on_the_xcd_count(jrc, ctx, monkeypatch, xcd
     assert np.array_equal(rd0, rd1)
     chain.close()
     c2.close()
+
+
+@pytest.mark.gpu
+def test_results_in_flight_equal_the_blocking_fetch(jrc, ctx):
+    """jrc_chain_fetch_results_begin / _end: the records of a run copied beside the next run's kernels (two buffers alternating) are the records
+    jrc_chain_fetch_results returns, in order; a third copy in flight and an _end with nothing begun are refused"""
+    import torch
+    from jrc_amd import synth
+    sc = synth.Scenario(256, 4, 4, 16, targets=[(14.0, 10.0, 0.0, 100.0)])
+    F, Ir, Ia = 24, 8, 16
+    rb, ab = jrc.radar_axes(sc.N, sc.fs, Ir, 16, Ia)
+    chain = jrc.RadarChain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb, ab, 2.4, 14.4, 15.0, 0.0, max_frames=F, ctx=ctx)
+    bufs = chain.alloc(F, "cuda:0")
+    rbuf = [bufs["results"], torch.empty_like(bufs["results"])]
+    want, got = [], []
+    for step in range(5):
+        frames = synth.make_frames(sc, F, first_frame=100 * step)
+        bufs["frames"].copy_(torch.from_numpy(frames.view(np.float32).reshape(bufs["frames"].shape)))
+        torch.cuda.synchronize()
+        b = dict(bufs, results=rbuf[step & 1])
+        n = F - 3 * step                                                    # batches of different sizes through the same ring
+        chain.run(b, n)
+        chain.results_begin(rbuf[step & 1], n)
+        if step >= 1:
+            got.append(chain.results_end())
+        ctx.sync()
+        want.append(chain.results(b, n))
+    with pytest.raises(ValueError, match="two copies"):
+        chain.results_begin(rbuf[0], F)
+        chain.results_begin(rbuf[1], F)
+    got.append(chain.results_end())
+    got.append(chain.results_end())                                         # the one the refused call's first half began
+    with pytest.raises(ValueError, match="no copy"):
+        chain.results_end()
+    key = lambda r: (r.peak_range_idx, r.peak_angle_idx, r.angle_null_idx, r.n_noise_samples, r.peak_power, r.noise_power, r.snr_est, r.range_val, r.angle_val, r.published)
+    assert [len(g) for g in got[:5]] == [len(w) for w in want]
+    for g, w in zip(got[:5], want):
+        assert [key(r) for r in g] == [key(r) for r in w]
+    chain.close()
+
+
+@pytest.mark.gpu
+def test_store_pacing_word_is_within_three_percent_of_the_best_setting(jrc):
+    """the derived pacing word of the map-writing kernel (chain.hip chain_pace: offered byte rate -> ticks of wall_clock64) is a
+    performance setting that nothing else guards — on another partition mode or clock it could silently cost 10 %.  Time the config-B fused
+    kernel with the derived word, unpaced (JRC_RA_PACE=0) and with the word derived for half the CUs (JRC_NCUS), and fail if the default is more
+    than 3 % slower than the best of the full-machine settings.  The three numbers go to gpurun_out/pacing_guard.json."""
+    import json
+    import subprocess
+    import sys
+    code = r'''
+import json, os, sys, time
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch, jrc_amd
+from jrc_amd import synth
+sc = synth.config_B(); Ir, Ia, F = 8, 16, 512
+rb, ab = jrc_amd.radar_axes(sc.N, sc.fs, Ir, 16, Ia)
+ctx = jrc_amd.Context(0)
+chain = jrc_amd.RadarChain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb, ab, 2.4, 14.36, 15.0, 0.0, max_frames=F, ctx=ctx)
+bufs = chain.alloc(F, "cuda:0")
+fr = synth.make_frames(sc, 8)
+hf = torch.from_numpy(fr.view(np.float32).reshape((8,) + tuple(bufs["frames"].shape[1:])))
+for f0 in range(0, F, 8): bufs["frames"][f0:f0 + 8].copy_(hf)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+while time.perf_counter() - t0 < 0.5:
+    chain.run(bufs, F); ctx.sync()
+best = []
+for rep in range(3):
+    chain.set_timing(True)
+    for _ in range(40): chain.run(bufs, F)
+    ctx.sync()
+    best.append(chain.get_timing()["range_angle_fused"])
+    chain.set_timing(False)
+print(json.dumps({"fused_ms": sorted(best)[1]}))
+'''
+    out = {}
+    for name, env in (("derived", {}), ("unpaced", {"JRC_RA_PACE": "0"}), ("derived_for_half_the_cus", {"JRC_NCUS": "128"})):
+        e = dict(os.environ, **env)
+        e.pop("JRC_RA_OFFERED_TBPS", None)
+        if name != "unpaced":
+            e.pop("JRC_RA_PACE", None)
+        r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, cwd=ROOT, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[name] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["fused_ms"]
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        json.dump(out, open(os.path.join(ROOT, "gpurun_out", "pacing_guard.json"), "w"), indent=1)
+    except OSError:
+        pass
+    best_full = min(out["derived"], out["unpaced"])
+    assert out["derived"] <= 1.03 * best_full, out
+    assert 0.25 < out["derived"] < 0.45, out                              # config B x 512: 0.33 ms = 82 % of the HBM peak; a halved clock or partition shows here

@@ -488,6 +488,7 @@ def test_radar_chain_block_runs_the_five_block_branch_in_one(jrc, ctx, tmp_path)
         blk.tag(0, stale + f * plen, "packet_len", plen)
         blk.tag(sc.T, f * plen, "packet_len", plen)
     assert blk.run(0, tx + rx, []) == 0
+    blk.set("flush", 1)                                                # batches may still be in flight when general_work returns
     done = F - 1
     assert [blk.consumed(p) for p in range(sc.T + sc.R)] == [stale + done * plen] * sc.T + [done * plen] * sc.R
     msgs = blk.state()["published"]
@@ -502,6 +503,7 @@ def test_radar_chain_block_runs_the_five_block_branch_in_one(jrc, ctx, tmp_path)
     tx2 = [port_stream(t, F)[done * plen:] for t in range(sc.T)]
     rx2 = [port_stream(sc.T + r, F)[done * plen:] for r in range(sc.R)]
     assert blk.run(0, tx2 + rx2, []) == 0
+    blk.set("stop", 1)                                                 # gr::block::stop(): publishes what is still in flight
     msgs = blk.state()["published"]
     assert len(msgs) == F
     assert {k: v[0] for k, v in msgs[-1]["msg"]}["snr"] == want[F - 1].snr_est
@@ -537,6 +539,7 @@ def test_radar_chain_block_over_several_devices_and_with_background(jrc, ctx, mo
             blk.tag(0, f * n_items, "packet_len", n_items)
             blk.tag(sc.T, f * n_items, "packet_len", n_items)
         assert blk.run(0, ports, []) == 0
+        blk.set("flush", 1)
         return blk, [{k: v[0] for k, v in m["msg"]} for m in blk.state()["published"]]
 
     one, m1 = run_block()
@@ -561,6 +564,77 @@ def test_radar_chain_block_over_several_devices_and_with_background(jrc, ctx, mo
     for f in range(F):
         assert mb[f] == {"range": want[f].range_val, "angle": want[f].angle_val, "power": want[f].peak_power, "snr": want[f].snr_est}, f
     assert mb != m1
+
+
+@gpu
+@pytest.mark.parametrize("max_age_us", ["0", "1000000"])
+def test_radar_chain_block_pipelines_across_turns_and_uploads_receive_ports_only(jrc, ctx, tmp_path, monkeypatch, max_age_us):
+    """the block at the reference flowgraph's own shape (4 TX x 2 RX, fft_len 64, N_pre 5, N_sym 4 = the MIMO-LTFs) fed one
+    scheduler turn at a time.  (b) The TX reference rows repeat from packet to packet: after the first batch only receive ports cross PCIe
+    (rx_only_batches), a packet with other rows in the middle goes up whole, and the preamble symbols never do.  (c) With an age bound the
+    batches of a turn stay in flight into the next turns (pending_batches > 0 after general_work) and still come out in frame order with the
+    log lines of range_angle_estimator; bound 0 = every turn drains, the behaviour of round 3.  Messages equal the device-resident chain's."""
+    import hostblocks as hb
+    import torch
+    from jrc_amd import synth
+    monkeypatch.setenv("JRC_RADAR_CHAIN_MAX_AGE_US", max_age_us)
+    sc = synth.Scenario(64, 4, 2, 4, targets=[(9.0, 15.0, 0.0, 80.0)])
+    Ir, Ia, P, F, per_turn = 8, 16, sc.T * sc.R, 40, 5
+    n_items = sc.Npre + sc.S
+    rb, ab = jrc.radar_axes(sc.N, sc.fs, Ir, P, Ia)
+    base = synth.make_frames(sc, 8)
+    frames = np.concatenate([base] * 5)[:F].copy()
+    frames[:, :sc.T] = base[0, :sc.T]                                  # the same reference rows in every packet ...
+    frames[17, :sc.T, sc.Npre:] = base[5, :sc.T, sc.Npre:]             # ... but one
+    frames[:, sc.T:] *= (1.0 + 0.02 * np.arange(F, dtype=np.float32))[:, None, None, None]
+    rng = np.random.default_rng(3)
+    frames[:, :, :sc.Npre] = crandn(rng, F, sc.T + sc.R, sc.Npre, sc.N)  # preamble symbols differ from packet to packet: never read, never compared
+    chain = jrc.RadarChain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb, ab, 2.4, 28.96, -100.0, 0.0, max_frames=F, ctx=ctx)
+    bufs = chain.alloc(F, "cuda:0")
+    bufs["frames"].copy_(torch.from_numpy(frames.view(np.float32).reshape(bufs["frames"].shape)))
+    torch.cuda.synchronize()
+    chain.run(bufs, F)
+    want = chain.results(bufs, F)
+    log = str(tmp_path / "radar_log.csv")
+    blk = hb.radar_chain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb, ab, 2.4, 28.96, -100.0, 0.0, log, True, frames_per_batch=2, batches_in_flight=3)
+    seen_pending = 0
+    for f0 in range(0, F, per_turn):
+        ports = _radar_chain_streams(sc, frames[f0:f0 + per_turn], n_items)
+        base_tx, base_rx = blk.state()["nitems_read"][0], blk.state()["nitems_read"][sc.T]
+        for k in range(per_turn):
+            blk.tag(0, base_tx + k * n_items, "packet_len", n_items)
+            blk.tag(sc.T, base_rx + k * n_items, "packet_len", n_items)
+        assert blk.run(0, ports, []) == 0
+        assert [blk.consumed(p) for p in range(sc.T + sc.R)] == [per_turn * n_items] * (sc.T + sc.R)
+        seen_pending = max(seen_pending, blk.query("pending_batches"))
+        msgs = blk.state()["published"]                                # whatever is out so far is a prefix, in frame order
+        for i, m in enumerate(msgs):
+            assert {k: v[0] for k, v in m["msg"]}["snr"] == want[i].snr_est, i
+    if max_age_us == "0":
+        assert seen_pending == 0 and len(blk.state()["published"]) == F
+    else:
+        assert seen_pending >= 1                                       # the last batches of a turn were still in flight when it returned
+    blk.set("stop", 1)
+    assert blk.query("pending_batches") == 0 and blk.query("frames_done") == F
+    msgs = blk.state()["published"]
+    assert len(msgs) == F
+    for f in range(F):
+        assert {k: v[0] for k, v in msgs[f]["msg"]} == {"range": want[f].range_val, "angle": want[f].angle_val, "power": want[f].peak_power,
+                                                        "snr": want[f].snr_est}, f
+    n_batches = F // 2
+    assert blk.query("rx_only_batches") >= n_batches - 4               # all but the first batch, the one with other rows and the ones re-arming after it
+    lines = [l for l in open(log).read().split("\n") if l.strip()]
+    assert lines[0].startswith(" NEW RECORD - ") and len(lines) == 1 + F
+    monkeypatch.setenv("JRC_RADAR_CHAIN_TX_RESIDENT", "0")            # switched off: the same messages, everything uploaded
+    blk2 = hb.radar_chain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb, ab, 2.4, 28.96, -100.0, 0.0, frames_per_batch=2, batches_in_flight=3)
+    ports = _radar_chain_streams(sc, frames, n_items)
+    for k in range(F):
+        blk2.tag(0, k * n_items, "packet_len", n_items)
+        blk2.tag(sc.T, k * n_items, "packet_len", n_items)
+    assert blk2.run(0, ports, []) == 0
+    blk2.set("flush", 1)
+    assert blk2.query("rx_only_batches") == 0
+    assert [{k: v[0] for k, v in m["msg"]} for m in blk2.state()["published"]] == [{k: v[0] for k, v in m["msg"]} for m in msgs]
 
 
 @gpu
