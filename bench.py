@@ -640,6 +640,8 @@ def secondary_figures(cfg, ctx, sc, axes):
         leg("detect_only_chain_noise_only_frames", lambda: be.detect_only(cfg if cfg in ("B", "D") else "B", noise_only=True))
     if hasattr(be, "power_map"):
         leg("power_map_chain", lambda: be.power_map(cfg if cfg in ("B", "D") else "B"))
+    if hasattr(be, "device_resident_flowgraph"):
+        leg("device_resident_sim_flowgraph", lambda: be.device_resident_flowgraph(64))
     leg("equalizer_config_c", _eq)
     leg("comm_rx_chain", _comm)
     leg("precoder_config_c", _pre)

@@ -798,19 +798,27 @@ __global__ void zero_pad_kernel(const float2* __restrict__ in, float2* __restric
     out[b * (size_t)out_stride + i] = v;
 }
 
-extern "C" int jrc_zero_pad_dev(jrc_ctx* ctx, int n_bursts, int n_input, unsigned pad_front, unsigned pad_tail, uint64_t seed,
-                                const jrc_cf32* d_in, jrc_cf32* d_out, void* stream)
+extern "C" int jrc_zero_pad_strided_dev(jrc_ctx* ctx, int n_bursts, int n_input, unsigned pad_front, unsigned pad_tail, uint64_t seed,
+                                        const jrc_cf32* d_in, long in_stride, jrc_cf32* d_out, long out_stride, void* stream)
 {
     if (!ctx || n_bursts < 0 || n_input < 0) return JRC_ERR_INVALID_ARG;
     const long n_out = (long)n_input + pad_front + pad_tail;
     if (n_bursts == 0 || n_out == 0) return (int)n_out;
     if ((n_input > 0 && !d_in) || !d_out) return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "zero_pad: null buffers");
+    if (in_stride < n_input || out_stride < n_out) return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "zero_pad: a row stride shorter than the row");
     JRC_BIND(ctx);
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     hipLaunchKernelGGL(zero_pad_kernel, dim3((unsigned)((n_out + 255) / 256), n_bursts), dim3(256), 0, s, (const float2*)d_in, (float2*)d_out,
-                       n_input, (int)pad_front, (int)pad_tail, (unsigned long long)seed, 1e-2f, (long)n_input, n_out);
+                       n_input, (int)pad_front, (int)pad_tail, (unsigned long long)seed, 1e-2f, in_stride, out_stride);
     JRC_HIP(ctx, hipGetLastError());
     return (int)n_out;
+}
+
+extern "C" int jrc_zero_pad_dev(jrc_ctx* ctx, int n_bursts, int n_input, unsigned pad_front, unsigned pad_tail, uint64_t seed,
+                                const jrc_cf32* d_in, jrc_cf32* d_out, void* stream)
+{
+    return jrc_zero_pad_strided_dev(ctx, n_bursts, n_input, pad_front, pad_tail, seed, d_in, (long)n_input, d_out,
+                                    (long)n_input + pad_front + pad_tail, stream);
 }
 
 extern "C" int jrc_zero_pad(jrc_ctx* ctx, int n_input, unsigned pad_front, unsigned pad_tail, uint64_t seed, const jrc_cf32* in, jrc_cf32* out)

@@ -509,6 +509,10 @@ int jrc_frame_sync_state(const jrc_frame_sync* f, int* state, int* frame_start, 
 int jrc_zero_pad(jrc_ctx* ctx, int n_input, unsigned pad_front, unsigned pad_tail, uint64_t seed, const jrc_cf32* in, jrc_cf32* out);
 int jrc_zero_pad_dev(jrc_ctx* ctx, int n_bursts, int n_input, unsigned pad_front, unsigned pad_tail, uint64_t seed,
                      const jrc_cf32* d_in, jrc_cf32* d_out, void* stream);
+/* the same with row strides (in items): burst b reads d_in + b*in_stride and writes d_out + b*out_stride — one TX port of a batch of
+ * precoder / modulator outputs laid out [frame][port][samples] is in_stride = n_ports * n_input apart */
+int jrc_zero_pad_strided_dev(jrc_ctx* ctx, int n_bursts, int n_input, unsigned pad_front, unsigned pad_tail, uint64_t seed,
+                             const jrc_cf32* d_in, long in_stride, jrc_cf32* d_out, long out_stride, void* stream);
 
 /* batched, device-resident form of the whole front end (detection metrics -> frame_detector -> frame_sync run to completion on
  * one capture): frame k of the capture lands in row k of d_frames ([max_frames][max_symbols * fft_len] time-domain samples,

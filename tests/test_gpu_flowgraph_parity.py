@@ -348,3 +348,38 @@ def test_radar_receive_graph_through_the_host_blocks_tags_and_consumption(jrc, c
     msg = est.state()["published"]
     assert res.published == 1 and len(msg) == 1 and msg[0]["port"] == "params"      # :234-253
     assert {k: v[0] for k, v in msg[0]["msg"]} == {"range": res.range_val, "angle": res.angle_val, "power": res.peak_power, "snr": res.snr_est}
+
+
+def test_device_resident_flowgraph_equals_the_block_by_block_graph(jrc, ctx):
+    """precoder -> OFDM modulator -> zero_pad -> target simulators -> A6+A7+A1 -> A2..A5 as one frame-batched leg that
+    never leaves HBM (examples/radar_sim_device_resident.py: jrc_precoder_frames_dev, jrc_ofdm_mod_dev, jrc_zero_pad_strided_dev,
+    jrc_tsim_run_dev, jrc_chain_run_td_dev) at config B's geometry, against the block-by-block graph of examples/radar_sim_flowgraph.py
+    fed the same symbols and the pads this leg drew (no noise sources on either side), packet by packet."""
+    import radar_sim_device_resident as drm
+    import radar_sim_flowgraph as fgm
+    o = tables_256(4)
+    N, R, n_data, S, F = 256, 4, 60, 64, 5
+    tg = dict(trgt_range=[10.0, 31.0], trgt_velocity=[0.0, 6.0], trgt_rcs_dbsm=[20.0, 24.0], trgt_angle=[20.0, -35.0])
+    sim = drm.DeviceResidentRadarSim(o, N, R, n_data, S, F, seed=40, ctx=ctx, **tg)
+    rng = np.random.default_rng(77)
+    nd = len(o["data_subcarriers"])
+    syms = np.stack([qpsk(rng, n_data * nd) for _ in range(F)])
+    assert sim.load_symbols(syms) == F
+    sim.step(F)
+    res = sim.results(F)
+    e = sim.edges(F)
+    blk = fgm.RadarSimFlowgraph(o, ctx=ctx, N_rx=R, fft_len=N, N_sym_radar=S, fused_demod=True, **tg)
+    assert blk.pad_tail == sim.pad_tail and blk.N_pre == sim.N_pre
+    rep = REPORT.setdefault("radar/device_resident_vs_blocks/config_B_4x4_N256_S64", {})
+    for f in range(F):
+        pads = [e["bursts"][f, t, sim.n_in:] for t in range(sim.T)]
+        assert all(0.007 < p.real.std() < 0.014 for p in pads)
+        bres, be = blk.run_packet(syms[f], 2, fgm.DATA, sim.pdu_len, sources=dict(pads=pads, noise=np.zeros((R, sim.n_burst), np.complex64)))
+        assert np.array_equal(e["tx_f"][f], be["tx_f"])                          # batched precoder == per-packet precoder, bit for bit
+        for k, a, b in (("tx_t", e["tx_t"][f], be["tx_t"]), ("bursts", e["bursts"][f], be["bursts"]), ("rx_t", e["rx_t"][f], be["rx_t"]),
+                        ("H", e["H"][f], be["H"][:, :N]), ("map", e["map"][f], be["map"])):
+            err = rel_err(a, b)
+            rep[k] = max(rep.get(k, 0.0), err)
+            assert err <= 1e-5, (f, k, err)
+        compare_results(res[f], bres, exact_floats=False)
+    assert any(r.published for r in res)

@@ -201,6 +201,22 @@ def simulated_chain(cfg="B", F=64):
                 frames_per_s=F / t, ms_simulators_only=ts * 1e3, bursts_per_s_simulators=F * sc.T / ts)
 
 
+def device_resident_flowgraph(F=64):
+    """the whole radar simulation flowgraph as one device-resident leg at config B's geometry (examples/radar_sim_device_resident.py):
+    data symbols in HBM -> precoder -> OFDM modulator -> zero_pad -> 4 target simulators -> A6+A7+A1 -> A2..A5 -> records in HBM"""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import radar_sim_device_resident as drm
+    o = drm.config_b_tables()
+    sim = drm.DeviceResidentRadarSim(o, 256, 4, 60, 64, F, trgt_range=[10.0], trgt_velocity=[0.0], trgt_rcs_dbsm=[20.0], trgt_angle=[20.0])
+    rng = np.random.default_rng(1)
+    sim.load_symbols(np.stack([drm.qpsk_symbols(rng, 60 * sim.nd) for _ in range(F)]))
+    t = timed(lambda: sim.step(F), steps=12, warm=3)
+    r = sim.results(F)[0]
+    return dict(what="device-resident simulation flowgraph, config B geometry (4x4, 256 subcarriers, radar window 64 symbols, %d-sample bursts): "
+                     "precoder -> OFDM mod -> zero_pad -> 4 target simulators -> RX demod + A1 -> A2..A5, %d packets per pass, no host hop" % (sim.n_burst, F),
+                frames_per_step=F, ms_per_step=t * 1e3, frames_per_s=F / t, packet0=dict(range_m=r.range_val, angle_deg=r.angle_val, snr_db=r.snr_est))
+
+
 def sync_front_end(n_frames=512):
     """capture in HBM -> frames of symbols (detection metrics, frame_detector, frame_sync run to completion)"""
     import subprocess
@@ -308,7 +324,7 @@ if __name__ == "__main__":
             "detectD_noise": lambda: detect_only("D", noise_only=True), "powerB": lambda: power_map("B"), "powerD": lambda: power_map("D"),
             "equalizer": equalizer_config_c, "precoder": precoder_config_c, "rdD": lambda: range_doppler("D", 64), "rdB": lambda: range_doppler("B", 64),
             "demodB": lambda: radar_with_demod("B", 512), "demodD": lambda: radar_with_demod("D", 256), "comm_rx": comm_rx_chain,
-            "simB": lambda: simulated_chain("B", 64), "simD": lambda: simulated_chain("D", 8)}
+            "simB": lambda: simulated_chain("B", 64), "simD": lambda: simulated_chain("D", 8), "flowgraphB": lambda: device_resident_flowgraph(64)}
     GROUPS = {"detect": ["detectB", "detectB_noise", "detectD", "detectD_noise", "powerB", "powerD"], "demod": ["demodB", "demodD"],
               "comm": ["comm_rx", "equalizer", "precoder"]}
     if only:
