@@ -116,10 +116,16 @@ def self_launch(a, argv):
 def rank_identity(torch, rank, local_rank, dev_index, my_windows, steps):
     """what makes the N > 1 line self-proving: which physical device this rank ran on and how long ITS OWN timed windows took"""
     p = torch.cuda.get_device_properties(dev_index)
-    bus = "%04x:%02x:%02x" % tuple(int(getattr(p, k, -1)) & 0xffff for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+    have_pci = all(hasattr(p, k) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+    bus = "%04x:%02x:%02x" % tuple(int(getattr(p, k)) & 0xffff for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")) if have_pci else "unknown"
+    uuid = str(getattr(p, "uuid", ""))
+    host = socket.gethostname()
+    # one physical device = (host, PCI address), or (host, uuid) where torch does not expose the address, or (host, device index) as a last resort:
+    # two hosts with the same PCI topology are different devices, and missing properties must not make every rank look like the same one
+    device_key = "%s/%s" % (host, bus if have_pci else (uuid if uuid else "index%d" % dev_index))
     return {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "device_name": p.name, "pci_bus_id": bus,
-            "uuid": str(getattr(p, "uuid", "")), "compute_units": int(getattr(p, "multi_processor_count", 0)),
-            "host": socket.gethostname(), "pid": os.getpid(),
+            "uuid": uuid, "device_key": device_key, "compute_units": int(getattr(p, "multi_processor_count", 0)),
+            "host": host, "pid": os.getpid(),
             "ms_per_step_window0": 1e3 * my_windows[0] / steps, "ms_per_step_windows": [1e3 * w / steps for w in my_windows]}
 
 
@@ -800,7 +806,7 @@ def main():
     ranks = gather_identities(dist, world, rank_identity(torch, rank, local_rank, torch.cuda.current_device(), windows, a.steps))
     windows = shard.max_over_ranks_vec(windows, coll_dev)
     elapsed = windows[0]
-    same_bus = sorted(r["pci_bus_id"] for r in ranks)
+    same_bus = sorted(r["device_key"] for r in ranks)
     shared_device = any(x == y for x, y in zip(same_bus, same_bus[1:]))
 
     check = None
@@ -850,7 +856,7 @@ def main():
             "ranks": ranks,
             "backend": (dist.get_backend() if world > 1 else None),
             "collective_world": (dist.get_world_size() if world > 1 else 1),
-            "distinct_devices": len(set(r["pci_bus_id"] for r in ranks)),
+            "distinct_devices": len(set(r["device_key"] for r in ranks)),
         }
         slowest = max(r["ms_per_step_window0"] for r in ranks)
         # consistency of the line with its parts (barrier cost + start skew), NOT the scaling efficiency (the driver computes that from the

@@ -1266,7 +1266,7 @@ extern "C" int jrc_chain_set_background(jrc_chain* ch, int background_removal, i
     } else if (record_len != ch->bg->record_len) {
         return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_set_background: record_len is fixed once the state exists (%d)", ch->bg->record_len);
     }
-    if (background_removal) JRC_TRY(chain_ensure_raw(ch));
+    JRC_TRY(chain_ensure_raw(ch));             // whoever holds the state may see removal switched on through a chain that shares it: no allocation on the run path
     ch->bg->removal = background_removal != 0;
     ch->bg->recording = background_recording != 0;
     return JRC_OK;
@@ -1539,7 +1539,15 @@ static int chain_run(jrc_chain* ch, int n_frames, const jrc_cf32* d_frames, cons
     // A1 (into the raw-estimate buffer when the background mean is subtracted afterwards)
     const bool bg_sub = bg && bg->removal;
     jrc_cf32* d_est_out = d_chanest;
-    if (bg_sub) { JRC_TRY(chain_ensure_raw(ch)); d_chanest = (jrc_cf32*)ch->d_raw; }
+    if (bg_sub) {
+        if (!ch->d_raw) {                              // every chain of a background group gets the buffer when it joins (set / share): only a state handed over by hand ends up here
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone)
+                return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_chain_run_dev: background removal was switched on while this stream is capturing; run the chain once outside the capture");
+            JRC_TRY(chain_ensure_raw(ch));
+        }
+        d_chanest = (jrc_cf32*)ch->d_raw;
+    }
     JRC_TRY(chain_a1_stage(ch, 0, n_frames, d_frames, d_tx, d_rx_td, cp_len, rx_stream_len, d_chanest, s));
     if (bg_on) {
         JRC_TRY(chain_background_step(ch, n_frames, (const float2*)d_chanest, (float2*)d_est_out, s));

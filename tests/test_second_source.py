@@ -37,6 +37,24 @@ def test_complex_division_and_product_are_the_ones_of_the_boxs_libgcc_s():
     """std::complex<float> operator/ and operator* of a g++ build resolve to libgcc_s.so.1 (g++ links it ahead of the static libgcc):
     the oracle's c_div, the second source's cdiv / cmul and that library agree bit for bit, magnitudes 1e-6 ... 1e6"""
     lg = _libgcc_s()
+    # libgcc_s >= 12 forms the quotient in double and rounds once (what the oracle, the second source and the device restate); older
+    # libraries run Smith's method in float, whose last bits differ.  On such a box a locally built reference would differ from this
+    # product in those bits as well (INTEGRATION.md "libgcc"): a property of the box, not a regression - skip with the reason.
+    def smith(a, b, c, d):
+        f = np.float32
+        a, b, c, d = f(a), f(b), f(c), f(d)
+        if abs(c) < abs(d):
+            r = f(c / d); den = f(f(c * r) + d)
+            return f(f(f(a * r) + b) / den), f(f(f(b * r) - a) / den)
+        r = f(d / c); den = f(c + f(d * r))
+        return f(f(a + f(b * r)) / den), f(f(b - f(a * r)) / den)
+    pr_rng = np.random.default_rng(123)
+    pa, pb = crandn(pr_rng, 256), crandn(pr_rng, 256)
+    pq = ss.cdiv(pa, pb)
+    bad = [i for i in range(256) if (lambda r: (np.float32(r.re), np.float32(r.im)))(lg.__divsc3(pa[i].real, pa[i].imag, pb[i].real, pb[i].imag)) != (pq[i].real, pq[i].imag)]
+    if bad and all((lambda r: (np.float32(r.re), np.float32(r.im)))(lg.__divsc3(pa[i].real, pa[i].imag, pb[i].real, pb[i].imag)) == smith(pa[i].real, pa[i].imag, pb[i].real, pb[i].imag)
+                   for i in bad):
+        pytest.skip("libgcc_s.so.1 of this box divides complex floats by Smith's method in float (GCC < 12): the bit-exact comparison assumes GCC >= 12")
     rng = np.random.default_rng(0)
     n = 4000
     a = crandn(rng, n)

@@ -11,8 +11,11 @@ export TMPDIR=/tmp
 for SPEC in $LEGS; do
   NAME=${SPEC%%:*}; EXTRA=""; [ "$SPEC" != "$NAME" ] && EXTRA=${SPEC#*:}
   LEG=${NAME%%_unpruned}
-  unset JRC_DETECT_EXP
-  [ -n "$EXTRA" ] && export "$EXTRA"
+  LEG=${LEG%%_sigfull}
+  # a leg's ENV=VAL holds for that leg only: whatever the previous leg exported is unset again before the next one starts
+  [ -n "$PREV_VAR" ] && unset "$PREV_VAR"
+  PREV_VAR=""
+  if [ -n "$EXTRA" ]; then export "$EXTRA"; PREV_VAR=${EXTRA%%=*}; fi
   export JRC_BENCH_EXTRA_ONLY=$LEG
   python3 tools/bench_extra.py > $OUT/$NAME.json 2> $OUT/$NAME.err
   ( cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/${NAME}_stats -o s -- python3 $REPO/tools/bench_extra.py > $OUT/${NAME}_stats.log 2>&1 )
