@@ -670,17 +670,23 @@ public:
         return n;
     }
     // chan_est_file wire format "sc:(re,im);(re,im);...\n" (:378-416), read back by mimo_precoder (:806-833).
-    // Eigen's FullPrecision prints 6-7 significant digits depending on its version; 9 are written here (float round trip).
+    // Eigen's FullPrecision = NumTraits<float>::digits10() significant digits through the stream's default float format ("%.<p>g"): 6 in Eigen
+    // 3.3 / 3.4 (std::numeric_limits<float>::digits10), 7 in 3.2 (ceil(-log10(eps))) — recollection, no Eigen in this image.  9 are written by
+    // default (a float round trip, so the precoder steers with the estimate itself, not its 6-digit rounding); JRC_CSV_DIGITS=6 writes the
+    // file byte for byte as the reference's Eigen 3.3 / 3.4 build would.  The precoder's reader takes any of them (:806-833).
     void write_chan_est()
     {
         std::ofstream f(d_chan_est_file, std::ofstream::trunc);
         if (!f.is_open()) throw std::runtime_error("[OFDM Equalizer] Could not open file!!");
-        char buf[96];
+        int digits = 9;
+        if (const char* e = getenv("JRC_CSV_DIGITS")) { const int v = atoi(e); if (v >= 1 && v <= 17) digits = v; }
+        char fmt[32], buf[96];
+        snprintf(fmt, sizeof(fmt), "%%s(%%.%dg,%%.%dg)", digits, digits);
         for (int sc = 0; sc < d_fft_len; sc++) {
             f << sc << ":";
             for (int t = 0; t < d_N_tx; t++) {
                 const gr_complex h = d_chan_est[(size_t)sc * d_N_tx + t];
-                snprintf(buf, sizeof(buf), "%s(%.9g,%.9g)", t ? ";" : "", h.real(), h.imag());
+                snprintf(buf, sizeof(buf), fmt, t ? ";" : "", h.real(), h.imag());
                 f << buf;
             }
             f << "\n";

@@ -99,6 +99,9 @@ class mimo_ofdm_radar:
     def general_work(self, tx, rx, tx_discard=0):
         return self._o.work(tx, rx, tx_discard)
 
+    def set_background_record(self, background_record):
+        self._o.set_background_record(background_record)
+
 
 class matrix_transpose:
     def __init__(self, input_len, output_len, interp_factor, debug=False, len_key="packet_len", ctx=None):

@@ -190,6 +190,37 @@ def test_equalizer_block_tags_and_chan_est_csv_feed_the_precoder(jrc, ofdm64, tm
 
 
 @gpu
+def test_chan_est_csv_with_eigens_full_precision_digits(jrc, ofdm64, tmp_path, monkeypatch):
+    """JRC_CSV_DIGITS=6: chan_est.csv as the reference's Eigen 3.3 / 3.4 build formats it (IOFormat FullPrecision = 6 significant digits
+    for float through the stream's default "%g" style, lib/mimo_ofdm_equalizer_impl.cc:378-409) - every number the 6-digit rendering of
+    the estimate, and the precoder steers from that file like from the 9-digit one (to the 1e-6 the rounding costs)"""
+    import hostblocks as hb
+    rng = np.random.default_rng(8)
+    o = ofdm64
+    h = crandn(rng, 4)
+    op = oracle.Precoder(64, 4, 1, o["data_subcarriers"], o["pilot_subcarriers"], o["pilot_symbols"], o["l_stf_ltf_64"], o["ltf_mapped_sc__ss_sym"])
+    nbytes, mcs = 40, 2
+    ns = oracle.n_ofdm_sym(mcs, 48, nbytes)
+    s = qpsk(rng, ns * 48)
+    y = through_channel(op.work(s, mcs, 1, nbytes), h)
+    files = {}
+    for digits in ("9", "6"):
+        monkeypatch.setenv("JRC_CSV_DIGITS", digits)
+        csv = str(tmp_path / ("chan_est_%s.csv" % digits))
+        eq = hb.equalizer(o, chan_est_file=csv)
+        eq.tag(0, 0, "frame_start", 0.0)
+        out = np.zeros((len(y), 48), np.complex64)
+        assert eq.run(len(y), [y], [out]) == ns
+        files[digits] = open(csv).read()
+    n9 = re.findall(r"[-+0-9.e]+(?=[,)])", files["9"].replace(":", " "))
+    n6 = re.findall(r"[-+0-9.e]+(?=[,)])", files["6"].replace(":", " "))
+    assert len(n9) == len(n6) == 64 * 4 * 2
+    for a, b in zip(n9, n6):
+        assert b == "%.6g" % np.float32(float(a)), (a, b)          # std::ostream << float at precision 6
+    assert files["6"].count("\n") == 64 and files["6"].startswith("0:(")
+
+
+@gpu
 def test_precoder_block_errors_and_radar_aided_steering(jrc, ofdm64, tmp_path):
     import hostblocks as hb
     rng = np.random.default_rng(4)
