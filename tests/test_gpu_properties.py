@@ -1,0 +1,166 @@
+"""GPU tier, the BASELINE sizes themselves (config B: 4x4, 256 subcarriers, 64 symbols, 512 frames per launch; config D: 4x4, 1024 subcarriers,
+128 symbols, 256 frames per launch), where the oracle would take minutes per batch: properties of the path that do not depend on the size
+and need no second implementation —
+
+  * linearity: A1 is linear in the received symbols and A2..A4 are linear maps, so map(a rx1 + b rx2) = a map(rx1) + b map(rx2);
+  * Parseval: the unnormalised 2-D transform of the zero-padded estimate carries (N Ir)(P Ia) times its energy;
+  * shift theorems: a phase ramp over the subcarriers of the received symbols moves the whole map along the range axis by whole bins, a
+    phase step from pair to pair moves it along the angle axis — the estimator's peak moves with it and keeps its power;
+  * scaling: the estimator's SNR does not depend on the level of the input, its peak power scales with the square.
+
+Every frame of the full launch geometry is checked (reductions on the device with torch, which is test plumbing here, not product)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def setup(jrc, ctx, cfg):
+    import torch
+    from jrc_amd import synth
+    sc = {"B": synth.config_B, "D": synth.config_D}[cfg]()
+    F = 512 if cfg == "B" else 256
+    Ir, Ia, P = 8, 16, sc.T * sc.R
+    rb, ab = jrc.radar_axes(sc.N, sc.fs, Ir, P, Ia)
+    chain = jrc.RadarChain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb, ab, 2.4, 14.36, 15.0, 0.0, max_frames=F, ctx=ctx)
+    bufs = chain.alloc(F, "cuda:0")
+    fr = synth.make_frames(sc, 16)
+    hf = torch.from_numpy(fr.view(np.float32).reshape((16,) + tuple(bufs["frames"].shape[1:]))).to("cuda:0")
+    base = hf.repeat((F // 16, 1, 1, 1, 1))
+    scale = (1.0 + 0.001 * torch.arange(F, device="cuda:0", dtype=torch.float32)).view(F, 1, 1, 1, 1)   # every frame a little different
+    base[:, sc.T:] *= scale
+    return sc, F, Ir, Ia, P, chain, bufs, base
+
+
+def cplx(t):
+    import torch
+    return torch.view_as_complex(t)
+
+
+def run(chain, bufs, ctx, frames, F):
+    bufs["frames"].copy_(frames)
+    import torch
+    torch.cuda.synchronize()
+    chain.run(bufs, F)
+    ctx.sync()
+    return cplx(bufs["map"]).clone(), cplx(bufs["chanest"]).clone(), chain.results(bufs, F)
+
+
+@pytest.mark.parametrize("cfg", ["B", "D"])
+def test_linearity_and_parseval_at_the_baseline_batch(jrc, ctx, cfg):
+    import torch
+    sc, F, Ir, Ia, P, chain, bufs, base = setup(jrc, ctx, cfg)
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    other = base.clone()
+    other[:, sc.T:] = torch.randn(other[:, sc.T:].shape, generator=g, device="cuda:0") * 1e-3
+    m1, h1, _ = run(chain, bufs, ctx, base, F)
+    # Parseval, frame by frame: sum |map|^2 = (N Ir)(P Ia) sum |H|^2
+    e_map = (m1.real.double() ** 2 + m1.imag.double() ** 2).sum(dim=(1, 2))
+    e_h = (h1.real.double() ** 2 + h1.imag.double() ** 2).sum(dim=(1, 2))
+    ratio = e_map / (e_h * (sc.N * Ir) * (P * Ia))
+    assert float((ratio - 1).abs().max()) < 2e-6, float((ratio - 1).abs().max())
+    m2, _, _ = run(chain, bufs, ctx, other, F)
+    a, b = 0.75, -1.5
+    mix = base.clone()
+    mix[:, sc.T:] = a * base[:, sc.T:] + b * other[:, sc.T:]
+    m3, _, _ = run(chain, bufs, ctx, mix, F)
+    want = a * m1 + b * m2
+    del m1, m2
+    err = (m3 - want).abs().amax(dim=(1, 2)) / want.abs().amax(dim=(1, 2))
+    assert float(err.max()) < 2e-5, float(err.max())          # three float32 chains against each other, every one of the F frames
+    chain.close()
+
+
+@pytest.mark.parametrize("cfg", ["B", "D"])
+def test_shift_theorems_and_scaling_at_the_baseline_batch(jrc, ctx, cfg):
+    import torch
+    sc, F, Ir, Ia, P, chain, bufs, base = setup(jrc, ctx, cfg)
+    NR, NA = sc.N * Ir, P * Ia
+    m0, _, r0 = run(chain, bufs, ctx, base, F)
+    # range axis: rx[n] * exp(+j 2 pi n q / NR) -> R'[k] = R[k + q]: the map rolls by -q rows
+    q = 37
+    n = torch.arange(sc.N, device="cuda:0", dtype=torch.float64)
+    ramp = torch.exp(2j * np.pi * n * q / NR).to(torch.complex64)
+    fr = base.clone()
+    cplx(fr)[:, sc.T:] *= ramp
+    m1, _, r1 = run(chain, bufs, ctx, fr, F)
+    err = (m1 - torch.roll(m0, -q, dims=1)).abs().amax(dim=(1, 2)) / m0.abs().amax(dim=(1, 2))
+    assert float(err.max()) < 2e-5, float(err.max())
+    for a, b in zip(r0, r1):
+        assert b.peak_range_idx == (a.peak_range_idx - q) % NR and b.peak_angle_idx == a.peak_angle_idx
+        assert abs(b.peak_power - a.peak_power) <= 2e-5 * a.peak_power
+    # angle axis: pair p = r T + t scaled by exp(+j 2 pi p d / NA) -> the (forward-transformed, fftshifted) angle axis rolls by +d columns;
+    # receiver r carries exp(+j 2 pi r T d / NA) on its symbols, transmitter t the conjugate of its factor on its reference symbols (A1 conjugates TX)
+    d = 5
+    fr = base.clone()
+    c = cplx(fr)
+    for r in range(sc.R):
+        c[:, sc.T + r] *= complex(np.exp(+2j * np.pi * r * sc.T * d / NA))
+    for t in range(sc.T):
+        c[:, t] *= complex(np.exp(-2j * np.pi * t * d / NA))
+    m2, _, r2 = run(chain, bufs, ctx, fr, F)
+    err = (m2 - torch.roll(m0, d, dims=2)).abs().amax(dim=(1, 2)) / m0.abs().amax(dim=(1, 2))
+    assert float(err.max()) < 2e-5, float(err.max())
+    for a, b in zip(r0, r2):
+        assert b.peak_angle_idx == (a.peak_angle_idx + d) % NA and b.peak_range_idx == a.peak_range_idx
+    del m1, m2
+    # scaling: rx * 4 (a power of two: exact in float) -> every map cell * 4 exactly, peak power * 16, SNR unchanged to the bit
+    fr = base.clone()
+    fr[:, sc.T:] *= 4.0
+    m3, _, r3 = run(chain, bufs, ctx, fr, F)
+    assert torch.equal(m3, m0 * 4.0)
+    for a, b in zip(r0, r3):
+        assert (b.peak_range_idx, b.peak_angle_idx, b.n_noise_samples) == (a.peak_range_idx, a.peak_angle_idx, a.n_noise_samples)
+        assert b.peak_power == a.peak_power * 16.0 and b.noise_power == a.noise_power * 16.0 and b.snr_est == a.snr_est
+    chain.close()
+
+
+def test_config_c_round_trip_and_scaling_at_the_benchmarked_batch(jrc, ctx):
+    """BASELINE config C at the size bench.py quotes it on (2048 packets x 4 RX lanes = 8192 lane-frames, 4 TX, 256 subcarriers, 64 data symbols):
+    batched precoder -> a flat 4x1 channel per lane-frame (torch, on the device) -> batched equalizer, no noise:
+      * round trip: every lane-frame's equalised symbols are the symbols its packet was made from (1e-4), its SIG says what was sent;
+      * lane-frames do not see each other: the ones that share packet and channel come out bit-equal wherever they sit in the launch;
+      * scaling the received symbols by 4 (exact in float) changes no output bit: estimate, noise term and symbols all scale together."""
+    import torch
+    from test_gpu_comm import config_c_tables
+    N, cp, T, S, n_pkt, lanes = 256, 64, 4, 64, 2048, 4
+    data, pilots, pil, ltf, mapped, sync = config_c_tables(N, T)
+    nd = len(data)
+    nbytes = (S * nd - 22) // 8
+    assert jrc.n_ofdm_sym(2, nd, nbytes) == S
+    rng = np.random.default_rng(3)
+    pts = (np.array([-1 - 1j, 1 - 1j, -1 + 1j, 1 + 1j]) * (0.707107 / 2)).astype(np.complex64)
+    n_distinct = 16
+    sym = pts[rng.integers(0, 4, (n_distinct, S * nd))]
+    pre = jrc.mimo_precoder(N, T, 1, data, pilots, pil, sync, mapped, ctx=ctx)
+    d_sym = torch.from_numpy(np.ascontiguousarray(sym[np.arange(n_pkt) % n_distinct]).view(np.float32).reshape(n_pkt, S * nd, 2)).to("cuda:0")
+    tx = torch.view_as_complex(pre.frames_dev(d_sym, 2, jrc.DATA, nbytes))              # [n_pkt][T][n_total][N]
+    ctx.sync()
+    n_total = tx.shape[2]
+    h = (rng.standard_normal((8, T)) + 1j * rng.standard_normal((8, T))).astype(np.complex64)
+    streams = n_pkt * lanes
+    hs = torch.from_numpy(h[np.arange(streams) % 8]).to("cuda:0")                        # lane-frame i: packet i // lanes, channel i % 8
+    y = torch.einsum("st,stkn->skn", hs, tx.repeat_interleave(lanes, dim=0))             # [streams][n_total][N]
+    y = torch.cat([y[:, 3:4], y[:, 3:]], dim=1).contiguous()                             # frame_sync hands over [LTF, LTF, SIG, MIMO-LTFs, data]
+    n_sym = y.shape[1]
+    eq = jrc.mimo_ofdm_equalizer(jrc.LS, 24e9, 125e6, N, cp, data, pilots, pil, ltf, mapped, T, n_streams=streams, ctx=ctx)
+    d_ph = torch.zeros(streams, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    out, n_out, ev = eq.frames_dev(torch.view_as_real(y), d_ph, n_sym, S)
+    ctx.sync()
+    assert int(n_out.min()) == S and int(n_out.max()) == S
+    got = torch.view_as_complex(out)                                                     # [streams][S][nd]
+    want = torch.from_numpy(sym.reshape(n_distinct, S, nd)).to("cuda:0")[(torch.arange(streams, device="cuda:0") // lanes) % n_distinct]
+    err = (got - want).abs().amax(dim=(1, 2)) / float(np.abs(pts).max())
+    assert float(err.max()) < 1e-4, float(err.max())
+    evs = ev.cpu().numpy()
+    e0 = jrc.EqEvent.from_buffer_copy(evs[streams - 1, 0].tobytes())
+    assert (e0.kind, e0.mcs, e0.packet_type, e0.data_bytes) == (1, 2, jrc.DATA, nbytes)
+    # same packet + same channel = same output bits, wherever the lane-frame sits: period lcm(16 packets x 4 lanes, 8 channels) = 64 lane-frames
+    period = 64
+    assert torch.equal(got[period:], got[:-period])
+    # scaling by a power of two
+    eq2 = jrc.mimo_ofdm_equalizer(jrc.LS, 24e9, 125e6, N, cp, data, pilots, pil, ltf, mapped, T, n_streams=streams, ctx=ctx)
+    out4, _, _ = eq2.frames_dev(torch.view_as_real(y * 4.0), d_ph, n_sym, S)
+    ctx.sync()
+    assert torch.equal(out4, out)
