@@ -666,6 +666,16 @@ def test_radar_chain_block_pipelines_across_turns_and_uploads_receive_ports_only
     blk2.set("flush", 1)
     assert blk2.query("rx_only_batches") == 0
     assert [{k: v[0] for k, v in m["msg"]} for m in blk2.state()["published"]] == [{k: v[0] for k, v in m["msg"]} for m in msgs]
+    monkeypatch.delenv("JRC_RADAR_CHAIN_TX_RESIDENT")
+    monkeypatch.setenv("JRC_DEVICES", "0,0")                          # two contexts, a host thread each: the resident rows live on both
+    blk3 = hb.radar_chain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb, ab, 2.4, 28.96, -100.0, 0.0, frames_per_batch=2, batches_in_flight=2)
+    for k in range(F):
+        blk3.tag(0, k * n_items, "packet_len", n_items)
+        blk3.tag(sc.T, k * n_items, "packet_len", n_items)
+    assert blk3.run(0, ports, []) == 0
+    blk3.set("stop", 1)
+    assert blk3.query("n_devices") == 2 and blk3.query("rx_only_batches") >= n_batches - 4
+    assert [{k: v[0] for k, v in m["msg"]} for m in blk3.state()["published"]] == [{k: v[0] for k, v in m["msg"]} for m in msgs]
 
 
 @gpu
