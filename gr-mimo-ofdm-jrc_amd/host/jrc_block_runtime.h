@@ -149,6 +149,7 @@ public:
     std::vector<uint64_t> t_read, t_written;
     std::vector<int> t_consumed;
     std::vector<std::pair<std::string, pmt::pmt_t>> t_published;
+    std::mutex t_pub_lock;                                        // guards t_published
     std::map<std::string, std::deque<pmt::pmt_t>> t_msg_in;     // message input queues (what the scheduler delivers)
     // one scheduler turn: call general_work, then advance the item counters like the scheduler does
     virtual int t_run(int noutput_items, gr_vector_int& nin, gr_vector_const_void_star& in, gr_vector_void_star& out)
@@ -202,7 +203,11 @@ protected:
         auto m = q.front(); q.pop_front();
         return m;
     }
-    void message_port_pub(const pmt::pmt_t& port, const pmt::pmt_t& msg) { t_published.emplace_back(port->s, msg); }
+    void message_port_pub(const pmt::pmt_t& port, const pmt::pmt_t& msg)      // may be called from a block's own thread, like gr::basic_block's
+    {
+        std::lock_guard<std::mutex> g(t_pub_lock);
+        t_published.emplace_back(port->s, msg);
+    }
     double pc_output_buffers_full(int) { return 0; }
     thread::mutex d_setlock;
 

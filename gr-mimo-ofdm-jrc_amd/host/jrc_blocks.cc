@@ -5,6 +5,7 @@
 
 #include <sys/stat.h>
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -12,6 +13,7 @@
 #include <ctime>
 #include <deque>
 #include <mutex>
+#include <thread>
 #include <fstream>
 #include <iomanip>
 #include <iostream>
@@ -317,6 +319,21 @@ class radar_chain_impl : public radar_chain {
     // d_max_age_us is waited for at the end of a call, stop() / flush() wait for all.  JRC_RADAR_CHAIN_MAX_AGE_US, 0 = every call drains.
     std::deque<std::chrono::steady_clock::time_point> d_submitted;
     long d_max_age_us = 2000;
+    // the age bound holds while the scheduler is idle too: a thread of the block's own wakes every half bound and publishes what is overdue
+    // (message_port_pub from a block's own thread is what gr::blocks::socket_pdu and friends do); every touch of the feed is under d_setlock
+    std::thread d_flusher;
+    std::atomic<bool> d_flusher_stop{false};
+    void flusher_main()
+    {
+        const auto nap = std::chrono::microseconds(std::max<long>(100, d_max_age_us / 2));
+        while (!d_flusher_stop.load()) {
+            std::this_thread::sleep_for(nap);
+            if (d_flusher_stop.load()) break;
+            jrc_rt::thread::scoped_lock guard(d_setlock);
+            try { if (d_feed && jrc_chain_feed_pending(d_feed) > 0) collect_ready(false); }
+            catch (const std::exception& e) { std::cerr << "[RADAR CHAIN] " << e.what() << std::endl; }
+        }
+    }
     // TX-resident submission: the reference rows the radar correlates with (the N_sym symbols behind N_pre of every TX port) are the MIMO-LTFs
     // in the reference's flowgraph, the same for every packet.  The block keeps the rows of the last full submission; a batch whose frames all
     // carry exactly those rows (memcmp, a few KB per frame) uploads its receive ports only.  Rows that keep changing (data symbols inside the
@@ -405,12 +422,18 @@ public:
         if (const char* e = getenv("JRC_RADAR_CHAIN_TX_RESIDENT")) d_tx_res_enabled = atoi(e) != 0;
         d_tx_ref.resize((size_t)N_tx * N_sym * fft_len);
         d_res.resize((size_t)d_fpb);
+        if (d_max_age_us > 0) d_flusher = std::thread(&radar_chain_impl::flusher_main, this);
         message_port_register_out(pmt::mp("params"));
         set_tag_propagation_policy(TPP_DONT);
         std::ofstream f(d_stats_path, std::ofstream::app);
         if (stats_record && !f.is_open()) std::cerr << "[RADAR CHAIN] Could not open log file at " << d_stats_path << std::endl;
     }
-    ~radar_chain_impl() override { jrc_chain_feed_destroy(d_feed); }
+    ~radar_chain_impl() override
+    {
+        d_flusher_stop.store(true);
+        if (d_flusher.joinable()) d_flusher.join();
+        jrc_chain_feed_destroy(d_feed);
+    }
     int frames_done() const override { return d_frames_done; }
     int n_devices() const override { return d_n_devices; }
     long rx_only_batches() const override { return d_rx_only_batches; }

@@ -236,6 +236,7 @@ int jrcb_state_json(void* h, char* buf, int len)
         o << ']';
     }
     o << "],\"published\":[";
+    std::lock_guard<std::mutex> pub_guard(b->t_pub_lock);
     for (size_t i = 0; i < b->t_published.size(); i++) {
         if (i) o << ',';
         o << "{\"port\":\"" << b->t_published[i].first << "\",\"msg\":";

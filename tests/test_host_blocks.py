@@ -679,6 +679,40 @@ def test_radar_chain_block_pipelines_across_turns_and_uploads_receive_ports_only
 
 
 @gpu
+def test_radar_chain_block_age_bound_holds_while_the_scheduler_is_idle(jrc, ctx, monkeypatch):
+    """the batches a turn leaves in flight are published within the age bound even if general_work is never called again (no more input):
+    the block's own thread collects what is overdue; messages still in frame order, nothing left pending"""
+    import time
+    import hostblocks as hb
+    import torch
+    from jrc_amd import synth
+    monkeypatch.setenv("JRC_RADAR_CHAIN_MAX_AGE_US", "3000")
+    sc = synth.Scenario(64, 4, 2, 4, targets=[(9.0, 15.0, 0.0, 80.0)])
+    Ir, Ia, P, F = 8, 16, sc.T * sc.R, 7
+    n_items = sc.Npre + sc.S
+    rb, ab = jrc.radar_axes(sc.N, sc.fs, Ir, P, Ia)
+    frames = synth.make_frames(sc, F)
+    chain = jrc.RadarChain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb, ab, 2.4, 28.96, -100.0, 0.0, max_frames=F, ctx=ctx)
+    bufs = chain.alloc(F, "cuda:0")
+    bufs["frames"].copy_(torch.from_numpy(frames.view(np.float32).reshape(bufs["frames"].shape)))
+    torch.cuda.synchronize()
+    chain.run(bufs, F)
+    want = chain.results(bufs, F)
+    blk = hb.radar_chain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb, ab, 2.4, 28.96, -100.0, 0.0, frames_per_batch=2, batches_in_flight=3)
+    ports = _radar_chain_streams(sc, frames, n_items)
+    for k in range(F):
+        blk.tag(0, k * n_items, "packet_len", n_items)
+        blk.tag(sc.T, k * n_items, "packet_len", n_items)
+    assert blk.run(0, ports, []) == 0
+    t0 = time.time()
+    while blk.query("pending_batches") > 0 and time.time() - t0 < 2.0:   # no flush, no stop, no further turn
+        time.sleep(0.002)
+    assert blk.query("pending_batches") == 0 and time.time() - t0 < 0.5
+    msgs = blk.state()["published"]
+    assert [{k: v[0] for k, v in m["msg"]}["snr"] for m in msgs] == [w.snr_est for w in want]
+
+
+@gpu
 def test_radar_block_capture_writes_radar_chan_csv(jrc, tmp_path):
     """capture_radar_data (lib/mimo_ofdm_radar_impl.cc:348-387): 'HH:MM:SS.mmm, N_tx, N_rx, fft_len:(re,im);...;' + an empty line per
     capture, appended; the values are the last frame's channel estimate (row p = r*T + t, without the zero padding)"""
