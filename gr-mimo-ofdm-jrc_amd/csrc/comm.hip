@@ -117,7 +117,7 @@ extern "C" int jrc_sig_encode(int n_data, int mcs, int packet_type, int length, 
 // C1 equalizer
 struct EqDev {
     int N, cp, ND, NP, NAct, NL, T, mapped_cols, n_pilot_rows, estimator, lds_tables;
-    int exp;            // JRC_EQ_EXP (timing experiments, WRONG RESULTS): 1 = the pilot phase reads the batch's first symbol for every symbol
+    int exp;            // JRC_EQ_EXP (timing experiments, WRONG RESULTS): 1 = the pilot phase reads the batch's first symbol for every symbol; 2 = the MIMO-LTF symbols are not stored to / read from HBM
     int sig_full;       // JRC_EQ_SIG_FULL: always run the windowed Viterbi on the SIG field (no codeword shortcut)
     double freq, bw;
     const int* data_c; const int* pilot_c; const int* active_c;
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
             if (s_flag && nev < io.max_events) nev++;
         } else if (sym <= 2 + NL) {                                                     // MIMO-LTFs :346-463
             const int l = sym - 3;
-            for (int i = tid; i < N; i += NT) pre[(size_t)i * NL + l] = Y[i];
+            if (d.exp != 2) for (int i = tid; i < N; i += NT) pre[(size_t)i * NL + l] = Y[i];       // JRC_EQ_EXP=2 (timing only): no MIMO-LTF store
             __syncthreads();
             if (l == NL - 1) {
                 if (S.packet_type == 1) {                                               // NDP :375-422
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
                         const int sc = k < ND ? dc[k] : pc[k - ND];
                         float2 acc = make_float2(0.f, 0.f);
                         for (int q = 0; q < NL; q++) {                                  // row(0).dot(y): conjugates the row
-                            const float2 p = c_mul(c_conj(d.mapped[(size_t)sc * d.mapped_cols + q]), pre[(size_t)sc * NL + q]);
+                            const float2 p = c_mul(c_conj(d.mapped[(size_t)sc * d.mapped_cols + q]), d.exp == 2 ? Y[sc] : pre[(size_t)sc * NL + q]);
                             acc.x = acc.x + p.x; acc.y = acc.y + p.y;
                         }
                         Hm[sc] = make_float2(acc.x / (float)NL, acc.y / (float)NL);
