@@ -121,3 +121,34 @@ def test_entry_points_bind_their_context_from_any_thread(jrc, ctx):
     assert not err
     assert torch.equal(bufs["chanest"], want[0]) and torch.equal(bufs["map"], want[1]) and torch.equal(bufs["results"], want[2])
     other.close()
+
+
+def test_zero_pad_with_row_strides(jrc, ctx):
+    """jrc_zero_pad_strided_dev: one port of a [frame][port][samples] batch padded into a contiguous [frame][n_out] array — the burst copied untouched,
+    the pads those of the contiguous entry point for the same seed (the generator is keyed by seed, burst and sample), strides shorter than a row
+    and null buffers refused, no bursts / nothing to write = nothing done"""
+    import ctypes as C
+    import torch
+    L = ctx.lib
+    L.jrc_zero_pad_strided_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint, C.c_uint, C.c_uint64, C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p]
+    L.jrc_zero_pad_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint, C.c_uint, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+    F, T, n, front, tail = 5, 3, 100, 7, 23
+    x = torch.randn((F, T, n, 2), device="cuda:0")
+    n_out = n + front + tail
+    for t in range(T):
+        out = torch.zeros((F, n_out + 9, 2), device="cuda:0")                               # rows further apart than they are long
+        assert L.jrc_zero_pad_strided_dev(ctx.h, F, n, front, tail, 11, x.data_ptr() + 8 * t * n, T * n, out.data_ptr(), n_out + 9, None) == n_out
+        ref = torch.zeros((F, n_out, 2), device="cuda:0")
+        port = x[:, t].contiguous()
+        assert L.jrc_zero_pad_dev(ctx.h, F, n, front, tail, 11, port.data_ptr(), ref.data_ptr(), None) == n_out
+        ctx.sync()
+        assert torch.equal(out[:, :n_out], ref) and not out[:, n_out:].any()
+        assert torch.equal(out[:, front:front + n], x[:, t])
+    with pytest.raises(ValueError, match="stride"):
+        ctx.check(L.jrc_zero_pad_strided_dev(ctx.h, F, n, front, tail, 11, x.data_ptr(), n - 1, out.data_ptr(), n_out, None))
+    with pytest.raises(ValueError, match="stride"):
+        ctx.check(L.jrc_zero_pad_strided_dev(ctx.h, F, n, front, tail, 11, x.data_ptr(), n, out.data_ptr(), n_out - 1, None))
+    with pytest.raises(ValueError, match="null"):
+        ctx.check(L.jrc_zero_pad_strided_dev(ctx.h, F, n, front, tail, 11, None, n, out.data_ptr(), n_out, None))
+    assert L.jrc_zero_pad_strided_dev(ctx.h, 0, n, front, tail, 11, None, n, None, n_out, None) == n_out
+    assert L.jrc_zero_pad_strided_dev(ctx.h, F, 0, 0, 0, 11, None, 0, None, 0, None) == 0
