@@ -33,7 +33,7 @@ NDP, DATA, LS, STA = 1, 2, 0, 1
 class CommSimFlowgraph:
     def __init__(self, ofdm_config, mcs=2, estimator=LS, seed=0, ctx=None, blocks=None, fft_len=64, cp_len=None, channel="flat",
                  samp_rate=125_000_000, freq=4e9, noise_figure_dB=10.0, tx_multiplier=0.5, distance=20.0, theta=20.0,
-                 smoothing=True):
+                 smoothing=True, phased_steering=False):
         if blocks is None:
             import jrc_amd as blocks
             ctx = ctx or blocks.Context(0)
@@ -56,7 +56,7 @@ class CommSimFlowgraph:
         self.corr_window_size = N // 2
         self.ignore_gap = (self.n_sync + T) * (N + cp)
         self.pad_front, self.pad_tail = 5, 6 * (N + cp) + 10
-        self.smoothing = smoothing
+        self.smoothing, self.phased = smoothing, phased_steering
         self.equalizer = B.mimo_ofdm_equalizer(estimator, self.rf_freq, samp_rate, N, cp, o["data_subcarriers"],
                                                o["pilot_subcarriers"], o["pilot_symbols"], o["l_stf_ltf_64"][3],
                                                o["ltf_mapped_sc__ss_sym"], T, ctx=ctx)
@@ -80,8 +80,8 @@ class CommSimFlowgraph:
         if self.chan_est is None:
             return {}
         if self.smoothing:
-            return dict(steer_mode=1, Q_mean=self.B.steering_from_channel(self.chan_est.mean(axis=0), ctx=self.ctx))
-        return dict(steer_mode=2, Q_sc=self.B.steering_from_channel(self.chan_est, ctx=self.ctx))
+            return dict(steer_mode=1, Q_mean=self.B.steering_from_channel(self.chan_est.mean(axis=0), self.phased, ctx=self.ctx))
+        return dict(steer_mode=2, Q_sc=self.B.steering_from_channel(self.chan_est, self.phased, ctx=self.ctx))
 
     def send(self, pdu, snr_db=30.0, steer=False, cfo=None, lead=640, sources=None, force=None):
         """one PDU through the graph; returns (crc_ok, payload, info); info["edges"] holds every block edge.

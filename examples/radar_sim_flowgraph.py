@@ -44,7 +44,8 @@ class RadarSimFlowgraph:
     def __init__(self, ofdm_config, trgt_range=(10.0,), trgt_velocity=(0.0,), trgt_rcs_dbsm=(20.0,), trgt_angle=(0.0,),
                  N_rx=2, samp_rate=125_000_000, freq=4e9, noise_figure_dB=10.0, tx_multiplier=0.1, interp_factor_range=8,
                  interp_factor_angle=16, sum_targets=True, seed=0, ctx=None, fft_len=64, cp_len=None, N_sym_radar=None,
-                 blocks=None, fused_demod=True, snr_threshold=15.0, background_removal=False, background_recording=False, record_len=8):
+                 blocks=None, fused_demod=True, snr_threshold=15.0, background_removal=False, background_recording=False, record_len=8,
+                 enable_tx_interleave=False):
         if blocks is None:
             import jrc_amd as blocks
             ctx = ctx or blocks.Context(0)
@@ -79,7 +80,7 @@ class RadarSimFlowgraph:
         self.zero_pads = [B.zero_pad(False, 0, self.pad_tail, seed=seed + 100 * t, ctx=ctx) for t in range(T)]
         self.cp_remover = B.ofdm_cyclic_prefix_remover(N, self.cp_len, ctx=ctx)
         self.rx_fft = B.fft_vcc(N, True, None, True, ctx=ctx)
-        self.radar = B.mimo_ofdm_radar(N, T, R, self.N_sym_radar, self.N_pre, background_removal, background_recording, record_len, self.Ir, False, "",
+        self.radar = B.mimo_ofdm_radar(N, T, R, self.N_sym_radar, self.N_pre, background_removal, background_recording, record_len, self.Ir, enable_tx_interleave, "",
                                        ctx=ctx)       # the simulation flowgraph has both off (…radar_sim.grc:1298-1299), the USRP one on
         self.range_ifft = B.fft_vcc(N * self.Ir, False, None, False, ctx=ctx)
         self.transpose = B.matrix_transpose(N * self.Ir, P, self.Ia, ctx=ctx)

@@ -979,7 +979,8 @@ __global__ void steering_kernel(const float2* __restrict__ h, float2* __restrict
         float nrm = 0.f;
         for (int t = 0; t < T; t++) nrm = nrm + (hv[t].x * hv[t].x + hv[t].y * hv[t].y);
         nrm = sqrtf(nrm);
-        for (int k = 0; k < T * T; k++) q[k] = make_float2(0.f, 0.f);
+        // Q = Q * sqrt(T) / Q.norm() runs over the whole matrix (:851): the zero columns stay zero unless the row is all zero, where 0 / 0 makes every entry NaN
+        for (int k = T; k < T * T; k++) q[k] = make_float2(0.f / nrm, 0.f / nrm);
         for (int t = 0; t < T; t++) q[t] = make_float2(hv[t].x * sqT / nrm, -hv[t].y * sqT / nrm);
         return;
     }

@@ -428,6 +428,8 @@ void orc_steering_from_channel(int T, const float* h_f, int phased, float* Q_f)
         for (int t = 0; t < T; t++) nrm += crealf(h[t] * conjf(h[t]));
         nrm = sqrtf(nrm);
         for (int t = 0; t < T; t++) Q[t] = conjf(h[t]) * sqrtf((float)T) / nrm;     /* column 0 */
+        /* Q = Q * sqrt(T) / Q.norm() runs over the whole matrix (:851): the zero columns stay zero unless the row is all zero, where 0 / 0 makes every entry NaN */
+        for (int k = T; k < T * T; k++) Q[k] = (0.0f / nrm) + (0.0f / nrm) * I;
         return;
     }
     cf x[16];

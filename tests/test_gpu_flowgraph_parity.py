@@ -439,3 +439,56 @@ def test_radar_flowgraph_with_background_removal_across_packets(jrc, ctx, ofdm64
     assert hip.radar.ring_size() == 3
     assert abs(seen[4][1] - 30.0) < 1.0 and abs(seen[4][2] - 30.0) < 3.0         # clutter at 8 m removed: the new target is the peak
     assert np.abs(ge["H"]).max() > 0
+
+
+def test_radar_flowgraph_with_tx_interleave(jrc, ctx, ofdm64):
+    """enable_tx_interleave (lib/mimo_ofdm_radar_impl.cc:262-269): the pairs leave the radar block transmitter-major (p = t R + r), which re-orders the
+    rows of `H` and with them the angle axis of everything downstream; the operating point once more with it switched on, chained"""
+    import radar_sim_flowgraph as fgm
+    o = tables_64(ofdm64, 4)
+    kw = dict(trgt_range=[14.0], trgt_velocity=[0.0], trgt_rcs_dbsm=[20.0], trgt_angle=[-20.0], N_rx=2, fft_len=64, seed=6, enable_tx_interleave=True)
+    hip = fgm.RadarSimFlowgraph(o, ctx=ctx, **kw)
+    orc = fgm.RadarSimFlowgraph(o, blocks=oracle_blocks, **kw)
+    plain = fgm.RadarSimFlowgraph(o, ctx=ctx, **dict(kw, enable_tx_interleave=False))
+    rng = np.random.default_rng(41)
+    ns = jrc.n_ofdm_sym(2, 48, 100)
+    sym = qpsk(rng, ns * 48)
+    rep = REPORT.setdefault("radar/tx_interleave/operating_point_4x2_N64", {})
+    gres, ge = hip.run_packet(sym, 2, fgm.DATA, 100)
+    src = dict(pads=ge["pads"], noise=ge["noise"])
+    ores, oe = orc.run_packet(sym, 2, fgm.DATA, 100, sources=src)
+    for k in RADAR_CF32_EDGES:
+        err = rel_err(ge[k], oe[k])
+        rep["chained:" + k] = err
+        assert err <= TOL, (k, err)
+    compare_results(gres, ores, exact_floats=False)
+    _, pe = plain.run_packet(sym, 2, fgm.DATA, 100, sources=src)
+    T, R = 4, 2
+    perm = [r * T + t for t in range(T) for r in range(R)]                    # row p = t R + r of the interleaved estimate is row r T + t of the plain one
+    assert np.array_equal(ge["H"], pe["H"][perm]) and not np.array_equal(ge["H"], pe["H"])
+
+
+@pytest.mark.parametrize("smoothing", [False, True], ids=["per_subcarrier", "mean_channel"])
+def test_comm_flowgraph_with_phased_steering(jrc, ctx, ofdm64, smoothing):
+    """phased_steering (lib/mimo_precoder_impl.cc:850-853): column 0 of the steering matrix is sqrt(T) conj(h)/|h|, the rest zero — the comm graph at the
+    .grc's point with the DATA packets steered that way after the sounding, chained edge by edge"""
+    import comm_sim_flowgraph as cfm
+    rep = REPORT.setdefault("comm/N64/phased/%s" % ("mean" if smoothing else "per_sc"), {})
+    kw = dict(mcs=2, estimator=0, seed=12, channel="los", smoothing=smoothing, phased_steering=True)
+    hip = cfm.CommSimFlowgraph(ofdm64, ctx=ctx, **kw)
+    orc = cfm.CommSimFlowgraph(ofdm64, blocks=oracle_blocks, **kw)
+    rng = np.random.default_rng(77)
+    for pdu, steer in [(bytes([1]) + b"sounding", False), (bytes([2]) + rng.integers(0, 256, 120, dtype=np.uint8).tobytes(), True),
+                       (bytes([2]) + rng.integers(0, 256, 333, dtype=np.uint8).tobytes(), True)]:
+        gok, gpay, ginfo = hip.send(pdu, steer=steer)
+        ge = ginfo["edges"]
+        ook, opay, oinfo = orc.send(pdu, steer=steer, sources=dict(pads=ge["pads"], noise=ge["noise"]))
+        compare_comm_edges(ge, oinfo["edges"], rep, "chained:", TOL)
+        assert (gok, gpay) == (ook, opay)
+        if steer:
+            qg, qo = ge["steering"].reshape(-1, 4, 4), oinfo["edges"]["steering"].reshape(-1, 4, 4)
+            dead = np.isnan(qo).all(axis=(1, 2))                  # carriers without a channel estimate: Q * sqrt(T) / Q.norm() = 0 / 0 everywhere (:851)
+            assert np.array_equal(np.isnan(qg), np.isnan(qo)) and not np.isnan(qo[~dead]).any()
+            assert dead.sum() == (0 if smoothing else int((np.asarray(ofdm64["ltf_64"]) == 0).sum())) and rel_err(qg[~dead], qo[~dead]) <= TOL
+            assert np.abs(qg[~dead][..., 1:]).max() == 0 and np.abs(qg[~dead][..., 0]).min() > 0       # phased: only column 0
+            assert gok and gpay == pdu
