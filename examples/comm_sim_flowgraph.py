@@ -83,7 +83,14 @@ class CommSimFlowgraph:
             return dict(steer_mode=1, Q_mean=self.B.steering_from_channel(self.chan_est.mean(axis=0), self.phased, ctx=self.ctx))
         return dict(steer_mode=2, Q_sc=self.B.steering_from_channel(self.chan_est, self.phased, ctx=self.ctx))
 
-    def send(self, pdu, snr_db=30.0, steer=False, cfo=None, lead=640, sources=None, force=None):
+    def radar_aided_steering(self, angle_estimate):
+        """compute_radar_aided_steering() (lib/mimo_precoder_impl.cc:901-983): the user is where the radar saw its target — the last line of
+        radar_log.csv carries the estimator's angle — so the channel is taken to be the array response h[t] = exp(j pi sin(angle) t)"""
+        a = np.float32(angle_estimate)
+        h = np.array([np.exp(1j * np.float32(np.pi * np.sin(float(a) / 180.0 * np.pi) * t)) for t in range(self.T)]).astype(np.complex64)
+        return dict(steer_mode=1, Q_mean=self.B.steering_from_channel(h, self.phased, ctx=self.ctx))
+
+    def send(self, pdu, snr_db=30.0, steer=False, cfo=None, lead=640, sources=None, force=None, radar_angle=None):
         """one PDU through the graph; returns (crc_ok, payload, info); info["edges"] holds every block edge.
         `sources` = {"pads": [T][2] (front, tail), "noise": [n]} replays the random sources of an earlier run;
         `force` = edges of another run that every block reads instead of what this graph computed upstream."""
@@ -101,7 +108,7 @@ class CommSimFlowgraph:
             return None, None, info
         e["symbols"], e["encoder_tags"] = sym, dict(tags)
         sym = use("symbols", sym)
-        kw = self.steering() if steer else {}
+        kw = (self.radar_aided_steering(radar_angle) if radar_angle is not None else self.steering()) if steer else {}
         e["steering"] = kw.get("Q_mean", kw.get("Q_sc"))
         e["tx_f"] = self.precoder.work(sym, tags["mcs"], tags["packet_type"], tags["pdu_len"], **kw)       # [T][n_total][N]
         tx_f = use("tx_f", e["tx_f"])

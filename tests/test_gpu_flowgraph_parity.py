@@ -492,3 +492,39 @@ def test_comm_flowgraph_with_phased_steering(jrc, ctx, ofdm64, smoothing):
             assert dead.sum() == (0 if smoothing else int((np.asarray(ofdm64["ltf_64"]) == 0).sum())) and rel_err(qg[~dead], qo[~dead]) <= TOL
             assert np.abs(qg[~dead][..., 1:]).max() == 0 and np.abs(qg[~dead][..., 0]).min() > 0       # phased: only column 0
             assert gok and gpay == pdu
+
+
+def test_radar_aided_precoding_across_the_two_flowgraphs(jrc, ctx, ofdm64):
+    """the paper's loop, radar -> comm, over both graphs: the radar graph sees the user as its target (10 m, 20 deg), range_angle_estimator's angle goes to the
+    precoder (in the reference through the last line of radar_log.csv: lib/range_angle_estimator_impl.cc:266-269 -> lib/mimo_precoder_impl.cc:901-983), which
+    steers the DATA packets of the comm graph towards it with no sounding at all; the .grc's line-of-sight channel points the same way (theta 20 deg).
+    HIP graphs against oracle graphs, each pair chained on its own radar estimate; and the beam really forms: the equalizer's precoded channel mean grows by
+    about ||h|| / |sum h_t / sqrt(T)|."""
+    import comm_sim_flowgraph as cfm
+    import radar_sim_flowgraph as fgm
+    o = tables_64(ofdm64, 4)
+    rkw = dict(trgt_range=[10.0], trgt_velocity=[0.0], trgt_rcs_dbsm=[20.0], trgt_angle=[20.0], N_rx=2, fft_len=64, seed=14)
+    hr, orr = fgm.RadarSimFlowgraph(o, ctx=ctx, **rkw), fgm.RadarSimFlowgraph(o, blocks=oracle_blocks, **rkw)
+    rng = np.random.default_rng(51)
+    ns = jrc.n_ofdm_sym(2, 48, 100)
+    sym = qpsk(rng, ns * 48)
+    gres, ge = hr.run_packet(sym, 2, fgm.DATA, 100)
+    ores, _ = orr.run_packet(sym, 2, fgm.DATA, 100, sources=dict(pads=ge["pads"], noise=ge["noise"]))
+    compare_results(gres, ores, exact_floats=False)
+    assert gres.published == 1 and gres.angle_val == ores.angle_val and abs(gres.angle_val - 20.0) < 2.0
+    ckw = dict(mcs=3, estimator=0, seed=15, channel="los", theta=20.0)
+    hc, oc = cfm.CommSimFlowgraph(ofdm64, ctx=ctx, **ckw), cfm.CommSimFlowgraph(ofdm64, blocks=oracle_blocks, **ckw)
+    rep = REPORT.setdefault("comm/N64/radar_aided", {})
+    gains = {}
+    for steer in (False, True):
+        pdu = bytes([2]) + rng.integers(0, 256, 200, dtype=np.uint8).tobytes()
+        gok, gpay, ginfo = hc.send(pdu, steer=steer, radar_angle=gres.angle_val)
+        e = ginfo["edges"]
+        ook, opay, oinfo = oc.send(pdu, steer=steer, radar_angle=ores.angle_val, sources=dict(pads=e["pads"], noise=e["noise"]))
+        compare_comm_edges(e, oinfo["edges"], rep, "chained:", TOL)
+        assert (gok, gpay) == (ook, opay) == (True, pdu)
+        if steer:
+            assert rel_err(e["steering"], oinfo["edges"]["steering"]) <= TOL
+        end = [ev for ev in e["eq_events"] if ev["kind"] == 2][0]
+        gains[steer] = float(np.abs(end["chan_mean"][0]))
+    assert gains[True] > 2.0 * gains[False], gains                 # ||h|| = 2 g against |sum_t h_t| / 2 = 0.82 g at 20 deg
