@@ -90,7 +90,7 @@ class CommSimFlowgraph:
         h = np.array([np.exp(1j * np.float32(np.pi * np.sin(float(a) / 180.0 * np.pi) * t)) for t in range(self.T)]).astype(np.complex64)
         return dict(steer_mode=1, Q_mean=self.B.steering_from_channel(h, self.phased, ctx=self.ctx))
 
-    def send(self, pdu, snr_db=30.0, steer=False, cfo=None, lead=640, sources=None, force=None, radar_angle=None):
+    def send(self, pdu, snr_db=30.0, steer=False, cfo=None, lead=640, sources=None, force=None, radar_angle=None, radar_streams=None):
         """one PDU through the graph; returns (crc_ok, payload, info); info["edges"] holds every block edge.
         `sources` = {"pads": [T][2] (front, tail), "noise": [n]} replays the random sources of an earlier run;
         `force` = edges of another run that every block reads instead of what this graph computed upstream."""
@@ -110,6 +110,8 @@ class CommSimFlowgraph:
         sym = use("symbols", sym)
         kw = (self.radar_aided_steering(radar_angle) if radar_angle is not None else self.steering()) if steer else {}
         e["steering"] = kw.get("Q_mean", kw.get("Q_sc"))
+        if radar_streams is not None:                                            # use_radar_streams: N_tx - 1 streams of radar symbols on the other columns of Q (:560-631)
+            kw = dict(kw, radar_streams=radar_streams)
         e["tx_f"] = self.precoder.work(sym, tags["mcs"], tags["packet_type"], tags["pdu_len"], **kw)       # [T][n_total][N]
         tx_f = use("tx_f", e["tx_f"])
         window = np.full(N, 1 / N ** 0.5, np.float32)

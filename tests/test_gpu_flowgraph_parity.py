@@ -528,3 +528,29 @@ def test_radar_aided_precoding_across_the_two_flowgraphs(jrc, ctx, ofdm64):
         end = [ev for ev in e["eq_events"] if ev["kind"] == 2][0]
         gains[steer] = float(np.abs(end["chan_mean"][0]))
     assert gains[True] > 2.0 * gains[False], gains                 # ||h|| = 2 g against |sum_t h_t| / 2 = 0.82 g at 20 deg
+
+
+def test_comm_flowgraph_with_radar_streams_on_the_null_space(jrc, ctx, ofdm64):
+    """use_radar_streams (lib/mimo_precoder_impl.cc:560-631): the other N_tx - 1 columns of the steering matrix carry radar symbols; steered from the sounding
+    they lie in the null space of the user's channel, so the PDU still decodes while three more streams are on the air.  Edge by edge, chained."""
+    import comm_sim_flowgraph as cfm
+    rep = REPORT.setdefault("comm/N64/radar_streams", {})
+    kw = dict(mcs=2, estimator=0, seed=21, channel="los", smoothing=True)
+    hip = cfm.CommSimFlowgraph(ofdm64, ctx=ctx, **kw)
+    orc = cfm.CommSimFlowgraph(ofdm64, blocks=oracle_blocks, **kw)
+    rng = np.random.default_rng(88)
+    pdus = [(bytes([1]) + b"sounding", False, False), (bytes([2]) + rng.integers(0, 256, 150, dtype=np.uint8).tobytes(), True, True)]
+    for pdu, steer, streams in pdus:
+        rs = None
+        if streams:
+            ns = jrc.n_ofdm_sym(2, 48, len(pdu) + 4)
+            rs = qpsk(rng, 3 * ns * 64).reshape(3, ns, 64)
+        gok, gpay, ginfo = hip.send(pdu, steer=steer, radar_streams=rs)
+        ge = ginfo["edges"]
+        ook, opay, oinfo = orc.send(pdu, steer=steer, radar_streams=rs, sources=dict(pads=ge["pads"], noise=ge["noise"]))
+        compare_comm_edges(ge, oinfo["edges"], rep, "chained:", TOL)
+        assert (gok, gpay) == (ook, opay)
+        if streams:
+            assert gok and gpay == pdu
+            plain = hip.precoder.work(ge["symbols"], 2, 2, len(pdu) + 4, **hip.steering())
+            assert rel_err(ge["tx_f"], plain) > 0.1                      # the radar streams really are on the air
