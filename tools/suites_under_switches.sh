@@ -16,3 +16,11 @@ run "JRC_DEMOD_SPR=4" tests/test_gpu_chain.py -k time_domain
 run "JRC_NO_WIDE=1" tests/test_gpu_chain.py tests/test_gpu_chain_modes.py
 run "JRC_RD_TWO_STEP=1" tests/test_gpu_chain.py -k range_doppler
 run "JRC_RD_CHUNK_MB=1" tests/test_gpu_chain.py -k range_doppler
+run "JRC_EQ_SIG_FULL=1" tests/test_gpu_comm.py
+run "JRC_EQ_SIG_FULL=1" tests/test_gpu_flowgraph_parity.py -k comm
+run "JRC_DETECT_SLICES=3" tests/test_gpu_chain_modes.py tests/test_gpu_fuzz.py
+run "JRC_DETECT_SLICES=4 JRC_CHANEST_U2=1" tests/test_gpu_chain_modes.py
+run "JRC_CHANEST_U2=1" tests/test_gpu_chain.py tests/test_gpu_blocks.py
+run "JRC_RADAR_CHAIN_MAX_AGE_US=0" tests/test_host_blocks.py
+run "JRC_RADAR_CHAIN_TX_RESIDENT=0" tests/test_host_blocks.py -k radar_chain_block_runs
+run "JRC_RADAR_CHAIN_TX_RESIDENT=0" tests/test_host_blocks.py -k several_devices
