@@ -312,7 +312,10 @@ class radar_chain_impl : public radar_chain {
     int d_fft_len, d_N_tx, d_N_rx, d_N_sym, d_N_pre, d_n_items, d_fpb, d_slots;
     std::string d_stats_path;
     bool d_stats_record, d_new_stat_started = false;
-    int d_frames_done = 0, d_n_devices = 1, d_record_len = 0;
+    int d_n_devices = 1, d_record_len = 0;
+    // read by the getters from any thread while the scheduler's thread or the flusher advances them under d_setlock
+    std::atomic<int> d_frames_done{0}, d_pending{0};
+    std::atomic<long> d_rx_only_batches{0};
     bool d_bg_removal = false;
     std::vector<jrc_ra_result> d_res;
     // batches stay in flight across general_work calls (at most d_slots), published in frame order as they complete; one older than
@@ -341,7 +344,7 @@ class radar_chain_impl : public radar_chain {
     bool d_tx_res_enabled = true, d_tx_ref_valid = false, d_tx_ref_on_device = false;
     std::vector<jrc_cf32> d_tx_ref;
     int d_tx_misses = 0, d_tx_backoff = 0;
-    long d_rx_only_batches = 0, d_full_batches = 0;
+    long d_full_batches = 0;
 
     static pmt::pmt_t pack(const char* key, float v) { return pmt::list2(pmt::string_to_symbol(key), pmt::init_f32vector(1, &v)); }
 
@@ -367,13 +370,14 @@ class radar_chain_impl : public radar_chain {
         int n = 0;
         ctx_holder::check_feed(d_feed, jrc_chain_feed_collect(d_feed, d_res.data(), nullptr, &n));
         if (!d_submitted.empty()) d_submitted.pop_front();
+        d_pending.store(jrc_chain_feed_pending(d_feed));
         publish(n);
     }
     // finished batches, and (wait) those in flight for longer than the age bound; all: everything
     void collect_ready(bool all)
     {
         while (jrc_chain_feed_pending(d_feed) > 0) {
-            if (!all && jrc_chain_feed_poll(d_feed) != 1) {
+            if (!all && !d_submitted.empty() && jrc_chain_feed_poll(d_feed) != 1) {
                 const auto age = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - d_submitted.front()).count();
                 if (age <= d_max_age_us) break;
             }
@@ -437,7 +441,7 @@ public:
     int frames_done() const override { return d_frames_done; }
     int n_devices() const override { return d_n_devices; }
     long rx_only_batches() const override { return d_rx_only_batches; }
-    int pending_batches() const override { return jrc_chain_feed_pending(d_feed); }
+    int pending_batches() const override { return d_pending.load(); }
     void flush() override
     {
         jrc_rt::thread::scoped_lock guard(d_setlock);
@@ -525,6 +529,7 @@ public:
                 }
             }
             d_submitted.push_back(std::chrono::steady_clock::now());
+            d_pending.store(jrc_chain_feed_pending(d_feed));
             if (nb < d_fpb) break;
         }
         collect_ready(d_max_age_us <= 0);                                                             // finished or overdue batches, in frame order
