@@ -82,6 +82,8 @@ extern "C" int jrc_create(int device, jrc_ctx** out)
     ctx->tune.chanest_u2 = getenv("JRC_CHANEST_U2") != nullptr;
     ctx->tune.fd_serial = getenv("JRC_FD_SERIAL") != nullptr;
     ctx->tune.sync_naive = getenv("JRC_SYNC_NAIVE") != nullptr;
+    ctx->tune.sync_streams = getenv("JRC_SYNC_STREAMS") != nullptr;
+    ctx->tune.sync_tile = getenv("JRC_SYNC_TILE") != nullptr;
     ctx->tune.dec_single = getenv("JRC_DEC_SINGLE") != nullptr;
     if (const char* e = getenv("JRC_DEC_FPW")) ctx->tune.dec_frames_per_wave = atoi(e);
     ctx->tune.ra_ref_sum = getenv("JRC_RA_REF_SUM") != nullptr;

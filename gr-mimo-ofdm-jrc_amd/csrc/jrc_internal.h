@@ -40,6 +40,8 @@ struct jrc_ctx {
         bool chanest_x1 = false;     // JRC_CHANEST_X1: one subcarrier per lane in A1
         bool fd_serial = false;      // JRC_FD_SERIAL: single-wave detector scan
         bool sync_naive = false;     // JRC_SYNC_NAIVE: detection metrics without the LDS tile
+        bool sync_tile = false;      // JRC_SYNC_TILE: the front end's peak mask from the one-sample-per-lane tile kernel
+        bool sync_streams = false;   // JRC_SYNC_STREAMS: the front end writes the three metric streams and reads them back (the form before round 4)
         bool dec_single = false;     // JRC_DEC_SINGLE: the first-generation Viterbi decoder kernel (one frame per wave, LDS path ring)
         int dec_frames_per_wave = 0; // JRC_DEC_FPW: 1 or 2 frames per wave in the decoder (0 = by batch size)
         bool ra_ref_sum = false;     // JRC_RA_REF_SUM: the estimator's noise sum always by the reference-order double chain (tests)

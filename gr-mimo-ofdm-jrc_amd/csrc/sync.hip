@@ -90,9 +90,16 @@ __global__ void sync_metrics_kernel(const float2* __restrict__ x, int n, int del
 // once per sample, then summed in a tree — runs of 4, runs of 16 (4 runs of 4), and the window as its runs of 16, of 4 and single
 // samples, oldest first.  Additions only (no running sum, no prefix differences: a 60 dB power step inside the tile costs nothing),
 // ~12 LDS accesses per output instead of window + power_window global loads (80 at fft_len 64, 1280 at fft_len 1024).
+// MARKS = true is the run-to-completion front end's form (jrc_sync_frontend_dev): nobody downstream of the detector's peak test reads the three
+// streams there — the test `threshold < cor < MAX_PEAK_VALUE` (lib/frame_detector_impl.cc:95) is taken on the value in the register and one
+// ballot word per 64 samples is all that reaches HBM (1 bit per sample written instead of 20 bytes, and no second kernel reading `cor` back);
+// the correlation the detector needs at a detection is re-formed by the scanning wave with the same tree (sm_abs_at), the delayed samples the
+// synchroniser copies are read from x at an offset.
 #define SM_TILE 1024
+template <bool MARKS>
 __global__ __launch_bounds__(256) void sync_metrics_tiled_kernel(const float2* __restrict__ x, int n, int delay, int window, int pwindow, float pscale,
-                                                                 float2* __restrict__ xd, float2* __restrict__ in_abs, float* __restrict__ in_cor)
+                                                                 float2* __restrict__ xd, float2* __restrict__ in_abs, float* __restrict__ in_cor,
+                                                                 unsigned long long* __restrict__ marks, double thr, double maxv)
 {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) float2 sm_lds[];
@@ -119,8 +126,8 @@ __global__ __launch_bounds__(256) void sync_metrics_tiled_kernel(const float2* _
         if (k >= delay && g >= delay) {                                   // the delayed stream starts with zeros
             const float2 v = A[k - delay];                                // conj(v) * u
             pr = make_float2(v.x * u.x + v.y * u.y, v.x * u.y - v.y * u.x);
-            if (k >= halo && g < n) xd[g] = v;
-        } else if (k >= halo && g < n) xd[g] = make_float2(0.f, 0.f);
+            if (!MARKS && k >= halo && g < n) xd[g] = v;
+        } else if (!MARKS && k >= halo && g < n) xd[g] = make_float2(0.f, 0.f);
         B[k] = pr;
         Cw[k] = u.x * u.x + u.y * u.y;
     }
@@ -141,22 +148,206 @@ __global__ __launch_bounds__(256) void sync_metrics_tiled_kernel(const float2* _
     const int p16 = pwindow >> 4, p4 = (pwindow >> 2) & 3, p1 = pwindow & 3;
     for (int t = tid; t < SM_TILE; t += 256) {
         const long i = i0 + t;
-        if (i >= n) break;
-        const int k = halo + t;
+        const bool valid = i < n;
+        if (!MARKS && !valid) break;
         float2 a = make_float2(0.f, 0.f);
-        int j = k - window + 1;
-        for (int m = 0; m < w16; m++, j += 16) { a.x = a.x + E[j].x; a.y = a.y + E[j].y; }
-        for (int m = 0; m < w4; m++, j += 4) { a.x = a.x + A[j].x; a.y = a.y + A[j].y; }
-        for (int m = 0; m < w1; m++, j++) { a.x = a.x + B[j].x; a.y = a.y + B[j].y; }
-        float p = 0.f;
-        j = k - pwindow + 1;
-        for (int m = 0; m < p16; m++, j += 16) p = p + Fw[j];
-        for (int m = 0; m < p4; m++, j += 4) p = p + Dw[j];
-        for (int m = 0; m < p1; m++, j++) p = p + Cw[j];
-        in_abs[i] = a;
-        in_cor[i] = ref_hypotf(a) / fabsf(p * pscale);
+        float cor = 0.f;
+        if (valid) {
+            const int k = halo + t;
+            int j = k - window + 1;
+            for (int m = 0; m < w16; m++, j += 16) { a.x = a.x + E[j].x; a.y = a.y + E[j].y; }
+            for (int m = 0; m < w4; m++, j += 4) { a.x = a.x + A[j].x; a.y = a.y + A[j].y; }
+            for (int m = 0; m < w1; m++, j++) { a.x = a.x + B[j].x; a.y = a.y + B[j].y; }
+            float p = 0.f;
+            j = k - pwindow + 1;
+            for (int m = 0; m < p16; m++, j += 16) p = p + Fw[j];
+            for (int m = 0; m < p4; m++, j += 4) p = p + Dw[j];
+            for (int m = 0; m < p1; m++, j++) p = p + Cw[j];
+            cor = ref_hypotf(a) / fabsf(p * pscale);
+        }
+        if (MARKS) {                                                   // fd_marks_kernel's test and word layout (one word past the end when n % 64 != 0)
+            const unsigned long long m = __ballot(valid && ((double)cor > thr) && ((double)cor < maxv));
+            if ((tid & 63) == 0 && i < (long)n + 63) marks[i >> 6] = m;
+        } else {
+            in_abs[i] = a;
+            in_cor[i] = cor;
+        }
     }
 }
+
+// The marks-only metrics for windows that are whole runs of 16 (window, power_window multiples of 16, delay a multiple of 4: fft_len 64 has
+// 48 / 64 / 16), four consecutive samples per lane: the products and powers of a lane's samples stay in registers, runs of 4 need the three
+// products behind them (the next lane's, formed again here rather than fetched), runs of 16 the runs of 4 of the next three lanes (through LDS),
+// the window sums the runs of 16 of earlier lanes (through LDS).  Every LDS access is 16 bytes wide and aligned: lane t holds local samples
+// 4t .. 4t+3 of a 4 * SMK_NT sample tile whose first `halo` samples (a number = 3 mod 4, so that k - (window - 1) is a multiple of 4 for the
+// outputs k = halo + 4t' + i) only feed the sums.  Same products, same tree and the same test as sync_metrics_tiled_kernel<true> — the masks
+// are equal bit for bit (tests/test_gpu_sync.py) — with 8 LDS instructions per sample instead of 32.
+// The test itself: `threshold < cor < MAX_PEAK_VALUE` on cor = (float)sqrt((double)|a|^2) / |p * pscale| promoted to double.  A float
+// estimate of cor (relative error < 1e-6) decides every sample further than 1e-5 from both bounds; only the others take the exact form.
+#define SMK_NT 512
+#define SMK_L (4 * SMK_NT)
+__global__ __launch_bounds__(SMK_NT) void sync_marks_kernel(const float2* __restrict__ x, int n, int delay, int window, int pwindow, float pscale, int T, int halo,
+                                                            unsigned long long* __restrict__ marks, double thr, double maxv, float thr_dn, float thr_up,
+                                                            float max_dn, float max_up)
+{
+#pragma clang fp contract(off)
+    __shared__ __attribute__((aligned(16))) float2 XE[SMK_L + 16];       // samples, later the runs of 16 of the products
+    __shared__ __attribute__((aligned(16))) float2 As[SMK_L + 16];       // runs of 4 of the products
+    __shared__ __attribute__((aligned(16))) float Ds[SMK_L + 16];        // runs of 4 of the powers
+    __shared__ __attribute__((aligned(16))) float Fs[SMK_L + 16];        // runs of 16 of the powers
+    const int t = threadIdx.x, k0 = 4 * t;
+    const long i0 = (long)blockIdx.x * T;
+    const long g0 = i0 - halo;
+    const long g = g0 + k0;
+    float2 u[7], v[7];
+    if (g >= 0 && g + 3 < n) {
+#pragma unroll
+        for (int m = 0; m < 4; m++) u[m] = x[g + m];
+    } else {
+#pragma unroll
+        for (int m = 0; m < 4; m++) u[m] = (g + m >= 0 && g + m < n) ? x[g + m] : make_float2(0.f, 0.f);
+    }
+    float4* XE4 = (float4*)XE;
+    XE4[2 * t] = make_float4(u[0].x, u[0].y, u[1].x, u[1].y);
+    XE4[2 * t + 1] = make_float4(u[2].x, u[2].y, u[3].x, u[3].y);
+    if (t < 8) XE4[2 * SMK_NT + t] = make_float4(0.f, 0.f, 0.f, 0.f);   // the 16 samples behind the tile: read by the last lanes, used by no output
+    __syncthreads();
+    {
+        const float4 a = XE4[2 * t + 2], b = XE4[2 * t + 3];
+        u[4] = make_float2(a.x, a.y); u[5] = make_float2(a.z, a.w); u[6] = make_float2(b.x, b.y);
+    }
+    if (k0 >= delay) {
+        const float4* V4 = XE4 + ((k0 - delay) >> 1);
+        const float4 a = V4[0], b = V4[1], c = V4[2], d = V4[3];
+        v[0] = make_float2(a.x, a.y); v[1] = make_float2(a.z, a.w); v[2] = make_float2(b.x, b.y); v[3] = make_float2(b.z, b.w);
+        v[4] = make_float2(c.x, c.y); v[5] = make_float2(c.z, c.w); v[6] = make_float2(d.x, d.y);
+    } else {
+#pragma unroll
+        for (int m = 0; m < 7; m++) v[m] = make_float2(0.f, 0.f);
+    }
+    float2 B[7];
+    float C[7];
+#pragma unroll
+    for (int m = 0; m < 7; m++) {
+        B[m] = make_float2(v[m].x * u[m].x + v[m].y * u[m].y, v[m].x * u[m].y - v[m].y * u[m].x);       // conj(v) * u
+        if (g + m < delay) B[m] = make_float2(0.f, 0.f);                                                // the delayed stream starts with zeros
+        C[m] = u[m].x * u[m].x + u[m].y * u[m].y;
+    }
+    float2 A[4];
+    float D[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        A[i] = make_float2(((B[i].x + B[i + 1].x) + B[i + 2].x) + B[i + 3].x, ((B[i].y + B[i + 1].y) + B[i + 2].y) + B[i + 3].y);
+        D[i] = ((C[i] + C[i + 1]) + C[i + 2]) + C[i + 3];
+    }
+    float4* As4 = (float4*)As;
+    As4[2 * t] = make_float4(A[0].x, A[0].y, A[1].x, A[1].y);
+    As4[2 * t + 1] = make_float4(A[2].x, A[2].y, A[3].x, A[3].y);
+    ((float4*)Ds)[t] = make_float4(D[0], D[1], D[2], D[3]);
+    __syncthreads();
+    {
+        float2 E[4];
+        float F[4];
+        float2 An[3][4];
+        float Dn[3][4];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const float4 a = As4[2 * (t + r + 1)], b = As4[2 * (t + r + 1) + 1];
+            An[r][0] = make_float2(a.x, a.y); An[r][1] = make_float2(a.z, a.w); An[r][2] = make_float2(b.x, b.y); An[r][3] = make_float2(b.z, b.w);
+            const float4 d = ((const float4*)Ds)[t + r + 1];
+            Dn[r][0] = d.x; Dn[r][1] = d.y; Dn[r][2] = d.z; Dn[r][3] = d.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            E[i] = make_float2(((A[i].x + An[0][i].x) + An[1][i].x) + An[2][i].x, ((A[i].y + An[0][i].y) + An[1][i].y) + An[2][i].y);
+            F[i] = ((D[i] + Dn[0][i]) + Dn[1][i]) + Dn[2][i];
+        }
+        XE4[2 * t] = make_float4(E[0].x, E[0].y, E[1].x, E[1].y);          // the samples are dead: every read of them was before the last barrier
+        XE4[2 * t + 1] = make_float4(E[2].x, E[2].y, E[3].x, E[3].y);
+        ((float4*)Fs)[t] = make_float4(F[0], F[1], F[2], F[3]);
+    }
+    __syncthreads();
+    if (4 * t >= T) return;                                                // whole waves: T is a multiple of 256
+    const int w16 = window >> 4, p16 = pwindow >> 4;
+    float2 a[4];
+    float pw[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { a[i] = make_float2(0.f, 0.f); pw[i] = 0.f; }
+    {
+        const float4* E4 = XE4 + ((halo - (window - 1) + 4 * t) >> 1);
+        for (int m = 0; m < w16; m++, E4 += 8) {
+            const float4 e0 = E4[0], e1 = E4[1];
+            a[0].x = a[0].x + e0.x; a[0].y = a[0].y + e0.y; a[1].x = a[1].x + e0.z; a[1].y = a[1].y + e0.w;
+            a[2].x = a[2].x + e1.x; a[2].y = a[2].y + e1.y; a[3].x = a[3].x + e1.z; a[3].y = a[3].y + e1.w;
+        }
+        const float4* F4 = (const float4*)Fs + ((halo - (pwindow - 1) + 4 * t) >> 2);
+        for (int m = 0; m < p16; m++, F4 += 4) {
+            const float4 f = F4[0];
+            pw[0] = pw[0] + f.x; pw[1] = pw[1] + f.y; pw[2] = pw[2] + f.z; pw[3] = pw[3] + f.w;
+        }
+    }
+    unsigned long long bits[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const long ig = i0 + 4 * t + i;
+        const float den = fabsf(pw[i] * pscale);
+        const float est = __builtin_amdgcn_sqrtf(fmaf(a[i].x, a[i].x, a[i].y * a[i].y)) * __builtin_amdgcn_rcpf(den);
+        bool pk = est > thr_up && est < max_dn;
+        if (!pk && !(est < thr_dn || est > max_up)) {                      // within 1e-5 of a bound (or not a number): the reference's own arithmetic
+            const float cor = ref_hypotf(a[i]) / den;
+            pk = ((double)cor > thr) && ((double)cor < maxv);
+        }
+        bits[i] = __ballot(pk && ig < n);
+    }
+    // lane l holds samples 4l .. 4l+3 of the wave's 256: word m = lanes 16m .. 16m+15, bit 4q+i of it = bits[i] of lane 16m+q
+    const int lane = t & 63;
+    if (lane < 4) {
+        unsigned long long wd = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            unsigned long long f = (bits[i] >> (16 * lane)) & 0xffffull;
+            f = (f | (f << 24)) & 0x000000ff000000ffull;
+            f = (f | (f << 12)) & 0x000f000f000f000full;
+            f = (f | (f << 6)) & 0x0303030303030303ull;
+            f = (f | (f << 3)) & 0x1111111111111111ull;
+            wd |= f << i;
+        }
+        const long ws = i0 + 4 * (t - lane) + 64 * lane;                   // first sample of the word
+        if (ws < (long)n + 63) marks[ws >> 6] = wd;
+    }
+}
+
+// in_abs[i] as the tiled kernel forms it (same products, same tree: runs of 16 of runs of 4, then runs of 4, then single products, oldest
+// first), for one sample, by one lane: the detector reads it once per detection (lib/frame_detector_impl.cc:112)
+__device__ float2 sm_abs_at(const float2* __restrict__ x, long i, int delay, int window)
+{
+#pragma clang fp contract(off)
+    auto B = [&](long g) -> float2 {
+        if (g < delay) return make_float2(0.f, 0.f);
+        const float2 u = x[g], v = x[g - delay];
+        return make_float2(v.x * u.x + v.y * u.y, v.x * u.y - v.y * u.x);
+    };
+    auto A4 = [&](long g) -> float2 {
+        const float2 a = B(g), b = B(g + 1), c = B(g + 2), d = B(g + 3);
+        return make_float2(((a.x + b.x) + c.x) + d.x, ((a.y + b.y) + c.y) + d.y);
+    };
+    auto E16 = [&](long g) -> float2 {
+        const float2 a = A4(g), b = A4(g + 4), c = A4(g + 8), d = A4(g + 12);
+        return make_float2(((a.x + b.x) + c.x) + d.x, ((a.y + b.y) + c.y) + d.y);
+    };
+    const int w16 = window >> 4, w4 = (window >> 2) & 3, w1 = window & 3;
+    float2 a = make_float2(0.f, 0.f);
+    long j = i - window + 1;
+    for (int m = 0; m < w16; m++, j += 16) { const float2 e = E16(j); a.x = a.x + e.x; a.y = a.y + e.y; }
+    for (int m = 0; m < w4; m++, j += 4) { const float2 e = A4(j); a.x = a.x + e.x; a.y = a.y + e.y; }
+    for (int m = 0; m < w1; m++, j++) { const float2 e = B(j); a.x = a.x + e.x; a.y = a.y + e.y; }
+    return a;
+}
+// where the scans take the correlation of a detection from: the stream (in_abs != NULL) or the capture itself
+struct FdAbs {
+    const float2* in_abs; const float2* x; int delay, window;
+    __device__ float2 at(int i) const { return in_abs ? in_abs[i] : sm_abs_at(x, i, delay, window); }
+};
 
 extern "C" int jrc_sync_metrics_dev(jrc_ctx* ctx, int n, int delay, int window, int pwindow, float pscale, const jrc_cf32* d_x,
                                     jrc_cf32* d_xd, jrc_cf32* d_in_abs, float* d_in_cor, void* stream)
@@ -168,9 +359,9 @@ extern "C" int jrc_sync_metrics_dev(jrc_ctx* ctx, int n, int delay, int window, 
     const size_t L = (size_t)SM_TILE + (size_t)(window > pwindow ? window : pwindow) - 1 + (size_t)delay;
     const size_t lds = L * (3 * sizeof(float2) + 3 * sizeof(float));
     if (lds <= 150 * 1024 && !ctx->tune.sync_naive) {
-        JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)sync_metrics_tiled_kernel, lds));
-        hipLaunchKernelGGL(sync_metrics_tiled_kernel, dim3((n + SM_TILE - 1) / SM_TILE), dim3(256), lds, s, (const float2*)d_x, n, delay, window, pwindow,
-                           pscale, (float2*)d_xd, (float2*)d_in_abs, d_in_cor);
+        JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)sync_metrics_tiled_kernel<false>, lds));
+        hipLaunchKernelGGL(sync_metrics_tiled_kernel<false>, dim3((n + SM_TILE - 1) / SM_TILE), dim3(256), lds, s, (const float2*)d_x, n, delay, window, pwindow,
+                           pscale, (float2*)d_xd, (float2*)d_in_abs, d_in_cor, (unsigned long long*)nullptr, 0.0, 0.0);
     } else {        // windows too long for an LDS tile: one lane per output, window + power_window loads each
         hipLaunchKernelGGL(sync_metrics_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const float2*)d_x, n, delay, window, pwindow, pscale,
                            (float2*)d_xd, (float2*)d_in_abs, d_in_cor);
@@ -687,7 +878,7 @@ struct SfFrame { int start, len; float coarse_cfo; int frame_start; float fine_c
 // one wave: the lanes fetch 64 mask words (4096 samples) at a time, the state machine itself is wave-uniform and steps
 // through them from registers; stretches without a peak bit are skipped a word — or, with no peak run open, a whole fetch —
 // at a time
-__global__ __launch_bounds__(64) void fd_scan_all_kernel(FdParams p, const unsigned long long* __restrict__ marks, const float2* __restrict__ in_abs,
+__global__ __launch_bounds__(64) void fd_scan_all_kernel(FdParams p, const unsigned long long* __restrict__ marks, FdAbs src,
                                                         int n, SfFrame* __restrict__ frames, int max_frames, int* __restrict__ n_frames)
 {
     const int lane = threadIdx.x;
@@ -775,7 +966,7 @@ __global__ __launch_bounds__(64) void fd_scan_all_kernel(FdParams p, const unsig
                 if (detect) {                                    // SEARCH -> COPY (:108-118) or a new frame inside COPY (:153-165)
                     if (nf == max_frames) { full = true; break; }
                     flush();
-                    const float2 av = in_abs[i];
+                    const float2 av = src.at(i);
                     state = 1; copied = 0;
                     nf++; cur_start = i; cur_len = 0;
                     cur_cfo = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)((double)atan2f(av.y, av.x) / (p.fft_len / 4.0)))));
@@ -804,7 +995,7 @@ __global__ __launch_bounds__(64) void fd_scan_all_kernel(FdParams p, const unsig
 #define FD_SEG_WORDS 64
 
 template <bool WRITE>
-__global__ __launch_bounds__(64) void fd_scan_seg_kernel(FdParams p, const unsigned long long* __restrict__ marks, const float2* __restrict__ in_abs,
+__global__ __launch_bounds__(64) void fd_scan_seg_kernel(FdParams p, const unsigned long long* __restrict__ marks, FdAbs src,
                                                          int n, int G, int* __restrict__ counts, SfFrame* __restrict__ frames, int max_frames,
                                                          int* __restrict__ overflow_start)
 {
@@ -905,7 +1096,7 @@ __global__ __launch_bounds__(64) void fd_scan_seg_kernel(FdParams p, const unsig
                     if (WRITE) {
                         const int idx = out_idx + nd;
                         if (idx < max_frames) {
-                            const float2 av = in_abs[i];
+                            const float2 av = src.at(i);
                             if (lane == 0) {
                                 SfFrame f; f.start = i; f.len = 0; f.coarse_cfo = (float)((double)atan2f(av.y, av.x) / (p.fft_len / 4.0));
                                 f.frame_start = 0; f.fine_cfo = 0.f; f.tag_value = 0; f.n_out = 0; f.pad_ = 0;
@@ -954,7 +1145,7 @@ __global__ __launch_bounds__(256) void fd_scan_finish_kernel(FdParams p, const i
 }
 
 // list the frames of a capture: segment-parallel scan (JRC_FD_SERIAL=1: the single-wave scan, kept for cross-checks)
-static int launch_fd_scan(jrc_ctx* ctx, const FdParams& p, const unsigned long long* d_marks, const float2* d_abs, int n_samples, SfFrame* d_info,
+static int launch_fd_scan(jrc_ctx* ctx, const FdParams& p, const unsigned long long* d_marks, FdAbs d_abs, int n_samples, SfFrame* d_info,
                           int max_frames, int* d_n_frames, hipStream_t s)
 {
     const int n_seg = (n_samples + FD_SEG_WORDS * 64 - 1) / (FD_SEG_WORDS * 64);
@@ -975,7 +1166,8 @@ static int launch_fd_scan(jrc_ctx* ctx, const FdParams& p, const unsigned long l
     return JRC_OK;
 }
 
-__global__ __launch_bounds__(256) void sf_frames_kernel(const float2* __restrict__ xd, int n, const float2* __restrict__ taps, int ntaps,
+__global__ __launch_bounds__(256) void sf_frames_kernel(const float2* __restrict__ xs, int xs_delay /* xd[g] = xs[g - xs_delay], 0 before the stream starts */, int n,
+                                                        const float2* __restrict__ taps, int ntaps,
                                                         int sync_length, int N, int cp, SfFrame* __restrict__ frames, const int* __restrict__ n_frames,
                                                         float2* __restrict__ out, long out_stride /* samples per row */)
 {
@@ -994,7 +1186,8 @@ __global__ __launch_bounds__(256) void sf_frames_kernel(const float2* __restrict
         if (so >= fr.len || fr.start + so >= n) return make_float2(0.f, 0.f);
         float sn, cs;
         sincosf(-fr.coarse_cfo * (float)so, &sn, &cs);
-        return cmul(xd[fr.start + so], make_float2(cs, sn));
+        const int g = fr.start + so - xs_delay;
+        return g >= 0 ? cmul(xs[g], make_float2(cs, sn)) : make_float2(0.f, 0.f);
     };
     for (int i = threadIdx.x; i < sync_length + ntaps - 1; i += blockDim.x) s_in[i] = det_out(i);
     __syncthreads();
@@ -1053,15 +1246,40 @@ extern "C" int jrc_sync_frontend_dev(jrc_ctx* ctx, const jrc_sync_cfg* c, int n_
     float2* d_abs = d_xd + n;
     float* d_cor = (float*)(d_abs + n);
     unsigned long long* d_marks = (unsigned long long*)(d_cor + ((n + 1) & ~(size_t)1));
-    JRC_TRY(jrc_sync_metrics_dev(ctx, n_samples, c->delay, c->window, c->power_window, c->power_scale, d_x, (jrc_cf32*)d_xd, (jrc_cf32*)d_abs, d_cor, s));
     FdParams p;
     p.fft_len = c->fft_len; p.min_n_peaks = (int)c->min_n_peaks; p.ignore_gap = (int)c->ignore_gap; p.threshold = c->threshold; p.max_peak_value = 2.0;
     p.max_peak_distance = 2 * (c->fft_len + c->cp_len); p.max_samples = 540 * (c->fft_len + c->cp_len);
-    const int nblk = (n_samples + 63 + 255) / 256;
-    hipLaunchKernelGGL(fd_marks_kernel, dim3(nblk > 0 ? nblk : 1), dim3(256), 0, s, (const float*)d_cor, d_marks, n_samples, p.threshold, p.max_peak_value);
-    JRC_TRY(launch_fd_scan(ctx, p, (const unsigned long long*)d_marks, (const float2*)d_abs, n_samples, (SfFrame*)d_info, max_frames, d_n_frames, s));
+    const size_t tile = (size_t)SM_TILE + (size_t)(c->window > c->power_window ? c->window : c->power_window) - 1 + (size_t)c->delay;
+    const size_t tile_lds = tile * (3 * sizeof(float2) + 3 * sizeof(float));
+    const float2* d_delayed = nullptr;                            // the delayed stream as an array of its own (three-kernel form), else x at an offset
+    FdAbs src;
+    if (n_samples > 0 && tile_lds <= 150 * 1024 && !ctx->tune.sync_naive && !ctx->tune.sync_streams) {
+        // the metric streams never reach HBM: peak mask straight from the tile kernel, correlation re-formed at the detections (see sync_metrics_tiled_kernel)
+        const int halo = (c->window > c->power_window ? c->window : c->power_window) - 1 + c->delay;
+        const int T = ((SMK_L - halo) / 256) * 256;
+        if (c->window % 16 == 0 && c->power_window % 16 == 0 && c->delay % 4 == 0 && T >= 256 && !ctx->tune.sync_tile) {
+            const double m = 1e-5;
+            hipLaunchKernelGGL(sync_marks_kernel, dim3((n_samples + T - 1) / T), dim3(SMK_NT), 0, s, (const float2*)d_x, n_samples, c->delay, c->window,
+                               c->power_window, c->power_scale, T, halo, d_marks, p.threshold, p.max_peak_value, (float)(p.threshold * (1 - m)),
+                               (float)(p.threshold * (1 + m)), (float)(p.max_peak_value * (1 - m)), (float)(p.max_peak_value * (1 + m)));
+        } else {
+        JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)sync_metrics_tiled_kernel<true>, tile_lds));
+        hipLaunchKernelGGL(sync_metrics_tiled_kernel<true>, dim3((n_samples + SM_TILE - 1) / SM_TILE), dim3(256), tile_lds, s, (const float2*)d_x, n_samples,
+                           c->delay, c->window, c->power_window, c->power_scale, (float2*)nullptr, (float2*)nullptr, (float*)nullptr, d_marks, p.threshold,
+                           p.max_peak_value);
+        }
+        src.in_abs = nullptr; src.x = (const float2*)d_x; src.delay = c->delay; src.window = c->window;
+    } else {
+        JRC_TRY(jrc_sync_metrics_dev(ctx, n_samples, c->delay, c->window, c->power_window, c->power_scale, d_x, (jrc_cf32*)d_xd, (jrc_cf32*)d_abs, d_cor, s));
+        const int nblk = (n_samples + 63 + 255) / 256;
+        hipLaunchKernelGGL(fd_marks_kernel, dim3(nblk > 0 ? nblk : 1), dim3(256), 0, s, (const float*)d_cor, d_marks, n_samples, p.threshold, p.max_peak_value);
+        src.in_abs = d_abs; src.x = nullptr; src.delay = 0; src.window = 0;
+        d_delayed = d_xd;
+    }
+    JRC_TRY(launch_fd_scan(ctx, p, (const unsigned long long*)d_marks, src, n_samples, (SfFrame*)d_info, max_frames, d_n_frames, s));
     const size_t lds = sizeof(float2) * ((size_t)2 * c->sync_length + c->n_taps - 1);
-    hipLaunchKernelGGL(sf_frames_kernel, dim3(max_frames), dim3(256), lds, s, (const float2*)d_xd, n_samples, (const float2*)c->d_ltf_taps, c->n_taps,
+    hipLaunchKernelGGL(sf_frames_kernel, dim3(max_frames), dim3(256), lds, s, d_delayed ? d_delayed : (const float2*)d_x, d_delayed ? 0 : c->delay, n_samples,
+                       (const float2*)c->d_ltf_taps, c->n_taps,
                        c->sync_length, c->fft_len, c->cp_len, (SfFrame*)d_info, (const int*)d_n_frames, (float2*)d_frames, (long)max_symbols * c->fft_len);
     JRC_HIP(ctx, hipGetLastError());
     return JRC_OK;
@@ -1080,7 +1298,8 @@ extern "C" int jrc_frame_detector_scan_dev(jrc_ctx* ctx, int fft_len, int cp_len
     p.max_peak_distance = 2 * (fft_len + cp_len); p.max_samples = 540 * (fft_len + cp_len);
     const int nblk = (n_samples + 63 + 255) / 256;
     hipLaunchKernelGGL(fd_marks_kernel, dim3(nblk > 0 ? nblk : 1), dim3(256), 0, s, d_in_cor, d_marks, n_samples, p.threshold, p.max_peak_value);
-    JRC_TRY(launch_fd_scan(ctx, p, (const unsigned long long*)d_marks, (const float2*)d_in_abs, n_samples, (SfFrame*)d_info, max_frames, d_n_frames, s));
+    FdAbs src; src.in_abs = (const float2*)d_in_abs; src.x = nullptr; src.delay = 0; src.window = 0;
+    JRC_TRY(launch_fd_scan(ctx, p, (const unsigned long long*)d_marks, src, n_samples, (SfFrame*)d_info, max_frames, d_n_frames, s));
     JRC_HIP(ctx, hipGetLastError());
     return JRC_OK;
 }

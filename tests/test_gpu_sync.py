@@ -216,3 +216,51 @@ def _scan_case(jrc, ctx, seed, density, min_peaks, gap, max_frames, max_quiet):
         assert f.len == offs[k + 1] - offs[k], k
         assert f.len == 0 or f.start == int(round(out[offs[k]].real)), k
         assert abs(f.coarse_cfo - tags[k][1]) < 1e-6
+
+
+def _front_end_outputs(jrc, env, monkeypatch, x, max_frames, n_list=None):
+    """mask words, frame list and frame rows of one front-end run in a context of its own (the switches are read when a context is made)"""
+    import torch
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    c = jrc.Context(0)
+    for k in env:
+        monkeypatch.delenv(k)
+    from conftest import GOLDEN  # noqa: F401
+    import os
+    o = np.load(os.path.join(GOLDEN, "ofdm_config_64.npz"))
+    fe = jrc.SyncFrontEnd(N, CP, 0.6, 10, 8 * (N + CP), SYNC_LEN, o["l_ltf_fir"], max_frames=max_frames, max_symbols=40, ctx=c)
+    d_x = torch.from_numpy(x.view(np.float32).reshape(-1, 2).copy()).cuda()
+    out = []
+    for n in (n_list or [x.size]):
+        fe._work = None
+        fe.frames.zero_()
+        torch.cuda.synchronize()
+        fe.run(d_x, n)
+        nf, info = fe.results()
+        off = 2 * n * 8 + ((n + 1) & ~1) * 4
+        words = fe._work[off:off + 8 * ((n + 63) // 64)].cpu().numpy().view(np.uint64).copy()
+        out.append((words, nf, [(f.start, f.len, f.coarse_cfo, f.frame_start, f.fine_cfo, f.tag_value, f.n_out) for f in info],
+                    fe.frames[:nf].cpu().numpy().tobytes()))
+    c.close()
+    return out
+
+
+def test_front_end_forms_agree_bit_for_bit(jrc, monkeypatch, ofdm64):
+    """the three forms of the front end's first stage — four samples per lane with the float pre-test (default), one sample per lane
+    (JRC_SYNC_TILE), the three metric streams through HBM + fd_marks_kernel (JRC_SYNC_STREAMS) — leave the same peak mask, the same frame
+    list (incl. the coarse CFO re-formed at the detections) and the same frame rows; capture lengths around the tile and word boundaries,
+    noise at the level where the correlation sits at the threshold for many samples"""
+    rng = np.random.default_rng(77)
+    x, _ = capture(ofdm64, 9, cfo=0.008, n_frames=7, gap=1800)
+    x = x + (0.05 * (rng.standard_normal(x.size) + 1j * rng.standard_normal(x.size))).astype(np.complex64)
+    x[5000:5400] = 0                                                 # an all-zero stretch: 0 / 0 in the metric
+    n_list = [x.size, x.size - 1, 1792 * 3, 1792 * 3 + 1, 1792 * 3 - 63, 2000, 64, 63, 1]
+    want = _front_end_outputs(jrc, {"JRC_SYNC_STREAMS": "1"}, monkeypatch, x, 16, n_list)
+    assert want[0][1] == 7 and int(sum(bin(int(w)).count("1") for w in want[0][0])) > 200
+    for env in ({}, {"JRC_SYNC_TILE": "1"}):
+        got = _front_end_outputs(jrc, env, monkeypatch, x, 16, n_list)
+        for n, w, g in zip(n_list, want, got):
+            assert np.array_equal(w[0], g[0]), (env, n, "peak mask")
+            assert w[1] == g[1] and w[2] == g[2], (env, n, "frame list")
+            assert w[3] == g[3], (env, n, "frame rows")
