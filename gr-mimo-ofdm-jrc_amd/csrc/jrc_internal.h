@@ -126,6 +126,25 @@ __device__ __forceinline__ double ref_power_f64(float2 z)
     float h = (float)sqrt(d);
     return (double)h * (double)h;
 }
+// sin and cos of a float angle within 1.5 ulp / 9.3e-8 absolute over |a| < 2^15 (numpy emulation against float64; ocml sincosf: 2 ulp), for the
+// de-rotation loops that take one per sample: Cody-Waite reduction by pi/2 in two fused steps (exact for |a| < 2^15: a - n * float(pi/2) has
+// at most 23 significant bits below 1), the single-precision minimax polynomials of Cephes' sinf / cosf on [-pi/4, pi/4], quadrant from n.
+// About 25 instructions; ocml's sincosf is several times that.  Larger angles and non-numbers go to sincosf.
+__device__ __forceinline__ void jrc_sincosf_fast(float a, float* sn, float* cs)
+{
+    if (!(fabsf(a) < 32768.f)) { sincosf(a, sn, cs); return; }
+    const float n = rintf(a * 0.636619772367581343f);
+    float r = fmaf(n, -1.57079637050628662109375f, a);
+    r = fmaf(n, 4.37113882867379223e-8f, r);
+    const float z = r * r;
+    const float s = fmaf(r * z, fmaf(z, fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), r);
+    const float c = fmaf(z * z, fmaf(z, fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f), fmaf(z, -0.5f, 1.0f));
+    const int q = (int)n;
+    const float ss = (q & 1) ? c : s, cc = (q & 1) ? s : c;
+    *sn = (q & 2) ? -ss : ss;
+    *cs = ((q + 1) & 2) ? -cc : cc;
+}
+
 __device__ __forceinline__ float ref_hypotf(float2 z)
 {
     double d = (double)z.x * (double)z.x + (double)z.y * (double)z.y;

@@ -1004,12 +1004,8 @@ __global__ __launch_bounds__(64) void fd_scan_seg_kernel(FdParams p, const unsig
     const long seg_start = (long)w * FD_SEG_WORDS * 64;
     const long seg_end = min((long)n, seg_start + (long)FD_SEG_WORDS * 64);
     int out_idx = 0;
-    if (WRITE) {                                                 // detections of the waves before this one
-        int sum = 0;
-        for (int i = lane; i < w; i += 64) sum += counts[i];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
-        out_idx = __builtin_amdgcn_readfirstlane(sum);
+    if (WRITE) {                                                 // detections of the waves before this one (fd_scan_prefix_kernel)
+        out_idx = counts[w];
         if (out_idx > max_frames) return;                        // everything from here on is beyond the caller's list
     }
     bool running = (w == 0), done = false;
@@ -1120,28 +1116,55 @@ __global__ __launch_bounds__(64) void fd_scan_seg_kernel(FdParams p, const unsig
     if (!WRITE && lane == 0) counts[w] = nd;
 }
 
-__global__ __launch_bounds__(256) void fd_scan_finish_kernel(FdParams p, const int* __restrict__ counts, int n_seg, int n, SfFrame* __restrict__ frames,
+// exclusive prefix sums of the segments' detection counts, 1024 segments per workgroup: sums of the blocks first, then every block scans its
+// own counts behind the sum of the blocks before it; the total lands behind the last prefix
+__global__ __launch_bounds__(1024) void fd_scan_blocksum_kernel(const int* __restrict__ counts, int n_seg, int* __restrict__ blocksum)
+{
+    __shared__ int s_wave[16];
+    const int t = threadIdx.x, i = blockIdx.x * 1024 + t;
+    int v = i < n_seg ? counts[i] : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((t & 63) == 0) s_wave[t >> 6] = v;
+    __syncthreads();
+    if (t == 0) { int sum = 0; for (int k = 0; k < 16; k++) sum += s_wave[k]; blocksum[blockIdx.x] = sum; }
+}
+__global__ __launch_bounds__(1024) void fd_scan_prefix_kernel(const int* __restrict__ counts, int n_seg, const int* __restrict__ blocksum, int* __restrict__ prefix)
+{
+    __shared__ int s_wave[16], s_base[16];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, i = blockIdx.x * 1024 + t;
+    int before = 0;
+    for (int k = t; k < (int)blockIdx.x; k += 1024) before += blocksum[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off);
+    if (lane == 0) s_base[wv] = before;
+    const int v = i < n_seg ? counts[i] : 0;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off); if (lane >= off) incl += o; }
+    if (lane == 63) s_wave[wv] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < 16; k++) base += s_base[k];
+    for (int k = 0; k < wv; k++) base += s_wave[k];
+    if (i < n_seg) prefix[i] = base + incl - v;
+    if (i == n_seg - 1) prefix[n_seg] = base + incl;
+}
+
+// the frame count and the copy lengths (next detection - start, capped by MAX_SAMPLES and by the end of the capture / of the caller's list)
+__global__ __launch_bounds__(256) void fd_scan_finish_kernel(FdParams p, const int* __restrict__ prefix, int n_seg, int n, SfFrame* __restrict__ frames,
                                                              int max_frames, const int* __restrict__ overflow_start, int* __restrict__ n_frames)
 {
-    __shared__ int s_part[256];
-    int sum = 0;
-    for (int i = threadIdx.x; i < n_seg; i += 256) sum += counts[i];
-    s_part[threadIdx.x] = sum;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) s_part[threadIdx.x] += s_part[threadIdx.x + off];
-        __syncthreads();
-    }
-    const int total = s_part[0];
+    const int total = prefix[n_seg];
     const int nf = total < max_frames ? total : max_frames;
-    if (threadIdx.x == 0) *n_frames = nf;
-    for (int k = threadIdx.x; k < nf; k += 256) {
-        const int start = frames[k].start;
-        const int next = (k + 1 < nf) ? frames[k + 1].start : (total > max_frames ? *overflow_start : n);
-        int len = next - start;
-        if (len > p.max_samples) len = p.max_samples;
-        frames[k].len = len;
-    }
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k == 0) *n_frames = nf;
+    if (k >= nf) return;
+    const int start = frames[k].start;
+    const int next = (k + 1 < nf) ? frames[k + 1].start : (total > max_frames ? *overflow_start : n);
+    int len = next - start;
+    if (len > p.max_samples) len = p.max_samples;
+    frames[k].len = len;
 }
 
 // list the frames of a capture: segment-parallel scan (JRC_FD_SERIAL=1: the single-wave scan, kept for cross-checks)
@@ -1154,14 +1177,20 @@ static int launch_fd_scan(jrc_ctx* ctx, const FdParams& p, const unsigned long l
         JRC_HIP(ctx, hipGetLastError());
         return JRC_OK;
     }
-    JRC_TRY(jrc_ensure_scratch(ctx, 3, sizeof(int) * ((size_t)n_seg + 16)));
+    const int n_blk = (n_seg + 1023) / 1024;
+    JRC_TRY(jrc_ensure_scratch(ctx, 3, sizeof(int) * (2 * (size_t)n_seg + n_blk + 16)));
     int* counts = (int*)ctx->scratch[3];
-    int* overflow = counts + n_seg;
+    int* prefix = counts + n_seg;                                   // [n_seg + 1]
+    int* overflow = prefix + n_seg + 1;
+    int* blocksum = overflow + 1;                                   // [n_blk]
     const int G = p.ignore_gap + p.max_peak_distance + 2;
     hipLaunchKernelGGL(fd_scan_seg_kernel<false>, dim3(n_seg), dim3(64), 0, s, p, d_marks, d_abs, n_samples, G, counts, d_info, max_frames, overflow);
-    hipLaunchKernelGGL(fd_scan_seg_kernel<true>, dim3(n_seg), dim3(64), 0, s, p, d_marks, d_abs, n_samples, G, counts, d_info, max_frames, overflow);
-    hipLaunchKernelGGL(fd_scan_finish_kernel, dim3(1), dim3(256), 0, s, p, (const int*)counts, n_seg, n_samples, d_info, max_frames, (const int*)overflow,
-                       d_n_frames);
+    hipLaunchKernelGGL(fd_scan_blocksum_kernel, dim3(n_blk), dim3(1024), 0, s, (const int*)counts, n_seg, blocksum);
+    hipLaunchKernelGGL(fd_scan_prefix_kernel, dim3(n_blk), dim3(1024), 0, s, (const int*)counts, n_seg, (const int*)blocksum, prefix);
+    hipLaunchKernelGGL(fd_scan_seg_kernel<true>, dim3(n_seg), dim3(64), 0, s, p, d_marks, d_abs, n_samples, G, prefix, d_info, max_frames, overflow);
+    const int cap = max_frames < n_samples ? max_frames : n_samples;  // a frame holds at least one sample
+    hipLaunchKernelGGL(fd_scan_finish_kernel, dim3((cap + 255) / 256 > 0 ? (cap + 255) / 256 : 1), dim3(256), 0, s, p, (const int*)prefix, n_seg, n_samples, d_info,
+                       max_frames, (const int*)overflow, d_n_frames);
     JRC_HIP(ctx, hipGetLastError());
     return JRC_OK;
 }
@@ -1185,7 +1214,7 @@ __global__ __launch_bounds__(256) void sf_frames_kernel(const float2* __restrict
     auto det_out = [&](int so) -> float2 {                      // what frame_detector hands over: xd de-rotated by the coarse CFO (:178)
         if (so >= fr.len || fr.start + so >= n) return make_float2(0.f, 0.f);
         float sn, cs;
-        sincosf(-fr.coarse_cfo * (float)so, &sn, &cs);
+        jrc_sincosf_fast(-fr.coarse_cfo * (float)so, &sn, &cs);
         const int g = fr.start + so - xs_delay;
         return g >= 0 ? cmul(xs[g], make_float2(cs, sn)) : make_float2(0.f, 0.f);
     };
@@ -1211,15 +1240,41 @@ __global__ __launch_bounds__(256) void sf_frames_kernel(const float2* __restrict
     const long kept = fs_kept_before(copy_len - fstart, N, cp);
     const long n_out = ((kept + N - 1) / N) * N;                  // RESET completes the last symbol with zeros (:204-223)
     float2* o = out + (size_t)f * out_stride;
-    for (long so = fstart + threadIdx.x; so < copy_len; so += blockDim.x) {
-        const long rel = so - fstart;
-        const bool keep = rel < 2L * N || ((rel - 2L * N) % (N + cp)) > cp - 1;
-        if (!keep) continue;
-        const long oi = fs_kept_before(rel, N, cp);
-        if (oi >= out_stride) continue;
+    // walked by OUTPUT index (the inverse of fs_kept_before): oi < 2N is sample rel = oi behind the frame start (the two long training symbols, no
+    // prefix between them), oi = 2N + q N + m is rel = 2N + q (N + cp) + cp + m; (q, m) advance by a constant per step, no division in the loop
+    const int lim = (int)(kept < out_stride ? kept : out_stride);
+    auto put = [&](int oi, int rel) {
+        const int so = fstart + rel;
         float sn, cs;
-        sincosf((float)so * fine, &sn, &cs);
-        o[oi] = cmul(det_out((int)so), make_float2(cs, sn));
+        jrc_sincosf_fast((float)so * fine, &sn, &cs);
+        o[oi] = cmul(det_out(so), make_float2(cs, sn));
+    };
+    for (int oi = threadIdx.x; oi < lim && oi < 2 * N; oi += blockDim.x) put(oi, oi);
+    {
+        int q = (int)threadIdx.x / N, m = (int)threadIdx.x % N;
+        const int dq = (int)blockDim.x / N, dm = (int)blockDim.x % N, bd = (int)blockDim.x;
+        for (int oi0 = 2 * N + (int)threadIdx.x; oi0 < lim; oi0 += 4 * bd) {                 // four steps at a time: their loads are in flight together
+            int so[4];
+            float2 xv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                so[u] = fstart + 2 * N + q * (N + cp) + cp + m;
+                q += dq; m += dm;
+                if (m >= N) { m -= N; q++; }
+                const int g = fr.start + so[u] - xs_delay;
+                const bool live = oi0 + u * bd < lim && so[u] < fr.len && fr.start + so[u] < n && g >= 0;
+                xv[u] = live ? xs[g] : make_float2(0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int oi = oi0 + u * bd;
+                if (oi >= lim) break;
+                float sn, cs, sn2, cs2;
+                jrc_sincosf_fast(-fr.coarse_cfo * (float)so[u], &sn, &cs);                    // frame_detector's de-rotation (:178), then frame_sync's (:193)
+                jrc_sincosf_fast((float)so[u] * fine, &sn2, &cs2);
+                o[oi] = cmul(cmul(xv[u], make_float2(cs, sn)), make_float2(cs2, sn2));
+            }
+        }
     }
     for (long oi = kept + threadIdx.x; oi < n_out && oi < out_stride; oi += blockDim.x) o[oi] = make_float2(0.f, 0.f);
     if (threadIdx.x == 0) {
