@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void sync_metrics_tiled_kernel(const float2* _
 // The marks-only metrics for windows that are whole runs of 16 (window, power_window multiples of 16, delay a multiple of 4: fft_len 64 has
 // 48 / 64 / 16), four consecutive samples per lane: the products and powers of a lane's samples stay in registers, runs of 4 need the three
 // products behind them (the next lane's, formed again here rather than fetched), runs of 16 the runs of 4 of the next three lanes (through LDS),
-// the window sums the runs of 16 of earlier lanes (through LDS).  Every LDS access is 16 bytes wide and aligned: lane t holds local samples
+// the window sums the runs of 16 of earlier lanes (through LDS).  Every LDS access is 16 bytes wide, aligned and free of bank conflicts: lane t holds local samples
 // 4t .. 4t+3 of a 4 * SMK_NT sample tile whose first `halo` samples (a number = 3 mod 4, so that k - (window - 1) is a multiple of 4 for the
 // outputs k = halo + 4t' + i) only feed the sums.  Same products, same tree and the same test as sync_metrics_tiled_kernel<true> — the masks
 // are equal bit for bit (tests/test_gpu_sync.py) — with 8 LDS instructions per sample instead of 32.
@@ -191,10 +191,12 @@ __global__ __launch_bounds__(SMK_NT) void sync_marks_kernel(const float2* __rest
                                                             float max_dn, float max_up)
 {
 #pragma clang fp contract(off)
-    __shared__ __attribute__((aligned(16))) float2 XE[SMK_L + 16];       // samples, later the runs of 16 of the products
-    __shared__ __attribute__((aligned(16))) float2 As[SMK_L + 16];       // runs of 4 of the products
-    __shared__ __attribute__((aligned(16))) float Ds[SMK_L + 16];        // runs of 4 of the powers
-    __shared__ __attribute__((aligned(16))) float Fs[SMK_L + 16];        // runs of 16 of the powers
+    // a lane's four samples as two 16-byte halves in two arrays (lo = samples 4t, 4t+1; hi = 4t+2, 4t+3): consecutive lanes are 16 bytes apart
+    // in each, so every ds_read_b128 / ds_write_b128 lane group covers whole bank rows (32 bytes apart they would collide two-way)
+    __shared__ float4 Xlo[SMK_NT + 4], Xhi[SMK_NT + 4];                  // samples, later the runs of 16 of the products
+    __shared__ float4 Alo[SMK_NT + 4], Ahi[SMK_NT + 4];                  // runs of 4 of the products
+    __shared__ float4 Ds[SMK_NT + 4];                                    // runs of 4 of the powers
+    __shared__ float4 Fs[SMK_NT + 4];                                    // runs of 16 of the powers
     const int t = threadIdx.x, k0 = 4 * t;
     const long i0 = (long)blockIdx.x * T;
     const long g0 = i0 - halo;
@@ -207,18 +209,17 @@ __global__ __launch_bounds__(SMK_NT) void sync_marks_kernel(const float2* __rest
 #pragma unroll
         for (int m = 0; m < 4; m++) u[m] = (g + m >= 0 && g + m < n) ? x[g + m] : make_float2(0.f, 0.f);
     }
-    float4* XE4 = (float4*)XE;
-    XE4[2 * t] = make_float4(u[0].x, u[0].y, u[1].x, u[1].y);
-    XE4[2 * t + 1] = make_float4(u[2].x, u[2].y, u[3].x, u[3].y);
-    if (t < 8) XE4[2 * SMK_NT + t] = make_float4(0.f, 0.f, 0.f, 0.f);   // the 16 samples behind the tile: read by the last lanes, used by no output
+    Xlo[t] = make_float4(u[0].x, u[0].y, u[1].x, u[1].y);
+    Xhi[t] = make_float4(u[2].x, u[2].y, u[3].x, u[3].y);
+    if (t < 4) { Xlo[SMK_NT + t] = make_float4(0.f, 0.f, 0.f, 0.f); Xhi[SMK_NT + t] = make_float4(0.f, 0.f, 0.f, 0.f); }   // behind the tile: read, used by no output
     __syncthreads();
     {
-        const float4 a = XE4[2 * t + 2], b = XE4[2 * t + 3];
+        const float4 a = Xlo[t + 1], b = Xhi[t + 1];
         u[4] = make_float2(a.x, a.y); u[5] = make_float2(a.z, a.w); u[6] = make_float2(b.x, b.y);
     }
     if (k0 >= delay) {
-        const float4* V4 = XE4 + ((k0 - delay) >> 1);
-        const float4 a = V4[0], b = V4[1], c = V4[2], d = V4[3];
+        const int td = t - (delay >> 2);
+        const float4 a = Xlo[td], b = Xhi[td], c = Xlo[td + 1], d = Xhi[td + 1];
         v[0] = make_float2(a.x, a.y); v[1] = make_float2(a.z, a.w); v[2] = make_float2(b.x, b.y); v[3] = make_float2(b.z, b.w);
         v[4] = make_float2(c.x, c.y); v[5] = make_float2(c.z, c.w); v[6] = make_float2(d.x, d.y);
     } else {
@@ -230,8 +231,11 @@ __global__ __launch_bounds__(SMK_NT) void sync_marks_kernel(const float2* __rest
 #pragma unroll
     for (int m = 0; m < 7; m++) {
         B[m] = make_float2(v[m].x * u[m].x + v[m].y * u[m].y, v[m].x * u[m].y - v[m].y * u[m].x);       // conj(v) * u
-        if (g + m < delay) B[m] = make_float2(0.f, 0.f);                                                // the delayed stream starts with zeros
         C[m] = u[m].x * u[m].x + u[m].y * u[m].y;
+    }
+    if (g0 < delay) {                                                      // the first workgroup(s): the delayed stream starts with zeros
+#pragma unroll
+        for (int m = 0; m < 7; m++) if (g + m < delay) B[m] = make_float2(0.f, 0.f);
     }
     float2 A[4];
     float D[4];
@@ -240,10 +244,9 @@ __global__ __launch_bounds__(SMK_NT) void sync_marks_kernel(const float2* __rest
         A[i] = make_float2(((B[i].x + B[i + 1].x) + B[i + 2].x) + B[i + 3].x, ((B[i].y + B[i + 1].y) + B[i + 2].y) + B[i + 3].y);
         D[i] = ((C[i] + C[i + 1]) + C[i + 2]) + C[i + 3];
     }
-    float4* As4 = (float4*)As;
-    As4[2 * t] = make_float4(A[0].x, A[0].y, A[1].x, A[1].y);
-    As4[2 * t + 1] = make_float4(A[2].x, A[2].y, A[3].x, A[3].y);
-    ((float4*)Ds)[t] = make_float4(D[0], D[1], D[2], D[3]);
+    Alo[t] = make_float4(A[0].x, A[0].y, A[1].x, A[1].y);
+    Ahi[t] = make_float4(A[2].x, A[2].y, A[3].x, A[3].y);
+    Ds[t] = make_float4(D[0], D[1], D[2], D[3]);
     __syncthreads();
     {
         float2 E[4];
@@ -252,9 +255,9 @@ __global__ __launch_bounds__(SMK_NT) void sync_marks_kernel(const float2* __rest
         float Dn[3][4];
 #pragma unroll
         for (int r = 0; r < 3; r++) {
-            const float4 a = As4[2 * (t + r + 1)], b = As4[2 * (t + r + 1) + 1];
+            const float4 a = Alo[t + r + 1], b = Ahi[t + r + 1];
             An[r][0] = make_float2(a.x, a.y); An[r][1] = make_float2(a.z, a.w); An[r][2] = make_float2(b.x, b.y); An[r][3] = make_float2(b.z, b.w);
-            const float4 d = ((const float4*)Ds)[t + r + 1];
+            const float4 d = Ds[t + r + 1];
             Dn[r][0] = d.x; Dn[r][1] = d.y; Dn[r][2] = d.z; Dn[r][3] = d.w;
         }
 #pragma unroll
@@ -262,9 +265,9 @@ __global__ __launch_bounds__(SMK_NT) void sync_marks_kernel(const float2* __rest
             E[i] = make_float2(((A[i].x + An[0][i].x) + An[1][i].x) + An[2][i].x, ((A[i].y + An[0][i].y) + An[1][i].y) + An[2][i].y);
             F[i] = ((D[i] + Dn[0][i]) + Dn[1][i]) + Dn[2][i];
         }
-        XE4[2 * t] = make_float4(E[0].x, E[0].y, E[1].x, E[1].y);          // the samples are dead: every read of them was before the last barrier
-        XE4[2 * t + 1] = make_float4(E[2].x, E[2].y, E[3].x, E[3].y);
-        ((float4*)Fs)[t] = make_float4(F[0], F[1], F[2], F[3]);
+        Xlo[t] = make_float4(E[0].x, E[0].y, E[1].x, E[1].y);              // the samples are dead: every read of them was before the last barrier
+        Xhi[t] = make_float4(E[2].x, E[2].y, E[3].x, E[3].y);
+        Fs[t] = make_float4(F[0], F[1], F[2], F[3]);
     }
     __syncthreads();
     if (4 * t >= T) return;                                                // whole waves: T is a multiple of 256
@@ -274,22 +277,22 @@ __global__ __launch_bounds__(SMK_NT) void sync_marks_kernel(const float2* __rest
 #pragma unroll
     for (int i = 0; i < 4; i++) { a[i] = make_float2(0.f, 0.f); pw[i] = 0.f; }
     {
-        const float4* E4 = XE4 + ((halo - (window - 1) + 4 * t) >> 1);
-        for (int m = 0; m < w16; m++, E4 += 8) {
-            const float4 e0 = E4[0], e1 = E4[1];
+        int c = ((halo - (window - 1)) >> 2) + t;                          // the lane whose runs of 16 start this lane's windows
+        for (int m = 0; m < w16; m++, c += 4) {
+            const float4 e0 = Xlo[c], e1 = Xhi[c];
             a[0].x = a[0].x + e0.x; a[0].y = a[0].y + e0.y; a[1].x = a[1].x + e0.z; a[1].y = a[1].y + e0.w;
             a[2].x = a[2].x + e1.x; a[2].y = a[2].y + e1.y; a[3].x = a[3].x + e1.z; a[3].y = a[3].y + e1.w;
         }
-        const float4* F4 = (const float4*)Fs + ((halo - (pwindow - 1) + 4 * t) >> 2);
-        for (int m = 0; m < p16; m++, F4 += 4) {
-            const float4 f = F4[0];
+        c = ((halo - (pwindow - 1)) >> 2) + t;
+        for (int m = 0; m < p16; m++, c += 4) {
+            const float4 f = Fs[c];
             pw[0] = pw[0] + f.x; pw[1] = pw[1] + f.y; pw[2] = pw[2] + f.z; pw[3] = pw[3] + f.w;
         }
     }
     unsigned long long bits[4];
+    const int left = (int)min((long)T, (long)n - i0) - 4 * t;              // outputs of the capture from this lane's first on
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const long ig = i0 + 4 * t + i;
         const float den = fabsf(pw[i] * pscale);
         const float est = __builtin_amdgcn_sqrtf(fmaf(a[i].x, a[i].x, a[i].y * a[i].y)) * __builtin_amdgcn_rcpf(den);
         bool pk = est > thr_up && est < max_dn;
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(SMK_NT) void sync_marks_kernel(const float2* __rest
             const float cor = ref_hypotf(a[i]) / den;
             pk = ((double)cor > thr) && ((double)cor < maxv);
         }
-        bits[i] = __ballot(pk && ig < n);
+        bits[i] = __ballot(pk && i < left);
     }
     // lane l holds samples 4l .. 4l+3 of the wave's 256: word m = lanes 16m .. 16m+15, bit 4q+i of it = bits[i] of lane 16m+q
     const int lane = t & 63;
@@ -1253,6 +1256,9 @@ __global__ __launch_bounds__(256) void sf_frames_kernel(const float2* __restrict
     {
         int q = (int)threadIdx.x / N, m = (int)threadIdx.x % N;
         const int dq = (int)blockDim.x / N, dm = (int)blockDim.x % N, bd = (int)blockDim.x;
+        // every sample the loop reads lies inside the frame's segment (so < copy_len < fr.len); only a frame at the very start or end of the
+        // capture can reach outside the capture
+        const bool inside = fr.start - xs_delay >= 0 && (long)fr.start + fr.len <= (long)n;
         for (int oi0 = 2 * N + (int)threadIdx.x; oi0 < lim; oi0 += 4 * bd) {                 // four steps at a time: their loads are in flight together
             int so[4];
             float2 xv[4];
@@ -1262,7 +1268,7 @@ __global__ __launch_bounds__(256) void sf_frames_kernel(const float2* __restrict
                 q += dq; m += dm;
                 if (m >= N) { m -= N; q++; }
                 const int g = fr.start + so[u] - xs_delay;
-                const bool live = oi0 + u * bd < lim && so[u] < fr.len && fr.start + so[u] < n && g >= 0;
+                const bool live = oi0 + u * bd < lim && (inside || (so[u] < fr.len && fr.start + so[u] < n && g >= 0));
                 xv[u] = live ? xs[g] : make_float2(0.f, 0.f);
             }
 #pragma unroll

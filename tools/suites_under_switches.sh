@@ -7,6 +7,8 @@ run() { echo "== $1"; env $1 python3 -m pytest ${@:2} -q -x 2>&1 | tail -1; }
 run "JRC_DEC_SINGLE=1" tests/test_gpu_codec.py
 run "JRC_SYNC_NAIVE=1" tests/test_gpu_sync.py
 run "JRC_FD_SERIAL=1" tests/test_gpu_sync.py
+run "JRC_SYNC_STREAMS=1" tests/test_gpu_sync.py
+run "JRC_SYNC_TILE=1" tests/test_gpu_sync.py
 run "JRC_EQ_THREADS=-1" tests/test_gpu_comm.py
 run "JRC_EQ_THREADS=128 JRC_EQ_WPE=4" tests/test_gpu_comm.py
 run "JRC_EQ_WPE=2" tests/test_gpu_comm.py
