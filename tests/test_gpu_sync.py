@@ -218,7 +218,7 @@ def _scan_case(jrc, ctx, seed, density, min_peaks, gap, max_frames, max_quiet):
         assert abs(f.coarse_cfo - tags[k][1]) < 1e-6
 
 
-def _front_end_outputs(jrc, env, monkeypatch, x, max_frames, n_list=None):
+def _front_end_outputs(jrc, env, monkeypatch, x, max_frames, n_list=None, fft_len=N, cp_len=CP, taps=None):
     """mask words, frame list and frame rows of one front-end run in a context of its own (the switches are read when a context is made)"""
     import torch
     for k, v in env.items():
@@ -229,7 +229,8 @@ def _front_end_outputs(jrc, env, monkeypatch, x, max_frames, n_list=None):
     from conftest import GOLDEN  # noqa: F401
     import os
     o = np.load(os.path.join(GOLDEN, "ofdm_config_64.npz"))
-    fe = jrc.SyncFrontEnd(N, CP, 0.6, 10, 8 * (N + CP), SYNC_LEN, o["l_ltf_fir"], max_frames=max_frames, max_symbols=40, ctx=c)
+    fe = jrc.SyncFrontEnd(fft_len, cp_len, 0.6, 10, 8 * (fft_len + cp_len), min(4 * (fft_len + cp_len), 4096), o["l_ltf_fir"] if taps is None else taps,
+                          max_frames=max_frames, max_symbols=40, ctx=c)
     d_x = torch.from_numpy(x.view(np.float32).reshape(-1, 2).copy()).cuda()
     out = []
     for n in (n_list or [x.size]):
@@ -260,6 +261,33 @@ def test_front_end_forms_agree_bit_for_bit(jrc, monkeypatch, ofdm64):
     assert want[0][1] == 7 and int(sum(bin(int(w)).count("1") for w in want[0][0])) > 200
     for env in ({}, {"JRC_SYNC_TILE": "1"}):
         got = _front_end_outputs(jrc, env, monkeypatch, x, 16, n_list)
+        for n, w, g in zip(n_list, want, got):
+            assert np.array_equal(w[0], g[0]), (env, n, "peak mask")
+            assert w[1] == g[1] and w[2] == g[2], (env, n, "frame list")
+            assert w[3] == g[3], (env, n, "frame rows")
+
+
+@pytest.mark.parametrize("fft_len", [256, 1024, 128])
+def test_front_end_forms_agree_at_other_carrier_counts(jrc, monkeypatch, fft_len):
+    """the same three forms at fft_len 256 and 1024 (windows of 8 / 12 and 32 / 48 runs of 16: 7 and 4 output waves per workgroup of the
+    four-samples-per-lane kernel) and 128; bursts = ten repeats of a random quarter symbol (the short training field's periodicity, which is all
+    the metric sees) in front of random symbols, in noise"""
+    rng = np.random.default_rng(fft_len)
+    cp = fft_len // 4
+    q = fft_len // 4
+    parts = []
+    for k in range(5):
+        stf = np.tile(rng.standard_normal(q) + 1j * rng.standard_normal(q), 10)
+        body = rng.standard_normal(14 * (fft_len + cp)) + 1j * rng.standard_normal(14 * (fft_len + cp))
+        parts += [np.zeros(3 * fft_len + 17 * k), stf, body, np.zeros(2 * fft_len)]
+    x = np.concatenate(parts)
+    x = (x + 0.05 * (rng.standard_normal(x.size) + 1j * rng.standard_normal(x.size))).astype(np.complex64)
+    taps = (rng.standard_normal(64) + 1j * rng.standard_normal(64)).astype(np.complex64)
+    n_list = [x.size, x.size - 777, 5 * 1024 + 3]
+    want = _front_end_outputs(jrc, {"JRC_SYNC_STREAMS": "1"}, monkeypatch, x, 16, n_list, fft_len, cp, taps)
+    assert want[0][1] >= 4
+    for env in ({}, {"JRC_SYNC_TILE": "1"}):
+        got = _front_end_outputs(jrc, env, monkeypatch, x, 16, n_list, fft_len, cp, taps)
         for n, w, g in zip(n_list, want, got):
             assert np.array_equal(w[0], g[0]), (env, n, "peak mask")
             assert w[1] == g[1] and w[2] == g[2], (env, n, "frame list")
