@@ -4,7 +4,8 @@ PARITY UNPINNED: the reference has no tests/golden vectors and cannot be built i
 (GNU Radio 3.8 / Eigen3 / Boost / FFTW3f / VOLK are absent; no stand-ins are written for them).
 The functions here restate the reference algorithm (file:line cited in oracle/jrc_oracle.c) and are
 checked against closed forms and the constant tables minted from the reference's embedded Python
-module (tests/golden/).
+module (tests/golden/); the SIGNAL field, scrambler, convolutional encoder and CRC also against the bit-level
+examples IEEE 802.11 publishes for them (tests/test_published_vectors.py).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
 """
