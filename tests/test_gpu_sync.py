@@ -218,7 +218,7 @@ def _scan_case(jrc, ctx, seed, density, min_peaks, gap, max_frames, max_quiet):
         assert abs(f.coarse_cfo - tags[k][1]) < 1e-6
 
 
-def _front_end_outputs(jrc, env, monkeypatch, x, max_frames, n_list=None, fft_len=N, cp_len=CP, taps=None):
+def _front_end_outputs(jrc, env, monkeypatch, x, max_frames, n_list=None, fft_len=N, cp_len=CP, taps=None, windows=None):
     """mask words, frame list and frame rows of one front-end run in a context of its own (the switches are read when a context is made)"""
     import torch
     for k, v in env.items():
@@ -231,6 +231,8 @@ def _front_end_outputs(jrc, env, monkeypatch, x, max_frames, n_list=None, fft_le
     o = np.load(os.path.join(GOLDEN, "ofdm_config_64.npz"))
     fe = jrc.SyncFrontEnd(fft_len, cp_len, 0.6, 10, 8 * (fft_len + cp_len), min(4 * (fft_len + cp_len), 4096), o["l_ltf_fir"] if taps is None else taps,
                           max_frames=max_frames, max_symbols=40, ctx=c)
+    if windows:                                                  # (delay, window, power_window) other than the flowgraph's fft_len / 4, / 2, 3/4
+        fe.cfg.delay, fe.cfg.window, fe.cfg.power_window = windows
     d_x = torch.from_numpy(x.view(np.float32).reshape(-1, 2).copy()).cuda()
     out = []
     for n in (n_list or [x.size]):
@@ -292,3 +294,20 @@ def test_front_end_forms_agree_at_other_carrier_counts(jrc, monkeypatch, fft_len
             assert np.array_equal(w[0], g[0]), (env, n, "peak mask")
             assert w[1] == g[1] and w[2] == g[2], (env, n, "frame list")
             assert w[3] == g[3], (env, n, "frame rows")
+
+
+def test_front_end_forms_agree_for_drawn_windows(jrc, monkeypatch, ofdm64):
+    """delay / window / power_window drawn at random: whole runs of 16 take the four-samples-per-lane kernel, everything else the tile kernel's
+    marks form; both against the streams form, bit for bit"""
+    rng = np.random.default_rng(5)
+    x, _ = capture(ofdm64, 12, cfo=0.004, n_frames=4, gap=1500)
+    x = x + (0.08 * (rng.standard_normal(x.size) + 1j * rng.standard_normal(x.size))).astype(np.complex64)
+    cases = [(16, 32, 48), (16, 48, 64), (4, 16, 16), (32, 64, 128), (64, 112, 48), (16, 31, 48), (16, 32, 47), (15, 32, 48), (1, 1, 1), (7, 45, 90), (20, 100, 3)]
+    cases += [tuple(int(v) for v in (rng.integers(0, 40), rng.integers(1, 120), rng.integers(1, 120))) for _ in range(8)]
+    n_list = [x.size, 4000, 1793]
+    for w in cases:
+        want = _front_end_outputs(jrc, {"JRC_SYNC_STREAMS": "1"}, monkeypatch, x, 16, n_list, windows=w)
+        got = _front_end_outputs(jrc, {}, monkeypatch, x, 16, n_list, windows=w)
+        for n, a, b in zip(n_list, want, got):
+            assert np.array_equal(a[0], b[0]), (w, n, "peak mask")
+            assert a[1] == b[1] and a[2] == b[2] and a[3] == b[3], (w, n)
