@@ -1,0 +1,7 @@
+import os, sys
+ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import bench_extra as be
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+r = be.device_resident_flowgraph(F)
+print("F=%d %.4f ms per pass -> %.0f packets/s" % (F, r["ms_per_step"], r["frames_per_s"]))
