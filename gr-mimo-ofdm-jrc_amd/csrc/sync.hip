@@ -996,13 +996,16 @@ __global__ __launch_bounds__(64) void fd_scan_all_kernel(FdParams p, const unsig
 // them at the prefix sums of the counts, and a last kernel fills in the copy lengths (next detection - start, capped by
 // MAX_SAMPLES and the end of the capture).  A capture without quiet stretches has no anchors: wave 0 then walks it alone, as before.
 #define FD_SEG_WORDS 64
+#define FD_SEG_KEEP 8       // detections of a segment the counting pass keeps (start sample); more: the writing pass walks the segment again
 
 template <bool WRITE>
 __global__ __launch_bounds__(64) void fd_scan_seg_kernel(FdParams p, const unsigned long long* __restrict__ marks, FdAbs src,
                                                          int n, int G, int* __restrict__ counts, SfFrame* __restrict__ frames, int max_frames,
-                                                         int* __restrict__ overflow_start)
+                                                         int* __restrict__ overflow_start, int* __restrict__ kept /* [n_seg][FD_SEG_KEEP] starts */,
+                                                         const int* __restrict__ raw_counts)
 {
     const int lane = threadIdx.x, w = blockIdx.x;
+    if (WRITE && raw_counts[w] <= FD_SEG_KEEP) return;           // the counting pass kept this segment's detections: fd_scan_gather_kernel lists them
     const int n_words = (n + 63) >> 6;
     const long seg_start = (long)w * FD_SEG_WORDS * 64;
     const long seg_end = min((long)n, seg_start + (long)FD_SEG_WORDS * 64);
@@ -1107,6 +1110,7 @@ __global__ __launch_bounds__(64) void fd_scan_seg_kernel(FdParams p, const unsig
                             break;
                         }
                     }
+                    if (!WRITE && nd < FD_SEG_KEEP && lane == 0) kept[w * FD_SEG_KEEP + nd] = i;
                     nd++;
                     state = 1; copied = 0;
                     n_peaks = 1; first = i;
@@ -1117,6 +1121,31 @@ __global__ __launch_bounds__(64) void fd_scan_seg_kernel(FdParams p, const unsig
         }
     }
     if (!WRITE && lane == 0) counts[w] = nd;
+}
+
+// the detections the counting pass kept (segments with at most FD_SEG_KEEP of them — frames are ignore_gap samples apart, a 4096-sample segment
+// rarely holds more) go to their places in the list, one lane per segment; the coarse CFO of each is formed here (:112)
+__global__ __launch_bounds__(256) void fd_scan_gather_kernel(FdParams p, FdAbs src, const int* __restrict__ counts, const int* __restrict__ prefix,
+                                                             const int* __restrict__ kept, int n_seg, SfFrame* __restrict__ frames, int max_frames,
+                                                             int* __restrict__ overflow_start)
+{
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= n_seg) return;
+    const int c = counts[w];
+    if (c > FD_SEG_KEEP) return;                                 // listed by fd_scan_seg_kernel<true>
+    const int base = prefix[w];
+    for (int d = 0; d < c; d++) {
+        const int idx = base + d, i = kept[w * FD_SEG_KEEP + d];
+        if (idx < max_frames) {
+            const float2 av = src.at(i);
+            SfFrame f; f.start = i; f.len = 0; f.coarse_cfo = (float)((double)atan2f(av.y, av.x) / (p.fft_len / 4.0));
+            f.frame_start = 0; f.fine_cfo = 0.f; f.tag_value = 0; f.n_out = 0; f.pad_ = 0;
+            frames[idx] = f;
+        } else {
+            if (idx == max_frames) *overflow_start = i;
+            break;
+        }
+    }
 }
 
 // exclusive prefix sums of the segments' detection counts, 1024 segments per workgroup: sums of the blocks first, then every block scans its
@@ -1181,16 +1210,21 @@ static int launch_fd_scan(jrc_ctx* ctx, const FdParams& p, const unsigned long l
         return JRC_OK;
     }
     const int n_blk = (n_seg + 1023) / 1024;
-    JRC_TRY(jrc_ensure_scratch(ctx, 3, sizeof(int) * (2 * (size_t)n_seg + n_blk + 16)));
+    JRC_TRY(jrc_ensure_scratch(ctx, 3, sizeof(int) * ((2 + FD_SEG_KEEP) * (size_t)n_seg + n_blk + 16)));
     int* counts = (int*)ctx->scratch[3];
     int* prefix = counts + n_seg;                                   // [n_seg + 1]
     int* overflow = prefix + n_seg + 1;
     int* blocksum = overflow + 1;                                   // [n_blk]
+    int* kept = blocksum + n_blk;                                   // [n_seg][FD_SEG_KEEP]
     const int G = p.ignore_gap + p.max_peak_distance + 2;
-    hipLaunchKernelGGL(fd_scan_seg_kernel<false>, dim3(n_seg), dim3(64), 0, s, p, d_marks, d_abs, n_samples, G, counts, d_info, max_frames, overflow);
+    hipLaunchKernelGGL(fd_scan_seg_kernel<false>, dim3(n_seg), dim3(64), 0, s, p, d_marks, d_abs, n_samples, G, counts, d_info, max_frames, overflow, kept,
+                       (const int*)nullptr);
     hipLaunchKernelGGL(fd_scan_blocksum_kernel, dim3(n_blk), dim3(1024), 0, s, (const int*)counts, n_seg, blocksum);
     hipLaunchKernelGGL(fd_scan_prefix_kernel, dim3(n_blk), dim3(1024), 0, s, (const int*)counts, n_seg, (const int*)blocksum, prefix);
-    hipLaunchKernelGGL(fd_scan_seg_kernel<true>, dim3(n_seg), dim3(64), 0, s, p, d_marks, d_abs, n_samples, G, prefix, d_info, max_frames, overflow);
+    hipLaunchKernelGGL(fd_scan_gather_kernel, dim3((n_seg + 255) / 256), dim3(256), 0, s, p, d_abs, (const int*)counts, (const int*)prefix, (const int*)kept, n_seg,
+                       d_info, max_frames, overflow);
+    hipLaunchKernelGGL(fd_scan_seg_kernel<true>, dim3(n_seg), dim3(64), 0, s, p, d_marks, d_abs, n_samples, G, prefix, d_info, max_frames, overflow, (int*)nullptr,
+                       (const int*)counts);
     const int cap = max_frames < n_samples ? max_frames : n_samples;  // a frame holds at least one sample
     hipLaunchKernelGGL(fd_scan_finish_kernel, dim3((cap + 255) / 256 > 0 ? (cap + 255) / 256 : 1), dim3(256), 0, s, p, (const int*)prefix, n_seg, n_samples, d_info,
                        max_frames, (const int*)overflow, d_n_frames);
