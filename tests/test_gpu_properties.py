@@ -134,6 +134,7 @@ def test_config_c_round_trip_and_scaling_at_the_benchmarked_batch(jrc, ctx):
     sym = pts[rng.integers(0, 4, (n_distinct, S * nd))]
     pre = jrc.mimo_precoder(N, T, 1, data, pilots, pil, sync, mapped, ctx=ctx)
     d_sym = torch.from_numpy(np.ascontiguousarray(sym[np.arange(n_pkt) % n_distinct]).view(np.float32).reshape(n_pkt, S * nd, 2)).to("cuda:0")
+    torch.cuda.synchronize()
     tx = torch.view_as_complex(pre.frames_dev(d_sym, 2, jrc.DATA, nbytes))              # [n_pkt][T][n_total][N]
     ctx.sync()
     n_total = tx.shape[2]
@@ -161,6 +162,8 @@ def test_config_c_round_trip_and_scaling_at_the_benchmarked_batch(jrc, ctx):
     assert torch.equal(got[period:], got[:-period])
     # scaling by a power of two
     eq2 = jrc.mimo_ofdm_equalizer(jrc.LS, 24e9, 125e6, N, cp, data, pilots, pil, ltf, mapped, T, n_streams=streams, ctx=ctx)
-    out4, _, _ = eq2.frames_dev(torch.view_as_real(y * 4.0), d_ph, n_sym, S)
+    y4 = (y * 4.0).contiguous()
+    torch.cuda.synchronize()                                                             # torch's stream made y4; the library reads it on its own
+    out4, _, _ = eq2.frames_dev(torch.view_as_real(y4), d_ph, n_sym, S)
     ctx.sync()
     assert torch.equal(out4, out)
