@@ -10,6 +10,7 @@ Context without a usable HIP device raises JrcError.  Nothing here imports oracl
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -59,6 +60,55 @@ class ChainCfg(C.Structure):
 
 _lib = None
 
+# The library launches on streams of its own (non-blocking: they do not order themselves against the caller's default stream, like any
+# stream a GNU Radio block would own).  A caller that prepares device buffers with torch — tests, tools — therefore has to finish
+# torch's work before handing them over.  set_torch_stream_sync(True) makes every call into the library do that first: it waits for
+# torch's CURRENT stream only (never for the library's streams, whose ordering stays what the C ABI gives it).  Off by default (bench.py keeps
+# its own discipline, and a block fed from host buffers never needs it); tests/conftest.py switches it on.
+_TORCH_STREAM_SYNC = False
+
+
+def set_torch_stream_sync(on):
+    global _TORCH_STREAM_SYNC
+    _TORCH_STREAM_SYNC = bool(on)
+
+
+def _sync_torch_stream():
+    torch = sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized():
+        torch.cuda.current_stream().synchronize()
+
+
+class _Fn:
+    """one entry point of the shared library; attribute access (argtypes / restype) goes to the ctypes function"""
+    __slots__ = ("f",)
+
+    def __init__(self, f):
+        object.__setattr__(self, "f", f)
+
+    def __call__(self, *a):
+        if _TORCH_STREAM_SYNC:
+            _sync_torch_stream()
+        return self.f(*a)
+
+    def __getattr__(self, k):
+        return getattr(self.f, k)
+
+    def __setattr__(self, k, v):
+        setattr(self.f, k, v)
+
+
+class _Lib:
+    def __init__(self, cdll):
+        self.__dict__["_cdll"] = cdll
+        self.__dict__["_fns"] = {}
+
+    def __getattr__(self, name):
+        fn = self._fns.get(name)
+        if fn is None:
+            fn = self._fns[name] = _Fn(getattr(self._cdll, name))
+        return fn
+
 
 def load(build_if_missing=False):
     """dlopen libjrc_hip.so.  Fails loudly when the HIP extension has not been built."""
@@ -77,7 +127,7 @@ def load(build_if_missing=False):
         import torch  # noqa: F401
     except ImportError:
         pass
-    L = C.CDLL(LIB_PATH)
+    L = _Lib(C.CDLL(LIB_PATH))
     L.jrc_abi_version.restype = C.c_int
     L.jrc_device_count.restype = C.c_int
     L.jrc_create.argtypes = [C.c_int, C.POINTER(_vp)]

@@ -25,6 +25,9 @@ def ofdm64():
 def jrc():
     import jrc_amd
     jrc_amd.load(build_if_missing=True)
+    # the tests prepare device buffers with torch, on torch's stream; the library launches on its own, which does not order itself against it:
+    # every call into the library first waits for what torch has queued (torch's stream only — the library's own stream ordering is not touched)
+    jrc_amd.set_torch_stream_sync(True)
     return jrc_amd
 
 
