@@ -63,8 +63,9 @@ _lib = None
 # The library launches on streams of its own (non-blocking: they do not order themselves against the caller's default stream, like any
 # stream a GNU Radio block would own).  A caller that prepares device buffers with torch — tests, tools — therefore has to finish
 # torch's work before handing them over.  set_torch_stream_sync(True) makes every call into the library do that first: it waits for
-# torch's CURRENT stream only (never for the library's streams, whose ordering stays what the C ABI gives it).  Off by default (bench.py keeps
-# its own discipline, and a block fed from host buffers never needs it); tests/conftest.py switches it on.
+# torch's CURRENT stream only (never for the library's streams, whose ordering stays what the C ABI gives it), and after the call makes
+# torch's stream depend on the contexts' streams (a stream dependency, no host wait), so that torch reads what the call enqueued.  Off by
+# default (bench.py keeps its own discipline, and a block fed from host buffers never needs it); tests/conftest.py switches it on.
 _TORCH_STREAM_SYNC = False
 
 
@@ -73,10 +74,32 @@ def set_torch_stream_sync(on):
     _TORCH_STREAM_SYNC = bool(on)
 
 
-def _sync_torch_stream():
+_live_contexts = None       # weak set of Context objects (their streams are what torch's stream is made to wait for after a call)
+
+
+def _torch():
     torch = sys.modules.get("torch")
-    if torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized():
+    return torch if torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized() else None
+
+
+def _sync_torch_stream():
+    torch = _torch()
+    if torch is not None:
         torch.cuda.current_stream().synchronize()
+
+
+def _torch_waits_for_library():
+    """the other direction, as a stream dependency (no host wait): what torch queues from here on runs behind what the contexts' streams hold now"""
+    torch = _torch()
+    if torch is None or not _live_contexts or _lib is None:
+        return
+    cur = torch.cuda.current_stream()
+    for c in list(_live_contexts):
+        h = getattr(c, "h", None)
+        if h:
+            sp = _lib._cdll.jrc_stream(h)
+            if sp:
+                cur.wait_stream(torch.cuda.ExternalStream(sp, device=c.device))
 
 
 class _Fn:
@@ -87,9 +110,12 @@ class _Fn:
         object.__setattr__(self, "f", f)
 
     def __call__(self, *a):
-        if _TORCH_STREAM_SYNC:
-            _sync_torch_stream()
-        return self.f(*a)
+        if not _TORCH_STREAM_SYNC:
+            return self.f(*a)
+        _sync_torch_stream()
+        r = self.f(*a)
+        _torch_waits_for_library()
+        return r
 
     def __getattr__(self, k):
         return getattr(self.f, k)
@@ -229,6 +255,11 @@ class Context:
             raise JrcError(st, self.lib.jrc_strerror(st).decode())
         self.h = h
         self.device = device
+        global _live_contexts
+        if _live_contexts is None:
+            import weakref
+            _live_contexts = weakref.WeakSet()
+        _live_contexts.add(self)
 
     def check(self, st):
         if st < 0:
@@ -249,9 +280,10 @@ class Context:
         self.check(self.lib.jrc_sync(self.h))
 
     def close(self):
-        if getattr(self, "h", None):
-            self.lib.jrc_destroy(self.h)
-            self.h = None
+        h = getattr(self, "h", None)
+        if h:
+            self.h = None                     # first: nothing may look the stream of a context up while or after it is destroyed
+            self.lib.jrc_destroy(h)
 
     def __del__(self):
         try:
