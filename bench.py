@@ -649,6 +649,8 @@ def secondary_figures(cfg, ctx, sc, axes):
     if hasattr(be, "device_resident_flowgraph"):
         leg("device_resident_sim_flowgraph", lambda: be.device_resident_flowgraph(64))
     leg("equalizer_config_c", _eq)
+    if hasattr(be, "sync_front_end"):
+        leg("sync_front_end", lambda: be.sync_front_end(4096))
     leg("comm_rx_chain", _comm)
     leg("precoder_config_c", _pre)
     leg("range_doppler_config_d", _rd)
