@@ -311,3 +311,32 @@ def test_front_end_forms_agree_for_drawn_windows(jrc, monkeypatch, ofdm64):
         for n, a, b in zip(n_list, want, got):
             assert np.array_equal(a[0], b[0]), (w, n, "peak mask")
             assert a[1] == b[1] and a[2] == b[2] and a[3] == b[3], (w, n)
+
+
+@pytest.mark.parametrize("seed,cfo,n_frames,gap", [(21, 0.006, 24, 1200), (22, -0.009, 17, 3100)])
+def test_batched_front_end_equals_the_block_chain_on_longer_captures(jrc, ctx, ofdm64, seed, cfo, n_frames, gap):
+    """the run-to-completion front end (peak mask from the registers, correlation re-formed at the detections, segment-parallel scan with kept
+    detections, output-indexed copy) against the oracle's frame_detector + frame_sync run sample by sample, on captures of 17 / 24 frames of
+    growing length: the frame list exact (tag offsets = cumulated copy lengths), coarse CFO and tag value to 1e-6 / 1e-5, every row to 1e-4"""
+    import torch
+    x, meta = capture(ofdm64, seed, cfo=cfo, n_frames=n_frames, gap=gap)
+    fe = jrc.SyncFrontEnd(N, CP, 0.6, 10, 8 * (N + CP), SYNC_LEN, ofdm64["l_ltf_fir"], max_frames=n_frames + 4, max_symbols=200, ctx=ctx)
+    d_x = torch.from_numpy(x.view(np.float32).reshape(-1, 2).copy()).cuda()
+    fe.run(d_x, x.size)
+    n, info = fe.results()
+    rows = fe.frames.cpu().numpy().view(np.complex64)[..., 0].reshape(n_frames + 4, -1)
+    xd, ia, ic = oracle.sync_metrics(x, 16, 32, 48, 1 / 1.5)
+    seg, dtags = oracle.FrameDetector(N, CP, 0.6, 10, 8 * (N + CP)).run(xd, ia, ic)
+    delayed = np.concatenate([np.zeros(SYNC_LEN, np.complex64), seg])[:seg.size]
+    out, otags = oracle.FrameSync(N, CP, SYNC_LEN, ofdm64["l_ltf_fir"]).run(seg, delayed, dtags)
+    assert n == n_frames == len(dtags) == len(otags)
+    assert [t[0] for t in dtags] == list(np.cumsum([0] + [f.len for f in info[:-1]]))
+    for k in range(n):
+        assert abs(info[k].coarse_cfo - dtags[k][1]) < 1e-6 and abs(info[k].tag_value - otags[k][1]) < 1e-5, k
+        lo = otags[k][0]
+        hi = otags[k + 1][0] if k + 1 < n else out.size
+        want = out[lo:hi]
+        m = min(want.size, info[k].n_out)
+        if k + 1 < n:
+            assert want.size == info[k].n_out, k
+        assert m > 20 * N and rel_err(rows[k][:m], want[:m]) < TOL, k
