@@ -346,6 +346,30 @@ __device__ float2 sm_abs_at(const float2* __restrict__ x, long i, int delay, int
     for (int m = 0; m < w1; m++, j++) { const float2 e = B(j); a.x = a.x + e.x; a.y = a.y + e.y; }
     return a;
 }
+// the same value formed by a whole wavefront (window <= 64): lane l takes product l of the window, the runs of 4 and of 16 come out of lane
+// shuffles in the tree's order, the window's runs are then added oldest first — every lane returns the sum
+__device__ float2 sm_abs_at_wave(const float2* __restrict__ x, long i, int delay, int window, int lane)
+{
+#pragma clang fp contract(off)
+    const long g = i - window + 1 + lane;
+    float2 B = make_float2(0.f, 0.f);
+    if (lane < window && g >= delay) {
+        const float2 u = x[g], v = x[g - delay];
+        B = make_float2(v.x * u.x + v.y * u.y, v.x * u.y - v.y * u.x);
+    }
+    auto down = [&](float2 v, int k) { return make_float2(__shfl_down(v.x, k), __shfl_down(v.y, k)); };
+    const float2 b1 = down(B, 1), b2 = down(B, 2), b3 = down(B, 3);
+    const float2 A = make_float2(((B.x + b1.x) + b2.x) + b3.x, ((B.y + b1.y) + b2.y) + b3.y);
+    const float2 a4 = down(A, 4), a8 = down(A, 8), a12 = down(A, 12);
+    const float2 E = make_float2(((A.x + a4.x) + a8.x) + a12.x, ((A.y + a4.y) + a8.y) + a12.y);
+    const int w16 = window >> 4, w4 = (window >> 2) & 3, w1 = window & 3;
+    float2 a = make_float2(0.f, 0.f);
+    int j = 0;
+    for (int m = 0; m < w16; m++, j += 16) { a.x = a.x + __shfl(E.x, j); a.y = a.y + __shfl(E.y, j); }
+    for (int m = 0; m < w4; m++, j += 4) { a.x = a.x + __shfl(A.x, j); a.y = a.y + __shfl(A.y, j); }
+    for (int m = 0; m < w1; m++, j++) { a.x = a.x + __shfl(B.x, j); a.y = a.y + __shfl(B.y, j); }
+    return a;
+}
 // where the scans take the correlation of a detection from: the stream (in_abs != NULL) or the capture itself
 struct FdAbs {
     const float2* in_abs; const float2* x; int delay, window;
@@ -1124,12 +1148,14 @@ __global__ __launch_bounds__(64) void fd_scan_seg_kernel(FdParams p, const unsig
 }
 
 // the detections the counting pass kept (segments with at most FD_SEG_KEEP of them — frames are ignore_gap samples apart, a 4096-sample segment
-// rarely holds more) go to their places in the list, one lane per segment; the coarse CFO of each is formed here (:112)
+// rarely holds more) go to their places in the list, one wavefront per segment; the coarse CFO of each is formed here (:112), the window's
+// products spread over the lanes
 __global__ __launch_bounds__(256) void fd_scan_gather_kernel(FdParams p, FdAbs src, const int* __restrict__ counts, const int* __restrict__ prefix,
                                                              const int* __restrict__ kept, int n_seg, SfFrame* __restrict__ frames, int max_frames,
                                                              int* __restrict__ overflow_start)
 {
-    const int w = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= n_seg) return;
     const int c = counts[w];
     if (c > FD_SEG_KEEP) return;                                 // listed by fd_scan_seg_kernel<true>
@@ -1137,12 +1163,14 @@ __global__ __launch_bounds__(256) void fd_scan_gather_kernel(FdParams p, FdAbs s
     for (int d = 0; d < c; d++) {
         const int idx = base + d, i = kept[w * FD_SEG_KEEP + d];
         if (idx < max_frames) {
-            const float2 av = src.at(i);
-            SfFrame f; f.start = i; f.len = 0; f.coarse_cfo = (float)((double)atan2f(av.y, av.x) / (p.fft_len / 4.0));
-            f.frame_start = 0; f.fine_cfo = 0.f; f.tag_value = 0; f.n_out = 0; f.pad_ = 0;
-            frames[idx] = f;
+            const float2 av = (!src.in_abs && src.window <= 64) ? sm_abs_at_wave(src.x, i, src.delay, src.window, lane) : src.at(i);
+            if (lane == 0) {
+                SfFrame f; f.start = i; f.len = 0; f.coarse_cfo = (float)((double)atan2f(av.y, av.x) / (p.fft_len / 4.0));
+                f.frame_start = 0; f.fine_cfo = 0.f; f.tag_value = 0; f.n_out = 0; f.pad_ = 0;
+                frames[idx] = f;
+            }
         } else {
-            if (idx == max_frames) *overflow_start = i;
+            if (idx == max_frames && lane == 0) *overflow_start = i;
             break;
         }
     }
@@ -1221,7 +1249,7 @@ static int launch_fd_scan(jrc_ctx* ctx, const FdParams& p, const unsigned long l
                        (const int*)nullptr);
     hipLaunchKernelGGL(fd_scan_blocksum_kernel, dim3(n_blk), dim3(1024), 0, s, (const int*)counts, n_seg, blocksum);
     hipLaunchKernelGGL(fd_scan_prefix_kernel, dim3(n_blk), dim3(1024), 0, s, (const int*)counts, n_seg, (const int*)blocksum, prefix);
-    hipLaunchKernelGGL(fd_scan_gather_kernel, dim3((n_seg + 255) / 256), dim3(256), 0, s, p, d_abs, (const int*)counts, (const int*)prefix, (const int*)kept, n_seg,
+    hipLaunchKernelGGL(fd_scan_gather_kernel, dim3((n_seg + 3) / 4), dim3(256), 0, s, p, d_abs, (const int*)counts, (const int*)prefix, (const int*)kept, n_seg,
                        d_info, max_frames, overflow);
     hipLaunchKernelGGL(fd_scan_seg_kernel<true>, dim3(n_seg), dim3(64), 0, s, p, d_marks, d_abs, n_samples, G, prefix, d_info, max_frames, overflow, (int*)nullptr,
                        (const int*)counts);
