@@ -73,6 +73,9 @@ int main(int argc, char** argv)
         }
     });
 
+    const char* age_env = getenv("JRC_RADAR_CHAIN_MAX_AGE_US");
+    const bool drains = age_env && atol(age_env) == 0;                 // bound 0: every turn publishes all it submitted
+    std::atomic<int> turns_left_in_flight{0};
     std::thread scheduler([&] {
         int turn = 0;
         for (int f0 = 0; f0 < F; f0 += per_turn, turn++) {
@@ -90,6 +93,10 @@ int main(int argc, char** argv)
             gr_vector_void_star out;
             CHECK(blk->t_run(0, nin, in, out) == 0, "general_work");
             for (int p = 0; p < T + R; p++) CHECK(blk->t_consumed[p] == nf * n_items, "turn %d consumed %d on port %d", turn, blk->t_consumed[p], p);
+            // the double's batches take 300 us: the turn's last one cannot be back yet — it stays in flight into the next turn unless the bound is 0
+            const int left = blk->pending_batches();
+            if (drains) CHECK(left == 0, "turn %d: bound 0 but %d batches in flight after general_work", turn, left);
+            else if (left > 0) turns_left_in_flight++;
             if (turn % 5 == 4) std::this_thread::sleep_for(std::chrono::milliseconds(3));      // idle scheduler: the flusher publishes what is overdue
             if (turn == 20) blk->flush();                                                       // a setter's path, between two turns
         }
@@ -113,6 +120,7 @@ int main(int argc, char** argv)
     }
     CHECK(blk->rx_only_batches() > 0 && rx_only_frames > F / 2, "rx-only batches %ld, frames %d of %d", blk->rx_only_batches(), rx_only_frames, F);
     CHECK(observations.load() > 10, "the observer ran %ld times", observations.load());
+    CHECK(drains || turns_left_in_flight.load() > 0, "no turn left a batch in flight: the block drained every call although the age bound is not 0");
     printf("ok: %d frames, %ld receive-only batches (%d frames), %ld observations\n", F, blk->rx_only_batches(), rx_only_frames, observations.load());
     blk.reset();                                                        // joins the flusher, destroys the feed
     return 0;

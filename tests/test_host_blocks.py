@@ -643,8 +643,9 @@ def test_radar_chain_block_pipelines_across_turns_and_uploads_receive_ports_only
             assert {k: v[0] for k, v in m["msg"]}["snr"] == want[i].snr_est, i
     if max_age_us == "0":
         assert seen_pending == 0 and len(blk.state()["published"]) == F
-    else:
-        assert seen_pending >= 1                                       # the last batches of a turn were still in flight when it returned
+    # with an age bound the last batches of a turn are normally still in flight when it returns (seen_pending >= 1); whether they are depends on
+    # how the GPU's ~50 us per batch compare with the host's time to publish the earlier ones, so it is not asserted here — the CPU tier holds it
+    # against a feed whose batches take a fixed 300 us (tests/host_sanitize/radar_chain_threads.cc)
     blk.set("stop", 1)
     assert blk.query("pending_batches") == 0 and blk.query("frames_done") == F
     msgs = blk.state()["published"]
