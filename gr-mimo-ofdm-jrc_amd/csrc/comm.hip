@@ -115,9 +115,15 @@ extern "C" int jrc_sig_encode(int n_data, int mcs, int packet_type, int length, 
 
 // ------------------------------------------------------------------------------------------------
 // C1 equalizer
+#ifdef JRC_TIMING_EXPERIMENTS
+#define EQ_EXP(d) ((d).exp)
+#else
+#define EQ_EXP(d) 0
+#endif
 struct EqDev {
     int N, cp, ND, NP, NAct, NL, T, mapped_cols, n_pilot_rows, estimator, lds_tables;
-    int exp;            // JRC_EQ_EXP (timing experiments, WRONG RESULTS): 1 = the pilot phase reads the batch's first symbol for every symbol; 2 = the MIMO-LTF symbols are not stored to / read from HBM
+    int exp;            // timing experiments of DESIGN.md §6 — WRONG RESULTS, so only in builds with -DJRC_TIMING_EXPERIMENTS (tools/ra_variants.py), where JRC_EQ_EXP selects:
+                        // 1 = the pilot phase reads the batch's first symbol for every symbol; 2 = the MIMO-LTF symbols are not stored to / read from HBM
     int sig_full;       // JRC_EQ_SIG_FULL: always run the windowed Viterbi on the SIG field (no codeword shortcut)
     double freq, bw;
     const int* data_c; const int* pilot_c; const int* active_c;
@@ -361,7 +367,7 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
                         const float2* prow = d.pilot_sym + (size_t)((sy - 3 - NL) % d.n_pilot_rows) * NP;
                         const double k0 = 2 * M_PI * sy * ((N + d.cp) * 1.0 / N) * eps;
                         const int c = pc[kc];
-                        const float2 yk = c_mul(in[(size_t)(n_in + (d.exp == 1 ? 0 : jc)) * N + c], c_expj(k0 * (c - N / 2)));
+                        const float2 yk = c_mul(in[(size_t)(n_in + (EQ_EXP(d) == 1 ? 0 : jc)) * N + c], c_expj(k0 * (c - N / 2)));
                         const float2 e = c_mul(Hsel[c], prow[kc]);
                         float2 sum = make_float2(0.f, 0.f);
                         if (on) { const float2 pp = c_mul(yk, c_conj(e)); sum.x = sum.x + pp.x; sum.y = sum.y + pp.y; }
@@ -577,7 +583,7 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
             if (s_flag && nev < io.max_events) nev++;
         } else if (sym <= 2 + NL) {                                                     // MIMO-LTFs :346-463
             const int l = sym - 3;
-            if (d.exp != 2) for (int i = tid; i < N; i += NT) pre[(size_t)i * NL + l] = Y[i];       // JRC_EQ_EXP=2 (timing only): no MIMO-LTF store
+            if (EQ_EXP(d) != 2) for (int i = tid; i < N; i += NT) pre[(size_t)i * NL + l] = Y[i];
             __syncthreads();
             if (l == NL - 1) {
                 if (S.packet_type == 1) {                                               // NDP :375-422
@@ -617,7 +623,7 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
                         const int sc = k < ND ? dc[k] : pc[k - ND];
                         float2 acc = make_float2(0.f, 0.f);
                         for (int q = 0; q < NL; q++) {                                  // row(0).dot(y): conjugates the row
-                            const float2 p = c_mul(c_conj(d.mapped[(size_t)sc * d.mapped_cols + q]), d.exp == 2 ? Y[sc] : pre[(size_t)sc * NL + q]);
+                            const float2 p = c_mul(c_conj(d.mapped[(size_t)sc * d.mapped_cols + q]), EQ_EXP(d) == 2 ? Y[sc] : pre[(size_t)sc * NL + q]);
                             acc.x = acc.x + p.x; acc.y = acc.y + p.y;
                         }
                         Hm[sc] = make_float2(acc.x / (float)NL, acc.y / (float)NL);
@@ -806,7 +812,11 @@ extern "C" int jrc_equalizer_create(jrc_ctx* ctx, const jrc_eq_cfg* c, int n_str
     d.mapped_cols = c->mapped_cols; d.n_pilot_rows = c->n_pilot_rows; d.estimator = c->estimator;
     d.freq = c->freq; d.bw = c->bw;
     d.sig_full = ctx->tune.eq_sig_full ? 1 : 0;
+#ifdef JRC_TIMING_EXPERIMENTS
     d.exp = getenv("JRC_EQ_EXP") ? atoi(getenv("JRC_EQ_EXP")) : 0;
+#else
+    d.exp = 0;
+#endif
     d.data_c = (const int*)tb; d.pilot_c = d.data_c + ND; d.active_c = d.pilot_c + NP;
     d.pilot_sym = (const float2*)(tb + off_ps); d.ltf = (const float2*)(tb + off_ps + b_ps);
     d.mapped = (const float2*)(tb + off_ps + b_ps + b_ltf);

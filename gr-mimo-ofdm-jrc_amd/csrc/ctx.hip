@@ -99,10 +99,19 @@ extern "C" int jrc_create(int device, jrc_ctx** out)
     ctx->tune.eq_sig_full = getenv("JRC_EQ_SIG_FULL") != nullptr;
     if (const char* e = getenv("JRC_EQ_WPE")) ctx->tune.eq_wpe = atoi(e);
     if (const char* e = getenv("JRC_EQ_THREADS")) ctx->tune.eq_threads = atoi(e);
-    // the timing experiments leave work out: say so where nobody can miss it
-    if ((ctx->tune.detect_exp & (1 | 2 | 32)) || (ctx->tune.rd_exp & (1 | 2)))
+    // the timing experiments leave work out (wrong results): they exist only in a library built for them (-DJRC_TIMING_EXPERIMENTS on this file,
+    // tools/ra_variants.py), and say so where nobody can miss it; any other build drops those bits
+    if ((ctx->tune.detect_exp & (1 | 2 | 32)) || (ctx->tune.rd_exp & (1 | 2))) {
+#ifdef JRC_TIMING_EXPERIMENTS
         fprintf(stderr, "libjrc_hip: JRC_DETECT_EXP=%d / JRC_RD_EXP=%d select TIMING-ONLY kernel experiments on this context: RESULTS ARE WRONG\n",
                 ctx->tune.detect_exp, ctx->tune.rd_exp);
+#else
+        fprintf(stderr, "libjrc_hip: the work-skipping bits of JRC_DETECT_EXP=%d / JRC_RD_EXP=%d are ignored (not a -DJRC_TIMING_EXPERIMENTS build)\n",
+                ctx->tune.detect_exp, ctx->tune.rd_exp);
+        ctx->tune.detect_exp &= ~(1 | 2 | 32);
+        ctx->tune.rd_exp &= ~(1 | 2);
+#endif
+    }
     *out = ctx;
     return JRC_OK;
 }

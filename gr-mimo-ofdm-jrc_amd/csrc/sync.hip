@@ -1386,10 +1386,10 @@ extern "C" int jrc_sync_frontend_dev(jrc_ctx* ctx, const jrc_sync_cfg* c, int n_
                                c->power_window, c->power_scale, T, halo, d_marks, p.threshold, p.max_peak_value, (float)(p.threshold * (1 - m)),
                                (float)(p.threshold * (1 + m)), (float)(p.max_peak_value * (1 - m)), (float)(p.max_peak_value * (1 + m)));
         } else {
-        JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)sync_metrics_tiled_kernel<true>, tile_lds));
-        hipLaunchKernelGGL(sync_metrics_tiled_kernel<true>, dim3((n_samples + SM_TILE - 1) / SM_TILE), dim3(256), tile_lds, s, (const float2*)d_x, n_samples,
-                           c->delay, c->window, c->power_window, c->power_scale, (float2*)nullptr, (float2*)nullptr, (float*)nullptr, d_marks, p.threshold,
-                           p.max_peak_value);
+            JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)sync_metrics_tiled_kernel<true>, tile_lds));
+            hipLaunchKernelGGL(sync_metrics_tiled_kernel<true>, dim3((n_samples + SM_TILE - 1) / SM_TILE), dim3(256), tile_lds, s, (const float2*)d_x,
+                               n_samples, c->delay, c->window, c->power_window, c->power_scale, (float2*)nullptr, (float2*)nullptr, (float*)nullptr, d_marks,
+                               p.threshold, p.max_peak_value);
         }
         src.in_abs = nullptr; src.x = (const float2*)d_x; src.delay = c->delay; src.window = c->window;
     } else {
@@ -1400,10 +1400,11 @@ extern "C" int jrc_sync_frontend_dev(jrc_ctx* ctx, const jrc_sync_cfg* c, int n_
         d_delayed = d_xd;
     }
     JRC_TRY(launch_fd_scan(ctx, p, (const unsigned long long*)d_marks, src, n_samples, (SfFrame*)d_info, max_frames, d_n_frames, s));
-    const size_t lds = sizeof(float2) * ((size_t)2 * c->sync_length + c->n_taps - 1);
+    const size_t lds = sizeof(float2) * ((size_t)2 * c->sync_length + c->n_taps - 1);       // up to 73 KB at sync_length 4096, n_taps 1024
+    JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)sf_frames_kernel, lds));
     hipLaunchKernelGGL(sf_frames_kernel, dim3(max_frames), dim3(256), lds, s, d_delayed ? d_delayed : (const float2*)d_x, d_delayed ? 0 : c->delay, n_samples,
-                       (const float2*)c->d_ltf_taps, c->n_taps,
-                       c->sync_length, c->fft_len, c->cp_len, (SfFrame*)d_info, (const int*)d_n_frames, (float2*)d_frames, (long)max_symbols * c->fft_len);
+                       (const float2*)c->d_ltf_taps, c->n_taps, c->sync_length, c->fft_len, c->cp_len, (SfFrame*)d_info, (const int*)d_n_frames,
+                       (float2*)d_frames, (long)max_symbols * c->fft_len);
     JRC_HIP(ctx, hipGetLastError());
     return JRC_OK;
 }

@@ -516,7 +516,9 @@ int jrc_zero_pad_strided_dev(jrc_ctx* ctx, int n_bursts, int n_input, unsigned p
 
 /* batched, device-resident form of the whole front end (detection metrics -> frame_detector -> frame_sync run to completion on
  * one capture): frame k of the capture lands in row k of d_frames ([max_frames][max_symbols * fft_len] time-domain samples,
- * cyclic prefixes removed, de-rotated, first two symbols = the long training field as frame_sync delivers it). */
+ * cyclic prefixes removed, de-rotated, first two symbols = the long training field as frame_sync delivers it).  d_work:
+ * jrc_sync_frontend_work_bytes(n_samples) bytes of scratch whose contents afterwards are unspecified (the metric streams only pass through it
+ * when the windows do not fit an LDS tile; otherwise the peak mask is all that is written). */
 typedef struct {
     int fft_len, cp_len;
     double threshold;                 /* frame_detector */

@@ -557,13 +557,31 @@ def test_power_map_random_shapes(jrc, ctx, T, R, N, S, Ir, Ia, interleave):
 
 
 @pytest.mark.gpu
-def test_timing_only_experiment_switches_announce_themselves():
-    """JRC_DETECT_EXP / JRC_RD_EXP bits that leave work out of a kernel (tools/detect_exp.sh, tools/rd_exp.sh) must not pass unnoticed in a process
-    that happens to inherit them: the context says so on stderr; the switches that keep the results (8, 16) stay silent"""
+def test_work_skipping_experiment_switches_do_nothing_in_this_library():
+    """JRC_DETECT_EXP / JRC_RD_EXP bits that leave work out of a kernel (tools/detect_exp.sh, tools/rd_exp.sh; the equalizer's JRC_EQ_EXP) exist
+    only in a library built with -DJRC_TIMING_EXPERIMENTS.  A process that happens to inherit them with the shipped library is told they are
+    ignored and gets the same records as without them; the switches that keep the results (8, 16) stay silent."""
     import subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = "import sys; sys.path.insert(0, %r); import jrc_amd; c = jrc_amd.Context(0); c.close()" % root
-    for env, loud in (({"JRC_RD_EXP": "1"}, True), ({"JRC_DETECT_EXP": "32"}, True), ({"JRC_DETECT_EXP": "8"}, False), ({}, False)):
+    code = r"""
+import sys, hashlib; sys.path.insert(0, %r)
+import numpy as np, torch, jrc_amd
+from jrc_amd import synth
+c = jrc_amd.Context(0)
+sc = synth.Scenario(256, 4, 4, 16, targets=[(12.0, 15.0, 0.0, 100.0)])
+rb, ab = jrc_amd.radar_axes(256, sc.fs, 8, 16, 16)
+chain = jrc_amd.RadarChain(256, 4, 4, 16, sc.Npre, 8, 16, rb, ab, 2.4, 14.4, 15.0, 0.0, max_frames=6, ctx=c)
+bufs = chain.alloc(6, "cuda:0")
+fr = synth.make_frames(sc, 6)
+bufs["frames"].copy_(torch.from_numpy(fr.view(np.float32).reshape(bufs["frames"].shape))); torch.cuda.synchronize()
+chain.set_write_map(False); chain.run(bufs, 6); c.sync()
+print("records", hashlib.sha256(bufs["results"].cpu().numpy().tobytes()).hexdigest())
+""" % root
+    seen = {}
+    for env, told in (({}, False), ({"JRC_RD_EXP": "1"}, True), ({"JRC_DETECT_EXP": "32"}, True), ({"JRC_DETECT_EXP": "3"}, True), ({"JRC_DETECT_EXP": "8"}, False),
+                      ({"JRC_EQ_EXP": "2"}, False)):
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
         assert r.returncode == 0, r.stderr[-1000:]
-        assert ("RESULTS ARE WRONG" in r.stderr) == loud, (env, r.stderr[-500:])
+        assert ("are ignored" in r.stderr) == told and "RESULTS ARE WRONG" not in r.stderr, (env, r.stderr[-500:])
+        seen[str(env)] = [l for l in r.stdout.splitlines() if l.startswith("records")][-1]
+    assert len(set(seen.values())) == 1, seen

@@ -1,5 +1,7 @@
 #!/bin/bash
-# detect-only kernel timing experiments (GPU box): JRC_DETECT_EXP variants of tools/bench_extra.py's detect legs
+# detect-only kernel timing experiments (GPU box): JRC_DETECT_EXP variants of tools/bench_extra.py's detect legs.  Bits 1 / 2 / 32 skip work and
+# exist only in a library whose ctx.hip was built with -DJRC_TIMING_EXPERIMENTS: tools/ra_variants.py build timing:ctx.hip:-DJRC_TIMING_EXPERIMENTS,
+# then JRC_LIB_PATH=gr-mimo-ofdm-jrc_amd/lib/variants/timing/libjrc_hip.so
 for E in ${DETECT_EXPS:-0 16 8}; do
   echo "== JRC_DETECT_EXP=$E"
   JRC_DETECT_EXP=$E JRC_BENCH_EXTRA_ONLY=detect python3 tools/bench_extra.py 2>/dev/null | python3 -c "

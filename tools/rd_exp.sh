@@ -1,5 +1,6 @@
 #!/bin/bash
-# range-Doppler pruned-FFT kernel experiments (GPU box): per-kernel times of tools/rd_probe.py under JRC_RD_EXP variants
+# range-Doppler pruned-FFT kernel experiments (GPU box): per-kernel times of tools/rd_probe.py under JRC_RD_EXP variants (work-skipping: needs a
+# library whose ctx.hip was built with -DJRC_TIMING_EXPERIMENTS, see tools/detect_exp.sh)
 # usage: tools/rd_exp.sh [cfg frames]      RD_EXPS="0 1 2 3"
 CFG=${1:-D}; F=${2:-16}
 REPO=$(pwd); export TMPDIR=/tmp
