@@ -340,3 +340,33 @@ def test_batched_front_end_equals_the_block_chain_on_longer_captures(jrc, ctx, o
         if k + 1 < n:
             assert want.size == info[k].n_out, k
         assert m > 20 * N and rel_err(rows[k][:m], want[:m]) < TOL, k
+
+
+def test_front_end_on_empty_and_frameless_captures(jrc, ctx, ofdm64):
+    """nothing to find: an empty capture, a capture shorter than a window, noise only, silence — zero frames, no row touched, in all three forms'
+    default one; and a list shorter than the capture's frames keeps the first ones"""
+    import torch
+    rng = np.random.default_rng(8)
+    fe = jrc.SyncFrontEnd(N, CP, 0.6, 10, 8 * (N + CP), SYNC_LEN, ofdm64["l_ltf_fir"], max_frames=2, max_symbols=40, ctx=ctx)
+    noise = (rng.standard_normal(50000) + 1j * rng.standard_normal(50000)).astype(np.complex64)
+    for x, n in ((noise, 0), (noise, 1), (noise, 47), (noise, noise.size), (np.zeros(9000, np.complex64), 9000)):
+        d_x = torch.from_numpy(x.view(np.float32).reshape(-1, 2).copy()).cuda()
+        fe.frames.fill_(7.0)
+        torch.cuda.synchronize()
+        fe.run(d_x, n)
+        nf, info = fe.results()
+        assert nf == 0 and info == [], n
+        assert float(fe.frames.min()) == 7.0 and float(fe.frames.max()) == 7.0
+    x, meta = capture(ofdm64, 30, cfo=0.01, n_frames=5)
+    d_x = torch.from_numpy(x.view(np.float32).reshape(-1, 2).copy()).cuda()
+    fe.run(d_x, x.size)
+    nf, info = fe.results()
+    big = jrc.SyncFrontEnd(N, CP, 0.6, 10, 8 * (N + CP), SYNC_LEN, ofdm64["l_ltf_fir"], max_frames=8, max_symbols=40, ctx=ctx)
+    big.run(d_x, x.size)
+    nb, binfo = big.results()
+    xd, ia, ic = oracle.sync_metrics(x, 16, 32, 48, 1 / 1.5)
+    _, dtags = oracle.FrameDetector(N, CP, 0.6, 10, 8 * (N + CP)).run(xd, ia, ic)
+    assert nb == len(dtags) >= 5 and nf == 2                   # (a payload can hold a plateau of its own: the detector's count is the oracle's)
+    for a, b in zip(info, binfo[:2]):
+        assert (a.start, a.len, a.coarse_cfo, a.frame_start, a.fine_cfo, a.n_out) == (b.start, b.len, b.coarse_cfo, b.frame_start, b.fine_cfo, b.n_out)
+    assert torch.equal(fe.frames[:2], big.frames[:2])
