@@ -159,7 +159,9 @@ def test_equalizer_against_oracle(jrc, ctx, ofdm64, i):
         pos += len(part)
     go, oo = np.concatenate(go), np.concatenate(oo)
     assert go.shape == (ns, 48), draw
-    assert rel_err(go, oo) < 2e-5, draw
+    # 1e-7 everywhere but in symbols whose four pilots nearly cancel in the phase estimate: the angle of a small sum turns the last-bit differences
+    # of the de-rotations before it (device polynomial vs libm's sincosf) into a few 1e-5 rad for that one symbol (seed 777123, draw 1078: 2.4e-5)
+    assert rel_err(go, oo) < 5e-5, draw
 
 
 @pytest.mark.parametrize("i", range(N_DRAWS))
