@@ -203,3 +203,41 @@ def test_precoder_and_codec_against_oracle(jrc, ctx, ofdm64, i):
     ok, payload = dec.work(noisy, dict(mcs=mcs, data_bytes=len(pdu) + 4))
     ook, opayload = oracle.stream_decode(mcs, 48, len(pdu) + 4, noisy)
     assert bool(ok) == bool(ook) and payload == opayload, (mcs, len(pdu))
+
+
+@pytest.mark.parametrize("i", range(max(4, N_DRAWS // 3)))
+def test_sync_front_end_against_oracle(jrc, ctx, ofdm64, i):
+    """random captures (1-9 frames of random length and MCS, random carrier offset, lead and gap, a low noise floor) through the run-to-completion
+    front end and through the oracle's sample-by-sample frame_detector + frame_sync: the same frame list (copy lengths exact, coarse CFO and tag value
+    to 1e-6 / 1e-5), every row to 1e-4"""
+    import torch
+    from test_gpu_sync import CP, N, SYNC_LEN
+    from test_oracle_sync import make_stream
+    rng = np.random.default_rng(SEED + 5000 + i)
+    n_frames, cfo = int(rng.integers(1, 10)), float(rng.uniform(-0.02, 0.02))
+    parts = []
+    for k in range(n_frames):
+        payload = bytes([2]) + rng.integers(0, 256, int(rng.integers(5, 400)), dtype=np.uint8).tobytes()
+        x, _, _ = make_stream(ofdm64, payload, int(rng.integers(0, 6)), rng, lead=int(rng.integers(300, 1500)), tail=int(rng.integers(700, 4000)), cfo=cfo)
+        parts.append(x)
+    x = np.concatenate(parts)
+    draw = dict(i=i, n_frames=n_frames, cfo=cfo, n=x.size)
+    fe = jrc.SyncFrontEnd(N, CP, 0.6, 10, 8 * (N + CP), SYNC_LEN, ofdm64["l_ltf_fir"], max_frames=n_frames + 6, max_symbols=640, ctx=ctx)
+    d_x = torch.from_numpy(x.view(np.float32).reshape(-1, 2).copy()).cuda()
+    fe.run(d_x, x.size)
+    n, info = fe.results()
+    rows = fe.frames.cpu().numpy().view(np.complex64)[..., 0].reshape(n_frames + 6, -1)
+    xd, ia, ic = oracle.sync_metrics(x, 16, 32, 48, 1 / 1.5)
+    seg, dtags = oracle.FrameDetector(N, CP, 0.6, 10, 8 * (N + CP)).run(xd, ia, ic)
+    delayed = np.concatenate([np.zeros(SYNC_LEN, np.complex64), seg])[:seg.size]
+    out, otags = oracle.FrameSync(N, CP, SYNC_LEN, ofdm64["l_ltf_fir"]).run(seg, delayed, dtags)
+    assert n == len(dtags) == len(otags) >= n_frames, draw
+    assert [t[0] for t in dtags] == list(np.cumsum([0] + [f.len for f in info[:-1]])), draw
+    for k in range(n):
+        assert abs(info[k].coarse_cfo - dtags[k][1]) < 1e-6 and abs(info[k].tag_value - otags[k][1]) < 1e-5, (draw, k)
+        lo, hi = otags[k][0], (otags[k + 1][0] if k + 1 < n else out.size)
+        want = out[lo:hi]
+        m = min(want.size, info[k].n_out)
+        if k + 1 < n:
+            assert want.size == info[k].n_out, (draw, k)
+        assert rel_err(rows[k][:m], want[:m]) < 1e-4, (draw, k)
