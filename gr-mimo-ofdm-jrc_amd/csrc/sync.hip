@@ -1260,6 +1260,11 @@ static int launch_fd_scan(jrc_ctx* ctx, const FdParams& p, const unsigned long l
     return JRC_OK;
 }
 
+// Two launches: PHASE 0 searches every frame's long training field (frame_start, fine offset — not a number when no pair of peaks matched),
+// PHASE 1 copies.  Between them lies the one thing frame_sync carries from frame to frame: d_freq_offset is only assigned when a pair matches
+// (:262-284), so a frame whose search fails — a false detection inside a payload, typically — is copied with the offset of the last frame
+// before it whose search succeeded (0 if there is none); PHASE 1 looks that up in the list PHASE 0 completed.
+template <int PHASE>
 __global__ __launch_bounds__(256) void sf_frames_kernel(const float2* __restrict__ xs, int xs_delay /* xd[g] = xs[g - xs_delay], 0 before the stream starts */, int n,
                                                         const float2* __restrict__ taps, int ntaps,
                                                         int sync_length, int N, int cp, SfFrame* __restrict__ frames, const int* __restrict__ n_frames,
@@ -1283,21 +1288,31 @@ __global__ __launch_bounds__(256) void sf_frames_kernel(const float2* __restrict
         const int g = fr.start + so - xs_delay;
         return g >= 0 ? cmul(xs[g], make_float2(cs, sn)) : make_float2(0.f, 0.f);
     };
-    for (int i = threadIdx.x; i < sync_length + ntaps - 1; i += blockDim.x) s_in[i] = det_out(i);
-    __syncthreads();
-    for (int i = threadIdx.x; i < sync_length; i += blockDim.x) {
-        float2 acc = make_float2(0.f, 0.f);
-        for (int k = 0; k < ntaps; k++) {
-            const float2 p = cmul(taps[k], s_in[i + ntaps - 1 - k]);
-            acc.x = acc.x + p.x; acc.y = acc.y + p.y;
+    if (PHASE == 0) {
+        for (int i = threadIdx.x; i < sync_length + ntaps - 1; i += blockDim.x) s_in[i] = det_out(i);
+        __syncthreads();
+        for (int i = threadIdx.x; i < sync_length; i += blockDim.x) {
+            float2 acc = make_float2(0.f, 0.f);
+            for (int k = 0; k < ntaps; k++) {
+                const float2 p = cmul(taps[k], s_in[i + ntaps - 1 - k]);
+                acc.x = acc.x + p.x; acc.y = acc.y + p.y;
+            }
+            s_corr[i] = acc;
         }
-        s_corr[i] = acc;
+        __syncthreads();
+        fs_search_block(s_corr, sync_length, N, &sr, s_best, s_bidx, top);
+        __syncthreads();
+        if (threadIdx.x == 0) { frames[f].frame_start = sr.frame_start; frames[f].fine_cfo = sr.freq_offset; }
+        return;
+    }
+    const int fstart = fr.frame_start;
+    if (threadIdx.x == 0) {
+        float v = fr.fine_cfo;
+        for (int k = f - 1; k >= 0 && v != v; k--) v = frames[k].fine_cfo;             // (a frame resolved meanwhile holds the same value its own walk would find)
+        sr.freq_offset = (v == v) ? v : 0.f;                                            // no pair matched on a fresh synchroniser: 0
     }
     __syncthreads();
-    fs_search_block(s_corr, sync_length, N, &sr, s_best, s_bidx, top);
-    __syncthreads();
-    const int fstart = sr.frame_start;
-    const float fine = (sr.freq_offset == sr.freq_offset) ? sr.freq_offset : 0.f;     // no pair matched on a fresh synchroniser: 0
+    const float fine = sr.freq_offset;
     // COPY: the synchroniser sees the segment again through the sync_length delay, sample offsets counted from the tag; the
     // next tag (or the end of the stream) arrives on the undelayed port sync_length samples before the delayed port has
     // delivered the segment's tail, so the last sync_length samples of a segment are never copied
@@ -1401,8 +1416,11 @@ extern "C" int jrc_sync_frontend_dev(jrc_ctx* ctx, const jrc_sync_cfg* c, int n_
     }
     JRC_TRY(launch_fd_scan(ctx, p, (const unsigned long long*)d_marks, src, n_samples, (SfFrame*)d_info, max_frames, d_n_frames, s));
     const size_t lds = sizeof(float2) * ((size_t)2 * c->sync_length + c->n_taps - 1);       // up to 73 KB at sync_length 4096, n_taps 1024
-    JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)sf_frames_kernel, lds));
-    hipLaunchKernelGGL(sf_frames_kernel, dim3(max_frames), dim3(256), lds, s, d_delayed ? d_delayed : (const float2*)d_x, d_delayed ? 0 : c->delay, n_samples,
+    JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)sf_frames_kernel<0>, lds));
+    hipLaunchKernelGGL(sf_frames_kernel<0>, dim3(max_frames), dim3(256), lds, s, d_delayed ? d_delayed : (const float2*)d_x, d_delayed ? 0 : c->delay, n_samples,
+                       (const float2*)c->d_ltf_taps, c->n_taps, c->sync_length, c->fft_len, c->cp_len, (SfFrame*)d_info, (const int*)d_n_frames,
+                       (float2*)d_frames, (long)max_symbols * c->fft_len);
+    hipLaunchKernelGGL(sf_frames_kernel<1>, dim3(max_frames), dim3(256), 0, s, d_delayed ? d_delayed : (const float2*)d_x, d_delayed ? 0 : c->delay, n_samples,
                        (const float2*)c->d_ltf_taps, c->n_taps, c->sync_length, c->fft_len, c->cp_len, (SfFrame*)d_info, (const int*)d_n_frames,
                        (float2*)d_frames, (long)max_symbols * c->fft_len);
     JRC_HIP(ctx, hipGetLastError());
