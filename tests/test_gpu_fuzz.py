@@ -245,3 +245,79 @@ def test_sync_front_end_against_oracle(jrc, ctx, ofdm64, i):
         # whose correlation angle means nothing, is 5e-4 rad at its end — so the rows are held to 1e-4 plus that ramp
         tol = 1e-4 + 1.5 * abs(info[k].coarse_cfo - dtags[k][1]) * info[k].len
         assert rel_err(rows[k][:m], want[:m]) < tol, (draw, k, tol)
+
+
+@pytest.mark.parametrize("i", range(max(4, N_DRAWS // 3)))
+def test_detector_and_synchroniser_blocks_call_for_call(jrc, ctx, ofdm64, i):
+    """the two blocks of the sync front end as a scheduler would drive them — drawn chunk sizes and output-buffer sizes per call — against the
+    oracle on the same calls: items consumed / produced and tags exact, samples to 1e-4 (+ the coarse-CFO ramp), the synchroniser's state
+    (frame_start, freq_offset) after every call"""
+    from test_gpu_sync import CP, N, SYNC_LEN
+    from test_oracle_sync import make_stream
+    rng = np.random.default_rng(SEED + 7000 + i)
+    parts = []
+    for k in range(int(rng.integers(1, 5))):
+        payload = bytes([2]) + rng.integers(0, 256, int(rng.integers(5, 300)), dtype=np.uint8).tobytes()
+        parts.append(make_stream(ofdm64, payload, int(rng.integers(0, 6)), rng, lead=int(rng.integers(300, 1200)), tail=int(rng.integers(700, 3000)),
+                                 cfo=float(rng.uniform(-0.02, 0.02)))[0])
+    x = np.concatenate(parts)
+    xd, ia, ic = oracle.sync_metrics(x, 16, 32, 48, 1 / 1.5)
+    gap = int(rng.choice([8 * (N + CP), 200, 2000]))
+    g, o = jrc.frame_detector(N, CP, 0.6, 10, gap, ctx=ctx), oracle.FrameDetector(N, CP, 0.6, 10, gap)
+    pos, seg_parts, dtags, cfo_err = 0, [], [], 0.0
+    while pos < x.size:
+        n = int(min(rng.choice([1, 17, 333, 1000, 4096, 20000]), x.size - pos))
+        nout = int(max(1, n - rng.choice([0, 0, 7, n // 2])))
+        go, gc, gt = g.work(xd[pos:pos + n], ia[pos:pos + n], ic[pos:pos + n], nout)
+        oo, oc, ot = o.work(xd[pos:pos + n], ia[pos:pos + n], ic[pos:pos + n], nout)
+        assert (gc, go.size, len(gt)) == (oc, oo.size, len(ot)), (i, pos, n, nout)
+        for a, b in zip(gt, ot):
+            assert a[0] == b[0] and abs(a[1] - b[1]) < 1e-6, (i, pos)
+            cfo_err = max(cfo_err, abs(a[1] - b[1]))
+        if go.size:
+            assert rel_err(go, oo) < 1e-4 + 1.5 * cfo_err * 540 * (N + CP), (i, pos)
+        dtags += ot                                                  # offsets are absolute (items written so far)
+        seg_parts.append(oo)
+        if gc == 0 and go.size == 0:
+            break
+        pos += gc
+    seg = np.concatenate(seg_parts) if seg_parts else np.zeros(0, np.complex64)
+    if seg.size < SYNC_LEN + 10 or not dtags:
+        return
+    delayed = np.concatenate([np.zeros(SYNC_LEN, np.complex64), seg])[:seg.size]
+    g, o = jrc.frame_sync(N, CP, SYNC_LEN, ofdm64["l_ltf_fir"], ctx=ctx), oracle.FrameSync(N, CP, SYNC_LEN, ofdm64["l_ltf_fir"])
+    pos, idle = 0, 0
+    while pos < seg.size and idle < 3:
+        m = int(min(rng.choice([64, 200, 1500, 8192]), seg.size - pos))
+        nout = int(max(1, m - rng.choice([0, 0, m // 2])))
+        go, gc, gt = g.work(seg[pos:pos + m], delayed[pos:pos + m], dtags, nout)
+        oo, oc, ot = o.work(seg[pos:pos + m], delayed[pos:pos + m], dtags, nout)
+        assert (gc, go.size, len(gt)) == (oc, oo.size, len(ot)), (i, pos, g.state)
+        for a, b in zip(gt, ot):
+            assert a[0] == b[0] and abs(a[1] - b[1]) < 1e-5, (i, pos)
+        if go.size:
+            assert rel_err(go, oo) < 1e-4, (i, pos)
+        assert g.frame_start == o.frame_start and abs(g.freq_offset - o.freq_offset) < 1e-6, (i, pos)
+        idle = idle + 1 if (gc == 0 and go.size == 0) else 0
+        pos += gc
+
+
+@pytest.mark.parametrize("i", range(max(4, N_DRAWS // 3)))
+def test_target_simulator_against_oracle(jrc, ctx, i):
+    """drawn burst lengths (1 ... 30000, most of them neither powers of two nor smooth), 0-6 targets, 1-4 receive antennas, targets summed or
+    overwriting each other, self coupling and a drawn phase per target: the device's chirp-z convolutions against the oracle's double-precision
+    transforms of the burst's own length, 1e-4"""
+    rng = np.random.default_rng(SEED + 9000 + i)
+    n = int(rng.choice([rng.integers(1, 200), rng.integers(200, 5000), rng.integers(5000, 30000)]))
+    K, R = int(rng.integers(0, 7)), int(rng.integers(1, 5))
+    tg = (rng.uniform(3, 80, K), rng.uniform(-40, 40, K), rng.uniform(1, 100, K), rng.uniform(-70, 70, K))
+    pos = list(np.arange(R) * 0.00625)
+    sc, sumt = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    x = crandn(rng, n)
+    phases = np.exp(2j * np.pi * rng.random(K)).astype(np.complex64) if (K and rng.integers(0, 2)) else None
+    draw = dict(i=i, n=n, K=K, R=R, self_coupling=sc, sum_targets=sumt, phases=phases is not None)
+    got = jrc.target_simulator(*tg, pos, 125_000_000, 24e9, self_coupling=sc, sum_targets=sumt, ctx=ctx).work(x, target_phase=phases)
+    want = oracle.TargetSimulator(*tg, pos, 125_000_000, 24e9, self_coupling=sc).work(x, target_phase=phases, sum_targets=sumt)
+    assert got.shape == want.shape == (R, n), draw
+    scale = np.abs(want).max()
+    assert (np.abs(got - want).max() <= 1e-4 * scale) if scale > 0 else (np.abs(got).max() == 0), draw
