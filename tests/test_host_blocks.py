@@ -748,3 +748,67 @@ def test_radar_block_capture_writes_radar_chan_csv(jrc, tmp_path):
     bad = hb.radar(N, T, R, S, Npre, interp=Ir, radar_chan_file=str(tmp_path / "no_such_dir" / "x.csv"))
     with pytest.raises(RuntimeError, match="Could not open file"):
         bad.set("capture_radar_data", 1)
+
+
+@gpu
+@pytest.mark.parametrize("i", range(int(os.environ.get("JRC_FUZZ_N", "24")) // 3))
+def test_sync_front_end_blocks_under_drawn_scheduling(jrc, ofdm64, i):
+    """frame_detector and frame_sync as C++ blocks (reference work() contracts over the C ABI) driven like a scheduler with drawn chunk and
+    output-buffer sizes over captures of 1-4 frames: items consumed / produced per call, the frame_start tags they attach (offset exact,
+    value to 1e-6 / 1e-5) and the samples, against the oracle called with the same pieces"""
+    import hostblocks as hb
+    from test_oracle_sync import CP, N, make_stream
+    rng = np.random.default_rng(int(os.environ.get("JRC_FUZZ_SEED", "20261002")) + 11000 + i)
+    parts = []
+    for k in range(int(rng.integers(1, 5))):
+        payload = bytes([2]) + rng.integers(0, 256, int(rng.integers(5, 300)), dtype=np.uint8).tobytes()
+        parts.append(make_stream(ofdm64, payload, int(rng.integers(0, 6)), rng, lead=int(rng.integers(300, 1200)), tail=int(rng.integers(700, 3000)),
+                                 cfo=float(rng.uniform(-0.02, 0.02)))[0])
+    x = np.concatenate(parts)
+    xd, ia, ic = oracle.sync_metrics(x, 16, 32, 48, 1 / 1.5)
+    gap = int(rng.choice([8 * (N + CP), 200, 2000]))
+    det, odet = hb.frame_detector(N, CP, 0.6, 10, gap), oracle.FrameDetector(N, CP, 0.6, 10, gap)
+    pos, seg_parts, want_tags, cfo_err = 0, [], [], 0.0
+    while pos < x.size:
+        n = int(min(rng.choice([1, 17, 333, 1000, 4096, 20000]), x.size - pos))
+        nout = int(max(1, n - rng.choice([0, 0, 7, n // 2])))
+        o = np.zeros(nout, np.complex64)
+        got = det.run(nout, [xd[pos:pos + n], ia[pos:pos + n], ic[pos:pos + n]], [o])
+        oo, oc, ot = odet.work(xd[pos:pos + n], ia[pos:pos + n], ic[pos:pos + n], nout)
+        assert got == oo.size and det.consumed(0) == det.consumed(1) == det.consumed(2) == oc, (i, pos, n, nout)
+        want_tags += ot
+        have = [t for t in det.state()["out_tags"][0] if t["key"] == "frame_start"]
+        assert [t["offset"] for t in have] == [t[0] for t in want_tags], (i, pos)
+        for a, b in zip(have, want_tags):
+            assert abs(a["value"] - b[1]) < 1e-6, (i, pos)
+            cfo_err = max(cfo_err, abs(a["value"] - b[1]))
+        if got:
+            assert rel_err(o[:got], oo) < 1e-4 + 1.5 * cfo_err * 540 * (N + CP), (i, pos)
+        seg_parts.append(oo)
+        if oc == 0 and got == 0:
+            break
+        pos += oc
+    seg = np.concatenate(seg_parts) if seg_parts else np.zeros(0, np.complex64)
+    sync_len = 4 * (N + CP)
+    if seg.size < sync_len + 10 or not want_tags:
+        return
+    fs, ofs = hb.frame_sync(N, CP, sync_len, ofdm64["l_ltf_fir"]), oracle.FrameSync(N, CP, sync_len, ofdm64["l_ltf_fir"])
+    for off, val in want_tags:
+        fs.tag(0, off, "frame_start", float(val))
+    delayed = np.concatenate([np.zeros(sync_len, np.complex64), seg])[:seg.size]
+    pos, idle, want_out = 0, 0, []
+    while pos < seg.size and idle < 3:
+        m = int(min(rng.choice([64, 200, 1500, 8192]), seg.size - pos))
+        nout = int(max(1, m - rng.choice([0, 0, m // 2])))
+        o = np.zeros(nout, np.complex64)
+        got = fs.run(nout, [seg[pos:pos + m], delayed[pos:pos + m]], [o])
+        oo, oc, ot = ofs.work(seg[pos:pos + m], delayed[pos:pos + m], want_tags, nout)
+        assert got == oo.size and fs.consumed(0) == fs.consumed(1) == oc, (i, pos, m, nout)
+        want_out += ot
+        have = [t for t in fs.state()["out_tags"][0] if t["key"] == "frame_start"]
+        assert [t["offset"] for t in have] == [t[0] for t in want_out], (i, pos)
+        assert all(abs(a["value"] - b[1]) < 1e-5 for a, b in zip(have, want_out)), (i, pos)
+        if got:
+            assert rel_err(o[:got], oo) < 1e-4, (i, pos)
+        idle = idle + 1 if (oc == 0 and got == 0) else 0
+        pos += oc
