@@ -812,3 +812,50 @@ def test_sync_front_end_blocks_under_drawn_scheduling(jrc, ofdm64, i):
             assert rel_err(o[:got], oo) < 1e-4, (i, pos)
         idle = idle + 1 if (oc == 0 and got == 0) else 0
         pos += oc
+
+
+@gpu
+@pytest.mark.parametrize("i", range(int(os.environ.get("JRC_FUZZ_N", "24")) // 3))
+def test_equalizer_block_under_drawn_scheduling(jrc, ofdm64, tmp_path, i):
+    """mimo_ofdm_equalizer as a C++ block fed a drawn frame (packet type, MCS, length, estimator, channel, noise, carrier-phase tag, junk around it)
+    in drawn pieces: items consumed / produced per call, the stream_start / stream_end tags it attaches (offsets and integer fields exact) and the
+    equalised symbols, against the oracle's general_work on the same pieces"""
+    import hostblocks as hb
+    from test_oracle_comm import qam16
+    rng = np.random.default_rng(int(os.environ.get("JRC_FUZZ_SEED", "20261002")) + 13000 + i)
+    o = ofdm64
+    est, ptype, mcs = int(rng.integers(0, 2)), int(rng.integers(1, 3)), int(rng.integers(0, 6))
+    nbytes = int(rng.integers(1, 260))
+    op = oracle.Precoder(64, 4, 1, o["data_subcarriers"], o["pilot_subcarriers"], o["pilot_symbols"], o["l_stf_ltf_64"], o["ltf_mapped_sc__ss_sym"])
+    oe = oracle.Equalizer(est, 24e9, 125e6, 64, 16, o["data_subcarriers"], o["pilot_subcarriers"], o["pilot_symbols"], o["ltf_64"], o["ltf_mapped_sc__ss_sym"], 4)
+    eq = hb.equalizer(o, algo=est, chan_est_file=str(tmp_path / "chan_est.csv"))        # an NDP writes its estimate (:378-416)
+    ns = oracle.n_ofdm_sym(mcs, 48, nbytes)
+    s = qam16(rng, ns * 48) if mcs >= 4 else qpsk(rng, ns * 48) if mcs >= 2 else (rng.integers(0, 2, ns * 48) * 2 - 1).astype(np.complex64)
+    y = through_channel(op.work(s, mcs, ptype, nbytes), crandn(rng, 4), float(rng.choice([0.0, 1e-3, 5e-3])), rng)
+    lead = int(rng.integers(0, 4))
+    y = np.concatenate([crandn(rng, lead, 64), y, crandn(rng, int(rng.integers(0, 4)), 64)])
+    phase = float(rng.uniform(-0.3, 0.3))
+    eq.tag(0, lead, "frame_start", phase)
+    draw = dict(i=i, est=est, ptype=ptype, mcs=mcs, nbytes=nbytes, lead=lead)
+    pos, go, oo, events, written = 0, [], [], [], 0
+    while pos < len(y):
+        step = int(rng.choice([1, 2, 3, 5, 8, 40, 400]))
+        part = y[pos:pos + step]
+        out = np.zeros((len(part), 48), np.complex64)
+        n = eq.run(len(part), [part], [out])
+        r = oe.general_work(part, [(lead - pos, phase)] if pos <= lead < pos + len(part) else [])
+        assert n == r["out"].shape[0] and eq.consumed(0) == r["consumed"] == len(part), (draw, pos)
+        events += [dict(e, offset=e["offset"] + written) for e in r["events"]]          # the oracle counts from this call's first output item
+        go.append(out[:n]); oo.append(r["out"])
+        written += n
+        pos += len(part)
+    tags = eq.state()["out_tags"][0]
+    assert [(t["key"], t["offset"]) for t in tags] == [("stream_start" if e["kind"] == 1 else "stream_end", e["offset"]) for e in events], draw
+    for t, e in zip(tags, events):
+        if e["kind"] == 1:
+            assert (t["value"]["data_bytes"], t["value"]["mcs"], t["value"]["packet_type"]) == (e["data_bytes"], e["mcs"], e["packet_type"]), draw
+    go, oo = np.concatenate(go), np.concatenate(oo)
+    assert go.shape == oo.shape, draw
+    if go.size and rel_err(go, oo) >= 2e-5:                       # a symbol whose pilots nearly cancel: one small common rotation (tests/test_gpu_fuzz.py)
+        delta = np.angle((go.astype(np.complex128) * np.conj(oo.astype(np.complex128))).sum(axis=1))
+        assert np.abs(delta).max() < 5e-4 and rel_err(go * np.exp(-1j * delta)[:, None], oo) < 2e-5, draw
