@@ -859,3 +859,47 @@ def test_equalizer_block_under_drawn_scheduling(jrc, ofdm64, tmp_path, i):
     if go.size and rel_err(go, oo) >= 2e-5:                       # a symbol whose pilots nearly cancel: one small common rotation (tests/test_gpu_fuzz.py)
         delta = np.angle((go.astype(np.complex128) * np.conj(oo.astype(np.complex128))).sum(axis=1))
         assert np.abs(delta).max() < 5e-4 and rel_err(go * np.exp(-1j * delta)[:, None], oo) < 2e-5, draw
+
+
+@gpu
+@pytest.mark.parametrize("i", range(int(os.environ.get("JRC_FUZZ_N", "24")) // 3))
+def test_radar_block_over_drawn_packet_sequences(jrc, i):
+    """mimo_ofdm_radar as a C++ block over a drawn sequence of packets: drawn array geometry, window, interpolation, TX interleave, background
+    recording / removal (switched by the setter on the way), packets longer than the window, stale TX packets ahead of some of them.  Every
+    call's estimate bit for bit the oracle's (same object, so the same background ring), items consumed as the reference's rules say
+    (:326-334), one packet_len tag per estimate (:303-309)"""
+    import hostblocks as hb
+    rng = np.random.default_rng(int(os.environ.get("JRC_FUZZ_SEED", "20261002")) + 15000 + i)
+    N = int(rng.choice([16, 64, 128, 256]))
+    T, R = int(rng.integers(1, 5)), int(rng.integers(1, 5))
+    S, Npre, Ir = int(rng.integers(1, 9)), int(rng.integers(0, 7)), int(rng.choice([1, 2, 8]))
+    il, bg_rem, bg_rec, rec_len = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), int(rng.integers(1, 5))
+    draw = dict(i=i, N=N, T=T, R=R, S=S, Npre=Npre, Ir=Ir, interleave=il, bg_removal=bg_rem, bg_recording=bg_rec, record_len=rec_len)
+    blk = hb.radar(N, T, R, S, Npre, bg_removal=bg_rem, bg_recording=bg_rec, record_len=rec_len, interp=Ir, interleave=il)
+    ref = oracle.Radar(N, T, R, S, Npre, background_removal=bg_rem, background_recording=bg_rec, record_len=rec_len, interp_factor=Ir,
+                       enable_tx_interleave=il)
+    P = T * R
+    written = 0
+    for k in range(int(rng.integers(2, 9))):
+        if rng.integers(0, 4) == 0:
+            on = bool(rng.integers(0, 2))
+            blk.set("set_background_record", on)
+            ref.set_background_record(on)
+        n_items = Npre + S + int(rng.integers(0, 4))
+        stale = int(rng.choice([0, 0, 0, 3, 11]))
+        tx = [crandn(rng, stale + n_items, N) for _ in range(T)]
+        rx = [crandn(rng, n_items, N) for _ in range(R)]
+        st = blk.state()
+        base_tx, base_rx = st["nitems_read"][0], st["nitems_read"][T]
+        if stale:
+            blk.tag(0, base_tx, "packet_len", stale)
+        blk.tag(0, base_tx + stale, "packet_len", n_items)
+        blk.tag(T, base_rx, "packet_len", n_items)
+        out = np.zeros((P, N * Ir), np.complex64)
+        assert blk.run(P, tx + rx, [out]) == P, (draw, k)
+        assert [blk.consumed(p) for p in range(T + R)] == [stale + n_items] * T + [n_items] * R, (draw, k)
+        want = ref.work(tx, rx, tx_discard=stale)
+        assert np.array_equal(out, want), (draw, k, float(np.abs(out - want).max()))
+        written += P
+    tags = blk.state()["out_tags"][0]
+    assert tags == [{"offset": j * P, "key": "packet_len", "value": P} for j in range(written // P)], draw
