@@ -321,3 +321,45 @@ def test_target_simulator_against_oracle(jrc, ctx, i):
     assert got.shape == want.shape == (R, n), draw
     scale = np.abs(want).max()
     assert (np.abs(got - want).max() <= 1e-4 * scale) if scale > 0 else (np.abs(got).max() == 0), draw
+
+
+@pytest.mark.parametrize("i", range(max(4, N_DRAWS // 2)))
+def test_range_angle_estimator_against_oracle(jrc, ctx, i):
+    """the estimator block alone on drawn maps: map size (rows 2 ... 700, angle bins 2 ... 300), the reference flowgraph's axes for a drawn geometry
+    or drawn sorted axes, noise-discard windows from a fraction of a bin to several times the map (the window wraps, :211-215), map scales from
+    1e-12 to 1e+12, a strong cell / exact ties / a flat map / zeros, thresholds either side of the result: all twelve fields of the record equal to
+    the oracle's bit for bit"""
+    from test_gpu_blocks import _same_result
+    rng = np.random.default_rng(SEED + 17000 + i)
+    n_rows, vlen = int(rng.integers(2, 700)), int(rng.integers(2, 300))
+    if rng.integers(0, 2):
+        rb = np.linspace(0.0, float(rng.uniform(5, 400)), n_rows).astype(np.float32)
+        k = np.arange(vlen)
+        ab = (np.arcsin(np.clip(2.0 / vlen * (k - vlen // 2 + 0.5), -1, 1)) * 180 / np.pi).astype(np.float32)       # the .grc's expression
+    else:
+        rb = np.sort(rng.uniform(0, 300, n_rows)).astype(np.float32)
+        ab = np.sort(rng.uniform(-90, 90, vlen)).astype(np.float32)
+        if len(np.unique(rb)) < n_rows or len(np.unique(ab)) < vlen:
+            rb, ab = np.linspace(0, 100, n_rows).astype(np.float32), np.linspace(-80, 80, vlen).astype(np.float32)
+    ndr = float(rng.choice([0.01, 0.5, 2.4, 9.0, 50.0, 500.0])) * float(max(rb[1] - rb[0], 1e-3))
+    nda = float(rng.choice([0.01, 1.0, 14.36, 28.96, 120.0]))
+    scale = float(10.0 ** rng.integers(-12, 13))
+    kind = int(rng.integers(0, 5))
+    m = crandn(rng, n_rows, vlen, scale=0.05 * scale)
+    if kind == 0:
+        m[int(rng.integers(0, n_rows)), int(rng.integers(0, vlen))] += 3.0 * scale
+    elif kind == 1:                                                  # exact ties of the maximum: first in scan order wins
+        m[:] = 0.1 * scale
+        for _ in range(3):
+            m[int(rng.integers(0, n_rows)), int(rng.integers(0, vlen))] = 2.0 * scale
+    elif kind == 2:
+        m[:] = (0.3 + 0.1j) * scale
+    elif kind == 3:
+        m[:] = 0
+    snr_thr, pow_thr = float(rng.choice([-100.0, 0.0, 15.0, 60.0])), float(rng.choice([0.0, 1e-6, 1.0])) * scale * scale
+    draw = dict(i=i, n_rows=n_rows, vlen=vlen, ndr=ndr, nda=nda, scale=scale, kind=kind, snr_thr=snr_thr, pow_thr=pow_thr)
+    est = jrc.range_angle_estimator(vlen, rb, ab, ndr, nda, snr_thr, pow_thr, ctx=ctx)
+    try:
+        _same_result(est.work(m), oracle.ra_estimate(m, rb, ab, ndr, nda, snr_thr, pow_thr))
+    except AssertionError as e:
+        raise AssertionError((draw, e))
