@@ -363,3 +363,41 @@ def test_range_angle_estimator_against_oracle(jrc, ctx, i):
         _same_result(est.work(m), oracle.ra_estimate(m, rb, ab, ndr, nda, snr_thr, pow_thr))
     except AssertionError as e:
         raise AssertionError((draw, e))
+
+
+@pytest.mark.parametrize("i", range(max(4, N_DRAWS // 2)))
+def test_stock_blocks_against_oracle(jrc, ctx, i):
+    """the stock blocks around the path on drawn shapes: fft_vxx of any size up to 4095 (powers of two to 16384) in either direction, with or
+    without shift and window, batches of 1-9 vectors; matrix_transpose; the cyclic-prefix remover alone and fused with the RX FFT; the TX
+    modulator (reverse FFT + window + prefix)"""
+    rng = np.random.default_rng(SEED + 19000 + i)
+    kind = int(rng.integers(0, 4))
+    if kind == 0:
+        n = int(rng.choice([rng.integers(1, 4096), 2 ** int(rng.integers(0, 15))]))
+        fwd, shift, batch = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), int(rng.integers(1, 10))
+        w = rng.uniform(0.2, 2.0, n).astype(np.float32) if rng.integers(0, 2) else None
+        x = crandn(rng, batch, n)
+        got = jrc.fft_vcc(n, fwd, w, shift, ctx=ctx).work(x)
+        assert rel_err(got, oracle.fft_vcc(x, fwd, shift, window=w)) < 2e-5, dict(i=i, n=n, fwd=fwd, shift=shift, window=w is not None, batch=batch)
+    elif kind == 1:
+        P, L, Ia = int(rng.integers(1, 70)), int(rng.integers(1, 3000)), int(rng.integers(1, 17))
+        x = crandn(rng, P, L)
+        assert np.array_equal(jrc.matrix_transpose(L, P, Ia, ctx=ctx).work(x), oracle.matrix_transpose(x, L, P, Ia)), dict(i=i, P=P, L=L, Ia=Ia)
+    elif kind == 2:
+        N = int(rng.choice([rng.integers(2, 700), 2 ** int(rng.integers(1, 11))]))
+        cp, k, tail = int(rng.integers(0, N)), int(rng.integers(1, 40)), int(rng.integers(0, 3))
+        x = crandn(rng, k * (N + cp) + tail)
+        blk = jrc.ofdm_cyclic_prefix_remover(N, cp, ctx=ctx)
+        ref = oracle.cp_remove(x, N, cp)
+        assert np.array_equal(blk.work(x), ref), dict(i=i, N=N, cp=cp, k=k, tail=tail)
+        got = jrc.ofdm_cyclic_prefix_remover(N, cp, ctx=ctx).work(x[:k * (N + cp)], fused_fft=True)
+        assert rel_err(got, oracle.fft_vcc(oracle.cp_remove(x[:k * (N + cp)], N, cp), True, True)) < 2e-5, dict(i=i, N=N, cp=cp, k=k, fused=True)
+    else:
+        N = int(rng.choice([rng.integers(2, 700), 2 ** int(rng.integers(1, 11))]))
+        cp, k = int(rng.integers(0, N)), int(rng.integers(1, 30))
+        w = rng.uniform(0.2, 2.0, N).astype(np.float32) if rng.integers(0, 2) else None
+        X = crandn(rng, k, N)
+        x = oracle.fft_vcc(X, False, True, window=w)
+        ref = np.concatenate([x[:, N - cp:], x], axis=1) if cp else x
+        got = jrc.ofdm_mod(X, N, cp, w, ctx=ctx)
+        assert got.shape == (k, N + cp) and rel_err(got, ref) < 2e-5, dict(i=i, N=N, cp=cp, k=k, window=w is not None)
