@@ -401,3 +401,77 @@ def test_stock_blocks_against_oracle(jrc, ctx, i):
         ref = np.concatenate([x[:, N - cp:], x], axis=1) if cp else x
         got = jrc.ofdm_mod(X, N, cp, w, ctx=ctx)
         assert got.shape == (k, N + cp) and rel_err(got, ref) < 2e-5, dict(i=i, N=N, cp=cp, k=k, window=w is not None)
+
+
+@pytest.mark.parametrize("i", range(max(3, N_DRAWS // 4)))
+def test_host_fed_feed_against_the_resident_chain(jrc, ctx, i):
+    """the host-fed pipeline under drawn geometry (array, carriers, window, interpolation), slot count, frames per slot, hipGraph replay on / off,
+    detect-only or with the first map of every batch copied back, and a drawn sequence of submissions — pageable or in place, whole or
+    receive-only against resident TX rows that the sequence replaces on the way, batches of drawn sizes, collected whenever the slots are full or
+    at random: every record, and every returned map, equal to the device-resident chain's on the same frames"""
+    from jrc_amd import synth
+    from test_gpu_chain import RES_KEYS, make_feed, run_chain
+    rng = np.random.default_rng(SEED + 21000 + i)
+    N = int(rng.choice([64, 128, 256]))
+    T, R = int(rng.choice([1, 2, 4])), int(rng.choice([1, 2, 4]))
+    S, Ir, Ia = int(rng.choice([2, 4, 8, 16])), int(rng.choice([1, 4, 8])), int(rng.choice([4, 16]))
+    sc = synth.Scenario(N, T, R, S, targets=[(float(rng.uniform(5, 40)), float(rng.uniform(-40, 40)), 0.0, 80.0)])
+    slots, fps, graph, with_map = int(rng.integers(1, 5)), int(rng.integers(1, 9)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    F = int(rng.integers(1, 60))
+    draw = dict(i=i, N=N, T=T, R=R, S=S, Ir=Ir, Ia=Ia, slots=slots, fps=fps, graph=graph, with_map=with_map, F=F)
+    base = synth.make_frames(sc, 8)
+    frames = np.concatenate([base] * (F // 8 + 1))[:F].copy()
+    frames[:, sc.T:] *= (1.0 + 0.01 * np.arange(F, dtype=np.float32))[:, None, None, None]
+    tx_sets = [base[0, :sc.T].copy(), base[3, :sc.T].copy()]
+    which = rng.integers(0, 2, F)                                   # the TX rows each frame carries
+    for f in range(F):
+        frames[f, :sc.T] = tx_sets[which[f]]
+    _, _, gmap, res, _ = run_chain(jrc, ctx, sc, Ir, Ia, F, frames=frames)
+    feed = make_feed(jrc, ctx, sc, Ir, Ia, n_slots=slots, frames_per_slot=fps, maps_per_slot=1 if with_map else 0, graph=graph)
+    if not with_map:
+        feed.set_write_map(False)
+    resident, got, maps, starts, f0 = None, [], [], [], 0
+
+    def collect():
+        r, m = feed.collect(want_maps=with_map)
+        got.extend(r)
+        if with_map:
+            maps.append(m)
+
+    while f0 < F or feed.pending():
+        if f0 < F and feed.pending() < slots and (feed.pending() == 0 or rng.integers(0, 3)):
+            n = int(min(rng.integers(1, fps + 1), F - f0))
+            same = resident is not None and all(which[f] == resident for f in range(f0, f0 + n))
+            mode = int(rng.integers(0, 4))
+            if mode == 3 and feed.pending() == 0 and rng.integers(0, 2):           # replace the resident rows (nothing may be in flight)
+                resident = int(which[f0])
+                feed.set_tx(tx_sets[resident])
+                same = all(which[f] == resident for f in range(f0, f0 + n))
+            x = frames[f0:f0 + n].copy()
+            if same and mode in (0, 1):
+                x[:, :sc.T] = np.nan                                                # receive-only: the TX part is never read
+                if mode == 0:
+                    feed.submit(x, rx_only=True)
+                else:
+                    st = feed.acquire()
+                    st[:n] = x
+                    feed.submit(None, n, rx_only=True)
+            elif mode == 2:
+                st = feed.acquire()
+                st[:n] = x
+                feed.submit(None, n)
+            else:
+                feed.submit(x)
+            starts.append(f0)
+            f0 += n
+        else:
+            collect()
+    assert len(got) == F, draw
+    for f in range(F):
+        for k in RES_KEYS:
+            assert getattr(got[f], k) == getattr(res[f], k), (draw, f, k)
+    if with_map:
+        assert len(maps) == len(starts), draw
+        for s0, m in zip(starts, maps):
+            assert np.array_equal(m[0], gmap[s0]), (draw, s0)
+    feed.close()
