@@ -554,3 +554,39 @@ def test_comm_flowgraph_with_radar_streams_on_the_null_space(jrc, ctx, ofdm64):
             assert gok and gpay == pdu
             plain = hip.precoder.work(ge["symbols"], 2, 2, len(pdu) + 4, **hip.steering())
             assert rel_err(ge["tx_f"], plain) > 0.1                      # the radar streams really are on the air
+
+
+@pytest.mark.parametrize("i", range(max(2, int(os.environ.get("JRC_FUZZ_N", "24")) // 6)))
+def test_radar_flowgraph_on_drawn_scenes(jrc, ctx, ofdm64, i):
+    """the composed radar simulation flowgraph on drawn scenes: 1-3 targets at drawn range / velocity / cross-section / angle, 1, 2 or 4 receive
+    antennas, a drawn PDU length, MCS and packet type, the demodulator fused or block by block, both random sources drawn once and replayed:
+    HIP blocks against the oracle's blocks chained (1e-4 on every complex edge, lengths equal) and block by block on the HIP graph's edges
+    (2e-5; copies, A1 and the estimator's record bit for bit)"""
+    import radar_sim_flowgraph as fgm
+    rng = np.random.default_rng(int(os.environ.get("JRC_FUZZ_SEED", "20261002")) + 23000 + i)
+    R = int(rng.choice([1, 2, 4]))
+    K = int(rng.integers(1, 4))
+    kw = dict(trgt_range=list(rng.uniform(4, 45, K)), trgt_velocity=list(rng.uniform(-30, 30, K)), trgt_rcs_dbsm=list(rng.uniform(10, 35, K)),
+              trgt_angle=list(rng.uniform(-60, 60, K)), N_rx=R, fft_len=64, seed=int(rng.integers(0, 1 << 30)))
+    fused = bool(rng.integers(0, 2))
+    hip = fgm.RadarSimFlowgraph(ofdm64, ctx=ctx, fused_demod=fused, **kw)
+    orc = fgm.RadarSimFlowgraph(ofdm64, blocks=oracle_blocks, fused_demod=fused, **kw)
+    mcs, ptype, nbytes = int(rng.choice([0, 2, 3])), int(rng.choice([fgm.DATA, fgm.NDP])), int(rng.integers(20, 300))
+    nd = len(ofdm64["data_subcarriers"])
+    n_data = jrc.n_ofdm_sym(mcs, nd, nbytes)
+    sym = qpsk(rng, n_data * nd)
+    draw = dict(i=i, R=R, fused=fused, mcs=mcs, ptype=ptype, nbytes=nbytes, **{k: [round(float(v), 2) for v in kw[k]] for k in ("trgt_range", "trgt_velocity", "trgt_rcs_dbsm", "trgt_angle")})
+    gres, ge = hip.run_packet(sym, mcs, ptype, nbytes)
+    src = dict(pads=ge["pads"], noise=ge["noise"])
+    ores, oe = orc.run_packet(sym, mcs, ptype, nbytes, sources=src)
+    assert ge["lengths"] == oe["lengths"], draw
+    for k in RADAR_CF32_EDGES:
+        assert ge[k].shape == oe[k].shape and rel_err(ge[k], oe[k]) <= TOL, (draw, k, rel_err(ge[k], oe[k]))
+    bres, be = orc.run_packet(sym, mcs, ptype, nbytes, sources=src, force={k: ge[k] for k in RADAR_CF32_EDGES})
+    for k in RADAR_CF32_EDGES:
+        assert rel_err(ge[k], be[k]) <= 2e-5, (draw, k, rel_err(ge[k], be[k]))
+    assert np.array_equal(ge["bursts"], be["bursts"]) and np.array_equal(ge["transposed"], be["transposed"]) and np.array_equal(ge["H"], be["H"]), draw
+    try:
+        compare_results(gres, bres, exact_floats=True)
+    except AssertionError as e:
+        raise AssertionError((draw, e))
