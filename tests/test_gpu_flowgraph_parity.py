@@ -192,13 +192,13 @@ def test_radar_flowgraph_edge_by_edge(jrc, ctx, ofdm64, shape, fused_demod):
 COMM_CF32_EDGES = ("symbols", "tx_f", "tx_t", "padded", "rx", "detector_out", "sync_out", "y", "eq_out")
 
 
-def same_events(ge, oe, tol):
+def same_events(ge, oe, tol, freq_floor=1.0):
     assert len(ge) == len(oe)
     for g, o in zip(ge, oe):
         assert g["kind"] == o["kind"] and g["offset"] == o["offset"]
         if g["kind"] == 1:
             assert (g["data_bytes"], g["mcs"], g["packet_type"]) == (o["data_bytes"], o["mcs"], o["packet_type"])
-            assert abs(g["snr"] - o["snr"]) <= max(tol * abs(o["snr"]), 1e-3) and abs(g["freq_offset"] - o["freq_offset"]) <= tol * max(1.0, abs(o["freq_offset"]))
+            assert abs(g["snr"] - o["snr"]) <= max(tol * abs(o["snr"]), 1e-3) and abs(g["freq_offset"] - o["freq_offset"]) <= tol * max(freq_floor, abs(o["freq_offset"]))
         else:
             assert abs(g["snr_data"] - o["snr_data"]) <= max(tol * abs(o["snr_data"]), 1e-3)
             assert g["chan_mean"].shape == o["chan_mean"].shape
@@ -206,7 +206,7 @@ def same_events(ge, oe, tol):
                 assert rel_err(g["chan_mean"], o["chan_mean"]) <= tol
 
 
-def compare_comm_edges(ge, oe, rep, tag, tol, live=48, norm_tol=1e-3):
+def compare_comm_edges(ge, oe, rep, tag, tol, live=48, norm_tol=1e-3, freq_floor=1.0, payload_equal=True):
     assert ge["encoder_tags"] == oe["encoder_tags"]               # packet_len, packet_type, mcs, pdu_len
     for k in COMM_CF32_EDGES:
         assert k in ge and k in oe, k
@@ -234,14 +234,14 @@ def compare_comm_edges(ge, oe, rep, tag, tol, live=48, norm_tol=1e-3):
         for a, b in zip(ge[key], oe[key]):
             assert abs(a[1] - b[1]) <= tol * max(1.0, abs(b[1])), key
     assert ge["eq_consumed"] == oe["eq_consumed"]
-    same_events(ge["eq_events"], oe["eq_events"], tol)
+    same_events(ge["eq_events"], oe["eq_events"], tol, freq_floor)
     if oe["chan_est"] is None:
         assert ge["chan_est"] is None
     else:
         err = rel_err(ge["chan_est"], oe["chan_est"])
         rep[tag + "chan_est"] = max(rep.get(tag + "chan_est", 0.0), err)
         assert err <= tol
-    assert ge.get("crc_ok") == oe.get("crc_ok") and ge.get("payload") == oe.get("payload")       # decoded PDU bytes + CRC flag
+    assert ge.get("crc_ok") == oe.get("crc_ok") and (not payload_equal or ge.get("payload") == oe.get("payload"))       # decoded PDU bytes + CRC flag
 
 
 @pytest.mark.parametrize("est", [0, 1], ids=["LS", "STA"])
@@ -590,3 +590,48 @@ def test_radar_flowgraph_on_drawn_scenes(jrc, ctx, ofdm64, i):
         compare_results(gres, bres, exact_floats=True)
     except AssertionError as e:
         raise AssertionError((draw, e))
+
+
+@pytest.mark.parametrize("i", range(max(2, int(os.environ.get("JRC_FUZZ_N", "24")) // 6)))
+def test_comm_flowgraph_on_drawn_links(jrc, ctx, ofdm64, i):
+    """the composed comm simulation flowgraph on drawn links: MCS, estimator, line-of-sight geometry (distance, angle) or a drawn flat channel,
+    carrier offset, lead, a sounding packet and then PDUs of drawn length without and with the steering derived from it; both random sources
+    replayed: HIP blocks against the oracle's blocks chained — every complex edge to 1e-4, tags / events / lengths / decoded bytes and the CRC
+    verdict equal"""
+    import comm_sim_flowgraph as cfm
+    rng = np.random.default_rng(int(os.environ.get("JRC_FUZZ_SEED", "20261002")) + 25000 + i)
+    mcs, est = int(rng.integers(0, 5)), int(rng.integers(0, 2))
+    channel = str(rng.choice(["los", "flat"]))
+    kw = dict(mcs=mcs, estimator=est, seed=int(rng.integers(0, 1 << 30)), channel=channel, smoothing=bool(rng.integers(0, 2)))
+    if channel == "los":
+        kw.update(distance=float(rng.uniform(5, 40)), theta=float(rng.uniform(-50, 50)))
+    hip = cfm.CommSimFlowgraph(ofdm64, ctx=ctx, **kw)
+    orc = cfm.CommSimFlowgraph(ofdm64, blocks=oracle_blocks, **kw)
+    cfo, lead = float(rng.uniform(-0.01, 0.01)), int(rng.integers(400, 1500))
+    draw = dict(i=i, cfo=cfo, lead=lead, **{k: (round(v, 2) if isinstance(v, float) else v) for k, v in kw.items()})
+    rep = {}
+    pdus = [(bytes([1]) + b"sounding", False)] + [(bytes([2]) + rng.integers(0, 256, int(rng.integers(10, 260)), dtype=np.uint8).tobytes(), bool(k)) for k in range(2)]
+    for pdu, steer in pdus:
+        gok, gpay, ginfo = hip.send(pdu, steer=steer, cfo=cfo, lead=lead)
+        ge = ginfo["edges"]
+        ook, opay, oinfo = orc.send(pdu, steer=steer, cfo=cfo, lead=lead, sources=dict(pads=ge["pads"], noise=ge["noise"]))
+        try:
+            # (a decode that fails on a marginal link fails in both graphs; what it leaves in the payload hangs on hard decisions of symbols
+            # that sit on a boundary, so the bytes are only compared when the CRC holds)
+            assert gok == ook and (not gok or gpay == opay)
+            oe_ = oinfo["edges"]
+            if not ge["detector_tags"]:                          # a drawn channel in a deep fade: nothing detected — by both graphs, and nothing behind it exists
+                assert not oe_["detector_tags"] and ge["detector_out"].size == oe_["detector_out"].size == 0 and not gok
+                assert all((ge.get(k) is None) == (oe_.get(k) is None) for k in ("sync_out", "y", "eq_out", "steering", "chan_est"))
+                continue
+            if steer and (ge.get("steering") is not None or oe_.get("steering") is not None):   # (no sounding received: nothing to steer with)
+                assert rel_err(ge["steering"], oe_["steering"]) <= TOL
+            # (the normalised metric: the reference's running sums drift by an amount that depends on the power steps that went through them, the device sums windows — DESIGN.md §5.1, §5.2; what the detector decides from it is compared exactly)
+            # the coarse CFO is the angle of the metric's correlation sum: a last-digit difference of it (same drift) is a phase ramp over the samples the
+            # detector de-rotates, and everything behind it inherits the ramp until the equalizer's own tracking takes it out
+            d_cfo = max([abs(a[1] - b[1]) for a, b in zip(ge["detector_tags"], oe_["detector_tags"])] + [0.0])
+            # (the offset the stream_start event announces is coarse - fine in Hz: near zero it is the difference of two 1e-2 rad / sample numbers
+            # known to 1e-9, so it is held to 1e-4 of a 1e-3 rad / sample offset — 2 Hz at 125 MS/s — rather than of itself)
+            compare_comm_edges(ge, oe_, rep, "chained:", TOL + 1.5 * d_cfo * max(1, ge["detector_out"].size), norm_tol=2e-2, freq_floor=2e4, payload_equal=bool(gok))
+        except AssertionError as e:
+            raise AssertionError((draw, len(pdu), steer, e))
