@@ -618,7 +618,8 @@ def test_comm_flowgraph_on_drawn_links(jrc, ctx, ofdm64, i):
         try:
             # (a decode that fails on a marginal link fails in both graphs; what it leaves in the payload hangs on hard decisions of symbols
             # that sit on a boundary, so the bytes are only compared when the CRC holds)
-            assert gok == ook and (not gok or gpay == opay)
+            sta = est == 1                                        # (with decision-directed tracking a boundary symbol may cost one graph the CRC: checked below)
+            assert sta or (gok == ook and (not gok or gpay == opay))
             oe_ = oinfo["edges"]
             if not ge["detector_tags"]:                          # a drawn channel in a deep fade: nothing detected — by both graphs, and nothing behind it exists
                 assert not oe_["detector_tags"] and ge["detector_out"].size == oe_["detector_out"].size == 0 and not gok
@@ -630,8 +631,25 @@ def test_comm_flowgraph_on_drawn_links(jrc, ctx, ofdm64, i):
             # the coarse CFO is the angle of the metric's correlation sum: a last-digit difference of it (same drift) is a phase ramp over the samples the
             # detector de-rotates, and everything behind it inherits the ramp until the equalizer's own tracking takes it out
             d_cfo = max([abs(a[1] - b[1]) for a, b in zip(ge["detector_tags"], oe_["detector_tags"])] + [0.0])
+            # decision-directed tracking (STA): a symbol that lands ON a decision boundary (1e-6 of it) is decided one way by one graph and the other way
+            # by the other, and that carrier's channel estimate — so everything behind it on that carrier — parts ways.  Such a carrier is compared
+            # up to the symbol behind which the two decisions differ, and only if they do differ there; everything else as always.
+            ge_cmp, on_boundary = ge, False
+            if est == 1 and ge.get("eq_out") is not None and oe_.get("eq_out") is not None and ge["eq_out"].shape == oe_["eq_out"].shape and ge["eq_out"].size:
+                a, b = ge["eq_out"], oe_["eq_out"]
+                off = np.abs(a - b) > 1e-3 * max(1e-9, float(np.abs(b).max()))
+                if off.any():
+                    bpsc = 1 if mcs <= 1 else (2 if mcs <= 3 else 4)
+                    patched = a.copy()
+                    for c in sorted(set(np.argwhere(off)[:, 1])):
+                        s0 = int(np.argwhere(off[:, c])[0, 0])
+                        assert s0 >= 1 and oracle.constellation_decide(bpsc, a[s0 - 1, c]) != oracle.constellation_decide(bpsc, b[s0 - 1, c]), (c, s0)
+                        patched[s0:, c] = b[s0:, c]
+                    ge_cmp, on_boundary = dict(ge, eq_out=patched, crc_ok=oe_.get("crc_ok"), payload=oe_.get("payload")), True
             # (the offset the stream_start event announces is coarse - fine in Hz: near zero it is the difference of two 1e-2 rad / sample numbers
             # known to 1e-9, so it is held to 1e-4 of a 1e-3 rad / sample offset — 2 Hz at 125 MS/s — rather than of itself)
-            compare_comm_edges(ge, oe_, rep, "chained:", TOL + 1.5 * d_cfo * max(1, ge["detector_out"].size), norm_tol=2e-2, freq_floor=2e4, payload_equal=bool(gok))
+            compare_comm_edges(ge_cmp, oe_, rep, "chained:", TOL + 1.5 * d_cfo * max(1, ge["detector_out"].size), norm_tol=2e-2, freq_floor=2e4, payload_equal=bool(gok))
+            if sta and not on_boundary:
+                assert gok == ook and (not gok or gpay == opay)
         except AssertionError as e:
             raise AssertionError((draw, len(pdu), steer, e))
