@@ -475,3 +475,29 @@ def test_host_fed_feed_against_the_resident_chain(jrc, ctx, i):
         for s0, m in zip(starts, maps):
             assert np.array_equal(m[0], gmap[s0]), (draw, s0)
     feed.close()
+
+
+@pytest.mark.parametrize("i", range(max(4, N_DRAWS // 3)))
+def test_time_domain_front_against_oracle(jrc, ctx, i):
+    """A6 + A7 + A1 as one kernel (jrc_radar_chanest_td_dev) on drawn shapes — fft_len 16 ... 1024, cyclic prefix 0 ... fft_len / 2, 1-4 (or 8)
+    transmitters, 1-4 receivers, window, preamble, frames, TX interleave, slack behind the last symbol — against the two separate device calls
+    (1e-6) and, on the first and last frame, against the oracle's prefix remover -> fft_vcc -> mimo_ofdm_radar (2e-6 x fft scale)"""
+    from test_gpu_chain import _td_case
+    rng = np.random.default_rng(SEED + 27000 + i)
+    N = int(2 ** rng.integers(4, 11))
+    T, R = int(rng.choice([1, 2, 3, 4, 8])), int(rng.integers(1, 5))
+    cp = int(rng.choice([0, N // 16, N // 4, N // 2]))
+    S, Npre, F = int(rng.integers(1, 20)), int(rng.integers(0, 7)), int(rng.integers(1, 12))
+    if N >= 512:
+        S, F = min(S, 8), min(F, 4)
+    il, extra = bool(rng.integers(0, 2)), int(rng.choice([0, 0, 3, 17]))
+    draw = dict(i=i, N=N, T=T, R=R, cp=cp, S=S, Npre=Npre, F=F, interleave=il, extra=extra)
+    tx, rx, Hf, Hu, L = _td_case(jrc, ctx, T, R, N, cp, S, Npre, F, il, extra, seed=int(rng.integers(0, 1 << 30)))
+    assert not np.isnan(Hf.view(np.float32)).any(), draw
+    assert rel_err(Hf, Hu) < 1e-6, (draw, rel_err(Hf, Hu))
+    rad = oracle.Radar(N, T, R, S, Npre, interp_factor=1, enable_tx_interleave=il)
+    n_items = Npre + S
+    for f in sorted({0, F - 1}):
+        rxf = [oracle.fft_vcc(oracle.cp_remove(rx[f, r, :n_items * (N + cp)], N, cp), True, True) for r in range(R)]
+        Ho = rad.work([tx[f, t] for t in range(T)], rxf)
+        assert rel_err(Hf[f], Ho[:, :N]) < 4e-6, (draw, f, rel_err(Hf[f], Ho[:, :N]))
