@@ -501,3 +501,37 @@ def test_time_domain_front_against_oracle(jrc, ctx, i):
         rxf = [oracle.fft_vcc(oracle.cp_remove(rx[f, r, :n_items * (N + cp)], N, cp), True, True) for r in range(R)]
         Ho = rad.work([tx[f, t] for t in range(T)], rxf)
         assert rel_err(Hf[f], Ho[:, :N]) < 4e-6, (draw, f, rel_err(Hf[f], Ho[:, :N]))
+
+
+@pytest.mark.parametrize("i", range(max(3, N_DRAWS // 4)))
+def test_range_doppler_against_its_definition(jrc, ctx, i):
+    """row D (the build's own definition, no reference counterpart) on drawn shapes — fft_len 16 ... 1024, 1-4 x 1-4 antennas, 2 ... 64 symbols,
+    range / Doppler interpolation 1 ... 8 / 1 ... 4, 1-5 frames: fftshift_d FFT_sym(IFFT_sc(rx conj(tx))), zero-padded on both axes, in numpy
+    complex128"""
+    import torch
+    from jrc_amd import synth
+    rng = np.random.default_rng(SEED + 29000 + i)
+    N = int(2 ** rng.integers(4, 11))
+    T, R = int(rng.integers(1, 5)), int(rng.integers(1, 5))
+    S = int(rng.choice([2, 4, 8, 16, 32, 64])) if N <= 256 else int(rng.choice([2, 4, 8, 16]))
+    Ir, Id, F = int(rng.choice([1, 2, 4, 8])), int(rng.choice([1, 2, 4])), int(rng.integers(1, 6))
+    draw = dict(i=i, N=N, T=T, R=R, S=S, Ir=Ir, Id=Id, F=F)
+    sc = synth.Scenario(N, T, R, S, targets=[(float(rng.uniform(3, 30)), float(rng.uniform(-30, 30)), float(rng.uniform(-40, 40)), 100.0)])
+    P = T * R
+    frames = synth.make_frames(sc, F)
+    frames = (frames + 0.1 * crandn(rng, *frames.shape)).astype(np.complex64)
+    rb, ab = jrc.radar_axes(N, sc.fs, Ir, P, 2)
+    chain = jrc.RadarChain(N, T, R, S, sc.Npre, Ir, 2, rb, ab, 2.4, 30.0, max_frames=F, ctx=ctx)
+    bufs = chain.alloc(F, "cuda:0")
+    bufs["frames"].copy_(torch.from_numpy(frames.view(np.float32).reshape(bufs["frames"].shape)))
+    torch.cuda.synchronize()
+    rd = chain.range_doppler(bufs, F, Id)
+    ctx.sync()
+    got = rd.cpu().numpy().view(np.complex64)[..., 0]
+    tx = frames[:, :T, sc.Npre:].astype(np.complex128)
+    rx = frames[:, T:, sc.Npre:].astype(np.complex128)
+    D = np.einsum("frsn,ftsn->frtsn", rx, np.conj(tx)).reshape(F, P, S, N)
+    prof = np.fft.ifft(D, n=N * Ir, axis=-1) * (N * Ir)
+    ref = np.fft.fftshift(np.fft.fft(np.swapaxes(prof, -1, -2), n=S * Id, axis=-1), axes=-1)
+    assert got.shape == ref.shape and rel_err(got, ref) < 5e-6, (draw, rel_err(got, ref))
+    chain.close()
