@@ -535,3 +535,47 @@ def test_range_doppler_against_its_definition(jrc, ctx, i):
     ref = np.fft.fftshift(np.fft.fft(np.swapaxes(prof, -1, -2), n=S * Id, axis=-1), axes=-1)
     assert got.shape == ref.shape and rel_err(got, ref) < 5e-6, (draw, rel_err(got, ref))
     chain.close()
+
+
+@pytest.mark.parametrize("i", range(max(3, N_DRAWS // 4)))
+def test_batched_background_state_against_the_oracle_block(jrc, ctx, i):
+    """mimo_ofdm_radar's background recording / removal in the batched chain on a drawn stream: geometry, window, record length, the stream cut
+    into batches of drawn sizes, recording switched on and off between batches at drawn places: the channel estimates of every frame bit for
+    bit those of the oracle block called once per frame, the ring as full"""
+    from jrc_amd import synth
+    from test_gpu_chain_modes import _chain, _load, _oracle_stream
+    rng = np.random.default_rng(SEED + 31000 + i)
+    N, T, R = int(rng.choice([64, 128, 256])), int(rng.choice([1, 2, 4])), int(rng.choice([1, 2, 4]))
+    S, L = int(rng.integers(1, 9)), int(rng.integers(1, 7))
+    sc = synth.Scenario(N, T, R, S, targets=[(float(rng.uniform(5, 30)), float(rng.uniform(-30, 30)), 0.0, 60.0)])
+    F = int(rng.integers(2, 30))
+    frames = synth.make_frames(sc, F)
+    frames = (frames * (1.0 + 0.05 * rng.standard_normal(F))[:, None, None, None]).astype(np.complex64)
+    cuts, lo = [], 0
+    while lo < F:
+        hi = int(min(F, lo + rng.integers(1, 9)))
+        cuts.append((lo, hi))
+        lo = hi
+    rec, recording_at = True, {}
+    for lo, hi in cuts[1:]:
+        if rng.integers(0, 3) == 0:
+            rec = not rec
+            recording_at[lo] = rec
+    draw = dict(i=i, N=N, T=T, R=R, S=S, L=L, F=F, cuts=cuts, recording_at=recording_at)
+    want, ring = _oracle_stream(sc, frames, L, recording_at=recording_at)
+    cap = max(hi - lo for lo, hi in cuts)
+    ch, _ = _chain(jrc, ctx, sc, int(rng.choice([1, 4])), 4, cap)
+    ch.set_background(True, True, L)
+    bufs = ch.alloc(cap, "cuda:0")
+    got = []
+    for lo, hi in cuts:
+        if lo in recording_at:
+            ch.set_background_record(recording_at[lo])
+        _load(bufs, frames[lo:hi], hi - lo)
+        ch.run(bufs, hi - lo)
+        ctx.sync()
+        got.append(bufs["chanest"][:hi - lo].cpu().numpy().view(np.complex64)[..., 0].copy())
+    got = np.concatenate(got)
+    assert np.array_equal(got, want), (draw, float(np.abs(got - want).max()))
+    assert ch.background_size() == ring, draw
+    ch.close()
