@@ -903,3 +903,60 @@ def test_radar_block_over_drawn_packet_sequences(jrc, i):
         written += P
     tags = blk.state()["out_tags"][0]
     assert tags == [{"offset": j * P, "key": "packet_len", "value": P} for j in range(written // P)], draw
+
+
+@gpu
+@pytest.mark.parametrize("i", range(int(os.environ.get("JRC_FUZZ_N", "24")) // 3))
+def test_stream_encoder_and_decoder_blocks_under_drawn_scheduling(jrc, tmp_path, i):
+    """stream_encoder / stream_decoder as C++ blocks over a drawn sequence of PDUs (length 1 ... 700 bytes, blob or string, MCS switched by the
+    setter on the way, one oversized PDU now and then) with the scheduler offering output buffers of drawn sizes: every frame's symbols equal
+    to the oracle's bit for bit with the scrambler seed counting 1 ... 127 per accepted PDU, the four tags at the frame's first item; the decoder
+    block publishes one blob per frame with the oracle's CRC verdict, and the PDU whenever it holds"""
+    import hostblocks as hb
+    rng = np.random.default_rng(int(os.environ.get("JRC_FUZZ_SEED", "20261002")) + 33000 + i)
+    ndc = 48
+    mcs = int(rng.integers(0, 6))
+    enc = hb.stream_encoder(mcs, ndc)
+    dec = hb.stream_decoder(ndc, "", False)
+    seed, off_dec, written, n_blobs = 1, 0, 0, 0
+    per = np.zeros(4, np.float32)
+    for k in range(int(rng.integers(1, 7))):
+        if rng.integers(0, 4) == 0:
+            mcs = int(rng.integers(0, 6))
+            enc.set("set_mcs", mcs)
+        if rng.integers(0, 6) == 0:
+            enc.post("pdu_in", bytes(3100), kind=1)                 # too large: dropped, the seed does not advance (:139-143)
+        pdu = bytes([int(rng.integers(1, 3))]) + rng.integers(0, 256, int(rng.integers(0, 700)), dtype=np.uint8).tobytes()
+        enc.post("pdu_in", pdu, kind=int(rng.integers(0, 2)))
+        want, tags = oracle.stream_encode(mcs, ndc, pdu, seed)
+        seed = seed + 1 if seed < 127 else 1
+        parts, guard = [], 0
+        while sum(p.size for p in parts) < want.size and guard < 10000:
+            nout = int(rng.choice([1, 7, 48, 100, 1000, 5000]))
+            buf = np.zeros(nout, np.complex64)
+            n = enc.run(nout, [], [buf])
+            parts.append(buf[:n])
+            guard += 1
+        got = np.concatenate(parts)
+        assert got.size == want.size and np.array_equal(got, want), (i, k, mcs, len(pdu))
+        st = [t for t in enc.state()["out_tags"][0] if t["offset"] == written]
+        assert [(t["key"], t["value"]) for t in st] == [("packet_len", tags["packet_len"]), ("packet_type", tags["packet_type"]), ("mcs", mcs),
+                                                         ("pdu_len", tags["pdu_len"])], (i, k)
+        written += want.size
+        x = got.reshape(-1, ndc)
+        dec.stream_start(off_dec, tags["pdu_len"], mcs, tags["packet_type"], 25.0)
+        dec.stream_end(off_dec + x.shape[0] - 1, 20.0, [1 + 0j])
+        assert dec.run(4, [x], [per]) == 1 and dec.consumed(0) == x.shape[0], (i, k)
+        off_dec += x.shape[0]
+        n_blobs += 1
+        syms = [m["msg"] for m in dec.state()["published"] if m["port"] == "sym"]
+        # the verdict is the oracle's: at the rate-3/4 MCS a clean frame whose pad is a few bits long can fail its CRC — the decoder runs
+        # ntraceback calls past the frame on what its buffers hold there (zeros in a fresh decoder, DESIGN.md §3.4), and with the punctured
+        # code's free distance of 5 that can outweigh the last data bits (lib/viterbi_decoder.cc:300-330)
+        ok, payload = oracle.stream_decode(mcs, ndc, tags["pdu_len"], got)
+        assert len(syms) == n_blobs and syms[-1]["cdr"]["blob"][0] == int(ok), (i, k, mcs, len(pdu))
+        if ok:
+            assert payload == pdu and bytes(syms[-1]["cdr"]["blob"])[10:] == pdu, (i, k)
+        else:
+            assert mcs in (1, 3, 5), (i, k, mcs, len(pdu))
+    assert enc.run(4096, [], [np.zeros(4096, np.complex64)]) == 0

@@ -254,3 +254,27 @@ def test_windowed_decoder_returns_the_input_of_any_clean_codeword():
             word[k] ^= 1
             assert shortcut(word) is None                         # distance 1 from a codeword is not a codeword (d_free = 10)
     assert fired > 1000 and rejected > 50
+
+
+def test_clean_rate_three_quarter_frames_with_a_short_pad_can_fail_their_crc():
+    """a property of the reference's decoder that the restatement keeps (found by the codec blocks' scheduling fuzz): viterbi_decoder::decode
+    runs until n_data_bits are out (lib/viterbi_decoder.cc:307-327), i.e. ntraceback calls past the end of the frame, on whatever its buffers hold
+    there — zeros in a decoder that has not seen a longer frame.  Those zeros are taken as received bits (also where the puncturing pattern has
+    erasures), the true path behind the scrambled pad does not agree with them, and at rate 3/4 (free distance 5) that can outweigh the frame's
+    last data bits: a noise-free frame then fails its CRC.  Only at the rate-3/4 MCS and only when the pad is 6 or 10 bits long; never at rate
+    1/2.  The HIP decoder reproduces each of these verdicts (tests/test_gpu_codec.py compares failing decodes bit for bit)."""
+    rng = np.random.default_rng(1)
+    failed = {m: [] for m in range(6)}
+    for mcs in range(6):
+        dbps = {0: 24, 1: 36, 2: 48, 3: 72, 4: 96, 5: 144}[mcs]
+        for n in range(1, 360, 1 if mcs == 1 else 3):
+            pdu = bytes([2]) + rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+            sym, tags = oracle.stream_encode(mcs, 48, pdu, 1 + n % 127)
+            ok, payload = oracle.stream_decode(mcs, 48, tags["pdu_len"], sym)
+            if ok:
+                assert payload == pdu
+            else:
+                bits = 16 + 8 * tags["pdu_len"] + 6
+                failed[mcs].append(-(-bits // dbps) * dbps - bits)
+    assert not failed[0] and not failed[2] and not failed[4]                       # rate 1/2: every clean frame decodes
+    assert failed[1] and set(failed[1] + failed[3] + failed[5]) <= {6, 10}          # rate 3/4: some short-pad frames do not
