@@ -427,7 +427,11 @@ def test_host_fed_feed_against_the_resident_chain(jrc, ctx, i):
     for f in range(F):
         frames[f, :sc.T] = tx_sets[which[f]]
     _, _, gmap, res, _ = run_chain(jrc, ctx, sc, Ir, Ia, F, frames=frames)
-    feed = make_feed(jrc, ctx, sc, Ir, Ia, n_slots=slots, frames_per_slot=fps, maps_per_slot=1 if with_map else 0, graph=graph)
+    devices = [0] * int(rng.integers(2, 4)) if rng.integers(0, 3) == 0 else None        # several contexts on this GPU, a host thread each
+    draw["devices"] = devices
+    feed = make_feed(jrc, ctx, sc, Ir, Ia, n_slots=slots, frames_per_slot=fps, maps_per_slot=1 if with_map else 0, graph=graph, devices=devices)
+    if devices:
+        slots = feed.n_slots                                            # n_slots per device
     if not with_map:
         feed.set_write_map(False)
     resident, got, maps, starts, f0 = None, [], [], [], 0
