@@ -1260,6 +1260,7 @@ extern "C" int jrc_chain_set_background(jrc_chain* ch, int background_removal, i
         if (e == hipSuccess) e = hipMalloc((void**)&b->hist[1], hb);
         if (e == hipSuccess) e = hipMalloc((void**)&b->temp, sizeof(float2) * pn);
         if (e == hipSuccess) e = hipMemset(b->temp, 0, sizeof(float2) * pn);            // vector::resize value-initialises (:115)
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);                         // the memset is on the null stream, the chain's work on non-blocking streams: no order between them otherwise
         if (e == hipSuccess) e = hipEventCreateWithFlags(&b->updated, hipEventDisableTiming);
         if (e != hipSuccess) { bg_release(b); return jrc_fail(ctx, JRC_ERR_HIP, "jrc_chain_set_background: %s", hipGetErrorString(e)); }
         ch->bg = b;

@@ -805,6 +805,7 @@ extern "C" int jrc_equalizer_create(jrc_ctx* ctx, const jrc_eq_cfg* c, int n_str
     if (e == hipSuccess) e = hipMemset(eq->H, 0, sizeof(float2) * (size_t)N * n_streams);
     if (e == hipSuccess) e = hipMemset(eq->Hm, 0, sizeof(float2) * (size_t)N * n_streams);
     if (e == hipSuccess) e = hipMemset(eq->pre, 0, sizeof(float2) * (size_t)N * c->n_mimo_ltf * n_streams);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);      // the memsets are on the null stream, the equalizer's launches on non-blocking streams: no order between them otherwise
     if (e != hipSuccess) { jrc_equalizer_destroy(eq); return jrc_fail(ctx, JRC_ERR_HIP, "jrc_equalizer_create: %s", hipGetErrorString(e)); }
     unsigned char* tb = (unsigned char*)eq->tables;
     EqDev& d = eq->d;

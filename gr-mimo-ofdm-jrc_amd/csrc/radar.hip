@@ -663,6 +663,9 @@ extern "C" int jrc_radar_create(jrc_ctx* ctx, int fft_len, int N_tx, int N_rx, i
     if (e == hipSuccess) e = hipMalloc((void**)&r->d_temp, sizeof(float2) * pn);
     if (e == hipSuccess) e = hipMalloc((void**)&r->d_ring, sizeof(float2) * pn * (record_len ? record_len : 1));
     if (e == hipSuccess) e = hipMemset(r->d_temp, 0, sizeof(float2) * pn);   // vector::resize value-initialises (:115)
+    // hipMemset runs on the null stream and may return before it has run; the work below is queued on the context's NON-BLOCKING stream, which the
+    // null stream does not order itself against: finish it here (found by the radar block's packet-sequence fuzz under load)
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     if (e != hipSuccess) {
         jrc_radar_destroy(r);
         return jrc_fail(ctx, JRC_ERR_HIP, "jrc_radar_create: %s", hipGetErrorString(e));
