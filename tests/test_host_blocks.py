@@ -960,3 +960,66 @@ def test_stream_encoder_and_decoder_blocks_under_drawn_scheduling(jrc, tmp_path,
         else:
             assert mcs in (1, 3, 5), (i, k, mcs, len(pdu))
     assert enc.run(4096, [], [np.zeros(4096, np.complex64)]) == 0
+
+
+@gpu
+@pytest.mark.parametrize("i", range(max(1, int(os.environ.get("JRC_FUZZ_N", "24")) // 12)))
+def test_radar_chain_block_over_a_long_drawn_stream(jrc, ctx, monkeypatch, i):
+    """the radar_chain block on the real feed over a long stream at the reference flowgraph's shape: scheduler turns of drawn size, idle gaps longer
+    than the age bound now and then (the block's own thread publishes), TX rows that change at drawn places (whole uploads in between receive-only
+    ones), a drawn age bound, batch size, slot count and — sometimes — two contexts: one message per frame, in frame order, each equal to the
+    device-resident chain's record of that frame; nothing left in flight after stop()"""
+    import time
+    import hostblocks as hb
+    import torch
+    from jrc_amd import synth
+    rng = np.random.default_rng(int(os.environ.get("JRC_FUZZ_SEED", "20261002")) + 35000 + i)
+    monkeypatch.setenv("JRC_RADAR_CHAIN_MAX_AGE_US", str(int(rng.choice([0, 300, 2000, 1000000]))))
+    if rng.integers(0, 4) == 0:
+        monkeypatch.setenv("JRC_DEVICES", "0,0")
+    sc = synth.Scenario(64, 4, 2, 4, targets=[(float(rng.uniform(5, 30)), float(rng.uniform(-30, 30)), 0.0, 80.0)])
+    Ir, Ia, P = 8, 16, sc.T * sc.R
+    F = int(rng.integers(200, 900))
+    n_items = sc.Npre + sc.S
+    rb, ab = jrc.radar_axes(sc.N, sc.fs, Ir, P, Ia)
+    base = synth.make_frames(sc, 8)
+    frames = np.concatenate([base] * (F // 8 + 1))[:F].copy()
+    which = np.zeros(F, int)
+    for cut in sorted(rng.integers(1, F, int(rng.integers(0, 5)))):             # the TX rows change at a few places, and for single packets
+        which[cut:] = 1 - which[cut]
+    for f in rng.integers(0, F, int(rng.integers(0, 4))):
+        which[f] = 2
+    for f in range(F):
+        frames[f, :sc.T] = base[(0, 3, 5)[which[f]], :sc.T]
+    frames[:, sc.T:] *= (1.0 + 0.001 * np.arange(F, dtype=np.float32))[:, None, None, None]
+    frames[:, :, :sc.Npre] = crandn(rng, F, sc.T + sc.R, sc.Npre, sc.N)          # preamble symbols: never read
+    chain = jrc.RadarChain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb, ab, 2.4, 28.96, -100.0, 0.0, max_frames=F, ctx=ctx)
+    bufs = chain.alloc(F, "cuda:0")
+    bufs["frames"].copy_(torch.from_numpy(frames.view(np.float32).reshape(bufs["frames"].shape)))
+    torch.cuda.synchronize()
+    chain.run(bufs, F)
+    want = chain.results(bufs, F)
+    blk = hb.radar_chain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, rb, ab, 2.4, 28.96, -100.0, 0.0, frames_per_batch=int(rng.integers(1, 9)),
+                         batches_in_flight=int(rng.integers(1, 5)))
+    f0 = 0
+    while f0 < F:
+        per_turn = int(min(rng.integers(1, 13), F - f0))
+        ports = _radar_chain_streams(sc, frames[f0:f0 + per_turn], n_items)
+        st = blk.state()
+        base_tx, base_rx = st["nitems_read"][0], st["nitems_read"][sc.T]
+        for k in range(per_turn):
+            blk.tag(0, base_tx + k * n_items, "packet_len", n_items)
+            blk.tag(sc.T, base_rx + k * n_items, "packet_len", n_items)
+        assert blk.run(0, ports, []) == 0
+        assert [blk.consumed(p) for p in range(sc.T + sc.R)] == [per_turn * n_items] * (sc.T + sc.R), (i, f0)
+        f0 += per_turn
+        if rng.integers(0, 40) == 0:
+            time.sleep(0.004)
+    blk.set("stop", 1)
+    assert blk.query("pending_batches") == 0 and blk.query("frames_done") == F, i
+    msgs = blk.state()["published"]
+    assert len(msgs) == F, (i, len(msgs), F)
+    for f in range(F):
+        assert {k: v[0] for k, v in msgs[f]["msg"]} == {"range": want[f].range_val, "angle": want[f].angle_val, "power": want[f].peak_power,
+                                                        "snr": want[f].snr_est}, (i, f)
+    chain.close()
