@@ -60,6 +60,9 @@ def parse(argv=None):
                     help="also RCCL all-gather the per-frame results every step (optional exchange, off by default)")
     ap.add_argument("--gather-maps", type=int, default=0, metavar="K",
                     help="also RCCL all-gather the range-angle maps of the first K frames of every rank each step (optional exchange, off by default)")
+    ap.add_argument("--stream-frames", type=int, default=0, metavar="M",
+                    help="testing: split ONE stream of M frames over the ranks (shard.frame_shard: contiguous blocks whose sizes may differ by one) "
+                         "instead of --frames per rank; the line then says scaling: strong")
     ap.add_argument("--dump", default="", metavar="PATH.npz",
                     help="rank 0 writes the frame-ordered results of all ranks (and the first --dump-maps maps of every rank) after the timed region")
     ap.add_argument("--dump-maps", type=int, default=0)
@@ -553,32 +556,53 @@ def flowgraph_shape_host_fed(ctx, seconds=1.0):
         L.jrcb_call_setter.argtypes = [vp, C.c_char_p, C.c_double]
         L.jrcb_destroy.argtypes = [vp]
         rbf, abf = np.ascontiguousarray(rb, np.float32), np.ascontiguousarray(ab, np.float32)
-        h = L.jrcb_make_radar_chain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, 0, rbf.ctypes.data_as(fp), len(rbf), abf.ctypes.data_as(fp), len(abf),
-                                    ndr, nda, 15.0, 0.0, b"", 0, 16, 3)
-        if h:
-            ports = [np.ascontiguousarray(np.concatenate([frames[f, p] for f in range(64)])) for p in range(sc.T + sc.R)]
-            nin = (C.c_int * 6)(*[64 * n_items] * 6)
-            pin = (vp * 6)(*[a.ctypes.data for a in ports])
-            pout = (vp * 1)()
-            turns, pos, t0 = 0, 0, None
+        L.jrcb_add_in_tags.argtypes = [vp, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_char_p, C.c_int, C.c_long, C.c_double]
+        ports = [np.ascontiguousarray(np.concatenate([frames[f, p] for f in range(64)])) for p in range(sc.T + sc.R)]
+        nin = (C.c_int * 6)(*[64 * n_items] * 6)
+        pin = (vp * 6)(*[a.ctypes.data for a in ports])
+        pout = (vp * 1)()
+
+        def run_block(fpb, slots, pre):
+            h = L.jrcb_make_radar_chain(sc.N, sc.T, sc.R, sc.S, sc.Npre, Ir, Ia, 0, rbf.ctypes.data_as(fp), len(rbf), abf.ctypes.data_as(fp), len(abf),
+                                        ndr, nda, 15.0, 0.0, b"", 0, fpb, slots)
+            if not h:
+                return
+            # the length tags of a turn arrive with its items, attached by the upstream blocks on THEIR threads: added here in two calls per
+            # turn (jrcb_add_in_tags), outside the block's work() — one ctypes call per tag costs the harness more than the block spends per packet
+            turns, pos, t0, t_turns, t_work, prof0 = 0, 0, None, 0, 0.0, None
             while True:
-                for k in range(64):
-                    L.jrcb_add_in_tag(h, 0, pos + k * n_items, b"packet_len", 0, n_items, 0.0)
-                    L.jrcb_add_in_tag(h, sc.T, pos + k * n_items, b"packet_len", 0, n_items, 0.0)
-                if L.jrcb_run(h, 0, nin, 6, pin, 0, pout) < 0:
+                L.jrcb_add_in_tags(h, 0, pos, n_items, 64, b"packet_len", 0, n_items, 0.0)
+                L.jrcb_add_in_tags(h, sc.T, pos, n_items, 64, b"packet_len", 0, n_items, 0.0)
+                tw = time.perf_counter()
+                rc_turn = L.jrcb_run(h, 0, nin, 6, pin, 0, pout)
+                if t0 is not None:
+                    t_work += time.perf_counter() - tw
+                if rc_turn < 0:
+                    out[pre + "error"] = "jrcb_run returned %d after %d turns" % (rc_turn, turns)
                     break
                 pos += 64 * n_items
                 turns += 1
                 if turns == 20:
                     t0, t_turns = time.perf_counter(), turns
+                    prof0 = [int(L.jrcb_call_setter(h, b"profile_us", float(k))) for k in range(4)]
                 if t0 is not None and time.perf_counter() - t0 > seconds:
                     break
+            if t0 is not None and turns > t_turns:
+                el = time.perf_counter() - t0                          # (before the final flush: the rate of the steady state)
+                npk = (turns - t_turns) * 64
+                prof = [int(L.jrcb_call_setter(h, b"profile_us", float(k))) - prof0[k] for k in range(4)]
+                out[pre + "frames_per_s"] = npk / el
+                out[pre + "us_per_packet_inside_work"] = 1e6 * t_work / npk
+                out[pre + "us_per_packet_breakdown"] = {"staging_tx_compare_and_copies": prof[0] / npk, "feed_submit_calls": prof[1] / npk,
+                                                        "collect_and_publish": prof[2] / npk, "general_work_total": prof[3] / npk}
             L.jrcb_call_setter(h, b"flush", 0.0)
-            el = time.perf_counter() - t0
-            out["radar_chain_block_frames_per_s"] = (turns - t_turns) * 64 / el
-            out["radar_chain_block_rx_only_batches"] = int(L.jrcb_call_setter(h, b"rx_only_batches", 0.0))
-            out["radar_chain_block_frames_done"] = int(L.jrcb_call_setter(h, b"frames_done", 0.0))
+            out[pre + "rx_only_batches"] = int(L.jrcb_call_setter(h, b"rx_only_batches", 0.0))
+            out[pre + "frames_done"] = int(L.jrcb_call_setter(h, b"frames_done", 0.0))
+            out[pre + "every_packet_accounted_for"] = out[pre + "frames_done"] == turns * 64
             L.jrcb_destroy(h)
+
+        run_block(16, 3, "radar_chain_block_")                       # the block's defaults (frames_per_batch 16, three batches in flight)
+        run_block(32, 3, "radar_chain_block_32_per_batch_")
     # (4) the CPU port on the same packets, one core
     import oracle
     n_cpu, t0 = 0, time.perf_counter()
@@ -681,8 +705,14 @@ def main():
     ndr = 2 * 3e8 / (2 * sc.fs)
     nda = 2 * float(np.rad2deg(np.arcsin(2 / P))) if P > 2 else 30.0
     axes = (rb, ab, ndr, nda)
+    n_stream = a.stream_frames if a.stream_frames > 0 else world * F   # frames of the global stream per step
+    if a.stream_frames > 0:
+        if a.stream_frames < world:
+            sys.exit("bench.py: --stream-frames must give every rank a frame")
+        lo, hi = shard.frame_shard(n_stream, rank, world)
+        F = hi - lo                                                 # ragged: the blocks differ by at most one frame
     n_distinct = min(a.distinct, F)
-    first_frame = shard.frame_shard(world * F, rank, world)[0]      # this rank's block of the global frame stream
+    first_frame = shard.frame_shard(n_stream, rank, world)[0]       # this rank's block of the global frame stream
     host_frames = synth.make_frames(sc, n_distinct, first_frame=first_frame)
     cpu_base = None
     expect = []
@@ -724,7 +754,7 @@ def main():
 
     gathered = [None]
     do_gather = a.gather_results and world > 1
-    k_maps = min(a.gather_maps, F) if world > 1 else 0
+    k_maps = min(a.gather_maps, n_stream // world) if world > 1 else 0
 
     def step():
         chain.run(bufs, F)
@@ -733,7 +763,7 @@ def main():
             # drained around it so that the exchange reads finished maps and its cost is part of the step.
             ctx.sync()
             if do_gather:                     # per-frame result records
-                gathered[0] = shard.gather_results(bufs["results"], world * F)
+                gathered[0] = shard.gather_results(bufs["results"], n_stream)
             if k_maps:                        # K maps per rank
                 gathered[0] = shard.gather_maps(bufs["map"][:k_maps], world * k_maps)
             torch.cuda.synchronize()
@@ -747,9 +777,17 @@ def main():
         step()
     ctx.sync()
     torch.cuda.synchronize()
-    chain.set_timing(True)
+    # Window 0 is the contract's timed region: exactly K steps between barrier + synchronize, with NO instrumentation inside it.  The
+    # per-kernel hipEvents the roofline record is made of (two events around every launch, on the chain's own stream) are switched on for
+    # windows 1.. — the same K steps on the same resident batch, directly behind window 0 — so `roofline.avg_launch_ms` is measured live in
+    # this run, but not inside the region `value` is taken from.  (With --windows 1 there is only window 0, and it carries the events.)
+    n_windows = max(1, a.windows)
+    events_in_window0 = n_windows == 1
+    chain.set_timing(events_in_window0)
     windows = []
-    for w in range(max(1, a.windows)):        # window 0 is the contract's timed region: exactly K steps between barrier + synchronize
+    for w in range(n_windows):
+        if w == 1:
+            chain.set_timing(True)
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -819,33 +857,37 @@ def main():
 
     if a.dump:
         ctx.sync()
-        allr = shard.gather_results(bufs["results"], world * F)
-        km = min(a.dump_maps, F)
+        allr = shard.gather_results(bufs["results"], n_stream)
+        km = min(a.dump_maps, n_stream // world)
         allm = shard.gather_maps(bufs["map"][:km].contiguous(), world * km) if km else None
-        allh = shard.gather_results(bufs["chanest"], world * F)
+        allh = shard.gather_results(bufs["chanest"], n_stream)
         if rank == 0:
             np.savez(a.dump, results=allr.cpu().numpy(), chanest=allh.cpu().numpy(),
                      maps=(allm.cpu().numpy() if allm is not None else np.zeros(0, np.float32)))
 
     rc = 0
     if rank == 0:
-        total_frames = F * a.steps * world
+        total_frames = n_stream * a.steps
         ms_step = 1e3 * elapsed / a.steps
         per = sorted(1e3 * w / a.steps for w in windows)
         out = {
             "metric": "ofdm_frames_per_sec", "value": total_frames / elapsed, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong" if a.stream_frames > 0 else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "config %s: %dTx x %dRx, %d subcarriers, %d symbols, Ir=%d, Ia=%d -> %dx%d range-angle map + "
                                    "peak/SNR estimate (mimo_ofdm_radar -> range IFFT -> transpose -> angle FFT -> "
                                    "range_angle_estimator), %d frames/GPU/step resident in HBM"
                                    % (a.config, sc.T, sc.R, sc.N, sc.S, Ir, Ia, NR, NA, F),
-                       "frames_per_gpu_per_step": F, "parallelism": "frame-sharded x%d, no data-path collective" % world,
+                       "frames_per_gpu_per_step": F, "stream_frames_per_step": n_stream, "parallelism": "frame-sharded x%d, no data-path collective" % world,
                        "gather_results": bool(do_gather), "gather_maps_per_gpu": int(k_maps),
                        "launcher": "self-launched children" if os.environ.get("JRC_BENCH_CHILD") else ("torch.distributed.run" if world > 1 else "direct")},
             "windows": {"n": len(per), "steps_each": a.steps, "ms_per_step_median": per[len(per) // 2], "ms_per_step_min": per[0],
-                        "ms_per_step_max": per[-1], "note": "`value` / `ms_per_step` are window 0 (the contract's timed region); max over ranks per window"},
+                        "ms_per_step_max": per[-1], "ms_per_step_each": [1e3 * w / a.steps for w in windows],
+                        "per_kernel_events_in_window0": events_in_window0,
+                        "note": "`value` / `ms_per_step` are window 0 (the contract's timed region, no per-kernel events inside it); windows 1.. repeat "
+                                "the same steps WITH two hipEvents around every kernel launch (the roofline's avg_launch_ms comes from those), "
+                                "which is why they, not window 0, may be the slower ones; max over ranks per window"},
             "roofline": dict(roofline_of(chain, kt, a.config, sc, Ir, Ia, F), chain=chain_roofline(sc, Ir, Ia, F, ms_step, kt)),
             "kernels_ms": {k: kt[k] for k in ("radar_chanest", "range_angle_fused", "ra_finalize")},
             "host_epilogue": "snr_est = 10 log10(peak/noise) and the publish decision of A5 (one log10f per frame) are finished on the host in "
@@ -863,7 +905,7 @@ def main():
         slowest = max(r["ms_per_step_window0"] for r in ranks)
         # consistency of the line with its parts (barrier cost + start skew), NOT the scaling efficiency (the driver computes that from the
         # per-N lines): whole-job value over N x the rate the slowest rank measured on its own clock
-        out["value_over_n_times_slowest_rank"] = (total_frames / elapsed) / (world * F / (slowest * 1e-3))
+        out["value_over_n_times_slowest_rank"] = (total_frames / elapsed) / (n_stream / (slowest * 1e-3))
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
         if world == 1 and not a.no_secondary:

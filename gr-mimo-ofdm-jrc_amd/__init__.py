@@ -255,11 +255,17 @@ class Context:
             raise JrcError(st, self.lib.jrc_strerror(st).decode())
         self.h = h
         self.device = device
+        import weakref
         global _live_contexts
         if _live_contexts is None:
-            import weakref
             _live_contexts = weakref.WeakSet()
         _live_contexts.add(self)
+        # jrc_destroy frees the context's own twiddles, scratch, pinned memory and stream — never the objects created on it (chains, feeds,
+        # blocks: device buffers, streams, events of their own).  So the context remembers them (weakly) and close() destroys them first.
+        self._children = weakref.WeakSet()
+
+    def _adopt(self, child):
+        self._children.add(child)
 
     def check(self, st):
         if st < 0:
@@ -282,6 +288,11 @@ class Context:
     def close(self):
         h = getattr(self, "h", None)
         if h:
+            for child in list(getattr(self, "_children", ())):   # objects created on this context, while it is still alive to destroy them with
+                try:
+                    child.close()
+                except Exception:
+                    pass
             self.h = None                     # first: nothing may look the stream of a context up while or after it is destroyed
             self.lib.jrc_destroy(h)
 
@@ -324,6 +335,7 @@ class mimo_ofdm_radar:
                                                      int(background_removal), int(background_recording), record_len,
                                                      interp_factor, int(enable_tx_interleave), C.byref(h)))
         self.h = h
+        self.ctx._adopt(self)
 
     def set_background_record(self, background_record):
         self.ctx.check(self.ctx.lib.jrc_radar_set_background_record(self.h, int(background_record)))
@@ -348,7 +360,7 @@ class mimo_ofdm_radar:
         return out
 
     def close(self):
-        if getattr(self, "h", None) and getattr(getattr(self, "ctx", None), "h", None):   # a context closed first took its objects with it
+        if getattr(self, "h", None) and getattr(getattr(self, "ctx", None), "h", None):   # (Context.close() closes its children before it destroys itself; a context already gone means this object went with it)
             self.ctx.lib.jrc_radar_destroy(self.h)
             self.h = None
 
@@ -520,6 +532,7 @@ class RadarChain:
         self.ctx.check(self.ctx.lib.jrc_chain_create(self.ctx.h, C.byref(self.cfg), _ptr(rb), _ptr(ab), max_frames,
                                                      C.byref(h)))
         self.h = h
+        self.ctx._adopt(self)
         L = self.ctx.lib
         self.frame_bytes = L.jrc_chain_frame_bytes(h)
         self.chanest_bytes = L.jrc_chain_chanest_bytes(h)
@@ -640,7 +653,7 @@ class RadarChain:
         return dict(radar_chanest=ms[0], range_angle_fused=ms[1], ra_finalize=ms[2], launches=n.value)
 
     def close(self):
-        if getattr(self, "h", None) and getattr(getattr(self, "ctx", None), "h", None):   # a context closed first took its objects with it
+        if getattr(self, "h", None) and getattr(getattr(self, "ctx", None), "h", None):   # (Context.close() closes its children before it destroys itself; a context already gone means this object went with it)
             self.ctx.lib.jrc_chain_destroy(self.h)
             self.h = None
 
@@ -689,6 +702,8 @@ class ChainFeed:
             self.ctx.check(L.jrc_chain_feed_create(self.ctx.h, C.byref(self.cfg), _ptr(rb), _ptr(ab), n_slots, frames_per_slot,
                                                    maps_per_slot, FEED_GRAPH if graph else 0, C.byref(h)))
         self.h = h
+        if self.ctx is not None:
+            self.ctx._adopt(self)
         self.frame_bytes = L.jrc_chain_feed_frame_bytes(h)
         self.map_bytes = L.jrc_chain_feed_map_bytes(h)
 
@@ -892,6 +907,7 @@ class mimo_ofdm_equalizer:
         h = _vp()
         self.ctx.check(L.jrc_equalizer_create(self.ctx.h, C.byref(cfg), n_streams, C.byref(h)))
         self.h = h
+        self.ctx._adopt(self)
 
     def set_estimator(self, algo):
         self.ctx.check(self.ctx.lib.jrc_equalizer_set_estimator(self.h, int(algo)))
@@ -930,7 +946,7 @@ class mimo_ofdm_equalizer:
         return out, n_out, ev
 
     def close(self):
-        if getattr(self, "h", None) and getattr(getattr(self, "ctx", None), "h", None):   # a context closed first took its objects with it
+        if getattr(self, "h", None) and getattr(getattr(self, "ctx", None), "h", None):   # (Context.close() closes its children before it destroys itself; a context already gone means this object went with it)
             self.ctx.lib.jrc_equalizer_destroy(self.h)
             self.h = None
 
@@ -978,6 +994,7 @@ class mimo_precoder:
         h = _vp()
         self.ctx.check(L.jrc_precoder_create(self.ctx.h, C.byref(cfg), C.byref(h)))
         self.h = h
+        self.ctx._adopt(self)
 
     def calculate_output_stream_length(self, ninput_items):
         return self.ctx.lib.jrc_precoder_output_length(self.h, ninput_items)
@@ -1018,7 +1035,7 @@ class mimo_precoder:
         return d_out
 
     def close(self):
-        if getattr(self, "h", None) and getattr(getattr(self, "ctx", None), "h", None):   # a context closed first took its objects with it
+        if getattr(self, "h", None) and getattr(getattr(self, "ctx", None), "h", None):   # (Context.close() closes its children before it destroys itself; a context already gone means this object went with it)
             self.ctx.lib.jrc_precoder_destroy(self.h)
             self.h = None
 
@@ -1079,6 +1096,7 @@ class target_simulator:
                       self.R, p.ctypes.data_as(_cfp), self.samp_rate, float(center_freq), float(self_coupling_db),
                       int(self.rndm_phaseshift), int(bool(self_coupling)), int(bool(sum_targets)), int(max_bursts))
         self.h = L.jrc_tsim_create(self.ctx.h, C.byref(cfg))
+        self.ctx._adopt(self)
         if not self.h:
             raise ValueError(self.ctx.lib.jrc_last_error(self.ctx.h).decode())
         self._rng = np.random.default_rng(seed)        # the reference seeds std::rand with time(NULL) (:196)
@@ -1126,7 +1144,7 @@ class target_simulator:
                                                      None if tp is None else _ptr(tp), int(accumulate_out), stream))
 
     def close(self):
-        if getattr(self, "h", None) and getattr(getattr(self, "ctx", None), "h", None):   # a context closed first took its objects with it
+        if getattr(self, "h", None) and getattr(getattr(self, "ctx", None), "h", None):   # (Context.close() closes its children before it destroys itself; a context already gone means this object went with it)
             self.ctx.lib.jrc_tsim_destroy(self.h)
             self.h = None
 
@@ -1310,6 +1328,7 @@ class frame_detector:
         self.ctx = ctx or default_context()
         self.L = _load_sync()
         self.h = self.L.jrc_frame_detector_create(self.ctx.h, fft_len, cp_len, float(threshold), int(min_n_peaks), int(ignore_gap))
+        self.ctx._adopt(self)
         if not self.h:
             raise ValueError(self.ctx.lib.jrc_last_error(self.ctx.h).decode())
 
@@ -1337,7 +1356,7 @@ class frame_detector:
         return (np.concatenate(outs) if outs else np.zeros(0, np.complex64)), tags
 
     def close(self):
-        if getattr(self, "h", None) and getattr(getattr(self, "ctx", None), "h", None):   # a context closed first took its objects with it
+        if getattr(self, "h", None) and getattr(getattr(self, "ctx", None), "h", None):   # (Context.close() closes its children before it destroys itself; a context already gone means this object went with it)
             self.L.jrc_frame_detector_destroy(self.h)
             self.h = None
 
@@ -1357,6 +1376,7 @@ class frame_sync:
         self.L = _load_sync()
         t = _c64(ltf_seq_time).ravel()
         self.h = self.L.jrc_frame_sync_create(self.ctx.h, fft_len, cp_len, int(sync_length), _ptr(t), t.size)
+        self.ctx._adopt(self)
         if not self.h:
             raise ValueError(self.ctx.lib.jrc_last_error(self.ctx.h).decode())
 
@@ -1395,7 +1415,7 @@ class frame_sync:
         return (np.concatenate(outs) if outs else np.zeros(0, np.complex64)), otags
 
     def close(self):
-        if getattr(self, "h", None) and getattr(getattr(self, "ctx", None), "h", None):   # a context closed first took its objects with it
+        if getattr(self, "h", None) and getattr(getattr(self, "ctx", None), "h", None):   # (Context.close() closes its children before it destroys itself; a context already gone means this object went with it)
             self.L.jrc_frame_sync_destroy(self.h)
             self.h = None
 
@@ -1522,6 +1542,7 @@ class ofdm_frame_generator:
                                               sw.shape[0] if sw.size else 0, _ptr(swp), int(bool(output_is_shifted)))
         if not self.h:
             raise ValueError(self.ctx.lib.jrc_last_error(self.ctx.h).decode())
+        self.ctx._adopt(self)
 
     def calculate_output_stream_length(self, ninput_items):
         return self.L.jrc_frame_generator_output_length(self.h, ninput_items)
@@ -1534,7 +1555,7 @@ class ofdm_frame_generator:
         return out
 
     def close(self):
-        if getattr(self, "h", None) and getattr(getattr(self, "ctx", None), "h", None):   # a context closed first took its objects with it
+        if getattr(self, "h", None) and getattr(getattr(self, "ctx", None), "h", None):   # (Context.close() closes its children before it destroys itself; a context already gone means this object went with it)
             self.L.jrc_frame_generator_destroy(self.h)
             self.h = None
 

@@ -1383,8 +1383,8 @@ static int chain_a1_stage(jrc_chain* ch, int f0, int nf, const jrc_cf32* d_frame
 }
 
 // A2 + A3 + A4 + A5 of frames [f0, f0 + nf) on stream s.  The per-frame work buffers (partial maxima, range profiles, window rows) are
-// addressed from the slice's first frame: a slice's partial maxima start at f0 x its own slices-per-frame count, which keeps equal
-// slices followed by one smaller slice (more slices per frame) apart.  ev2: recorded between the transforms and the estimator epilogue.
+// addressed from the slice's first frame: a slice's partial maxima start at f0 x C (the most slices a frame can have), whatever stride the
+// slice itself uses, so slices never overlap.  ev2: recorded between the transforms and the estimator epilogue.
 static int chain_transform_stage(jrc_chain* ch, int f0, int nf, const jrc_cf32* d_chanest_all, jrc_cf32* d_map_all, jrc_ra_result* d_results_all,
                                  hipStream_t s, hipEvent_t ev2)
 {
@@ -1427,7 +1427,9 @@ static int chain_transform_stage(jrc_chain* ch, int f0, int nf, const jrc_cf32* 
         const int chunk = chain_chunk(ch, wpf);
         const int tail = nf % chunk;
         const int pstride = tail ? chain_pick_wpf(ch, tail) : wpf;
-        ch->d_partials += (size_t)f0 * pstride;
+        // (base f0 x C, the per-frame size d_partials was allocated with: slices run side by side on two streams and each picks its own
+        // pstride <= C from its own frame count, so a base of f0 x pstride let a later slice with a SMALLER stride land inside an earlier one)
+        ch->d_partials += (size_t)f0 * ch->C;
         if (ch->d_rng) ch->d_rng += (size_t)f0 * ch->NR * ch->P;
         if (ch->d_win) ch->d_win += (size_t)f0 * 2 * ch->win_dr * ch->NA;
         if (pstride != wpf)      // frames of full chunks leave slots unused: all-ones = NaN power, never wins a merge
@@ -1600,12 +1602,28 @@ extern "C" int jrc_chain_fetch_results_begin(jrc_chain* ch, int n_frames, const 
     JRC_BIND(ctx);
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     if (!ch->copy_stream) {
-        JRC_HIP(ctx, hipStreamCreateWithFlags(&ch->copy_stream, hipStreamNonBlocking));
-        for (int k = 0; k < 2; k++) {
-            JRC_HIP(ctx, hipHostMalloc((void**)&ch->h_ring[k], sizeof(jrc_ra_result) * (size_t)ch->max_frames, hipHostMallocDefault));
-            JRC_HIP(ctx, hipEventCreateWithFlags(&ch->ev_ready[k], hipEventDisableTiming));
-            JRC_HIP(ctx, hipEventCreateWithFlags(&ch->ev_copied[k], hipEventDisableTiming));
+        // all-or-nothing: everything is created into locals and handed to the chain only when complete, so a failed allocation leaves the
+        // chain as it was and the next call tries again (a half-made set behind a non-null copy_stream used to fail every later call)
+        hipStream_t cs = nullptr;
+        jrc_ra_result* hr[2] = {nullptr, nullptr};
+        hipEvent_t er[2] = {nullptr, nullptr}, ec[2] = {nullptr, nullptr};
+        hipError_t e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+        for (int k = 0; k < 2 && e == hipSuccess; k++) {
+            e = hipHostMalloc((void**)&hr[k], sizeof(jrc_ra_result) * (size_t)ch->max_frames, hipHostMallocDefault);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&er[k], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ec[k], hipEventDisableTiming);
         }
+        if (e != hipSuccess) {
+            for (int k = 0; k < 2; k++) {
+                if (ec[k]) (void)hipEventDestroy(ec[k]);
+                if (er[k]) (void)hipEventDestroy(er[k]);
+                if (hr[k]) (void)hipHostFree(hr[k]);
+            }
+            if (cs) (void)hipStreamDestroy(cs);
+            JRC_HIP(ctx, e);
+        }
+        for (int k = 0; k < 2; k++) { ch->h_ring[k] = hr[k]; ch->ev_ready[k] = er[k]; ch->ev_copied[k] = ec[k]; }
+        ch->copy_stream = cs;
     }
     const int slot = (ch->ring_head + ch->ring_count) & 1;
     JRC_HIP(ctx, hipEventRecord(ch->ev_ready[slot], s));

@@ -42,6 +42,7 @@ struct feed_slot {
     jrc_ra_result* h_results = nullptr;  // pinned
     float2* h_maps = nullptr;            // pinned [maps_per_slot] maps (optional)
     hipGraphExec_t graph = nullptr;      // full-slot replay
+    hipGraphExec_t graph_rx = nullptr;   // full-slot replay of the TX-resident sequence (receive ports up, kernels, results down)
     bool graph_failed = false;
     bool warm = false;                   // one direct pass done (tables cached, nothing left to allocate inside a capture)
     int n_frames = 0;                    // frames of the batch in flight
@@ -103,6 +104,7 @@ static void feed_worker_main(jrc_chain_feed::worker* w)
 static void feed_free_slot(feed_slot& s)
 {
     if (s.graph) (void)hipGraphExecDestroy(s.graph);
+    if (s.graph_rx) (void)hipGraphExecDestroy(s.graph_rx);
     if (s.chain) jrc_chain_destroy(s.chain);
     if (s.done) (void)hipEventDestroy(s.done);
     if (s.stream) (void)hipStreamDestroy(s.stream);
@@ -242,6 +244,7 @@ extern "C" int jrc_chain_feed_set_background(jrc_chain_feed* fd, int background_
     for (int i = 1; i < fd->n_slots; i++) FEED_TRY(fd, fd->slots[(size_t)i].ctx, jrc_chain_share_background(fd->slots[(size_t)i].chain, fd->slots[0].chain));
     for (auto& s : fd->slots) {          // the history buffers alternate from batch to batch: no fixed graph
         if (s.graph) { (void)hipGraphExecDestroy(s.graph); s.graph = nullptr; }
+        if (s.graph_rx) { (void)hipGraphExecDestroy(s.graph_rx); s.graph_rx = nullptr; }
         s.graph_failed = true;
     }
     return JRC_OK;
@@ -255,6 +258,7 @@ extern "C" int jrc_chain_feed_set_write_map(jrc_chain_feed* fd, int write_map)
     for (auto& s : fd->slots) {
         FEED_TRY(fd, s.ctx, jrc_chain_set_write_map(s.chain, write_map));
         if (s.graph) { (void)hipGraphExecDestroy(s.graph); s.graph = nullptr; }      // recorded with the other kernels: record again
+        if (s.graph_rx) { (void)hipGraphExecDestroy(s.graph_rx); s.graph_rx = nullptr; }
     }
     return JRC_OK;
 }
@@ -321,38 +325,34 @@ static int feed_launch_slot(jrc_chain_feed* fd, feed_slot& s, const jrc_cf32* h_
         }
     }
     JRC_HIP(ctx, hipSetDevice(ctx->device));
-    if (rx_only) {                                              // submitted directly: the recorded graph is the full-copy sequence
-        JRC_TRY(feed_enqueue(fd, s, n_frames, true));
-        s.warm = true;
-        *replayed = false;
-        JRC_HIP(ctx, hipEventRecord(s.done, s.stream));
-        return JRC_OK;
-    }
-    const bool want_graph = (fd->flags & JRC_FEED_GRAPH) && n_frames == fd->fps && !s.graph_failed && s.warm;
-    if (want_graph && !s.graph) {
-        // record the slot's sequence once; pointers and sizes of a full slot never change
+    // A full slot is replayed from a recorded graph once the slot is warm (pointers and sizes of a full slot never change): one graph for the
+    // full-copy sequence, one for the TX-resident one.  The broadcast of the resident rows into the slot's frames is not part of the recorded
+    // sequence: a slot whose frames do not hold them yet (first rx-only batch, or a full submission overwrote them) is submitted directly once.
+    hipGraphExec_t& gx = rx_only ? s.graph_rx : s.graph;
+    const bool want_graph = (fd->flags & JRC_FEED_GRAPH) && n_frames == fd->fps && !s.graph_failed && s.warm && (!rx_only || s.tx_in_frames);
+    if (want_graph && !gx) {
         hipGraph_t g = nullptr;
         hipError_t e = hipStreamBeginCapture(s.stream, hipStreamCaptureModeRelaxed);
         int st = JRC_OK;
         if (e == hipSuccess) {
-            st = feed_enqueue(fd, s, n_frames);
+            st = feed_enqueue(fd, s, n_frames, rx_only);
             e = hipStreamEndCapture(s.stream, &g);
         }
-        if (e == hipSuccess && st == JRC_OK) e = hipGraphInstantiate(&s.graph, g, nullptr, nullptr, 0);
+        if (e == hipSuccess && st == JRC_OK) e = hipGraphInstantiate(&gx, g, nullptr, nullptr, 0);
         if (g) (void)hipGraphDestroy(g);
         if (e != hipSuccess || st != JRC_OK) {       // fall back to direct submission on this slot, loudly in last_error
             (void)hipGetLastError();
-            s.graph = nullptr; s.graph_failed = true;
+            gx = nullptr; s.graph_failed = true;
             jrc_fail(ctx, JRC_ERR_HIP, "jrc_chain_feed: graph capture failed (%s), submitting directly", hipGetErrorString(e));
         }
     }
     *replayed = false;
-    if (want_graph && s.graph) {
-        JRC_HIP(ctx, hipGraphLaunch(s.graph, s.stream));
-        s.tx_in_frames = false;
+    if (want_graph && gx) {
+        JRC_HIP(ctx, hipGraphLaunch(gx, s.stream));
+        if (!rx_only) s.tx_in_frames = false;
         *replayed = true;
     } else {
-        JRC_TRY(feed_enqueue(fd, s, n_frames));
+        JRC_TRY(feed_enqueue(fd, s, n_frames, rx_only));
         s.warm = true;
     }
     JRC_HIP(ctx, hipEventRecord(s.done, s.stream));

@@ -316,6 +316,12 @@ class radar_chain_impl : public radar_chain {
     // read by the getters from any thread while the scheduler's thread or the flusher advances them under d_setlock
     std::atomic<int> d_frames_done{0}, d_pending{0};
     std::atomic<long> d_rx_only_batches{0};
+    std::atomic<long> d_prof_ns[4] = {{0}, {0}, {0}, {0}};          // profile_ns(): staging, submit, collect + publish, whole general_work
+    struct prof_scope {                                            // (two steady_clock reads, ~50 ns, per scope)
+        std::atomic<long>& acc; std::chrono::steady_clock::time_point t0;
+        explicit prof_scope(std::atomic<long>& a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+        ~prof_scope() { acc.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed); }
+    };
     bool d_bg_removal = false;
     std::vector<jrc_ra_result> d_res;
     // batches stay in flight across general_work calls (at most d_slots), published in frame order as they complete; one older than
@@ -333,9 +339,24 @@ class radar_chain_impl : public radar_chain {
             std::this_thread::sleep_for(nap);
             if (d_flusher_stop.load()) break;
             jrc_rt::thread::scoped_lock guard(d_setlock);
+            // (the lock is held while an OVERDUE batch is waited for — at most the rest of one batch's device time, well under the age bound;
+            // batches that are merely in flight are polled, never waited for)
             try { if (d_feed && jrc_chain_feed_pending(d_feed) > 0) collect_ready(false); }
-            catch (const std::exception& e) { std::cerr << "[RADAR CHAIN] " << e.what() << std::endl; }
+            catch (const std::exception& e) {
+                // a failed collect or publish (HIP error, log file not writable) will fail again: say it once, remember it for the scheduler's
+                // thread — the next general_work / flush rethrows it, as it would have had it collected the batch itself — and stop retrying
+                std::cerr << "[RADAR CHAIN] " << e.what() << std::endl;
+                d_flusher_error = e.what();
+                d_flusher_failed.store(true);
+                break;
+            }
         }
+    }
+    std::atomic<bool> d_flusher_failed{false};
+    std::string d_flusher_error;                                    // written once by the flusher before d_flusher_failed, read after it
+    void rethrow_flusher_error()
+    {
+        if (d_flusher_failed.load()) throw std::runtime_error("[RADAR CHAIN] (from the flusher thread) " + d_flusher_error);
     }
     // TX-resident submission: the reference rows the radar correlates with (the N_sym symbols behind N_pre of every TX port) are the MIMO-LTFs
     // in the reference's flowgraph, the same for every packet.  The block keeps the rows of the last full submission; a batch whose frames all
@@ -367,6 +388,7 @@ class radar_chain_impl : public radar_chain {
     }
     void collect_one()
     {
+        prof_scope ps(d_prof_ns[2]);
         int n = 0;
         ctx_holder::check_feed(d_feed, jrc_chain_feed_collect(d_feed, d_res.data(), nullptr, &n));
         if (!d_submitted.empty()) d_submitted.pop_front();
@@ -406,14 +428,18 @@ public:
         cfg.n_items = N_sym; cfg.noise_discard_range_m = ndr; cfg.noise_discard_angle_deg = nda;
         cfg.snr_threshold = snr_threshold; cfg.power_threshold = power_threshold;
         const std::vector<int> devs = devices_from_env();
+        // full batches are replayed from a recorded hipGraph (one launch instead of copy + kernels + copy enqueued one by one: at the reference
+        // flowgraph's 27 KB packets the enqueue calls are what a batch costs the scheduler's thread); JRC_RADAR_CHAIN_GRAPH=0 submits directly
+        const char* ge = getenv("JRC_RADAR_CHAIN_GRAPH");
+        const int feed_flags = (ge && atoi(ge) == 0) ? 0 : JRC_FEED_GRAPH;
         if (devs.size() > 1) {         // one host process, several GPUs: batch k on device k mod n, results in frame order (jrc_chain_feed_create_multi)
             if (background_removal || background_recording)
                 throw std::invalid_argument("[RADAR CHAIN] background removal keeps the frames of a stream on one GPU: unset JRC_DEVICES");
-            int st = jrc_chain_feed_create_multi(devs.data(), (int)devs.size(), &cfg, range_bins.data(), angle_bins.data(), batches_in_flight, d_fpb, 0, 0, &d_feed);
+            int st = jrc_chain_feed_create_multi(devs.data(), (int)devs.size(), &cfg, range_bins.data(), angle_bins.data(), batches_in_flight, d_fpb, 0, feed_flags, &d_feed);
             if (st != JRC_OK) throw std::runtime_error(std::string("[RADAR CHAIN] jrc_chain_feed_create_multi: ") + jrc_strerror(st));
             d_slots = batches_in_flight * (int)devs.size();
         } else {
-            d_c.check(jrc_chain_feed_create(d_c.ctx, &cfg, range_bins.data(), angle_bins.data(), d_slots, d_fpb, 0, 0, &d_feed));
+            d_c.check(jrc_chain_feed_create(d_c.ctx, &cfg, range_bins.data(), angle_bins.data(), d_slots, d_fpb, 0, feed_flags, &d_feed));
         }
         d_n_devices = (int)devs.size();
         // the block has no stream output: nobody reads the range-angle map, so it is not stored (results are bit-identical); shapes
@@ -436,15 +462,20 @@ public:
     {
         d_flusher_stop.store(true);
         if (d_flusher.joinable()) d_flusher.join();
+        // a block destroyed without stop() / flush(): publish what is still in flight (a destructor must not throw: a failure is only reported)
+        try { if (d_feed && !d_flusher_failed.load() && jrc_chain_feed_pending(d_feed) > 0) collect_ready(true); }
+        catch (const std::exception& e) { std::cerr << "[RADAR CHAIN] ~radar_chain: " << e.what() << std::endl; }
         jrc_chain_feed_destroy(d_feed);
     }
     int frames_done() const override { return d_frames_done; }
     int n_devices() const override { return d_n_devices; }
     long rx_only_batches() const override { return d_rx_only_batches; }
+    long profile_ns(int what) const override { return what >= 0 && what < 4 ? d_prof_ns[what].load() : 0; }
     int pending_batches() const override { return d_pending.load(); }
     void flush() override
     {
         jrc_rt::thread::scoped_lock guard(d_setlock);
+        rethrow_flusher_error();
         collect_ready(true);
     }
     bool stop() override { flush(); return true; }                      // the scheduler is done with the block: publish what is still in flight
@@ -458,6 +489,8 @@ public:
     int general_work(int, gr_vector_int& ninput_items, gr_vector_const_void_star& input_items, gr_vector_void_star&) override
     {
         jrc_rt::thread::scoped_lock guard(d_setlock);
+        prof_scope ps_all(d_prof_ns[3]);
+        rethrow_flusher_error();
         collect_ready(false);                                                                         // what finished since the last call
         std::vector<jrc_rt::tag_t> rx_tags, tx_tags;
         get_tags_in_range(rx_tags, d_N_tx, nitems_read(d_N_tx), nitems_read(d_N_tx) + ninput_items[d_N_tx], pmt::mp("packet_len"));
@@ -482,6 +515,7 @@ public:
             if (jrc_chain_feed_pending(d_feed) == d_slots) collect_one();
             ctx_holder::check_feed(d_feed, jrc_chain_feed_acquire(d_feed, &stage));
             int nb = 0;
+            auto t_stage = std::chrono::steady_clock::now();
             const bool try_resident = d_tx_res_enabled && d_tx_ref_valid && d_tx_backoff == 0;
             bool tx_same = try_resident;                                                              // all frames of the batch carry the resident rows
             for (; f < n_frames && nb < d_fpb; f++) {
@@ -505,7 +539,9 @@ public:
                 rx_end = rx0 + rx_len; tx_end = tx0 + tx_len;
                 nb++;
             }
+            d_prof_ns[0].fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_stage).count(), std::memory_order_relaxed);
             if (nb == 0) break;                                                                       // the next frame is not complete yet
+            prof_scope ps_submit(d_prof_ns[1]);
             if (tx_same) {
                 if (!d_tx_ref_on_device) {                                                            // first use of these rows: hand them to the feed (nothing may be in flight)
                     collect_ready(true);

@@ -85,6 +85,9 @@ public:
     virtual void flush() = 0;
     virtual int pending_batches() const = 0;
     virtual long rx_only_batches() const = 0;                              // batches whose TX reference rows were already on the device
+    // where general_work's time went so far, ns: 0 staging (TX row compare + copies into the pinned slot), 1 submit calls into the feed,
+    // 2 collecting + publishing finished batches, 3 the whole of general_work
+    virtual long profile_ns(int what) const = 0;
 };
 
 class MIMO_OFDM_JRC_API matrix_transpose : virtual public jrc_rt::tagged_stream_block {

@@ -204,6 +204,21 @@ int jrcb_add_in_tag(void* h, int port, uint64_t offset, const char* key, int kin
     return 0;
 }
 
+// `count` tags `stride` items apart in one call: what an upstream block's own thread has attached by the time the scheduler calls work()
+// (a harness that adds them one ctypes call at a time pays more for the tags than the block pays for the packets)
+int jrcb_add_in_tags(void* h, int port, uint64_t first_offset, uint64_t stride, int count, const char* key, int kind, long lv, double dv)
+{
+    auto& b = ((handle*)h)->b;
+    if (port < 0 || port >= (int)b->t_in_tags.size() || count < 0) return -1;
+    jrc_host::tag_t t;
+    t.key = pmt::mp(key);
+    t.value = kind == 0 ? pmt::from_long(lv) : (kind == 1 ? pmt::from_uint64((uint64_t)lv) : pmt::from_double(dv));
+    auto& v = b->t_in_tags[port];
+    v.reserve(v.size() + (size_t)count);
+    for (int i = 0; i < count; i++) { t.offset = first_offset + (uint64_t)i * stride; v.push_back(t); }
+    return 0;
+}
+
 // one scheduler turn; returns items produced, or -1000 on exception (see jrcb_last_error)
 int jrcb_run(void* h, int noutput_items, const int* ninput_items, int n_in, const void* const* in, int n_out, void* const* out)
 {
@@ -271,6 +286,7 @@ int jrcb_call_setter(void* h, const char* name, double v)
             if (n == "stop") { return rc->stop() ? 0 : -1; }
             if (n == "pending_batches") return rc->pending_batches();
             if (n == "rx_only_batches") return (int)rc->rx_only_batches();
+            if (n == "profile_us") return (int)(rc->profile_ns((int)v) / 1000);
         }
         if (auto* e = dynamic_cast<range_angle_estimator*>(b.get())) {
             if (n == "set_snr_threshold") { e->set_snr_threshold((float)v); return 0; }

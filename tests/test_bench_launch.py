@@ -84,6 +84,36 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path):
 
 
 @pytest.mark.gpu
+def test_eight_ranks_with_ragged_shards_equal_one_rank(tmp_path):
+    """BASELINE config 5's world size on the one GPU there is: 8 ranks (--same-device, gloo) split ONE stream of 203 frames into the ragged
+    blocks of shard.frame_shard (26 / 25 frames), gather the per-frame records and two maps per rank inside every step, and the dump —
+    records, channel estimates, maps, in frame order — must equal the single-rank run of the same 203 frames bit for bit"""
+    sys.path.insert(0, ROOT)
+    from jrc_amd import shard
+    M, W = 203, 8
+    one, eight = str(tmp_path / "one.npz"), str(tmp_path / "eight.npz")
+    r1, l1 = _run(COMMON + ["--frames", str(M), "--distinct", str(M), "--dump", one, "--dump-maps", str(M), "--oracle-frames", "4"])
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    r8, l8 = _run(COMMON + ["--gpus", str(W), "--same-device", "--backend", "gloo", "--stream-frames", str(M), "--distinct", str(M), "--dump", eight,
+                            "--dump-maps", "2", "--oracle-frames", "4", "--gather-results", "--gather-maps", "2"], timeout=1200)
+    assert r8.returncode == 0, r8.stderr[-3000:]
+    assert len(l8) == 1
+    j = json.loads(l8[-1])
+    sizes = shard.shard_sizes(M, W)
+    assert sorted(set(sizes)) == [25, 26] and sum(sizes) == M                 # ragged
+    assert j["n_gpus"] == W and j["scaling"] == "strong" and j["collective_world"] == W and j["backend"] == "gloo" and j["distinct_devices"] == 1
+    assert j["check"]["ok"] and j["check"]["ok_all_ranks"]
+    assert j["config"]["stream_frames_per_step"] == M and j["config"]["gather_results"] and j["config"]["gather_maps_per_gpu"] == 2
+    assert [r["rank"] for r in j["ranks"]] == list(range(W)) and len(set(r["pid"] for r in j["ranks"])) == W
+    assert abs(j["value"] - M * 3 / (j["ms_per_step"] * 3e-3)) < 1e-6 * j["value"]
+    a, b = np.load(one), np.load(eight)
+    assert a["results"].shape[0] == b["results"].shape[0] == M
+    assert np.array_equal(a["results"], b["results"]) and np.array_equal(a["chanest"], b["chanest"])
+    firsts = [shard.frame_shard(M, r, W)[0] for r in range(W)]
+    assert np.array_equal(np.concatenate([a["maps"][f:f + 2] for f in firsts]), b["maps"])
+
+
+@pytest.mark.gpu
 def test_two_ranks_on_one_device_without_the_test_flag_is_refused():
     """an N-GPU line whose ranks share a physical device is not an N-GPU measurement: without --same-device (where every rank is
     pinned to GPU 0 on purpose) bench.py must exit non-zero.  On this one-GPU box LOCAL_RANK 1 has no device of its own, so the ranks are

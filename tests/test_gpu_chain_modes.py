@@ -455,6 +455,61 @@ def test_multi_device_feed_equals_single_device_feed(jrc, ctx, devices):
     single.close()
 
 
+def test_multi_device_feed_refuses_background_and_one_feed_per_stream_carries_it(jrc, ctx):
+    """background removal orders the frames of ONE radar stream (lib/mimo_ofdm_radar_impl.cc:281-300): a feed that deals batches over devices
+    refuses it loudly (no silent per-device histories), and the supported layout — one feed per stream, each on its own device context, all
+    driven from one host thread with their batches interleaved and in flight together — gives every stream exactly the estimates it gets
+    alone.  The devices are the one GPU of the box under two contexts."""
+    from jrc_amd import synth
+    sc = synth.Scenario(64, 2, 2, 3, targets=[(15.0, -20.0, 0.0, 50.0)])
+    P, L, fps, nb = sc.T * sc.R, 3, 2, 6
+    rb, ab = jrc.radar_axes(sc.N, sc.fs, 2, P, 4)
+    mk = lambda c, **kw: jrc.ChainFeed(sc.N, sc.T, sc.R, sc.S, sc.Npre, 2, 4, rb, ab, 2.4, 29.0, 15.0, 0.0, ctx=c, n_slots=3, frames_per_slot=fps,
+                                       maps_per_slot=fps, **kw)
+    multi = mk(ctx, devices=[0, 0])
+    with pytest.raises(jrc.JrcError) as e:
+        multi.set_background(True, True, L)
+    assert e.value.status == jrc.JRC_ERR_UNSUPPORTED and "one feed per stream" in str(e.value)
+    multi.set_background(False, False, L)                           # (off is accepted)
+    multi.close()
+    streams = [synth.make_frames(sc, fps * nb, first_frame=1000 * k) for k in range(2)]
+    for k in range(2):
+        streams[k][:, sc.T:] *= (1.0 + 0.05 * (k + 1) * np.arange(fps * nb, dtype=np.float32))[:, None, None, None]
+
+    def drive(feeds, frames_of):
+        maps = [[] for _ in feeds]
+        for b in range(nb):
+            for k, fd in enumerate(feeds):                          # interleaved: both feeds have batches in flight at once
+                if fd.pending() == 3:
+                    maps[k].append(fd.collect(want_maps=True)[1])
+                fd.submit(frames_of[k][b * fps:(b + 1) * fps])
+        for k, fd in enumerate(feeds):
+            while fd.pending():
+                maps[k].append(fd.collect(want_maps=True)[1])
+        return [np.concatenate(m) for m in maps]
+
+    ctx2 = jrc.Context(0)
+    feeds = [mk(ctx), mk(ctx2)]
+    for fd in feeds:
+        fd.set_background(True, True, L)
+    together = drive(feeds, streams)
+    for fd in feeds:
+        fd.close()
+    for k in range(2):
+        alone = mk(ctx)
+        alone.set_background(True, True, L)
+        want = drive([alone], [streams[k]])[0]
+        alone.close()
+        assert np.array_equal(together[k], want), k
+        ref, _ = _oracle_stream(sc, streams[k], L)                    # and the history is the reference's: map of frame f from the oracle's estimate
+        for f in (0, L, fps * nb - 1):
+            Hp = np.zeros((P, sc.N * 2), np.complex64)
+            Hp[:, :sc.N] = ref[f]
+            m = oracle.fft_vcc(oracle.matrix_transpose(oracle.fft_vcc(Hp, False, False), sc.N * 2, P, 4), True, True)
+            assert rel_err(together[k][f], m) < 5e-6, (k, f)
+    ctx2.close()
+
+
 def test_time_domain_entry_with_background_and_detect_only(jrc, ctx):
     """jrc_chain_run_td_dev (A6 + A7 + A1 as one kernel) goes through the same background step and the same detect-only modes as the
     frequency-domain entry: its detect-only records equal its own map-mode records byte for byte, and its background-free estimates

@@ -152,3 +152,28 @@ def test_zero_pad_with_row_strides(jrc, ctx):
         ctx.check(L.jrc_zero_pad_strided_dev(ctx.h, F, n, front, tail, 11, None, n, out.data_ptr(), n_out, None))
     assert L.jrc_zero_pad_strided_dev(ctx.h, 0, n, front, tail, 11, None, n, None, n_out, None) == n_out
     assert L.jrc_zero_pad_strided_dev(ctx.h, F, 0, 0, 0, 11, None, 0, None, 0, None) == 0
+
+
+def test_a_context_closed_first_destroys_the_objects_created_on_it(jrc):
+    """jrc_destroy frees only the context's own twiddles / scratch / stream, so a context that goes first must take its chains, feeds
+    and blocks with it (their device buffers used to leak silently): Context.close() closes its children, their own close() afterwards is a
+    no-op, and the device memory they held is back."""
+    import torch
+    from jrc_amd import synth
+    sc = synth.Scenario(256, 4, 4, 8, targets=[(10.0, 20.0, 0.0, 100.0)])
+    P = sc.T * sc.R
+    rb, ab = jrc.radar_axes(sc.N, sc.fs, 8, P, 16)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    c = jrc.Context(0)
+    chain = jrc.RadarChain(sc.N, sc.T, sc.R, sc.S, sc.Npre, 8, 16, rb, ab, 2.4, 14.4, 15.0, 0.0, max_frames=64, ctx=c)
+    feed = jrc.ChainFeed(sc.N, sc.T, sc.R, sc.S, sc.Npre, 8, 16, rb, ab, 2.4, 14.4, 15.0, 0.0, ctx=c, n_slots=2, frames_per_slot=32, maps_per_slot=1)
+    radar = jrc.mimo_ofdm_radar(sc.N, sc.T, sc.R, sc.S, sc.Npre, ctx=c)
+    det = jrc.frame_detector(64, 16, 0.6, 10, 640, ctx=c)
+    held = free0 - torch.cuda.mem_get_info()[0]
+    assert held > 32 << 20                                            # the feed's slots alone are 2 x 32 frames x 9 symbols x 8 streams x 2 KiB
+    c.close()
+    assert chain.h is None and feed.h is None and radar.h is None and det.h is None
+    for o in (chain, feed, radar, det):
+        o.close()                                                     # no-ops now
+    assert free0 - torch.cuda.mem_get_info()[0] < held // 8, (free0, torch.cuda.mem_get_info()[0], held)

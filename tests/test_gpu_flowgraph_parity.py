@@ -23,6 +23,7 @@ import pytest
 import oracle
 import oracle_blocks
 from conftest import GOLDEN, ROOT, rel_err
+from metric_truth import assert_metric_parity
 
 sys.path.insert(0, os.path.join(ROOT, "examples"))
 pytestmark = pytest.mark.gpu
@@ -206,7 +207,7 @@ def same_events(ge, oe, tol, freq_floor=1.0):
                 assert rel_err(g["chan_mean"], o["chan_mean"]) <= tol
 
 
-def compare_comm_edges(ge, oe, rep, tag, tol, live=48, norm_tol=1e-3, freq_floor=1.0, payload_equal=True):
+def compare_comm_edges(ge, oe, rep, tag, tol, fft_len=64, freq_floor=1.0, payload_equal=True):
     assert ge["encoder_tags"] == oe["encoder_tags"]               # packet_len, packet_type, mcs, pdu_len
     for k in COMM_CF32_EDGES:
         assert k in ge and k in oe, k
@@ -218,13 +219,18 @@ def compare_comm_edges(ge, oe, rep, tag, tol, live=48, norm_tol=1e-3, freq_floor
     for i, name in enumerate(("metric_delayed", "metric_corr", "metric_norm")):
         a, b = ge["metrics"][i], oe["metrics"][i]
         if name == "metric_norm":
-            # float edge |corr| / power: the stock blocks_moving_average_ff keeps a RUNNING sum whose round-off depends on everything that
-            # went through it (worst behind the 40 dB step from pad noise to burst); the device adds each window afresh (sync.hip) and is
-            # the more accurate of the two.  The first window of samples divides by a near-empty power window.  DESIGN.md §5.2.
-            a, b = a[live:], b[live:]
-            err = float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
-            rep[tag + name] = max(rep.get(tag + name, 0.0), err)
-            assert err <= norm_tol, (name, err)
+            # float edge |corr| / power.  The stock blocks_moving_average_ff keeps a RUNNING sum whose round-off depends on everything that went
+            # through it since the scheduler call began (worst behind the 40 dB step from burst to pad noise); the oracle restates the worst
+            # case (one sum over the capture), the device adds each window afresh (sync.hip).  So the edge is held against its definition in
+            # float64 (tests/metric_truth.py): device within north_star's 1e-4 of it and no further from it than the oracle's running sum;
+            # device against oracle within 1e-4 plus the running sum's own measured distance from the definition.  DESIGN.md §5.2.
+            window = fft_len // 2                                  # corr_window_size of the flowgraph (examples/comm_sim_flowgraph.py)
+            pw = int(1.5 * window)
+            x_ora = ge["rx"] if tag == "block:" else oe["rx"]      # block by block the oracle's metric blocks read the HIP graph's samples
+            e = assert_metric_parity(a, b, ge["rx"], x_ora, fft_len // 4, window, pw, 1 / 1.5, live=pw, tol=TOL)
+            rep[tag + name + "_vs_float64_definition"] = max(rep.get(tag + name + "_vs_float64_definition", 0.0), e["dev"])
+            rep[tag + name + "_oracle_running_sum_vs_definition"] = max(rep.get(tag + name + "_oracle_running_sum_vs_definition", 0.0), e["ora"])
+            rep[tag + name] = max(rep.get(tag + name, 0.0), e["dev_vs_ora"])
             continue
         err = rel_err(a, b)
         rep[tag + name] = max(rep.get(tag + name, 0.0), err)
@@ -306,8 +312,9 @@ def test_comm_flowgraph_edge_by_edge_256_subcarriers(jrc, ctx):
         ge = ginfo["edges"]
         ook, opay, oinfo = orc.send(pdu, snr_db=30.0, steer=steer, lead=2560, sources=dict(pads=None, noise=ge["noise"]))
         assert "y" in ge, ginfo.keys()
-        # behind the burst (30 dB over the noise that follows) the reference's running power sum keeps the burst's round-off: 2e-3 of the metric there
-        compare_comm_edges(ge, oinfo["edges"], rep, "chained:", TOL, live=192, norm_tol=5e-3)
+        # (behind the burst, 30 dB over the noise that follows, the oracle's running power sum keeps the burst's round-off — 2e-3 of the metric
+        # there; the device's metric is within 1e-4 of the float64 definition throughout: compare_comm_edges)
+        compare_comm_edges(ge, oinfo["edges"], rep, "chained:", TOL, fft_len=256)
         assert (gok, gpay) == (ook, opay)
         if pdu[0] == 2:
             assert gok and gpay == pdu
@@ -648,7 +655,7 @@ def test_comm_flowgraph_on_drawn_links(jrc, ctx, ofdm64, i):
                     ge_cmp, on_boundary = dict(ge, eq_out=patched, crc_ok=oe_.get("crc_ok"), payload=oe_.get("payload")), True
             # (the offset the stream_start event announces is coarse - fine in Hz: near zero it is the difference of two 1e-2 rad / sample numbers
             # known to 1e-9, so it is held to 1e-4 of a 1e-3 rad / sample offset — 2 Hz at 125 MS/s — rather than of itself)
-            compare_comm_edges(ge_cmp, oe_, rep, "chained:", TOL + 1.5 * d_cfo * max(1, ge["detector_out"].size), norm_tol=2e-2, freq_floor=2e4, payload_equal=bool(gok))
+            compare_comm_edges(ge_cmp, oe_, rep, "chained:", TOL + 1.5 * d_cfo * max(1, ge["detector_out"].size), freq_floor=2e4, payload_equal=bool(gok))
             if sta and not on_boundary:
                 assert gok == ook and (not gok or gpay == opay)
         except AssertionError as e:

@@ -9,7 +9,7 @@ SWITCHES = [{"JRC_WPF": "2"}, {"JRC_WPF": "8"}, {"JRC_WG_PER_CU": "1"}, {"JRC_RA
             {"JRC_DETECT_SLICES": "2"}, {"JRC_DETECT_SLICES": "5"}, {"JRC_DETECT_SLICES": "3", "JRC_CHANEST_U2": "1"}]
 
 
-def _run(jrc, env, monkeypatch, cfg):
+def _run(jrc, env, monkeypatch, cfg, with_map=True):
     import torch
     from jrc_amd import synth
     for k in list(env):
@@ -26,7 +26,7 @@ def _run(jrc, env, monkeypatch, cfg):
     torch.cuda.synchronize()
     chain.run(bufs, F)
     c.sync()
-    out = [bufs["chanest"].cpu().numpy().tobytes(), bufs["map"].cpu().numpy().tobytes(), bufs["results"].cpu().numpy().tobytes()]
+    out = [bufs["chanest"].cpu().numpy().tobytes(), bufs["map"].cpu().numpy().tobytes() if with_map else b"", bufs["results"].cpu().numpy().tobytes()]
     chain.set_write_map(False)
     chain.run(bufs, F)
     c.sync()
@@ -47,6 +47,22 @@ def test_radar_chain_does_not_depend_on_the_launch_switches(jrc, monkeypatch, cf
         got = _run(jrc, env, monkeypatch, cfg)
         for name, a, b in zip(("chanest", "map", "records", "detect-only records"), want, got):
             assert a == b, (env, name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"JRC_DETECT_SLICES": "2", "JRC_NCUS": "32"}, {"JRC_DETECT_SLICES": "3", "JRC_NCUS": "32"}, {"JRC_DETECT_SLICES": "2"}])
+def test_detect_slices_beyond_one_resident_wave_with_an_uneven_last_slice(jrc, monkeypatch, env):
+    """the sliced detect-only pipeline with more frames than resident workgroups and slices that pick DIFFERENT partial strides — with
+    32 CUs x 2 workgroups, 136 frames in 2 slices are 72 frames (one full chunk of 64 + a tail of 8: stride 8) beside 64 frames (stride 1) on
+    the other stream; the second slice's partial maxima used to start at 72 x 1, inside the first slice's 72 x 8 (corrupted peaks).  Slices now
+    start at f0 x C.  Records byte for byte as with the defaults; the third case is the ADVICE's own (1032 frames on all CUs: 520 + 512)."""
+    small = "JRC_NCUS" in env
+    cfg = (256, 4, 4, 4, 8, 136 if small else 1032)
+    want = _run(jrc, {}, monkeypatch, cfg, with_map=small)
+    got = _run(jrc, env, monkeypatch, cfg, with_map=small)
+    assert want[2] == want[3]
+    for name, a, b in zip(("chanest", "map", "records", "detect-only records"), want, got):
+        assert a == b, (env, name)
 
 
 @pytest.mark.gpu
