@@ -48,6 +48,12 @@ struct jrc_tsim {
     float2* d_g = nullptr;        // [max_bursts][R][M]
     float2* d_phase = nullptr;    // [K]
     size_t u_cap = 0, g_cap = 0;
+    // direct four-step plan (td_*): n = n1 x n2, n2 a power of two — no chirp, no padding; d_ts then holds timeshift permuted to [R][K][n1][n2]
+    bool direct = false;
+    int n1 = 0;                   // column transform length (rows of the [n1][n2] view); n2 above is the row length
+    int nrad = 0, rad[24] = {0};  // radices of the n1-point column transform
+    float2* d_w1 = nullptr;       // [n1]      exp(-j 2 pi q / n1)
+    float2* d_two = nullptr;      // [n1][n2]  exp(-j 2 pi i2 k1 / n)
 };
 
 __device__ __forceinline__ float2 conjf2(float2 a) { return make_float2(a.x, -a.y); }
@@ -481,6 +487,374 @@ __global__ void tsim_passthrough_kernel(float2* __restrict__ out, long out_burst
     o[m] = v;
 }
 
+// =====================================================================================================================
+// Direct four-step path (round 5).  Every burst the flowgraphs produce has n = n_symbols x (fft_len + cp) samples with
+// fft_len + cp = 5 x 2^k (lib/target_simulator_impl.cc:243-245 takes n from the packet_len tag; 23,040 = 45 x 512 at config B),
+// and the chirp-z route above pads such a burst to M = 65,536 = 2.84 n and walks it five times through HBM.  Here the length-n
+// DFT itself is split  n = n1 x n2  with n2 the largest power of two dividing n (<= 4096) and n1 = n / n2 (any integer <= 512):
+//      i = i1 n2 + i2,  k = k1 + n1 k2:   X[k1 + n1 k2] = sum_i2 w_n2^{i2 k2} [ w_n^{i2 k1} sum_i1 x[i1 n2 + i2] w_n1^{i1 k1} ]
+//   * td_col_fwd_kernel   (in . doppler) viewed as [n1][n2]: n1-point DFTs down 16 columns per workgroup (mixed-radix Stockham in LDS:
+//                         radix 4 / 2 / 3 / 5 butterflies, any other prime factor p by its p-term sums), . w_n^{i2 k1} -> U[k1][i2]
+//   * td_rows*_kernel     per row k1: n2-point FFT -> . timeshift_l[k1 + n1 k2] (summed over the targets of the launch) -> inverse
+//                         n2-point FFT, for every RX antenna out of the one forward transform -> G[l][k1][i2]
+//   * td_col_inv_kernel   . conj w_n^{i2 k1}, inverse n1-point DFTs down the columns -> out_l[i1 n2 + i2] (natural order)
+// "doppler -> FFT once per target -> x timeshift per antenna -> IFFT" is the algebra of the route above; the spectrum stays in
+// [k1][k2] order between the passes (the timeshift table is stored in that order once per burst length), so there is no transpose and
+// no reordering pass.  HBM traffic per burst: (3 + 3R) n x 8 B against (1 + R) n x 8 B algorithmic = 3x at R = 4 (chirp-z: 13.6x).
+// Lengths that do not split this way (n2 < 16 or n1 > 512) keep the chirp-z route; JRC_TSIM_BLUESTEIN=1 forces it for all.
+// =====================================================================================================================
+#define TD_CW 16
+#define TD_MAX_N1 512
+
+struct td_plan { int n1, n2, nrad; int rad[24]; };
+
+template <int R>
+__device__ __forceinline__ void td_dft_small(float2 (&v)[R]);
+template <> __device__ __forceinline__ void td_dft_small<2>(float2 (&v)[2]) { fft_fwd_small<2>(v); }
+template <> __device__ __forceinline__ void td_dft_small<4>(float2 (&v)[4]) { fft_fwd_small<4>(v); }
+template <> __device__ __forceinline__ void td_dft_small<3>(float2 (&v)[3])
+{
+    const float s3 = 0.86602540378443864676f;
+    const float2 t = cadd(v[1], v[2]), d = csub(v[1], v[2]);
+    const float2 m = make_float2(v[0].x - 0.5f * t.x, v[0].y - 0.5f * t.y);
+    const float2 jd = make_float2(s3 * d.y, -s3 * d.x);                      // -j s3 d
+    v[0] = cadd(v[0], t); v[1] = cadd(m, jd); v[2] = csub(m, jd);
+}
+template <> __device__ __forceinline__ void td_dft_small<5>(float2 (&v)[5])
+{
+    const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f, s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
+    const float2 a1 = cadd(v[1], v[4]), a2 = cadd(v[2], v[3]), b1 = csub(v[1], v[4]), b2 = csub(v[2], v[3]);
+    const float2 r1 = make_float2(v[0].x + c1 * a1.x + c2 * a2.x, v[0].y + c1 * a1.y + c2 * a2.y);
+    const float2 r2 = make_float2(v[0].x + c2 * a1.x + c1 * a2.x, v[0].y + c2 * a1.y + c1 * a2.y);
+    const float2 i1 = make_float2(s1 * b1.x + s2 * b2.x, s1 * b1.y + s2 * b2.y);
+    const float2 i2 = make_float2(s2 * b1.x - s1 * b2.x, s2 * b1.y - s1 * b2.y);
+    v[0] = cadd(v[0], cadd(a1, a2));
+    v[1] = make_float2(r1.x + i1.y, r1.y - i1.x); v[4] = make_float2(r1.x - i1.y, r1.y + i1.x);      // r -/+ j i
+    v[2] = make_float2(r2.x + i2.y, r2.y - i2.x); v[3] = make_float2(r2.x - i2.y, r2.y + i2.x);
+}
+
+// one forward Stockham pass of radix R down the columns of an LDS tile [n1][TD_CW]; thread (c, w) of (TD_CW, nw); Ns = product of the
+// radices already done.  w1[q] = exp(-j 2 pi q / n1).
+template <int R>
+__device__ __forceinline__ void td_col_pass(const float2* x, float2* y, const float2* w1, int n1, int Ns, int c, int w, int nw)
+{
+    const int m = n1 / R, tws = n1 / (Ns * R);
+    for (int j = w; j < m; j += nw) {
+        const int k = j % Ns;
+        float2 v[R];
+#pragma unroll
+        for (int t = 0; t < R; t++) {
+            v[t] = x[(j + t * m) * TD_CW + c];
+            if (t && k) v[t] = cmul(v[t], w1[k * t * tws]);                  // k t tws < n1
+        }
+        td_dft_small<R>(v);
+        const int j0 = (j - k) * R + k;
+#pragma unroll
+        for (int u = 0; u < R; u++) y[(j0 + u * Ns) * TD_CW + c] = v[u];
+    }
+}
+// any radix r (the prime factors of n1 beyond 2, 3, 5): every thread forms outputs, each as its r-term sum
+__device__ __forceinline__ void td_col_pass_any(const float2* x, float2* y, const float2* w1, int n1, int r, int Ns, int c, int w, int nw)
+{
+    const int m = n1 / r, tws = n1 / (Ns * r);
+    for (int e = w; e < n1; e += nw) {
+        const int j = e % m, u = e / m, k = j % Ns;
+        int step = k * tws + u * m;                                          // exponent per input t: twiddle w_{Ns r}^{k t} and w_r^{u t}
+        if (step >= n1) step -= n1;
+        int q = 0;
+        float2 acc = x[j * TD_CW + c];
+        for (int t = 1; t < r; t++) {
+            q += step; if (q >= n1) q -= n1;
+            acc = cadd(acc, cmul(x[(j + t * m) * TD_CW + c], w1[q]));
+        }
+        y[((j - k) * r + k + u * Ns) * TD_CW + c] = acc;
+    }
+}
+// the whole n1-point forward transform of the tile in buf0; returns the buffer that holds the result
+__device__ __forceinline__ float2* td_col_transform(float2* buf0, float2* buf1, const float2* w1, const td_plan& pl, int c, int w, int nw)
+{
+    float2 *cur = buf0, *nxt = buf1;
+    int Ns = 1;
+    for (int p = 0; p < pl.nrad; p++) {
+        const int r = pl.rad[p];
+        if (r == 4) td_col_pass<4>(cur, nxt, w1, pl.n1, Ns, c, w, nw);
+        else if (r == 2) td_col_pass<2>(cur, nxt, w1, pl.n1, Ns, c, w, nw);
+        else if (r == 3) td_col_pass<3>(cur, nxt, w1, pl.n1, Ns, c, w, nw);
+        else if (r == 5) td_col_pass<5>(cur, nxt, w1, pl.n1, Ns, c, w, nw);
+        else td_col_pass_any(cur, nxt, w1, pl.n1, r, Ns, c, w, nw);
+        __syncthreads();
+        float2* t = cur; cur = nxt; nxt = t;
+        Ns *= r;
+    }
+    return cur;
+}
+
+// ---- column pass, forward:  x = in . doppler_z  as [n1][n2]  ->  n1-point DFT per column  ->  . w_n^{i2 k1}  ->  U[b][z][k1][i2] ------------
+__global__ __launch_bounds__(256) void td_col_fwd_kernel(const float2* __restrict__ in, long in_stride, const float2* __restrict__ dop,
+                                                         float2* __restrict__ U, const float2* __restrict__ w1_g,
+                                                         const float2* __restrict__ two, td_plan pl, int n)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 td_lds[];
+    const int n1 = pl.n1, n2 = pl.n2;
+    float2* buf0 = td_lds;
+    float2* buf1 = buf0 + (size_t)n1 * TD_CW;
+    float2* w1 = buf1 + (size_t)n1 * TD_CW;
+    const int c = threadIdx.x & (TD_CW - 1), w = threadIdx.x / TD_CW, nw = 256 / TD_CW;
+    const int col = blockIdx.x * TD_CW + c;
+    const size_t b = blockIdx.y, z = blockIdx.z;
+    const float2* src = in + b * (size_t)in_stride;
+    const float2* dz = dop + z * (size_t)n;
+    for (int i = threadIdx.x; i < n1; i += 256) w1[i] = w1_g[i];
+    for (int i1 = w; i1 < n1; i1 += nw) {
+        const size_t i = (size_t)i1 * n2 + col;
+        buf0[i1 * TD_CW + c] = cmul(src[i], dz[i]);                          // volk_32fc_x2_multiply_32fc (:345)
+    }
+    __syncthreads();
+    const float2* cur = td_col_transform(buf0, buf1, w1, pl, c, w, nw);
+    float2* dst = U + (b * gridDim.z + z) * (size_t)n;
+    for (int k1 = w; k1 < n1; k1 += nw) {
+        const size_t o = (size_t)k1 * n2 + col;
+        dst[o] = cmul(cur[k1 * TD_CW + c], two[o]);
+    }
+}
+
+// ---- column pass, inverse:  G[bl][k1][i2] . conj w_n^{i2 k1}  ->  inverse n1-point DFT per column (conj, forward, conj)  ->  out_l[i1 n2 + i2]
+//      (= or +=), plus the self-coupling term sc . in (:372-378) when asked ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void td_col_inv_kernel(const float2* __restrict__ G, float2* __restrict__ out, long out_burst_stride,
+                                                         long out_rx_stride, const float2* __restrict__ in, long in_stride,
+                                                         float self_coupling, int add_self, int accumulate,
+                                                         const float2* __restrict__ w1_g, const float2* __restrict__ two, td_plan pl, int R, int n)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 td_lds[];
+    const int n1 = pl.n1, n2 = pl.n2;
+    float2* buf0 = td_lds;
+    float2* buf1 = buf0 + (size_t)n1 * TD_CW;
+    float2* w1 = buf1 + (size_t)n1 * TD_CW;
+    const int c = threadIdx.x & (TD_CW - 1), w = threadIdx.x / TD_CW, nw = 256 / TD_CW;
+    const int col = blockIdx.x * TD_CW + c;
+    const size_t bl = blockIdx.y, b = bl / R, l = bl % R;
+    const float2* src = G + bl * (size_t)n;
+    for (int i = threadIdx.x; i < n1; i += 256) w1[i] = w1_g[i];
+    for (int k1 = w; k1 < n1; k1 += nw) {
+        const size_t o = (size_t)k1 * n2 + col;
+        const float2 v = cmul(src[o], conjf2(two[o]));
+        buf0[k1 * TD_CW + c] = conjf2(v);
+    }
+    __syncthreads();
+    const float2* cur = td_col_transform(buf0, buf1, w1, pl, c, w, nw);
+    float2* o = out + b * (size_t)out_burst_stride + l * (size_t)out_rx_stride;
+    const float2* inb = in + b * (size_t)in_stride;
+    for (int i1 = w; i1 < n1; i1 += nw) {
+        const size_t m = (size_t)i1 * n2 + col;
+        float2 v = conjf2(cur[i1 * TD_CW + c]);
+        if (accumulate) v = cadd(o[m], v);
+        if (add_self) {                                                      // out += (gr_complex)pow(10, db/20) * in  (:376)
+            const float2 xi = inb[m];
+            v = cadd(v, make_float2(self_coupling * xi.x - 0.0f * xi.y, self_coupling * xi.y + 0.0f * xi.x));
+        }
+        o[m] = v;
+    }
+}
+
+// ---- row pass, n2 == 256: 16 rows per workgroup, everything in registers.  RC antennas of the launch out of one forward transform per target;
+//      tsp = timeshift as [R][K][n1][n2] (+ (l0 K + k0) n), the sum over the Kz targets of the launch is taken on the spectrum ----------------
+template <int RC>
+__global__ __launch_bounds__(256) void td_rows256_kernel(const float2* __restrict__ U, float2* __restrict__ G, const float2* __restrict__ tsp,
+                                                         long ts_l_stride, const float2* __restrict__ phase, const float2* __restrict__ tw256_g,
+                                                         int Kz, int R, int l0, int n1, long rows)
+{
+    __shared__ float2 xch[16 * TS_XPAD];
+    __shared__ float2 tw256[256];
+    const int s = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    long row = (long)blockIdx.x * 16 + rl;                                    // over bursts x n1
+    const bool live = row < rows;
+    if (!live) row = rows - 1;
+    const size_t b = (size_t)(row / n1), k1 = (size_t)(row % n1);
+    const size_t n = (size_t)n1 * 256;
+    tw256[threadIdx.x] = tw256_g[threadIdx.x];
+    __syncthreads();
+    float2 acc[RC][16];
+    for (int z = 0; z < Kz; z++) {
+        const float2* g = U + ((b * Kz + z) * n1 + k1) * 256;
+        float2 x[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) x[j] = g[s + 16 * j];
+        fft256_rows(x, xch, tw256);
+        if (phase) {
+            const float2 ph = phase[z];                                       // :358-362, on the spectrum (the inverse transform is linear)
+#pragma unroll
+            for (int r = 0; r < 16; r++) x[r] = cmul(x[r], ph);
+        }
+#pragma unroll
+        for (int l = 0; l < RC; l++) {
+            const float2* tr = tsp + (size_t)l * ts_l_stride + (size_t)z * n + k1 * 256;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float2 p = cmul(x[r], tr[s + 16 * r]);                  // :352
+                acc[l][r] = z ? cadd(acc[l][r], p) : p;
+            }
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < RC; l++) {
+        swap_reim(acc[l]); fft256_rows(acc[l], xch, tw256); swap_reim(acc[l]);
+        float2* d = G + ((b * R + l0 + l) * n1 + k1) * 256;
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) d[s + 16 * r] = acc[l][r];
+        }
+    }
+}
+
+// ---- row pass, n2 = m x 256 (m = 2, 4, 8, 16): the row transform of tsim_rowconv_m_kernel (m-point step in registers, 256-point step through
+//      LDS, spectrum in [k_a][k_b] order — the timeshift table is stored in that order), RC antennas out of one forward transform per target ----
+template <int M_, int RC>
+__global__ __launch_bounds__(256) void td_rows_m_kernel(const float2* __restrict__ U, float2* __restrict__ G, const float2* __restrict__ tsp,
+                                                        long ts_l_stride, const float2* __restrict__ phase, const float2* __restrict__ tw256_g,
+                                                        const float2* __restrict__ twn2_g, int Kz, int R, int l0, int n1, long rows)
+{
+    constexpr int TPR = 16 * M_;
+    constexpr int UU = 16 / M_;
+    constexpr int N2 = 256 * M_;
+    __shared__ float2 xch[16 * TS_XPAD];
+    __shared__ float2 tw256[256];
+    const int rowl = threadIdx.x / TPR, t = threadIdx.x % TPR;
+    const int s = threadIdx.x & 15, plane = threadIdx.x >> 4;                 // plane = rowl * M_ + k_a
+    long row = (long)blockIdx.x * (256 / TPR) + rowl;
+    const bool live = row < rows;
+    if (!live) row = rows - 1;
+    const size_t b = (size_t)(row / n1), k1 = (size_t)(row % n1);
+    const size_t n = (size_t)n1 * N2;
+    const int ka = plane % M_;
+    tw256[threadIdx.x] = tw256_g[threadIdx.x];
+    float2 acc[RC][16];
+    for (int z = 0; z < Kz; z++) {
+        const float2* g = U + ((b * Kz + z) * n1 + k1) * N2;
+        float2 y[16];                                                         // [u][i_a]
+#pragma unroll
+        for (int u = 0; u < UU; u++)
+#pragma unroll
+            for (int a = 0; a < M_; a++) y[u * M_ + a] = g[a * 256 + t + TPR * u];
+#pragma unroll
+        for (int u = 0; u < UU; u++) {
+            fft_fwd_small<M_>(*reinterpret_cast<float2(*)[M_]>(&y[u * M_]));
+            const int ib = t + TPR * u;
+#pragma unroll
+            for (int a = 1; a < M_; a++) y[u * M_ + a] = cmul(y[u * M_ + a], twn2_g[ib * a]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < UU; u++)
+#pragma unroll
+            for (int a = 0; a < M_; a++) xch[(rowl * M_ + a) * TS_XPAD + t + TPR * u] = y[u * M_ + a];
+        __syncthreads();
+        float2 x[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) x[j] = xch[plane * TS_XPAD + s + 16 * j];
+        fft256_rows(x, xch, tw256);                                           // x[r] = spectrum element k_b = s + 16 r of plane k_a
+        if (phase) {
+            const float2 ph = phase[z];
+#pragma unroll
+            for (int r = 0; r < 16; r++) x[r] = cmul(x[r], ph);
+        }
+#pragma unroll
+        for (int l = 0; l < RC; l++) {
+            const float2* tr = tsp + (size_t)l * ts_l_stride + (size_t)z * n + k1 * N2 + ka * 256;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float2 p = cmul(x[r], tr[s + 16 * r]);
+                acc[l][r] = z ? cadd(acc[l][r], p) : p;
+            }
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < RC; l++) {
+        swap_reim(acc[l]); fft256_rows(acc[l], xch, tw256); swap_reim(acc[l]);   // acc[l][r] = element i_b = s + 16 r of plane k_a
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; r++) xch[plane * TS_XPAD + s + 16 * r] = acc[l][r];
+        __syncthreads();
+        float2* d = G + ((b * R + l0 + l) * n1 + k1) * N2;
+#pragma unroll
+        for (int u = 0; u < UU; u++) {
+            const int ib = t + TPR * u;
+            float2 y[M_];
+#pragma unroll
+            for (int a = 0; a < M_; a++) {
+                float2 v = xch[(rowl * M_ + a) * TS_XPAD + ib];
+                if (a) v = cmul(v, conjf2(twn2_g[ib * a]));
+                y[a] = make_float2(v.y, v.x);                                 // swapped: inverse m-point FFT via the forward one
+            }
+            fft_fwd_small<M_>(y);
+            if (live) {
+#pragma unroll
+                for (int a = 0; a < M_; a++) d[a * 256 + ib] = make_float2(y[a].y, y[a].x);
+            }
+        }
+    }
+}
+
+// ---- row pass, any power of two 16 <= n2 <= 128 (the 64-carrier flowgraphs: n2 = 16 x 2^v2(n_symbols)): Stockham passes in LDS, tp threads per
+//      row, one antenna per blockIdx.y; the spectrum sum over the targets is kept in a third LDS row -----------------------------------------
+__global__ __launch_bounds__(256) void td_rows_small_kernel(const float2* __restrict__ U, float2* __restrict__ G, const float2* __restrict__ tsp,
+                                                            long ts_l_stride, const float2* __restrict__ phase, const float2* __restrict__ tw_f,
+                                                            const float2* __restrict__ tw_i, int Kz, int R, int n1, int n2, int logn2, long rows, int tp)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 td_lds[];
+    const int per_block = blockDim.x / tp;
+    const int lt = threadIdx.x % tp, lb = threadIdx.x / tp;
+    long row = (long)blockIdx.x * per_block + lb;
+    const bool live = row < rows;
+    if (!live) row = rows - 1;
+    const size_t b = (size_t)(row / n1), k1 = (size_t)(row % n1);
+    const size_t n = (size_t)n1 * n2;
+    const int l = blockIdx.y;
+    float2* buf0 = td_lds + (size_t)lb * 3 * n2;
+    float2* buf1 = buf0 + n2;
+    float2* accb = buf1 + n2;
+    for (int z = 0; z < Kz; z++) {
+        const float2* g = U + ((b * Kz + z) * n1 + k1) * n2;
+        const float2* cur = nullptr;
+        float2* nxt = buf0;
+        int Ns = 1;
+        bool first = true;
+        while (Ns < n2) {
+            const int Rx = ((logn2 & 1) && first) ? 2 : 4;
+            if (Rx == 2) stockham_pass<2>(first ? g : nullptr, 0, nullptr, cur, nxt, nullptr, 0, tw_f, n2, Ns, -1, lt, tp);
+            else stockham_pass<4>(first ? g : nullptr, 0, nullptr, cur, nxt, nullptr, 0, tw_f, n2, Ns, -1, lt, tp);
+            __syncthreads();
+            cur = nxt; nxt = (nxt == buf0) ? buf1 : buf0;
+            Ns *= Rx; first = false;
+        }
+        const float2* tr = tsp + (size_t)l * ts_l_stride + (size_t)z * n + k1 * n2;
+        for (int k2 = lt; k2 < n2; k2 += tp) {
+            float2 v = cur[k2];
+            if (phase) v = cmul(v, phase[z]);
+            v = cmul(v, tr[k2]);
+            accb[k2] = z ? cadd(accb[k2], v) : v;
+        }
+        __syncthreads();
+    }
+    {
+        const float2* cur = accb;
+        float2* nxt = buf0;
+        float2* d = G + ((b * R + l) * n1 + k1) * n2;
+        int Ns = 1;
+        bool first = true;
+        while (Ns < n2) {
+            const int Rx = ((logn2 & 1) && first) ? 2 : 4;
+            const bool last = Ns * Rx == n2;
+            float2* dg = (last && live) ? d : nullptr;
+            float2* dl = last ? (live ? nullptr : nxt) : nxt;
+            if (Rx == 2) stockham_pass<2>(nullptr, 0, nullptr, cur, dl, dg, 0, tw_i, n2, Ns, +1, lt, tp);
+            else stockham_pass<4>(nullptr, 0, nullptr, cur, dl, dg, 0, tw_i, n2, Ns, +1, lt, tp);
+            __syncthreads();
+            cur = nxt; nxt = (nxt == buf0) ? buf1 : buf0;
+            Ns *= Rx; first = false;
+        }
+    }
+}
+
 // ---- host side -------------------------------------------------------------------------------
 static const double TS_FOUR_PI_CUBED_SQRT = 44.54662397465366;   // :33
 static const float TS_C_LIGHT = 3e8f;                           // target_simulator_impl.h c_light
@@ -548,9 +922,36 @@ static int tsim_rows_launch(jrc_tsim* h, bool fwd_only, float2* X, int conj_b, s
 static void tsim_free_tables(jrc_tsim* h)
 {
     (void)hipFree(h->d_dop); (void)hipFree(h->d_ts); (void)hipFree(h->d_chirp); (void)hipFree(h->d_bhat);
-    h->d_dop = h->d_ts = h->d_chirp = h->d_bhat = nullptr;
-    h->n = 0;
+    (void)hipFree(h->d_w1); (void)hipFree(h->d_two);
+    h->d_dop = h->d_ts = h->d_chirp = h->d_bhat = h->d_w1 = h->d_two = nullptr;
+    h->n = 0; h->direct = false;
 }
+
+// n = n1 x n2 with n2 the largest power of two dividing n (<= 4096) and n1 <= TD_MAX_N1; the radices of the n1-point column transform
+static bool tsim_plan_direct(int n, td_plan* pl)
+{
+    if (const char* e = getenv("JRC_TSIM_BLUESTEIN")) { if (atoi(e) != 0) return false; }
+    int n2 = 1;
+    while (n2 < 4096 && n % (n2 * 2) == 0) n2 *= 2;
+    if (n2 < TD_CW) return false;
+    const int n1 = n / n2;
+    if (n1 > TD_MAX_N1) return false;
+    pl->n1 = n1; pl->n2 = n2; pl->nrad = 0;
+    int m = n1;
+    while (m % 4 == 0) { pl->rad[pl->nrad++] = 4; m /= 4; }
+    if (m % 2 == 0) { pl->rad[pl->nrad++] = 2; m /= 2; }
+    for (int p = 3; m > 1; p += 2)
+        while (m % p == 0) { pl->rad[pl->nrad++] = p; m /= p; }
+    return true;
+}
+static td_plan tsim_plan_of(const jrc_tsim* h)
+{
+    td_plan pl;
+    pl.n1 = h->n1; pl.n2 = h->n2; pl.nrad = h->nrad;
+    for (int i = 0; i < 24; i++) pl.rad[i] = h->rad[i];
+    return pl;
+}
+static size_t td_col_lds_bytes(int n1) { return sizeof(float2) * ((size_t)2 * n1 * TD_CW + (size_t)n1); }
 
 // channel filters and chirp tables for bursts of n samples (:249-300 + the Bluestein tables)
 static int tsim_prepare(jrc_tsim* h, int n, hipStream_t stream)
@@ -562,9 +963,12 @@ static int tsim_prepare(jrc_tsim* h, int n, hipStream_t stream)
     JRC_HIP(ctx, hipStreamSynchronize(stream));
     tsim_free_tables(h);
     const int K = h->K, R = h->R;
+    td_plan pl;
+    const bool direct = tsim_plan_direct(n, &pl);
     long M = 32768;
     while (M < 2L * n - 1) M <<= 1;
-    const int n2 = (int)(M / TS_N1);
+    if (direct) M = n;                                 // the work buffers hold bursts of n samples, nothing is padded
+    const int n2 = direct ? pl.n2 : (int)(M / TS_N1);
     // work buffers
     const size_t per = sizeof(float2) * (size_t)h->max_bursts * M;
     const size_t need_u = per * (size_t)(h->sum_targets && K > 1 ? K : 1), need_g = per * (size_t)(R > 0 ? R : 1);
@@ -590,6 +994,43 @@ static int tsim_prepare(jrc_tsim* h, int n, hipStream_t stream)
                 t[i] = std::exp(-phase_time) / (float)n;
             }
         }
+    }
+    if (direct) {
+        // timeshift in the order the row pass leaves the spectrum in: row k1, then position p <-> k2 (natural for n2 <= 256, [k_a][k_b] with
+        // k2 = k_a + m k_b for n2 = m x 256), k = k1 + n1 k2;  w_n1 and the outer twiddles w_n^{i2 k1} in double
+        const int n1 = pl.n1, m = n2 > 256 ? n2 / 256 : 1;
+        std::vector<std::complex<float>> tsp(ts.size());
+        for (size_t lk = 0; lk < (size_t)R * K; lk++)
+            for (int k1 = 0; k1 < n1; k1++)
+                for (int p = 0; p < n2; p++) {
+                    const int k2 = m > 1 ? (p / 256) + m * (p % 256) : p;
+                    tsp[lk * n + (size_t)k1 * n2 + p] = ts[lk * n + (size_t)k1 + (size_t)n1 * k2];
+                }
+        std::vector<float2> w1((size_t)n1), two((size_t)n);
+        for (int q = 0; q < n1; q++) {
+            const double a = -2.0 * M_PI * (double)q / (double)n1;
+            w1[q] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+        for (int k1 = 0; k1 < n1; k1++)
+            for (int i2 = 0; i2 < n2; i2++) {
+                const double a = -2.0 * M_PI * (double)(((long)i2 * k1) % n) / (double)n;
+                two[(size_t)k1 * n2 + i2] = make_float2((float)std::cos(a), (float)std::sin(a));
+            }
+        if (K > 0) {
+            JRC_HIP(ctx, hipMalloc((void**)&h->d_dop, sizeof(float2) * (size_t)K * n));
+            JRC_HIP(ctx, hipMalloc((void**)&h->d_ts, sizeof(float2) * (size_t)R * K * n));
+            JRC_HIP(ctx, hipMemcpy(h->d_dop, dop.data(), sizeof(float2) * (size_t)K * n, hipMemcpyHostToDevice));
+            JRC_HIP(ctx, hipMemcpy(h->d_ts, tsp.data(), sizeof(float2) * (size_t)R * K * n, hipMemcpyHostToDevice));
+        }
+        JRC_HIP(ctx, hipMalloc((void**)&h->d_w1, sizeof(float2) * (size_t)n1));
+        JRC_HIP(ctx, hipMalloc((void**)&h->d_two, sizeof(float2) * (size_t)n));
+        JRC_HIP(ctx, hipMemcpy(h->d_w1, w1.data(), sizeof(float2) * (size_t)n1, hipMemcpyHostToDevice));
+        JRC_HIP(ctx, hipMemcpy(h->d_two, two.data(), sizeof(float2) * (size_t)n, hipMemcpyHostToDevice));
+        JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)td_col_fwd_kernel, td_col_lds_bytes(n1)));
+        JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)td_col_inv_kernel, td_col_lds_bytes(n1)));
+        h->n = n; h->M = n; h->n2 = n2; h->n1 = n1; h->nrad = pl.nrad; h->direct = true;
+        for (int i = 0; i < 24; i++) h->rad[i] = i < pl.nrad ? pl.rad[i] : 0;
+        return JRC_OK;
     }
     // chirp c[i] = exp(-j pi i^2 / n) with i^2 reduced mod 2n in integers; b = conj(c) wrapped to length M, / M
     std::vector<float2> chirp((size_t)n), bpad((size_t)M, make_float2(0.f, 0.f));
@@ -699,6 +1140,55 @@ extern "C" int jrc_tsim_run_dev(jrc_tsim* h, int n_bursts, int n_input, const jr
     // as written in the reference every target overwrites the output buffer (:354-366), so only the last one is
     // observable; sum_targets accumulates them instead (in the middle kernel, between the two convolutions)
     const int k0 = h->sum_targets ? 0 : K - 1, Kz = K - k0;
+    if (h->direct) {
+        const td_plan pl = tsim_plan_of(h);
+        const int n1 = h->n1;
+        const size_t lds = td_col_lds_bytes(n1);
+        const float2* ph = use_phase ? (const float2*)h->d_phase + k0 : (const float2*)nullptr;
+        hipLaunchKernelGGL(td_col_fwd_kernel, dim3(n2 / TD_CW, n_bursts, Kz), dim3(256), lds, s, in, (long)n, (const float2*)h->d_dop + (size_t)k0 * n,
+                           h->d_u, (const float2*)h->d_w1, (const float2*)h->d_two, pl, n);
+        JRC_HIP(ctx, hipGetLastError());
+        const long rows = (long)n_bursts * n1;
+        if (n2 >= 256) {
+            const float2* twn2 = nullptr;
+            if (n2 > 256) JRC_TRY(jrc_get_twiddles(ctx, n2, -1, &twn2));
+            const int m = n2 / 256, rpb = 16 / m;                        // rows per workgroup
+            const dim3 grid((unsigned)((rows + rpb - 1) / rpb));
+            for (int l0 = 0; l0 < R;) {
+                const int rc = (R - l0 >= 4) ? 4 : ((R - l0 >= 2) ? 2 : 1);
+                const float2* tsp = (const float2*)h->d_ts + ((size_t)l0 * K + k0) * n;
+#define TD_ROWS(MM, RC_)                                                                                                                  \
+                hipLaunchKernelGGL((td_rows_m_kernel<MM, RC_>), grid, dim3(256), 0, s, (const float2*)h->d_u, h->d_g, tsp, (long)K * n, ph, tw256, \
+                                   twn2, Kz, R, l0, n1, rows)
+#define TD_ROWS_RC(MM) do { if (rc == 4) TD_ROWS(MM, 4); else if (rc == 2) TD_ROWS(MM, 2); else TD_ROWS(MM, 1); } while (0)
+                if (m == 1) {
+                    if (rc == 4) hipLaunchKernelGGL(td_rows256_kernel<4>, grid, dim3(256), 0, s, (const float2*)h->d_u, h->d_g, tsp, (long)K * n, ph, tw256, Kz, R, l0, n1, rows);
+                    else if (rc == 2) hipLaunchKernelGGL(td_rows256_kernel<2>, grid, dim3(256), 0, s, (const float2*)h->d_u, h->d_g, tsp, (long)K * n, ph, tw256, Kz, R, l0, n1, rows);
+                    else hipLaunchKernelGGL(td_rows256_kernel<1>, grid, dim3(256), 0, s, (const float2*)h->d_u, h->d_g, tsp, (long)K * n, ph, tw256, Kz, R, l0, n1, rows);
+                } else if (m == 2) TD_ROWS_RC(2);
+                else if (m == 4) TD_ROWS_RC(4);
+                else if (m == 8) TD_ROWS_RC(8);
+                else TD_ROWS_RC(16);
+#undef TD_ROWS_RC
+#undef TD_ROWS
+                JRC_HIP(ctx, hipGetLastError());
+                l0 += rc;
+            }
+        } else {
+            const float2 *twf = nullptr, *twi = nullptr;
+            JRC_TRY(jrc_get_twiddles(ctx, n2, -1, &twf));
+            JRC_TRY(jrc_get_twiddles(ctx, n2, +1, &twi));
+            const int tp = n2 / 4, per_block = 256 / tp;
+            const size_t lds_rows = sizeof(float2) * 3 * (size_t)n2 * per_block;
+            hipLaunchKernelGGL(td_rows_small_kernel, dim3((unsigned)((rows + per_block - 1) / per_block), R), dim3(256), lds_rows, s, (const float2*)h->d_u,
+                               h->d_g, (const float2*)h->d_ts + (size_t)k0 * n, (long)K * n, ph, twf, twi, Kz, R, n1, n2, jrc_ilog2(n2), rows, tp);
+            JRC_HIP(ctx, hipGetLastError());
+        }
+        hipLaunchKernelGGL(td_col_inv_kernel, dim3(n2 / TD_CW, n_bursts * R), dim3(256), lds, s, (const float2*)h->d_g, out, (long)R * n, (long)n, in, (long)n,
+                           sc, h->self_coupling ? 1 : 0, accumulate_out ? 1 : 0, (const float2*)h->d_w1, (const float2*)h->d_two, pl, R, n);
+        JRC_HIP(ctx, hipGetLastError());
+        return JRC_OK;
+    }
     const dim3 grid_first(n2 / TS_CW, n_bursts, Kz), grid_mid(n2 / TS_CW, n_bursts), grid_out(n2 / TS_CW, n_bursts * R);
     hipLaunchKernelGGL(tsim_col_first_kernel<false>, grid_first, dim3(256), 0, s, in, (long)n, (const float2*)h->d_dop + (size_t)k0 * n,
                        (const float2*)h->d_chirp, h->d_u, tw256, n, n2, M);

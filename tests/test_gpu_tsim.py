@@ -1,6 +1,7 @@
 """GPU tier: target_simulator on the device through the C ABI against the oracle restatement of
 lib/target_simulator_impl.cc:132-385 on the same bursts.  Tolerance: the north star's 1e-4 on ||a-b||_inf/||b||_inf
-(the device evaluates the two length-n DFTs as float32 chirp-z transforms, the oracle in double)."""
+(the device evaluates the two length-n DFTs in float32 — as a direct four-step split n = n1 x 2^a where the length allows it, as chirp-z
+transforms otherwise — the oracle in double)."""
 import numpy as np
 import pytest
 
@@ -36,6 +37,56 @@ def test_long_bursts(jrc, ctx, n):
     got = jrc.target_simulator(*args, ctx=ctx).work(x)
     want = oracle.TargetSimulator(*args).work(x)
     assert rel_err(got, want) < TOL
+
+
+# burst lengths of the direct four-step route (tsim.hip td_*): n = n1 x n2, n2 the power of two in n (16 .. 4096), n1 = the rest (<= 512)
+DIRECT = [
+    (256, 1, 256), (4096, 1, 4096), (16, 1, 16),                      # n1 = 1: the row pass alone
+    (80, 5, 16), (2400, 75, 32), (3 * 64 * 7, 21, 64), (1920, 15, 128),   # 64-carrier flowgraph bursts: rows through the LDS Stockham kernel
+    (11520, 45, 256), (23040, 45, 512), (9216, 9, 1024),              # config B's burst (72 symbols x 320): 45 x 512
+    (174080, 85, 2048), (28672, 7, 4096), (1 << 20, 256, 4096),       # config D's burst (136 x 1280): 85 = 5 x 17 (a 17-term pass); 2^20 = 256 x 4096
+    (22080, 345, 64), (64 * 509, 509, 64), (32 * 512, 4, 4096), (512 * 121, 121, 512), (6 * 256 * 13, 39, 512),   # 23 / 509 / 11 / 13 as radices
+]
+
+
+@pytest.mark.parametrize("n,n1,n2", DIRECT)
+def test_direct_four_step_lengths(jrc, ctx, monkeypatch, n, n1, n2):
+    """every split the direct route takes — all three row kernels, every row length, column lengths that are 1, smooth, prime or carry a large
+    prime — against the oracle (1e-4), and against the chirp-z route on the same burst (JRC_TSIM_BLUESTEIN=1): two independent evaluations of
+    the same two DFTs"""
+    assert n == n1 * n2
+    args = ([35.0], [-12.0], [40.0], [-25.0], POS4 if n <= 30000 else POS4[:2], FS, FC)
+    x = burst(n, n)
+    got = jrc.target_simulator(*args, ctx=ctx).work(x)
+    want = oracle.TargetSimulator(*args).work(x)
+    assert got.shape == want.shape
+    assert rel_err(got, want) < 2e-6, rel_err(got, want)               # measured <= 8e-7: the direct split rounds less than the chirp-z route
+    monkeypatch.setenv("JRC_TSIM_BLUESTEIN", "1")
+    old = jrc.target_simulator(*args, ctx=ctx).work(x)
+    monkeypatch.delenv("JRC_TSIM_BLUESTEIN")
+    assert rel_err(old, want) < TOL and rel_err(got, old) < TOL
+
+
+@pytest.mark.parametrize("n", [23040, 2400, 11520, 174080])
+@pytest.mark.parametrize("R", [1, 2, 3, 4])
+def test_direct_route_targets_phases_coupling_accumulate(jrc, ctx, n, R):
+    """the direct route through every option of the block: three targets summed or last-only, random phases, self coupling, bursts batched on the
+    device and accumulated into RX buffers that already hold another simulator's output — for 1..4 RX antennas (antenna groups of 4 / 2 / 1)"""
+    import torch
+    pos = POS4[:R]
+    x = np.stack([burst(n, 3 * n + b) for b in range(2)])
+    for sum_targets in (False, True):
+        g = jrc.target_simulator(*TGT3, pos, FS, FC, self_coupling_db=-20.0, rndm_phaseshift=True, self_coupling=True, sum_targets=sum_targets,
+                                 seed=4, max_bursts=2, ctx=ctx)
+        ph = g.draw_phases()
+        o = oracle.TargetSimulator(*TGT3, pos, FS, FC, self_coupling_db=-20.0, rndm_phaseshift=True, self_coupling=True)
+        want = np.stack([o.work(x[b], target_phase=ph, sum_targets=sum_targets) for b in range(2)])
+        assert rel_err(g.work(x[0], target_phase=ph), want[0]) < 2e-6
+        base = (np.arange(2 * R * n, dtype=np.float32).reshape(2, R, n) % 7).astype(np.complex64)
+        d_out = torch.from_numpy(base.copy()).cuda()
+        g.run_dev(torch.from_numpy(x).cuda(), d_out, 2, n, accumulate_out=True, target_phase=ph)
+        ctx.sync()
+        assert rel_err(d_out.cpu().numpy() - base, want) < 2e-5         # (the sum with the buffer's 0..6 rounds at 6 x 2^-24)
 
 
 def test_burst_too_long_is_refused(jrc, ctx):

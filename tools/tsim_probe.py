@@ -42,12 +42,23 @@ def main():
         sim.run_dev(d_in, d_out, B, n)
     ctx.sync()
     dt = (time.perf_counter() - t0) / a.iters
-    M = 32768
-    while M < 2 * n - 1:
-        M *= 2
-    traffic = B * K * (M * 8 * (3 + 4 * 4) + n * 8 * (2 + 4 + 4 * 2))
-    print("config %s: n=%d M=%d K=%d R=4 bursts=%d: %.3f ms/launch-set, %.0f bursts/s, %.1f M samples/s in, ~%.0f GB/s work-buffer traffic"
-          % (a.config, n, M, K, B, dt * 1e3, B / dt, B * n / dt / 1e6, traffic / dt / 1e9))
+    n2 = 1
+    while n2 < 4096 and n % (n2 * 2) == 0:
+        n2 *= 2
+    direct = n2 >= 16 and n // n2 <= 512 and os.environ.get("JRC_TSIM_BLUESTEIN", "0") in ("", "0")
+    alg = B * n * 8 * (1 + 4)                                   # a burst in, R = 4 bursts out
+    if direct:                                                  # tsim.hip td_*: (Kz + Kz + Kz... ) see DESIGN.md §3.3
+        Kz = K
+        traffic = B * n * 8 * (Kz + Kz + Kz + 4 + 4 + 4)        # col fwd: in -> U; rows: U -> G; col inv: G -> out
+        route = "direct four-step %d x %d" % (n // n2, n2)
+    else:
+        M = 32768
+        while M < 2 * n - 1:
+            M *= 2
+        traffic = B * K * (M * 8 * (3 + 4 * 4) + n * 8 * (2 + 4 + 4 * 2))
+        route = "chirp-z M=%d" % M
+    print("config %s: n=%d %s K=%d R=4 bursts=%d: %.3f ms/launch-set, %.0f bursts/s, %.1f M samples/s in, algorithmic %.0f GB/s, ~%.0f GB/s work-buffer traffic (%.1fx algorithmic)"
+          % (a.config, n, route, K, B, dt * 1e3, B / dt, B * n / dt / 1e6, alg / dt / 1e9, traffic / dt / 1e9, traffic / alg))
 
 
 if __name__ == "__main__":
