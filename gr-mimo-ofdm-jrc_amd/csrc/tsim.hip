@@ -533,9 +533,9 @@ template <> __device__ __forceinline__ void td_dft_small<5>(float2 (&v)[5])
     v[2] = make_float2(r2.x + i2.y, r2.y - i2.x); v[3] = make_float2(r2.x - i2.y, r2.y + i2.x);
 }
 
-// one forward Stockham pass of radix R down the columns of an LDS tile [n1][TD_CW]; thread (c, w) of (TD_CW, nw); Ns = product of the
+// one forward Stockham pass of radix R down the columns of an LDS tile [n1][CW]; thread (c, w) of (CW, nw); Ns = product of the
 // radices already done.  w1[q] = exp(-j 2 pi q / n1).
-template <int R>
+template <int R, int CW>
 __device__ __forceinline__ void td_col_pass(const float2* x, float2* y, const float2* w1, int n1, int Ns, int c, int w, int nw)
 {
     const int m = n1 / R, tws = n1 / (Ns * R);
@@ -544,16 +544,17 @@ __device__ __forceinline__ void td_col_pass(const float2* x, float2* y, const fl
         float2 v[R];
 #pragma unroll
         for (int t = 0; t < R; t++) {
-            v[t] = x[(j + t * m) * TD_CW + c];
+            v[t] = x[(j + t * m) * CW + c];
             if (t && k) v[t] = cmul(v[t], w1[k * t * tws]);                  // k t tws < n1
         }
         td_dft_small<R>(v);
         const int j0 = (j - k) * R + k;
 #pragma unroll
-        for (int u = 0; u < R; u++) y[(j0 + u * Ns) * TD_CW + c] = v[u];
+        for (int u = 0; u < R; u++) y[(j0 + u * Ns) * CW + c] = v[u];
     }
 }
 // any radix r (the prime factors of n1 beyond 2, 3, 5): every thread forms outputs, each as its r-term sum
+template <int CW>
 __device__ __forceinline__ void td_col_pass_any(const float2* x, float2* y, const float2* w1, int n1, int r, int Ns, int c, int w, int nw)
 {
     const int m = n1 / r, tws = n1 / (Ns * r);
@@ -562,26 +563,27 @@ __device__ __forceinline__ void td_col_pass_any(const float2* x, float2* y, cons
         int step = k * tws + u * m;                                          // exponent per input t: twiddle w_{Ns r}^{k t} and w_r^{u t}
         if (step >= n1) step -= n1;
         int q = 0;
-        float2 acc = x[j * TD_CW + c];
+        float2 acc = x[j * CW + c];
         for (int t = 1; t < r; t++) {
             q += step; if (q >= n1) q -= n1;
-            acc = cadd(acc, cmul(x[(j + t * m) * TD_CW + c], w1[q]));
+            acc = cadd(acc, cmul(x[(j + t * m) * CW + c], w1[q]));
         }
-        y[((j - k) * r + k + u * Ns) * TD_CW + c] = acc;
+        y[((j - k) * r + k + u * Ns) * CW + c] = acc;
     }
 }
 // the whole n1-point forward transform of the tile in buf0; returns the buffer that holds the result
+template <int CW>
 __device__ __forceinline__ float2* td_col_transform(float2* buf0, float2* buf1, const float2* w1, const td_plan& pl, int c, int w, int nw)
 {
     float2 *cur = buf0, *nxt = buf1;
     int Ns = 1;
     for (int p = 0; p < pl.nrad; p++) {
         const int r = pl.rad[p];
-        if (r == 4) td_col_pass<4>(cur, nxt, w1, pl.n1, Ns, c, w, nw);
-        else if (r == 2) td_col_pass<2>(cur, nxt, w1, pl.n1, Ns, c, w, nw);
-        else if (r == 3) td_col_pass<3>(cur, nxt, w1, pl.n1, Ns, c, w, nw);
-        else if (r == 5) td_col_pass<5>(cur, nxt, w1, pl.n1, Ns, c, w, nw);
-        else td_col_pass_any(cur, nxt, w1, pl.n1, r, Ns, c, w, nw);
+        if (r == 4) td_col_pass<4, CW>(cur, nxt, w1, pl.n1, Ns, c, w, nw);
+        else if (r == 2) td_col_pass<2, CW>(cur, nxt, w1, pl.n1, Ns, c, w, nw);
+        else if (r == 3) td_col_pass<3, CW>(cur, nxt, w1, pl.n1, Ns, c, w, nw);
+        else if (r == 5) td_col_pass<5, CW>(cur, nxt, w1, pl.n1, Ns, c, w, nw);
+        else td_col_pass_any<CW>(cur, nxt, w1, pl.n1, r, Ns, c, w, nw);
         __syncthreads();
         float2* t = cur; cur = nxt; nxt = t;
         Ns *= r;
@@ -590,6 +592,7 @@ __device__ __forceinline__ float2* td_col_transform(float2* buf0, float2* buf1, 
 }
 
 // ---- column pass, forward:  x = in . doppler_z  as [n1][n2]  ->  n1-point DFT per column  ->  . w_n^{i2 k1}  ->  U[b][z][k1][i2] ------------
+template <int CW>
 __global__ __launch_bounds__(256) void td_col_fwd_kernel(const float2* __restrict__ in, long in_stride, const float2* __restrict__ dop,
                                                          float2* __restrict__ U, const float2* __restrict__ w1_g,
                                                          const float2* __restrict__ two, td_plan pl, int n)
@@ -597,29 +600,30 @@ __global__ __launch_bounds__(256) void td_col_fwd_kernel(const float2* __restric
     extern __shared__ __attribute__((aligned(16))) float2 td_lds[];
     const int n1 = pl.n1, n2 = pl.n2;
     float2* buf0 = td_lds;
-    float2* buf1 = buf0 + (size_t)n1 * TD_CW;
-    float2* w1 = buf1 + (size_t)n1 * TD_CW;
-    const int c = threadIdx.x & (TD_CW - 1), w = threadIdx.x / TD_CW, nw = 256 / TD_CW;
-    const int col = blockIdx.x * TD_CW + c;
+    float2* buf1 = buf0 + (size_t)n1 * CW;
+    float2* w1 = buf1 + (size_t)n1 * CW;
+    const int c = threadIdx.x & (CW - 1), w = threadIdx.x / CW, nw = 256 / CW;
+    const int col = blockIdx.x * CW + c;
     const size_t b = blockIdx.y, z = blockIdx.z;
     const float2* src = in + b * (size_t)in_stride;
     const float2* dz = dop + z * (size_t)n;
     for (int i = threadIdx.x; i < n1; i += 256) w1[i] = w1_g[i];
     for (int i1 = w; i1 < n1; i1 += nw) {
         const size_t i = (size_t)i1 * n2 + col;
-        buf0[i1 * TD_CW + c] = cmul(src[i], dz[i]);                          // volk_32fc_x2_multiply_32fc (:345)
+        buf0[i1 * CW + c] = cmul(src[i], dz[i]);                          // volk_32fc_x2_multiply_32fc (:345)
     }
     __syncthreads();
-    const float2* cur = td_col_transform(buf0, buf1, w1, pl, c, w, nw);
+    const float2* cur = td_col_transform<CW>(buf0, buf1, w1, pl, c, w, nw);
     float2* dst = U + (b * gridDim.z + z) * (size_t)n;
     for (int k1 = w; k1 < n1; k1 += nw) {
         const size_t o = (size_t)k1 * n2 + col;
-        dst[o] = cmul(cur[k1 * TD_CW + c], two[o]);
+        dst[o] = cmul(cur[k1 * CW + c], two[o]);
     }
 }
 
 // ---- column pass, inverse:  G[bl][k1][i2] . conj w_n^{i2 k1}  ->  inverse n1-point DFT per column (conj, forward, conj)  ->  out_l[i1 n2 + i2]
 //      (= or +=), plus the self-coupling term sc . in (:372-378) when asked ---------------------------------------------------------------------
+template <int CW>
 __global__ __launch_bounds__(256) void td_col_inv_kernel(const float2* __restrict__ G, float2* __restrict__ out, long out_burst_stride,
                                                          long out_rx_stride, const float2* __restrict__ in, long in_stride,
                                                          float self_coupling, int add_self, int accumulate,
@@ -628,25 +632,25 @@ __global__ __launch_bounds__(256) void td_col_inv_kernel(const float2* __restric
     extern __shared__ __attribute__((aligned(16))) float2 td_lds[];
     const int n1 = pl.n1, n2 = pl.n2;
     float2* buf0 = td_lds;
-    float2* buf1 = buf0 + (size_t)n1 * TD_CW;
-    float2* w1 = buf1 + (size_t)n1 * TD_CW;
-    const int c = threadIdx.x & (TD_CW - 1), w = threadIdx.x / TD_CW, nw = 256 / TD_CW;
-    const int col = blockIdx.x * TD_CW + c;
+    float2* buf1 = buf0 + (size_t)n1 * CW;
+    float2* w1 = buf1 + (size_t)n1 * CW;
+    const int c = threadIdx.x & (CW - 1), w = threadIdx.x / CW, nw = 256 / CW;
+    const int col = blockIdx.x * CW + c;
     const size_t bl = blockIdx.y, b = bl / R, l = bl % R;
     const float2* src = G + bl * (size_t)n;
     for (int i = threadIdx.x; i < n1; i += 256) w1[i] = w1_g[i];
     for (int k1 = w; k1 < n1; k1 += nw) {
         const size_t o = (size_t)k1 * n2 + col;
         const float2 v = cmul(src[o], conjf2(two[o]));
-        buf0[k1 * TD_CW + c] = conjf2(v);
+        buf0[k1 * CW + c] = conjf2(v);
     }
     __syncthreads();
-    const float2* cur = td_col_transform(buf0, buf1, w1, pl, c, w, nw);
+    const float2* cur = td_col_transform<CW>(buf0, buf1, w1, pl, c, w, nw);
     float2* o = out + b * (size_t)out_burst_stride + l * (size_t)out_rx_stride;
     const float2* inb = in + b * (size_t)in_stride;
     for (int i1 = w; i1 < n1; i1 += nw) {
         const size_t m = (size_t)i1 * n2 + col;
-        float2 v = conjf2(cur[i1 * TD_CW + c]);
+        float2 v = conjf2(cur[i1 * CW + c]);
         if (accumulate) v = cadd(o[m], v);
         if (add_self) {                                                      // out += (gr_complex)pow(10, db/20) * in  (:376)
             const float2 xi = inb[m];
@@ -658,10 +662,13 @@ __global__ __launch_bounds__(256) void td_col_inv_kernel(const float2* __restric
 
 // ---- row pass, n2 == 256: 16 rows per workgroup, everything in registers.  RC antennas of the launch out of one forward transform per target;
 //      tsp = timeshift as [R][K][n1][n2] (+ (l0 K + k0) n), the sum over the Kz targets of the launch is taken on the spectrum ----------------
+// RC == 0: one target per launch (the reference's own behaviour) — the forward spectrum stays in 16 registers and the R antennas are taken one
+// after the other out of it, no accumulators.  Two workgroups per CU (<= 256 VGPRs, no spills) measured faster at config B than three with
+// spills or than one antenna per workgroup with the forward transform repeated (0.221 / 0.236 / 0.236 ms per 256 bursts, round 5).
 template <int RC>
-__global__ __launch_bounds__(256) void td_rows256_kernel(const float2* __restrict__ U, float2* __restrict__ G, const float2* __restrict__ tsp,
-                                                         long ts_l_stride, const float2* __restrict__ phase, const float2* __restrict__ tw256_g,
-                                                         int Kz, int R, int l0, int n1, long rows)
+__global__ __launch_bounds__(256, RC == 1 ? 3 : 2) void td_rows256_kernel(const float2* __restrict__ U, float2* __restrict__ G, const float2* __restrict__ tsp,
+                                                            long ts_l_stride, const float2* __restrict__ phase, const float2* __restrict__ tw256_g,
+                                                            int Kz, int R, int l0, int n1, long rows)
 {
     __shared__ float2 xch[16 * TS_XPAD];
     __shared__ float2 tw256[256];
@@ -673,7 +680,34 @@ __global__ __launch_bounds__(256) void td_rows256_kernel(const float2* __restric
     const size_t n = (size_t)n1 * 256;
     tw256[threadIdx.x] = tw256_g[threadIdx.x];
     __syncthreads();
-    float2 acc[RC][16];
+    if (RC == 0) {
+        const float2* g = U + (b * n1 + k1) * 256;
+        float2 x[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) x[j] = g[s + 16 * j];
+        fft256_rows(x, xch, tw256);
+        if (phase) {
+            const float2 ph = phase[0];                                       // :358-362, on the spectrum (the inverse transform is linear)
+#pragma unroll
+            for (int r = 0; r < 16; r++) x[r] = cmul(x[r], ph);
+        }
+#pragma unroll 1
+        for (int l = 0; l < R; l++) {
+            const float2* tr = tsp + (size_t)l * ts_l_stride + k1 * 256;
+            float2 y[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) y[r] = cmul(x[r], tr[s + 16 * r]);   // :352
+            swap_reim(y); fft256_rows(y, xch, tw256); swap_reim(y);
+            float2* d = G + ((b * R + l) * n1 + k1) * 256;
+            if (live) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) d[s + 16 * r] = y[r];
+            }
+        }
+        return;
+    }
+    constexpr int RCA = RC > 0 ? RC : 1;
+    float2 acc[RCA][16];
     for (int z = 0; z < Kz; z++) {
         const float2* g = U + ((b * Kz + z) * n1 + k1) * 256;
         float2 x[16];
@@ -681,22 +715,22 @@ __global__ __launch_bounds__(256) void td_rows256_kernel(const float2* __restric
         for (int j = 0; j < 16; j++) x[j] = g[s + 16 * j];
         fft256_rows(x, xch, tw256);
         if (phase) {
-            const float2 ph = phase[z];                                       // :358-362, on the spectrum (the inverse transform is linear)
+            const float2 ph = phase[z];
 #pragma unroll
             for (int r = 0; r < 16; r++) x[r] = cmul(x[r], ph);
         }
 #pragma unroll
-        for (int l = 0; l < RC; l++) {
+        for (int l = 0; l < RCA; l++) {
             const float2* tr = tsp + (size_t)l * ts_l_stride + (size_t)z * n + k1 * 256;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const float2 p = cmul(x[r], tr[s + 16 * r]);                  // :352
+                const float2 p = cmul(x[r], tr[s + 16 * r]);
                 acc[l][r] = z ? cadd(acc[l][r], p) : p;
             }
         }
     }
 #pragma unroll
-    for (int l = 0; l < RC; l++) {
+    for (int l = 0; l < RCA; l++) {
         swap_reim(acc[l]); fft256_rows(acc[l], xch, tw256); swap_reim(acc[l]);
         float2* d = G + ((b * R + l0 + l) * n1 + k1) * 256;
         if (live) {
@@ -708,13 +742,70 @@ __global__ __launch_bounds__(256) void td_rows256_kernel(const float2* __restric
 
 // ---- row pass, n2 = m x 256 (m = 2, 4, 8, 16): the row transform of tsim_rowconv_m_kernel (m-point step in registers, 256-point step through
 //      LDS, spectrum in [k_a][k_b] order — the timeshift table is stored in that order), RC antennas out of one forward transform per target ----
-template <int M_, int RC>
-__global__ __launch_bounds__(256) void td_rows_m_kernel(const float2* __restrict__ U, float2* __restrict__ G, const float2* __restrict__ tsp,
-                                                        long ts_l_stride, const float2* __restrict__ phase, const float2* __restrict__ tw256_g,
-                                                        const float2* __restrict__ twn2_g, int Kz, int R, int l0, int n1, long rows)
+template <int M_>
+__device__ __forceinline__ void td_row_m_fwd(const float2* __restrict__ g, float2 (&x)[16], float2* xch, const float2* tw256,
+                                             const float2* __restrict__ twn2_g, int rowl, int t, int s, int plane)
 {
     constexpr int TPR = 16 * M_;
     constexpr int UU = 16 / M_;
+    float2 y[16];                                                             // [u][i_a]
+#pragma unroll
+    for (int u = 0; u < UU; u++)
+#pragma unroll
+        for (int a = 0; a < M_; a++) y[u * M_ + a] = g[a * 256 + t + TPR * u];
+#pragma unroll
+    for (int u = 0; u < UU; u++) {
+        fft_fwd_small<M_>(*reinterpret_cast<float2(*)[M_]>(&y[u * M_]));
+        const int ib = t + TPR * u;
+#pragma unroll
+        for (int a = 1; a < M_; a++) y[u * M_ + a] = cmul(y[u * M_ + a], twn2_g[ib * a]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < UU; u++)
+#pragma unroll
+        for (int a = 0; a < M_; a++) xch[(rowl * M_ + a) * TS_XPAD + t + TPR * u] = y[u * M_ + a];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; j++) x[j] = xch[plane * TS_XPAD + s + 16 * j];
+    fft256_rows(x, xch, tw256);                                               // x[r] = spectrum element k_b = s + 16 r of plane k_a
+}
+// v[r] = spectrum element k_b = s + 16 r of plane k_a  ->  the row in time order, stored to d (natural order)
+template <int M_>
+__device__ __forceinline__ void td_row_m_inv(float2 (&v)[16], float2* __restrict__ d, bool live, float2* xch, const float2* tw256,
+                                             const float2* __restrict__ twn2_g, int rowl, int t, int s, int plane)
+{
+    constexpr int TPR = 16 * M_;
+    constexpr int UU = 16 / M_;
+    swap_reim(v); fft256_rows(v, xch, tw256); swap_reim(v);                   // v[r] = element i_b = s + 16 r of plane k_a
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; r++) xch[plane * TS_XPAD + s + 16 * r] = v[r];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < UU; u++) {
+        const int ib = t + TPR * u;
+        float2 y[M_];
+#pragma unroll
+        for (int a = 0; a < M_; a++) {
+            float2 q = xch[(rowl * M_ + a) * TS_XPAD + ib];
+            if (a) q = cmul(q, conjf2(twn2_g[ib * a]));
+            y[a] = make_float2(q.y, q.x);                                     // swapped: inverse m-point FFT via the forward one
+        }
+        fft_fwd_small<M_>(y);
+        if (live) {
+#pragma unroll
+            for (int a = 0; a < M_; a++) d[a * 256 + ib] = make_float2(y[a].y, y[a].x);
+        }
+    }
+}
+
+template <int M_, int RC>
+__global__ __launch_bounds__(256, RC == 1 ? 3 : 2) void td_rows_m_kernel(const float2* __restrict__ U, float2* __restrict__ G, const float2* __restrict__ tsp,
+                                                           long ts_l_stride, const float2* __restrict__ phase, const float2* __restrict__ tw256_g,
+                                                           const float2* __restrict__ twn2_g, int Kz, int R, int l0, int n1, long rows)
+{
+    constexpr int TPR = 16 * M_;
     constexpr int N2 = 256 * M_;
     __shared__ float2 xch[16 * TS_XPAD];
     __shared__ float2 tw256[256];
@@ -727,38 +818,36 @@ __global__ __launch_bounds__(256) void td_rows_m_kernel(const float2* __restrict
     const size_t n = (size_t)n1 * N2;
     const int ka = plane % M_;
     tw256[threadIdx.x] = tw256_g[threadIdx.x];
-    float2 acc[RC][16];
-    for (int z = 0; z < Kz; z++) {
-        const float2* g = U + ((b * Kz + z) * n1 + k1) * N2;
-        float2 y[16];                                                         // [u][i_a]
-#pragma unroll
-        for (int u = 0; u < UU; u++)
-#pragma unroll
-            for (int a = 0; a < M_; a++) y[u * M_ + a] = g[a * 256 + t + TPR * u];
-#pragma unroll
-        for (int u = 0; u < UU; u++) {
-            fft_fwd_small<M_>(*reinterpret_cast<float2(*)[M_]>(&y[u * M_]));
-            const int ib = t + TPR * u;
-#pragma unroll
-            for (int a = 1; a < M_; a++) y[u * M_ + a] = cmul(y[u * M_ + a], twn2_g[ib * a]);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < UU; u++)
-#pragma unroll
-            for (int a = 0; a < M_; a++) xch[(rowl * M_ + a) * TS_XPAD + t + TPR * u] = y[u * M_ + a];
-        __syncthreads();
+    if (RC == 0) {                                                            // one target: the antennas one after the other out of x
         float2 x[16];
+        td_row_m_fwd<M_>(U + (b * n1 + k1) * N2, x, xch, tw256, twn2_g, rowl, t, s, plane);
+        if (phase) {
+            const float2 ph = phase[0];
 #pragma unroll
-        for (int j = 0; j < 16; j++) x[j] = xch[plane * TS_XPAD + s + 16 * j];
-        fft256_rows(x, xch, tw256);                                           // x[r] = spectrum element k_b = s + 16 r of plane k_a
+            for (int r = 0; r < 16; r++) x[r] = cmul(x[r], ph);
+        }
+#pragma unroll 1
+        for (int l = 0; l < R; l++) {
+            const float2* tr = tsp + (size_t)l * ts_l_stride + k1 * N2 + ka * 256;
+            float2 y[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) y[r] = cmul(x[r], tr[s + 16 * r]);
+            td_row_m_inv<M_>(y, G + ((b * R + l) * n1 + k1) * N2, live, xch, tw256, twn2_g, rowl, t, s, plane);
+        }
+        return;
+    }
+    constexpr int RCA = (RC == 1 || RC == 2) ? RC : 1;
+    float2 acc[RCA][16];
+    for (int z = 0; z < Kz; z++) {
+        float2 x[16];
+        td_row_m_fwd<M_>(U + ((b * Kz + z) * n1 + k1) * N2, x, xch, tw256, twn2_g, rowl, t, s, plane);
         if (phase) {
             const float2 ph = phase[z];
 #pragma unroll
             for (int r = 0; r < 16; r++) x[r] = cmul(x[r], ph);
         }
 #pragma unroll
-        for (int l = 0; l < RC; l++) {
+        for (int l = 0; l < RCA; l++) {
             const float2* tr = tsp + (size_t)l * ts_l_stride + (size_t)z * n + k1 * N2 + ka * 256;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
@@ -768,30 +857,8 @@ __global__ __launch_bounds__(256) void td_rows_m_kernel(const float2* __restrict
         }
     }
 #pragma unroll
-    for (int l = 0; l < RC; l++) {
-        swap_reim(acc[l]); fft256_rows(acc[l], xch, tw256); swap_reim(acc[l]);   // acc[l][r] = element i_b = s + 16 r of plane k_a
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 16; r++) xch[plane * TS_XPAD + s + 16 * r] = acc[l][r];
-        __syncthreads();
-        float2* d = G + ((b * R + l0 + l) * n1 + k1) * N2;
-#pragma unroll
-        for (int u = 0; u < UU; u++) {
-            const int ib = t + TPR * u;
-            float2 y[M_];
-#pragma unroll
-            for (int a = 0; a < M_; a++) {
-                float2 v = xch[(rowl * M_ + a) * TS_XPAD + ib];
-                if (a) v = cmul(v, conjf2(twn2_g[ib * a]));
-                y[a] = make_float2(v.y, v.x);                                 // swapped: inverse m-point FFT via the forward one
-            }
-            fft_fwd_small<M_>(y);
-            if (live) {
-#pragma unroll
-                for (int a = 0; a < M_; a++) d[a * 256 + ib] = make_float2(y[a].y, y[a].x);
-            }
-        }
-    }
+    for (int l = 0; l < RCA; l++)
+        td_row_m_inv<M_>(acc[l], G + ((b * R + l0 + l) * n1 + k1) * N2, live, xch, tw256, twn2_g, rowl, t, s, plane);
 }
 
 // ---- row pass, any power of two 16 <= n2 <= 128 (the 64-carrier flowgraphs: n2 = 16 x 2^v2(n_symbols)): Stockham passes in LDS, tp threads per
@@ -951,7 +1018,14 @@ static td_plan tsim_plan_of(const jrc_tsim* h)
     for (int i = 0; i < 24; i++) pl.rad[i] = h->rad[i];
     return pl;
 }
-static size_t td_col_lds_bytes(int n1) { return sizeof(float2) * ((size_t)2 * n1 * TD_CW + (size_t)n1); }
+static size_t td_col_lds_bytes(int n1, int cw) { return sizeof(float2) * ((size_t)2 * n1 * cw + (size_t)n1); }
+// columns per workgroup of the column passes: 32 (256-byte row segments) while the tile fits 64 KB of LDS, else 16; JRC_TSIM_CW overrides
+static int td_pick_cw(int n1, int n2)
+{
+    int cw = (n2 >= 32 && td_col_lds_bytes(n1, 32) <= 64 * 1024) ? 32 : 16;
+    if (const char* e = getenv("JRC_TSIM_CW")) { const int v = atoi(e); if ((v == 16 || v == 32) && v <= n2) cw = v; }
+    return cw;
+}
 
 // channel filters and chirp tables for bursts of n samples (:249-300 + the Bluestein tables)
 static int tsim_prepare(jrc_tsim* h, int n, hipStream_t stream)
@@ -1026,8 +1100,8 @@ static int tsim_prepare(jrc_tsim* h, int n, hipStream_t stream)
         JRC_HIP(ctx, hipMalloc((void**)&h->d_two, sizeof(float2) * (size_t)n));
         JRC_HIP(ctx, hipMemcpy(h->d_w1, w1.data(), sizeof(float2) * (size_t)n1, hipMemcpyHostToDevice));
         JRC_HIP(ctx, hipMemcpy(h->d_two, two.data(), sizeof(float2) * (size_t)n, hipMemcpyHostToDevice));
-        JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)td_col_fwd_kernel, td_col_lds_bytes(n1)));
-        JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)td_col_inv_kernel, td_col_lds_bytes(n1)));
+        JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)td_col_fwd_kernel<16>, td_col_lds_bytes(n1, 16)));
+        JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)td_col_inv_kernel<16>, td_col_lds_bytes(n1, 16)));
         h->n = n; h->M = n; h->n2 = n2; h->n1 = n1; h->nrad = pl.nrad; h->direct = true;
         for (int i = 0; i < 24; i++) h->rad[i] = i < pl.nrad ? pl.rad[i] : 0;
         return JRC_OK;
@@ -1143,10 +1217,15 @@ extern "C" int jrc_tsim_run_dev(jrc_tsim* h, int n_bursts, int n_input, const jr
     if (h->direct) {
         const td_plan pl = tsim_plan_of(h);
         const int n1 = h->n1;
-        const size_t lds = td_col_lds_bytes(n1);
+        const int cw = td_pick_cw(n1, n2);
+        const size_t lds = td_col_lds_bytes(n1, cw);
         const float2* ph = use_phase ? (const float2*)h->d_phase + k0 : (const float2*)nullptr;
-        hipLaunchKernelGGL(td_col_fwd_kernel, dim3(n2 / TD_CW, n_bursts, Kz), dim3(256), lds, s, in, (long)n, (const float2*)h->d_dop + (size_t)k0 * n,
-                           h->d_u, (const float2*)h->d_w1, (const float2*)h->d_two, pl, n);
+        if (cw == 32)
+            hipLaunchKernelGGL(td_col_fwd_kernel<32>, dim3(n2 / 32, n_bursts, Kz), dim3(256), lds, s, in, (long)n, (const float2*)h->d_dop + (size_t)k0 * n,
+                               h->d_u, (const float2*)h->d_w1, (const float2*)h->d_two, pl, n);
+        else
+            hipLaunchKernelGGL(td_col_fwd_kernel<16>, dim3(n2 / 16, n_bursts, Kz), dim3(256), lds, s, in, (long)n, (const float2*)h->d_dop + (size_t)k0 * n,
+                               h->d_u, (const float2*)h->d_w1, (const float2*)h->d_two, pl, n);
         JRC_HIP(ctx, hipGetLastError());
         const long rows = (long)n_bursts * n1;
         if (n2 >= 256) {
@@ -1155,14 +1234,16 @@ extern "C" int jrc_tsim_run_dev(jrc_tsim* h, int n_bursts, int n_input, const jr
             const int m = n2 / 256, rpb = 16 / m;                        // rows per workgroup
             const dim3 grid((unsigned)((rows + rpb - 1) / rpb));
             for (int l0 = 0; l0 < R;) {
-                const int rc = (R - l0 >= 4) ? 4 : ((R - l0 >= 2) ? 2 : 1);
+                // one target per launch: all R antennas out of one forward transform, one after the other (RC 0); a sum over targets keeps
+                // the antennas' spectra in accumulators, two antennas per launch
+                const int rc = (Kz == 1) ? 0 : ((R - l0 >= 2) ? 2 : 1);
                 const float2* tsp = (const float2*)h->d_ts + ((size_t)l0 * K + k0) * n;
 #define TD_ROWS(MM, RC_)                                                                                                                  \
                 hipLaunchKernelGGL((td_rows_m_kernel<MM, RC_>), grid, dim3(256), 0, s, (const float2*)h->d_u, h->d_g, tsp, (long)K * n, ph, tw256, \
                                    twn2, Kz, R, l0, n1, rows)
-#define TD_ROWS_RC(MM) do { if (rc == 4) TD_ROWS(MM, 4); else if (rc == 2) TD_ROWS(MM, 2); else TD_ROWS(MM, 1); } while (0)
+#define TD_ROWS_RC(MM) do { if (rc == 0) TD_ROWS(MM, 0); else if (rc == 2) TD_ROWS(MM, 2); else TD_ROWS(MM, 1); } while (0)
                 if (m == 1) {
-                    if (rc == 4) hipLaunchKernelGGL(td_rows256_kernel<4>, grid, dim3(256), 0, s, (const float2*)h->d_u, h->d_g, tsp, (long)K * n, ph, tw256, Kz, R, l0, n1, rows);
+                    if (rc == 0) hipLaunchKernelGGL(td_rows256_kernel<0>, grid, dim3(256), 0, s, (const float2*)h->d_u, h->d_g, tsp, (long)K * n, ph, tw256, Kz, R, l0, n1, rows);
                     else if (rc == 2) hipLaunchKernelGGL(td_rows256_kernel<2>, grid, dim3(256), 0, s, (const float2*)h->d_u, h->d_g, tsp, (long)K * n, ph, tw256, Kz, R, l0, n1, rows);
                     else hipLaunchKernelGGL(td_rows256_kernel<1>, grid, dim3(256), 0, s, (const float2*)h->d_u, h->d_g, tsp, (long)K * n, ph, tw256, Kz, R, l0, n1, rows);
                 } else if (m == 2) TD_ROWS_RC(2);
@@ -1172,7 +1253,7 @@ extern "C" int jrc_tsim_run_dev(jrc_tsim* h, int n_bursts, int n_input, const jr
 #undef TD_ROWS_RC
 #undef TD_ROWS
                 JRC_HIP(ctx, hipGetLastError());
-                l0 += rc;
+                l0 += rc ? rc : R;
             }
         } else {
             const float2 *twf = nullptr, *twi = nullptr;
@@ -1184,8 +1265,12 @@ extern "C" int jrc_tsim_run_dev(jrc_tsim* h, int n_bursts, int n_input, const jr
                                h->d_g, (const float2*)h->d_ts + (size_t)k0 * n, (long)K * n, ph, twf, twi, Kz, R, n1, n2, jrc_ilog2(n2), rows, tp);
             JRC_HIP(ctx, hipGetLastError());
         }
-        hipLaunchKernelGGL(td_col_inv_kernel, dim3(n2 / TD_CW, n_bursts * R), dim3(256), lds, s, (const float2*)h->d_g, out, (long)R * n, (long)n, in, (long)n,
-                           sc, h->self_coupling ? 1 : 0, accumulate_out ? 1 : 0, (const float2*)h->d_w1, (const float2*)h->d_two, pl, R, n);
+        if (cw == 32)
+            hipLaunchKernelGGL(td_col_inv_kernel<32>, dim3(n2 / 32, n_bursts * R), dim3(256), lds, s, (const float2*)h->d_g, out, (long)R * n, (long)n, in, (long)n,
+                               sc, h->self_coupling ? 1 : 0, accumulate_out ? 1 : 0, (const float2*)h->d_w1, (const float2*)h->d_two, pl, R, n);
+        else
+            hipLaunchKernelGGL(td_col_inv_kernel<16>, dim3(n2 / 16, n_bursts * R), dim3(256), lds, s, (const float2*)h->d_g, out, (long)R * n, (long)n, in, (long)n,
+                               sc, h->self_coupling ? 1 : 0, accumulate_out ? 1 : 0, (const float2*)h->d_w1, (const float2*)h->d_two, pl, R, n);
         JRC_HIP(ctx, hipGetLastError());
         return JRC_OK;
     }
