@@ -6,7 +6,8 @@ frame-batched leg — what SURVEY.md §8(f) ranks 1-2 were built for: data symbo
     -> jrc_precoder_frames_dev        mimo_precoder, all F packets in one launch          -> [F][T][n_total][N]      (also the radar's TX reference)
     -> jrc_ofdm_mod_dev               fft_vxx(reverse, shift, window) + cyclic prefixer;  the window carries the blocks_multiply_const (tx_multiplier)
     -> jrc_zero_pad_strided_dev       zero_pad(0, 3 symbols), one launch per TX port      -> [T][F][n_burst]
-    -> jrc_tsim_run_dev per TX        target_simulator, accumulating into the RX streams  -> [F][R][n_burst]         (absorbs blocks_add_xx)
+    -> jrc_tsim_run_sum_dev           the T target_simulators and the blocks_add_xx per RX behind them, summed on the spectrum -> [F][R][n_burst]
+                                      (jrc_tsim_run_dev per TX with accumulate_out where the burst length has no direct route)
     -> jrc_chain_run_td_dev           A6 + A7 + A1 as one kernel, then A2..A5             -> channel estimate, map, records
 
 The analog noise sources of the .grc are not part of this leg (a stock block without a device counterpart here); examples/radar_sim_flowgraph.py
@@ -50,6 +51,7 @@ class DeviceResidentRadarSim:
         self.n_in = self.n_total * (N + cp)
         self.n_burst = self.n_in + self.pad_tail
         self.seed = seed
+        self.sum_on_spectrum = os.environ.get("JRC_DRF_SUM_ON_SPECTRUM", "1") != "0"
         P = T * R
         self.precoder = jrc.mimo_precoder(N, T, 1, o["data_subcarriers"], o["pilot_subcarriers"], o["pilot_symbols"], o["l_stf_ltf_64"],
                                           o["ltf_mapped_sc__ss_sym"], ctx=self.ctx)
@@ -94,7 +96,18 @@ class DeviceResidentRadarSim:
             src = self.d_txt.data_ptr() + 8 * t * self.n_in
             c.check(L.jrc_zero_pad_strided_dev(c.h, n_frames, self.n_in, 0, self.pad_tail if pads else 0, self.seed + 100 * t, src, T * self.n_in,
                                                self.d_pad[t].data_ptr(), self.n_burst, None))
-            self.sims[t].run_dev(self.d_pad[t], self.d_rx, n_frames, self.n_burst, accumulate_out=(t > 0))
+            if not self.sum_on_spectrum:
+                self.sims[t].run_dev(self.d_pad[t], self.d_rx, n_frames, self.n_burst, accumulate_out=(t > 0))
+        if self.sum_on_spectrum:
+            # the T simulators and the blocks_add_xx behind them in one pass (jrc_tsim_run_sum_dev): one inverse transform per RX antenna
+            try:
+                self.jrc.target_simulator.run_sum_dev(self.sims, [self.d_pad[t] for t in range(T)], self.d_rx, n_frames, self.n_burst)
+            except self.jrc.JrcError as e:
+                if e.status != self.jrc.JRC_ERR_UNSUPPORTED:
+                    raise
+                self.sum_on_spectrum = False                                         # a burst length outside the direct route: one by one
+                for t in range(T):
+                    self.sims[t].run_dev(self.d_pad[t], self.d_rx, n_frames, self.n_burst, accumulate_out=(t > 0))
         self.chain.run_td(self.bufs, self.d_txf, self.d_rx, n_frames, self.cp)
 
     def results(self, n_frames):

@@ -1065,6 +1065,7 @@ def _load_tsim():
         L.jrc_tsim_set_targets.argtypes = [_vp, C.c_int, _cfp, _cfp, _cfp, _cfp]
         L.jrc_tsim_work.argtypes = [_vp, _vp, C.c_int, C.POINTER(_vp), _vp]
         L.jrc_tsim_run_dev.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _vp]
+        L.jrc_tsim_run_sum_dev.argtypes = [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.POINTER(_vp), _vp, C.POINTER(_vp), C.c_int, _vp]
         L.jrc_tsim_burst_capacity.argtypes = [_vp]
         L._tsim_ready = True
     return L
@@ -1142,6 +1143,18 @@ class target_simulator:
         tp = None if target_phase is None else _c64(target_phase)
         self.ctx.check(self.ctx.lib.jrc_tsim_run_dev(self.h, n_bursts, n_input, _vp(d_in.data_ptr()), _vp(d_out.data_ptr()),
                                                      None if tp is None else _ptr(tp), int(accumulate_out), stream))
+
+    @staticmethod
+    def run_sum_dev(sims, d_ins, d_out, n_bursts, n_input, target_phases=None, accumulate_out=False, stream=None):
+        """jrc_tsim_run_sum_dev: the simulators of a flowgraph's TX ports, their outputs summed per RX antenna on the spectrum, in one pass.
+        d_ins: one device tensor [n_bursts][n_input] per simulator; raises JrcError(JRC_ERR_UNSUPPORTED) when the burst length does not take
+        the direct route (run them one by one with accumulate_out then)."""
+        ctx = sims[0].ctx
+        hs = (_vp * len(sims))(*[s.h for s in sims])
+        ins = (_vp * len(sims))(*[_vp(t.data_ptr()) for t in d_ins])
+        keep = [None if (target_phases is None or p is None) else _c64(p) for p in (target_phases or [None] * len(sims))]
+        phs = (_vp * len(sims))(*[None if k is None else k.ctypes.data_as(_vp) for k in keep]) if target_phases is not None else None
+        ctx.check(ctx.lib.jrc_tsim_run_sum_dev(hs, len(sims), n_bursts, n_input, ins, _vp(d_out.data_ptr()), phs, int(accumulate_out), stream))
 
     def close(self):
         if getattr(self, "h", None) and getattr(getattr(self, "ctx", None), "h", None):   # (Context.close() closes its children before it destroys itself; a context already gone means this object went with it)

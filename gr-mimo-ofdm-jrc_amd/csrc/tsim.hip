@@ -507,6 +507,13 @@ __global__ void tsim_passthrough_kernel(float2* __restrict__ out, long out_burst
 #define TD_MAX_N1 512
 
 struct td_plan { int n1, n2, nrad; int rad[24]; };
+// the spectra a launch sums: one entry per (simulator, target) pair — the targets of one simulator (sum_targets), and the simulators of a
+// flowgraph's TX ports whose outputs a blocks_add_xx adds (jrc_tsim_run_sum_dev)
+#define TD_MAXV 32
+#define TD_MAXSIMS 8
+struct td_srcs { const float2* in[TD_MAXV]; const float2* dop[TD_MAXV]; };            // burst 0 of the pair's input; its doppler filter [n]
+struct td_ts { const float2* tsp[TD_MAXV]; float2 phase[TD_MAXV]; int use_phase; };   // timeshift of (antenna 0, target) in row-pass order; per-target phase
+struct td_self { const float2* in[TD_MAXSIMS]; int n; };                              // inputs whose self-coupling term is added (:372-378)
 
 template <int R>
 __device__ __forceinline__ void td_dft_small(float2 (&v)[R]);
@@ -593,7 +600,7 @@ __device__ __forceinline__ float2* td_col_transform(float2* buf0, float2* buf1, 
 
 // ---- column pass, forward:  x = in . doppler_z  as [n1][n2]  ->  n1-point DFT per column  ->  . w_n^{i2 k1}  ->  U[b][z][k1][i2] ------------
 template <int CW>
-__global__ __launch_bounds__(256) void td_col_fwd_kernel(const float2* __restrict__ in, long in_stride, const float2* __restrict__ dop,
+__global__ __launch_bounds__(256) void td_col_fwd_kernel(td_srcs srcs, long in_stride,
                                                          float2* __restrict__ U, const float2* __restrict__ w1_g,
                                                          const float2* __restrict__ two, td_plan pl, int n)
 {
@@ -605,8 +612,8 @@ __global__ __launch_bounds__(256) void td_col_fwd_kernel(const float2* __restric
     const int c = threadIdx.x & (CW - 1), w = threadIdx.x / CW, nw = 256 / CW;
     const int col = blockIdx.x * CW + c;
     const size_t b = blockIdx.y, z = blockIdx.z;
-    const float2* src = in + b * (size_t)in_stride;
-    const float2* dz = dop + z * (size_t)n;
+    const float2* __restrict__ src = srcs.in[z] + b * (size_t)in_stride;
+    const float2* __restrict__ dz = srcs.dop[z];
     for (int i = threadIdx.x; i < n1; i += 256) w1[i] = w1_g[i];
     for (int i1 = w; i1 < n1; i1 += nw) {
         const size_t i = (size_t)i1 * n2 + col;
@@ -625,8 +632,8 @@ __global__ __launch_bounds__(256) void td_col_fwd_kernel(const float2* __restric
 //      (= or +=), plus the self-coupling term sc . in (:372-378) when asked ---------------------------------------------------------------------
 template <int CW>
 __global__ __launch_bounds__(256) void td_col_inv_kernel(const float2* __restrict__ G, float2* __restrict__ out, long out_burst_stride,
-                                                         long out_rx_stride, const float2* __restrict__ in, long in_stride,
-                                                         float self_coupling, int add_self, int accumulate,
+                                                         long out_rx_stride, td_self self, long in_stride,
+                                                         float self_coupling, int accumulate,
                                                          const float2* __restrict__ w1_g, const float2* __restrict__ two, td_plan pl, int R, int n)
 {
     extern __shared__ __attribute__((aligned(16))) float2 td_lds[];
@@ -647,13 +654,12 @@ __global__ __launch_bounds__(256) void td_col_inv_kernel(const float2* __restric
     __syncthreads();
     const float2* cur = td_col_transform<CW>(buf0, buf1, w1, pl, c, w, nw);
     float2* o = out + b * (size_t)out_burst_stride + l * (size_t)out_rx_stride;
-    const float2* inb = in + b * (size_t)in_stride;
     for (int i1 = w; i1 < n1; i1 += nw) {
         const size_t m = (size_t)i1 * n2 + col;
         float2 v = conjf2(cur[i1 * CW + c]);
         if (accumulate) v = cadd(o[m], v);
-        if (add_self) {                                                      // out += (gr_complex)pow(10, db/20) * in  (:376)
-            const float2 xi = inb[m];
+        for (int q = 0; q < self.n; q++) {                                   // out += (gr_complex)pow(10, db/20) * in  (:376), per simulator
+            const float2 xi = self.in[q][b * (size_t)in_stride + m];
             v = cadd(v, make_float2(self_coupling * xi.x - 0.0f * xi.y, self_coupling * xi.y + 0.0f * xi.x));
         }
         o[m] = v;
@@ -666,8 +672,8 @@ __global__ __launch_bounds__(256) void td_col_inv_kernel(const float2* __restric
 // after the other out of it, no accumulators.  Two workgroups per CU (<= 256 VGPRs, no spills) measured faster at config B than three with
 // spills or than one antenna per workgroup with the forward transform repeated (0.221 / 0.236 / 0.236 ms per 256 bursts, round 5).
 template <int RC>
-__global__ __launch_bounds__(256, RC == 1 ? 3 : 2) void td_rows256_kernel(const float2* __restrict__ U, float2* __restrict__ G, const float2* __restrict__ tsp,
-                                                            long ts_l_stride, const float2* __restrict__ phase, const float2* __restrict__ tw256_g,
+__global__ __launch_bounds__(256, RC == 1 ? 3 : 2) void td_rows256_kernel(const float2* __restrict__ U, float2* __restrict__ G, td_ts ts,
+                                                            long ts_l_stride, const float2* __restrict__ tw256_g,
                                                             int Kz, int R, int l0, int n1, long rows)
 {
     __shared__ float2 xch[16 * TS_XPAD];
@@ -677,7 +683,6 @@ __global__ __launch_bounds__(256, RC == 1 ? 3 : 2) void td_rows256_kernel(const 
     const bool live = row < rows;
     if (!live) row = rows - 1;
     const size_t b = (size_t)(row / n1), k1 = (size_t)(row % n1);
-    const size_t n = (size_t)n1 * 256;
     tw256[threadIdx.x] = tw256_g[threadIdx.x];
     __syncthreads();
     if (RC == 0) {
@@ -686,14 +691,14 @@ __global__ __launch_bounds__(256, RC == 1 ? 3 : 2) void td_rows256_kernel(const 
 #pragma unroll
         for (int j = 0; j < 16; j++) x[j] = g[s + 16 * j];
         fft256_rows(x, xch, tw256);
-        if (phase) {
-            const float2 ph = phase[0];                                       // :358-362, on the spectrum (the inverse transform is linear)
+        if (ts.use_phase) {
+            const float2 ph = ts.phase[0];                                    // :358-362, on the spectrum (the inverse transform is linear)
 #pragma unroll
             for (int r = 0; r < 16; r++) x[r] = cmul(x[r], ph);
         }
 #pragma unroll 1
         for (int l = 0; l < R; l++) {
-            const float2* tr = tsp + (size_t)l * ts_l_stride + k1 * 256;
+            const float2* __restrict__ tr = ts.tsp[0] + (size_t)l * ts_l_stride + k1 * 256;
             float2 y[16];
 #pragma unroll
             for (int r = 0; r < 16; r++) y[r] = cmul(x[r], tr[s + 16 * r]);   // :352
@@ -714,14 +719,14 @@ __global__ __launch_bounds__(256, RC == 1 ? 3 : 2) void td_rows256_kernel(const 
 #pragma unroll
         for (int j = 0; j < 16; j++) x[j] = g[s + 16 * j];
         fft256_rows(x, xch, tw256);
-        if (phase) {
-            const float2 ph = phase[z];
+        if (ts.use_phase) {
+            const float2 ph = ts.phase[z];
 #pragma unroll
             for (int r = 0; r < 16; r++) x[r] = cmul(x[r], ph);
         }
 #pragma unroll
         for (int l = 0; l < RCA; l++) {
-            const float2* tr = tsp + (size_t)l * ts_l_stride + (size_t)z * n + k1 * 256;
+            const float2* __restrict__ tr = ts.tsp[z] + (size_t)(l0 + l) * ts_l_stride + k1 * 256;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const float2 p = cmul(x[r], tr[s + 16 * r]);
@@ -801,8 +806,8 @@ __device__ __forceinline__ void td_row_m_inv(float2 (&v)[16], float2* __restrict
 }
 
 template <int M_, int RC>
-__global__ __launch_bounds__(256, RC == 1 ? 3 : 2) void td_rows_m_kernel(const float2* __restrict__ U, float2* __restrict__ G, const float2* __restrict__ tsp,
-                                                           long ts_l_stride, const float2* __restrict__ phase, const float2* __restrict__ tw256_g,
+__global__ __launch_bounds__(256, RC == 1 ? 3 : 2) void td_rows_m_kernel(const float2* __restrict__ U, float2* __restrict__ G, td_ts ts,
+                                                           long ts_l_stride, const float2* __restrict__ tw256_g,
                                                            const float2* __restrict__ twn2_g, int Kz, int R, int l0, int n1, long rows)
 {
     constexpr int TPR = 16 * M_;
@@ -815,20 +820,19 @@ __global__ __launch_bounds__(256, RC == 1 ? 3 : 2) void td_rows_m_kernel(const f
     const bool live = row < rows;
     if (!live) row = rows - 1;
     const size_t b = (size_t)(row / n1), k1 = (size_t)(row % n1);
-    const size_t n = (size_t)n1 * N2;
     const int ka = plane % M_;
     tw256[threadIdx.x] = tw256_g[threadIdx.x];
     if (RC == 0) {                                                            // one target: the antennas one after the other out of x
         float2 x[16];
         td_row_m_fwd<M_>(U + (b * n1 + k1) * N2, x, xch, tw256, twn2_g, rowl, t, s, plane);
-        if (phase) {
-            const float2 ph = phase[0];
+        if (ts.use_phase) {
+            const float2 ph = ts.phase[0];
 #pragma unroll
             for (int r = 0; r < 16; r++) x[r] = cmul(x[r], ph);
         }
 #pragma unroll 1
         for (int l = 0; l < R; l++) {
-            const float2* tr = tsp + (size_t)l * ts_l_stride + k1 * N2 + ka * 256;
+            const float2* __restrict__ tr = ts.tsp[0] + (size_t)l * ts_l_stride + k1 * N2 + ka * 256;
             float2 y[16];
 #pragma unroll
             for (int r = 0; r < 16; r++) y[r] = cmul(x[r], tr[s + 16 * r]);
@@ -841,14 +845,14 @@ __global__ __launch_bounds__(256, RC == 1 ? 3 : 2) void td_rows_m_kernel(const f
     for (int z = 0; z < Kz; z++) {
         float2 x[16];
         td_row_m_fwd<M_>(U + ((b * Kz + z) * n1 + k1) * N2, x, xch, tw256, twn2_g, rowl, t, s, plane);
-        if (phase) {
-            const float2 ph = phase[z];
+        if (ts.use_phase) {
+            const float2 ph = ts.phase[z];
 #pragma unroll
             for (int r = 0; r < 16; r++) x[r] = cmul(x[r], ph);
         }
 #pragma unroll
         for (int l = 0; l < RCA; l++) {
-            const float2* tr = tsp + (size_t)l * ts_l_stride + (size_t)z * n + k1 * N2 + ka * 256;
+            const float2* __restrict__ tr = ts.tsp[z] + (size_t)(l0 + l) * ts_l_stride + k1 * N2 + ka * 256;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const float2 p = cmul(x[r], tr[s + 16 * r]);
@@ -863,8 +867,8 @@ __global__ __launch_bounds__(256, RC == 1 ? 3 : 2) void td_rows_m_kernel(const f
 
 // ---- row pass, any power of two 16 <= n2 <= 128 (the 64-carrier flowgraphs: n2 = 16 x 2^v2(n_symbols)): Stockham passes in LDS, tp threads per
 //      row, one antenna per blockIdx.y; the spectrum sum over the targets is kept in a third LDS row -----------------------------------------
-__global__ __launch_bounds__(256) void td_rows_small_kernel(const float2* __restrict__ U, float2* __restrict__ G, const float2* __restrict__ tsp,
-                                                            long ts_l_stride, const float2* __restrict__ phase, const float2* __restrict__ tw_f,
+__global__ __launch_bounds__(256) void td_rows_small_kernel(const float2* __restrict__ U, float2* __restrict__ G, td_ts ts,
+                                                            long ts_l_stride, const float2* __restrict__ tw_f,
                                                             const float2* __restrict__ tw_i, int Kz, int R, int n1, int n2, int logn2, long rows, int tp)
 {
     extern __shared__ __attribute__((aligned(16))) float2 td_lds[];
@@ -874,7 +878,6 @@ __global__ __launch_bounds__(256) void td_rows_small_kernel(const float2* __rest
     const bool live = row < rows;
     if (!live) row = rows - 1;
     const size_t b = (size_t)(row / n1), k1 = (size_t)(row % n1);
-    const size_t n = (size_t)n1 * n2;
     const int l = blockIdx.y;
     float2* buf0 = td_lds + (size_t)lb * 3 * n2;
     float2* buf1 = buf0 + n2;
@@ -893,10 +896,10 @@ __global__ __launch_bounds__(256) void td_rows_small_kernel(const float2* __rest
             cur = nxt; nxt = (nxt == buf0) ? buf1 : buf0;
             Ns *= Rx; first = false;
         }
-        const float2* tr = tsp + (size_t)l * ts_l_stride + (size_t)z * n + k1 * n2;
+        const float2* __restrict__ tr = ts.tsp[z] + (size_t)l * ts_l_stride + k1 * n2;
         for (int k2 = lt; k2 < n2; k2 += tp) {
             float2 v = cur[k2];
-            if (phase) v = cmul(v, phase[z]);
+            if (ts.use_phase) v = cmul(v, ts.phase[z]);
             v = cmul(v, tr[k2]);
             accb[k2] = z ? cadd(accb[k2], v) : v;
         }
@@ -1181,6 +1184,99 @@ extern "C" void jrc_tsim_destroy(jrc_tsim* h)
     delete h;
 }
 
+// The direct route for one simulator or for several whose outputs are summed (all prepared for bursts of n samples, same plan, same
+// antenna count): the (simulator, target) pairs are the "virtual targets" of the three launches.  Work buffers: the first simulator's.
+static int tsim_run_direct(jrc_tsim* const* sims, int n_sims, int n_bursts, int n, const jrc_cf32* const* d_in, jrc_cf32* d_out,
+                           const jrc_cf32* const* target_phase /* host, per simulator, or null */, int accumulate_out, hipStream_t s)
+{
+    jrc_tsim* h = sims[0];
+    jrc_ctx* ctx = h->ctx;
+    const int R = h->R, n1 = h->n1, n2 = h->n2;
+    td_srcs srcs; td_ts ts; td_self self;
+    self.n = 0; ts.use_phase = 0;
+    int V = 0;
+    for (int q = 0; q < n_sims; q++) {
+        const jrc_tsim* g = sims[q];
+        const int K = g->K, k0 = g->sum_targets ? 0 : K - 1;
+        const bool ph = g->rndm_phaseshift && target_phase && target_phase[q];
+        for (int k = k0; k < K; k++, V++) {
+            if (V >= TD_MAXV) return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "target_simulator: more than %d (simulator, target) pairs in one launch", TD_MAXV);
+            srcs.in[V] = (const float2*)d_in[q];
+            srcs.dop[V] = (const float2*)g->d_dop + (size_t)k * n;
+            ts.tsp[V] = (const float2*)g->d_ts + (size_t)k * n;             // [R][K][n]: antenna l at + l K n
+            ts.phase[V] = ph ? make_float2(target_phase[q][k].re, target_phase[q][k].im) : make_float2(1.f, 0.f);
+            if (ph) ts.use_phase = 1;
+        }
+        if (g->self_coupling) self.in[self.n++] = (const float2*)d_in[q];
+    }
+    for (int v = V; v < TD_MAXV; v++) { srcs.in[v] = srcs.dop[v] = ts.tsp[v] = nullptr; ts.phase[v] = make_float2(1.f, 0.f); }
+    for (int q = self.n; q < TD_MAXSIMS; q++) self.in[q] = nullptr;
+    const long ts_l_stride = (long)h->K * n;
+    const float sc = (float)std::pow(10, h->self_coupling_db / 20.0);         // :376
+    const size_t need_u = sizeof(float2) * (size_t)n_bursts * V * n;
+    if (need_u > h->u_cap) {                                                // more pairs than this simulator's own targets: grow its spectrum buffer
+        JRC_HIP(ctx, hipStreamSynchronize(s));
+        (void)hipFree(h->d_u); h->d_u = nullptr; h->u_cap = 0;
+        JRC_HIP(ctx, hipMalloc((void**)&h->d_u, need_u));
+        h->u_cap = need_u;
+    }
+    const float2* tw256 = nullptr;
+    JRC_TRY(jrc_get_twiddles(ctx, TS_N1, -1, &tw256));
+    const td_plan pl = tsim_plan_of(h);
+    const int cw = td_pick_cw(n1, n2);
+    const size_t lds = td_col_lds_bytes(n1, cw);
+    if (cw == 32)
+        hipLaunchKernelGGL(td_col_fwd_kernel<32>, dim3(n2 / 32, n_bursts, V), dim3(256), lds, s, srcs, (long)n, h->d_u, (const float2*)h->d_w1, (const float2*)h->d_two, pl, n);
+    else
+        hipLaunchKernelGGL(td_col_fwd_kernel<16>, dim3(n2 / 16, n_bursts, V), dim3(256), lds, s, srcs, (long)n, h->d_u, (const float2*)h->d_w1, (const float2*)h->d_two, pl, n);
+    JRC_HIP(ctx, hipGetLastError());
+    const long rows = (long)n_bursts * n1;
+    if (n2 >= 256) {
+        const float2* twn2 = nullptr;
+        if (n2 > 256) JRC_TRY(jrc_get_twiddles(ctx, n2, -1, &twn2));
+        const int m = n2 / 256, rpb = 16 / m;                        // rows per workgroup
+        const dim3 grid((unsigned)((rows + rpb - 1) / rpb));
+        for (int l0 = 0; l0 < R;) {
+            // one spectrum per launch: all R antennas out of one forward transform, one after the other (RC 0); a sum of spectra keeps the
+            // antennas' sums in accumulators, two antennas per launch
+            const int rc = (V == 1) ? 0 : ((R - l0 >= 2) ? 2 : 1);
+#define TD_ROWS(MM, RC_)                                                                                                                  \
+            hipLaunchKernelGGL((td_rows_m_kernel<MM, RC_>), grid, dim3(256), 0, s, (const float2*)h->d_u, h->d_g, ts, ts_l_stride, tw256, twn2, V, R, l0, n1, rows)
+#define TD_ROWS_RC(MM) do { if (rc == 0) TD_ROWS(MM, 0); else if (rc == 2) TD_ROWS(MM, 2); else TD_ROWS(MM, 1); } while (0)
+            if (m == 1) {
+                if (rc == 0) hipLaunchKernelGGL(td_rows256_kernel<0>, grid, dim3(256), 0, s, (const float2*)h->d_u, h->d_g, ts, ts_l_stride, tw256, V, R, l0, n1, rows);
+                else if (rc == 2) hipLaunchKernelGGL(td_rows256_kernel<2>, grid, dim3(256), 0, s, (const float2*)h->d_u, h->d_g, ts, ts_l_stride, tw256, V, R, l0, n1, rows);
+                else hipLaunchKernelGGL(td_rows256_kernel<1>, grid, dim3(256), 0, s, (const float2*)h->d_u, h->d_g, ts, ts_l_stride, tw256, V, R, l0, n1, rows);
+            } else if (m == 2) TD_ROWS_RC(2);
+            else if (m == 4) TD_ROWS_RC(4);
+            else if (m == 8) TD_ROWS_RC(8);
+            else TD_ROWS_RC(16);
+#undef TD_ROWS_RC
+#undef TD_ROWS
+            JRC_HIP(ctx, hipGetLastError());
+            l0 += rc ? rc : R;
+        }
+    } else {
+        const float2 *twf = nullptr, *twi = nullptr;
+        JRC_TRY(jrc_get_twiddles(ctx, n2, -1, &twf));
+        JRC_TRY(jrc_get_twiddles(ctx, n2, +1, &twi));
+        const int tp = n2 / 4, per_block = 256 / tp;
+        const size_t lds_rows = sizeof(float2) * 3 * (size_t)n2 * per_block;
+        hipLaunchKernelGGL(td_rows_small_kernel, dim3((unsigned)((rows + per_block - 1) / per_block), R), dim3(256), lds_rows, s, (const float2*)h->d_u,
+                           h->d_g, ts, ts_l_stride, twf, twi, V, R, n1, n2, jrc_ilog2(n2), rows, tp);
+        JRC_HIP(ctx, hipGetLastError());
+    }
+    float2* out = (float2*)d_out;
+    if (cw == 32)
+        hipLaunchKernelGGL(td_col_inv_kernel<32>, dim3(n2 / 32, n_bursts * R), dim3(256), lds, s, (const float2*)h->d_g, out, (long)R * n, (long)n, self, (long)n,
+                           sc, accumulate_out ? 1 : 0, (const float2*)h->d_w1, (const float2*)h->d_two, pl, R, n);
+    else
+        hipLaunchKernelGGL(td_col_inv_kernel<16>, dim3(n2 / 16, n_bursts * R), dim3(256), lds, s, (const float2*)h->d_g, out, (long)R * n, (long)n, self, (long)n,
+                           sc, accumulate_out ? 1 : 0, (const float2*)h->d_w1, (const float2*)h->d_two, pl, R, n);
+    JRC_HIP(ctx, hipGetLastError());
+    return JRC_OK;
+}
+
 extern "C" int jrc_tsim_run_dev(jrc_tsim* h, int n_bursts, int n_input, const jrc_cf32* d_in, jrc_cf32* d_out,
                                 const jrc_cf32* target_phase, int accumulate_out, void* stream)
 {
@@ -1207,6 +1303,12 @@ extern "C" int jrc_tsim_run_dev(jrc_tsim* h, int n_bursts, int n_input, const jr
     }
     JRC_TRY(tsim_prepare(h, n, s));
     const bool use_phase = h->rndm_phaseshift && target_phase;
+    if (h->direct) {
+        jrc_tsim* one[1] = {h};
+        const jrc_cf32* ins[1] = {d_in};
+        const jrc_cf32* phs[1] = {use_phase ? target_phase : nullptr};
+        return tsim_run_direct(one, 1, n_bursts, n, ins, d_out, phs, accumulate_out, s);
+    }
     if (use_phase) JRC_HIP(ctx, hipMemcpyAsync(h->d_phase, target_phase, sizeof(float2) * (size_t)K, hipMemcpyHostToDevice, s));
     const float2* tw256 = nullptr;
     JRC_TRY(jrc_get_twiddles(ctx, TS_N1, -1, &tw256));
@@ -1214,66 +1316,6 @@ extern "C" int jrc_tsim_run_dev(jrc_tsim* h, int n_bursts, int n_input, const jr
     // as written in the reference every target overwrites the output buffer (:354-366), so only the last one is
     // observable; sum_targets accumulates them instead (in the middle kernel, between the two convolutions)
     const int k0 = h->sum_targets ? 0 : K - 1, Kz = K - k0;
-    if (h->direct) {
-        const td_plan pl = tsim_plan_of(h);
-        const int n1 = h->n1;
-        const int cw = td_pick_cw(n1, n2);
-        const size_t lds = td_col_lds_bytes(n1, cw);
-        const float2* ph = use_phase ? (const float2*)h->d_phase + k0 : (const float2*)nullptr;
-        if (cw == 32)
-            hipLaunchKernelGGL(td_col_fwd_kernel<32>, dim3(n2 / 32, n_bursts, Kz), dim3(256), lds, s, in, (long)n, (const float2*)h->d_dop + (size_t)k0 * n,
-                               h->d_u, (const float2*)h->d_w1, (const float2*)h->d_two, pl, n);
-        else
-            hipLaunchKernelGGL(td_col_fwd_kernel<16>, dim3(n2 / 16, n_bursts, Kz), dim3(256), lds, s, in, (long)n, (const float2*)h->d_dop + (size_t)k0 * n,
-                               h->d_u, (const float2*)h->d_w1, (const float2*)h->d_two, pl, n);
-        JRC_HIP(ctx, hipGetLastError());
-        const long rows = (long)n_bursts * n1;
-        if (n2 >= 256) {
-            const float2* twn2 = nullptr;
-            if (n2 > 256) JRC_TRY(jrc_get_twiddles(ctx, n2, -1, &twn2));
-            const int m = n2 / 256, rpb = 16 / m;                        // rows per workgroup
-            const dim3 grid((unsigned)((rows + rpb - 1) / rpb));
-            for (int l0 = 0; l0 < R;) {
-                // one target per launch: all R antennas out of one forward transform, one after the other (RC 0); a sum over targets keeps
-                // the antennas' spectra in accumulators, two antennas per launch
-                const int rc = (Kz == 1) ? 0 : ((R - l0 >= 2) ? 2 : 1);
-                const float2* tsp = (const float2*)h->d_ts + ((size_t)l0 * K + k0) * n;
-#define TD_ROWS(MM, RC_)                                                                                                                  \
-                hipLaunchKernelGGL((td_rows_m_kernel<MM, RC_>), grid, dim3(256), 0, s, (const float2*)h->d_u, h->d_g, tsp, (long)K * n, ph, tw256, \
-                                   twn2, Kz, R, l0, n1, rows)
-#define TD_ROWS_RC(MM) do { if (rc == 0) TD_ROWS(MM, 0); else if (rc == 2) TD_ROWS(MM, 2); else TD_ROWS(MM, 1); } while (0)
-                if (m == 1) {
-                    if (rc == 0) hipLaunchKernelGGL(td_rows256_kernel<0>, grid, dim3(256), 0, s, (const float2*)h->d_u, h->d_g, tsp, (long)K * n, ph, tw256, Kz, R, l0, n1, rows);
-                    else if (rc == 2) hipLaunchKernelGGL(td_rows256_kernel<2>, grid, dim3(256), 0, s, (const float2*)h->d_u, h->d_g, tsp, (long)K * n, ph, tw256, Kz, R, l0, n1, rows);
-                    else hipLaunchKernelGGL(td_rows256_kernel<1>, grid, dim3(256), 0, s, (const float2*)h->d_u, h->d_g, tsp, (long)K * n, ph, tw256, Kz, R, l0, n1, rows);
-                } else if (m == 2) TD_ROWS_RC(2);
-                else if (m == 4) TD_ROWS_RC(4);
-                else if (m == 8) TD_ROWS_RC(8);
-                else TD_ROWS_RC(16);
-#undef TD_ROWS_RC
-#undef TD_ROWS
-                JRC_HIP(ctx, hipGetLastError());
-                l0 += rc ? rc : R;
-            }
-        } else {
-            const float2 *twf = nullptr, *twi = nullptr;
-            JRC_TRY(jrc_get_twiddles(ctx, n2, -1, &twf));
-            JRC_TRY(jrc_get_twiddles(ctx, n2, +1, &twi));
-            const int tp = n2 / 4, per_block = 256 / tp;
-            const size_t lds_rows = sizeof(float2) * 3 * (size_t)n2 * per_block;
-            hipLaunchKernelGGL(td_rows_small_kernel, dim3((unsigned)((rows + per_block - 1) / per_block), R), dim3(256), lds_rows, s, (const float2*)h->d_u,
-                               h->d_g, (const float2*)h->d_ts + (size_t)k0 * n, (long)K * n, ph, twf, twi, Kz, R, n1, n2, jrc_ilog2(n2), rows, tp);
-            JRC_HIP(ctx, hipGetLastError());
-        }
-        if (cw == 32)
-            hipLaunchKernelGGL(td_col_inv_kernel<32>, dim3(n2 / 32, n_bursts * R), dim3(256), lds, s, (const float2*)h->d_g, out, (long)R * n, (long)n, in, (long)n,
-                               sc, h->self_coupling ? 1 : 0, accumulate_out ? 1 : 0, (const float2*)h->d_w1, (const float2*)h->d_two, pl, R, n);
-        else
-            hipLaunchKernelGGL(td_col_inv_kernel<16>, dim3(n2 / 16, n_bursts * R), dim3(256), lds, s, (const float2*)h->d_g, out, (long)R * n, (long)n, in, (long)n,
-                               sc, h->self_coupling ? 1 : 0, accumulate_out ? 1 : 0, (const float2*)h->d_w1, (const float2*)h->d_two, pl, R, n);
-        JRC_HIP(ctx, hipGetLastError());
-        return JRC_OK;
-    }
     const dim3 grid_first(n2 / TS_CW, n_bursts, Kz), grid_mid(n2 / TS_CW, n_bursts), grid_out(n2 / TS_CW, n_bursts * R);
     hipLaunchKernelGGL(tsim_col_first_kernel<false>, grid_first, dim3(256), 0, s, in, (long)n, (const float2*)h->d_dop + (size_t)k0 * n,
                        (const float2*)h->d_chirp, h->d_u, tw256, n, n2, M);
@@ -1299,6 +1341,47 @@ extern "C" int jrc_tsim_run_dev(jrc_tsim* h, int n_bursts, int n_input, const jr
                        (const float2*)h->d_chirp, in, (long)n, sc, h->self_coupling ? 1 : 0, accumulate_out ? 1 : 0, tw256, R, n, n2, M);
     JRC_HIP(ctx, hipGetLastError());
     return JRC_OK;
+}
+
+// Several simulators whose RX outputs a flowgraph adds (the target_simulator per TX port feeding one blocks_add_xx per RX antenna,
+// examples/simulation/radar/mimo_ofdm_jrc_radar_sim.grc): out_l (+)= sum_t sim_t(in_t)_l with the sum taken on the spectrum — one inverse
+// transform per RX antenna instead of one per (TX, RX) pair, the output written once.  Needs the direct route for this burst length and
+// simulators of one context with the same antenna count; anything else: JRC_ERR_UNSUPPORTED, and the caller runs them one by one with
+// accumulate_out (which is what this call equals, to the rounding of a float sum taken in another order).
+extern "C" int jrc_tsim_run_sum_dev(jrc_tsim* const* sims, int n_sims, int n_bursts, int n_input, const jrc_cf32* const* d_in, jrc_cf32* d_out,
+                                    const jrc_cf32* const* target_phase, int accumulate_out, void* stream)
+{
+    JRC_TRACE("jrc_tsim_run_sum_dev");
+    if (!sims || n_sims < 1 || !sims[0]) return JRC_ERR_INVALID_ARG;
+    jrc_ctx* ctx = sims[0]->ctx;
+    if (n_sims > TD_MAXSIMS) return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "jrc_tsim_run_sum_dev: at most %d simulators per call", TD_MAXSIMS);
+    if (n_bursts < 0 || n_input < 0 || !d_in || (n_bursts > 0 && n_input > 0 && !d_out))
+        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_tsim_run_sum_dev: invalid arguments");
+    for (int q = 0; q < n_sims; q++) {
+        if (!sims[q] || (n_bursts > 0 && n_input > 0 && !d_in[q])) return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "jrc_tsim_run_sum_dev: null simulator or input");
+        if (sims[q]->ctx != ctx || sims[q]->R != sims[0]->R)
+            return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "jrc_tsim_run_sum_dev: simulators of one context and one antenna count only");
+        if (sims[q]->K == 0) return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "jrc_tsim_run_sum_dev: a simulator without targets");
+        if (sims[q]->self_coupling && sims[q]->self_coupling_db != sims[0]->self_coupling_db)
+            return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "jrc_tsim_run_sum_dev: simulators with different self-coupling gains");
+        if (n_bursts > sims[q]->max_bursts)
+            return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "target_simulator: %d bursts exceed max_bursts %d", n_bursts, sims[q]->max_bursts);
+    }
+    if (sims[0]->self_coupling == 0)
+        for (int q = 1; q < n_sims; q++)
+            if (sims[q]->self_coupling && sims[q]->self_coupling_db != sims[0]->self_coupling_db)
+                return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "jrc_tsim_run_sum_dev: simulators with different self-coupling gains");
+    if (n_bursts == 0 || n_input == 0) return JRC_OK;
+    JRC_HIP(ctx, hipSetDevice(ctx->device));
+    JRC_BIND(ctx);
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    for (int q = 0; q < n_sims; q++) {
+        JRC_TRY(tsim_prepare(sims[q], n_input, s));
+        if (!sims[q]->direct)
+            return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "jrc_tsim_run_sum_dev: bursts of %d samples do not take the direct route (n = n1 x 2^a, 2^a >= 16, n1 <= %d)",
+                            n_input, TD_MAXSIMS * 0 + TD_MAX_N1);
+    }
+    return tsim_run_direct(sims, n_sims, n_bursts, n_input, d_in, d_out, target_phase, accumulate_out, s);
 }
 
 extern "C" int jrc_tsim_work(jrc_tsim* h, const jrc_cf32* in, int n_input, jrc_cf32* const* out, const jrc_cf32* target_phase)

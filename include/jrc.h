@@ -405,7 +405,9 @@ int  jrc_sig_encode(int n_data_carriers, int mcs, int packet_type, int length, f
 /* ---- target_simulator (lib/target_simulator_impl.cc:66-385; make() in
  * include/mimo_ofdm_jrc/target_simulator.h) — one input stream (a TX burst), n_rx output streams.  Per target k and
  * antenna l: out_l = IFFT_n(FFT_n(in . doppler_k) . timeshift_{l,k}) [. phase_k], + 10^(self_coupling_db/20) . in
- * when self_coupling.  n = burst length, any value up to 2^20 (chirp-z transforms on the device). ---- */
+ * when self_coupling.  n = burst length, any value up to 2^20: lengths n = n1 x 2^a with 2^a >= 16 and n1 <= 512 — every burst the
+ * flowgraphs produce, n_symbols x (fft_len + cp) with fft_len + cp = 5 x 2^k — are transformed directly as n1-point x 2^a-point
+ * four-step DFTs, all others as chirp-z transforms (JRC_TSIM_BLUESTEIN=1 forces those). ---- */
 typedef struct jrc_tsim jrc_tsim;
 typedef struct {
     int n_targets;                 /* range.size() (:160) */
@@ -439,6 +441,14 @@ int jrc_tsim_work(jrc_tsim* h, const jrc_cf32* in, int n_input, jrc_cf32* const*
  * examples/simulation/radar/mimo_ofdm_jrc_radar_sim.grc:2213-2220).  Asynchronous on `stream` (NULL = ctx stream). */
 int jrc_tsim_run_dev(jrc_tsim* h, int n_bursts, int n_input, const jrc_cf32* d_in, jrc_cf32* d_out,
                      const jrc_cf32* target_phase, int accumulate_out, void* stream);
+/* n_sims simulators whose RX outputs the flowgraph adds (one target_simulator per TX port into one blocks_add_xx per RX antenna,
+ * mimo_ofdm_jrc_radar_sim.grc:2213-2220) in ONE pass: d_out[b][l] (+)= sum_q sims[q](d_in[q][b])_l, the sum taken on the spectrum, so each
+ * RX antenna costs one inverse transform and one write of d_out whatever n_sims is.  Equals n_sims calls of jrc_tsim_run_dev with
+ * accumulate_out to the rounding of a float sum taken in another order.  d_in[q]: [n_bursts][n_input] of simulator q; target_phase[q]:
+ * that simulator's host phases or NULL (the array itself may be NULL).  Simulators of one context with the same n_rx, at most 8 of them and
+ * 32 (simulator, target) pairs; JRC_ERR_UNSUPPORTED when the burst length does not take the direct route (then run them one by one). */
+int jrc_tsim_run_sum_dev(jrc_tsim* const* sims, int n_sims, int n_bursts, int n_input, const jrc_cf32* const* d_in, jrc_cf32* d_out,
+                         const jrc_cf32* const* target_phase, int accumulate_out, void* stream);
 int jrc_tsim_burst_capacity(const jrc_tsim* h);
 
 /* ---- bit codec.  stream_encoder (lib/stream_encoder_impl.cc:76-270, make(mod_encode, data_len,

@@ -373,7 +373,8 @@ def test_radar_receive_graph_through_the_host_blocks_tags_and_consumption(jrc, c
     assert {k: v[0] for k, v in msg[0]["msg"]} == {"range": res.range_val, "angle": res.angle_val, "power": res.peak_power, "snr": res.snr_est}
 
 
-def test_device_resident_flowgraph_equals_the_block_by_block_graph(jrc, ctx):
+@pytest.mark.parametrize("summed", [True, False], ids=["simulators_summed_on_the_spectrum", "simulators_one_by_one"])
+def test_device_resident_flowgraph_equals_the_block_by_block_graph(jrc, ctx, monkeypatch, summed):
     """precoder -> OFDM modulator -> zero_pad -> target simulators -> A6+A7+A1 -> A2..A5 as one frame-batched leg that
     never leaves HBM (examples/radar_sim_device_resident.py: jrc_precoder_frames_dev, jrc_ofdm_mod_dev, jrc_zero_pad_strided_dev,
     jrc_tsim_run_dev, jrc_chain_run_td_dev) at config B's geometry, against the block-by-block graph of examples/radar_sim_flowgraph.py
@@ -383,7 +384,9 @@ def test_device_resident_flowgraph_equals_the_block_by_block_graph(jrc, ctx):
     o = tables_256(4)
     N, R, n_data, S, F = 256, 4, 60, 64, 5
     tg = dict(trgt_range=[10.0, 31.0], trgt_velocity=[0.0, 6.0], trgt_rcs_dbsm=[20.0, 24.0], trgt_angle=[20.0, -35.0])
+    monkeypatch.setenv("JRC_DRF_SUM_ON_SPECTRUM", "1" if summed else "0")        # jrc_tsim_run_sum_dev, or jrc_tsim_run_dev per TX port with accumulate_out
     sim = drm.DeviceResidentRadarSim(o, N, R, n_data, S, F, seed=40, ctx=ctx, **tg)
+    assert sim.sum_on_spectrum == summed
     rng = np.random.default_rng(77)
     nd = len(o["data_subcarriers"])
     syms = np.stack([qpsk(rng, n_data * nd) for _ in range(F)])
@@ -393,7 +396,8 @@ def test_device_resident_flowgraph_equals_the_block_by_block_graph(jrc, ctx):
     e = sim.edges(F)
     blk = fgm.RadarSimFlowgraph(o, ctx=ctx, N_rx=R, fft_len=N, N_sym_radar=S, fused_demod=True, **tg)
     assert blk.pad_tail == sim.pad_tail and blk.N_pre == sim.N_pre
-    rep = REPORT.setdefault("radar/device_resident_vs_blocks/config_B_4x4_N256_S64", {})
+    assert sim.sum_on_spectrum == summed                                         # (the summed pass was taken, not its fallback)
+    rep = REPORT.setdefault("radar/device_resident_vs_blocks/config_B_4x4_N256_S64" + ("/summed" if summed else "/one_by_one"), {})
     for f in range(F):
         pads = [e["bursts"][f, t, sim.n_in:] for t in range(sim.T)]
         assert all(0.007 < p.real.std() < 0.014 for p in pads)

@@ -170,6 +170,48 @@ def test_batched_device_form_accumulates_tx_simulators(jrc, ctx):
         sims[0].run_dev(d_in, d_out, B + 1, n)
 
 
+@pytest.mark.parametrize("n", [2000, 11520, 23040])
+@pytest.mark.parametrize("sum_targets", [False, True])
+def test_simulators_summed_on_the_spectrum(jrc, ctx, n, sum_targets):
+    """jrc_tsim_run_sum_dev: the simulators of the flowgraph's TX ports (same targets, other antenna positions) and the blocks_add_xx behind
+    them as one pass — against the oracle's sum, against the simulators run one by one with accumulate_out (equal to the rounding of the sum's
+    order), on top of a buffer that already holds something, with random phases and self coupling; and refused for a length outside the
+    direct route"""
+    import torch
+    B, T, R = 3, 3, 4
+    xs = [np.stack([burst(n, 100 * t + b + n) for b in range(B)]) for t in range(T)]
+    pos = [[p + 0.025 * t for p in POS4] for t in range(T)]
+    kw = dict(self_coupling_db=-25.0, rndm_phaseshift=True, self_coupling=True, sum_targets=sum_targets, max_bursts=B, ctx=ctx)
+    sims = [jrc.target_simulator(*TGT3, pos[t], FS, FC, seed=t, **kw) for t in range(T)]
+    phases = [g.draw_phases() for g in sims]
+    d_ins = [torch.from_numpy(x).cuda() for x in xs]
+    want = np.zeros((B, R, n), np.complex128)
+    for t in range(T):
+        o = oracle.TargetSimulator(*TGT3, pos[t], FS, FC, self_coupling_db=-25.0, rndm_phaseshift=True, self_coupling=True)
+        for b in range(B):
+            want[b] += o.work(xs[t][b], target_phase=phases[t], sum_targets=sum_targets)
+    d_out = torch.zeros((B, R, n), dtype=torch.complex64, device="cuda")
+    jrc.target_simulator.run_sum_dev(sims, d_ins, d_out, B, n, target_phases=phases)
+    ctx.sync()
+    got = d_out.cpu().numpy()
+    assert rel_err(got, want) < 2e-6
+    d_one = torch.zeros_like(d_out)
+    for t in range(T):
+        sims[t].run_dev(d_ins[t], d_one, B, n, target_phase=phases[t], accumulate_out=(t > 0))
+    ctx.sync()
+    assert rel_err(got, d_one.cpu().numpy()) < 2e-6
+    base = (np.arange(B * R * n, dtype=np.float32).reshape(B, R, n) % 5).astype(np.complex64)
+    d_acc = torch.from_numpy(base.copy()).cuda()
+    jrc.target_simulator.run_sum_dev(sims, d_ins, d_acc, B, n, target_phases=phases, accumulate_out=True)
+    ctx.sync()
+    assert rel_err(d_acc.cpu().numpy() - base, want) < 2e-5
+    with pytest.raises(jrc.JrcError) as e:                           # 5000 = 8 x 625: the chirp-z route, which has no summed form
+        jrc.target_simulator.run_sum_dev(sims, [d[:, :5000].contiguous() for d in d_ins], d_out, B, 5000)
+    assert e.value.status == jrc.JRC_ERR_UNSUPPORTED
+    with pytest.raises(ValueError):
+        jrc.target_simulator.run_sum_dev(sims, d_ins, d_out, B + 1, n)
+
+
 def test_synthetic_target_is_recovered_by_the_radar_chain(jrc, ctx):
     """simulator -> CP removal + FFT -> mimo_ofdm_radar -> range FFT: the peak sits at the simulated range"""
     N, cp, S = 64, 16, 16
