@@ -34,6 +34,13 @@ def timed(fn, steps=30, warm=5):
     return sorted(per)[1]
 
 
+def roof(alg_bytes_per_step, seconds_per_step):
+    """the three fields every secondary leg carries: algorithmic bytes of one step (inputs read once + outputs written once, SURVEY §8(d) counting),
+    their rate, and that rate against the 8 TB/s HBM peak (/opt/skills/guides/MI355X_MICROARCH.md)"""
+    g = alg_bytes_per_step / seconds_per_step / 1e9
+    return dict(algorithmic_bytes_per_step=int(alg_bytes_per_step), GBps_algorithmic=g, frac_of_hbm_peak=g / 8000.0)
+
+
 def radar_with_demod(cfg="B", F=256):
     sc = {"B": synth.config_B, "D": synth.config_D}[cfg]()
     Ir, Ia, P = 8, 16, sc.T * sc.R
@@ -62,7 +69,10 @@ def radar_with_demod(cfg="B", F=256):
     t_chain = timed(lambda: chain.run(bufs, F))
     d_tx = bufs["frames"][:, :sc.T].contiguous()
     t = timed(lambda: chain.run_td(bufs, d_tx, td, F, sc.cp))        # A6+A7+A1 in one kernel (jrc_chain_run_td_dev)
-    return dict(what="radar chain incl. RX OFDM demod (A6+A7+A1 one kernel, time-domain RX in) config %s" % cfg, frames_per_step=F,
+    # algorithmic bytes: the S radar symbols of the T reference ports (frequency domain) and of the R time-domain RX streams (with their cyclic
+    # prefixes) read once, the complex map written once
+    alg = F * ((sc.T * sc.S * sc.N + sc.R * sc.S * (sc.N + sc.cp)) * 8 + (sc.N * Ir) * (P * Ia) * 8)
+    return dict(what="radar chain incl. RX OFDM demod (A6+A7+A1 one kernel, time-domain RX in) config %s" % cfg, frames_per_step=F, **roof(alg, t),
                 ms_per_step=t * 1e3, frames_per_s=F / t, ms_per_step_separate_demod=t_unfused * 1e3,
                 frames_per_s_separate_demod=F / t_unfused, ms_chain_only=t_chain * 1e3, frames_per_s_chain_only=F / t_chain)
 
@@ -108,7 +118,7 @@ def detect_only(cfg="B", F=None, noise_only=False):
     alg = F * ((sc.T + sc.R) * sc.S * sc.N * 8 + 48)
     return dict(what="detect-only chain (no map stored; results bit-identical to map mode), config %s, %d frames per step%s" % (cfg, F, ", NOISE-ONLY frames (worst case of the pruned angle stage)" if noise_only else ""),
                 frames_per_step=F, ms_per_step=t * 1e3, frames_per_s=F / t, results_equal_map_mode=bool(same),
-                algorithmic_bytes_per_frame=alg // F, GBps_algorithmic=alg / t / 1e9, frac_of_hbm_peak=alg / t / 1e9 / 8000.0,
+                algorithmic_bytes_per_frame=alg // F, **roof(alg, t),
                 kernels_ms={"radar_chanest": kt["radar_chanest"], "fused_detect_plus_window": kt["range_angle_fused"], "ra_finalize": kt["ra_finalize"]},
                 ms_per_step_map_mode=t_map * 1e3, ms_per_step_kernels_in_series=t_serial * 1e3)
 
@@ -135,7 +145,7 @@ def power_map(cfg="B", F=None):
     kt = chain.get_timing()
     alg = F * ((sc.T + sc.R) * sc.S * sc.N * 8 + chain.NR * chain.NA * 4 + 48)
     return dict(what="chain with the map as float |z|^2 (heat-map stream), config %s, %d frames per step" % (cfg, F), frames_per_step=F,
-                ms_per_step=t * 1e3, frames_per_s=F / t, algorithmic_bytes_per_frame=alg // F, GBps_algorithmic=alg / t / 1e9,
+                ms_per_step=t * 1e3, frames_per_s=F / t, algorithmic_bytes_per_frame=alg // F, **roof(alg, t),
                 kernels_ms={"radar_chanest": kt["radar_chanest"], "fused_power_plus_window": kt["range_angle_fused"], "ra_finalize": kt["ra_finalize"]})
 
 
@@ -162,7 +172,7 @@ def range_doppler(cfg="D", F=8, Id=1):
     t = timed(step, steps=10, warm=2)
     alg = F * ((sc.T + sc.R) * sc.S * sc.N * 8 + P * chain.NR * sc.S * Id * 8)
     return dict(what="range-Doppler map (row D, build's own definition) config %s: %d pairs x %d range bins x %d Doppler bins per frame" % (cfg, P, chain.NR, sc.S * Id),
-                frames_per_step=F, ms_per_step=t * 1e3, frames_per_s=F / t, GBps_algorithmic=alg / t / 1e9)
+                frames_per_step=F, ms_per_step=t * 1e3, frames_per_s=F / t, **roof(alg, t))
 
 
 def simulated_chain(cfg="B", F=64):
@@ -212,9 +222,17 @@ def device_resident_flowgraph(F=64):
     sim.load_symbols(np.stack([drm.qpsk_symbols(rng, 60 * sim.nd) for _ in range(F)]))
     t = timed(lambda: sim.step(F), steps=12, warm=3)
     r = sim.results(F)[0]
+    # algorithmic bytes of a pass = what has to cross HBM if every block of the graph read its input once and wrote its output once, block by
+    # block (the graph's edges are the reference's stream buffers): symbols in, TX frequency-domain frames, TX time-domain, padded bursts, RX bursts, map
+    T, R, N = sim.T, sim.R, sim.N
+    edges = dict(symbols=sim.n_data * sim.nd, tx_f=T * sim.n_total * N, tx_t=T * sim.n_in, bursts=T * sim.n_burst, rx_t=R * sim.n_burst,
+                 map=(N * 8) * (T * R * 16))
+    alg = F * 8 * (edges["symbols"] + 2 * edges["tx_f"] + 2 * edges["tx_t"] + 2 * edges["bursts"] + 2 * edges["rx_t"] + edges["map"])
+    alg_what = "every edge of the graph written once and read once (symbols, tx_f, tx_t, bursts, rx_t) + the map written: %s cf32 per packet" % edges
     return dict(what="device-resident simulation flowgraph, config B geometry (4x4, 256 subcarriers, radar window 64 symbols, %d-sample bursts): "
                      "precoder -> OFDM mod -> zero_pad -> 4 target simulators -> RX demod + A1 -> A2..A5, %d packets per pass, no host hop" % (sim.n_burst, F),
-                frames_per_step=F, ms_per_step=t * 1e3, frames_per_s=F / t, packet0=dict(range_m=r.range_val, angle_deg=r.angle_val, snr_db=r.snr_est))
+                frames_per_step=F, ms_per_step=t * 1e3, frames_per_s=F / t, **roof(alg, t), algorithmic_bytes_what=alg_what,
+                simulators_summed_on_the_spectrum=bool(sim.sum_on_spectrum), packet0=dict(range_m=r.range_val, angle_deg=r.angle_val, snr_db=r.snr_est))
 
 
 def sync_front_end(n_frames=512):
@@ -227,7 +245,8 @@ def sync_front_end(n_frames=512):
     nsamp = int(line.split()[2])
     nf = int(line.split("frames found")[0].split(",")[-1])
     return dict(what="sync front end (metrics + frame_detector + frame_sync) on a %d-sample capture with %d frames" % (nsamp, nf),
-                ms_per_capture=ms, M_samples_per_s=nsamp / ms / 1e3, frames_per_s=nf / ms * 1e3)
+                ms_per_capture=ms, M_samples_per_s=nsamp / ms / 1e3, frames_per_s=nf / ms * 1e3,
+                algorithmic_bytes_what="the capture read once (8 B per sample); the frames' symbols written are < 10 % of it", **roof(nsamp * 8, ms * 1e-3))
 
 
 def comm_rx_chain(n_frames=4096):
@@ -235,7 +254,11 @@ def comm_rx_chain(n_frames=4096):
     import subprocess
     out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "comm_rx_probe.py"), "--frames", str(n_frames), "--json"],
                          capture_output=True, text=True).stdout.strip().splitlines()
-    return json.loads([l for l in out if l.startswith("{")][-1])
+    r = json.loads([l for l in out if l.startswith("{")][-1])
+    if "M_samples_per_s" in r and "frames_per_s" in r and r.get("frames"):
+        sec = r["frames"] / r["frames_per_s"]
+        r.update(algorithmic_bytes_what="the capture read once (8 B per sample); decoded payloads are bytes per frame", **roof(r["M_samples_per_s"] * 1e6 * sec * 8, sec))
+    return r
 
 
 def precoder_config_c(n_frames=2048):
@@ -264,7 +287,7 @@ def precoder_config_c(n_frames=2048):
     for name, kw in (("dft", {}), ("per-subcarrier steering + radar streams", dict(steer_mode=2, d_Q_sc=d_q, d_radar_streams=d_rs))):
         t = timed(lambda: pre.frames_dev(d_in, 2, 2, nbytes, d_out=d_out, **kw), steps=20, warm=3)
         byts = d_in.numel() * 4 + d_out.numel() * 4 + (d_rs.numel() * 4 if kw else 0)
-        out[name] = dict(ms_per_step=t * 1e3, frames_per_s=n_frames / t, GBps=byts / t / 1e9)
+        out[name] = dict(ms_per_step=t * 1e3, frames_per_s=n_frames / t, GBps=byts / t / 1e9, **roof(byts, t))
     return dict(what="precoder config C: %d packets x 4 TX, 73 symbols x 256 sc, DATA" % n_frames, **{k.replace(" ", "_"): v for k, v in out.items()})
 
 
@@ -313,7 +336,7 @@ def equalizer_config_c(n_frames=2048, lanes=4, S=64, N=256):
     t = timed(lambda: eq.frames_dev(d_in, d_ph, n_sym, ns))
     byts = streams * (n_sym * N * 8 + ns * nd * 8)
     return dict(what="equalizer config C: %d frames x %d RX lanes, %d symbols x %d sc, LS, DATA" % (n_frames, lanes, n_sym, N),
-                ms_per_step=t * 1e3, frames_per_s=n_frames / t, lane_frames_per_s=streams / t, GBps=byts / t / 1e9,
+                ms_per_step=t * 1e3, frames_per_s=n_frames / t, lane_frames_per_s=streams / t, GBps=byts / t / 1e9, **roof(byts, t),
                 symbol_error_vs_tx=float(err))
 
 

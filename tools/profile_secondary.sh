@@ -3,7 +3,8 @@
 # `rocprofv3 --kernel-trace --stats` pass plus separate PMC passes (FETCH_SIZE, WRITE_SIZE, two sets of SQ counters); the program
 # comes directly after `--`.  usage: tools/profile_secondary.sh TAG "leg[:ENV=VAL] ..."   -> gpurun_out/prof_TAG/<name>_rocprof_summary.csv
 TAG=${1:-r03}
-LEGS=${2:-"detectB detectB_unpruned:JRC_DETECT_EXP=8 powerB equalizer precoder rdD"}
+# default: one summary per secondary key of bench.py's line that has kernels of its own
+LEGS=${2:-"demodB detectB detectB_noise powerB flowgraphB equalizer precoder rdD"}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
