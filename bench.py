@@ -601,8 +601,10 @@ def flowgraph_shape_host_fed(ctx, seconds=1.0):
             out[pre + "every_packet_accounted_for"] = out[pre + "frames_done"] == turns * 64
             L.jrcb_destroy(h)
 
-        run_block(16, 3, "radar_chain_block_")                       # the block's defaults (frames_per_batch 16, three batches in flight)
-        run_block(32, 3, "radar_chain_block_32_per_batch_")
+        run_block(0, 0, "radar_chain_block_")                        # the block's defaults (make(): frames_per_batch, batches_in_flight)
+        for combo in os.environ.get("JRC_BENCH_BLOCK_COMBOS", "16x3,32x3").split(","):   # other (frames per batch) x (batches in flight)
+            fpb, slots = (int(v) for v in combo.split("x"))
+            run_block(fpb, slots, "radar_chain_block_%d_per_batch_%d_in_flight_" % (fpb, slots))
     # (4) the CPU port on the same packets, one core
     import oracle
     n_cpu, t0 = 0, time.perf_counter()
