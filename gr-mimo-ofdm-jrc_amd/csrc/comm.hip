@@ -123,7 +123,8 @@ extern "C" int jrc_sig_encode(int n_data, int mcs, int packet_type, int length, 
 struct EqDev {
     int N, cp, ND, NP, NAct, NL, T, mapped_cols, n_pilot_rows, estimator, lds_tables;
     int exp;            // timing experiments of DESIGN.md §6 — WRONG RESULTS, so only in builds with -DJRC_TIMING_EXPERIMENTS (tools/ra_variants.py), where JRC_EQ_EXP selects:
-                        // 1 = the pilot phase reads the batch's first symbol for every symbol; 2 = the MIMO-LTF symbols are not stored to / read from HBM
+                        // 1 = the pilot phase reads the batch's first symbol for every symbol; 2 = the MIMO-LTF symbols are not stored to / read from HBM;
+                        // 3 = the equalisation phase reads the batch's first row for every symbol; 4 = no pilot phase; 5 = the equalisation phase stores its input cells; 6 = it stores nothing; 7 = it stores through the caches
     int sig_full;       // JRC_EQ_SIG_FULL: always run the windowed Viterbi on the SIG field (no codeword shortcut)
     double freq, bw;
     const int* data_c; const int* pilot_c; const int* active_c;
@@ -356,6 +357,9 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
                 const int ptype = S.packet_type;
                 const float2* Hsel = ptype == 1 ? H : Hm;
                 const double eps = S.epsilon0 + S.er;
+                if (EQ_EXP(d) == 4) {                                                   // timing experiment: no pilot phase at all
+                    for (int j = tid; j < nb; j += NT) { s_brot[j] = make_float2(1.f, 0.f); s_bsig[j] = 1.0; s_bnoi[j] = 1e-3; }
+                } else
                 if (NP <= 64) {                                                         // (A) 64 / G symbols per wavefront pass, G = NP rounded up
                     const int G = NP <= 1 ? 1 : (1 << (32 - __clz(NP - 1)));            //     to a power of two lanes per symbol
                     const int spw = 64 / G, kk = ln & (G - 1), sl = ln / G;
@@ -438,7 +442,7 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
                     hv[e] = Hsel[scv[e]];
                     hm2[e] = (double)c_mul(hv[e], c_conj(hv[e])).x;
 #pragma unroll
-                    for (int q = 0; q < EQ_PD; q++) xq[q][e] = in[(size_t)(n_in + min(q, nb - 1)) * N + scv[e]];
+                    for (int q = 0; q < EQ_PD; q++) xq[q][e] = in[(size_t)(n_in + (EQ_EXP(d) == 3 ? 0 : min(q, nb - 1))) * N + scv[e]];
                 }
                 // The rotation angle of a cell is k0 (sc - N/2) with |sc - N/2| <= N/2 and |k0| growing with the symbol index: when the last
                 // symbol's k0 * N/2 rounds to at most pi/4 every angle of the batch does (rounding is monotonic), and the loop runs on
@@ -454,7 +458,7 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
                             const int j = j0 + q;
                             if (j >= nb) break;
                             float2 xc[EPT];
-                            const size_t nxt = (size_t)(n_in + min(j + EQ_PD, nb - 1)) * N;
+                            const size_t nxt = (size_t)(n_in + (EQ_EXP(d) == 3 ? 0 : min(j + EQ_PD, nb - 1))) * N;   // (3: timing experiment, every symbol reads the batch's first row)
 #pragma unroll
                             for (int e = 0; e < EPT; e++) {
                                 xc[e] = xq[q][e];
@@ -469,6 +473,8 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
                                 const double ang = k0 * (scv[e] - N / 2);
                                 const float2 yr = c_mul(c_mul(xc[e], small ? c_expj_small(ang) : c_expj(ang)), rot);
                                 float2 z;
+                                if (EQ_EXP(d) == 5) z = xc[e];                          // timing experiment: no arithmetic on the cell
+                                else
                                 if constexpr (pt == 1) z = c_div(yr, hv[e]);            // symbol_equalize :900-906
                                 else {                                                  // :540-550
                                     const float csi = (float)(hm2[e] + nvar);
@@ -477,6 +483,9 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
                                 }
                                 typedef float v2f __attribute__((ext_vector_type(2)));     // :602; write-once output: around the caches
                                 const v2f zz = {z.x, z.y};
+                                if (EQ_EXP(d) == 6) { if (z.x == 1.2345e30f) o[oi[e]] = z; }   // timing experiment: (practically) no stores
+                                else if (EQ_EXP(d) == 7) o[oi[e]] = z;                         // timing experiment: cached stores
+                                else
                                 __builtin_nontemporal_store(zz, reinterpret_cast<v2f*>(o + oi[e]));
                             }
                         }
