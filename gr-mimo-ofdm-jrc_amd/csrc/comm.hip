@@ -126,7 +126,6 @@ struct EqDev {
                         // 1 = the pilot phase reads the batch's first symbol for every symbol; 2 = the MIMO-LTF symbols are not stored to / read from HBM;
                         // 3 = the equalisation phase reads the batch's first row for every symbol; 4 = no pilot phase; 5 = the equalisation phase stores its input cells; 6 = it stores nothing; 7 = it stores through the caches
     int sig_full;       // JRC_EQ_SIG_FULL: always run the windowed Viterbi on the SIG field (no codeword shortcut)
-    int ring_off, ring_rows, ptab_off;   // split data phase (SPLIT kernels): byte offsets of the input-row ring and of the staged pilot table in dynamic LDS
     double freq, bw;
     const int* data_c; const int* pilot_c; const int* active_c;
     const float2* pilot_sym; const float2* ltf; const float2* mapped;
@@ -248,9 +247,6 @@ __device__ __forceinline__ unsigned sig_viterbi_wave(const float2* Z, int ND, un
     return sig;
 }
 
-#ifndef EQ_SPLIT_WPE
-#define EQ_SPLIT_WPE 4   // waves per SIMD the split kernels are compiled for (128 VGPRs)
-#endif
 #ifndef EQ_BATCH
 #define EQ_BATCH 64   // data symbols per three-phase pass of the equalizer
 #endif
@@ -258,51 +254,8 @@ __device__ __forceinline__ unsigned sig_viterbi_wave(const float2* Z, int ND, un
 #define EQ_PD 2       // input symbols in flight per lane in the equalisation phase (measured at config C once the loop had no branch around its loads: 1: 0.602-0.613 ms, 2: 0.593-0.599, 3: 0.596, 4: 0.602-0.65 with 31 spilled registers)
 #endif
 
-// ---- split data phase (round 5): LDS-DMA row ring, a loader wave and a worker wave ---------------------------------------------------------
-// gfx950's memory counter is in order and shared by loads and stores: a wave that streams rows in AND symbols out waits for its older stores
-// whenever it waits for a row, and every row costs it a round trip at two symbols of prefetch (profiles/r05_equalizer_experiments.txt).
-// In the split form a lane-frame is two waves: the LOADER issues `global_load_lds_dwordx4` of whole input rows into a ring in LDS (no VGPR,
-// its counter holds loads only, so it can wait for exactly the row it needs while the next rows are in flight), does the row's pilot work
-// (residual-CFO rotation, signal / noise terms, the running sums in symbol order) from the staged row and publishes (rotation, noise) of the
-// symbol; the WORKER takes the row's data cells from LDS, equalises and stores them — its counter holds stores only and is never waited on.
-// Rows cross HBM once (the pilot cells are read from the staged row).  The two waves meet through two LDS counters (rows ready, rows consumed).
-__device__ __forceinline__ unsigned lds_byte_address(const void* p)
-{
-    return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(p);
-}
-// one wave-wide 1 KiB piece: lane l's 16 bytes at gsrc land at lds_dst + 16 l.  The compiler does not count this load (asm): the issuing
-// code keeps its own count and waits with eq_wait_vm.
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst /* wave-uniform */)
-{
-    unsigned keep;
-    lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);          // an SGPR operand: uniformity of the computed address is not provable
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-__device__ __forceinline__ void eq_wait_vm(int outstanding)      // at most `outstanding` vector memory operations of this wave still in flight
-{
-    switch (outstanding) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
-        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
-        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
-    }
-}
-
 // NTMAX = workgroup size the variant is compiled for, WPE = waves per SIMD it must allow (register budget 512 / WPE)
-template <int NTMAX, int WPE, int EPT /* subcarriers per lane: fft_len <= EPT * blockDim */, int SPLIT = 0 /* 1: two waves per lane-frame, split data phase */>
+template <int NTMAX, int WPE, int EPT /* subcarriers per lane: fft_len <= EPT * blockDim */>
 __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState* states, float2* H_all, float2* Hm_all,
                                                          float2* pre_all, EqIo io)
 {
@@ -346,10 +299,6 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
     for (int i = tid; i < ND; i += NT) dc[i] = d.data_c[i];
     for (int i = tid; i < NP; i += NT) pc[i] = d.pilot_c[i];
     for (int i = tid; i < d.NAct; i += NT) ac[i] = d.active_c[i];
-    if constexpr (SPLIT != 0) {
-        float2* ptab_w = reinterpret_cast<float2*>(eq_smem + d.ptab_off);
-        for (int i = tid; i < d.n_pilot_rows * NP; i += NT) ptab_w[i] = d.pilot_sym[i];
-    }
     __syncthreads();
 
     int n_in = 0, n_out = 0, nev = 0, ce_written = 0, advance = 0;
@@ -403,147 +352,7 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
                     }
                 nb = min(nb, EQ_BATCH);
             }
-            if constexpr (SPLIT != 0) {
-                if (nb >= 2 && NT == 128 && (N == 256 || N == 128) && ND <= 256 && NP <= 8 && d.ring_rows >= 2 && (reinterpret_cast<size_t>(in) & 15) == 0) {
-                    __shared__ int s_ready, s_cons;
-                    const int ln = tid & 63, wv = tid >> 6;
-                    const int ptype = S.packet_type;
-                    const float2* Hsel = ptype == 1 ? H : Hm;
-                    const double eps = S.epsilon0 + S.er;
-                    float2* ring = reinterpret_cast<float2*>(eq_smem + d.ring_off);
-                    const float2* ptab = reinterpret_cast<const float2*>(eq_smem + d.ptab_off);      // the whole pilot table, staged at kernel entry
-                    const int RING = d.ring_rows, PARTS = N / 128;                                    // 1 KiB pieces per row
-                    if (tid == 0) { s_ready = 0; s_cons = 0; }
-                    __syncthreads();
-                    if (wv == 1) {
-                        // ---- loader: the batch's pilot work first (phases A and B of the one-wave form: its pilot cells with ordinary loads, all of
-                        // them in flight at once, eight symbols per pass over the wave), then nothing but keeping the ring of rows full ----
-                        const int G = NP <= 1 ? 1 : (1 << (32 - __clz(NP - 1)));                          // NP <= 8 here: G <= 8, at most 8 passes of 64 / G symbols
-                        const int spw = 64 / G, kk = ln & (G - 1), sl = ln / G;
-                        const int kc = kk < NP ? kk : 0;
-                        const int c = pc[kc];
-                        const float2 hc = Hsel[c];
-                        const unsigned ring_base = __builtin_amdgcn_readfirstlane(lds_byte_address(ring));
-                        const char* src0 = reinterpret_cast<const char*>(in + (size_t)n_in * N) + ln * 16;
-                        float2 raw[8];
-#pragma unroll
-                        for (int p8 = 0; p8 < 8; p8++) raw[p8] = in[(size_t)(n_in + min(p8 * spw + sl, nb - 1)) * N + c];
-                        int issued = 0;
-                        for (; issued < nb && issued < RING; issued++) {
-                            const char* src = src0 + (size_t)issued * N * 8;
-                            const unsigned dst = ring_base + (unsigned)(issued * N * 8);
-                            for (int part = 0; part < PARTS; part++) glds16(src + part * 1024, dst + part * 1024);
-                        }
-#pragma unroll
-                        for (int p8 = 0; p8 < 8; p8++) {
-                            const int j = p8 * spw + sl;
-                            if (p8 * spw >= nb) break;
-                            const bool on = j < nb && kk < NP;
-                            const int sy = sym + min(j, nb - 1);
-                            const float2 pk = ptab[(size_t)((sy - 3 - NL) % d.n_pilot_rows) * NP + kc];
-                            const double k0 = 2 * M_PI * sy * ((N + d.cp) * 1.0 / N) * eps;
-                            const float2 yk = c_mul(raw[p8], c_expj(k0 * (c - N / 2)));
-                            const float2 e = c_mul(hc, pk);
-                            float2 sum = make_float2(0.f, 0.f);
-                            if (on) { const float2 pp = c_mul(yk, c_conj(e)); sum.x = sum.x + pp.x; sum.y = sum.y + pp.y; }
-                            for (int off = G >> 1; off > 0; off >>= 1) { sum.x += __shfl_xor(sum.x, off); sum.y += __shfl_xor(sum.y, off); }
-                            const float2 r0 = c_expj(-(double)atan2f(sum.y, sum.x));
-                            double sig = 0, noi = 0;
-                            if (on) {
-                                sig += (double)c_mul(e, c_conj(e)).x;
-                                const float2 yr = c_mul(yk, r0);
-                                const float2 er = make_float2(e.x - yr.x, e.y - yr.y);
-                                noi += (double)c_mul(er, c_conj(er)).x;
-                            }
-                            for (int off = G >> 1; off > 0; off >>= 1) { sig += __shfl_xor(sig, off); noi += __shfl_xor(noi, off); }
-                            if (kk == 0 && j < nb) { s_brot[j] = r0; s_bsig[j] = sig; s_bnoi[j] = noi; }
-                        }
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        if (ln == 0) {                                                                    // (B): the running sums, symbol after symbol (:484-493, :545)
-                            for (int j = 0; j < nb; j++) {
-                                S.signal_power_sum += s_bsig[j]; S.noise_power_sum += s_bnoi[j]; S.snr_est_count += NP;
-                                s_bnoi[j] = S.noise_power_sum / S.snr_est_count;
-                            }
-                            S.symbol_ind = sym + nb - 1;
-                        }
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        for (int j = 0; j < nb; j++) {
-                            for (;;) {
-                                const int cons = *(volatile int*)&s_cons;
-                                while (issued < nb && issued < cons + RING) {
-                                    const char* src = src0 + (size_t)issued * N * 8;
-                                    const unsigned dst = ring_base + (unsigned)((issued % RING) * N * 8);
-                                    for (int part = 0; part < PARTS; part++) glds16(src + part * 1024, dst + part * 1024);
-                                    issued++;
-                                }
-                                if (issued > j) break;
-                                __builtin_amdgcn_s_sleep(1);
-                            }
-                            eq_wait_vm((issued - j - 1) * PARTS);                                         // row j has landed; later rows stay in flight
-                            if (ln == 0) *(volatile int*)&s_ready = j + 1;
-                        }
-                    } else {
-                        // ---- worker: the data cells of each staged row, equalised and stored; never waits on the memory counter ----
-                        constexpr int WE = 4;
-                        int scv[WE], oi[WE];
-                        float2 hv[WE];
-                        double hm2[WE];
-#pragma unroll
-                        for (int e = 0; e < WE; e++) {
-                            oi[e] = min(ln + e * 64, ND - 1);
-                            scv[e] = dc[oi[e]];
-                            hv[e] = Hsel[scv[e]];
-                            hm2[e] = (double)c_mul(hv[e], c_conj(hv[e])).x;
-                        }
-                        const double k0_last = 2 * M_PI * (sym + nb - 1) * ((N + d.cp) * 1.0 / N) * eps;
-                        const bool all_small = fabsf((float)(k0_last * (N / 2))) <= 0.78539816f;
-                        auto equalise = [&](auto PT, auto SMALL) {
-                            constexpr int pt = decltype(PT)::value;
-                            constexpr bool small = decltype(SMALL)::value;
-                            for (int j = 0; j < nb; j++) {
-                                while (*(volatile int*)&s_ready <= j) __builtin_amdgcn_s_sleep(1);
-                                asm volatile("" ::: "memory");
-                                const float2* row = ring + (size_t)(j % RING) * N;
-                                float2 xc[WE];
-#pragma unroll
-                                for (int e = 0; e < WE; e++) xc[e] = row[scv[e]];
-                                const float2 rot = s_brot[j];
-                                const double nvar = s_bnoi[j];
-                                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                                if (ln == 0) *(volatile int*)&s_cons = j + 1;                             // the slot may be refilled
-                                const double k0 = 2 * M_PI * (sym + j) * ((N + d.cp) * 1.0 / N) * eps;
-                                float2* o = out + (size_t)(n_out + j) * ND;
-#pragma unroll
-                                for (int e = 0; e < WE; e++) {
-                                    const double ang = k0 * (scv[e] - N / 2);
-                                    const float2 yr = c_mul(c_mul(xc[e], small ? c_expj_small(ang) : c_expj(ang)), rot);
-                                    float2 z;
-                                    if constexpr (pt == 1) z = c_div(yr, hv[e]);                        // symbol_equalize :900-906
-                                    else {                                                              // :540-550
-                                        const float csi = (float)(hm2[e] + nvar);
-                                        const float2 num = c_mul(yr, c_conj(hv[e]));
-                                        z = make_float2(num.x / csi, num.y / csi);
-                                    }
-                                    typedef float v2f __attribute__((ext_vector_type(2)));
-                                    const v2f zz = {z.x, z.y};
-                                    __builtin_nontemporal_store(zz, reinterpret_cast<v2f*>(o + oi[e]));
-                                }
-                            }
-                        };
-                        if (all_small) {
-                            if (ptype == 1) equalise(std::integral_constant<int, 1>{}, std::true_type{}); else equalise(std::integral_constant<int, 2>{}, std::true_type{});
-                        } else {
-                            if (ptype == 1) equalise(std::integral_constant<int, 1>{}, std::false_type{}); else equalise(std::integral_constant<int, 2>{}, std::false_type{});
-                        }
-                    }
-                    n_in += nb; n_out += nb; advance = 1;
-                    __syncthreads();
-#pragma unroll
-                    for (int e = 0; e < EPT; e++) { const int i = tid + e * NT; if (i < N && n_in < io.ninput) xin[e] = in[(size_t)n_in * N + i]; }
-                    continue;
-                }
-            }
-            if (SPLIT == 0 && nb >= 2) {        // (a SPLIT kernel whose input is not 16-byte aligned takes its symbols one at a time below)
+            if (nb >= 2) {
                 const int ln = tid & 63, wv = tid >> 6, NW = NT >> 6;
                 const int ptype = S.packet_type;
                 const float2* Hsel = ptype == 1 ? H : Hm;
@@ -957,7 +766,6 @@ struct jrc_equalizer {
     float2 *H = nullptr, *Hm = nullptr, *pre = nullptr;
     int* counters = nullptr;     // [n_streams][4]: n_out, n_consumed, n_events, chan_est_written
     size_t lds_bytes;
-    size_t lds_bytes_split = 0;  // dynamic LDS of the SPLIT kernels (0: this configuration has no split form)
     int threads;
 };
 
@@ -1029,23 +837,6 @@ extern "C" int jrc_equalizer_create(jrc_ctx* ctx, const jrc_eq_cfg* c, int n_str
         d.lds_tables = (int)off;
         eq->lds_bytes = off + sizeof(int) * (size_t)(ND + NP + ac.size() + 1) + sizeof(float2) * (size_t)(N + NP) + 16;
     }
-    {
-        // split data phase (two waves per lane-frame): behind the ordinary layout a staged copy of the pilot table and the ring of input rows.
-        // JRC_EQ_RING = rows of the ring (default 4; 0 switches the split form off)
-        int ring = 4;
-        if (const char* e = getenv("JRC_EQ_RING")) ring = atoi(e);
-        const size_t ptab = sizeof(float2) * (size_t)c->n_pilot_rows * NP;
-        d.ring_rows = 0; d.ring_off = d.ptab_off = 0;
-        if (ring >= 2 && ring <= 16 && (N == 256 || N == 128) && ND <= 256 && NP <= 8 && ptab <= 8192) {
-            size_t off = (eq->lds_bytes + 15) & ~size_t(15);
-            d.ptab_off = (int)off;
-            off = (off + ptab + 15) & ~size_t(15);
-            d.ring_off = (int)off;
-            d.ring_rows = ring;
-            eq->lds_bytes_split = off + sizeof(float2) * (size_t)ring * N;
-            JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)equalizer_kernel<128, EQ_SPLIT_WPE, 2, 1>, eq->lds_bytes_split));
-        }
-    }
     JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)equalizer_kernel<1024, 4, 4>, eq->lds_bytes));
     JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)equalizer_kernel<1024, 4, 1>, eq->lds_bytes));
     JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)equalizer_kernel<256, 4, 1>, eq->lds_bytes));
@@ -1074,11 +865,6 @@ static void launch_equalizer(jrc_equalizer* eq, int grid, hipStream_t s, const E
     else if (forced == 0 && N > 64 && N <= 1024 && grid >= eq->ctx->n_cus) {
         threads = N <= 128 ? 64 : ((N / 4 + 63) / 64) * 64;
         if (!wpe) wpe = 2;
-    }
-    // the split form: batched launches (a workgroup per CU and more) of the LS estimator at fft_len 128 / 256; JRC_EQ_SPLIT=0 keeps the one-wave form
-    if (forced == 0 && eq->lds_bytes_split && eq->d.estimator == 0 && grid >= eq->ctx->n_cus && !(getenv("JRC_EQ_SPLIT") && atoi(getenv("JRC_EQ_SPLIT")) == 0)) {
-        hipLaunchKernelGGL((equalizer_kernel<128, EQ_SPLIT_WPE, 2, 1>), dim3(grid), dim3(128), eq->lds_bytes_split, s, eq->d, eq->states, eq->H, eq->Hm, eq->pre, io);
-        return;
     }
     if (!wpe) wpe = threads <= 64 ? 2 : 4;      // a single wavefront (fft_len <= 64): 171 VGPRs without spills beat 128 with 29 (comm receive chain, 1024 frames: 0.56 -> 0.53 ms)
 #define EQ_LAUNCH(NTM, W, E) hipLaunchKernelGGL((equalizer_kernel<NTM, W, E>), dim3(grid), dim3(threads), eq->lds_bytes, s, eq->d, eq->states, eq->H, eq->Hm, eq->pre, io)
@@ -1195,165 +981,6 @@ extern "C" int jrc_equalizer_frames_dev(jrc_equalizer* eq, int n_streams, int n_
     io.n_out = d_n_out; io.n_consumed = eq->counters; io.n_events = eq->counters + eq->n_streams;
     io.chan_est_written = nullptr; io.events = d_events; io.max_events = 2; io.chan_est = nullptr; io.stream0 = 0;
     launch_equalizer(eq, n_streams, s, io);
-    JRC_HIP(ctx, hipGetLastError());
-    return JRC_OK;
-}
-
-// ---- PROTOTYPE (round 5, attempt 2 on the equalizer): the data phase of an LS frame as a kernel of its own ------------------------------------
-// The monolithic kernel's head sections set its register budget (256 VGPRs without spills, two waves per SIMD); this kernel is only the
-// split data phase (loader wave + worker wave over an LDS-DMA ring, see above) and reads the stream state a head-only launch left in HBM.
-// Timing prototype behind jrc_equalizer_data_proto_dev (not part of include/jrc.h): one batch of <= EQ_BATCH symbols, no epilogue.
-template <int RING>
-__global__ __launch_bounds__(128, 4) void eq_data_proto_kernel(EqDev d, const EqState* __restrict__ states, const float2* __restrict__ H_all,
-                                                               const float2* __restrict__ Hm_all, const float2* __restrict__ in_all, long in_stride,
-                                                               int first, int nb, float2* __restrict__ out_all, long out_stride)
-{
-#pragma clang fp contract(off)
-    __shared__ __attribute__((aligned(16))) float2 ring[RING * 256];
-    __shared__ float2 s_brot[EQ_BATCH];
-    __shared__ double s_bsig[EQ_BATCH], s_bnoi[EQ_BATCH];
-    __shared__ int s_ready, s_cons;
-    const int N = d.N, ND = d.ND, NP = d.NP, NL = d.NL;
-    const int tid = threadIdx.x, ln = tid & 63, wv = tid >> 6;
-    const size_t b = blockIdx.x;
-    const EqState* S = states + b;
-    const int sym = S->symbol_ind, ptype = S->packet_type;
-    const float2* Hsel = (ptype == 1 ? H_all : Hm_all) + b * N;
-    const float2* in = in_all + b * (size_t)in_stride + (size_t)first * N;
-    float2* out = out_all + b * (size_t)out_stride;
-    const double eps = S->epsilon0 + S->er;
-    const int PARTS = N / 128;
-    if (tid == 0) { s_ready = 0; s_cons = 0; }
-    __syncthreads();
-    if (wv == 1) {
-        const int G = NP <= 1 ? 1 : (1 << (32 - __clz(NP - 1)));
-        const int spw = 64 / G, kk = ln & (G - 1), sl = ln / G;
-        const int kc = kk < NP ? kk : 0;
-        const int c = d.pilot_c[kc];
-        const float2 hc = Hsel[c];
-        double sig_sum = S->signal_power_sum, noi_sum = S->noise_power_sum;
-        int cnt = S->snr_est_count;
-        const unsigned ring_base = __builtin_amdgcn_readfirstlane(lds_byte_address(ring));
-        const char* src0 = reinterpret_cast<const char*>(in) + ln * 16;
-        float2 raw[8], pk8[8];
-#pragma unroll
-        for (int p8 = 0; p8 < 8; p8++) {
-            const int jc = min(p8 * spw + sl, nb - 1);
-            raw[p8] = in[(size_t)jc * N + c];
-            pk8[p8] = d.pilot_sym[(size_t)((sym + jc - 3 - NL) % d.n_pilot_rows) * NP + kc];
-        }
-        int issued = 0;
-        for (; issued < nb && issued < RING; issued++)
-            for (int part = 0; part < PARTS; part++) glds16(src0 + (size_t)issued * N * 8 + part * 1024, ring_base + (unsigned)(issued * N * 8 + part * 1024));
-#pragma unroll
-        for (int p8 = 0; p8 < 8; p8++) {
-            const int j = p8 * spw + sl;
-            if (p8 * spw >= nb) break;
-            const bool on = j < nb && kk < NP;
-            const int sy = sym + min(j, nb - 1);
-            const double k0 = 2 * M_PI * sy * ((N + d.cp) * 1.0 / N) * eps;
-            const float2 yk = c_mul(raw[p8], c_expj(k0 * (c - N / 2)));
-            const float2 e = c_mul(hc, pk8[p8]);
-            float2 sum = make_float2(0.f, 0.f);
-            if (on) { const float2 pp = c_mul(yk, c_conj(e)); sum.x = sum.x + pp.x; sum.y = sum.y + pp.y; }
-            for (int off = G >> 1; off > 0; off >>= 1) { sum.x += __shfl_xor(sum.x, off); sum.y += __shfl_xor(sum.y, off); }
-            const float2 r0 = c_expj(-(double)atan2f(sum.y, sum.x));
-            double sig = 0, noi = 0;
-            if (on) {
-                sig += (double)c_mul(e, c_conj(e)).x;
-                const float2 yr = c_mul(yk, r0);
-                const float2 er = make_float2(e.x - yr.x, e.y - yr.y);
-                noi += (double)c_mul(er, c_conj(er)).x;
-            }
-            for (int off = G >> 1; off > 0; off >>= 1) { sig += __shfl_xor(sig, off); noi += __shfl_xor(noi, off); }
-            if (kk == 0 && j < nb) { s_brot[j] = r0; s_bsig[j] = sig; s_bnoi[j] = noi; }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (ln == 0)
-            for (int j = 0; j < nb; j++) { sig_sum += s_bsig[j]; noi_sum += s_bnoi[j]; cnt += NP; s_bnoi[j] = noi_sum / cnt; }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        for (int j = 0; j < nb; j++) {
-            for (;;) {
-                const int cons = *(volatile int*)&s_cons;
-                while (issued < nb && issued < cons + RING) {
-                    for (int part = 0; part < PARTS; part++)
-                        glds16(src0 + (size_t)issued * N * 8 + part * 1024, ring_base + (unsigned)((issued % RING) * N * 8 + part * 1024));
-                    issued++;
-                }
-                if (issued > j) break;
-                __builtin_amdgcn_s_sleep(1);
-            }
-            eq_wait_vm((issued - j - 1) * PARTS);
-            if (ln == 0) *(volatile int*)&s_ready = j + 1;
-        }
-    } else {
-        constexpr int WE = 4;
-        int scv[WE], oi[WE];
-        float2 hv[WE];
-        double hm2[WE];
-#pragma unroll
-        for (int e = 0; e < WE; e++) {
-            oi[e] = min(ln + e * 64, ND - 1);
-            scv[e] = d.data_c[oi[e]];
-            hv[e] = Hsel[scv[e]];
-            hm2[e] = (double)c_mul(hv[e], c_conj(hv[e])).x;
-        }
-        const double k0_last = 2 * M_PI * (sym + nb - 1) * ((N + d.cp) * 1.0 / N) * eps;
-        const bool all_small = fabsf((float)(k0_last * (N / 2))) <= 0.78539816f;
-        auto equalise = [&](auto PT, auto SMALL) {
-            constexpr int pt = decltype(PT)::value;
-            constexpr bool small = decltype(SMALL)::value;
-            for (int j = 0; j < nb; j++) {
-                while (*(volatile int*)&s_ready <= j) __builtin_amdgcn_s_sleep(1);
-                asm volatile("" ::: "memory");
-                const float2* row = ring + (size_t)(j % RING) * N;
-                float2 xc[WE];
-#pragma unroll
-                for (int e = 0; e < WE; e++) xc[e] = row[scv[e]];
-                const float2 rot = s_brot[j];
-                const double nvar = s_bnoi[j];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (ln == 0) *(volatile int*)&s_cons = j + 1;
-                const double k0 = 2 * M_PI * (sym + j) * ((N + d.cp) * 1.0 / N) * eps;
-                float2* o = out + (size_t)j * ND;
-#pragma unroll
-                for (int e = 0; e < WE; e++) {
-                    const double ang = k0 * (scv[e] - N / 2);
-                    const float2 yr = c_mul(c_mul(xc[e], small ? c_expj_small(ang) : c_expj(ang)), rot);
-                    float2 z;
-                    if constexpr (pt == 1) z = c_div(yr, hv[e]);
-                    else {
-                        const float csi = (float)(hm2[e] + nvar);
-                        const float2 num = c_mul(yr, c_conj(hv[e]));
-                        z = make_float2(num.x / csi, num.y / csi);
-                    }
-                    typedef float v2f __attribute__((ext_vector_type(2)));
-                    const v2f zz = {z.x, z.y};
-                    __builtin_nontemporal_store(zz, reinterpret_cast<v2f*>(o + oi[e]));
-                }
-            }
-        };
-        if (all_small) {
-            if (ptype == 1) equalise(std::integral_constant<int, 1>{}, std::true_type{}); else equalise(std::integral_constant<int, 2>{}, std::true_type{});
-        } else {
-            if (ptype == 1) equalise(std::integral_constant<int, 1>{}, std::false_type{}); else equalise(std::integral_constant<int, 2>{}, std::false_type{});
-        }
-    }
-}
-
-extern "C" int jrc_equalizer_data_proto_dev(jrc_equalizer* eq, int n_streams, int n_symbols, int first, int nb, int ring, const jrc_cf32* d_in,
-                                            jrc_cf32* d_out, void* stream)
-{
-    if (!eq || !d_in || !d_out || nb < 1 || nb > EQ_BATCH || eq->d.N != 256 || eq->d.NP > 8) return JRC_ERR_INVALID_ARG;
-    jrc_ctx* ctx = eq->ctx;
-    JRC_BIND(ctx);
-    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-    const long in_stride = (long)n_symbols * eq->d.N, out_stride = (long)nb * eq->d.ND;
-#define EQ_PROTO(R) hipLaunchKernelGGL(eq_data_proto_kernel<R>, dim3(n_streams), dim3(128), 0, s, eq->d, (const EqState*)eq->states, (const float2*)eq->H, \
-                                       (const float2*)eq->Hm, (const float2*)d_in, in_stride, first, nb, (float2*)d_out, out_stride)
-    if (ring == 2) EQ_PROTO(2); else if (ring == 3) EQ_PROTO(3); else if (ring == 4) EQ_PROTO(4); else if (ring == 6) EQ_PROTO(6); else if (ring == 8) EQ_PROTO(8);
-    else return JRC_ERR_INVALID_ARG;
-#undef EQ_PROTO
     JRC_HIP(ctx, hipGetLastError());
     return JRC_OK;
 }
