@@ -33,7 +33,10 @@ struct jrc_chain_feed {
     std::string err;
     std::atomic<int> inside{0};                           // > 1 = two threads inside the feed at once: the contract says one feeder thread
     bool overlapped = false;
+    long collects = 0, fail_collect_at = -1;              // FEED_DOUBLE_FAIL_COLLECT_AT=k: the k-th collect call and every later one fail
 };
+// what the block still collected while it was being destroyed is only visible from outside the block: totals over all feeds of the process
+std::atomic<long> feed_double_frames_collected{0}, feed_double_collect_calls_after_failure{0};
 
 namespace {
 struct in_feed {                                          // the feed is not thread-safe: the block must serialise every call
@@ -68,6 +71,7 @@ int jrc_chain_feed_create(jrc_ctx*, const jrc_chain_cfg* cfg, const float*, cons
     f->tx_resident.resize(f->port * cfg->N_tx);
     const char* e = getenv("FEED_DOUBLE_LATENCY_US");
     f->latency_us = e ? atol(e) : 300;
+    if (const char* k = getenv("FEED_DOUBLE_FAIL_COLLECT_AT")) f->fail_collect_at = atol(k);
     *feed = f;
     return JRC_OK;
 }
@@ -118,6 +122,10 @@ int jrc_chain_feed_collect(jrc_chain_feed* f, jrc_ra_result* results, jrc_cf32*,
     in_feed g(f);
     if (f->overlapped) return fail(f, JRC_ERR_INVALID_ARG, "two threads were inside the feed at once");
     if (f->flight.empty()) { if (n_frames) *n_frames = 0; return 0; }
+    if (f->fail_collect_at >= 0 && ++f->collects >= f->fail_collect_at) {
+        if (f->collects > f->fail_collect_at) feed_double_collect_calls_after_failure++;
+        return fail(f, JRC_ERR_HIP, "feed double: collect fails (FEED_DOUBLE_FAIL_COLLECT_AT)");
+    }
     const batch b = f->flight.front();
     std::this_thread::sleep_until(b.done);
     f->flight.pop_front();
@@ -132,6 +140,7 @@ int jrc_chain_feed_collect(jrc_chain_feed* f, jrc_ra_result* results, jrc_cf32*,
         results[i].snr_est = 30.f;
     }
     if (n_frames) *n_frames = b.n;
+    feed_double_frames_collected += b.n;
     return b.n;
 }
 

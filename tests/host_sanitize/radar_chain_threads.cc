@@ -27,8 +27,62 @@ static float checksum(const gr_complex* p, size_t n, size_t i0 = 0)
 }
 #define CHECK(c, ...) do { if (!(c)) { fprintf(stderr, "FAILED %s:%d: ", __FILE__, __LINE__); fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\n"); exit(1); } } while (0)
 
+extern std::atomic<long> feed_double_frames_collected, feed_double_collect_calls_after_failure;
+
+// (a) a block destroyed without stop() / flush() still publishes what is in flight — the destructor collects; (b) a collect that fails
+// in the flusher thread is reported once, remembered, rethrown by the scheduler's next general_work / flush, and not retried for ever
+static int scenario(const std::string& which)
+{
+    // (destructor: six packets = a full batch and a receive-only one, whose first use of the resident rows collects the first inside the turn;
+    //  flusher_error: four packets = one batch, so that the first collect call is the flusher's)
+    const int N = 64, T = 4, R = 2, S = 4, NPRE = 5, n_items = NPRE + S, Ir = 8, Ia = 16, fpb = 4, slots = 3, nf = which == "destructor" ? 6 : 4;
+    std::vector<float> rb((size_t)N * Ir, 0.f), ab((size_t)T * R * Ia, 0.f);
+    auto blk = radar_chain::make(N, T, R, S, NPRE, Ir, Ia, false, rb, ab, 2.4f, 28.96f, -100.f, 0.f, "", false, fpb, slots);
+    std::vector<std::vector<gr_complex>> ports(T + R, std::vector<gr_complex>((size_t)2 * nf * n_items * N, gr_complex(1.f, -1.f)));
+    auto turn = [&](int k) {
+        for (int i = 0; i < nf; i++) {
+            jrc_rt::tag_t t;
+            t.key = pmt::mp("packet_len"); t.value = pmt::from_long(n_items);
+            t.offset = (uint64_t)(k * nf + i) * n_items;
+            blk->t_in_tags[0].push_back(t);
+            blk->t_in_tags[T].push_back(t);
+        }
+        gr_vector_int nin(T + R, nf * n_items);
+        gr_vector_const_void_star in;
+        for (int p = 0; p < T + R; p++) in.push_back(ports[p].data() + (size_t)k * nf * n_items * N);
+        gr_vector_void_star out;
+        return blk->t_run(0, nin, in, out);
+    };
+    if (which == "destructor") {
+        CHECK(turn(0) == 0, "general_work");
+        const int left = blk->pending_batches();
+        CHECK(left > 0, "nothing left in flight to destroy the block over");
+        const long before = feed_double_frames_collected.load();
+        CHECK(before < nf, "every frame was collected before the destructor ran");
+        blk.reset();                                                    // no stop(), no flush()
+        CHECK(feed_double_frames_collected.load() == nf, "the destructor collected %ld of %d frames", feed_double_frames_collected.load(), nf);
+        printf("ok: destructor collected %ld frames that were in flight\n", feed_double_frames_collected.load() - before);
+        return 0;
+    }
+    // "flusher_error": FEED_DOUBLE_FAIL_COLLECT_AT makes a collect fail while the scheduler idles, i.e. in the flusher thread
+    CHECK(turn(0) == 0, "general_work");
+    std::this_thread::sleep_for(std::chrono::milliseconds(60));         // many flusher periods: it must fail once and stop, not retry every half bound
+    const long retries = feed_double_collect_calls_after_failure.load();
+    CHECK(retries <= 1, "the flusher kept calling a failing collect (%ld calls after the failure)", retries);
+    bool thrown = false;
+    try { turn(1); } catch (const std::runtime_error& e) { thrown = std::string(e.what()).find("flusher") != std::string::npos; }
+    CHECK(thrown, "general_work after a failed flusher collect did not rethrow it");
+    thrown = false;
+    try { blk->flush(); } catch (const std::runtime_error&) { thrown = true; }
+    CHECK(thrown, "flush() after a failed flusher collect did not rethrow it");
+    blk.reset();                                                        // the destructor neither throws nor retries
+    printf("ok: flusher error was sticky, %ld collect calls after the failure\n", feed_double_collect_calls_after_failure.load());
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
+    if (argc > 2) return scenario(argv[2]);
     const int N = 64, T = 4, R = 2, S = 4, NPRE = 5, n_items = NPRE + S, Ir = 8, Ia = 16;
     const int F = argc > 1 ? atoi(argv[1]) : 240, per_turn = 6, fpb = 4, slots = 3;
     std::vector<float> rb((size_t)N * Ir, 0.f), ab((size_t)T * R * Ia, 0.f);

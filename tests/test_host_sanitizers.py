@@ -46,3 +46,18 @@ def test_radar_chain_block_threads_under_sanitizers(tmp_path_factory, sanitize, 
     r = subprocess.run([exe, "240"], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0 and r.stdout.startswith("ok: 240 frames"), (r.returncode, r.stdout[-500:], r.stderr[-3000:])
     assert "Sanitizer" not in r.stderr, r.stderr[-3000:]
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="no g++")
+@pytest.mark.parametrize("scenario,env,expect", [("destructor", {}, "ok: destructor collected"),
+                                                 ("flusher_error", {"FEED_DOUBLE_FAIL_COLLECT_AT": "1", "JRC_RADAR_CHAIN_MAX_AGE_US": "8000"}, "ok: flusher error was sticky")])
+def test_radar_chain_block_destructor_collects_and_flusher_errors_are_sticky(tmp_path_factory, scenario, env, expect):
+    """ADVICE r4 on host/jrc_blocks.cc: a block destroyed without stop() / flush() publishes what is still in flight; a collect that fails in the
+    flusher thread is said once, rethrown by the scheduler's next general_work / flush and not retried every half age bound — under
+    ThreadSanitizer, against the test double of the feed ABI"""
+    exe = build(tmp_path_factory.mktemp("host_sanitize"), "thread")
+    e = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66", FEED_DOUBLE_LATENCY_US="1500", **env)
+    e.pop("JRC_DEVICES", None)
+    r = subprocess.run([exe, "0", scenario], capture_output=True, text=True, env=e, timeout=120)
+    assert r.returncode == 0 and expect in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
+    assert "Sanitizer" not in r.stderr, r.stderr[-3000:]
