@@ -305,10 +305,17 @@ def test_detector_and_synchroniser_blocks_call_for_call(jrc, ctx, ofdm64, i):
 @pytest.mark.parametrize("i", range(max(4, N_DRAWS // 3)))
 def test_target_simulator_against_oracle(jrc, ctx, i):
     """drawn burst lengths (1 ... 30000, most of them neither powers of two nor smooth), 0-6 targets, 1-4 receive antennas, targets summed or
-    overwriting each other, self coupling and a drawn phase per target: the device's chirp-z convolutions against the oracle's double-precision
-    transforms of the burst's own length, 1e-4"""
+    overwriting each other, self coupling and a drawn phase per target: the device's chirp-z convolutions — and, for every other draw, a length
+    its direct four-step route takes — against the oracle's double-precision transforms of the burst's own length, 1e-4"""
     rng = np.random.default_rng(SEED + 9000 + i)
     n = int(rng.choice([rng.integers(1, 200), rng.integers(200, 5000), rng.integers(5000, 30000)]))
+    if i % 2:         # round 5: every other draw is a length of the direct four-step route — the flowgraphs' n_symbols x 5 x 2^k, or any n1 x 2^a
+        if rng.integers(0, 2):
+            n = int(rng.integers(10, 140)) * 5 * (1 << int(rng.integers(4, 9)))
+        else:
+            n = int(rng.integers(1, 513)) << int(rng.integers(4, 13))
+        while n > 60000:
+            n //= 2
     K, R = int(rng.integers(0, 7)), int(rng.integers(1, 5))
     tg = (rng.uniform(3, 80, K), rng.uniform(-40, 40, K), rng.uniform(1, 100, K), rng.uniform(-70, 70, K))
     pos = list(np.arange(R) * 0.00625)
