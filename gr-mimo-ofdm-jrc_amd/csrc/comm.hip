@@ -126,6 +126,7 @@ struct EqDev {
                         // 1 = the pilot phase reads the batch's first symbol for every symbol; 2 = the MIMO-LTF symbols are not stored to / read from HBM;
                         // 3 = the equalisation phase reads the batch's first row for every symbol; 4 = no pilot phase; 5 = the equalisation phase stores its input cells; 6 = it stores nothing; 7 = it stores through the caches
     int sig_full;       // JRC_EQ_SIG_FULL: always run the windowed Viterbi on the SIG field (no codeword shortcut)
+    int pre_lds;        // the MIMO-LTF symbols of a frame are kept in LDS (on the arrays that are dead between the SIG field and the data symbols) instead of HBM
     double freq, bw;
     const int* data_c; const int* pilot_c; const int* active_c;
     const float2* pilot_sym; const float2* ltf; const float2* mapped;
@@ -288,7 +289,11 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
     EqState* gst = states + stream;
     float2* gH = H_all + (size_t)stream * N;
     float2* gHm = Hm_all + (size_t)stream * N;
-    float2* pre = pre_all + (size_t)stream * N * NL;
+    // MIMO-LTF store [N][NL] (:213: a stack array in the reference).  round 5: in LDS where it fits, on Z / est / the Viterbi scratch — all dead
+    // between the SIG field and the first data symbol — grown to N x NL cells; it only goes to HBM (pre_g) when a call ends between two MIMO-LTF
+    // symbols of a frame and comes back when the next call starts there (a frame may span calls).  (A flat pointer: LDS or global.)
+    float2* const pre_g = pre_all + (size_t)stream * N * NL;
+    float2* const pre = d.pre_lds ? Z : pre_g;
     const float2* in = io.in + (size_t)b * io.in_stride;
     float2* out = io.out + (size_t)b * io.out_stride;
     float2* chan_est = io.chan_est ? io.chan_est + (size_t)b * N * T : nullptr;
@@ -300,6 +305,8 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
     for (int i = tid; i < NP; i += NT) pc[i] = d.pilot_c[i];
     for (int i = tid; i < d.NAct; i += NT) ac[i] = d.active_c[i];
     __syncthreads();
+    if (d.pre_lds && S.sig_ok && S.symbol_ind >= 4 && S.symbol_ind <= 2 + NL)        // the call before this one ended between two MIMO-LTF symbols
+        for (int i = tid; i < N * NL; i += NT) pre[i] = pre_g[i];
 
     int n_in = 0, n_out = 0, nev = 0, ce_written = 0, advance = 0;
     // input symbols are prefetched one symbol ahead into registers: a symbol is only a few microseconds of work, so
@@ -755,6 +762,11 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
         if (io.chan_est_written) io.chan_est_written[b] = ce_written;
     }
     for (int i = tid; i < N; i += NT) { gH[i] = H[i]; gHm[i] = Hm[i]; }
+    if (d.pre_lds) {                                                                   // this call ends between two MIMO-LTF symbols: their store goes to HBM
+        __syncthreads();
+        if (S.sig_ok && S.symbol_ind >= 4 && S.symbol_ind <= 2 + NL)
+            for (int i = tid; i < N * NL; i += NT) pre_g[i] = pre[i];
+    }
 }
 
 struct jrc_equalizer {
@@ -834,6 +846,15 @@ extern "C" int jrc_equalizer_create(jrc_ctx* ctx, const jrc_eq_cfg* c, int n_str
     {
         size_t off = sizeof(float2) * (size_t)(3 * N + ND + NP) + sizeof(unsigned long long) * eq_surv_words(ND) + eq_pair_bytes(ND);
         off = (off + 15) & ~size_t(15);
+        // MIMO-LTF store in LDS, on Z / est / the Viterbi scratch grown to N x NL cells — when the dynamic LDS then still lets eight narrow
+        // workgroups share a CU (18 KiB + ~2 KiB of static arrays each); JRC_EQ_PRE_LDS=0 keeps it in HBM
+        d.pre_lds = 0;
+        {
+            const size_t tables = sizeof(int) * (size_t)(ND + NP + ac.size() + 1) + sizeof(float2) * (size_t)(N + NP) + 16;
+            const size_t grown = std::max(off, (sizeof(float2) * (size_t)(3 * N + N * c->n_mimo_ltf) + 15) & ~size_t(15));
+            const char* e = getenv("JRC_EQ_PRE_LDS");
+            if (!(e && atoi(e) == 0) && grown + tables <= 18432) { d.pre_lds = 1; off = grown; }
+        }
         d.lds_tables = (int)off;
         eq->lds_bytes = off + sizeof(int) * (size_t)(ND + NP + ac.size() + 1) + sizeof(float2) * (size_t)(N + NP) + 16;
     }

@@ -103,6 +103,32 @@ def test_equalizer_whole_frame(jrc, ctx, ofdm64, est, ptype, mcs):
         assert g["chan_est"] is None and o["chan_est"] is None
 
 
+@pytest.mark.parametrize("est", [STA, LS])
+@pytest.mark.parametrize("ptype", [DATA, NDP])
+def test_equalizer_frame_cut_at_every_symbol(jrc, ctx, ofdm64, est, ptype):
+    """a frame handed over in two calls, cut behind every one of its symbols in turn, and symbol by symbol: the same output as in one call, to the
+    bit.  Round 5: the MIMO-LTF store lives in LDS (on arrays that are dead between the SIG field and the data symbols) and only travels through
+    HBM when a call ends between two MIMO-LTF symbols — the cuts behind symbols 3 .. 5 are exactly that."""
+    rng = np.random.default_rng(11)
+    gp, ge, op, oe = blocks(jrc, ctx, ofdm64, est)
+    nbytes, mcs = 60, 2
+    ns = oracle.n_ofdm_sym(mcs, 48, nbytes)
+    y = through_channel(op.work(qpsk(rng, ns * 48), mcs, ptype, nbytes), crandn(rng, 4), 1e-3, rng)
+    whole = ge.general_work(y, [(0, 0.01)])
+    assert rel_err(whole["out"], oe.general_work(y, [(0, 0.01)])["out"]) < TOL
+    for cuts in [[k] for k in range(1, len(y))] + [list(range(1, len(y)))]:
+        outs, pos, ce = [], 0, None
+        for end in cuts + [len(y)]:
+            r = ge.general_work(y[pos:end], [(0, 0.01)] if pos == 0 else [])
+            assert r["consumed"] == end - pos
+            outs.append(r["out"])
+            ce = r["chan_est"] if r["chan_est"] is not None else ce
+            pos = end
+        assert np.array_equal(np.concatenate(outs), whole["out"]), cuts
+        if ptype == NDP:
+            assert np.array_equal(ce, whole["chan_est"]), cuts
+
+
 def test_equalizer_split_calls_keep_state(jrc, ctx, ofdm64):
     """work() may see a frame in pieces; state (incl. the MIMO-LTF store the reference loses) persists"""
     rng = np.random.default_rng(5)
