@@ -5,6 +5,8 @@
 //      out_l = IFFT_n( FFT_n( in . doppler_k ) . timeshift_{l,k} ) [. phase_k]   (+ self coupling)
 // with two FFTW3f transforms of length n per (l, k).  Here:
 //   * FFT_n( in . doppler_k ) does not depend on l and is computed once per target;
+//   * lengths n = n1 x 2^a (2^a >= 16, n1 <= 512: every burst of the flowgraphs) are transformed directly as four-step DFTs — the td_* kernels
+//     further down (round 5); what follows here is the route for all other lengths:
 //   * the length-n DFTs are chirp-z (Bluestein) transforms over a power-of-two M >= 2n-1:
 //         X[k] = c[k] . sum_i (x[i] c[i]) conj(c)[k-i],   c[i] = exp(-j pi i^2 / n)
 //     and because the inverse DFT uses conj(c), the chirp factors between the two transforms cancel
@@ -1379,7 +1381,7 @@ extern "C" int jrc_tsim_run_sum_dev(jrc_tsim* const* sims, int n_sims, int n_bur
         JRC_TRY(tsim_prepare(sims[q], n_input, s));
         if (!sims[q]->direct)
             return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "jrc_tsim_run_sum_dev: bursts of %d samples do not take the direct route (n = n1 x 2^a, 2^a >= 16, n1 <= %d)",
-                            n_input, TD_MAXSIMS * 0 + TD_MAX_N1);
+                            n_input, TD_MAX_N1);
     }
     return tsim_run_direct(sims, n_sims, n_bursts, n_input, d_in, d_out, target_phase, accumulate_out, s);
 }

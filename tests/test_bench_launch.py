@@ -168,6 +168,9 @@ x = torch.arange(48 * 5, dtype=torch.uint8, device="cuda:0").reshape(5, 48)
 out = torch.empty_like(x)
 dist.all_gather_into_tensor(out, x)
 assert torch.equal(out, x) and torch.equal(shard.gather_results(x, 5), x)
+objs = [None]
+dist.all_gather_object(objs, {"rank": 0, "device_key": "x"})      # bench.gather_identities: pickled through RCCL's own device tensors
+assert objs == [{"rank": 0, "device_key": "x"}]
 dist.barrier()
 dist.destroy_process_group()
 print("rccl ok")

@@ -31,7 +31,9 @@ def test_single_target_any_length(jrc, ctx, n):
 
 @pytest.mark.parametrize("n", [40000, 70000, 174080, 300000, 600000])
 def test_long_bursts(jrc, ctx, n):
-    """chirp-z lengths M = 2^17 .. 2^21: row pass as m x 256 two-step transforms (m = 2..16) and the generic Stockham rows"""
+    """long bursts: chirp-z lengths M = 2^17 .. 2^21 (row pass as m x 256 two-step transforms, m = 2..16, and the generic Stockham rows) for the
+    lengths outside the direct route; 174080 = 85 x 2048 (config D's burst) takes the direct route here and the chirp-z one in
+    test_direct_four_step_lengths"""
     args = ([35.0], [-12.0], [40.0], [-25.0], POS4[:2], FS, FC)
     x = burst(n, n)
     got = jrc.target_simulator(*args, ctx=ctx).work(x)

@@ -206,8 +206,8 @@ def simulated_chain(cfg="B", F=64):
         chain.run_td(bufs, d_tx, rx_td, F, sc.cp)           # A6+A7+A1 one kernel; the streams carry 3 trailing pad symbols
     t = timed(step, steps=10, warm=2)
     ts = timed(sim_only, steps=10, warm=2)
-    return dict(what="simulated frame: %d target simulators (%d targets, %d-sample bursts, chirp-z M=%d) + RX demod + radar chain, config %s"
-                % (sc.T, len(tg), n, 1 << int(np.ceil(np.log2(max(2 * n - 1, 32768)))), cfg), frames_per_step=F, ms_per_step=t * 1e3,
+    return dict(what="simulated frame: %d target simulators (%d targets, %d-sample bursts) + RX demod + radar chain, config %s"
+                % (sc.T, len(tg), n, cfg), frames_per_step=F, ms_per_step=t * 1e3,
                 frames_per_s=F / t, ms_simulators_only=ts * 1e3, bursts_per_s_simulators=F * sc.T / ts)
 
 
