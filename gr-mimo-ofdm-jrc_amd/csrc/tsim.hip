@@ -617,17 +617,26 @@ __global__ __launch_bounds__(256) void td_col_fwd_kernel(td_srcs srcs, long in_s
     const float2* __restrict__ src = srcs.in[z] + b * (size_t)in_stride;
     const float2* __restrict__ dz = srcs.dop[z];
     for (int i = threadIdx.x; i < n1; i += 256) w1[i] = w1_g[i];
-    for (int i1 = w; i1 < n1; i1 += nw) {
-        const size_t i = (size_t)i1 * n2 + col;
-        buf0[i1 * CW + c] = cmul(src[i], dz[i]);                          // volk_32fc_x2_multiply_32fc (:345)
+    // global accesses two columns (16 bytes) per lane; the passes below work a column per lane on the same tile
+    const int c2 = (threadIdx.x % (CW / 2)) * 2, wp = threadIdx.x / (CW / 2), nwp = 256 / (CW / 2);
+    const int colp = blockIdx.x * CW + c2;
+    for (int i1 = wp; i1 < n1; i1 += nwp) {
+        const size_t i = (size_t)i1 * n2 + colp;
+        const float4 a = *reinterpret_cast<const float4*>(src + i), dd = *reinterpret_cast<const float4*>(dz + i);
+        const float2 p0 = cmul(make_float2(a.x, a.y), make_float2(dd.x, dd.y));      // volk_32fc_x2_multiply_32fc (:345)
+        const float2 p1 = cmul(make_float2(a.z, a.w), make_float2(dd.z, dd.w));
+        *reinterpret_cast<float4*>(buf0 + i1 * CW + c2) = make_float4(p0.x, p0.y, p1.x, p1.y);
     }
     __syncthreads();
     const float2* cur = td_col_transform<CW>(buf0, buf1, w1, pl, c, w, nw);
     float2* dst = U + (b * gridDim.z + z) * (size_t)n;
-    for (int k1 = w; k1 < n1; k1 += nw) {
-        const size_t o = (size_t)k1 * n2 + col;
-        dst[o] = cmul(cur[k1 * CW + c], two[o]);
+    for (int k1 = wp; k1 < n1; k1 += nwp) {
+        const size_t o = (size_t)k1 * n2 + colp;
+        const float4 v = *reinterpret_cast<const float4*>(cur + k1 * CW + c2), t = *reinterpret_cast<const float4*>(two + o);
+        const float2 p0 = cmul(make_float2(v.x, v.y), make_float2(t.x, t.y)), p1 = cmul(make_float2(v.z, v.w), make_float2(t.z, t.w));
+        *reinterpret_cast<float4*>(dst + o) = make_float4(p0.x, p0.y, p1.x, p1.y);
     }
+    (void)col;
 }
 
 // ---- column pass, inverse:  G[bl][k1][i2] . conj w_n^{i2 k1}  ->  inverse n1-point DFT per column (conj, forward, conj)  ->  out_l[i1 n2 + i2]
@@ -648,24 +657,30 @@ __global__ __launch_bounds__(256) void td_col_inv_kernel(const float2* __restric
     const size_t bl = blockIdx.y, b = bl / R, l = bl % R;
     const float2* src = G + bl * (size_t)n;
     for (int i = threadIdx.x; i < n1; i += 256) w1[i] = w1_g[i];
-    for (int k1 = w; k1 < n1; k1 += nw) {
-        const size_t o = (size_t)k1 * n2 + col;
-        const float2 v = cmul(src[o], conjf2(two[o]));
-        buf0[k1 * CW + c] = conjf2(v);
+    const int c2 = (threadIdx.x % (CW / 2)) * 2, wp = threadIdx.x / (CW / 2), nwp = 256 / (CW / 2);      // two columns (16 bytes) per lane on the global side
+    const int colp = blockIdx.x * CW + c2;
+    for (int k1 = wp; k1 < n1; k1 += nwp) {
+        const size_t o = (size_t)k1 * n2 + colp;
+        const float4 g = *reinterpret_cast<const float4*>(src + o), t = *reinterpret_cast<const float4*>(two + o);
+        const float2 v0 = cmul(make_float2(g.x, g.y), make_float2(t.x, -t.y)), v1 = cmul(make_float2(g.z, g.w), make_float2(t.z, -t.w));
+        *reinterpret_cast<float4*>(buf0 + k1 * CW + c2) = make_float4(v0.x, -v0.y, v1.x, -v1.y);          // conjugated: the inverse runs on the forward passes
     }
     __syncthreads();
     const float2* cur = td_col_transform<CW>(buf0, buf1, w1, pl, c, w, nw);
     float2* o = out + b * (size_t)out_burst_stride + l * (size_t)out_rx_stride;
-    for (int i1 = w; i1 < n1; i1 += nw) {
-        const size_t m = (size_t)i1 * n2 + col;
-        float2 v = conjf2(cur[i1 * CW + c]);
-        if (accumulate) v = cadd(o[m], v);
+    for (int i1 = wp; i1 < n1; i1 += nwp) {
+        const size_t m = (size_t)i1 * n2 + colp;
+        const float4 r = *reinterpret_cast<const float4*>(cur + i1 * CW + c2);
+        float2 v0 = make_float2(r.x, -r.y), v1 = make_float2(r.z, -r.w);
+        if (accumulate) { const float4 e = *reinterpret_cast<const float4*>(o + m); v0 = cadd(make_float2(e.x, e.y), v0); v1 = cadd(make_float2(e.z, e.w), v1); }
         for (int q = 0; q < self.n; q++) {                                   // out += (gr_complex)pow(10, db/20) * in  (:376), per simulator
-            const float2 xi = self.in[q][b * (size_t)in_stride + m];
-            v = cadd(v, make_float2(self_coupling * xi.x - 0.0f * xi.y, self_coupling * xi.y + 0.0f * xi.x));
+            const float4 xi = *reinterpret_cast<const float4*>(self.in[q] + b * (size_t)in_stride + m);
+            v0 = cadd(v0, make_float2(self_coupling * xi.x - 0.0f * xi.y, self_coupling * xi.y + 0.0f * xi.x));
+            v1 = cadd(v1, make_float2(self_coupling * xi.z - 0.0f * xi.w, self_coupling * xi.w + 0.0f * xi.z));
         }
-        o[m] = v;
+        *reinterpret_cast<float4*>(o + m) = make_float4(v0.x, v0.y, v1.x, v1.y);
     }
+    (void)col;
 }
 
 // ---- row pass, n2 == 256: 16 rows per workgroup, everything in registers.  RC antennas of the launch out of one forward transform per target;

@@ -91,6 +91,26 @@ def test_direct_route_targets_phases_coupling_accumulate(jrc, ctx, n, R):
         assert rel_err(d_out.cpu().numpy() - base, want) < 2e-5         # (the sum with the buffer's 0..6 rounds at 6 x 2^-24)
 
 
+def test_direct_route_on_buffers_that_are_only_8_byte_aligned(jrc, ctx):
+    """the column passes move two samples (16 bytes) per lane; a caller's buffers need only be gr_complex-aligned: input and output one sample off
+    a 16-byte boundary give the same bytes as aligned ones"""
+    import torch
+    n, B, R = 11520, 2, 3
+    x = np.stack([burst(n, 7 + b) for b in range(B)])
+    g = jrc.target_simulator(*TGT3, POS4[:R], FS, FC, sum_targets=True, max_bursts=B, ctx=ctx)
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.zeros((B, R, n), dtype=torch.complex64, device="cuda")
+    g.run_dev(d_in, d_out, B, n)
+    ctx.sync()
+    flat_in = torch.zeros(B * n + 1, dtype=torch.complex64, device="cuda")
+    flat_out = torch.zeros(B * R * n + 1, dtype=torch.complex64, device="cuda")
+    flat_in[1:] = d_in.reshape(-1)
+    assert flat_in[1:].data_ptr() % 16 == 8 and flat_out[1:].data_ptr() % 16 == 8
+    g.run_dev(flat_in[1:], flat_out[1:], B, n)
+    ctx.sync()
+    assert torch.equal(flat_out[1:].reshape(B, R, n), d_out) and flat_out[0].item() == 0
+
+
 def test_burst_too_long_is_refused(jrc, ctx):
     g = jrc.target_simulator([10.0], [0.0], [1.0], [0.0], [0.0], FS, FC, ctx=ctx)
     with pytest.raises(jrc.JrcError):
