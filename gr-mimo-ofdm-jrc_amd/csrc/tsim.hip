@@ -1379,15 +1379,14 @@ extern "C" int jrc_tsim_run_sum_dev(jrc_tsim* const* sims, int n_sims, int n_bur
         if (sims[q]->ctx != ctx || sims[q]->R != sims[0]->R)
             return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "jrc_tsim_run_sum_dev: simulators of one context and one antenna count only");
         if (sims[q]->K == 0) return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "jrc_tsim_run_sum_dev: a simulator without targets");
-        if (sims[q]->self_coupling && sims[q]->self_coupling_db != sims[0]->self_coupling_db)
-            return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "jrc_tsim_run_sum_dev: simulators with different self-coupling gains");
+        // one antenna stride (K n) and one self-coupling gain serve the whole launch: the simulators of a flowgraph's TX ports are built alike
+        if (sims[q]->K != sims[0]->K || sims[q]->sum_targets != sims[0]->sum_targets)
+            return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "jrc_tsim_run_sum_dev: simulators with different target counts or sum_targets settings");
+        if (sims[q]->self_coupling != sims[0]->self_coupling || (sims[q]->self_coupling && sims[q]->self_coupling_db != sims[0]->self_coupling_db))
+            return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "jrc_tsim_run_sum_dev: simulators with different self-coupling settings");
         if (n_bursts > sims[q]->max_bursts)
             return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "target_simulator: %d bursts exceed max_bursts %d", n_bursts, sims[q]->max_bursts);
     }
-    if (sims[0]->self_coupling == 0)
-        for (int q = 1; q < n_sims; q++)
-            if (sims[q]->self_coupling && sims[q]->self_coupling_db != sims[0]->self_coupling_db)
-                return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "jrc_tsim_run_sum_dev: simulators with different self-coupling gains");
     if (n_bursts == 0 || n_input == 0) return JRC_OK;
     JRC_HIP(ctx, hipSetDevice(ctx->device));
     JRC_BIND(ctx);

@@ -445,8 +445,10 @@ int jrc_tsim_run_dev(jrc_tsim* h, int n_bursts, int n_input, const jrc_cf32* d_i
  * mimo_ofdm_jrc_radar_sim.grc:2213-2220) in ONE pass: d_out[b][l] (+)= sum_q sims[q](d_in[q][b])_l, the sum taken on the spectrum, so each
  * RX antenna costs one inverse transform and one write of d_out whatever n_sims is.  Equals n_sims calls of jrc_tsim_run_dev with
  * accumulate_out to the rounding of a float sum taken in another order.  d_in[q]: [n_bursts][n_input] of simulator q; target_phase[q]:
- * that simulator's host phases or NULL (the array itself may be NULL).  Simulators of one context with the same n_rx, at most 8 of them and
- * 32 (simulator, target) pairs; JRC_ERR_UNSUPPORTED when the burst length does not take the direct route (then run them one by one). */
+ * that simulator's host phases or NULL (the array itself may be NULL).  Simulators of one context built alike (same n_rx, target count,
+ * sum_targets and self-coupling settings — the simulators of a flowgraph's TX ports differ in their antenna positions), at most 8 of them
+ * and 32 (simulator, target) pairs; JRC_ERR_UNSUPPORTED otherwise and when the burst length does not take the direct route (then run them
+ * one by one). */
 int jrc_tsim_run_sum_dev(jrc_tsim* const* sims, int n_sims, int n_bursts, int n_input, const jrc_cf32* const* d_in, jrc_cf32* d_out,
                          const jrc_cf32* const* target_phase, int accumulate_out, void* stream);
 int jrc_tsim_burst_capacity(const jrc_tsim* h);

@@ -232,6 +232,10 @@ def test_simulators_summed_on_the_spectrum(jrc, ctx, n, sum_targets):
     assert e.value.status == jrc.JRC_ERR_UNSUPPORTED
     with pytest.raises(ValueError):
         jrc.target_simulator.run_sum_dev(sims, d_ins, d_out, B + 1, n)
+    other = jrc.target_simulator([10.0], [0.0], [5.0], [0.0], pos[0], FS, FC, seed=9, **kw)       # another target count: one launch cannot serve both
+    with pytest.raises(jrc.JrcError) as e:
+        jrc.target_simulator.run_sum_dev([sims[0], other], d_ins[:2], d_out, B, n)
+    assert e.value.status == jrc.JRC_ERR_UNSUPPORTED
 
 
 def test_synthetic_target_is_recovered_by_the_radar_chain(jrc, ctx):
