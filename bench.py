@@ -759,7 +759,11 @@ def secondary_figures(cfg, ctx, sc, axes):
     if hasattr(be, "power_map"):
         leg("power_map_chain", lambda: be.power_map(cfg if cfg in ("B", "D") else "B"))
     if hasattr(be, "device_resident_flowgraph"):
-        leg("device_resident_sim_flowgraph", lambda: be.device_resident_flowgraph(64))
+        def _drf():
+            r = be.device_resident_flowgraph(64)
+            r["packets_per_s_at_256_per_pass"] = be.device_resident_flowgraph(256)["frames_per_s"]     # the same leg when a pass holds four times the packets
+            return r
+        leg("device_resident_sim_flowgraph", _drf)
     leg("equalizer_config_c", _eq)
     if hasattr(be, "sync_front_end"):
         leg("sync_front_end", lambda: be.sync_front_end(4096))
