@@ -27,7 +27,7 @@
 #include <cmath>
 #include <cstdlib>
 
-#define RA_GROUP 8   // map stores a wave issues back to back; then it waits until all but one have completed
+#define RA_GROUP 8   // map stores a wave issues back to back; then it waits until all but one have completed (docs/history.md §3.1)
 #define RA_L 64   // range bins (and fold length) per workgroup
 
 // ---- the fused kernel ------------------------------------------------------------------------
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
     float* s_pw = reinterpret_cast<float*>(s_twc + (TWC_LDS ? N : 0)) + (size_t)wave * (ROWS1 ? NA : RA_L * P);   // MODE 3: this wave's tile
 
     typedef float v2f __attribute__((ext_vector_type(2)));
-    // store pacing (MODE 0): release time of the wave's next group of stores, in ticks of the 100 MHz real-time counter
+    // store pacing (MODE 0, docs/history.md §3.1): release time of the wave's next group of stores, in ticks of the 100 MHz real-time counter
     const int pace_T = pace & 0xfff, pace_K = (pace >> 12) & 0xf;
     long long t_next = 0;
     if constexpr (MODE == 0 && IA > 0) {
@@ -263,8 +263,8 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
             }
             if constexpr (MODE == 0) {
                 // The map is write-once data nothing on the GPU reads back except the estimator's few cells: it is stored non-temporally, so
-                // that no dirty lines are left behind for the next (read-bound) kernel to compete with.
-                // How a lane's P stores are issued is measured, not cosmetic (tools/ra_variants.py; DESIGN.md §3.1 has the table).  The memory
+                // that no dirty lines are left behind for the next (read-bound) kernel to compete with (docs/history.md §3.1).
+                // How a lane's P stores are issued is measured, not cosmetic (tools/ra_variants.py; docs/history.md §3.1 has the table).  The memory
                 // system rewards a wave that keeps FEW stores in flight: with interp_angle compiled in (row offsets as immediates, no
                 // spills) the stores go out back to back with an `s_waitcnt vmcnt(1)` after every eighth — 0.362 ms per 512 config-B frames
                 // (74.6 % of the HBM peak) against 0.488 ms unthrottled and 0.405 ms for the round-1 shape.  That shape — kept for the
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(NT, (NT == 1024 ? 4 : (NT == 512 ? 2 : JRC_WPS256))
 // (8 or 16 pairs x interp_angle 16 at fft_len 256 / 512 / 1024; everything else runs the 64-bin kernel above.)
 // With classes of 64 range bins the rows a wave stores together lie NR / 64 rows apart — 64 KiB at config B, 256 KiB at config D — and at
 // fft_len 1024 the 128 KiB of H in LDS leave one workgroup per CU with two barriers around the range phase of every 128 KiB class: 80 % of
-// the HBM peak at config B only with paced stores, 65-70 % at config D or with longer range axes.  Here a class is
+// the HBM peak at config B only with paced stores, 65-70 % at config D or with longer range axes (docs/history.md §3.1).  Here a class is
 // k = C q + c with C = NR / 256 and q < 256:
 //     R[p][C q + c] = IFFT_256( g_c[p] )[q],   g_c[p][n'] = sum_{m < fft_len/256} H[p][n' + 256 m] e^{+j 2 pi (n' + 256 m) c / NR}
 // The fold inputs of a lane — H[p][lane + 64 j + 256 m], the same for every class — live in registers, so H needs no LDS at all; the
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(NT_, 2) void range_angle_wide_kernel(
                                                                   // range phase fills was last read before this barrier
         if constexpr (MODE == 1 || MODE == 3) {
             // write-once for the window pass: around the caches — a cached store would sit dirty in the Infinity Cache and be written back
-            // while the NEXT step's A1 streams its input (A1 0.098 -> 0.13 ms per 512 config-B frames behind 128 MB of cached stores)
+            // while the NEXT step's A1 streams its input (docs/history.md §6: A1 0.098 -> 0.13 ms per 512 config-B frames behind 128 MB of cached stores)
             // (MODE 3: cached or non-temporal measures the same, 0.284 ms per 512 config-B frames, and the A1 behind it 0.127 ms either way)
             typedef float v4f __attribute__((ext_vector_type(4)));
             v4f* dst = reinterpret_cast<v4f*>(rng_out + ((size_t)f * C + c) * (P * RW_L));
@@ -880,7 +880,7 @@ static int chain_chunk(const jrc_chain* ch, int wpf)
     return chunk - chunk % nx;
 }
 
-// Store pacing of the map-writing kernels: every wave releases its map stores in groups of RA_GROUP x 512 B, one group per T
+// Store pacing of the map-writing kernels (docs/history.md §3.1): every wave releases its map stores in groups of RA_GROUP x 512 B, one group per T
 // ticks of wall_clock64().  What the sweeps (tools/pace_sweep.sh) found is a property of the memory system, an OFFERED BYTE RATE at which the map
 // stream runs at the pace of a pure store stream — not a tick count: so the word is derived from that rate, the bytes of a group, the waves
 // actually resident for this launch and the clock of the counter,
@@ -1068,7 +1068,7 @@ extern "C" int jrc_chain_create(jrc_ctx* ctx, const jrc_chain_cfg* cfg, const fl
     // (JRC_NO_WIDE: the 64-bin kernel; fft_len 64 / 128 were measured on it as well — zero inputs beyond fft_len — and stay on the 64-bin
     // kernel: 4 x 2 at fft_len 64 0.60-0.62 against 0.58-0.59, but 4 x 4 at fft_len 64 / 128 0.44 / 0.72 against 0.66 / 0.74).  Two 256-thread workgroups per CU while a lane's share of H
     // stays within 64 VGPRs (pairs per wave x fold terms <= 8), else one 512-thread workgroup (16 pairs at fft_len 1024).  Measured against
-    // the 64-bin kernel, of the HBM peak: 16 pairs, fft_len 256, interp_range 4 / 8 / 16 / 32: 0.75 / 0.82 / 0.82 / 0.82
+    // the 64-bin kernel, of the HBM peak (docs/history.md §3.1): 16 pairs, fft_len 256, interp_range 4 / 8 / 16 / 32: 0.75 / 0.82 / 0.82 / 0.82
     // against 0.72 / 0.80 / 0.60 / 0.65; fft_len 512 with 4 / 8: 0.78 / 0.80 against 0.74 / 0.71; 8 pairs, interp_range 8: fft_len 256 0.76
     // against 0.65, fft_len 1024 0.68-0.75 against 0.56.
     ch->wide = !ch->generic && (P == 16 || P == 8) && cfg->interp_angle == 16 && !getenv("JRC_NO_WIDE") && (N == 256 || N == 512 || N == 1024) && NR >= RW_L;
@@ -1499,7 +1499,7 @@ static int chain_run(jrc_chain* ch, int n_frames, const jrc_cf32* d_frames, cons
     const bool bg_on = bg && (bg->removal || bg->recording);
     // Detect-only mode, no per-kernel timing, no background state (its kernels walk the whole batch), JRC_DETECT_SLICES > 1: the batch runs as a
     // pipeline of slices — A1 of slice i+1 on the caller's stream beside A2..A5 of slice i on a side stream (A1 is HBM-bound, the detect kernel
-    // instruction-issue-bound).  The caller's stream waits for the side streams before this call returns control of it: the
+    // instruction-issue-bound, docs/history.md §3.6).  The caller's stream waits for the side streams before this call returns control of it: the
     // stream-order contract of the entry point is unchanged.  Off by default: measured slower than the kernels in series (chain_pick_slices).
     int n_slices = 1;
     if (!ch->write_map && !ch->generic && !ch->timing && !bg_on) {

@@ -122,7 +122,7 @@ extern "C" int jrc_sig_encode(int n_data, int mcs, int packet_type, int length, 
 #endif
 struct EqDev {
     int N, cp, ND, NP, NAct, NL, T, mapped_cols, n_pilot_rows, estimator, lds_tables;
-    int exp;            // timing experiments of DESIGN.md §6 — WRONG RESULTS, so only in builds with -DJRC_TIMING_EXPERIMENTS (tools/ra_variants.py), where JRC_EQ_EXP selects:
+    int exp;            // timing experiments of docs/history.md §6 — WRONG RESULTS, so only in builds with -DJRC_TIMING_EXPERIMENTS (tools/ra_variants.py), where JRC_EQ_EXP selects:
                         // 1 = the pilot phase reads the batch's first symbol for every symbol; 2 = the MIMO-LTF symbols are not stored to / read from HBM;
                         // 3 = the equalisation phase reads the batch's first row for every symbol; 4 = no pilot phase; 5 = the equalisation phase stores its input cells; 6 = it stores nothing; 7 = it stores through the caches
     int sig_full;       // JRC_EQ_SIG_FULL: always run the windowed Viterbi on the SIG field (no codeword shortcut)

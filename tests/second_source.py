@@ -4,7 +4,7 @@ Written directly from the reference's C++ (`/root/reference/lib/*.cc`, cited per
 cannot be compiled in this image (GNU Radio / Eigen / Boost headers absent), so the C oracle is "parity unpinned"; these
 independent numpy-float32 / pure-Python restatements are a second reading of the same source that the oracle must agree with
 (`tests/test_second_source.py`).  Two readings that agree bit for bit are still not an execution of the reference - parity
-stays "partial" (README) - but a misreading now has to be made twice, the same way, in two languages.
+stays "partial" (README, docs/history.md §5) - but a misreading now has to be made twice, the same way, in two languages.
 
 Arithmetic model (what a g++ build of the reference does on x86-64, the image's toolchain: gcc 11.4 / glibc 2.35):
   * gr_complex = std::complex<float>; `*` is the inline form of libgcc __mulsc3 (four products, one subtraction, one addition, each
@@ -403,7 +403,7 @@ class EqualizerRef:
                         for sc in range(N):
                             for t in range(self.T):
                                 terms = cmul(cconj(self.mapped[sc, t * NL:(t + 1) * NL]), self.pre[sc])
-                                chan_est[sc, t] = csum_in_order(terms)                        # Eigen's order: see DESIGN §5 (unpinned)
+                                chan_est[sc, t] = csum_in_order(terms)                        # Eigen's order: see docs/history.md §5 (unpinned)
                             if sc in self.active:
                                 mean = cadd(mean, chan_est[sc])
                         self.chan_mean = cdiv_real(mean, len(self.active))                    # VectorXcf / int -> Literal = float
@@ -493,7 +493,7 @@ class PrecoderRef:
         self.F = dft_matrix(N_tx)
 
     def _matvec(self, W, s):
-        """(T x J) times (J) in index order of j (Eigen's summation order: DESIGN §5, unpinned)"""
+        """(T x J) times (J) in index order of j (Eigen's summation order: docs/history.md §5, unpinned)"""
         out = np.zeros(W.shape[0], c64)
         for t in range(W.shape[0]):
             out[t] = csum_in_order(cmul(W[t], s))
@@ -566,7 +566,7 @@ def _pow2_abs(z):
 def ra_estimate_ref(m, range_bins, angle_bins, noise_discard_range_m, noise_discard_angle_deg, snr_threshold=0.0, power_threshold=0.0):
     """range_angle_estimator_impl::work (lib/range_angle_estimator_impl.cc:122-283) on a [n_inputs][vlen] complex64 map.
     `iter_geq == end()` dereferences past the vector in the reference (:169-170); as everywhere in this build that case is
-    angle_null_idx = size - 1, then the clamp of :184-187."""
+    angle_null_idx = size - 1, then the clamp of :184-187 (docs/history.md §4)."""
     m = np.asarray(m, c64)
     n_inputs, vlen = m.shape
     rb, ab = np.asarray(range_bins, f32), np.asarray(angle_bins, f32)

@@ -8,7 +8,7 @@ once over the CPU oracle's blocks (tests/oracle_blocks.py) — fed identical sym
     complex-float edges  ||a-b||_inf / ||b||_inf <= 1e-4 (north_star's tolerance), integer edges bit-exact (lengths announced by the
     tagged-stream blocks, items consumed, SIG fields, tag offsets, estimator indices, decoded bytes, CRC flag);
   * block by block: the oracle graph re-run with every block reading the HIP graph's tensor on its input edge (`force=`), which
-    isolates each block's own error (the number DESIGN.md §5.2 tabulates).
+    isolates each block's own error (the number docs/history.md §5.2 tabulates).
 
 Shapes: the reference's operating point (4x2, N=64, N_pre=5, N_sym=4; tests/golden/radar_flowgraph_point.npz), BASELINE config A
 (1x1, 64 subcarriers, 16 symbols) and a config-B scale-up (4x4, 256 subcarriers, 64 symbols).  The per-edge errors of the run are
@@ -223,7 +223,7 @@ def compare_comm_edges(ge, oe, rep, tag, tol, fft_len=64, freq_floor=1.0, payloa
             # through it since the scheduler call began (worst behind the 40 dB step from burst to pad noise); the oracle restates the worst
             # case (one sum over the capture), the device adds each window afresh (sync.hip).  So the edge is held against its definition in
             # float64 (tests/metric_truth.py): device within north_star's 1e-4 of it and no further from it than the oracle's running sum;
-            # device against oracle within 1e-4 plus the running sum's own measured distance from the definition.  DESIGN.md §5.2.
+            # device against oracle within 1e-4 plus the running sum's own measured distance from the definition.  DESIGN.md §4.
             window = fft_len // 2                                  # corr_window_size of the flowgraph (examples/comm_sim_flowgraph.py)
             pw = int(1.5 * window)
             x_ora = ge["rx"] if tag == "block:" else oe["rx"]      # block by block the oracle's metric blocks read the HIP graph's samples
@@ -638,7 +638,7 @@ def test_comm_flowgraph_on_drawn_links(jrc, ctx, ofdm64, i):
                 continue
             if steer and (ge.get("steering") is not None or oe_.get("steering") is not None):   # (no sounding received: nothing to steer with)
                 assert rel_err(ge["steering"], oe_["steering"]) <= TOL
-            # (the normalised metric: the reference's running sums drift by an amount that depends on the power steps that went through them, the device sums windows — DESIGN.md §5.1, §5.2; what the detector decides from it is compared exactly)
+            # (the normalised metric: the reference's running sums drift by an amount that depends on the power steps that went through them, the device sums windows — docs/history.md §5.1, §5.2; what the detector decides from it is compared exactly)
             # the coarse CFO is the angle of the metric's correlation sum: a last-digit difference of it (same drift) is a phase ramp over the samples the
             # detector de-rotates, and everything behind it inherits the ramp until the equalizer's own tracking takes it out
             d_cfo = max([abs(a[1] - b[1]) for a, b in zip(ge["detector_tags"], oe_["detector_tags"])] + [0.0])

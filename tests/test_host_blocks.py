@@ -951,7 +951,7 @@ def test_stream_encoder_and_decoder_blocks_under_drawn_scheduling(jrc, tmp_path,
         n_blobs += 1
         syms = [m["msg"] for m in dec.state()["published"] if m["port"] == "sym"]
         # the verdict is the oracle's: at the rate-3/4 MCS a clean frame whose pad is a few bits long can fail its CRC — the decoder runs
-        # ntraceback calls past the frame on what its buffers hold there (zeros in a fresh decoder), and with the punctured
+        # ntraceback calls past the frame on what its buffers hold there (zeros in a fresh decoder, docs/history.md §3.4), and with the punctured
         # code's free distance of 5 that can outweigh the last data bits (lib/viterbi_decoder.cc:300-330)
         ok, payload = oracle.stream_decode(mcs, ndc, tags["pdu_len"], got)
         assert len(syms) == n_blobs and syms[-1]["cdr"]["blob"][0] == int(ok), (i, k, mcs, len(pdu))

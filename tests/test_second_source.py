@@ -1,6 +1,6 @@
 """CPU tier: the C oracle (oracle/*.c) against an independent second reading of the reference (tests/second_source.py: numpy
 float32 / pure Python, written from /root/reference/lib/*.cc) and against the third-party code the reference would link on this
-image (libgcc_s __divsc3 / __mulsc3).  The reference itself cannot be built here (parity unpinned); what this
+image (libgcc_s __divsc3 / __mulsc3).  The reference itself cannot be built here (parity unpinned, docs/history.md §5); what this
 tier adds is that the oracle and the second source agree BIT FOR BIT on the equalizer's symbol loop (sampling-offset
 derotation, L-LTF and MIMO-LTF LS, residual CFO, pilot SNR sums, DATA / NDP equalisation, STA updates), on the precoder's output
 assembly and on SIG decoding through the reference's windowed Viterbi decoder with bit errors."""

@@ -47,7 +47,7 @@ def main():
         n2 *= 2
     direct = n2 >= 16 and n // n2 <= 512 and os.environ.get("JRC_TSIM_BLUESTEIN", "0") in ("", "0")
     alg = B * n * 8 * (1 + 4)                                   # a burst in, R = 4 bursts out
-    if direct:                                                  # tsim.hip td_*: (Kz + Kz + Kz... ) see DESIGN.md §3.3
+    if direct:                                                  # tsim.hip td_*: (Kz + Kz + Kz... ) see docs/history.md §3.3
         Kz = K
         traffic = B * n * 8 * (Kz + Kz + Kz + 4 + 4 + 4)        # col fwd: in -> U; rows: U -> G; col inv: G -> out
         route = "direct four-step %d x %d" % (n // n2, n2)
