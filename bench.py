@@ -447,7 +447,10 @@ def host_fed_rate(ctx, cfg, sc, axes, seconds=1.5):
     while feed.pending():
         done += len(feed.collect()[0])
     el = time.perf_counter() - t0
-    out = {"frames_per_s": done / el, "host_GBps": done * feed.frame_bytes / el / 1e9, "frames_per_batch": fps, "batches_in_flight": slots,
+    g = done * feed.frame_bytes / el / 1e9
+    out = {"frames_per_s": done / el, "host_GBps": g, "frames_per_batch": fps, "batches_in_flight": slots,
+           # the three fields every secondary leg carries; this leg's bound is the PCIe link (~56 GB/s in practice), not HBM
+           "algorithmic_bytes_per_step": int(fps * feed.frame_bytes), "GBps_algorithmic": g, "frac_of_hbm_peak": g / HBM_PEAK_GBS, "bound": "pcie",
            "what": "config %s, frames in pinned host memory -> H2D -> chain -> 48-byte results D2H, hipGraph replay (jrc_chain_feed_*)" % cfg}
     feed.close()
     return out
@@ -491,7 +494,9 @@ def host_fed_tx_resident_rate(ctx, cfg, sc, axes, seconds=1.5):
         done += len(feed.collect()[0])
     el = time.perf_counter() - t0
     rx_bytes = sc.R * sc.S * sc.N * 8
-    out = {"frames_per_s": done / el, "host_GBps": done * rx_bytes / el / 1e9, "bytes_per_frame_over_pcie": rx_bytes,
+    g = done * rx_bytes / el / 1e9
+    out = {"frames_per_s": done / el, "host_GBps": g, "bytes_per_frame_over_pcie": rx_bytes,
+           "algorithmic_bytes_per_step": int(fps * rx_bytes), "GBps_algorithmic": g, "frac_of_hbm_peak": g / HBM_PEAK_GBS, "bound": "pcie",
            "bytes_per_frame_full_upload": (sc.T + sc.R) * (sc.Npre + sc.S) * sc.N * 8, "results_equal_full_upload": bool(same),
            "frames_per_batch": fps, "batches_in_flight": slots,
            "what": "config %s with the TX reference ports resident on the device (jrc_chain_feed_set_tx / _submit_rx): receive ports of the "
