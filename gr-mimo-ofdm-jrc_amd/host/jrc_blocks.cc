@@ -428,8 +428,8 @@ public:
         cfg.n_items = N_sym; cfg.noise_discard_range_m = ndr; cfg.noise_discard_angle_deg = nda;
         cfg.snr_threshold = snr_threshold; cfg.power_threshold = power_threshold;
         const std::vector<int> devs = devices_from_env();
-        // full batches are replayed from a recorded hipGraph (one launch instead of copy + kernels + copy enqueued one by one: at the reference
-        // flowgraph's 27 KB packets the enqueue calls are what a batch costs the scheduler's thread); JRC_RADAR_CHAIN_GRAPH=0 submits directly
+        // full batches are replayed from a recorded hipGraph (one launch instead of copy + kernels + copy enqueued one by one; measured neutral at the
+        // reference flowgraph's 27 KB packets, round 5: what a batch costs is its size); JRC_RADAR_CHAIN_GRAPH=0 submits directly
         const char* ge = getenv("JRC_RADAR_CHAIN_GRAPH");
         const int feed_flags = (ge && atoi(ge) == 0) ? 0 : JRC_FEED_GRAPH;
         if (devs.size() > 1) {         // one host process, several GPUs: batch k on device k mod n, results in frame order (jrc_chain_feed_create_multi)
