@@ -767,6 +767,8 @@ def secondary_figures(cfg, ctx, sc, axes):
         def _drf():
             r = be.device_resident_flowgraph(64)
             r["packets_per_s_at_256_per_pass"] = be.device_resident_flowgraph(256)["frames_per_s"]     # the same leg when a pass holds four times the packets
+            g = be.device_resident_flowgraph_grc(512)                                                  # and at the reference flowgraph's own geometry (4x2, 64 subcarriers)
+            r["grc_geometry"] = {k: g[k] for k in ("what", "frames_per_step", "ms_per_step", "frames_per_s", "packet0")}
             return r
         leg("device_resident_sim_flowgraph", _drf)
     leg("equalizer_config_c", _eq)

@@ -235,6 +235,23 @@ def device_resident_flowgraph(F=64):
                 simulators_summed_on_the_spectrum=bool(sim.sum_on_spectrum), packet0=dict(range_m=r.range_val, angle_deg=r.angle_val, snr_db=r.snr_est))
 
 
+def device_resident_flowgraph_grc(F=512):
+    """the same device-resident leg at the reference flowgraph's OWN geometry (…radar_sim.grc: 4 TX x 2 RX, fft_len 64, 100-byte PDUs = 18 data symbols,
+    radar window N_pre 5 / N_sym 4, 2400-sample bursts, map 512 x 128), constant tables from tests/golden/ofdm_config_64.npz"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "examples"))
+    import radar_sim_device_resident as drm
+    o = np.load(os.path.join(root, "tests", "golden", "ofdm_config_64.npz"))
+    o = {k: o[k] for k in o.files}
+    sim = drm.DeviceResidentRadarSim(o, 64, 2, 18, 4, F, trgt_range=[10.0], trgt_velocity=[0.0], trgt_rcs_dbsm=[20.0], trgt_angle=[20.0])
+    rng = np.random.default_rng(1)
+    sim.load_symbols(np.stack([drm.qpsk_symbols(rng, 18 * sim.nd) for _ in range(F)]))
+    t = timed(lambda: sim.step(F), steps=12, warm=3)
+    r = sim.results(F)[0]
+    return dict(what="device-resident simulation flowgraph at the .grc's own geometry (4x2, 64 subcarriers, %d-sample bursts), %d packets per pass" % (sim.n_burst, F),
+                frames_per_step=F, ms_per_step=t * 1e3, frames_per_s=F / t, packet0=dict(range_m=r.range_val, angle_deg=r.angle_val, snr_db=r.snr_est))
+
+
 def sync_front_end(n_frames=512):
     """capture in HBM -> frames of symbols (detection metrics, frame_detector, frame_sync run to completion)"""
     import subprocess
@@ -347,7 +364,8 @@ if __name__ == "__main__":
             "detectD_noise": lambda: detect_only("D", noise_only=True), "powerB": lambda: power_map("B"), "powerD": lambda: power_map("D"),
             "equalizer": equalizer_config_c, "precoder": precoder_config_c, "rdD": lambda: range_doppler("D", 64), "rdB": lambda: range_doppler("B", 64),
             "demodB": lambda: radar_with_demod("B", 512), "demodD": lambda: radar_with_demod("D", 256), "comm_rx": comm_rx_chain,
-            "simB": lambda: simulated_chain("B", 64), "simD": lambda: simulated_chain("D", 8), "flowgraphB": lambda: device_resident_flowgraph(64)}
+            "simB": lambda: simulated_chain("B", 64), "simD": lambda: simulated_chain("D", 8), "flowgraphB": lambda: device_resident_flowgraph(64),
+            "flowgraph_grc": lambda: device_resident_flowgraph_grc(512)}
     GROUPS = {"detect": ["detectB", "detectB_noise", "detectD", "detectD_noise", "powerB", "powerD"], "demod": ["demodB", "demodD"],
               "comm": ["comm_rx", "equalizer", "precoder"]}
     if only:
