@@ -111,6 +111,31 @@ def test_direct_route_on_buffers_that_are_only_8_byte_aligned(jrc, ctx):
     assert torch.equal(flat_out[1:].reshape(B, R, n), d_out) and flat_out[0].item() == 0
 
 
+@pytest.mark.parametrize("n", [23040, 174080])
+def test_closed_forms_at_the_baseline_burst_sizes(jrc, ctx, n):
+    """properties that need no second implementation, at config B's (72 x 320 = 45 x 512) and config D's (136 x 1280 = 85 x 2048) burst length:
+    a target whose delay is a whole number of samples and whose carrier phase is a whole number of turns gives amp x the burst rolled by that
+    delay (lib/target_simulator_impl.cc:291-305: the time-shift filter is then exp(-j 2 pi k delay / n) / n exactly); a Doppler-only target
+    multiplies the burst by a tone; and the block is linear in its input"""
+    fs, fc, delay = 100_000_000, 1e9, 7
+    R = delay * 3e8 / fs / 2                                        # 10.5 m: 2R/c = 7 samples, fc x tau = 70 turns
+    rng = np.random.default_rng(n)
+    x, y2 = crandn(rng, n), crandn(rng, n)
+    sim = jrc.target_simulator([R], [0.0], [10.0], [0.0], [0.0, 0.0], fs, fc, ctx=ctx)
+    amp = 3e8 * np.sqrt(10.0) / 44.54662397465366 / R ** 2 / fc
+    out = sim.work(x)
+    assert rel_err(out[0], amp * np.roll(x, delay)) < 2e-4 and np.array_equal(out[0], out[1])      # (the reference's float filter phases: 2e-4, as in the CPU tier)
+    a, b = np.complex64(0.7 - 0.2j), np.complex64(-1.1 + 0.4j)
+    lin = sim.work((a * x + b * y2).astype(np.complex64))
+    assert rel_err(lin, a * out + b * sim.work(y2)) < 1e-5
+    v = 15.0
+    dop = jrc.target_simulator([R], [v], [10.0], [0.0], [0.0], fs, fc, ctx=ctx).work(x)[0]
+    tone = np.exp(2j * np.pi * (2 * v * fc / 3e8) / fs * np.arange(n))
+    # doppler first (:345), then the delay.  The reference advances the Doppler phase by a FLOAT recurrence (:281-287: fmod of a float sum, n steps), which
+    # the device's filter table follows step for step; against the exact tone that recurrence has drifted 4e-4 after 23,040 steps and 1.5e-3 after 174,080
+    assert rel_err(dop, amp * np.roll(x * tone, delay)) < (5e-4 if n < 30000 else 3e-3)
+
+
 def test_burst_too_long_is_refused(jrc, ctx):
     g = jrc.target_simulator([10.0], [0.0], [1.0], [0.0], [0.0], FS, FC, ctx=ctx)
     with pytest.raises(jrc.JrcError):
