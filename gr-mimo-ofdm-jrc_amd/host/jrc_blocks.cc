@@ -582,7 +582,11 @@ radar_chain::sptr radar_chain::make(int fft_len, int N_tx, int N_rx, int N_sym, 
                                     const std::string& stats_path, bool stats_record, int frames_per_batch, int batches_in_flight,
                                     const std::string&, bool, bool background_removal, bool background_recording, int record_len)
 {
-    if (frames_per_batch <= 0) frames_per_batch = RADAR_CHAIN_DEFAULT_FRAMES_PER_BATCH;             // 0: the defaults of the header
+    if (frames_per_batch <= 0) {                                                                    // 0: automatic — the header's default, within 64 MiB of staging per slot
+        const long long frame_bytes = (long long)(N_tx + N_rx) * N_sym * fft_len * (long long)sizeof(gr_complex);
+        const long long fit = frame_bytes > 0 ? (64LL << 20) / frame_bytes : RADAR_CHAIN_DEFAULT_FRAMES_PER_BATCH;
+        frames_per_batch = (int)std::max<long long>(1, std::min<long long>(RADAR_CHAIN_DEFAULT_FRAMES_PER_BATCH, fit));
+    }
     if (batches_in_flight <= 0) batches_in_flight = RADAR_CHAIN_DEFAULT_BATCHES_IN_FLIGHT;
     return JRC_GET_INITIAL_SPTR(new radar_chain_impl(fft_len, N_tx, N_rx, N_sym, N_pre, interp_range, interp_angle, enable_tx_interleave,
                                                      range_bins, angle_bins, noise_discard_range_m, noise_discard_angle_deg, snr_threshold,

@@ -67,7 +67,8 @@ public:
 // mimo_ofdm_radar (N_tx + N_rx streams of fft_len vectors, `packet_len`), same `params` message port and log file as
 // range_angle_estimator; no stream output — the range-angle map stays on the device.  Every frame offered in a scheduler turn goes
 // through the host-fed pipeline (jrc_chain_feed_*): batches in flight on their own streams, results published in frame order.
-// defaults of radar_chain::make (a value <= 0 selects them): a batch is whatever a scheduler turn offers up to frames_per_batch, so a larger
+// defaults of radar_chain::make (a value <= 0 selects them; the frames per batch are capped so that a slot's pinned staging buffer stays within 64 MiB:
+// 64 frames at the .grc's shape and at config B, 7 at config D's 8.4 MB frames): a batch is whatever a scheduler turn offers up to frames_per_batch, so a larger
 // value costs nothing at low packet rates; sized on the reference flowgraph's own 27 KB packets (bench.py, host_fed_reference_flowgraph_shape:
 // 16 x 3 -> 335 k packets/s, 32 x 3 -> 478 k, 64 x 3 -> 853 k with 64 packets per scheduler turn, round 5; a batch is one H2D + five kernels
 // + one D2H, replayed from a hipGraph, whatever it holds)
@@ -79,7 +80,8 @@ public:
     static sptr make(int fft_len, int N_tx, int N_rx, int N_sym, int N_pre, int interp_range, int interp_angle, bool enable_tx_interleave,
                      std::vector<float> range_bins, std::vector<float> angle_bins, float noise_discard_range_m,
                      float noise_discard_angle_deg, float snr_threshold, float power_threshold, const std::string& stats_path,
-                     bool stats_record, int frames_per_batch = RADAR_CHAIN_DEFAULT_FRAMES_PER_BATCH,
+                     bool stats_record,
+                     int frames_per_batch = 0,            // 0 = automatic: up to RADAR_CHAIN_DEFAULT_FRAMES_PER_BATCH, a slot of at most 64 MiB
                      int batches_in_flight = RADAR_CHAIN_DEFAULT_BATCHES_IN_FLIGHT,
                      const std::string& len_tag_key = "packet_len", bool debug = false,
                      // mimo_ofdm_radar's background arguments (include/mimo_ofdm_jrc/mimo_ofdm_radar.h:52-56)
