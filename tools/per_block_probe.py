@@ -90,7 +90,8 @@ def block_legs(point, calls):
         assert blk.run(P, tx + rx, [H]) == P
         pos[0] += n_total
     r = time_calls(radar_call, calls)
-    r.update(h2d_bytes=(T + R) * S * N * 8, d2h_bytes=P * NR * 8, what="%d ports x %d items x %d carriers in, %d x %d out (zero-padded rows)" % (T + R, n_total, N, P, NR))
+    # (only the N_sym used symbols of each port go up, and only the P x N estimates come back: the rows are zero-padded on the host side of the link)
+    r.update(h2d_bytes=(T + R) * S * N * 8, d2h_bytes=P * N * 8, what="%d ports x %d items x %d carriers in, %d x %d out (zero-padded rows)" % (T + R, n_total, N, P, NR))
     out["mimo_ofdm_radar"] = r
 
     # --- matrix_transpose: [P][NR] -> [NR][NA] ------------------------------------------------------------------------------------------------
