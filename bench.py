@@ -66,6 +66,10 @@ def parse(argv=None):
     ap.add_argument("--dump", default="", metavar="PATH.npz",
                     help="rank 0 writes the frame-ordered results of all ranks (and the first --dump-maps maps of every rank) after the timed region")
     ap.add_argument("--dump-maps", type=int, default=0)
+    ap.add_argument("--verbose-out", default="", metavar="PATH.json",
+                    help="where rank 0 writes the full record (every leg with its description); default gpurun_out/bench_verbose.json")
+    ap.add_argument("--launch-timeout", type=float, default=900.0,
+                    help="self-launch path: seconds the ranks may take before the launcher kills the children it started and exits 124")
     return ap.parse_args(argv)
 
 
@@ -80,6 +84,15 @@ def _free_port():
     return p
 
 
+def same_device_hw_queues(world):
+    """--same-device (testing only) puts `world` processes on ONE GPU.  HIP multiplexes a process's streams onto up to GPU_MAX_HW_QUEUES (default 4)
+    hardware queues, and the device's compute scheduler holds 24 user queues per XCC before it has to time-slice the run list with wave
+    save/restore — the regime in which the 8-rank run of round 5 ended in `HW Exception ... GPU Hang` on the driver's box (8 x 4 = 32 queues).
+    A rank of this bench needs two (torch's stream and the context's), so the ranks of a shared device are capped to fit with room to spare (16 // world,
+    at least 1, at most HIP's default 4).  One process per GPU — the real N-GPU launch — is not touched."""
+    return max(1, min(4, 16 // max(1, world)))
+
+
 def self_launch(a, argv):
     # the ranks start together: build (or find built) the extension ONCE here, before any of them looks for it.  Compiling is not a GPU
     # call; the build is also flock-guarded (build.build_lock) for ranks that a launcher other than this one starts on an unbuilt tree.
@@ -92,22 +105,44 @@ def self_launch(a, argv):
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    LOCAL_WORLD_SIZE=str(a.gpus), JRC_BENCH_CHILD="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if a.same_device and a.gpus > 1:
+            env.setdefault("GPU_MAX_HW_QUEUES", str(same_device_hw_queues(a.gpus)))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
-    out0, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    deadline = time.time() + 120
-    for p in procs[1:]:
-        try:
-            p.wait(timeout=max(1.0, deadline - time.time()))
-        except subprocess.TimeoutExpired:
-            p.kill()                      # exactly the child this process started
-            p.wait()
-        rc = rc or p.returncode
+    # bounded: a rank that never comes back (a device fault under it, a rendezvous that never completes) must not hold the launcher — and
+    # whatever started the launcher — for ever.  On expiry the children THIS process started are killed (never anything else) and the exit is non-zero.
+    deadline = time.time() + a.launch_timeout
+    timed_out, out0 = False, ""
+    try:
+        out0, _ = procs[0].communicate(timeout=max(1.0, deadline - time.time()))
+    except subprocess.TimeoutExpired:
+        timed_out = True
+    rc = procs[0].returncode or 0
+    if not timed_out:
+        for p in procs[1:]:
+            try:
+                p.wait(timeout=max(1.0, min(deadline, time.time() + 120) - time.time()))
+            except subprocess.TimeoutExpired:
+                timed_out = True
+                break
+            rc = rc or p.returncode
+    if timed_out:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()                  # exactly the children this process started
+        for p in procs:
+            try:
+                p.wait(timeout=15)        # a child stuck under a device fault may not even take SIGKILL at once: do not wait for it for ever
+            except subprocess.TimeoutExpired:
+                pass
+        sys.stderr.write("bench.py: the ranks did not finish within --launch-timeout %.0f s: children killed\n" % a.launch_timeout)
+        return 124
     lines = [l for l in (out0 or "").splitlines() if l.startswith("{")]
     for l in (out0 or "").splitlines():
         if not l.startswith("{"):
             sys.stderr.write(l + "\n")
+    for l in lines[:-1]:                  # a rank's earlier lines (the verbose record) pass through in front of the contract's line
+        print(l)
     if lines:
         print(lines[-1])
     sys.stdout.flush()
@@ -694,7 +729,7 @@ def per_block_drop_in():
         cpu = per_block_cpu_blocks(point)
         for name, b in out[point]["blocks"].items():
             b["cpu_block_p50_us"] = cpu.get(name)
-            b["gpu_over_cpu"] = (b["p50_us"] / cpu[name]) if cpu.get(name) else None
+            b["gpu_us_over_cpu_us"] = (b["p50_us"] / cpu[name]) if cpu.get(name) else None     # > 1: the GPU call takes LONGER than the CPU block
         out[point]["stock_fft_vxx_cpu_p50_us"] = {"range": cpu["stock_fft_vxx_range_cpu"], "angle": cpu["stock_fft_vxx_angle_cpu"]}
     out["what"] = ("one work() call of each hot block through host/jrc_blocks.cc with host buffers (H2D + kernels + D2H + sync per call) — p50 / p99 us and the "
                    "bytes over PCIe — beside the oracle's CPU block on the same shapes (cpu_block_p50_us, one core); radar_branch_unchanged_grc = GPU radar -> CPU "
@@ -778,6 +813,118 @@ def secondary_figures(cfg, ctx, sc, axes):
     leg("precoder_config_c", _pre)
     leg("range_doppler_config_d", _rd)
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the contract's line.  The full record (`out` of main(): every secondary leg with its prose, per-window times, per-rank identities) is written
+# to --verbose-out and to stderr; the LAST stdout line is this compact form, held under LINE_LIMIT bytes whatever the legs grow to — round 5's
+# 21 KB line was not parsed by the driver, and took the headline down with it.
+# ----------------------------------------------------------------------------------------------------------------------
+LINE_LIMIT = 6000
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def _rnd(v, sig=6):
+    if isinstance(v, float):
+        if v != v or abs(v) == float("inf"):
+            return None
+        if v.is_integer() and abs(v) < 2.0 ** 53:
+            return int(v)                    # byte and frame counts stay exact
+        return float("%.*g" % (sig, v))
+    if isinstance(v, dict):
+        return {k: _rnd(x, sig) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_rnd(x, sig) for x in v]
+    return v
+
+
+_LEG_VALUE_KEYS = ("frames_per_s", "packets_per_s_steering_and_radar_streams", "packets_per_s_dft", "radar_chain_block_frames_per_s", "M_samples_per_s")
+
+
+def compact_secondary(sec):
+    """{leg: {value, unit, frac_of_hbm_peak}} — numbers only"""
+    out = {}
+    for name, leg in (sec or {}).items():
+        if not isinstance(leg, dict):
+            continue
+        if "error" in leg:
+            out[name] = {"error": str(leg["error"])[:80]}
+            continue
+        if name == "per_block_drop_in":       # GPU call / CPU block, p50 microseconds, at the .grc point and at config B
+            e = {}
+            for point in ("grc", "B"):
+                for blk, b in (leg.get(point, {}).get("blocks", {}) or {}).items():
+                    e.setdefault(blk, {})[point] = [b.get("p50_us"), b.get("cpu_block_p50_us")]
+            out[name] = {"unit": "p50 us [gpu call, cpu block]", "blocks": e}
+            continue
+        c = {}
+        for k in _LEG_VALUE_KEYS:
+            if k in leg:
+                c["value"] = leg[k]
+                c["unit"] = {"M_samples_per_s": "Msamples/s"}.get(k, "packets/s" if "packets" in k or "block" in k else "frames/s")
+                break
+        f = leg.get("frac_of_hbm_peak", leg.get("frac"))
+        if f is not None:
+            c["frac_of_hbm_peak"] = f
+        out[name] = c
+    return out
+
+
+def compact_line(out, verbose_path=None):
+    """the ONE stdout line of the contract from the full record: headline fields, roofline (+ chain), cpu_baseline (numbers), check, and the
+    secondary legs as {value, unit, frac_of_hbm_peak}.  Guaranteed to serialise to fewer than LINE_LIMIT bytes: if it ever would not, the
+    optional parts are dropped, largest first, and the line says which."""
+    c = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"))
+    cfg = dict(out.get("config", {}))
+    c["config"] = cfg
+    r = out.get("roofline", {})
+    c["roofline"] = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_stale", "algorithmic_bytes_per_launch",
+                              "avg_launch_ms", "launches_timed", "launches_per_step", "frames_per_launch"))
+    ch = r.get("chain")
+    if ch:
+        c["roofline"]["chain"] = dict(_pick(ch, ("compulsory_bytes_per_frame", "achieved", "frac", "ms_per_step", "kernels_sum_ms")),
+                                      **({"a1": _pick(ch["a1"], ("kernel", "achieved", "frac", "avg_ms"))} if "a1" in ch else {}))
+    cb = out.get("cpu_baseline")
+    if cb:
+        c["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "host_cpus"))
+        c["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:120]
+        if isinstance(cb.get("all_cores"), dict):
+            c["cpu_baseline"]["all_cores"] = _pick(cb["all_cores"], ("value", "cores"))
+        if isinstance(cb.get("pipeline_ideal"), dict):
+            c["cpu_baseline"]["pipeline_ideal"] = _pick(cb["pipeline_ideal"], ("value", "cores", "value_with_tuned_fft"))
+    c["windows"] = _pick(out.get("windows", {}), ("n", "ms_per_step_median", "ms_per_step_min", "ms_per_step_max"))
+    c["kernels_ms"] = out.get("kernels_ms")
+    c["check"] = _pick(out.get("check", {}), ("ok", "ok_all_ranks", "frames_checked", "oracle_frames", "tiled_bit_equal", "chanest_bit_exact",
+                                             "map_max_rel_err", "map_tol", "estimator_fields_exact", "range_m", "angle_deg", "snr_db"))
+    if out.get("with_results_on_host"):
+        c["with_results_on_host"] = _pick(out["with_results_on_host"], ("frames_per_s", "ms_per_step", "records_complete_on_host", "records_equal_headline_run"))
+    c.update(_pick(out, ("device", "backend", "collective_world", "distinct_devices", "value_over_n_times_slowest_rank")))
+    c["ranks"] = [_pick(rk, ("rank", "device_key", "pid", "ms_per_step_window0")) for rk in out.get("ranks", [])]
+    if "secondary" in out:
+        c["secondary"] = compact_secondary(out["secondary"])
+    if verbose_path:
+        c["verbose_record"] = verbose_path
+    c = _rnd(c)
+    dropped = []
+    for victim in (None, "secondary.per_block_drop_in", "ranks", "secondary", "with_results_on_host", "windows", "kernels_ms"):
+        if victim:
+            top, _, sub = victim.partition(".")
+            if sub:
+                if isinstance(c.get(top), dict) and sub in c[top]:
+                    del c[top][sub]
+                    dropped.append(victim)
+            elif top in c:
+                del c[top]
+                dropped.append(victim)
+            if dropped:
+                c["dropped_to_fit"] = dropped
+        line = json.dumps(c, separators=(",", ":"), allow_nan=False)
+        if len(line) < LINE_LIMIT:
+            return line
+    raise RuntimeError("compact_line: %d bytes after dropping every optional part" % len(line))
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -1013,7 +1160,19 @@ def main():
             bufs.clear()                         # the secondary legs allocate their own batches (config D: 6 GiB)
             torch.cuda.empty_cache()
             out["secondary"] = secondary_figures(a.config, ctx, sc, axes)
-        print(json.dumps(out))
+        # full record: to the file and to stderr; the contract's ONE stdout line is the compact form (< LINE_LIMIT bytes)
+        vpath = a.verbose_out or os.path.join(ROOT, "gpurun_out", "bench_verbose.json")
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(vpath)), exist_ok=True)
+            with open(vpath, "w") as fh:
+                json.dump(out, fh)
+                fh.write("\n")
+        except OSError as ex:
+            sys.stderr.write("bench.py: verbose record not written to %s: %s\n" % (vpath, ex))
+            vpath = None
+        sys.stderr.write("bench.py verbose record: " + json.dumps(out) + "\n")
+        sys.stderr.flush()
+        print(compact_line(out, os.path.relpath(vpath, ROOT) if vpath else None))
         sys.stdout.flush()
     if shared_device and not a.same_device:
         sys.stderr.write("bench.py: two ranks ran on the same device (%s): not an N-GPU measurement\n" % ", ".join(same_bus))

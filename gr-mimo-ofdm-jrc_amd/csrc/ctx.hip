@@ -3,6 +3,7 @@
 #include <cstring>
 
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -228,7 +229,21 @@ const roctx_api& roctx() { static const roctx_api api; return api; }
 
 void jrc_trace_push(const char* name) { if (roctx().push) roctx().push(name); }
 void jrc_trace_pop() { if (roctx().pop) roctx().pop(); }
-jrc_trace_range::jrc_trace_range(const char* name) : on(roctx().push != nullptr) { if (on) jrc_trace_push(name); }
+// JRC_LOG_CALLS=1: every batched entry point writes "[jrc <pid> rank <RANK>] <entry point>" to stderr (unbuffered) before it launches, so a
+// process that dies under a device fault has named the call it was in (the 8-rank same-device run that hung on the driver box)
+static bool jrc_log_calls()
+{
+    static const bool on = []() { const char* v = getenv("JRC_LOG_CALLS"); return v && *v && *v != '0'; }();
+    return on;
+}
+jrc_trace_range::jrc_trace_range(const char* name) : on(roctx().push != nullptr)
+{
+    if (jrc_log_calls()) {
+        const char* rk = getenv("RANK");
+        fprintf(stderr, "[jrc %d rank %s] %s\n", (int)getpid(), rk ? rk : "-", name);
+    }
+    if (on) jrc_trace_push(name);
+}
 
 void jrc_host_copy(void* dst, const void* src, size_t bytes)
 {

@@ -17,13 +17,23 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
 
 
-def _run(args, timeout=600, env=None):
+def _run(args, timeout=300, env=None, verbose=None):
+    """runs bench.py; returns (completed process, the JSON lines of its stdout).  With `verbose` = a path, bench.py writes its full record there
+    and the last element of `lines` is replaced by that record (the stdout line itself is the compact form, checked on its own below)."""
     e = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         e.pop(k, None)
     e.update(env or {})
+    if verbose:
+        args = args + ["--verbose-out", verbose]
     r = subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, timeout=timeout, env=e, cwd=ROOT)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if verbose and r.returncode == 0 and lines:
+        assert len(lines[-1]) < 6000                       # the contract's line stays short whatever the record holds
+        c = json.loads(lines[-1])
+        full = json.loads(open(verbose).read())
+        assert c["value"] == pytest.approx(full["value"], rel=1e-5) and c["n_gpus"] == full["n_gpus"] and c["check"]["ok"] == full["check"]["ok"]
+        lines[-1] = json.dumps(full)
     return r, lines
 
 
@@ -36,6 +46,69 @@ def test_self_launch_without_gpu_fails_loudly():
     assert r.returncode != 0
     assert not lines                                   # no result line from a run that did not happen
     assert "needs a GPU" in r.stderr
+
+
+def test_contract_line_stays_short_and_parses():
+    """round 5's line grew to 21 KB and the driver could not parse it.  The recorded full record of that run
+    (tests/golden/bench_verbose_r05.json) through the same compaction bench.py prints: < 6000 bytes, strict JSON, headline + roofline +
+    cpu_baseline + every secondary leg as {value, unit, frac_of_hbm_peak}; an 8-rank record and a record with runaway legs stay short too."""
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.loads(open(os.path.join(ROOT, "tests", "golden", "bench_verbose_r05.json")).read())
+    assert len(json.dumps(full)) > 20000
+    line = bench.compact_line(full, "gpurun_out/bench_verbose.json")
+    assert len(line) < bench.LINE_LIMIT == 6000 and "\n" not in line
+    c = json.loads(line)
+    assert json.loads(json.dumps(c)) == c
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in c, k
+    assert c["value"] == pytest.approx(full["value"], rel=1e-5) and c["ms_per_step"] == pytest.approx(full["ms_per_step"], rel=1e-5)
+    assert c["config"]["workload"] == full["config"]["workload"]
+    r = c["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-4)
+    assert r["traffic"] == full["roofline"]["traffic"] and r["algorithmic_bytes_per_launch"] == 512 * 4227072
+    assert r["chain"]["frac"] > 0 and r["chain"]["a1"]["frac"] > 0
+    b = c["cpu_baseline"]
+    assert b["kind"] == "port" and b["cores"] == 1 and b["value"] > 0 and b["unit"] == "frames/s" and len(b["sample"]) <= 120
+    assert c["check"]["ok"] is True
+    assert set(c["secondary"]) == set(full["secondary"])
+    for name, leg in c["secondary"].items():
+        if name == "per_block_drop_in":
+            assert leg["blocks"]["mimo_ofdm_radar"]["B"][0] > 0
+            continue
+        assert set(leg) <= {"value", "unit", "frac_of_hbm_peak", "error"} and "value" in leg, (name, leg)
+    # eight ranks: the per-rank entries are cut to what identifies a rank
+    eight = dict(full, n_gpus=8, ranks=[dict(full["ranks"][0], rank=k, pid=1000 + k) for k in range(8)])
+    l8 = bench.compact_line(eight)
+    assert len(l8) < 6000 and [r["rank"] for r in json.loads(l8)["ranks"]] == list(range(8))
+    # legs that run away (a secondary leg returning pages of prose, hundreds of legs) cannot take the headline with them
+    fat = dict(full, secondary=dict(full["secondary"], **{"leg_%d" % k: {"frames_per_s": 1.0 * k, "what": "x" * 4000} for k in range(400)}))
+    lf = bench.compact_line(fat)
+    cf = json.loads(lf)
+    assert len(lf) < 6000 and cf["value"] == c["value"] and cf["roofline"]["frac"] == c["roofline"]["frac"] and "secondary" in cf["dropped_to_fit"]
+    # a NaN from a failed leg must not produce a line json.loads rejects
+    bad = dict(full, secondary={"x": {"frames_per_s": float("nan"), "frac_of_hbm_peak": float("inf")}})
+    assert json.loads(bench.compact_line(bad))["secondary"]["x"]["value"] is None
+
+
+def test_self_launch_is_bounded(tmp_path):
+    """bench.py's launcher must not wait for its ranks for ever: with ranks that never finish (a stand-in script that
+    sleeps) the launcher kills the children it started and exits 124 within --launch-timeout"""
+    sys.path.insert(0, ROOT)
+    import bench
+    import time
+    a = bench.parse(["--gpus", "2", "--launch-timeout", "3"])
+    real_file = bench.__file__
+    sleeper = tmp_path / "sleeper.py"
+    sleeper.write_text("import time\ntime.sleep(600)\n")
+    bench.__file__ = str(sleeper)
+    try:
+        t0 = time.time()
+        rc = bench.self_launch(a, [])
+        assert rc == 124 and time.time() - t0 < 30
+    finally:
+        bench.__file__ = real_file
+    assert bench.same_device_hw_queues(8) == 2 and bench.same_device_hw_queues(2) == 4 and bench.same_device_hw_queues(64) == 1
 
 
 def test_argument_surface():
@@ -55,13 +128,14 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path):
     F = 48
     one = str(tmp_path / "one.npz")
     two = str(tmp_path / "two.npz")
-    r1, l1 = _run(COMMON + ["--frames", str(2 * F), "--distinct", str(2 * F), "--dump", one, "--dump-maps", str(2 * F), "--oracle-frames", "4"])
+    r1, l1 = _run(COMMON + ["--frames", str(2 * F), "--distinct", str(2 * F), "--dump", one, "--dump-maps", str(2 * F), "--oracle-frames", "4"],
+                  verbose=str(tmp_path / "v1.json"))
     assert r1.returncode == 0, r1.stderr[-2000:]
     j1 = json.loads(l1[-1])
     assert j1["n_gpus"] == 1 and j1["check"]["ok"] and j1["config"]["launcher"] == "direct"
     assert len(j1["ranks"]) == 1 and j1["collective_world"] == 1 and j1["backend"] is None and j1["distinct_devices"] == 1
     r2, l2 = _run(COMMON + ["--gpus", "2", "--same-device", "--backend", "gloo", "--frames", str(F), "--distinct", str(F), "--dump", two,
-                            "--dump-maps", "3", "--oracle-frames", "4", "--gather-results", "--gather-maps", "2"])
+                            "--dump-maps", "3", "--oracle-frames", "4", "--gather-results", "--gather-maps", "2"], verbose=str(tmp_path / "v2.json"))
     assert r2.returncode == 0, r2.stderr[-2000:]
     assert len(l2) == 1                                # ONE JSON line, from rank 0
     j2 = json.loads(l2[-1])
@@ -92,10 +166,11 @@ def test_eight_ranks_with_ragged_shards_equal_one_rank(tmp_path):
     from jrc_amd import shard
     M, W = 203, 8
     one, eight = str(tmp_path / "one.npz"), str(tmp_path / "eight.npz")
-    r1, l1 = _run(COMMON + ["--frames", str(M), "--distinct", str(M), "--dump", one, "--dump-maps", str(M), "--oracle-frames", "4"])
+    r1, l1 = _run(COMMON + ["--frames", str(M), "--distinct", str(M), "--dump", one, "--dump-maps", str(M), "--oracle-frames", "4"], timeout=240)
     assert r1.returncode == 0, r1.stderr[-2000:]
     r8, l8 = _run(COMMON + ["--gpus", str(W), "--same-device", "--backend", "gloo", "--stream-frames", str(M), "--distinct", str(M), "--dump", eight,
-                            "--dump-maps", "2", "--oracle-frames", "4", "--gather-results", "--gather-maps", "2"], timeout=1200)
+                            "--dump-maps", "2", "--oracle-frames", "4", "--gather-results", "--gather-maps", "2", "--launch-timeout", "200"],
+                  timeout=240, verbose=str(tmp_path / "v8.json"), env={"JRC_LOG_CALLS": os.environ.get("JRC_LOG_CALLS", "0")})
     assert r8.returncode == 0, r8.stderr[-3000:]
     assert len(l8) == 1
     j = json.loads(l8[-1])
@@ -125,7 +200,12 @@ def test_two_ranks_on_one_device_without_the_test_flag_is_refused():
         e = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, BENCH] + COMMON + ["--gpus", "2", "--backend", "gloo", "--frames", "16", "--no-check"],
                                       env=e, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    outs = [p.communicate(timeout=600) for p in procs]
+    try:
+        outs = [p.communicate(timeout=240) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()                                   # the children this test started, nothing else
     assert all(p.returncode == 4 for p in procs), [(p.returncode, o[1][-500:]) for p, o in zip(procs, outs)]
     assert "same device" in outs[0][1]
 
@@ -140,7 +220,9 @@ def test_self_launched_single_rank_matches_direct():
     assert jd["config"]["launcher"] == "direct" and js["config"]["launcher"] == "self-launched children"
     assert js["check"]["ok"] and jd["check"]["ok"]
     md, ms = jd["windows"]["ms_per_step_median"], js["windows"]["ms_per_step_median"]
-    assert abs(md - ms) / md < 0.15, (md, ms)          # same work per step whichever way the rank was started (measured: within 1-2 %)
+    # same work per step whichever way the rank was started (measured: within 1-2 %).  A sanity bound, not a performance assertion: this suite is
+    # the correctness evidence and runs on a shared box; the figures themselves are bench.py's business
+    assert 0.5 < ms / md < 2.0, (md, ms)
 
 
 @pytest.mark.gpu
@@ -176,5 +258,5 @@ dist.destroy_process_group()
 print("rccl ok")
 ''' % ROOT)
     e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=e, cwd=ROOT)
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=240, env=e, cwd=ROOT)
     assert r.returncode == 0 and "rccl ok" in r.stdout, r.stderr[-3000:]

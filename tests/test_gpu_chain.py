@@ -822,6 +822,7 @@ def test_results_in_flight_equal_the_blocking_fetch(jrc, ctx):
 
 
 @pytest.mark.gpu
+@pytest.mark.spawns
 def test_store_pacing_word_is_within_three_percent_of_the_best_setting(jrc):
     """the derived pacing word of the map-writing kernel (chain.hip chain_pace: offered byte rate -> ticks of wall_clock64) is a
     performance setting that nothing else guards — on another partition mode or clock it could silently cost 10 %.  Time the config-B fused

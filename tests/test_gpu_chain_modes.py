@@ -612,6 +612,7 @@ def test_power_map_random_shapes(jrc, ctx, T, R, N, S, Ir, Ia, interleave):
 
 
 @pytest.mark.gpu
+@pytest.mark.spawns
 def test_work_skipping_experiment_switches_do_nothing_in_this_library():
     """JRC_DETECT_EXP / JRC_RD_EXP bits that leave work out of a kernel (tools/detect_exp.sh, tools/rd_exp.sh; the equalizer's JRC_EQ_EXP) exist
     only in a library built with -DJRC_TIMING_EXPERIMENTS.  A process that happens to inherit them with the shipped library is told they are
