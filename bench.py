@@ -595,6 +595,8 @@ def flowgraph_shape_host_fed(ctx, seconds=1.0):
         L.jrcb_run.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(vp), C.c_int, C.POINTER(vp)]
         L.jrcb_call_setter.argtypes = [vp, C.c_char_p, C.c_double]
         L.jrcb_destroy.argtypes = [vp]
+        L.jrcb_profile_ns.restype = C.c_longlong
+        L.jrcb_profile_ns.argtypes = [vp, C.c_int]
         rbf, abf = np.ascontiguousarray(rb, np.float32), np.ascontiguousarray(ab, np.float32)
         L.jrcb_add_in_tags.argtypes = [vp, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_char_p, C.c_int, C.c_long, C.c_double]
         ports = [np.ascontiguousarray(np.concatenate([frames[f, p] for f in range(64)])) for p in range(sc.T + sc.R)]
@@ -624,13 +626,13 @@ def flowgraph_shape_host_fed(ctx, seconds=1.0):
                 turns += 1
                 if turns == 20:
                     t0, t_turns = time.perf_counter(), turns
-                    prof0 = [int(L.jrcb_call_setter(h, b"profile_us", float(k))) for k in range(4)]
+                    prof0 = [L.jrcb_profile_ns(h, k) / 1e3 for k in range(4)]
                 if t0 is not None and time.perf_counter() - t0 > seconds:
                     break
             if t0 is not None and turns > t_turns:
                 el = time.perf_counter() - t0                          # (before the final flush: the rate of the steady state)
                 npk = (turns - t_turns) * 64
-                prof = [int(L.jrcb_call_setter(h, b"profile_us", float(k))) - prof0[k] for k in range(4)]
+                prof = [L.jrcb_profile_ns(h, k) / 1e3 - prof0[k] for k in range(4)]
                 out[pre + "frames_per_s"] = npk / el
                 out[pre + "us_per_packet_inside_work"] = 1e6 * t_work / npk
                 out[pre + "us_per_packet_breakdown"] = {"staging_tx_compare_and_copies": prof[0] / npk, "feed_submit_calls": prof[1] / npk,

@@ -728,7 +728,11 @@ __global__ __launch_bounds__(NTMAX, WPE) void equalizer_kernel(EqDev d, EqState*
                         Hm[sc] = make_float2(a.x + bb.x, a.y + bb.y);
                     }
             } else {
-                for (int i = tid; i < ND; i += NT) o[i] = Z[i];                         // unknown packet type: the reference emits stale Z
+                // unknown packet type: the reference emits the stale equalised SIG cells Z.  UNREACHABLE here — data symbols are only processed
+                // with sig_ok set, and the SIG parse sets sig_ok only for packet_type 1 (NDP) or 2 (DATA) — which matters because with `pre_lds`
+                // the MIMO-LTF store aliases Z: were this branch ever taken in that mode it would emit MIMO-LTF cells, not the reference's
+                // stale SIG cells.  Kept so that the control flow reads like the reference's.
+                for (int i = tid; i < ND; i += NT) o[i] = Z[i];
             }
             n_out++;
         }

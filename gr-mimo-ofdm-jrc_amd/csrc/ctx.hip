@@ -77,6 +77,7 @@ extern "C" int jrc_create(int device, jrc_ctx** out)
         ctx->n_xcd = (per_xcd && ctx->n_cus % per_xcd == 0) ? ctx->n_cus / per_xcd : 1;
     }
     if (const char* e = getenv("JRC_XCDS")) { const int v = atoi(e); if (v >= 1 && v <= 64) ctx->n_xcd = v; }
+    { int lds = 0; if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && lds > 0) ctx->max_lds_per_block = (size_t)lds; }
     { int khz = 0; if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) ctx->wall_clock_khz = khz; }
     if (const char* e = getenv("JRC_CHANEST_CHUNK")) ctx->tune.chanest_chunk = atoi(e);
     ctx->tune.chanest_x1 = getenv("JRC_CHANEST_X1") != nullptr;

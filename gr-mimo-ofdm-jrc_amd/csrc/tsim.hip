@@ -1015,14 +1015,20 @@ static void tsim_free_tables(jrc_tsim* h)
 }
 
 // n = n1 x n2 with n2 the largest power of two dividing n (<= 4096) and n1 <= TD_MAX_N1; the radices of the n1-point column transform
-static bool tsim_plan_direct(int n, td_plan* pl)
+static size_t td_col_lds_bytes(int n1, int cw) { return sizeof(float2) * ((size_t)2 * n1 * cw + (size_t)n1); }
+// `pairs` = (simulator, target) pairs one launch of this simulator carries (K with sum_targets, else 1): the launches hold at most TD_MAXV
+// of them, a simulator with more keeps the chirp-z route, which takes any K.  `max_lds` = the device's LDS per workgroup: the column passes
+// stage 2 x n1 x 16 cells (+ n1 twiddles), a length whose tile does not fit keeps the chirp-z route too.
+static bool tsim_plan_direct(int n, int pairs, size_t max_lds, td_plan* pl)
 {
     if (const char* e = getenv("JRC_TSIM_BLUESTEIN")) { if (atoi(e) != 0) return false; }
+    if (pairs > TD_MAXV) return false;
     int n2 = 1;
     while (n2 < 4096 && n % (n2 * 2) == 0) n2 *= 2;
     if (n2 < TD_CW) return false;
     const int n1 = n / n2;
     if (n1 > TD_MAX_N1) return false;
+    if (td_col_lds_bytes(n1, TD_CW) > max_lds) return false;
     pl->n1 = n1; pl->n2 = n2; pl->nrad = 0;
     int m = n1;
     while (m % 4 == 0) { pl->rad[pl->nrad++] = 4; m /= 4; }
@@ -1038,12 +1044,13 @@ static td_plan tsim_plan_of(const jrc_tsim* h)
     for (int i = 0; i < 24; i++) pl.rad[i] = h->rad[i];
     return pl;
 }
-static size_t td_col_lds_bytes(int n1, int cw) { return sizeof(float2) * ((size_t)2 * n1 * cw + (size_t)n1); }
-// columns per workgroup of the column passes: 32 (256-byte row segments) while the tile fits 64 KB of LDS, else 16; JRC_TSIM_CW overrides
+// columns per workgroup of the column passes: 32 (256-byte row segments) while the tile fits 64 KB of LDS, else 16; JRC_TSIM_CW overrides —
+// 32 only where its tile fits the 64 KB the <32> kernels may use without a dynamic-LDS opt-in (they never get one)
 static int td_pick_cw(int n1, int n2)
 {
-    int cw = (n2 >= 32 && td_col_lds_bytes(n1, 32) <= 64 * 1024) ? 32 : 16;
-    if (const char* e = getenv("JRC_TSIM_CW")) { const int v = atoi(e); if ((v == 16 || v == 32) && v <= n2) cw = v; }
+    const bool fits32 = n2 >= 32 && td_col_lds_bytes(n1, 32) <= 64 * 1024;
+    int cw = fits32 ? 32 : 16;
+    if (const char* e = getenv("JRC_TSIM_CW")) { const int v = atoi(e); if (v == 16 || (v == 32 && fits32)) cw = v; }
     return cw;
 }
 
@@ -1058,7 +1065,7 @@ static int tsim_prepare(jrc_tsim* h, int n, hipStream_t stream)
     tsim_free_tables(h);
     const int K = h->K, R = h->R;
     td_plan pl;
-    const bool direct = tsim_plan_direct(n, &pl);
+    const bool direct = tsim_plan_direct(n, (h->sum_targets && K > 1) ? K : 1, ctx->max_lds_per_block, &pl);
     long M = 32768;
     while (M < 2L * n - 1) M <<= 1;
     if (direct) M = n;                                 // the work buffers hold bursts of n samples, nothing is padded

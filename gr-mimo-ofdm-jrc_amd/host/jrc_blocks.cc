@@ -584,7 +584,14 @@ radar_chain::sptr radar_chain::make(int fft_len, int N_tx, int N_rx, int N_sym, 
 {
     if (frames_per_batch <= 0) {                                                                    // 0: automatic — the header's default, within 64 MiB of staging per slot
         const long long frame_bytes = (long long)(N_tx + N_rx) * N_sym * fft_len * (long long)sizeof(gr_complex);
-        const long long fit = frame_bytes > 0 ? (64LL << 20) / frame_bytes : RADAR_CHAIN_DEFAULT_FRAMES_PER_BATCH;
+        long long fit = frame_bytes > 0 ? (64LL << 20) / frame_bytes : RADAR_CHAIN_DEFAULT_FRAMES_PER_BATCH;
+        // the feed also holds a map and a channel estimate per frame of every slot ON THE DEVICE (jrc_chain_feed_create allocates them whether or
+        // not the block asks for maps): kept within 4 GiB per device over the slots — no change at the .grc's shape or at configs B / D (0.8 /
+        // 0.35 GB), a bound for shapes whose maps are large beside their frames
+        const long long P = (long long)N_tx * N_rx;
+        const long long dev_per_frame = ((long long)fft_len * interp_range * P * interp_angle + P * fft_len) * (long long)sizeof(gr_complex);
+        const int slots = batches_in_flight > 0 ? batches_in_flight : RADAR_CHAIN_DEFAULT_BATCHES_IN_FLIGHT;
+        if (dev_per_frame > 0) fit = std::min<long long>(fit, (4LL << 30) / (dev_per_frame * slots));
         frames_per_batch = (int)std::max<long long>(1, std::min<long long>(RADAR_CHAIN_DEFAULT_FRAMES_PER_BATCH, fit));
     }
     if (batches_in_flight <= 0) batches_in_flight = RADAR_CHAIN_DEFAULT_BATCHES_IN_FLIGHT;

@@ -269,6 +269,15 @@ int jrcb_state_json(void* h, char* buf, int len)
     return (int)s.size();
 }
 
+// accumulated time inside radar_chain's general_work by phase (0 staging, 1 feed submits, 2 collect + publish, 3 total), nanoseconds, 64 bits:
+// what a soak run differences (the "profile_us" name of jrcb_call_setter saturates at INT_MAX microseconds).  -1: not a radar_chain.
+long long jrcb_profile_ns(void* h, int what)
+{
+    auto& b = ((handle*)h)->b;
+    if (auto* rc = dynamic_cast<radar_chain*>(b.get())) return (long long)rc->profile_ns(what);
+    return -1;
+}
+
 int jrcb_call_setter(void* h, const char* name, double v)
 {
     auto& b = ((handle*)h)->b;
@@ -286,7 +295,10 @@ int jrcb_call_setter(void* h, const char* name, double v)
             if (n == "stop") { return rc->stop() ? 0 : -1; }
             if (n == "pending_batches") return rc->pending_batches();
             if (n == "rx_only_batches") return (int)rc->rx_only_batches();
-            if (n == "profile_us") return (int)(rc->profile_ns((int)v) / 1000);
+            if (n == "profile_us") {                   // an int holds 35 minutes of microseconds: saturate instead of wrapping (long runs: jrcb_profile_ns)
+                const long long us = rc->profile_ns((int)v) / 1000;
+                return us > 2147483647LL ? 2147483647 : (int)us;
+            }
         }
         if (auto* e = dynamic_cast<range_angle_estimator*>(b.get())) {
             if (n == "set_snr_threshold") { e->set_snr_threshold((float)v); return 0; }

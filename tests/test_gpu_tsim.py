@@ -276,3 +276,20 @@ def test_synthetic_target_is_recovered_by_the_radar_chain(jrc, ctx):
     prof = np.abs(np.fft.ifft(np.fft.ifftshift(H), 8 * N))
     r_axis = np.arange(8 * N) * 3e8 / (2 * FS * 8)
     assert abs(r_axis[int(prof.argmax())] - R_true) < 3e8 / (2 * FS) / 2
+
+
+@pytest.mark.parametrize("n", [23040, 2400])
+def test_more_summed_targets_than_the_direct_route_holds(jrc, ctx, n):
+    """the direct four-step route carries at most 32 (simulator, target) pairs per launch and the number of targets of a simulator is
+    unbounded (jrc_tsim_create / _set_targets): a simulator that SUMS 40 targets at a direct-route burst length must take the chirp-z route
+    (any K) instead of failing; 32 summed targets and 40 targets with only the last observable (the reference's own behaviour: one pair) stay
+    on the direct route.  All three against the oracle."""
+    rng = np.random.default_rng(40)
+    for K, sum_targets in ((40, True), (32, True), (40, False)):
+        tg = (list(rng.uniform(5.0, 60.0, K)), list(rng.uniform(-40.0, 40.0, K)), list(rng.uniform(10.0, 100.0, K)), list(rng.uniform(-60.0, 60.0, K)))
+        x = burst(n, n + K)
+        g = jrc.target_simulator(*tg, POS4[:2], FS, FC, sum_targets=sum_targets, ctx=ctx)
+        got = g.work(x)
+        want = oracle.TargetSimulator(*tg, POS4[:2], FS, FC).work(x, sum_targets=sum_targets)
+        assert got.shape == want.shape == (2, n)
+        assert rel_err(got, want) < TOL, (K, sum_targets, rel_err(got, want))
