@@ -111,6 +111,16 @@ static inline int  jrc_ilog2(long n) { int l = 0; while ((1L << l) < n) l++; ret
 // ---- device helpers -----------------------------------------------------------------------
 #ifdef __HIPCC__
 
+// The 64 lanes of a wavefront execute every instruction together, and a wave's LDS operations complete in program order: a kernel may let all
+// lanes READ a wave-private LDS region and then WRITE it again with nothing in between.  JRC_LOCKSTEP() marks the places that rely on this.
+// On the device it expands to nothing (the binary is the one without the marker).  The CPU emulation the tests run without a GPU
+// (tests/hipcpu: one fiber per lane, run one after the other) makes it a rendezvous of the wave's lanes, which is what lockstep guarantees.
+#ifdef HIPCPU_EMULATION
+#define JRC_LOCKSTEP() __builtin_amdgcn_wave_barrier()
+#else
+#define JRC_LOCKSTEP() ((void)0)
+#endif
+
 __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);

@@ -453,6 +453,7 @@ __global__ __launch_bounds__(256, LOGN == 10 ? 2 : 4) void demod_chanest16_kerne
 #pragma unroll
         for (int q = 1; q < 16; q++) v[q] = cmul(v[q], tw[(k * q * (N / 256)) & (N - 1)]);
         fft_fwd_small<16>(v);
+        JRC_LOCKSTEP();                                        // every lane has read its sixteen points before any lane overwrites the buffer
         if constexpr (LOGN == 8) {                             // done: X[l + 16 q] goes where fft_vxx's shift puts it
 #pragma unroll
             for (int q = 0; q < 16; q++) my[ph((l + 16 * q + N / 2) & (N - 1))] = v[q];
@@ -477,6 +478,7 @@ __global__ __launch_bounds__(256, LOGN == 10 ? 2 : 4) void demod_chanest16_kerne
                 const float2 jd = make_float2(d1.y, -d1.x);
                 a[0] = cadd(s0, s1); a[1] = cadd(d0, jd); a[2] = csub(s0, s1); a[3] = csub(d0, jd);
             }
+            JRC_LOCKSTEP();                                    // (as above: reads of the pass before its writes)
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll

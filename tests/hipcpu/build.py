@@ -1,0 +1,133 @@
+"""Builds the CPU EMULATION of libjrc_hip.so (test infrastructure; see include/hip/hip_runtime.h): the library's own kernel sources,
+gr-mimo-ofdm-jrc_amd/csrc/*.hip, compiled for the host with clang++ against the emulation header and linked with hipcpu_runtime.cc into
+tests/hipcpu/_build/libjrc_hipcpu.so.  Two textual rewrites are applied to a COPY of each source (the tracked files are not touched):
+  * `extern __shared__ T name[];`          ->  `T* const name = (T*)::hipcpu::dyn_lds();`   (dynamic LDS of the running workgroup)
+  * `asm volatile("s_sleep ..." / "s_waitcnt ..." / "")`  ->  `((void)0)`                     (scheduling hints, no data effect)
+Nothing under gr-mimo-ofdm-jrc_amd/ knows this exists; the tests load it by path (JRC_LIB_PATH) in their own processes."""
+import concurrent.futures
+import fcntl
+import hashlib
+import importlib
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "gr-mimo-ofdm-jrc_amd", "csrc")
+OUT = os.path.join(HERE, "_build")
+LIB = os.path.join(OUT, "libjrc_hipcpu.so")
+
+_DYN = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?([A-Za-z_][\w ]*?)\s+(\w+)\[\];")
+_ASM = re.compile(r"asm\s+volatile\s*\(\s*\"[^\"]*\"\s*(?::[^;]*?)?\)\s*;")
+
+
+def rewrite(text):
+    text = _DYN.sub(lambda m: "%s* const %s = (%s*)::hipcpu::dyn_lds();" % (m.group(1), m.group(2), m.group(1)), text)
+    text = _ASM.sub("((void)0);", text)
+    return text
+
+
+def compiler():
+    for c in ("/opt/rocm/lib/llvm/bin/clang++", shutil.which("clang++")):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcpu: needs clang++ (the kernels use clang vector extensions and builtins)")
+
+
+def host_has_fma():
+    try:
+        return " fma " in open("/proc/cpuinfo").read()
+    except OSError:
+        return False
+
+
+def flags(sanitize=None):
+    f = ["-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-fno-omit-frame-pointer", "-Wno-unknown-pragmas", "-Wno-unused-value", "-Wno-unused-function",
+         "-Wno-pass-failed", "-Wno-array-bounds", "-I" + os.path.join(HERE, "include"), "-I" + CSRC, "-I" + os.path.join(ROOT, "include"), "-DHIPCPU_EMULATION=1"]
+    # hipcc fuses by default (-ffp-contract=fast) and the sources pin what must not be fused with `#pragma clang fp contract(off)`.  On x86 "fast"
+    # ignores that pragma (the backend fuses whatever it finds), "on" honours it and still fuses within an expression: the closest host equivalent
+    f += ["-ffp-contract=on", "-mfma"] if host_has_fma() else ["-ffp-contract=off"]
+    if sanitize:
+        f += ["-fsanitize=" + sanitize]
+    return f
+
+
+def sources():
+    # every kernel source of the library (not imported from the package's build module: importing the package would fix its library path
+    # before the emulation mode of tests/conftest.py has pointed it here)
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def build(verbose=False, sanitize=None):
+    sys.path.insert(0, ROOT)
+    os.makedirs(OUT, exist_ok=True)
+    tag = "_" + sanitize.replace(",", "_") if sanitize else ""
+    lib = LIB.replace(".so", tag + ".so")
+    with open(os.path.join(OUT, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        cxx = compiler()
+        fl = flags(sanitize)
+        srcs = sources()
+        deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "include", "hip", "hip_runtime.h"), os.path.join(HERE, "hipcpu_runtime.cc"),
+                                                                os.path.join(ROOT, "include", "jrc.h"), os.path.abspath(__file__)]
+        stamp = hashlib.sha256()
+        for d in sorted(deps):
+            stamp.update(d.encode()); stamp.update(open(d, "rb").read())
+        stamp.update(repr(fl).encode())
+        stamp = stamp.hexdigest()
+        stamp_file = lib + ".stamp"
+        if os.path.exists(lib) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+            return lib
+
+        def one(name):
+            if name.endswith(".hip"):
+                src = os.path.join(OUT, name.replace(".hip", tag + ".emu.cc"))
+                with open(src, "w") as fh:
+                    fh.write('#line 1 "%s"\n' % os.path.join(CSRC, name))
+                    fh.write(rewrite(open(os.path.join(CSRC, name)).read()))
+            else:
+                src = os.path.join(HERE, name)
+            obj = os.path.join(OUT, os.path.basename(src).rsplit(".", 1)[0] + tag + ".o")
+            r = subprocess.run([cxx] + fl + ["-c", src, "-o", obj], capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("hipcpu: %s failed:\n%s" % (name, r.stderr[-6000:]))
+            return obj
+
+        with concurrent.futures.ThreadPoolExecutor(max_workers=4) as ex:
+            objs = list(ex.map(one, srcs + ["hipcpu_runtime.cc"]))
+        r = subprocess.run([cxx, "-shared", "-fPIC", "-o", lib] + objs + (["-fsanitize=" + sanitize] if sanitize else []) + ["-lpthread", "-lm"], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcpu: link failed:\n%s" % r.stderr[-4000:])
+        open(stamp_file, "w").write(stamp)
+        if verbose:
+            print("built", lib)
+        return lib
+
+
+def build_blocks(verbose=False, sanitize=None):
+    """the host-side C++ blocks (gr-mimo-ofdm-jrc_amd/host) linked against the emulated library instead of libjrc_hip.so"""
+    lib = build(verbose=verbose, sanitize=sanitize)
+    tag = "_" + sanitize.replace(",", "_") if sanitize else ""
+    out = os.path.join(OUT, "libjrc_blocks_emu%s.so" % tag)
+    host = os.path.join(ROOT, "gr-mimo-ofdm-jrc_amd", "host")
+    srcs = [os.path.join(host, f) for f in ("jrc_blocks.cc", "jrc_blocks_capi.cc")]
+    deps = srcs + [os.path.join(host, f) for f in ("jrc_blocks.h", "jrc_block_runtime.h")] + [os.path.join(ROOT, "include", "jrc.h"), lib]
+    with open(os.path.join(OUT, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(d) for d in deps):
+            return out
+        cmd = [compiler(), "-O1", "-g", "-std=c++14", "-fPIC", "-shared", "-o", out] + srcs + [lib, "-Wl,-rpath," + OUT, "-lpthread"] + \
+              (["-fsanitize=" + sanitize] if sanitize else [])
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcpu: host blocks failed:\n%s" % r.stderr[-4000:])
+        if verbose:
+            print("built", out)
+    return out
+
+
+if __name__ == "__main__":
+    print(build_blocks(verbose=True, sanitize=(sys.argv[1] if len(sys.argv) > 1 else None)))

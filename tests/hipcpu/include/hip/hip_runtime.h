@@ -1,0 +1,245 @@
+// hip/hip_runtime.h of the CPU EMULATION build — test infrastructure, never part of the product.
+//
+// tests/hipcpu builds the library's own kernel sources (gr-mimo-ofdm-jrc_amd/csrc/*.hip, unchanged) for the host CPU so that the kernels can be
+// executed, checked against the oracle and run under sanitizers on a machine without a GPU (the GPU pool refuses GPU AddressSanitizer; round 6
+// had no GPU at all).  The execution model mirrors the one the kernels are written for:
+//   * a workgroup = one fiber per work-item, scheduled co-operatively, wavefront by wavefront (64 lanes);
+//   * __syncthreads = every live fiber of the workgroup arrives before any leaves;
+//   * cross-lane operations (__shfl*, __ballot, DPP moves, permlane swaps, v_readlane, wave barriers) = a rendezvous of the lanes of ONE wavefront
+//     that arrive at the same call site; the lanes that arrive form the exec mask (sources outside it keep the `old` / own value);
+//   * lanes of a wavefront do NOT otherwise run in lockstep: a lane runs until it blocks.  Code that relies on lockstep without saying so
+//     (LDS exchange inside a wave with no wave barrier) shows up as a mismatch here — on purpose;
+//   * the order in which waves (and lanes) are run can be permuted (HIPCPU_SCHEDULE=reverse|shuffle:<seed>) to shake out missing barriers.
+// Everything runs synchronously: streams are labels, events are time stamps, a captured graph is a list of closures replayed on launch.
+// What it is NOT: a timing model, an occupancy model, or a statement about what the hardware does beyond the documented semantics above.
+#pragma once
+#ifndef HIPCPU_EMULATION
+#define HIPCPU_EMULATION 1
+#endif
+#ifndef __HIPCC__
+#define __HIPCC__ 1
+#endif
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <tuple>
+#include <type_traits>
+#include <utility>
+
+// ---- language ---------------------------------------------------------------------------------------------------------------------------
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static          // one workgroup runs at a time (launches are serialised process-wide): a function-local static is the workgroup's LDS
+#define __noinline__ __attribute__((noinline))
+
+struct alignas(8) float2 { float x, y; };
+struct float4 { float x, y, z, w; };          // no 16-byte alignment claim: the kernels move float4s through pointers that are only 8-byte aligned
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+struct uint3 { unsigned x, y, z; };
+struct dim3 {
+    unsigned x, y, z;
+    constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+namespace hipcpu {
+struct Stream;
+struct Event;
+struct Graph;
+struct GraphExec;
+extern thread_local uint3 t_threadIdx, t_blockIdx;
+extern thread_local dim3 t_blockDim, t_gridDim;
+}
+typedef hipcpu::Stream* hipStream_t;
+typedef hipcpu::Event* hipEvent_t;
+typedef hipcpu::Graph* hipGraph_t;
+typedef hipcpu::GraphExec* hipGraphExec_t;
+#define threadIdx (::hipcpu::t_threadIdx)
+#define blockIdx (::hipcpu::t_blockIdx)
+#define blockDim (::hipcpu::t_blockDim)
+#define gridDim (::hipcpu::t_gridDim)
+#define warpSize 64
+
+// ---- runtime API (the subset the library uses) ------------------------------------------------------------------------------------------
+enum hipError_t { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNoDevice = 100, hipErrorInvalidDevice = 101, hipErrorNotReady = 600,
+                  hipErrorStreamCaptureUnsupported = 900, hipErrorUnknown = 999 };
+enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
+enum hipStreamCaptureStatus { hipStreamCaptureStatusNone = 0, hipStreamCaptureStatusActive = 1, hipStreamCaptureStatusInvalidated = 2 };
+enum hipStreamCaptureMode { hipStreamCaptureModeGlobal = 0, hipStreamCaptureModeThreadLocal = 1, hipStreamCaptureModeRelaxed = 2 };
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 1, hipDeviceAttributeWallClockRate = 2, hipDeviceAttributeMaxSharedMemoryPerBlock = 3 };
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+#define hipStreamNonBlocking 1u
+#define hipStreamDefault 0u
+#define hipEventDisableTiming 2u
+#define hipEventDefault 0u
+#define hipHostMallocDefault 0u
+struct hipDeviceProp_t { char name[256]; char gcnArchName[256]; int multiProcessorCount; size_t totalGlobalMem; size_t sharedMemPerBlock; int pciDomainID, pciBusID, pciDeviceID; };
+
+hipError_t hipGetDeviceCount(int* n);
+hipError_t hipSetDevice(int d);
+hipError_t hipDeviceSynchronize();
+hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t a, int dev);
+hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int dev);
+hipError_t hipGetLastError();
+const char* hipGetErrorString(hipError_t e);
+hipError_t hipMalloc(void** p, size_t bytes);
+hipError_t hipFree(void* p);
+hipError_t hipHostMalloc(void** p, size_t bytes, unsigned flags);
+hipError_t hipHostFree(void* p);
+hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind k);
+hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKind k, hipStream_t s);
+hipError_t hipMemcpy2DAsync(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, hipMemcpyKind k, hipStream_t s);
+hipError_t hipMemset(void* p, int v, size_t bytes);
+hipError_t hipMemsetAsync(void* p, int v, size_t bytes, hipStream_t s);
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags);
+hipError_t hipStreamDestroy(hipStream_t s);
+hipError_t hipStreamSynchronize(hipStream_t s);
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags);
+hipError_t hipStreamIsCapturing(hipStream_t s, hipStreamCaptureStatus* st);
+hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode m);
+hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t* g);
+hipError_t hipGraphInstantiate(hipGraphExec_t* x, hipGraph_t g, void*, void*, size_t);
+hipError_t hipGraphDestroy(hipGraph_t g);
+hipError_t hipGraphExecDestroy(hipGraphExec_t x);
+hipError_t hipGraphLaunch(hipGraphExec_t x, hipStream_t s);
+hipError_t hipEventCreate(hipEvent_t* e);
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned flags);
+hipError_t hipEventDestroy(hipEvent_t e);
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
+hipError_t hipEventSynchronize(hipEvent_t e);
+hipError_t hipEventQuery(hipEvent_t e);
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
+hipError_t hipFuncSetAttribute(const void* f, hipFuncAttribute a, int v);
+template <class F> static inline hipError_t hipFuncSetAttribute(F* f, hipFuncAttribute a, int v) { return hipFuncSetAttribute((const void*)f, a, v); }
+
+// ---- kernel launch ----------------------------------------------------------------------------------------------------------------------
+namespace hipcpu {
+void launch_closure(dim3 grid, dim3 block, size_t dyn_lds, hipStream_t s, std::function<void()> body, const char* name, const void* kernel);
+void* dyn_lds();                       // the dynamic LDS of the running workgroup (16-byte aligned)
+// the arguments are converted to the kernel's parameter types when the launch is made (what hipLaunchKernelGGL does), not when a captured graph replays
+template <class... KArgs, class... Args>
+static inline void launch(const char* name, void (*k)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t s, Args&&... args)
+{
+    std::tuple<std::decay_t<KArgs>...> t(std::forward<Args>(args)...);
+    launch_closure(grid, block, lds, s, [k, t]() { std::apply(k, t); }, name, (const void*)k);
+}
+}
+#define hipLaunchKernelGGL(k, grid, block, lds, stream, ...) ::hipcpu::launch(#k, k, dim3(grid), dim3(block), (size_t)(lds), (stream), ##__VA_ARGS__)
+
+// ---- device intrinsics ------------------------------------------------------------------------------------------------------------------
+namespace hipcpu {
+enum Op { OP_WAVE_BARRIER = 1, OP_SHFL_IDX, OP_BALLOT, OP_DPP, OP_SWAP32, OP_SWAP16, OP_READLANE, OP_READFIRST };
+struct OpArgs { unsigned in0, in1; int p0, p1, p2, p3; unsigned old0; };
+struct OpOut { unsigned out0, out1; unsigned long long mask, active; };
+// blocks the calling lane until the lanes of its wavefront that come to the same call site have arrived; returns this lane's result.
+// Never inlined: its own return address — a point inside the (inlined) intrinsic wrapper in the kernel's code — identifies the call site.
+OpOut wave_op(int op, const OpArgs& a) __attribute__((noinline));
+void block_barrier();
+int block_barrier_or(int pred);
+int lane_id();
+long long wall_clock();
+struct pair32 { unsigned v[2]; unsigned operator[](int i) const { return v[i]; } };
+
+template <class T> struct Bits {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "shuffles move 4- or 8-byte values");
+    static void split(T v, unsigned& a, unsigned& b) { unsigned w[2] = {0, 0}; std::memcpy(w, &v, sizeof(T)); a = w[0]; b = w[1]; }
+    static T join(unsigned a, unsigned b) { unsigned w[2] = {a, b}; T v; std::memcpy(&v, w, sizeof(T)); return v; }
+};
+template <class T> static __forceinline__ T shfl_from(T v, int src_lane)
+{
+    OpArgs a{}; Bits<T>::split(v, a.in0, a.in1); a.p0 = src_lane;
+    const OpOut o = wave_op(OP_SHFL_IDX, a);
+    return Bits<T>::join(o.out0, o.out1);
+}
+}
+template <class T> static __forceinline__ T __shfl(T v, int src, int width = 64) { const int l = hipcpu::lane_id(); return hipcpu::shfl_from(v, (l & ~(width - 1)) | (src & (width - 1))); }
+template <class T> static __forceinline__ T __shfl_xor(T v, int m, int width = 64) { const int l = hipcpu::lane_id(), s = l ^ m; return hipcpu::shfl_from(v, (s & ~(width - 1)) == (l & ~(width - 1)) ? s : l); }
+template <class T> static __forceinline__ T __shfl_down(T v, unsigned d, int width = 64) { const int l = hipcpu::lane_id(), s = l + (int)d; return hipcpu::shfl_from(v, (s & ~(width - 1)) == (l & ~(width - 1)) ? s : l); }
+template <class T> static __forceinline__ T __shfl_up(T v, unsigned d, int width = 64) { const int l = hipcpu::lane_id(), s = l - (int)d; return hipcpu::shfl_from(v, (s >= 0 && (s & ~(width - 1)) == (l & ~(width - 1))) ? s : l); }
+static __forceinline__ unsigned long long __ballot(int pred)
+{
+    hipcpu::OpArgs a{}; a.in0 = pred ? 1u : 0u;
+    return hipcpu::wave_op(hipcpu::OP_BALLOT, a).mask;
+}
+static __forceinline__ int __all(int pred)
+{
+    hipcpu::OpArgs a{}; a.in0 = pred ? 1u : 0u;
+    const hipcpu::OpOut o = hipcpu::wave_op(hipcpu::OP_BALLOT, a);
+    return o.mask == o.active;
+}
+static __forceinline__ int __any(int pred)
+{
+    hipcpu::OpArgs a{}; a.in0 = pred ? 1u : 0u;
+    return hipcpu::wave_op(hipcpu::OP_BALLOT, a).mask != 0;
+}
+static __forceinline__ void __syncthreads() { hipcpu::block_barrier(); }
+static __forceinline__ int __syncthreads_or(int pred) { return hipcpu::block_barrier_or(pred); }
+static __forceinline__ int __popc(unsigned v) { return __builtin_popcount(v); }
+static __forceinline__ int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static __forceinline__ int __ffs(int v) { return __builtin_ffs(v); }
+static __forceinline__ int __ffsll(long long v) { return __builtin_ffsll(v); }
+static __forceinline__ int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
+template <class A, class B> static __forceinline__ typename std::common_type<A, B>::type min(A a, B b) { return b < a ? b : a; }
+template <class A, class B> static __forceinline__ typename std::common_type<A, B>::type max(A a, B b) { return a < b ? b : a; }
+static __forceinline__ void sincospif(float x, float* s, float* c) { const double a = 3.14159265358979323846 * (double)x; *s = (float)sin(a); *c = (float)cos(a); }
+static __forceinline__ unsigned __brev(unsigned v) { return __builtin_bitreverse32(v); }
+static __forceinline__ int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
+static __forceinline__ int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
+static __forceinline__ unsigned __float_as_uint(float f) { unsigned i; std::memcpy(&i, &f, 4); return i; }
+static __forceinline__ float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
+static __forceinline__ float __uint_as_float(unsigned i) { float f; std::memcpy(&f, &i, 4); return f; }
+static __forceinline__ float __fsqrt_rn(float x) { return sqrtf(x); }
+static __forceinline__ long long wall_clock64() { return hipcpu::wall_clock(); }
+// one workgroup at a time, lanes co-operative: a plain read-modify-write is atomic here
+template <class T> static __forceinline__ T atomicMax(T* p, T v) { const T o = *p; if (v > o) *p = v; return o; }
+template <class T> static __forceinline__ T atomicMin(T* p, T v) { const T o = *p; if (v < o) *p = v; return o; }
+template <class T> static __forceinline__ T atomicAdd(T* p, T v) { const T o = *p; *p = o + v; return o; }
+template <class T> static __forceinline__ T atomicOr(T* p, T v) { const T o = *p; *p = o | v; return o; }
+
+// AMDGCN builtins the kernels use, by documented semantics (CDNA ISA: DPP control words, v_permlane*_swap, v_readlane / v_readfirstlane)
+namespace hipcpu {
+static __forceinline__ int update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl)
+{
+    OpArgs a{}; a.in0 = (unsigned)src; a.old0 = (unsigned)old; a.p0 = ctrl; a.p1 = row_mask; a.p2 = bank_mask; a.p3 = bound_ctrl ? 1 : 0;
+    return (int)wave_op(OP_DPP, a).out0;
+}
+static __forceinline__ pair32 permlane_swap(int op, unsigned old, unsigned src)
+{
+    OpArgs a{}; a.in0 = src; a.old0 = old;
+    const OpOut o = wave_op(op, a);
+    return pair32{{o.out0, o.out1}};
+}
+static __forceinline__ int readlane(int v, int lane)
+{
+    OpArgs a{}; a.in0 = (unsigned)v; a.p0 = lane;
+    return (int)wave_op(OP_READLANE, a).out0;
+}
+static __forceinline__ int readfirstlane(int v)
+{
+    OpArgs a{}; a.in0 = (unsigned)v;
+    return (int)wave_op(OP_READFIRST, a).out0;
+}
+static __forceinline__ void wave_barrier() { OpArgs a{}; (void)wave_op(OP_WAVE_BARRIER, a); }
+static __forceinline__ int sbfe(int v, int off, int width) { return width >= 32 ? (v >> off) : (int)((unsigned)v << (32 - off - width)) >> (32 - width); }
+}
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) ::hipcpu::update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
+#define __builtin_amdgcn_mov_dpp(src, ctrl, rm, bm, bc) ::hipcpu::update_dpp((src), (src), (ctrl), (rm), (bm), (bc))
+#define __builtin_amdgcn_permlane32_swap(old, src, fi, bc) ::hipcpu::permlane_swap(::hipcpu::OP_SWAP32, (unsigned)(old), (unsigned)(src))
+#define __builtin_amdgcn_permlane16_swap(old, src, fi, bc) ::hipcpu::permlane_swap(::hipcpu::OP_SWAP16, (unsigned)(old), (unsigned)(src))
+#define __builtin_amdgcn_readlane(v, l) ::hipcpu::readlane((v), (l))
+#define __builtin_amdgcn_readfirstlane(v) ::hipcpu::readfirstlane((v))
+// a wave barrier orders the LDS traffic of a wave's lanes: here it is what makes the other lanes' stores visible (they have all run up to it)
+#define __builtin_amdgcn_wave_barrier() ::hipcpu::wave_barrier()
+#define __builtin_amdgcn_fence(...) ((void)0)
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_sbfe(v, o, w) ::hipcpu::sbfe((v), (o), (w))
+#define __builtin_amdgcn_sqrtf(x) sqrtf(x)            // v_sqrt_f32: 1 ulp on the device, correctly rounded here
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))         // v_rcp_f32: 1 ulp on the device, correctly rounded here

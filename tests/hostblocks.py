@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB = os.path.join(ROOT, "gr-mimo-ofdm-jrc_amd", "lib", "libjrc_blocks.so")
+LIB = os.environ.get("JRC_BLOCKS_LIB_PATH") or os.path.join(ROOT, "gr-mimo-ofdm-jrc_amd", "lib", "libjrc_blocks.so")   # (the override: tests/hipcpu emulation mode)
 _vp, _fp, _ip = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)
 _lib = None
 
