@@ -33,6 +33,16 @@ asm(".text\n"
 #error "hipcpu: the fiber switch is written for x86-64"
 #endif
 
+// AddressSanitizer keeps the bounds of the stack it believes the thread is on: tell it about every switch (the kernels can then be run under
+// -fsanitize=address, which the GPU pool refuses on the device)
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define HIPCPU_ASAN 1
+extern "C" void __sanitizer_start_switch_fiber(void** fake_stack_save, const void* bottom, size_t size);
+extern "C" void __sanitizer_finish_switch_fiber(void* fake_stack_save, const void** bottom_old, size_t* size_old);
+#endif
+#endif
+
 enum { ST_RUN = 0, ST_WAVE, ST_BLOCK, ST_DONE };
 static const size_t STACK_BYTES = 512 * 1024;
 
@@ -47,6 +57,7 @@ struct Fiber {
     OpArgs a{};
     OpOut o{};
     int pred = 0;
+    void* asan_fake = nullptr;
 };
 
 struct Worker {
@@ -57,6 +68,8 @@ struct Worker {
     void* dyn = nullptr;
     size_t dyn_cap = 0;
     bool in_kernel = false;
+    const void* sched_stack = nullptr;      // (ASan) the scheduler's own stack, learnt at the first switch into a fiber
+    size_t sched_stack_size = 0;
     ~Worker()
     {
         for (Fiber* f : pool) { if (f->stack) munmap(f->stack - 4096, STACK_BYTES + 4096); delete f; }
@@ -69,8 +82,14 @@ static struct Stats { unsigned long long kernels = 0, blocks = 0, wave_ops = 0, 
 
 static void fiber_main()
 {
+#ifdef HIPCPU_ASAN
+    __sanitizer_finish_switch_fiber(nullptr, &W.sched_stack, &W.sched_stack_size);
+#endif
     (*W.body)();
     W.cur->st = ST_DONE;
+#ifdef HIPCPU_ASAN
+    __sanitizer_start_switch_fiber(nullptr, W.sched_stack, W.sched_stack_size);      // null: this fiber's stack is done with
+#endif
     hipcpu_switch(&W.cur->sp, W.sched_sp);
     abort();      // a finished fiber is never resumed
 }
@@ -103,14 +122,27 @@ static inline void run_fiber(Fiber* f)
 {
     W.cur = f;
     t_threadIdx = uint3{f->tx, f->ty, f->tz};
+#ifdef HIPCPU_ASAN
+    void* fake = nullptr;
+    __sanitizer_start_switch_fiber(&fake, f->stack, STACK_BYTES);
+#endif
     hipcpu_switch(&W.sched_sp, f->sp);
+#ifdef HIPCPU_ASAN
+    __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
+#endif
 }
 
 static inline void yield_to_scheduler()
 {
     Fiber* f = W.cur;
+#ifdef HIPCPU_ASAN
+    __sanitizer_start_switch_fiber(&f->asan_fake, W.sched_stack, W.sched_stack_size);
+#endif
     hipcpu_switch(&f->sp, W.sched_sp);
     // resumed: the scheduler has set t_threadIdx and W.cur for us
+#ifdef HIPCPU_ASAN
+    __sanitizer_finish_switch_fiber(f->asan_fake, nullptr, nullptr);
+#endif
 }
 
 int lane_id() { return W.cur->lane; }
@@ -306,7 +338,13 @@ static void run_kernel(dim3 grid, dim3 block, size_t dyn, const std::function<vo
     std::lock_guard<std::mutex> lk(g_kernel_mutex);
     schedule_init();
     if (W.in_kernel) { fprintf(stderr, "hipcpu: nested kernel launch\n"); abort(); }
+#ifdef HIPCPU_ASAN
+    // exactly the bytes the launch asked for, so that a kernel reading or writing past its dynamic LDS runs into the sanitizer's red zone
+    free(W.dyn); W.dyn = nullptr; W.dyn_cap = 0;
+    if (dyn) { if (posix_memalign(&W.dyn, 64, dyn) != 0) abort(); W.dyn_cap = dyn; }
+#else
     if (dyn > W.dyn_cap) { free(W.dyn); W.dyn = aligned_alloc(64, (dyn + 63) & ~(size_t)63); W.dyn_cap = dyn; }
+#endif
     if (getenv("HIPCPU_TRACE")) fprintf(stderr, "[hipcpu] %s grid (%u,%u,%u) block (%u,%u,%u) lds %zu\n", name, grid.x, grid.y, grid.z, block.x, block.y, block.z, dyn);
     W.in_kernel = true;
     t_blockDim = block; t_gridDim = grid;
@@ -405,8 +443,8 @@ hipError_t hipMalloc(void** p, size_t bytes)
     *p = nullptr;
     if (bytes == 0) return hipSuccess;
     if (bytes > ((size_t)48 << 30)) return hipErrorOutOfMemory;
-    void* m = aligned_alloc(256, (bytes + 255) & ~(size_t)255);
-    if (!m) return hipErrorOutOfMemory;
+    void* m = nullptr;
+    if (posix_memalign(&m, 256, bytes) != 0 || !m) return hipErrorOutOfMemory;      // exactly `bytes`: an overrun meets the sanitizer's red zone
     memset(m, 0xCD, std::min(bytes, (size_t)1 << 20));                    // device memory is not zeroed: poison the head
     { std::lock_guard<std::mutex> lk(g_mem_mutex); g_device_allocs[m] = bytes; g_device_bytes += bytes; }
     *p = m;

@@ -1,0 +1,30 @@
+#!/bin/bash
+# The GPU tier on the emulated kernels (tests/hipcpu), whole: the default pass, the heavy shapes, and a pass under AddressSanitizer +
+# UndefinedBehaviorSanitizer (which the GPU pool refuses on the device).  Runs on any x86-64 machine with clang++; no GPU.
+# Writes gpurun_out/<TAG>_emulated_*.log and the stamped record gpurun_out/<TAG>_emulated_suite.json (copy it to profiles/).
+# usage: tools/emulated_suite.sh TAG [workers] [heavy|noheavy] [asan|noasan]
+TAG=${1:-r06}
+NW=${2:-6}
+HEAVY=${3:-heavy}
+ASAN=${4:-asan}
+mkdir -p gpurun_out
+export JRC_EMULATE=1 OMP_NUM_THREADS=1
+python3 -m pytest tests -m gpu -v -n $NW --timeout 1800 -p no:cacheprovider > gpurun_out/${TAG}_emulated_default.log 2>&1
+RC1=$?
+RC2=0; RC3=0
+if [ "$HEAVY" = heavy ]; then
+  # the shapes the default pass leaves out (bench batches, 10^6-sample streams): fewer workers, they are large
+  JRC_EMULATE_HEAVY=1 python3 -m pytest tests -m gpu -v -n 3 --timeout 3600 -p no:cacheprovider \
+    -k "benchmarked or long_bursts or 1048576 or million_samples or B-1100 or B-300 or B-700 or D-256 or B-512 or 600] or baseline_batch or test_wide_kernel_batches or config_d_eight" \
+    > gpurun_out/${TAG}_emulated_heavy.log 2>&1
+  RC2=$?
+fi
+if [ "$ASAN" = asan ]; then
+  RT=$(/opt/rocm/lib/llvm/bin/clang++ -print-file-name=libclang_rt.asan-x86_64.so)
+  JRC_EMULATE_SANITIZE=address,undefined LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:halt_on_error=1:exitcode=77 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
+    python3 -m pytest tests/test_gpu_blocks.py tests/test_gpu_chain.py tests/test_gpu_chain_modes.py tests/test_gpu_comm.py tests/test_gpu_tsim.py tests/test_gpu_sync.py \
+      tests/test_gpu_codec.py tests/test_gpu_edges.py tests/test_gpu_flowgraph.py tests/test_gpu_flowgraph_parity.py tests/test_host_blocks.py tests/test_golden_fixtures.py \
+      -m gpu -v -n $NW --timeout 3600 -p no:cacheprovider > gpurun_out/${TAG}_emulated_asan_ubsan.log 2>&1
+  RC3=$?
+fi
+python3 tools/stamp_emulated.py $TAG $RC1 $RC2 $RC3
