@@ -52,6 +52,9 @@ class DeviceResidentRadarSim:
         self.n_burst = self.n_in + self.pad_tail
         self.seed = seed
         self.sum_on_spectrum = os.environ.get("JRC_DRF_SUM_ON_SPECTRUM", "1") != "0"
+        # the OFDM modulator and the T zero_pads as one kernel (jrc_ofdm_mod_pad_dev, round 6): bit-identical bursts, the unpadded time-domain packet
+        # is never written.  Opt-in until it has been timed on a device (round 6 had no GPU); off = the 1 + T launches of rounds 4-5.
+        self.fused_mod = os.environ.get("JRC_DRF_FUSED_MOD", "0") != "0"
         P = T * R
         self.precoder = jrc.mimo_precoder(N, T, 1, o["data_subcarriers"], o["pilot_subcarriers"], o["pilot_symbols"], o["l_stf_ltf_64"],
                                           o["ltf_mapped_sc__ss_sym"], ctx=self.ctx)
@@ -77,6 +80,8 @@ class DeviceResidentRadarSim:
         self.d_window = torch.from_numpy(w).to(dev)
         L = self.ctx.lib
         L.jrc_zero_pad_strided_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint, C.c_uint, C.c_uint64, C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p]
+        L.jrc_ofdm_mod_pad_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_uint, C.c_uint64, C.c_uint64,
+                                           C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_void_p]
         torch.cuda.synchronize()
 
     def load_symbols(self, symbols):
@@ -90,12 +95,17 @@ class DeviceResidentRadarSim:
         """one pass of the whole graph over n_frames packets; asynchronous on the context's stream"""
         c, L, T = self.ctx, self.ctx.lib, self.T
         self.precoder.frames_dev(self.d_sym[:n_frames], self.mcs, self.ptype, self.pdu_len, d_out=self.d_txf)
-        c.check(L.jrc_ofdm_mod_dev(c.h, self.N, self.cp, self.d_window.data_ptr(), n_frames * T * self.n_total, self.d_txf.data_ptr(),
-                                   self.d_txt.data_ptr(), None))
+        if self.fused_mod:
+            c.check(L.jrc_ofdm_mod_pad_dev(c.h, self.N, self.cp, self.d_window.data_ptr(), n_frames, T, self.n_total, 0, self.pad_tail if pads else 0,
+                                           self.seed, 100, self.d_txf.data_ptr(), self.d_pad.data_ptr(), self.F * self.n_burst, self.n_burst, None))
+        else:
+            c.check(L.jrc_ofdm_mod_dev(c.h, self.N, self.cp, self.d_window.data_ptr(), n_frames * T * self.n_total, self.d_txf.data_ptr(),
+                                       self.d_txt.data_ptr(), None))
         for t in range(T):
-            src = self.d_txt.data_ptr() + 8 * t * self.n_in
-            c.check(L.jrc_zero_pad_strided_dev(c.h, n_frames, self.n_in, 0, self.pad_tail if pads else 0, self.seed + 100 * t, src, T * self.n_in,
-                                               self.d_pad[t].data_ptr(), self.n_burst, None))
+            if not self.fused_mod:
+                src = self.d_txt.data_ptr() + 8 * t * self.n_in
+                c.check(L.jrc_zero_pad_strided_dev(c.h, n_frames, self.n_in, 0, self.pad_tail if pads else 0, self.seed + 100 * t, src, T * self.n_in,
+                                                   self.d_pad[t].data_ptr(), self.n_burst, None))
             if not self.sum_on_spectrum:
                 self.sims[t].run_dev(self.d_pad[t], self.d_rx, n_frames, self.n_burst, accumulate_out=(t > 0))
         if self.sum_on_spectrum:
@@ -117,8 +127,11 @@ class DeviceResidentRadarSim:
         """the tensors on the block edges, on the host (for the comparison with the block-by-block graph)"""
         self.ctx.sync()
         cx = lambda t: t.cpu().numpy().view(np.complex64)[..., 0]
-        return dict(tx_f=cx(self.d_txf[:n_frames]), tx_t=cx(self.d_txt[:n_frames]), bursts=np.swapaxes(cx(self.d_pad[:, :n_frames]), 0, 1),
-                    rx_t=cx(self.d_rx[:n_frames]), H=cx(self.bufs["chanest"][:n_frames]), map=cx(self.bufs["map"][:n_frames]))
+        e = dict(tx_f=cx(self.d_txf[:n_frames]), tx_t=cx(self.d_txt[:n_frames]), bursts=np.swapaxes(cx(self.d_pad[:, :n_frames]), 0, 1),
+                 rx_t=cx(self.d_rx[:n_frames]), H=cx(self.bufs["chanest"][:n_frames]), map=cx(self.bufs["map"][:n_frames]))
+        if self.fused_mod:
+            del e["tx_t"]                       # the unpadded time-domain packet does not exist on this path
+        return e
 
 
 def config_b_tables(T=4, N=256):

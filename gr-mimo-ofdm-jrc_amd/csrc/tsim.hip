@@ -1495,6 +1495,97 @@ extern "C" int jrc_zero_pad_strided_dev(jrc_ctx* ctx, int n_bursts, int n_input,
     return (int)n_out;
 }
 
+// ---- OFDM modulator + zero_pad as ONE kernel: the fft_vxx(reverse, shift, window) -> ofdm_cyclic_prefixer -> zero_pad chain behind
+// every TX port of the simulation flowgraph (examples/simulation/radar/mimo_ofdm_jrc_radar_sim.grc:801-897, :2184-2188; lib/zero_pad_impl.cc:76-90)
+// writes, block by block, the time-domain packet [F][T][n_sym (N + cp)] to HBM, reads it again and writes the padded burst; here symbol
+// (f, t, k) of the precoder's output goes through the SAME Stockham passes as jrc_ofdm_mod_dev (fft_stockham_kernel: bit-identical samples) and
+// lands at bursts[t][f][pad_front + k (N + cp)] directly, and the workgroups that hold a burst's first / last symbol write its pad noise with the
+// generator of zero_pad_kernel (same key: seed of the port, burst, sample -> bit-identical padding).  One launch instead of 1 + T, the unpadded
+// time-domain packet never exists.
+__global__ __launch_bounds__(256) void ofdm_mod_burst_kernel(const float2* __restrict__ in, float2* __restrict__ out, const float2* __restrict__ tw,
+                                                             const float* __restrict__ window, int n, int logn, size_t batch, int tp,
+                                                             int n_ports, int n_sym, int cp, int pad_front, int pad_tail,
+                                                             unsigned long long seed, unsigned long long seed_port_step, float sigma,
+                                                             long out_port_stride, long out_burst_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    const int per_block = blockDim.x / tp;
+    const int lt = threadIdx.x % tp, lb = threadIdx.x / tp;
+    const size_t b = (size_t)blockIdx.x * per_block + lb;
+    const bool live = b < batch;
+    float2* buf0 = lds + (size_t)lb * 2 * n;
+    float2* buf1 = buf0 + n;
+    const size_t f = b / ((size_t)n_ports * n_sym);
+    const int t = (int)((b / n_sym) % n_ports), k = (int)(b % n_sym);
+    const float2* src_g = in + b * (size_t)n;
+    float2* burst = out + (size_t)t * out_port_stride + f * (size_t)out_burst_stride;
+    float2* dst_g = burst + pad_front + (size_t)k * (n + cp) + cp;
+
+    int Ns = 1;
+    const float2* cur = nullptr;                  // nullptr = still in global memory
+    float2* nxt = buf0;
+    bool first = true;
+    while (Ns < n) {                              // the passes of fft_stockham_kernel with forward = 0, shift = 1, a cyclic prefix to prepend
+        const int R = ((logn & 1) && first) ? 2 : 4;
+        if (live) {
+            if (R == 2) stockham_pass<2>(first ? src_g : nullptr, n, first ? window : nullptr, cur, nxt, nullptr, 0, tw, n, Ns, 1, lt, tp);
+            else stockham_pass<4>(first ? src_g : nullptr, n, first ? window : nullptr, cur, nxt, nullptr, 0, tw, n, Ns, 1, lt, tp);
+        }
+        __syncthreads();
+        cur = nxt; nxt = (nxt == buf0) ? buf1 : buf0;
+        Ns *= R; first = false;
+    }
+    if (!live) return;
+    for (int pos = lt; pos < n; pos += tp) dst_g[pos] = cur[pos];
+    for (int jj = lt; jj < cp; jj += tp) dst_g[jj - cp] = cur[n - cp + jj];
+    // pad noise of burst (t, f): the front by the transform of its first symbol, the tail by that of its last
+    const unsigned long long port_seed = seed + seed_port_step * (unsigned long long)t;
+    const int n_in = n_sym * (n + cp);
+    auto noise = [&](int i) {
+        const unsigned long long r = splitmix64(port_seed ^ splitmix64(((unsigned long long)f << 32) | (unsigned)i));
+        const float u1 = ((float)(unsigned)(r >> 40) + 1.0f) * (1.0f / 16777216.0f);          // (0, 1]
+        const float u2 = (float)(unsigned)((r >> 8) & 0xffffffu) * (1.0f / 16777216.0f);     // [0, 1)
+        const float rad = sigma * sqrtf(-2.0f * logf(u1));
+        float sn, cs;
+        sincospif(2.0f * u2, &sn, &cs);
+        burst[i] = make_float2(rad * cs, rad * sn);
+    };
+    if (k == 0) for (int i = lt; i < pad_front; i += tp) noise(i);
+    if (k == n_sym - 1) for (int i = pad_front + n_in + lt; i < pad_front + n_in + pad_tail; i += tp) noise(i);
+}
+
+extern "C" int jrc_ofdm_mod_pad_dev(jrc_ctx* ctx, int fft_len, int cp_len, const float* d_window, int n_frames, int n_ports, int n_symbols,
+                                    unsigned pad_front, unsigned pad_tail, uint64_t seed, uint64_t seed_port_step,
+                                    const jrc_cf32* d_in, jrc_cf32* d_out, long out_port_stride, long out_burst_stride, void* stream)
+{
+    JRC_TRACE("jrc_ofdm_mod_pad_dev");
+    if (!ctx || n_frames < 0 || n_ports < 1 || n_symbols < 1) return JRC_ERR_INVALID_ARG;
+    if (cp_len < 0 || cp_len > fft_len) return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "ofdm_mod_pad: bad cp_len");
+    if (!jrc_is_pow2(fft_len) || fft_len < 4 || fft_len > 8192)
+        return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "ofdm_mod_pad: fft_len %d is not a power of two in [4, 8192] (use jrc_ofdm_mod_dev + jrc_zero_pad_strided_dev)", fft_len);
+    const long n_out = (long)n_symbols * (fft_len + cp_len) + pad_front + pad_tail;
+    if (n_frames == 0) return (int)n_out;
+    if (!d_in || !d_out) return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "ofdm_mod_pad: null buffers");
+    if (out_burst_stride < n_out || (n_ports > 1 && out_port_stride < out_burst_stride * (long)n_frames))
+        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "ofdm_mod_pad: output strides shorter than the bursts they hold");
+    JRC_BIND(ctx);
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    const int n = fft_len;
+    const float2* tw = nullptr;
+    JRC_TRY(jrc_get_twiddles(ctx, n, +1, &tw));
+    int tp = n / 4; if (tp > 256) tp = 256; if (tp < 1) tp = 1;                 // the geometry of launch_fft_vcc_ex's Stockham branch
+    const int per_block = 256 / tp;
+    const size_t batch = (size_t)n_frames * n_ports * n_symbols;
+    const size_t blocks = (batch + per_block - 1) / per_block;
+    const size_t lds_bytes = sizeof(float2) * 2 * (size_t)n * per_block;
+    JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)ofdm_mod_burst_kernel, lds_bytes));
+    hipLaunchKernelGGL(ofdm_mod_burst_kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, s, (const float2*)d_in, (float2*)d_out, tw, d_window, n,
+                       jrc_ilog2(n), batch, tp, n_ports, n_symbols, cp_len, (int)pad_front, (int)pad_tail, (unsigned long long)seed,
+                       (unsigned long long)seed_port_step, 1e-2f, out_port_stride, out_burst_stride);
+    JRC_HIP(ctx, hipGetLastError());
+    return (int)n_out;
+}
+
 extern "C" int jrc_zero_pad_dev(jrc_ctx* ctx, int n_bursts, int n_input, unsigned pad_front, unsigned pad_tail, uint64_t seed,
                                 const jrc_cf32* d_in, jrc_cf32* d_out, void* stream)
 {

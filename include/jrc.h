@@ -525,6 +525,14 @@ int jrc_zero_pad_dev(jrc_ctx* ctx, int n_bursts, int n_input, unsigned pad_front
  * precoder / modulator outputs laid out [frame][port][samples] is in_stride = n_ports * n_input apart */
 int jrc_zero_pad_strided_dev(jrc_ctx* ctx, int n_bursts, int n_input, unsigned pad_front, unsigned pad_tail, uint64_t seed,
                              const jrc_cf32* d_in, long in_stride, jrc_cf32* d_out, long out_stride, void* stream);
+/* the OFDM modulator (jrc_ofdm_mod_dev) and the zero_pad behind each TX port as ONE pass (…radar_sim.grc:801-897, :2184-2188 -> lib/zero_pad_impl.cc:76-90):
+ * d_in = the precoder's output [n_frames][n_ports][n_symbols][fft_len]; burst (port t, frame f) = [pad_front noise | n_symbols x (cp | symbol) |
+ * pad_tail noise] is written at d_out + t*out_port_stride + f*out_burst_stride (items).  Samples and padding are bit-identical to
+ * jrc_ofdm_mod_dev followed by jrc_zero_pad_strided_dev per port with seed + t*seed_port_step; the unpadded time-domain packet is never
+ * written.  fft_len: a power of two in [4, 8192] (else JRC_ERR_UNSUPPORTED: use the two calls).  Returns the burst length in items. */
+int jrc_ofdm_mod_pad_dev(jrc_ctx* ctx, int fft_len, int cp_len, const float* d_window, int n_frames, int n_ports, int n_symbols,
+                         unsigned pad_front, unsigned pad_tail, uint64_t seed, uint64_t seed_port_step,
+                         const jrc_cf32* d_in, jrc_cf32* d_out, long out_port_stride, long out_burst_stride, void* stream);
 
 /* batched, device-resident form of the whole front end (detection metrics -> frame_detector -> frame_sync run to completion on
  * one capture): frame k of the capture lands in row k of d_frames ([max_frames][max_symbols * fft_len] time-domain samples,

@@ -26,6 +26,8 @@ if EMULATED:
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "spawns: starts child processes that open the device (ordered behind the parity tests)")
+    config.addinivalue_line("markers", "unvetted: exercises a kernel that has never run on hardware (written while the GPU was closed to this repository): runs "
+                                       "on the emulated kernels; on a device only with JRC_TEST_UNVETTED=1 (tools/final_check.sh sets it), ordered last")
 
 
 # Order of the suite.  The reference ships no tests, so this suite is the only correctness evidence there is: the files that
@@ -51,6 +53,8 @@ def suite_tier(item):
     tier = _TIER_BY_FILE.get(fname, 1)
     if tier < 2 and item.get_closest_marker("spawns") is not None:
         tier = 2
+    if item.get_closest_marker("unvetted") is not None:
+        tier = 4
     return tier
 
 
@@ -80,6 +84,11 @@ def pytest_collection_modifyitems(config, items):
     items.sort(key=suite_tier)          # list.sort is stable: collection order survives inside a tier
     if EMULATED:
         _emulation_marks(items)
+    elif os.environ.get("JRC_TEST_UNVETTED", "") in ("", "0"):
+        for it in items:
+            if it.get_closest_marker("unvetted") is not None:
+                it.add_marker(pytest.mark.skip(reason="a kernel that has not run on hardware yet (round 6 had no GPU): JRC_TEST_UNVETTED=1 runs it on the device; "
+                                                      "tests/test_emulated_kernels.py runs it on the emulated kernels in the CPU tier"))
 
 
 @pytest.fixture(scope="session")

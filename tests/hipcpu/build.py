@@ -102,9 +102,11 @@ def build(verbose=False, sanitize=None):
 
         with concurrent.futures.ThreadPoolExecutor(max_workers=4) as ex:
             objs = list(ex.map(one, srcs + ["hipcpu_runtime.cc"]))
-        r = subprocess.run([cxx, "-shared", "-fPIC", "-o", lib] + objs + (["-fsanitize=" + sanitize] if sanitize else []) + ["-lpthread", "-lm"], capture_output=True, text=True)
+        # linked beside the target and renamed over it: a process that has the previous build mapped keeps its inode
+        r = subprocess.run([cxx, "-shared", "-fPIC", "-o", lib + ".tmp"] + objs + (["-fsanitize=" + sanitize] if sanitize else []) + ["-lpthread", "-lm"], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcpu: link failed:\n%s" % r.stderr[-4000:])
+        os.replace(lib + ".tmp", lib)
         open(stamp_file, "w").write(stamp)
         if verbose:
             print("built", lib)
@@ -123,11 +125,12 @@ def build_blocks(verbose=False, sanitize=None):
         fcntl.flock(lock, fcntl.LOCK_EX)
         if os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(d) for d in deps):
             return out
-        cmd = [compiler(), "-O1", "-g", "-std=c++14", "-fPIC", "-shared", "-o", out] + srcs + [lib, "-Wl,-rpath," + OUT, "-lpthread"] + \
+        cmd = [compiler(), "-O1", "-g", "-std=c++14", "-fPIC", "-shared", "-o", out + ".tmp"] + srcs + [lib, "-Wl,-rpath," + OUT, "-lpthread"] + \
               (["-fsanitize=" + sanitize] if sanitize else [])
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcpu: host blocks failed:\n%s" % r.stderr[-4000:])
+        os.replace(out + ".tmp", out)
         if verbose:
             print("built", out)
     return out

@@ -1,0 +1,109 @@
+"""GPU tier, kernels written in round 6 — while the GPU pool was closed to this repository — and therefore never run on hardware.  They are opt-in in
+the product (environment switches, the defaults are the kernels the driver's GPU runs of rounds 1-5 covered) and these tests are `unvetted`: they
+run on the emulated kernels in the CPU tier (tests/test_emulated_kernels.py) and on a device only when JRC_TEST_UNVETTED=1 is set, last in the suite."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import crandn
+
+pytestmark = [pytest.mark.gpu, pytest.mark.unvetted]
+
+
+def _mod_pad_argtypes(L):
+    L.jrc_ofdm_mod_pad_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_uint, C.c_uint64, C.c_uint64,
+                                       C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_void_p]
+    L.jrc_zero_pad_strided_dev.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint, C.c_uint, C.c_uint64, C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p]
+
+
+@pytest.mark.parametrize("N,cp,T,F,n_sym,front,tail", [
+    (64, 16, 4, 5, 27, 0, 240),          # the .grc's packet: 4 TX, 27 symbols of 80 samples, zero_pad(0, 3 symbols)
+    (256, 64, 4, 3, 9, 0, 960),          # config B's carriers
+    (64, 16, 1, 7, 3, 33, 17),           # a front pad, odd lengths, four transforms per workgroup with a ragged last workgroup
+    (1024, 256, 2, 2, 4, 5, 0),          # no tail pad
+    (8, 0, 3, 4, 5, 2, 3),               # no cyclic prefix, log2 n odd (leading radix-2 pass)
+    (128, 32, 2, 1, 1, 0, 0),            # one symbol per burst: the same transform writes both pads (none here)
+])
+def test_ofdm_mod_and_zero_pad_as_one_kernel_equals_the_two_blocks(jrc, ctx, N, cp, T, F, n_sym, front, tail):
+    """jrc_ofdm_mod_pad_dev against jrc_ofdm_mod_dev followed by jrc_zero_pad_strided_dev per port: every sample and every pad value bit for bit (same
+    Stockham passes, same noise generator and key), nothing written outside the bursts, and the modulator itself against numpy's ifft"""
+    import torch
+    L = ctx.lib
+    _mod_pad_argtypes(L)
+    rng = np.random.default_rng(N + T + F)
+    x = crandn(rng, F, T, n_sym, N)
+    w = (np.hanning(N) + 0.5).astype(np.float32)
+    d_in = torch.from_numpy(x.view(np.float32).reshape(F, T, n_sym, N, 2).copy()).cuda()
+    d_w = torch.from_numpy(w).cuda()
+    n_in = n_sym * (N + cp)
+    n_out = n_in + front + tail
+    seed, step = 1234, 100
+    # the two blocks
+    d_t = torch.zeros((F, T, n_in, 2), dtype=torch.float32, device="cuda")
+    ctx.check(L.jrc_ofdm_mod_dev(ctx.h, N, cp, d_w.data_ptr(), F * T * n_sym, d_in.data_ptr(), d_t.data_ptr(), None))
+    want = torch.full((T, F, n_out + 3, 2), -7.0, dtype=torch.float32, device="cuda")
+    for t in range(T):
+        r = L.jrc_zero_pad_strided_dev(ctx.h, F, n_in, front, tail, seed + step * t, d_t.data_ptr() + 8 * t * n_in, T * n_in, want[t].data_ptr(), n_out + 3, None)
+        assert r == n_out
+    # one kernel
+    got = torch.full((T, F, n_out + 3, 2), -7.0, dtype=torch.float32, device="cuda")
+    r = L.jrc_ofdm_mod_pad_dev(ctx.h, N, cp, d_w.data_ptr(), F, T, n_sym, front, tail, seed, step, d_in.data_ptr(), got.data_ptr(), F * (n_out + 3), n_out + 3, None)
+    assert r == n_out
+    ctx.sync()
+    g, wv = got.cpu().numpy(), want.cpu().numpy()
+    assert np.array_equal(g.view(np.uint32), wv.view(np.uint32))                       # bit for bit, the untouched guard items included
+    assert np.all(g[:, :, n_out:] == -7.0)
+    # and the samples are the modulator's: ifft of the ifftshift-ed, windowed carriers, unnormalised, cyclic prefix in front
+    gc = g[..., 0] + 1j * g[..., 1]
+    ref = np.fft.ifft(np.fft.ifftshift(x * w, axes=-1), axis=-1) * N
+    ref = np.concatenate([ref[..., N - cp:], ref], axis=-1).reshape(F, T, n_in)
+    err = np.abs(gc[:, :, front:front + n_in] - np.swapaxes(ref, 0, 1)).max() / np.abs(ref).max()
+    assert err < 2e-6, err
+    if front + tail:
+        pads = np.concatenate([gc[:, :, :front], gc[:, :, front + n_in:n_out]], axis=-1)
+        assert 0.5e-2 < pads.real.std() < 2e-2 or pads.size < 50                          # N(0, 1e-2) per component
+
+
+def test_ofdm_mod_pad_refuses_what_it_does_not_take(jrc, ctx):
+    import torch
+    L = ctx.lib
+    _mod_pad_argtypes(L)
+    x = torch.zeros((1, 1, 1, 48, 2), device="cuda")
+    o = torch.zeros((1, 1, 100, 2), device="cuda")
+    assert L.jrc_ofdm_mod_pad_dev(ctx.h, 48, 12, None, 1, 1, 1, 0, 0, 0, 0, x.data_ptr(), o.data_ptr(), 100, 100, None) == jrc.JRC_ERR_UNSUPPORTED
+    assert L.jrc_ofdm_mod_pad_dev(ctx.h, 64, 65, None, 1, 1, 1, 0, 0, 0, 0, x.data_ptr(), o.data_ptr(), 100, 100, None) == jrc.JRC_ERR_INVALID_ARG
+    assert L.jrc_ofdm_mod_pad_dev(ctx.h, 64, 16, None, 1, 1, 1, 0, 30, 0, 0, x.data_ptr(), o.data_ptr(), 100, 100, None) == jrc.JRC_ERR_INVALID_ARG   # 110 > stride 100
+    assert L.jrc_ofdm_mod_pad_dev(ctx.h, 64, 16, None, 0, 1, 1, 0, 30, 0, 0, None, None, 0, 0, None) == 110                                            # no frames: the length
+
+
+def test_device_resident_flowgraph_with_the_fused_modulator_equals_the_default_leg(jrc, ctx, monkeypatch):
+    """examples/radar_sim_device_resident.py with JRC_DRF_FUSED_MOD=1 (jrc_ofdm_mod_pad_dev in place of jrc_ofdm_mod_dev + T jrc_zero_pad_strided_dev):
+    every edge downstream — the padded bursts, the RX bursts, the channel estimate, the map, the records — equal to the default leg's BIT FOR BIT at
+    config B's geometry and at the .grc's own"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import radar_sim_device_resident as drm
+    for N, R, n_data, S, F, tables in ((256, 4, 60, 64, 3, drm.config_b_tables()), (64, 2, 18, 4, 6, None)):
+        if tables is None:
+            o = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ofdm_config_64.npz"))
+            tables = {k: o[k] for k in o.files}
+        tg = dict(trgt_range=[10.0, 31.0], trgt_velocity=[0.0, 6.0], trgt_rcs_dbsm=[20.0, 24.0], trgt_angle=[20.0, -35.0])
+        rng = np.random.default_rng(N)
+        edges, recs = [], []
+        for fused in ("0", "1"):
+            monkeypatch.setenv("JRC_DRF_FUSED_MOD", fused)
+            sim = drm.DeviceResidentRadarSim(tables, N, R, n_data, S, F, seed=40, ctx=ctx, **tg)
+            assert sim.fused_mod == (fused == "1")
+            if not edges:
+                syms = np.stack([drm.qpsk_symbols(rng, n_data * sim.nd) for _ in range(F)])
+            sim.load_symbols(syms)
+            sim.step(F)
+            recs.append([bytes(memoryview(r)) for r in sim.results(F)])
+            edges.append(sim.edges(F))
+        a, b = edges
+        assert "tx_t" in a and "tx_t" not in b
+        for k in ("tx_f", "bursts", "rx_t", "H", "map"):
+            assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), (N, k)
+        assert recs[0] == recs[1]
