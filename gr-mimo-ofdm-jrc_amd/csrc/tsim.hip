@@ -942,6 +942,64 @@ __global__ __launch_bounds__(256) void td_rows_small_kernel(const float2* __rest
     }
 }
 
+// ---- the whole burst on chip: bursts short enough for (2 + R) x n cells of LDS — the 64-carrier flowgraphs' 2400-sample
+//      bursts (77 KB at two RX antennas) — go through ONE kernel, one workgroup per burst: per (simulator, target) pair the input . doppler is
+//      loaded, transformed as a single n-point mixed-radix Stockham transform in LDS (the column passes above with a tile one column wide, radices =
+//      the factors of n, twiddles from the context's n-entry table), multiplied by the pair's timeshift (and phase) into one LDS accumulator per RX
+//      antenna; then every antenna's sum goes through the inverse transform (conj, forward, conj) and out, with the self-coupling term and the
+//      accumulate option of the column pass.  One read of every input, R writes, nothing else touches HBM; 1 launch instead of 3.
+//      The timeshift table is the direct route's (row-pass order [k1][pos(k2)], n = n1 x n2): natural k = k1 + n1 k2 reads entry k1 n2 + pos(k2).
+//      Same algebra as the three passes, another factorisation: results agree with them to rounding, not bit for bit.
+//      Written in round 6 without a device: opt-in (JRC_TSIM_ONCHIP=1), never timed.
+__global__ __launch_bounds__(256) void td_onchip_kernel(td_srcs srcs, long in_stride, td_ts ts, long ts_l_stride, int V, int R,
+                                                        float2* __restrict__ out, long out_burst_stride, long out_rx_stride, td_self self,
+                                                        float self_coupling, int accumulate, const float2* __restrict__ wn, td_plan pl /* n1 = n: radices of n */,
+                                                        int d_n1, int d_n2 /* the direct route's split of n: order of the timeshift table */)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 td_lds[];
+    const int n = pl.n1, tid = threadIdx.x;
+    float2* buf0 = td_lds;
+    float2* buf1 = buf0 + n;
+    float2* acc = buf1 + n;                                                  // [R][n]
+    const size_t b = blockIdx.x;
+    const int m = d_n2 > 256 ? d_n2 / 256 : 1;
+    for (int v = 0; v < V; v++) {
+        const float2* __restrict__ src = srcs.in[v] + b * (size_t)in_stride;
+        const float2* __restrict__ dz = srcs.dop[v];
+        for (int i = tid; i < n; i += 256) buf0[i] = cmul(src[i], dz[i]);    // volk_32fc_x2_multiply_32fc (:345)
+        __syncthreads();
+        const float2* X = td_col_transform<1>(buf0, buf1, wn, pl, 0, tid, 256);
+        for (int k = tid; k < n; k += 256) {
+            const int k1 = k % d_n1, k2 = k / d_n1;
+            const int pos = m > 1 ? (k2 % m) * 256 + k2 / m : k2;
+            float2 x = X[k];
+            if (ts.use_phase) x = cmul(x, ts.phase[v]);
+            const float2* __restrict__ tr = ts.tsp[v] + (size_t)k1 * d_n2 + pos;
+            for (int l = 0; l < R; l++) {
+                const float2 y = cmul(x, tr[(size_t)l * ts_l_stride]);
+                acc[(size_t)l * n + k] = v ? cadd(acc[(size_t)l * n + k], y) : y;
+            }
+        }
+        __syncthreads();
+    }
+    for (int l = 0; l < R; l++) {
+        for (int k = tid; k < n; k += 256) { const float2 a = acc[(size_t)l * n + k]; buf0[k] = make_float2(a.x, -a.y); }   // conjugated: the inverse runs on the forward passes
+        __syncthreads();
+        const float2* y = td_col_transform<1>(buf0, buf1, wn, pl, 0, tid, 256);
+        float2* o = out + b * (size_t)out_burst_stride + (size_t)l * out_rx_stride;
+        for (int i = tid; i < n; i += 256) {
+            float2 r = make_float2(y[i].x, -y[i].y);
+            if (accumulate) r = cadd(o[i], r);
+            for (int q = 0; q < self.n; q++) {                               // out += (gr_complex)pow(10, db/20) * in  (:376), per simulator
+                const float2 xi = self.in[q][b * (size_t)in_stride + i];
+                r = cadd(r, make_float2(self_coupling * xi.x - 0.0f * xi.y, self_coupling * xi.y + 0.0f * xi.x));
+            }
+            o[i] = r;
+        }
+        __syncthreads();                                                     // buf0 / buf1 are the next antenna's
+    }
+}
+
 // ---- host side -------------------------------------------------------------------------------
 static const double TS_FOUR_PI_CUBED_SQRT = 44.54662397465366;   // :33
 static const float TS_C_LIGHT = 3e8f;                           // target_simulator_impl.h c_light
@@ -1015,6 +1073,15 @@ static void tsim_free_tables(jrc_tsim* h)
 }
 
 // n = n1 x n2 with n2 the largest power of two dividing n (<= 4096) and n1 <= TD_MAX_N1; the radices of the n1-point column transform
+// radices of an m-point column transform: 4s, a 2, then the odd prime factors in rising order (3 and 5 have butterflies of their own)
+static void td_factor(int m, td_plan* pl)
+{
+    pl->n1 = m; pl->n2 = 1; pl->nrad = 0;
+    while (m % 4 == 0) { pl->rad[pl->nrad++] = 4; m /= 4; }
+    if (m % 2 == 0) { pl->rad[pl->nrad++] = 2; m /= 2; }
+    for (int p = 3; m > 1; p += 2)
+        while (m % p == 0) { pl->rad[pl->nrad++] = p; m /= p; }
+}
 static size_t td_col_lds_bytes(int n1, int cw) { return sizeof(float2) * ((size_t)2 * n1 * cw + (size_t)n1); }
 // `pairs` = (simulator, target) pairs one launch of this simulator carries (K with sum_targets, else 1): the launches hold at most TD_MAXV
 // of them, a simulator with more keeps the chirp-z route, which takes any K.  `max_lds` = the device's LDS per workgroup: the column passes
@@ -1243,6 +1310,21 @@ static int tsim_run_direct(jrc_tsim* const* sims, int n_sims, int n_bursts, int 
         (void)hipFree(h->d_u); h->d_u = nullptr; h->u_cap = 0;
         JRC_HIP(ctx, hipMalloc((void**)&h->d_u, need_u));
         h->u_cap = need_u;
+    }
+    if (const char* e_on = getenv("JRC_TSIM_ONCHIP"); e_on && *e_on && *e_on != '0') {     // read per call, like JRC_TSIM_BLUESTEIN
+        // the burst-on-chip kernel where (2 + R) x n cells fit a workgroup's LDS (opt-in, JRC_TSIM_ONCHIP=1: written without a device, never timed)
+        const size_t lds_on = sizeof(float2) * (size_t)(2 + R) * n;
+        if (lds_on <= ctx->max_lds_per_block && n >= 2) {
+            td_plan pn;
+            td_factor(n, &pn);
+            const float2* wn = nullptr;
+            JRC_TRY(jrc_get_twiddles(ctx, n, -1, &wn));
+            JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)td_onchip_kernel, lds_on));
+            hipLaunchKernelGGL(td_onchip_kernel, dim3((unsigned)n_bursts), dim3(256), lds_on, s, srcs, (long)n, ts, ts_l_stride, V, R, (float2*)d_out,
+                               (long)R * n, (long)n, self, sc, accumulate_out ? 1 : 0, wn, pn, n1, n2);
+            JRC_HIP(ctx, hipGetLastError());
+            return JRC_OK;
+        }
     }
     const float2* tw256 = nullptr;
     JRC_TRY(jrc_get_twiddles(ctx, TS_N1, -1, &tw256));

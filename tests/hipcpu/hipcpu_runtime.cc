@@ -392,6 +392,16 @@ void launch_closure(dim3 grid, dim3 block, size_t dyn, hipStream_t s, std::funct
 
 using namespace hipcpu;
 
+// HIPCPU_STATS=1: the counters on stderr when the process ends (how many cross-lane operations read a lane outside the exec mask, for instance)
+static struct StatsAtExit {
+    ~StatsAtExit()
+    {
+        if (getenv("HIPCPU_STATS"))
+            fprintf(stderr, "[hipcpu] kernels %llu workgroups %llu cross-lane ops %llu barriers %llu readlane-of-inactive-lane %llu shuffle-from-inactive-lane %llu\n",
+                    g_stats.kernels, g_stats.blocks, g_stats.wave_ops, g_stats.barriers, g_stats.readlane_inactive, g_stats.shfl_inactive);
+    }
+} g_stats_at_exit;
+
 extern "C" void hipcpu_stats(unsigned long long* out6)
 {
     out6[0] = g_stats.kernels; out6[1] = g_stats.blocks; out6[2] = g_stats.wave_ops; out6[3] = g_stats.barriers; out6[4] = g_stats.readlane_inactive; out6[5] = g_stats.shfl_inactive;

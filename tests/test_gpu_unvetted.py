@@ -107,3 +107,84 @@ def test_device_resident_flowgraph_with_the_fused_modulator_equals_the_default_l
         for k in ("tx_f", "bursts", "rx_t", "H", "map"):
             assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), (N, k)
         assert recs[0] == recs[1]
+
+
+# ---- target simulator: the whole burst on chip (JRC_TSIM_ONCHIP=1, tsim.hip td_onchip_kernel) -----------------------------------------------------------
+FS, FC = 125_000_000, 24e9
+POS4 = [0.0, 0.00625, 0.0125, 0.01875]
+TGT3 = ([10.0, 23.5, 41.0], [0.0, 12.0, -30.0], [100.0, 10.0, 31.0], [20.0, -35.0, 5.0])
+
+
+def _burst(n, seed):
+    return crandn(np.random.default_rng(seed), n)
+
+
+@pytest.mark.parametrize("n,R", [(2400, 2), (2400, 4), (80, 4), (1920, 3), (1344, 2), (256, 4), (4096, 2), (16, 1), (5 * 7 * 11 * 16, 1), (127 * 16, 2), (3 * 31 * 64, 1)])
+def test_target_simulator_burst_on_chip_against_the_oracle_and_the_three_pass_route(jrc, ctx, monkeypatch, n, R):
+    """every burst length class the on-chip kernel takes (the .grc's 2400 = 75 x 32, 80-sample symbols, powers of two incl. n2 = 4096 with its
+    permuted timeshift order, odd primes up to 127 as radices) against the oracle (as the direct route: <= 2e-6) and against the default three-pass
+    route on the same burst; with one target and with three summed targets, random phases, self coupling and accumulation into a filled buffer"""
+    import oracle
+    import torch
+    from conftest import rel_err
+    pos = POS4[:R]
+    x = np.stack([_burst(n, 3 * n + b) for b in range(2)])
+    for sum_targets in (False, True):
+        want, got, alone = None, {}, {}
+        for onchip in ("0", "1"):
+            monkeypatch.setenv("JRC_TSIM_ONCHIP", onchip)
+            g = jrc.target_simulator(*TGT3, pos, FS, FC, self_coupling_db=-20.0, rndm_phaseshift=True, self_coupling=True, sum_targets=sum_targets,
+                                     seed=4, max_bursts=2, ctx=ctx)
+            ph = g.draw_phases()
+            if want is None:
+                o = oracle.TargetSimulator(*TGT3, pos, FS, FC, self_coupling_db=-20.0, rndm_phaseshift=True, self_coupling=True)
+                want = np.stack([o.work(x[b], target_phase=ph, sum_targets=sum_targets) for b in range(2)])
+            base = (np.arange(2 * R * n, dtype=np.float32).reshape(2, R, n) % 7).astype(np.complex64)
+            d_out = torch.from_numpy(base.copy()).cuda()
+            g.run_dev(torch.from_numpy(x).cuda(), d_out, 2, n, accumulate_out=True, target_phase=ph)
+            ctx.sync()
+            got[onchip] = d_out.cpu().numpy() - base
+            alone[onchip] = g.work(x[0], target_phase=ph)
+            assert rel_err(alone[onchip], want[0]) < 2e-6, (onchip, sum_targets)
+        assert rel_err(got["1"], want) < 2e-5 and rel_err(got["0"], want) < 2e-5          # (the sum with the buffer's 0..6 rounds at 6 x 2^-24)
+        assert rel_err(got["1"], got["0"]) < 2e-5
+        assert not np.array_equal(alone["1"], alone["0"]) or n != 2400                     # another factorisation: the on-chip kernel really ran
+
+
+def test_summed_simulators_on_chip_equal_the_default_route(jrc, ctx, monkeypatch):
+    """jrc_tsim_run_sum_dev (the T target simulators of a flowgraph's TX ports and the adders behind them) through the on-chip kernel: 4 simulators x 2 targets
+    = 8 pairs, 2 RX antennas, 2400-sample bursts, 5 bursts — against the default route and against the simulators run one by one"""
+    import torch
+    from conftest import rel_err
+    n, R, T, B = 2400, 2, 4, 5
+    wavelength = 3e8 / FC
+    xs = [np.stack([_burst(n, 100 * t + b) for b in range(B)]) for t in range(T)]
+    outs = {}
+    for onchip in ("0", "1"):
+        monkeypatch.setenv("JRC_TSIM_ONCHIP", onchip)
+        sims = [jrc.target_simulator([10.0, 31.0], [0.0, 6.0], [100.0, 250.0], [20.0, -35.0], [(1 + t / 2 + 2 * r) * wavelength for r in range(R)], FS, FC,
+                                     -40.0, False, False, sum_targets=True, max_bursts=B, ctx=ctx) for t in range(T)]
+        d_in = [torch.from_numpy(x).cuda() for x in xs]
+        d_out = torch.zeros((B, R, n), dtype=torch.complex64, device="cuda")
+        jrc.target_simulator.run_sum_dev(sims, d_in, d_out, B, n)
+        ctx.sync()
+        outs[onchip] = d_out.cpu().numpy()
+        if onchip == "0":
+            one = torch.zeros((B, R, n), dtype=torch.complex64, device="cuda")
+            for t in range(T):
+                sims[t].run_dev(d_in[t], one, B, n, accumulate_out=(t > 0))
+            ctx.sync()
+            outs["one_by_one"] = one.cpu().numpy()
+    assert rel_err(outs["1"], outs["0"]) < 2e-6 and rel_err(outs["1"], outs["one_by_one"]) < 2e-6
+    assert not np.array_equal(outs["1"], outs["0"])
+
+
+def test_bursts_too_long_for_the_chip_keep_the_three_pass_route(jrc, ctx, monkeypatch):
+    """23,040 samples x (2 + 4) cells = 1.1 MB: with the switch on, config B's burst still goes the default way, bit for bit"""
+    x = _burst(23040, 5)
+    args = ([35.0], [-12.0], [40.0], [-25.0], POS4, FS, FC)
+    monkeypatch.setenv("JRC_TSIM_ONCHIP", "0")
+    a = jrc.target_simulator(*args, ctx=ctx).work(x)
+    monkeypatch.setenv("JRC_TSIM_ONCHIP", "1")
+    b = jrc.target_simulator(*args, ctx=ctx).work(x)
+    assert np.array_equal(a, b)
