@@ -87,5 +87,5 @@ def test_suite_order_puts_parity_first_and_process_spawning_last():
                                                              "tests/test_gpu_flowgraph_parity.py", "tests/test_gpu_sync.py", "tests/test_gpu_codec.py"))
               and "pacing_word" not in i]
     assert max(parity) < first_spawn
-    assert files[-1] == "tests/test_bench_launch.py"
+    assert files[-2:] == ["tests/test_bench_launch.py", "tests/test_gpu_unvetted.py"]      # rank launches, then the kernels that have never run on hardware
     assert ids[0].startswith(("tests/test_golden", "tests/test_gpu_blocks.py"))
