@@ -455,6 +455,48 @@ def test_multi_device_feed_equals_single_device_feed(jrc, ctx, devices):
     single.close()
 
 
+def test_multi_device_feed_with_a_device_that_does_not_exist_is_refused_and_leaks_nothing(jrc, ctx):
+    """the device list of jrc_chain_feed_create_multi (the radar_chain block's JRC_DEVICES) names a device the process cannot
+    open — first, in the middle, last: creation fails loudly (jrc_create refuses the index), the contexts and slots made for the
+    devices before it are destroyed again (device memory in use afterwards = before, over twenty refused creations), and a list of eight entries
+    that do exist (the box's one GPU eight times: BASELINE config 5's device count) works and reports eight devices"""
+    import torch
+    from jrc_amd import synth
+    sc = synth.Scenario(64, 2, 2, 3, targets=[(15.0, -20.0, 0.0, 50.0)])
+    P = sc.T * sc.R
+    rb, ab = jrc.radar_axes(sc.N, sc.fs, 2, P, 4)
+    mk = lambda devices: jrc.ChainFeed(sc.N, sc.T, sc.R, sc.S, sc.Npre, 2, 4, rb, ab, 2.4, 29.0, 15.0, 0.0, ctx=ctx, n_slots=2, frames_per_slot=2,
+                                       maps_per_slot=1, devices=devices)
+    ctx.sync()
+    torch.cuda.synchronize()
+    mk([0, 0]).close()                                              # whatever the first creation caches (twiddle tables of the context) exists now
+    free0 = torch.cuda.mem_get_info()[0]
+    whole = mk([0, 0, 0])
+    held = free0 - torch.cuda.mem_get_info()[0]                     # what one feed over three contexts holds: the unit a leak would come in
+    whole.close()
+    assert held > 0
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 1
+    missing = max(n_dev, 1) + 57                                    # no such device on any box
+    for rep in range(7):
+        for devices in ([missing, 0, 0], [0, missing, 0], [0, 0, 0, missing]):
+            with pytest.raises(jrc.JrcError) as e:
+                mk(devices)
+            assert e.value.status in (jrc.JRC_ERR_INVALID_ARG, jrc.JRC_ERR_NO_DEVICE), e.value      # jrc_create: a device index outside [0, count)
+    ctx.sync()
+    # 21 refused creations, each after one or two contexts with their slots had been made: leaked, they would hold several times `held`
+    assert free0 - torch.cuda.mem_get_info()[0] < max(held // 2, 2 << 20), (free0, torch.cuda.mem_get_info()[0], held)
+    eight = mk([0] * 8)
+    assert eight.n_devices() == 8 and eight.n_slots == 16
+    frames = synth.make_frames(sc, 2)
+    for _ in range(16):
+        eight.submit(frames)
+    got = []
+    while eight.pending():
+        got += [_rec(x) for x in eight.collect()[0]]
+    assert len(got) == 32 and all(g == got[i % 2] for i, g in enumerate(got))          # the same two frames through every slot of every context
+    eight.close()
+
+
 def test_multi_device_feed_refuses_background_and_one_feed_per_stream_carries_it(jrc, ctx):
     """background removal orders the frames of ONE radar stream (lib/mimo_ofdm_radar_impl.cc:281-300): a feed that deals batches over devices
     refuses it loudly (no silent per-device histories), and the supported layout — one feed per stream, each on its own device context, all
