@@ -53,6 +53,22 @@ def test_stamped_full_suite_record_matches_this_tree():
         "%s was stamped at kernel sources %s, the tree is at %s: re-run tools/final_check.sh on the GPU box" % (os.path.basename(rec), d["source_hash"], jb.source_hash())
 
 
+def test_stamped_emulated_suite_record_matches_this_tree():
+    """profiles/rNN_emulated_suite.json (tools/emulated_suite.sh): every pass green, no sanitizer report, stamped at the kernel sources of this tree"""
+    recs = sorted(glob.glob(os.path.join(PROFILES, "r[0-9][0-9]*_emulated_suite.json")))
+    if not recs:
+        pytest.skip("no stamped emulated-suite record under profiles/")
+    from jrc_amd import build as jb
+    d = json.load(open(recs[-1]))
+    assert "NOT a device run" in d["what"]
+    assert set(d["passes"]) >= {"default", "asan_ubsan"}
+    for name, p in d["passes"].items():
+        assert p["rc"] == 0 and p["failed"] == 0 and p["errors"] == 0 and p["sanitizer_reports"] == 0, (name, p)
+    assert d["passes"]["default"]["passed"] >= 750
+    assert d["source_hash"] == jb.source_hash(), \
+        "%s was stamped at kernel sources %s, the tree is at %s: re-run tools/emulated_suite.sh" % (os.path.basename(recs[-1]), d["source_hash"], jb.source_hash())
+
+
 def test_stamp_suite_parses_a_verbose_log():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import stamp_suite

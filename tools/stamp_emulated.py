@@ -16,7 +16,7 @@ def main():
     tag, rcs = sys.argv[1], [int(x) for x in sys.argv[2:5]]
     from jrc_amd import build as jb
     rec = {"what": "the -m gpu tests on the library's kernel sources built for the host CPU under the emulated execution model of tests/hipcpu "
-                   "(no GPU: the pool was closed to this repository in round 6); NOT a device run", "source_hash": jb.source_hash(),
+                   "(no GPU: the pool was closed to this repository in round 6) - NOT a device run", "source_hash": jb.source_hash(),
            "when": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()), "host": os.uname().machine, "passes": {}}
     for name, rc in zip(("default", "heavy", "asan_ubsan"), rcs):
         p = os.path.join(ROOT, "gpurun_out", "%s_emulated_%s.log" % (tag, name))
