@@ -561,6 +561,7 @@ __global__ __launch_bounds__(NT_, 2) void range_angle_wide_kernel(
                 // lower bound of the maximum: it raises the filter threshold (never the tracked candidates) before anything else of the class is computed
                 const float wm = wave_max_f32(rowmax) * (1.0f - 4e-6f);
                 if (wm > trk.run_max) { trk.run_max = wm; if (lane == 0) atomicMax(s_run, __float_as_uint(wm)); }
+                JRC_LOCKSTEP();                                   // lane 0's store precedes every lane's next read of s_run (one instruction stream)
             }
             unsigned long long surv = __ballot(rowmax * (EZ * (1.0f + 1e-4f)) >= trk.run_max * (1.0f - 1e-5f));
             if constexpr (RPW < 64) surv &= 0xffffffffull;
@@ -685,6 +686,7 @@ __global__ __launch_bounds__(NT_, 2) void range_angle_wide_kernel(
             const float before = trk.run_max;
             const float thr = trk.raise(m);
             if constexpr (MODE == 1) { if (trk.run_max > before && lane == 0) atomicMax(s_run, __float_as_uint(trk.run_max)); }   // non-negative floats order as their bit patterns
+            if constexpr (MODE == 1) JRC_LOCKSTEP();          // (as above: the wave reads s_run again at its next trip)
             if (m >= thr) {
                 const unsigned flat0 = (unsigned)k * (unsigned)NA;
 #pragma unroll
