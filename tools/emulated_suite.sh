@@ -11,7 +11,12 @@ mkdir -p gpurun_out
 export JRC_EMULATE=1 OMP_NUM_THREADS=1
 python3 -m pytest tests -m gpu -v -n $NW --timeout 1800 -p no:cacheprovider > gpurun_out/${TAG}_emulated_default.log 2>&1
 RC1=$?
-RC2=0; RC3=0
+RC2=0; RC3=0; RC4=0; RC5=0
+# the same pass with the emulated waves and lanes run backwards, and in a shuffled order: results must not depend on it
+HIPCPU_SCHEDULE=reverse python3 -m pytest tests -m gpu -v -n $NW --timeout 1800 -p no:cacheprovider > gpurun_out/${TAG}_emulated_reverse.log 2>&1
+RC4=$?
+HIPCPU_SCHEDULE=shuffle:2026 python3 -m pytest tests -m gpu -v -n $NW --timeout 1800 -p no:cacheprovider > gpurun_out/${TAG}_emulated_shuffle.log 2>&1
+RC5=$?
 if [ "$HEAVY" = heavy ]; then
   # the shapes the default pass leaves out (bench batches, 10^6-sample streams): fewer workers, they are large
   JRC_EMULATE_HEAVY=1 python3 -m pytest tests -m gpu -v -n 3 --timeout 3600 -p no:cacheprovider \
@@ -23,8 +28,8 @@ if [ "$ASAN" = asan ]; then
   RT=$(/opt/rocm/lib/llvm/bin/clang++ -print-file-name=libclang_rt.asan-x86_64.so)
   JRC_EMULATE_SANITIZE=address,undefined LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:halt_on_error=1:exitcode=77 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
     python3 -m pytest tests/test_gpu_blocks.py tests/test_gpu_chain.py tests/test_gpu_chain_modes.py tests/test_gpu_comm.py tests/test_gpu_tsim.py tests/test_gpu_sync.py \
-      tests/test_gpu_codec.py tests/test_gpu_edges.py tests/test_gpu_flowgraph.py tests/test_gpu_flowgraph_parity.py tests/test_host_blocks.py tests/test_golden_fixtures.py \
+      tests/test_gpu_codec.py tests/test_gpu_edges.py tests/test_gpu_flowgraph.py tests/test_gpu_flowgraph_parity.py tests/test_host_blocks.py tests/test_golden_fixtures.py tests/test_gpu_unvetted.py \
       -m gpu -v -n $NW --timeout 3600 -p no:cacheprovider > gpurun_out/${TAG}_emulated_asan_ubsan.log 2>&1
   RC3=$?
 fi
-python3 tools/stamp_emulated.py $TAG $RC1 $RC2 $RC3
+python3 tools/stamp_emulated.py $TAG $RC1 $RC2 $RC3 $RC4 $RC5
