@@ -54,3 +54,28 @@ def test_product_does_not_import_oracle():
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert not re.search(r"^\s*(import|from)\s+oracle\b", txt, flags=re.M), f
                 assert "jrc_oracle" not in txt, f
+
+
+def test_product_does_not_know_the_cpu_emulation():
+    """tests/hipcpu (the kernels built for the host under an emulated execution model) is a checker like oracle/: nothing under the package, the
+    bench or the entry points' smoke() names it, looks for its library or switches to it.  The one trace in the product is the JRC_LOCKSTEP() marker
+    of jrc_internal.h, which expands to nothing unless the emulation build defines HIPCPU_EMULATION; the package's JRC_LIB_PATH override (kernel-variant
+    experiments since round 2) is how the TESTS point a child process at it."""
+    pkg = os.path.join(ROOT, "gr-mimo-ofdm-jrc_amd")
+    hits = []
+    for dirpath, dirs, files in os.walk(pkg):
+        dirs[:] = [d for d in dirs if d not in ("build", "lib", "__pycache__")]
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cc", ".cpp")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                for word in ("hipcpu", "JRC_EMULATE", "libjrc_hipcpu"):
+                    if word in txt:
+                        hits.append((f, word))
+                if "HIPCPU_EMULATION" in txt:
+                    hits.append((f, "HIPCPU_EMULATION"))
+    assert sorted(set(hits)) == [("jrc_internal.h", "HIPCPU_EMULATION"), ("jrc_internal.h", "hipcpu")], hits
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    assert "hipcpu" not in bench and "JRC_EMULATE" not in bench
+    entry = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    smoke = entry[entry.index("def smoke()"):]
+    assert "hipcpu" not in smoke and "JRC_EMULATE" not in smoke            # build() builds the checker; smoke() runs the device
