@@ -18,8 +18,8 @@ OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libjrc_hip.so")
 ARCH = "gfx950"
 
-SOURCES = ["ctx.hip", "radar.hip", "fft.hip", "estimator.hip", "chain.hip", "feed.hip", "comm.hip", "tsim.hip", "codec.hip", "sync.hip"]
-HEADERS = ["jrc_internal.h", "radar_kernels.h", "fft_device.h", os.path.join("..", "..", "include", "jrc.h")]
+SOURCES = ["ctx.hip", "radar.hip", "fft.hip", "estimator.hip", "chain.hip", "feed.hip", "comm.hip", "tsim.hip", "codec.hip", "sync.hip", "onchip.hip"]
+HEADERS = ["jrc_internal.h", "radar_kernels.h", "fft_device.h", "tsim_device.h", os.path.join("..", "..", "include", "jrc.h")]
 
 HIPCC_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
                "-fno-gpu-rdc"]

@@ -22,6 +22,7 @@
 // The channel filters themselves (doppler_k, timeshift_{l,k}) are the reference's float/double recurrences,
 // evaluated on the host once per burst length like the reference does (:249-300) and kept in HBM.
 #include "fft_device.h"
+#include "tsim_device.h"
 
 #include <cmath>
 #include <complex>
@@ -505,101 +506,6 @@ __global__ void tsim_passthrough_kernel(float2* __restrict__ out, long out_burst
 // no reordering pass.  HBM traffic per burst: (3 + 3R) n x 8 B against (1 + R) n x 8 B algorithmic = 3x at R = 4 (chirp-z: 13.6x).
 // Lengths that do not split this way (n2 < 16 or n1 > 512) keep the chirp-z route; JRC_TSIM_BLUESTEIN=1 forces it for all.
 // =====================================================================================================================
-#define TD_CW 16
-#define TD_MAX_N1 512
-
-struct td_plan { int n1, n2, nrad; int rad[24]; };
-// the spectra a launch sums: one entry per (simulator, target) pair — the targets of one simulator (sum_targets), and the simulators of a
-// flowgraph's TX ports whose outputs a blocks_add_xx adds (jrc_tsim_run_sum_dev)
-#define TD_MAXV 32
-#define TD_MAXSIMS 8
-struct td_srcs { const float2* in[TD_MAXV]; const float2* dop[TD_MAXV]; };            // burst 0 of the pair's input; its doppler filter [n]
-struct td_ts { const float2* tsp[TD_MAXV]; float2 phase[TD_MAXV]; int use_phase; };   // timeshift of (antenna 0, target) in row-pass order; per-target phase
-struct td_self { const float2* in[TD_MAXSIMS]; int n; };                              // inputs whose self-coupling term is added (:372-378)
-
-template <int R>
-__device__ __forceinline__ void td_dft_small(float2 (&v)[R]);
-template <> __device__ __forceinline__ void td_dft_small<2>(float2 (&v)[2]) { fft_fwd_small<2>(v); }
-template <> __device__ __forceinline__ void td_dft_small<4>(float2 (&v)[4]) { fft_fwd_small<4>(v); }
-template <> __device__ __forceinline__ void td_dft_small<3>(float2 (&v)[3])
-{
-    const float s3 = 0.86602540378443864676f;
-    const float2 t = cadd(v[1], v[2]), d = csub(v[1], v[2]);
-    const float2 m = make_float2(v[0].x - 0.5f * t.x, v[0].y - 0.5f * t.y);
-    const float2 jd = make_float2(s3 * d.y, -s3 * d.x);                      // -j s3 d
-    v[0] = cadd(v[0], t); v[1] = cadd(m, jd); v[2] = csub(m, jd);
-}
-template <> __device__ __forceinline__ void td_dft_small<5>(float2 (&v)[5])
-{
-    const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f, s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
-    const float2 a1 = cadd(v[1], v[4]), a2 = cadd(v[2], v[3]), b1 = csub(v[1], v[4]), b2 = csub(v[2], v[3]);
-    const float2 r1 = make_float2(v[0].x + c1 * a1.x + c2 * a2.x, v[0].y + c1 * a1.y + c2 * a2.y);
-    const float2 r2 = make_float2(v[0].x + c2 * a1.x + c1 * a2.x, v[0].y + c2 * a1.y + c1 * a2.y);
-    const float2 i1 = make_float2(s1 * b1.x + s2 * b2.x, s1 * b1.y + s2 * b2.y);
-    const float2 i2 = make_float2(s2 * b1.x - s1 * b2.x, s2 * b1.y - s1 * b2.y);
-    v[0] = cadd(v[0], cadd(a1, a2));
-    v[1] = make_float2(r1.x + i1.y, r1.y - i1.x); v[4] = make_float2(r1.x - i1.y, r1.y + i1.x);      // r -/+ j i
-    v[2] = make_float2(r2.x + i2.y, r2.y - i2.x); v[3] = make_float2(r2.x - i2.y, r2.y + i2.x);
-}
-
-// one forward Stockham pass of radix R down the columns of an LDS tile [n1][CW]; thread (c, w) of (CW, nw); Ns = product of the
-// radices already done.  w1[q] = exp(-j 2 pi q / n1).
-template <int R, int CW>
-__device__ __forceinline__ void td_col_pass(const float2* x, float2* y, const float2* w1, int n1, int Ns, int c, int w, int nw)
-{
-    const int m = n1 / R, tws = n1 / (Ns * R);
-    for (int j = w; j < m; j += nw) {
-        const int k = j % Ns;
-        float2 v[R];
-#pragma unroll
-        for (int t = 0; t < R; t++) {
-            v[t] = x[(j + t * m) * CW + c];
-            if (t && k) v[t] = cmul(v[t], w1[k * t * tws]);                  // k t tws < n1
-        }
-        td_dft_small<R>(v);
-        const int j0 = (j - k) * R + k;
-#pragma unroll
-        for (int u = 0; u < R; u++) y[(j0 + u * Ns) * CW + c] = v[u];
-    }
-}
-// any radix r (the prime factors of n1 beyond 2, 3, 5): every thread forms outputs, each as its r-term sum
-template <int CW>
-__device__ __forceinline__ void td_col_pass_any(const float2* x, float2* y, const float2* w1, int n1, int r, int Ns, int c, int w, int nw)
-{
-    const int m = n1 / r, tws = n1 / (Ns * r);
-    for (int e = w; e < n1; e += nw) {
-        const int j = e % m, u = e / m, k = j % Ns;
-        int step = k * tws + u * m;                                          // exponent per input t: twiddle w_{Ns r}^{k t} and w_r^{u t}
-        if (step >= n1) step -= n1;
-        int q = 0;
-        float2 acc = x[j * CW + c];
-        for (int t = 1; t < r; t++) {
-            q += step; if (q >= n1) q -= n1;
-            acc = cadd(acc, cmul(x[(j + t * m) * CW + c], w1[q]));
-        }
-        y[((j - k) * r + k + u * Ns) * CW + c] = acc;
-    }
-}
-// the whole n1-point forward transform of the tile in buf0; returns the buffer that holds the result
-template <int CW>
-__device__ __forceinline__ float2* td_col_transform(float2* buf0, float2* buf1, const float2* w1, const td_plan& pl, int c, int w, int nw)
-{
-    float2 *cur = buf0, *nxt = buf1;
-    int Ns = 1;
-    for (int p = 0; p < pl.nrad; p++) {
-        const int r = pl.rad[p];
-        if (r == 4) td_col_pass<4, CW>(cur, nxt, w1, pl.n1, Ns, c, w, nw);
-        else if (r == 2) td_col_pass<2, CW>(cur, nxt, w1, pl.n1, Ns, c, w, nw);
-        else if (r == 3) td_col_pass<3, CW>(cur, nxt, w1, pl.n1, Ns, c, w, nw);
-        else if (r == 5) td_col_pass<5, CW>(cur, nxt, w1, pl.n1, Ns, c, w, nw);
-        else td_col_pass_any<CW>(cur, nxt, w1, pl.n1, r, Ns, c, w, nw);
-        __syncthreads();
-        float2* t = cur; cur = nxt; nxt = t;
-        Ns *= r;
-    }
-    return cur;
-}
-
 // ---- column pass, forward:  x = in . doppler_z  as [n1][n2]  ->  n1-point DFT per column  ->  . w_n^{i2 k1}  ->  U[b][z][k1][i2] ------------
 template <int CW>
 __global__ __launch_bounds__(256) void td_col_fwd_kernel(td_srcs srcs, long in_stride,
@@ -942,64 +848,6 @@ __global__ __launch_bounds__(256) void td_rows_small_kernel(const float2* __rest
     }
 }
 
-// ---- the whole burst on chip: bursts short enough for (2 + R) x n cells of LDS — the 64-carrier flowgraphs' 2400-sample
-//      bursts (77 KB at two RX antennas) — go through ONE kernel, one workgroup per burst: per (simulator, target) pair the input . doppler is
-//      loaded, transformed as a single n-point mixed-radix Stockham transform in LDS (the column passes above with a tile one column wide, radices =
-//      the factors of n, twiddles from the context's n-entry table), multiplied by the pair's timeshift (and phase) into one LDS accumulator per RX
-//      antenna; then every antenna's sum goes through the inverse transform (conj, forward, conj) and out, with the self-coupling term and the
-//      accumulate option of the column pass.  One read of every input, R writes, nothing else touches HBM; 1 launch instead of 3.
-//      The timeshift table is the direct route's (row-pass order [k1][pos(k2)], n = n1 x n2): natural k = k1 + n1 k2 reads entry k1 n2 + pos(k2).
-//      Same algebra as the three passes, another factorisation: results agree with them to rounding, not bit for bit.
-//      Written in round 6 without a device: opt-in (JRC_TSIM_ONCHIP=1), never timed.
-__global__ __launch_bounds__(256) void td_onchip_kernel(td_srcs srcs, long in_stride, td_ts ts, long ts_l_stride, int V, int R,
-                                                        float2* __restrict__ out, long out_burst_stride, long out_rx_stride, td_self self,
-                                                        float self_coupling, int accumulate, const float2* __restrict__ wn, td_plan pl /* n1 = n: radices of n */,
-                                                        int d_n1, int d_n2 /* the direct route's split of n: order of the timeshift table */)
-{
-    extern __shared__ __attribute__((aligned(16))) float2 td_lds[];
-    const int n = pl.n1, tid = threadIdx.x;
-    float2* buf0 = td_lds;
-    float2* buf1 = buf0 + n;
-    float2* acc = buf1 + n;                                                  // [R][n]
-    const size_t b = blockIdx.x;
-    const int m = d_n2 > 256 ? d_n2 / 256 : 1;
-    for (int v = 0; v < V; v++) {
-        const float2* __restrict__ src = srcs.in[v] + b * (size_t)in_stride;
-        const float2* __restrict__ dz = srcs.dop[v];
-        for (int i = tid; i < n; i += 256) buf0[i] = cmul(src[i], dz[i]);    // volk_32fc_x2_multiply_32fc (:345)
-        __syncthreads();
-        const float2* X = td_col_transform<1>(buf0, buf1, wn, pl, 0, tid, 256);
-        for (int k = tid; k < n; k += 256) {
-            const int k1 = k % d_n1, k2 = k / d_n1;
-            const int pos = m > 1 ? (k2 % m) * 256 + k2 / m : k2;
-            float2 x = X[k];
-            if (ts.use_phase) x = cmul(x, ts.phase[v]);
-            const float2* __restrict__ tr = ts.tsp[v] + (size_t)k1 * d_n2 + pos;
-            for (int l = 0; l < R; l++) {
-                const float2 y = cmul(x, tr[(size_t)l * ts_l_stride]);
-                acc[(size_t)l * n + k] = v ? cadd(acc[(size_t)l * n + k], y) : y;
-            }
-        }
-        __syncthreads();
-    }
-    for (int l = 0; l < R; l++) {
-        for (int k = tid; k < n; k += 256) { const float2 a = acc[(size_t)l * n + k]; buf0[k] = make_float2(a.x, -a.y); }   // conjugated: the inverse runs on the forward passes
-        __syncthreads();
-        const float2* y = td_col_transform<1>(buf0, buf1, wn, pl, 0, tid, 256);
-        float2* o = out + b * (size_t)out_burst_stride + (size_t)l * out_rx_stride;
-        for (int i = tid; i < n; i += 256) {
-            float2 r = make_float2(y[i].x, -y[i].y);
-            if (accumulate) r = cadd(o[i], r);
-            for (int q = 0; q < self.n; q++) {                               // out += (gr_complex)pow(10, db/20) * in  (:376), per simulator
-                const float2 xi = self.in[q][b * (size_t)in_stride + i];
-                r = cadd(r, make_float2(self_coupling * xi.x - 0.0f * xi.y, self_coupling * xi.y + 0.0f * xi.x));
-            }
-            o[i] = r;
-        }
-        __syncthreads();                                                     // buf0 / buf1 are the next antenna's
-    }
-}
-
 // ---- host side -------------------------------------------------------------------------------
 static const double TS_FOUR_PI_CUBED_SQRT = 44.54662397465366;   // :33
 static const float TS_C_LIGHT = 3e8f;                           // target_simulator_impl.h c_light
@@ -1073,15 +921,6 @@ static void tsim_free_tables(jrc_tsim* h)
 }
 
 // n = n1 x n2 with n2 the largest power of two dividing n (<= 4096) and n1 <= TD_MAX_N1; the radices of the n1-point column transform
-// radices of an m-point column transform: 4s, a 2, then the odd prime factors in rising order (3 and 5 have butterflies of their own)
-static void td_factor(int m, td_plan* pl)
-{
-    pl->n1 = m; pl->n2 = 1; pl->nrad = 0;
-    while (m % 4 == 0) { pl->rad[pl->nrad++] = 4; m /= 4; }
-    if (m % 2 == 0) { pl->rad[pl->nrad++] = 2; m /= 2; }
-    for (int p = 3; m > 1; p += 2)
-        while (m % p == 0) { pl->rad[pl->nrad++] = p; m /= p; }
-}
 static size_t td_col_lds_bytes(int n1, int cw) { return sizeof(float2) * ((size_t)2 * n1 * cw + (size_t)n1); }
 // `pairs` = (simulator, target) pairs one launch of this simulator carries (K with sum_targets, else 1): the launches hold at most TD_MAXV
 // of them, a simulator with more keeps the chirp-z route, which takes any K.  `max_lds` = the device's LDS per workgroup: the column passes
@@ -1314,17 +1153,8 @@ static int tsim_run_direct(jrc_tsim* const* sims, int n_sims, int n_bursts, int 
     if (const char* e_on = getenv("JRC_TSIM_ONCHIP"); e_on && *e_on && *e_on != '0') {     // read per call, like JRC_TSIM_BLUESTEIN
         // the burst-on-chip kernel where (2 + R) x n cells fit a workgroup's LDS (opt-in, JRC_TSIM_ONCHIP=1: written without a device, never timed)
         const size_t lds_on = sizeof(float2) * (size_t)(2 + R) * n;
-        if (lds_on <= ctx->max_lds_per_block && n >= 2) {
-            td_plan pn;
-            td_factor(n, &pn);
-            const float2* wn = nullptr;
-            JRC_TRY(jrc_get_twiddles(ctx, n, -1, &wn));
-            JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)td_onchip_kernel, lds_on));
-            hipLaunchKernelGGL(td_onchip_kernel, dim3((unsigned)n_bursts), dim3(256), lds_on, s, srcs, (long)n, ts, ts_l_stride, V, R, (float2*)d_out,
-                               (long)R * n, (long)n, self, sc, accumulate_out ? 1 : 0, wn, pn, n1, n2);
-            JRC_HIP(ctx, hipGetLastError());
-            return JRC_OK;
-        }
+        if (lds_on <= ctx->max_lds_per_block && n >= 2)
+            return td_onchip_launch(ctx, s, srcs, ts, ts_l_stride, self, V, R, n, n1, n2, n_bursts, (float2*)d_out, sc, accumulate_out ? 1 : 0);
     }
     const float2* tw256 = nullptr;
     JRC_TRY(jrc_get_twiddles(ctx, TS_N1, -1, &tw256));
@@ -1532,13 +1362,6 @@ extern "C" int jrc_tsim_burst_capacity(const jrc_tsim* h) { return h ? h->max_bu
 // ---- zero_pad (lib/zero_pad_impl.cc:62-94): out = [pad_front noise | in | pad_tail noise], noise ~ N(0, 1e-2) per component.
 // The reference draws from std::random_device every call; here a counter-based generator (splitmix64 -> Box-Muller) keyed by
 // (seed, burst, sample) makes the padding reproducible. ------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x)
-{
-    x += 0x9E3779B97F4A7C15ull;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    return x ^ (x >> 31);
-}
 __global__ void zero_pad_kernel(const float2* __restrict__ in, float2* __restrict__ out, int n_in, int pad_front, int pad_tail,
                                 unsigned long long seed, float sigma, long in_stride, long out_stride)
 {
@@ -1573,97 +1396,6 @@ extern "C" int jrc_zero_pad_strided_dev(jrc_ctx* ctx, int n_bursts, int n_input,
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     hipLaunchKernelGGL(zero_pad_kernel, dim3((unsigned)((n_out + 255) / 256), n_bursts), dim3(256), 0, s, (const float2*)d_in, (float2*)d_out,
                        n_input, (int)pad_front, (int)pad_tail, (unsigned long long)seed, 1e-2f, in_stride, out_stride);
-    JRC_HIP(ctx, hipGetLastError());
-    return (int)n_out;
-}
-
-// ---- OFDM modulator + zero_pad as ONE kernel: the fft_vxx(reverse, shift, window) -> ofdm_cyclic_prefixer -> zero_pad chain behind
-// every TX port of the simulation flowgraph (examples/simulation/radar/mimo_ofdm_jrc_radar_sim.grc:801-897, :2184-2188; lib/zero_pad_impl.cc:76-90)
-// writes, block by block, the time-domain packet [F][T][n_sym (N + cp)] to HBM, reads it again and writes the padded burst; here symbol
-// (f, t, k) of the precoder's output goes through the SAME Stockham passes as jrc_ofdm_mod_dev (fft_stockham_kernel: bit-identical samples) and
-// lands at bursts[t][f][pad_front + k (N + cp)] directly, and the workgroups that hold a burst's first / last symbol write its pad noise with the
-// generator of zero_pad_kernel (same key: seed of the port, burst, sample -> bit-identical padding).  One launch instead of 1 + T, the unpadded
-// time-domain packet never exists.
-__global__ __launch_bounds__(256) void ofdm_mod_burst_kernel(const float2* __restrict__ in, float2* __restrict__ out, const float2* __restrict__ tw,
-                                                             const float* __restrict__ window, int n, int logn, size_t batch, int tp,
-                                                             int n_ports, int n_sym, int cp, int pad_front, int pad_tail,
-                                                             unsigned long long seed, unsigned long long seed_port_step, float sigma,
-                                                             long out_port_stride, long out_burst_stride)
-{
-    extern __shared__ __attribute__((aligned(16))) float2 lds[];
-    const int per_block = blockDim.x / tp;
-    const int lt = threadIdx.x % tp, lb = threadIdx.x / tp;
-    const size_t b = (size_t)blockIdx.x * per_block + lb;
-    const bool live = b < batch;
-    float2* buf0 = lds + (size_t)lb * 2 * n;
-    float2* buf1 = buf0 + n;
-    const size_t f = b / ((size_t)n_ports * n_sym);
-    const int t = (int)((b / n_sym) % n_ports), k = (int)(b % n_sym);
-    const float2* src_g = in + b * (size_t)n;
-    float2* burst = out + (size_t)t * out_port_stride + f * (size_t)out_burst_stride;
-    float2* dst_g = burst + pad_front + (size_t)k * (n + cp) + cp;
-
-    int Ns = 1;
-    const float2* cur = nullptr;                  // nullptr = still in global memory
-    float2* nxt = buf0;
-    bool first = true;
-    while (Ns < n) {                              // the passes of fft_stockham_kernel with forward = 0, shift = 1, a cyclic prefix to prepend
-        const int R = ((logn & 1) && first) ? 2 : 4;
-        if (live) {
-            if (R == 2) stockham_pass<2>(first ? src_g : nullptr, n, first ? window : nullptr, cur, nxt, nullptr, 0, tw, n, Ns, 1, lt, tp);
-            else stockham_pass<4>(first ? src_g : nullptr, n, first ? window : nullptr, cur, nxt, nullptr, 0, tw, n, Ns, 1, lt, tp);
-        }
-        __syncthreads();
-        cur = nxt; nxt = (nxt == buf0) ? buf1 : buf0;
-        Ns *= R; first = false;
-    }
-    if (!live) return;
-    for (int pos = lt; pos < n; pos += tp) dst_g[pos] = cur[pos];
-    for (int jj = lt; jj < cp; jj += tp) dst_g[jj - cp] = cur[n - cp + jj];
-    // pad noise of burst (t, f): the front by the transform of its first symbol, the tail by that of its last
-    const unsigned long long port_seed = seed + seed_port_step * (unsigned long long)t;
-    const int n_in = n_sym * (n + cp);
-    auto noise = [&](int i) {
-        const unsigned long long r = splitmix64(port_seed ^ splitmix64(((unsigned long long)f << 32) | (unsigned)i));
-        const float u1 = ((float)(unsigned)(r >> 40) + 1.0f) * (1.0f / 16777216.0f);          // (0, 1]
-        const float u2 = (float)(unsigned)((r >> 8) & 0xffffffu) * (1.0f / 16777216.0f);     // [0, 1)
-        const float rad = sigma * sqrtf(-2.0f * logf(u1));
-        float sn, cs;
-        sincospif(2.0f * u2, &sn, &cs);
-        burst[i] = make_float2(rad * cs, rad * sn);
-    };
-    if (k == 0) for (int i = lt; i < pad_front; i += tp) noise(i);
-    if (k == n_sym - 1) for (int i = pad_front + n_in + lt; i < pad_front + n_in + pad_tail; i += tp) noise(i);
-}
-
-extern "C" int jrc_ofdm_mod_pad_dev(jrc_ctx* ctx, int fft_len, int cp_len, const float* d_window, int n_frames, int n_ports, int n_symbols,
-                                    unsigned pad_front, unsigned pad_tail, uint64_t seed, uint64_t seed_port_step,
-                                    const jrc_cf32* d_in, jrc_cf32* d_out, long out_port_stride, long out_burst_stride, void* stream)
-{
-    JRC_TRACE("jrc_ofdm_mod_pad_dev");
-    if (!ctx || n_frames < 0 || n_ports < 1 || n_symbols < 1) return JRC_ERR_INVALID_ARG;
-    if (cp_len < 0 || cp_len > fft_len) return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "ofdm_mod_pad: bad cp_len");
-    if (!jrc_is_pow2(fft_len) || fft_len < 4 || fft_len > 8192)
-        return jrc_fail(ctx, JRC_ERR_UNSUPPORTED, "ofdm_mod_pad: fft_len %d is not a power of two in [4, 8192] (use jrc_ofdm_mod_dev + jrc_zero_pad_strided_dev)", fft_len);
-    const long n_out = (long)n_symbols * (fft_len + cp_len) + pad_front + pad_tail;
-    if (n_frames == 0) return (int)n_out;
-    if (!d_in || !d_out) return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "ofdm_mod_pad: null buffers");
-    if (out_burst_stride < n_out || (n_ports > 1 && out_port_stride < out_burst_stride * (long)n_frames))
-        return jrc_fail(ctx, JRC_ERR_INVALID_ARG, "ofdm_mod_pad: output strides shorter than the bursts they hold");
-    JRC_BIND(ctx);
-    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-    const int n = fft_len;
-    const float2* tw = nullptr;
-    JRC_TRY(jrc_get_twiddles(ctx, n, +1, &tw));
-    int tp = n / 4; if (tp > 256) tp = 256; if (tp < 1) tp = 1;                 // the geometry of launch_fft_vcc_ex's Stockham branch
-    const int per_block = 256 / tp;
-    const size_t batch = (size_t)n_frames * n_ports * n_symbols;
-    const size_t blocks = (batch + per_block - 1) / per_block;
-    const size_t lds_bytes = sizeof(float2) * 2 * (size_t)n * per_block;
-    JRC_TRY(jrc_ensure_dyn_lds(ctx, (const void*)ofdm_mod_burst_kernel, lds_bytes));
-    hipLaunchKernelGGL(ofdm_mod_burst_kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, s, (const float2*)d_in, (float2*)d_out, tw, d_window, n,
-                       jrc_ilog2(n), batch, tp, n_ports, n_symbols, cp_len, (int)pad_front, (int)pad_tail, (unsigned long long)seed,
-                       (unsigned long long)seed_port_step, 1e-2f, out_port_stride, out_burst_stride);
     JRC_HIP(ctx, hipGetLastError());
     return (int)n_out;
 }

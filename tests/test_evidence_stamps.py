@@ -69,6 +69,20 @@ def test_stamped_emulated_suite_record_matches_this_tree():
         "%s was stamped at kernel sources %s, the tree is at %s: re-run tools/emulated_suite.sh" % (os.path.basename(recs[-1]), d["source_hash"], jb.source_hash())
 
 
+def test_device_code_record_says_round5s_kernels_are_unchanged_and_is_of_this_tree():
+    """profiles/r06_device_code_vs_r05.json (tools/device_code_diff.py 02f2fef WORKTREE): every kernel file round 5 ended on compiles to byte-identical
+    DEVICE code in this tree — the defaults launch round 5's machine code, whose GPU runs stand — and the only file with new device code is
+    onchip.hip (opt-in kernels); the record is of THIS tree's kernel sources"""
+    p = os.path.join(PROFILES, "r06_device_code_vs_r05.json")
+    if not os.path.exists(p):
+        pytest.skip("no device-code record")
+    from jrc_amd import build as jb
+    d = json.load(open(p))
+    assert d["differs"] == ["onchip.hip"] and d["hashes_a"]["onchip.hip"] == "absent"
+    assert set(d["identical_device_code"]) == {"chain.hip", "codec.hip", "comm.hip", "ctx.hip", "estimator.hip", "feed.hip", "fft.hip", "radar.hip", "sync.hip", "tsim.hip"}
+    assert d["source_hash_of_worktree"] == jb.source_hash(), "kernel sources changed since the record was taken: re-run tools/device_code_diff.py 02f2fef WORKTREE profiles/r06_device_code_vs_r05.json"
+
+
 def test_stamp_suite_parses_a_verbose_log():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import stamp_suite

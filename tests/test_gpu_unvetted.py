@@ -109,7 +109,7 @@ def test_device_resident_flowgraph_with_the_fused_modulator_equals_the_default_l
         assert recs[0] == recs[1]
 
 
-# ---- target simulator: the whole burst on chip (JRC_TSIM_ONCHIP=1, tsim.hip td_onchip_kernel) -----------------------------------------------------------
+# ---- target simulator: the whole burst on chip (JRC_TSIM_ONCHIP=1, onchip.hip td_onchip_kernel) -----------------------------------------------------------
 FS, FC = 125_000_000, 24e9
 POS4 = [0.0, 0.00625, 0.0125, 0.01875]
 TGT3 = ([10.0, 23.5, 41.0], [0.0, 12.0, -30.0], [100.0, 10.0, 31.0], [20.0, -35.0, 5.0])
