@@ -370,6 +370,15 @@ def pmc_traffic(cfg, frames_per_launch):
         if not pt or pt.get("frames_per_launch") != frames_per_launch:
             return None, False
         if d.get("source_hash") != jb.source_hash():
+            # measured at other kernel SOURCES.  It still describes this tree's kernel if the DEVICE CODE of the files the chain's kernels live in is
+            # byte-identical between the tree it was measured at and this one: profiles/rNN_device_code_vs_*.json (tools/device_code_diff.py — both trees
+            # compiled with the library's flags and --offload-device-only, outputs compared byte for byte), itself stamped with both source hashes
+            import glob
+            for rec in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_device_code_vs_*.json")), reverse=True):
+                dc = json.load(open(rec))
+                if (dc.get("source_hash_a") == d.get("source_hash") and dc.get("source_hash_b") == jb.source_hash()
+                        and all(f in dc.get("identical_device_code", []) for f in ("chain.hip", "radar.hip", "estimator.hip"))):
+                    return pt["hbm_bytes_per_launch"], False
             return None, True
         return pt["hbm_bytes_per_launch"], False
     except (OSError, ValueError, KeyError):

@@ -28,16 +28,18 @@ HIPCC_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", 
 EXTRA_FLAGS = {"chain.hip": ["-fno-slp-vectorize"], "radar.hip": ["-fno-slp-vectorize"]}
 
 
-def source_hash():
+def source_hash(csrc=None, jrc_h=None):
     """hash of everything the device code is built from (kernel sources, headers, compiler flags): profiles/pmc_traffic.json is
-    stamped with it, and bench.py drops `roofline.traffic` when the stamp is not the hash of the tree it runs in"""
+    stamped with it, and bench.py drops `roofline.traffic` when the stamp is not the hash of the tree it runs in.
+    (csrc / jrc_h: the same hash of another checkout's sources — tools/device_code_diff.py)"""
     import hashlib
+    csrc = csrc or CSRC
     h = hashlib.sha256()
-    names = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    names = sorted(f for f in os.listdir(csrc) if f.endswith((".hip", ".h")))
     for n in names:
         h.update(n.encode())
-        h.update(open(os.path.join(CSRC, n), "rb").read())
-    h.update(open(os.path.join(HERE, "..", "include", "jrc.h"), "rb").read())
+        h.update(open(os.path.join(csrc, n), "rb").read())
+    h.update(open(jrc_h or os.path.join(HERE, "..", "include", "jrc.h"), "rb").read())
     h.update(repr((HIPCC_FLAGS, sorted(EXTRA_FLAGS.items()))).encode())
     return h.hexdigest()[:16]
 

@@ -115,6 +115,28 @@ def test_contract_line_stays_short_and_parses():
     assert json.loads(bench.compact_line(bad))["secondary"]["x"]["value"] is None
 
 
+def test_traffic_of_another_tree_counts_only_with_identical_device_code(tmp_path, monkeypatch):
+    """bench.pmc_traffic: the PMC figure of profiles/pmc_traffic.json was measured at round 5's kernel sources; this tree's sources differ (markers, host code)
+    but profiles/r06_device_code_vs_r05.json shows chain / radar / estimator compiling to byte-identical device code, stamped with both trees' hashes:
+    the figure is reported.  With the record's hashes not matching (another tree, a file that differs) it is withheld and flagged stale."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from jrc_amd import build as jb
+    rec_path = os.path.join(ROOT, "profiles", "r06_device_code_vs_r05.json")
+    if not os.path.exists(rec_path):
+        pytest.skip("no device-code record")
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    rec = json.load(open(rec_path))
+    if rec.get("source_hash_b") != jb.source_hash() or rec.get("source_hash_a") != pmc["source_hash"]:
+        pytest.skip("the record is not of this pair of trees (test_evidence_stamps.py says so loudly)")
+    got, stale = bench.pmc_traffic("B", pmc["B"]["frames_per_launch"])
+    assert got == pmc["B"]["hbm_bytes_per_launch"] and not stale
+    # a tree with other kernel sources and no record for it: withheld
+    monkeypatch.setattr(jb, "source_hash", lambda *a, **k: "0000000000000000")
+    got, stale = bench.pmc_traffic("B", pmc["B"]["frames_per_launch"])
+    assert got is None and stale
+
+
 def test_self_launch_is_bounded(tmp_path):
     """bench.py's launcher must not wait for its ranks for ever: with ranks that never finish (a stand-in script that
     sleeps) the launcher kills the children it started and exits 124 within --launch-timeout"""

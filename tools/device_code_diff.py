@@ -46,7 +46,9 @@ def device_hashes(rev, scratch):
             return f, "compile failed: " + r.stderr[-300:]
         return f, hashlib.sha256(open(out, "rb").read()).hexdigest()[:16]
     with ThreadPoolExecutor(max_workers=4) as ex:
-        return dict(ex.map(one, files))
+        out = dict(ex.map(one, files))
+    out["__source_hash__"] = jb.source_hash(csrc, os.path.join(scratch, "include", "jrc.h"))
+    return out
 
 
 def main():
@@ -55,6 +57,7 @@ def main():
     scratch = os.path.join(tempfile.gettempdir(), "jrc_device_code_diff")
     ha = device_hashes(a, scratch)
     hb = device_hashes(b, scratch)
+    sha, shb = ha.pop("__source_hash__"), hb.pop("__source_hash__")
     same, differ = [], []
     for f in sorted(set(ha) | set(hb)):
         x, y = ha.get(f, "absent"), hb.get(f, "absent")
@@ -63,6 +66,7 @@ def main():
     from jrc_amd import build as jb
     rec = {"a": a, "b": b, "identical_device_code": same, "differs": differ, "hashes_a": ha, "hashes_b": hb,
            "flags": "build.HIPCC_FLAGS + EXTRA_FLAGS + --offload-device-only", "compiler": subprocess.run([jb.hipcc(), "--version"], capture_output=True, text=True).stdout.splitlines()[0]}
+    rec["source_hash_a"], rec["source_hash_b"] = sha, shb
     if b == "WORKTREE":
         rec["source_hash_of_worktree"] = jb.source_hash()
     print(json.dumps(rec))
