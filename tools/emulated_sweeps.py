@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Exhaustive small-case sweeps that only make sense without launch latency: run with JRC_EMULATE=1 (the kernels on the CPU emulation, tests/hipcpu).
+Every fft_vcc size 1..700 (+ the sizes around powers of two up to 4096) in all four direction / shift combinations against numpy; every
+matrix_transpose shape up to 24 x 24 x interp 1..3 against the oracle; every (fft_len, cp_len) of the prefix remover up to 40 / 12.
+Prints one line per sweep; exit status 1 if anything disagrees."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+assert os.environ.get("JRC_EMULATE"), "run with JRC_EMULATE=1"
+import conftest  # noqa: F401,E402  (points the package at the emulated library)
+import numpy as np  # noqa: E402
+
+import jrc_amd as jrc  # noqa: E402
+import oracle  # noqa: E402
+
+
+def main():
+    ctx = jrc.Context(0)
+    rng = np.random.default_rng(2026)
+    bad = 0
+    sizes = list(range(1, 701)) + [n + d for n in (1024, 2048, 4096) for d in (-3, -1, 0, 1) if 1 <= n + d <= 4096] + [1536, 3000, 3072, 4095]
+    worst = 0.0
+    for n in sizes:
+        for fwd in (True, False):
+            for shift in (False, True):
+                b = 1 + (n % 3)
+                x = (rng.standard_normal((b, n)) + 1j * rng.standard_normal((b, n))).astype(np.complex64)
+                w = None if n % 5 else (0.5 + rng.random(n)).astype(np.float32)
+                got = jrc.fft_vcc(n, fwd, window=w, shift=shift, ctx=ctx).work(x)
+                xin = x.astype(np.complex128)
+                if w is not None:
+                    xin = xin * w
+                if fwd:
+                    ref = np.fft.fft(xin, axis=-1)
+                    if shift:
+                        ref = np.fft.fftshift(ref, axes=-1)
+                else:
+                    if shift:
+                        xin = np.fft.ifftshift(xin, axes=-1)
+                    ref = np.fft.ifft(xin, axis=-1) * n
+                err = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)
+                worst = max(worst, err)
+                if not err < 1e-4:                      # north_star tolerance; the tests hold the stages to 5e-6 on their own shapes
+                    bad += 1
+                    print("fft_vcc n=%d forward=%s shift=%s: %g" % (n, fwd, shift, err))
+    print("fft_vcc: %d sizes x 4 forms, worst relative error %.3g, %d outside 1e-4" % (len(sizes), worst, bad))
+    nbad = 0
+    cases = 0
+    for P in range(1, 25):
+        for L in list(range(1, 25)) + [64, 100]:
+            for interp in (1, 2, 3):
+                x = (rng.standard_normal((P, L)) + 1j * rng.standard_normal((P, L))).astype(np.complex64)
+                got = jrc.matrix_transpose(L, P, interp, ctx=ctx).work(x)
+                want = oracle.matrix_transpose(x, L, P, interp)
+                cases += 1
+                if got.shape != want.shape or not np.array_equal(got, want):
+                    nbad += 1
+                    print("matrix_transpose P=%d L=%d interp=%d differs" % (P, L, interp))
+    print("matrix_transpose: %d shapes, %d differ" % (cases, nbad))
+    bad += nbad
+    nbad = cases = 0
+    for N in range(1, 41):
+        for cp in range(0, min(N, 12) + 1):
+            for k in (1, 2, 5):
+                x = (rng.standard_normal(k * (N + cp) + (N % 3)) + 0j).astype(np.complex64)     # a ragged tail the block must not read as a symbol
+                got = jrc.ofdm_cyclic_prefix_remover(N, cp, ctx=ctx).work(x)
+                want = oracle.cp_remove(x, N, cp)
+                cases += 1
+                if got.shape != want.shape or not np.array_equal(got, want):
+                    nbad += 1
+                    print("cp_remove N=%d cp=%d k=%d differs" % (N, cp, k))
+    print("ofdm_cyclic_prefix_remover: %d shapes, %d differ" % (cases, nbad))
+    bad += nbad
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
