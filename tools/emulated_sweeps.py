@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Exhaustive small-case sweeps that only make sense without launch latency: run with JRC_EMULATE=1 (the kernels on the CPU emulation, tests/hipcpu).
 Every fft_vcc size 1..700 (+ the sizes around powers of two up to 4096) in all four direction / shift combinations against numpy; every
-matrix_transpose shape up to 24 x 24 x interp 1..3 against the oracle; every (fft_len, cp_len) of the prefix remover up to 40 / 12.
+matrix_transpose shape up to 24 x 24 x interp 1..3 against the oracle; every (fft_len, cp_len) of the prefix remover up to 40 / 12; the estimator's
+peak in every angle bin x 7 range rows x 3 discard settings (records byte for byte); fft_peak_detect's peak at every bin x 3 thresholds.
 Prints one line per sweep; exit status 1 if anything disagrees."""
 import os
 import sys
@@ -73,6 +74,39 @@ def main():
                     nbad += 1
                     print("cp_remove N=%d cp=%d k=%d differs" % (N, cp, k))
     print("ofdm_cyclic_prefix_remover: %d shapes, %d differ" % (cases, nbad))
+    bad += nbad
+    # range_angle_estimator: the peak in every angle bin x a set of range rows (window wrap on both axes), three discard settings, records byte for byte
+    import ctypes
+    rb, ab = jrc.radar_axes(64, 125e6, 8, 8, 16)
+    nbad = cases = 0
+    base = (0.05 * (rng.standard_normal((512, 128)) + 1j * rng.standard_normal((512, 128)))).astype(np.complex64)
+    for ndr, nda in ((2.4, 28.96), (9.0, 14.0), (0.3, 60.0)):
+        est = jrc.range_angle_estimator(128, rb, ab, ndr, nda, 15.0, 0.0, ctx=ctx)
+        for row in (0, 1, 255, 256, 257, 510, 511):
+            for col in range(128):
+                m = base.copy()
+                m[row, col] = 3.0 + 0.5j
+                g = est.work(m)
+                o = oracle.ra_estimate(m, rb, ab, ndr, nda, 15.0, 0.0)
+                cases += 1
+                if ctypes.string_at(ctypes.byref(g), ctypes.sizeof(g)) != ctypes.string_at(ctypes.byref(o), ctypes.sizeof(o)):
+                    nbad += 1
+                    if nbad < 10:
+                        print("range_angle_estimator row=%d col=%d discard=(%g, %g) differs" % (row, col, ndr, nda))
+    print("range_angle_estimator: %d maps (every angle bin x 7 range rows x 3 discard settings), %d records differ" % (cases, nbad))
+    bad += nbad
+    # fft_peak_detect: the peak at every position of a 257-bin spectrum (both halves of the frequency formula, the protected edges), three thresholds
+    nbad = cases = 0
+    for thr in (-20.0, 3.0, 40.0):
+        det = jrc.fft_peak_detect(1000000, 4.0, thr, 5, ctx=ctx)
+        for pk in range(257):
+            x = (0.01 * (rng.standard_normal(257) + 1j * rng.standard_normal(257))).astype(np.complex64)
+            x[pk] = 2 * np.exp(0.3j * pk)
+            cases += 1
+            if not np.array_equal(np.array(det.work(x), np.float64), np.array(oracle.fft_peak_detect(x, 1000000, 4.0, thr, 5), np.float64), equal_nan=True):     # nothing over the threshold: (-1, nan, nan, nan) on both sides
+                nbad += 1
+                print("fft_peak_detect peak at %d thr %g differs" % (pk, thr))
+    print("fft_peak_detect: %d spectra, %d differ" % (cases, nbad))
     bad += nbad
     return 1 if bad else 0
 
