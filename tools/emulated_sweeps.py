@@ -108,6 +108,29 @@ def main():
                 print("fft_peak_detect peak at %d thr %g differs" % (pk, thr))
     print("fft_peak_detect: %d spectra, %d differ" % (cases, nbad))
     bad += nbad
+    # stream_encoder / stream_decoder: every PDU length 1..160 at every MCS — symbols bit-exact against the oracle, decoded bytes and CRC verdict back
+    nbad = cases = lost = 0
+    for mcs in range(6):
+        enc = jrc.stream_encoder(mcs, 48, ctx=ctx)
+        dec = jrc.stream_decoder(48, ctx=ctx)
+        for nbytes in range(1, 161):
+            pdu = bytes([2]) + rng.integers(0, 256, nbytes - 1, dtype=np.uint8).tobytes()
+            seed = enc.d_scrambler
+            got, tags = enc.work(pdu)
+            want, wtags = oracle.stream_encode(mcs, 48, pdu, seed)
+            ok = np.array_equal(got, want) and tags == wtags
+            # the decoder against the ORACLE's decoder on the same clean symbols (not against "must decode": the reference's windowed Viterbi loses
+            # some clean frames — BPSK 3/4 at 6 and 42 bytes, about one payload in seven — and the device must lose exactly those)
+            d = dec.work(got, dict(mcs=mcs, data_bytes=tags["pdu_len"], packet_type=2, snr=20.0))
+            o = oracle.stream_decode(mcs, 48, tags["pdu_len"], want)
+            ok = ok and d == o
+            lost += d != (True, pdu)
+            cases += 1
+            if not ok:
+                nbad += 1
+                print("codec mcs=%d nbytes=%d differs" % (mcs, nbytes))
+    print("stream_encoder -> stream_decoder: %d (MCS, PDU length) pairs, %d differ from the oracle (%d clean frames lost by both decoders alike)" % (cases, nbad, lost))
+    bad += nbad
     return 1 if bad else 0
 
 
