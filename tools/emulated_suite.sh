@@ -18,8 +18,9 @@ RC4=$?
 HIPCPU_SCHEDULE=shuffle:2026 python3 -m pytest tests -m gpu -v -n $NW --timeout 1800 -p no:cacheprovider > gpurun_out/${TAG}_emulated_shuffle.log 2>&1
 RC5=$?
 if [ "$HEAVY" = heavy ]; then
-  # the shapes the default pass leaves out (bench batches, 10^6-sample streams): fewer workers, they are large
-  JRC_EMULATE_HEAVY=1 python3 -m pytest tests -m gpu -v -n 3 --timeout 3600 -p no:cacheprovider \
+  # the shapes the default pass leaves out (bench batches, 10^6-sample streams): two workers only — the config-D batch tests hold up to 35 GB each
+  # ("device" memory is host memory here), and a third worker ran this machine (62 GB) out of memory once
+  JRC_EMULATE_HEAVY=1 python3 -m pytest tests -m gpu -v -n 2 --timeout 5400 -p no:cacheprovider \
     -k "benchmarked or long_bursts or 1048576 or million_samples or B-1100 or B-300 or B-700 or D-256 or B-512 or 600] or baseline_batch or test_wide_kernel_batches or config_d_eight" \
     > gpurun_out/${TAG}_emulated_heavy.log 2>&1
   RC2=$?
