@@ -1,8 +1,9 @@
 """Builds the CPU EMULATION of libjrc_hip.so (test infrastructure; see include/hip/hip_runtime.h): the library's own kernel sources,
 gr-mimo-ofdm-jrc_amd/csrc/*.hip, compiled for the host with clang++ against the emulation header and linked with hipcpu_runtime.cc into
-tests/hipcpu/_build/libjrc_hipcpu.so.  Two textual rewrites are applied to a COPY of each source (the tracked files are not touched):
+tests/hipcpu/_build/libjrc_hipcpu.so.  Three textual rewrites are applied to a COPY of each source (the tracked files are not touched):
   * `extern __shared__ T name[];`          ->  `T* const name = (T*)::hipcpu::dyn_lds();`   (dynamic LDS of the running workgroup)
   * `asm volatile("s_sleep ..." / "s_waitcnt ..." / "")`  ->  `((void)0)`                     (scheduling hints, no data effect)
+  * `__shared__ T x[N];`  gets `::hipcpu::poison_static_lds(&x, sizeof(x));` appended       (LDS is garbage at workgroup start, not zero)
 Nothing under gr-mimo-ofdm-jrc_amd/ knows this exists; the tests load it by path (JRC_LIB_PATH) in their own processes."""
 import concurrent.futures
 import fcntl
@@ -24,9 +25,54 @@ _DYN = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)
 _ASM = re.compile(r"asm\s+volatile\s*\(\s*\"[^\"]*\"\s*(?::[^;]*?)?\)\s*;")
 
 
+_STATIC_LDS = re.compile(r"^(\s*)__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?(.*?);(.*)$")
+_BASE_TYPE_WORDS = {"unsigned", "signed", "char", "short", "int", "long", "float", "double", "const", "volatile"}
+
+
+def _static_lds_names(decl):
+    """names declared by `TYPE a[..][..], b, c[..]` (the text between `__shared__ [aligned]` and `;`)"""
+    toks = decl.split()
+    i = 0
+    while i < len(toks) and toks[i] in _BASE_TYPE_WORDS:
+        i += 1
+    if i == 0:
+        i = 1                                   # a single type name (float2, EqState, ...)
+    rest = " ".join(toks[i:])
+    names, depth, cur = [], 0, ""
+    for ch in rest + ",":
+        if ch == "[":
+            depth += 1
+        elif ch == "]":
+            depth -= 1
+        if ch == "," and depth == 0:
+            m = re.match(r"\s*\*?\s*(\w+)", cur)
+            if m:
+                names.append(m.group(1))
+            cur = ""
+        else:
+            cur += ch
+    return names
+
+
+def _poison_static_lds(line):
+    """LDS is not zeroed between workgroups on the device; a function-local static would be zero at first use and hold the previous workgroup's
+    contents afterwards.  Every static `__shared__` declaration is followed (on the same line) by a call that fills it with 0xFF bytes — NaN as a
+    float, -1 as an int — once per workgroup, by whichever work-item comes first, so that a kernel reading LDS it never wrote shows."""
+    m = _STATIC_LDS.match(line)
+    if not m or "extern" in line:
+        return line
+    names = _static_lds_names(m.group(2))
+    if not names:
+        return line
+    return "%s__shared__ %s; %s%s" % (m.group(1), line[line.index("__shared__") + len("__shared__"):line.index(";")].strip(),
+                                     " ".join("::hipcpu::poison_static_lds(&%s, sizeof(%s));" % (n, n) for n in names), m.group(3))
+
+
 def rewrite(text):
     text = _DYN.sub(lambda m: "%s* const %s = (%s*)::hipcpu::dyn_lds();" % (m.group(1), m.group(2), m.group(1)), text)
     text = _ASM.sub("((void)0);", text)
+    if os.environ.get("HIPCPU_NO_LDS_POISON", "") in ("", "0"):
+        text = "\n".join(_poison_static_lds(l) for l in text.split("\n"))
     return text
 
 

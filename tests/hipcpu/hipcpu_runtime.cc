@@ -68,6 +68,7 @@ struct Worker {
     void* dyn = nullptr;
     size_t dyn_cap = 0;
     bool in_kernel = false;
+    std::vector<void*> poisoned;            // static __shared__ objects already filled for the running workgroup
     const void* sched_stack = nullptr;      // (ASan) the scheduler's own stack, learnt at the first switch into a fiber
     size_t sched_stack_size = 0;
     ~Worker()
@@ -147,6 +148,12 @@ static inline void yield_to_scheduler()
 
 int lane_id() { return W.cur->lane; }
 void* dyn_lds() { return W.dyn; }
+void poison_static_lds(void* p, size_t bytes)
+{
+    for (void* q : W.poisoned) if (q == p) return;
+    W.poisoned.push_back(p);
+    memset(p, 0xFF, bytes);
+}
 long long wall_clock()
 {
     using namespace std::chrono;
@@ -352,7 +359,8 @@ static void run_kernel(dim3 grid, dim3 block, size_t dyn, const std::function<vo
         for (unsigned by = 0; by < grid.y; by++)
             for (unsigned bx = 0; bx < grid.x; bx++) {
                 t_blockIdx = uint3{bx, by, bz};
-                if (dyn) memset(W.dyn, 0xA5, dyn);                // LDS is not zeroed between workgroups: poison it
+                if (dyn) memset(W.dyn, 0xFF, dyn);                // LDS is not zeroed between workgroups: poison it (NaN as a float, -1 as an int)
+                W.poisoned.clear();
                 run_block(body, block);
                 g_stats.blocks++;
             }

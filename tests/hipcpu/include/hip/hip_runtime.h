@@ -124,6 +124,7 @@ template <class F> static inline hipError_t hipFuncSetAttribute(F* f, hipFuncAtt
 namespace hipcpu {
 void launch_closure(dim3 grid, dim3 block, size_t dyn_lds, hipStream_t s, std::function<void()> body, const char* name, const void* kernel);
 void* dyn_lds();                       // the dynamic LDS of the running workgroup (16-byte aligned)
+void poison_static_lds(void* p, size_t bytes);   // fills a static __shared__ object with 0xFF once per workgroup (first work-item to reach its declaration)
 // the arguments are converted to the kernel's parameter types when the launch is made (what hipLaunchKernelGGL does), not when a captured graph replays
 template <class... KArgs, class... Args>
 static inline void launch(const char* name, void (*k)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t s, Args&&... args)

@@ -74,11 +74,12 @@ def test_emulation_semantics_selftest(tmp_path):
 
 
 def test_the_emulated_sources_are_the_tracked_sources():
-    """what the emulation compiles is each tracked .hip with exactly two kinds of line rewritten — `extern __shared__ T x[];` (the running workgroup's
-    dynamic LDS) and `asm volatile("s_sleep" / "s_waitcnt" / "")` (scheduling hints without a data effect) — and nothing else"""
+    """what the emulation compiles is each tracked .hip with exactly three kinds of line rewritten — `extern __shared__ T x[];` (the running workgroup's
+    dynamic LDS), `asm volatile("s_sleep" / "s_waitcnt" / "")` (scheduling hints without a data effect) and static `__shared__` declarations, which get a
+    call appended that fills the object with 0xFF once per workgroup (LDS is garbage at workgroup start on the device, not zero) — and nothing else"""
     from hipcpu import build as eb
     csrc = os.path.join(ROOT, "gr-mimo-ofdm-jrc_amd", "csrc")
-    n_dyn = n_asm = 0
+    n_dyn = n_asm = n_static = 0
     for f in sorted(os.listdir(csrc)):
         if not f.endswith(".hip"):
             continue
@@ -88,14 +89,24 @@ def test_the_emulated_sources_are_the_tracked_sources():
         for x, y in zip(a, b):
             if x == y:
                 continue
-            if "extern __shared__" in x:
+            if "__shared__" in x and "extern" not in x:
+                head, _, tail = y.partition("; ::hipcpu::poison_static_lds(")
+                assert tail and x.startswith(head.rstrip()) or head.split() == x[:x.index(";")].split(), (f, x, y)
+                rest = y
+                while "::hipcpu::poison_static_lds(" in rest:
+                    i = rest.index("::hipcpu::poison_static_lds(")
+                    j = rest.index(");", i) + 2
+                    rest = rest[:i] + rest[j:]
+                assert rest.split() == x.split(), (f, x, y)          # the declaration and its comment are untouched
+                n_static += 1
+            elif "extern __shared__" in x:
                 assert "::hipcpu::dyn_lds()" in y and "extern" not in y, (f, x, y)
                 n_dyn += 1
             else:
                 assert "asm volatile" in x and "asm" not in y and "((void)0);" in y, (f, x, y)
                 assert any(h in x for h in ('"s_sleep 1"', '"s_waitcnt vmcnt(1)"', '""')), (f, x)
                 n_asm += 1
-    assert n_dyn >= 18 and n_asm == 5, (n_dyn, n_asm)
+    assert n_dyn >= 18 and n_asm == 5 and n_static >= 50, (n_dyn, n_asm, n_static)
 
 
 def test_gpu_tier_under_emulation():
