@@ -463,7 +463,7 @@ hipError_t hipMalloc(void** p, size_t bytes)
     if (bytes > ((size_t)48 << 30)) return hipErrorOutOfMemory;
     void* m = nullptr;
     if (posix_memalign(&m, 256, bytes) != 0 || !m) return hipErrorOutOfMemory;      // exactly `bytes`: an overrun meets the sanitizer's red zone
-    memset(m, 0xCD, std::min(bytes, (size_t)1 << 20));                    // device memory is not zeroed: poison the head
+    memset(m, 0xFF, std::min(bytes, (size_t)256 << 20));                  // device memory is not zeroed: NaN as a float, -1 as an int (allocations beyond 256 MB: their head)
     { std::lock_guard<std::mutex> lk(g_mem_mutex); g_device_allocs[m] = bytes; g_device_bytes += bytes; }
     *p = m;
     return hipSuccess;
