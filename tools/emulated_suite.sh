@@ -11,19 +11,22 @@ mkdir -p gpurun_out
 export JRC_EMULATE=1 OMP_NUM_THREADS=1
 python3 -m pytest tests -m gpu -v -n $NW --timeout 1800 -p no:cacheprovider > gpurun_out/${TAG}_emulated_default.log 2>&1
 RC1=$?
-RC2=0; RC3=0; RC4=0; RC5=0
+RC2=0; RC3=0; RC4=0; RC5=0; RC6=0
 # the same pass with the emulated waves and lanes run backwards, and in a shuffled order: results must not depend on it
 HIPCPU_SCHEDULE=reverse python3 -m pytest tests -m gpu -v -n $NW --timeout 1800 -p no:cacheprovider > gpurun_out/${TAG}_emulated_reverse.log 2>&1
 RC4=$?
 HIPCPU_SCHEDULE=shuffle:2026 python3 -m pytest tests -m gpu -v -n $NW --timeout 1800 -p no:cacheprovider > gpurun_out/${TAG}_emulated_shuffle.log 2>&1
 RC5=$?
 if [ "$HEAVY" = heavy ]; then
-  # the shapes the default pass leaves out (bench batches, 10^6-sample streams): two workers only — the config-D batch tests hold up to 35 GB each
-  # ("device" memory is host memory here), and a third worker ran this machine (62 GB) out of memory once
-  JRC_EMULATE_HEAVY=1 python3 -m pytest tests -m gpu -v -n 2 --timeout 5400 -p no:cacheprovider \
-    -k "benchmarked or long_bursts or 1048576 or million_samples or B-1100 or B-300 or B-700 or D-256 or B-512 or 600] or baseline_batch or test_wide_kernel_batches or config_d_eight" \
+  # the shapes the default pass leaves out (bench batches, 10^6-sample streams).  "Device" memory is host memory here: the config-D batch property tests
+  # hold ~37 GB each and run ALONE afterwards (beside another worker they ran this 62 GB machine out of memory, twice)
+  HEAVY_K="benchmarked or long_bursts or 1048576 or million_samples or B-1100 or B-300 or B-700 or D-256 or B-512 or 600] or baseline_batch or test_wide_kernel_batches or config_d_eight"
+  JRC_EMULATE_HEAVY=1 python3 -m pytest tests -m gpu -v -n 3 --timeout 5400 -p no:cacheprovider -k "($HEAVY_K) and not baseline_batch[D]" \
     > gpurun_out/${TAG}_emulated_heavy.log 2>&1
   RC2=$?
+  JRC_EMULATE_HEAVY=1 python3 -m pytest tests -m gpu -v -n 0 --timeout 5400 -p no:cacheprovider -k "baseline_batch[D]" \
+    > gpurun_out/${TAG}_emulated_heavy_config_d_batches.log 2>&1
+  RC6=$?
 fi
 if [ "$ASAN" = asan ]; then
   RT=$(/opt/rocm/lib/llvm/bin/clang++ -print-file-name=libclang_rt.asan-x86_64.so)
@@ -33,4 +36,4 @@ if [ "$ASAN" = asan ]; then
       -m gpu -v -n $NW --timeout 3600 -p no:cacheprovider > gpurun_out/${TAG}_emulated_asan_ubsan.log 2>&1
   RC3=$?
 fi
-python3 tools/stamp_emulated.py $TAG $RC1 $RC2 $RC3 $RC4 $RC5
+python3 tools/stamp_emulated.py $TAG $RC1 $RC2 $RC3 $RC4 $RC5 $RC6

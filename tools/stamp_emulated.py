@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """gpurun_out/<TAG>_emulated_{default,heavy,asan_ubsan}.log -> gpurun_out/<TAG>_emulated_suite.json, stamped with build.source_hash() of the tree
-(tests/test_evidence_stamps.py holds the tracked copy under profiles/ against the tree's hash).  usage: stamp_emulated.py TAG RC_DEFAULT RC_HEAVY RC_ASAN RC_REVERSE RC_SHUFFLE"""
+(tests/test_evidence_stamps.py holds the tracked copy under profiles/ against the tree's hash).  usage: stamp_emulated.py TAG RC_DEFAULT RC_HEAVY RC_ASAN RC_REVERSE RC_SHUFFLE RC_HEAVY_D_BATCHES"""
 import json
 import os
 import sys
@@ -13,12 +13,12 @@ import stamp_suite  # noqa: E402
 
 
 def main():
-    tag, rcs = sys.argv[1], [int(x) for x in sys.argv[2:7]]
+    tag, rcs = sys.argv[1], [int(x) for x in sys.argv[2:8]]
     from jrc_amd import build as jb
     rec = {"what": "the -m gpu tests on the library's kernel sources built for the host CPU under the emulated execution model of tests/hipcpu "
                    "(no GPU: the pool was closed to this repository in round 6) - NOT a device run", "source_hash": jb.source_hash(),
            "when": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()), "host": os.uname().machine, "passes": {}}
-    for name, rc in zip(("default", "heavy", "asan_ubsan", "reverse", "shuffle"), rcs):
+    for name, rc in zip(("default", "heavy", "asan_ubsan", "reverse", "shuffle", "heavy_config_d_batches"), rcs):
         p = os.path.join(ROOT, "gpurun_out", "%s_emulated_%s.log" % (tag, name))
         if not os.path.exists(p):
             continue
