@@ -131,6 +131,42 @@ def main():
                 print("codec mcs=%d nbytes=%d differs" % (mcs, nbytes))
     print("stream_encoder -> stream_decoder: %d (MCS, PDU length) pairs, %d differ from the oracle (%d clean frames lost by both decoders alike)" % (cases, nbad, lost))
     bad += nbad
+    # precoder -> flat channel -> equalizer at the .grc's carriers: every PDU length 1..40 x every MCS x LS / STA x NDP / DATA, device blocks against the
+    # oracle's blocks on the same symbols (precoder: sync words + SIG exact, the rest 1e-6; equalizer: 2e-5, events equal)
+    from test_oracle_comm import qam16, qpsk, through_channel
+    from conftest import crandn, rel_err
+    o64 = np.load(os.path.join(ROOT, "tests", "golden", "ofdm_config_64.npz"))
+    dc, pc, ps, sw, ml, ltf = (o64[k] for k in ("data_subcarriers", "pilot_subcarriers", "pilot_symbols", "l_stf_ltf_64", "ltf_mapped_sc__ss_sym", "ltf_64"))
+    nbad = cases = 0
+    worst_p = worst_e = 0.0
+    for est in (0, 1):
+        gp = jrc.mimo_precoder(64, 4, 1, dc, pc, ps, sw, ml, ctx=ctx)
+        op = oracle.Precoder(64, 4, 1, dc, pc, ps, sw, ml)
+        for ptype in (1, 2):
+            for mcs in range(6):
+                if est == 1 and mcs in (4, 5):
+                    continue                      # STA with 16-QAM decides through gr-digital's table (recollected: covered by its own test, not swept)
+                for nbytes in range(1, 41):
+                    ge = jrc.mimo_ofdm_equalizer(est, 24e9, 125e6, 64, 16, dc, pc, ps, ltf, ml, 4, ctx=ctx)
+                    oe = oracle.Equalizer(est, 24e9, 125e6, 64, 16, dc, pc, ps, ltf, ml, 4)
+                    ns = oracle.n_ofdm_sym(mcs, 48, nbytes)
+                    sy = qam16(rng, ns * 48) if mcs >= 4 else qpsk(rng, ns * 48) if mcs >= 2 else (rng.integers(0, 2, ns * 48) * 2 - 1).astype(np.complex64)
+                    tg, tr = gp.work(sy, mcs, ptype, nbytes), op.work(sy, mcs, ptype, nbytes)
+                    ep = rel_err(tg, tr)
+                    ok = tg.shape == tr.shape and ep < 1e-6 and np.array_equal(tg[:, :5], tr[:, :5])
+                    y = through_channel(tr, crandn(rng, 4), 2e-3, rng)
+                    g, o = ge.general_work(y, [(0, 0.013)]), oe.general_work(y, [(0, 0.013)])
+                    ee = rel_err(g["out"], o["out"]) if g["out"].shape == o["out"].shape and g["out"].size else (0.0 if g["out"].shape == o["out"].shape else 1.0)
+                    ok = ok and g["consumed"] == o["consumed"] and ee < 2e-5 and len(g["events"]) == len(o["events"]) and \
+                        all(a["kind"] == b["kind"] and a["offset"] == b["offset"] for a, b in zip(g["events"], o["events"]))
+                    worst_p, worst_e = max(worst_p, ep), max(worst_e, ee)
+                    cases += 1
+                    if not ok:
+                        nbad += 1
+                        if nbad < 12:
+                            print("comm est=%d ptype=%d mcs=%d nbytes=%d: precoder %g equalizer %g" % (est, ptype, mcs, nbytes, ep, ee))
+    print("precoder -> channel -> equalizer: %d (estimator, packet type, MCS, PDU length) cases, %d outside tolerance (worst precoder %.2g, equalizer %.2g)" % (cases, nbad, worst_p, worst_e))
+    bad += nbad
     return 1 if bad else 0
 
 
