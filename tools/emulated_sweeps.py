@@ -167,6 +167,29 @@ def main():
                             print("comm est=%d ptype=%d mcs=%d nbytes=%d: precoder %g equalizer %g" % (est, ptype, mcs, nbytes, ep, ee))
     print("precoder -> channel -> equalizer: %d (estimator, packet type, MCS, PDU length) cases, %d outside tolerance (worst precoder %.2g, equalizer %.2g)" % (cases, nbad, worst_p, worst_e))
     bad += nbad
+    # target_simulator: every burst length n1 x 2^a with n1 = 1..80 and 2^a = 16..256 (the direct route's column lengths incl. every prime to 79), and the
+    # lengths just off them (chirp-z route), two RX antennas, two summed targets: default route, and the burst-on-chip kernel where it takes the burst
+    nbad = cases = 0
+    worst = {"default": 0.0, "onchip": 0.0}
+    args = ([12.0, 33.0], [3.0, -20.0], [50.0, 20.0], [15.0, -40.0], [0.0, 0.00625], 125_000_000, 24e9)
+    ref = oracle.TargetSimulator(*args)
+    lengths = sorted(set([n1 * p2 for n1 in range(1, 81) for p2 in (16, 64, 256)] + [n1 * 32 + 1 for n1 in range(1, 40, 3)]))
+    for n in lengths:
+        x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+        want = ref.work(x, sum_targets=True)
+        for route in ("default", "onchip"):
+            os.environ["JRC_TSIM_ONCHIP"] = "1" if route == "onchip" else "0"
+            got = jrc.target_simulator(*args, sum_targets=True, ctx=ctx).work(x)
+            err = rel_err(got, want)
+            worst[route] = max(worst[route], err)
+            cases += 1
+            if not err < 1e-4:
+                nbad += 1
+                if nbad < 12:
+                    print("target_simulator n=%d route=%s: %g" % (n, route, err))
+    os.environ.pop("JRC_TSIM_ONCHIP", None)
+    print("target_simulator: %d burst lengths x 2 routes, %d outside 1e-4 (worst: default route %.2g, on-chip switch on %.2g)" % (len(lengths), nbad, worst["default"], worst["onchip"]))
+    bad += nbad
     return 1 if bad else 0
 
 
