@@ -60,10 +60,11 @@ def suite_tier(item):
 
 # Emulation mode: what makes no sense without the device is skipped with its reason, and the shapes that take the emulation minutes are left to
 # JRC_EMULATE_HEAVY=1 (tools/emulated_suite.sh); everything else runs unchanged.
-_EMU_SKIP_FILES = {"test_bench_launch.py": "starts bench.py ranks that need the device", "test_gpu_switches.py": "re-imports the library in child processes"}
+_EMU_SKIP_FILES = {"test_bench_launch.py": "starts bench.py ranks that need the device"}
 _EMU_HEAVY = ("test_range_doppler_at_the_benchmarked_config_d_shape", "test_chain_at_the_benchmarked_launch_geometry", "test_long_bursts[300000]",
               "test_long_bursts[600000]", "[1048576-256-4096]", "test_metric_and_decisions_on_a_million_samples", "B-1100", "B-300", "B-700", "D-256", "B-512",
-              "-600]", "baseline_batch", "test_wide_kernel_batches_against_oracle_and_each_other", "test_soak", "test_chain_config_d_eight_targets")
+              "-600]", "baseline_batch", "test_wide_kernel_batches_against_oracle_and_each_other", "test_soak", "test_chain_config_d_eight_targets",
+              "test_detect_slices_beyond_one_resident_wave", "launch_switches[cfg0]", "launch_switches[cfg1]")
 
 
 def _emulation_marks(items):

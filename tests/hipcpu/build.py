@@ -149,7 +149,7 @@ def build(verbose=False, sanitize=None):
         with concurrent.futures.ThreadPoolExecutor(max_workers=4) as ex:
             objs = list(ex.map(one, srcs + ["hipcpu_runtime.cc"]))
         # linked beside the target and renamed over it: a process that has the previous build mapped keeps its inode
-        r = subprocess.run([cxx, "-shared", "-fPIC", "-o", lib + ".tmp"] + objs + (["-fsanitize=" + sanitize] if sanitize else []) + ["-lpthread", "-lm"], capture_output=True, text=True)
+        r = subprocess.run([cxx, "-shared", "-fPIC", "-o", lib + ".tmp"] + objs + (["-fsanitize=" + sanitize] if sanitize else []) + ["-lpthread", "-lm", "-ldl"], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcpu: link failed:\n%s" % r.stderr[-4000:])
         os.replace(lib + ".tmp", lib)

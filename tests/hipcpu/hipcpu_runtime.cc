@@ -9,7 +9,10 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+#include <set>
 #include <sys/mman.h>
+#include <unistd.h>
 
 namespace hipcpu {
 
@@ -393,6 +396,19 @@ void launch_closure(dim3 grid, dim3 block, size_t dyn, hipStream_t s, std::funct
         return;
     }
     std::string nm(name);
+    if (getenv("HIPCPU_LAUNCH_LOG")) {            // which kernel INSTANTIATIONS a run launches: the symbol behind the function pointer (tools/kernel_launch_coverage.py)
+        static std::mutex m;
+        static std::set<std::string> seen;
+        Dl_info di;
+        if (dladdr(kernel, &di) && di.dli_sname) {
+            std::lock_guard<std::mutex> lk(m);
+            if (seen.insert(di.dli_sname).second) {
+                char path[512];
+                snprintf(path, sizeof(path), "%s.%d", getenv("HIPCPU_LAUNCH_LOG"), (int)getpid());
+                if (FILE* fh = fopen(path, "a")) { fprintf(fh, "%s\n", di.dli_sname); fclose(fh); }
+            }
+        }
+    }
     submit(s, [grid, block, dyn, body, nm]() { run_kernel(grid, block, dyn, body, nm.c_str()); });
 }
 

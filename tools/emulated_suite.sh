@@ -20,7 +20,7 @@ RC5=$?
 if [ "$HEAVY" = heavy ]; then
   # the shapes the default pass leaves out (bench batches, 10^6-sample streams).  "Device" memory is host memory here: the config-D batch property tests
   # hold ~37 GB each and run ALONE afterwards (beside another worker they ran this 62 GB machine out of memory, twice)
-  HEAVY_K="benchmarked or long_bursts or 1048576 or million_samples or B-1100 or B-300 or B-700 or D-256 or B-512 or 600] or baseline_batch or test_wide_kernel_batches or config_d_eight"
+  HEAVY_K="benchmarked or long_bursts or 1048576 or million_samples or B-1100 or B-300 or B-700 or D-256 or B-512 or 600] or baseline_batch or test_wide_kernel_batches or config_d_eight or detect_slices_beyond or launch_switches"
   JRC_EMULATE_HEAVY=1 python3 -m pytest tests -m gpu -v -n 3 --timeout 5400 -p no:cacheprovider -k "($HEAVY_K) and not baseline_batch[D]" \
     > gpurun_out/${TAG}_emulated_heavy.log 2>&1
   RC2=$?
