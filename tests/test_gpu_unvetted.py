@@ -188,3 +188,139 @@ def test_bursts_too_long_for_the_chip_keep_the_three_pass_route(jrc, ctx, monkey
     monkeypatch.setenv("JRC_TSIM_ONCHIP", "1")
     b = jrc.target_simulator(*args, ctx=ctx).work(x)
     assert np.array_equal(a, b)
+
+
+# ---- the 64-bin range-angle kernel: every instantiation its dispatch can reach -------------------------------------------------------------------
+# tools/kernel_launch_coverage.py (round 6): the suite launches 187 of the library's 361 kernel instantiations; 150 of the other 174 are
+# range_angle_fused_kernel<P, NT, MMAX, TWC_LDS, MODE, IA, ROWS1> — the cross product of pair count x workgroup size (JRC_THREADS) x fft_len class x
+# output mode x compiled-in / run-time angle interpolation that chain.hip's launch_fused* can select and no test shape had selected.  The kernels are
+# round 5's device code; this TEST is new (hence in this file): each reachable combination against the oracle chain, and its three modes against each other.
+@pytest.mark.parametrize("threads", [None, 512, 1024])
+@pytest.mark.parametrize("N", [64, 512])
+@pytest.mark.parametrize("Ia", [16, 8])
+@pytest.mark.parametrize("T,R", [(1, 1), (1, 2), (2, 2), (2, 4), (4, 4)])
+def test_every_instantiation_of_the_64_bin_range_angle_kernel(jrc, monkeypatch, T, R, N, Ia, threads):
+    import oracle
+    import torch
+    from jrc_amd import synth
+    from conftest import rel_err
+    monkeypatch.setenv("JRC_NO_WIDE", "1")                       # the wide kernel would take 8 / 16 pairs at fft_len 512 with Ia 16
+    if threads:
+        monkeypatch.setenv("JRC_THREADS", str(threads))
+    else:
+        monkeypatch.delenv("JRC_THREADS", raising=False)
+    c = jrc.Context(0)
+    S, Ir, F, P = 3, 2, 2, T * R
+    sc = synth.Scenario(N, T, R, S, targets=[(0.2 * 3e8 * N / (2 * 125e6), 22.0, 0.0, 80.0)])
+    frames = synth.make_frames(sc, F)
+    rb, ab = jrc.radar_axes(N, sc.fs, Ir, P, Ia)
+    nda = 2 * float(np.rad2deg(np.arcsin(min(1.0, 2 / P)))) if P > 2 else 30.0
+    ch = jrc.RadarChain(N, T, R, S, sc.Npre, Ir, Ia, rb, ab, 2.4, nda, 15.0, 0.0, max_frames=F, ctx=c)
+    bufs = ch.alloc(F, "cuda:0")
+    bufs["frames"].copy_(torch.from_numpy(frames.view(np.float32).reshape(bufs["frames"].shape)))
+    torch.cuda.synchronize()
+    ch.run(bufs, F)
+    c.sync()
+    recs = [bytes(memoryview(r)) for r in ch.results(bufs, F)]
+    gmap = bufs["map"].cpu().numpy().view(np.complex64)[..., 0]
+    gH = bufs["chanest"].cpu().numpy().view(np.complex64)[..., 0]
+    for f in range(F):
+        rad = oracle.Radar(N, T, R, S, sc.Npre, interp_factor=Ir)
+        H = rad.work([frames[f, t] for t in range(T)], [frames[f, T + r] for r in range(R)])
+        assert np.array_equal(H[:, :N], gH[f])
+        m = oracle.fft_vcc(oracle.matrix_transpose(oracle.fft_vcc(H, False, False), N * Ir, P, Ia), True, True)
+        assert rel_err(gmap[f], m) < 1e-4
+        ro = oracle.ra_estimate(gmap[f], rb, ab, 2.4, nda, 15.0, 0.0)
+        assert recs[f] == bytes(memoryview(ro))
+    # detect-only mode: the same records without a map
+    ch.set_write_map(False)
+    ch.run(bufs, F)
+    c.sync()
+    assert [bytes(memoryview(r)) for r in ch.results(bufs, F)] == recs
+    ch.set_write_map(True)
+    # power-map format: |z|^2 of every cell, the same records
+    ch.set_map_format(True)
+    pb = ch.alloc(F, "cuda:0", power_map=True)
+    pb["frames"].copy_(bufs["frames"])
+    pb["map"].fill_(float("nan"))
+    torch.cuda.synchronize()
+    ch.run(pb, F)
+    c.sync()
+    assert [bytes(memoryview(r)) for r in ch.results(pb, F)] == recs
+    re, im = bufs["map"][..., 0], bufs["map"][..., 1]
+    assert torch.equal(pb["map"], re * re + im * im)
+    ch.close()
+    c.close()
+
+
+# ---- equalizer geometries behind JRC_EQ_THREADS / JRC_EQ_WPE, precoder with 8 and with 3 TX antennas: instantiations no other test launches --------------
+def _comm_tables(N, T, seed=0):
+    rng = np.random.default_rng(seed)
+    guard = N // 16
+    act = [c for c in range(-N // 2 + guard, N // 2 - guard + 1) if c != 0]
+    pilots = [c for c in act if c % 32 == 16][:8]
+    data = [c for c in act if c not in pilots]
+    ltf = np.zeros(N, np.complex64)
+    ltf[np.array(act) + N // 2] = rng.choice([-1.0, 1.0], len(act))
+    k = np.arange(T)
+    Pm = np.exp(-2j * np.pi * np.outer(k, k) / T).astype(np.complex64)          # an orthogonal mapping matrix for any T (DFT; the reference's is Hadamard at T = 4)
+    mapped = np.stack([(Pm * ltf[sc]).reshape(-1) for sc in range(N)]).astype(np.complex64)
+    pil = np.array([[1, 1, 1, -1, 1, 1, 1, -1], [-1, -1, -1, 1, -1, -1, -1, 1], [1, 1, 1, -1, 1, 1, 1, -1]], np.complex64)[:, :len(pilots)]
+    return data, pilots, pil, ltf, mapped, np.stack([ltf, ltf, ltf, ltf])
+
+
+@pytest.mark.parametrize("threads,wpe", [(64, 2), (64, 4), (128, 2), (128, 4), (256, 2), (256, 4), (256, 6), (256, 8), (-1, 4)])
+def test_equalizer_workgroup_geometries_against_the_oracle(jrc, monkeypatch, threads, wpe):
+    import oracle
+    from conftest import rel_err
+    from test_oracle_comm import qpsk
+    monkeypatch.setenv("JRC_EQ_THREADS", str(threads))
+    monkeypatch.setenv("JRC_EQ_WPE", str(wpe))
+    c = jrc.Context(0)
+    N, cp, T, S, mcs = 256, 64, 4, 6, 2
+    rng = np.random.default_rng(abs(threads) * 10 + wpe)
+    data, pilots, pil, ltf, mapped, sync = _comm_tables(N, T)
+    nd = len(data)
+    nbytes = (S * nd - 22) // 8
+    assert oracle.n_ofdm_sym(mcs, nd, nbytes) == S
+    for est, ptype in ((0, 2), (1, 2), (0, 1)):
+        op = oracle.Precoder(N, T, 1, data, pilots, pil, sync, mapped)
+        tx = op.work(qpsk(rng, S * nd), mcs, ptype, nbytes)
+        y = np.tensordot(crandn(rng, T), tx, axes=(0, 0))
+        y = np.concatenate([y[3:4], y[3:]], axis=0)
+        y = (y + 2e-3 * (rng.standard_normal(y.shape) + 1j * rng.standard_normal(y.shape))).astype(np.complex64)
+        g = jrc.mimo_ofdm_equalizer(est, 24e9, 125e6, N, cp, data, pilots, pil, ltf, mapped, T, ctx=c).general_work(y, [(0, 0.004)])
+        o = oracle.Equalizer(est, 24e9, 125e6, N, cp, data, pilots, pil, ltf, mapped, T).general_work(y, [(0, 0.004)])
+        assert g["out"].shape == o["out"].shape == (S, nd) and g["consumed"] == o["consumed"] == len(y)
+        assert rel_err(g["out"], o["out"]) < 1e-4
+        assert [(a["kind"], a["offset"]) for a in g["events"]] == [(b["kind"], b["offset"]) for b in o["events"]]
+        if ptype == 1:
+            assert rel_err(g["chan_est"], o["chan_est"]) < 1e-4
+    c.close()
+
+
+@pytest.mark.parametrize("T", [8, 3, 5])
+@pytest.mark.parametrize("ptype", [1, 2])
+def test_precoder_with_eight_and_with_odd_antenna_counts(jrc, ctx, T, ptype):
+    """T = 8 takes precoder_frames_kernel<8>, T = 3 / 5 the kernel with a run-time antenna count: per packet and batched on the device, against the oracle"""
+    import oracle
+    import torch
+    from conftest import rel_err
+    from test_oracle_comm import qpsk
+    N, S, mcs, F = 64 if T != 8 else 256, 5, 2, 3
+    data, pilots, pil, ltf, mapped, sync = _comm_tables(N, T, seed=T)
+    nd = len(data)
+    nbytes = (S * nd - 22) // 8
+    assert oracle.n_ofdm_sym(mcs, nd, nbytes) == S
+    rng = np.random.default_rng(T)
+    gp = jrc.mimo_precoder(N, T, 1, data, pilots, pil, sync, mapped, ctx=ctx)
+    op = oracle.Precoder(N, T, 1, data, pilots, pil, sync, mapped)
+    syms = np.stack([qpsk(rng, S * nd) for _ in range(F)])
+    want = np.stack([op.work(s, mcs, ptype, nbytes) for s in syms])
+    got = np.stack([gp.work(s, mcs, ptype, nbytes) for s in syms])
+    assert got.shape == want.shape == (F, T, S + 5 + T, N) and rel_err(got, want) < 1e-6
+    d_sym = torch.from_numpy(syms.view(np.float32).reshape(F, S * nd, 2).copy()).cuda()
+    d_out = torch.zeros((F, T, S + 5 + T, N, 2), dtype=torch.float32, device="cuda")
+    gp.frames_dev(d_sym, mcs, ptype, nbytes, d_out=d_out)
+    ctx.sync()
+    assert np.array_equal(d_out.cpu().numpy().view(np.complex64)[..., 0], got)           # batched == per packet, bit for bit

@@ -17,7 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def main():
     res, out = sys.argv[1], sys.argv[2]
     extra = sys.argv[3:] or ["tests", "-n", "6"]
-    log = os.path.join(tempfile.mkdtemp(), "launches")
+    logdir = os.environ.get("KLC_LOG_DIR") or tempfile.mkdtemp()       # KLC_LOG_DIR: accumulate the launches of several runs (default pass, heavy pass, ...)
+    os.makedirs(logdir, exist_ok=True)
+    log = os.path.join(logdir, "launches")
     env = dict(os.environ, JRC_EMULATE="1", OMP_NUM_THREADS="1", HIPCPU_LAUNCH_LOG=log)
     r = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-p", "no:cacheprovider", "--timeout", "1800"] + extra, cwd=ROOT, env=env, capture_output=True, text=True)
     tail = [l for l in r.stdout.splitlines() if " passed" in l or " failed" in l][-1:]
