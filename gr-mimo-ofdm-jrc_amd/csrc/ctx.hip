@@ -75,9 +75,13 @@ extern "C" int jrc_create(int device, jrc_ctx** out)
             else if (strncmp(prop.gcnArchName, "gfx942", 6) == 0) per_xcd = 38;
         }
         ctx->n_xcd = (per_xcd && ctx->n_cus % per_xcd == 0) ? ctx->n_cus / per_xcd : 1;
+        // LDS a workgroup may be granted (with the per-kernel dynamic-LDS opt-in): 160 KB on gfx950 whatever the runtime's attribute says — it may
+        // report the 64 KB a kernel gets WITHOUT the opt-in, and the target simulator's direct route has run with up to 132 KB on this part since
+        // round 5; elsewhere the attribute (read below) is believed
+        if (per_xcd == 32) ctx->max_lds_per_block = 160 * 1024;
     }
     if (const char* e = getenv("JRC_XCDS")) { const int v = atoi(e); if (v >= 1 && v <= 64) ctx->n_xcd = v; }
-    { int lds = 0; if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && lds > 0) ctx->max_lds_per_block = (size_t)lds; }
+    { int lds = 0; if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && lds > 0 && (size_t)lds > ctx->max_lds_per_block) ctx->max_lds_per_block = (size_t)lds; }
     { int khz = 0; if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) ctx->wall_clock_khz = khz; }
     if (const char* e = getenv("JRC_CHANEST_CHUNK")) ctx->tune.chanest_chunk = atoi(e);
     ctx->tune.chanest_x1 = getenv("JRC_CHANEST_X1") != nullptr;

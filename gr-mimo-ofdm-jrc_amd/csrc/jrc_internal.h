@@ -30,7 +30,7 @@ struct jrc_ctx {
     // dynamic-LDS opt-in granted so far, per kernel (hipFuncAttributeMaxDynamicSharedMemorySize is per device: kept per context)
     std::map<const void*, size_t> dyn_lds;
     int n_cus = 0;
-    size_t max_lds_per_block = 64 * 1024;   // hipDeviceAttributeMaxSharedMemoryPerBlock (160 KB on gfx950): what a dynamic-LDS opt-in may ask for
+    size_t max_lds_per_block = 64 * 1024;   // what a dynamic-LDS opt-in may ask for: 160 KB on gfx950, else hipDeviceAttributeMaxSharedMemoryPerBlock (at least 64 KB)
     // XCDs (L2 domains) workgroups are dealt over round-robin: 8 on an MI355X in SPX mode (256 CUs), 1 per 32 CUs in the smaller
     // partition modes; JRC_XCDS overrides.  Only locality depends on it (a frame's workgroups share one L2), never results.
     int n_xcd = 8;

@@ -324,3 +324,26 @@ def test_precoder_with_eight_and_with_odd_antenna_counts(jrc, ctx, T, ptype):
     gp.frames_dev(d_sym, mcs, ptype, nbytes, d_out=d_out)
     ctx.sync()
     assert np.array_equal(d_out.cpu().numpy().view(np.complex64)[..., 0], got)           # batched == per packet, bit for bit
+
+
+def test_direct_route_does_not_depend_on_what_the_runtime_reports_as_lds_per_block(jrc, monkeypatch):
+    """ctx.hip bounds the target simulator's direct route (and the opt-in on-chip kernel) by the LDS a workgroup can be granted.  A runtime may report the
+    64 KB a kernel gets WITHOUT the per-kernel opt-in; on gfx950 the library knows the part's 160 KB, so column lengths whose tile needs more than 64 KB
+    (n1 = 509: 131 KB; 2^20 = 256 x 4096: 66 KB) stay on the direct route — the tests that hold that route to 2e-6 would fail on the chirp-z route"""
+    import os
+    import oracle
+    from conftest import rel_err
+    if "hipcpu" not in os.environ.get("JRC_LIB_PATH", ""):
+        pytest.skip("the reported attribute can only be changed in the emulation")
+    monkeypatch.setenv("HIPCPU_LDS_ATTR", "65536")
+    c = jrc.Context(0)
+    n = 64 * 509
+    args = ([35.0], [-12.0], [40.0], [-25.0], POS4[:2], FS, FC)
+    x = _burst(n, n)
+    got = jrc.target_simulator(*args, ctx=c).work(x)
+    want = oracle.TargetSimulator(*args).work(x)
+    assert rel_err(got, want) < 2e-6
+    monkeypatch.setenv("JRC_TSIM_BLUESTEIN", "1")
+    old = jrc.target_simulator(*args, ctx=c).work(x)
+    assert not np.array_equal(old, got)                          # the direct route was taken above
+    c.close()
