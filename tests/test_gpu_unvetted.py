@@ -347,3 +347,41 @@ def test_direct_route_does_not_depend_on_what_the_runtime_reports_as_lds_per_blo
     old = jrc.target_simulator(*args, ctx=c).work(x)
     assert not np.array_equal(old, got)                          # the direct route was taken above
     c.close()
+
+
+# ---- kernels kept behind switches that no other test sets (tools/kernel_launch_coverage.py) ---------------------------------------------------------------
+def test_single_frame_decoder_kernel_behind_its_switch(jrc, monkeypatch):
+    """JRC_DEC_SINGLE=1: the first-generation decoder kernel (one frame per wave, LDS path ring) - verdicts and bytes as the oracle's, clean and noisy"""
+    import oracle
+    monkeypatch.setenv("JRC_DEC_SINGLE", "1")
+    c = jrc.Context(0)
+    for mcs, nbytes in ((0, 5), (1, 42), (2, 100), (3, 77), (4, 300), (5, 1500)):
+        rng = np.random.default_rng(100 + mcs * 13 + nbytes)
+        p = bytes([2]) + rng.integers(0, 256, nbytes - 1, dtype=np.uint8).tobytes()
+        sym, tags = oracle.stream_encode(mcs, 48, p, 1 + nbytes % 127)
+        dec = jrc.stream_decoder(48, ctx=c)
+        start = dict(mcs=mcs, data_bytes=tags["pdu_len"], packet_type=2, snr=20.0)
+        assert dec.work(sym, start) == oracle.stream_decode(mcs, 48, tags["pdu_len"], sym)
+        bpsc = oracle.packet_params(mcs, 48, 8)["n_bpsc"]
+        for scale in (1.0, 2.5, 6.0):
+            sigma = scale * {1: 0.25, 2: 0.12, 4: 0.05}[bpsc]
+            noisy = sym + sigma * (rng.standard_normal(sym.size) + 1j * rng.standard_normal(sym.size)).astype(np.complex64)
+            assert dec.work(noisy, start) == oracle.stream_decode(mcs, 48, tags["pdu_len"], noisy)
+    c.close()
+
+
+def test_one_lane_per_output_metrics_kernel_behind_its_switch(jrc, ctx, monkeypatch):
+    """JRC_SYNC_NAIVE=1: the detection metrics without the LDS tile (one lane per output, every window summed afresh) against the tiled kernel on the same
+    capture — the delayed samples bit for bit, the two metric streams to rounding (both sum each window on its own, in another order)"""
+    from conftest import rel_err
+    rng = np.random.default_rng(3)
+    x = crandn(rng, 5000)
+    x[1000:1400] *= 30.0
+    a = jrc.sync_metrics(x, 16, 48, 64, 1.0 / 64, ctx=ctx)
+    monkeypatch.setenv("JRC_SYNC_NAIVE", "1")
+    c = jrc.Context(0)
+    b = jrc.sync_metrics(x, 16, 48, 64, 1.0 / 64, ctx=c)
+    c.close()
+    assert np.array_equal(a[0], b[0])
+    assert rel_err(b[1], a[1]) < 1e-5 and rel_err(b[2], a[2]) < 1e-5
+    assert not np.array_equal(a[1], b[1]) or True                # (equal or not: two summation orders of the same windows)
