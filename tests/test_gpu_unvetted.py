@@ -385,3 +385,80 @@ def test_one_lane_per_output_metrics_kernel_behind_its_switch(jrc, ctx, monkeypa
     assert np.array_equal(a[0], b[0])
     assert rel_err(b[1], a[1]) < 1e-5 and rel_err(b[2], a[2]) < 1e-5
     assert not np.array_equal(a[1], b[1]) or True                # (equal or not: two summation orders of the same windows)
+
+
+# ---- more instantiations no other test launches: shapes nothing drew ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("T,R,N,cp,S,Npre,F", [(1, 2, 64, 16, 5, 1, 3), (2, 2, 128, 32, 4, 2, 2), (3, 1, 64, 16, 6, 0, 2), (2, 3, 512, 128, 3, 1, 2), (1, 1, 128, 0, 7, 0, 1)])
+def test_time_domain_front_with_fewer_than_four_tx_antennas(jrc, ctx, T, R, N, cp, S, Npre, F):
+    """A6 + A7 + A1 as one kernel at fft_len other than 256 / 1024 with 1, 2, 3 TX antennas (demod_chanest_kernel<T, ...>): against the two device calls (1e-6)"""
+    import test_gpu_chain as tgc
+    from conftest import rel_err
+    tx, rx, Hf, Hu, L = tgc._td_case(jrc, ctx, T, R, N, cp, S, Npre, F, False, 3, seed=N + T)
+    assert not np.isnan(Hf.view(np.float32)).any() and rel_err(Hf, Hu) < 1e-6
+
+
+@pytest.mark.parametrize("n,R,K", [(3 * 1024, 3, 3), (3 * 4096, 1, 2), (3 * 4096, 3, 2), (5000, 3, 3), (2 * 1024, 1, 2)])
+def test_target_simulator_row_passes_with_odd_antenna_counts_and_summed_targets(jrc, ctx, n, R, K):
+    """1024- and 4096-point rows (td_rows_m_kernel<4 | 16, RC>) with an odd number of RX antennas behind a sum of targets (two antennas per launch, then one),
+    and the chirp-z route's middle pass with one antenna left over (tsim_col_mid_kernel<1>): against the oracle"""
+    import oracle
+    from conftest import rel_err
+    rng = np.random.default_rng(n + R)
+    tg = (list(rng.uniform(5.0, 60.0, K)), list(rng.uniform(-40.0, 40.0, K)), list(rng.uniform(10.0, 100.0, K)), list(rng.uniform(-60.0, 60.0, K)))
+    pos = [0.00625 * r for r in range(R)]
+    x = _burst(n, n)
+    got = jrc.target_simulator(*tg, pos, FS, FC, sum_targets=True, ctx=ctx).work(x)
+    want = oracle.TargetSimulator(*tg, pos, FS, FC).work(x, sum_targets=True)
+    assert got.shape == want.shape == (R, n) and rel_err(got, want) < 1e-4
+
+
+@pytest.mark.parametrize("N", [512, 1024])
+def test_power_map_on_the_wide_kernel_with_eight_pairs(jrc, ctx, N):
+    """range_angle_wide_kernel<8, 3, ...>: the float |z|^2 map at 2 x 4 antennas, fft_len 512 / 1024 — every cell re^2 + im^2 of the complex map, same records"""
+    import torch
+    from jrc_amd import synth
+    sc = synth.Scenario(N, 2, 4, 3, targets=[(0.2 * 3e8 * N / (2 * 125e6), 22.0, 0.0, 80.0)])
+    F, Ir, Ia, P = 2, 2, 16, 8
+    rb, ab = jrc.radar_axes(N, sc.fs, Ir, P, Ia)
+    ch = jrc.RadarChain(N, 2, 4, 3, sc.Npre, Ir, Ia, rb, ab, 2.4, 29.0, 15.0, 0.0, max_frames=F, ctx=ctx)
+    bufs = ch.alloc(F, "cuda:0")
+    bufs["frames"].copy_(torch.from_numpy(synth.make_frames(sc, F).view(np.float32).reshape(bufs["frames"].shape)))
+    torch.cuda.synchronize()
+    ch.run(bufs, F)
+    ctx.sync()
+    recs = [bytes(memoryview(r)) for r in ch.results(bufs, F)]
+    ch.set_map_format(True)
+    pb = ch.alloc(F, "cuda:0", power_map=True)
+    pb["frames"].copy_(bufs["frames"])
+    pb["map"].fill_(float("nan"))
+    torch.cuda.synchronize()
+    ch.run(pb, F)
+    ctx.sync()
+    assert [bytes(memoryview(r)) for r in ch.results(pb, F)] == recs
+    re, im = bufs["map"][..., 0], bufs["map"][..., 1]
+    assert torch.equal(pb["map"], re * re + im * im)
+    ch.close()
+
+
+@pytest.mark.parametrize("N", [1024, 2048])
+def test_equalizer_at_1024_and_2048_subcarriers(jrc, ctx, N):
+    """equalizer_kernel<1024, 4, 1> (a lane per subcarrier at fft_len 1024) and <1024, 4, 4> (several per lane at 2048): LS, DATA and NDP, against the oracle"""
+    import oracle
+    from conftest import rel_err
+    from test_oracle_comm import qpsk
+    cp, T, S, mcs = N // 4, 4, 3, 2
+    rng = np.random.default_rng(N)
+    data, pilots, pil, ltf, mapped, sync = _comm_tables(N, T)
+    nd = len(data)
+    nbytes = (S * nd - 22) // 8
+    assert oracle.n_ofdm_sym(mcs, nd, nbytes) == S
+    for ptype in (2, 1):
+        tx = oracle.Precoder(N, T, 1, data, pilots, pil, sync, mapped).work(qpsk(rng, S * nd), mcs, ptype, nbytes)
+        y = np.tensordot(crandn(rng, T), tx, axes=(0, 0))
+        y = np.concatenate([y[3:4], y[3:]], axis=0)
+        y = (y + 2e-3 * (rng.standard_normal(y.shape) + 1j * rng.standard_normal(y.shape))).astype(np.complex64)
+        g = jrc.mimo_ofdm_equalizer(0, 24e9, 125e6, N, cp, data, pilots, pil, ltf, mapped, T, ctx=ctx).general_work(y, [(0, 0.004)])
+        o = oracle.Equalizer(0, 24e9, 125e6, N, cp, data, pilots, pil, ltf, mapped, T).general_work(y, [(0, 0.004)])
+        assert g["out"].shape == o["out"].shape == (S, nd) and rel_err(g["out"], o["out"]) < 1e-4
+        if ptype == 1:
+            assert rel_err(g["chan_est"], o["chan_est"]) < 1e-4
