@@ -39,7 +39,7 @@ pytestmark = pytest.mark.skipif(not _have_clang() or os.uname().machine != "x86_
 
 
 def _workers():
-    return max(1, min(6, (os.cpu_count() or 2) - 1))
+    return max(1, min(7, (os.cpu_count() or 2) - 1))
 
 
 def _run_emulated(args, env=None, timeout=2400):
@@ -135,7 +135,7 @@ def test_results_do_not_depend_on_the_order_waves_and_lanes_are_run_in():
     whose lanes rely on running in index order, gives different results — the tests' own assertions catch it.  (This pass over the whole suite is
     what found the detect-only chain re-reading its shared running maximum after lane 0's store with nothing in between: fine on the device, marked
     JRC_LOCKSTEP() since.  tools/emulated_suite.sh runs the whole suite both backwards and in a shuffled order; here: the cross-lane-heavy files.)"""
-    files = ["tests/test_gpu_blocks.py", "tests/test_gpu_chain_modes.py", "tests/test_gpu_comm.py", "tests/test_gpu_sync.py", "tests/test_gpu_tsim.py",
-             "tests/test_gpu_flowgraph.py", "tests/test_golden_fixtures.py", "tests/test_golden_flowgraphs.py", "tests/test_gpu_unvetted.py"]
+    files = ["tests/test_gpu_blocks.py", "tests/test_gpu_chain_modes.py", "tests/test_gpu_comm.py", "tests/test_gpu_sync.py",
+             "tests/test_gpu_flowgraph.py", "tests/test_golden_fixtures.py", "tests/test_golden_flowgraphs.py"]
     r, c, tail = _run_emulated(files + ["-k", "not 174080 and not long_bursts and not B-40 and not D-9 and not A-300"], env={"HIPCPU_SCHEDULE": "reverse"})
-    assert r.returncode == 0 and c["failed"] == 0 and c["error"] == 0 and c["passed"] >= 350, (c, tail)
+    assert r.returncode == 0 and c["failed"] == 0 and c["error"] == 0 and c["passed"] >= 280, (c, tail)
